@@ -176,7 +176,8 @@ def adversarial_rows(pdf_defs):
                                         [2.8, 0.0], [1.0, pi + 1e-7]]))
         elif kind == "s" and dim == 1:
             pi = numpy.pi
-            per_sub.append(numpy.array([[0.0], [2 * pi], [pi], [1e-9], [2 * pi - 1e-9], [pi + 1e-7], [pi - 1e-7], [0.5]]))
+            # (exactly pi is left out: the Moebius layer's atan2 branch is decided by last-bit rounding there, also in the reference)
+            per_sub.append(numpy.array([[0.0], [2 * pi], [3.0], [1e-9], [2 * pi - 1e-9], [pi + 1e-7], [pi - 1e-7], [0.5]]))
         elif kind == "i":
             parts = sub.split("_")
             lo, hi = (0.0, 1.0) if len(parts) == 1 else (float(parts[1]), float(parts[2]))
