@@ -1,0 +1,103 @@
+/* jammy_hip.h -- C ABI of libjammy_hip.so: the MI355X (gfx950) kernels behind the per-layer forward / inverse +
+ * log-det hot path of thoglu/jammy_flows.
+ *
+ * Conventions:
+ *   - plain pointers to DEVICE memory + sizes, no torch types; every matrix argument carries its row stride (elements)
+ *   - `params` is the reference's `extra_inputs` row block: row-major (param_batch, n_params) with param_batch 1
+ *     (permanent / broadcast parameters) or B (one row per sample, as the amortisation MLP emits them,
+ *     jammy_flows/main/default.py:956, 1002-1012, 1488); row layout per layer letter: see each struct below
+ *   - inputs are never written (reference contract: tests/test_general.py:519, 533-550); outputs are fresh buffers
+ *   - `status` (nullable) points to JF_STATUS_WORDS int32 counters that kernels bump atomically; the host turns them
+ *     into the reference's warnings / exceptions (layers/bisection_n_newton.py:84-133, layers/spline_fns.py:57-59)
+ *   - functions return JF_OK or a negative error code; they never throw, allocate, or synchronise;
+ *     `stream` is a hipStream_t (the caller passes torch.cuda.current_stream().cuda_stream)
+ *   - every entry point exists as _f32 and _f64
+ */
+#ifndef JAMMY_HIP_H
+#define JAMMY_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define JF_OK 0
+#define JF_ERR_BADARG (-1)
+#define JF_ERR_UNSUPPORTED (-2)
+#define JF_ERR_LAUNCH (-3)
+
+#define JF_STATUS_NONCONVERGED 0 /* rows whose Newton iteration ended above the reference's print threshold */
+#define JF_STATUS_NONFINITE 1    /* non-finite iterates / outputs */
+#define JF_STATUS_OUT_OF_RANGE 2 /* spline inputs outside [left,right] */
+#define JF_STATUS_WORDS 4
+
+#define JF_MAX_CHAIN 8 /* max layers fused into one launch */
+
+int jf_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * 'g' Gaussianization flow (replaces gf_block._inv_flow_mapping / _flow_mapping + euclidean_base offset handling:
+ * jammy_flows/layers/euclidean/gaussianization_flow.py:911-989, 995-1114; euclidean_base.py:34-76;
+ * layers/bisection_n_newton.py:11-135).
+ * Row layout: [offset D if model_offset][householder v: hh_iter*D][means K*D][log_widths K*D][log_weights K*D if fit_normalization]
+ *             ((K,D) K-major)   -- gaussianization_flow.py:739-742, 820-834
+ * ------------------------------------------------------------------------------------------------------------ */
+enum { JF_GF_ISIGMOID = 0, JF_GF_INORMAL_PARTLY_PRECISE = 1, JF_GF_INORMAL_PARTLY_CRUDE = 2, JF_GF_INORMAL_FULL_PADE = 3 };
+enum { JF_GF_WIDTH_SMOOTH_SATURATION = 0, JF_GF_WIDTH_EXP = 1, JF_GF_WIDTH_SOFTPLUS = 2 };
+
+typedef struct jf_gf_layer {
+    int32_t num_kde;                /* K */
+    int32_t hh_iter;                /* number of Householder reflections, 0 = no rotation */
+    int32_t model_offset;           /* row starts with D offsets (last layer of an e-block) */
+    int32_t fit_normalization;      /* log_weights present */
+    int32_t regulate_normalization; /* soft-clamp log_weights to [ln norm_min, ln norm_max] */
+    int32_t inverse_function_type;  /* JF_GF_* */
+    int32_t width_mode;             /* JF_GF_WIDTH_* */
+    int32_t clamp_widths;
+    double width_min, width_max;    /* width_max <= 0: no upper bound */
+    double norm_min, norm_max;
+} jf_gf_layer;
+
+/* log-prob direction of a chain of `n_layers` g layers applied in REVERSE order (layer n-1 first), all in one launch.
+ * params row = the layers' rows concatenated in layer order 0..n-1.  log_det_in / base_logp_in may be NULL (= 0);
+ * base_logp_out (nullable) receives base_logp_in + sum_d N(0,1).log_prob(x_out_d)  (main/default.py:1110-1115). */
+int jf_gf_chain_inv_f32(const float* x, int64_t x_stride, const float* log_det_in, const float* params, int64_t param_stride,
+                        int32_t param_batch, int64_t B, int32_t D, int32_t n_layers, const jf_gf_layer* layers, float* x_out,
+                        int64_t x_out_stride, float* log_det_out, const float* base_logp_in, float* base_logp_out,
+                        int32_t* status, void* stream);
+int jf_gf_chain_inv_f64(const double* x, int64_t x_stride, const double* log_det_in, const double* params, int64_t param_stride,
+                        int32_t param_batch, int64_t B, int32_t D, int32_t n_layers, const jf_gf_layer* layers, double* x_out,
+                        int64_t x_out_stride, double* log_det_out, const double* base_logp_in, double* base_logp_out,
+                        int32_t* status, void* stream);
+
+/* sampling direction: layers applied in order 0..n-1; each solves its mixture-CDF map by 25 bisection steps on [-1e5,1e5]
+ * + <= 20 Newton steps (row stops when sum_d |update| < 1e-14).  log_det_out = log_det_in - sum log-derivatives. */
+int jf_gf_chain_fwd_f32(const float* z, int64_t z_stride, const float* log_det_in, const float* params, int64_t param_stride,
+                        int32_t param_batch, int64_t B, int32_t D, int32_t n_layers, const jf_gf_layer* layers, float* x_out,
+                        int64_t x_out_stride, float* log_det_out, int32_t* status, void* stream);
+int jf_gf_chain_fwd_f64(const double* z, int64_t z_stride, const double* log_det_in, const double* params, int64_t param_stride,
+                        int32_t param_batch, int64_t B, int32_t D, int32_t n_layers, const jf_gf_layer* layers, double* x_out,
+                        int64_t x_out_stride, double* log_det_out, int32_t* status, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Dense layer of the parameter-emitting MLPs: out = act(in @ W^T + bias)   (MFMA)
+ * replaces torch.nn.Linear + tanh of the default nn.Sequential (main/default.py:656-670) and the U / V^T products of
+ * AmortizableMLP._apply_amortized_mlp with permanent parameters (amortizable_mlp.py:508-578).
+ * W row-major (N, K) with row stride w_stride; bias nullable; act: 0 identity, 1 tanh.
+ * ------------------------------------------------------------------------------------------------------------ */
+int jf_linear_f32(const float* in, int64_t in_stride, const float* W, int64_t w_stride, const float* bias, int64_t B, int32_t K,
+                  int32_t N, int32_t act, float* out, int64_t out_stride, void* stream);
+int jf_linear_f64(const double* in, int64_t in_stride, const double* W, int64_t w_stride, const double* bias, int64_t B,
+                  int32_t K, int32_t N, int32_t act, double* out, int64_t out_stride, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * base-distribution log-prob: out[b] = (in ? in[b] : 0) + sum_d N(0,1).log_prob(z[b,d])
+ * (torch.distributions.Normal(0,1).log_prob(base_pos).sum(-1), jammy_flows/main/default.py:1110-1115, 1657, 1670)
+ * ------------------------------------------------------------------------------------------------------------ */
+int jf_normal_logp_f32(const float* z, int64_t z_stride, int64_t B, int32_t D, const float* in, float* out, void* stream);
+int jf_normal_logp_f64(const double* z, int64_t z_stride, int64_t B, int32_t D, const double* in, double* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* JAMMY_HIP_H */

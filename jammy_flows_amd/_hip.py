@@ -1,0 +1,210 @@
+"""ctypes binding of libjammy_hip.so (the C ABI declared in include/jammy_hip.h).
+
+This is the ONLY compute path of the package: there is no CPU / eager fallback.  Anything that cannot run on the
+HIP kernels raises (missing library, CPU tensors, unsupported option) -- silently routing through PyTorch ops would
+void every parity claim made for the kernels.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libjammy_hip.so")
+
+JF_OK = 0
+JF_ERRORS = {-1: "bad argument", -2: "unsupported configuration (dimension > 8, chain too long, LDS budget ...)", -3: "kernel launch failed"}
+JF_STATUS_WORDS = 4
+JF_STATUS_NONCONVERGED, JF_STATUS_NONFINITE, JF_STATUS_OUT_OF_RANGE = 0, 1, 2
+JF_MAX_CHAIN = 8
+
+GF_INV_TYPES = {"isigmoid": 0, "inormal_partly_precise": 1, "inormal_partly_crude": 2, "inormal_full_pade": 3}
+GF_WIDTH_SMOOTH, GF_WIDTH_EXP, GF_WIDTH_SOFTPLUS = 0, 1, 2
+
+
+class HipUnavailable(RuntimeError):
+    pass
+
+
+class jf_gf_layer(ctypes.Structure):
+    _fields_ = [("num_kde", ctypes.c_int32), ("hh_iter", ctypes.c_int32), ("model_offset", ctypes.c_int32),
+                ("fit_normalization", ctypes.c_int32), ("regulate_normalization", ctypes.c_int32),
+                ("inverse_function_type", ctypes.c_int32), ("width_mode", ctypes.c_int32), ("clamp_widths", ctypes.c_int32),
+                ("width_min", ctypes.c_double), ("width_max", ctypes.c_double), ("norm_min", ctypes.c_double),
+                ("norm_max", ctypes.c_double)]
+
+
+_lib = None
+
+_P = ctypes.c_void_p
+_I64 = ctypes.c_int64
+_I32 = ctypes.c_int32
+
+# name -> argtypes (without the _f32/_f64 suffix); every entry point of include/jammy_hip.h
+_SIGNATURES = {
+    "jf_gf_chain_inv": [_P, _I64, _P, _P, _I64, _I32, _I64, _I32, _I32, ctypes.POINTER(jf_gf_layer), _P, _I64, _P, _P, _P, _P, _P],
+    "jf_gf_chain_fwd": [_P, _I64, _P, _P, _I64, _I32, _I64, _I32, _I32, ctypes.POINTER(jf_gf_layer), _P, _I64, _P, _P, _P],
+    "jf_linear": [_P, _I64, _P, _I64, _P, _I64, _I32, _I32, _I32, _P, _I64, _P],
+    "jf_normal_logp": [_P, _I64, _I64, _I32, _P, _P, _P],
+}
+
+
+def exported_symbols():
+    """all symbols include/jammy_hip.h declares (used by the CPU-side ABI test)."""
+    names = ["jf_abi_version"]
+    for base in _SIGNATURES:
+        names += [base + "_f32", base + "_f64"]
+    return names
+
+
+def lib():
+    """load (once) and return the shared library; raises HipUnavailable with a build hint when it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipUnavailable("libjammy_hip.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                             "(or `make -C jammy_flows_amd/csrc`); jammy_flows_amd has no CPU fallback" % LIB_PATH)
+    try:
+        l = ctypes.CDLL(LIB_PATH)
+    except OSError as e:  # pragma: no cover
+        raise HipUnavailable("cannot load %s: %s" % (LIB_PATH, e))
+    l.jf_abi_version.restype = ctypes.c_int
+    for base, argtypes in _SIGNATURES.items():
+        for suf in ("_f32", "_f64"):
+            fn = getattr(l, base + suf)
+            fn.argtypes = argtypes
+            fn.restype = ctypes.c_int
+    _lib = l
+    return _lib
+
+
+def _suffix(t):
+    if t.dtype == torch.float32:
+        return "_f32"
+    if t.dtype == torch.float64:
+        return "_f64"
+    raise TypeError("jammy_flows_amd kernels exist for float32 and float64 only, got %s" % t.dtype)
+
+
+def require_device(*tensors):
+    """every tensor must live on a HIP device (no CPU path exists)."""
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise HipUnavailable("jammy_flows_amd computes on MI355X (HIP) tensors only; got a %s tensor. "
+                                 "Move the pdf and its inputs to 'cuda' -- there is no CPU fallback." % t.device)
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise ValueError("tensors on different devices: %s vs %s" % (dev, t.device))
+    return dev
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _check(rc, what):
+    if rc != JF_OK:
+        raise RuntimeError("%s failed: %s (code %d)" % (what, JF_ERRORS.get(rc, "unknown"), rc))
+
+
+def _rowmajor(t):
+    """(B, n) tensor usable by the kernels: unit stride in the last dim, any row stride."""
+    if t.dim() != 2:
+        raise ValueError("expected a 2-d tensor, got shape %s" % (tuple(t.shape),))
+    if t.shape[1] > 1 and t.stride(1) != 1:
+        t = t.contiguous()
+    if t.shape[1] == 1 and t.stride(0) < 1:
+        t = t.contiguous()
+    return t
+
+
+def new_status(device):
+    return torch.zeros(JF_STATUS_WORDS, dtype=torch.int32, device=device)
+
+
+# --------------------------------------------------------------------------------------------------------------
+def gf_layer_array(structs):
+    arr = (jf_gf_layer * len(structs))()
+    for i, s in enumerate(structs):
+        arr[i] = s
+    return arr
+
+
+def gf_chain(direction, x, log_det, params, layer_array, n_layers, D, x_out=None, base_logp_in=None, want_base_logp=False, status=None):
+    """run a chain of g layers.  direction 'inv' (log-prob) or 'fwd' (sampling).
+    x (B, D) view (row stride arbitrary), log_det (B,) or None, params (1|B, P).  Returns (x_out, log_det_out[, base_logp])."""
+    require_device(x, log_det, params, x_out, base_logp_in, status)
+    x = _rowmajor(x)
+    params = _rowmajor(params)
+    if params.dtype != x.dtype:
+        raise TypeError("parameter dtype %s != input dtype %s" % (params.dtype, x.dtype))
+    B = x.shape[0]
+    if x.shape[1] != D:
+        raise ValueError("expected %d target columns, got %d" % (D, x.shape[1]))
+    if params.shape[0] not in (1, B):
+        raise ValueError("extra_inputs must have 1 or B=%d rows, got %d" % (B, params.shape[0]))
+    if log_det is not None:
+        log_det = log_det.contiguous()
+        if log_det.dtype != x.dtype or log_det.shape[0] != B:
+            raise ValueError("log_det must be a (B,) tensor of the input dtype")
+    if x_out is None:
+        x_out = torch.empty((B, D), dtype=x.dtype, device=x.device)
+    ld_out = torch.empty((B,), dtype=x.dtype, device=x.device)
+    suf = _suffix(x)
+    pb = 1 if (params.shape[0] == 1 and B != 1) else params.shape[0]
+    if B == 1:
+        pb = 1
+    if direction == "inv":
+        blp_out = torch.empty((B,), dtype=x.dtype, device=x.device) if want_base_logp else None
+        rc = getattr(lib(), "jf_gf_chain_inv" + suf)(_ptr(x), x.stride(0), _ptr(log_det), _ptr(params), params.stride(0), pb, B, D, n_layers,
+                                                     layer_array, _ptr(x_out), x_out.stride(0), _ptr(ld_out), _ptr(base_logp_in),
+                                                     _ptr(blp_out), _ptr(status), _stream())
+        _check(rc, "jf_gf_chain_inv" + suf)
+        return (x_out, ld_out, blp_out) if want_base_logp else (x_out, ld_out)
+    rc = getattr(lib(), "jf_gf_chain_fwd" + suf)(_ptr(x), x.stride(0), _ptr(log_det), _ptr(params), params.stride(0), pb, B, D, n_layers,
+                                                 layer_array, _ptr(x_out), x_out.stride(0), _ptr(ld_out), _ptr(status), _stream())
+    _check(rc, "jf_gf_chain_fwd" + suf)
+    return x_out, ld_out
+
+
+def linear(inp, weight, bias=None, act=0, out=None):
+    """out = act(inp @ weight^T + bias) on the matrix cores; act 0 identity / 1 tanh."""
+    require_device(inp, weight, bias, out)
+    inp = _rowmajor(inp)
+    weight = _rowmajor(weight)
+    if weight.dtype != inp.dtype or (bias is not None and bias.dtype != inp.dtype):
+        raise TypeError("linear: dtype mismatch")
+    B, K = inp.shape
+    N = weight.shape[0]
+    if weight.shape[1] != K:
+        raise ValueError("linear: weight %s does not match input width %d" % (tuple(weight.shape), K))
+    if bias is not None:
+        bias = bias.contiguous()
+    if out is None:
+        out = torch.empty((B, N), dtype=inp.dtype, device=inp.device)
+    suf = _suffix(inp)
+    rc = getattr(lib(), "jf_linear" + suf)(_ptr(inp), inp.stride(0), _ptr(weight), weight.stride(0), _ptr(bias), B, K, N, act, _ptr(out),
+                                           out.stride(0), _stream())
+    _check(rc, "jf_linear" + suf)
+    return out
+
+
+def normal_logp(z, acc=None):
+    """acc + sum_d N(0,1).log_prob(z[:, d]) -> (B,)"""
+    require_device(z, acc)
+    z = _rowmajor(z)
+    B, D = z.shape
+    out = torch.empty((B,), dtype=z.dtype, device=z.device)
+    suf = _suffix(z)
+    rc = getattr(lib(), "jf_normal_logp" + suf)(_ptr(z), z.stride(0), B, D, _ptr(acc), _ptr(out), _stream())
+    _check(rc, "jf_normal_logp" + suf)
+    return out

@@ -1,0 +1,85 @@
+// Scalar math policy for the flow kernels.
+//
+//  float : hardware transcendentals (v_exp_f32 / v_log_f32 / v_rcp_f32, quarter-rate on CDNA4) on the hot
+//          linear-space path -- the fp32 bar is |dlogp| < 1e-2 against the fp64 reference, these are ~1e-6;
+//          accurate OCML functions on the rare log-space (tail) path and in the iterative solvers.
+//  double: OCML double functions throughout (fp64 bar: |dlogp| < 1e-4).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+
+namespace jf {
+
+template <typename T> struct M;
+
+template <> struct M<float> {
+    static constexpr float PI = 3.14159265358979323846f;
+    static constexpr float TWO_PI = 6.28318530717958647692f;
+    static constexpr float HALF_LN_2PI = 0.91893853320467274178f;
+    static constexpr float SQRT2 = 1.41421356237309504880f;
+    static constexpr float TINY = 1e-30f;       // below this a linear-space cdf/sf is recomputed in log space
+    static constexpr float EPS_COS = 1e-7f;     // sphere_base.return_safe_costheta float32 margin
+    static constexpr float EPS_S1 = 1e-5f;      // sphere_base.sphere_to_plane float32 clamp
+    static constexpr float KAPPA_ID = 1e-4f;    // fvm_2d small-kappa identity switch (float32)
+    static __device__ __forceinline__ float exp_fast(float x) { return __expf(x); }
+    static __device__ __forceinline__ float log_fast(float x) { return __logf(x); }
+    static __device__ __forceinline__ float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+    static __device__ __forceinline__ float exp(float x) { return expf(x); }
+    static __device__ __forceinline__ float log(float x) { return logf(x); }
+    static __device__ __forceinline__ float log1p(float x) { return log1pf(x); }
+    static __device__ __forceinline__ float sqrt(float x) { return sqrtf(x); }
+    static __device__ __forceinline__ float erf(float x) { return erff(x); }
+    static __device__ __forceinline__ float erfinv(float x) { return erfinvf(x); }
+    static __device__ __forceinline__ float erfcinv(float x) { return erfcinvf(x); }
+    static __device__ __forceinline__ float sin(float x) { return sinf(x); }
+    static __device__ __forceinline__ float cos(float x) { return cosf(x); }
+    static __device__ __forceinline__ float acos(float x) { return acosf(x); }
+    static __device__ __forceinline__ float atan2(float y, float x) { return atan2f(y, x); }
+    static __device__ __forceinline__ float tanh(float x) { return tanhf(x); }
+    static __device__ __forceinline__ float abs(float x) { return fabsf(x); }
+    static __device__ __forceinline__ float max(float a, float b) { return fmaxf(a, b); }
+    static __device__ __forceinline__ float min(float a, float b) { return fminf(a, b); }
+    static __device__ __forceinline__ bool finite(float x) { return isfinite(x); }
+};
+
+template <> struct M<double> {
+    static constexpr double PI = 3.14159265358979323846;
+    static constexpr double TWO_PI = 6.28318530717958647692;
+    static constexpr double HALF_LN_2PI = 0.91893853320467274178;
+    static constexpr double SQRT2 = 1.41421356237309504880;
+    static constexpr double TINY = 1e-280;
+    static constexpr double EPS_COS = 1e-10;
+    static constexpr double EPS_S1 = 1e-8;
+    static constexpr double KAPPA_ID = 1e-8;
+    static __device__ __forceinline__ double exp_fast(double x) { return ::exp(x); }
+    static __device__ __forceinline__ double log_fast(double x) { return ::log(x); }
+    static __device__ __forceinline__ double rcp(double x) { return 1.0 / x; }
+    static __device__ __forceinline__ double exp(double x) { return ::exp(x); }
+    static __device__ __forceinline__ double log(double x) { return ::log(x); }
+    static __device__ __forceinline__ double log1p(double x) { return ::log1p(x); }
+    static __device__ __forceinline__ double sqrt(double x) { return ::sqrt(x); }
+    static __device__ __forceinline__ double erf(double x) { return ::erf(x); }
+    static __device__ __forceinline__ double erfinv(double x) { return ::erfinv(x); }
+    static __device__ __forceinline__ double erfcinv(double x) { return ::erfcinv(x); }
+    static __device__ __forceinline__ double sin(double x) { return ::sin(x); }
+    static __device__ __forceinline__ double cos(double x) { return ::cos(x); }
+    static __device__ __forceinline__ double acos(double x) { return ::acos(x); }
+    static __device__ __forceinline__ double atan2(double y, double x) { return ::atan2(y, x); }
+    static __device__ __forceinline__ double tanh(double x) { return ::tanh(x); }
+    static __device__ __forceinline__ double abs(double x) { return ::fabs(x); }
+    static __device__ __forceinline__ double max(double a, double b) { return ::fmax(a, b); }
+    static __device__ __forceinline__ double min(double a, double b) { return ::fmin(a, b); }
+    static __device__ __forceinline__ bool finite(double x) { return isfinite(x); }
+};
+
+// softplus(x) = log(1 + e^x), overflow-free (torch F.softplus agrees to < 2.1e-9 with its threshold=20 shortcut)
+template <typename T> __device__ __forceinline__ T softplus(T x) {
+    return M<T>::max(x, T(0)) + M<T>::log1p(M<T>::exp(-M<T>::abs(x)));
+}
+template <typename T> __device__ __forceinline__ T logaddexp(T a, T b) {
+    const T m = M<T>::max(a, b);
+    return m + M<T>::log1p(M<T>::exp(-M<T>::abs(a - b)));
+}
+template <typename T> __device__ __forceinline__ T clampv(T x, T lo, T hi) { return M<T>::min(M<T>::max(x, lo), hi); }
+
+}  // namespace jf

@@ -1,0 +1,227 @@
+"""Gaussianization flow layer 'g' -- host side.
+
+Same constructor arguments, parameter names/shapes (state_dict compatible) and bookkeeping as
+jammy_flows/layers/euclidean/gaussianization_flow.py (class gf_block, :50-386, 1116-1222); all arithmetic
+(parameter regulation, Householder rotation, logistic-mixture CDF, inverse-CDF stage, bisection + Newton inverse) runs
+in the HIP kernels of csrc/gf_kernels.hip through the C ABI (jf_gf_chain_inv_* / jf_gf_chain_fwd_*).
+"""
+import math
+
+import numpy
+import torch
+from torch import nn
+
+from . import euclidean_base
+from ... import _hip
+
+
+class gf_block(euclidean_base.euclidean_base):
+    def __init__(self,
+                 dimension,
+                 nonlinear_stretch_type="classic",
+                 num_kde=5,
+                 num_householder_iter=-1,
+                 use_permanent_parameters=False,
+                 fit_normalization=0,
+                 inverse_function_type="inormal_partly_precise",
+                 model_offset=0,
+                 softplus_for_width=0,
+                 width_smooth_saturation=1,
+                 lower_bound_for_widths=0.01,
+                 upper_bound_for_widths=100,
+                 lower_bound_for_norms=1,
+                 upper_bound_for_norms=10,
+                 center_mean=0,
+                 clamp_widths=0,
+                 regulate_normalization=0,
+                 add_skewness=0,
+                 rotation_mode="householder"):
+        """Symbol "g".  Parameters as in the reference (gaussianization_flow.py:71-102)."""
+        super().__init__(dimension=dimension, use_permanent_parameters=use_permanent_parameters, model_offset=model_offset)
+        if nonlinear_stretch_type not in ("classic", "rq_splines"):
+            raise Exception("Unknown non linear stretch type: %s" % nonlinear_stretch_type)
+        if inverse_function_type not in _hip.GF_INV_TYPES:
+            raise AssertionError("unknown inverse_function_type %s" % inverse_function_type)
+        unsupported = []
+        if center_mean:
+            unsupported.append("center_mean=1")
+        if add_skewness:
+            unsupported.append("add_skewness=1")
+        if rotation_mode not in ("householder", "none"):
+            unsupported.append("rotation_mode=%s" % rotation_mode)
+        if nonlinear_stretch_type != "classic":
+            unsupported.append("nonlinear_stretch_type=%s" % nonlinear_stretch_type)
+        if unsupported:
+            raise NotImplementedError("g layer option(s) without a HIP kernel yet: %s (no eager fallback exists)" % ", ".join(unsupported))
+        assert lower_bound_for_widths > 0.0
+        if width_smooth_saturation and not softplus_for_width:
+            assert upper_bound_for_widths > 0, "We require a maximum saturation level for smooth saturation!"
+
+        self.nonlinear_stretch_type = nonlinear_stretch_type
+        self.num_kde = num_kde
+        self.fit_normalization = fit_normalization
+        self.regulate_normalization = regulate_normalization
+        self.inverse_function_type = inverse_function_type
+        self.softplus_for_width = softplus_for_width
+        self.width_smooth_saturation = width_smooth_saturation
+        self.clamp_widths = clamp_widths
+        self.width_min = lower_bound_for_widths
+        self.width_max = upper_bound_for_widths if upper_bound_for_widths > 0 else None
+        self.lower_bound_for_norms = lower_bound_for_norms
+        self.upper_bound_for_norms = upper_bound_for_norms
+        self.center_mean = center_mean
+        self.add_skewness = add_skewness
+        self.rotation_mode = rotation_mode
+
+        # Householder rotation (gaussianization_flow.py:172-196)
+        self.use_householder = False
+        self.householder_iter = 0
+        self.num_householder_params = 0
+        if rotation_mode == "householder":
+            self.householder_iter = dimension if num_householder_iter == -1 else num_householder_iter
+            self.use_householder = self.householder_iter > 0
+            if self.use_householder:
+                self.num_householder_params = self.householder_iter * dimension
+                if use_permanent_parameters:
+                    self.vs = nn.Parameter(torch.randn(self.householder_iter, dimension).unsqueeze(0))
+        self.total_param_num += self.num_householder_params
+
+        self.num_params_datapoints = num_kde * dimension
+        self.total_param_num_means = num_kde * dimension
+        bandwidth = (4. * numpy.sqrt(math.pi) / ((math.pi ** 4) * num_kde)) ** 0.2      # Gaussianization-flow paper init (:233)
+        self.init_log_width = float(numpy.log(bandwidth))
+        if use_permanent_parameters:
+            self.kde_means = nn.Parameter(torch.randn(num_kde, dimension).unsqueeze(0))
+            self.kde_log_widths = nn.Parameter(torch.ones(num_kde, dimension).unsqueeze(0) * self.init_log_width)
+            if fit_normalization:
+                self.kde_log_weights = nn.Parameter(torch.randn(num_kde, dimension).unsqueeze(0))
+        self.total_param_num += 2 * self.num_params_datapoints + (self.num_params_datapoints if fit_normalization else 0)
+
+        self._row_cache = None
+        self._c_struct = None
+
+    # ------------------------------------------------------------------------------------------------------
+    def c_struct(self):
+        """the jf_gf_layer descriptor of this layer (include/jammy_hip.h)."""
+        if self._c_struct is None:
+            if self.softplus_for_width:
+                mode = _hip.GF_WIDTH_SOFTPLUS
+            elif self.width_smooth_saturation:
+                mode = _hip.GF_WIDTH_SMOOTH
+            else:
+                mode = _hip.GF_WIDTH_EXP
+            s = _hip.jf_gf_layer()
+            s.num_kde = self.num_kde
+            s.hh_iter = self.householder_iter if self.use_householder else 0
+            s.model_offset = 1 if self.model_offset else 0
+            s.fit_normalization = 1 if self.fit_normalization else 0
+            s.regulate_normalization = 1 if (self.fit_normalization and self.regulate_normalization) else 0
+            s.inverse_function_type = _hip.GF_INV_TYPES[self.inverse_function_type]
+            s.width_mode = mode
+            s.clamp_widths = 1 if self.clamp_widths else 0
+            s.width_min = float(self.width_min)
+            s.width_max = float(self.width_max) if self.width_max is not None else -1.0
+            s.norm_min = float(self.lower_bound_for_norms)
+            s.norm_max = float(self.upper_bound_for_norms)
+            self._c_struct = s
+        return self._c_struct
+
+    def _permanent_tensors(self):
+        ts = []
+        if self.model_offset:
+            ts.append(self.offsets)
+        if self.use_householder:
+            ts.append(self.vs)
+        ts += [self.kde_means, self.kde_log_widths]
+        if self.fit_normalization:
+            ts.append(self.kde_log_weights)
+        return ts
+
+    def permanent_row(self, like):
+        """the permanent parameters as one (1, total_param_num) row in the extra_inputs layout (cached until a parameter changes)."""
+        ts = self._permanent_tensors()
+        key = (like.dtype, like.device, tuple((t._version, t.data_ptr()) for t in ts))
+        if self._row_cache is None or self._row_cache[0] != key:
+            with torch.no_grad():
+                row = torch.cat([t.detach().reshape(-1).to(device=like.device, dtype=like.dtype) for t in ts]).reshape(1, -1)
+            assert row.shape[1] == self.total_param_num
+            self._row_cache = (key, row)
+        return self._row_cache[1]
+
+    def _params_for(self, x, extra_inputs):
+        if extra_inputs is None:
+            if not self.use_permanent_parameters:
+                raise ValueError("layer has no permanent parameters: extra_inputs required")
+            return self.permanent_row(x)
+        if extra_inputs.shape[1] != self.total_param_num:
+            raise ValueError("extra_inputs has %d columns, layer needs %d" % (extra_inputs.shape[1], self.total_param_num))
+        return extra_inputs
+
+    # ---- plugin API: one fused launch per call (offset + rotation + mixture + inverse-CDF stage)
+    def inv_flow_mapping(self, inputs, extra_inputs=None, force_embedding_coordinates=False, force_intrinsic_coordinates=False):
+        x, log_det = inputs
+        return run_chain([self], "inv", x, log_det, self._params_for(x, extra_inputs))
+
+    def flow_mapping(self, inputs, extra_inputs=None, force_embedding_coordinates=False, force_intrinsic_coordinates=False, status=None):
+        z, log_det = inputs
+        return run_chain([self], "fwd", z, log_det, self._params_for(z, extra_inputs), status=status)
+
+    _inv_flow_mapping = None
+    _flow_mapping = None
+
+    # ---- initialisation bookkeeping (gaussianization_flow.py:1116-1222)
+    def _get_desired_init_parameters(self):
+        vec = []
+        if self.num_householder_params > 0:
+            vec.append(torch.randn(self.householder_iter * self.dimension))
+        vec.append(torch.randn(self.total_param_num_means))
+        vec.append(torch.ones(self.num_kde * self.dimension) * self.init_log_width)
+        if self.fit_normalization:
+            vec.append(torch.ones(self.num_kde * self.dimension))
+        return torch.cat(vec)
+
+    def _init_params(self, params):
+        c = 0
+        if self.use_householder:
+            self.vs.data = torch.reshape(params[:self.num_householder_params], [1, self.householder_iter, self.dimension])
+            c += self.num_householder_params
+        n = self.num_params_datapoints
+        self.kde_means.data = torch.reshape(params[c:c + n], [1, self.num_kde, self.dimension]); c += n
+        self.kde_log_widths.data = torch.reshape(params[c:c + n], [1, self.num_kde, self.dimension]); c += n
+        if self.fit_normalization:
+            self.kde_log_weights.data = torch.reshape(params[c:c + n], [1, self.num_kde, self.dimension]); c += n
+
+    def _obtain_layer_param_structure(self, param_dict, extra_inputs=None, previous_x=None, extra_prefix=""):
+        c = 0
+        n = self.num_params_datapoints
+        if self.use_householder:
+            param_dict[extra_prefix + "vs"] = (self.vs.data.reshape(1, -1) if extra_inputs is None else extra_inputs[:, :self.num_householder_params])
+            c += self.num_householder_params
+        if extra_inputs is None:
+            param_dict[extra_prefix + "means"] = self.kde_means.data
+            param_dict[extra_prefix + "log_widths"] = self.kde_log_widths.data
+            if self.fit_normalization:
+                param_dict[extra_prefix + "log_norms"] = self.kde_log_weights.data
+        else:
+            param_dict[extra_prefix + "means"] = extra_inputs[:, c:c + n].reshape(-1, self.num_kde, self.dimension); c += n
+            param_dict[extra_prefix + "log_widths"] = extra_inputs[:, c:c + n].reshape(-1, self.num_kde, self.dimension); c += n
+            if self.fit_normalization:
+                param_dict[extra_prefix + "log_norms"] = extra_inputs[:, c:c + n].reshape(-1, self.num_kde, self.dimension)
+
+
+# ----------------------------------------------------------------------------------------------------------
+def chain_supported(layers):
+    """can this list of layers of one e-block be run as one fused launch?"""
+    return 1 <= len(layers) <= _hip.JF_MAX_CHAIN and all(type(l) is gf_block for l in layers) and layers[0].dimension <= 8
+
+
+def chain_permanent_row(layers, like):
+    return torch.cat([l.permanent_row(like) for l in layers], dim=1) if len(layers) > 1 else layers[0].permanent_row(like)
+
+
+def run_chain(layers, direction, x, log_det, params, x_out=None, base_logp_in=None, want_base_logp=False, status=None):
+    """all layers of an e-block in ONE kernel launch.  `params`: (1|B, sum of the layers' total_param_num), layer order 0..n-1
+    (what the amortisation MLP emits, main/default.py:1002-1012 / :1488)."""
+    arr = _hip.gf_layer_array([l.c_struct() for l in layers])
+    return _hip.gf_chain(direction, x, log_det, params, arr, len(layers), layers[0].dimension, x_out=x_out, base_logp_in=base_logp_in,
+                         want_base_logp=want_base_logp, status=status)

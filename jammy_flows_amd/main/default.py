@@ -1,0 +1,601 @@
+"""`pdf` -- the autoregressive orchestrator over a product of manifolds, host side of the MI355X hot path.
+
+User-facing API of jammy_flows/main/default.py (class pdf): same constructor arguments, model strings ("e4+s2+e4" / "gggg+f+gggg"),
+``forward`` -> (log_prob, log_prob_base, base_pos), ``sample`` -> (x, base, log_prob, log_prob_base), ``all_layer_inverse`` /
+``all_layer_forward``, ``transform_target_space``, ``init_params``, ``count_parameters`` and state_dict-compatible modules.
+What differs is underneath: every sub-pdf is evaluated by fused HIP kernels (one launch per Euclidean block, one per manifold
+layer, MFMA launches for the amortisation MLPs) instead of thousands of eager ops.
+
+Reference line numbers cited below refer to jammy_flows/main/default.py.
+"""
+import copy
+
+import numpy
+import torch
+from torch import nn
+
+from .. import _hip
+from ..amortizable_mlp import AmortizableMLP
+from ..extra_functions import list_from_str
+from ..flow_options import canonical, check_flow_option, layer_class, obtain_default_options, opts_dict
+from ..layers.euclidean import gaussianization_flow as gfl
+
+
+class HipLinearStack(nn.Sequential):
+    """nn.Sequential(Linear, Tanh, ..., Linear) of the default amortisation MLP (:656-670) -- identical module names, so the
+    reference's ``mlp_predictors.N.{0,2,..}.{weight,bias}`` state loads -- evaluated with the MFMA dense kernel (tanh fused)."""
+
+    def forward(self, x):
+        _hip.require_device(x)
+        mods = list(self)
+        i = 0
+        while i < len(mods):
+            lin = mods[i]
+            assert isinstance(lin, nn.Linear)
+            act = 1 if (i + 1 < len(mods) and isinstance(mods[i + 1], nn.Tanh)) else 0
+            w, b = lin.weight, lin.bias
+            if w.dtype != x.dtype:
+                w, b = w.to(x.dtype), b.to(x.dtype)
+            x = _hip.linear(x, w.detach(), b.detach(), act)
+            i += 2 if act else 1
+        return x
+
+
+class pdf(nn.Module):
+    def __init__(self,
+                 pdf_defs,
+                 flow_defs,
+                 options_overwrite=dict(),
+                 conditional_input_dim=None,
+                 amortization_mlp_dims="128",
+                 predict_log_normalization=False,
+                 join_poisson_and_pdf_description=False,
+                 hidden_mlp_dims_poisson="128",
+                 rank_of_mlp_mappings_poisson=0,
+                 amortization_mlp_use_custom_mode=False,
+                 amortization_mlp_ranks=0,
+                 amortization_mlp_highway_mode=0,
+                 amortize_everything=False,
+                 use_as_passthrough_instead_of_pdf=False,
+                 skip_mlp_initialization=False,
+                 verbose=False):
+        """Arguments as documented for the reference (:63-100)."""
+        super().__init__()
+        if predict_log_normalization:
+            raise NotImplementedError("predict_log_normalization (Poisson log-mean head) is outside the MI355X hot path")
+        self.amortization_mlp_use_custom_mode = amortization_mlp_use_custom_mode
+        self.predict_log_normalization = False
+        self.join_poisson_and_pdf_description = join_poisson_and_pdf_description
+        self.amortization_mlp_highway_mode = amortization_mlp_highway_mode
+        self.amortize_everything = amortize_everything
+        self.use_as_passthrough_instead_of_pdf = use_as_passthrough_instead_of_pdf
+        self.skip_mlp_initialization = skip_mlp_initialization
+        self.total_number_amortizable_params = None
+        if amortize_everything:
+            assert amortization_mlp_use_custom_mode, "Amortizing all MLPs requires custom MLPs."
+            self.total_number_amortizable_params = 0
+        self.check_status = True       # turn kernel status words into the reference's warnings / exceptions after each call
+
+        self._read_model_definition(pdf_defs, flow_defs, options_overwrite, conditional_input_dim, amortization_mlp_dims,
+                                    amortization_mlp_ranks)
+        self._init_flow_structure()
+        self._init_encoding_structure()
+        self.init_params()
+
+    # =========================================================================================== construction
+    def _read_model_definition(self, pdf_defs, flow_defs, options_overwrite, conditional_input_dim, mlp_dims, mlp_ranks):
+        """option resolution: (sub,layer) tuple > sub-pdf index > layer letter (:153-325)."""
+        self.pdf_defs_list = pdf_defs.split("+")
+        self.flow_defs_list = ["".join(canonical(c) for c in f) for f in flow_defs.split("+")]
+        if len(self.pdf_defs_list) != len(self.flow_defs_list):
+            raise Exception("PDF defs list has to be same length as flow defs list, but ... ", self.pdf_defs_list, self.flow_defs_list)
+        nsub = len(self.pdf_defs_list)
+        self.flow_opts = dict()
+        for si, letters in enumerate(self.flow_defs_list):
+            self.flow_opts[si] = []
+            for li, letter in enumerate(letters):
+                opts = obtain_default_options(letter)
+                chosen = None
+                for k, v in options_overwrite.items():
+                    if type(k) == tuple:
+                        assert type(k[0]) == int and type(k[1]) == int, "Require 2 ints for tuple-based flow definition!"
+                        assert 0 <= k[0] < nsub, "Index of detailed options is outside allowed range of defined autoregressive structure."
+                        if k == (si, li):
+                            assert len(v) == 1 and canonical(list(v.keys())[0]) == letter
+                            chosen = list(v.values())[0]
+                if chosen is None:
+                    for k, v in options_overwrite.items():
+                        if type(k) == int:
+                            assert 0 <= k < nsub, "Index of detailed options is outside allowed range of defined autoregressive structure."
+                            if k == si:
+                                for kk, vv in v.items():
+                                    if canonical(kk) == letter:
+                                        chosen = vv
+                if chosen is None:
+                    for k, v in options_overwrite.items():
+                        if type(k) == str and canonical(k) == letter:
+                            chosen = v
+                if chosen is not None:
+                    for name, val in chosen.items():
+                        check_flow_option(letter, name, val)
+                        opts[name] = val
+                self.flow_opts[si].append(opts)
+
+        self.conditional_input_dim = conditional_input_dim
+        self.encoding_type = "single"
+        if type(conditional_input_dim) == list:
+            assert all(type(ci) == int for ci in conditional_input_dim)
+            self.encoding_type = "multi"
+        if type(mlp_dims) == str:
+            mlp_dims = [mlp_dims] * nsub
+        elif type(mlp_dims) != list:
+            raise Exception("Hidden MLP dimensions must be defined either str or list, received ", type(mlp_dims))
+        if len(mlp_dims) != nsub:
+            raise Exception("hidden mlp dimension definitions for sub pdfs is wrong length (%d) .. requires length (%d)" % (len(mlp_dims), nsub))
+        self.amortization_mlp_dims = mlp_dims
+        if type(mlp_ranks) in (int, str):
+            mlp_ranks = [mlp_ranks] * nsub
+        elif type(mlp_ranks) != list:
+            raise Exception("Rank of MLP sub pdfs has to defined as an int or list type!")
+        self.amortization_mlp_ranks = mlp_ranks
+        self.force_permanent_parameters_in_first_subpdf = 1 if (conditional_input_dim is None and not self.amortize_everything) else 0
+
+    def _init_flow_structure(self):
+        """instantiate the layers (:378-479)."""
+        self.layer_list = nn.ModuleList()
+        self.num_parameter_list = []
+        for si, sub in enumerate(self.pdf_defs_list):
+            kind = sub[0]
+            dim = int(sub.split("_")[0][1:])
+            letters = self.flow_defs_list[si]
+            block = nn.ModuleList()
+            for li, letter in enumerate(letters):
+                if opts_dict[letter]["type"] != kind:
+                    raise Exception("layer type ", letter, " is not compatible with flow type ", sub)
+                kw = copy.deepcopy(self.flow_opts[si][li])
+                kw["use_permanent_parameters"] = 1 if (self.force_permanent_parameters_in_first_subpdf and si == 0) else 0
+                first = 1 if (li == 0 and not self.use_as_passthrough_instead_of_pdf) else 0
+                if kind == "s":
+                    kw["euclidean_to_sphere_as_first"] = first
+                elif kind == "i":
+                    bounds = sub.split("_")[1:]
+                    kw["low_boundary"] = float(bounds[0]) if bounds else 0.0
+                    kw["high_boundary"] = float(bounds[1]) if bounds else 1.0
+                    kw["euclidean_to_interval_as_first"] = first
+                elif kind == "e" and letter != "x":
+                    if li == len(letters) - 1 and kw["skip_model_offset"] == 0:
+                        kw["model_offset"] = 1
+                    elif li == 0 and letter == "g":
+                        if kw["replace_first_sigmoid_with_icdf"] > 0 and kw["inverse_function_type"] == "isigmoid":
+                            kw["inverse_function_type"] = "inormal_partly_precise"
+                kw.pop("skip_model_offset", None)
+                kw.pop("replace_first_sigmoid_with_icdf", None)
+                block.append(layer_class(letter)(dim, **kw))
+            self.layer_list.append(block)
+            self.num_parameter_list.append([l.get_total_param_num() for l in block])
+        self.log_normalization = None
+        self.update_embedding_structure()
+
+    def get_embedding_flags(self):
+        flags = []
+        for block in self.layer_list:
+            f = block[0].always_parametrize_in_embedding_space
+            assert all(l.always_parametrize_in_embedding_space == f for l in block)
+            flags.append(f)
+        return flags
+
+    def set_embedding_flags(self, usement_flag, sub_pdf_index=None):
+        """switch (sub-)manifolds between intrinsic and embedding default coordinates (:346-374)."""
+        assert usement_flag in (True, False)
+        for si, block in enumerate(self.layer_list):
+            if sub_pdf_index is None or si == sub_pdf_index:
+                for l in block:
+                    l.always_parametrize_in_embedding_space = usement_flag
+        self.update_embedding_structure()
+
+    def update_embedding_structure(self):
+        """column bookkeeping of target / base tensors (:481-567)."""
+        self.target_dims_intrinsic, self.target_dims_embedded, self.target_dims = [], [], []
+        self.target_dim_indices_intrinsic, self.target_dim_indices_embedded, self.target_dim_indices, self.base_dim_indices = [], [], [], []
+        ti = te = td = tb = 0
+        for block in self.layer_list:
+            intr = block[-1].get_layer_intrinsic_target_dimension()
+            emb = block[-1].get_layer_embedded_target_dimension()
+            use_emb = any(l.always_parametrize_in_embedding_space for l in block)
+            base = block[0].get_layer_base_dimension()
+            cur = emb if use_emb else intr
+            self.target_dims_intrinsic.append(intr)
+            self.target_dims_embedded.append(emb)
+            self.target_dims.append(cur)
+            self.base_dim_indices.append((tb, tb + base)); tb += base
+            self.target_dim_indices_intrinsic.append((ti, ti + intr)); ti += intr
+            self.target_dim_indices_embedded.append((te, te + emb)); te += emb
+            self.target_dim_indices.append((td, td + cur)); td += cur
+        self.total_target_dim_intrinsic, self.total_target_dim_embedded, self.total_target_dim, self.total_base_dim = ti, te, td, tb
+
+    def _init_encoding_structure(self):
+        """one amortisation MLP per sub-pdf that has parameters and a non-empty input (:571-722)."""
+        self.mlp_predictors = nn.ModuleList()
+        self.log_normalization_mlp = None
+        if self.skip_mlp_initialization:
+            return
+        prev = 0
+        for si in range(len(self.pdf_defs_list)):
+            emb = self.layer_list[si][-1]._embedding_conditional_return_num()
+            npar = sum(self.num_parameter_list[si])
+            if si == 0 and self.conditional_input_dim is None:
+                self.mlp_predictors.append(None)
+                if self.amortize_everything:
+                    self.total_number_amortizable_params += npar
+            elif npar == 0:
+                self.mlp_predictors.append(None)
+            else:
+                in_dim = prev
+                if self.conditional_input_dim is not None:
+                    in_dim += self.conditional_input_dim if type(self.conditional_input_dim) == int else self.conditional_input_dim[si]
+                if self.amortization_mlp_use_custom_mode:
+                    mlp = AmortizableMLP(in_dim, list_from_str(self.amortization_mlp_dims[si]), npar,
+                                         low_rank_approximations=self.amortization_mlp_ranks[si],
+                                         use_permanent_parameters=not self.amortize_everything,
+                                         highway_mode=self.amortization_mlp_highway_mode, svd_mode="smart")
+                    if self.amortize_everything:
+                        self.total_number_amortizable_params += mlp.num_amortization_params
+                else:
+                    hidden = list_from_str(self.amortization_mlp_dims[si])
+                    dims_in = [in_dim] + hidden
+                    dims_out = hidden + [npar]
+                    mods = []
+                    for i in range(len(dims_in)):
+                        mods.append(nn.Linear(dims_in[i], dims_out[i]))
+                        if i < len(dims_in) - 1:
+                            mods.append(nn.Tanh())
+                    mlp = HipLinearStack(*mods)
+                self.mlp_predictors.append(mlp)
+            prev += emb
+
+    def init_params(self, data=None, damping_factor=1000.0, mvn_min_max_sv_ratio=1e-4):
+        """layer "desired init" vectors become the final bias of each MLP (everything else / damping_factor) or are written into
+        the permanent parameters (:1817-1952).  Data-driven initialisation (scipy.optimize on the host) is out of scope."""
+        if data is not None:
+            raise NotImplementedError("init_params(data=...) (PCA / percentile based initialisation) is outside the MI355X hot path")
+        global_init = torch.zeros(self.total_number_amortizable_params) if self.amortize_everything else None
+        gi = 0
+        with torch.no_grad():
+            for si, block in enumerate(self.layer_list):
+                parts = [l.get_desired_init_parameters() for l in (reversed(block) if self.pdf_defs_list[si][0] == "e" else block)]
+                if self.pdf_defs_list[si][0] == "e":
+                    parts = parts[::-1]
+                these = torch.cat(parts) if len(parts) else torch.zeros(0)
+                if len(these) == 0:
+                    continue
+                mlp = self.mlp_predictors[si] if len(self.mlp_predictors) > si else None
+                if mlp is not None:
+                    if isinstance(mlp, AmortizableMLP):
+                        if self.amortize_everything:
+                            n = mlp.num_amortization_params
+                            global_init[gi:gi + n] = mlp.obtain_default_init_tensor(fix_final_bias=these, prev_damping_factor=damping_factor)
+                            gi += n
+                        else:
+                            mlp.initialize_uvbs(fix_final_bias=these, prev_damping_factor=damping_factor)
+                    else:
+                        for m in mlp:
+                            if hasattr(m, "weight"):
+                                nn.init.kaiming_uniform_(m.weight.data, a=numpy.sqrt(5))
+                                fan_in, _ = nn.init._calculate_fan_in_and_fan_out(m.weight.data)
+                                bound = 1 / numpy.sqrt(fan_in)
+                                nn.init.uniform_(m.bias.data, -bound, bound)
+                                m.weight.data /= damping_factor
+                                m.bias.data /= damping_factor
+                        mlp[-1].bias.data = these.data.type(mlp[-1].bias.data.dtype)
+                else:
+                    c = 0
+                    for l in block:
+                        n = l.get_total_param_num()
+                        if not self.amortize_everything:
+                            l.init_params(these[c:c + n])
+                        c += n
+                    if self.amortize_everything:
+                        global_init[gi:gi + c] = these
+                        gi += c
+        return global_init
+
+    def count_parameters(self, verbose=False):
+        """number of trainable parameters (MLPs + permanent layer parameters) (:724-830)."""
+        tot = 0
+        for m in self.mlp_predictors:
+            if m is not None:
+                tot += sum(int(numpy.prod(p.size())) for p in m.parameters() if p.requires_grad)
+        for block in self.layer_list:
+            for l in block:
+                tot += sum(int(numpy.prod(p.size())) for p in l.parameters() if p.requires_grad)
+        if verbose:
+            print("total Conditional PDF pars: %d" % tot)
+        return tot
+
+    def get_total_embedding_dim(self):
+        return sum(block[-1]._embedding_conditional_return_num() for block in self.layer_list)
+
+    def obtain_current_dtype_n_device(self):
+        try:
+            first = next(self.parameters())
+        except StopIteration:
+            return None, None
+        return first.dtype, first.device
+
+    # =========================================================================================== parameter routing
+    def _block_params(self, si, data_summary, embeds, amort, counter):
+        """extra_inputs row block of sub-pdf si, or None for permanent parameters (:936-993, 1420-1475)."""
+        mlp = self.mlp_predictors[si] if len(self.mlp_predictors) > si else None
+        if mlp is not None:
+            if data_summary is not None:
+                inp = data_summary[si] if type(data_summary) == list else data_summary
+                if len(embeds) > 0:
+                    inp = torch.cat([inp] + embeds, dim=1)
+            elif len(embeds) > 0:
+                inp = torch.cat(embeds, dim=1) if len(embeds) > 1 else embeds[0]
+            else:
+                raise Exception("extra conditional input is empty but required for encoding!")
+            if amort is not None:
+                n = mlp.num_amortization_params
+                out = mlp(inp, extra_inputs=amort[:, counter:counter + n])
+                counter += n
+            else:
+                out = mlp(inp)
+            return out, counter
+        if self.amortize_everything:
+            assert amort is not None
+            n = sum(l.get_total_param_num() for l in self.layer_list[si])
+            if n > 0:
+                out = amort[:, counter:counter + n]
+                return out, counter + n
+        return None, counter
+
+    def _check_cond(self, x, conditional_input):
+        if conditional_input is None:
+            return
+        if type(conditional_input) == list:
+            assert len(self.conditional_input_dim) == len(conditional_input)
+            for d, ci in zip(self.conditional_input_dim, conditional_input):
+                assert d == ci.shape[1], "Inputs of conditional input vector do not match with pre-defined input_dims!"
+                assert x.shape[0] == ci.shape[0], "Evaluating input x and condititional input shape must be similar!"
+        else:
+            assert x.shape[0] == conditional_input.shape[0], "Evaluating input x and condititional input shape must be similar!"
+
+    def _report_status(self, status):
+        """kernel status words -> the reference's warnings / exceptions (bisection_n_newton.py:84-133, default.py:1516)."""
+        if status is None or not self.check_status:
+            return
+        nonconv, nonfinite, oob, _ = status.tolist()
+        if oob > 0:
+            raise Exception("outside boundaries in rational-spline flow! (%d rows)" % oob)
+        if nonfinite > 0:
+            raise Exception("nonfinite values generated in %d rows .. this should never happen!" % nonfinite)
+        if nonconv > 0:
+            print(nonconv, " items did not converge in Newton iterations")
+
+    # =========================================================================================== log-prob direction
+    def _inverse_impl(self, x, log_det, data_summary, amortization_parameters, force_embedding_coordinates, force_intrinsic_coordinates,
+                      only_last, want_base_logp, status):
+        _hip.require_device(x, log_det)
+        if force_embedding_coordinates:
+            assert x.shape[1] == self.total_target_dim_embedded, (x.shape[1], self.total_target_dim_embedded)
+            x, log_det = self.transform_target_space(x, log_det, transform_from="embedding", transform_to="default")
+        elif force_intrinsic_coordinates:
+            assert x.shape[1] == self.total_target_dim_intrinsic
+            x, log_det = self.transform_target_space(x, log_det, transform_from="intrinsic", transform_to="default")
+        else:
+            assert x.shape[1] == self.total_target_dim, (x.shape[1], self.total_target_dim)
+        if amortization_parameters is not None:
+            assert amortization_parameters.shape[1] == self.total_number_amortizable_params
+        B = x.shape[0]
+        base = torch.empty((B, self.total_base_dim), dtype=x.dtype, device=x.device)
+        base_logp = None
+        embeds = []
+        counter = 0
+        for si, block in enumerate(self.layer_list):
+            extra, counter = self._block_params(si, data_summary, embeds, amortization_parameters, counter)
+            a, b = self.target_dim_indices[si]
+            tgt = x[:, a:b]
+            ba, bb = self.base_dim_indices[si]
+            out_view = base[:, ba:bb]
+            layers = list(block)
+            kind = self.pdf_defs_list[si][0]
+            if only_last:
+                layers = layers[-1:]
+            if kind == "e" and gfl.chain_supported(layers):
+                if extra is None:
+                    params = gfl.chain_permanent_row(layers, x)
+                elif only_last:
+                    params = extra[:, extra.shape[1] - layers[0].total_param_num:]
+                else:
+                    params = extra
+                res = gfl.run_chain(layers, "inv", tgt, log_det, params, x_out=out_view, base_logp_in=base_logp,
+                                    want_base_logp=want_base_logp, status=status)
+                log_det = res[1]
+                if want_base_logp:
+                    base_logp = res[2]
+            else:
+                if log_det is None:
+                    log_det = torch.zeros(B, dtype=x.dtype, device=x.device)
+                cur = tgt
+                used = 0
+                for l in reversed(list(block)):
+                    this = None
+                    if extra is not None:
+                        end = extra.shape[1] - used
+                        this = extra[:, end - l.total_param_num:end]
+                    kw = {}
+                    if only_last and kind == "s":
+                        kw["fix_euclidean_to_sphere_first"] = True
+                    cur, log_det = l.inv_flow_mapping([cur, log_det], extra_inputs=this, **kw)[:2]
+                    used += l.total_param_num
+                    if only_last:
+                        break
+                out_view.copy_(cur)
+                if want_base_logp:
+                    base_logp = _hip.normal_logp(out_view, base_logp)
+            embeds.append(block[-1]._embedding_conditional_return(tgt))
+        return base, log_det, base_logp
+
+    def all_layer_inverse(self, x, log_det, data_summary, amortization_parameters=None, force_embedding_coordinates=False,
+                          force_intrinsic_coordinates=False, only_last=False):
+        """autoregressive backward mapping of all sub-manifold flows -> (base_pos, log_det)  (:879-1057)."""
+        base, log_det, _ = self._inverse_impl(x, log_det, data_summary, amortization_parameters, force_embedding_coordinates,
+                                              force_intrinsic_coordinates, only_last, False, None)
+        return base, log_det
+
+    def forward(self, x, conditional_input=None, amortization_parameters=None, force_embedding_coordinates=False,
+                force_intrinsic_coordinates=False, only_last=False):
+        """log-probability at x -> (log_prob (B,), log_prob_base (B,), base_pos (B, D))  (:1059-1117)."""
+        assert not self.use_as_passthrough_instead_of_pdf, "The module is only used as a passthrough of all layers, not as actually evaluating the pdf!"
+        self._check_cond(x, conditional_input)
+        if torch.is_grad_enabled() and x.requires_grad:
+            # the kernels are forward-only (backward kernels: SURVEY.md section 8f, next row): never build a wrong graph silently
+            raise NotImplementedError("jammy_flows_amd kernels are forward-only in this version; call under torch.no_grad()")
+        with torch.no_grad():
+            status = _hip.new_status(x.device) if self.check_status else None
+            base, log_det, log_pdf = self._inverse_impl(x, None, conditional_input, amortization_parameters, force_embedding_coordinates,
+                                                        force_intrinsic_coordinates, only_last, True, status)
+            total = log_pdf + log_det
+            self._report_status(status)
+        return total, log_pdf, base
+
+    def log_prob(self, x, conditional_input=None, **kwargs):
+        """convenience: forward(...)[0]  (the reference has no such method)."""
+        return self.forward(x, conditional_input=conditional_input, **kwargs)[0]
+
+    # =========================================================================================== sampling direction
+    def all_layer_forward(self, x, log_det, data_summary, amortization_parameters=None, force_embedding_coordinates=False,
+                          force_intrinsic_coordinates=False, only_last=False, status=None):
+        """autoregressive forward mapping base -> target -> (x, log_det)  (:1373-1531)."""
+        _hip.require_device(x, log_det)
+        if amortization_parameters is not None:
+            assert amortization_parameters.shape[1] == self.total_number_amortizable_params
+        else:
+            assert not self.amortize_everything
+        B = x.shape[0]
+        out = torch.empty((B, self.total_target_dim), dtype=x.dtype, device=x.device)
+        embeds = []
+        counter = 0
+        for si, block in enumerate(self.layer_list):
+            extra, counter = self._block_params(si, data_summary, embeds, amortization_parameters, counter)
+            ba, bb = self.base_dim_indices[si]
+            cur = x[:, ba:bb]
+            a, b = self.target_dim_indices[si]
+            out_view = out[:, a:b]
+            kind = self.pdf_defs_list[si][0]
+            layers = list(block)
+            if only_last:
+                if kind not in "es":
+                    raise Exception("Flow type ", kind, " does not supported *only_last*!")
+                layers = layers[-1:]
+            if kind == "e" and gfl.chain_supported(layers):
+                if extra is None:
+                    params = gfl.chain_permanent_row(layers, x)
+                elif only_last:
+                    params = extra[:, extra.shape[1] - layers[0].total_param_num:]
+                else:
+                    params = extra
+                _, log_det = gfl.run_chain(layers, "fwd", cur, log_det, params, x_out=out_view, status=status)
+            else:
+                if log_det is None:
+                    log_det = torch.zeros(B, dtype=x.dtype, device=x.device)
+                c = 0
+                for li, l in enumerate(block):
+                    this = None if extra is None else extra[:, c:c + l.total_param_num]
+                    c += l.total_param_num
+                    if only_last and li < len(block) - 1:
+                        continue
+                    kw = {}
+                    if only_last and kind == "s":
+                        kw["fix_euclidean_to_sphere_first"] = True
+                    cur, log_det = l.flow_mapping([cur, log_det], extra_inputs=this, **kw)[:2]
+                out_view.copy_(cur)
+            embeds.append(block[-1]._embedding_conditional_return(out_view))
+        x_new = out
+        if force_embedding_coordinates:
+            x_new, log_det = self.transform_target_space(x_new, log_det, transform_from="default", transform_to="embedding")
+        elif force_intrinsic_coordinates:
+            x_new, log_det = self.transform_target_space(x_new, log_det, transform_from="default", transform_to="intrinsic")
+        return x_new, log_det
+
+    def _obtain_sample(self, conditional_input=None, predefined_target_input=None, samplesize=1, seed=None, amortization_parameters=None,
+                       force_embedding_coordinates=False, force_intrinsic_coordinates=False, failsafe_crosscheck_tolerance=None, dtype=None,
+                       device=None, only_last=False):
+        """base noise (drawn with numpy on the host like the reference does, or injected) -> (x, base, log_prob, log_prob_base)  (:1533-1707)."""
+        if failsafe_crosscheck_tolerance:
+            raise NotImplementedError("failsafe_crosscheck_tolerance (recheck_sampling) is outside the MI355X hot path")
+        used = samplesize
+        if self.amortize_everything:
+            assert amortization_parameters is not None
+            dev, dt, used = amortization_parameters.device, amortization_parameters.dtype, amortization_parameters.shape[0]
+        elif conditional_input is not None:
+            ci = conditional_input[0] if type(conditional_input) == list else conditional_input
+            used, dt, dev = ci.shape[0], ci.dtype, ci.device
+        else:
+            dt, dev = self.obtain_current_dtype_n_device()
+            if device is not None:
+                dev = device
+            if dtype is not None:
+                dt = dtype
+        assert dt is not None and dev is not None, "DType and/or device is None: pass dtype and device as keyword arguments"
+        if predefined_target_input is not None:
+            z = predefined_target_input
+            if conditional_input is not None:
+                ci = conditional_input[0] if type(conditional_input) == list else conditional_input
+                assert z.shape[0] == ci.shape[0] and z.dtype == ci.dtype and z.device == ci.device
+            base_ret = 0.0
+        else:
+            if seed is not None:
+                numpy.random.seed(seed)
+            z = torch.from_numpy(numpy.random.normal(size=(used, self.total_base_dim))).type(dt).to(dev)
+            base_ret = z
+        _hip.require_device(z)
+        status = _hip.new_status(z.device) if self.check_status else None
+        log_gauss = _hip.normal_logp(z, None)
+        x, log_det = self.all_layer_forward(z, None, conditional_input, amortization_parameters=amortization_parameters,
+                                            force_embedding_coordinates=force_embedding_coordinates,
+                                            force_intrinsic_coordinates=force_intrinsic_coordinates, only_last=only_last, status=status)
+        self._report_status(status)
+        return x, base_ret, -log_det + log_gauss, log_gauss
+
+    def sample(self, conditional_input=None, samplesize=1, seed=None, allow_gradients=False, amortization_parameters=None,
+               force_embedding_coordinates=False, force_intrinsic_coordinates=False, failsafe_crosscheck_tolerance=None, dtype=None,
+               device=None, only_last=False):
+        """draw samples -> (x, base, log_prob, log_prob_base)  (:1300-1371)."""
+        assert not self.use_as_passthrough_instead_of_pdf
+        if allow_gradients:
+            raise NotImplementedError("differentiable sampling needs the backward kernels (SURVEY.md 8f); not available in this version")
+        with torch.no_grad():
+            return self._obtain_sample(conditional_input=conditional_input, seed=seed, samplesize=samplesize,
+                                       amortization_parameters=amortization_parameters,
+                                       force_embedding_coordinates=force_embedding_coordinates,
+                                       force_intrinsic_coordinates=force_intrinsic_coordinates,
+                                       failsafe_crosscheck_tolerance=failsafe_crosscheck_tolerance, device=device, dtype=dtype,
+                                       only_last=only_last)
+
+    # =========================================================================================== coordinate systems
+    def transform_target_into_returnable_params(self, target):
+        return self.transform_target_space(target)[0]
+
+    def transform_target_space(self, target, log_det=0, transform_from="default", transform_to="embedding"):
+        """default / intrinsic / embedding coordinates of the target tensor (:1737-1813)."""
+        new_target = target.unsqueeze(0) if target.dim() == 1 else target
+        dims = {"default": self.target_dims, "intrinsic": self.target_dims_intrinsic, "embedding": self.target_dims_embedded}
+        totals = {"default": self.total_target_dim, "intrinsic": self.total_target_dim_intrinsic, "embedding": self.total_target_dim_embedded}
+        if transform_from not in dims or transform_to not in dims:
+            raise Exception("Unknown transformation space! Allowed: default/intrinsic/embedding")
+        assert new_target.shape[1] == totals[transform_from]
+        vals = []
+        c = 0
+        for si, block in enumerate(self.layer_list):
+            n = dims[transform_from][si]
+            t, log_det = block[-1].transform_target_space(new_target[:, c:c + n], log_det=log_det, transform_from=transform_from,
+                                                          transform_to=transform_to)
+            vals.append(t)
+            c += n
+        res = torch.cat(vals, dim=1) if len(vals) > 1 else vals[0]
+        assert res.shape[1] == totals[transform_to]
+        if target.dim() == 1:
+            res = res.squeeze(0)
+        return res, log_det

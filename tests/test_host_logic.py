@@ -1,0 +1,95 @@
+"""CPU-side tests of the host logic: pdf construction rules, parameter bookkeeping, state_dict compatibility with the reference,
+the C-ABI library exports, and the "no CPU fallback" contract.  No kernel is launched here (no GPU in the build container)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import helpers
+from helpers import ALL_FIXTURES
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SUPPORTED = [fx for fx in ALL_FIXTURES if helpers.product_supports(fx)]
+
+
+def test_library_exports_every_declared_symbol():
+    from jammy_flows_amd import _hip
+    header = open(os.path.join(ROOT, "include", "jammy_hip.h")).read()
+    declared = set(re.findall(r"\bint\s+(jf_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(_hip.exported_symbols()), declared ^ set(_hip.exported_symbols())
+    lib = _hip.lib()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.jf_abi_version() >= 1
+
+
+def test_gf_layer_struct_matches_header():
+    from jammy_flows_amd import _hip
+    # 8 int32 + 4 double, no padding surprises: sizeof must be 8*4 + 4*8
+    assert ctypes.sizeof(_hip.jf_gf_layer) == 64
+
+
+@pytest.mark.parametrize("fx", SUPPORTED, ids=[f.name for f in SUPPORTED])
+def test_construction_matches_reference_bookkeeping(fx):
+    import jammy_flows_amd
+    pdf = jammy_flows_amd.pdf(fx.pdf_defs, fx.flow_defs, **fx.kwargs)
+    assert [[l.total_param_num for l in blk] for blk in pdf.layer_list] == fx.meta["layer_param_nums"]
+    assert [[type(l).__name__ for l in blk] for blk in pdf.layer_list] == fx.meta["layer_types"]
+    assert pdf.total_base_dim == fx.meta["total_base_dim"]
+    assert pdf.total_target_dim == fx.meta["total_target_dim"]
+    assert pdf.total_target_dim_embedded == fx.meta["total_target_dim_embedded"]
+    assert pdf.count_parameters() == fx.meta["count_parameters"]
+    ref_sd = fx.state_dict()
+    sd = pdf.state_dict()
+    assert set(sd.keys()) == set(ref_sd.keys())
+    for k, v in sd.items():
+        assert tuple(v.shape) == tuple(ref_sd[k].shape), k
+    pdf.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in ref_sd.items()}, strict=True)
+
+
+def test_first_layer_rules():
+    """first g layer of a multi-layer e-block -> inormal_partly_precise, last one gets the offset (main/default.py:440-448)."""
+    import jammy_flows_amd
+    pdf = jammy_flows_amd.pdf("e4+e1", "gggg+g", conditional_input_dim=2)
+    types = [l.inverse_function_type for l in pdf.layer_list[0]]
+    assert types == ["inormal_partly_precise", "isigmoid", "isigmoid", "isigmoid"]
+    assert [l.model_offset for l in pdf.layer_list[0]] == [0, 0, 0, 1]
+    assert pdf.layer_list[1][0].model_offset == 1 and pdf.layer_list[1][0].inverse_function_type == "isigmoid"
+    assert pdf.mlp_predictors[1][0].in_features == 2 + 4
+
+
+def test_options_overwrite_precedence():
+    import jammy_flows_amd
+    ow = {"g": {"num_kde": 7}, 1: {"g": {"num_kde": 3}}, (1, 1): {"g": {"num_kde": 4}}}
+    pdf = jammy_flows_amd.pdf("e2+e2", "gg+gg", options_overwrite=ow)
+    assert [[l.num_kde for l in blk] for blk in pdf.layer_list] == [[7, 7], [3, 4]]
+    with pytest.raises(AssertionError):
+        jammy_flows_amd.pdf("e2", "gg", options_overwrite={"g": {"num_kde": -1}})
+    with pytest.raises(AssertionError):
+        jammy_flows_amd.pdf("e2", "gg", options_overwrite={"g": {"no_such_option": 1}})
+
+
+def test_no_cpu_fallback():
+    import jammy_flows_amd
+    from jammy_flows_amd._hip import HipUnavailable
+    pdf = jammy_flows_amd.pdf("e2", "gg").double()
+    with pytest.raises(HipUnavailable):
+        pdf(torch.zeros(4, 2, dtype=torch.float64))
+    with pytest.raises(HipUnavailable):
+        pdf.sample(samplesize=4)
+    layer = pdf.layer_list[0][0]
+    with pytest.raises(HipUnavailable):
+        layer.inv_flow_mapping([torch.zeros(4, 2, dtype=torch.float64), torch.zeros(4, dtype=torch.float64)])
+
+
+def test_unsupported_things_fail_loudly():
+    import jammy_flows_amd
+    with pytest.raises(NotImplementedError):
+        jammy_flows_amd.pdf("e2", "t")
+    with pytest.raises(NotImplementedError):
+        jammy_flows_amd.pdf("e2", "gg", options_overwrite={"g": {"add_skewness": 1}})
+    with pytest.raises(NotImplementedError):
+        jammy_flows_amd.pdf("e2", "gg", predict_log_normalization=True)
