@@ -18,7 +18,7 @@ def product_supports(fx):
 def build_product(fx, dtype, device="cuda"):
     import jammy_flows_amd
     torch.manual_seed(0)
-    pdf = jammy_flows_amd.pdf(fx.pdf_defs, fx.flow_defs, **fx.kwargs)
+    pdf = jammy_flows_amd.pdf(fx.pdf_defs, fx.flow_defs, **fx.kwargs).double()    # load at full precision, cast afterwards
     sd = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in fx.state_dict().items()}
     missing, unexpected = pdf.load_state_dict(sd, strict=True)
     assert not missing and not unexpected
