@@ -91,6 +91,81 @@ int jf_linear_f64(const double* in, int64_t in_stride, const double* W, int64_t 
                   int32_t K, int32_t N, int32_t act, double* out, int64_t out_stride, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * Manifold layers (interval / S1 / S2).  All take / return INTRINSIC coordinates (interval value, angle, (theta, phi));
+ * `first` = the layer also applies the chart to / from the Euclidean base space (euclidean_to_{interval,sphere}_as_first).
+ * A chain = the layers of one sub-manifold block, applied n-1..0 in the log-prob direction and 0..n-1 when sampling;
+ * params row = the layers' rows concatenated in layer order.  `bins` (nullable) receives the raw spline bin index of every
+ * spline call in call order, one int64 column per call (what the reference's spline_fns.searchsorted returns; -2 = not called
+ * for this row), row stride bins_stride.
+ * ------------------------------------------------------------------------------------------------------------ */
+#define JF_MAX_MCHAIN 4
+#define JF_MAX_NESTED 4
+
+/* width / height / derivative bookkeeping shared by 'r' and 'o'
+ * (layers/intervals/rational_quadratic_spline.py:99-178, layers/spheres/splines_1d.py:39-109); row: [w n_w][h n_h][d n_d] */
+typedef struct jf_spline_opts {
+    int32_t num_bins, smooth, fix_first, fix_second, independent, fix_bd, n_w, n_h, n_d, reserved;
+    double fix_bd_value; /* un-softplus'ed value of a fixed boundary derivative */
+    double min_w, min_h, min_d, ratio; /* ratio <= 0: restrict_max_min_width_height_ratio off */
+} jf_spline_opts;
+
+/* 'r' rational-quadratic spline on [lo, hi] (rational_quadratic_spline.py:180-400 + interval_base.py:33-79) */
+typedef struct jf_r_layer { jf_spline_opts sp; double lo, hi; int32_t first, reserved; } jf_r_layer;
+/* 'o' circular spline (splines_1d.py:111-306 + sphere_base.py:601-695); row: [householder hh_iter*2][spline row] */
+typedef struct jf_o_layer { jf_spline_opts sp; int32_t natural_direction, hh_iter, first, reserved; } jf_o_layer;
+/* 'm' Moebius mixture (moebius_1d.py:57-259, bisection_n_newton.py:137-256); row: [householder hh_iter*2][(wx,wy,logit-len,log-w) x nc] */
+typedef struct jf_m_layer { int32_t num_components, natural_direction, hh_iter, first; } jf_m_layer;
+/* 'f' von-Mises-Fisher z-scaling + optional vertical 'r' / circular 'o' flows (fvm_2d.py:273-726);
+ * row: [householder hh_iter*3][log kappa][vertical rows][circular rows] */
+typedef struct jf_f_layer {
+    int32_t hh_iter, first, n_vertical, n_circular;
+    double z_sign, min_kappa, identity_region;
+    jf_r_layer vertical[JF_MAX_NESTED];
+    jf_o_layer circular[JF_MAX_NESTED];
+} jf_f_layer;
+/* 'v' exponential map on S2, float64 only (exponential_map_s2.py:248-528, bisection_n_newton.py:330-465);
+ * row: [householder hh_iter*3][(mu_x,mu_y,mu_z,log-w[,log-beta]) as (n_pot, nc)] */
+enum { JF_V_LINEAR = 0, JF_V_QUADRATIC = 1, JF_V_EXPONENTIAL = 2 };
+typedef struct jf_v_layer { int32_t num_components, exp_map_type, natural_direction, hh_iter, max_newton_iter, first; } jf_v_layer;
+
+/* base-class steps only: optional Householder rotation in embedding space + optional first-layer chart; kind 0 interval, 1 S1, 2 S2
+ * (identity layers 'y' / 'z'; sphere_base.py:601-695 and interval_base.py:61-79 around third-party subclasses); row: [householder] */
+typedef struct jf_c_layer { int32_t kind, hh_iter, first, reserved; double lo, hi; } jf_c_layer;
+
+#define JF_DECLARE_MCHAIN(fam, T, suffix)                                                                                            \
+    int jf_##fam##_chain_inv_##suffix(const T* x, int64_t x_stride, const T* log_det_in, const T* params, int64_t param_stride,        \
+                                      int32_t param_batch, int64_t B, int32_t n_layers, const jf_##fam##_layer* layers, T* x_out,      \
+                                      int64_t x_out_stride, T* log_det_out, const T* base_logp_in, T* base_logp_out, int64_t* bins,    \
+                                      int64_t bins_stride, int32_t* status, void* stream);                                             \
+    int jf_##fam##_chain_fwd_##suffix(const T* x, int64_t x_stride, const T* log_det_in, const T* params, int64_t param_stride,        \
+                                      int32_t param_batch, int64_t B, int32_t n_layers, const jf_##fam##_layer* layers, T* x_out,      \
+                                      int64_t x_out_stride, T* log_det_out, const T* base_logp_in, T* base_logp_out, int64_t* bins,    \
+                                      int64_t bins_stride, int32_t* status, void* stream);
+JF_DECLARE_MCHAIN(r, float, f32)
+JF_DECLARE_MCHAIN(r, double, f64)
+JF_DECLARE_MCHAIN(o, float, f32)
+JF_DECLARE_MCHAIN(o, double, f64)
+JF_DECLARE_MCHAIN(m, float, f32)
+JF_DECLARE_MCHAIN(m, double, f64)
+JF_DECLARE_MCHAIN(f, float, f32)
+JF_DECLARE_MCHAIN(f, double, f64)
+JF_DECLARE_MCHAIN(v, float, f32) /* returns JF_ERR_UNSUPPORTED: the reference asserts float64 (exponential_map_s2.py:450) */
+JF_DECLARE_MCHAIN(v, double, f64)
+JF_DECLARE_MCHAIN(c, float, f32) /* x has 2 columns for kind 2, else 1 */
+JF_DECLARE_MCHAIN(c, double, f64)
+
+/* intrinsic <-> embedding coordinates of S1 (angle <-> (cos, sin)) and S2 ((theta, phi) <-> (x, y, z)) with the log-det of
+ * sphere_base.spherical_to_eucl_embedding / eucl_to_spherical_embedding (sphere_base.py:242-335); dim = 1 or 2 */
+int jf_sphere_to_embedding_f32(const float* x, int64_t x_stride, const float* log_det_in, int64_t B, int32_t dim, float* x_out,
+                               int64_t x_out_stride, float* log_det_out, void* stream);
+int jf_sphere_to_embedding_f64(const double* x, int64_t x_stride, const double* log_det_in, int64_t B, int32_t dim, double* x_out,
+                               int64_t x_out_stride, double* log_det_out, void* stream);
+int jf_sphere_from_embedding_f32(const float* x, int64_t x_stride, const float* log_det_in, int64_t B, int32_t dim, float* x_out,
+                                 int64_t x_out_stride, float* log_det_out, void* stream);
+int jf_sphere_from_embedding_f64(const double* x, int64_t x_stride, const double* log_det_in, int64_t B, int32_t dim, double* x_out,
+                                 int64_t x_out_stride, double* log_det_out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
  * base-distribution log-prob: out[b] = (in ? in[b] : 0) + sum_d N(0,1).log_prob(z[b,d])
  * (torch.distributions.Normal(0,1).log_prob(base_pos).sum(-1), jammy_flows/main/default.py:1110-1115, 1657, 1670)
  * ------------------------------------------------------------------------------------------------------------ */

@@ -34,6 +34,48 @@ class jf_gf_layer(ctypes.Structure):
                 ("norm_max", ctypes.c_double)]
 
 
+class jf_spline_opts(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in ("num_bins", "smooth", "fix_first", "fix_second", "independent", "fix_bd", "n_w", "n_h", "n_d",
+                                               "reserved")] + [(n, ctypes.c_double) for n in ("fix_bd_value", "min_w", "min_h", "min_d", "ratio")]
+
+
+class jf_r_layer(ctypes.Structure):
+    _fields_ = [("sp", jf_spline_opts), ("lo", ctypes.c_double), ("hi", ctypes.c_double), ("first", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
+
+class jf_o_layer(ctypes.Structure):
+    _fields_ = [("sp", jf_spline_opts), ("natural_direction", ctypes.c_int32), ("hh_iter", ctypes.c_int32), ("first", ctypes.c_int32),
+                ("reserved", ctypes.c_int32)]
+
+
+class jf_m_layer(ctypes.Structure):
+    _fields_ = [("num_components", ctypes.c_int32), ("natural_direction", ctypes.c_int32), ("hh_iter", ctypes.c_int32), ("first", ctypes.c_int32)]
+
+
+JF_MAX_MCHAIN = 4
+JF_MAX_NESTED = 4
+
+
+class jf_f_layer(ctypes.Structure):
+    _fields_ = [("hh_iter", ctypes.c_int32), ("first", ctypes.c_int32), ("n_vertical", ctypes.c_int32), ("n_circular", ctypes.c_int32),
+                ("z_sign", ctypes.c_double), ("min_kappa", ctypes.c_double), ("identity_region", ctypes.c_double),
+                ("vertical", jf_r_layer * JF_MAX_NESTED), ("circular", jf_o_layer * JF_MAX_NESTED)]
+
+
+V_KINDS = {"linear": 0, "quadratic": 1, "exponential": 2}
+
+
+class jf_v_layer(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in ("num_components", "exp_map_type", "natural_direction", "hh_iter", "max_newton_iter", "first")]
+
+
+class jf_c_layer(ctypes.Structure):
+    _fields_ = [("kind", ctypes.c_int32), ("hh_iter", ctypes.c_int32), ("first", ctypes.c_int32), ("reserved", ctypes.c_int32),
+                ("lo", ctypes.c_double), ("hi", ctypes.c_double)]
+
+
+MCHAIN_LAYER_TYPES = {"r": jf_r_layer, "o": jf_o_layer, "m": jf_m_layer, "f": jf_f_layer, "v": jf_v_layer, "c": jf_c_layer}
+
 _lib = None
 
 _P = ctypes.c_void_p
@@ -46,7 +88,13 @@ _SIGNATURES = {
     "jf_gf_chain_fwd": [_P, _I64, _P, _P, _I64, _I32, _I64, _I32, _I32, ctypes.POINTER(jf_gf_layer), _P, _I64, _P, _P, _P],
     "jf_linear": [_P, _I64, _P, _I64, _P, _I64, _I32, _I32, _I32, _P, _I64, _P],
     "jf_normal_logp": [_P, _I64, _I64, _I32, _P, _P, _P],
+    "jf_sphere_to_embedding": [_P, _I64, _P, _I64, _I32, _P, _I64, _P, _P],
+    "jf_sphere_from_embedding": [_P, _I64, _P, _I64, _I32, _P, _I64, _P, _P],
 }
+for _fam, _cls in MCHAIN_LAYER_TYPES.items():
+    for _d in ("inv", "fwd"):
+        _SIGNATURES["jf_%s_chain_%s" % (_fam, _d)] = [_P, _I64, _P, _P, _I64, _I32, _I64, _I32, ctypes.POINTER(_cls), _P, _I64, _P, _P, _P, _P,
+                                                      _I64, _P, _P]
 
 
 def exported_symbols():
@@ -208,3 +256,60 @@ def normal_logp(z, acc=None):
     rc = getattr(lib(), "jf_normal_logp" + suf)(_ptr(z), z.stride(0), B, D, _ptr(acc), _ptr(out), _stream())
     _check(rc, "jf_normal_logp" + suf)
     return out
+
+
+def mchain(fam, direction, x, log_det, params, layer_structs, dim, x_out=None, base_logp_in=None, want_base_logp=False, bins=None, status=None):
+    """run a chain of manifold layers of family `fam` ('r','o','m','f','v','c') on intrinsic coordinates.
+    x (B, dim) view; params (1|B, P) or None when the chain has no parameters.  Returns (x_out, log_det_out[, base_logp])."""
+    require_device(x, log_det, params, x_out, base_logp_in, status, bins)
+    x = _rowmajor(x)
+    B = x.shape[0]
+    if x.shape[1] != dim:
+        raise ValueError("expected %d target columns, got %d" % (dim, x.shape[1]))
+    pb = 1
+    if params is not None and params.shape[1] > 0:
+        params = _rowmajor(params)
+        if params.dtype != x.dtype:
+            raise TypeError("parameter dtype %s != input dtype %s" % (params.dtype, x.dtype))
+        if params.shape[0] not in (1, B):
+            raise ValueError("extra_inputs must have 1 or B=%d rows, got %d" % (B, params.shape[0]))
+        pb = 1 if params.shape[0] == 1 else B
+        pptr, pstride = _ptr(params), params.stride(0)
+    else:
+        pptr, pstride = None, 0
+    if log_det is not None:
+        log_det = log_det.contiguous()
+        if log_det.dtype != x.dtype or log_det.shape[0] != B:
+            raise ValueError("log_det must be a (B,) tensor of the input dtype")
+    if x_out is None:
+        x_out = torch.empty((B, dim), dtype=x.dtype, device=x.device)
+    ld_out = torch.empty((B,), dtype=x.dtype, device=x.device)
+    blp_out = torch.empty((B,), dtype=x.dtype, device=x.device) if want_base_logp else None
+    n = len(layer_structs)
+    arr = (MCHAIN_LAYER_TYPES[fam] * n)(*layer_structs)
+    suf = _suffix(x)
+    name = "jf_%s_chain_%s%s" % (fam, direction, suf)
+    if bins is not None:
+        assert bins.dtype == torch.int64 and bins.dim() == 2 and bins.shape[0] == B and bins.stride(1) == 1
+    rc = getattr(lib(), name)(_ptr(x), x.stride(0), _ptr(log_det), pptr, pstride, pb, B, n, arr, _ptr(x_out), x_out.stride(0), _ptr(ld_out),
+                              _ptr(base_logp_in), _ptr(blp_out), _ptr(bins), bins.stride(0) if bins is not None else 0, _ptr(status), _stream())
+    _check(rc, name)
+    return (x_out, ld_out, blp_out) if want_base_logp else (x_out, ld_out)
+
+
+def sphere_embedding(x, log_det, dim, to_embedding):
+    """S1: angle <-> (cos, sin); S2: (theta, phi) <-> (x, y, z), with the log-det bookkeeping of sphere_base.py:242-335."""
+    require_device(x, log_det if isinstance(log_det, torch.Tensor) else None)
+    x = _rowmajor(x)
+    B = x.shape[0]
+    ld_in = log_det if isinstance(log_det, torch.Tensor) else None
+    if ld_in is not None:
+        ld_in = ld_in.contiguous()
+    out = torch.empty((B, dim + 1 if to_embedding else dim), dtype=x.dtype, device=x.device)
+    want_ld = isinstance(log_det, torch.Tensor) and dim == 2
+    ld_out = torch.empty((B,), dtype=x.dtype, device=x.device) if want_ld else None
+    suf = _suffix(x)
+    name = ("jf_sphere_to_embedding" if to_embedding else "jf_sphere_from_embedding") + suf
+    rc = getattr(lib(), name)(_ptr(x), x.stride(0), _ptr(ld_in), B, dim, _ptr(out), out.stride(0), _ptr(ld_out), _stream())
+    _check(rc, name)
+    return out, (ld_out if want_ld else log_det)

@@ -1,0 +1,334 @@
+// Lane-per-sample device code of the manifold flow layers:
+//   'r'  jammy_flows/layers/intervals/rational_quadratic_spline.py:180-400  (+ interval_base.py:61-79)
+//   'o'  jammy_flows/layers/spheres/splines_1d.py:111-306
+//   'm'  jammy_flows/layers/spheres/moebius_1d.py:57-259  (+ layers/bisection_n_newton.py:137-256)
+//   'f'  jammy_flows/layers/spheres/fvm_2d.py:273-726
+//   'v'  jammy_flows/layers/spheres/exponential_map_s2.py:153-528  (+ layers/bisection_n_newton.py:330-465)
+// wrapped by the sphere_base rotation / chart steps (jammy_flows/layers/spheres/sphere_base.py:601-695).
+// Every family exposes  apply<FWD>(layer, row, x[3], log_det, ctx)  on INTRINSIC coordinates.
+#pragma once
+#include "jf_sphere.h"
+#include "jf_spline.h"
+
+namespace jf {
+
+template <typename T> struct LaneCtx {
+    T* tab;              // lane-private LDS scratch (JF_SPLINE_TAB elements)
+    int64_t* bins;       // this row's bin slots (nullable)
+    int bin_i;
+    bool oob, nonconv, nonfinite;
+    bool lane_valid;
+    __device__ __forceinline__ void put_bin(int b) {
+        if (bins) bins[bin_i] = (int64_t)b;
+        ++bin_i;
+    }
+};
+
+template <typename T> __device__ __forceinline__ SplineDev<T> to_dev(const jf_spline_opts& s) {
+    SplineDev<T> o;
+    o.nb = s.num_bins; o.smooth = s.smooth; o.fix_first = s.fix_first; o.fix_second = s.fix_second; o.independent = s.independent;
+    o.fix_bd = s.fix_bd; o.n_w = s.n_w; o.n_h = s.n_h; o.n_d = s.n_d;
+    o.fix_bd_value = (T)s.fix_bd_value; o.min_w = (T)s.min_w; o.min_h = (T)s.min_h; o.min_d = (T)s.min_d; o.ratio = (T)s.ratio;
+    return o;
+}
+__host__ __device__ inline int spline_row_len(const jf_spline_opts& s) { return s.n_w + s.n_h + s.n_d; }
+
+// =================================================================================================  'r'
+template <typename T> __device__ __forceinline__ T r_core(const jf_r_layer& L, const T* __restrict__ p, T x, T& ld, LaneCtx<T>& c, bool inverse) {
+    x = x > T(1) ? T(1) : (x < T(-1) ? T(-1) : x);                         // rational_quadratic_spline.py:185-186, 295-296
+    bool oob;
+    const SplineDev<T> o = to_dev<T>(L.sp);
+    const SplineOut<T> r = spline_interval<T>(p, o, c.tab, x, inverse, (T)L.lo, (T)L.hi, oob);
+    c.oob = c.oob || oob;
+    c.put_bin(r.bin);
+    ld += r.lad;
+    return r.y > T(1) ? T(1) : (r.y < T(-1) ? T(-1) : r.y);
+}
+struct RFam {
+    using CLayer = jf_r_layer;
+    static constexpr int DIM = 1;
+    static __host__ int row_len(const CLayer& L) { return spline_row_len(L.sp); }
+    static __host__ int n_bins(const CLayer&) { return 1; }
+    template <typename T, bool FWD> static __device__ __forceinline__ void apply(const CLayer& L, const T* __restrict__ p, T (&x)[3], T& ld, LaneCtx<T>& c) {
+        if constexpr (FWD) {
+            if (L.first) x[0] = real_line_to_interval<T>(x[0], (T)L.lo, (T)L.hi, ld);        // interval_base.py:71-79
+            x[0] = r_core<T>(L, p, x[0], ld, c, false);
+        } else {
+            x[0] = r_core<T>(L, p, x[0], ld, c, true);
+            if (L.first) x[0] = interval_to_real_line<T>(x[0], (T)L.lo, (T)L.hi, ld);        // interval_base.py:61-69
+        }
+    }
+};
+
+// =================================================================================================  S1 helpers
+template <typename T> __device__ __forceinline__ T s1_rotate(const T* __restrict__ vs, int hh, T phi, bool transpose) {
+    T e[3];
+    s1_to_eucl<T>(phi, e);
+    rotate_embed<T, 2>(vs, hh, e, transpose);
+    return eucl_to_s1<T>(e);
+}
+
+template <typename T> __device__ __forceinline__ void s2_rotate(const T* __restrict__ vs, int hh, T (&x)[3], T& ld, bool transpose) {
+    T e[3];
+    s2_to_eucl<T>(x[0], x[1], e, ld);
+    rotate_embed<T, 3>(vs, hh, e, transpose);
+    eucl_to_s2<T>(e, x[0], x[1], ld);
+}
+
+// =================================================================================================  'o'
+template <typename T> __device__ __forceinline__ T o_core(const jf_o_layer& L, const T* __restrict__ p, T x, T& ld, LaneCtx<T>& c, bool fwd, T scale) {
+    // splines_1d.py:119-120/198-199 (inverse: safe clamp) vs :219-221/298-300 (forward: hard clip)
+    if (fwd) x = x >= M<T>::TWO_PI ? M<T>::TWO_PI : (x < T(0) ? T(0) : x);
+    else x = safe_angle_2pi<T>(x);
+    const bool use_inverse = fwd ? (L.natural_direction == 0) : (L.natural_direction != 0);
+    bool oob;
+    const SplineDev<T> o = to_dev<T>(L.sp);
+    const SplineOut<T> r = spline_circular<T>(p, o, c.tab, x, use_inverse, scale, oob);
+    c.oob = c.oob || oob;
+    c.put_bin(r.bin);
+    ld += r.lad;
+    if (fwd) return r.y >= M<T>::TWO_PI ? M<T>::TWO_PI : (r.y < T(0) ? T(0) : r.y);
+    return safe_angle_2pi<T>(r.y);
+}
+struct OFam {
+    using CLayer = jf_o_layer;
+    static constexpr int DIM = 1;
+    static __host__ int row_len(const CLayer& L) { return 2 * L.hh_iter + spline_row_len(L.sp); }
+    static __host__ int n_bins(const CLayer&) { return 1; }
+    template <typename T, bool FWD> static __device__ __forceinline__ void apply(const CLayer& L, const T* __restrict__ p, T (&x)[3], T& ld, LaneCtx<T>& c) {
+        const T* sp = p + 2 * L.hh_iter;
+        if constexpr (FWD) {
+            if (L.first) x[0] = plane_to_s1<T>(x[0], ld);
+            x[0] = o_core<T>(L, sp, x[0], ld, c, true, T(1));
+            if (L.hh_iter > 0) x[0] = s1_rotate<T>(p, L.hh_iter, x[0], false);
+        } else {
+            if (L.hh_iter > 0) x[0] = s1_rotate<T>(p, L.hh_iter, x[0], true);
+            x[0] = o_core<T>(L, sp, x[0], ld, c, false, T(1));
+            if (L.first) x[0] = s1_to_plane<T>(x[0], ld);
+        }
+    }
+};
+
+// =================================================================================================  'm'
+// moebius_1d.py:140-259.  x in [-pi, pi].  value: sum_k pi_k * arg(Moebius_k(e^{ix})) normalised so that -pi -> -pi; deriv: sum_k pi_k (1-|w|^2)/|e^{ix}-w|^2
+template <typename T> __device__ inline void moebius_eval(const T* __restrict__ p, int nc, T x, T& val, T& deriv) {
+    const T cx = M<T>::cos(x), sx = M<T>::sin(x);
+    const T cmp = T(-1), smp = (T)(-1.2246467991473532e-16);          // numpy.cos(-pi), numpy.sin(-pi)
+    T lmax = p[3];
+    for (int k = 1; k < nc; ++k) lmax = M<T>::max(lmax, p[4 * k + 3]);
+    T wsum = T(0), vsum = T(0), dsum = T(0);
+    for (int k = 0; k < nc; ++k) {
+        const T* q = p + 4 * k;
+        const T denom = logaddexp<T>(T(0), -q[2]);
+        const T len = T(0.001) + M<T>::exp(T(-0.0020020026706730793) - denom);      // ln(0.999 - 0.001)
+        const T nrm = len / M<T>::sqrt(q[0] * q[0] + q[1] * q[1]);
+        const T ox = q[0] * nrm, oy = q[1] * nrm;
+        const T omo = T(1) - len * len;
+        const T opo = T(1) + len * len - T(2) * (cx * ox + sx * oy);
+        const T opo_mp = T(1) + len * len - T(2) * (cmp * ox + smp * oy);
+        const T y_mp = omo * (smp - oy) - oy * opo_mp;
+        const T x_mp = omo * (cmp - ox) - ox * opo_mp;
+        const T rot = -M<T>::PI - M<T>::atan2(y_mp, x_mp);
+        const T yv = omo * (sx - oy) - oy * opo;
+        const T xv = omo * (cx - ox) - ox * opo;
+        const T cr = M<T>::cos(rot), sr = M<T>::sin(rot);
+        const T arc = M<T>::atan2(sr * xv + cr * yv, cr * xv - sr * yv) + M<T>::PI;
+        const T w = M<T>::exp(q[3] - lmax);
+        wsum += w;
+        vsum += w * arc;
+        dsum += w * (omo / opo);
+    }
+    val = vsum / wsum - M<T>::PI;
+    deriv = dsum / wsum;
+}
+template <typename T> __device__ inline T moebius_solve(const T* __restrict__ p, int nc, T z, LaneCtx<T>& c) {
+    T lo = -M<T>::PI, hi = M<T>::PI, x = T(0), f, d;
+    for (int it = 0; it < 20; ++it) {                                     // bisection_n_newton.py:171-182
+        x = (hi + lo) * T(0.5);
+        moebius_eval<T>(p, nc, x, f, d);
+        if (M<T>::abs(f - z) <= T(1e-6) * M<T>::abs(z)) { lo = x; hi = x; }
+        else if (f < z) lo = x;
+        else hi = x;
+    }
+    bool active = c.lane_valid;
+    T ferr = T(0);
+    for (int it = 0; it < 20 && __any(active); ++it) {                    // :192-238
+        moebius_eval<T>(p, nc, x, f, d);
+        if (active) {
+            const T upd = (f - z) / d;
+            x -= upd;
+            ferr = M<T>::abs(f - z);
+            active = M<T>::abs(upd) >= T(1e-14);
+        }
+    }
+    c.nonconv = c.nonconv || (ferr > (sizeof(T) == 8 ? T(1e-7) : T(1e-4)));
+    c.nonfinite = c.nonfinite || !M<T>::finite(x);
+    return x;
+}
+struct MFam {
+    using CLayer = jf_m_layer;
+    static constexpr int DIM = 1;
+    static __host__ int row_len(const CLayer& L) { return 2 * L.hh_iter + 4 * L.num_components; }
+    static __host__ int n_bins(const CLayer&) { return 0; }
+    template <typename T> static __device__ __forceinline__ T core(const CLayer& L, const T* __restrict__ mp, T x, T& ld, LaneCtx<T>& c, bool direct) {
+        x = x > M<T>::PI ? x - M<T>::TWO_PI : x;                           // moebius_1d.py:73-74
+        T val, d;
+        if (direct) {
+            moebius_eval<T>(mp, L.num_components, x, val, d);
+            ld += M<T>::log(d);
+            x = val;
+        } else {
+            x = moebius_solve<T>(mp, L.num_components, x, c);
+            moebius_eval<T>(mp, L.num_components, x, val, d);
+            ld -= M<T>::log(d);
+        }
+        return x < T(0) ? M<T>::TWO_PI + x : x;
+    }
+    template <typename T, bool FWD> static __device__ __forceinline__ void apply(const CLayer& L, const T* __restrict__ p, T (&x)[3], T& ld, LaneCtx<T>& c) {
+        const T* mp = p + 2 * L.hh_iter;
+        if constexpr (FWD) {
+            if (L.first) x[0] = plane_to_s1<T>(x[0], ld);
+            x[0] = core<T>(L, mp, x[0], ld, c, L.natural_direction != 0);
+            if (L.hh_iter > 0) x[0] = s1_rotate<T>(p, L.hh_iter, x[0], false);
+        } else {
+            if (L.hh_iter > 0) x[0] = s1_rotate<T>(p, L.hh_iter, x[0], true);
+            x[0] = core<T>(L, mp, x[0], ld, c, L.natural_direction == 0);
+            if (L.first) x[0] = s1_to_plane<T>(x[0], ld);
+        }
+    }
+};
+
+// =================================================================================================  base-class steps only
+// rotation (sphere_base.py:607-624 / 678-693) and / or the first-layer chart (interval_base.py:61-79, sphere_base.py:641-667): the identity
+// layers 'y' / 'z' and the generic sphere_base / interval_base wrappers around third-party subclasses.
+struct CFam {
+    using CLayer = jf_c_layer;
+    static constexpr int DIM = 2;      // interval / S1 use column 0 only (the host passes dim)
+    static __host__ int row_len(const CLayer& L) { return L.hh_iter * (L.kind == 2 ? 3 : 2); }
+    static __host__ int n_bins(const CLayer&) { return 0; }
+    template <typename T, bool FWD> static __device__ __forceinline__ void apply(const CLayer& L, const T* __restrict__ p, T (&x)[3], T& ld, LaneCtx<T>& c) {
+        if constexpr (FWD) {
+            if (L.first) {
+                if (L.kind == 0) x[0] = real_line_to_interval<T>(x[0], (T)L.lo, (T)L.hi, ld);
+                else if (L.kind == 1) x[0] = plane_to_s1<T>(x[0], ld);
+                else { T pl[3] = {x[0], x[1], T(0)}; plane_to_s2<T>(pl, x[0], x[1], ld); }
+            }
+            if (L.hh_iter > 0) {
+                if (L.kind == 1) x[0] = s1_rotate<T>(p, L.hh_iter, x[0], false);
+                else if (L.kind == 2) s2_rotate<T>(p, L.hh_iter, x, ld, false);
+            }
+        } else {
+            if (L.hh_iter > 0) {
+                if (L.kind == 1) x[0] = s1_rotate<T>(p, L.hh_iter, x[0], true);
+                else if (L.kind == 2) s2_rotate<T>(p, L.hh_iter, x, ld, true);
+            }
+            if (L.first) {
+                if (L.kind == 0) x[0] = interval_to_real_line<T>(x[0], (T)L.lo, (T)L.hi, ld);
+                else if (L.kind == 1) x[0] = s1_to_plane<T>(x[0], ld);
+                else { T pl[3]; s2_to_plane<T>(x[0], x[1], pl, ld); x[0] = pl[0]; x[1] = pl[1]; }
+            }
+        }
+    }
+};
+
+// =================================================================================================  'f'
+template <typename T> __device__ __forceinline__ T azimuthal_scaling(T c) {     // fvm_2d.py:267-271
+    const T c3 = c * c * c, c4 = c3 * c, c5 = c4 * c;
+    return c <= T(0) ? T(6) * c5 + T(15) * c4 + T(10) * c3 + T(1) : T(-6) * c5 + T(15) * c4 - T(10) * c3 + T(1);
+}
+struct FFam {
+    using CLayer = jf_f_layer;
+    static constexpr int DIM = 2;
+    static __host__ int row_len(const CLayer& L) {
+        int n = 3 * L.hh_iter + 1;
+        for (int i = 0; i < L.n_vertical; ++i) n += spline_row_len(L.vertical[i].sp);
+        for (int i = 0; i < L.n_circular; ++i) n += spline_row_len(L.circular[i].sp);
+        return n;
+    }
+    static __host__ int n_bins(const CLayer& L) { return L.n_vertical + L.n_circular; }
+
+    template <typename T, bool FWD> static __device__ __forceinline__ void apply(const CLayer& L, const T* __restrict__ p, T (&x)[3], T& ld, LaneCtx<T>& c) {
+        const T* fp = p + 3 * L.hh_iter;
+        const T zs = (T)L.z_sign, region = (T)L.identity_region;
+        const T kappa = M<T>::exp(fp[0]) + (T)L.min_kappa;                                   // fvm_2d.py:123
+        int nv = 0;
+        for (int i = 0; i < L.n_vertical; ++i) nv += spline_row_len(L.vertical[i].sp);
+        const T* vert = fp + 1;
+        const T* circ = vert + nv;
+        if constexpr (!FWD) {
+            if (L.hh_iter > 0) s2_rotate<T>(p, L.hh_iter, x, ld, true);
+            const T prev = M<T>::cos(x[0]);
+            ld += M<T>::log(M<T>::sin(safe_angle_pi<T>(x[0])));
+            const T e2k = M<T>::exp(T(-2) * kappa);
+            const T safe = kappa < T(100) ? M<T>::log(M<T>::exp(T(2) * kappa) - T(1)) : T(2) * kappa;      // :352-357
+            ld += M<T>::log(T(2) * kappa) + kappa * (zs * prev + T(1)) - safe;
+            T ret = zs * ((T(1) + e2k - T(2) * M<T>::exp(kappa * (zs * prev - T(1)))) / (T(-1) + e2k));       // :361
+            if (kappa < M<T>::KAPPA_ID) ret = prev;
+            ret = safe_cos<T>(ret, M<T>::EPS_COS);
+            T angle = x[1];
+            const bool inside = (region == T(0)) || ((ret > T(-1) + region) && (ret < T(1) - region));
+            if (L.n_circular > 0) {                                                         // :416-427 (layers in reverse, tail-first)
+                const T sc = azimuthal_scaling<T>(ret);
+                int off = 0;
+                for (int i = 0; i < L.n_circular; ++i) off += spline_row_len(L.circular[i].sp);
+                for (int i = L.n_circular - 1; i >= 0; --i) {
+                    off -= spline_row_len(L.circular[i].sp);
+                    if (inside) angle = o_core<T>(L.circular[i], circ + off, angle, ld, c, false, sc);
+                    else c.put_bin(-2);
+                }
+            }
+            if (L.n_vertical > 0) {                                                         // :430-432
+                int off = nv;
+                for (int i = L.n_vertical - 1; i >= 0; --i) {
+                    off -= spline_row_len(L.vertical[i].sp);
+                    if (inside) ret = r_core<T>(L.vertical[i], vert + off, ret, ld, c, true);
+                    else c.put_bin(-2);
+                }
+            }
+            ret = safe_cos<T>(ret, M<T>::EPS_COS);
+            const T th = M<T>::acos(ret);
+            ld -= M<T>::log(M<T>::sin(safe_angle_pi<T>(th)));
+            if (L.first) {
+                T pl[3];
+                s2_to_plane<T>(th, angle, pl, ld);
+                x[0] = pl[0]; x[1] = pl[1];
+            } else { x[0] = th; x[1] = angle; }
+        } else {
+            if (L.first) {
+                T pl[3] = {x[0], x[1], T(0)};
+                plane_to_s2<T>(pl, x[0], x[1], ld);
+            }
+            T prev = M<T>::cos(x[0]);
+            ld += M<T>::log(M<T>::sin(safe_angle_pi<T>(x[0])));
+            T angle = x[1];
+            const bool inside = (region == T(0)) || ((prev > T(-1) + region) && (prev < T(1) - region));
+            if (L.n_vertical > 0) {                                                         // :591-592 (layers in order, head-first)
+                int off = 0;
+                for (int i = 0; i < L.n_vertical; ++i) {
+                    if (inside) prev = r_core<T>(L.vertical[i], vert + off, prev, ld, c, false);
+                    else c.put_bin(-2);
+                    off += spline_row_len(L.vertical[i].sp);
+                }
+            }
+            if (L.n_circular > 0) {                                                         // :596-607
+                const T sc = azimuthal_scaling<T>(prev);
+                int off = 0;
+                for (int i = 0; i < L.n_circular; ++i) {
+                    if (inside) angle = o_core<T>(L.circular[i], circ + off, angle, ld, c, true, sc);
+                    else c.put_bin(-2);
+                    off += spline_row_len(L.circular[i].sp);
+                }
+            }
+            ld -= M<T>::log(kappa * zs * prev + kappa / M<T>::tanh(kappa));                   // :698
+            T ret = zs * (T(1) + (T(1) / kappa) * M<T>::log(T(0.5) * (T(1) + zs * prev) + (T(0.5) - T(0.5) * zs * prev) * M<T>::exp(T(-2) * kappa)));
+            if (kappa < M<T>::KAPPA_ID) ret = prev;
+            ret = safe_cos<T>(ret, M<T>::EPS_COS);
+            x[0] = M<T>::acos(ret);
+            ld -= M<T>::log(M<T>::sin(safe_angle_pi<T>(x[0])));
+            x[1] = angle;
+            if (L.hh_iter > 0) s2_rotate<T>(p, L.hh_iter, x, ld, false);
+        }
+    }
+};
+
+}  // namespace jf

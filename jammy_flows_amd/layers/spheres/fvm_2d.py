@@ -1,0 +1,157 @@
+"""von-Mises-Fisher scaling layer 'f' on S2 with optional vertical ('r...') and azimuthal ('o...') spline flows -- host side
+(jammy_flows/layers/spheres/fvm_2d.py:28-824).  This is the "2-sphere autoregressive spline" layer (legacy letter 'n').
+
+Where the reference embeds nested ``pdf`` objects as passthrough flows (:193-197, 221-225) this implementation flattens them at
+construction into the jf_f_layer descriptor; the whole layer (rotation, kappa map, nested splines, S2 <-> R2 chart) is ONE launch of
+the 'f' HIP kernel (jf_f_chain_*).  The correlated variant (per-sample amortised MLP between the two spline flows) has no kernel yet.
+"""
+import torch
+from torch import nn
+
+from . import sphere_base
+from .splines_1d import spline_1d
+from ..intervals.rational_quadratic_spline import rational_quadratic_spline
+from ... import _hip
+
+
+class fisher_von_mises_2d(sphere_base.sphere_base):
+    FAMILY = "f"
+
+    def __init__(self, dimension, euclidean_to_sphere_as_first=False, use_permanent_parameters=False, fisher_parametrization="split",
+                 add_vertical_rq_spline_flow=0, add_circular_rq_spline_flow=0, vertical_flow_defs="r", circular_flow_defs="o",
+                 add_correlated_rq_spline_flow=0, correlated_max_rank=3, inverse_z_scaling=1, spline_num_basis_functions=5,
+                 boundary_cos_theta_identity_region=0.0, vertical_smooth=0, vertical_restrict_max_min_width_height_ratio=-1.0,
+                 vertical_fix_boundary_derivative=1, vertical_fix_first_width_n_height_to_zero=0, vertical_also_fix_second_width_to_zero=0,
+                 vertical_independent_width_height_parametrization=0, circular_add_rotation=1, min_kappa=1e-10,
+                 kappa_prediction="direct_log_real_bounded", add_extra_rotation_inbetween=0, kappa_clamping=0, add_rotation=1,
+                 rotation_mode="householder", num_householder_iter=-1):
+        """Symbol "f".  Parameters as in the reference (:58-80)."""
+        super().__init__(dimension=dimension, euclidean_to_sphere_as_first=euclidean_to_sphere_as_first,
+                         use_permanent_parameters=use_permanent_parameters, add_rotation=add_rotation,
+                         num_householder_iter=num_householder_iter, rotation_mode=rotation_mode)
+        if dimension != 2:
+            raise Exception("2-D Flow")
+        assert fisher_parametrization == "split"
+        unsupported = []
+        if kappa_prediction != "direct_log_real_bounded":
+            unsupported.append("kappa_prediction=%s" % kappa_prediction)
+        if kappa_clamping:
+            unsupported.append("kappa_clamping=1")
+        if add_extra_rotation_inbetween:
+            unsupported.append("add_extra_rotation_inbetween=1")
+        if add_correlated_rq_spline_flow:
+            unsupported.append("add_correlated_rq_spline_flow=1")
+        if unsupported:
+            raise NotImplementedError("f layer option(s) without a HIP kernel yet: %s" % ", ".join(unsupported))
+        self.z_scaling_factor = -1.0 if inverse_z_scaling else 1.0
+        self.min_kappa = min_kappa
+        self.kappa_prediction = kappa_prediction
+        self.kappa_fn = True      # (kappa is predicted from its own parameter; see sphere_base.get_desired_init_parameters)
+        self.num_loglike_kappa_params = 1
+        if use_permanent_parameters:
+            self.loglike_kappa = nn.Parameter(torch.randn(1).unsqueeze(0))
+        self.total_param_num += 1
+        self.add_vertical_rq_spline_flow = add_vertical_rq_spline_flow
+        self.add_circular_rq_spline_flow = add_circular_rq_spline_flow
+        self.add_correlated_rq_spline_flow = 0
+        self.boundary_cos_theta_identity_region = boundary_cos_theta_identity_region
+        self.spline_num_basis_functions = spline_num_basis_functions
+        if spline_num_basis_functions == -1:
+            assert vertical_smooth == 1, "num_basis_functions=-1 means alternating 2/3 as basis functions and requires smooth splines."
+
+        # nested flows, flattened (the reference builds passthrough pdfs "i1_-b_b : r.." and "s1 : o.." here, :157-241)
+        self._vertical, self._circular = [], []
+        bound = float("%.2f" % (1.0 - boundary_cos_theta_identity_region))
+        self.total_num_vertical_params = 0
+        if add_vertical_rq_spline_flow:
+            for i, letter in enumerate(vertical_flow_defs):
+                assert letter == "r", "vertical flows must be 'r' layers"
+                nb = spline_num_basis_functions if spline_num_basis_functions != -1 else (3 if i % 2 == 1 else 2)
+                self._vertical.append(rational_quadratic_spline(
+                    1, num_basis_functions=nb, euclidean_to_interval_as_first=0, use_permanent_parameters=0, low_boundary=-bound,
+                    high_boundary=bound, fix_boundary_derivatives=-1.0 if vertical_fix_boundary_derivative == 0 else 1.0,
+                    smooth_second_derivative=vertical_smooth, restrict_max_min_width_height_ratio=vertical_restrict_max_min_width_height_ratio,
+                    fix_first_width_n_height_to_zero=vertical_fix_first_width_n_height_to_zero,
+                    also_fix_second_width_to_zero=vertical_also_fix_second_width_to_zero,
+                    independent_width_height_parametrization=vertical_independent_width_height_parametrization))
+            self.total_num_vertical_params = sum(l.total_param_num for l in self._vertical)
+            self.total_param_num += self.total_num_vertical_params
+            if use_permanent_parameters:
+                self.vertical_flow_params = nn.Parameter(torch.randn(1, self.total_num_vertical_params))
+        self.total_num_circular_params = 0
+        self.circular_add_rotation = circular_add_rotation
+        if add_circular_rq_spline_flow:
+            assert circular_add_rotation == 0, "Currently not allowing additional S-1 rotations due to potential complications at the poles."
+            for letter in circular_flow_defs:
+                assert letter == "o", "circular flows must be 'o' layers"
+                self._circular.append(spline_1d(
+                    1, euclidean_to_sphere_as_first=0, add_rotation=0, use_permanent_parameters=0, num_basis_functions=2, smooth_second_derivative=1,
+                    fix_first_width_n_height_to_zero=vertical_fix_first_width_n_height_to_zero,
+                    also_fix_second_width_to_zero=vertical_also_fix_second_width_to_zero,
+                    independent_width_height_parametrization=vertical_independent_width_height_parametrization))
+            self.total_num_circular_params = sum(l.total_param_num for l in self._circular)
+            self.total_param_num += self.total_num_circular_params
+            if use_permanent_parameters:
+                self.circular_flow_params = nn.Parameter(torch.randn(1, self.total_num_circular_params))
+        if len(self._vertical) > _hip.JF_MAX_NESTED or len(self._circular) > _hip.JF_MAX_NESTED:
+            raise NotImplementedError("at most %d nested vertical / circular layers are supported by the kernel" % _hip.JF_MAX_NESTED)
+        self.total_num_correlated_params = 0
+        self.add_extra_rotation_inbetween = 0
+
+    def c_struct(self, first):
+        L = _hip.jf_f_layer()
+        L.hh_iter = self.num_householder_iter
+        L.first = int(first)
+        L.n_vertical = len(self._vertical)
+        L.n_circular = len(self._circular)
+        L.z_sign = float(self.z_scaling_factor)
+        L.min_kappa = float(self.min_kappa)
+        L.identity_region = float(self.boundary_cos_theta_identity_region)
+        for i, l in enumerate(self._vertical):
+            L.vertical[i] = l.c_struct(0)
+        for i, l in enumerate(self._circular):
+            L.circular[i] = l.c_struct(0)
+        return L
+
+    def n_spline_calls(self):
+        return len(self._vertical) + len(self._circular)
+
+    def _layer_tensors(self):
+        ts = [self.loglike_kappa]
+        if self.add_vertical_rq_spline_flow:
+            ts.append(self.vertical_flow_params)
+        if self.add_circular_rq_spline_flow:
+            ts.append(self.circular_flow_params)
+        return ts
+
+    def _init_params(self, params):
+        self.loglike_kappa.data = params[:1].reshape(1, 1)
+        assert len(params) == 1 + self.total_num_vertical_params + self.total_num_circular_params
+        c = 1
+        if self.add_vertical_rq_spline_flow:
+            self.vertical_flow_params.data = params[c:c + self.total_num_vertical_params].reshape(1, -1)
+            c += self.total_num_vertical_params
+        if self.add_circular_rq_spline_flow:
+            self.circular_flow_params.data = params[c:c + self.total_num_circular_params].reshape(1, -1)
+
+    def _get_desired_init_parameters(self):
+        parts = [torch.randn(1) - 3.0]                                   # log kappa (:750)
+        parts += [l.get_desired_init_parameters() for l in self._vertical]
+        parts += [l.get_desired_init_parameters() for l in self._circular]
+        return torch.cat(parts)
+
+    def _obtain_layer_param_structure(self, param_dict, extra_inputs=None, previous_x=None, extra_prefix=""):
+        if extra_inputs is not None:
+            param_dict[extra_prefix + "loglike_kappa"] = extra_inputs[:, :1].data
+            c = 1
+            if self.add_vertical_rq_spline_flow:
+                param_dict[extra_prefix + "vertical_params"] = extra_inputs[:, c:c + self.total_num_vertical_params].data
+                c += self.total_num_vertical_params
+            if self.add_circular_rq_spline_flow:
+                param_dict[extra_prefix + "circular_params"] = extra_inputs[:, c:c + self.total_num_circular_params].data
+        else:
+            param_dict[extra_prefix + "loglike_kappa"] = self.loglike_kappa.data
+            if self.add_vertical_rq_spline_flow:
+                param_dict[extra_prefix + "vertical_params"] = self.vertical_flow_params.data
+            if self.add_circular_rq_spline_flow:
+                param_dict[extra_prefix + "circular_params"] = self.circular_flow_params.data

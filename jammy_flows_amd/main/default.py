@@ -41,6 +41,38 @@ class HipLinearStack(nn.Sequential):
         return x
 
 
+def _manifold_family(layers):
+    """kernel family letter if the layers of a block can run as ONE manifold-chain launch, else None."""
+    from ..layers.intervals.rational_quadratic_spline import rational_quadratic_spline
+    from ..layers.spheres.sphere_base import sphere_base
+    if not (1 <= len(layers) <= _hip.JF_MAX_MCHAIN):
+        return None
+    if all(type(l) is rational_quadratic_spline for l in layers):
+        return "r"
+    l0 = layers[0]
+    if isinstance(l0, sphere_base) and l0.FAMILY is not None and all(type(l) is type(l0) for l in layers):
+        if any(l.always_parametrize_in_embedding_space for l in layers):
+            return None
+        return l0.FAMILY
+    return None
+
+
+def _manifold_chain(fam, layers, direction, x, log_det, extra, only_last_first, x_out, base_logp_in, want_base_logp, status):
+    structs = []
+    for l in layers:
+        if fam == "r":
+            structs.append(l.c_struct())
+        else:
+            structs.append(l.c_struct(1 if (only_last_first or l.euclidean_to_sphere_as_first) else 0))
+    if extra is None:
+        rows = [l._params_for(x, None) for l in layers]
+        params = torch.cat(rows, dim=1) if len(rows) > 1 else rows[0]
+    else:
+        params = extra
+    return _hip.mchain(fam, direction, x, log_det, params, structs, layers[0].dimension, x_out=x_out, base_logp_in=base_logp_in,
+                       want_base_logp=want_base_logp, status=status)
+
+
 class pdf(nn.Module):
     def __init__(self,
                  pdf_defs,
@@ -414,6 +446,15 @@ class pdf(nn.Module):
                 log_det = res[1]
                 if want_base_logp:
                     base_logp = res[2]
+            elif _manifold_family(layers) is not None:
+                params = extra
+                if extra is not None and only_last:
+                    params = extra[:, extra.shape[1] - layers[0].total_param_num:]
+                res = _manifold_chain(_manifold_family(layers), layers, "inv", tgt, log_det, params, only_last and kind == "s", out_view,
+                                      base_logp, want_base_logp, status)
+                log_det = res[1]
+                if want_base_logp:
+                    base_logp = res[2]
             else:
                 if log_det is None:
                     log_det = torch.zeros(B, dtype=x.dtype, device=x.device)
@@ -497,6 +538,12 @@ class pdf(nn.Module):
                 else:
                     params = extra
                 _, log_det = gfl.run_chain(layers, "fwd", cur, log_det, params, x_out=out_view, status=status)
+            elif _manifold_family(layers) is not None:
+                params = extra
+                if extra is not None and only_last:
+                    params = extra[:, extra.shape[1] - layers[0].total_param_num:]
+                _, log_det = _manifold_chain(_manifold_family(layers), layers, "fwd", cur, log_det, params, only_last and kind == "s", out_view,
+                                             None, False, status)
             else:
                 if log_det is None:
                     log_det = torch.zeros(B, dtype=x.dtype, device=x.device)
