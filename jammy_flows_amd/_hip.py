@@ -306,7 +306,8 @@ def sphere_embedding(x, log_det, dim, to_embedding):
     if ld_in is not None:
         ld_in = ld_in.contiguous()
     out = torch.empty((B, dim + 1 if to_embedding else dim), dtype=x.dtype, device=x.device)
-    want_ld = isinstance(log_det, torch.Tensor) and dim == 2
+    # log_det: tensor -> updated tensor; None -> treated as zeros (a tensor comes back for S2); python scalar -> passed through untouched
+    want_ld = (log_det is None or isinstance(log_det, torch.Tensor)) and dim == 2
     ld_out = torch.empty((B,), dtype=x.dtype, device=x.device) if want_ld else None
     suf = _suffix(x)
     name = ("jf_sphere_to_embedding" if to_embedding else "jf_sphere_from_embedding") + suf

@@ -20,6 +20,30 @@ IDS = [fx.name for fx in SUPPORTED]
 LOOSE_SAMPLING = {"v_s2": 5e-5, "v_s2_cond_vv": 5e-5, "v_s2_nat1_rot": 5e-5, "c5_e8s2_ggggv": 5e-5}
 
 
+def float32_domain_mask(fx):
+    """rows whose inputs survive rounding to float32: interval ends closer than 1e-5, S2 poles closer than 1e-4 and the S1 seam / Moebius
+    branch point closer than 1e-5 are not representable (1e-9 from an interval end IS the end in float32 -> erfinv(+-1) = inf, also in
+    the reference); those rows (part of the adversarial tail of each fixture) are only meaningful in float64."""
+    x = fx["x"]
+    if fx.meta["embedding"]:
+        x = build_oracle(fx)._to_default(x, np.zeros(x.shape[0]), True)[0]
+    ok = np.ones(x.shape[0], dtype=bool)
+    c = 0
+    for sub in fx.pdf_defs.split("+"):
+        kind, dim = sub[0], int(sub.split("_")[0][1:])
+        col = x[:, c:c + dim]
+        if kind == "i":
+            parts = sub.split("_")
+            lo, hi = (0.0, 1.0) if len(parts) == 1 else (float(parts[1]), float(parts[2]))
+            ok &= (np.minimum(col[:, 0] - lo, hi - col[:, 0]) > 1e-5 * (hi - lo))
+        elif kind == "s" and dim == 2:
+            ok &= (np.minimum(col[:, 0], np.pi - col[:, 0]) > 1e-4)
+        elif kind == "s" and dim == 1:
+            ok &= (np.abs(col[:, 0] - np.pi) > 1e-5) & (col[:, 0] > 1e-6) & (col[:, 0] < 2 * np.pi - 1e-6)
+        c += dim
+    return ok
+
+
 def test_some_fixtures_are_supported():
     assert len(SUPPORTED) >= 10, [fx.name for fx in SUPPORTED]
 
@@ -47,12 +71,16 @@ def test_logprob_float32_vs_float64_reference(fx):
     if "v" in fx.flow_defs:
         pytest.skip("'v' asserts float64 in the reference (exponential_map_s2.py:450)")
     pdf = build_product(fx, torch.float32)
+    pdf.check_status = False     # rows outside the float32-representable domain (below) may legitimately be non-finite
     x = to_dev(fx["x"], torch.float32)
     cond = to_dev(fx.get("cond"), torch.float32)
     logp, logp_base, base = pdf(x, conditional_input=cond, force_embedding_coordinates=fx.meta["embedding"])
-    assert torch.isfinite(logp).all(), "float32 path must stay finite where the float64 reference is (SURVEY D9)"
-    ref = fx["logp"]
-    err = np.abs(logp.double().cpu().numpy() - ref)
+    ok = float32_domain_mask(fx)
+    assert ok.sum() >= fx["x"].shape[0] - 8
+    got = logp.double().cpu().numpy()[ok]
+    assert np.isfinite(got).all(), "float32 path must stay finite where the float64 reference is (SURVEY D9)"
+    ref = fx["logp"][ok]
+    err = np.abs(got - ref)
     # inputs were rounded to float32 first: allow for the input-rounding sensitivity of rows deep in the tails (|logp| ~ 1e3..1e4)
     bar = 1e-2 + 2e-6 * np.abs(ref)
     assert (err < bar).all(), "max |dlogp| = %.3e at row %d (logp %.3f)" % (err.max(), err.argmax(), ref[err.argmax()])
@@ -75,6 +103,8 @@ def test_sampling_float64_vs_reference(fx):
 def test_roundtrip_selfconsistency_float64(fx):
     """the reference's own pin (tests/test_general.py:482-556): sample -> forward reproduces base samples and log-probs to 1e-6
     (1e-4 for 'v')."""
+    if fx.name == "mix_e2s1i1":
+        pytest.skip("'r' clamps to [-1,1] whatever the interval bounds are (rational_quadratic_spline.py:185-186): not invertible on [-2,3]")
     pdf = build_product(fx, torch.float64)
     n = 2048
     g = torch.Generator(device="cpu").manual_seed(11)
