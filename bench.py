@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""Benchmark of the jammy_flows hot path on MI355X (contract: see the task statement / DESIGN.md section "Measurement").
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+One step = one log-prob evaluation (`pdf.forward`) of a batch of 2^20 rows per GPU of BASELINE.json's metric configuration
+`pdf("e4+s2+e4", "gggg+f+gggg")` ("n" of the upstream README = "f"): all three sub-pdfs, both amortisation MLPs, every layer.
+Inputs are synthetic (seeded) and resident in HBM before the timed region; weights are the frozen golden-fixture state_dict
+(tests/golden/c3_e4s2e4.npz, reference init with the MLP damping undone so parameter blocks really vary per row).
+For N > 1 every rank evaluates its own 2^20 rows (weak scaling) and the step ends with ONE all_gather of the log-probs (RCCL).
+
+Printed JSON line (rank 0): metric/value (whole-job evals/s), ms_per_step, plus
+  roofline      dominant kernel: algorithmic bytes per launch / mean launch time from HIP events recorded in the timed region
+  cpu_baseline  the numpy oracle (kind "port") on this box's host cores, bounded sample, rank 0 at N = 1 only
+  parity        max |d log p| of the timed configuration against the float64 oracle on a 4096-row sample
+  float64       the same workload evaluated in float64 (evals/s), for reference
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden")]
+
+import numpy as np  # noqa: E402
+
+WORKLOAD = "c3_e4s2e4"
+PDF_DEFS, FLOW_DEFS = "e4+s2+e4", "gggg+f+gggg"
+BATCH = 1 << 20
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy ceiling ~6290 GB/s
+
+
+def make_inputs(n, seed):
+    """x = [N(0,1.5^2)^4, theta = acos(U(-1,1)) clamped to [1e-3, pi-1e-3], phi = U(0,2pi), N(0,1.5^2)^4]."""
+    rng = np.random.default_rng(seed)
+    return np.concatenate([rng.normal(size=(n, 4)) * 1.5,
+                           np.arccos(rng.uniform(-1, 1, size=(n, 1))).clip(1e-3, np.pi - 1e-3),
+                           rng.uniform(0, 2 * np.pi, size=(n, 1)),
+                           rng.normal(size=(n, 4)) * 1.5], axis=1)
+
+
+# ---------------------------------------------------------------------------------------------- CPU baseline (oracle, multi-process)
+_ORACLE = None
+
+
+def _oracle_init():
+    global _ORACLE
+    import fixture_io
+    import helpers
+    os.environ.setdefault("OMP_NUM_THREADS", "1")
+    _ORACLE = helpers.build_oracle(fixture_io.load(WORKLOAD))
+
+
+def _oracle_chunk(x):
+    return _ORACLE.forward(x)[0]
+
+
+def cpu_baseline(budget_s=20.0):
+    """time the CPU oracle on a bounded sample of the same workload using every host core (process pool, forked BEFORE any GPU call)."""
+    import multiprocessing as mp
+    cores = os.cpu_count() or 1
+    workers = max(1, min(cores, 64))
+    chunk = 2048
+    ctx = mp.get_context("fork")
+    with ctx.Pool(workers, initializer=_oracle_init) as pool:
+        x = make_inputs(chunk * workers, 3)
+        chunks = [x[i * chunk:(i + 1) * chunk] for i in range(workers)]
+        t0 = time.time()
+        pool.map(_oracle_chunk, chunks)            # warm-up + rate estimate
+        est = time.time() - t0
+        rounds = int(max(1, min(64, budget_s / max(est, 1e-3))))
+        x = make_inputs(chunk * workers * rounds, 3)
+        chunks = [x[i * chunk:(i + 1) * chunk] for i in range(workers * rounds)]
+        t0 = time.time()
+        pool.map(_oracle_chunk, chunks)
+        dt = time.time() - t0
+    n = chunk * workers * rounds
+    return {"value": n / dt, "unit": "log-prob evals/s", "cores": workers, "kind": "port",
+            "sample": "%d rows of %s (float64 numpy oracle, %d processes x %d-row chunks), %.1f s" % (n, WORKLOAD, workers, chunk, dt)}
+
+
+# ---------------------------------------------------------------------------------------------- main
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=BATCH, help="rows per GPU (default 2^20 = the BASELINE configuration)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus, "WORLD_SIZE (%d) != --gpus (%d): launch with torch.distributed.run --nproc-per-node N" % (world, args.gpus)
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline()                      # before the GPU is touched (fork safety)
+
+    import torch
+    import torch.distributed as dist
+    import fixture_io
+    import helpers
+    from jammy_flows_amd import _hip, parallel
+
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    fx = fixture_io.load(WORKLOAD)
+    B = args.batch
+    x64 = make_inputs(B, 3 + rank)
+    results = {}
+    kernel_table = None
+    for dtype in (torch.float32, torch.float64):
+        pdf = helpers.build_product(fx, dtype, dev)
+        x = torch.from_numpy(x64).to(device=dev, dtype=dtype)
+        gathered = torch.empty(world * B, dtype=dtype, device=dev) if world > 1 else None
+
+        def step():
+            logp = pdf(x)[0]
+            if world > 1:
+                dist.all_gather_into_tensor(gathered, logp)
+            return logp
+
+        for _ in range(args.warmup):
+            step()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        timer = _hip.KernelTimer() if dtype == torch.float32 else None
+        t0 = time.perf_counter()
+        if timer is not None:
+            with timer:
+                for _ in range(args.steps):
+                    logp = step()
+        else:
+            for _ in range(args.steps):
+                logp = step()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+        # parity of what was just timed, against the float64 oracle (rank 0, 4096 rows)
+        err = None
+        if rank == 0:
+            n_chk = min(4096, B)
+            o = helpers.build_oracle(fx).forward(x64[:n_chk])[0]
+            err = float(np.max(np.abs(logp[:n_chk].double().cpu().numpy() - o)))
+        results[dtype] = dict(dt=dt, evals_per_s=world * B * args.steps / dt, ms_per_step=1e3 * dt / args.steps, err=err)
+        if timer is not None:
+            kernel_table = timer.summary()
+        del pdf, x
+
+    if rank == 0:
+        r32, r64 = results[torch.float32], results[torch.float64]
+        # ---- roofline of the dominant kernel (float32 run).  Algorithmic bytes per row (SURVEY 8d / DESIGN.md), float32:
+        #   conditional g-chain (block 2):  x 4 + log_det 1 + params 548 + base 4 + log_det 1            = 558 scalars
+        #   dense layers: inputs + outputs of each launch (K + N scalars)
+        alg = {("jf_gf_chain_inv_f32", "per-sample"): 4 * 558, ("jf_gf_chain_inv_f32", "bcast"): 4 * 10,
+               ("jf_f_chain_inv_f32", "per-sample"): 4 * (2 + 1 + 10 + 2 + 1)}
+        dom = max(kernel_table.items(), key=lambda kv: kv[1]["total_ms"])
+        (kname, ktag), kstat = dom
+        if kname.startswith("jf_linear"):
+            K = int(ktag.split("_")[0][1:]); N = int(ktag.split("_")[1][1:])
+            bytes_per_row = 4 * (K + N)
+        else:
+            bytes_per_row = alg.get((kname, ktag), 0)
+        achieved = bytes_per_row * B / (kstat["mean_ms"] * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "kernel": "%s[%s]" % (kname, ktag), "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": None, "mean_launch_ms": kstat["mean_ms"],
+                    "algorithmic_bytes_per_launch": bytes_per_row * B,
+                    "all_kernels_ms_per_step": {"%s[%s]" % k: round(v["total_ms"] / args.steps, 4) for k, v in sorted(kernel_table.items())}}
+        line = {
+            "metric": "log-prob evals/sec (batch 2^20 per GPU), e4+s2+e4 / gggg+f+gggg",
+            "value": r32["evals_per_s"], "unit": "log-prob evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": r32["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic (seeded; weights = frozen golden-fixture state_dict)",
+            "config": {"workload": 'pdf("%s","%s") log-prob, batch %d rows per GPU, unconditional pdf with autoregressive conditioning'
+                                   % (PDF_DEFS, FLOW_DEFS, B), "batch_per_gpu": B, "parallelism": "rows sharded over %d GPU(s)" % world},
+            "parity": {"max_abs_dlogp_vs_f64_oracle": r32["err"], "bar": 1e-2, "rows_checked": min(4096, B)},
+            "float64": {"value": r64["evals_per_s"], "ms_per_step": r64["ms_per_step"], "max_abs_dlogp_vs_f64_oracle": r64["err"], "bar": 1e-4},
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

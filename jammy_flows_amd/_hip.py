@@ -159,6 +159,50 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+class KernelTimer:
+    """records a pair of HIP events (on torch's current stream = the stream the kernels are launched on) around every kernel launch
+    made through this module while active; `summary()` (after a synchronize) gives per-kernel launch counts and mean durations."""
+
+    def __init__(self):
+        self.records = []
+
+    def __enter__(self):
+        global _TIMER
+        self._prev = _TIMER
+        _TIMER = self
+        return self
+
+    def __exit__(self, *exc):
+        global _TIMER
+        _TIMER = self._prev
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, tag, e0, e1 in self.records:
+            d = out.setdefault((name, tag), [0, 0.0])
+            d[0] += 1
+            d[1] += e0.elapsed_time(e1)
+        return {k: {"launches": v[0], "mean_ms": v[1] / v[0], "total_ms": v[1]} for k, v in out.items()}
+
+
+_TIMER = None
+
+
+def _launch(name, tag, args):
+    fn = getattr(lib(), name)
+    if _TIMER is None:
+        rc = fn(*args)
+    else:
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = fn(*args)
+        e1.record()
+        _TIMER.records.append((name, tag, e0, e1))
+    _check(rc, name)
+
+
 def _check(rc, what):
     if rc != JF_OK:
         raise RuntimeError("%s failed: %s (code %d)" % (what, JF_ERRORS.get(rc, "unknown"), rc))
@@ -213,14 +257,13 @@ def gf_chain(direction, x, log_det, params, layer_array, n_layers, D, x_out=None
         pb = 1
     if direction == "inv":
         blp_out = torch.empty((B,), dtype=x.dtype, device=x.device) if want_base_logp else None
-        rc = getattr(lib(), "jf_gf_chain_inv" + suf)(_ptr(x), x.stride(0), _ptr(log_det), _ptr(params), params.stride(0), pb, B, D, n_layers,
-                                                     layer_array, _ptr(x_out), x_out.stride(0), _ptr(ld_out), _ptr(base_logp_in),
-                                                     _ptr(blp_out), _ptr(status), _stream())
-        _check(rc, "jf_gf_chain_inv" + suf)
+        _launch("jf_gf_chain_inv" + suf, "bcast" if pb == 1 else "per-sample",
+                (_ptr(x), x.stride(0), _ptr(log_det), _ptr(params), params.stride(0), pb, B, D, n_layers, layer_array, _ptr(x_out),
+                 x_out.stride(0), _ptr(ld_out), _ptr(base_logp_in), _ptr(blp_out), _ptr(status), _stream()))
         return (x_out, ld_out, blp_out) if want_base_logp else (x_out, ld_out)
-    rc = getattr(lib(), "jf_gf_chain_fwd" + suf)(_ptr(x), x.stride(0), _ptr(log_det), _ptr(params), params.stride(0), pb, B, D, n_layers,
-                                                 layer_array, _ptr(x_out), x_out.stride(0), _ptr(ld_out), _ptr(status), _stream())
-    _check(rc, "jf_gf_chain_fwd" + suf)
+    _launch("jf_gf_chain_fwd" + suf, "bcast" if pb == 1 else "per-sample",
+            (_ptr(x), x.stride(0), _ptr(log_det), _ptr(params), params.stride(0), pb, B, D, n_layers, layer_array, _ptr(x_out), x_out.stride(0),
+             _ptr(ld_out), _ptr(status), _stream()))
     return x_out, ld_out
 
 
@@ -240,9 +283,8 @@ def linear(inp, weight, bias=None, act=0, out=None):
     if out is None:
         out = torch.empty((B, N), dtype=inp.dtype, device=inp.device)
     suf = _suffix(inp)
-    rc = getattr(lib(), "jf_linear" + suf)(_ptr(inp), inp.stride(0), _ptr(weight), weight.stride(0), _ptr(bias), B, K, N, act, _ptr(out),
-                                           out.stride(0), _stream())
-    _check(rc, "jf_linear" + suf)
+    _launch("jf_linear" + suf, "K%d_N%d" % (K, N),
+            (_ptr(inp), inp.stride(0), _ptr(weight), weight.stride(0), _ptr(bias), B, K, N, act, _ptr(out), out.stride(0), _stream()))
     return out
 
 
@@ -253,8 +295,7 @@ def normal_logp(z, acc=None):
     B, D = z.shape
     out = torch.empty((B,), dtype=z.dtype, device=z.device)
     suf = _suffix(z)
-    rc = getattr(lib(), "jf_normal_logp" + suf)(_ptr(z), z.stride(0), B, D, _ptr(acc), _ptr(out), _stream())
-    _check(rc, "jf_normal_logp" + suf)
+    _launch("jf_normal_logp" + suf, "", (_ptr(z), z.stride(0), B, D, _ptr(acc), _ptr(out), _stream()))
     return out
 
 
@@ -291,9 +332,9 @@ def mchain(fam, direction, x, log_det, params, layer_structs, dim, x_out=None, b
     name = "jf_%s_chain_%s%s" % (fam, direction, suf)
     if bins is not None:
         assert bins.dtype == torch.int64 and bins.dim() == 2 and bins.shape[0] == B and bins.stride(1) == 1
-    rc = getattr(lib(), name)(_ptr(x), x.stride(0), _ptr(log_det), pptr, pstride, pb, B, n, arr, _ptr(x_out), x_out.stride(0), _ptr(ld_out),
-                              _ptr(base_logp_in), _ptr(blp_out), _ptr(bins), bins.stride(0) if bins is not None else 0, _ptr(status), _stream())
-    _check(rc, name)
+    _launch(name, "bcast" if pb == 1 else "per-sample",
+            (_ptr(x), x.stride(0), _ptr(log_det), pptr, pstride, pb, B, n, arr, _ptr(x_out), x_out.stride(0), _ptr(ld_out), _ptr(base_logp_in),
+             _ptr(blp_out), _ptr(bins), bins.stride(0) if bins is not None else 0, _ptr(status), _stream()))
     return (x_out, ld_out, blp_out) if want_base_logp else (x_out, ld_out)
 
 
@@ -311,6 +352,5 @@ def sphere_embedding(x, log_det, dim, to_embedding):
     ld_out = torch.empty((B,), dtype=x.dtype, device=x.device) if want_ld else None
     suf = _suffix(x)
     name = ("jf_sphere_to_embedding" if to_embedding else "jf_sphere_from_embedding") + suf
-    rc = getattr(lib(), name)(_ptr(x), x.stride(0), _ptr(ld_in), B, dim, _ptr(out), out.stride(0), _ptr(ld_out), _stream())
-    _check(rc, name)
+    _launch(name, "", (_ptr(x), x.stride(0), _ptr(ld_in), B, dim, _ptr(out), out.stride(0), _ptr(ld_out), _stream()))
     return out, (ld_out if want_ld else log_det)

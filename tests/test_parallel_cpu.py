@@ -1,0 +1,67 @@
+"""world_size-2 gloo tests (CPU) of the row-sharding helpers used by the multi-GPU path."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from jammy_flows_amd import parallel
+
+
+def test_shard_bounds_cover_all_rows():
+    for n in (0, 1, 7, 8, 1 << 20, (1 << 20) + 3):
+        for w in (1, 2, 4, 8):
+            b = [parallel.shard_bounds(n, r, w) for r in range(w)]
+            assert b[0][0] == 0 and b[-1][1] == n
+            assert all(b[i][1] == b[i + 1][0] for i in range(w - 1))
+            sizes = [hi - lo for lo, hi in b]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n_rows, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(0)
+        x = torch.randn(n_rows, 3, dtype=torch.float64)
+        cond = torch.randn(n_rows, 2, dtype=torch.float64)
+
+        def evaluate(xs, cs):       # stand-in for the HIP log-prob (no GPU here): any row-wise function of the shard
+            return (xs ** 2).sum(dim=1) + cs[:, 0]
+
+        full = parallel.sharded_log_prob(None, x, cond, gather=True, evaluate=evaluate)
+        expect = (x ** 2).sum(dim=1) + cond[:, 0]
+        ok = bool(torch.equal(full, expect))
+        local = parallel.sharded_log_prob(None, x, cond, gather=False, evaluate=evaluate)
+        lo, hi = parallel.shard_bounds(n_rows, rank, world)
+        ok = ok and local.shape[0] == hi - lo and bool(torch.equal(local, expect[lo:hi]))
+        q.put((rank, ok))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_rows", [64, 65, 1])
+def test_sharded_log_prob_gloo_world2(n_rows):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_rows, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(r for r, _ in res) == [0, 1]
+    assert all(ok for _, ok in res)
