@@ -59,17 +59,16 @@ template <typename T> __device__ __forceinline__ void derive_broadcast(T* lds, c
 }
 
 // stage + derive the slab of one layer for the rows of this wave (per-sample regime)
-template <typename T> __device__ __forceinline__ const T* stage_layer(T* lds, const GfChainArgs<T>& a, const GfLayerDev<T>& o, int D, int64_t row0,
+template <typename T, int D, bool DERIVE> __device__ __forceinline__ const T* stage_layer(T* lds, const GfChainArgs<T>& a, const GfLayerDev<T>& o, int64_t row0,
                                                              int valid_rows, bool lane_active) {
     const int tid = threadIdx.x;
     __syncthreads();   // previous layer's reads are done
-    stage_rows<T>(lds, a.tile_stride, a.params + row0 * a.ps + o.col0, a.ps, o.n_params, a.rows_per_block, valid_rows, tid, blockDim.x,
-                  o.vec_ok != 0);
+    stage_rows<T, 18>(lds, a.tile_stride, a.params + row0 * a.ps + o.col0, a.ps, o.n_params, a.rows_per_block, valid_rows, tid, blockDim.x,
+                      o.vec_ok != 0);
     __syncthreads();
     T* row = lds + (lane_active ? tid : 0) * a.tile_stride;   // idle lanes (tid >= rows_per_block) shadow row 0, read-only
-    if (lane_active) {
-        for (int d = 0; d < D; ++d) gf_derive_column<T>(row, o, D, d);
-        for (int i = 0; i < o.hh; ++i) gf_derive_reflection<T>(row, o, D, i);
+    if constexpr (DERIVE) {
+        if (lane_active) gf_derive_row<T, D>(row, o);
     }
     return row;
 }
@@ -95,13 +94,18 @@ __global__ void __launch_bounds__(BCAST ? 256 : 64) gf_chain_inv_kernel(const Gf
         const GfLayerDev<T> o = a.L[l];      // uniform index: scalar loads from the kernarg segment
         const T* prow;
         if constexpr (BCAST) prow = lds + l * a.tile_stride;
-        else prow = stage_layer<T>(lds, a, o, D, row0, valid_rows, tid < rpb);
+        else prow = stage_layer<T, D, false>(lds, a, o, row0, valid_rows, tid < rpb);     // raw rows: regulation fused into the mixture loop
         if (o.model_offset) {
 #pragma unroll
             for (int d = 0; d < D; ++d) x[d] -= prow[d];                 // euclidean_base.py:40-45
         }
-        gf_rotate_inv<T, D>(prow, o, x);
-        ld += gf_stage<T, D>(prow, o, x, y);
+        if constexpr (BCAST) {
+            gf_rotate_inv<T, D>(prow, o, x);
+            ld += gf_stage<T, D>(prow, o, x, y);
+        } else {
+            gf_rotate_inv_raw<T, D>(prow, o, x);
+            ld += gf_stage_raw<T, D>(prow, o, x, y);
+        }
 #pragma unroll
         for (int d = 0; d < D; ++d) x[d] = y[d];
     }
@@ -142,7 +146,7 @@ __global__ void __launch_bounds__(BCAST ? 256 : 64) gf_chain_fwd_kernel(const Gf
         const GfLayerDev<T> o = a.L[l];
         const T* prow;
         if constexpr (BCAST) prow = lds + l * a.tile_stride;
-        else prow = stage_layer<T>(lds, a, o, D, row0, valid_rows, tid < rpb);
+        else prow = stage_layer<T, D, true>(lds, a, o, row0, valid_rows, tid < rpb);
         gf_solve<T, D>(prow, o, z, x, active, a.status);
         gf_stage_deriv<T, D>(prow, o, x, y, logd);                       // gaussianization_flow.py:922-924
 #pragma unroll

@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "../../include/jammy_hip.h"
 
 #define JF_WAVE 64
@@ -32,32 +34,59 @@ template <typename T> __host__ __device__ inline int padded_stride(int n) {
 // at most a few rows.  Falls back to element-wise copies when the slab is not 16-byte aligned.
 // `nthreads` threads (tid in [0,nthreads)) cooperate; rows beyond `valid_rows` replicate the last valid row.
 // ---------------------------------------------------------------------------------------------
-template <typename T>
-__device__ inline void stage_rows(T* __restrict__ tile, int tile_stride, const T* __restrict__ src, int64_t src_stride,
-                                  int ncols, int rows, int valid_rows, int tid, int nthreads, bool vec_ok) {
+// U = loads in flight per lane.  Measured on MI355X (scripts/probe/stream2.hip): one wave per SIMD with ~34 x 16 B per lane in flight
+// streams at 6.2 TB/s, so U is chosen to cover (half of) a layer slab.  A batch is straight-line code: piece coordinates advance
+// incrementally (no per-piece division), out-of-range lanes re-read a valid piece and only skip the LDS write, so the U
+// global_load_dwordx4 are issued back to back and waited for once (any branch between the loads makes hipcc wait after each of them).
+template <typename T> struct StageCursor {
+    const T* src; int64_t src_stride; T* tile; int tile_stride;
+    int nv, rows, last_row, total, nthreads, tid;
+    int r, c, dq, dr, it;
+};
+
+template <typename T, int U, bool VEC> __device__ __forceinline__ void stage_batch(StageCursor<T>& s) {
     constexpr int N = Vec16<T>::N;
     using V = typename Vec16<T>::type;
-    if (vec_ok) {
-        const int nv = ncols / N;  // vectors per row (ncols is a multiple of N when vec_ok)
-        const int total = rows * nv;
-        int r = tid / nv, c = tid - r * nv;
-        const int dr = nthreads / nv, dc = nthreads - dr * nv;
-        for (int idx = tid; idx < total; idx += nthreads) {
-            const int rs = r < valid_rows ? r : valid_rows - 1;
-            const V v = *reinterpret_cast<const V*>(src + (int64_t)rs * src_stride + c * N);
-            *reinterpret_cast<V*>(tile + r * tile_stride + c * N) = v;
-            r += dr;
-            c += dc;
-            if (c >= nv) { c -= nv; r += 1; }
-        }
-    } else {
-        const int total = rows * ncols;
-        for (int idx = tid; idx < total; idx += nthreads) {
-            const int r = idx / ncols, c = idx - r * ncols;
-            const int rs = r < valid_rows ? r : valid_rows - 1;
-            tile[r * tile_stride + c] = src[(int64_t)rs * src_stride + c];
-        }
+    using E = typename std::conditional<VEC, V, T>::type;
+    constexpr int W = VEC ? N : 1;
+    E v[U];
+    int off[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        // pieces past the end of the slab (last batch only) fall on row >= rows: they are clamped to the last row and simply rewrite one
+        // of its pieces with the same data -- no predicate, hence no branch for the compiler to sink the load into
+        const int rr = s.r < s.rows ? s.r : s.rows - 1;
+        const int rs = rr < s.last_row ? rr : s.last_row;
+        v[u] = *reinterpret_cast<const E*>(s.src + (int64_t)rs * s.src_stride + s.c * W);
+        off[u] = rr * s.tile_stride + s.c * W;
+        s.r += s.dq; s.c += s.dr;
+        if (s.c >= s.nv) { s.c -= s.nv; s.r += 1; }
     }
+    asm volatile("" ::: "memory");   // keep every load of the batch ahead of the first LDS write (the scheduler otherwise caps ~8 in flight)
+#pragma unroll
+    for (int u = 0; u < U; ++u) *reinterpret_cast<E*>(s.tile + off[u]) = v[u];
+    s.it += U;
+}
+
+template <typename T, int U, bool VEC> __device__ __forceinline__ void stage_all(StageCursor<T>& s, int iters) {
+    while (s.it + U <= iters) stage_batch<T, U, VEC>(s);
+    if constexpr (U > 4) { while (s.it + 4 <= iters) stage_batch<T, 4, VEC>(s); }
+    while (s.it < iters) stage_batch<T, 1, VEC>(s);
+}
+
+template <typename T, int U = 8>
+__device__ __forceinline__ void stage_rows(T* __restrict__ tile, int tile_stride, const T* __restrict__ src, int64_t src_stride,
+                                           int ncols, int rows, int valid_rows, int tid, int nthreads, bool vec_ok) {
+    constexpr int N = Vec16<T>::N;
+    StageCursor<T> s;
+    s.src = src; s.src_stride = src_stride; s.tile = tile; s.tile_stride = tile_stride;
+    s.nv = vec_ok ? ncols / N : ncols;                     // pieces per row (16-byte vectors or single elements)
+    s.rows = rows; s.last_row = valid_rows - 1; s.total = rows * s.nv; s.nthreads = nthreads; s.tid = tid;
+    s.r = tid / s.nv; s.c = tid - s.r * s.nv;              // piece idx = it * nthreads + tid  ->  (row r, piece c)
+    s.dq = nthreads / s.nv; s.dr = nthreads - s.dq * s.nv; s.it = 0;
+    const int iters = (s.total + nthreads - 1) / nthreads;
+    if (vec_ok) stage_all<T, U, true>(s, iters);
+    else stage_all<T, U, false>(s, iters);
 }
 
 template <typename T> __host__ inline bool aligned16(const void* p, int64_t stride_elems, int64_t col0_elems) {
@@ -79,6 +108,23 @@ template <typename T, int D> __device__ inline void load_d(const T* __restrict__
     } else {
 #pragma unroll
         for (int i = 0; i < D; ++i) v[i] = p[i];
+    }
+}
+
+template <typename T, int D> __device__ inline void store_d(T* __restrict__ p, const T (&v)[D]) {
+    constexpr int N = Vec16<T>::N;
+    using V = typename Vec16<T>::type;
+    if constexpr (D % N == 0) {
+#pragma unroll
+        for (int i = 0; i < D / N; ++i) {
+            V t;
+            if constexpr (N == 4) { t.x = v[4 * i]; t.y = v[4 * i + 1]; t.z = v[4 * i + 2]; t.w = v[4 * i + 3]; }
+            else { t.x = v[2 * i]; t.y = v[2 * i + 1]; }
+            reinterpret_cast<V*>(p)[i] = t;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < D; ++i) p[i] = v[i];
     }
 }
 

@@ -64,6 +64,63 @@ template <typename T> __device__ __forceinline__ void gf_derive_column(T* __rest
     }
 }
 
+// pi_k weight before normalisation (gaussianization_flow.py:342, 406)
+template <typename T> __device__ __forceinline__ T gf_weight(const GfLayerDev<T>& o, T xn, T shift) {
+    return o.reg_norm ? o.nmin + o.nmax * M<T>::rcp(T(1) + M<T>::exp_fast(-xn)) : M<T>::exp(xn - shift);
+}
+
+// derive a whole row in place with D-wide vector LDS accesses and D independent dependency chains per k
+template <typename T, int D> __device__ __forceinline__ void gf_derive_row(T* __restrict__ row, const GfLayerDev<T>& o) {
+    const int K = o.K;
+    T shift[D], nsum[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) { shift[d] = T(0); nsum[d] = T(0); }
+    if (o.fit_norm && !o.reg_norm) {
+        load_d<T, D>(row + o.off_ln, shift);
+        for (int k = 1; k < K; ++k) {
+            T v[D];
+            load_d<T, D>(row + o.off_ln + k * D, v);
+#pragma unroll
+            for (int d = 0; d < D; ++d) shift[d] = M<T>::max(shift[d], v[d]);
+        }
+    }
+    for (int k = 0; k < K; ++k) {
+        T lw[D], ln[D];
+        load_d<T, D>(row + o.off_lw + k * D, lw);
+#pragma unroll
+        for (int d = 0; d < D; ++d) lw[d] = M<T>::rcp(gf_width(o, lw[d]));
+        store_d<T, D>(row + o.off_lw + k * D, lw);
+        if (o.fit_norm) {
+            load_d<T, D>(row + o.off_ln + k * D, ln);
+#pragma unroll
+            for (int d = 0; d < D; ++d) { ln[d] = gf_weight(o, ln[d], shift[d]); nsum[d] += ln[d]; }
+            store_d<T, D>(row + o.off_ln + k * D, ln);
+        }
+    }
+    if (o.fit_norm) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) nsum[d] = M<T>::rcp(nsum[d]);
+        for (int k = 0; k < K; ++k) {
+            T ln[D];
+            load_d<T, D>(row + o.off_ln + k * D, ln);
+#pragma unroll
+            for (int d = 0; d < D; ++d) ln[d] *= nsum[d];
+            store_d<T, D>(row + o.off_ln + k * D, ln);
+        }
+    }
+    for (int i = 0; i < o.hh; ++i) {
+        T v[D];
+        load_d<T, D>(row + o.off_rot + i * D, v);
+        T n2 = T(0);
+#pragma unroll
+        for (int d = 0; d < D; ++d) n2 += v[d] * v[d];
+        const T sc = M<T>::SQRT2 / M<T>::sqrt(n2);
+#pragma unroll
+        for (int d = 0; d < D; ++d) v[d] *= sc;
+        store_d<T, D>(row + o.off_rot + i * D, v);
+    }
+}
+
 // Householder vector i -> sqrt(2) v/|v| so that a reflection is x -= v (v.x)   (H = I - 2 v v^T/|v|^2)
 template <typename T> __device__ __forceinline__ void gf_derive_reflection(T* __restrict__ row, const GfLayerDev<T>& o, int D, int i) {
     T n2 = T(0);
@@ -169,6 +226,96 @@ template <typename T, int D> __device__ __forceinline__ void gf_mixture(const T*
     }
 }
 
+// Log-prob direction, per-sample regime: the lane's row holds RAW parameters; width / weight regulation is fused into the
+// mixture loop (no LDS write-back, D independent chains per k).  Reflections use the raw Householder vectors.
+template <typename T, int D> __device__ __forceinline__ void gf_rotate_inv_raw(const T* __restrict__ row, const GfLayerDev<T>& o, T (&x)[D]) {
+    for (int i = 0; i < o.hh; ++i) {
+        T v[D];
+        load_d<T, D>(row + o.off_rot + i * D, v);
+        T n2 = T(0), dot = T(0);
+#pragma unroll
+        for (int d = 0; d < D; ++d) { n2 += v[d] * v[d]; dot += v[d] * x[d]; }
+        const T f = T(2) * dot * M<T>::rcp(n2);
+#pragma unroll
+        for (int d = 0; d < D; ++d) x[d] -= f * v[d];
+    }
+}
+
+template <typename T, int D> __device__ __forceinline__ void gf_mixture_raw(const T* __restrict__ row, const GfLayerDev<T>& o, const T (&x)[D], MixQ<T> (&q)[D]) {
+    T C[D], S[D], P[D], Nn[D], shift[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) { C[d] = T(0); S[d] = T(0); P[d] = T(0); Nn[d] = T(0); shift[d] = T(0); }
+    if (o.fit_norm && !o.reg_norm) {
+        load_d<T, D>(row + o.off_ln, shift);
+        for (int k = 1; k < o.K; ++k) {
+            T v[D];
+            load_d<T, D>(row + o.off_ln + k * D, v);
+#pragma unroll
+            for (int d = 0; d < D; ++d) shift[d] = M<T>::max(shift[d], v[d]);
+        }
+    }
+    for (int k = 0; k < o.K; ++k) {
+        T mu[D], lw[D], ln[D];
+        load_d<T, D>(row + o.off_mean + k * D, mu);
+        load_d<T, D>(row + o.off_lw + k * D, lw);
+        if (o.fit_norm) load_d<T, D>(row + o.off_ln + k * D, ln);
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const T iw = M<T>::rcp(gf_width(o, lw[d]));
+            const T wk = o.fit_norm ? gf_weight(o, ln[d], shift[d]) : T(1);
+            const T u = (x[d] - mu[d]) * iw;
+            const T t = M<T>::exp_fast(-M<T>::abs(u));
+            const T hi = M<T>::rcp(T(1) + t);
+            const T lo = t * hi;
+            const bool pos = u >= T(0);
+            C[d] += wk * (pos ? hi : lo);
+            S[d] += wk * (pos ? lo : hi);
+            P[d] += wk * hi * lo * iw;
+            Nn[d] += wk;
+        }
+    }
+    bool slow = false;
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        const T inv = M<T>::rcp(Nn[d]);
+        C[d] *= inv; S[d] *= inv; P[d] *= inv;
+        q[d].lc = M<T>::log_fast(C[d]);
+        q[d].ls = M<T>::log_fast(S[d]);
+        q[d].lp = M<T>::log_fast(P[d]);
+        q[d].cdf = C[d];
+        q[d].sf = S[d];
+        slow = slow || !(C[d] > M<T>::TINY && S[d] > M<T>::TINY && P[d] > M<T>::TINY);
+    }
+    if (__any(slow)) {   // rare (tails): redo the flagged dimensions in log space = the reference's arithmetic (:389-454)
+        Lse<T> c[D], s[D], p[D];
+        for (int k = 0; k < o.K; ++k) {
+            T mu[D], lw[D], ln[D];
+            load_d<T, D>(row + o.off_mean + k * D, mu);
+            load_d<T, D>(row + o.off_lw + k * D, lw);
+            if (o.fit_norm) load_d<T, D>(row + o.off_ln + k * D, ln);
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                const T w = gf_width(o, lw[d]);
+                const T u = (x[d] - mu[d]) / w;
+                const T sp = softplus(-u);
+                const T lnpi = (o.fit_norm ? M<T>::log(gf_weight(o, ln[d], shift[d])) : T(0)) - M<T>::log(Nn[d]);
+                c[d].add(-sp + lnpi);
+                s[d].add(-u - sp + lnpi);
+                p[d].add(-u - M<T>::log(w) - T(2) * sp + lnpi);
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const bool bad = !(C[d] > M<T>::TINY && S[d] > M<T>::TINY && P[d] > M<T>::TINY);
+            if (bad) {
+                q[d].lc = c[d].value(); q[d].ls = s[d].value(); q[d].lp = p[d].value();
+                q[d].cdf = M<T>::exp(q[d].lc);
+                q[d].sf = M<T>::exp(q[d].ls);
+            }
+        }
+    }
+}
+
 // ----------------------------------------------------------------------------------------------------------
 // inverse-CDF stage  (gaussianization_flow.py:480-560 value, :568-671 log-derivative)
 // ----------------------------------------------------------------------------------------------------------
@@ -233,6 +380,18 @@ template <typename T> __device__ __forceinline__ T gf_inverse_cdf(int inv_type, 
 template <typename T, int D> __device__ __forceinline__ T gf_stage(const T* __restrict__ row, const GfLayerDev<T>& o, const T (&x)[D], T (&y)[D]) {
     MixQ<T> q[D];
     gf_mixture<T, D>(row, o, x, q);
+    T sum = T(0);
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        T ld;
+        y[d] = gf_inverse_cdf<T>(o.inv_type, q[d], ld);
+        sum += ld;
+    }
+    return sum;
+}
+template <typename T, int D> __device__ __forceinline__ T gf_stage_raw(const T* __restrict__ row, const GfLayerDev<T>& o, const T (&x)[D], T (&y)[D]) {
+    MixQ<T> q[D];
+    gf_mixture_raw<T, D>(row, o, x, q);
     T sum = T(0);
 #pragma unroll
     for (int d = 0; d < D; ++d) {

@@ -32,6 +32,51 @@ template <> struct Mfma<double> {
 
 constexpr int BM = 128, BN = 64, KC = 32, WM = 32, WN = 64, LDP = KC + 1;
 
+// [ROWS x KC] chunk of a row-major matrix -> LDS rows padded to LDP; rows >= max_row and columns >= kc are zero filled
+template <typename T, int ROWS>
+__device__ __forceinline__ void stage_chunk(T* __restrict__ dst, const T* __restrict__ src, int64_t stride, int64_t row0, int64_t max_row, int k0,
+                                            int kc, int tid, bool vec_ok) {
+    constexpr int N = Vec16<T>::N;
+    using V = typename Vec16<T>::type;
+    if (vec_ok) {
+        constexpr int PER_ROW = KC / N;
+        constexpr int CNT = ROWS * PER_ROW / 256;
+        V v[CNT];
+#pragma unroll
+        for (int u = 0; u < CNT; ++u) {
+            const int idx = u * 256 + tid;
+            const int r = idx / PER_ROW, c = (idx % PER_ROW) * N;
+            const int64_t gr = row0 + r;
+            if (gr < max_row && c < kc) v[u] = *reinterpret_cast<const V*>(src + gr * stride + k0 + c);     // kc % N == 0 when vec_ok
+            else if constexpr (N == 4) v[u] = V{T(0), T(0), T(0), T(0)};
+            else v[u] = V{T(0), T(0)};
+        }
+#pragma unroll
+        for (int u = 0; u < CNT; ++u) {
+            const int idx = u * 256 + tid;
+            const int r = idx / PER_ROW, c = (idx % PER_ROW) * N;
+            T* d = dst + r * LDP + c;
+            d[0] = v[u].x; d[1] = v[u].y;
+            if constexpr (N == 4) { d[2] = v[u].z; d[3] = v[u].w; }
+        }
+    } else {
+        constexpr int CNT = ROWS * KC / 256;
+        T v[CNT];
+#pragma unroll
+        for (int u = 0; u < CNT; ++u) {
+            const int idx = u * 256 + tid;
+            const int r = idx / KC, c = idx % KC;
+            const int64_t gr = row0 + r;
+            v[u] = (gr < max_row && c < kc) ? src[gr * stride + k0 + c] : T(0);
+        }
+#pragma unroll
+        for (int u = 0; u < CNT; ++u) {
+            const int idx = u * 256 + tid;
+            dst[(idx / KC) * LDP + (idx % KC)] = v[u];
+        }
+    }
+}
+
 template <typename T>
 __global__ void __launch_bounds__(256) linear_kernel(const T* __restrict__ in, int64_t in_stride, const T* __restrict__ W, int64_t w_stride,
                                                      const T* __restrict__ bias, int64_t B, int K, int N, int act, T* __restrict__ out,
@@ -42,8 +87,11 @@ __global__ void __launch_bounds__(256) linear_kernel(const T* __restrict__ in, i
     __shared__ T As[BM * LDP];
     __shared__ T Ws[BN * LDP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t row0 = (int64_t)blockIdx.x * BM;
-    const int col0 = blockIdx.y * BN;
+    const int n_tiles = (N + BN - 1) / BN;                 // 1-D grid, N tile is the fast index: the blocks that share an activation
+    const int col0 = (int)(blockIdx.x % n_tiles) * BN;     // tile are dispatched back to back and find it in L2
+    const int64_t row0 = (int64_t)(blockIdx.x / n_tiles) * BM;
+    const bool vec_in = (K % Vec16<T>::N == 0) && (in_stride % Vec16<T>::N == 0) && ((reinterpret_cast<uintptr_t>(in) & 15u) == 0);
+    const bool vec_w = (K % Vec16<T>::N == 0) && (w_stride % Vec16<T>::N == 0) && ((reinterpret_cast<uintptr_t>(W) & 15u) == 0);
 
     typename MF::Acc acc[TM][TN];
 #pragma unroll
@@ -57,17 +105,9 @@ __global__ void __launch_bounds__(256) linear_kernel(const T* __restrict__ in, i
     for (int k0 = 0; k0 < K; k0 += KC) {
         const int kc = (K - k0) < KC ? (K - k0) : KC;
         __syncthreads();
-        // stage A chunk [BM x KC] and W chunk [BN x KC], zero padded
-        for (int idx = tid; idx < BM * KC; idx += 256) {
-            const int r = idx / KC, c = idx - r * KC;
-            const int64_t gr = row0 + r;
-            As[r * LDP + c] = (gr < B && c < kc) ? in[gr * in_stride + k0 + c] : T(0);
-        }
-        for (int idx = tid; idx < BN * KC; idx += 256) {
-            const int r = idx / KC, c = idx - r * KC;
-            const int gc = col0 + r;
-            Ws[r * LDP + c] = (gc < N && c < kc) ? W[(int64_t)gc * w_stride + k0 + c] : T(0);
-        }
+        // stage the A chunk [BM x KC] and the W chunk [BN x KC] (zero padded); all global loads of a thread are issued before its LDS writes
+        stage_chunk<T, BM>(As, in, in_stride, row0, B, k0, kc, tid, vec_in);
+        stage_chunk<T, BN>(Ws, W, w_stride, (int64_t)col0, (int64_t)N, k0, kc, tid, vec_w);
         __syncthreads();
         const int ksteps = (kc + KS - 1) / KS;
         for (int s = 0; s < ksteps; ++s) {
@@ -108,7 +148,9 @@ static int linear(const T* in, int64_t in_stride, const T* W, int64_t w_stride, 
                   int64_t out_stride, void* stream) {
     if (!in || !W || !out || K < 1 || N < 1 || B < 0 || (act != 0 && act != 1)) return JF_ERR_BADARG;
     if (B == 0) return JF_OK;
-    dim3 grid((unsigned)((B + BM - 1) / BM), (unsigned)((N + BN - 1) / BN));
+    const int64_t blocks = ((B + BM - 1) / BM) * ((N + BN - 1) / BN);
+    if (blocks > 0x7fffffffLL) return JF_ERR_UNSUPPORTED;
+    dim3 grid((unsigned)blocks);
     hipLaunchKernelGGL(linear_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, in, in_stride, W, w_stride, bias, B, (int)K, (int)N, (int)act, out,
                        out_stride);
     return check_launch();
