@@ -88,6 +88,7 @@ _SIGNATURES = {
     "jf_gf_chain_fwd": [_P, _I64, _P, _P, _I64, _I32, _I64, _I32, _I32, ctypes.POINTER(jf_gf_layer), _P, _I64, _P, _P, _P],
     "jf_linear": [_P, _I64, _P, _I64, _P, _I64, _I32, _I32, _I32, _P, _I64, _P],
     "jf_normal_logp": [_P, _I64, _I64, _I32, _P, _P, _P],
+    "jf_mlp2": [_P, _I64, _P, _I64, _P, _P, _I64, _P, _I64, _I32, _I32, _I32, _P, _I64, _P],
     "jf_sphere_to_embedding": [_P, _I64, _P, _I64, _I32, _P, _I64, _P, _P],
     "jf_sphere_from_embedding": [_P, _I64, _P, _I64, _I32, _P, _I64, _P, _P],
 }
@@ -354,3 +355,24 @@ def sphere_embedding(x, log_det, dim, to_embedding):
     name = ("jf_sphere_to_embedding" if to_embedding else "jf_sphere_from_embedding") + suf
     _launch(name, "", (_ptr(x), x.stride(0), _ptr(ld_in), B, dim, _ptr(out), out.stride(0), _ptr(ld_out), _stream()))
     return out, (ld_out if want_ld else log_det)
+
+
+MLP2_MAX_IN, MLP2_MAX_HIDDEN = 32, 128
+
+
+def mlp2(inp, w1, b1, w2, b2, out=None):
+    """tanh(inp @ w1^T + b1) @ w2^T + b2 in one launch (hidden activations stay in LDS)."""
+    require_device(inp, w1, b1, w2, b2, out)
+    inp, w1, w2 = _rowmajor(inp), _rowmajor(w1), _rowmajor(w2)
+    B, K1 = inp.shape
+    H, N = w1.shape[0], w2.shape[0]
+    if w1.shape[1] != K1 or w2.shape[1] != H or b1.shape[0] != H or b2.shape[0] != N:
+        raise ValueError("mlp2: inconsistent shapes")
+    if any(t.dtype != inp.dtype for t in (w1, b1, w2, b2)):
+        raise TypeError("mlp2: dtype mismatch")
+    if out is None:
+        out = torch.empty((B, N), dtype=inp.dtype, device=inp.device)
+    _launch("jf_mlp2" + _suffix(inp), "K%d_H%d_N%d" % (K1, H, N),
+            (_ptr(inp), inp.stride(0), _ptr(w1), w1.stride(0), _ptr(b1.contiguous()), _ptr(w2), w2.stride(0), _ptr(b2.contiguous()), B, K1, H, N,
+             _ptr(out), out.stride(0), _stream()))
+    return out

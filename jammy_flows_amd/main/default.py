@@ -28,6 +28,13 @@ class HipLinearStack(nn.Sequential):
     def forward(self, x):
         _hip.require_device(x)
         mods = list(self)
+        if (len(mods) == 3 and isinstance(mods[1], nn.Tanh) and mods[0].in_features <= _hip.MLP2_MAX_IN
+                and mods[0].out_features <= _hip.MLP2_MAX_HIDDEN):
+            # Linear-tanh-Linear (the reference's default "128"): one fused launch, hidden activations never leave LDS
+            ps = [mods[0].weight, mods[0].bias, mods[2].weight, mods[2].bias]
+            if ps[0].dtype != x.dtype:
+                ps = [p.to(x.dtype) for p in ps]
+            return _hip.mlp2(x, *[p.detach() for p in ps])
         i = 0
         while i < len(mods):
             lin = mods[i]

@@ -20,6 +20,17 @@ __global__ void __launch_bounds__(64) k(const float4* __restrict__ src, float* _
             __syncthreads();
             const float4 t = lds[tid * 34 + (tid & 31)];
             acc += t.x + t.w;
+        } else if (MODE == 2) {      // strided row segments (34 x 16 B of every 137 x 16 B row), straight-line loads, summed
+            float4 s = {0, 0, 0, 0};
+            const float4* q = src + (long)blockIdx.x * 64 * 137 + layer * 34;
+            int r = tid / 34, c = tid - r * 34;
+#pragma unroll
+            for (int i = 0; i < n; ++i) {
+                const float4 v = q[r * 137 + c];
+                s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+                r += 1; c += 30; if (c >= 34) { c -= 34; r += 1; }
+            }
+            acc += s.x + s.y + s.z + s.w;
         } else {
             float4 s = {0, 0, 0, 0};
 #pragma unroll
@@ -52,7 +63,8 @@ int main() {
     for (size_t lds : {(size_t)35840, (size_t)17920 * 1}) {
         float a = timeit([&] { hipLaunchKernelGGL((k<0>), dim3(nblk), dim3(64), lds, 0, src, out); });
         float b = timeit([&] { hipLaunchKernelGGL((k<1>), dim3(nblk), dim3(64), lds, 0, src, out); });
-        printf("LDS %zu: LDS-DMA %.3f ms (%.0f GB/s) | register read-sum %.3f ms (%.0f GB/s)\n", lds, a, gb / a * 1e3, b, gb / b * 1e3);
+        float c2 = timeit([&] { hipLaunchKernelGGL((k<2>), dim3(nblk), dim3(64), lds, 0, src, out); });
+        printf("LDS %zu: LDS-DMA %.3f ms (%.0f GB/s) | register read-sum %.3f ms (%.0f GB/s) | strided row segments %.3f ms (%.0f GB/s)\n", lds, a, gb / a * 1e3, b, gb / b * 1e3, c2, gb / c2 * 1e3);
     }
     float c = timeit([&] { hipLaunchKernelGGL(kread, dim3(2048), dim3(256), 0, 0, src, out, B * 137); });
     printf("grid-stride float4 read, 2048x256: %.3f ms (%.0f GB/s)\n", c, B * 137.0 * 16 / 1e9 / c * 1e3);
