@@ -3,15 +3,18 @@
 //   jf_gf_chain_inv_*  log-prob direction   (gaussianization_flow.py:995-1114 per layer, main/default.py:998-1031 loop)
 //   jf_gf_chain_fwd_*  sampling direction   (gaussianization_flow.py:911-989,  main/default.py:1482-1506 loop)
 //
+// Work distribution (jf_gf_group.h): lane = (row, coordinate); the G = next-power-of-two(D) lanes of a group own one row, a wave
+// owns 64/G rows.  Per-coordinate arithmetic is scalar code per lane, reductions over the coordinates are DPP butterflies.
+//
 // Two parameter regimes:
 //   broadcast (param_batch == 1, unconditional first sub-pdf): 256-thread workgroups; the chain's derived parameters
-//       (<= a few KB) are prepared once per workgroup in LDS and read by every lane as LDS broadcasts.
-//   per-sample (param_batch == B, the autoregressive / conditional blocks): one wave per workgroup; each layer's slab of
-//       64 rows x n_params is fetched from HBM with coalesced 16-byte loads into an LDS tile (row stride = 4*odd dwords, so the
-//       lane-per-row ds_read_b128 that follow are bank-conflict free), derived in place, then consumed lane-per-row.
-//       This is the "coalesced HBM reads of the per-sample autoregressive parameter blocks" path; its HBM traffic is the
-//       algorithmic minimum (every parameter byte is read exactly once).
-#include "jf_gf.h"
+//       (<= a few KB) are prepared once per workgroup in LDS (one wave per layer) and the workgroup then walks several row tiles.
+//   per-sample (param_batch == B, the autoregressive / conditional blocks): one wave per workgroup, no workgroup barrier coupling
+//       different waves; each layer's slab of (64/G rows) x n_params is fetched from HBM with coalesced 16-byte loads issued back to
+//       back (stage_rows) into an LDS tile whose row stride is 4*odd dwords, then read by the lanes of each row.  A wave's tile is a few
+//       KB, so 16+ waves per CU are resident and the HBM latency of one wave's slab is covered by the arithmetic of the others.
+//       HBM traffic is the algorithmic minimum (every parameter byte is read exactly once).
+#include "jf_gf_group.h"
 
 namespace jf {
 
@@ -20,8 +23,9 @@ template <typename T> struct GfChainArgs {
     const T* ld_in;
     const T* params; int64_t ps;
     int64_t B;
+    int D;
     int n_layers;
-    int rows_per_block;      // per-sample kernels: rows (<= 64) handled by one wave
+    int tiles_per_block;     // broadcast kernels: row tiles walked by one workgroup
     int tile_stride;         // per-sample: LDS row stride (elements); broadcast: row capacity per layer
     GfLayerDev<T> L[JF_MAX_CHAIN];
     T* x_out; int64_t xos;
@@ -30,138 +34,94 @@ template <typename T> struct GfChainArgs {
     int32_t* status;
 };
 
-template <typename T, int D> __device__ __forceinline__ void load_x(const T* __restrict__ p, int64_t stride, int64_t row, T (&x)[D]) {
-    const T* r = p + row * stride;
-#pragma unroll
-    for (int d = 0; d < D; ++d) x[d] = r[d];
-}
-template <typename T, int D> __device__ __forceinline__ void store_x(T* __restrict__ p, int64_t stride, int64_t row, const T (&x)[D]) {
-    T* r = p + row * stride;
-#pragma unroll
-    for (int d = 0; d < D; ++d) r[d] = x[d];
-}
+template <int G> struct Log2 { static constexpr int v = (G == 1) ? 0 : (G == 2) ? 1 : (G == 4) ? 2 : 3; };
 
-// cooperative derive of broadcast rows: thread t handles column t (t < D) and reflection t (t < hh) of every layer
-template <typename T> __device__ __forceinline__ void derive_broadcast(T* lds, const GfChainArgs<T>& a, int D) {
-    const int tid = threadIdx.x;
+// broadcast regime: raw rows -> LDS, then wave w derives layers w, w+4, ... (columns on lanes 0..D-1, reflections on lanes 32..)
+template <typename T> __device__ __forceinline__ void derive_broadcast(T* lds, const GfChainArgs<T>& a) {
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     for (int l = 0; l < a.n_layers; ++l) {
         const GfLayerDev<T> o = a.L[l];
         for (int j = tid; j < o.n_params; j += blockDim.x) lds[l * a.tile_stride + j] = a.params[o.col0 + j];
     }
     __syncthreads();
-    for (int l = 0; l < a.n_layers; ++l) {
-        const GfLayerDev<T> o = a.L[l];
+    for (int l = wave; l < a.n_layers; l += 4) {
+        const GfLayerDev<T> o = a.L[l];      // wave-uniform index
         T* row = lds + l * a.tile_stride;
-        if (tid < D) gf_derive_column<T>(row, o, D, tid);
-        else if (tid >= 64 && tid - 64 < o.hh) gf_derive_reflection<T>(row, o, D, tid - 64);
+        if (lane < a.D) gf_derive_column<T>(row, o, a.D, lane);
+        else if (lane >= 32 && lane - 32 < o.hh) gf_derive_reflection<T>(row, o, a.D, lane - 32);
     }
     __syncthreads();
 }
 
-// stage + derive the slab of one layer for the rows of this wave (per-sample regime)
-template <typename T, int D, bool DERIVE> __device__ __forceinline__ const T* stage_layer(T* lds, const GfChainArgs<T>& a, const GfLayerDev<T>& o, int64_t row0,
-                                                             int valid_rows, bool lane_active) {
-    const int tid = threadIdx.x;
-    __syncthreads();   // previous layer's reads are done
-    stage_rows<T, 18>(lds, a.tile_stride, a.params + row0 * a.ps + o.col0, a.ps, o.n_params, a.rows_per_block, valid_rows, tid, blockDim.x,
-                      o.vec_ok != 0);
-    __syncthreads();
-    T* row = lds + (lane_active ? tid : 0) * a.tile_stride;   // idle lanes (tid >= rows_per_block) shadow row 0, read-only
-    if constexpr (DERIVE) {
-        if (lane_active) gf_derive_row<T, D>(row, o);
-    }
-    return row;
-}
-
-template <typename T, int D, bool BCAST>
-__global__ void __launch_bounds__(BCAST ? 256 : 64) gf_chain_inv_kernel(const GfChainArgs<T> a) {
+template <typename T, int G, bool BCAST, bool FWD>
+__global__ void __launch_bounds__(BCAST ? 256 : 64, sizeof(T) == 8 ? 2 : 4) gf_chain_kernel(const GfChainArgs<T> a) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     T* lds = reinterpret_cast<T*>(smem_raw);
+    constexpr int NT = BCAST ? 256 : 64;
+    constexpr int R = NT / G;                           // rows per tile
     const int tid = threadIdx.x;
-    const int rpb = BCAST ? (int)blockDim.x : a.rows_per_block;
-    const int64_t row0 = (int64_t)blockIdx.x * rpb;
-    const int64_t row = row0 + tid;
-    const bool active = (tid < rpb) && (row < a.B);
-    const int64_t rrow = active ? row : a.B - 1;
-    const int valid_rows = (int)((a.B - row0) < rpb ? (a.B - row0) : rpb);
+    const int g = tid & (G - 1), r = tid >> Log2<G>::v;
+    const int D = a.D;
+    const bool live = g < D, leader = g == 0;
+    const int d = live ? g : D - 1;
+    if constexpr (BCAST) derive_broadcast<T>(lds, a);
 
-    T x[D], y[D];
-    load_x<T, D>(a.x, a.xs, rrow, x);
-    T ld = a.ld_in ? a.ld_in[rrow] : T(0);
-    if constexpr (BCAST) derive_broadcast<T>(lds, a, D);
+    const int tiles = BCAST ? a.tiles_per_block : 1;
+    for (int t = 0; t < tiles; ++t) {
+        const int64_t row0 = ((int64_t)blockIdx.x * tiles + t) * R;
+        if (row0 >= a.B) break;                          // block-uniform
+        const int64_t row = row0 + r;
+        const bool row_valid = row < a.B;
+        const int64_t rrow = row_valid ? row : a.B - 1;
+        const int valid_rows = (int)((a.B - row0) < R ? (a.B - row0) : R);
 
-    for (int l = a.n_layers - 1; l >= 0; --l) {
-        const GfLayerDev<T> o = a.L[l];      // uniform index: scalar loads from the kernarg segment
-        const T* prow;
-        if constexpr (BCAST) prow = lds + l * a.tile_stride;
-        else prow = stage_layer<T, D, false>(lds, a, o, row0, valid_rows, tid < rpb);     // raw rows: regulation fused into the mixture loop
-        if (o.model_offset) {
-#pragma unroll
-            for (int d = 0; d < D; ++d) x[d] -= prow[d];                 // euclidean_base.py:40-45
+        T x = a.x[rrow * a.xs + d];
+        T ld = a.ld_in ? a.ld_in[rrow] : T(0);
+
+        for (int li = 0; li < a.n_layers; ++li) {
+            const int l = FWD ? li : a.n_layers - 1 - li;
+            const GfLayerDev<T> o = a.L[l];              // uniform index: scalar loads from the kernarg segment
+            const T* p;
+            if constexpr (BCAST) {
+                p = lds + l * a.tile_stride + d;
+            } else {
+                __syncthreads();                         // single-wave workgroup: orders the previous layer's LDS reads before the refill
+                stage_rows<T>(lds, a.tile_stride, a.params + row0 * a.ps + o.col0, a.ps, o.n_params, R, valid_rows, tid, NT, o.vec_ok != 0);
+                __syncthreads();
+                if constexpr (FWD) {                     // 45 evaluations per layer follow: regulate the row once, in place
+                    gfg_derive<T, G>(lds + r * a.tile_stride, o, D, g);
+                    __syncthreads();
+                }
+                p = lds + r * a.tile_stride + d;
+            }
+            if constexpr (!FWD) {
+                if (o.model_offset) x -= p[0];                                               // euclidean_base.py:40-45
+                x = gfg_rotate_inv<T, G, !BCAST>(p, o, D, live, x);
+                const MixQ<T> q = BCAST ? gfg_mixture<T>(p, o, D, x) : gfg_mixture_raw<T>(p, o, D, x);
+                const IcdfOut<T> s = gf_icdf<T>(o.inv_type, q);
+                x = s.y;
+                ld += group_sum<T, G>(live ? s.logd : T(0));
+            } else {
+                x = gfg_solve<T, G>(p, o, D, live, x, row_valid, leader, a.status);
+                const MixQ<T> q = gfg_mixture<T>(p, o, D, x);                                // gaussianization_flow.py:922-924
+                ld -= group_sum<T, G>(live ? gf_icdf<T>(o.inv_type, q).logd : T(0));
+                x = gfg_rotate_fwd<T, G, false>(p, o, D, live, x);
+                if (o.model_offset) x += p[0];                                               // euclidean_base.py:63-68
+            }
         }
-        if constexpr (BCAST) {
-            gf_rotate_inv<T, D>(prow, o, x);
-            ld += gf_stage<T, D>(prow, o, x, y);
+        if (row_valid && live) a.x_out[row * a.xos + d] = x;
+        if constexpr (!FWD) {
+            T s = T(0);
+            if (a.blp_out) s = group_sum<T, G>(live ? T(-0.5) * x * x - M<T>::HALF_LN_2PI : T(0));
+            if (row_valid && leader) {
+                a.ld_out[row] = ld;
+                if (a.blp_out) a.blp_out[row] = s + (a.blp_in ? a.blp_in[row] : T(0));
+            }
+            const T bad = group_max<T, G>((live && !M<T>::finite(x)) ? T(1) : T(0));
+            status_add(a.status, JF_STATUS_NONFINITE, row_valid && leader && (bad > T(0) || !M<T>::finite(ld)));
         } else {
-            gf_rotate_inv_raw<T, D>(prow, o, x);
-            ld += gf_stage_raw<T, D>(prow, o, x, y);
+            if (row_valid && leader) a.ld_out[row] = ld;
         }
-#pragma unroll
-        for (int d = 0; d < D; ++d) x[d] = y[d];
-    }
-    if (active) {
-        store_x<T, D>(a.x_out, a.xos, row, x);
-        a.ld_out[row] = ld;
-        if (a.blp_out) {
-            T s = a.blp_in ? a.blp_in[row] : T(0);
-#pragma unroll
-            for (int d = 0; d < D; ++d) s += T(-0.5) * x[d] * x[d] - M<T>::HALF_LN_2PI;
-            a.blp_out[row] = s;
-        }
-    }
-    bool bad = !M<T>::finite(ld);
-#pragma unroll
-    for (int d = 0; d < D; ++d) bad = bad || !M<T>::finite(x[d]);
-    status_add(a.status, JF_STATUS_NONFINITE, active && bad);
-}
-
-template <typename T, int D, bool BCAST>
-__global__ void __launch_bounds__(BCAST ? 256 : 64) gf_chain_fwd_kernel(const GfChainArgs<T> a) {
-    extern __shared__ __align__(16) unsigned char smem_raw[];
-    T* lds = reinterpret_cast<T*>(smem_raw);
-    const int tid = threadIdx.x;
-    const int rpb = BCAST ? (int)blockDim.x : a.rows_per_block;
-    const int64_t row0 = (int64_t)blockIdx.x * rpb;
-    const int64_t row = row0 + tid;
-    const bool active = (tid < rpb) && (row < a.B);
-    const int64_t rrow = active ? row : a.B - 1;
-    const int valid_rows = (int)((a.B - row0) < rpb ? (a.B - row0) : rpb);
-
-    T z[D], x[D], y[D], logd[D];
-    load_x<T, D>(a.x, a.xs, rrow, z);
-    T ld = a.ld_in ? a.ld_in[rrow] : T(0);
-    if constexpr (BCAST) derive_broadcast<T>(lds, a, D);
-
-    for (int l = 0; l < a.n_layers; ++l) {
-        const GfLayerDev<T> o = a.L[l];
-        const T* prow;
-        if constexpr (BCAST) prow = lds + l * a.tile_stride;
-        else prow = stage_layer<T, D, true>(lds, a, o, row0, valid_rows, tid < rpb);
-        gf_solve<T, D>(prow, o, z, x, active, a.status);
-        gf_stage_deriv<T, D>(prow, o, x, y, logd);                       // gaussianization_flow.py:922-924
-#pragma unroll
-        for (int d = 0; d < D; ++d) ld -= logd[d];
-        gf_rotate_fwd<T, D>(prow, o, x);
-        if (o.model_offset) {
-#pragma unroll
-            for (int d = 0; d < D; ++d) x[d] += prow[d];                 // euclidean_base.py:63-68
-        }
-#pragma unroll
-        for (int d = 0; d < D; ++d) z[d] = x[d];
-    }
-    if (active) {
-        store_x<T, D>(a.x_out, a.xos, row, z);
-        a.ld_out[row] = ld;
     }
 }
 
@@ -170,9 +130,12 @@ __global__ void __launch_bounds__(BCAST ? 256 : 64) gf_chain_fwd_kernel(const Gf
 // ----------------------------------------------------------------------------------------------------------
 constexpr int LDS_LIMIT = 160 * 1024;
 
+static inline int group_width(int D) { return D <= 1 ? 1 : D <= 2 ? 2 : D <= 4 ? 4 : 8; }
+
 template <typename T> static int fill_args(GfChainArgs<T>& a, const T* params, int64_t ps, int32_t pb, int64_t B, int32_t D, int32_t n_layers,
                                            const jf_gf_layer* layers, size_t& lds_bytes, bool& bcast) {
     if (n_layers < 1 || n_layers > JF_MAX_CHAIN || D < 1 || B < 0 || layers == nullptr) return JF_ERR_BADARG;
+    if (D > 8) return JF_ERR_UNSUPPORTED;
     if (pb != 1 && pb != B) return JF_ERR_BADARG;
     bcast = (pb == 1);
     int col = 0, maxp = 0;
@@ -200,49 +163,45 @@ template <typename T> static int fill_args(GfChainArgs<T>& a, const T* params, i
         col += o.n_params;
         if (o.n_params > maxp) maxp = o.n_params;
     }
-    a.params = params; a.ps = ps; a.B = B; a.n_layers = n_layers;
+    a.params = params; a.ps = ps; a.B = B; a.n_layers = n_layers; a.D = D;
+    a.tile_stride = padded_stride<T>(maxp);
+    const int G = group_width(D);
     if (bcast) {
-        a.tile_stride = padded_stride<T>(maxp);
-        a.rows_per_block = 256;
         lds_bytes = (size_t)n_layers * a.tile_stride * sizeof(T);
+        const int64_t n_tiles = (B + 256 / G - 1) / (256 / G);
+        int tpb = (int)(n_tiles / 4096);                 // keep >= ~16 workgroups per CU in the grid, <= 8 tiles per workgroup
+        a.tiles_per_block = tpb < 1 ? 1 : tpb > 8 ? 8 : tpb;
     } else {
-        a.tile_stride = padded_stride<T>(maxp);
-        int rows = 64;
-        while (rows > 8 && (size_t)rows * a.tile_stride * sizeof(T) > (size_t)LDS_LIMIT) rows >>= 1;
-        a.rows_per_block = rows;
-        lds_bytes = (size_t)rows * a.tile_stride * sizeof(T);
+        lds_bytes = (size_t)(64 / G) * a.tile_stride * sizeof(T);
+        a.tiles_per_block = 1;
     }
     if (lds_bytes > (size_t)LDS_LIMIT) return JF_ERR_UNSUPPORTED;
     return JF_OK;
 }
 
-template <typename T, int D, bool FWD> static int launch_d(const GfChainArgs<T>& a, bool bcast, size_t lds_bytes, hipStream_t st) {
-    if (a.B == 0) return JF_OK;
+template <typename T, int G, bool FWD> static int launch_g(const GfChainArgs<T>& a, bool bcast, size_t lds_bytes, hipStream_t st) {
     if (bcast) {
-        auto k = FWD ? gf_chain_fwd_kernel<T, D, true> : gf_chain_inv_kernel<T, D, true>;
+        auto k = gf_chain_kernel<T, G, true, FWD>;
         if (lds_bytes > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        const unsigned grid = (unsigned)((a.B + 255) / 256);
+        const int64_t rows_per_block = (int64_t)(256 / G) * a.tiles_per_block;
+        const unsigned grid = (unsigned)((a.B + rows_per_block - 1) / rows_per_block);
         hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds_bytes, st, a);
     } else {
-        auto k = FWD ? gf_chain_fwd_kernel<T, D, false> : gf_chain_inv_kernel<T, D, false>;
+        auto k = gf_chain_kernel<T, G, false, FWD>;
         if (lds_bytes > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        const unsigned grid = (unsigned)((a.B + a.rows_per_block - 1) / a.rows_per_block);
+        const unsigned grid = (unsigned)((a.B + 64 / G - 1) / (64 / G));
         hipLaunchKernelGGL(k, dim3(grid), dim3(64), lds_bytes, st, a);
     }
     return check_launch();
 }
 
 template <typename T, bool FWD> static int launch(const GfChainArgs<T>& a, int D, bool bcast, size_t lds_bytes, hipStream_t st) {
-    switch (D) {
-        case 1: return launch_d<T, 1, FWD>(a, bcast, lds_bytes, st);
-        case 2: return launch_d<T, 2, FWD>(a, bcast, lds_bytes, st);
-        case 3: return launch_d<T, 3, FWD>(a, bcast, lds_bytes, st);
-        case 4: return launch_d<T, 4, FWD>(a, bcast, lds_bytes, st);
-        case 5: return launch_d<T, 5, FWD>(a, bcast, lds_bytes, st);
-        case 6: return launch_d<T, 6, FWD>(a, bcast, lds_bytes, st);
-        case 7: return launch_d<T, 7, FWD>(a, bcast, lds_bytes, st);
-        case 8: return launch_d<T, 8, FWD>(a, bcast, lds_bytes, st);
-        default: return JF_ERR_UNSUPPORTED;
+    if (a.B == 0) return JF_OK;
+    switch (group_width(D)) {
+        case 1: return launch_g<T, 1, FWD>(a, bcast, lds_bytes, st);
+        case 2: return launch_g<T, 2, FWD>(a, bcast, lds_bytes, st);
+        case 4: return launch_g<T, 4, FWD>(a, bcast, lds_bytes, st);
+        default: return launch_g<T, 8, FWD>(a, bcast, lds_bytes, st);
     }
 }
 

@@ -34,8 +34,8 @@ template <typename T> __host__ __device__ inline int padded_stride(int n) {
 // at most a few rows.  Falls back to element-wise copies when the slab is not 16-byte aligned.
 // `nthreads` threads (tid in [0,nthreads)) cooperate; rows beyond `valid_rows` replicate the last valid row.
 // ---------------------------------------------------------------------------------------------
-// U = loads in flight per lane.  Measured on MI355X (scripts/probe/stream2.hip): one wave per SIMD with ~34 x 16 B per lane in flight
-// streams at 6.2 TB/s, so U is chosen to cover (half of) a layer slab.  A batch is straight-line code: piece coordinates advance
+// Loads are issued in batches of up to 16 per lane (measured on MI355X, scripts/probe/stream2.hip: HBM streams at full rate once a few
+// tens of 16-byte loads per lane are in flight per SIMD, which occupancy supplies here).  A batch is straight-line code: piece coordinates advance
 // incrementally (no per-piece division), out-of-range lanes re-read a valid piece and only skip the LDS write, so the U
 // global_load_dwordx4 are issued back to back and waited for once (any branch between the loads makes hipcc wait after each of them).
 template <typename T> struct StageCursor {
@@ -44,37 +44,57 @@ template <typename T> struct StageCursor {
     int r, c, dq, dr, it;
 };
 
-template <typename T, int U, bool VEC> __device__ __forceinline__ void stage_batch(StageCursor<T>& s) {
-    constexpr int N = Vec16<T>::N;
-    using V = typename Vec16<T>::type;
-    using E = typename std::conditional<VEC, V, T>::type;
-    constexpr int W = VEC ? N : 1;
-    E v[U];
-    int off[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
+// One batch = U loads then U LDS writes, written as a template recursion that carries the loaded pieces as a parameter pack, so that
+// every piece lives in a plain local: an array `E v[U]` is not promoted to registers by hipcc here and bounces through scratch memory.
+template <typename E> struct StagePiece { E v; int off; };
+
+template <typename T, int U, bool VEC> struct StageRec {
+    template <typename... P> static __device__ __forceinline__ void run(StageCursor<T>& s, P... done) {
+        constexpr int N = Vec16<T>::N;
+        using V = typename Vec16<T>::type;
+        using E = typename std::conditional<VEC, V, T>::type;
+        constexpr int W = VEC ? N : 1;
         // pieces past the end of the slab (last batch only) fall on row >= rows: they are clamped to the last row and simply rewrite one
         // of its pieces with the same data -- no predicate, hence no branch for the compiler to sink the load into
         const int rr = s.r < s.rows ? s.r : s.rows - 1;
         const int rs = rr < s.last_row ? rr : s.last_row;
-        v[u] = *reinterpret_cast<const E*>(s.src + (int64_t)rs * s.src_stride + s.c * W);
-        off[u] = rr * s.tile_stride + s.c * W;
+        StagePiece<E> p;
+        p.v = *reinterpret_cast<const E*>(s.src + (int64_t)rs * s.src_stride + s.c * W);
+        p.off = rr * s.tile_stride + s.c * W;
         s.r += s.dq; s.c += s.dr;
         if (s.c >= s.nv) { s.c -= s.nv; s.r += 1; }
+        StageRec<T, U - 1, VEC>::run(s, done..., p);
     }
-    asm volatile("" ::: "memory");   // keep every load of the batch ahead of the first LDS write (the scheduler otherwise caps ~8 in flight)
-#pragma unroll
-    for (int u = 0; u < U; ++u) *reinterpret_cast<E*>(s.tile + off[u]) = v[u];
+};
+template <typename T, bool VEC> struct StageRec<T, 0, VEC> {
+    template <typename... P> static __device__ __forceinline__ void run(StageCursor<T>& s, P... done) {
+        __builtin_amdgcn_sched_barrier(0);   // keep every load of the batch ahead of the first LDS write (the scheduler otherwise caps ~8 in flight)
+        ((*reinterpret_cast<decltype(done.v)*>(s.tile + done.off) = done.v), ...);   // in load order: the waits count down vmcnt(U-1) .. vmcnt(0)
+    }
+};
+template <typename T, int U, bool VEC> __device__ __forceinline__ void stage_batch(StageCursor<T>& s) {
+    StageRec<T, U, VEC>::run(s);
     s.it += U;
 }
 
-template <typename T, int U, bool VEC> __device__ __forceinline__ void stage_all(StageCursor<T>& s, int iters) {
-    while (s.it + U <= iters) stage_batch<T, U, VEC>(s);
-    if constexpr (U > 4) { while (s.it + 4 <= iters) stage_batch<T, 4, VEC>(s); }
-    while (s.it < iters) stage_batch<T, 1, VEC>(s);
+// All pieces of a slab: batches of 16 while more than 16 remain, then ONE batch sized to the remainder rounded up to even (the extra
+// piece, if any, is a clamped duplicate), so a slab of <= 16 pieces per lane costs a single HBM round trip.
+template <typename T, bool VEC> __device__ __forceinline__ void stage_all(StageCursor<T>& s, int iters) {
+    while (iters - s.it > 16) stage_batch<T, 16, VEC>(s);
+    switch ((iters - s.it + 1) >> 1) {
+        case 1: stage_batch<T, 2, VEC>(s); break;
+        case 2: stage_batch<T, 4, VEC>(s); break;
+        case 3: stage_batch<T, 6, VEC>(s); break;
+        case 4: stage_batch<T, 8, VEC>(s); break;
+        case 5: stage_batch<T, 10, VEC>(s); break;
+        case 6: stage_batch<T, 12, VEC>(s); break;
+        case 7: stage_batch<T, 14, VEC>(s); break;
+        case 8: stage_batch<T, 16, VEC>(s); break;
+        default: break;
+    }
 }
 
-template <typename T, int U = 8>
+template <typename T>
 __device__ __forceinline__ void stage_rows(T* __restrict__ tile, int tile_stride, const T* __restrict__ src, int64_t src_stride,
                                            int ncols, int rows, int valid_rows, int tid, int nthreads, bool vec_ok) {
     constexpr int N = Vec16<T>::N;
@@ -85,8 +105,8 @@ __device__ __forceinline__ void stage_rows(T* __restrict__ tile, int tile_stride
     s.r = tid / s.nv; s.c = tid - s.r * s.nv;              // piece idx = it * nthreads + tid  ->  (row r, piece c)
     s.dq = nthreads / s.nv; s.dr = nthreads - s.dq * s.nv; s.it = 0;
     const int iters = (s.total + nthreads - 1) / nthreads;
-    if (vec_ok) stage_all<T, U, true>(s, iters);
-    else stage_all<T, U, false>(s, iters);
+    if (vec_ok) stage_all<T, true>(s, iters);
+    else stage_all<T, false>(s, iters);
 }
 
 template <typename T> __host__ inline bool aligned16(const void* p, int64_t stride_elems, int64_t col0_elems) {

@@ -376,6 +376,20 @@ template <typename T> __device__ __forceinline__ T gf_inverse_cdf(int inv_type, 
     return right ? tot : -tot;
 }
 
+// Call form used by the lane = (row, coordinate) kernels.  In float64 the stage is an out-of-line function: inlined, the several dozen
+// double-precision polynomial constants of erfcinv / log / log1p / sqrt are hoisted out of the layer loop and pin > 250 VGPRs.
+template <typename T> struct IcdfOut { T y, logd; };
+template <typename T> __device__ __forceinline__ IcdfOut<T> gf_icdf(int inv_type, MixQ<T> q) {
+    IcdfOut<T> r;
+    r.y = gf_inverse_cdf<T>(inv_type, q, r.logd);
+    return r;
+}
+template <> __device__ __noinline__ IcdfOut<double> gf_icdf<double>(int inv_type, MixQ<double> q) {
+    IcdfOut<double> r;
+    r.y = gf_inverse_cdf<double>(inv_type, q, r.logd);
+    return r;
+}
+
 // one full layer evaluation at x (already offset-shifted and rotated): y[d], sum_d log dy/dx
 template <typename T, int D> __device__ __forceinline__ T gf_stage(const T* __restrict__ row, const GfLayerDev<T>& o, const T (&x)[D], T (&y)[D]) {
     MixQ<T> q[D];
