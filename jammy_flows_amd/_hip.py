@@ -371,7 +371,10 @@ def mlp2(inp, w1, b1, w2, b2, out=None):
     if any(t.dtype != inp.dtype for t in (w1, b1, w2, b2)):
         raise TypeError("mlp2: dtype mismatch")
     if out is None:
-        out = torch.empty((B, N), dtype=inp.dtype, device=inp.device)
+        # rows padded to whole 128-byte lines: every 64-lane result store of the kernel then covers full, aligned HBM lines
+        # (an unpadded 548-float row makes every line at a tile boundary a partial write); the pad columns are never touched
+        line = 128 // inp.element_size()
+        out = torch.empty((B, (N + line - 1) // line * line), dtype=inp.dtype, device=inp.device)[:, :N]
     _launch("jf_mlp2" + _suffix(inp), "K%d_H%d_N%d" % (K1, H, N),
             (_ptr(inp), inp.stride(0), _ptr(w1), w1.stride(0), _ptr(b1.contiguous()), _ptr(w2), w2.stride(0), _ptr(b2.contiguous()), B, K1, H, N,
              _ptr(out), out.stride(0), _stream()))

@@ -18,13 +18,13 @@ using f64x4 = __attribute__((ext_vector_type(4))) double;
 
 template <typename T> struct Mfma;
 template <> struct Mfma<float> {
-    static constexpr int MT = 32, KS = 2, NREG = 16;
+    static constexpr int MT = 32, KS = 2, NREG = 16, RUN = 4;   // RUN: consecutive registers hold consecutive rows
     using Acc = f32x16;
     static __device__ __forceinline__ Acc mma(float a, float b, Acc c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
     static __device__ __forceinline__ int row_of(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
 };
 template <> struct Mfma<double> {
-    static constexpr int MT = 16, KS = 4, NREG = 4;
+    static constexpr int MT = 16, KS = 4, NREG = 4, RUN = 1;
     using Acc = f64x4;
     static __device__ __forceinline__ Acc mma(double a, double b, Acc c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
     static __device__ __forceinline__ int row_of(int reg, int lane) { return (lane >> 4) + 4 * reg; }
@@ -152,147 +152,212 @@ __global__ void __launch_bounds__(256) linear_kernel(const T* __restrict__ in, i
 
 // ------------------------------------------------------------------------------------------------------------------
 // Fused two-layer amortisation MLP:  out = (tanh(in @ W1^T + b1)) @ W2^T + b2      (main/default.py:656-670 with one hidden layer)
-// The hidden activations of a row tile stay in LDS (never written to HBM); W2 is streamed through LDS in 64-column tiles with the
-// next tile prefetched into registers while the current one feeds the MFMAs.  Requires K1 <= 64 and H in {32, 64, 96, 128}.
+//
+// Workgroup = 4 waves; wave w owns MT rows (f32: 32, f64: 16) of the row tile and keeps their hidden activations IN REGISTERS for the
+// whole kernel.  Both products are computed transposed (h^T = W1 x^T, out^T = W2 h^T): the MFMA result layout of the first
+// (lane = row, registers = hidden units) is exactly the B-operand layout of the second (lane = row, k-slot = lane group), so h never
+// touches LDS, and the second result has lane = row with groups of 4 consecutive output columns per lane: 16-byte result stores.
+// The k index a (register, lane group) pair stands for is row_of(v, lane); the W2 fragment is read from LDS at that same k, so the
+// contraction pairs up correctly whatever the order.  W2 is streamed through one LDS tile of BN output columns shared by the 4 waves
+// (f32: rows padded to 132 floats -> aligned, conflict-free ds_read_b128 of four consecutive k), read one MFMA group ahead.
+// No predicates anywhere: rows past B duplicate row B-1 and columns past N duplicate column N-1 (same inputs -> same values ->
+// benign duplicate stores), so the instruction stream between two barriers is one straight scheduling region.
+// Barriers wait for LDS traffic only; result stores drain behind the next tile's loads and MFMAs.  Requires K1 <= 32, H <= 128.
 // ------------------------------------------------------------------------------------------------------------------
-constexpr int HMAX = 128, K1MAX = 32, LDH = HMAX + 1, LDK1 = K1MAX + 1;
-constexpr int BM2 = 64, WM2 = 32, WN2 = 32;     // 64-row block, 4 waves as 2 (rows) x 2 (cols): 66 KB (f32) of LDS => 2 workgroups per CU
+constexpr int HMAX = 128, K1MAX = 32;
+// workgroup barrier that waits for this wave's LDS traffic only (a __syncthreads() also drains the wave's outstanding global stores)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+template <typename T> struct Mlp2Cfg;
+template <> struct Mlp2Cfg<float> { static constexpr int BN = 64, LDW = HMAX + 4; };
+template <> struct Mlp2Cfg<double> { static constexpr int BN = 32, LDW = HMAX + 1; };
 
-template <typename T>
-__global__ void __launch_bounds__(256) mlp2_kernel(const T* __restrict__ in, int64_t in_stride, const T* __restrict__ W1, int64_t w1_stride,
-                                                   const T* __restrict__ b1, const T* __restrict__ W2, int64_t w2_stride, const T* __restrict__ b2,
-                                                   int64_t B, int K1, int H, int N, T* __restrict__ out, int64_t out_stride) {
+template <typename T, int JH, bool VECROW>
+__global__ void __launch_bounds__(256, 3) mlp2_kernel(const T* __restrict__ in, int64_t in_stride, const T* __restrict__ W1, int64_t w1_stride,
+                                                      const T* __restrict__ b1, const T* __restrict__ W2, int64_t w2_stride, const T* __restrict__ b2,
+                                                      int64_t B, int K1, int H, int N, T* __restrict__ out, int64_t out_stride) {
     using MF = Mfma<T>;
     using V = typename Vec16<T>::type;
     constexpr int VN = Vec16<T>::N;
     constexpr int MT = MF::MT, KS = MF::KS, NREG = MF::NREG;
-    constexpr int TM = WM2 / MT, TN = WN2 / MT;              // mfma tiles per wave in phase 2 (f32: 1 x 1, f64: 2 x 2)
-    constexpr int TH = (HMAX / 2) / MT;                      // phase 1: each wave owns 32 rows x 64 hidden units
-    constexpr int WPT = BN * HMAX / VN / 256;                // 16-byte pieces of a W2 tile per thread
+    constexpr int BN2 = Mlp2Cfg<T>::BN, LDW = Mlp2Cfg<T>::LDW;
+    constexpr int TN = BN2 / MT;                             // mfma column tiles per W2 tile
+    constexpr int BMR = 4 * MT;                              // rows per workgroup
+    constexpr int HP = JH * MT;                              // hidden width padded to whole mfma tiles
+    constexpr int WPT = BN2 * HMAX / VN / 256;               // 16-byte pieces of a W2 tile per thread
+    constexpr int RG = MF::RUN;                              // consecutive result registers = consecutive columns (f32: 4, f64: 1)
     extern __shared__ __align__(16) unsigned char smem_raw[];
-    T* Hs = reinterpret_cast<T*>(smem_raw);                  // [BM2][LDH]   hidden activations
-    T* Ws = Hs + BM2 * LDH;                                  // [BN][LDH]    W2 tile (phase 2)
-    T* Xs = Ws;                                              // [BM2][LDK1]  input tile  } phase 1 only: overlays the W2 tile region
-    T* W1s = Xs + BM2 * LDK1;                                // [HMAX][LDK1] W1          } (a barrier separates the phases)
+    T* Ws = reinterpret_cast<T*>(smem_raw);                  // [BN2][LDW]   W2 tile (phase 2)
+    const int k1p = (K1 + KS - 1) / KS * KS, ldk = k1p + 1;
+    T* Xs = Ws;                                              // [BMR][ldk]   input tile  } phase 1 only: overlays the W2 tile region
+    T* W1s = Xs + BMR * ldk;                                 // [HP][ldk]    W1          } (a barrier separates the phases)
+    T* b1s = W1s + HP * ldk;                                 // [HP]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave & 1, wn = wave >> 1;
-    const int li = lane % MT, lk = lane / MT;
-    const int64_t row0 = (int64_t)blockIdx.x * BM2;
-    const int k1p = (K1 + KS - 1) / KS * KS;
+    const int li = lane % MT, lq = lane / MT;
+    const int64_t row0 = (int64_t)blockIdx.x * BMR;
+    const int64_t last = B - 1;
 
-    // ---- phase 1: h = tanh(x W1^T + b1)   (loads unconditional: clamped address + select)
+    // ---- phase 1: h^T = tanh(W1 x^T + b1).  Staging in straight-line batches of 4 loads per thread (clamped addresses + selects):
+    // issued back to back, one round trip per batch.  Rows past B replicate row B-1.
     {
-        const int64_t last = B - 1;
-        for (int idx = tid; idx < BM2 * k1p; idx += 256) {
-            const int r = idx / k1p, c = idx - r * k1p;
-            const int64_t gr = row0 + r;
-            const T t = in[(gr <= last ? gr : last) * in_stride + (c < K1 ? c : 0)];
-            Xs[r * LDK1 + c] = (gr <= last && c < K1) ? t : T(0);
+        const int nx = BMR * k1p, nw = HP * k1p;
+        for (int base = 0; base < nx; base += 4 * 256) {
+            T v[4]; int o[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = base + u * 256 + tid;
+                const int r = idx / k1p, c = idx - r * k1p;
+                const int64_t gr = row0 + r;
+                const T t = in[(gr <= last ? gr : last) * in_stride + (c < K1 ? c : 0)];
+                v[u] = c < K1 ? t : T(0);
+                o[u] = idx < nx ? r * ldk + c : -1;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) if (o[u] >= 0) Xs[o[u]] = v[u];
         }
-        for (int idx = tid; idx < HMAX * k1p; idx += 256) {
-            const int r = idx / k1p, c = idx - r * k1p;
-            const T t = W1[(int64_t)(r < H ? r : H - 1) * w1_stride + (c < K1 ? c : 0)];
-            W1s[r * LDK1 + c] = (r < H && c < K1) ? t : T(0);
+        for (int base = 0; base < nw; base += 4 * 256) {
+            T v[4]; int o[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = base + u * 256 + tid;
+                const int r = idx / k1p, c = idx - r * k1p;
+                const T t = W1[(int64_t)(r < H ? r : H - 1) * w1_stride + (c < K1 ? c : 0)];
+                v[u] = (r < H && c < K1) ? t : T(0);
+                o[u] = idx < nw ? r * ldk + c : -1;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) if (o[u] >= 0) W1s[o[u]] = v[u];
         }
+        if (tid < HP) b1s[tid] = tid < H ? b1[tid < H ? tid : 0] : T(0);
     }
     __syncthreads();
+    T hreg[JH][NREG];
     {
-        typename MF::Acc acc[TM][TH];
+        typename MF::Acc acc[JH];
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+        for (int j = 0; j < JH; ++j)
 #pragma unroll
-            for (int j = 0; j < TH; ++j)
-#pragma unroll
-                for (int r = 0; r < NREG; ++r) acc[i][j][r] = T(0);
+            for (int r = 0; r < NREG; ++r) acc[j][r] = T(0);
         for (int s = 0; s < k1p / KS; ++s) {
-            const int kk = s * KS + lk;
-            T a[TM], b[TH];
+            const int kk = s * KS + lq;
+            const T xb = Xs[(wave * MT + li) * ldk + kk];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = Xs[(wm * WM2 + i * MT + li) * LDK1 + kk];
-#pragma unroll
-            for (int j = 0; j < TH; ++j) b[j] = W1s[(wn * (HMAX / 2) + j * MT + li) * LDK1 + kk];
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TH; ++j) acc[i][j] = MF::mma(a[i], b[j], acc[i][j]);
+            for (int j = 0; j < JH; ++j) acc[j] = MF::mma(W1s[(j * MT + li) * ldk + kk], xb, acc[j]);
         }
-        __syncthreads();       // every wave is done reading Xs / W1s (the W2 tile region) -- Hs is a separate region
 #pragma unroll
-        for (int j = 0; j < TH; ++j) {
-            const int hc = wn * (HMAX / 2) + j * MT + li;
-            const T bv = b1[hc < H ? hc : 0];
+        for (int j = 0; j < JH; ++j)
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int r = 0; r < NREG; ++r) {
-                    const int hr = wm * WM2 + i * MT + MF::row_of(r, lane);
-                    Hs[hr * LDH + hc] = hc < H ? M<T>::tanh(acc[i][j][r] + bv) : T(0);
-                }
-        }
+            for (int r = 0; r < NREG; ++r) hreg[j][r] = M<T>::tanh_fast(acc[j][r] + b1s[j * MT + MF::row_of(r, lane)]);   // padded units: tanh(0) = 0
     }
-    // ---- phase 2: out = h W2^T + b2, W2 streamed in BN-column tiles (prefetched into registers one tile ahead)
-    const int n_tiles = (N + BN - 1) / BN;
-    V wreg[WPT];
-    auto fetch = [&](int t) {       // straight-line: clamped addresses + selects, so the WPT loads are issued back to back
+
+    // ---- phase 2: out^T = W2 h^T + b2, W2 streamed in BN2-column tiles
+    const int n_tiles = (N + BN2 - 1) / BN2;
+    T* Bs = Ws + BN2 * LDW;                                  // [BN2] bias of the tile's columns
+    auto load_tile = [&](int t) {                            // straight-line: clamped addresses + selects, loads issued back to back
+        V wreg[WPT];
+        const int bc = t * BN2 + (tid < BN2 ? tid : 0);
+        const T bval = (b2 != nullptr) ? b2[bc < N ? bc : N - 1] : T(0);
 #pragma unroll
         for (int u = 0; u < WPT; ++u) {
             const int idx = u * 256 + tid;
             const int r = idx / (HMAX / VN), c = (idx % (HMAX / VN)) * VN;
-            const int gc = t * BN + r;
-            const bool ok = (gc < N) && (c < H);
-            const V v = *reinterpret_cast<const V*>(W2 + (int64_t)(gc < N ? gc : N - 1) * w2_stride + (c < H ? c : 0));
+            const int gc = t * BN2 + r;
+            const bool ok = c < H;
+            const V v = *reinterpret_cast<const V*>(W2 + (int64_t)(gc < N ? gc : N - 1) * w2_stride + (c < H ? c : 0));   // columns past N replicate N-1
             wreg[u].x = ok ? v.x : T(0); wreg[u].y = ok ? v.y : T(0);
             if constexpr (VN == 4) { wreg[u].z = ok ? v.z : T(0); wreg[u].w = ok ? v.w : T(0); }
         }
-    };
-    fetch(0);
-    const int ksteps = (H + KS - 1) / KS;
-    for (int t = 0; t < n_tiles; ++t) {
-        __syncthreads();                                     // previous tile's MFMAs are done with Ws; first pass: Hs is complete
 #pragma unroll
         for (int u = 0; u < WPT; ++u) {
             const int idx = u * 256 + tid;
             const int r = idx / (HMAX / VN), c = (idx % (HMAX / VN)) * VN;
-            T* d = Ws + r * LDH + c;
-            d[0] = wreg[u].x; d[1] = wreg[u].y;
-            if constexpr (VN == 4) { d[2] = wreg[u].z; d[3] = wreg[u].w; }
+            T* d = Ws + r * LDW + c;
+            if constexpr (VN == 4) { *reinterpret_cast<V*>(d) = wreg[u]; }
+            else { d[0] = wreg[u].x; d[1] = wreg[u].y; }
         }
-        __syncthreads();
-        if (t + 1 < n_tiles) fetch(t + 1);                   // in flight while the MFMAs below run
-        typename MF::Acc acc[TM][TN];
+        if (tid < BN2) Bs[tid] = bval;
+    };
+    // result addressing: lane = row (clamped to B-1); per (tile, column tile, register group) a uniform column offset
+    const int64_t grow = row0 + wave * MT + li;
+    T* const orow = out + (grow <= last ? grow : last) * out_stride;
+    const T* wb = Ws + li * LDW;
+    constexpr int NGRP = VN == 4 ? NREG / 4 : NREG;          // W2 fragment reads per hidden tile (f32: one b128 = 4 k, f64: one b64 = 1 k)
+    constexpr int KPG = NREG / NGRP;                         // MFMAs (k values) per read
+    using F = typename std::conditional<VN == 4, V, T>::type;
+    auto read_frag = [&](F (&f)[TN], int j, int g) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+        for (int ct = 0; ct < TN; ++ct) f[ct] = *reinterpret_cast<const F*>(wb + ct * MT * LDW + j * MT + MF::row_of(g * KPG, lane));
+    };
+    auto elem = [](const F& f, int e) -> T {
+        if constexpr (VN == 4) return e == 0 ? f.x : e == 1 ? f.y : e == 2 ? f.z : f.w;
+        else return f;
+    };
+
+    lds_barrier();                                           // every wave is done with Xs / W1s / b1s
+    load_tile(0);
+    lds_barrier();
+    for (int t = 0; t < n_tiles; ++t) {
+        typename MF::Acc acc[TN];
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
+        for (int ct = 0; ct < TN; ++ct)
 #pragma unroll
-                for (int r = 0; r < NREG; ++r) acc[i][j][r] = T(0);
-        const T* ha = Hs + (wm * WM2 + li) * LDH + lk;
-        const T* wb = Ws + (wn * WN2 + li) * LDH + lk;
-#pragma unroll 2
-        for (int s = 0; s < ksteps; ++s) {
-            T a[TM], b[TN];
+            for (int r = 0; r < NREG; ++r) acc[ct][r] = T(0);
+        F frag[2][TN];
+        read_frag(frag[0], 0, 0);
 #pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = ha[i * MT * LDH + s * KS];
+        for (int j = 0; j < JH; ++j)
 #pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = wb[j * MT * LDH + s * KS];
+            for (int g = 0; g < NGRP; ++g) {
+                const int cur = (j * NGRP + g) & 1;
+                if (j * NGRP + g + 1 < JH * NGRP) read_frag(frag[cur ^ 1], (j * NGRP + g + 1) / NGRP, (j * NGRP + g + 1) % NGRP);   // one group ahead
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+                for (int e = 0; e < KPG; ++e)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = MF::mma(a[i], b[j], acc[i][j]);
-        }
+                    for (int ct = 0; ct < TN; ++ct) acc[ct] = MF::mma(elem(frag[cur][ct], e), hreg[j][g * KPG + e], acc[ct]);
+            }
+        // results: acc[ct][r] = out[row = lane's row][col = t*BN2 + ct*MT + row_of(r, lane)]; bias from the LDS tile
+        const bool edge = (t + 1) * BN2 > N;                 // block-uniform: only the last tile can reach past N
+        if (VECROW && RG == 4 && !edge) {
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int gc = t * BN + wn * WN2 + j * MT + li;
-            const T bv = (b2 != nullptr) ? b2[gc < N ? gc : 0] : T(0);
+            for (int ct = 0; ct < TN; ++ct)
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+                for (int r0 = 0; r0 < NREG; r0 += RG) {
+                    const int lc = ct * MT + MF::row_of(r0, lane);
+                    const V bb = *reinterpret_cast<const V*>(Bs + lc);
+                    V o;
+                    o.x = acc[ct][r0] + bb.x; o.y = acc[ct][r0 + 1] + bb.y;
+                    if constexpr (VN == 4) { o.z = acc[ct][r0 + 2] + bb.z; o.w = acc[ct][r0 + 3] + bb.w; }
+                    *reinterpret_cast<V*>(orow + t * BN2 + lc) = o;
+                }
+        } else {
+#pragma unroll
+            for (int ct = 0; ct < TN; ++ct)
 #pragma unroll
                 for (int r = 0; r < NREG; ++r) {
-                    const int64_t gr = row0 + wm * WM2 + i * MT + MF::row_of(r, lane);
-                    if (gr < B && gc < N) out[gr * out_stride + gc] = acc[i][j][r] + bv;
+                    const int lc = ct * MT + MF::row_of(r, lane);
+                    const int c = (t * BN2 + lc) < N ? (t * BN2 + lc) : N - 1;       // duplicates of column N-1 carry its value
+                    orow[c] = acc[ct][r] + Bs[lc];
                 }
         }
+        lds_barrier();                                       // every wave has read the tile
+        if (t + 1 < n_tiles) load_tile(t + 1);
+        lds_barrier();
     }
+}
+
+template <typename T, int JH>
+static int mlp2_launch(const T* in, int64_t in_stride, const T* W1, int64_t w1_stride, const T* b1, const T* W2, int64_t w2_stride, const T* b2, int64_t B,
+                       int32_t K1, int32_t H, int32_t N, T* out, int64_t out_stride, void* stream) {
+    constexpr int MT = Mfma<T>::MT, KS = Mfma<T>::KS, BMR = 4 * MT, HP = JH * MT;
+    const int k1p = (K1 + KS - 1) / KS * KS, ldk = k1p + 1;
+    const size_t phase1 = (size_t)BMR * ldk + (size_t)HP * ldk + HP, phase2 = (size_t)Mlp2Cfg<T>::BN * Mlp2Cfg<T>::LDW + Mlp2Cfg<T>::BN;
+    const size_t lds = (phase1 > phase2 ? phase1 : phase2) * sizeof(T);
+    // 16-byte result stores need 16-byte aligned rows
+    const bool vecrow = (out_stride % Vec16<T>::N == 0) && ((reinterpret_cast<uintptr_t>(out) & 15u) == 0);
+    auto k = vecrow ? mlp2_kernel<T, JH, true> : mlp2_kernel<T, JH, false>;
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k, dim3((unsigned)((B + BMR - 1) / BMR)), dim3(256), lds, (hipStream_t)stream, in, in_stride, W1, w1_stride, b1, W2, w2_stride, b2, B,
+                       (int)K1, (int)H, (int)N, out, out_stride);
+    return check_launch();
 }
 
 template <typename T>
@@ -302,13 +367,12 @@ static int mlp2(const T* in, int64_t in_stride, const T* W1, int64_t w1_stride, 
     if (K1 > K1MAX || H > HMAX) return JF_ERR_UNSUPPORTED;
     if ((H % Vec16<T>::N) || (w2_stride % Vec16<T>::N) || (reinterpret_cast<uintptr_t>(W2) & 15u)) return JF_ERR_UNSUPPORTED;   // 16-byte W2 rows
     if (B == 0) return JF_OK;
-    const size_t phase1 = (size_t)BM2 * LDK1 + (size_t)HMAX * LDK1, phase2 = (size_t)BN * LDH;
-    const size_t lds = ((size_t)BM2 * LDH + (phase1 > phase2 ? phase1 : phase2)) * sizeof(T);
-    auto k = mlp2_kernel<T>;
-    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k, dim3((unsigned)((B + BM2 - 1) / BM2)), dim3(256), lds, (hipStream_t)stream, in, in_stride, W1, w1_stride, b1, W2, w2_stride, b2, B,
-                       (int)K1, (int)H, (int)N, out, out_stride);
-    return check_launch();
+    constexpr int MT = Mfma<T>::MT;
+    const int tiles = (H + MT - 1) / MT;                     // hidden width in mfma tiles, rounded up to an instantiated count
+    constexpr int Q = HMAX / MT / 4;                         // f32: 1, f64: 2
+    if (tiles <= 1 * Q) return mlp2_launch<T, 1 * Q>(in, in_stride, W1, w1_stride, b1, W2, w2_stride, b2, B, K1, H, N, out, out_stride, stream);
+    if (tiles <= 2 * Q) return mlp2_launch<T, 2 * Q>(in, in_stride, W1, w1_stride, b1, W2, w2_stride, b2, B, K1, H, N, out, out_stride, stream);
+    return mlp2_launch<T, 4 * Q>(in, in_stride, W1, w1_stride, b1, W2, w2_stride, b2, B, K1, H, N, out, out_stride, stream);
 }
 
 template <typename T>
