@@ -3,7 +3,7 @@
 //   jf_gf_chain_inv_*  log-prob direction   (gaussianization_flow.py:995-1114 per layer, main/default.py:998-1031 loop)
 //   jf_gf_chain_fwd_*  sampling direction   (gaussianization_flow.py:911-989,  main/default.py:1482-1506 loop)
 //
-// Work distribution (jf_gf_group.h): lane = (row, coordinate); the G = next-power-of-two(D) lanes of a group own one row, a wave
+// Work distribution (jf_gf.h): lane = (row, coordinate); the G = next-power-of-two(D) lanes of a group own one row, a wave
 // owns 64/G rows.  Per-coordinate arithmetic is scalar code per lane, reductions over the coordinates are DPP butterflies.
 //
 // Two parameter regimes:
@@ -14,7 +14,8 @@
 //       back (stage_rows) into an LDS tile whose row stride is 4*odd dwords, then read by the lanes of each row.  A wave's tile is a few
 //       KB, so 16+ waves per CU are resident and the HBM latency of one wave's slab is covered by the arithmetic of the others.
 //       HBM traffic is the algorithmic minimum (every parameter byte is read exactly once).
-#include "jf_gf_group.h"
+#include "jf_gf.h"
+#include <cstdlib>
 
 namespace jf {
 
@@ -97,13 +98,13 @@ __global__ void __launch_bounds__(BCAST ? 256 : 64, sizeof(T) == 8 ? 2 : 4) gf_c
             if constexpr (!FWD) {
                 if (o.model_offset) x -= p[0];                                               // euclidean_base.py:40-45
                 x = gfg_rotate_inv<T, G, !BCAST>(p, o, D, live, x);
-                const MixQ<T> q = BCAST ? gfg_mixture<T>(p, o, D, x) : gfg_mixture_raw<T>(p, o, D, x);
+                const MixQ<T> q = gfg_mixture<T, !BCAST>(p, o, D, x);
                 const IcdfOut<T> s = gf_icdf<T>(o.inv_type, q);
                 x = s.y;
                 ld += group_sum<T, G>(live ? s.logd : T(0));
             } else {
                 x = gfg_solve<T, G>(p, o, D, live, x, row_valid, leader, a.status);
-                const MixQ<T> q = gfg_mixture<T>(p, o, D, x);                                // gaussianization_flow.py:922-924
+                const MixQ<T> q = gfg_mixture<T, false>(p, o, D, x);                                // gaussianization_flow.py:922-924
                 ld -= group_sum<T, G>(live ? gf_icdf<T>(o.inv_type, q).logd : T(0));
                 x = gfg_rotate_fwd<T, G, false>(p, o, D, live, x);
                 if (o.model_offset) x += p[0];                                               // euclidean_base.py:63-68
@@ -168,9 +169,7 @@ template <typename T> static int fill_args(GfChainArgs<T>& a, const T* params, i
     const int G = group_width(D);
     if (bcast) {
         lds_bytes = (size_t)n_layers * a.tile_stride * sizeof(T);
-        const int64_t n_tiles = (B + 256 / G - 1) / (256 / G);
-        int tpb = (int)(n_tiles / 4096);                 // keep >= ~16 workgroups per CU in the grid, <= 8 tiles per workgroup
-        a.tiles_per_block = tpb < 1 ? 1 : tpb > 8 ? 8 : tpb;
+        a.tiles_per_block = 1;                           // set by launch_g from the kernel's occupancy
     } else {
         lds_bytes = (size_t)(64 / G) * a.tile_stride * sizeof(T);
         a.tiles_per_block = 1;
@@ -179,12 +178,29 @@ template <typename T> static int fill_args(GfChainArgs<T>& a, const T* params, i
     return JF_OK;
 }
 
-template <typename T, int G, bool FWD> static int launch_g(const GfChainArgs<T>& a, bool bcast, size_t lds_bytes, hipStream_t st) {
+// resident workgroups of a broadcast kernel on the whole device (occupancy x CUs), queried once per kernel
+template <typename K> static int resident_blocks(K k, size_t lds_bytes) {
+    int dev = 0, cus = 256, per_cu = 0;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, 256, lds_bytes) != hipSuccess || per_cu < 1) per_cu = 4;
+    return cus * per_cu;
+}
+
+template <typename T, int G, bool FWD> static int launch_g(GfChainArgs<T> a, bool bcast, size_t lds_bytes, hipStream_t st) {
     if (bcast) {
         auto k = gf_chain_kernel<T, G, true, FWD>;
         if (lds_bytes > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        const int64_t rows_per_block = (int64_t)(256 / G) * a.tiles_per_block;
-        const unsigned grid = (unsigned)((a.B + rows_per_block - 1) / rows_per_block);
+        // one wave of workgroups: every workgroup derives the parameters once and walks ceil(tiles / resident) row tiles, so the grid has
+        // no partially filled last round (a 2.3-round grid idles a quarter of the chip in its tail)
+        static size_t cached_lds = ~(size_t)0;               // benign race: every thread computes the same value
+        static int resident = 0;
+        if (cached_lds != lds_bytes) { resident = resident_blocks(k, lds_bytes); cached_lds = lds_bytes; }
+        const int64_t n_tiles = (a.B + 256 / G - 1) / (256 / G);
+        const int64_t tpb = (n_tiles + resident - 1) / resident;
+        a.tiles_per_block = (int)(tpb < 1 ? 1 : tpb);
+        if (getenv("JF_TPB")) a.tiles_per_block = atoi(getenv("JF_TPB"));
+        const unsigned grid = (unsigned)((n_tiles + a.tiles_per_block - 1) / a.tiles_per_block);
         hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds_bytes, st, a);
     } else {
         auto k = gf_chain_kernel<T, G, false, FWD>;

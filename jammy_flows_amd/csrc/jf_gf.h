@@ -2,11 +2,18 @@
 // Restates jammy_flows/layers/euclidean/gaussianization_flow.py:389-454 (mixture), :480-671 (inverse-CDF stage and its
 // log-derivative), :699-861 (parameter regulation), :457-471 (Householder) for a lane-per-sample CDNA4 kernel.
 //
-// Data flow per layer and lane:   raw parameter row (LDS)  --derive-->  (mean, 1/width, pi_k) row (same LDS slots)
-//                                 x[D] --offset, reflections--> mixture sums in LINEAR space (1 v_exp + 1 v_rcp per (k,d))
+// Work distribution: lane = (row, coordinate).  A wave holds 64/G rows; the G = next-power-of-two(D) neighbouring lanes of a group own
+// the D coordinates of one row (lanes g >= D shadow coordinate D-1 and never store).  Everything per coordinate (mixture sums,
+// inverse-CDF stage, bisection) is scalar code per lane, so the register footprint does not grow with D; the three places the
+// reference reduces over the coordinates (Householder dot products, sum of log-derivatives, the Newton stopping rule) are DPP
+// butterflies inside the group.
+//
+// Data flow per layer and lane:   parameter row of the lane's sample (LDS)
+//                                 x --offset, reflections--> mixture sums in LINEAR space (1 v_exp + 1 v_rcp per k)
 //                                 --> log cdf / log sf / log pdf --> inverse-CDF stage.
-// A (lane, d) whose cdf or sf falls below M<T>::TINY is redone in log space (online log-sum-exp), i.e. exactly the
-// reference's arithmetic; that branch is what the +-50 sigma rows of the golden fixtures exercise.
+// When a cdf, sf or pdf of some lane underflows (M<T>::TINY) the wave re-evaluates the mixture with every sum scaled by e^{m},
+// m = min_k |u_k| (gfg_mixture_scaled): same relative accuracy as the reference's log-sum-exp arithmetic at any distance from the
+// components; that branch is what the +-50 sigma rows of the golden fixtures exercise.
 #pragma once
 #include "jf_common.h"
 #include "jf_math.h"
@@ -30,6 +37,17 @@ constexpr double PADE_A = 0.147;        // gaussianization_flow.py:143
 //   smooth saturation  logw' = LSE( ln wmax - softplus(ln wmax - x), ln wmin )   <=>   w = wmin + 1 / (1/wmax + e^-x)
 //   norm regulator     logn' = LSE( ln nmax - softplus(-x), ln nmin )            <=>   n = nmin + nmax / (1 + e^-x)
 // ----------------------------------------------------------------------------------------------------------
+// 1 / width directly: smooth saturation  1/w = (a + e) / (wmin (a + e) + 1),  a = 1/wmax, e = e^-x   (one rcp instead of two)
+template <typename T> __device__ __forceinline__ T gf_inv_width(const GfLayerDev<T>& o, T x) {
+    if (o.width_mode == JF_GF_WIDTH_SMOOTH_SATURATION) {
+        if (o.clamp_widths) x = clampv(x, o.lw_lo, o.lw_hi);
+        const T ae = o.inv_wmax + M<T>::exp_fast(-x);
+        return ae * M<T>::rcp(o.wmin * ae + T(1));
+    }
+    if (o.clamp_widths) x = clampv(x, o.lw_lo, o.lw_hi);
+    if (o.width_mode == JF_GF_WIDTH_EXP) return M<T>::rcp(M<T>::exp(x) + o.wmin);
+    return M<T>::rcp(softplus(x) + o.wmin);
+}
 template <typename T> __device__ __forceinline__ T gf_width(const GfLayerDev<T>& o, T x) {
     if (o.width_mode == JF_GF_WIDTH_SMOOTH_SATURATION) {
         if (o.clamp_widths) x = clampv(x, o.lw_lo, o.lw_hi);
@@ -69,58 +87,6 @@ template <typename T> __device__ __forceinline__ T gf_weight(const GfLayerDev<T>
     return o.reg_norm ? o.nmin + o.nmax * M<T>::rcp(T(1) + M<T>::exp_fast(-xn)) : M<T>::exp(xn - shift);
 }
 
-// derive a whole row in place with D-wide vector LDS accesses and D independent dependency chains per k
-template <typename T, int D> __device__ __forceinline__ void gf_derive_row(T* __restrict__ row, const GfLayerDev<T>& o) {
-    const int K = o.K;
-    T shift[D], nsum[D];
-#pragma unroll
-    for (int d = 0; d < D; ++d) { shift[d] = T(0); nsum[d] = T(0); }
-    if (o.fit_norm && !o.reg_norm) {
-        load_d<T, D>(row + o.off_ln, shift);
-        for (int k = 1; k < K; ++k) {
-            T v[D];
-            load_d<T, D>(row + o.off_ln + k * D, v);
-#pragma unroll
-            for (int d = 0; d < D; ++d) shift[d] = M<T>::max(shift[d], v[d]);
-        }
-    }
-    for (int k = 0; k < K; ++k) {
-        T lw[D], ln[D];
-        load_d<T, D>(row + o.off_lw + k * D, lw);
-#pragma unroll
-        for (int d = 0; d < D; ++d) lw[d] = M<T>::rcp(gf_width(o, lw[d]));
-        store_d<T, D>(row + o.off_lw + k * D, lw);
-        if (o.fit_norm) {
-            load_d<T, D>(row + o.off_ln + k * D, ln);
-#pragma unroll
-            for (int d = 0; d < D; ++d) { ln[d] = gf_weight(o, ln[d], shift[d]); nsum[d] += ln[d]; }
-            store_d<T, D>(row + o.off_ln + k * D, ln);
-        }
-    }
-    if (o.fit_norm) {
-#pragma unroll
-        for (int d = 0; d < D; ++d) nsum[d] = M<T>::rcp(nsum[d]);
-        for (int k = 0; k < K; ++k) {
-            T ln[D];
-            load_d<T, D>(row + o.off_ln + k * D, ln);
-#pragma unroll
-            for (int d = 0; d < D; ++d) ln[d] *= nsum[d];
-            store_d<T, D>(row + o.off_ln + k * D, ln);
-        }
-    }
-    for (int i = 0; i < o.hh; ++i) {
-        T v[D];
-        load_d<T, D>(row + o.off_rot + i * D, v);
-        T n2 = T(0);
-#pragma unroll
-        for (int d = 0; d < D; ++d) n2 += v[d] * v[d];
-        const T sc = M<T>::SQRT2 / M<T>::sqrt(n2);
-#pragma unroll
-        for (int d = 0; d < D; ++d) v[d] *= sc;
-        store_d<T, D>(row + o.off_rot + i * D, v);
-    }
-}
-
 // Householder vector i -> sqrt(2) v/|v| so that a reflection is x -= v (v.x)   (H = I - 2 v v^T/|v|^2)
 template <typename T> __device__ __forceinline__ void gf_derive_reflection(T* __restrict__ row, const GfLayerDev<T>& o, int D, int i) {
     T n2 = T(0);
@@ -129,192 +95,7 @@ template <typename T> __device__ __forceinline__ void gf_derive_reflection(T* __
     for (int d = 0; d < D; ++d) row[o.off_rot + i * D + d] *= s;
 }
 
-template <typename T, int D> __device__ __forceinline__ void gf_reflect(const T* __restrict__ v, T (&x)[D]) {
-    T vv[D];
-    load_d<T, D>(v, vv);
-    T dot = T(0);
-#pragma unroll
-    for (int d = 0; d < D; ++d) dot += vv[d] * x[d];
-#pragma unroll
-    for (int d = 0; d < D; ++d) x[d] -= vv[d] * dot;
-}
-
-// x <- Q^T x  (inverse / log-prob direction: H_0 first)   gaussianization_flow.py:1038
-template <typename T, int D> __device__ __forceinline__ void gf_rotate_inv(const T* __restrict__ row, const GfLayerDev<T>& o, T (&x)[D]) {
-    for (int i = 0; i < o.hh; ++i) gf_reflect<T, D>(row + o.off_rot + i * D, x);
-}
-// x <- Q x  (sampling direction: H_{n-1} first)            gaussianization_flow.py:975
-template <typename T, int D> __device__ __forceinline__ void gf_rotate_fwd(const T* __restrict__ row, const GfLayerDev<T>& o, T (&x)[D]) {
-    for (int i = o.hh - 1; i >= 0; --i) gf_reflect<T, D>(row + o.off_rot + i * D, x);
-}
-
-// ----------------------------------------------------------------------------------------------------------
-// mixture quantities
-// ----------------------------------------------------------------------------------------------------------
-template <typename T> struct Lse {   // online log-sum-exp
-    T m, s;
-    __device__ __forceinline__ Lse() : m(-INFINITY), s(T(0)) {}
-    __device__ __forceinline__ void add(T a) {
-        if (a > m) { s = s * M<T>::exp(m - a) + T(1); m = a; }
-        else s += M<T>::exp(a - m);
-    }
-    __device__ __forceinline__ T value() const { return m + M<T>::log(s); }
-};
-
-// faithful log-space evaluation of one dimension (gaussianization_flow.py:389-454) from a derived row
-template <typename T> struct Log3 { T lc, ls, lp; };
-template <typename T> __device__ __noinline__ Log3<T> gf_logspace_dim(const T* __restrict__ mean, const T* __restrict__ invw, const T* __restrict__ pi,
-                                                                     int K, int D, T xd) {
-    Lse<T> c, s, p;
-    const T uniform_ln = -M<T>::log(T(K));
-    for (int k = 0; k < K; ++k) {
-        const T iw = invw[k * D];
-        const T u = (xd - mean[k * D]) * iw;
-        const T sp = softplus(-u);
-        const T lnpi = pi ? M<T>::log(pi[k * D]) : uniform_ln;
-        c.add(-sp + lnpi);
-        s.add(-u - sp + lnpi);
-        p.add(-u + M<T>::log(iw) - T(2) * sp + lnpi);
-    }
-    Log3<T> r;
-    r.lc = c.value();
-    r.ls = s.value();
-    r.lp = p.value();
-    return r;
-}
-
-template <typename T> struct MixQ { T lc, ls, lp, cdf, sf; };   // log cdf, log sf, log pdf, cdf, sf of one dimension
-
-// all D dimensions at once, linear space with per-(lane,d) log-space fallback
-template <typename T, int D> __device__ __forceinline__ void gf_mixture(const T* __restrict__ row, const GfLayerDev<T>& o, const T (&x)[D], MixQ<T> (&q)[D]) {
-    T C[D], S[D], P[D];
-#pragma unroll
-    for (int d = 0; d < D; ++d) { C[d] = T(0); S[d] = T(0); P[d] = T(0); }
-    const T uniform_w = M<T>::rcp(T(o.K));
-    for (int k = 0; k < o.K; ++k) {
-        T mu[D], iw[D], w[D];
-        load_d<T, D>(row + o.off_mean + k * D, mu);
-        load_d<T, D>(row + o.off_lw + k * D, iw);
-        if (o.fit_norm) load_d<T, D>(row + o.off_ln + k * D, w);
-#pragma unroll
-        for (int d = 0; d < D; ++d) {
-            const T u = (x[d] - mu[d]) * iw[d];
-            const T t = M<T>::exp_fast(-M<T>::abs(u));
-            const T hi = M<T>::rcp(T(1) + t);      // sigma(|u|)
-            const T lo = t * hi;                   // sigma(-|u|)
-            const T wk = o.fit_norm ? w[d] : uniform_w;
-            const bool pos = u >= T(0);
-            C[d] += wk * (pos ? hi : lo);
-            S[d] += wk * (pos ? lo : hi);
-            P[d] += wk * hi * lo * iw[d];
-        }
-    }
-#pragma unroll
-    for (int d = 0; d < D; ++d) {
-        if (C[d] > M<T>::TINY && S[d] > M<T>::TINY && P[d] > M<T>::TINY) {
-            q[d].lc = M<T>::log_fast(C[d]);
-            q[d].ls = M<T>::log_fast(S[d]);
-            q[d].lp = M<T>::log_fast(P[d]);
-            q[d].cdf = C[d];
-            q[d].sf = S[d];
-        } else {
-            const Log3<T> r = gf_logspace_dim<T>(row + o.off_mean + d, row + o.off_lw + d, o.fit_norm ? row + o.off_ln + d : nullptr, o.K, D, x[d]);
-            q[d].lc = r.lc; q[d].ls = r.ls; q[d].lp = r.lp;
-            q[d].cdf = M<T>::exp(q[d].lc);
-            q[d].sf = M<T>::exp(q[d].ls);
-        }
-    }
-}
-
-// Log-prob direction, per-sample regime: the lane's row holds RAW parameters; width / weight regulation is fused into the
-// mixture loop (no LDS write-back, D independent chains per k).  Reflections use the raw Householder vectors.
-template <typename T, int D> __device__ __forceinline__ void gf_rotate_inv_raw(const T* __restrict__ row, const GfLayerDev<T>& o, T (&x)[D]) {
-    for (int i = 0; i < o.hh; ++i) {
-        T v[D];
-        load_d<T, D>(row + o.off_rot + i * D, v);
-        T n2 = T(0), dot = T(0);
-#pragma unroll
-        for (int d = 0; d < D; ++d) { n2 += v[d] * v[d]; dot += v[d] * x[d]; }
-        const T f = T(2) * dot * M<T>::rcp(n2);
-#pragma unroll
-        for (int d = 0; d < D; ++d) x[d] -= f * v[d];
-    }
-}
-
-template <typename T, int D> __device__ __forceinline__ void gf_mixture_raw(const T* __restrict__ row, const GfLayerDev<T>& o, const T (&x)[D], MixQ<T> (&q)[D]) {
-    T C[D], S[D], P[D], Nn[D], shift[D];
-#pragma unroll
-    for (int d = 0; d < D; ++d) { C[d] = T(0); S[d] = T(0); P[d] = T(0); Nn[d] = T(0); shift[d] = T(0); }
-    if (o.fit_norm && !o.reg_norm) {
-        load_d<T, D>(row + o.off_ln, shift);
-        for (int k = 1; k < o.K; ++k) {
-            T v[D];
-            load_d<T, D>(row + o.off_ln + k * D, v);
-#pragma unroll
-            for (int d = 0; d < D; ++d) shift[d] = M<T>::max(shift[d], v[d]);
-        }
-    }
-    for (int k = 0; k < o.K; ++k) {
-        T mu[D], lw[D], ln[D];
-        load_d<T, D>(row + o.off_mean + k * D, mu);
-        load_d<T, D>(row + o.off_lw + k * D, lw);
-        if (o.fit_norm) load_d<T, D>(row + o.off_ln + k * D, ln);
-#pragma unroll
-        for (int d = 0; d < D; ++d) {
-            const T iw = M<T>::rcp(gf_width(o, lw[d]));
-            const T wk = o.fit_norm ? gf_weight(o, ln[d], shift[d]) : T(1);
-            const T u = (x[d] - mu[d]) * iw;
-            const T t = M<T>::exp_fast(-M<T>::abs(u));
-            const T hi = M<T>::rcp(T(1) + t);
-            const T lo = t * hi;
-            const bool pos = u >= T(0);
-            C[d] += wk * (pos ? hi : lo);
-            S[d] += wk * (pos ? lo : hi);
-            P[d] += wk * hi * lo * iw;
-            Nn[d] += wk;
-        }
-    }
-    bool slow = false;
-#pragma unroll
-    for (int d = 0; d < D; ++d) {
-        const T inv = M<T>::rcp(Nn[d]);
-        C[d] *= inv; S[d] *= inv; P[d] *= inv;
-        q[d].lc = M<T>::log_fast(C[d]);
-        q[d].ls = M<T>::log_fast(S[d]);
-        q[d].lp = M<T>::log_fast(P[d]);
-        q[d].cdf = C[d];
-        q[d].sf = S[d];
-        slow = slow || !(C[d] > M<T>::TINY && S[d] > M<T>::TINY && P[d] > M<T>::TINY);
-    }
-    if (__any(slow)) {   // rare (tails): redo the flagged dimensions in log space = the reference's arithmetic (:389-454)
-        Lse<T> c[D], s[D], p[D];
-        for (int k = 0; k < o.K; ++k) {
-            T mu[D], lw[D], ln[D];
-            load_d<T, D>(row + o.off_mean + k * D, mu);
-            load_d<T, D>(row + o.off_lw + k * D, lw);
-            if (o.fit_norm) load_d<T, D>(row + o.off_ln + k * D, ln);
-#pragma unroll
-            for (int d = 0; d < D; ++d) {
-                const T w = gf_width(o, lw[d]);
-                const T u = (x[d] - mu[d]) / w;
-                const T sp = softplus(-u);
-                const T lnpi = (o.fit_norm ? M<T>::log(gf_weight(o, ln[d], shift[d])) : T(0)) - M<T>::log(Nn[d]);
-                c[d].add(-sp + lnpi);
-                s[d].add(-u - sp + lnpi);
-                p[d].add(-u - M<T>::log(w) - T(2) * sp + lnpi);
-            }
-        }
-#pragma unroll
-        for (int d = 0; d < D; ++d) {
-            const bool bad = !(C[d] > M<T>::TINY && S[d] > M<T>::TINY && P[d] > M<T>::TINY);
-            if (bad) {
-                q[d].lc = c[d].value(); q[d].ls = s[d].value(); q[d].lp = p[d].value();
-                q[d].cdf = M<T>::exp(q[d].lc);
-                q[d].sf = M<T>::exp(q[d].ls);
-            }
-        }
-    }
-}
+template <typename T> struct MixQ { T lc, ls, lp, cdf, sf; };   // log cdf, log sf, log pdf, cdf, sf of one coordinate
 
 // ----------------------------------------------------------------------------------------------------------
 // inverse-CDF stage  (gaussianization_flow.py:480-560 value, :568-671 log-derivative)
@@ -343,6 +124,28 @@ template <typename T> __device__ __forceinline__ T pade_logderiv(const Pade<T>& 
     return log_num - log_den - q.ls - q.lc + M<T>::log(M<T>::abs(q.sf - q.cdf));
 }
 
+// float32 inverse normal CDF of the central region (5e-8 < cdf, sf):  y = sqrt(2) erfinv(cdf - sf) with M. Giles' single-precision
+// erfinv ("Approximating the erfinv function", GPU Computing Gems 2011): erfinv(x) = x p(w), w = -ln((1-x)(1+x)) = -ln(4 cdf sf), which
+// the mixture already delivers without cancellation as -(log cdf + log sf + ln 4).  Both branches of the approximation are 9-term Horner
+// forms, evaluated branch-free with selected coefficients.  |error| < 2e-6 over the region (checked against scipy ndtri), ~25 VALU
+// instructions where OCML erfcinvf needs ~140.
+__device__ __forceinline__ float inormal_central_f32(const MixQ<float>& q) {
+    const float w = fmaxf(-(q.lc + q.ls + 1.38629436112f), 0.0f);
+    const bool c = w < 5.0f;
+    const float t = c ? w - 2.5f : M<float>::sqrt_fast(w) - 3.0f;
+    float p = c ? 2.81022636e-08f : -0.000200214257f;
+    p = fmaf(p, t, c ? 3.43273939e-07f : 0.000100950558f);
+    p = fmaf(p, t, c ? -3.5233877e-06f : 0.00134934322f);
+    p = fmaf(p, t, c ? -4.39150654e-06f : -0.00367342844f);
+    p = fmaf(p, t, c ? 0.00021858087f : 0.00573950773f);
+    p = fmaf(p, t, c ? -0.00125372503f : -0.0076224613f);
+    p = fmaf(p, t, c ? -0.00417768164f : 0.00943887047f);
+    p = fmaf(p, t, c ? 0.246640727f : 1.00167406f);
+    p = fmaf(p, t, c ? 1.50140941f : 2.83297682f);
+    return 1.41421356237f * p * (q.cdf - q.sf);
+}
+template <typename T> __device__ __forceinline__ T inormal_central_f32(const MixQ<T>&) { return T(0); }   // never called for double
+
 // returns y, writes the log-derivative d y / d x
 template <typename T> __device__ __forceinline__ T gf_inverse_cdf(int inv_type, const MixQ<T>& q, T& logd) {
     if (inv_type == JF_GF_ISIGMOID) {
@@ -358,10 +161,16 @@ template <typename T> __device__ __forceinline__ T gf_inverse_cdf(int inv_type, 
         return q.cdf <= q.sf ? -tot : tot;
     }
     const bool left = q.cdf <= bound, right = q.sf <= bound;
-    if (!left && !right) {   // central region: exact inverse normal CDF, evaluated from the smaller of cdf / sf
-        const T e = M<T>::erfcinv(T(2) * M<T>::min(q.cdf, q.sf));
-        logd = M<T>::HALF_LN_2PI + e * e + q.lp;
-        return (q.cdf < q.sf ? -M<T>::SQRT2 : M<T>::SQRT2) * e;
+    if (!left && !right) {   // central region: exact inverse normal CDF
+        if constexpr (sizeof(T) == 4) {
+            const T y = inormal_central_f32(q);
+            logd = M<T>::HALF_LN_2PI + T(0.5) * y * y + q.lp;
+            return y;
+        } else {             // evaluated from the smaller of cdf / sf
+            const T e = M<T>::erfcinv(T(2) * M<T>::min(q.cdf, q.sf));
+            logd = M<T>::HALF_LN_2PI + e * e + q.lp;
+            return (q.cdf < q.sf ? -M<T>::SQRT2 : M<T>::SQRT2) * e;
+        }
     }
     T tot;
     if (inv_type == JF_GF_INORMAL_PARTLY_CRUDE) {
@@ -390,84 +199,175 @@ template <> __device__ __noinline__ IcdfOut<double> gf_icdf<double>(int inv_type
     return r;
 }
 
-// one full layer evaluation at x (already offset-shifted and rotated): y[d], sum_d log dy/dx
-template <typename T, int D> __device__ __forceinline__ T gf_stage(const T* __restrict__ row, const GfLayerDev<T>& o, const T (&x)[D], T (&y)[D]) {
-    MixQ<T> q[D];
-    gf_mixture<T, D>(row, o, x, q);
-    T sum = T(0);
-#pragma unroll
-    for (int d = 0; d < D; ++d) {
-        T ld;
-        y[d] = gf_inverse_cdf<T>(o.inv_type, q[d], ld);
-        sum += ld;
-    }
-    return sum;
+// ---------------------------------------------------------------------------------------------------------- DPP group reductions
+template <int CTRL> __device__ __forceinline__ float dpp_swap(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
 }
-template <typename T, int D> __device__ __forceinline__ T gf_stage_raw(const T* __restrict__ row, const GfLayerDev<T>& o, const T (&x)[D], T (&y)[D]) {
-    MixQ<T> q[D];
-    gf_mixture_raw<T, D>(row, o, x, q);
-    T sum = T(0);
-#pragma unroll
-    for (int d = 0; d < D; ++d) {
-        T ld;
-        y[d] = gf_inverse_cdf<T>(o.inv_type, q[d], ld);
-        sum += ld;
-    }
-    return sum;
+template <int CTRL> __device__ __forceinline__ double dpp_swap(double v) {
+    const long long b = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, true);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (long long)(unsigned)lo);
 }
-template <typename T, int D> __device__ __forceinline__ void gf_stage_deriv(const T* __restrict__ row, const GfLayerDev<T>& o, const T (&x)[D], T (&y)[D], T (&logd)[D]) {
-    MixQ<T> q[D];
-    gf_mixture<T, D>(row, o, x, q);
-#pragma unroll
-    for (int d = 0; d < D; ++d) y[d] = gf_inverse_cdf<T>(o.inv_type, q[d], logd[d]);
+constexpr int DPP_XOR1 = 0xB1;          // quad_perm [1,0,3,2]
+constexpr int DPP_XOR2 = 0x4E;          // quad_perm [2,3,0,1]
+constexpr int DPP_HALF_MIRROR = 0x141;  // lane i <-> 7-i inside each 8 lanes (after the quad steps both quads hold their sums)
+
+template <typename T, int G> __device__ __forceinline__ T group_sum(T v) {
+    if constexpr (G >= 2) v += dpp_swap<DPP_XOR1>(v);
+    if constexpr (G >= 4) v += dpp_swap<DPP_XOR2>(v);
+    if constexpr (G >= 8) v += dpp_swap<DPP_HALF_MIRROR>(v);
+    return v;
+}
+template <typename T, int G> __device__ __forceinline__ T group_max(T v) {
+    if constexpr (G >= 2) v = M<T>::max(v, dpp_swap<DPP_XOR1>(v));
+    if constexpr (G >= 4) v = M<T>::max(v, dpp_swap<DPP_XOR2>(v));
+    if constexpr (G >= 8) v = M<T>::max(v, dpp_swap<DPP_HALF_MIRROR>(v));
+    return v;
 }
 
-// ----------------------------------------------------------------------------------------------------------
-// sampling direction: bisection + Newton per row (layers/bisection_n_newton.py:11-135; called with 25 / 20 iterations
-// and [-1e5, 1e5] from gaussianization_flow.py:921).  A row keeps iterating while sum_d |update| >= 1e-14; the wave leaves
-// the Newton loop when no lane is active any more (ballot).
-// ----------------------------------------------------------------------------------------------------------
-template <typename T, int D> __device__ __forceinline__ void gf_solve(const T* __restrict__ row, const GfLayerDev<T>& o, const T (&z)[D], T (&x)[D],
-                                                             bool lane_valid, int32_t* status) {
-    T lo[D], hi[D], y[D], logd[D];
-#pragma unroll
-    for (int d = 0; d < D; ++d) { lo[d] = T(-1e5); hi[d] = T(1e5); x[d] = T(0); }
-    for (int it = 0; it < 25; ++it) {
-#pragma unroll
-        for (int d = 0; d < D; ++d) x[d] = (hi[d] + lo[d]) * T(0.5);
-        gf_stage_deriv<T, D>(row, o, x, y, logd);
-#pragma unroll
-        for (int d = 0; d < D; ++d) {
-            const bool ok = M<T>::abs(y[d] - z[d]) <= T(1e-6) * M<T>::abs(z[d]);
-            const bool right = y[d] < z[d];
-            if (ok) { lo[d] = x[d]; hi[d] = x[d]; }
-            else if (right) lo[d] = x[d];
-            else hi[d] = x[d];
-        }
+// ---------------------------------------------------------------------------------------------------------- Householder rotations
+// p = row + d (the lane's coordinate), live = lane owns a real coordinate.  RAW rows hold the reference's unnormalised vectors
+// (H = I - 2 v v^T / |v|^2, gaussianization_flow.py:457-471); derived rows hold sqrt(2) v / |v|.
+template <typename T, int G, bool RAW> __device__ __forceinline__ T gfg_reflect(const T* __restrict__ p, int off, bool live, T x) {
+    const T v = live ? p[off] : T(0);
+    if constexpr (RAW) {
+        const T n2 = group_sum<T, G>(v * v), dot = group_sum<T, G>(v * x);
+        return x - T(2) * dot * M<T>::rcp(n2) * v;
+    } else {
+        return x - v * group_sum<T, G>(v * x);
     }
-    bool active = lane_valid;
+}
+template <typename T, int G, bool RAW> __device__ __forceinline__ T gfg_rotate_inv(const T* __restrict__ p, const GfLayerDev<T>& o, int D, bool live, T x) {
+    for (int i = 0; i < o.hh; ++i) x = gfg_reflect<T, G, RAW>(p, o.off_rot + i * D, live, x);      // x <- Q^T x (:1038)
+    return x;
+}
+template <typename T, int G, bool RAW> __device__ __forceinline__ T gfg_rotate_fwd(const T* __restrict__ p, const GfLayerDev<T>& o, int D, bool live, T x) {
+    for (int i = o.hh - 1; i >= 0; --i) x = gfg_reflect<T, G, RAW>(p, o.off_rot + i * D, live, x);  // x <- Q x (:975)
+    return x;
+}
+
+// ---------------------------------------------------------------------------------------------------------- mixture, one coordinate
+// Logistic mixture (gaussianization_flow.py:389-454):  with u_k = (x - mu_k)/w_k, a_k = |u_k|, hi_k = sigma(a_k), lo_k = e^{-a_k} hi_k
+//   cdf = sum_k pi_k sigma(u_k),  sf = sum_k pi_k sigma(-u_k),  pdf = sum_k pi_k hi_k lo_k / w_k.
+// RAW rows hold (mean, log-width, log-weight) as the amortisation MLP emits them (width / weight regulation fused into the loop, the
+// weights are normalised at the end); derived rows hold (mean, 1/width, pi).
+
+// Underflow-proof evaluation: every e^{-a_k} is factored as e^{-m} e^{-(a_k - m)}, m = min_k a_k, so each sum splits into an unscaled
+// part (terms of order pi_k) and a part scaled by e^{-m} whose leading term is of order pi_k as well:
+//   cdf = Cu + e^{-m} Cs,  sf = Su + e^{-m} Ss,  pdf = e^{-m} Ps      ->  log cdf = log(Cs) - m when no component lies left of x, ...
+// Equivalent to the reference's log-sum-exp over components to rounding, at any distance from the components.
+template <typename T, bool RAW> __device__ __forceinline__ MixQ<T> gfg_mixture_scaled(const T* __restrict__ p, const GfLayerDev<T>& o, int D, T x, T shift) {
+    const T uniform_w = RAW ? T(1) : M<T>::rcp(T(o.K));
+    T m = T(INFINITY);
+    for (int k = 0; k < o.K; ++k) {
+        const T iw = RAW ? gf_inv_width(o, p[o.off_lw + k * D]) : p[o.off_lw + k * D];
+        m = M<T>::min(m, M<T>::abs((x - p[o.off_mean + k * D]) * iw));
+    }
+    const T em = M<T>::exp(-m);
+    T Cu = T(0), Cs = T(0), Su = T(0), Ss = T(0), Ps = T(0), Nn = T(0);
+    for (int k = 0; k < o.K; ++k) {
+        const T iw = RAW ? gf_inv_width(o, p[o.off_lw + k * D]) : p[o.off_lw + k * D];
+        const T wk = o.fit_norm ? (RAW ? gf_weight(o, p[o.off_ln + k * D], shift) : p[o.off_ln + k * D]) : uniform_w;
+        const T u = (x - p[o.off_mean + k * D]) * iw;
+        const T t = M<T>::exp(m - M<T>::abs(u));           // <= 1, equals 1 for the nearest component
+        const T hi = T(1) / (T(1) + t * em);
+        const T c1 = wk * hi, c2 = c1 * t;
+        if (u >= T(0)) { Cu += c1; Ss += c2; }
+        else { Su += c1; Cs += c2; }
+        Ps += c2 * hi * iw;
+        Nn += wk;
+    }
+    if constexpr (RAW) {
+        const T inv = T(1) / Nn;
+        Cu *= inv; Cs *= inv; Su *= inv; Ss *= inv; Ps *= inv;
+    }
+    MixQ<T> q;
+    q.cdf = Cu + em * Cs;
+    q.sf = Su + em * Ss;
+    q.lc = Cu > T(0) ? M<T>::log(q.cdf) : M<T>::log(Cs) - m;
+    q.ls = Su > T(0) ? M<T>::log(q.sf) : M<T>::log(Ss) - m;
+    q.lp = M<T>::log(Ps) - m;
+    return q;
+}
+
+template <typename T, bool RAW> __device__ __forceinline__ MixQ<T> gfg_mixture(const T* __restrict__ p, const GfLayerDev<T>& o, int D, T x) {
+    T C = T(0), S = T(0), P = T(0), Nn = T(0), shift = T(0);
+    const T uniform_w = RAW ? T(1) : M<T>::rcp(T(o.K));
+    if (RAW && o.fit_norm && !o.reg_norm) {                // unbounded log-weights: shift by the max before exponentiating
+        shift = p[o.off_ln];
+        for (int k = 1; k < o.K; ++k) shift = M<T>::max(shift, p[o.off_ln + k * D]);
+    }
+#pragma unroll 2
+    for (int k = 0; k < o.K; ++k) {
+        const T iw = RAW ? gf_inv_width(o, p[o.off_lw + k * D]) : p[o.off_lw + k * D];
+        const T wk = o.fit_norm ? (RAW ? gf_weight(o, p[o.off_ln + k * D], shift) : p[o.off_ln + k * D]) : uniform_w;
+        const T u = (x - p[o.off_mean + k * D]) * iw;
+        const T t = M<T>::exp_fast(-M<T>::abs(u));
+        const T hi = M<T>::rcp(T(1) + t);                  // sigma(|u|)
+        const T lo = t * hi;                               // sigma(-|u|)
+        const bool pos = u >= T(0);
+        C += wk * (pos ? hi : lo);
+        S += wk * (pos ? lo : hi);
+        P += wk * hi * lo * iw;
+        if constexpr (RAW) Nn += wk;
+    }
+    if constexpr (RAW) {
+        const T inv = M<T>::rcp(Nn);
+        C *= inv; S *= inv; P *= inv;
+    }
+    MixQ<T> q;
+    q.lc = M<T>::log_fast(C); q.ls = M<T>::log_fast(S); q.lp = M<T>::log_fast(P);
+    q.cdf = C; q.sf = S;
+    const bool under = !(C > M<T>::TINY && S > M<T>::TINY && P > M<T>::TINY);
+    if (__any(under)) {                                    // wave-uniform branch
+        const MixQ<T> qs = gfg_mixture_scaled<T, RAW>(p, o, D, x, shift);
+        if (under) q = qs;
+    }
+    return q;
+}
+
+// in-place derive of a staged raw row by the G lanes of its group: lane d < D takes column d, reflections are dealt round-robin
+template <typename T, int G> __device__ __forceinline__ void gfg_derive(T* __restrict__ row, const GfLayerDev<T>& o, int D, int g) {
+    if (g < D) gf_derive_column<T>(row, o, D, g);
+    for (int i = g; i < o.hh; i += G) gf_derive_reflection<T>(row, o, D, i);
+}
+
+// ---------------------------------------------------------------------------------------------------------- sampling direction
+// bisection + Newton (layers/bisection_n_newton.py:11-135, called with 25 / 20 iterations on [-1e5, 1e5], :921) for one coordinate;
+// the Newton stopping rule sums |update| over the row's coordinates (group butterfly), so the D lanes of a row stop together.
+template <typename T, int G> __device__ __forceinline__ T gfg_solve(const T* __restrict__ p, const GfLayerDev<T>& o, int D, bool live, T z,
+                                                                     bool row_valid, bool leader, int32_t* status) {
+    T lo = T(-1e5), hi = T(1e5), x = T(0);
+    for (int it = 0; it < 25; ++it) {
+        x = (hi + lo) * T(0.5);
+        const T y = gf_icdf<T>(o.inv_type, gfg_mixture<T, false>(p, o, D, x)).y;
+        const bool ok = M<T>::abs(y - z) <= T(1e-6) * M<T>::abs(z);
+        if (ok) { lo = x; hi = x; }
+        else if (y < z) lo = x;
+        else hi = x;
+    }
+    bool active = row_valid;
     T ferr = T(0);
     bool nonfinite = false;
     for (int it = 0; it < 20 && __any(active); ++it) {
-        gf_stage_deriv<T, D>(row, o, x, y, logd);
+        const IcdfOut<T> s = gf_icdf<T>(o.inv_type, gfg_mixture<T, false>(p, o, D, x));
+        const T f = s.y - z;
+        const T upd = f / M<T>::exp(s.logd);
+        const T usum = group_sum<T, G>(live ? M<T>::abs(upd) : T(0));
         if (active) {
-            T usum = T(0);
-            ferr = T(0);
-#pragma unroll
-            for (int d = 0; d < D; ++d) {
-                const T f = y[d] - z[d];
-                const T upd = f / M<T>::exp(logd[d]);
-                const T nx = x[d] - upd;
-                if (M<T>::finite(nx)) x[d] = nx; else nonfinite = true;      // keep the previous iterate (:84-91)
-                usum += M<T>::abs(upd);
-                ferr = M<T>::max(ferr, M<T>::abs(f));
-            }
+            const T nx = x - upd;
+            if (M<T>::finite(nx)) x = nx; else nonfinite = nonfinite || live;     // keep the previous iterate (:84-91)
+            ferr = M<T>::abs(f);
             active = usum >= T(1e-14);
         }
     }
     const T prec = sizeof(T) == 8 ? T(1e-7) : T(1e-4);
-    status_add(status, JF_STATUS_NONCONVERGED, lane_valid && (ferr > prec));
-    status_add(status, JF_STATUS_NONFINITE, lane_valid && nonfinite);
+    const T ferr_row = group_max<T, G>(live ? ferr : T(0));
+    const T nf_row = group_max<T, G>(nonfinite ? T(1) : T(0));
+    status_add(status, JF_STATUS_NONCONVERGED, row_valid && leader && (ferr_row > prec));
+    status_add(status, JF_STATUS_NONFINITE, row_valid && leader && (nf_row > T(0)));
+    return x;
 }
 
 }  // namespace jf

@@ -17,12 +17,13 @@ template <> struct M<float> {
     static constexpr float TWO_PI = 6.28318530717958647692f;
     static constexpr float HALF_LN_2PI = 0.91893853320467274178f;
     static constexpr float SQRT2 = 1.41421356237309504880f;
-    static constexpr float TINY = 1e-30f;       // below this a linear-space cdf/sf is recomputed in log space
+    static constexpr float TINY = 1e-35f;       // below this a linear-space cdf / sf / pdf is re-evaluated with scaled sums
     static constexpr float EPS_COS = 1e-7f;     // sphere_base.return_safe_costheta float32 margin
     static constexpr float EPS_S1 = 1e-5f;      // sphere_base.sphere_to_plane float32 clamp
     static constexpr float KAPPA_ID = 1e-4f;    // fvm_2d small-kappa identity switch (float32)
     static __device__ __forceinline__ float exp_fast(float x) { return __expf(x); }
-    static __device__ __forceinline__ float log_fast(float x) { return __logf(x); }
+    static __device__ __forceinline__ float log_fast(float x) { return 0.69314718056f * __builtin_amdgcn_logf(x); }   // v_log_f32 (normal-range inputs only)
+    static __device__ __forceinline__ float sqrt_fast(float x) { return __builtin_amdgcn_sqrtf(x); }
     static __device__ __forceinline__ float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
     static __device__ __forceinline__ float exp(float x) { return expf(x); }
     static __device__ __forceinline__ float log(float x) { return logf(x); }
@@ -55,6 +56,7 @@ template <> struct M<double> {
     static constexpr double KAPPA_ID = 1e-8;
     static __device__ __forceinline__ double exp_fast(double x) { return ::exp(x); }
     static __device__ __forceinline__ double log_fast(double x) { return ::log(x); }
+    static __device__ __forceinline__ double sqrt_fast(double x) { return ::sqrt(x); }
     static __device__ __forceinline__ double rcp(double x) { return 1.0 / x; }
     static __device__ __forceinline__ double exp(double x) { return ::exp(x); }
     static __device__ __forceinline__ double log(double x) { return ::log(x); }

@@ -168,10 +168,10 @@ constexpr int HMAX = 128, K1MAX = 32;
 // workgroup barrier that waits for this wave's LDS traffic only (a __syncthreads() also drains the wave's outstanding global stores)
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 template <typename T> struct Mlp2Cfg;
-template <> struct Mlp2Cfg<float> { static constexpr int BN = 64, LDW = HMAX + 4; };
-template <> struct Mlp2Cfg<double> { static constexpr int BN = 32, LDW = HMAX + 1; };
+template <> struct Mlp2Cfg<float> { static constexpr int LDW = HMAX + 4; };
+template <> struct Mlp2Cfg<double> { static constexpr int LDW = HMAX + 1; };
 
-template <typename T, int JH, bool VECROW>
+template <typename T, int JH, int TN, bool VECROW>
 __global__ void __launch_bounds__(256, 3) mlp2_kernel(const T* __restrict__ in, int64_t in_stride, const T* __restrict__ W1, int64_t w1_stride,
                                                       const T* __restrict__ b1, const T* __restrict__ W2, int64_t w2_stride, const T* __restrict__ b2,
                                                       int64_t B, int K1, int H, int N, T* __restrict__ out, int64_t out_stride) {
@@ -179,8 +179,7 @@ __global__ void __launch_bounds__(256, 3) mlp2_kernel(const T* __restrict__ in, 
     using V = typename Vec16<T>::type;
     constexpr int VN = Vec16<T>::N;
     constexpr int MT = MF::MT, KS = MF::KS, NREG = MF::NREG;
-    constexpr int BN2 = Mlp2Cfg<T>::BN, LDW = Mlp2Cfg<T>::LDW;
-    constexpr int TN = BN2 / MT;                             // mfma column tiles per W2 tile
+    constexpr int BN2 = TN * MT, LDW = Mlp2Cfg<T>::LDW;      // TN mfma column tiles per W2 tile (1 for narrow outputs)
     constexpr int BMR = 4 * MT;                              // rows per workgroup
     constexpr int HP = JH * MT;                              // hidden width padded to whole mfma tiles
     constexpr int WPT = BN2 * HMAX / VN / 256;               // 16-byte pieces of a W2 tile per thread
@@ -344,16 +343,16 @@ __global__ void __launch_bounds__(256, 3) mlp2_kernel(const T* __restrict__ in, 
     }
 }
 
-template <typename T, int JH>
+template <typename T, int JH, int TN>
 static int mlp2_launch(const T* in, int64_t in_stride, const T* W1, int64_t w1_stride, const T* b1, const T* W2, int64_t w2_stride, const T* b2, int64_t B,
                        int32_t K1, int32_t H, int32_t N, T* out, int64_t out_stride, void* stream) {
     constexpr int MT = Mfma<T>::MT, KS = Mfma<T>::KS, BMR = 4 * MT, HP = JH * MT;
     const int k1p = (K1 + KS - 1) / KS * KS, ldk = k1p + 1;
-    const size_t phase1 = (size_t)BMR * ldk + (size_t)HP * ldk + HP, phase2 = (size_t)Mlp2Cfg<T>::BN * Mlp2Cfg<T>::LDW + Mlp2Cfg<T>::BN;
+    const size_t phase1 = (size_t)BMR * ldk + (size_t)HP * ldk + HP, phase2 = (size_t)(TN * MT) * Mlp2Cfg<T>::LDW + TN * MT;
     const size_t lds = (phase1 > phase2 ? phase1 : phase2) * sizeof(T);
     // 16-byte result stores need 16-byte aligned rows
     const bool vecrow = (out_stride % Vec16<T>::N == 0) && ((reinterpret_cast<uintptr_t>(out) & 15u) == 0);
-    auto k = vecrow ? mlp2_kernel<T, JH, true> : mlp2_kernel<T, JH, false>;
+    auto k = vecrow ? mlp2_kernel<T, JH, TN, true> : mlp2_kernel<T, JH, TN, false>;
     if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k, dim3((unsigned)((B + BMR - 1) / BMR)), dim3(256), lds, (hipStream_t)stream, in, in_stride, W1, w1_stride, b1, W2, w2_stride, b2, B,
                        (int)K1, (int)H, (int)N, out, out_stride);
@@ -370,9 +369,13 @@ static int mlp2(const T* in, int64_t in_stride, const T* W1, int64_t w1_stride, 
     constexpr int MT = Mfma<T>::MT;
     const int tiles = (H + MT - 1) / MT;                     // hidden width in mfma tiles, rounded up to an instantiated count
     constexpr int Q = HMAX / MT / 4;                         // f32: 1, f64: 2
-    if (tiles <= 1 * Q) return mlp2_launch<T, 1 * Q>(in, in_stride, W1, w1_stride, b1, W2, w2_stride, b2, B, K1, H, N, out, out_stride, stream);
-    if (tiles <= 2 * Q) return mlp2_launch<T, 2 * Q>(in, in_stride, W1, w1_stride, b1, W2, w2_stride, b2, B, K1, H, N, out, out_stride, stream);
-    return mlp2_launch<T, 4 * Q>(in, in_stride, W1, w1_stride, b1, W2, w2_stride, b2, B, K1, H, N, out, out_stride, stream);
+#define JF_MLP2_GO(JH_) \
+    return (N <= MT) ? mlp2_launch<T, JH_, 1>(in, in_stride, W1, w1_stride, b1, W2, w2_stride, b2, B, K1, H, N, out, out_stride, stream) \
+                     : mlp2_launch<T, JH_, 2>(in, in_stride, W1, w1_stride, b1, W2, w2_stride, b2, B, K1, H, N, out, out_stride, stream)
+    if (tiles <= 1 * Q) JF_MLP2_GO(1 * Q);
+    if (tiles <= 2 * Q) JF_MLP2_GO(2 * Q);
+    JF_MLP2_GO(4 * Q);
+#undef JF_MLP2_GO
 }
 
 template <typename T>

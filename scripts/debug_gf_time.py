@@ -17,3 +17,13 @@ e0.record()
 for _ in range(10): gfl.run_chain(layers, "inv", x, None, params)
 e1.record(); torch.cuda.synchronize()
 print("JF_DBG=%s  gf per-sample chain: %.3f ms" % (os.environ.get("JF_DBG", "0"), e0.elapsed_time(e1) / 10))
+# broadcast regime: the first sub-pdf's chain with permanent parameters
+layers0 = list(pdf.layer_list[0])
+row = gfl.chain_permanent_row(layers0, x)
+if row is not None:
+    for _ in range(3): gfl.run_chain(layers0, "inv", x, None, row)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(10): gfl.run_chain(layers0, "inv", x, None, row)
+    e1.record(); torch.cuda.synchronize()
+    print("JF_TPB=%s  gf broadcast chain: %.3f ms" % (os.environ.get("JF_TPB", "-"), e0.elapsed_time(e1) / 10))
