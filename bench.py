@@ -82,6 +82,34 @@ def cpu_baseline(budget_s=20.0):
             "sample": "%d rows of %s (float64 numpy oracle, %d processes x %d-row chunks), %.1f s" % (n, WORKLOAD, workers, chunk, dt)}
 
 
+# ---------------------------------------------------------------------------------------------- HBM traffic from the committed PMC passes
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r01_c_traffic.json")
+TRAFFIC_KEYS = {("jf_mlp2_f32", "K7_H128_N548"): "jf::mlp2_kernel<float, 4, 2, true>",
+                ("jf_mlp2_f32", "K4_H128_N10"): "jf::mlp2_kernel<float, 4, 1, true>",
+                ("jf_gf_chain_inv_f32", "per-sample"): "jf::gf_chain_kernel<float, 4, false, false>",
+                ("jf_gf_chain_inv_f32", "bcast"): "jf::gf_chain_kernel<float, 4, true, false>"}
+
+
+def pmc_traffic(kname, ktag, B):
+    """HBM bytes per launch of one kernel from the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command
+    (profiles/r01_c_*; PMC collection needs its own rocprofv3 runs, so the figure is read from the committed summary, not measured live).
+    Corrections (MI355X_MICROARCH.md, HBM section): FETCH_SIZE x 2 on gfx950 for wide coalesced reads; WRITE_SIZE x 0.965, calibrated on
+    scripts/probe/wstore for the 16-byte lane-per-row tile stores these kernels use.  None when the profile was taken at another batch."""
+    try:
+        table = json.load(open(TRAFFIC_FILE))
+    except OSError:
+        return None
+    prefix = TRAFFIC_KEYS.get((kname, ktag))
+    if prefix is None or B != BATCH:
+        return None
+    for key, v in table.items():
+        if key.startswith(prefix) and v.get("FETCH_SIZE_raw_KB") is not None and v.get("WRITE_SIZE_raw_KB") is not None:
+            return {"hbm_bytes_per_launch": v["FETCH_SIZE_raw_KB"] * 1024 * 2 + v["WRITE_SIZE_raw_KB"] * 1024 * 0.965,
+                    "read_bytes": v["FETCH_SIZE_raw_KB"] * 1024 * 2, "write_bytes": v["WRITE_SIZE_raw_KB"] * 1024 * 0.965,
+                    "source": "profiles/r01_c_traffic.json (rocprofv3 --pmc, separate passes)"}
+    return None
+
+
 # ---------------------------------------------------------------------------------------------- main
 def main():
     ap = argparse.ArgumentParser()
@@ -195,6 +223,7 @@ def main():
         else:
             roofline = {"bound": "hbm", "kernel": "%s[%s]" % (kname, ktag), "achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": hbm_gbs / HBM_PEAK_GBS, "traffic": None}
+        roofline["traffic"] = pmc_traffic(kname, ktag, B)
         roofline.update({"mean_launch_ms": kstat["mean_ms"], "algorithmic_bytes_per_launch": bytes_per_row * B,
                          "all_kernels_ms_per_step": {"%s[%s]" % k: round(v["total_ms"] / args.steps, 4) for k, v in sorted(kernel_table.items())}})
         # the HBM-bound flow kernel the north star names (per-sample parameter blocks), reported alongside
@@ -202,7 +231,8 @@ def main():
         if gfk is not None:
             g = 4 * 558 * B / (gfk["mean_ms"] * 1e-3) / 1e9
             roofline["gf_chain_per_sample"] = {"bound": "hbm", "achieved": g, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": g / HBM_PEAK_GBS,
-                                               "mean_launch_ms": gfk["mean_ms"], "algorithmic_bytes_per_launch": 4 * 558 * B}
+                                               "mean_launch_ms": gfk["mean_ms"], "algorithmic_bytes_per_launch": 4 * 558 * B,
+                                               "traffic": pmc_traffic("jf_gf_chain_inv_f32", "per-sample", B)}
         line = {
             "metric": "log-prob evals/sec (batch 2^20 per GPU), e4+s2+e4 / gggg+f+gggg",
             "value": r32["evals_per_s"], "unit": "log-prob evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
