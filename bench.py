@@ -223,7 +223,9 @@ def main():
         else:
             roofline = {"bound": "hbm", "kernel": "%s[%s]" % (kname, ktag), "achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": hbm_gbs / HBM_PEAK_GBS, "traffic": None}
-        roofline["traffic"] = pmc_traffic(kname, ktag, B)
+        tr = pmc_traffic(kname, ktag, B)
+        roofline["traffic"] = tr["hbm_bytes_per_launch"] if tr else None
+        roofline["traffic_detail"] = tr
         roofline.update({"mean_launch_ms": kstat["mean_ms"], "algorithmic_bytes_per_launch": bytes_per_row * B,
                          "all_kernels_ms_per_step": {"%s[%s]" % k: round(v["total_ms"] / args.steps, 4) for k, v in sorted(kernel_table.items())}})
         # the HBM-bound flow kernel the north star names (per-sample parameter blocks), reported alongside
@@ -232,7 +234,7 @@ def main():
             g = 4 * 558 * B / (gfk["mean_ms"] * 1e-3) / 1e9
             roofline["gf_chain_per_sample"] = {"bound": "hbm", "achieved": g, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": g / HBM_PEAK_GBS,
                                                "mean_launch_ms": gfk["mean_ms"], "algorithmic_bytes_per_launch": 4 * 558 * B,
-                                               "traffic": pmc_traffic("jf_gf_chain_inv_f32", "per-sample", B)}
+                                               "traffic": (pmc_traffic("jf_gf_chain_inv_f32", "per-sample", B) or {}).get("hbm_bytes_per_launch")}
         line = {
             "metric": "log-prob evals/sec (batch 2^20 per GPU), e4+s2+e4 / gggg+f+gggg",
             "value": r32["evals_per_s"], "unit": "log-prob evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
