@@ -44,6 +44,7 @@ int jf_abi_version(void);
  * ------------------------------------------------------------------------------------------------------------ */
 enum { JF_GF_ISIGMOID = 0, JF_GF_INORMAL_PARTLY_PRECISE = 1, JF_GF_INORMAL_PARTLY_CRUDE = 2, JF_GF_INORMAL_FULL_PADE = 3 };
 enum { JF_GF_WIDTH_SMOOTH_SATURATION = 0, JF_GF_WIDTH_EXP = 1, JF_GF_WIDTH_SOFTPLUS = 2 };
+enum { JF_GF_STRETCH_CLASSIC = 0, JF_GF_STRETCH_RQ_SPLINES = 1 };
 
 typedef struct jf_gf_layer {
     int32_t num_kde;                /* K */
@@ -54,6 +55,10 @@ typedef struct jf_gf_layer {
     int32_t inverse_function_type;  /* JF_GF_* */
     int32_t width_mode;             /* JF_GF_WIDTH_* */
     int32_t clamp_widths;
+    int32_t nonlinear_stretch_type; /* JF_GF_STRETCH_*: CLASSIC = logistic mixture + inverse-CDF stage; RQ_SPLINES = per-dimension
+                                       rational-quadratic spline with learnable box and linear tails (spline_fns.py:188-358), row layout
+                                       [offset][rot][log_w D*K][log_h D*K][log_d D*(K+1)][box D*4] (gaussianization_flow.py:873-909) */
+    int32_t reserved;
     double width_min, width_max;    /* width_max <= 0: no upper bound */
     double norm_min, norm_max;
 } jf_gf_layer;

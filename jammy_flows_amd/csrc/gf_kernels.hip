@@ -28,6 +28,7 @@ template <typename T> struct GfChainArgs {
     int n_layers;
     int tiles_per_block;     // broadcast kernels: row tiles walked by one workgroup
     int tile_stride;         // per-sample: LDS row stride (elements); broadcast: row capacity per layer
+    int tab_offset;          // element offset of the spline knot tables behind the parameter tile
     GfLayerDev<T> L[JF_MAX_CHAIN];
     T* x_out; int64_t xos;
     T* ld_out;
@@ -48,7 +49,7 @@ template <typename T> __device__ __forceinline__ void derive_broadcast(T* lds, c
     for (int l = wave; l < a.n_layers; l += 4) {
         const GfLayerDev<T> o = a.L[l];      // wave-uniform index
         T* row = lds + l * a.tile_stride;
-        if (lane < a.D) gf_derive_column<T>(row, o, a.D, lane);
+        if (lane < a.D) { if (o.stretch == JF_GF_STRETCH_CLASSIC) gf_derive_column<T>(row, o, a.D, lane); }
         else if (lane >= 32 && lane - 32 < o.hh) gf_derive_reflection<T>(row, o, a.D, lane - 32);
     }
     __syncthreads();
@@ -65,6 +66,7 @@ __global__ void __launch_bounds__(BCAST ? 256 : 64, sizeof(T) == 8 ? 2 : 4) gf_c
     const int D = a.D;
     const bool live = g < D, leader = g == 0;
     const int d = live ? g : D - 1;
+    T* spl_tab = lds + a.tab_offset;                    // lane-private knot tables (only sized when a layer uses rq_splines)
     if constexpr (BCAST) derive_broadcast<T>(lds, a);
 
     const int tiles = BCAST ? a.tiles_per_block : 1;
@@ -90,12 +92,28 @@ __global__ void __launch_bounds__(BCAST ? 256 : 64, sizeof(T) == 8 ? 2 : 4) gf_c
                 stage_rows<T>(lds, a.tile_stride, a.params + row0 * a.ps + o.col0, a.ps, o.n_params, R, valid_rows, tid, NT, o.vec_ok != 0);
                 __syncthreads();
                 if constexpr (FWD) {                     // 45 evaluations per layer follow: regulate the row once, in place
-                    gfg_derive<T, G>(lds + r * a.tile_stride, o, D, g);
+                    gfg_derive<T, G>(lds + r * a.tile_stride, o, D, g, o.stretch == JF_GF_STRETCH_CLASSIC);
                     __syncthreads();
                 }
                 p = lds + r * a.tile_stride + d;
             }
-            if constexpr (!FWD) {
+            if (o.stretch == JF_GF_STRETCH_RQ_SPLINES) {
+                // per-dimension spline with learnable box and linear tails (gaussianization_flow.py:926-940, 1060-1068); lane-private knot table
+                const T* pr = p - d;                                                         // start of the lane's row
+                T* tab = spl_tab + tid * JF_SPLINE_TAB;
+                if constexpr (!FWD) {
+                    if (o.model_offset) x -= p[0];
+                    x = gfg_rotate_inv<T, G, !BCAST>(p, o, D, live, x);
+                }
+                const SplineOut<T> r = spline_linext<T>(pr + o.off_mean + d * o.K, pr + o.off_lw + d * o.K, pr + o.off_ln + d * (o.K + 1),
+                                                        pr + o.off_box + d * 4, o.K, tab, x, FWD);
+                x = r.y;
+                ld += group_sum<T, G>(live ? r.lad : T(0));
+                if constexpr (FWD) {
+                    x = gfg_rotate_fwd<T, G, false>(p, o, D, live, x);
+                    if (o.model_offset) x += p[0];
+                }
+            } else if constexpr (!FWD) {
                 if (o.model_offset) x -= p[0];                                               // euclidean_base.py:40-45
                 x = gfg_rotate_inv<T, G, !BCAST>(p, o, D, live, x);
                 const MixQ<T> q = gfg_mixture<T, !BCAST>(p, o, D, x);
@@ -140,6 +158,7 @@ template <typename T> static int fill_args(GfChainArgs<T>& a, const T* params, i
     if (pb != 1 && pb != B) return JF_ERR_BADARG;
     bcast = (pb == 1);
     int col = 0, maxp = 0;
+    bool any_spline = false;
     for (int l = 0; l < n_layers; ++l) {
         const jf_gf_layer& h = layers[l];
         GfLayerDev<T>& o = a.L[l];
@@ -149,11 +168,21 @@ template <typename T> static int fill_args(GfChainArgs<T>& a, const T* params, i
         o.reg_norm = h.regulate_normalization; o.inv_type = h.inverse_function_type; o.width_mode = h.width_mode;
         o.clamp_widths = h.clamp_widths;
         const int kd = h.num_kde * D;
+        o.stretch = h.nonlinear_stretch_type;
+        if (o.stretch != JF_GF_STRETCH_CLASSIC && o.stretch != JF_GF_STRETCH_RQ_SPLINES) return JF_ERR_BADARG;
         o.off_rot = h.model_offset ? D : 0;
         o.off_mean = o.off_rot + h.hh_iter * D;
         o.off_lw = o.off_mean + kd;
         o.off_ln = o.off_lw + kd;
-        o.n_params = o.off_ln + (h.fit_normalization ? kd : 0);
+        if (o.stretch == JF_GF_STRETCH_RQ_SPLINES) {
+            if (h.num_kde > JF_SPLINE_MAX_BINS) return JF_ERR_UNSUPPORTED;
+            o.off_box = o.off_ln + (h.num_kde + 1) * D;
+            o.n_params = o.off_box + 4 * D;
+            any_spline = true;
+        } else {
+            o.off_box = 0;
+            o.n_params = o.off_ln + (h.fit_normalization ? kd : 0);
+        }
         o.col0 = col;
         o.vec_ok = (!bcast && aligned16<T>(params, ps, col) && (o.n_params % Vec16<T>::N == 0)) ? 1 : 0;
         o.wmin = (T)h.width_min; o.wmax = (T)h.width_max; o.inv_wmax = h.width_max > 0 ? (T)(1.0 / h.width_max) : T(0);
@@ -167,13 +196,11 @@ template <typename T> static int fill_args(GfChainArgs<T>& a, const T* params, i
     a.params = params; a.ps = ps; a.B = B; a.n_layers = n_layers; a.D = D;
     a.tile_stride = padded_stride<T>(maxp);
     const int G = group_width(D);
-    if (bcast) {
-        lds_bytes = (size_t)n_layers * a.tile_stride * sizeof(T);
-        a.tiles_per_block = 1;                           // set by launch_g from the kernel's occupancy
-    } else {
-        lds_bytes = (size_t)(64 / G) * a.tile_stride * sizeof(T);
-        a.tiles_per_block = 1;
-    }
+    size_t elems = bcast ? (size_t)n_layers * a.tile_stride : (size_t)(64 / G) * a.tile_stride;
+    a.tab_offset = (int)elems;
+    if (any_spline) elems += (size_t)(bcast ? 256 : 64) * JF_SPLINE_TAB;
+    lds_bytes = elems * sizeof(T);
+    a.tiles_per_block = 1;                               // broadcast: set by launch_g from the kernel's occupancy
     if (lds_bytes > (size_t)LDS_LIMIT) return JF_ERR_UNSUPPORTED;
     return JF_OK;
 }

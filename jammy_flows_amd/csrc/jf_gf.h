@@ -17,11 +17,14 @@
 #pragma once
 #include "jf_common.h"
 #include "jf_math.h"
+#include "jf_spline.h"
 
 namespace jf {
 
 template <typename T> struct GfLayerDev {
     int K, hh, model_offset, fit_norm, reg_norm, inv_type, width_mode, clamp_widths;
+    int stretch;                             // JF_GF_STRETCH_*: for RQ_SPLINES off_mean / off_lw / off_ln hold the log_w / log_h / log_d sections
+    int off_box;                             //   (each d-major, K / K / K+1 values per coordinate) and off_box the 4 box values per coordinate
     int n_params;                            // raw row length of this layer
     int col0;                                // first column of the layer inside the chain's parameter row
     int off_rot, off_mean, off_lw, off_ln;   // section offsets inside the layer row (elements)
@@ -328,8 +331,8 @@ template <typename T, bool RAW> __device__ __forceinline__ MixQ<T> gfg_mixture(c
 }
 
 // in-place derive of a staged raw row by the G lanes of its group: lane d < D takes column d, reflections are dealt round-robin
-template <typename T, int G> __device__ __forceinline__ void gfg_derive(T* __restrict__ row, const GfLayerDev<T>& o, int D, int g) {
-    if (g < D) gf_derive_column<T>(row, o, D, g);
+template <typename T, int G> __device__ __forceinline__ void gfg_derive(T* __restrict__ row, const GfLayerDev<T>& o, int D, int g, bool columns) {
+    if (columns && g < D) gf_derive_column<T>(row, o, D, g);
     for (int i = g; i < o.hh; i += G) gf_derive_reflection<T>(row, o, D, i);
 }
 

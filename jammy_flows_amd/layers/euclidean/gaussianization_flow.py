@@ -49,8 +49,6 @@ class gf_block(euclidean_base.euclidean_base):
             unsupported.append("add_skewness=1")
         if rotation_mode not in ("householder", "none"):
             unsupported.append("rotation_mode=%s" % rotation_mode)
-        if nonlinear_stretch_type != "classic":
-            unsupported.append("nonlinear_stretch_type=%s" % nonlinear_stretch_type)
         if unsupported:
             raise NotImplementedError("g layer option(s) without a HIP kernel yet: %s (no eager fallback exists)" % ", ".join(unsupported))
         assert lower_bound_for_widths > 0.0
@@ -90,12 +88,24 @@ class gf_block(euclidean_base.euclidean_base):
         self.total_param_num_means = num_kde * dimension
         bandwidth = (4. * numpy.sqrt(math.pi) / ((math.pi ** 4) * num_kde)) ** 0.2      # Gaussianization-flow paper init (:233)
         self.init_log_width = float(numpy.log(bandwidth))
-        if use_permanent_parameters:
-            self.kde_means = nn.Parameter(torch.randn(num_kde, dimension).unsqueeze(0))
-            self.kde_log_widths = nn.Parameter(torch.ones(num_kde, dimension).unsqueeze(0) * self.init_log_width)
-            if fit_normalization:
-                self.kde_log_weights = nn.Parameter(torch.randn(num_kde, dimension).unsqueeze(0))
-        self.total_param_num += 2 * self.num_params_datapoints + (self.num_params_datapoints if fit_normalization else 0)
+        if nonlinear_stretch_type == "classic":
+            if use_permanent_parameters:
+                self.kde_means = nn.Parameter(torch.randn(num_kde, dimension).unsqueeze(0))
+                self.kde_log_widths = nn.Parameter(torch.ones(num_kde, dimension).unsqueeze(0) * self.init_log_width)
+                if fit_normalization:
+                    self.kde_log_weights = nn.Parameter(torch.randn(num_kde, dimension).unsqueeze(0))
+            self.total_param_num += 2 * self.num_params_datapoints + (self.num_params_datapoints if fit_normalization else 0)
+        else:
+            # per-dimension rational-quadratic splines with a learnable box and linear tails (:370-382): (D, K) widths / heights,
+            # (D, K+1) derivatives, (D, 4) box = (left, ln(width - 0.5), bottom, ln(height - 0.5))
+            if num_kde > _hip.JF_SPLINE_MAX_BINS:
+                raise NotImplementedError("g layer with rq_splines: at most %d bins per dimension in the HIP kernel" % _hip.JF_SPLINE_MAX_BINS)
+            if use_permanent_parameters:
+                self.log_widths = nn.Parameter(torch.randn(dimension, num_kde).unsqueeze(0))
+                self.log_heights = nn.Parameter(torch.randn(dimension, num_kde).unsqueeze(0))
+                self.log_derivatives = nn.Parameter(torch.randn(dimension, num_kde + 1).unsqueeze(0))
+                self.boundary_points = nn.Parameter(torch.randn(dimension, 4).unsqueeze(0))
+            self.total_param_num += 2 * num_kde * dimension + (num_kde + 1) * dimension + 4 * dimension
 
         self._row_cache = None
         self._c_struct = None
@@ -119,6 +129,7 @@ class gf_block(euclidean_base.euclidean_base):
             s.inverse_function_type = _hip.GF_INV_TYPES[self.inverse_function_type]
             s.width_mode = mode
             s.clamp_widths = 1 if self.clamp_widths else 0
+            s.nonlinear_stretch_type = _hip.GF_STRETCH_RQ_SPLINES if self.nonlinear_stretch_type == "rq_splines" else _hip.GF_STRETCH_CLASSIC
             s.width_min = float(self.width_min)
             s.width_max = float(self.width_max) if self.width_max is not None else -1.0
             s.norm_min = float(self.lower_bound_for_norms)
@@ -132,6 +143,8 @@ class gf_block(euclidean_base.euclidean_base):
             ts.append(self.offsets)
         if self.use_householder:
             ts.append(self.vs)
+        if self.nonlinear_stretch_type == "rq_splines":
+            return ts + [self.log_widths, self.log_heights, self.log_derivatives, self.boundary_points]
         ts += [self.kde_means, self.kde_log_widths]
         if self.fit_normalization:
             ts.append(self.kde_log_weights)
@@ -174,6 +187,12 @@ class gf_block(euclidean_base.euclidean_base):
         vec = []
         if self.num_householder_params > 0:
             vec.append(torch.randn(self.householder_iter * self.dimension))
+        if self.nonlinear_stretch_type == "rq_splines":          # (:1150-1166)
+            vec.append(torch.ones(self.num_kde * self.dimension))
+            vec.append(torch.ones(self.num_kde * self.dimension))
+            vec.append(torch.ones((self.num_kde + 1) * self.dimension) * 0.54135)    # softplus^-1(1)
+            vec.append(torch.Tensor(self.dimension * [-1.0, 1.0, -1.0, 1.0]))
+            return torch.cat(vec)
         vec.append(torch.randn(self.total_param_num_means))
         vec.append(torch.ones(self.num_kde * self.dimension) * self.init_log_width)
         if self.fit_normalization:
@@ -186,6 +205,13 @@ class gf_block(euclidean_base.euclidean_base):
             self.vs.data = torch.reshape(params[:self.num_householder_params], [1, self.householder_iter, self.dimension])
             c += self.num_householder_params
         n = self.num_params_datapoints
+        if self.nonlinear_stretch_type == "rq_splines":          # (:1211-1222)
+            K, D = self.num_kde, self.dimension
+            self.log_widths.data = torch.reshape(params[c:c + K * D], [1, D, K]); c += K * D
+            self.log_heights.data = torch.reshape(params[c:c + K * D], [1, D, K]); c += K * D
+            self.log_derivatives.data = torch.reshape(params[c:c + (K + 1) * D], [1, D, K + 1]); c += (K + 1) * D
+            self.boundary_points.data = torch.reshape(params[c:c + 4 * D], [1, D, 4])
+            return
         self.kde_means.data = torch.reshape(params[c:c + n], [1, self.num_kde, self.dimension]); c += n
         self.kde_log_widths.data = torch.reshape(params[c:c + n], [1, self.num_kde, self.dimension]); c += n
         if self.fit_normalization:
@@ -197,6 +223,16 @@ class gf_block(euclidean_base.euclidean_base):
         if self.use_householder:
             param_dict[extra_prefix + "vs"] = (self.vs.data.reshape(1, -1) if extra_inputs is None else extra_inputs[:, :self.num_householder_params])
             c += self.num_householder_params
+        if self.nonlinear_stretch_type == "rq_splines":
+            K, D = self.num_kde, self.dimension
+            names = (("log_widths", K), ("log_heights", K), ("log_derivatives", K + 1), ("boundary_points", 4))
+            for name, w in names:
+                if extra_inputs is None:
+                    param_dict[extra_prefix + name] = getattr(self, name).data
+                else:
+                    param_dict[extra_prefix + name] = extra_inputs[:, c:c + D * w].reshape(-1, D, w)
+                    c += D * w
+            return
         if extra_inputs is None:
             param_dict[extra_prefix + "means"] = self.kde_means.data
             param_dict[extra_prefix + "log_widths"] = self.kde_log_widths.data

@@ -30,8 +30,8 @@ def test_library_exports_every_declared_symbol():
 
 def test_gf_layer_struct_matches_header():
     from jammy_flows_amd import _hip
-    # 8 int32 + 4 double, no padding surprises: sizeof must be 8*4 + 4*8
-    assert ctypes.sizeof(_hip.jf_gf_layer) == 64
+    # 10 int32 + 4 double, no padding surprises: sizeof must be 10*4 + 4*8
+    assert ctypes.sizeof(_hip.jf_gf_layer) == 72
 
 
 @pytest.mark.parametrize("fx", SUPPORTED, ids=[f.name for f in SUPPORTED])
