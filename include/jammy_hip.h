@@ -129,9 +129,15 @@ typedef struct jf_o_layer { jf_spline_opts sp; int32_t natural_direction, hh_ite
 /* 'm' Moebius mixture (moebius_1d.py:57-259, bisection_n_newton.py:137-256); row: [householder hh_iter*2][(wx,wy,logit-len,log-w) x nc] */
 typedef struct jf_m_layer { int32_t num_components, natural_direction, hh_iter, first; } jf_m_layer;
 /* 'f' von-Mises-Fisher z-scaling + optional vertical 'r' / circular 'o' flows (fvm_2d.py:273-726);
- * row: [householder hh_iter*3][log kappa][vertical rows][circular rows] */
+ * row: [householder hh_iter*3][log kappa][vertical rows][circular rows]
+ * correlated != 0 (add_correlated_rq_spline_flow, fvm_2d.py:244-262, 406-409, 575-578): the circular rows are not in the row but are
+ * emitted PER SAMPLE by a tanh MLP  z -> corr_hidden -> sum(circular row lengths)  whose own weights are in the row
+ * (amortize_everything layout of AmortizableMLP, amortizable_mlp.py:284-375: stage 1 [W1 H][b1 H] (input dim 1 => full matrix),
+ * stage 2 [U n_out x H][b2] if corr_full2 else [U n_out x rank][V rank x H][b2]); row: [householder][log kappa][vertical rows][MLP];
+ * the circular layers then carry their own Householder rotation (hh_iter of jf_o_layer) and no azimuthal scaling is applied. */
 typedef struct jf_f_layer {
     int32_t hh_iter, first, n_vertical, n_circular;
+    int32_t correlated, corr_hidden, corr_rank, corr_full2;
     double z_sign, min_kappa, identity_region;
     jf_r_layer vertical[JF_MAX_NESTED];
     jf_o_layer circular[JF_MAX_NESTED];

@@ -22,6 +22,7 @@ GF_INV_TYPES = {"isigmoid": 0, "inormal_partly_precise": 1, "inormal_partly_crud
 GF_WIDTH_SMOOTH, GF_WIDTH_EXP, GF_WIDTH_SOFTPLUS = 0, 1, 2
 GF_STRETCH_CLASSIC, GF_STRETCH_RQ_SPLINES = 0, 1
 JF_SPLINE_MAX_BINS = 16
+JF_CORR_SCRATCH = 81
 
 
 class HipUnavailable(RuntimeError):
@@ -61,6 +62,7 @@ JF_MAX_NESTED = 4
 
 class jf_f_layer(ctypes.Structure):
     _fields_ = [("hh_iter", ctypes.c_int32), ("first", ctypes.c_int32), ("n_vertical", ctypes.c_int32), ("n_circular", ctypes.c_int32),
+                ("correlated", ctypes.c_int32), ("corr_hidden", ctypes.c_int32), ("corr_rank", ctypes.c_int32), ("corr_full2", ctypes.c_int32),
                 ("z_sign", ctypes.c_double), ("min_kappa", ctypes.c_double), ("identity_region", ctypes.c_double),
                 ("vertical", jf_r_layer * JF_MAX_NESTED), ("circular", jf_o_layer * JF_MAX_NESTED)]
 

@@ -12,8 +12,11 @@
 
 namespace jf {
 
+constexpr int JF_CORR_SCRATCH = 81;   // odd stride; emitted parameters + rank accumulators of the correlated MLP
+
 template <typename T> struct LaneCtx {
     T* tab;              // lane-private LDS scratch (JF_SPLINE_TAB elements)
+    T* corr;             // lane-private LDS scratch for per-sample emitted parameters (JF_CORR_SCRATCH elements, 'f' correlated only)
     int64_t* bins;       // this row's bin slots (nullable)
     int bin_i;
     bool oob, nonconv, nonfinite;
@@ -239,13 +242,55 @@ template <typename T> __device__ __forceinline__ T azimuthal_scaling(T c) {     
 struct FFam {
     using CLayer = jf_f_layer;
     static constexpr int DIM = 2;
+    static __host__ __device__ int corr_out(const CLayer& L) {      // parameters the correlated MLP emits = rows of the circular layers incl. their rotations
+        int n = 0;
+        for (int i = 0; i < L.n_circular; ++i) n += 2 * L.circular[i].hh_iter + spline_row_len(L.circular[i].sp);
+        return n;
+    }
+    static __host__ __device__ int corr_len(const CLayer& L) {      // U/V/b vector of the MLP 1 -> H -> n_out (amortizable_mlp.py:284-375)
+        const int H = L.corr_hidden, n = corr_out(L);
+        return 2 * H + (L.corr_full2 ? n * H : L.corr_rank * (n + H)) + n;
+    }
     static __host__ int row_len(const CLayer& L) {
         int n = 3 * L.hh_iter + 1;
         for (int i = 0; i < L.n_vertical; ++i) n += spline_row_len(L.vertical[i].sp);
+        if (L.correlated) return n + corr_len(L);
         for (int i = 0; i < L.n_circular; ++i) n += spline_row_len(L.circular[i].sp);
         return n;
     }
     static __host__ int n_bins(const CLayer& L) { return L.n_vertical + L.n_circular; }
+    static __host__ int scratch(const CLayer& L) { return L.correlated ? JF_CORR_SCRATCH : 0; }
+
+    // the per-sample MLP of the correlated variant: out[0..n_out) = W2 tanh(W1 z + b1) + b2 with this row's own weights
+    // (_apply_amortized_mlp, amortizable_mlp.py:508-578); out / the rank accumulators live in the lane's LDS scratch
+    template <typename T> static __device__ inline void corr_mlp(const CLayer& L, const T* __restrict__ mp, T z, T* __restrict__ out) {
+        const int H = L.corr_hidden, R = L.corr_rank, n = corr_out(L);
+        const T* W1 = mp;
+        const T* b1 = mp + H;
+        const T* s2 = mp + 2 * H;
+        if (L.corr_full2) {
+            const T* b2 = s2 + n * H;
+            for (int i = 0; i < n; ++i) out[i] = b2[i];
+            for (int j = 0; j < H; ++j) {
+                const T h = M<T>::tanh(W1[j] * z + b1[j]);
+                for (int i = 0; i < n; ++i) out[i] += s2[i * H + j] * h;
+            }
+        } else {
+            const T* V = s2 + n * R;
+            const T* b2 = V + R * H;
+            T* t = out + n;
+            for (int r = 0; r < R; ++r) t[r] = T(0);
+            for (int j = 0; j < H; ++j) {
+                const T h = M<T>::tanh(W1[j] * z + b1[j]);
+                for (int r = 0; r < R; ++r) t[r] += V[r * H + j] * h;
+            }
+            for (int i = 0; i < n; ++i) {
+                T acc = T(0);
+                for (int r = 0; r < R; ++r) acc += s2[i * R + r] * t[r];
+                out[i] = acc + b2[i];
+            }
+        }
+    }
 
     template <typename T, bool FWD> static __device__ __forceinline__ void apply(const CLayer& L, const T* __restrict__ p, T (&x)[3], T& ld, LaneCtx<T>& c) {
         const T* fp = p + 3 * L.hh_iter;
@@ -267,6 +312,26 @@ struct FFam {
             ret = safe_cos<T>(ret, M<T>::EPS_COS);
             T angle = x[1];
             const bool inside = (region == T(0)) || ((ret > T(-1) + region) && (ret < T(1) - region));
+            if (L.correlated) {                                                             // :406-409: nested i1+s1 passthrough pdf, inverse direction
+                if (inside) {
+                    const T z_in = ret;                                                     // block 1 is conditioned on block 0's TARGET value
+                    int off = nv;
+                    for (int i = L.n_vertical - 1; i >= 0; --i) {
+                        off -= spline_row_len(L.vertical[i].sp);
+                        ret = r_core<T>(L.vertical[i], vert + off, ret, ld, c, true);
+                    }
+                    corr_mlp<T>(L, vert + nv, z_in, c.corr);
+                    int coff = corr_out(L);
+                    for (int i = L.n_circular - 1; i >= 0; --i) {
+                        coff -= 2 * L.circular[i].hh_iter + spline_row_len(L.circular[i].sp);
+                        T xx[3] = {angle, T(0), T(0)};
+                        OFam::apply<T, false>(L.circular[i], c.corr + coff, xx, ld, c);
+                        angle = xx[0];
+                    }
+                } else {
+                    for (int i = 0; i < L.n_vertical + L.n_circular; ++i) c.put_bin(-2);
+                }
+            } else {
             if (L.n_circular > 0) {                                                         // :416-427 (layers in reverse, tail-first)
                 const T sc = azimuthal_scaling<T>(ret);
                 int off = 0;
@@ -285,6 +350,7 @@ struct FFam {
                     else c.put_bin(-2);
                 }
             }
+            }
             ret = safe_cos<T>(ret, M<T>::EPS_COS);
             const T th = M<T>::acos(ret);
             ld -= M<T>::log(M<T>::sin(safe_angle_pi<T>(th)));
@@ -302,6 +368,25 @@ struct FFam {
             ld += M<T>::log(M<T>::sin(safe_angle_pi<T>(x[0])));
             T angle = x[1];
             const bool inside = (region == T(0)) || ((prev > T(-1) + region) && (prev < T(1) - region));
+            if (L.correlated) {                                                             // :575-578: sampling direction
+                if (inside) {
+                    int off = 0;
+                    for (int i = 0; i < L.n_vertical; ++i) {
+                        prev = r_core<T>(L.vertical[i], vert + off, prev, ld, c, false);
+                        off += spline_row_len(L.vertical[i].sp);
+                    }
+                    corr_mlp<T>(L, vert + nv, prev, c.corr);                                // conditioned on the PRODUCED target of block 0
+                    int coff = 0;
+                    for (int i = 0; i < L.n_circular; ++i) {
+                        T xx[3] = {angle, T(0), T(0)};
+                        OFam::apply<T, true>(L.circular[i], c.corr + coff, xx, ld, c);
+                        angle = xx[0];
+                        coff += 2 * L.circular[i].hh_iter + spline_row_len(L.circular[i].sp);
+                    }
+                } else {
+                    for (int i = 0; i < L.n_vertical + L.n_circular; ++i) c.put_bin(-2);
+                }
+            } else {
             if (L.n_vertical > 0) {                                                         // :591-592 (layers in order, head-first)
                 int off = 0;
                 for (int i = 0; i < L.n_vertical; ++i) {
@@ -318,6 +403,7 @@ struct FFam {
                     else c.put_bin(-2);
                     off += spline_row_len(L.circular[i].sp);
                 }
+            }
             }
             ld -= M<T>::log(kappa * zs * prev + kappa / M<T>::tanh(kappa));                   // :698
             T ret = zs * (T(1) + (T(1) / kappa) * M<T>::log(T(0.5) * (T(1) + zs * prev) + (T(0.5) - T(0.5) * zs * prev) * M<T>::exp(T(-2) * kappa)));

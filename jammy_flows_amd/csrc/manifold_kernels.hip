@@ -20,6 +20,8 @@ template <typename T, typename CLayer> struct MChainArgs {
     int n_layers;
     int dim;                 // columns of x actually used (<= Fam::DIM)
     int tile_stride;
+    int scratch;             // per-lane elements of the emitted-parameter scratch behind the knot tables (0 = none)
+    int rows;                // rows per workgroup (64 unless the parameter tile of 64 rows would not fit in LDS)
     int vec_ok[JF_MAX_MCHAIN];
     int col0[JF_MAX_MCHAIN];
     int ncols[JF_MAX_MCHAIN];
@@ -36,13 +38,16 @@ __global__ void __launch_bounds__(64) mchain_kernel(const MChainArgs<T, typename
     extern __shared__ __align__(16) unsigned char smem_raw[];
     T* tile = reinterpret_cast<T*>(smem_raw);
     const int tid = threadIdx.x;
-    const int tile_rows = a.bcast ? 1 : 64;
-    T* tab = tile + tile_rows * a.tile_stride + tid * JF_SPLINE_TAB;
-    const int64_t row0 = (int64_t)blockIdx.x * 64;
+    const int rows = a.rows;
+    const int tile_rows = a.bcast ? 1 : rows;
+    const bool lane_in = tid < rows;                     // lanes beyond the workgroup's rows idle (they own no scratch)
+    const int slot = lane_in ? tid : 0;
+    T* tab = tile + tile_rows * a.tile_stride + slot * JF_SPLINE_TAB;
+    const int64_t row0 = (int64_t)blockIdx.x * rows;
     const int64_t row = row0 + tid;
-    const bool active = row < a.B;
+    const bool active = lane_in && row < a.B;
     const int64_t rrow = active ? row : a.B - 1;
-    const int valid_rows = (int)((a.B - row0) < 64 ? (a.B - row0) : 64);
+    const int valid_rows = (int)((a.B - row0) < rows ? (a.B - row0) : rows);
 
     T x[3] = {T(0), T(0), T(0)};
 #pragma unroll
@@ -50,6 +55,7 @@ __global__ void __launch_bounds__(64) mchain_kernel(const MChainArgs<T, typename
     T ld = a.ld_in ? a.ld_in[rrow] : T(0);
     LaneCtx<T> ctx;
     ctx.tab = tab;
+    ctx.corr = tile + tile_rows * a.tile_stride + rows * JF_SPLINE_TAB + slot * a.scratch;
     ctx.bins = (a.bins && active) ? a.bins + row * a.bins_stride : nullptr;
     ctx.bin_i = 0;
     ctx.oob = ctx.nonconv = ctx.nonfinite = false;
@@ -61,11 +67,11 @@ __global__ void __launch_bounds__(64) mchain_kernel(const MChainArgs<T, typename
         if (a.bcast) {
             for (int j = tid; j < a.ncols[l]; j += 64) tile[j] = a.params[a.col0[l] + j];
         } else {
-            stage_rows<T>(tile, a.tile_stride, a.params + row0 * a.ps + a.col0[l], a.ps, a.ncols[l], 64, valid_rows, tid, 64, a.vec_ok[l] != 0);
+            stage_rows<T>(tile, a.tile_stride, a.params + row0 * a.ps + a.col0[l], a.ps, a.ncols[l], rows, valid_rows, tid, 64, a.vec_ok[l] != 0);
         }
         __syncthreads();
-        const T* prow = tile + (a.bcast ? 0 : tid * a.tile_stride);
-        Fam::template apply<T, FWD>(a.L[l], prow, x, ld, ctx);
+        const T* prow = tile + (a.bcast ? 0 : slot * a.tile_stride);
+        if (lane_in) Fam::template apply<T, FWD>(a.L[l], prow, x, ld, ctx);
     }
     bool bad = !M<T>::finite(ld);
 #pragma unroll
@@ -109,11 +115,26 @@ static int mchain(const T* x, int64_t xs, const T* ld_in, const T* params, int64
     a.dim = Fam::DIM;
     if constexpr (std::is_same<Fam, CFam>::value) a.dim = layers[0].kind == 2 ? 2 : 1;
     a.x_out = x_out; a.xos = xos; a.ld_out = ld_out; a.blp_in = blp_in; a.blp_out = blp_out; a.bins = bins; a.bins_stride = bins_stride; a.status = status;
-    const size_t lds = ((size_t)(a.bcast ? 1 : 64) * a.tile_stride + 64 * JF_SPLINE_TAB) * sizeof(T);
+    a.scratch = 0;
+    if constexpr (std::is_same<Fam, FFam>::value) {
+        for (int l = 0; l < n_layers; ++l) {
+            if (!layers[l].correlated) continue;
+            if (layers[l].corr_hidden < 1 || layers[l].corr_rank < 0 || FFam::corr_out(layers[l]) + layers[l].corr_rank > JF_CORR_SCRATCH - 1)
+                return JF_ERR_UNSUPPORTED;
+            a.scratch = JF_CORR_SCRATCH;
+        }
+    }
+    a.rows = 64;
+    size_t lds = 0;
+    for (;;) {
+        lds = ((size_t)(a.bcast ? 1 : a.rows) * a.tile_stride + (size_t)a.rows * (JF_SPLINE_TAB + a.scratch)) * sizeof(T);
+        if (lds <= 160 * 1024 || a.rows == 8) break;
+        a.rows >>= 1;
+    }
     if (lds > 160 * 1024) return JF_ERR_UNSUPPORTED;
     auto k = mchain_kernel<T, Fam, FWD>;
     if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k, dim3((unsigned)((B + 63) / 64)), dim3(64), lds, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(k, dim3((unsigned)((B + a.rows - 1) / a.rows)), dim3(64), lds, (hipStream_t)stream, a);
     return check_launch();
 }
 

@@ -3,7 +3,8 @@
 
 Where the reference embeds nested ``pdf`` objects as passthrough flows (:193-197, 221-225) this implementation flattens them at
 construction into the jf_f_layer descriptor; the whole layer (rotation, kappa map, nested splines, S2 <-> R2 chart) is ONE launch of
-the 'f' HIP kernel (jf_f_chain_*).  The correlated variant (per-sample amortised MLP between the two spline flows) has no kernel yet.
+the 'f' HIP kernel (jf_f_chain_*).  The correlated variant (azimuthal spline parameters emitted per sample by an MLP of z whose weights are themselves in the
+layer's row) is evaluated inside the same kernel.
 """
 import torch
 from torch import nn
@@ -39,8 +40,6 @@ class fisher_von_mises_2d(sphere_base.sphere_base):
             unsupported.append("kappa_clamping=1")
         if add_extra_rotation_inbetween:
             unsupported.append("add_extra_rotation_inbetween=1")
-        if add_correlated_rq_spline_flow:
-            unsupported.append("add_correlated_rq_spline_flow=1")
         if unsupported:
             raise NotImplementedError("f layer option(s) without a HIP kernel yet: %s" % ", ".join(unsupported))
         self.z_scaling_factor = -1.0 if inverse_z_scaling else 1.0
@@ -53,7 +52,7 @@ class fisher_von_mises_2d(sphere_base.sphere_base):
         self.total_param_num += 1
         self.add_vertical_rq_spline_flow = add_vertical_rq_spline_flow
         self.add_circular_rq_spline_flow = add_circular_rq_spline_flow
-        self.add_correlated_rq_spline_flow = 0
+        self.add_correlated_rq_spline_flow = add_correlated_rq_spline_flow
         self.boundary_cos_theta_identity_region = boundary_cos_theta_identity_region
         self.spline_num_basis_functions = spline_num_basis_functions
         if spline_num_basis_functions == -1:
@@ -93,9 +92,38 @@ class fisher_von_mises_2d(sphere_base.sphere_base):
             self.total_param_num += self.total_num_circular_params
             if use_permanent_parameters:
                 self.circular_flow_params = nn.Parameter(torch.randn(1, self.total_num_circular_params))
+        self.total_num_correlated_params = 0
+        self._corr_mlp = None
+        if add_correlated_rq_spline_flow:
+            # the reference nests pdf("i1_-b_b+s1", vertical_flow_defs + "+" + circular_flow_defs, amortize_everything=True,
+            # amortization_mlp_use_custom_mode=True, amortization_mlp_dims="64", amortization_mlp_ranks=correlated_max_rank) with DEFAULT
+            # layer options (:244-262): the z splines take their rows from this layer's row, the azimuthal splines (incl. their own
+            # Householder rotations) take theirs from a per-sample MLP of z whose weights are in this layer's row as well
+            assert add_circular_rq_spline_flow == 0
+            assert add_vertical_rq_spline_flow == 0
+            from ... import flow_options
+            from ...amortizable_mlp import AmortizableMLP
+            r_opts, o_opts = flow_options.obtain_default_options("r"), flow_options.obtain_default_options("o")
+            for letter in vertical_flow_defs:
+                assert letter == "r", "vertical flows must be 'r' layers"
+                self._vertical.append(rational_quadratic_spline(1, euclidean_to_interval_as_first=0, use_permanent_parameters=0,
+                                                                low_boundary=-bound, high_boundary=bound, **r_opts))
+            for letter in circular_flow_defs:
+                assert letter == "o", "circular flows must be 'o' layers"
+                self._circular.append(spline_1d(1, euclidean_to_sphere_as_first=0, use_permanent_parameters=0, **o_opts))
+            n_vert = sum(l.total_param_num for l in self._vertical)
+            n_circ = sum(l.total_param_num for l in self._circular)
+            self._corr_mlp = AmortizableMLP(1, "64", n_circ, low_rank_approximations=correlated_max_rank, use_permanent_parameters=False)
+            assert self._corr_mlp.stages[0]["full"] and len(self._corr_mlp.stages) == 2
+            self.total_num_correlated_params = n_vert + self._corr_mlp.num_amortization_params
+            self.total_param_num += self.total_num_correlated_params
+            if n_circ + self._corr_mlp.stages[1]["rank"] > _hip.JF_CORR_SCRATCH - 1:
+                raise NotImplementedError("correlated f flow: the nested circular flows need %d parameters, the kernel holds at most %d"
+                                          % (n_circ, _hip.JF_CORR_SCRATCH - 1 - self._corr_mlp.stages[1]["rank"]))
+            if use_permanent_parameters:
+                self.correlated_flow_params = nn.Parameter(torch.randn(1, self.total_num_correlated_params))
         if len(self._vertical) > _hip.JF_MAX_NESTED or len(self._circular) > _hip.JF_MAX_NESTED:
             raise NotImplementedError("at most %d nested vertical / circular layers are supported by the kernel" % _hip.JF_MAX_NESTED)
-        self.total_num_correlated_params = 0
         self.add_extra_rotation_inbetween = 0
 
     def c_struct(self, first):
@@ -111,6 +139,9 @@ class fisher_von_mises_2d(sphere_base.sphere_base):
             L.vertical[i] = l.c_struct(0)
         for i, l in enumerate(self._circular):
             L.circular[i] = l.c_struct(0)
+        if self._corr_mlp is not None:
+            st = self._corr_mlp.stages[1]
+            L.correlated, L.corr_hidden, L.corr_rank, L.corr_full2 = 1, st["inp"], st["rank"], int(st["full"])
         return L
 
     def n_spline_calls(self):
@@ -122,12 +153,16 @@ class fisher_von_mises_2d(sphere_base.sphere_base):
             ts.append(self.vertical_flow_params)
         if self.add_circular_rq_spline_flow:
             ts.append(self.circular_flow_params)
+        if self.add_correlated_rq_spline_flow:
+            ts.append(self.correlated_flow_params)
         return ts
 
     def _init_params(self, params):
         self.loglike_kappa.data = params[:1].reshape(1, 1)
-        assert len(params) == 1 + self.total_num_vertical_params + self.total_num_circular_params
+        assert len(params) == 1 + self.total_num_vertical_params + self.total_num_circular_params + self.total_num_correlated_params
         c = 1
+        if self.add_correlated_rq_spline_flow:
+            self.correlated_flow_params.data = params[c:c + self.total_num_correlated_params].reshape(1, -1)
         if self.add_vertical_rq_spline_flow:
             self.vertical_flow_params.data = params[c:c + self.total_num_vertical_params].reshape(1, -1)
             c += self.total_num_vertical_params
@@ -137,6 +172,10 @@ class fisher_von_mises_2d(sphere_base.sphere_base):
     def _get_desired_init_parameters(self):
         parts = [torch.randn(1) - 3.0]                                   # log kappa (:750)
         parts += [l.get_desired_init_parameters() for l in self._vertical]
+        if self._corr_mlp is not None:       # nested pdf.init_params() (:756-758): the MLP starts damped with the circular init as final bias
+            circ = torch.cat([l.get_desired_init_parameters() for l in self._circular])
+            parts.append(self._corr_mlp.obtain_default_init_tensor(fix_final_bias=circ).to(parts[0].dtype))
+            return torch.cat(parts)
         parts += [l.get_desired_init_parameters() for l in self._circular]
         return torch.cat(parts)
 
@@ -149,9 +188,13 @@ class fisher_von_mises_2d(sphere_base.sphere_base):
                 c += self.total_num_vertical_params
             if self.add_circular_rq_spline_flow:
                 param_dict[extra_prefix + "circular_params"] = extra_inputs[:, c:c + self.total_num_circular_params].data
+            if self.add_correlated_rq_spline_flow:
+                param_dict[extra_prefix + "correlated_params"] = extra_inputs[:, c:c + self.total_num_correlated_params].data
         else:
             param_dict[extra_prefix + "loglike_kappa"] = self.loglike_kappa.data
             if self.add_vertical_rq_spline_flow:
                 param_dict[extra_prefix + "vertical_params"] = self.vertical_flow_params.data
             if self.add_circular_rq_spline_flow:
                 param_dict[extra_prefix + "circular_params"] = self.circular_flow_params.data
+            if self.add_correlated_rq_spline_flow:
+                param_dict[extra_prefix + "correlated_params"] = self.correlated_flow_params.data
