@@ -65,24 +65,26 @@ typedef struct jf_gf_layer {
 
 /* log-prob direction of a chain of `n_layers` g layers applied in REVERSE order (layer n-1 first), all in one launch.
  * params row = the layers' rows concatenated in layer order 0..n-1.  log_det_in / base_logp_in may be NULL (= 0);
- * base_logp_out (nullable) receives base_logp_in + sum_d N(0,1).log_prob(x_out_d)  (main/default.py:1110-1115). */
+ * base_logp_out (nullable) receives base_logp_in + sum_d N(0,1).log_prob(x_out_d)  (main/default.py:1110-1115).
+ * bins (nullable, row stride bins_stride): raw searchsorted result of every rq_splines layer in execution order, D columns per such
+ * layer (spline_fns.py:13-19, 252-258) -- the integer output the bit-exact parity tests compare. */
 int jf_gf_chain_inv_f32(const float* x, int64_t x_stride, const float* log_det_in, const float* params, int64_t param_stride,
                         int32_t param_batch, int64_t B, int32_t D, int32_t n_layers, const jf_gf_layer* layers, float* x_out,
                         int64_t x_out_stride, float* log_det_out, const float* base_logp_in, float* base_logp_out,
-                        int32_t* status, void* stream);
+                        int64_t* bins, int64_t bins_stride, int32_t* status, void* stream);
 int jf_gf_chain_inv_f64(const double* x, int64_t x_stride, const double* log_det_in, const double* params, int64_t param_stride,
                         int32_t param_batch, int64_t B, int32_t D, int32_t n_layers, const jf_gf_layer* layers, double* x_out,
                         int64_t x_out_stride, double* log_det_out, const double* base_logp_in, double* base_logp_out,
-                        int32_t* status, void* stream);
+                        int64_t* bins, int64_t bins_stride, int32_t* status, void* stream);
 
 /* sampling direction: layers applied in order 0..n-1; each solves its mixture-CDF map by 25 bisection steps on [-1e5,1e5]
  * + <= 20 Newton steps (row stops when sum_d |update| < 1e-14).  log_det_out = log_det_in - sum log-derivatives. */
 int jf_gf_chain_fwd_f32(const float* z, int64_t z_stride, const float* log_det_in, const float* params, int64_t param_stride,
                         int32_t param_batch, int64_t B, int32_t D, int32_t n_layers, const jf_gf_layer* layers, float* x_out,
-                        int64_t x_out_stride, float* log_det_out, int32_t* status, void* stream);
+                        int64_t x_out_stride, float* log_det_out, int64_t* bins, int64_t bins_stride, int32_t* status, void* stream);
 int jf_gf_chain_fwd_f64(const double* z, int64_t z_stride, const double* log_det_in, const double* params, int64_t param_stride,
                         int32_t param_batch, int64_t B, int32_t D, int32_t n_layers, const jf_gf_layer* layers, double* x_out,
-                        int64_t x_out_stride, double* log_det_out, int32_t* status, void* stream);
+                        int64_t x_out_stride, double* log_det_out, int64_t* bins, int64_t bins_stride, int32_t* status, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Dense layer of the parameter-emitting MLPs: out = act(in @ W^T + bias)   (MFMA)

@@ -89,8 +89,8 @@ _I32 = ctypes.c_int32
 
 # name -> argtypes (without the _f32/_f64 suffix); every entry point of include/jammy_hip.h
 _SIGNATURES = {
-    "jf_gf_chain_inv": [_P, _I64, _P, _P, _I64, _I32, _I64, _I32, _I32, ctypes.POINTER(jf_gf_layer), _P, _I64, _P, _P, _P, _P, _P],
-    "jf_gf_chain_fwd": [_P, _I64, _P, _P, _I64, _I32, _I64, _I32, _I32, ctypes.POINTER(jf_gf_layer), _P, _I64, _P, _P, _P],
+    "jf_gf_chain_inv": [_P, _I64, _P, _P, _I64, _I32, _I64, _I32, _I32, ctypes.POINTER(jf_gf_layer), _P, _I64, _P, _P, _P, _P, _I64, _P, _P],
+    "jf_gf_chain_fwd": [_P, _I64, _P, _P, _I64, _I32, _I64, _I32, _I32, ctypes.POINTER(jf_gf_layer), _P, _I64, _P, _P, _I64, _P, _P],
     "jf_linear": [_P, _I64, _P, _I64, _P, _I64, _I32, _I32, _I32, _P, _I64, _P],
     "jf_normal_logp": [_P, _I64, _I64, _I32, _P, _P, _P],
     "jf_mlp2": [_P, _I64, _P, _I64, _P, _P, _I64, _P, _I64, _I32, _I32, _I32, _P, _I64, _P],
@@ -237,6 +237,11 @@ def gf_layer_array(structs):
     return arr
 
 
+# When set to a list, every spline-carrying chain launch appends its (B, n_searches) int64 tensor of raw searchsorted results
+# (execution order, -3 = not written, -2 = row skipped by an identity region): the integer output of the bit-exact parity tests.
+BINS_LOG = None
+
+
 def gf_chain(direction, x, log_det, params, layer_array, n_layers, D, x_out=None, base_logp_in=None, want_base_logp=False, status=None):
     """run a chain of g layers.  direction 'inv' (log-prob) or 'fwd' (sampling).
     x (B, D) view (row stride arbitrary), log_det (B,) or None, params (1|B, P).  Returns (x_out, log_det_out[, base_logp])."""
@@ -261,15 +266,22 @@ def gf_chain(direction, x, log_det, params, layer_array, n_layers, D, x_out=None
     pb = 1 if (params.shape[0] == 1 and B != 1) else params.shape[0]
     if B == 1:
         pb = 1
+    bins = None
+    if BINS_LOG is not None:
+        n_spl = sum(1 for i in range(n_layers) if layer_array[i].nonlinear_stretch_type == GF_STRETCH_RQ_SPLINES)
+        if n_spl:
+            bins = torch.full((B, n_spl * D), -3, dtype=torch.int64, device=x.device)
+            BINS_LOG.append(bins)
+    bs = bins.stride(0) if bins is not None else 0
     if direction == "inv":
         blp_out = torch.empty((B,), dtype=x.dtype, device=x.device) if want_base_logp else None
         _launch("jf_gf_chain_inv" + suf, "bcast" if pb == 1 else "per-sample",
                 (_ptr(x), x.stride(0), _ptr(log_det), _ptr(params), params.stride(0), pb, B, D, n_layers, layer_array, _ptr(x_out),
-                 x_out.stride(0), _ptr(ld_out), _ptr(base_logp_in), _ptr(blp_out), _ptr(status), _stream()))
+                 x_out.stride(0), _ptr(ld_out), _ptr(base_logp_in), _ptr(blp_out), _ptr(bins), bs, _ptr(status), _stream()))
         return (x_out, ld_out, blp_out) if want_base_logp else (x_out, ld_out)
     _launch("jf_gf_chain_fwd" + suf, "bcast" if pb == 1 else "per-sample",
             (_ptr(x), x.stride(0), _ptr(log_det), _ptr(params), params.stride(0), pb, B, D, n_layers, layer_array, _ptr(x_out), x_out.stride(0),
-             _ptr(ld_out), _ptr(status), _stream()))
+             _ptr(ld_out), _ptr(bins), bs, _ptr(status), _stream()))
     return x_out, ld_out
 
 
@@ -336,6 +348,11 @@ def mchain(fam, direction, x, log_det, params, layer_structs, dim, x_out=None, b
     arr = (MCHAIN_LAYER_TYPES[fam] * n)(*layer_structs)
     suf = _suffix(x)
     name = "jf_%s_chain_%s%s" % (fam, direction, suf)
+    if bins is None and BINS_LOG is not None and fam in ("r", "o", "f"):
+        n_search = sum(1 if fam in "ro" else (L.n_vertical + L.n_circular) for L in layer_structs)
+        if n_search:
+            bins = torch.full((B, n_search), -3, dtype=torch.int64, device=x.device)
+            BINS_LOG.append(bins)
     if bins is not None:
         assert bins.dtype == torch.int64 and bins.dim() == 2 and bins.shape[0] == B and bins.stride(1) == 1
     _launch(name, "bcast" if pb == 1 else "per-sample",

@@ -33,6 +33,7 @@ template <typename T> struct GfChainArgs {
     T* x_out; int64_t xos;
     T* ld_out;
     const T* blp_in; T* blp_out;
+    int64_t* bins; int64_t bins_stride;
     int32_t* status;
 };
 
@@ -81,6 +82,7 @@ __global__ void __launch_bounds__(BCAST ? 256 : 64, sizeof(T) == 8 ? 2 : 4) gf_c
         T x = a.x[rrow * a.xs + d];
         T ld = a.ld_in ? a.ld_in[rrow] : T(0);
 
+        int spline_calls = 0;
         for (int li = 0; li < a.n_layers; ++li) {
             const int l = FWD ? li : a.n_layers - 1 - li;
             const GfLayerDev<T> o = a.L[l];              // uniform index: scalar loads from the kernarg segment
@@ -109,6 +111,8 @@ __global__ void __launch_bounds__(BCAST ? 256 : 64, sizeof(T) == 8 ? 2 : 4) gf_c
                                                         pr + o.off_box + d * 4, o.K, tab, x, FWD);
                 x = r.y;
                 ld += group_sum<T, G>(live ? r.lad : T(0));
+                if (a.bins != nullptr && row_valid && live) a.bins[row * a.bins_stride + spline_calls * D + d] = (int64_t)r.bin;
+                ++spline_calls;
                 if constexpr (FWD) {
                     x = gfg_rotate_fwd<T, G, false>(p, o, D, live, x);
                     if (o.model_offset) x += p[0];
@@ -250,24 +254,28 @@ template <typename T, bool FWD> static int launch(const GfChainArgs<T>& a, int D
 
 template <typename T>
 static int gf_chain_inv(const T* x, int64_t xs, const T* ld_in, const T* params, int64_t ps, int32_t pb, int64_t B, int32_t D, int32_t n_layers,
-                        const jf_gf_layer* layers, T* x_out, int64_t xos, T* ld_out, const T* blp_in, T* blp_out, int32_t* status, void* stream) {
+                        const jf_gf_layer* layers, T* x_out, int64_t xos, T* ld_out, const T* blp_in, T* blp_out, int64_t* bins, int64_t bins_stride,
+                        int32_t* status, void* stream) {
     if (!x || !params || !x_out || !ld_out) return JF_ERR_BADARG;
     GfChainArgs<T> a{};
     size_t lds = 0; bool bcast = false;
     int rc = fill_args<T>(a, params, ps, pb, B, D, n_layers, layers, lds, bcast);
     if (rc != JF_OK) return rc;
     a.x = x; a.xs = xs; a.ld_in = ld_in; a.x_out = x_out; a.xos = xos; a.ld_out = ld_out; a.blp_in = blp_in; a.blp_out = blp_out; a.status = status;
+    a.bins = bins; a.bins_stride = bins_stride;
     return launch<T, false>(a, D, bcast, lds, (hipStream_t)stream);
 }
 template <typename T>
 static int gf_chain_fwd(const T* z, int64_t zs, const T* ld_in, const T* params, int64_t ps, int32_t pb, int64_t B, int32_t D, int32_t n_layers,
-                        const jf_gf_layer* layers, T* x_out, int64_t xos, T* ld_out, int32_t* status, void* stream) {
+                        const jf_gf_layer* layers, T* x_out, int64_t xos, T* ld_out, int64_t* bins, int64_t bins_stride, int32_t* status,
+                        void* stream) {
     if (!z || !params || !x_out || !ld_out) return JF_ERR_BADARG;
     GfChainArgs<T> a{};
     size_t lds = 0; bool bcast = false;
     int rc = fill_args<T>(a, params, ps, pb, B, D, n_layers, layers, lds, bcast);
     if (rc != JF_OK) return rc;
     a.x = z; a.xs = zs; a.ld_in = ld_in; a.x_out = x_out; a.xos = xos; a.ld_out = ld_out; a.blp_in = nullptr; a.blp_out = nullptr; a.status = status;
+    a.bins = bins; a.bins_stride = bins_stride;
     return launch<T, true>(a, D, bcast, lds, (hipStream_t)stream);
 }
 
@@ -277,19 +285,21 @@ extern "C" {
 int jf_abi_version(void) { return 1; }
 
 int jf_gf_chain_inv_f32(const float* x, int64_t xs, const float* ld_in, const float* p, int64_t ps, int32_t pb, int64_t B, int32_t D, int32_t n,
-                        const jf_gf_layer* L, float* xo, int64_t xos, float* ldo, const float* bi, float* bo, int32_t* st, void* s) {
-    return jf::gf_chain_inv<float>(x, xs, ld_in, p, ps, pb, B, D, n, L, xo, xos, ldo, bi, bo, st, s);
+                        const jf_gf_layer* L, float* xo, int64_t xos, float* ldo, const float* bi, float* bo, int64_t* bins, int64_t bs, int32_t* st,
+                        void* s) {
+    return jf::gf_chain_inv<float>(x, xs, ld_in, p, ps, pb, B, D, n, L, xo, xos, ldo, bi, bo, bins, bs, st, s);
 }
 int jf_gf_chain_inv_f64(const double* x, int64_t xs, const double* ld_in, const double* p, int64_t ps, int32_t pb, int64_t B, int32_t D, int32_t n,
-                        const jf_gf_layer* L, double* xo, int64_t xos, double* ldo, const double* bi, double* bo, int32_t* st, void* s) {
-    return jf::gf_chain_inv<double>(x, xs, ld_in, p, ps, pb, B, D, n, L, xo, xos, ldo, bi, bo, st, s);
+                        const jf_gf_layer* L, double* xo, int64_t xos, double* ldo, const double* bi, double* bo, int64_t* bins, int64_t bs,
+                        int32_t* st, void* s) {
+    return jf::gf_chain_inv<double>(x, xs, ld_in, p, ps, pb, B, D, n, L, xo, xos, ldo, bi, bo, bins, bs, st, s);
 }
 int jf_gf_chain_fwd_f32(const float* z, int64_t zs, const float* ld_in, const float* p, int64_t ps, int32_t pb, int64_t B, int32_t D, int32_t n,
-                        const jf_gf_layer* L, float* xo, int64_t xos, float* ldo, int32_t* st, void* s) {
-    return jf::gf_chain_fwd<float>(z, zs, ld_in, p, ps, pb, B, D, n, L, xo, xos, ldo, st, s);
+                        const jf_gf_layer* L, float* xo, int64_t xos, float* ldo, int64_t* bins, int64_t bs, int32_t* st, void* s) {
+    return jf::gf_chain_fwd<float>(z, zs, ld_in, p, ps, pb, B, D, n, L, xo, xos, ldo, bins, bs, st, s);
 }
 int jf_gf_chain_fwd_f64(const double* z, int64_t zs, const double* ld_in, const double* p, int64_t ps, int32_t pb, int64_t B, int32_t D, int32_t n,
-                        const jf_gf_layer* L, double* xo, int64_t xos, double* ldo, int32_t* st, void* s) {
-    return jf::gf_chain_fwd<double>(z, zs, ld_in, p, ps, pb, B, D, n, L, xo, xos, ldo, st, s);
+                        const jf_gf_layer* L, double* xo, int64_t xos, double* ldo, int64_t* bins, int64_t bs, int32_t* st, void* s) {
+    return jf::gf_chain_fwd<double>(z, zs, ld_in, p, ps, pb, B, D, n, L, xo, xos, ldo, bins, bs, st, s);
 }
 }

@@ -155,3 +155,44 @@ def test_full_size_batch_properties():
     small = pdf(x_small)[0]
     assert torch.equal(a[: x_small.shape[0]], small)
     assert torch.equal(a[x_small.shape[0]: 2 * x_small.shape[0]], small)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# spline bin indices: bit-exact (north star).  Every searchsorted call of the reference is recorded in the fixtures (raw result, call
+# order); the kernels write the same integers through the `bins` output of the C ABI.
+BIN_FIXTURES = [fx for fx in helpers.ALL_FIXTURES if int(fx.meta.get("n_bins_inv", 0)) > 0]
+
+
+def _collect_bins(fx, direction, dtype):
+    from jammy_flows_amd import _hip
+    pdf = helpers.build_product(fx, dtype)
+    cond = helpers.to_dev(fx.get("cond"), dtype)
+    _hip.BINS_LOG = []
+    try:
+        if direction == "inv":
+            pdf(helpers.to_dev(fx["x"], dtype), conditional_input=cond, force_embedding_coordinates=bool(fx.meta["embedding"]))
+        else:
+            pdf.sample(conditional_input=cond, samplesize=fx["z"].shape[0], force_embedding_coordinates=bool(fx.meta["embedding"]),
+                       base_noise=helpers.to_dev(fx["z"], dtype)) if hasattr(pdf, "sample") else None
+        cols = []
+        for t in _hip.BINS_LOG:
+            t = t.cpu().numpy()
+            cols += [t[:, j] for j in range(t.shape[1])]
+    finally:
+        _hip.BINS_LOG = None
+    return cols
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fx", BIN_FIXTURES, ids=lambda f: f.name)
+def test_spline_bins_bit_exact_float64(fx):
+    cols = _collect_bins(fx, "inv", torch.float64)
+    ref = []
+    for b in fx.bins("inv"):                       # (B', 1) per call, or (B', D, 1) for the per-dimension splines of 'g'
+        b = b.reshape(b.shape[0], -1)
+        ref += [b[:, j] for j in range(b.shape[1])]
+    assert len(cols) == len(ref), (len(cols), len(ref))
+    for i, (c, r) in enumerate(zip(cols, ref)):
+        c = c[c != -2]                             # rows inside an identity region never reach searchsorted in the reference
+        assert c.shape == r.shape, (i, c.shape, r.shape)
+        assert np.array_equal(c, r.astype(np.int64)), "search %d: %d of %d bin indices differ" % (i, int((c != r).sum()), c.size)
