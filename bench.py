@@ -84,7 +84,8 @@ def cpu_baseline(budget_s=20.0):
 
 # ---------------------------------------------------------------------------------------------- HBM traffic from the committed PMC passes
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r01_c_traffic.json")
-TRAFFIC_KEYS = {("jf_mlp2_f32", "K7_H128_N548"): "jf::mlp2_kernel<float, 4, 2, true>",
+TRAFFIC_KEYS = {("jf_cond_gf_chain_inv_f32", "K7_H128_N548_D4"): "jf::cond_gf_chain_kernel<float, 8>",
+                ("jf_mlp2_f32", "K7_H128_N548"): "jf::mlp2_kernel<float, 4, 2, true>",
                 ("jf_mlp2_f32", "K4_H128_N10"): "jf::mlp2_kernel<float, 4, 1, true>",
                 ("jf_gf_chain_inv_f32", "per-sample"): "jf::gf_chain_kernel<float, 4, false, false>",
                 ("jf_gf_chain_inv_f32", "bcast"): "jf::gf_chain_kernel<float, 4, true, false>"}
@@ -118,6 +119,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=BATCH, help="rows per GPU (default 2^20 = the BASELINE configuration)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fuse", action="store_true", help="run the conditional e-block as ONE launch (jf_cond_gf_chain_inv, parameter block on chip)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -148,6 +150,7 @@ def main():
     kernel_table = None
     for dtype in (torch.float32, torch.float64):
         pdf = helpers.build_product(fx, dtype, dev)
+        pdf.fuse_conditional_blocks = bool(args.fuse)
         x = torch.from_numpy(x64).to(device=dev, dtype=dtype)
         gathered = torch.empty(world * B, dtype=dtype, device=dev) if world > 1 else None
 
@@ -201,10 +204,18 @@ def main():
         (kname, ktag), kstat = dom
         secs = kstat["mean_ms"] * 1e-3
         flops_per_row = 0
+        fused = False
         if kname.startswith("jf_linear"):
             K = int(ktag.split("_")[0][1:]); N = int(ktag.split("_")[1][1:])
             bytes_per_row = 4 * (K + N)
             flops_per_row = 2 * K * N
+        elif kname.startswith("jf_cond_gf_chain"):
+            K1, H, N, D = (int(t[1:]) for t in ktag.split("_"))
+            # fused launch (MLP + g layers): SURVEY 8d "materialised" accounting = MLP (reads inputs, writes block) + flow (reads block);
+            # the block itself never reaches HBM, so the real traffic is only 4 (K1 + 2 D + 2) bytes per row
+            bytes_per_row = 4 * (K1 + N) + 4 * (D + 1 + N + D + 1)
+            flops_per_row = 2 * (K1 * H + H * N)
+            fused = True
         elif kname.startswith("jf_mlp2"):
             K1, H, N = (int(t[1:]) for t in ktag.split("_"))
             bytes_per_row = 4 * (K1 + N)                       # MLP reads its inputs, writes the parameter block
@@ -223,13 +234,17 @@ def main():
         else:
             roofline = {"bound": "hbm", "kernel": "%s[%s]" % (kname, ktag), "achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": hbm_gbs / HBM_PEAK_GBS, "traffic": None}
+        if fused:
+            roofline["fused"] = True
+            roofline["note"] = ("amortisation MLP + its 4 g layers in one launch; the parameter block stays in LDS.  f32 MFMA and VALU work "
+                                "do not co-issue on a CDNA4 SIMD (scripts/probe/coexec.hip), so this kernel's floor is MFMA time + VALU time")
         tr = pmc_traffic(kname, ktag, B)
         roofline["traffic"] = tr["hbm_bytes_per_launch"] if tr else None
         roofline["traffic_detail"] = tr
         roofline.update({"mean_launch_ms": kstat["mean_ms"], "algorithmic_bytes_per_launch": bytes_per_row * B,
                          "all_kernels_ms_per_step": {"%s[%s]" % k: round(v["total_ms"] / args.steps, 4) for k, v in sorted(kernel_table.items())}})
         # the HBM-bound flow kernel the north star names (per-sample parameter blocks), reported alongside
-        gfk = kernel_table.get(("jf_gf_chain_inv_f32", "per-sample"))
+        gfk = kernel_table.get(("jf_gf_chain_inv_f32", "per-sample"))      # absent with --fuse
         if gfk is not None:
             g = 4 * 558 * B / (gfk["mean_ms"] * 1e-3) / 1e9
             roofline["gf_chain_per_sample"] = {"bound": "hbm", "achieved": g, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": g / HBM_PEAK_GBS,

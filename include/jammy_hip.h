@@ -86,6 +86,23 @@ int jf_gf_chain_fwd_f64(const double* z, int64_t z_stride, const double* log_det
                         int32_t param_batch, int64_t B, int32_t D, int32_t n_layers, const jf_gf_layer* layers, double* x_out,
                         int64_t x_out_stride, double* log_det_out, int64_t* bins, int64_t bins_stride, int32_t* status, void* stream);
 
+/* A whole conditional / autoregressive Euclidean block in ONE launch, log-prob direction: the default amortisation MLP
+ * params = tanh(in @ W1^T + b1) @ W2^T + b2  (nn.Sequential(Linear, Tanh, Linear), main/default.py:656-670, input = cat of conditional
+ * input and the embeddings of the previous sub-manifolds, :946-962) followed by jf_gf_chain_inv on those per-sample parameters
+ * (main/default.py:998-1031).  The (B, sum of the layers' row lengths) parameter block never reaches HBM: it is produced on the matrix
+ * cores into LDS tiles and consumed there ("fused" accounting).  W2 (N, H) with N = sum of the layers' row lengths.
+ * Limits: D in {3, 4}, K1 <= 28, H <= 128, classic stretch; otherwise JF_ERR_UNSUPPORTED (use jf_mlp2 + jf_gf_chain_inv). */
+int jf_cond_gf_chain_inv_f32(const float* in, int64_t in_stride, const float* W1, int64_t w1_stride, const float* b1, const float* W2,
+                             int64_t w2_stride, const float* b2, int32_t K1, int32_t H, const float* x, int64_t x_stride,
+                             const float* log_det_in, int64_t B, int32_t D, int32_t n_layers, const jf_gf_layer* layers, float* x_out,
+                             int64_t x_out_stride, float* log_det_out, const float* base_logp_in, float* base_logp_out, int32_t* status,
+                             void* stream);
+int jf_cond_gf_chain_inv_f64(const double* in, int64_t in_stride, const double* W1, int64_t w1_stride, const double* b1, const double* W2,
+                             int64_t w2_stride, const double* b2, int32_t K1, int32_t H, const double* x, int64_t x_stride,
+                             const double* log_det_in, int64_t B, int32_t D, int32_t n_layers, const jf_gf_layer* layers, double* x_out,
+                             int64_t x_out_stride, double* log_det_out, const double* base_logp_in, double* base_logp_out, int32_t* status,
+                             void* stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * Dense layer of the parameter-emitting MLPs: out = act(in @ W^T + bias)   (MFMA)
  * replaces torch.nn.Linear + tanh of the default nn.Sequential (main/default.py:656-670) and the U / V^T products of

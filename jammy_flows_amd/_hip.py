@@ -90,6 +90,8 @@ _I32 = ctypes.c_int32
 # name -> argtypes (without the _f32/_f64 suffix); every entry point of include/jammy_hip.h
 _SIGNATURES = {
     "jf_gf_chain_inv": [_P, _I64, _P, _P, _I64, _I32, _I64, _I32, _I32, ctypes.POINTER(jf_gf_layer), _P, _I64, _P, _P, _P, _P, _I64, _P, _P],
+    "jf_cond_gf_chain_inv": [_P, _I64, _P, _I64, _P, _P, _I64, _P, _I32, _I32, _P, _I64, _P, _I64, _I32, _I32, ctypes.POINTER(jf_gf_layer), _P, _I64,
+                             _P, _P, _P, _P, _P],
     "jf_gf_chain_fwd": [_P, _I64, _P, _P, _I64, _I32, _I64, _I32, _I32, ctypes.POINTER(jf_gf_layer), _P, _I64, _P, _P, _I64, _P, _P],
     "jf_linear": [_P, _I64, _P, _I64, _P, _I64, _I32, _I32, _I32, _P, _I64, _P],
     "jf_normal_logp": [_P, _I64, _I64, _I32, _P, _P, _P],
@@ -283,6 +285,32 @@ def gf_chain(direction, x, log_det, params, layer_array, n_layers, D, x_out=None
             (_ptr(x), x.stride(0), _ptr(log_det), _ptr(params), params.stride(0), pb, B, D, n_layers, layer_array, _ptr(x_out), x_out.stride(0),
              _ptr(ld_out), _ptr(bins), bs, _ptr(status), _stream()))
     return x_out, ld_out
+
+
+COND_GF_MAX_IN, COND_GF_MAX_HIDDEN = 28, 128
+
+
+def cond_gf_chain_inv(inp, w1, b1, w2, b2, x, log_det, layer_array, n_layers, D, x_out=None, base_logp_in=None, want_base_logp=False, status=None):
+    """amortisation MLP (Linear-tanh-Linear) + the chain of g layers it parametrises in ONE launch; the parameter block stays on chip."""
+    require_device(inp, w1, b1, w2, b2, x, log_det, x_out, base_logp_in, status)
+    inp, w1, w2, x = _rowmajor(inp), _rowmajor(w1), _rowmajor(w2), _rowmajor(x)
+    B, K1 = inp.shape
+    H = w1.shape[0]
+    if x.shape[0] != B or x.shape[1] != D or w1.shape[1] != K1 or w2.shape[1] != H or b1.shape[0] != H or b2.shape[0] != w2.shape[0]:
+        raise ValueError("cond_gf_chain_inv: inconsistent shapes")
+    if any(t.dtype != x.dtype for t in (inp, w1, b1, w2, b2)):
+        raise TypeError("cond_gf_chain_inv: dtype mismatch")
+    if log_det is not None:
+        log_det = log_det.contiguous()
+    if x_out is None:
+        x_out = torch.empty((B, D), dtype=x.dtype, device=x.device)
+    ld_out = torch.empty((B,), dtype=x.dtype, device=x.device)
+    blp_out = torch.empty((B,), dtype=x.dtype, device=x.device) if want_base_logp else None
+    _launch("jf_cond_gf_chain_inv" + _suffix(x), "K%d_H%d_N%d_D%d" % (K1, H, w2.shape[0], D),
+            (_ptr(inp), inp.stride(0), _ptr(w1), w1.stride(0), _ptr(b1.contiguous()), _ptr(w2), w2.stride(0), _ptr(b2.contiguous()), K1, H,
+             _ptr(x), x.stride(0), _ptr(log_det), B, D, n_layers, layer_array, _ptr(x_out), x_out.stride(0), _ptr(ld_out), _ptr(base_logp_in),
+             _ptr(blp_out), _ptr(status), _stream()))
+    return (x_out, ld_out, blp_out) if want_base_logp else (x_out, ld_out)
 
 
 def linear(inp, weight, bias=None, act=0, out=None):

@@ -10,25 +10,9 @@
 // The epilogue adds the bias, applies tanh and writes 128-byte row segments per half wave.
 #include "jf_common.h"
 #include "jf_math.h"
+#include "jf_mfma.h"
 
 namespace jf {
-
-using f32x16 = __attribute__((ext_vector_type(16))) float;
-using f64x4 = __attribute__((ext_vector_type(4))) double;
-
-template <typename T> struct Mfma;
-template <> struct Mfma<float> {
-    static constexpr int MT = 32, KS = 2, NREG = 16, RUN = 4;   // RUN: consecutive registers hold consecutive rows
-    using Acc = f32x16;
-    static __device__ __forceinline__ Acc mma(float a, float b, Acc c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
-    static __device__ __forceinline__ int row_of(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
-};
-template <> struct Mfma<double> {
-    static constexpr int MT = 16, KS = 4, NREG = 4, RUN = 1;
-    using Acc = f64x4;
-    static __device__ __forceinline__ Acc mma(double a, double b, Acc c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
-    static __device__ __forceinline__ int row_of(int reg, int lane) { return (lane >> 4) + 4 * reg; }
-};
 
 constexpr int BM = 128, BN = 64, KC = 32, WM = 32, WN = 64, LDP = KC + 1;
 
@@ -165,8 +149,6 @@ __global__ void __launch_bounds__(256) linear_kernel(const T* __restrict__ in, i
 // Barriers wait for LDS traffic only; result stores drain behind the next tile's loads and MFMAs.  Requires K1 <= 32, H <= 128.
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int HMAX = 128, K1MAX = 32;
-// workgroup barrier that waits for this wave's LDS traffic only (a __syncthreads() also drains the wave's outstanding global stores)
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 template <typename T> struct Mlp2Cfg;
 template <> struct Mlp2Cfg<float> { static constexpr int LDW = HMAX + 4; };
 template <> struct Mlp2Cfg<double> { static constexpr int LDW = HMAX + 1; };

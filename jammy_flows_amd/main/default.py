@@ -114,6 +114,9 @@ class pdf(nn.Module):
             assert amortization_mlp_use_custom_mode, "Amortizing all MLPs requires custom MLPs."
             self.total_number_amortizable_params = 0
         self.check_status = True       # turn kernel status words into the reference's warnings / exceptions after each call
+        # conditional e-blocks (Linear-tanh-Linear MLP + g layers, D in {3,4}) as ONE launch with the parameter block kept on chip
+        # (jf_cond_gf_chain_inv).  Off by default: measured +3 % on the C3 step only (f32 MFMA and VALU do not co-issue on CDNA4)
+        self.fuse_conditional_blocks = False
 
         self._read_model_definition(pdf_defs, flow_defs, options_overwrite, conditional_input_dim, amortization_mlp_dims,
                                     amortization_mlp_ranks)
@@ -362,6 +365,36 @@ class pdf(nn.Module):
         return first.dtype, first.device
 
     # =========================================================================================== parameter routing
+    def _mlp_input(self, si, data_summary, embeds):
+        if data_summary is not None:
+            inp = data_summary[si] if type(data_summary) == list else data_summary
+            if len(embeds) > 0:
+                inp = torch.cat([inp] + embeds, dim=1)
+            return inp
+        if len(embeds) > 0:
+            return torch.cat(embeds, dim=1) if len(embeds) > 1 else embeds[0]
+        raise Exception("extra conditional input is empty but required for encoding!")
+
+    def _fusable_block(self, si, layers, only_last, amort, dtype):
+        """can sub-pdf si run as ONE fused launch (amortisation MLP + its g layers, parameter block kept on chip)?"""
+        if not self.fuse_conditional_blocks or only_last or amort is not None or _hip.BINS_LOG is not None:
+            return None
+        if dtype != torch.float32:      # measured: in float64 the two-launch path (jf_mlp2 + jf_gf_chain_inv) is faster
+            return None
+        mlp = self.mlp_predictors[si] if len(self.mlp_predictors) > si else None
+        if not isinstance(mlp, HipLinearStack) or len(mlp) != 3 or not isinstance(mlp[1], nn.Tanh):
+            return None
+        if not (3 <= layers[0].dimension <= 4) or not gfl.chain_supported(layers):
+            return None
+        if any(l.nonlinear_stretch_type != "classic" for l in layers):
+            return None
+        if mlp[0].in_features > _hip.COND_GF_MAX_IN or mlp[0].out_features > _hip.COND_GF_MAX_HIDDEN or mlp[0].out_features % 4:
+            return None
+        ps = [mlp[0].weight, mlp[0].bias, mlp[2].weight, mlp[2].bias]
+        if ps[0].dtype != dtype:
+            ps = [p.to(dtype) for p in ps]
+        return [p.detach() for p in ps]
+
     def _block_params(self, si, data_summary, embeds, amort, counter):
         """extra_inputs row block of sub-pdf si, or None for permanent parameters (:936-993, 1420-1475)."""
         mlp = self.mlp_predictors[si] if len(self.mlp_predictors) > si else None
@@ -432,13 +465,24 @@ class pdf(nn.Module):
         embeds = []
         counter = 0
         for si, block in enumerate(self.layer_list):
-            extra, counter = self._block_params(si, data_summary, embeds, amortization_parameters, counter)
             a, b = self.target_dim_indices[si]
             tgt = x[:, a:b]
             ba, bb = self.base_dim_indices[si]
             out_view = base[:, ba:bb]
             layers = list(block)
             kind = self.pdf_defs_list[si][0]
+            fused = self._fusable_block(si, layers, only_last, amortization_parameters, x.dtype) if kind == "e" else None
+            if fused is not None:
+                # amortisation MLP + g layers in one launch: the per-sample parameter block never reaches HBM
+                res = _hip.cond_gf_chain_inv(self._mlp_input(si, data_summary, embeds), *fused, tgt, log_det,
+                                             _hip.gf_layer_array([l.c_struct() for l in layers]), len(layers), layers[0].dimension,
+                                             x_out=out_view, base_logp_in=base_logp, want_base_logp=want_base_logp, status=status)
+                log_det = res[1]
+                if want_base_logp:
+                    base_logp = res[2]
+                embeds.append(block[-1]._embedding_conditional_return(tgt))
+                continue
+            extra, counter = self._block_params(si, data_summary, embeds, amortization_parameters, counter)
             if only_last:
                 layers = layers[-1:]
             if kind == "e" and gfl.chain_supported(layers):

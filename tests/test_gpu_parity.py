@@ -196,3 +196,29 @@ def test_spline_bins_bit_exact_float64(fx):
         c = c[c != -2]                             # rows inside an identity region never reach searchsorted in the reference
         assert c.shape == r.shape, (i, c.shape, r.shape)
         assert np.array_equal(c, r.astype(np.int64)), "search %d: %d of %d bin indices differ" % (i, int((c != r).sum()), c.size)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# fused conditional block (amortisation MLP + g layers in one launch, jf_cond_gf_chain_inv): same results as the two-launch path
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["c3_e4s2e4", "c3b_e4s2e4_fsplines", "g_e3_ggg_cond"])
+def test_fused_conditional_block_matches_two_launch_path(name):
+    from jammy_flows_amd import _hip
+    fx = [f for f in ALL_FIXTURES if f.name == name][0]
+    pdf = build_product(fx, torch.float32)
+    x = to_dev(fx["x"], torch.float32)
+    cond = to_dev(fx.get("cond"), torch.float32)
+    emb = bool(fx.meta["embedding"])
+    pdf.check_status = False                      # the adversarial fixture rows are not representable in float32
+    pdf.fuse_conditional_blocks = False
+    ref = pdf(x, conditional_input=cond, force_embedding_coordinates=emb)
+    pdf.fuse_conditional_blocks = True
+    timer = _hip.KernelTimer()
+    with timer:
+        got = pdf(x, conditional_input=cond, force_embedding_coordinates=emb)
+    assert any(k[0].startswith("jf_cond_gf_chain_inv") for k in timer.summary()), "fused kernel was not used"
+    ok = torch.isfinite(ref[0]) & torch.isfinite(got[0])
+    assert ok.float().mean() > 0.9
+    # identical arithmetic per row up to the MFMA tile shape (16x16x4 vs 32x32x2 summation order)
+    assert max_abs(got[0][ok], ref[0][ok]) < 2e-3
+    assert max_abs(got[2][ok], ref[2][ok]) < 2e-3
