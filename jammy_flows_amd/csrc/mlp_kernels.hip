@@ -168,33 +168,21 @@ __global__ void __launch_bounds__(256, 3) mlp2_kernel(const T* __restrict__ in, 
     constexpr int RG = MF::RUN;                              // consecutive result registers = consecutive columns (f32: 4, f64: 1)
     extern __shared__ __align__(16) unsigned char smem_raw[];
     T* Ws = reinterpret_cast<T*>(smem_raw);                  // [BN2][LDW]   W2 tile (phase 2)
+    T* Bs = Ws + BN2 * LDW;                                  // [BN2]        bias of the tile's columns
     const int k1p = (K1 + KS - 1) / KS * KS, ldk = k1p + 1;
-    T* Xs = Ws;                                              // [BMR][ldk]   input tile  } phase 1 only: overlays the W2 tile region
-    T* W1s = Xs + BMR * ldk;                                 // [HP][ldk]    W1          } (a barrier separates the phases)
-    T* b1s = W1s + HP * ldk;                                 // [HP]
+    T* Xs = Bs + BN2;                                        // [BMR][ldk]   input tile
+    T* W1s = Xs + BMR * ldk;                                 // [HP][ldk]    W1   } staged once per workgroup
+    T* b1s = W1s + HP * ldk;                                 // [HP]         b1   }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane % MT, lq = lane / MT;
-    const int64_t row0 = (int64_t)blockIdx.x * BMR;
     const int64_t last = B - 1;
+    const int n_tiles = (N + BN2 - 1) / BN2;
+    const int64_t n_row_tiles = (B + BMR - 1) / BMR;
 
-    // ---- phase 1: h^T = tanh(W1 x^T + b1).  Staging in straight-line batches of 4 loads per thread (clamped addresses + selects):
-    // issued back to back, one round trip per batch.  Rows past B replicate row B-1.
+    // ---- W1, b1: once per workgroup.  Staging in straight-line batches of 4 loads per thread (clamped addresses + selects): issued
+    // back to back, one round trip per batch.
     {
-        const int nx = BMR * k1p, nw = HP * k1p;
-        for (int base = 0; base < nx; base += 4 * 256) {
-            T v[4]; int o[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int idx = base + u * 256 + tid;
-                const int r = idx / k1p, c = idx - r * k1p;
-                const int64_t gr = row0 + r;
-                const T t = in[(gr <= last ? gr : last) * in_stride + (c < K1 ? c : 0)];
-                v[u] = c < K1 ? t : T(0);
-                o[u] = idx < nx ? r * ldk + c : -1;
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) if (o[u] >= 0) Xs[o[u]] = v[u];
-        }
+        const int nw = HP * k1p;
         for (int base = 0; base < nw; base += 4 * 256) {
             T v[4]; int o[4];
 #pragma unroll
@@ -210,29 +198,7 @@ __global__ void __launch_bounds__(256, 3) mlp2_kernel(const T* __restrict__ in, 
         }
         if (tid < HP) b1s[tid] = tid < H ? b1[tid < H ? tid : 0] : T(0);
     }
-    __syncthreads();
-    T hreg[JH][NREG];
-    {
-        typename MF::Acc acc[JH];
-#pragma unroll
-        for (int j = 0; j < JH; ++j)
-#pragma unroll
-            for (int r = 0; r < NREG; ++r) acc[j][r] = T(0);
-        for (int s = 0; s < k1p / KS; ++s) {
-            const int kk = s * KS + lq;
-            const T xb = Xs[(wave * MT + li) * ldk + kk];
-#pragma unroll
-            for (int j = 0; j < JH; ++j) acc[j] = MF::mma(W1s[(j * MT + li) * ldk + kk], xb, acc[j]);
-        }
-#pragma unroll
-        for (int j = 0; j < JH; ++j)
-#pragma unroll
-            for (int r = 0; r < NREG; ++r) hreg[j][r] = M<T>::tanh_fast(acc[j][r] + b1s[j * MT + MF::row_of(r, lane)]);   // padded units: tanh(0) = 0
-    }
-
     // ---- phase 2: out^T = W2 h^T + b2, W2 streamed in BN2-column tiles
-    const int n_tiles = (N + BN2 - 1) / BN2;
-    T* Bs = Ws + BN2 * LDW;                                  // [BN2] bias of the tile's columns
     auto load_tile = [&](int t) {                            // straight-line: clamped addresses + selects, loads issued back to back
         V wreg[WPT];
         const int bc = t * BN2 + (tid < BN2 ? tid : 0);
@@ -257,9 +223,6 @@ __global__ void __launch_bounds__(256, 3) mlp2_kernel(const T* __restrict__ in, 
         }
         if (tid < BN2) Bs[tid] = bval;
     };
-    // result addressing: lane = row (clamped to B-1); per (tile, column tile, register group) a uniform column offset
-    const int64_t grow = row0 + wave * MT + li;
-    T* const orow = out + (grow <= last ? grow : last) * out_stride;
     const T* wb = Ws + li * LDW;
     constexpr int NGRP = VN == 4 ? NREG / 4 : NREG;          // W2 fragment reads per hidden tile (f32: one b128 = 4 k, f64: one b64 = 1 k)
     constexpr int KPG = NREG / NGRP;                         // MFMAs (k values) per read
@@ -273,55 +236,114 @@ __global__ void __launch_bounds__(256, 3) mlp2_kernel(const T* __restrict__ in, 
         else return f;
     };
 
-    lds_barrier();                                           // every wave is done with Xs / W1s / b1s
+    // ---- row tiles: one per workgroup, or a grid-stride walk when the output is a single W2 tile wide (narrow outputs: the launch is
+    // then dominated by per-workgroup fixed latency, so a resident set of workgroups keeps W1 / b1 / W2 in LDS and only streams x)
+    __syncthreads();                                         // W1s / b1s staged
     load_tile(0);
-    lds_barrier();
-    for (int t = 0; t < n_tiles; ++t) {
-        typename MF::Acc acc[TN];
+    for (int64_t rt = blockIdx.x; rt < n_row_tiles; rt += gridDim.x) {
+        const int64_t row0 = rt * BMR;
+        {
+            const int nx = BMR * k1p;
+            for (int base = 0; base < nx; base += 4 * 256) {
+                T v[4]; int o[4];
 #pragma unroll
-        for (int ct = 0; ct < TN; ++ct)
+                for (int u = 0; u < 4; ++u) {
+                    const int idx = base + u * 256 + tid;
+                    const int r = idx / k1p, c = idx - r * k1p;
+                    const int64_t gr = row0 + r;
+                    const T t = in[(gr <= last ? gr : last) * in_stride + (c < K1 ? c : 0)];      // rows past B replicate row B-1
+                    v[u] = c < K1 ? t : T(0);
+                    o[u] = idx < nx ? r * ldk + c : -1;
+                }
 #pragma unroll
-            for (int r = 0; r < NREG; ++r) acc[ct][r] = T(0);
-        F frag[2][TN];
-        read_frag(frag[0], 0, 0);
-#pragma unroll
-        for (int j = 0; j < JH; ++j)
-#pragma unroll
-            for (int g = 0; g < NGRP; ++g) {
-                const int cur = (j * NGRP + g) & 1;
-                if (j * NGRP + g + 1 < JH * NGRP) read_frag(frag[cur ^ 1], (j * NGRP + g + 1) / NGRP, (j * NGRP + g + 1) % NGRP);   // one group ahead
-#pragma unroll
-                for (int e = 0; e < KPG; ++e)
-#pragma unroll
-                    for (int ct = 0; ct < TN; ++ct) acc[ct] = MF::mma(elem(frag[cur][ct], e), hreg[j][g * KPG + e], acc[ct]);
+                for (int u = 0; u < 4; ++u) if (o[u] >= 0) Xs[o[u]] = v[u];
             }
-        // results: acc[ct][r] = out[row = lane's row][col = t*BN2 + ct*MT + row_of(r, lane)]; bias from the LDS tile
-        const bool edge = (t + 1) * BN2 > N;                 // block-uniform: only the last tile can reach past N
-        if (VECROW && RG == 4 && !edge) {
-#pragma unroll
-            for (int ct = 0; ct < TN; ++ct)
-#pragma unroll
-                for (int r0 = 0; r0 < NREG; r0 += RG) {
-                    const int lc = ct * MT + MF::row_of(r0, lane);
-                    const V bb = *reinterpret_cast<const V*>(Bs + lc);
-                    V o;
-                    o.x = acc[ct][r0] + bb.x; o.y = acc[ct][r0 + 1] + bb.y;
-                    if constexpr (VN == 4) { o.z = acc[ct][r0 + 2] + bb.z; o.w = acc[ct][r0 + 3] + bb.w; }
-                    *reinterpret_cast<V*>(orow + t * BN2 + lc) = o;
-                }
-        } else {
-#pragma unroll
-            for (int ct = 0; ct < TN; ++ct)
-#pragma unroll
-                for (int r = 0; r < NREG; ++r) {
-                    const int lc = ct * MT + MF::row_of(r, lane);
-                    const int c = (t * BN2 + lc) < N ? (t * BN2 + lc) : N - 1;       // duplicates of column N-1 carry its value
-                    orow[c] = acc[ct][r] + Bs[lc];
-                }
         }
-        lds_barrier();                                       // every wave has read the tile
-        if (t + 1 < n_tiles) load_tile(t + 1);
-        lds_barrier();
+        __syncthreads();                                     // x tile (and, first pass, the W2 tile) visible
+        T hreg[JH][NREG];
+        {
+            typename MF::Acc acc[JH];
+    #pragma unroll
+            for (int j = 0; j < JH; ++j)
+    #pragma unroll
+                for (int r = 0; r < NREG; ++r) acc[j][r] = T(0);
+            for (int s = 0; s < k1p / KS; ++s) {
+                const int kk = s * KS + lq;
+                const T xb = Xs[(wave * MT + li) * ldk + kk];
+    #pragma unroll
+                for (int j = 0; j < JH; ++j) acc[j] = MF::mma(W1s[(j * MT + li) * ldk + kk], xb, acc[j]);
+            }
+    #pragma unroll
+            for (int j = 0; j < JH; ++j)
+    #pragma unroll
+                for (int r = 0; r < NREG; ++r) hreg[j][r] = M<T>::tanh_fast(acc[j][r] + b1s[j * MT + MF::row_of(r, lane)]);   // padded units: tanh(0) = 0
+        }
+
+        // result addressing: lane = row (clamped to B-1); per (tile, column tile, register group) a uniform column offset
+        const int64_t grow = row0 + wave * MT + li;
+        T* const orow = out + (grow <= last ? grow : last) * out_stride;
+        for (int t = 0; t < n_tiles; ++t) {
+            typename MF::Acc acc[TN];
+    #pragma unroll
+            for (int ct = 0; ct < TN; ++ct)
+    #pragma unroll
+                for (int r = 0; r < NREG; ++r) acc[ct][r] = T(0);
+            F frag[2][TN];
+            read_frag(frag[0], 0, 0);
+    #pragma unroll
+            for (int j = 0; j < JH; ++j)
+    #pragma unroll
+                for (int g = 0; g < NGRP; ++g) {
+                    const int cur = (j * NGRP + g) & 1;
+                    if (j * NGRP + g + 1 < JH * NGRP) read_frag(frag[cur ^ 1], (j * NGRP + g + 1) / NGRP, (j * NGRP + g + 1) % NGRP);   // one group ahead
+    #pragma unroll
+                    for (int e = 0; e < KPG; ++e)
+    #pragma unroll
+                        for (int ct = 0; ct < TN; ++ct) acc[ct] = MF::mma(elem(frag[cur][ct], e), hreg[j][g * KPG + e], acc[ct]);
+                }
+            // results: acc[ct][r] = out[row = lane's row][col = t*BN2 + ct*MT + row_of(r, lane)]; bias from the LDS tile
+            const bool edge = (t + 1) * BN2 > N;                 // block-uniform: only the last tile can reach past N
+            if (VECROW && RG == 4 && !edge) {
+    #pragma unroll
+                for (int ct = 0; ct < TN; ++ct)
+    #pragma unroll
+                    for (int r0 = 0; r0 < NREG; r0 += RG) {
+                        const int lc = ct * MT + MF::row_of(r0, lane);
+                        const V bb = *reinterpret_cast<const V*>(Bs + lc);
+                        V o;
+                        o.x = acc[ct][r0] + bb.x; o.y = acc[ct][r0 + 1] + bb.y;
+                        if constexpr (VN == 4) { o.z = acc[ct][r0 + 2] + bb.z; o.w = acc[ct][r0 + 3] + bb.w; }
+                        *reinterpret_cast<V*>(orow + t * BN2 + lc) = o;
+                    }
+            } else {
+                // edge tile: 16-byte stores for the register groups that lie inside N, scalar stores (last column duplicated) for the group that
+                // straddles N, nothing for groups past N -- a narrow output (N = 10) would otherwise issue 16 scattered dword stores per lane
+#pragma unroll
+                for (int ct = 0; ct < TN; ++ct)
+#pragma unroll
+                    for (int r0 = 0; r0 < NREG; r0 += RG) {
+                        const int lc = ct * MT + MF::row_of(r0, lane);
+                        const int gc = t * BN2 + lc;
+                        if (VECROW && RG == 4 && gc + RG <= N) {
+                            V o;
+                            o.x = acc[ct][r0] + Bs[lc]; o.y = acc[ct][r0 + 1] + Bs[lc + 1];
+                            if constexpr (VN == 4) { o.z = acc[ct][r0 + 2] + Bs[lc + 2]; o.w = acc[ct][r0 + 3] + Bs[lc + 3]; }
+                            *reinterpret_cast<V*>(orow + gc) = o;
+                        } else if (gc < N) {
+#pragma unroll
+                            for (int e = 0; e < RG; ++e)
+                                if (gc + e < N) orow[gc + e] = acc[ct][r0 + e] + Bs[lc + e];
+                        }
+                    }
+            }
+            if (n_tiles > 1 && (t + 1 < n_tiles || rt + gridDim.x < n_row_tiles)) {   // block-uniform; a single tile stays resident
+                lds_barrier();                               // every wave has read the tile
+                load_tile(t + 1 < n_tiles ? t + 1 : 0);      // (after the last one: tile 0 for the workgroup's next row tile)
+                lds_barrier();
+            }
+        }
+
+        lds_barrier();                                       // every wave is done with Xs before the next row tile overwrites it
     }
 }
 
@@ -330,13 +352,21 @@ static int mlp2_launch(const T* in, int64_t in_stride, const T* W1, int64_t w1_s
                        int32_t K1, int32_t H, int32_t N, T* out, int64_t out_stride, void* stream) {
     constexpr int MT = Mfma<T>::MT, KS = Mfma<T>::KS, BMR = 4 * MT, HP = JH * MT;
     const int k1p = (K1 + KS - 1) / KS * KS, ldk = k1p + 1;
-    const size_t phase1 = (size_t)BMR * ldk + (size_t)HP * ldk + HP, phase2 = (size_t)(TN * MT) * Mlp2Cfg<T>::LDW + TN * MT;
-    const size_t lds = (phase1 > phase2 ? phase1 : phase2) * sizeof(T);
+    const size_t lds = ((size_t)BMR * ldk + (size_t)HP * ldk + HP + (size_t)(TN * MT) * Mlp2Cfg<T>::LDW + TN * MT) * sizeof(T);
     // 16-byte result stores need 16-byte aligned rows
     const bool vecrow = (out_stride % Vec16<T>::N == 0) && ((reinterpret_cast<uintptr_t>(out) & 15u) == 0);
     auto k = vecrow ? mlp2_kernel<T, JH, TN, true> : mlp2_kernel<T, JH, TN, false>;
     if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k, dim3((unsigned)((B + BMR - 1) / BMR)), dim3(256), lds, (hipStream_t)stream, in, in_stride, W1, w1_stride, b1, W2, w2_stride, b2, B,
+    int64_t grid = (B + BMR - 1) / BMR;
+    if (N <= TN * MT) {                                      // single W2 tile: resident workgroups walk the row tiles
+        int dev = 0, cus = 256, per_cu = 0;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, 256, lds) != hipSuccess || per_cu < 1) per_cu = 2;
+        const int64_t resident = (int64_t)cus * per_cu;
+        if (grid > resident) grid = resident;
+    }
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream, in, in_stride, W1, w1_stride, b1, W2, w2_stride, b2, B,
                        (int)K1, (int)H, (int)N, out, out_stride);
     return check_launch();
 }
