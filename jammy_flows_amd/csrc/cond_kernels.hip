@@ -274,7 +274,8 @@ static int cond_gf_chain_inv(const T* in, int64_t in_stride, const T* W1, int64_
         if (h.nonlinear_stretch_type != JF_GF_STRETCH_CLASSIC) return JF_ERR_UNSUPPORTED;     // per-lane knot tables do not fit beside the tiles
         o.K = h.num_kde; o.hh = h.hh_iter; o.model_offset = h.model_offset; o.fit_norm = h.fit_normalization;
         o.reg_norm = h.regulate_normalization; o.inv_type = h.inverse_function_type; o.width_mode = h.width_mode;
-        o.clamp_widths = h.clamp_widths; o.stretch = JF_GF_STRETCH_CLASSIC; o.off_box = 0;
+        o.clamp_widths = h.clamp_widths;
+        o.fast = (h.width_mode == JF_GF_WIDTH_SMOOTH_SATURATION && !h.clamp_widths && h.fit_normalization && h.regulate_normalization) ? 1 : 0; o.stretch = JF_GF_STRETCH_CLASSIC; o.off_box = 0;
         const int kd = h.num_kde * D;
         o.off_rot = h.model_offset ? D : 0;
         o.off_mean = o.off_rot + h.hh_iter * D;

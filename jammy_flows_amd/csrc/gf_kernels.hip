@@ -91,7 +91,10 @@ __global__ void __launch_bounds__(BCAST ? 256 : 64, sizeof(T) == 8 ? 2 : 4) gf_c
                 p = lds + l * a.tile_stride + d;
             } else {
                 __syncthreads();                         // single-wave workgroup: orders the previous layer's LDS reads before the refill
-                stage_rows<T>(lds, a.tile_stride, a.params + row0 * a.ps + o.col0, a.ps, o.n_params, R, valid_rows, tid, NT, o.vec_ok != 0);
+                if (G >= 4 && o.vec_ok == 2)                   // aligned rows of <= 20 pieces per lane: constant-offset staging
+                    stage_rows_grouped<T, (G >= 4 ? G : 4)>(lds, a.tile_stride, a.params + row0 * a.ps + o.col0, a.ps, o.n_params, valid_rows, tid);
+                else
+                    stage_rows<T>(lds, a.tile_stride, a.params + row0 * a.ps + o.col0, a.ps, o.n_params, R, valid_rows, tid, NT, o.vec_ok != 0);
                 __syncthreads();
                 if constexpr (FWD) {                     // 45 evaluations per layer follow: regulate the row once, in place
                     gfg_derive<T, G>(lds + r * a.tile_stride, o, D, g, o.stretch == JF_GF_STRETCH_CLASSIC);
@@ -171,6 +174,7 @@ template <typename T> static int fill_args(GfChainArgs<T>& a, const T* params, i
         o.K = h.num_kde; o.hh = h.hh_iter; o.model_offset = h.model_offset; o.fit_norm = h.fit_normalization;
         o.reg_norm = h.regulate_normalization; o.inv_type = h.inverse_function_type; o.width_mode = h.width_mode;
         o.clamp_widths = h.clamp_widths;
+        o.fast = (h.width_mode == JF_GF_WIDTH_SMOOTH_SATURATION && !h.clamp_widths && h.fit_normalization && h.regulate_normalization) ? 1 : 0;
         const int kd = h.num_kde * D;
         o.stretch = h.nonlinear_stretch_type;
         if (o.stretch != JF_GF_STRETCH_CLASSIC && o.stretch != JF_GF_STRETCH_RQ_SPLINES) return JF_ERR_BADARG;
@@ -189,6 +193,10 @@ template <typename T> static int fill_args(GfChainArgs<T>& a, const T* params, i
         }
         o.col0 = col;
         o.vec_ok = (!bcast && aligned16<T>(params, ps, col) && (o.n_params % Vec16<T>::N == 0)) ? 1 : 0;
+        {   // 2: the grouped constant-offset staging applies (G lanes per row, at most JF_GROUP_STAGE_MAX_PIECES pieces per lane)
+            const int Gw = group_width(D), nvp = o.n_params / Vec16<T>::N;
+            if (o.vec_ok && Gw >= 4 && (nvp + Gw - 1) / Gw <= JF_GROUP_STAGE_MAX_PIECES) o.vec_ok = 2;
+        }
         o.wmin = (T)h.width_min; o.wmax = (T)h.width_max; o.inv_wmax = h.width_max > 0 ? (T)(1.0 / h.width_max) : T(0);
         o.nmin = (T)h.norm_min; o.nmax = (T)h.norm_max;
         o.lw_lo = (T)log(0.01 * h.width_min);                                  // gaussianization_flow.py:129

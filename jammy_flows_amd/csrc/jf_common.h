@@ -109,6 +109,54 @@ __device__ __forceinline__ void stage_rows(T* __restrict__ tile, int tile_stride
     else stage_all<T, false>(s, iters);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Staging for tiles of few rows (rows * LPR == 64 lanes, LPR a power of two >= 4): LPR neighbouring lanes share a row and walk it in
+// 16-byte pieces j, j + LPR, j + 2 LPR, ...  Every address of a lane is its first one plus a compile-time constant, so a piece costs
+// no VALU instruction at all (immediate offsets of global_load_dwordx4 / ds_write_b128); the generic cursor above spends ~24 per
+// piece.  Per instruction the wave reads `rows` segments of 16 LPR bytes (64 B for D = 3, 4; 128 B for D = 5..8); the other half of each
+// 128-byte line is served by the L1 hit of the next instruction.  Only the last piece of a lane can fall past the row: it is clamped
+// onto the row's last piece (duplicate load and store of the same data).  Requires 16-byte aligned rows (vec_ok).
+// ---------------------------------------------------------------------------------------------
+template <typename T, int LPR, int I, int NIT> struct GroupStage {
+    using V = typename Vec16<T>::type;
+    template <typename... P> static __device__ __forceinline__ void run(const V* __restrict__ g, V* __restrict__ l, int last_off, P... done) {
+        if constexpr (I + 1 < NIT) {
+            const V v = g[I * LPR];
+            GroupStage<T, LPR, I + 1, NIT>::run(g, l, last_off, done..., v);
+        } else {
+            const V v = g[last_off];                                  // (NIT-1) * LPR, or clamped onto the row's last piece
+            __builtin_amdgcn_sched_barrier(0);                       // all loads ahead of the first LDS write
+            int i = 0;
+            ((l[i++ * LPR] = done), ...);
+            l[last_off] = v;
+        }
+    }
+};
+
+template <typename T, int LPR>
+__device__ __forceinline__ void stage_rows_grouped(T* __restrict__ tile, int tile_stride, const T* __restrict__ src, int64_t src_stride, int ncols,
+                                                   int valid_rows, int lane) {
+    using V = typename Vec16<T>::type;
+    constexpr int N = Vec16<T>::N;
+    const int r = lane / LPR, j = lane % LPR;
+    const int rs = r < valid_rows ? r : valid_rows - 1;              // rows past the end replicate the last valid row
+    const int nv = ncols / N;
+    const int nit = (nv + LPR - 1) / LPR;                            // pieces per lane (uniform)
+    const int jj = j < nv ? j : nv - 1;
+    const V* g = reinterpret_cast<const V*>(src + (int64_t)rs * src_stride) + jj;
+    V* l = reinterpret_cast<V*>(tile + r * tile_stride) + jj;
+    const int c_last = jj + (nit - 1) * LPR;
+    const int last_off = (c_last < nv ? c_last : nv - 1) - jj;
+    switch (nit) {
+#define JF_GS(n) case n: GroupStage<T, LPR, 0, n>::run(g, l, last_off); break;
+        JF_GS(1) JF_GS(2) JF_GS(3) JF_GS(4) JF_GS(5) JF_GS(6) JF_GS(7) JF_GS(8) JF_GS(9) JF_GS(10) JF_GS(11) JF_GS(12)
+        JF_GS(13) JF_GS(14) JF_GS(15) JF_GS(16) JF_GS(17) JF_GS(18) JF_GS(19) JF_GS(20)
+#undef JF_GS
+        default: break;                                              // callers fall back to stage_rows for longer rows
+    }
+}
+constexpr int JF_GROUP_STAGE_MAX_PIECES = 20;
+
 template <typename T> __host__ inline bool aligned16(const void* p, int64_t stride_elems, int64_t col0_elems) {
     constexpr int N = Vec16<T>::N;
     return ((reinterpret_cast<uintptr_t>(p) & 15u) == 0) && (stride_elems % N == 0) && (col0_elems % N == 0);

@@ -23,6 +23,8 @@ namespace jf {
 
 template <typename T> struct GfLayerDev {
     int K, hh, model_offset, fit_norm, reg_norm, inv_type, width_mode, clamp_widths;
+    int fast;                                // all options at the reference's defaults (smooth-saturation widths without clamping, fitted and
+                                             //   regulated weights): the mixture loop then runs a branch-free specialisation
     int stretch;                             // JF_GF_STRETCH_*: for RQ_SPLINES off_mean / off_lw / off_ln hold the log_w / log_h / log_d sections
     int off_box;                             //   (each d-major, K / K / K+1 values per coordinate) and off_box the 4 box values per coordinate
     int n_params;                            // raw row length of this layer
@@ -294,18 +296,38 @@ template <typename T, bool RAW> __device__ __forceinline__ MixQ<T> gfg_mixture_s
     return q;
 }
 
-template <typename T, bool RAW> __device__ __forceinline__ MixQ<T> gfg_mixture(const T* __restrict__ p, const GfLayerDev<T>& o, int D, T x) {
+// FAST: the layer has the reference's default options (o.fast), which turns every option test inside the loop into a compile-time
+// constant -- without it the k loop keeps ~10 scalar branches and a wait after every LDS read.
+template <typename T, bool RAW, bool FAST> __device__ __forceinline__ MixQ<T> gfg_mixture_impl(const T* __restrict__ p, const GfLayerDev<T>& o, int D, T x) {
     T C = T(0), S = T(0), P = T(0), Nn = T(0), shift = T(0);
+    const bool fit_norm = FAST ? true : (o.fit_norm != 0);
     const T uniform_w = RAW ? T(1) : M<T>::rcp(T(o.K));
-    if (RAW && o.fit_norm && !o.reg_norm) {                // unbounded log-weights: shift by the max before exponentiating
+    if (!FAST && RAW && o.fit_norm && !o.reg_norm) {       // unbounded log-weights: shift by the max before exponentiating
         shift = p[o.off_ln];
         for (int k = 1; k < o.K; ++k) shift = M<T>::max(shift, p[o.off_ln + k * D]);
     }
+    const T* pm = p + o.off_mean;
+    const T* pw = p + o.off_lw;
+    const T* pn = p + o.off_ln;
 #pragma unroll 2
     for (int k = 0; k < o.K; ++k) {
-        const T iw = RAW ? gf_inv_width(o, p[o.off_lw + k * D]) : p[o.off_lw + k * D];
-        const T wk = o.fit_norm ? (RAW ? gf_weight(o, p[o.off_ln + k * D], shift) : p[o.off_ln + k * D]) : uniform_w;
-        const T u = (x - p[o.off_mean + k * D]) * iw;
+        const T mu = pm[k * D], rw = pw[k * D];
+        const T rn = fit_norm ? pn[k * D] : T(0);
+        T iw, wk;
+        if constexpr (RAW) {
+            if constexpr (FAST) {
+                const T ae = o.inv_wmax + M<T>::exp_fast(-rw);
+                iw = ae * M<T>::rcp(o.wmin * ae + T(1));
+                wk = o.nmin + o.nmax * M<T>::rcp(T(1) + M<T>::exp_fast(-rn));
+            } else {
+                iw = gf_inv_width(o, rw);
+                wk = fit_norm ? gf_weight(o, rn, shift) : T(1);
+            }
+        } else {
+            iw = rw;
+            wk = fit_norm ? rn : uniform_w;
+        }
+        const T u = (x - mu) * iw;
         const T t = M<T>::exp_fast(-M<T>::abs(u));
         const T hi = M<T>::rcp(T(1) + t);                  // sigma(|u|)
         const T lo = t * hi;                               // sigma(-|u|)
@@ -328,6 +350,9 @@ template <typename T, bool RAW> __device__ __forceinline__ MixQ<T> gfg_mixture(c
         if (under) q = qs;
     }
     return q;
+}
+template <typename T, bool RAW> __device__ __forceinline__ MixQ<T> gfg_mixture(const T* __restrict__ p, const GfLayerDev<T>& o, int D, T x) {
+    return o.fast ? gfg_mixture_impl<T, RAW, true>(p, o, D, x) : gfg_mixture_impl<T, RAW, false>(p, o, D, x);
 }
 
 // in-place derive of a staged raw row by the G lanes of its group: lane d < D takes column d, reflections are dealt round-robin
