@@ -83,7 +83,7 @@ def cpu_baseline(budget_s=20.0):
 
 
 # ---------------------------------------------------------------------------------------------- HBM traffic from the committed PMC passes
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r01_c_traffic.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r01_d_traffic.json")
 TRAFFIC_KEYS = {("jf_cond_gf_chain_inv_f32", "K7_H128_N548_D4"): "jf::cond_gf_chain_kernel<float, 8>",
                 ("jf_mlp2_f32", "K7_H128_N548"): "jf::mlp2_kernel<float, 4, 2, true>",
                 ("jf_mlp2_f32", "K4_H128_N10"): "jf::mlp2_kernel<float, 4, 1, true>",
@@ -93,7 +93,7 @@ TRAFFIC_KEYS = {("jf_cond_gf_chain_inv_f32", "K7_H128_N548_D4"): "jf::cond_gf_ch
 
 def pmc_traffic(kname, ktag, B):
     """HBM bytes per launch of one kernel from the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command
-    (profiles/r01_c_*; PMC collection needs its own rocprofv3 runs, so the figure is read from the committed summary, not measured live).
+    (profiles/r01_d_*; PMC collection needs its own rocprofv3 runs, so the figure is read from the committed summary, not measured live).
     Corrections (MI355X_MICROARCH.md, HBM section): FETCH_SIZE x 2 on gfx950 for wide coalesced reads; WRITE_SIZE x 0.965, calibrated on
     scripts/probe/wstore for the 16-byte lane-per-row tile stores these kernels use.  None when the profile was taken at another batch."""
     try:
@@ -107,7 +107,7 @@ def pmc_traffic(kname, ktag, B):
         if key.startswith(prefix) and v.get("FETCH_SIZE_raw_KB") is not None and v.get("WRITE_SIZE_raw_KB") is not None:
             return {"hbm_bytes_per_launch": v["FETCH_SIZE_raw_KB"] * 1024 * 2 + v["WRITE_SIZE_raw_KB"] * 1024 * 0.965,
                     "read_bytes": v["FETCH_SIZE_raw_KB"] * 1024 * 2, "write_bytes": v["WRITE_SIZE_raw_KB"] * 1024 * 0.965,
-                    "source": "profiles/r01_c_traffic.json (rocprofv3 --pmc, separate passes)"}
+                    "source": "profiles/r01_d_traffic.json (rocprofv3 --pmc, separate passes)"}
     return None
 
 
