@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""Throughput of the five BASELINE.json configurations (SURVEY 8d inputs) on one MI355X: log-prob evals/s and samples/s.
+Not the contract benchmark (bench.py is, on configs[2]); this is the table in DESIGN.md section 5."""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden")]
+import numpy as np
+import torch
+import fixture_io
+import helpers
+
+CONFIGS = [  # (fixture, dtype, rows, label)
+    ("c1_e2_gg", torch.float64, 4096, 'C1 pdf("e2","gg") f64'),
+    ("c2_e4_gggg", torch.float32, 1 << 20, 'C2 pdf("e4","gggg") f32'),
+    ("c3_e4s2e4", torch.float32, 1 << 20, 'C3 pdf("e4+s2+e4","gggg+f+gggg") f32'),
+    ("c3_e4s2e4", torch.float64, 1 << 20, 'C3 f64'),
+    ("c3b_e4s2e4_fsplines", torch.float32, 1 << 20, 'C3 with f splines (vertical rr + circular oo) f32'),
+    ("c4_i1s1_ro", torch.float32, 1 << 20, 'C4 pdf("i1+s1","r+o") f32'),
+    ("c4_i1s1_ro", torch.float64, 1 << 20, 'C4 f64'),
+    ("c5_e8s2_ggggv", torch.float64, 1 << 19, 'C5 conditional pdf("e8+s2","gggg+v"), AmortizableMLP rank 8, f64, 2^19 rows (one GPU share)'),
+]
+
+
+def inputs(fx, n, seed):
+    rng = np.random.default_rng(seed)
+    cols = []
+    for part in fx.pdf_defs.split("+"):
+        kind, dim = part[0], int(part[1:].split("_")[0])
+        if kind == "e":
+            cols.append(rng.normal(size=(n, dim)) * 1.5)
+        elif kind == "i":
+            cols.append(rng.uniform(1e-6, 1 - 1e-6, size=(n, 1)))
+        elif dim == 1:
+            cols.append(rng.uniform(0, 2 * np.pi, size=(n, 1)))
+        else:
+            cols.append(np.arccos(rng.uniform(-1, 1, size=(n, 1))).clip(1e-3, np.pi - 1e-3))
+            cols.append(rng.uniform(0, 2 * np.pi, size=(n, 1)))
+    x = np.concatenate(cols, axis=1)
+    c = fx.get("cond")
+    cond = rng.normal(size=(n, c.shape[1])) if c is not None else None
+    return x, cond
+
+
+def timeit(fn, n=5):
+    fn(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n
+
+
+print("| configuration | rows | log-prob ms | evals/s | sampling ms | samples/s |")
+print("|---|---|---|---|---|---|")
+for name, dtype, n, label in CONFIGS:
+    fx = fixture_io.load(name)
+    pdf = helpers.build_product(fx, dtype)
+    pdf.check_status = False
+    x, cond = inputs(fx, n, 7)
+    x = torch.from_numpy(x).to(device="cuda", dtype=dtype)
+    cond = torch.from_numpy(cond).to(device="cuda", dtype=dtype) if cond is not None else None
+    t_lp = timeit(lambda: pdf(x, conditional_input=cond))
+    z = torch.randn(n, pdf.total_base_dim, device="cuda", dtype=dtype)
+    try:
+        t_s = timeit(lambda: pdf._obtain_sample(conditional_input=cond, predefined_target_input=z), n=2)
+        s_txt = "%.2f | %.3g" % (1e3 * t_s, n / t_s)
+    except Exception as e:            # noqa: BLE001 -- report, do not hide
+        s_txt = "%s | -" % type(e).__name__
+    print("| %s | %d | %.3f | %.3g | %s |" % (label, n, 1e3 * t_lp, n / t_lp, s_txt))

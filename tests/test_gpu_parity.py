@@ -172,8 +172,8 @@ def _collect_bins(fx, direction, dtype):
         if direction == "inv":
             pdf(helpers.to_dev(fx["x"], dtype), conditional_input=cond, force_embedding_coordinates=bool(fx.meta["embedding"]))
         else:
-            pdf.sample(conditional_input=cond, samplesize=fx["z"].shape[0], force_embedding_coordinates=bool(fx.meta["embedding"]),
-                       base_noise=helpers.to_dev(fx["z"], dtype)) if hasattr(pdf, "sample") else None
+            pdf._obtain_sample(conditional_input=cond, predefined_target_input=helpers.to_dev(fx["z"], dtype),
+                               force_embedding_coordinates=bool(fx.meta["embedding"]))
         cols = []
         for t in _hip.BINS_LOG:
             t = t.cpu().numpy()
@@ -194,6 +194,22 @@ def test_spline_bins_bit_exact_float64(fx):
     assert len(cols) == len(ref), (len(cols), len(ref))
     for i, (c, r) in enumerate(zip(cols, ref)):
         c = c[c != -2]                             # rows inside an identity region never reach searchsorted in the reference
+        assert c.shape == r.shape, (i, c.shape, r.shape)
+        assert np.array_equal(c, r.astype(np.int64)), "search %d: %d of %d bin indices differ" % (i, int((c != r).sum()), c.size)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fx", BIN_FIXTURES, ids=lambda f: f.name)
+def test_spline_bins_bit_exact_sampling_float64(fx):
+    """the same integers in the sampling direction (searchsorted on the inverse knots)."""
+    cols = _collect_bins(fx, "fwd", torch.float64)
+    ref = []
+    for b in fx.bins("fwd"):
+        b = b.reshape(b.shape[0], -1)
+        ref += [b[:, j] for j in range(b.shape[1])]
+    assert len(cols) == len(ref), (len(cols), len(ref))
+    for i, (c, r) in enumerate(zip(cols, ref)):
+        c = c[c != -2]
         assert c.shape == r.shape, (i, c.shape, r.shape)
         assert np.array_equal(c, r.astype(np.int64)), "search %d: %d of %d bin indices differ" % (i, int((c != r).sum()), c.size)
 
