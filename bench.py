@@ -174,6 +174,7 @@ def main():
         else:
             for _ in range(args.steps):
                 logp = step()
+        pdf.flush_status()                            # deferred kernel status words of the timed steps: raises if any row went wrong
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -193,6 +194,8 @@ def main():
             kernel_table = timer.summary()
         del pdf, x
 
+    if world > 1:
+        dist.barrier()
     if rank == 0:
         r32, r64 = results[torch.float32], results[torch.float64]
         # ---- roofline of the dominant kernel (float32 run).  Algorithmic bytes per row (SURVEY 8d / DESIGN.md), float32:

@@ -113,7 +113,10 @@ class pdf(nn.Module):
         if amortize_everything:
             assert amortization_mlp_use_custom_mode, "Amortizing all MLPs requires custom MLPs."
             self.total_number_amortizable_params = 0
-        self.check_status = True       # turn kernel status words into the reference's warnings / exceptions after each call
+        # kernel status words (rows with out-of-range spline inputs, non-finite results, non-converged Newton rows) -> the reference's
+        # exceptions / warnings.  True: sampling checks after every call; log-prob calls read the words back asynchronously and raise at
+        # the next call or in flush_status().  "immediate": blocking check after every call.  False: never.
+        self.check_status = True
         # conditional e-blocks (Linear-tanh-Linear MLP + g layers, D in {3,4}) as ONE launch with the parameter block kept on chip
         # (jf_cond_gf_chain_inv).  Off by default: measured +3 % on the C3 step only (f32 MFMA and VALU do not co-issue on CDNA4)
         self.fuse_conditional_blocks = False
@@ -433,6 +436,47 @@ class pdf(nn.Module):
         else:
             assert x.shape[0] == conditional_input.shape[0], "Evaluating input x and condititional input shape must be similar!"
 
+    def _status_ring(self, device):
+        """a few pinned host slots + events for the deferred status read-back of the log-prob direction"""
+        ring = getattr(self, "_ring", None)
+        if ring is None or ring["device"] != device:
+            ring = {"device": device, "host": [torch.zeros(_hip.JF_STATUS_WORDS, dtype=torch.int32).pin_memory() for _ in range(8)],
+                    "event": [torch.cuda.Event() for _ in range(8)], "pending": [], "next": 0}
+            self._ring = ring
+        return ring
+
+    def _defer_status(self, status):
+        """log-prob direction: copy the status words to pinned host memory WITHOUT synchronising; they are examined when the copy has
+        landed -- at the next call into this pdf or in flush_status() -- so a step does not end in a host-device round trip.
+        check_status = "immediate" restores a blocking check after every call."""
+        if status is None or not self.check_status:
+            return
+        if self.check_status == "immediate":
+            return self._report_status(status)
+        ring = self._status_ring(status.device)
+        if len(ring["pending"]) == len(ring["host"]):
+            self._poll_status(block=True)
+        i = ring["next"]
+        ring["next"] = (i + 1) % len(ring["host"])
+        ring["host"][i].copy_(status, non_blocking=True)
+        ring["event"][i].record()
+        ring["pending"].append(i)
+
+    def _poll_status(self, block=False):
+        ring = getattr(self, "_ring", None)
+        while ring is not None and ring["pending"]:
+            i = ring["pending"][0]
+            if block:
+                ring["event"][i].synchronize()
+            elif not ring["event"][i].query():
+                return
+            ring["pending"].pop(0)
+            self._report_status(ring["host"][i])
+
+    def flush_status(self):
+        """wait for every deferred status read-back and raise / warn exactly as an immediate check would have."""
+        self._poll_status(block=True)
+
     def _report_status(self, status):
         """kernel status words -> the reference's warnings / exceptions (bisection_n_newton.py:84-133, default.py:1516)."""
         if status is None or not self.check_status:
@@ -545,11 +589,12 @@ class pdf(nn.Module):
             # the kernels are forward-only (backward kernels: SURVEY.md section 8f, next row): never build a wrong graph silently
             raise NotImplementedError("jammy_flows_amd kernels are forward-only in this version; call under torch.no_grad()")
         with torch.no_grad():
+            self._poll_status()                          # surfaces problems of earlier calls whose status has arrived meanwhile
             status = _hip.new_status(x.device) if self.check_status else None
             base, log_det, log_pdf = self._inverse_impl(x, None, conditional_input, amortization_parameters, force_embedding_coordinates,
                                                         force_intrinsic_coordinates, only_last, True, status)
             total = log_pdf + log_det
-            self._report_status(status)
+            self._defer_status(status)
         return total, log_pdf, base
 
     def log_prob(self, x, conditional_input=None, **kwargs):

@@ -238,3 +238,24 @@ def test_fused_conditional_block_matches_two_launch_path(name):
     # identical arithmetic per row up to the MFMA tile shape (16x16x4 vs 32x32x2 summation order)
     assert max_abs(got[0][ok], ref[0][ok]) < 2e-3
     assert max_abs(got[2][ok], ref[2][ok]) < 2e-3
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# kernel status words -> exceptions: immediately ("immediate") or at the next call / flush_status() (default, no host sync)
+@pytest.mark.gpu
+def test_status_words_raise_like_the_reference():
+    fx = [f for f in ALL_FIXTURES if f.name == "c4_i1s1_ro"][0]
+    pdf = build_product(fx, torch.float64)
+    x = to_dev(fx["x"], torch.float64).clone()
+    x[3, 0] = 1.5                                   # outside the interval: 'r' clamps it onto the boundary, whose chart image is infinite
+    pdf.check_status = "immediate"
+    with pytest.raises(Exception, match="nonfinite|outside boundaries"):
+        pdf(x)
+    pdf.check_status = True
+    pdf(x)                                          # deferred: no host synchronisation inside the call ...
+    with pytest.raises(Exception, match="nonfinite|outside boundaries"):
+        pdf.flush_status()                          # ... the problem surfaces here (or at the next call)
+    pdf.flush_status()                              # nothing pending any more
+    good = to_dev(fx["x"], torch.float64)
+    pdf(good)
+    pdf.flush_status()
