@@ -259,3 +259,40 @@ def test_status_words_raise_like_the_reference():
     good = to_dev(fx["x"], torch.float64)
     pdf(good)
     pdf.flush_status()
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# C ABI error behaviour: bad arguments and unsupported configurations are reported by return code, never by a silent fallback
+@pytest.mark.gpu
+def test_c_abi_error_codes():
+    import ctypes
+    from jammy_flows_amd import _hip
+    lib = _hip.lib()
+    x = torch.zeros(8, 4, dtype=torch.float32, device="cuda")
+    p = torch.zeros(1, 136, dtype=torch.float32, device="cuda")
+    out = torch.empty_like(x)
+    ld = torch.empty(8, dtype=torch.float32, device="cuda")
+    L = _hip.jf_gf_layer()
+    L.num_kde, L.hh_iter, L.fit_normalization, L.regulate_normalization = 10, 4, 1, 1
+    L.width_min, L.width_max, L.norm_min, L.norm_max = 0.01, 100.0, 1.0, 10.0
+    arr = (_hip.jf_gf_layer * 1)(L)
+
+    def call(n_layers=1, D=4, pb=1, xptr=x.data_ptr(), layers=arr, B=8):
+        return lib.jf_gf_chain_inv_f32(ctypes.c_void_p(xptr), 4, None, ctypes.c_void_p(p.data_ptr()), 136, pb, B, D, n_layers, layers,
+                                       ctypes.c_void_p(out.data_ptr()), 4, ctypes.c_void_p(ld.data_ptr()), None, None, None, 0, None, None)
+
+    assert call() == _hip.JF_OK
+    torch.cuda.synchronize()
+    assert call(n_layers=0) == _hip.JF_ERR_BADARG
+    assert call(n_layers=_hip.JF_MAX_CHAIN + 1) == _hip.JF_ERR_BADARG
+    assert call(xptr=None) == _hip.JF_ERR_BADARG
+    assert call(pb=3) == _hip.JF_ERR_BADARG                      # param_batch must be 1 or B
+    assert call(D=9) == _hip.JF_ERR_UNSUPPORTED
+    assert call(B=0) == _hip.JF_OK                                # empty batch: nothing launched
+    L.width_min = 0.0
+    assert call(layers=(_hip.jf_gf_layer * 1)(L)) == _hip.JF_ERR_BADARG
+    # fused MLP: hidden width / input width limits
+    w = torch.zeros(8, 200, dtype=torch.float32, device="cuda")
+    rc = lib.jf_mlp2_f32(ctypes.c_void_p(x.data_ptr()), 4, ctypes.c_void_p(w.data_ptr()), 200, ctypes.c_void_p(w.data_ptr()),
+                         ctypes.c_void_p(w.data_ptr()), 200, None, 8, 4, 200, 8, ctypes.c_void_p(out.data_ptr()), 4, None)
+    assert rc == _hip.JF_ERR_UNSUPPORTED
