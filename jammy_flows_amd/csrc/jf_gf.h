@@ -269,14 +269,14 @@ template <typename T, bool RAW> __device__ __forceinline__ MixQ<T> gfg_mixture_s
         const T iw = RAW ? gf_inv_width(o, p[o.off_lw + k * D]) : p[o.off_lw + k * D];
         m = M<T>::min(m, M<T>::abs((x - p[o.off_mean + k * D]) * iw));
     }
-    const T em = M<T>::exp(-m);
+    const T em = M<T>::exp_fast(-m);                         // may underflow to 0: the unscaled parts then stand alone
     T Cu = T(0), Cs = T(0), Su = T(0), Ss = T(0), Ps = T(0), Nn = T(0);
     for (int k = 0; k < o.K; ++k) {
         const T iw = RAW ? gf_inv_width(o, p[o.off_lw + k * D]) : p[o.off_lw + k * D];
         const T wk = o.fit_norm ? (RAW ? gf_weight(o, p[o.off_ln + k * D], shift) : p[o.off_ln + k * D]) : uniform_w;
         const T u = (x - p[o.off_mean + k * D]) * iw;
-        const T t = M<T>::exp(m - M<T>::abs(u));           // <= 1, equals 1 for the nearest component
-        const T hi = T(1) / (T(1) + t * em);
+        const T t = M<T>::exp_fast(m - M<T>::abs(u));      // <= 1, equals 1 for the nearest component (argument <= 0: v_exp is accurate here)
+        const T hi = M<T>::rcp(T(1) + t * em);
         const T c1 = wk * hi, c2 = c1 * t;
         if (u >= T(0)) { Cu += c1; Ss += c2; }
         else { Su += c1; Cs += c2; }
@@ -284,15 +284,15 @@ template <typename T, bool RAW> __device__ __forceinline__ MixQ<T> gfg_mixture_s
         Nn += wk;
     }
     if constexpr (RAW) {
-        const T inv = T(1) / Nn;
+        const T inv = M<T>::rcp(Nn);
         Cu *= inv; Cs *= inv; Su *= inv; Ss *= inv; Ps *= inv;
     }
     MixQ<T> q;
     q.cdf = Cu + em * Cs;
     q.sf = Su + em * Ss;
-    q.lc = Cu > T(0) ? M<T>::log(q.cdf) : M<T>::log(Cs) - m;
-    q.ls = Su > T(0) ? M<T>::log(q.sf) : M<T>::log(Ss) - m;
-    q.lp = M<T>::log(Ps) - m;
+    q.lc = Cu > T(0) ? M<T>::log_fast(q.cdf) : M<T>::log_fast(Cs) - m;
+    q.ls = Su > T(0) ? M<T>::log_fast(q.sf) : M<T>::log_fast(Ss) - m;
+    q.lp = M<T>::log_fast(Ps) - m;
     return q;
 }
 
