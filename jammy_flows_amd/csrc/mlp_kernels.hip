@@ -153,10 +153,12 @@ template <typename T> struct Mlp2Cfg;
 template <> struct Mlp2Cfg<float> { static constexpr int LDW = HMAX + 4; };
 template <> struct Mlp2Cfg<double> { static constexpr int LDW = HMAX + 1; };
 
-template <typename T, int JH, int TN, bool VECROW>
+// L1 = false: no first layer -- the "hidden activations" are the input itself (single dense layer out = act(in W2^T + b2) with K = H <= 128
+// input columns, jf_linear); act: 0 identity, 1 tanh on the output.
+template <typename T, int JH, int TN, bool VECROW, bool L1>
 __global__ void __launch_bounds__(256, 3) mlp2_kernel(const T* __restrict__ in, int64_t in_stride, const T* __restrict__ W1, int64_t w1_stride,
                                                       const T* __restrict__ b1, const T* __restrict__ W2, int64_t w2_stride, const T* __restrict__ b2,
-                                                      int64_t B, int K1, int H, int N, T* __restrict__ out, int64_t out_stride) {
+                                                      int64_t B, int K1, int H, int N, T* __restrict__ out, int64_t out_stride, int act) {
     using MF = Mfma<T>;
     using V = typename Vec16<T>::type;
     constexpr int VN = Vec16<T>::N;
@@ -169,7 +171,7 @@ __global__ void __launch_bounds__(256, 3) mlp2_kernel(const T* __restrict__ in, 
     extern __shared__ __align__(16) unsigned char smem_raw[];
     T* Ws = reinterpret_cast<T*>(smem_raw);                  // [BN2][LDW]   W2 tile (phase 2)
     T* Bs = Ws + BN2 * LDW;                                  // [BN2]        bias of the tile's columns
-    const int k1p = (K1 + KS - 1) / KS * KS, ldk = k1p + 1;
+    const int k1p = L1 ? (K1 + KS - 1) / KS * KS : MT, ldk = k1p + 1;   // (!L1: the input is staged in MT-column chunks)
     T* Xs = Bs + BN2;                                        // [BMR][ldk]   input tile
     T* W1s = Xs + BMR * ldk;                                 // [HP][ldk]    W1   } staged once per workgroup
     T* b1s = W1s + HP * ldk;                                 // [HP]         b1   }
@@ -181,7 +183,7 @@ __global__ void __launch_bounds__(256, 3) mlp2_kernel(const T* __restrict__ in, 
 
     // ---- W1, b1: once per workgroup.  Staging in straight-line batches of 4 loads per thread (clamped addresses + selects): issued
     // back to back, one round trip per batch.
-    {
+    if constexpr (L1) {
         const int nw = HP * k1p;
         for (int base = 0; base < nw; base += 4 * 256) {
             T v[4]; int o[4];
@@ -242,43 +244,66 @@ __global__ void __launch_bounds__(256, 3) mlp2_kernel(const T* __restrict__ in, 
     load_tile(0);
     for (int64_t rt = blockIdx.x; rt < n_row_tiles; rt += gridDim.x) {
         const int64_t row0 = rt * BMR;
-        {
-            const int nx = BMR * k1p;
-            for (int base = 0; base < nx; base += 4 * 256) {
-                T v[4]; int o[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int idx = base + u * 256 + tid;
-                    const int r = idx / k1p, c = idx - r * k1p;
-                    const int64_t gr = row0 + r;
-                    const T t = in[(gr <= last ? gr : last) * in_stride + (c < K1 ? c : 0)];      // rows past B replicate row B-1
-                    v[u] = c < K1 ? t : T(0);
-                    o[u] = idx < nx ? r * ldk + c : -1;
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) if (o[u] >= 0) Xs[o[u]] = v[u];
-            }
-        }
-        __syncthreads();                                     // x tile (and, first pass, the W2 tile) visible
         T hreg[JH][NREG];
-        {
+        if constexpr (L1) {
+            {
+                const int nx = BMR * k1p;
+                for (int base = 0; base < nx; base += 4 * 256) {
+                    T v[4]; int o[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int idx = base + u * 256 + tid;
+                        const int r = idx / k1p, c = idx - r * k1p;
+                        const int64_t gr = row0 + r;
+                        const T t = in[(gr <= last ? gr : last) * in_stride + (c < K1 ? c : 0)];      // rows past B replicate row B-1
+                        v[u] = c < K1 ? t : T(0);
+                        o[u] = idx < nx ? r * ldk + c : -1;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) if (o[u] >= 0) Xs[o[u]] = v[u];
+                }
+            }
+            __syncthreads();                                 // x tile (and, first pass, the W2 tile) visible
             typename MF::Acc acc[JH];
-    #pragma unroll
+#pragma unroll
             for (int j = 0; j < JH; ++j)
-    #pragma unroll
+#pragma unroll
                 for (int r = 0; r < NREG; ++r) acc[j][r] = T(0);
             for (int s = 0; s < k1p / KS; ++s) {
                 const int kk = s * KS + lq;
                 const T xb = Xs[(wave * MT + li) * ldk + kk];
-    #pragma unroll
+#pragma unroll
                 for (int j = 0; j < JH; ++j) acc[j] = MF::mma(W1s[(j * MT + li) * ldk + kk], xb, acc[j]);
             }
-    #pragma unroll
+#pragma unroll
             for (int j = 0; j < JH; ++j)
-    #pragma unroll
+#pragma unroll
                 for (int r = 0; r < NREG; ++r) hreg[j][r] = M<T>::tanh_fast(acc[j][r] + b1s[j * MT + MF::row_of(r, lane)]);   // padded units: tanh(0) = 0
+        } else {
+            // the input itself in the B-operand layout (lane = row, register r of tile j <-> column j*MT + row_of(r, lane)), staged MT columns at a time
+#pragma unroll
+            for (int j = 0; j < JH; ++j) {
+                if (j > 0) lds_barrier();                    // previous chunk consumed
+                constexpr int PER = BMR * MT / 256;          // elements per thread and chunk
+                T v[PER];
+#pragma unroll
+                for (int u = 0; u < PER; ++u) {
+                    const int idx = u * 256 + tid;
+                    const int r = idx / MT, c = j * MT + idx % MT;
+                    const int64_t gr = row0 + r;
+                    const T t = in[(gr <= last ? gr : last) * in_stride + (c < K1 ? c : 0)];
+                    v[u] = c < K1 ? t : T(0);
+                }
+#pragma unroll
+                for (int u = 0; u < PER; ++u) {
+                    const int idx = u * 256 + tid;
+                    Xs[(idx / MT) * ldk + idx % MT] = v[u];
+                }
+                __syncthreads();
+#pragma unroll
+                for (int r = 0; r < NREG; ++r) hreg[j][r] = Xs[(wave * MT + li) * ldk + MF::row_of(r, lane)];
+            }
         }
-
         // result addressing: lane = row (clamped to B-1); per (tile, column tile, register group) a uniform column offset
         const int64_t grow = row0 + wave * MT + li;
         T* const orow = out + (grow <= last ? grow : last) * out_stride;
@@ -299,42 +324,72 @@ __global__ void __launch_bounds__(256, 3) mlp2_kernel(const T* __restrict__ in, 
     #pragma unroll
                     for (int e = 0; e < KPG; ++e)
     #pragma unroll
-                        for (int ct = 0; ct < TN; ++ct) acc[ct] = MF::mma(elem(frag[cur][ct], e), hreg[j][g * KPG + e], acc[ct]);
-                }
-            // results: acc[ct][r] = out[row = lane's row][col = t*BN2 + ct*MT + row_of(r, lane)]; bias from the LDS tile
-            const bool edge = (t + 1) * BN2 > N;                 // block-uniform: only the last tile can reach past N
-            if (VECROW && RG == 4 && !edge) {
-    #pragma unroll
-                for (int ct = 0; ct < TN; ++ct)
-    #pragma unroll
-                    for (int r0 = 0; r0 < NREG; r0 += RG) {
-                        const int lc = ct * MT + MF::row_of(r0, lane);
-                        const V bb = *reinterpret_cast<const V*>(Bs + lc);
-                        V o;
-                        o.x = acc[ct][r0] + bb.x; o.y = acc[ct][r0 + 1] + bb.y;
-                        if constexpr (VN == 4) { o.z = acc[ct][r0 + 2] + bb.z; o.w = acc[ct][r0 + 3] + bb.w; }
-                        *reinterpret_cast<V*>(orow + t * BN2 + lc) = o;
-                    }
-            } else {
-                // edge tile: 16-byte stores for the register groups that lie inside N, scalar stores (last column duplicated) for the group that
-                // straddles N, nothing for groups past N -- a narrow output (N = 10) would otherwise issue 16 scattered dword stores per lane
-#pragma unroll
-                for (int ct = 0; ct < TN; ++ct)
-#pragma unroll
-                    for (int r0 = 0; r0 < NREG; r0 += RG) {
-                        const int lc = ct * MT + MF::row_of(r0, lane);
-                        const int gc = t * BN2 + lc;
-                        if (VECROW && RG == 4 && gc + RG <= N) {
-                            V o;
-                            o.x = acc[ct][r0] + Bs[lc]; o.y = acc[ct][r0 + 1] + Bs[lc + 1];
-                            if constexpr (VN == 4) { o.z = acc[ct][r0 + 2] + Bs[lc + 2]; o.w = acc[ct][r0 + 3] + Bs[lc + 3]; }
-                            *reinterpret_cast<V*>(orow + gc) = o;
-                        } else if (gc < N) {
-#pragma unroll
-                            for (int e = 0; e < RG; ++e)
-                                if (gc + e < N) orow[gc + e] = acc[ct][r0 + e] + Bs[lc + e];
+                        for (int ct = 0; ct < TN; ++ct) {
+                            if constexpr (RG == 4) acc[ct] = MF::mma(elem(frag[cur][ct], e), hreg[j][g * KPG + e], acc[ct]);   // out^T tile: lane = row
+                            else acc[ct] = MF::mma(hreg[j][g * KPG + e], elem(frag[cur][ct], e), acc[ct]);                    // out tile: lane = column
                         }
+                }
+            if constexpr (RG == 1) {
+                // float64: the 16x16x4 result registers hold rows q + 4v, so the product is taken un-transposed (hreg is equally valid as the A
+                // operand) and each store instruction writes 4 rows x 16 consecutive columns (128-byte segments)
+#pragma unroll
+                for (int ct = 0; ct < TN; ++ct) {
+                    const int lc = ct * MT + li;
+                    const int gc = t * BN2 + lc;
+                    const T bb = Bs[lc];
+#pragma unroll
+                    for (int r = 0; r < NREG; ++r) {
+                        const int64_t gr = row0 + wave * MT + MF::row_of(r, lane);
+                        T v = acc[ct][r] + bb;
+                        if (act == 1) v = M<T>::tanh(v);
+                        out[(gr <= last ? gr : last) * out_stride + (gc < N ? gc : N - 1)] = v;      // duplicates carry identical values
                     }
+                }
+            } else {
+            // results: acc[ct][r] = out[row = lane's row][col = t*BN2 + ct*MT + row_of(r, lane)]; bias from the LDS tile
+    #pragma unroll
+                for (int ct = 0; ct < TN; ++ct)
+    #pragma unroll
+                    for (int r = 0; r < NREG; ++r) acc[ct][r] += Bs[ct * MT + MF::row_of(r, lane)];
+                if (act == 1) {                                      // block-uniform
+    #pragma unroll
+                    for (int ct = 0; ct < TN; ++ct)
+    #pragma unroll
+                        for (int r = 0; r < NREG; ++r) acc[ct][r] = M<T>::tanh(acc[ct][r]);
+                }
+                const bool edge = (t + 1) * BN2 > N;                 // block-uniform: only the last tile can reach past N
+                if (VECROW && RG == 4 && !edge) {
+        #pragma unroll
+                    for (int ct = 0; ct < TN; ++ct)
+        #pragma unroll
+                        for (int r0 = 0; r0 < NREG; r0 += RG) {
+                            const int lc = ct * MT + MF::row_of(r0, lane);
+                            V o;
+                            o.x = acc[ct][r0]; o.y = acc[ct][r0 + 1];
+                            if constexpr (VN == 4) { o.z = acc[ct][r0 + 2]; o.w = acc[ct][r0 + 3]; }
+                            *reinterpret_cast<V*>(orow + t * BN2 + lc) = o;
+                        }
+                } else {
+                    // edge tile: 16-byte stores for the register groups that lie inside N, scalar stores (last column duplicated) for the group that
+                    // straddles N, nothing for groups past N -- a narrow output (N = 10) would otherwise issue 16 scattered dword stores per lane
+    #pragma unroll
+                    for (int ct = 0; ct < TN; ++ct)
+    #pragma unroll
+                        for (int r0 = 0; r0 < NREG; r0 += RG) {
+                            const int lc = ct * MT + MF::row_of(r0, lane);
+                            const int gc = t * BN2 + lc;
+                            if (VECROW && RG == 4 && gc + RG <= N) {
+                                V o;
+                                o.x = acc[ct][r0]; o.y = acc[ct][r0 + 1];
+                                if constexpr (VN == 4) { o.z = acc[ct][r0 + 2]; o.w = acc[ct][r0 + 3]; }
+                                *reinterpret_cast<V*>(orow + gc) = o;
+                            } else if (gc < N) {
+    #pragma unroll
+                                for (int e = 0; e < RG; ++e)
+                                    if (gc + e < N) orow[gc + e] = acc[ct][r0 + e];
+                            }
+                        }
+                }
             }
             if (n_tiles > 1 && (t + 1 < n_tiles || rt + gridDim.x < n_row_tiles)) {   // block-uniform; a single tile stays resident
                 lds_barrier();                               // every wave has read the tile
@@ -347,15 +402,15 @@ __global__ void __launch_bounds__(256, 3) mlp2_kernel(const T* __restrict__ in, 
     }
 }
 
-template <typename T, int JH, int TN>
+template <typename T, int JH, int TN, bool L1>
 static int mlp2_launch(const T* in, int64_t in_stride, const T* W1, int64_t w1_stride, const T* b1, const T* W2, int64_t w2_stride, const T* b2, int64_t B,
-                       int32_t K1, int32_t H, int32_t N, T* out, int64_t out_stride, void* stream) {
+                       int32_t K1, int32_t H, int32_t N, T* out, int64_t out_stride, int act, void* stream) {
     constexpr int MT = Mfma<T>::MT, KS = Mfma<T>::KS, BMR = 4 * MT, HP = JH * MT;
-    const int k1p = (K1 + KS - 1) / KS * KS, ldk = k1p + 1;
-    const size_t lds = ((size_t)BMR * ldk + (size_t)HP * ldk + HP + (size_t)(TN * MT) * Mlp2Cfg<T>::LDW + TN * MT) * sizeof(T);
+    const int k1p = L1 ? (K1 + KS - 1) / KS * KS : MT, ldk = k1p + 1;
+    const size_t lds = ((size_t)BMR * ldk + (L1 ? (size_t)HP * ldk + HP : 0) + (size_t)(TN * MT) * Mlp2Cfg<T>::LDW + TN * MT) * sizeof(T);
     // 16-byte result stores need 16-byte aligned rows
     const bool vecrow = (out_stride % Vec16<T>::N == 0) && ((reinterpret_cast<uintptr_t>(out) & 15u) == 0);
-    auto k = vecrow ? mlp2_kernel<T, JH, TN, true> : mlp2_kernel<T, JH, TN, false>;
+    auto k = vecrow ? mlp2_kernel<T, JH, TN, true, L1> : mlp2_kernel<T, JH, TN, false, L1>;
     if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     int64_t grid = (B + BMR - 1) / BMR;
     if (N <= TN * MT) {                                      // single W2 tile: resident workgroups walk the row tiles
@@ -367,8 +422,24 @@ static int mlp2_launch(const T* in, int64_t in_stride, const T* W1, int64_t w1_s
         if (grid > resident) grid = resident;
     }
     hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream, in, in_stride, W1, w1_stride, b1, W2, w2_stride, b2, B,
-                       (int)K1, (int)H, (int)N, out, out_stride);
+                       (int)K1, (int)H, (int)N, out, out_stride, act);
     return check_launch();
+}
+
+// hidden width (L1) / input width (!L1) in mfma tiles, rounded up to an instantiated count; N <= MT takes the single-tile variant
+template <typename T, bool L1>
+static int mlp2_dispatch(const T* in, int64_t in_stride, const T* W1, int64_t w1_stride, const T* b1, const T* W2, int64_t w2_stride, const T* b2, int64_t B,
+                         int32_t K1, int32_t H, int32_t N, T* out, int64_t out_stride, int act, void* stream) {
+    constexpr int MT = Mfma<T>::MT;
+    const int tiles = (H + MT - 1) / MT;
+    constexpr int Q = HMAX / MT / 4;                         // f32: 1, f64: 2
+#define JF_MLP2_GO(JH_) \
+    return (N <= MT) ? mlp2_launch<T, JH_, 1, L1>(in, in_stride, W1, w1_stride, b1, W2, w2_stride, b2, B, K1, H, N, out, out_stride, act, stream) \
+                     : mlp2_launch<T, JH_, 2, L1>(in, in_stride, W1, w1_stride, b1, W2, w2_stride, b2, B, K1, H, N, out, out_stride, act, stream)
+    if (tiles <= 1 * Q) JF_MLP2_GO(1 * Q);
+    if (tiles <= 2 * Q) JF_MLP2_GO(2 * Q);
+    JF_MLP2_GO(4 * Q);
+#undef JF_MLP2_GO
 }
 
 template <typename T>
@@ -378,16 +449,7 @@ static int mlp2(const T* in, int64_t in_stride, const T* W1, int64_t w1_stride, 
     if (K1 > K1MAX || H > HMAX) return JF_ERR_UNSUPPORTED;
     if ((H % Vec16<T>::N) || (w2_stride % Vec16<T>::N) || (reinterpret_cast<uintptr_t>(W2) & 15u)) return JF_ERR_UNSUPPORTED;   // 16-byte W2 rows
     if (B == 0) return JF_OK;
-    constexpr int MT = Mfma<T>::MT;
-    const int tiles = (H + MT - 1) / MT;                     // hidden width in mfma tiles, rounded up to an instantiated count
-    constexpr int Q = HMAX / MT / 4;                         // f32: 1, f64: 2
-#define JF_MLP2_GO(JH_) \
-    return (N <= MT) ? mlp2_launch<T, JH_, 1>(in, in_stride, W1, w1_stride, b1, W2, w2_stride, b2, B, K1, H, N, out, out_stride, stream) \
-                     : mlp2_launch<T, JH_, 2>(in, in_stride, W1, w1_stride, b1, W2, w2_stride, b2, B, K1, H, N, out, out_stride, stream)
-    if (tiles <= 1 * Q) JF_MLP2_GO(1 * Q);
-    if (tiles <= 2 * Q) JF_MLP2_GO(2 * Q);
-    JF_MLP2_GO(4 * Q);
-#undef JF_MLP2_GO
+    return mlp2_dispatch<T, true>(in, in_stride, W1, w1_stride, b1, W2, w2_stride, b2, B, K1, H, N, out, out_stride, 0, stream);
 }
 
 template <typename T>
@@ -395,6 +457,10 @@ static int linear(const T* in, int64_t in_stride, const T* W, int64_t w_stride, 
                   int64_t out_stride, void* stream) {
     if (!in || !W || !out || K < 1 || N < 1 || B < 0 || (act != 0 && act != 1)) return JF_ERR_BADARG;
     if (B == 0) return JF_OK;
+    // K <= 128 with 16-byte aligned weight rows: the mlp2 machinery without a first layer (input held in registers as the B operand,
+    // transposed product, 16-byte predicate-free stores, resident workgroups for narrow outputs)
+    if (K <= HMAX && (K % Vec16<T>::N == 0) && (w_stride % Vec16<T>::N == 0) && ((reinterpret_cast<uintptr_t>(W) & 15u) == 0))
+        return mlp2_dispatch<T, false>(in, in_stride, nullptr, 0, nullptr, W, w_stride, bias, B, K, K, N, out, out_stride, act, stream);
     const int64_t blocks = ((B + BM - 1) / BM) * ((N + BN - 1) / BN);
     if (blocks > 0x7fffffffLL) return JF_ERR_UNSUPPORTED;
     dim3 grid((unsigned)blocks);
