@@ -60,3 +60,38 @@ def sharded_log_prob(pdf, x, conditional_input=None, gather=True, evaluate=None,
     else:
         local = evaluate(xs, cs)
     return all_gather_rows(local, x.shape[0]) if gather else local
+
+
+class PipelinedGather:
+    """all-gather of equal-sized per-rank row blocks that overlaps with the NEXT step's kernels: submit() enqueues the collective
+    asynchronously (RCCL runs it on its own stream once the producer kernels of `local` are done) into one of `depth` rotating output
+    buffers and returns immediately; the buffer of a submission is complete after the next submit() into the same slot or after wait().
+    A step of the row-sharded hot path therefore never stalls on the 4 MiB log-prob exchange."""
+
+    def __init__(self, n_rows_local, dtype, device, tail_shape=(), depth=2, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+        self.out = [torch.empty((self.world * n_rows_local,) + tuple(tail_shape), dtype=dtype, device=device) for _ in range(depth)]
+        self.work = [None] * depth
+        self.keep = [None] * depth          # the submitted tensors must outlive their collectives
+        self.i = 0
+
+    def submit(self, local):
+        j = self.i % len(self.out)
+        self.i += 1
+        if self.work[j] is not None:
+            self.work[j].wait()
+        if self.world == 1:
+            self.out[j].copy_(local)
+            return self.out[j]
+        self.keep[j] = local.contiguous()
+        self.work[j] = dist.all_gather_into_tensor(self.out[j], self.keep[j], group=self.group, async_op=True)
+        return self.out[j]
+
+    def wait(self):
+        """block the current stream (not the host) until every outstanding gather has landed; returns the most recent buffer."""
+        for j, w in enumerate(self.work):
+            if w is not None:
+                w.wait()
+                self.work[j] = None
+        return self.out[(self.i - 1) % len(self.out)] if self.i else None

@@ -65,3 +65,46 @@ def test_sharded_log_prob_gloo_world2(n_rows):
         p.join(timeout=60)
     assert sorted(r for r, _ in res) == [0, 1]
     assert all(ok for _, ok in res)
+
+
+def _pipe_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n = 33
+        pg = parallel.PipelinedGather(n, torch.float64, torch.device("cpu"), depth=2)
+        ok = True
+        bufs = []
+        for step in range(5):                               # more steps than buffers: slots are reused only after their gather finished
+            local = torch.full((n,), float(10 * step + rank), dtype=torch.float64)
+            bufs.append((step, pg.submit(local)))
+        last = pg.wait()
+        expect = torch.cat([torch.full((n,), float(10 * 4 + r), dtype=torch.float64) for r in range(world)])
+        ok = ok and bool(torch.equal(last, expect))
+        # slot of step 3 (the other buffer) holds step 3's gather
+        expect3 = torch.cat([torch.full((n,), float(10 * 3 + r), dtype=torch.float64) for r in range(world)])
+        ok = ok and bool(torch.equal(bufs[3][1], expect3))
+        q.put((rank, ok))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_pipelined_gather_gloo_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_pipe_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(r for r, _ in res) == [0, 1]
+    assert all(ok for _, ok in res)
+
+
+def test_pipelined_gather_single_process():
+    pg = parallel.PipelinedGather(4, torch.float32, torch.device("cpu"))
+    a = pg.submit(torch.arange(4, dtype=torch.float32))
+    assert torch.equal(pg.wait(), torch.arange(4, dtype=torch.float32)) and a.shape[0] == 4
