@@ -138,11 +138,18 @@ def main():
     import helpers
     from jammy_flows_amd import _hip, parallel
 
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one rank per GPU.  (JF_BENCH_BACKEND=gloo lets the multi-process logic be exercised on a box with fewer GPUs than ranks: the ranks
+    # then share devices round-robin, which RCCL refuses; never used for reported numbers.)
+    backend = os.environ.get("JF_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     fx = fixture_io.load(WORKLOAD)
     B = args.batch
