@@ -331,3 +331,57 @@ def test_c_abi_error_codes():
     rc = lib.jf_mlp2_f32(ctypes.c_void_p(x.data_ptr()), 4, ctypes.c_void_p(w.data_ptr()), 200, ctypes.c_void_p(w.data_ptr()),
                          ctypes.c_void_p(w.data_ptr()), 200, None, 8, 4, 200, 8, ctypes.c_void_p(out.data_ptr()), 4, None)
     assert rc == _hip.JF_ERR_UNSUPPORTED
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Shapes and option combinations the golden fixtures do not reach (5..8 Euclidean dimensions = row groups with idle lanes, reduced
+# Householder counts, odd mixture sizes, unregulated weights, ...), against the oracle -- which the fixtures pin to the reference.
+RANDOM_CONFIGS = [
+    ("e5", "gg", {}),
+    ("e6", "ggg", {}),
+    ("e7", "g", {}),
+    ("e8", "gg", {}),
+    ("e5", "gg", {"conditional_input_dim": 3}),
+    ("e2+e5", "g+gg", {}),
+    ("e3+e6", "gg+gg", {"conditional_input_dim": 2}),
+    ("e6", "gg", {"options_overwrite": {"g": {"num_householder_iter": 2, "num_kde": 7, "fit_normalization": 0}}}),
+    ("e5", "gg", {"options_overwrite": {"g": {"regulate_normalization": 0, "num_kde": 3, "inverse_function_type": "isigmoid"}}}),
+    ("e7", "gg", {"options_overwrite": {"g": {"softplus_for_width": 1, "width_smooth_saturation": 0, "clamp_widths": 1, "upper_bound_for_widths": 5}}}),
+    ("e5", "gg", {"options_overwrite": {"g": {"nonlinear_stretch_type": "rq_splines", "num_kde": 6}}}),
+    ("e8", "g", {"conditional_input_dim": 4, "options_overwrite": {"g": {"nonlinear_stretch_type": "rq_splines", "num_kde": 4}}}),
+    ("e4+s1+i1", "gg+o+r", {"conditional_input_dim": 2}),
+    ("s2+e5", "f+gg", {}),
+]
+
+
+@pytest.mark.parametrize("cfg", RANDOM_CONFIGS, ids=lambda c: "%s:%s:%s" % (c[0], c[1], "".join(ch for ch in str(sorted(c[2])) if ch.isalnum())[:24]))
+def test_random_configurations_vs_oracle_float64(cfg):
+    import jammy_flows_amd
+    from oracle import OraclePdf
+    pdf_defs, flow_defs, kw = cfg
+    torch.manual_seed(1234)
+    pdf = jammy_flows_amd.pdf(pdf_defs, flow_defs, **kw).double()
+    with torch.no_grad():                                # un-damp the amortisation MLPs so that parameter blocks really vary per row
+        for m in pdf.mlp_predictors:
+            if m is not None:
+                for name, p in m.named_parameters():
+                    if not name.startswith(str(len(m) - 1)):
+                        p.mul_(300.0)
+    sd = {k: v.detach().cpu().numpy() for k, v in pdf.state_dict().items()}
+    oracle = OraclePdf(pdf_defs, flow_defs, state_dict=sd, **kw)
+    pdf = pdf.cuda()
+    pdf.check_status = False
+    n = 257
+    g = torch.Generator(device="cpu").manual_seed(7)
+    cond = torch.randn(n, kw["conditional_input_dim"], generator=g, dtype=torch.float64) if "conditional_input_dim" in kw else None
+    z = torch.randn(n, pdf.total_base_dim, generator=g, dtype=torch.float64)
+    # sampling direction from injected base points, then the log-prob direction on the samples
+    xs, _, lps, lpb = pdf._obtain_sample(conditional_input=None if cond is None else cond.cuda(), predefined_target_input=z.cuda())
+    ox, olp, olpb = oracle.sample_from_base(z.numpy(), None if cond is None else cond.numpy())[:3]
+    assert max_rel(xs, ox) < 1e-6
+    assert max_rel(lps, olp) < 1e-6
+    x = torch.from_numpy(np.asarray(ox))
+    lp, lpb2, base = pdf(x.cuda(), conditional_input=None if cond is None else cond.cuda())
+    o_lp, o_lpb, o_base = oracle.forward(x.numpy(), None if cond is None else cond.numpy())[:3]
+    assert max_rel(lp, o_lp) < 1e-7
+    assert max_rel(base, o_base) < 1e-6
