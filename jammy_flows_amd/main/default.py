@@ -29,7 +29,7 @@ class HipLinearStack(nn.Sequential):
         _hip.require_device(x)
         mods = list(self)
         if (len(mods) == 3 and isinstance(mods[1], nn.Tanh) and mods[0].in_features <= _hip.MLP2_MAX_IN
-                and mods[0].out_features <= _hip.MLP2_MAX_HIDDEN):
+                and mods[0].out_features <= _hip.MLP2_MAX_HIDDEN and mods[0].out_features % 4 == 0):
             # Linear-tanh-Linear (the reference's default "128"): one fused launch, hidden activations never leave LDS
             ps = [mods[0].weight, mods[0].bias, mods[2].weight, mods[2].bias]
             if ps[0].dtype != x.dtype:

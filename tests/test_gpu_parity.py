@@ -351,6 +351,9 @@ RANDOM_CONFIGS = [
     ("e8", "g", {"conditional_input_dim": 4, "options_overwrite": {"g": {"nonlinear_stretch_type": "rq_splines", "num_kde": 4}}}),
     ("e4+s1+i1", "gg+o+r", {"conditional_input_dim": 2}),
     ("s2+e5", "f+gg", {}),
+    ("e3+e4", "gg+gg", {"amortization_mlp_dims": "30"}),                       # hidden width not a multiple of 4: per-layer dense kernels
+    ("e2+e4", "g+gg", {"amortization_mlp_dims": "64-32"}),                     # two hidden layers
+    ("e4+e4", "gg+gg", {"conditional_input_dim": 40, "amortization_mlp_dims": "160"}),   # wider than the fused kernel's limits
 ]
 
 
