@@ -115,7 +115,7 @@ int jf_linear_f64(const double* in, int64_t in_stride, const double* W, int64_t 
                   int32_t K, int32_t N, int32_t act, double* out, int64_t out_stride, void* stream);
 
 /* The default amortisation MLP with ONE hidden layer in a single launch: out = tanh(in @ W1^T + b1) @ W2^T + b2
- * (nn.Sequential(Linear, Tanh, Linear), main/default.py:656-670); hidden activations stay in LDS.  K1 <= 32, H <= 128,
+ * (nn.Sequential(Linear, Tanh, Linear), main/default.py:656-670); hidden activations stay in registers (never in HBM).  K1 <= 32, H <= 128,
  * otherwise JF_ERR_UNSUPPORTED (use jf_linear per layer).  W1 (H, K1), W2 (N, H) row-major. */
 int jf_mlp2_f32(const float* in, int64_t in_stride, const float* W1, int64_t w1_stride, const float* b1, const float* W2, int64_t w2_stride,
                 const float* b2, int64_t B, int32_t K1, int32_t H, int32_t N, float* out, int64_t out_stride, void* stream);

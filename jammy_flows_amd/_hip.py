@@ -411,7 +411,7 @@ MLP2_MAX_IN, MLP2_MAX_HIDDEN = 32, 128
 
 
 def mlp2(inp, w1, b1, w2, b2, out=None):
-    """tanh(inp @ w1^T + b1) @ w2^T + b2 in one launch (hidden activations stay in LDS)."""
+    """tanh(inp @ w1^T + b1) @ w2^T + b2 in one launch (the hidden activations stay in registers, nothing but the result reaches HBM)."""
     require_device(inp, w1, b1, w2, b2, out)
     inp, w1, w2 = _rowmajor(inp), _rowmajor(w1), _rowmajor(w2)
     B, K1 = inp.shape

@@ -5,9 +5,11 @@
 // Shapes on the hot path: M = batch (2^20), K <= 128 (inputs / hidden / rank), N = 8 ... 1224 (parameter block width).
 //
 // f32: v_mfma_f32_32x32x2_f32 (exact f32, 64 FLOP/clk/SIMD); f64: v_mfma_f64_16x16x4_f64.
-// Workgroup = 4 waves stacked along M: tile 128 (rows) x 64 (cols); each wave owns 32 x 64.  K is walked in chunks of 32
-// staged through LDS with rows padded by one element (conflict-free ds_read_b32 for the A[i][k] / B[k][j] fragment reads).
-// The epilogue adds the bias, applies tanh and writes 128-byte row segments per half wave.
+//
+//   mlp2_kernel    Linear -> tanh -> Linear in one launch, and (without its first layer) every single dense layer with K <= 128:
+//                  the operand that is reused for all output tiles lives in registers, W streams through LDS (see below).
+//   linear_kernel  generic fall-back (K > 128 or unaligned weight rows): workgroup = 4 waves stacked along M, tile 128 x 64, K walked in
+//                  chunks of 32 staged through LDS (rows padded by one element: conflict-free ds_read_b32 fragment reads).
 #include "jf_common.h"
 #include "jf_math.h"
 #include "jf_mfma.h"

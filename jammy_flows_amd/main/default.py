@@ -30,7 +30,7 @@ class HipLinearStack(nn.Sequential):
         mods = list(self)
         if (len(mods) == 3 and isinstance(mods[1], nn.Tanh) and mods[0].in_features <= _hip.MLP2_MAX_IN
                 and mods[0].out_features <= _hip.MLP2_MAX_HIDDEN and mods[0].out_features % 4 == 0):
-            # Linear-tanh-Linear (the reference's default "128"): one fused launch, hidden activations never leave LDS
+            # Linear-tanh-Linear (the reference's default "128"): one fused launch, the hidden activations never leave the registers
             ps = [mods[0].weight, mods[0].bias, mods[2].weight, mods[2].bias]
             if ps[0].dtype != x.dtype:
                 ps = [p.to(x.dtype) for p in ps]
