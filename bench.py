@@ -84,17 +84,40 @@ def cpu_baseline(budget_s=20.0):
 
 
 # ---------------------------------------------------------------------------------------------- HBM traffic from the committed PMC passes
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r01_d_traffic.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r01_f_traffic.json")
 TRAFFIC_KEYS = {("jf_cond_gf_chain_inv_f32", "K7_H128_N548_D4"): "jf::cond_gf_chain_kernel<float, 8>",
-                ("jf_mlp2_f32", "K7_H128_N548"): "jf::mlp2_kernel<float, 4, 2, true>",
-                ("jf_mlp2_f32", "K4_H128_N10"): "jf::mlp2_kernel<float, 4, 1, true>",
+                ("jf_mlp2_f32", "K7_H128_N548"): "jf::mlp2_kernel<float, 4, 2, true, true>",
+                ("jf_mlp2_f32", "K4_H128_N10"): "jf::mlp2_kernel<float, 4, 1, true, true>",
                 ("jf_gf_chain_inv_f32", "per-sample"): "jf::gf_chain_kernel<float, 4, false, false>",
                 ("jf_gf_chain_inv_f32", "bcast"): "jf::gf_chain_kernel<float, 4, true, false>"}
 
 
+SQ_FILE = os.path.join(ROOT, "profiles", "r01_f_sq_counters.json")
+
+
+def pmc_issue(kname, ktag, B):
+    """share of the kernel's cycles in which the matrix pipe / the VALU were busy, from the committed SQ counter pass of this command
+    (SQ_VALU_MFMA_BUSY_CYCLES, SQ_ACTIVE_INST_VALU [quad-cycles], GRBM_GUI_ACTIVE; 1024 SIMDs, 8 XCDs).  On CDNA4 f32 MFMA and VALU work
+    do not co-issue on a SIMD (scripts/probe/coexec.hip), so their sum is the fraction of the kernel's issue floor that is reached."""
+    prefix = TRAFFIC_KEYS.get((kname, ktag))
+    try:
+        table = json.load(open(SQ_FILE))
+    except OSError:
+        return None
+    if prefix is None or B != BATCH:
+        return None
+    for key, v in table.items():
+        if key.startswith(prefix) and v.get("GRBM_GUI_ACTIVE"):
+            cyc = v["GRBM_GUI_ACTIVE"] / 8.0
+            m = v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / 1024.0 / cyc
+            a = v.get("SQ_ACTIVE_INST_VALU", 0.0) * 4.0 / 1024.0 / cyc
+            return {"mfma_busy_frac": m, "valu_busy_frac": a, "issue_frac": m + a, "source": "profiles/r01_f_sq_counters.json"}
+    return None
+
+
 def pmc_traffic(kname, ktag, B):
     """HBM bytes per launch of one kernel from the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command
-    (profiles/r01_d_*; PMC collection needs its own rocprofv3 runs, so the figure is read from the committed summary, not measured live).
+    (profiles/r01_f_*; PMC collection needs its own rocprofv3 runs, so the figure is read from the committed summary, not measured live).
     Corrections (MI355X_MICROARCH.md, HBM section): FETCH_SIZE x 2 on gfx950 for wide coalesced reads; WRITE_SIZE x 0.965, calibrated on
     scripts/probe/wstore for the 16-byte lane-per-row tile stores these kernels use.  None when the profile was taken at another batch."""
     try:
@@ -108,7 +131,7 @@ def pmc_traffic(kname, ktag, B):
         if key.startswith(prefix) and v.get("FETCH_SIZE_raw_KB") is not None and v.get("WRITE_SIZE_raw_KB") is not None:
             return {"hbm_bytes_per_launch": v["FETCH_SIZE_raw_KB"] * 1024 * 2 + v["WRITE_SIZE_raw_KB"] * 1024 * 0.965,
                     "read_bytes": v["FETCH_SIZE_raw_KB"] * 1024 * 2, "write_bytes": v["WRITE_SIZE_raw_KB"] * 1024 * 0.965,
-                    "source": "profiles/r01_d_traffic.json (rocprofv3 --pmc, separate passes)"}
+                    "source": "profiles/r01_f_traffic.json (rocprofv3 --pmc, separate passes)"}
     return None
 
 
@@ -120,7 +143,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=BATCH, help="rows per GPU (default 2^20 = the BASELINE configuration)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--fuse", action="store_true", help="run the conditional e-block as ONE launch (jf_cond_gf_chain_inv, parameter block on chip)")
+    ap.add_argument("--no-fuse", action="store_true", help="time the two-launch path (jf_mlp2 + jf_gf_chain_inv) instead of the fused conditional block")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -156,9 +179,10 @@ def main():
     x64 = make_inputs(B, 3 + rank)
     results = {}
     kernel_table = None
+    two_launch = None
     for dtype in (torch.float32, torch.float64):
         pdf = helpers.build_product(fx, dtype, dev)
-        pdf.fuse_conditional_blocks = bool(args.fuse)
+        pdf.fuse_conditional_blocks = not args.no_fuse
         x = torch.from_numpy(x64).to(device=dev, dtype=dtype)
         # N > 1: the per-row log-probs of every step are all-gathered (RCCL), asynchronously, while the next step computes
         gather = parallel.PipelinedGather(B, dtype, dev) if world > 1 else None
@@ -205,6 +229,22 @@ def main():
         results[dtype] = dict(dt=dt, evals_per_s=world * B * args.steps / dt, ms_per_step=1e3 * dt / args.steps, err=err)
         if timer is not None:
             kernel_table = timer.summary()
+            if rank == 0 and pdf.fuse_conditional_blocks:
+                # for reference, outside the timed region: the same steps with the conditional block as two launches (jf_mlp2 + jf_gf_chain_inv),
+                # whose kernels have clean single-roof accountings (MFMA for the MLP, HBM for the g-chain reading the materialised block)
+                pdf.fuse_conditional_blocks = False
+                for _ in range(2):
+                    pdf(x)
+                torch.cuda.synchronize()
+                t2 = _hip.KernelTimer()
+                tt0 = time.perf_counter()
+                with t2:
+                    for _ in range(args.steps):
+                        pdf(x)
+                pdf.flush_status()
+                torch.cuda.synchronize()
+                two_launch = {"dt": time.perf_counter() - tt0, "table": t2.summary()}
+                pdf.fuse_conditional_blocks = True
         del pdf, x
 
     if world > 1:
@@ -254,13 +294,14 @@ def main():
             roofline["fused"] = True
             roofline["note"] = ("amortisation MLP + its 4 g layers in one launch; the parameter block stays in LDS.  f32 MFMA and VALU work "
                                 "do not co-issue on a CDNA4 SIMD (scripts/probe/coexec.hip), so this kernel's floor is MFMA time + VALU time")
+        roofline["issue"] = pmc_issue(kname, ktag, B)
         tr = pmc_traffic(kname, ktag, B)
         roofline["traffic"] = tr["hbm_bytes_per_launch"] if tr else None
         roofline["traffic_detail"] = tr
         roofline.update({"mean_launch_ms": kstat["mean_ms"], "algorithmic_bytes_per_launch": bytes_per_row * B,
                          "all_kernels_ms_per_step": {"%s[%s]" % k: round(v["total_ms"] / args.steps, 4) for k, v in sorted(kernel_table.items())}})
         # the HBM-bound flow kernel the north star names (per-sample parameter blocks), reported alongside
-        gfk = kernel_table.get(("jf_gf_chain_inv_f32", "per-sample"))      # absent with --fuse
+        gfk = kernel_table.get(("jf_gf_chain_inv_f32", "per-sample"))      # only with --no-fuse
         if gfk is not None:
             g = 4 * 558 * B / (gfk["mean_ms"] * 1e-3) / 1e9
             roofline["gf_chain_per_sample"] = {"bound": "hbm", "achieved": g, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": g / HBM_PEAK_GBS,
@@ -278,6 +319,22 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu,
         }
+        if two_launch is not None:
+            tb = two_launch["table"]
+            ml = tb.get(("jf_mlp2_f32", "K7_H128_N548"))
+            gf = tb.get(("jf_gf_chain_inv_f32", "per-sample"))
+            blk = {"ms_per_step": 1e3 * two_launch["dt"] / args.steps, "value": B * args.steps / two_launch["dt"],
+                   "note": "same steps with the conditional block as jf_mlp2 + jf_gf_chain_inv (measured after the timed region, this rank only)"}
+            if ml is not None:
+                tf = 2 * (7 * 128 + 128 * 548) * B / (ml["mean_ms"] * 1e-3) / 1e12
+                blk["mlp2"] = {"bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TFLOPS,
+                               "mean_launch_ms": ml["mean_ms"], "traffic": (pmc_traffic("jf_mlp2_f32", "K7_H128_N548", B) or {}).get("hbm_bytes_per_launch")}
+            if gf is not None:
+                gb = 4 * 558 * B / (gf["mean_ms"] * 1e-3) / 1e9
+                blk["gf_chain_per_sample"] = {"bound": "hbm", "achieved": gb, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gb / HBM_PEAK_GBS,
+                                              "mean_launch_ms": gf["mean_ms"], "algorithmic_bytes_per_launch": 4 * 558 * B,
+                                              "traffic": (pmc_traffic("jf_gf_chain_inv_f32", "per-sample", B) or {}).get("hbm_bytes_per_launch")}
+            line["two_launch_path"] = blk
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

@@ -117,9 +117,9 @@ class pdf(nn.Module):
         # exceptions / warnings.  True: sampling checks after every call; log-prob calls read the words back asynchronously and raise at
         # the next call or in flush_status().  "immediate": blocking check after every call.  False: never.
         self.check_status = True
-        # conditional e-blocks (Linear-tanh-Linear MLP + g layers, D in {3,4}) as ONE launch with the parameter block kept on chip
-        # (jf_cond_gf_chain_inv).  Off by default: measured +3 % on the C3 step only (f32 MFMA and VALU do not co-issue on CDNA4)
-        self.fuse_conditional_blocks = False
+        # conditional e-blocks (Linear-tanh-Linear MLP + g layers, D in {3,4}, float32) as ONE launch with the parameter block kept on chip
+        # (jf_cond_gf_chain_inv): +9 % on the C3 step against jf_mlp2 + jf_gf_chain_inv.  False selects the two-launch path.
+        self.fuse_conditional_blocks = True
 
         self._read_model_definition(pdf_defs, flow_defs, options_overwrite, conditional_input_dim, amortization_mlp_dims,
                                     amortization_mlp_ranks)
