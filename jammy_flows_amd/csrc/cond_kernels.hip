@@ -55,7 +55,8 @@ __global__ void __launch_bounds__(256, 2) cond_gf_chain_kernel(const CondArgs<T>
     constexpr int MT = 16, KS = 4, NREG = 4;
     constexpr int LDW = CgCfg<T>::LDW;
     constexpr int HP = JH * MT;
-    constexpr int WPT = (CG_CHUNK * CG_HMAX / VN + 255) / 256;     // 16-byte pieces of a W2 chunk per thread (f32: 6, f64: 12)
+    constexpr int WPT = CG_CHUNK * CG_HMAX / VN / 256;             // 16-byte pieces of a W2 chunk per thread (f32: 6, f64: 12)
+    static_assert(CG_CHUNK * CG_HMAX / VN % 256 == 0, "chunk must be a whole number of thread passes");
     constexpr int G = 4;                                           // lanes per row in the flow phase (D = 3, 4)
     extern __shared__ __align__(16) unsigned char smem_raw[];
     T* Ws = reinterpret_cast<T*>(smem_raw);                        // [CG_CHUNK][LDW]  W2 chunk
@@ -137,16 +138,30 @@ __global__ void __launch_bounds__(256, 2) cond_gf_chain_kernel(const CondArgs<T>
     // ---- W2 chunk streaming: (layer, chunk) pairs in consumption order
     V wreg[WPT];
     T breg = T(0);
-    auto fetch = [&](int col0) {                                   // straight-line: clamped addresses + selects, loads issued back to back
+    // per-thread constants of the chunk copy: piece u of thread tid is row u*RPP + r_t, 16-byte column c_t of the chunk, so the global address
+    // is (uniform chunk/pass base) + (one 32-bit lane offset) and the LDS address a constant -- no address arithmetic per piece
+    constexpr int PPR = CG_HMAX / VN;                             // 16-byte pieces per W2 row
+    constexpr int RPP = 256 / PPR;                                // rows covered by one pass of the 256 threads
+    const int r_t = tid / PPR, c_t = (tid % PPR) * VN;
+    const unsigned voff = (unsigned)((r_t * a.w2s + c_t) * (int64_t)sizeof(T));
+    T* const lbase = Ws + r_t * LDW + c_t;
+    const bool h_full = a.H == CG_HMAX;                            // block-uniform
+    auto fetch = [&](int col0) {                                   // straight-line, loads issued back to back
+        if (h_full && col0 + CG_CHUNK <= a.N) {                    // block-uniform fast path: whole chunk inside W2, no clamps, no selects
 #pragma unroll
-        for (int u = 0; u < WPT; ++u) {
-            const int idx = u * 256 + tid;
-            const int r = idx / (CG_HMAX / VN), c = (idx % (CG_HMAX / VN)) * VN;
-            const int gc = col0 + (r < CG_CHUNK ? r : CG_CHUNK - 1);
-            const bool ok = c < a.H;
-            const V v = *reinterpret_cast<const V*>(a.W2 + (int64_t)(gc < a.N ? gc : a.N - 1) * a.w2s + (c < a.H ? c : 0));
-            wreg[u].x = ok ? v.x : T(0); wreg[u].y = ok ? v.y : T(0);
-            if constexpr (VN == 4) { wreg[u].z = ok ? v.z : T(0); wreg[u].w = ok ? v.w : T(0); }
+            for (int u = 0; u < WPT; ++u) {
+                const char* base = reinterpret_cast<const char*>(a.W2 + (int64_t)(col0 + u * RPP) * a.w2s);    // uniform
+                wreg[u] = *reinterpret_cast<const V*>(base + voff);
+            }
+        } else {                                                   // clamped addresses + selects (rows past N replicate row N-1)
+#pragma unroll
+            for (int u = 0; u < WPT; ++u) {
+                const int gc = col0 + u * RPP + r_t;
+                const bool ok = c_t < a.H;
+                const V v = *reinterpret_cast<const V*>(a.W2 + (int64_t)(gc < a.N ? gc : a.N - 1) * a.w2s + (ok ? c_t : 0));
+                wreg[u].x = ok ? v.x : T(0); wreg[u].y = ok ? v.y : T(0);
+                if constexpr (VN == 4) { wreg[u].z = ok ? v.z : T(0); wreg[u].w = ok ? v.w : T(0); }
+            }
         }
         const int bc = col0 + (tid < CG_CHUNK ? tid : 0);
         breg = (a.b2 != nullptr) ? a.b2[bc < a.N ? bc : a.N - 1] : T(0);
@@ -154,13 +169,9 @@ __global__ void __launch_bounds__(256, 2) cond_gf_chain_kernel(const CondArgs<T>
     auto put = [&]() {
 #pragma unroll
         for (int u = 0; u < WPT; ++u) {
-            const int idx = u * 256 + tid;
-            const int r = idx / (CG_HMAX / VN), c = (idx % (CG_HMAX / VN)) * VN;
-            if (r < CG_CHUNK) {
-                T* dd = Ws + r * LDW + c;
-                if constexpr (VN == 4) { *reinterpret_cast<V*>(dd) = wreg[u]; }
-                else { dd[0] = wreg[u].x; dd[1] = wreg[u].y; }
-            }
+            T* dd = lbase + u * RPP * LDW;
+            if constexpr (VN == 4) { *reinterpret_cast<V*>(dd) = wreg[u]; }
+            else { dd[0] = wreg[u].x; dd[1] = wreg[u].y; }
         }
         if (tid < CG_CHUNK) Bs[tid] = breg;
     };

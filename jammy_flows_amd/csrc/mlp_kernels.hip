@@ -203,25 +203,36 @@ __global__ void __launch_bounds__(256, 3) mlp2_kernel(const T* __restrict__ in, 
         if (tid < HP) b1s[tid] = tid < H ? b1[tid < H ? tid : 0] : T(0);
     }
     // ---- phase 2: out^T = W2 h^T + b2, W2 streamed in BN2-column tiles
-    auto load_tile = [&](int t) {                            // straight-line: clamped addresses + selects, loads issued back to back
+    // per-thread constants of the tile copy: piece u of thread tid is row u*RPP + r_t, 16-byte column c_t of the tile, so the global address is
+    // (uniform tile/pass base) + (one 32-bit lane offset) and the LDS address a constant -- no address arithmetic per piece
+    constexpr int PPR = HMAX / VN, RPP = 256 / PPR;
+    const int r_t = tid / PPR, c_t = (tid % PPR) * VN;
+    const unsigned voff = (unsigned)((r_t * w2_stride + c_t) * (int64_t)sizeof(T));
+    T* const lbase = Ws + r_t * LDW + c_t;
+    const bool h_full = H == HMAX;                           // block-uniform
+    auto load_tile = [&](int t) {                            // straight-line, loads issued back to back
         V wreg[WPT];
         const int bc = t * BN2 + (tid < BN2 ? tid : 0);
         const T bval = (b2 != nullptr) ? b2[bc < N ? bc : N - 1] : T(0);
+        if (h_full && (t + 1) * BN2 <= N) {                  // block-uniform fast path: whole tile inside W2, no clamps, no selects
 #pragma unroll
-        for (int u = 0; u < WPT; ++u) {
-            const int idx = u * 256 + tid;
-            const int r = idx / (HMAX / VN), c = (idx % (HMAX / VN)) * VN;
-            const int gc = t * BN2 + r;
-            const bool ok = c < H;
-            const V v = *reinterpret_cast<const V*>(W2 + (int64_t)(gc < N ? gc : N - 1) * w2_stride + (c < H ? c : 0));   // columns past N replicate N-1
-            wreg[u].x = ok ? v.x : T(0); wreg[u].y = ok ? v.y : T(0);
-            if constexpr (VN == 4) { wreg[u].z = ok ? v.z : T(0); wreg[u].w = ok ? v.w : T(0); }
+            for (int u = 0; u < WPT; ++u) {
+                const char* base = reinterpret_cast<const char*>(W2 + (int64_t)(t * BN2 + u * RPP) * w2_stride);    // uniform
+                wreg[u] = *reinterpret_cast<const V*>(base + voff);
+            }
+        } else {                                             // clamped addresses + selects (columns past N replicate column N-1)
+#pragma unroll
+            for (int u = 0; u < WPT; ++u) {
+                const int gc = t * BN2 + u * RPP + r_t;
+                const bool ok = c_t < H;
+                const V v = *reinterpret_cast<const V*>(W2 + (int64_t)(gc < N ? gc : N - 1) * w2_stride + (ok ? c_t : 0));
+                wreg[u].x = ok ? v.x : T(0); wreg[u].y = ok ? v.y : T(0);
+                if constexpr (VN == 4) { wreg[u].z = ok ? v.z : T(0); wreg[u].w = ok ? v.w : T(0); }
+            }
         }
 #pragma unroll
         for (int u = 0; u < WPT; ++u) {
-            const int idx = u * 256 + tid;
-            const int r = idx / (HMAX / VN), c = (idx % (HMAX / VN)) * VN;
-            T* d = Ws + r * LDW + c;
+            T* d = lbase + u * RPP * LDW;
             if constexpr (VN == 4) { *reinterpret_cast<V*>(d) = wreg[u]; }
             else { d[0] = wreg[u].x; d[1] = wreg[u].y; }
         }
