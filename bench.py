@@ -84,7 +84,7 @@ def cpu_baseline(budget_s=20.0):
 
 
 # ---------------------------------------------------------------------------------------------- HBM traffic from the committed PMC passes
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r01_f_traffic.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r01_g_traffic.json")
 TRAFFIC_KEYS = {("jf_cond_gf_chain_inv_f32", "K7_H128_N548_D4"): "jf::cond_gf_chain_kernel<float, 8>",
                 ("jf_mlp2_f32", "K7_H128_N548"): "jf::mlp2_kernel<float, 4, 2, true, true>",
                 ("jf_mlp2_f32", "K4_H128_N10"): "jf::mlp2_kernel<float, 4, 1, true, true>",
@@ -92,7 +92,7 @@ TRAFFIC_KEYS = {("jf_cond_gf_chain_inv_f32", "K7_H128_N548_D4"): "jf::cond_gf_ch
                 ("jf_gf_chain_inv_f32", "bcast"): "jf::gf_chain_kernel<float, 4, true, false>"}
 
 
-SQ_FILE = os.path.join(ROOT, "profiles", "r01_f_sq_counters.json")
+SQ_FILE = os.path.join(ROOT, "profiles", "r01_g_sq_counters.json")
 
 
 def pmc_issue(kname, ktag, B):
@@ -111,13 +111,13 @@ def pmc_issue(kname, ktag, B):
             cyc = v["GRBM_GUI_ACTIVE"] / 8.0
             m = v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / 1024.0 / cyc
             a = v.get("SQ_ACTIVE_INST_VALU", 0.0) * 4.0 / 1024.0 / cyc
-            return {"mfma_busy_frac": m, "valu_busy_frac": a, "issue_frac": m + a, "source": "profiles/r01_f_sq_counters.json"}
+            return {"mfma_busy_frac": m, "valu_busy_frac": a, "issue_frac": m + a, "source": "profiles/r01_g_sq_counters.json"}
     return None
 
 
 def pmc_traffic(kname, ktag, B):
     """HBM bytes per launch of one kernel from the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command
-    (profiles/r01_f_*; PMC collection needs its own rocprofv3 runs, so the figure is read from the committed summary, not measured live).
+    (profiles/r01_g_*; PMC collection needs its own rocprofv3 runs, so the figure is read from the committed summary, not measured live).
     Corrections (MI355X_MICROARCH.md, HBM section): FETCH_SIZE x 2 on gfx950 for wide coalesced reads; WRITE_SIZE x 0.965, calibrated on
     scripts/probe/wstore for the 16-byte lane-per-row tile stores these kernels use.  None when the profile was taken at another batch."""
     try:
@@ -131,7 +131,7 @@ def pmc_traffic(kname, ktag, B):
         if key.startswith(prefix) and v.get("FETCH_SIZE_raw_KB") is not None and v.get("WRITE_SIZE_raw_KB") is not None:
             return {"hbm_bytes_per_launch": v["FETCH_SIZE_raw_KB"] * 1024 * 2 + v["WRITE_SIZE_raw_KB"] * 1024 * 0.965,
                     "read_bytes": v["FETCH_SIZE_raw_KB"] * 1024 * 2, "write_bytes": v["WRITE_SIZE_raw_KB"] * 1024 * 0.965,
-                    "source": "profiles/r01_f_traffic.json (rocprofv3 --pmc, separate passes)"}
+                    "source": "profiles/r01_g_traffic.json (rocprofv3 --pmc, separate passes)"}
     return None
 
 
