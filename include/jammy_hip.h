@@ -103,6 +103,21 @@ int jf_cond_gf_chain_inv_f64(const double* in, int64_t in_stride, const double* 
                              int64_t x_out_stride, double* log_det_out, const double* base_logp_in, double* base_logp_out, int32_t* status,
                              void* stream);
 
+/* The same block with the 128 -> N product on split-bf16 MFMA (every f32 operand = three bf16 pieces, the six products whose piece
+ * indices sum to <= 2, f32 accumulation: products exact, dropped terms <= 3 * 2^-24 |w||h|) and the parameter block kept in the register
+ * file (W2's rows are permuted so that the MFMA result registers of lane (row, coordinate) are that lane's parameters).  float32 only;
+ * D in {3, 4}; layers at the reference's default options (num_kde 10, smooth-saturation widths without clamping, fitted + regulated
+ * normalisation, hh_iter <= 4, classic stretch); K1 <= 28, H <= 128.  jf_cond_gf_packed_bytes returns the size of the packed image or
+ * JF_ERR_UNSUPPORTED; jf_cond_gf_pack_f32 builds it from W2 (N, H) / b2 (N) -- redo whenever the weights change (one small launch);
+ * jf_cond_gf_chain_inv_split_f32 = jf_cond_gf_chain_inv_f32 with (W2, b2) replaced by the packed image. */
+int64_t jf_cond_gf_packed_bytes(int32_t D, int32_t n_layers, const jf_gf_layer* layers);
+int jf_cond_gf_pack_f32(const float* W2, int64_t w2_stride, const float* b2, int32_t H, int32_t D, int32_t n_layers, const jf_gf_layer* layers,
+                        void* packed, void* stream);
+int jf_cond_gf_chain_inv_split_f32(const float* in, int64_t in_stride, const float* W1, int64_t w1_stride, const float* b1, const void* packed,
+                                   int32_t K1, int32_t H, const float* x, int64_t x_stride, const float* log_det_in, int64_t B, int32_t D,
+                                   int32_t n_layers, const jf_gf_layer* layers, float* x_out, int64_t x_out_stride, float* log_det_out,
+                                   const float* base_logp_in, float* base_logp_out, int32_t* status, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * Dense layer of the parameter-emitting MLPs: out = act(in @ W^T + bias)   (MFMA)
  * replaces torch.nn.Linear + tanh of the default nn.Sequential (main/default.py:656-670) and the U / V^T products of

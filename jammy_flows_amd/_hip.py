@@ -99,6 +99,13 @@ _SIGNATURES = {
     "jf_sphere_to_embedding": [_P, _I64, _P, _I64, _I32, _P, _I64, _P, _P],
     "jf_sphere_from_embedding": [_P, _I64, _P, _I64, _I32, _P, _I64, _P, _P],
 }
+# entry points that exist for one precision only: full symbol name -> (argtypes, restype)
+_SIGNATURES_SINGLE = {
+    "jf_cond_gf_packed_bytes": ([_I32, _I32, ctypes.POINTER(jf_gf_layer)], ctypes.c_int64),
+    "jf_cond_gf_pack_f32": ([_P, _I64, _P, _I32, _I32, _I32, ctypes.POINTER(jf_gf_layer), _P, _P], ctypes.c_int),
+    "jf_cond_gf_chain_inv_split_f32": ([_P, _I64, _P, _I64, _P, _P, _I32, _I32, _P, _I64, _P, _I64, _I32, _I32, ctypes.POINTER(jf_gf_layer), _P, _I64,
+                                        _P, _P, _P, _P, _P], ctypes.c_int),
+}
 for _fam, _cls in MCHAIN_LAYER_TYPES.items():
     for _d in ("inv", "fwd"):
         _SIGNATURES["jf_%s_chain_%s" % (_fam, _d)] = [_P, _I64, _P, _P, _I64, _I32, _I64, _I32, ctypes.POINTER(_cls), _P, _I64, _P, _P, _P, _P,
@@ -110,7 +117,7 @@ def exported_symbols():
     names = ["jf_abi_version"]
     for base in _SIGNATURES:
         names += [base + "_f32", base + "_f64"]
-    return names
+    return names + list(_SIGNATURES_SINGLE)
 
 
 def lib():
@@ -131,6 +138,10 @@ def lib():
             fn = getattr(l, base + suf)
             fn.argtypes = argtypes
             fn.restype = ctypes.c_int
+    for name, (argtypes, restype) in _SIGNATURES_SINGLE.items():
+        fn = getattr(l, name)
+        fn.argtypes = argtypes
+        fn.restype = restype
     _lib = l
     return _lib
 
@@ -310,6 +321,48 @@ def cond_gf_chain_inv(inp, w1, b1, w2, b2, x, log_det, layer_array, n_layers, D,
             (_ptr(inp), inp.stride(0), _ptr(w1), w1.stride(0), _ptr(b1.contiguous()), _ptr(w2), w2.stride(0), _ptr(b2.contiguous()), K1, H,
              _ptr(x), x.stride(0), _ptr(log_det), B, D, n_layers, layer_array, _ptr(x_out), x_out.stride(0), _ptr(ld_out), _ptr(base_logp_in),
              _ptr(blp_out), _ptr(status), _stream()))
+    return (x_out, ld_out, blp_out) if want_base_logp else (x_out, ld_out)
+
+
+def cond_gf_packed_bytes(layer_array, n_layers, D):
+    """size of the packed W2 / b2 image of the split-bf16 fused block, or a negative JF_ERR_* when the chain is not supported by it."""
+    return int(lib().jf_cond_gf_packed_bytes(D, n_layers, layer_array))
+
+
+def cond_gf_pack(w2, b2, layer_array, n_layers, D):
+    """W2 (N, H) / b2 (N,) of the amortisation MLP -> packed image for cond_gf_chain_inv_split (bf16 pieces in MFMA fragment order,
+    rows permuted so that the MFMA result registers are the flow's parameter registers).  Redo whenever the weights change."""
+    require_device(w2, b2)
+    w2 = _rowmajor(w2)
+    if w2.dtype != torch.float32 or b2.dtype != torch.float32:
+        raise TypeError("cond_gf_pack: float32 only")
+    nbytes = cond_gf_packed_bytes(layer_array, n_layers, D)
+    _check(min(nbytes, 0), "jf_cond_gf_packed_bytes")
+    packed = torch.empty((nbytes,), dtype=torch.uint8, device=w2.device)
+    _launch("jf_cond_gf_pack_f32", "", (_ptr(w2), w2.stride(0), _ptr(b2.contiguous()), w2.shape[1], D, n_layers, layer_array, _ptr(packed), _stream()))
+    return packed
+
+
+def cond_gf_chain_inv_split(inp, w1, b1, packed, x, log_det, layer_array, n_layers, D, x_out=None, base_logp_in=None, want_base_logp=False,
+                            status=None):
+    """as cond_gf_chain_inv with the second product on split-bf16 MFMA and the parameter block in registers (float32, default layer options)."""
+    require_device(inp, w1, b1, packed, x, log_det, x_out, base_logp_in, status)
+    inp, w1, x = _rowmajor(inp), _rowmajor(w1), _rowmajor(x)
+    B, K1 = inp.shape
+    H = w1.shape[0]
+    if x.shape[0] != B or x.shape[1] != D or w1.shape[1] != K1 or b1.shape[0] != H:
+        raise ValueError("cond_gf_chain_inv_split: inconsistent shapes")
+    if any(t.dtype != torch.float32 for t in (inp, w1, b1, x)) or packed.dtype != torch.uint8:
+        raise TypeError("cond_gf_chain_inv_split: float32 inputs and a uint8 packed image expected")
+    if log_det is not None:
+        log_det = log_det.contiguous()
+    if x_out is None:
+        x_out = torch.empty((B, D), dtype=x.dtype, device=x.device)
+    ld_out = torch.empty((B,), dtype=x.dtype, device=x.device)
+    blp_out = torch.empty((B,), dtype=x.dtype, device=x.device) if want_base_logp else None
+    _launch("jf_cond_gf_chain_inv_split_f32", "K%d_H%d_L%d_D%d" % (K1, H, n_layers, D),
+            (_ptr(inp), inp.stride(0), _ptr(w1), w1.stride(0), _ptr(b1.contiguous()), _ptr(packed), K1, H, _ptr(x), x.stride(0), _ptr(log_det), B, D,
+             n_layers, layer_array, _ptr(x_out), x_out.stride(0), _ptr(ld_out), _ptr(base_logp_in), _ptr(blp_out), _ptr(status), _stream()))
     return (x_out, ld_out, blp_out) if want_base_logp else (x_out, ld_out)
 
 

@@ -1,0 +1,456 @@
+// Conditional e-block in ONE launch, second generation: split-bf16 matrix arithmetic + register-resident parameters.
+//
+//   jf_cond_gf_pack_f32            W2 / b2 of the amortisation MLP -> the packed image the kernel streams (once per weight version)
+//   jf_cond_gf_chain_inv_split_f32 log-prob direction of a conditional Euclidean block = mlp_predictors[i](...) (main/default.py:656-670,
+//                                  946-962) + the per-block layer loop of all_layer_inverse (main/default.py:998-1031)
+//
+// What changed against cond_kernels.hip (exact-f32 MFMA, parameter tile in LDS), and why:
+//  * f32-input MFMA runs at the VECTOR rate on CDNA4 (64 flop/clk/SIMD) and does not overlap with VALU work, so the 128 -> 548 product
+//    alone cost 0.95 ms per 2^20 rows.  Here every f32 operand is split into three bf16 pieces (8 + 8 + 8 significant bits:
+//    v = hi + mid + lo exactly, each piece rounded to nearest), and the product is evaluated as the six bf16 MFMAs whose piece
+//    indices sum to <= 2, accumulated in f32 (v_mfma_f32_16x16x32_bf16).  Every bf16 x bf16 product is exact in f32; the dropped terms are
+//    <= 3 * 2^-24 |w||h| -- the same size as the rounding of one f32 multiply.  Six passes at 16x the f32 rate = 0.37x the matrix time.
+//    The first layer (K1 <= 28 inputs) stays on exact f32 MFMA: it is 1 % of the flops.
+//  * The MFMA result layout IS the flow layout.  W2's rows are permuted on the host side of the launch (pack kernel) so that the
+//    accumulator registers of lane (row n = lane % 16, coordinate d = lane / 16) hold exactly the parameters that lane needs for its
+//    coordinate: register 4 t + r of column tile t = slot (4 t + r) of { mean_0..9, log_width_0..9, log_weight_0..9, householder_0..3,
+//    offset, pad }.  The parameter block therefore never exists outside the register file: no LDS tile, no 34 ds_read per lane and layer.
+//    The three reductions over a row's coordinates (Householder dots, sum of log-derivatives) run over lanes {l, l^16, l^32, l^48} with
+//    v_permlane16_swap / v_permlane32_swap (2 swaps + 2 adds).
+//  * W2 is streamed as ready-made MFMA A-fragments (1 KiB per fragment, lane-contiguous 16 bytes: conflict-free ds_read_b128, straight
+//    memcpy from the packed image), 3 column tiles x 4 k-steps x 3 pieces = 36 KiB per chunk, shared by the 4 waves of a workgroup.
+//
+// Supported: float32, D in {3, 4}, layers with the reference's default options (K = 10 components, smooth-saturation widths, fitted and
+// regulated weights, <= 4 Householder reflections), H <= 128, K1 <= 28.  Everything else: jf_cond_gf_chain_inv_* / jf_mlp2 + jf_gf_chain_inv.
+#include "jf_gf.h"
+#include "jf_mfma.h"
+
+namespace jf {
+
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+typedef __attribute__((address_space(3))) void* cs_lptr;
+typedef const __attribute__((address_space(1))) void* cs_gptr;
+
+constexpr int CS_K = 10;                           // mixture components (parameter registers are indexed statically)
+constexpr int CS_HH = 4;                           // Householder slots
+constexpr int CS_SLOT_MEAN = 0, CS_SLOT_LW = CS_K, CS_SLOT_LN = 2 * CS_K, CS_SLOT_ROT = 3 * CS_K, CS_SLOT_OFF = 3 * CS_K + CS_HH;
+constexpr int CS_TILES = 9;                        // 16-column MFMA tiles per layer (36 slots x 4 coordinates)
+constexpr int CS_SLOTS = 4 * CS_TILES;
+constexpr int CS_CT = 3;                           // tiles per chunk
+constexpr int CS_CPL = CS_TILES / CS_CT;           // chunks per layer
+constexpr int CS_KSTEPS = 4;                       // 128 hidden units = 4 x 32
+constexpr int CS_NP = 3;                           // bf16 pieces per f32 operand
+constexpr int CS_FRAG = 1024;                      // bytes of one A fragment (64 lanes x 8 bf16)
+constexpr int CS_W_BYTES = CS_CT * CS_KSTEPS * CS_NP * CS_FRAG;       // 36864
+constexpr int CS_B_BYTES = CS_CT * 16 * 4;                            // 192: the chunk's bias, permuted column order
+constexpr int CS_CHUNK_BYTES = CS_W_BYTES + CS_B_BYTES;               // 37056 (16-byte multiple)
+constexpr int CS_ROWS = 64;                        // rows per workgroup (4 waves x 16)
+constexpr int CS_HMAX = 128, CS_K1MAX = 28;
+
+struct CsLayer { int hh, model_offset, inv_type; float wmin, inv_wmax, nmin, nmax; };
+
+// ---------------------------------------------------------------------------------------------------------- packing
+struct CsPackLayer { int col0, off_rot, off_mean, off_lw, off_ln, hh, model_offset; };
+struct CsPackArgs {
+    const float* W2; int64_t w2s; const float* b2;
+    int H, D, n_layers;
+    CsPackLayer L[JF_MAX_CHAIN];
+    unsigned char* out;
+};
+
+// original column (inside the layer's row) of parameter slot `slot` for coordinate d, or -1
+__device__ __forceinline__ int cs_slot_column(const CsPackLayer& o, int D, int slot, int d) {
+    if (d >= D) return -1;
+    if (slot < CS_SLOT_LW) return o.off_mean + slot * D + d;
+    if (slot < CS_SLOT_LN) return o.off_lw + (slot - CS_SLOT_LW) * D + d;
+    if (slot < CS_SLOT_ROT) return o.off_ln + (slot - CS_SLOT_LN) * D + d;
+    if (slot < CS_SLOT_OFF) return (slot - CS_SLOT_ROT) < o.hh ? o.off_rot + (slot - CS_SLOT_ROT) * D + d : -1;
+    if (slot == CS_SLOT_OFF) return o.model_offset ? d : -1;
+    return -1;
+}
+
+__device__ __forceinline__ void cs_split(float v, __bf16& hi, __bf16& mid, __bf16& lo) {
+    hi = (__bf16)v;
+    const float r1 = v - (float)hi;                // exact
+    mid = (__bf16)r1;
+    lo = (__bf16)(r1 - (float)mid);                // exact difference, rounded once
+}
+
+// one thread per (chunk, tile, k-step, lane): writes the three pieces' fragments (16 bytes each); the first 48 threads of a chunk's
+// first k-step also write the bias
+__global__ void __launch_bounds__(256) cs_pack_kernel(const CsPackArgs a) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int lane = idx & 63;
+    int rest = idx >> 6;
+    const int s = rest % CS_KSTEPS; rest /= CS_KSTEPS;
+    const int tc = rest % CS_CT; rest /= CS_CT;
+    const int chunk = rest;                                         // consumption order: last layer first
+    if (chunk >= a.n_layers * CS_CPL) return;
+    const int l = a.n_layers - 1 - chunk / CS_CPL;
+    const int tile = (chunk % CS_CPL) * CS_CT + tc;
+    const CsPackLayer o = a.L[l];
+    const int m = lane & 15, q = lane >> 4;
+    const int col = cs_slot_column(o, a.D, 4 * tile + (m & 3), m >> 2);
+    bf16x8 f[CS_NP];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int k = 16 * (2 * s + (i >> 2)) + 4 * q + (i & 3);    // hidden unit of k-slot i of lane group q in k-step s (matches the h layout)
+        const float w = (col >= 0 && k < a.H) ? a.W2[(int64_t)(o.col0 + col) * a.w2s + k] : 0.0f;
+        __bf16 p0, p1, p2;
+        cs_split(w, p0, p1, p2);
+        f[0][i] = p0; f[1][i] = p1; f[2][i] = p2;
+    }
+    unsigned char* base = a.out + (size_t)chunk * CS_CHUNK_BYTES;
+#pragma unroll
+    for (int p = 0; p < CS_NP; ++p)
+        *reinterpret_cast<bf16x8*>(base + (size_t)((tc * CS_KSTEPS + s) * CS_NP + p) * CS_FRAG + lane * 16) = f[p];
+    if (s == 0 && lane < 16) {
+        const float b = (col >= 0 && a.b2 != nullptr) ? a.b2[o.col0 + col] : 0.0f;
+        reinterpret_cast<float*>(base + CS_W_BYTES)[tc * 16 + m] = b;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------- row-group reductions
+// the 4 coordinate lanes of a row are l, l^16, l^32, l^48.  v_permlane16_swap(vdst, src) exchanges vdst's odd 16-lane rows with src's even
+// rows, v_permlane32_swap the upper half of vdst with the lower half of src (scripts/probe/swapsem.hip), so with both operands = v the
+// two results are "my pair's even member" and "my pair's odd member" in every lane.  Written as inline asm: hipcc (ROCm 7.2) miscompiles
+// __builtin_amdgcn_permlane{16,32}_swap(v, v) followed by op(r[0], r[1]) into op(r[0], r[0]) (scripts/probe/layout16x32.hip caught it).
+// s_nop 1 = the two wait states the swap needs after a VALU write of its operands.
+template <typename Op> __device__ __forceinline__ float cs_rreduce(float v, Op op) {
+    float a = v, b = v;
+    asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    float c = op(a, b), e = c;
+    asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(c), "+v"(e));
+    return op(c, e);
+}
+__device__ __forceinline__ float cs_rsum(float v) { return cs_rreduce(v, [](float a, float b) { return a + b; }); }
+__device__ __forceinline__ float cs_rmax(float v) { return cs_rreduce(v, [](float a, float b) { return fmaxf(a, b); }); }
+
+// ---------------------------------------------------------------------------------------------------------- mixture on register rows
+// gfg_mixture_impl<float, RAW, FAST> / gfg_mixture_scaled (jf_gf.h) with the lane's parameters in registers P[slot]
+__device__ __forceinline__ MixQ<float> cs_mixture_scaled(const float (&P)[CS_SLOTS], const CsLayer& o, float x) {
+    using Mf = M<float>;
+    float iw[CS_K], u[CS_K];
+    float m = INFINITY;
+#pragma unroll
+    for (int k = 0; k < CS_K; ++k) {
+        const float ae = o.inv_wmax + Mf::exp_fast(-P[CS_SLOT_LW + k]);
+        iw[k] = ae * Mf::rcp(o.wmin * ae + 1.0f);
+        u[k] = (x - P[CS_SLOT_MEAN + k]) * iw[k];
+        m = fminf(m, fabsf(u[k]));
+    }
+    const float em = Mf::exp_fast(-m);
+    float Cu = 0.f, Cs = 0.f, Su = 0.f, Ss = 0.f, Ps = 0.f, Nn = 0.f;
+#pragma unroll
+    for (int k = 0; k < CS_K; ++k) {
+        const float wk = o.nmin + o.nmax * Mf::rcp(1.0f + Mf::exp_fast(-P[CS_SLOT_LN + k]));
+        const float t = Mf::exp_fast(m - fabsf(u[k]));
+        const float hi = Mf::rcp(1.0f + t * em);
+        const float c1 = wk * hi, c2 = c1 * t;
+        if (u[k] >= 0.f) { Cu += c1; Ss += c2; }
+        else { Su += c1; Cs += c2; }
+        Ps += c2 * hi * iw[k];
+        Nn += wk;
+    }
+    const float inv = Mf::rcp(Nn);
+    Cu *= inv; Cs *= inv; Su *= inv; Ss *= inv; Ps *= inv;
+    MixQ<float> q;
+    q.cdf = Cu + em * Cs;
+    q.sf = Su + em * Ss;
+    q.lc = Cu > 0.f ? Mf::log_fast(q.cdf) : Mf::log_fast(Cs) - m;
+    q.ls = Su > 0.f ? Mf::log_fast(q.sf) : Mf::log_fast(Ss) - m;
+    q.lp = Mf::log_fast(Ps) - m;
+    return q;
+}
+
+__device__ __forceinline__ MixQ<float> cs_mixture(const float (&P)[CS_SLOTS], const CsLayer& o, float x, bool live) {
+    using Mf = M<float>;
+    float C = 0.f, S = 0.f, Pd = 0.f, Nn = 0.f;
+#pragma unroll
+    for (int k = 0; k < CS_K; ++k) {
+        const float ae = o.inv_wmax + Mf::exp_fast(-P[CS_SLOT_LW + k]);
+        const float iw = ae * Mf::rcp(o.wmin * ae + 1.0f);
+        const float wk = o.nmin + o.nmax * Mf::rcp(1.0f + Mf::exp_fast(-P[CS_SLOT_LN + k]));
+        const float u = (x - P[CS_SLOT_MEAN + k]) * iw;
+        const float t = Mf::exp_fast(-fabsf(u));
+        const float hi = Mf::rcp(1.0f + t);
+        const float lo = t * hi;
+        const bool pos = u >= 0.f;
+        C += wk * (pos ? hi : lo);
+        S += wk * (pos ? lo : hi);
+        Pd += wk * hi * lo * iw;
+        Nn += wk;
+    }
+    const float inv = Mf::rcp(Nn);
+    C *= inv; S *= inv; Pd *= inv;
+    MixQ<float> q;
+    q.lc = Mf::log_fast(C); q.ls = Mf::log_fast(S); q.lp = Mf::log_fast(Pd);
+    q.cdf = C; q.sf = S;
+    const bool under = live && !(C > Mf::TINY && S > Mf::TINY && Pd > Mf::TINY);
+    if (__any(under)) {                                            // wave-uniform branch
+        const MixQ<float> qs = cs_mixture_scaled(P, o, x);
+        if (under) q = qs;
+    }
+    return q;
+}
+
+// ---------------------------------------------------------------------------------------------------------- the fused kernel
+struct CsArgs {
+    const float* in; int64_t in_stride;
+    const float* W1; int64_t w1s; const float* b1;
+    const unsigned char* packed;
+    int K1, H;
+    const float* x; int64_t xs;
+    const float* ld_in;
+    int64_t B;
+    int D, n_layers;
+    CsLayer L[JF_MAX_CHAIN];
+    float* x_out; int64_t xos;
+    float* ld_out;
+    const float* blp_in; float* blp_out;
+    int32_t* status;
+};
+
+__global__ void __launch_bounds__(256, 2) cond_gf_split_kernel(const CsArgs a) {
+    using MF = Mfma16<float>;
+    constexpr int MT = 16, KS = 4, NREG = 4, JH = CS_HMAX / MT;
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    unsigned char* Ws0 = smem_raw;                                 // two packed chunks (double buffer)
+    const int k1p = (a.K1 + KS - 1) / KS * KS, ldk = k1p + 1;
+    float* Xs = reinterpret_cast<float*>(smem_raw + CS_CHUNK_BYTES);   // phase 1 only (overlays buffer 1 while chunk 0 lands in buffer 0)
+    float* W1s = Xs + CS_ROWS * ldk;
+    float* b1s = W1s + CS_HMAX * ldk;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lq = lane >> 4;
+    const int64_t row0 = (int64_t)blockIdx.x * CS_ROWS;
+    const int64_t last = a.B - 1;
+    const int D = a.D;
+
+    // ---- chunk streaming: LDS-DMA (global_load_lds_dwordx4: 1 KiB per wave instruction, no register hop) into the buffer that is not being
+    //      multiplied; wave w moves KiB pieces w, w + 4, ... of the chunk, the bias tail goes with the last piece of wave 0
+    auto dma = [&](int chunk) {
+        const unsigned char* g = a.packed + (size_t)chunk * CS_CHUNK_BYTES;
+        unsigned char* l = Ws0 + (chunk & 1) * CS_CHUNK_BYTES;
+#pragma unroll
+        for (int u = 0; u < CS_W_BYTES / 4096; ++u)
+            __builtin_amdgcn_global_load_lds((cs_gptr)(g + (u * 4 + wave) * 1024 + lane * 16), (cs_lptr)(l + (u * 4 + wave) * 1024), 16, 0, 0);
+        if (wave == 0 && lane < CS_B_BYTES / 16)
+            __builtin_amdgcn_global_load_lds((cs_gptr)(g + CS_W_BYTES + lane * 16), (cs_lptr)(l + CS_W_BYTES), 16, 0, 0);
+    };
+    dma(0);                                                        // lands in buffer 0 while phase 1 works in buffer 1
+
+    // ---- phase 1: h^T = tanh(W1 x^T + b1) for the wave's 16 rows (exact f32 MFMA); rows past B replicate row B-1
+    {
+        const int nx = CS_ROWS * k1p, nw = CS_HMAX * k1p;
+        for (int base = 0; base < nx; base += 4 * 256) {
+            float v[4]; int o[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = base + u * 256 + tid;
+                const int r = idx / k1p, c = idx - r * k1p;
+                const int64_t gr = row0 + r;
+                const float t = a.in[(gr <= last ? gr : last) * a.in_stride + (c < a.K1 ? c : 0)];
+                v[u] = c < a.K1 ? t : 0.f;
+                o[u] = idx < nx ? r * ldk + c : -1;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) if (o[u] >= 0) Xs[o[u]] = v[u];
+        }
+        for (int base = 0; base < nw; base += 4 * 256) {
+            float v[4]; int o[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = base + u * 256 + tid;
+                const int r = idx / k1p, c = idx - r * k1p;
+                const float t = a.W1[(int64_t)(r < a.H ? r : a.H - 1) * a.w1s + (c < a.K1 ? c : 0)];
+                v[u] = (r < a.H && c < a.K1) ? t : 0.f;
+                o[u] = idx < nw ? r * ldk + c : -1;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) if (o[u] >= 0) W1s[o[u]] = v[u];
+        }
+        if (tid < CS_HMAX) b1s[tid] = tid < a.H ? a.b1[tid < a.H ? tid : 0] : 0.f;
+    }
+    __syncthreads();
+    bf16x8 hB[CS_KSTEPS][CS_NP];                                   // the hidden activations as MFMA B operands, three bf16 pieces
+    {
+        typename MF::Acc acc[JH];
+#pragma unroll
+        for (int j = 0; j < JH; ++j)
+#pragma unroll
+            for (int r = 0; r < NREG; ++r) acc[j][r] = 0.f;
+        for (int s = 0; s < k1p / KS; ++s) {
+            const int kk = s * KS + lq;
+            const float xb = Xs[(wave * MT + li) * ldk + kk];
+#pragma unroll
+            for (int j = 0; j < JH; ++j) acc[j] = MF::mma(W1s[(j * MT + li) * ldk + kk], xb, acc[j]);
+        }
+        // acc[j][r] = pre-activation of hidden unit 16 j + 4 lq + r for row li: k-slot i of k-step s <-> (j = 2 s + i / 4, r = i % 4)
+#pragma unroll
+        for (int s = 0; s < CS_KSTEPS; ++s)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int j = 2 * s + (i >> 2), r = i & 3;
+                const float h = M<float>::tanh_fast(acc[j][r] + b1s[j * MT + 4 * lq + r]);
+                __bf16 p0, p1, p2;
+                cs_split(h, p0, p1, p2);
+                hB[s][0][i] = p0; hB[s][1][i] = p1; hB[s][2][i] = p2;
+            }
+    }
+
+    // ---- flow state: lane = (row li of the wave's 16, coordinate lq)
+    const bool live = lq < D, leader = lq == 0;
+    const int d = live ? lq : D - 1;
+    const int64_t row = row0 + wave * MT + li;
+    const bool row_valid = row <= last;
+    const int64_t rrow = row_valid ? row : last;
+    float x = a.x[rrow * a.xs + d];
+    float ld = a.ld_in ? a.ld_in[rrow] : 0.f;
+
+    auto landed = [&]() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+
+    const int n_chunks = a.n_layers * CS_CPL;
+    landed();                                                      // chunk 0 is in buffer 0 and every wave is done with Xs / W1s / b1s (buffer 1)
+    int chunk = 0;
+    for (int l = a.n_layers - 1; l >= 0; --l) {
+        float P[CS_SLOTS];
+#pragma unroll
+        for (int c = 0; c < CS_CPL; ++c, ++chunk) {
+            if (chunk + 1 < n_chunks) dma(chunk + 1);              // in flight while this chunk is multiplied
+            const unsigned char* Ws = Ws0 + (chunk & 1) * CS_CHUNK_BYTES;
+            const float* Bs = reinterpret_cast<const float*>(Ws + CS_W_BYTES);
+            f32x4 acc[CS_CT];
+#pragma unroll
+            for (int t = 0; t < CS_CT; ++t) acc[t] = *reinterpret_cast<const f32x4*>(Bs + t * 16 + 4 * lq);    // bias of columns 4 lq .. 4 lq + 3
+#pragma unroll
+            for (int s = 0; s < CS_KSTEPS; ++s) {
+                bf16x8 A[CS_CT][CS_NP];
+#pragma unroll
+                for (int t = 0; t < CS_CT; ++t)
+#pragma unroll
+                    for (int p = 0; p < CS_NP; ++p)
+                        A[t][p] = *reinterpret_cast<const bf16x8*>(Ws + ((t * CS_KSTEPS + s) * CS_NP + p) * CS_FRAG + lane * 16);
+                // products with piece indices pa + pb <= 2, smallest first
+#pragma unroll
+                for (int t = 0; t < CS_CT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[t][2], hB[s][0], acc[t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < CS_CT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[t][1], hB[s][1], acc[t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < CS_CT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[t][0], hB[s][2], acc[t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < CS_CT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[t][1], hB[s][0], acc[t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < CS_CT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[t][0], hB[s][1], acc[t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < CS_CT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[t][0], hB[s][0], acc[t], 0, 0, 0);
+            }
+#pragma unroll
+            for (int t = 0; t < CS_CT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) P[4 * (c * CS_CT + t) + r] = acc[t][r];
+            if (c + 1 < CS_CPL) landed();                          // next chunk in place, every wave has read this one
+        }
+        // ---- flow phase on the lane's register row (raw parameters; jf_gf.h arithmetic)
+        const CsLayer o = a.L[l];                                  // uniform index: scalar loads from the kernarg segment
+        x -= P[CS_SLOT_OFF];                                       // euclidean_base.py:40-45 (zero column when the layer models no offset)
+#pragma unroll
+        for (int i = 0; i < CS_HH; ++i) {
+            if (i < o.hh) {                                        // x <- Q^T x (gaussianization_flow.py:1038), H_i = I - 2 v v^T / |v|^2
+                const float v = live ? P[CS_SLOT_ROT + i] : 0.f;
+                const float n2 = cs_rsum(v * v), dot = cs_rsum(v * x);
+                x -= 2.0f * dot * M<float>::rcp(n2) * v;
+            }
+        }
+        const MixQ<float> q = cs_mixture(P, o, x, live);
+        const IcdfOut<float> sy = gf_icdf<float>(o.inv_type, q);
+        x = sy.y;
+        ld += cs_rsum(live ? sy.logd : 0.f);
+        landed();
+    }
+
+    if (row_valid && live) a.x_out[row * a.xos + d] = x;
+    float sb = 0.f;
+    if (a.blp_out) sb = cs_rsum(live ? -0.5f * x * x - M<float>::HALF_LN_2PI : 0.f);
+    if (row_valid && leader) {
+        a.ld_out[row] = ld;
+        if (a.blp_out) a.blp_out[row] = sb + (a.blp_in ? a.blp_in[row] : 0.f);
+    }
+    const float bad = cs_rmax((live && !M<float>::finite(x)) ? 1.f : 0.f);
+    status_add(a.status, JF_STATUS_NONFINITE, row_valid && leader && (bad > 0.f || !M<float>::finite(ld)));
+}
+
+// ---------------------------------------------------------------------------------------------------------- host side
+static bool cs_layer_supported(const jf_gf_layer& h, int D) {
+    return h.num_kde == CS_K && h.hh_iter >= 0 && h.hh_iter <= CS_HH && h.nonlinear_stretch_type == JF_GF_STRETCH_CLASSIC &&
+           h.width_mode == JF_GF_WIDTH_SMOOTH_SATURATION && !h.clamp_widths && h.fit_normalization && h.regulate_normalization &&
+           h.width_min > 0 && h.width_max > 0 && D >= 3 && D <= 4;
+}
+
+static int cs_pack(const float* W2, int64_t w2s, const float* b2, int32_t H, int32_t D, int32_t n_layers, const jf_gf_layer* layers, void* packed,
+                   void* stream) {
+    if (!W2 || !layers || !packed) return JF_ERR_BADARG;
+    if (H < 1 || n_layers < 1 || n_layers > JF_MAX_CHAIN) return JF_ERR_BADARG;
+    if (H > CS_HMAX) return JF_ERR_UNSUPPORTED;
+    CsPackArgs a{};
+    int col = 0;
+    for (int l = 0; l < n_layers; ++l) {
+        const jf_gf_layer& h = layers[l];
+        if (!cs_layer_supported(h, D)) return JF_ERR_UNSUPPORTED;
+        CsPackLayer& o = a.L[l];
+        const int kd = h.num_kde * D;
+        o.col0 = col; o.hh = h.hh_iter; o.model_offset = h.model_offset;
+        o.off_rot = h.model_offset ? D : 0;
+        o.off_mean = o.off_rot + h.hh_iter * D;
+        o.off_lw = o.off_mean + kd;
+        o.off_ln = o.off_lw + kd;
+        col += o.off_ln + kd;
+    }
+    a.W2 = W2; a.w2s = w2s; a.b2 = b2; a.H = H; a.D = D; a.n_layers = n_layers; a.out = static_cast<unsigned char*>(packed);
+    const int threads = n_layers * CS_CPL * CS_CT * CS_KSTEPS * 64;
+    hipLaunchKernelGGL(cs_pack_kernel, dim3((threads + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
+    return hipPeekAtLastError() == hipSuccess ? JF_OK : JF_ERR_LAUNCH;
+}
+
+static int cs_chain(const float* in, int64_t in_stride, const float* W1, int64_t w1s, const float* b1, const void* packed, int32_t K1, int32_t H,
+                    const float* x, int64_t xs, const float* ld_in, int64_t B, int32_t D, int32_t n_layers, const jf_gf_layer* layers, float* x_out,
+                    int64_t xos, float* ld_out, const float* blp_in, float* blp_out, int32_t* status, void* stream) {
+    if (!in || !W1 || !b1 || !packed || !x || !x_out || !ld_out || !layers) return JF_ERR_BADARG;
+    if (K1 < 1 || H < 1 || B < 0 || n_layers < 1 || n_layers > JF_MAX_CHAIN) return JF_ERR_BADARG;
+    if (K1 > CS_K1MAX || H > CS_HMAX || (reinterpret_cast<uintptr_t>(packed) & 15u)) return JF_ERR_UNSUPPORTED;
+    CsArgs a{};
+    for (int l = 0; l < n_layers; ++l) {
+        const jf_gf_layer& h = layers[l];
+        if (!cs_layer_supported(h, D)) return JF_ERR_UNSUPPORTED;
+        CsLayer& o = a.L[l];
+        o.hh = h.hh_iter; o.model_offset = h.model_offset; o.inv_type = h.inverse_function_type;
+        o.wmin = (float)h.width_min; o.inv_wmax = (float)(1.0 / h.width_max); o.nmin = (float)h.norm_min; o.nmax = (float)h.norm_max;
+    }
+    if (B == 0) return JF_OK;
+    a.in = in; a.in_stride = in_stride; a.W1 = W1; a.w1s = w1s; a.b1 = b1; a.packed = static_cast<const unsigned char*>(packed); a.K1 = K1; a.H = H;
+    a.x = x; a.xs = xs; a.ld_in = ld_in; a.B = B; a.D = D; a.n_layers = n_layers;
+    a.x_out = x_out; a.xos = xos; a.ld_out = ld_out; a.blp_in = blp_in; a.blp_out = blp_out; a.status = status;
+    const size_t lds = 2 * CS_CHUNK_BYTES;
+    static bool attr_set = false;
+    if (!attr_set) { (void)hipFuncSetAttribute((const void*)cond_gf_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
+    hipLaunchKernelGGL(cond_gf_split_kernel, dim3((unsigned)((B + CS_ROWS - 1) / CS_ROWS)), dim3(256), lds, (hipStream_t)stream, a);
+    return hipPeekAtLastError() == hipSuccess ? JF_OK : JF_ERR_LAUNCH;
+}
+
+}  // namespace jf
+
+extern "C" {
+int64_t jf_cond_gf_packed_bytes(int32_t D, int32_t n_layers, const jf_gf_layer* layers) {
+    if (!layers || n_layers < 1 || n_layers > JF_MAX_CHAIN) return JF_ERR_BADARG;
+    for (int l = 0; l < n_layers; ++l)
+        if (!jf::cs_layer_supported(layers[l], D)) return JF_ERR_UNSUPPORTED;
+    return (int64_t)n_layers * jf::CS_CPL * jf::CS_CHUNK_BYTES;
+}
+int jf_cond_gf_pack_f32(const float* W2, int64_t w2s, const float* b2, int32_t H, int32_t D, int32_t n, const jf_gf_layer* L, void* packed, void* s) {
+    return jf::cs_pack(W2, w2s, b2, H, D, n, L, packed, s);
+}
+int jf_cond_gf_chain_inv_split_f32(const float* in, int64_t is, const float* W1, int64_t w1s, const float* b1, const void* packed, int32_t K1,
+                                   int32_t H, const float* x, int64_t xs, const float* ld_in, int64_t B, int32_t D, int32_t n,
+                                   const jf_gf_layer* L, float* xo, int64_t xos, float* ldo, const float* bi, float* bo, int32_t* st, void* s) {
+    return jf::cs_chain(in, is, W1, w1s, b1, packed, K1, H, x, xs, ld_in, B, D, n, L, xo, xos, ldo, bi, bo, st, s);
+}
+}

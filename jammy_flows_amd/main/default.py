@@ -120,6 +120,11 @@ class pdf(nn.Module):
         # conditional e-blocks (Linear-tanh-Linear MLP + g layers, D in {3,4}, float32) as ONE launch with the parameter block kept on chip
         # (jf_cond_gf_chain_inv): +9 % on the C3 step against jf_mlp2 + jf_gf_chain_inv.  False selects the two-launch path.
         self.fuse_conditional_blocks = True
+        # matrix arithmetic of the fused block's 128 -> P product: "split_bf16" (three bf16 pieces per f32 operand, six MFMA passes with f32
+        # accumulation: products exact, result within ~3 * 2^-24 relative of the f32 dot product; parameters stay in registers) or "f32"
+        # (exact f32-input MFMA, parameter tile in LDS).  Layer options outside the split kernel's set fall back to "f32" by themselves.
+        self.fused_matrix_arithmetic = "split_bf16"
+        self._packed_cache = {}
 
         self._read_model_definition(pdf_defs, flow_defs, options_overwrite, conditional_input_dim, amortization_mlp_dims,
                                     amortization_mlp_ranks)
@@ -398,6 +403,19 @@ class pdf(nn.Module):
             ps = [p.to(dtype) for p in ps]
         return [p.detach() for p in ps]
 
+    def _packed_w2(self, si, w2, b2, layer_array, n_layers, D):
+        """packed split-bf16 image of the block's output layer, rebuilt when the weights change (tensor identity + in-place version)."""
+        key = (w2.data_ptr(), w2._version, b2.data_ptr(), b2._version, str(w2.device))
+        hit = self._packed_cache.get(si)
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        if _hip.cond_gf_packed_bytes(layer_array, n_layers, D) < 0:
+            packed = None                                                    # layer options outside the split kernel's set
+        else:
+            packed = _hip.cond_gf_pack(w2, b2, layer_array, n_layers, D)
+        self._packed_cache[si] = (key, packed)
+        return packed
+
     def _block_params(self, si, data_summary, embeds, amort, counter):
         """extra_inputs row block of sub-pdf si, or None for permanent parameters (:936-993, 1420-1475)."""
         mlp = self.mlp_predictors[si] if len(self.mlp_predictors) > si else None
@@ -518,9 +536,18 @@ class pdf(nn.Module):
             fused = self._fusable_block(si, layers, only_last, amortization_parameters, x.dtype) if kind == "e" else None
             if fused is not None:
                 # amortisation MLP + g layers in one launch: the per-sample parameter block never reaches HBM
-                res = _hip.cond_gf_chain_inv(self._mlp_input(si, data_summary, embeds), *fused, tgt, log_det,
-                                             _hip.gf_layer_array([l.c_struct() for l in layers]), len(layers), layers[0].dimension,
-                                             x_out=out_view, base_logp_in=base_logp, want_base_logp=want_base_logp, status=status)
+                larr = _hip.gf_layer_array([l.c_struct() for l in layers])
+                packed = None
+                if self.fused_matrix_arithmetic == "split_bf16" and fused[0].shape[0] <= 128:
+                    packed = self._packed_w2(si, fused[2], fused[3], larr, len(layers), layers[0].dimension)
+                if packed is not None:
+                    res = _hip.cond_gf_chain_inv_split(self._mlp_input(si, data_summary, embeds), fused[0], fused[1], packed, tgt, log_det, larr,
+                                                       len(layers), layers[0].dimension, x_out=out_view, base_logp_in=base_logp,
+                                                       want_base_logp=want_base_logp, status=status)
+                else:
+                    res = _hip.cond_gf_chain_inv(self._mlp_input(si, data_summary, embeds), *fused, tgt, log_det, larr, len(layers),
+                                                 layers[0].dimension, x_out=out_view, base_logp_in=base_logp, want_base_logp=want_base_logp,
+                                                 status=status)
                 log_det = res[1]
                 if want_base_logp:
                     base_logp = res[2]
