@@ -1,138 +1,258 @@
 #!/usr/bin/env python3
 """Benchmark of the jammy_flows hot path on MI355X (contract: see the task statement / DESIGN.md section "Measurement").
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W [--workload c3|c5] [--scaling weak|strong]
+                                                   (N > 1: launched by torch.distributed.run, one rank per GPU)
 
-One step = one log-prob evaluation (`pdf.forward`) of a batch of 2^20 rows per GPU of BASELINE.json's metric configuration
-`pdf("e4+s2+e4", "gggg+f+gggg")` ("n" of the upstream README = "f"): all three sub-pdfs, both amortisation MLPs, every layer.
-Inputs are synthetic (seeded) and resident in HBM before the timed region; weights are the frozen golden-fixture state_dict
-(tests/golden/c3_e4s2e4.npz, reference init with the MLP damping undone so parameter blocks really vary per row).
-For N > 1 every rank evaluates its own 2^20 rows (weak scaling) and every step all-gathers its log-probs (ONE RCCL all_gather,
-issued asynchronously so that it overlaps the next step; all of them are waited for inside the timed region).
+One step = one log-prob evaluation (`pdf.forward`) of one batch of synthetic rows: all sub-pdfs, all amortisation MLPs, every layer.
+  --workload c3 (default): BASELINE.json's metric configuration `pdf("e4+s2+e4", "gggg+f+gggg")` ("n" of the upstream README = "f"),
+                float32 `value` (+ the float64 rate beside it), 2^20 rows per GPU
+  --workload c5: BASELINE configs[4], conditional `pdf("e8+s2", "gggg+v")`, 16 conditioning inputs, AmortizableMLP hidden 128 rank 8, float64
+                ('v' asserts float64 in the reference), 2^19 rows per GPU (= 2^22 over 8)
+  --scaling weak (default): the per-GPU batch is fixed as N grows;  strong: the TOTAL batch is fixed (2^20 for c3, 2^22 for c5) and row-sharded
+                over the ranks -- BASELINE.md section 3 defines efficiency = T_1 / (G T_G) on that.
+Inputs are synthetic (seeded) and resident in HBM before the timed region; weights are the frozen golden-fixture state_dicts
+(tests/golden/*.npz: reference init with the MLP damping undone, so parameter blocks really vary per row).
+For N > 1 every step all-gathers its log-probs (ONE RCCL all_gather, asynchronous, overlapping the next step; all waited for in the timed region).
 
 Printed JSON line (rank 0): metric/value (whole-job evals/s), ms_per_step, plus
-  roofline      dominant kernel: algorithmic bytes per launch / mean launch time from HIP events recorded in the timed region
-  cpu_baseline  the numpy oracle (kind "port") on this box's host cores, bounded sample, rank 0 at N = 1 only
+  roofline      dominant kernel: SURVEY 8d algorithmic bytes per launch / mean launch time from HIP events recorded in the timed region on
+                the launch stream; `traffic` = HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE) of this same
+                workload run as child processes before the timed run (or, if rocprofv3 is missing / fails, from the committed profile
+                when the kernel sources are unchanged since it was taken -- otherwise null and `traffic_stale`)
+  cpu_baseline  the numpy oracle (kind "port") on this box's host cores (one single-threaded process per core), bounded sample, N = 1 only
   parity        max |d log p| of the timed configuration against the float64 oracle on a 4096-row sample
-  float64       the same workload evaluated in float64 (evals/s), for reference
 """
-import argparse
-import json
 import os
-import sys
-import time
+
+# the CPU baseline forks one single-threaded worker per core: the BLAS / OpenMP pools must be sized BEFORE numpy is imported
+for _v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS", "NUMEXPR_NUM_THREADS"):
+    os.environ.setdefault(_v, "1")
+
+import argparse  # noqa: E402
+import glob  # noqa: E402
+import hashlib  # noqa: E402
+import json  # noqa: E402
+import shutil  # noqa: E402
+import sqlite3  # noqa: E402
+import subprocess  # noqa: E402
+import sys  # noqa: E402
+import tempfile  # noqa: E402
+import time  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden")]
 
 import numpy as np  # noqa: E402
 
-WORKLOAD = "c3_e4s2e4"
-PDF_DEFS, FLOW_DEFS = "e4+s2+e4", "gggg+f+gggg"
-BATCH = 1 << 20
-HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy ceiling ~6290 GB/s
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy ceiling ~6290 GB/s
 MFMA_F32_PEAK_TFLOPS = 157.3   # dense f32-input MFMA peak (v_mfma_f32_32x32x2_f32), MI355X_MICROARCH.md
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak, MI355X_MICROARCH.md
+MFMA_F64_PEAK_TFLOPS = 78.6    # v_mfma_f64_16x16x4_f64: 256 flop/clk/CU x 256 CUs x 2.4 GHz / 2 -- measured: scripts/probe/mfma64.hip
+
+WORKLOADS = {
+    # fixture, pdf/flow strings, dtype of `value`, rows per GPU (weak), total rows (strong), SURVEY 8d algorithmic bytes per eval by dtype
+    "c3": dict(fixture="c3_e4s2e4", defs=("e4+s2+e4", "gggg+f+gggg"), dtype="f32", rows=1 << 20, total=1 << 20, seed=3,
+               bytes_per_eval={"f32": 4612, "f64": 9224}, flops_per_eval=145664,
+               metric="log-prob evals/sec (batch 2^20 per GPU), e4+s2+e4 / gggg+f+gggg",
+               desc="unconditional pdf with autoregressive conditioning"),
+    "c5": dict(fixture="c5_e8s2_ggggv", defs=("e8+s2", "gggg+v"), dtype="f64", rows=1 << 19, total=1 << 22, seed=5,
+               bytes_per_eval={"f64": 20912}, flops_per_eval=29216,
+               metric="log-prob evals/sec (batch 2^19 per GPU = 2^22 over 8), conditional e8+s2 / gggg+v, AmortizableMLP rank 8",
+               desc="conditional pdf (16 inputs), AmortizableMLP hidden 128 rank 8"),
+}
+REFERENCE_8THREAD = {"c3": {"value": 3.71e4, "what": "true reference, float64, batch 2^18, 8 threads of the survey container (BASELINE.md section 2)"},
+                     "c5": {"value": 2.44e4, "what": "true reference, float64, batch 2^16, 8 threads of the survey container (BASELINE.md section 2)"}}
 
 
-def make_inputs(n, seed):
-    """x = [N(0,1.5^2)^4, theta = acos(U(-1,1)) clamped to [1e-3, pi-1e-3], phi = U(0,2pi), N(0,1.5^2)^4]."""
+def make_inputs(workload, n, seed):
+    """SURVEY 8d inputs.  c3: x = [N(0,1.5^2)^4, theta = acos(U(-1,1)) clamped to [1e-3, pi-1e-3], phi = U(0,2pi), N(0,1.5^2)^4];
+    c5: c ~ N(0, I_16), x = [N(0,1.5^2)^8, uniform on S2 as (theta, phi)].  Returns (x, cond or None)."""
     rng = np.random.default_rng(seed)
-    return np.concatenate([rng.normal(size=(n, 4)) * 1.5,
-                           np.arccos(rng.uniform(-1, 1, size=(n, 1))).clip(1e-3, np.pi - 1e-3),
-                           rng.uniform(0, 2 * np.pi, size=(n, 1)),
-                           rng.normal(size=(n, 4)) * 1.5], axis=1)
+    if workload == "c3":
+        return np.concatenate([rng.normal(size=(n, 4)) * 1.5,
+                               np.arccos(rng.uniform(-1, 1, size=(n, 1))).clip(1e-3, np.pi - 1e-3),
+                               rng.uniform(0, 2 * np.pi, size=(n, 1)),
+                               rng.normal(size=(n, 4)) * 1.5], axis=1), None
+    x = np.concatenate([rng.normal(size=(n, 8)) * 1.5,
+                        np.arccos(rng.uniform(-1, 1, size=(n, 1))).clip(1e-3, np.pi - 1e-3),
+                        rng.uniform(0, 2 * np.pi, size=(n, 1))], axis=1)
+    return x, rng.normal(size=(n, 16))
 
 
-# ---------------------------------------------------------------------------------------------- CPU baseline (oracle, multi-process)
+# ---------------------------------------------------------------------------------------------- CPU baseline (oracle, one process per core)
 _ORACLE = None
 
 
-def _oracle_init():
+def _oracle_init(fixture):
     global _ORACLE
     import fixture_io
     import helpers
-    os.environ.setdefault("OMP_NUM_THREADS", "1")
-    _ORACLE = helpers.build_oracle(fixture_io.load(WORKLOAD))
+    try:                                             # belt and braces: the env vars above already size the pools of a fresh import
+        from threadpoolctl import threadpool_limits
+        threadpool_limits(1)
+    except Exception:                                # noqa: BLE001
+        pass
+    _ORACLE = helpers.build_oracle(fixture_io.load(fixture))
 
 
-def _oracle_chunk(x):
-    return _ORACLE.forward(x)[0]
+def _oracle_chunk(args):
+    x, c = args
+    return _ORACLE.forward(x, c)[0]
 
 
-def cpu_baseline(budget_s=20.0):
-    """time the CPU oracle on a bounded sample of the same workload using every host core (process pool, forked BEFORE any GPU call)."""
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(workload, budget_s=15.0):
+    """time the CPU oracle on a bounded sample of the same workload with one single-threaded process per host core (fork BEFORE any GPU
+    call).  Chunks of 1024 rows keep the (rows, K, D) float64 temporaries of a 'g' layer (~330 KB each) in the core's L2."""
     import multiprocessing as mp
+    w = WORKLOADS[workload]
     cores = os.cpu_count() or 1
-    workers = max(1, min(cores, 64))
-    chunk = 2048
+    workers = max(1, min(cores, 128))
+    chunk = 1024
     ctx = mp.get_context("fork")
-    with ctx.Pool(workers, initializer=_oracle_init) as pool:
-        x = make_inputs(chunk * workers, 3)
-        chunks = [x[i * chunk:(i + 1) * chunk] for i in range(workers)]
+
+    def chunks_of(n_chunks):
+        x, c = make_inputs(workload, chunk * n_chunks, w["seed"])
+        return [(x[i * chunk:(i + 1) * chunk], None if c is None else c[i * chunk:(i + 1) * chunk]) for i in range(n_chunks)]
+
+    with ctx.Pool(workers, initializer=_oracle_init, initargs=(w["fixture"],)) as pool:
+        pool.map(_oracle_chunk, chunks_of(workers))                 # warm-up (imports, first-touch)
         t0 = time.time()
-        pool.map(_oracle_chunk, chunks)            # warm-up + rate estimate
+        pool.map(_oracle_chunk, chunks_of(workers))
         est = time.time() - t0
-        rounds = int(max(1, min(64, budget_s / max(est, 1e-3))))
-        x = make_inputs(chunk * workers * rounds, 3)
-        chunks = [x[i * chunk:(i + 1) * chunk] for i in range(workers * rounds)]
+        rounds = int(max(2, min(256, budget_s / max(est, 1e-3))))
+        work = chunks_of(workers * rounds)
         t0 = time.time()
-        pool.map(_oracle_chunk, chunks)
+        pool.map(_oracle_chunk, work, chunksize=1)
         dt = time.time() - t0
     n = chunk * workers * rounds
-    return {"value": n / dt, "unit": "log-prob evals/s", "cores": workers, "kind": "port",
-            "sample": "%d rows of %s (float64 numpy oracle, %d processes x %d-row chunks), %.1f s" % (n, WORKLOAD, workers, chunk, dt)}
+    return {"value": n / dt, "unit": "log-prob evals/s", "cores": workers, "kind": "port", "cpu_model": cpu_model(),
+            "per_core": n / dt / workers,
+            "sample": "%d rows of %s (float64 numpy oracle, %d single-threaded processes x %d-row chunks), %.1f s"
+                      % (n, w["fixture"], workers, chunk, dt),
+            "reference_container_8thread": REFERENCE_8THREAD[workload]}
 
 
-# ---------------------------------------------------------------------------------------------- HBM traffic from the committed PMC passes
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r01_g_traffic.json")
-TRAFFIC_KEYS = {("jf_cond_gf_chain_inv_f32", "K7_H128_N548_D4"): "jf::cond_gf_chain_kernel<float, 8>",
-                ("jf_mlp2_f32", "K7_H128_N548"): "jf::mlp2_kernel<float, 4, 2, true, true>",
-                ("jf_mlp2_f32", "K4_H128_N10"): "jf::mlp2_kernel<float, 4, 1, true, true>",
-                ("jf_gf_chain_inv_f32", "per-sample"): "jf::gf_chain_kernel<float, 4, false, false>",
-                ("jf_gf_chain_inv_f32", "bcast"): "jf::gf_chain_kernel<float, 4, true, false>"}
+# ---------------------------------------------------------------------------------------------- HBM traffic (rocprofv3 PMC)
+PROFILE_TRAFFIC = os.path.join(ROOT, "profiles", "r02_traffic.json")
+WRITE_CAL = 0.965     # WRITE_SIZE calibration on scripts/probe/wstore (16-byte lane-per-row tile stores); FETCH_SIZE x 2 on gfx950 (guide)
 
 
-SQ_FILE = os.path.join(ROOT, "profiles", "r01_g_sq_counters.json")
+def kernel_source_hash():
+    h = hashlib.sha256()
+    for p in sorted(glob.glob(os.path.join(ROOT, "jammy_flows_amd", "csrc", "*.h*")) + [os.path.join(ROOT, "include", "jammy_hip.h")]):
+        h.update(open(p, "rb").read())
+    return h.hexdigest()[:16]
 
 
-def pmc_issue(kname, ktag, B):
-    """share of the kernel's cycles in which the matrix pipe / the VALU were busy, from the committed SQ counter pass of this command
-    (SQ_VALU_MFMA_BUSY_CYCLES, SQ_ACTIVE_INST_VALU [quad-cycles], GRBM_GUI_ACTIVE; 1024 SIMDs, 8 XCDs).  On CDNA4 f32 MFMA and VALU work
-    do not co-issue on a SIMD (scripts/probe/coexec.hip), so their sum is the fraction of the kernel's issue floor that is reached."""
-    prefix = TRAFFIC_KEYS.get((kname, ktag))
+def pmc_pass(counter, workload, rows, fuse):
+    """one rocprofv3 --pmc pass of a few steps of this workload in a child process -> {kernel name: mean raw counter value}.
+    The child is this script (`--pmc-child`): python itself is what follows `--`, nothing re-execs after the GPU is initialised."""
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None
+    tmp = tempfile.mkdtemp(prefix="jf_pmc_", dir="/tmp")
     try:
-        table = json.load(open(SQ_FILE))
-    except OSError:
+        cmd = [exe, "--pmc", counter, "-d", tmp, "--", sys.executable, os.path.abspath(__file__), "--pmc-child", "--workload", workload,
+               "--batch", str(rows)] + ([] if fuse else ["--no-fuse"])
+        env = dict(os.environ, TMPDIR="/tmp")
+        r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=240)
+        dbs = glob.glob(os.path.join(tmp, "**", "*.db"), recursive=True)
+        if r.returncode != 0 or not dbs:
+            return None
+        cur = sqlite3.connect(dbs[0]).cursor()
+        q = "select kernel_name, avg(value) from counters_collection where counter_name=? group by kernel_name"
+        return {n: v for n, v in cur.execute(q, (counter,)) if "jf::" in n}
+    except Exception:                                # noqa: BLE001 -- profiling is optional; the fallback is the committed profile
         return None
-    if prefix is None or B != BATCH:
-        return None
-    for key, v in table.items():
-        if key.startswith(prefix) and v.get("GRBM_GUI_ACTIVE"):
-            cyc = v["GRBM_GUI_ACTIVE"] / 8.0
-            m = v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / 1024.0 / cyc
-            a = v.get("SQ_ACTIVE_INST_VALU", 0.0) * 4.0 / 1024.0 / cyc
-            return {"mfma_busy_frac": m, "valu_busy_frac": a, "issue_frac": m + a, "source": "profiles/r01_g_sq_counters.json"}
-    return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
-def pmc_traffic(kname, ktag, B):
-    """HBM bytes per launch of one kernel from the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command
-    (profiles/r01_g_*; PMC collection needs its own rocprofv3 runs, so the figure is read from the committed summary, not measured live).
-    Corrections (MI355X_MICROARCH.md, HBM section): FETCH_SIZE x 2 on gfx950 for wide coalesced reads; WRITE_SIZE x 0.965, calibrated on
-    scripts/probe/wstore for the 16-byte lane-per-row tile stores these kernels use.  None when the profile was taken at another batch."""
+def measure_traffic(workload, rows, fuse):
+    """{kernel name: {"read_bytes", "write_bytes", "hbm_bytes_per_launch"}} from two PMC passes (FETCH_SIZE and WRITE_SIZE cannot share one)."""
+    f = pmc_pass("FETCH_SIZE", workload, rows, fuse)
+    if not f:
+        return None
+    w = pmc_pass("WRITE_SIZE", workload, rows, fuse)
+    if not w:
+        return None
+    out = {}
+    for k in f:
+        if k in w:
+            rd, wr = f[k] * 1024 * 2, w[k] * 1024 * WRITE_CAL
+            out[k] = {"read_bytes": rd, "write_bytes": wr, "hbm_bytes_per_launch": rd + wr}
+    return {"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate child passes of this run (FETCH_SIZE x 2, WRITE_SIZE x %.3f)" % WRITE_CAL,
+            "kernels": out}
+
+
+def committed_traffic():
     try:
-        table = json.load(open(TRAFFIC_FILE))
-    except OSError:
+        t = json.load(open(PROFILE_TRAFFIC))
+    except (OSError, ValueError):
         return None
-    prefix = TRAFFIC_KEYS.get((kname, ktag))
-    if prefix is None or B != BATCH:
+    if t.get("kernel_source_hash") != kernel_source_hash():
+        return {"stale": True, "source": "profiles/r02_traffic.json (taken at kernel sources %s, now %s)" % (t.get("kernel_source_hash"), kernel_source_hash())}
+    t["source"] = "profiles/r02_traffic.json (committed rocprofv3 --pmc passes of this command; kernel sources unchanged since)"
+    return t
+
+
+# device-kernel name (as rocprofv3 reports it) of a (C entry point, tag) pair of the host-side timer
+KERNEL_OF = {"jf_cond_gf_chain_inv_split_f32": "cond_gf_split_kernel", "jf_cond_gf_chain_inv_f32": "cond_gf_chain_kernel<float",
+             "jf_cond_gf_chain_inv_f64": "cond_gf_chain_kernel<double", "jf_mlp2_f32": "mlp2_kernel<float", "jf_mlp2_f64": "mlp2_kernel<double",
+             "jf_gf_chain_inv_f32": "gf_chain_kernel<float", "jf_gf_chain_inv_f64": "gf_chain_kernel<double",
+             "jf_amlp_gf_chain_inv_f64": "amlp_gf_kernel"}
+
+
+def traffic_of(traffic, kname, ktag):
+    if not traffic or traffic.get("stale") or "kernels" not in traffic:
         return None
-    for key, v in table.items():
-        if key.startswith(prefix) and v.get("FETCH_SIZE_raw_KB") is not None and v.get("WRITE_SIZE_raw_KB") is not None:
-            return {"hbm_bytes_per_launch": v["FETCH_SIZE_raw_KB"] * 1024 * 2 + v["WRITE_SIZE_raw_KB"] * 1024 * 0.965,
-                    "read_bytes": v["FETCH_SIZE_raw_KB"] * 1024 * 2, "write_bytes": v["WRITE_SIZE_raw_KB"] * 1024 * 0.965,
-                    "source": "profiles/r01_g_traffic.json (rocprofv3 --pmc, separate passes)"}
-    return None
+    key = KERNEL_OF.get(kname)
+    if key is None:
+        return None
+    cands = [(n, v) for n, v in traffic["kernels"].items() if key in n]
+    if kname.startswith("jf_gf_chain_inv"):          # the chain kernel exists as broadcast (..., true, false>) and per-sample (..., false, false>)
+        want = ", true, false>" if ktag == "bcast" else ", false, false>"
+        cands = [(n, v) for n, v in cands if want in n]
+    if kname.startswith("jf_mlp2") and len(cands) > 1:   # narrow-output variant (TN = 1) for N <= 16, wide otherwise
+        narrow = int(ktag.split("_")[-1][1:]) <= 32
+        cands = [(n, v) for n, v in cands if (", 1, true" in n) == narrow] or cands
+    return cands[0][1] if len(cands) == 1 else None
+
+
+# ---------------------------------------------------------------------------------------------- algorithmic accounting
+def kernel_accounting(kname, ktag, s):
+    """(algorithmic HBM bytes per row, MFMA flops per row, fused?) of one timed kernel; s = bytes per scalar."""
+    if kname.startswith("jf_cond_gf_chain_inv_split"):
+        K1, H, L, D = (int(t[1:]) for t in ktag.split("_"))
+        N = L * (3 * 10 * D + D * D) + D                 # default g rows: 3 K D + D^2 (+ D offsets on the last layer)
+        return s * (K1 + N) + s * (D + 1 + N + D + 1), 2 * (K1 * H + H * N), True
+    if kname.startswith("jf_cond_gf_chain") or kname.startswith("jf_amlp_gf_chain"):
+        K1, H, N, D = (int(t[1:]) for t in ktag.split("_")[:4])
+        # fused launch (MLP + g layers): SURVEY 8d "materialised" accounting = MLP (reads inputs, writes block) + flow (reads block);
+        # the block itself never reaches HBM, so the real traffic is only s (K1 + 2 D + 2) bytes per row
+        return s * (K1 + N) + s * (D + 1 + N + D + 1), 2 * (K1 * H + H * N), True
+    if kname.startswith("jf_linear"):
+        K, N = int(ktag.split("_")[0][1:]), int(ktag.split("_")[1][1:])
+        return s * (K + N), 2 * K * N, False
+    if kname.startswith("jf_mlp2"):
+        K1, H, N = (int(t[1:]) for t in ktag.split("_"))
+        return s * (K1 + N), 2 * (K1 * H + H * N), False
+    if kname.startswith("jf_gf_chain_inv"):
+        if ktag == "bcast":
+            return s * 10, 0, False
+        return None, 0, False                            # per-sample: depends on the block (filled in by the caller)
+    return 0, 0, False
 
 
 # ---------------------------------------------------------------------------------------------- main
@@ -141,19 +261,41 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=BATCH, help="rows per GPU (default 2^20 = the BASELINE configuration)")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c3")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--batch", type=int, default=None, help="rows per GPU (weak) / total rows (strong); default: the BASELINE configuration")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-fuse", action="store_true", help="time the two-launch path (jf_mlp2 + jf_gf_chain_inv) instead of the fused conditional block")
+    ap.add_argument("--no-pmc", action="store_true", help="do not run the rocprofv3 PMC child passes (traffic then comes from the committed profile)")
+    ap.add_argument("--no-fuse", action="store_true", help="time the two-launch path (MLP launch + flow launch) instead of the fused conditional block")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    W = WORKLOADS[args.workload]
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    assert world == args.gpus, "WORLD_SIZE (%d) != --gpus (%d): launch with torch.distributed.run --nproc-per-node N" % (world, args.gpus)
+    assert world == args.gpus or args.pmc_child, "WORLD_SIZE (%d) != --gpus (%d): launch with torch.distributed.run --nproc-per-node N" % (world, args.gpus)
+
+    # rows of this rank
+    if args.scaling == "weak":
+        B = args.batch if args.batch is not None else W["rows"]
+        total_rows = B * world
+        lo = rank * B
+    else:
+        total_rows = args.batch if args.batch is not None else W["total"]
+        base, rem = divmod(total_rows, world)
+        lo = rank * base + min(rank, rem)
+        B = base + (1 if rank < rem else 0)
 
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline()                      # before the GPU is touched (fork safety)
+    traffic = None
+    if rank == 0 and world == 1 and not args.pmc_child:
+        if not args.no_cpu_baseline:
+            cpu = cpu_baseline(args.workload)                        # before the GPU is touched (fork safety)
+        if not args.no_pmc:
+            traffic = measure_traffic(args.workload, B, not args.no_fuse)   # child processes; this process has not touched the GPU yet
+    if traffic is None:
+        traffic = committed_traffic()
 
     import torch
     import torch.distributed as dist
@@ -173,63 +315,66 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+    n_ranks_seen = dist.get_world_size() if world > 1 else 1
+    backend_name = dist.get_backend() if world > 1 else None
 
-    fx = fixture_io.load(WORKLOAD)
-    B = args.batch
-    x64 = make_inputs(B, 3 + rank)
+    fx = fixture_io.load(W["fixture"])
+    # every rank generates the rows it owns from its own seed (no scatter)
+    x64, c64 = make_inputs(args.workload, B, W["seed"] + rank)
+    dtypes = {"f32": torch.float32, "f64": torch.float64}
+    main_dt = W["dtype"]
+    order = [main_dt] + (["f64"] if (main_dt == "f32" and not args.pmc_child) else [])
+
+    if args.pmc_child:                                   # a few untimed steps for the PMC passes
+        pdf = helpers.build_product(fx, dtypes[main_dt], dev)
+        pdf.check_status = "deferred"
+        pdf.fuse_conditional_blocks = not args.no_fuse
+        x = torch.from_numpy(x64).to(device=dev, dtype=dtypes[main_dt])
+        c = None if c64 is None else torch.from_numpy(c64).to(device=dev, dtype=dtypes[main_dt])
+        for _ in range(4):
+            pdf(x, conditional_input=c)
+        pdf.flush_status()
+        torch.cuda.synchronize()
+        return
+
     results = {}
     kernel_table = None
     two_launch = None
-    for dtype in (torch.float32, torch.float64):
+    for dname in order:
+        dtype = dtypes[dname]
         pdf = helpers.build_product(fx, dtype, dev)
+        pdf.check_status = "deferred"                 # throughput loop: status words are read back asynchronously and flushed inside the timed region
         pdf.fuse_conditional_blocks = not args.no_fuse
         x = torch.from_numpy(x64).to(device=dev, dtype=dtype)
+        c = None if c64 is None else torch.from_numpy(c64).to(device=dev, dtype=dtype)
         # N > 1: the per-row log-probs of every step are all-gathered (RCCL), asynchronously, while the next step computes
-        gather = parallel.PipelinedGather(B, dtype, dev) if world > 1 else None
+        gather = parallel.PipelinedGather(B, dtype, dev) if (world > 1 and total_rows % world == 0) else None
+        last = {}
 
         def step():
-            logp = pdf(x)[0]
+            logp = pdf(x, conditional_input=c)[0]
             if gather is not None:
                 gather.submit(logp)
-            return logp
+            last["logp"] = logp
 
-        for _ in range(args.warmup):
-            step()
-        if gather is not None:
-            gather.wait()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        timer = _hip.KernelTimer() if dtype == torch.float32 else None
-        t0 = time.perf_counter()
-        if timer is not None:
-            with timer:
-                for _ in range(args.steps):
-                    logp = step()
-        else:
-            for _ in range(args.steps):
-                logp = step()
-        pdf.flush_status()                            # deferred kernel status words of the timed steps: raises if any row went wrong
-        if gather is not None:
-            gather.wait()                             # every step's gather has landed inside the timed region
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-        if world > 1:
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+        def finish():
+            pdf.flush_status()                        # deferred kernel status words of the timed steps: raises if any row went wrong
+            if gather is not None:
+                gather.wait()                         # every step's gather has landed inside the timed region
+
+        timer = _hip.KernelTimer() if dname == main_dt else None
+        dt = parallel.timed_steps(step, args.steps, args.warmup, finish=finish, device=dev, timer=timer)
+        logp = last["logp"]
         # parity of what was just timed, against the float64 oracle (rank 0, 4096 rows)
         err = None
         if rank == 0:
             n_chk = min(4096, B)
-            o = helpers.build_oracle(fx).forward(x64[:n_chk])[0]
+            o = helpers.build_oracle(fx).forward(x64[:n_chk], None if c64 is None else c64[:n_chk])[0]
             err = float(np.max(np.abs(logp[:n_chk].double().cpu().numpy() - o)))
-        results[dtype] = dict(dt=dt, evals_per_s=world * B * args.steps / dt, ms_per_step=1e3 * dt / args.steps, err=err)
+        results[dname] = dict(dt=dt, evals_per_s=total_rows * args.steps / dt, ms_per_step=1e3 * dt / args.steps, err=err)
         if timer is not None:
             kernel_table = timer.summary()
-            if rank == 0 and pdf.fuse_conditional_blocks:
+            if rank == 0 and pdf.fuse_conditional_blocks and args.workload == "c3":
                 # for reference, outside the timed region: the same steps with the conditional block as two launches (jf_mlp2 + jf_gf_chain_inv),
                 # whose kernels have clean single-roof accountings (MFMA for the MLP, HBM for the g-chain reading the materialised block)
                 pdf.fuse_conditional_blocks = False
@@ -245,80 +390,69 @@ def main():
                 torch.cuda.synchronize()
                 two_launch = {"dt": time.perf_counter() - tt0, "table": t2.summary()}
                 pdf.fuse_conditional_blocks = True
-        del pdf, x
+        del pdf, x, c
 
     if world > 1:
         dist.barrier()
     if rank == 0:
-        r32, r64 = results[torch.float32], results[torch.float64]
-        # ---- roofline of the dominant kernel (float32 run).  Algorithmic bytes per row (SURVEY 8d / DESIGN.md), float32:
-        #   conditional g-chain (block 2):  x 4 + log_det 1 + params 548 + base 4 + log_det 1            = 558 scalars
-        #   dense layers: inputs + outputs of each launch (K + N scalars)
-        alg = {("jf_gf_chain_inv_f32", "per-sample"): 4 * 558, ("jf_gf_chain_inv_f32", "bcast"): 4 * 10,
-               ("jf_f_chain_inv_f32", "per-sample"): 4 * (2 + 1 + 10 + 2 + 1)}
+        rm = results[main_dt]
+        s = 4 if main_dt == "f32" else 8
+        # ---- roofline of the dominant kernel.  SURVEY 8d: the conditional blocks are priced against HBM on the MATERIALISED accounting
+        # (MLP reads its inputs and writes the block, the flow reads the block); a fused kernel moves almost none of it and may exceed 100 %.
         dom = max(kernel_table.items(), key=lambda kv: kv[1]["total_ms"])
         (kname, ktag), kstat = dom
         secs = kstat["mean_ms"] * 1e-3
-        flops_per_row = 0
-        fused = False
-        if kname.startswith("jf_linear"):
-            K = int(ktag.split("_")[0][1:]); N = int(ktag.split("_")[1][1:])
-            bytes_per_row = 4 * (K + N)
-            flops_per_row = 2 * K * N
-        elif kname.startswith("jf_cond_gf_chain"):
-            K1, H, N, D = (int(t[1:]) for t in ktag.split("_"))
-            # fused launch (MLP + g layers): SURVEY 8d "materialised" accounting = MLP (reads inputs, writes block) + flow (reads block);
-            # the block itself never reaches HBM, so the real traffic is only 4 (K1 + 2 D + 2) bytes per row
-            bytes_per_row = 4 * (K1 + N) + 4 * (D + 1 + N + D + 1)
-            flops_per_row = 2 * (K1 * H + H * N)
-            fused = True
-        elif kname.startswith("jf_mlp2"):
-            K1, H, N = (int(t[1:]) for t in ktag.split("_"))
-            bytes_per_row = 4 * (K1 + N)                       # MLP reads its inputs, writes the parameter block
-            flops_per_row = 2 * (K1 * H + H * N)
-        else:
-            bytes_per_row = alg.get((kname, ktag), 0)
+        bytes_per_row, flops_per_row, fused = kernel_accounting(kname, ktag, s)
+        if bytes_per_row is None:                        # per-sample g-chain: the block's row (C3 block 2: 548 floats, C5 block 0: 1224 doubles)
+            P = {"c3": 548, "c5": 1224}[args.workload]
+            D = {"c3": 4, "c5": 8}[args.workload]
+            bytes_per_row = s * (D + 1 + P + D + 1)
         hbm_gbs = bytes_per_row * B / secs / 1e9
-        # which roofline binds this kernel: time at the HBM peak vs time at the dense f32 MFMA peak (157.3 TFLOP/s, MI355X_MICROARCH.md)
-        t_hbm = bytes_per_row * B / (HBM_PEAK_GBS * 1e9)
-        t_mfma = flops_per_row * B / (MFMA_F32_PEAK_TFLOPS * 1e12)
-        if t_mfma > t_hbm:
-            achieved = flops_per_row * B / secs / 1e12
-            roofline = {"bound": "mfma", "kernel": "%s[%s]" % (kname, ktag), "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": None, "hbm_algorithmic_GBs": hbm_gbs,
-                        "hbm_frac": hbm_gbs / HBM_PEAK_GBS, "algorithmic_flops_per_launch": flops_per_row * B}
-        else:
-            roofline = {"bound": "hbm", "kernel": "%s[%s]" % (kname, ktag), "achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": hbm_gbs / HBM_PEAK_GBS, "traffic": None}
+        tr = traffic_of(traffic, kname, ktag)
+        roofline = {"bound": "hbm", "kernel": "%s[%s]" % (kname, ktag), "achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": hbm_gbs / HBM_PEAK_GBS, "traffic": tr["hbm_bytes_per_launch"] if tr else None,
+                    "traffic_detail": tr, "traffic_source": (traffic or {}).get("source"), "traffic_stale": bool((traffic or {}).get("stale")),
+                    "mean_launch_ms": kstat["mean_ms"], "algorithmic_bytes_per_launch": bytes_per_row * B}
         if fused:
             roofline["fused"] = True
-            roofline["note"] = ("amortisation MLP + its 4 g layers in one launch; the parameter block stays in LDS.  f32 MFMA and VALU work "
-                                "do not co-issue on a CDNA4 SIMD (scripts/probe/coexec.hip), so this kernel's floor is MFMA time + VALU time")
-        roofline["issue"] = pmc_issue(kname, ktag, B)
-        tr = pmc_traffic(kname, ktag, B)
-        roofline["traffic"] = tr["hbm_bytes_per_launch"] if tr else None
-        roofline["traffic_detail"] = tr
-        roofline.update({"mean_launch_ms": kstat["mean_ms"], "algorithmic_bytes_per_launch": bytes_per_row * B,
-                         "all_kernels_ms_per_step": {"%s[%s]" % k: round(v["total_ms"] / args.steps, 4) for k, v in sorted(kernel_table.items())}})
-        # the HBM-bound flow kernel the north star names (per-sample parameter blocks), reported alongside
-        gfk = kernel_table.get(("jf_gf_chain_inv_f32", "per-sample"))      # only with --no-fuse
-        if gfk is not None:
-            g = 4 * 558 * B / (gfk["mean_ms"] * 1e-3) / 1e9
-            roofline["gf_chain_per_sample"] = {"bound": "hbm", "achieved": g, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": g / HBM_PEAK_GBS,
-                                               "mean_launch_ms": gfk["mean_ms"], "algorithmic_bytes_per_launch": 4 * 558 * B,
-                                               "traffic": (pmc_traffic("jf_gf_chain_inv_f32", "per-sample", B) or {}).get("hbm_bytes_per_launch")}
+            roofline["note"] = ("amortisation MLP + its g layers in one launch: the per-sample parameter block never leaves the chip, so the SURVEY 8d "
+                                "(materialised-block) bytes are far more than the kernel moves -- see `traffic`")
+        if flops_per_row:
+            tf = flops_per_row * B / secs / 1e12
+            mf = {"algorithmic_TFLOPs": tf, "algorithmic_flops_per_launch": flops_per_row * B}
+            if kname.endswith("_split_f32"):
+                K1, H, L, D = (int(t[1:]) for t in ktag.split("_"))
+                executed = 2 * K1 * 128 + 6 * 2 * 128 * (L * 9 * 16)        # exact-f32 first layer + six bf16 passes over the padded 9 x 16 columns per layer
+                mf.update({"arithmetic": "3-way split bf16, 6 MFMA passes, f32 accumulate", "executed_bf16_TFLOPs": executed * B / secs / 1e12,
+                           "frac_of_bf16_peak": executed * B / secs / 1e12 / MFMA_BF16_PEAK_TFLOPS,
+                           "frac_of_f32_mfma_peak_equivalent": tf / MFMA_F32_PEAK_TFLOPS})
+            elif main_dt == "f32":
+                mf.update({"arithmetic": "exact f32 MFMA", "frac_of_f32_mfma_peak": tf / MFMA_F32_PEAK_TFLOPS})
+            else:
+                mf.update({"arithmetic": "f64 MFMA", "frac_of_f64_mfma_peak": tf / MFMA_F64_PEAK_TFLOPS})
+            roofline["mfma"] = mf
+        step_bytes = W["bytes_per_eval"][main_dt]
+        roofline["whole_step"] = {"algorithmic_bytes_per_eval": step_bytes, "achieved_GBs": step_bytes * B / (rm["ms_per_step"] * 1e-3) / 1e9,
+                                  "frac": step_bytes * B / (rm["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                  "note": "SURVEY 8d bytes of ALL blocks over the whole step time (the north-star >= 40 % figure)"}
+        roofline["all_kernels_ms_per_step"] = {"%s[%s]" % k: round(v["total_ms"] / args.steps, 4) for k, v in sorted(kernel_table.items())}
         line = {
-            "metric": "log-prob evals/sec (batch 2^20 per GPU), e4+s2+e4 / gggg+f+gggg",
-            "value": r32["evals_per_s"], "unit": "log-prob evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": r32["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "metric": W["metric"],
+            "value": rm["evals_per_s"], "unit": "log-prob evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": rm["ms_per_step"], "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": main_dt,
             "data": "synthetic (seeded; weights = frozen golden-fixture state_dict)",
-            "config": {"workload": 'pdf("%s","%s") log-prob, batch %d rows per GPU, unconditional pdf with autoregressive conditioning'
-                                   % (PDF_DEFS, FLOW_DEFS, B), "batch_per_gpu": B, "parallelism": "rows sharded over %d GPU(s)" % world},
-            "parity": {"max_abs_dlogp_vs_f64_oracle": r32["err"], "bar": 1e-2, "rows_checked": min(4096, B)},
-            "float64": {"value": r64["evals_per_s"], "ms_per_step": r64["ms_per_step"], "max_abs_dlogp_vs_f64_oracle": r64["err"], "bar": 1e-4},
+            "config": {"workload": 'pdf("%s","%s") log-prob, %s, %d rows %s' % (W["defs"][0], W["defs"][1], W["desc"],
+                                                                                  B if args.scaling == "weak" else total_rows,
+                                                                                  "per GPU" if args.scaling == "weak" else "in total, row-sharded"),
+                       "batch_per_gpu": B, "total_rows": total_rows, "parallelism": "rows sharded over %d GPU(s)" % world},
+            "n_ranks_seen": n_ranks_seen, "collective_backend": backend_name,
+            "parity": {"max_abs_dlogp_vs_f64_oracle": rm["err"], "bar": 1e-2 if main_dt == "f32" else 1e-4, "rows_checked": min(4096, B)},
             "roofline": roofline,
             "cpu_baseline": cpu,
         }
+        if "f64" in results and main_dt != "f64":
+            r64 = results["f64"]
+            line["float64"] = {"value": r64["evals_per_s"], "ms_per_step": r64["ms_per_step"], "max_abs_dlogp_vs_f64_oracle": r64["err"], "bar": 1e-4}
         if two_launch is not None:
             tb = two_launch["table"]
             ml = tb.get(("jf_mlp2_f32", "K7_H128_N548"))
@@ -328,12 +462,11 @@ def main():
             if ml is not None:
                 tf = 2 * (7 * 128 + 128 * 548) * B / (ml["mean_ms"] * 1e-3) / 1e12
                 blk["mlp2"] = {"bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TFLOPS,
-                               "mean_launch_ms": ml["mean_ms"], "traffic": (pmc_traffic("jf_mlp2_f32", "K7_H128_N548", B) or {}).get("hbm_bytes_per_launch")}
+                               "mean_launch_ms": ml["mean_ms"]}
             if gf is not None:
                 gb = 4 * 558 * B / (gf["mean_ms"] * 1e-3) / 1e9
                 blk["gf_chain_per_sample"] = {"bound": "hbm", "achieved": gb, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gb / HBM_PEAK_GBS,
-                                              "mean_launch_ms": gf["mean_ms"], "algorithmic_bytes_per_launch": 4 * 558 * B,
-                                              "traffic": (pmc_traffic("jf_gf_chain_inv_f32", "per-sample", B) or {}).get("hbm_bytes_per_launch")}
+                                              "mean_launch_ms": gf["mean_ms"], "algorithmic_bytes_per_launch": 4 * 558 * B}
             line["two_launch_path"] = blk
         print(json.dumps(line))
     if world > 1:

@@ -218,6 +218,15 @@ int jf_sphere_from_embedding_f32(const float* x, int64_t x_stride, const float* 
 int jf_sphere_from_embedding_f64(const double* x, int64_t x_stride, const double* log_det_in, int64_t B, int32_t dim, double* x_out,
                                  int64_t x_out_stride, double* log_det_out, void* stream);
 
+/* input rows of the amortisation MLPs in one launch: out row = the segments' contributions side by side, i.e.
+ * cat[conditional_input, embed(x_0), embed(x_1), ...] of main/default.py:946-962 with embed = identity for Euclidean / interval targets
+ * (kind 0, n_in columns copied), (cos, sin) for an S1 angle (kind 1) and (x, y, z) for S2 (theta, phi) (kind 2)
+ * (sphere_base.py:305-332, 786-794).  Block i's MLP reads a prefix of the row (autoregressive conditioning). */
+#define JF_MAX_SEGMENTS 16
+typedef struct jf_cond_segment { const void* src; int64_t stride; int32_t kind; int32_t n_in; } jf_cond_segment;
+int jf_conditioning_rows_f32(const jf_cond_segment* segments, int32_t n_segments, int64_t B, float* out, int64_t out_stride, void* stream);
+int jf_conditioning_rows_f64(const jf_cond_segment* segments, int32_t n_segments, int64_t B, double* out, int64_t out_stride, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * base-distribution log-prob: out[b] = (in ? in[b] : 0) + sum_d N(0,1).log_prob(z[b,d])
  * (torch.distributions.Normal(0,1).log_prob(base_pos).sum(-1), jammy_flows/main/default.py:1110-1115, 1657, 1670)

@@ -79,6 +79,11 @@ class jf_c_layer(ctypes.Structure):
                 ("lo", ctypes.c_double), ("hi", ctypes.c_double)]
 
 
+class jf_cond_segment(ctypes.Structure):
+    _fields_ = [("src", ctypes.c_void_p), ("stride", ctypes.c_int64), ("kind", ctypes.c_int32), ("n_in", ctypes.c_int32)]
+
+
+JF_MAX_SEGMENTS = 16
 MCHAIN_LAYER_TYPES = {"r": jf_r_layer, "o": jf_o_layer, "m": jf_m_layer, "f": jf_f_layer, "v": jf_v_layer, "c": jf_c_layer}
 
 _lib = None
@@ -98,6 +103,7 @@ _SIGNATURES = {
     "jf_mlp2": [_P, _I64, _P, _I64, _P, _P, _I64, _P, _I64, _I32, _I32, _I32, _P, _I64, _P],
     "jf_sphere_to_embedding": [_P, _I64, _P, _I64, _I32, _P, _I64, _P, _P],
     "jf_sphere_from_embedding": [_P, _I64, _P, _I64, _I32, _P, _I64, _P, _P],
+    "jf_conditioning_rows": [ctypes.POINTER(jf_cond_segment), _I32, _I64, _P, _I64, _P],
 }
 # entry points that exist for one precision only: full symbol name -> (argtypes, restype)
 _SIGNATURES_SINGLE = {
@@ -174,8 +180,8 @@ def _ptr(t):
     return None if t is None else t.data_ptr()
 
 
-def _stream():
-    return torch.cuda.current_stream().cuda_stream
+def _stream(dev=None):
+    return torch.cuda.current_stream(dev).cuda_stream
 
 
 class KernelTimer:
@@ -208,17 +214,25 @@ class KernelTimer:
 _TIMER = None
 
 
-def _launch(name, tag, args):
+def _launch(name, tag, args, dev):
+    """call entry point `name` with `args` + the stream argument.  The launch goes to the TENSORS' device (`dev`, from require_device) and to
+    torch's current stream OF THAT DEVICE -- not to whatever device happens to be current: the C side sizes grids with hipGetDevice and a
+    kernel launched on device 0 with device-1 pointers faults or computes on the wrong GPU."""
     fn = getattr(lib(), name)
-    if _TIMER is None:
-        rc = fn(*args)
-    else:
-        e0 = torch.cuda.Event(enable_timing=True)
-        e1 = torch.cuda.Event(enable_timing=True)
-        e0.record()
-        rc = fn(*args)
-        e1.record()
-        _TIMER.records.append((name, tag, e0, e1))
+    if dev is None:
+        raise HipUnavailable("%s: no device tensor among the arguments" % name)
+    with torch.cuda.device(dev):
+        stream = torch.cuda.current_stream(dev)
+        args = tuple(args) + (stream.cuda_stream,)
+        if _TIMER is None:
+            rc = fn(*args)
+        else:
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            rc = fn(*args)
+            e1.record(stream)
+            _TIMER.records.append((name, tag, e0, e1))
     _check(rc, name)
 
 
@@ -258,7 +272,7 @@ BINS_LOG = None
 def gf_chain(direction, x, log_det, params, layer_array, n_layers, D, x_out=None, base_logp_in=None, want_base_logp=False, status=None):
     """run a chain of g layers.  direction 'inv' (log-prob) or 'fwd' (sampling).
     x (B, D) view (row stride arbitrary), log_det (B,) or None, params (1|B, P).  Returns (x_out, log_det_out[, base_logp])."""
-    require_device(x, log_det, params, x_out, base_logp_in, status)
+    dev = require_device(x, log_det, params, x_out, base_logp_in, status)
     x = _rowmajor(x)
     params = _rowmajor(params)
     if params.dtype != x.dtype:
@@ -290,11 +304,11 @@ def gf_chain(direction, x, log_det, params, layer_array, n_layers, D, x_out=None
         blp_out = torch.empty((B,), dtype=x.dtype, device=x.device) if want_base_logp else None
         _launch("jf_gf_chain_inv" + suf, "bcast" if pb == 1 else "per-sample",
                 (_ptr(x), x.stride(0), _ptr(log_det), _ptr(params), params.stride(0), pb, B, D, n_layers, layer_array, _ptr(x_out),
-                 x_out.stride(0), _ptr(ld_out), _ptr(base_logp_in), _ptr(blp_out), _ptr(bins), bs, _ptr(status), _stream()))
+                 x_out.stride(0), _ptr(ld_out), _ptr(base_logp_in), _ptr(blp_out), _ptr(bins), bs, _ptr(status)), dev)
         return (x_out, ld_out, blp_out) if want_base_logp else (x_out, ld_out)
     _launch("jf_gf_chain_fwd" + suf, "bcast" if pb == 1 else "per-sample",
             (_ptr(x), x.stride(0), _ptr(log_det), _ptr(params), params.stride(0), pb, B, D, n_layers, layer_array, _ptr(x_out), x_out.stride(0),
-             _ptr(ld_out), _ptr(bins), bs, _ptr(status), _stream()))
+             _ptr(ld_out), _ptr(bins), bs, _ptr(status)), dev)
     return x_out, ld_out
 
 
@@ -303,7 +317,7 @@ COND_GF_MAX_IN, COND_GF_MAX_HIDDEN = 28, 128
 
 def cond_gf_chain_inv(inp, w1, b1, w2, b2, x, log_det, layer_array, n_layers, D, x_out=None, base_logp_in=None, want_base_logp=False, status=None):
     """amortisation MLP (Linear-tanh-Linear) + the chain of g layers it parametrises in ONE launch; the parameter block stays on chip."""
-    require_device(inp, w1, b1, w2, b2, x, log_det, x_out, base_logp_in, status)
+    dev = require_device(inp, w1, b1, w2, b2, x, log_det, x_out, base_logp_in, status)
     inp, w1, w2, x = _rowmajor(inp), _rowmajor(w1), _rowmajor(w2), _rowmajor(x)
     B, K1 = inp.shape
     H = w1.shape[0]
@@ -320,7 +334,7 @@ def cond_gf_chain_inv(inp, w1, b1, w2, b2, x, log_det, layer_array, n_layers, D,
     _launch("jf_cond_gf_chain_inv" + _suffix(x), "K%d_H%d_N%d_D%d" % (K1, H, w2.shape[0], D),
             (_ptr(inp), inp.stride(0), _ptr(w1), w1.stride(0), _ptr(b1.contiguous()), _ptr(w2), w2.stride(0), _ptr(b2.contiguous()), K1, H,
              _ptr(x), x.stride(0), _ptr(log_det), B, D, n_layers, layer_array, _ptr(x_out), x_out.stride(0), _ptr(ld_out), _ptr(base_logp_in),
-             _ptr(blp_out), _ptr(status), _stream()))
+             _ptr(blp_out), _ptr(status)), dev)
     return (x_out, ld_out, blp_out) if want_base_logp else (x_out, ld_out)
 
 
@@ -332,21 +346,21 @@ def cond_gf_packed_bytes(layer_array, n_layers, D):
 def cond_gf_pack(w2, b2, layer_array, n_layers, D):
     """W2 (N, H) / b2 (N,) of the amortisation MLP -> packed image for cond_gf_chain_inv_split (bf16 pieces in MFMA fragment order,
     rows permuted so that the MFMA result registers are the flow's parameter registers).  Redo whenever the weights change."""
-    require_device(w2, b2)
+    dev = require_device(w2, b2)
     w2 = _rowmajor(w2)
     if w2.dtype != torch.float32 or b2.dtype != torch.float32:
         raise TypeError("cond_gf_pack: float32 only")
     nbytes = cond_gf_packed_bytes(layer_array, n_layers, D)
     _check(min(nbytes, 0), "jf_cond_gf_packed_bytes")
     packed = torch.empty((nbytes,), dtype=torch.uint8, device=w2.device)
-    _launch("jf_cond_gf_pack_f32", "", (_ptr(w2), w2.stride(0), _ptr(b2.contiguous()), w2.shape[1], D, n_layers, layer_array, _ptr(packed), _stream()))
+    _launch("jf_cond_gf_pack_f32", "", (_ptr(w2), w2.stride(0), _ptr(b2.contiguous()), w2.shape[1], D, n_layers, layer_array, _ptr(packed)), dev)
     return packed
 
 
 def cond_gf_chain_inv_split(inp, w1, b1, packed, x, log_det, layer_array, n_layers, D, x_out=None, base_logp_in=None, want_base_logp=False,
                             status=None):
     """as cond_gf_chain_inv with the second product on split-bf16 MFMA and the parameter block in registers (float32, default layer options)."""
-    require_device(inp, w1, b1, packed, x, log_det, x_out, base_logp_in, status)
+    dev = require_device(inp, w1, b1, packed, x, log_det, x_out, base_logp_in, status)
     inp, w1, x = _rowmajor(inp), _rowmajor(w1), _rowmajor(x)
     B, K1 = inp.shape
     H = w1.shape[0]
@@ -362,13 +376,13 @@ def cond_gf_chain_inv_split(inp, w1, b1, packed, x, log_det, layer_array, n_laye
     blp_out = torch.empty((B,), dtype=x.dtype, device=x.device) if want_base_logp else None
     _launch("jf_cond_gf_chain_inv_split_f32", "K%d_H%d_L%d_D%d" % (K1, H, n_layers, D),
             (_ptr(inp), inp.stride(0), _ptr(w1), w1.stride(0), _ptr(b1.contiguous()), _ptr(packed), K1, H, _ptr(x), x.stride(0), _ptr(log_det), B, D,
-             n_layers, layer_array, _ptr(x_out), x_out.stride(0), _ptr(ld_out), _ptr(base_logp_in), _ptr(blp_out), _ptr(status), _stream()))
+             n_layers, layer_array, _ptr(x_out), x_out.stride(0), _ptr(ld_out), _ptr(base_logp_in), _ptr(blp_out), _ptr(status)), dev)
     return (x_out, ld_out, blp_out) if want_base_logp else (x_out, ld_out)
 
 
 def linear(inp, weight, bias=None, act=0, out=None):
     """out = act(inp @ weight^T + bias) on the matrix cores; act 0 identity / 1 tanh."""
-    require_device(inp, weight, bias, out)
+    dev = require_device(inp, weight, bias, out)
     inp = _rowmajor(inp)
     weight = _rowmajor(weight)
     if weight.dtype != inp.dtype or (bias is not None and bias.dtype != inp.dtype):
@@ -383,25 +397,48 @@ def linear(inp, weight, bias=None, act=0, out=None):
         out = torch.empty((B, N), dtype=inp.dtype, device=inp.device)
     suf = _suffix(inp)
     _launch("jf_linear" + suf, "K%d_N%d" % (K, N),
-            (_ptr(inp), inp.stride(0), _ptr(weight), weight.stride(0), _ptr(bias), B, K, N, act, _ptr(out), out.stride(0), _stream()))
+            (_ptr(inp), inp.stride(0), _ptr(weight), weight.stride(0), _ptr(bias), B, K, N, act, _ptr(out), out.stride(0)), dev)
+    return out
+
+
+def conditioning_rows(segments, B, dtype, device):
+    """segments: list of (tensor (B, n), kind) with kind 0 = copy the columns, 1 = S1 angle -> (cos, sin), 2 = S2 (theta, phi) -> (x, y, z).
+    Returns the (B, sum of output widths) row block cat[...] in ONE launch (the amortisation MLPs read prefixes of it)."""
+    if not 1 <= len(segments) <= JF_MAX_SEGMENTS:
+        raise ValueError("conditioning_rows: 1..%d segments" % JF_MAX_SEGMENTS)
+    arr = (jf_cond_segment * len(segments))()
+    width = 0
+    keep = []
+    dev = require_device(*[t for t, _ in segments])
+    for i, (t, kind) in enumerate(segments):
+        t = _rowmajor(t)
+        if t.dtype != dtype or t.shape[0] != B:
+            raise TypeError("conditioning_rows: segment %d has dtype %s / %d rows, expected %s / %d" % (i, t.dtype, t.shape[0], dtype, B))
+        if kind != 0 and t.shape[1] != kind:
+            raise ValueError("conditioning_rows: an S%d segment needs %d intrinsic columns" % (kind, kind))
+        keep.append(t)
+        arr[i] = jf_cond_segment(t.data_ptr(), t.stride(0), kind, t.shape[1])
+        width += t.shape[1] if kind == 0 else kind + 1
+    out = torch.empty((B, width), dtype=dtype, device=device)
+    _launch("jf_conditioning_rows" + _suffix(out), "", (arr, len(segments), B, _ptr(out), out.stride(0)), dev)
     return out
 
 
 def normal_logp(z, acc=None):
     """acc + sum_d N(0,1).log_prob(z[:, d]) -> (B,)"""
-    require_device(z, acc)
+    dev = require_device(z, acc)
     z = _rowmajor(z)
     B, D = z.shape
     out = torch.empty((B,), dtype=z.dtype, device=z.device)
     suf = _suffix(z)
-    _launch("jf_normal_logp" + suf, "", (_ptr(z), z.stride(0), B, D, _ptr(acc), _ptr(out), _stream()))
+    _launch("jf_normal_logp" + suf, "", (_ptr(z), z.stride(0), B, D, _ptr(acc), _ptr(out)), dev)
     return out
 
 
 def mchain(fam, direction, x, log_det, params, layer_structs, dim, x_out=None, base_logp_in=None, want_base_logp=False, bins=None, status=None):
     """run a chain of manifold layers of family `fam` ('r','o','m','f','v','c') on intrinsic coordinates.
     x (B, dim) view; params (1|B, P) or None when the chain has no parameters.  Returns (x_out, log_det_out[, base_logp])."""
-    require_device(x, log_det, params, x_out, base_logp_in, status, bins)
+    dev = require_device(x, log_det, params, x_out, base_logp_in, status, bins)
     x = _rowmajor(x)
     B = x.shape[0]
     if x.shape[1] != dim:
@@ -438,26 +475,31 @@ def mchain(fam, direction, x, log_det, params, layer_structs, dim, x_out=None, b
         assert bins.dtype == torch.int64 and bins.dim() == 2 and bins.shape[0] == B and bins.stride(1) == 1
     _launch(name, "bcast" if pb == 1 else "per-sample",
             (_ptr(x), x.stride(0), _ptr(log_det), pptr, pstride, pb, B, n, arr, _ptr(x_out), x_out.stride(0), _ptr(ld_out), _ptr(base_logp_in),
-             _ptr(blp_out), _ptr(bins), bins.stride(0) if bins is not None else 0, _ptr(status), _stream()))
+             _ptr(blp_out), _ptr(bins), bins.stride(0) if bins is not None else 0, _ptr(status)), dev)
     return (x_out, ld_out, blp_out) if want_base_logp else (x_out, ld_out)
 
 
-def sphere_embedding(x, log_det, dim, to_embedding):
-    """S1: angle <-> (cos, sin); S2: (theta, phi) <-> (x, y, z), with the log-det bookkeeping of sphere_base.py:242-335."""
-    require_device(x, log_det if isinstance(log_det, torch.Tensor) else None)
+def sphere_embedding(x, log_det, dim, to_embedding, want_log_det=True):
+    """S1: angle <-> (cos, sin); S2: (theta, phi) <-> (x, y, z), with the log-det bookkeeping of sphere_base.py:242-335:
+    S2 adds +log sin(theta) towards the embedding and -log sin(theta) back, S1 adds nothing.  `log_det` may be a (B,) tensor, None (= 0) or a
+    python number (the reference's public default ``log_det=0``): in every case the S2 Jacobian is included in what comes back, as a (B,)
+    tensor.  want_log_det=False skips it (callers that only need the coordinates)."""
+    is_tensor = isinstance(log_det, torch.Tensor)
+    dev = require_device(x, log_det if is_tensor else None)
     x = _rowmajor(x)
     B = x.shape[0]
-    ld_in = log_det if isinstance(log_det, torch.Tensor) else None
-    if ld_in is not None:
-        ld_in = ld_in.contiguous()
+    ld_in = log_det.contiguous() if is_tensor else None
     out = torch.empty((B, dim + 1 if to_embedding else dim), dtype=x.dtype, device=x.device)
-    # log_det: tensor -> updated tensor; None -> treated as zeros (a tensor comes back for S2); python scalar -> passed through untouched
-    want_ld = (log_det is None or isinstance(log_det, torch.Tensor)) and dim == 2
+    want_ld = want_log_det and dim == 2
     ld_out = torch.empty((B,), dtype=x.dtype, device=x.device) if want_ld else None
     suf = _suffix(x)
     name = ("jf_sphere_to_embedding" if to_embedding else "jf_sphere_from_embedding") + suf
-    _launch(name, "", (_ptr(x), x.stride(0), _ptr(ld_in), B, dim, _ptr(out), out.stride(0), _ptr(ld_out), _stream()))
-    return out, (ld_out if want_ld else log_det)
+    _launch(name, "", (_ptr(x), x.stride(0), _ptr(ld_in), B, dim, _ptr(out), out.stride(0), _ptr(ld_out)), dev)
+    if not want_ld:
+        return out, log_det                      # S1 (no Jacobian) or not asked for: handed back unchanged
+    if not is_tensor and log_det is not None and log_det != 0:
+        ld_out = ld_out + log_det                # numeric offset of the caller
+    return out, ld_out
 
 
 MLP2_MAX_IN, MLP2_MAX_HIDDEN = 32, 128
@@ -465,7 +507,7 @@ MLP2_MAX_IN, MLP2_MAX_HIDDEN = 32, 128
 
 def mlp2(inp, w1, b1, w2, b2, out=None):
     """tanh(inp @ w1^T + b1) @ w2^T + b2 in one launch (the hidden activations stay in registers, nothing but the result reaches HBM)."""
-    require_device(inp, w1, b1, w2, b2, out)
+    dev = require_device(inp, w1, b1, w2, b2, out)
     inp, w1, w2 = _rowmajor(inp), _rowmajor(w1), _rowmajor(w2)
     B, K1 = inp.shape
     H, N = w1.shape[0], w2.shape[0]
@@ -480,5 +522,5 @@ def mlp2(inp, w1, b1, w2, b2, out=None):
         out = torch.empty((B, (N + line - 1) // line * line), dtype=inp.dtype, device=inp.device)[:, :N]
     _launch("jf_mlp2" + _suffix(inp), "K%d_H%d_N%d" % (K1, H, N),
             (_ptr(inp), inp.stride(0), _ptr(w1), w1.stride(0), _ptr(b1.contiguous()), _ptr(w2), w2.stride(0), _ptr(b2.contiguous()), B, K1, H, N,
-             _ptr(out), out.stride(0), _stream()))
+             _ptr(out), out.stride(0)), dev)
     return out

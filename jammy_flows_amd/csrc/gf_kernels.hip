@@ -15,7 +15,6 @@
 //       KB, so 16+ waves per CU are resident and the HBM latency of one wave's slab is covered by the arithmetic of the others.
 //       HBM traffic is the algorithmic minimum (every parameter byte is read exactly once).
 #include "jf_gf.h"
-#include <cstdlib>
 
 namespace jf {
 
@@ -232,13 +231,11 @@ template <typename T, int G, bool FWD> static int launch_g(GfChainArgs<T> a, boo
         if (lds_bytes > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         // one wave of workgroups: every workgroup derives the parameters once and walks ceil(tiles / resident) row tiles, so the grid has
         // no partially filled last round (a 2.3-round grid idles a quarter of the chip in its tail)
-        static size_t cached_lds = ~(size_t)0;               // benign race: every thread computes the same value
-        static int resident = 0;
-        if (cached_lds != lds_bytes) { resident = resident_blocks(k, lds_bytes); cached_lds = lds_bytes; }
+        int resident = resident_blocks(k, lds_bytes);       // for the CURRENT device; two cheap runtime queries, no cross-thread cache
+        if (resident < 1) resident = 1;
         const int64_t n_tiles = (a.B + 256 / G - 1) / (256 / G);
         const int64_t tpb = (n_tiles + resident - 1) / resident;
         a.tiles_per_block = (int)(tpb < 1 ? 1 : tpb);
-        if (getenv("JF_TPB")) a.tiles_per_block = atoi(getenv("JF_TPB"));
         const unsigned grid = (unsigned)((n_tiles + a.tiles_per_block - 1) / a.tiles_per_block);
         hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds_bytes, st, a);
     } else {

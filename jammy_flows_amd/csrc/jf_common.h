@@ -203,8 +203,10 @@ __device__ inline void status_add(int32_t* status, int which, bool flag) {
     if (m != 0ull && (threadIdx.x & (JF_WAVE - 1)) == (unsigned)(__ffsll((long long)m) - 1)) atomicAdd(status + which, (int32_t)__popcll(m));
 }
 
+// launch status of the kernel just enqueued.  hipPeekAtLastError does not clear the sticky error state, so an error left behind by an
+// unrelated earlier call of the application is neither swallowed nor misattributed silently: it keeps surfacing until the caller handles it.
 inline int check_launch() {
-    hipError_t e = hipGetLastError();
+    hipError_t e = hipPeekAtLastError();
     return e == hipSuccess ? JF_OK : JF_ERR_LAUNCH;
 }
 

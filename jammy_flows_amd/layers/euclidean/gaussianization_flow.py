@@ -252,7 +252,16 @@ def chain_supported(layers):
 
 
 def chain_permanent_row(layers, like):
-    return torch.cat([l.permanent_row(like) for l in layers], dim=1) if len(layers) > 1 else layers[0].permanent_row(like)
+    """the permanent rows of a block's layers side by side (cached: rebuilt only when one of the layers' rows was)."""
+    rows = [l.permanent_row(like) for l in layers]
+    if len(rows) == 1:
+        return rows[0]
+    key = tuple(id(r) for r in rows)
+    hit = getattr(layers[0], "_chain_row_cache", None)
+    if hit is None or hit[0] != key:
+        hit = (key, torch.cat(rows, dim=1), rows)          # `rows` keeps the ids alive
+        layers[0]._chain_row_cache = hit
+    return hit[1]
 
 
 def run_chain(layers, direction, x, log_det, params, x_out=None, base_logp_in=None, want_base_logp=False, status=None):

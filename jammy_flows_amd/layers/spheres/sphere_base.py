@@ -163,7 +163,7 @@ class sphere_base(layer_base.layer_base):
 
     def _embedding_conditional_return(self, x):
         if x.shape[1] == self.dimension:
-            x, _ = self.spherical_to_eucl_embedding(x, 0.0)
+            x, _ = _hip.sphere_embedding(x, None, self.dimension, True, want_log_det=False)
         return x
 
     def _embedding_conditional_return_num(self):

@@ -114,8 +114,10 @@ class pdf(nn.Module):
             assert amortization_mlp_use_custom_mode, "Amortizing all MLPs requires custom MLPs."
             self.total_number_amortizable_params = 0
         # kernel status words (rows with out-of-range spline inputs, non-finite results, non-converged Newton rows) -> the reference's
-        # exceptions / warnings.  True: sampling checks after every call; log-prob calls read the words back asynchronously and raise at
-        # the next call or in flush_status().  "immediate": blocking check after every call.  False: never.
+        # exceptions / warnings.  True (default) / "immediate": checked before the call returns, so the exception belongs to the batch that
+        # caused it, like the reference's (spline_fns.py:57-59, default.py:1516).  "deferred": log-prob calls copy the words to pinned host memory
+        # asynchronously and raise at the next call or in flush_status() (saves one host-device round trip per call; throughput loops
+        # such as bench.py opt into it and flush inside their timed region).  False: never.
         self.check_status = True
         # conditional e-blocks (Linear-tanh-Linear MLP + g layers, D in {3,4}, float32) as ONE launch with the parameter block kept on chip
         # (jf_cond_gf_chain_inv): +9 % on the C3 step against jf_mlp2 + jf_gf_chain_inv.  False selects the two-launch path.
@@ -373,7 +375,42 @@ class pdf(nn.Module):
         return first.dtype, first.device
 
     # =========================================================================================== parameter routing
+    def _conditioning_rows(self, x, data_summary):
+        """log-prob direction: every target is known up front, so the input rows of all amortisation MLPs,
+        cat[conditional_input, embed(x_0), embed(x_1), ...] (:946-962), are laid out by ONE launch; block si reads the prefix
+        ``rows[:, :prefix[si]]`` (no torch.cat, no separate embedding launches).  None when nothing needs them / a per-block summary list."""
+        if type(data_summary) == list or len(self.mlp_predictors) == 0 or all(m is None for m in self.mlp_predictors):
+            return None
+        segs, prefix, width = [], [], 0
+        if data_summary is not None:
+            segs.append((data_summary, 0))
+            width = data_summary.shape[1]
+        for si, block in enumerate(self.layer_list):
+            prefix.append(width)
+            a, b = self.target_dim_indices[si]
+            last = block[-1]
+            kind = 0
+            if self.pdf_defs_list[si][0] == "s" and (b - a) == last.dimension:
+                kind = last.dimension                                            # intrinsic angles -> embedding (sphere_base.py:786-794)
+            segs.append((x[:, a:b], kind))
+            width += last._embedding_conditional_return_num()
+        need = max([prefix[si] for si, m in enumerate(self.mlp_predictors) if m is not None])
+        keep, w = [], 0
+        for t, kind in segs:                                                     # only the segments some MLP reads
+            if w >= need:
+                break
+            keep.append((t, kind))
+            w += t.shape[1] if kind == 0 else kind + 1
+        if not keep or len(keep) > _hip.JF_MAX_SEGMENTS:
+            return None
+        return {"rows": _hip.conditioning_rows(keep, x.shape[0], x.dtype, x.device), "prefix": prefix}
+
     def _mlp_input(self, si, data_summary, embeds):
+        if isinstance(embeds, dict):
+            n = embeds["prefix"][si]
+            if n == 0:
+                raise Exception("extra conditional input is empty but required for encoding!")
+            return embeds["rows"][:, :n]
         if data_summary is not None:
             inp = data_summary[si] if type(data_summary) == list else data_summary
             if len(embeds) > 0:
@@ -420,14 +457,7 @@ class pdf(nn.Module):
         """extra_inputs row block of sub-pdf si, or None for permanent parameters (:936-993, 1420-1475)."""
         mlp = self.mlp_predictors[si] if len(self.mlp_predictors) > si else None
         if mlp is not None:
-            if data_summary is not None:
-                inp = data_summary[si] if type(data_summary) == list else data_summary
-                if len(embeds) > 0:
-                    inp = torch.cat([inp] + embeds, dim=1)
-            elif len(embeds) > 0:
-                inp = torch.cat(embeds, dim=1) if len(embeds) > 1 else embeds[0]
-            else:
-                raise Exception("extra conditional input is empty but required for encoding!")
+            inp = self._mlp_input(si, data_summary, embeds)
             if amort is not None:
                 n = mlp.num_amortization_params
                 out = mlp(inp, extra_inputs=amort[:, counter:counter + n])
@@ -464,12 +494,12 @@ class pdf(nn.Module):
         return ring
 
     def _defer_status(self, status):
-        """log-prob direction: copy the status words to pinned host memory WITHOUT synchronising; they are examined when the copy has
-        landed -- at the next call into this pdf or in flush_status() -- so a step does not end in a host-device round trip.
-        check_status = "immediate" restores a blocking check after every call."""
+        """check_status == "deferred": copy the status words to pinned host memory WITHOUT synchronising; they are examined when the copy has
+        landed -- at the next call into this pdf or in flush_status() -- so a step does not end in a host-device round trip.  Any other
+        truthy setting checks before returning."""
         if status is None or not self.check_status:
             return
-        if self.check_status == "immediate":
+        if self.check_status != "deferred":
             return self._report_status(status)
         ring = self._status_ring(status.device)
         if len(ring["pending"]) == len(ring["host"]):
@@ -524,7 +554,10 @@ class pdf(nn.Module):
         B = x.shape[0]
         base = torch.empty((B, self.total_base_dim), dtype=x.dtype, device=x.device)
         base_logp = None
-        embeds = []
+        embeds = self._conditioning_rows(x, data_summary)
+        lazy = embeds is None
+        if lazy:
+            embeds = []
         counter = 0
         for si, block in enumerate(self.layer_list):
             a, b = self.target_dim_indices[si]
@@ -551,7 +584,8 @@ class pdf(nn.Module):
                 log_det = res[1]
                 if want_base_logp:
                     base_logp = res[2]
-                embeds.append(block[-1]._embedding_conditional_return(tgt))
+                if lazy:
+                    embeds.append(block[-1]._embedding_conditional_return(tgt))
                 continue
             extra, counter = self._block_params(si, data_summary, embeds, amortization_parameters, counter)
             if only_last:
@@ -597,7 +631,8 @@ class pdf(nn.Module):
                 out_view.copy_(cur)
                 if want_base_logp:
                     base_logp = _hip.normal_logp(out_view, base_logp)
-            embeds.append(block[-1]._embedding_conditional_return(tgt))
+            if lazy:
+                embeds.append(block[-1]._embedding_conditional_return(tgt))
         return base, log_det, base_logp
 
     def all_layer_inverse(self, x, log_det, data_summary, amortization_parameters=None, force_embedding_coordinates=False,

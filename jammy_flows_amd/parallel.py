@@ -95,3 +95,40 @@ class PipelinedGather:
                 w.wait()
                 self.work[j] = None
         return self.out[(self.i - 1) % len(self.out)] if self.i else None
+
+
+def timed_steps(step, steps, warmup, finish=None, device=None, timer=None):
+    """the benchmark contract's timing loop: `warmup` untimed calls of step(), then EXACTLY `steps` calls bracketed by a barrier + device
+    synchronisation on both sides; returns the wall time in seconds, MAX over ranks.  `finish()` (optional) runs inside the timed region after
+    the last step (flush deferred status words, wait for outstanding gathers).  `device`: the rank's torch device (None / cpu: no device sync,
+    which is how the world-size-2 gloo tests drive this loop without a GPU).  `timer`: optional context manager active during the timed steps
+    (per-kernel HIP events)."""
+    import contextlib
+    import time
+    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    on_gpu = device is not None and torch.device(device).type == "cuda"
+
+    def fence():
+        if multi:
+            dist.barrier()
+        if on_gpu:
+            torch.cuda.synchronize(device)
+
+    for _ in range(warmup):
+        step()
+    if finish is not None:
+        finish()
+    fence()
+    t0 = time.perf_counter()
+    with (timer if timer is not None else contextlib.nullcontext()):
+        for _ in range(steps):
+            step()
+    if finish is not None:
+        finish()
+    fence()
+    dt = time.perf_counter() - t0
+    if multi:
+        t = torch.tensor([dt], dtype=torch.float64, device=device if on_gpu else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt

@@ -66,24 +66,49 @@ def test_logprob_float64_vs_reference(fx):
     assert max_rel(logp, o_logp) < tol
 
 
+F32_ABS_BAR = 1e-2            # north-star float32 bar, absolute
+F32_BIG = 1e4                 # |log p| beyond which a float32 RESULT cannot carry 1e-2 absolute any more (ulp(1e4) = 1e-3, and the sum of
+                              # ~20 terms of that size that make up such a log-prob each round at that level): those rows are held to
+                              # 16 float32 ulps of the value instead, and are counted, not hidden
+FUSABLE = {"c3_e4s2e4", "c3b_e4s2e4_fsplines", "g_e3_ggg_cond"}     # conditional e-blocks of D in {3, 4} with the default MLP
+
+
+def assert_float32_parity(got, ref, ok, what):
+    """got: float32 kernel result, ref: float64 reference (golden), ok: rows representable in float32."""
+    got = np.asarray(got, dtype=np.float64)[ok]
+    ref = np.asarray(ref, dtype=np.float64)[ok]
+    assert np.isfinite(got).all(), "%s: float32 path must stay finite where the float64 reference is (SURVEY D9)" % what
+    err = np.abs(got - ref)
+    small = np.abs(ref) < F32_BIG
+    worst = float(err[small].max()) if small.any() else 0.0
+    print("%s: max |dlogp| = %.3e over %d rows with |logp| < 1e4 (bar %.0e); %d deep-tail rows, worst %.2f float32 ulps"
+          % (what, worst, int(small.sum()), F32_ABS_BAR, int((~small).sum()),
+             float((err[~small] / np.spacing(np.abs(ref[~small]).astype(np.float32)).astype(np.float64)).max()) if (~small).any() else 0.0))
+    assert worst < F32_ABS_BAR, "%s: max |dlogp| = %.3e at logp %.3f" % (what, worst, ref[small][err[small].argmax()])
+    if (~small).any():
+        ulps = err[~small] / np.spacing(np.abs(ref[~small]).astype(np.float32)).astype(np.float64)
+        assert (ulps < 16).all(), "%s: deep-tail row off by %.1f float32 ulps" % (what, ulps.max())
+
+
 @pytest.mark.parametrize("fx", SUPPORTED, ids=IDS)
 def test_logprob_float32_vs_float64_reference(fx):
+    from jammy_flows_amd import _hip
     if "v" in fx.flow_defs:
         pytest.skip("'v' asserts float64 in the reference (exponential_map_s2.py:450)")
     pdf = build_product(fx, torch.float32)
-    pdf.check_status = False     # rows outside the float32-representable domain (below) may legitimately be non-finite
-    x = to_dev(fx["x"], torch.float32)
-    cond = to_dev(fx.get("cond"), torch.float32)
-    logp, logp_base, base = pdf(x, conditional_input=cond, force_embedding_coordinates=fx.meta["embedding"])
     ok = float32_domain_mask(fx)
     assert ok.sum() >= fx["x"].shape[0] - 8
-    got = logp.double().cpu().numpy()[ok]
-    assert np.isfinite(got).all(), "float32 path must stay finite where the float64 reference is (SURVEY D9)"
-    ref = fx["logp"][ok]
-    err = np.abs(got - ref)
-    # inputs were rounded to float32 first: allow for the input-rounding sensitivity of rows deep in the tails (|logp| ~ 1e3..1e4)
-    bar = 1e-2 + 2e-6 * np.abs(ref)
-    assert (err < bar).all(), "max |dlogp| = %.3e at row %d (logp %.3f)" % (err.max(), err.argmax(), ref[err.argmax()])
+    # rows outside the float32-representable domain may legitimately be non-finite: only then are the status words not turned into
+    # exceptions; every fixture whose rows all survive the rounding runs with the (default, immediate) check on
+    pdf.check_status = bool(ok.all())
+    x = to_dev(fx["x"], torch.float32)
+    cond = to_dev(fx.get("cond"), torch.float32)
+    timer = _hip.KernelTimer()
+    with timer:
+        logp, logp_base, base = pdf(x, conditional_input=cond, force_embedding_coordinates=fx.meta["embedding"])
+    if fx.name in FUSABLE:       # the default float32 hot kernel is what these golden values are compared with
+        assert any(k[0] == "jf_cond_gf_chain_inv_split_f32" for k in timer.summary()), sorted(timer.summary())
+    assert_float32_parity(logp.double().cpu().numpy(), fx["logp"], ok, fx.name)
 
 
 @pytest.mark.parametrize("fx", SUPPORTED, ids=IDS)
@@ -250,43 +275,89 @@ def test_spline_bins_bit_exact_sampling_float64(fx):
 
 
 # ----------------------------------------------------------------------------------------------------------------------
-# fused conditional block (amortisation MLP + g layers in one launch, jf_cond_gf_chain_inv): same results as the two-launch path
+# fused conditional block (amortisation MLP + g layers in one launch): each matrix arithmetic against the golden float64 values, the kernel
+# that ran asserted by name, and the three paths against each other
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["c3_e4s2e4", "c3b_e4s2e4_fsplines", "g_e3_ggg_cond"])
-def test_fused_conditional_block_matches_two_launch_path(name):
+@pytest.mark.parametrize("name", sorted(FUSABLE))
+def test_fused_conditional_block_vs_golden_and_two_launch_path(name):
     from jammy_flows_amd import _hip
     fx = [f for f in ALL_FIXTURES if f.name == name][0]
     pdf = build_product(fx, torch.float32)
     x = to_dev(fx["x"], torch.float32)
     cond = to_dev(fx.get("cond"), torch.float32)
     emb = bool(fx.meta["embedding"])
-    pdf.check_status = False                      # the adversarial fixture rows are not representable in float32
-    pdf.fuse_conditional_blocks = False
-    ref = pdf(x, conditional_input=cond, force_embedding_coordinates=emb)
-    pdf.fuse_conditional_blocks = True
-    timer = _hip.KernelTimer()
-    with timer:
-        got = pdf(x, conditional_input=cond, force_embedding_coordinates=emb)
-    assert any(k[0].startswith("jf_cond_gf_chain_inv") for k in timer.summary()), "fused kernel was not used"
-    ok = torch.isfinite(ref[0]) & torch.isfinite(got[0])
-    assert ok.float().mean() > 0.9
-    # identical arithmetic per row up to the MFMA tile shape (16x16x4 vs 32x32x2 summation order)
-    assert max_abs(got[0][ok], ref[0][ok]) < 2e-3
-    assert max_abs(got[2][ok], ref[2][ok]) < 2e-3
+    ok = float32_domain_mask(fx)
+    pdf.check_status = bool(ok.all())
+    out = {}
+    for mode, kernel in (("two", "jf_gf_chain_inv_f32"), ("f32", "jf_cond_gf_chain_inv_f32"), ("split_bf16", "jf_cond_gf_chain_inv_split_f32")):
+        pdf.fuse_conditional_blocks = mode != "two"
+        pdf.fused_matrix_arithmetic = mode
+        timer = _hip.KernelTimer()
+        with timer:
+            out[mode] = pdf(x, conditional_input=cond, force_embedding_coordinates=emb)
+        ran = sorted(set(k[0] for k in timer.summary()))
+        assert kernel in ran, (mode, ran)
+        if mode != "split_bf16":
+            assert "jf_cond_gf_chain_inv_split_f32" not in ran
+        assert_float32_parity(out[mode][0].double().cpu().numpy(), fx["logp"], ok, "%s [%s]" % (name, mode))
+    sel = torch.from_numpy(ok).cuda()
+    for mode in ("f32", "split_bf16"):
+        # per row the same flow arithmetic; the parameters differ by the summation order / the 3 * 2^-24 split residue of the 128-term products
+        scale = 1.0 + out["two"][0][sel].abs()
+        assert float(((out[mode][0][sel] - out["two"][0][sel]).abs() / scale).max()) < 2e-5, mode
+        assert max_abs(out[mode][2][sel], out["two"][2][sel]) < 2e-3, mode
+
+
+def test_packed_image_follows_the_weights():
+    """the split-bf16 image of W2 / b2 is rebuilt when the weights change in place (optimizer step) or are replaced (load_state_dict)"""
+    fx = [f for f in ALL_FIXTURES if f.name == "g_e3_ggg_cond"][0]
+    pdf = build_product(fx, torch.float32)
+    x = to_dev(fx["x"], torch.float32)
+    cond = to_dev(fx.get("cond"), torch.float32)
+    pdf.check_status = False
+    a = pdf(x, conditional_input=cond)[0]
+    with torch.no_grad():
+        pdf.mlp_predictors[0][2].bias.add_(0.01)
+    b = pdf(x, conditional_input=cond)[0]
+    pdf.fused_matrix_arithmetic = "f32"
+    c = pdf(x, conditional_input=cond)[0]
+    fin = torch.isfinite(a) & torch.isfinite(b) & torch.isfinite(c)
+    assert float((a - b)[fin].abs().max()) > 1e-4, "stale packed weights were used"
+    assert float(((b - c)[fin].abs() / (1 + c[fin].abs())).max()) < 2e-5
+
+
+def test_transform_target_space_keeps_the_s2_jacobian_for_scalar_log_det():
+    """public default log_det=0 (a python number): the +-log sin(theta) of S2 must come back as a tensor (sphere_base.py:242-335, 796-841)"""
+    import jammy_flows_amd
+    pdf = jammy_flows_amd.pdf("e1+s2", "g+f").double().cuda()
+    g = torch.Generator().manual_seed(5)
+    x = torch.cat([torch.randn(64, 1, generator=g, dtype=torch.float64), torch.rand(64, 1, generator=g, dtype=torch.float64) * 3.0 + 0.07,
+                   torch.rand(64, 1, generator=g, dtype=torch.float64) * 6.2], dim=1).cuda()
+    emb, ld = pdf.transform_target_space(x)                       # default -> embedding, log_det = 0
+    assert isinstance(ld, torch.Tensor) and ld.shape == (64,)
+    assert max_abs(ld, torch.log(torch.sin(x[:, 1]))) < 1e-12
+    back, ld2 = pdf.transform_target_space(emb, log_det=0.25, transform_from="embedding", transform_to="default")
+    assert max_abs(back, x) < 1e-9
+    assert max_abs(ld2, 0.25 - torch.log(torch.sin(x[:, 1]))) < 1e-9
+    emb3, ld3 = pdf.transform_target_space(x, log_det=ld)         # tensor log_det accumulates
+    assert max_abs(ld3, 2 * torch.log(torch.sin(x[:, 1]))) < 1e-12
 
 
 # ----------------------------------------------------------------------------------------------------------------------
-# kernel status words -> exceptions: immediately ("immediate") or at the next call / flush_status() (default, no host sync)
+# kernel status words -> exceptions: before the call returns (default), or at the next call / flush_status() ("deferred", no host sync)
 @pytest.mark.gpu
 def test_status_words_raise_like_the_reference():
     fx = [f for f in ALL_FIXTURES if f.name == "c4_i1s1_ro"][0]
     pdf = build_product(fx, torch.float64)
     x = to_dev(fx["x"], torch.float64).clone()
     x[3, 0] = 1.5                                   # outside the interval: 'r' clamps it onto the boundary, whose chart image is infinite
-    pdf.check_status = "immediate"
+    assert pdf.check_status is True                 # the default: the exception belongs to the call that caused it, like the reference's
     with pytest.raises(Exception, match="nonfinite|outside boundaries"):
         pdf(x)
-    pdf.check_status = True
+    pdf32 = build_product(fx, torch.float32)        # the float32 kernels report the same way
+    with pytest.raises(Exception, match="nonfinite|outside boundaries"):
+        pdf32(x.float())
+    pdf.check_status = "deferred"
     pdf(x)                                          # deferred: no host synchronisation inside the call ...
     with pytest.raises(Exception, match="nonfinite|outside boundaries"):
         pdf.flush_status()                          # ... the problem surfaces here (or at the next call)

@@ -18,7 +18,7 @@ SUPPORTED = [fx for fx in ALL_FIXTURES if helpers.product_supports(fx)]
 def test_library_exports_every_declared_symbol():
     from jammy_flows_amd import _hip
     header = open(os.path.join(ROOT, "include", "jammy_hip.h")).read()
-    declared = set(re.findall(r"\bint\s+(jf_[a-z0-9_]+)\s*\(", header))
+    declared = set(re.findall(r"\bint(?:64_t)?\s+(jf_[a-z0-9_]+)\s*\(", header))
     for fam, suffix in re.findall(r"^JF_DECLARE_MCHAIN\((\w+),\s*\w+,\s*(\w+)\)", header, flags=re.M):   # macro-declared chain entry points
         declared |= {"jf_%s_chain_inv_%s" % (fam, suffix), "jf_%s_chain_fwd_%s" % (fam, suffix)}
     assert declared == set(_hip.exported_symbols()), declared ^ set(_hip.exported_symbols())

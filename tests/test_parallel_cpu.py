@@ -108,3 +108,55 @@ def test_pipelined_gather_single_process():
     pg = parallel.PipelinedGather(4, torch.float32, torch.device("cpu"))
     a = pg.submit(torch.arange(4, dtype=torch.float32))
     assert torch.equal(pg.wait(), torch.arange(4, dtype=torch.float32)) and a.shape[0] == 4
+
+
+def _loop_worker(rank, world, port, q):
+    """the bench.py step loop (parallel.timed_steps + PipelinedGather, weak and strong row sharding) with a stand-in evaluate, world 2 on gloo"""
+    import time
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ok = True
+        for scaling, total in (("weak", None), ("strong", 130)):
+            if scaling == "weak":
+                n = 64
+            else:
+                lo, hi = parallel.shard_bounds(total, rank, world)
+                n = hi - lo
+            x = torch.arange(n, dtype=torch.float64) + 1000 * rank
+            gather = parallel.PipelinedGather(n, torch.float64, torch.device("cpu"))
+            calls = {"step": 0, "finish": 0}
+
+            def step():
+                calls["step"] += 1
+                if rank == 1:
+                    time.sleep(0.01)                      # the slow rank sets the job's time (MAX over ranks)
+                gather.submit(x * 2.0)
+
+            def finish():
+                calls["finish"] += 1
+                gather.wait()
+
+            dt = parallel.timed_steps(step, steps=5, warmup=2, finish=finish, device=None)
+            ok = ok and calls["step"] == 7 and calls["finish"] == 2 and dt >= 0.05
+            full = gather.wait()
+            expect = torch.cat([(torch.arange(n, dtype=torch.float64) + 1000 * r) * 2.0 for r in range(world)])
+            ok = ok and bool(torch.equal(full, expect))
+        q.put((rank, ok))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bench_step_loop_gloo_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_loop_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(r for r, _ in res) == [0, 1]
+    assert all(ok for _, ok in res)
