@@ -303,6 +303,7 @@ def main():
     import helpers
     from jammy_flows_amd import _hip, parallel
 
+    torch.set_grad_enabled(False)        # a log-prob EVALUATION benchmark: no autograd graph (under grad mode pdf.forward builds one, like the reference)
     # one rank per GPU.  (JF_BENCH_BACKEND=gloo lets the multi-process logic be exercised on a box with fewer GPUs than ranks: the ranks
     # then share devices round-robin, which RCCL refuses; never used for reported numbers.)
     backend = os.environ.get("JF_BENCH_BACKEND", "nccl")

@@ -86,6 +86,23 @@ int jf_gf_chain_fwd_f64(const double* z, int64_t z_stride, const double* log_det
                         int32_t param_batch, int64_t B, int32_t D, int32_t n_layers, const jf_gf_layer* layers, double* x_out,
                         int64_t x_out_stride, double* log_det_out, int64_t* bins, int64_t bins_stride, int32_t* status, void* stream);
 
+/* Backward of jf_gf_chain_inv_* (classic stretch): vector-Jacobian product for upstream gradients g_x_out (B, D; nullable = 0),
+ * g_log_det (B; nullable) and g_base_logp (B; nullable) of the three outputs -- what torch.autograd computes by replaying
+ * gf_block._inv_flow_mapping (gaussianization_flow.py:995-1114) + the offset (euclidean_base.py:34-51) layer by layer.  The kernel re-runs
+ * the chain itself (nothing has to be saved by the forward launch) and writes g_x (B, D) and g_params:
+ *   param_batch == B: (B, P) rows in the layout of `params` (what the amortisation MLP's backward consumes);
+ *   param_batch == 1: jf_gf_chain_inv_bwd_partials(B, D) rows of partial sums (one per workgroup, deterministic), to be added up by the caller.
+ * The gradients of log_det_in and base_logp_in are g_log_det and g_base_logp themselves. */
+int64_t jf_gf_chain_inv_bwd_partials(int64_t B, int32_t D);
+int jf_gf_chain_inv_bwd_f32(const float* x, int64_t x_stride, const float* params, int64_t param_stride, int32_t param_batch, int64_t B,
+                            int32_t D, int32_t n_layers, const jf_gf_layer* layers, const float* g_x_out, int64_t g_x_out_stride,
+                            const float* g_log_det, const float* g_base_logp, float* g_x, int64_t g_x_stride, float* g_params,
+                            int64_t g_params_stride, int32_t* status, void* stream);
+int jf_gf_chain_inv_bwd_f64(const double* x, int64_t x_stride, const double* params, int64_t param_stride, int32_t param_batch, int64_t B,
+                            int32_t D, int32_t n_layers, const jf_gf_layer* layers, const double* g_x_out, int64_t g_x_out_stride,
+                            const double* g_log_det, const double* g_base_logp, double* g_x, int64_t g_x_stride, double* g_params,
+                            int64_t g_params_stride, int32_t* status, void* stream);
+
 /* A whole conditional / autoregressive Euclidean block in ONE launch, log-prob direction: the default amortisation MLP
  * params = tanh(in @ W1^T + b1) @ W2^T + b2  (nn.Sequential(Linear, Tanh, Linear), main/default.py:656-670, input = cat of conditional
  * input and the embeddings of the previous sub-manifolds, :946-962) followed by jf_gf_chain_inv on those per-sample parameters
@@ -206,6 +223,29 @@ JF_DECLARE_MCHAIN(v, float, f32) /* returns JF_ERR_UNSUPPORTED: the reference as
 JF_DECLARE_MCHAIN(v, double, f64)
 JF_DECLARE_MCHAIN(c, float, f32) /* x has 2 columns for kind 2, else 1 */
 JF_DECLARE_MCHAIN(c, double, f64)
+
+/* Backward of jf_<fam>_chain_inv_*: vector-Jacobian product for upstream gradients of (x_out, log_det_out, base_logp_out) (each nullable = 0),
+ * i.e. torch.autograd over the layer loop of all_layer_inverse (main/default.py:998-1031) for a manifold block.  Evaluated in forward mode:
+ * one pass of the chain per input direction on dual numbers through the same device code as the forward kernels.  g_x (B, dim);
+ * g_params: (B, P) for per-sample parameters; for param_batch == 1 the row sums are ADDED into g_params (1, P) (zero it first).
+ * g_log_det_in = g_log_det, g_base_logp_in = g_base_logp (pass through). */
+#define JF_DECLARE_MCHAIN_BWD(fam, T, suffix)                                                                                          \
+    int jf_##fam##_chain_inv_bwd_##suffix(const T* x, int64_t x_stride, const T* params, int64_t param_stride, int32_t param_batch,       \
+                                          int64_t B, int32_t n_layers, const jf_##fam##_layer* layers, const T* g_x_out,                  \
+                                          int64_t g_x_out_stride, const T* g_log_det, const T* g_base_logp, T* g_x, int64_t g_x_stride,  \
+                                          T* g_params, int64_t g_params_stride, int32_t* status, void* stream);
+JF_DECLARE_MCHAIN_BWD(r, float, f32)
+JF_DECLARE_MCHAIN_BWD(r, double, f64)
+JF_DECLARE_MCHAIN_BWD(o, float, f32)
+JF_DECLARE_MCHAIN_BWD(o, double, f64)
+JF_DECLARE_MCHAIN_BWD(m, float, f32)
+JF_DECLARE_MCHAIN_BWD(m, double, f64)
+JF_DECLARE_MCHAIN_BWD(f, float, f32)
+JF_DECLARE_MCHAIN_BWD(f, double, f64)
+JF_DECLARE_MCHAIN_BWD(v, float, f32) /* JF_ERR_UNSUPPORTED ('v' is float64 only) */
+JF_DECLARE_MCHAIN_BWD(v, double, f64)
+JF_DECLARE_MCHAIN_BWD(c, float, f32)
+JF_DECLARE_MCHAIN_BWD(c, double, f64)
 
 /* intrinsic <-> embedding coordinates of S1 (angle <-> (cos, sin)) and S2 ((theta, phi) <-> (x, y, z)) with the log-det of
  * sphere_base.spherical_to_eucl_embedding / eucl_to_spherical_embedding (sphere_base.py:242-335); dim = 1 or 2 */

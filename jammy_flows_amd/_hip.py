@@ -104,9 +104,11 @@ _SIGNATURES = {
     "jf_sphere_to_embedding": [_P, _I64, _P, _I64, _I32, _P, _I64, _P, _P],
     "jf_sphere_from_embedding": [_P, _I64, _P, _I64, _I32, _P, _I64, _P, _P],
     "jf_conditioning_rows": [ctypes.POINTER(jf_cond_segment), _I32, _I64, _P, _I64, _P],
+    "jf_gf_chain_inv_bwd": [_P, _I64, _P, _I64, _I32, _I64, _I32, _I32, ctypes.POINTER(jf_gf_layer), _P, _I64, _P, _P, _P, _I64, _P, _I64, _P, _P],
 }
 # entry points that exist for one precision only: full symbol name -> (argtypes, restype)
 _SIGNATURES_SINGLE = {
+    "jf_gf_chain_inv_bwd_partials": ([_I64, _I32], ctypes.c_int64),
     "jf_cond_gf_packed_bytes": ([_I32, _I32, ctypes.POINTER(jf_gf_layer)], ctypes.c_int64),
     "jf_cond_gf_pack_f32": ([_P, _I64, _P, _I32, _I32, _I32, ctypes.POINTER(jf_gf_layer), _P, _P], ctypes.c_int),
     "jf_cond_gf_chain_inv_split_f32": ([_P, _I64, _P, _I64, _P, _P, _I32, _I32, _P, _I64, _P, _I64, _I32, _I32, ctypes.POINTER(jf_gf_layer), _P, _I64,
@@ -116,6 +118,8 @@ for _fam, _cls in MCHAIN_LAYER_TYPES.items():
     for _d in ("inv", "fwd"):
         _SIGNATURES["jf_%s_chain_%s" % (_fam, _d)] = [_P, _I64, _P, _P, _I64, _I32, _I64, _I32, ctypes.POINTER(_cls), _P, _I64, _P, _P, _P, _P,
                                                       _I64, _P, _P]
+    _SIGNATURES["jf_%s_chain_inv_bwd" % _fam] = [_P, _I64, _P, _I64, _I32, _I64, _I32, ctypes.POINTER(_cls), _P, _I64, _P, _P, _P, _I64, _P, _I64,
+                                                 _P, _P]
 
 
 def exported_symbols():
@@ -312,6 +316,35 @@ def gf_chain(direction, x, log_det, params, layer_array, n_layers, D, x_out=None
     return x_out, ld_out
 
 
+def gf_chain_inv_bwd(x, params, layer_array, n_layers, D, g_xout, g_ld, g_blp, status=None):
+    """vector-Jacobian product of gf_chain('inv', ...): upstream gradients of (x_out, log_det_out, base_logp_out) -> (g_x (B, D), g_params).
+    g_params has the shape of `params`: (B, P) per-sample, (1, P) for permanent parameters (partial sums of the launch added up here)."""
+    dev = require_device(x, params, g_xout, g_ld, g_blp, status)
+    x, params = _rowmajor(x), _rowmajor(params)
+    B = x.shape[0]
+    pb = 1 if (params.shape[0] == 1) else B
+    if params.shape[0] not in (1, B):
+        raise ValueError("params must have 1 or B rows")
+    if g_xout is not None:
+        g_xout = _rowmajor(g_xout)
+    g_ld = None if g_ld is None else g_ld.contiguous()
+    g_blp = None if g_blp is None else g_blp.contiguous()
+    g_x = torch.empty((B, D), dtype=x.dtype, device=x.device)
+    P = params.shape[1]
+    if pb == 1:
+        n_part = int(lib().jf_gf_chain_inv_bwd_partials(B, D))
+        g_p = torch.empty((n_part, P), dtype=x.dtype, device=x.device)
+    else:
+        g_p = torch.empty((B, P), dtype=x.dtype, device=x.device)
+    _launch("jf_gf_chain_inv_bwd" + _suffix(x), "bcast" if pb == 1 else "per-sample",
+            (_ptr(x), x.stride(0), _ptr(params), params.stride(0), pb, B, D, n_layers, layer_array, _ptr(g_xout),
+             g_xout.stride(0) if g_xout is not None else 0, _ptr(g_ld), _ptr(g_blp), _ptr(g_x), g_x.stride(0), _ptr(g_p), g_p.stride(0),
+             _ptr(status)), dev)
+    if pb == 1:
+        g_p = g_p.sum(0, keepdim=True)
+    return g_x, g_p
+
+
 COND_GF_MAX_IN, COND_GF_MAX_HIDDEN = 28, 128
 
 
@@ -477,6 +510,35 @@ def mchain(fam, direction, x, log_det, params, layer_structs, dim, x_out=None, b
             (_ptr(x), x.stride(0), _ptr(log_det), pptr, pstride, pb, B, n, arr, _ptr(x_out), x_out.stride(0), _ptr(ld_out), _ptr(base_logp_in),
              _ptr(blp_out), _ptr(bins), bins.stride(0) if bins is not None else 0, _ptr(status)), dev)
     return (x_out, ld_out, blp_out) if want_base_logp else (x_out, ld_out)
+
+
+def mchain_inv_bwd(fam, x, params, layer_structs, dim, g_xout, g_ld, g_blp, status=None):
+    """vector-Jacobian product of mchain(fam, 'inv', ...): -> (g_x (B, dim), g_params in the shape of `params`)."""
+    dev = require_device(x, params, g_xout, g_ld, g_blp, status)
+    x = _rowmajor(x)
+    B = x.shape[0]
+    P = 0 if params is None else params.shape[1]
+    pb = 1
+    pptr, pstride = None, 0
+    g_p = None
+    if P > 0:
+        params = _rowmajor(params)
+        pb = 1 if params.shape[0] == 1 else B
+        pptr, pstride = _ptr(params), params.stride(0)
+        g_p = torch.zeros((1, P), dtype=x.dtype, device=x.device) if pb == 1 else torch.empty((B, P), dtype=x.dtype, device=x.device)
+    if g_xout is not None:
+        g_xout = _rowmajor(g_xout)
+    g_ld = None if g_ld is None else g_ld.contiguous()
+    g_blp = None if g_blp is None else g_blp.contiguous()
+    g_x = torch.empty((B, dim), dtype=x.dtype, device=x.device)
+    n = len(layer_structs)
+    arr = (MCHAIN_LAYER_TYPES[fam] * n)(*layer_structs)
+    _launch("jf_%s_chain_inv_bwd%s" % (fam, _suffix(x)), "bcast" if pb == 1 else "per-sample",
+            (_ptr(x), x.stride(0), pptr, pstride, pb, B, n, arr, _ptr(g_xout), g_xout.stride(0) if g_xout is not None else 0, _ptr(g_ld), _ptr(g_blp),
+             _ptr(g_x), g_x.stride(0), _ptr(g_p), g_p.stride(0) if g_p is not None else 0, _ptr(status)), dev)
+    if g_p is None:
+        g_p = torch.zeros((params.shape[0] if params is not None else 1, 0), dtype=x.dtype, device=x.device)
+    return g_x, g_p
 
 
 def sphere_embedding(x, log_det, dim, to_embedding, want_log_det=True):

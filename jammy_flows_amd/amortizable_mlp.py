@@ -12,7 +12,7 @@ import numpy
 import torch
 from torch import nn
 
-from . import _hip
+from . import _hip, autograd
 from .extra_functions import list_from_str
 
 
@@ -117,7 +117,9 @@ class AmortizableMLP(nn.Module):
             raise NotImplementedError("AmortizableMLP with per-sample weights (extra_inputs) has no HIP kernel yet")
         assert self.use_permanent_parameters
         _hip.require_device(i)
-        flat = self._flat(i)
+        grad = autograd._needs_grad(i, self.u_v_b_pars)
+        flat = self.u_v_b_pars.to(dtype=i.dtype).reshape(-1) if grad else self._flat(i)
+        lin = autograd.linear if grad else _hip.linear
         x = i
         last = len(self.stages) - 1
         for si, st in enumerate(self.stages):
@@ -127,8 +129,8 @@ class AmortizableMLP(nn.Module):
             b = flat[o + st["num_u"] + st["num_v"]:o + st["num_u"] + st["num_v"] + st["num_b"]]
             act = 0 if si == last else 1
             if st["full"]:
-                x = _hip.linear(x, u.view(st["out"], st["inp"]), b, act)
+                x = lin(x, u.view(st["out"], st["inp"]), b, act)
             else:
-                t = _hip.linear(x, v.view(st["rank"], st["inp"]), None, 0)        # V^T x
-                x = _hip.linear(t, u.view(st["out"], st["rank"]), b, act)         # U (V^T x) + b
+                t = lin(x, v.view(st["rank"], st["inp"]), None, 0)                # V^T x
+                x = lin(t, u.view(st["out"], st["rank"]), b, act)                 # U (V^T x) + b
         return x

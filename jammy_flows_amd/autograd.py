@@ -1,0 +1,137 @@
+"""torch.autograd wrappers around the C-ABI launches: what makes ``-pdf(x)[0].mean().backward()`` work (the reference's training step,
+examples/jammy_flows.py:381-412, docs/source/usage/training.rst:24-44).
+
+Every Function's forward is the SAME kernel launch the inference path uses; nothing but the inputs is saved.  Backward:
+  * g-layer chains: one hand-written HIP launch (jf_gf_chain_inv_bwd_*, csrc/gf_bwd_kernels.hip) that re-runs the chain and returns the
+    gradient of the targets and of the parameter row block -- (B, P) for per-sample blocks, partial sums for permanent parameters;
+  * dense layers: the three products of a linear layer's backward (g W, g^T x, column sums) are plain GEMMs and go to rocBLAS through
+    torch.matmul; the tanh derivative is applied to the saved activation;
+  * the fused conditional block (MLP + g layers in one launch) recomputes its parameter block with two dense launches in backward and
+    then runs the same two steps.
+"""
+import torch
+
+from . import _hip
+
+
+def _needs_grad(*ts):
+    return torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad for t in ts)
+
+
+class LinearFn(torch.autograd.Function):
+    """out = act(inp @ weight^T + bias) on the MFMA dense kernel (jf_linear); act 0 identity / 1 tanh."""
+
+    @staticmethod
+    def forward(ctx, inp, weight, bias, act):
+        out = _hip.linear(inp.detach(), weight.detach(), None if bias is None else bias.detach(), act)
+        ctx.act = act
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(inp, weight, out if act else None)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        inp, weight, out = ctx.saved_tensors
+        if ctx.act:
+            g = g * (1.0 - out * out)
+        g = g.contiguous()
+        g_inp = g @ weight if ctx.needs_input_grad[0] else None
+        g_w = g.t() @ inp if ctx.needs_input_grad[1] else None
+        g_b = g.sum(0) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        return g_inp, g_w, g_b, None
+
+
+def linear(inp, weight, bias=None, act=0):
+    if _needs_grad(inp, weight, bias):
+        return LinearFn.apply(inp, weight, bias, act)
+    return _hip.linear(inp, weight, bias, act)
+
+
+class GfChainInvFn(torch.autograd.Function):
+    """log-prob direction of a chain of g layers (jf_gf_chain_inv) -> (x_out, log_det_out, base_logp_out)."""
+
+    @staticmethod
+    def forward(ctx, x, log_det, params, base_logp_in, layer_array, n_layers, D, status):
+        res = _hip.gf_chain("inv", x.detach(), None if log_det is None else log_det.detach(), params.detach(), layer_array, n_layers, D,
+                            base_logp_in=None if base_logp_in is None else base_logp_in.detach(), want_base_logp=True, status=status)
+        ctx.meta = (layer_array, n_layers, D, status)
+        ctx.save_for_backward(x, params)
+        ctx.has = (log_det is not None, base_logp_in is not None)
+        return res
+
+    @staticmethod
+    def backward(ctx, g_xout, g_ld, g_blp):
+        x, params = ctx.saved_tensors
+        layer_array, n_layers, D, status = ctx.meta
+        g_x, g_params = _hip.gf_chain_inv_bwd(x, params, layer_array, n_layers, D, g_xout, g_ld, g_blp, status=None)
+        return (g_x, g_ld if ctx.has[0] else None, g_params, g_blp if ctx.has[1] else None, None, None, None, None)
+
+
+class CondBlockFn(torch.autograd.Function):
+    """conditional e-block in one launch (jf_cond_gf_chain_inv[_split]): amortisation MLP Linear-tanh-Linear + its g layers."""
+
+    @staticmethod
+    def forward(ctx, inp, w1, b1, w2, b2, x, log_det, base_logp_in, packed, layer_array, n_layers, D, status):
+        args = (x.detach(), None if log_det is None else log_det.detach(), layer_array, n_layers, D)
+        kw = dict(base_logp_in=None if base_logp_in is None else base_logp_in.detach(), want_base_logp=True, status=status)
+        if packed is not None:
+            res = _hip.cond_gf_chain_inv_split(inp.detach(), w1.detach(), b1.detach(), packed, *args, **kw)
+        else:
+            res = _hip.cond_gf_chain_inv(inp.detach(), w1.detach(), b1.detach(), w2.detach(), b2.detach(), *args, **kw)
+        ctx.meta = (layer_array, n_layers, D)
+        ctx.has = (log_det is not None, base_logp_in is not None)
+        ctx.save_for_backward(inp, w1, b1, w2, b2, x)
+        return res
+
+    @staticmethod
+    def backward(ctx, g_xout, g_ld, g_blp):
+        inp, w1, b1, w2, b2, x = ctx.saved_tensors
+        layer_array, n_layers, D = ctx.meta
+        # the parameter block is not kept by the forward launch: two dense launches bring it back (exact f32 MFMA)
+        h = _hip.linear(inp, w1, b1, 1)
+        params = _hip.linear(h, w2, b2, 0)
+        g_x, g_p = _hip.gf_chain_inv_bwd(x, params, layer_array, n_layers, D, g_xout, g_ld, g_blp, status=None)
+        del params
+        need = ctx.needs_input_grad
+        g_w2 = g_p.t() @ h if need[3] else None
+        g_b2 = g_p.sum(0) if need[4] else None
+        g_h = (g_p @ w2) * (1.0 - h * h)
+        del g_p
+        g_w1 = g_h.t() @ inp if need[1] else None
+        g_b1 = g_h.sum(0) if need[2] else None
+        g_inp = g_h @ w1 if need[0] else None
+        return (g_inp, g_w1, g_b1, g_w2, g_b2, g_x, g_ld if ctx.has[0] else None, g_blp if ctx.has[1] else None, None, None, None, None, None)
+
+
+def embed(tgt, kind, layer):
+    """differentiable conditioning embedding of a target block (main/default.py:946-962; sphere_base.py:305-332): only needed when the
+    TARGET itself requires grad (d log_prob / d x through the autoregressive conditioning); plain elementwise torch ops."""
+    if kind != "s" or tgt.shape[1] != layer.dimension:
+        return tgt
+    if layer.dimension == 1:
+        return torch.cat([torch.cos(tgt), torch.sin(tgt)], dim=1)
+    th = tgt[:, 0:1].clamp(1e-7, 3.14159265358979323846 - 1e-7)
+    ph = tgt[:, 1:2]
+    st = torch.sin(th)
+    return torch.cat([st * torch.cos(ph), st * torch.sin(ph), torch.cos(th)], dim=1)
+
+
+class MChainInvFn(torch.autograd.Function):
+    """log-prob direction of a chain of manifold layers (jf_{r,o,m,f,v,c}_chain_inv) -> (x_out, log_det_out, base_logp_out).
+    Backward: jf_*_chain_inv_jvp launches (forward-mode passes through the very same device code instantiated on dual numbers)."""
+
+    @staticmethod
+    def forward(ctx, x, log_det, params, base_logp_in, fam, structs, dim, status):
+        res = _hip.mchain(fam, "inv", x.detach(), None if log_det is None else log_det.detach(), params.detach(), structs, dim,
+                          base_logp_in=None if base_logp_in is None else base_logp_in.detach(), want_base_logp=True, status=status)
+        ctx.meta = (fam, structs, dim)
+        ctx.has = (log_det is not None, base_logp_in is not None)
+        ctx.save_for_backward(x, params)
+        return res
+
+    @staticmethod
+    def backward(ctx, g_xout, g_ld, g_blp):
+        x, params = ctx.saved_tensors
+        fam, structs, dim = ctx.meta
+        g_x, g_params = _hip.mchain_inv_bwd(fam, x, params, structs, dim, g_xout, g_ld, g_blp)
+        return (g_x, g_ld if ctx.has[0] else None, g_params, g_blp if ctx.has[1] else None, None, None, None, None)

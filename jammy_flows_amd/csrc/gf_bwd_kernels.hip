@@ -48,7 +48,8 @@ template <typename T> struct IcdfCoef { T Ay, By, AH, BH; };
 template <typename T> __device__ __forceinline__ IcdfCoef<T> pade_coeffs(const MixQ<T>& q, T y, bool centre_window) {
     const T a = T(PADE_A);
     const T c = T(2.0 / (3.14159265358979323846 * PADE_A));
-    const T L = q.lc + q.ls + T(1.38629436111989061883);
+    const T dlt = q.sf - q.cdf;                              // ln(4 cdf sf) without cancellation near the centre, as in the forward (pade_terms)
+    const T L = (M<T>::min(q.cdf, q.sf) > T(0.01)) ? M<T>::log1p(-dlt * dlt) : q.lc + q.ls + T(1.38629436111989061883);
     const T F = L * T(0.5) + c;
     const T rad = -L / a;
     const T F2 = M<T>::sqrt(F * F + rad);

@@ -45,10 +45,12 @@ class rational_quadratic_spline(interval_base.interval_base):
         L.first = int(self.euclidean_to_interval_as_first if first is None else first)
         return L
 
+    def _permanent_tensors(self):
+        return [self.rel_log_widths, self.rel_log_heights] + ([self.rel_log_derivatives] if self.num_derivative_params > 0 else [])
+
     def _params_for(self, x, extra_inputs):
         if self.use_permanent_parameters:
-            ts = [self.rel_log_widths, self.rel_log_heights] + ([self.rel_log_derivatives] if self.num_derivative_params > 0 else [])
-            return self._rows.get(ts, x, self.total_param_num)
+            return self._rows.get(self._permanent_tensors(), x, self.total_param_num)
         assert extra_inputs is not None, "Conditional PDF.. require *extra_inputs*"
         assert extra_inputs.shape[0] in (x.shape[0], 1), "Extra inputs must be Tensor of shape B X .. or 1 X .. (broadcasting)"
         return extra_inputs

@@ -50,10 +50,13 @@ class sphere_base(layer_base.layer_base):
         """permanent tensors AFTER the rotation block, in extra_inputs order (concrete layers override)."""
         return []
 
+    def _permanent_tensors(self):
+        """all permanent tensors of the layer in extra_inputs order (rotation block first)"""
+        return ([self.householder_params] if self.num_householder_params > 0 else []) + self._layer_tensors()
+
     def _params_for(self, x, extra_inputs):
         if extra_inputs is None:
-            ts = ([self.householder_params] if self.num_householder_params > 0 else []) + self._layer_tensors()
-            return self._rows.get(ts, x, self.total_param_num)
+            return self._rows.get(self._permanent_tensors(), x, self.total_param_num)
         if extra_inputs.shape[1] != self.total_param_num:
             raise ValueError("extra_inputs has %d columns, layer needs %d" % (extra_inputs.shape[1], self.total_param_num))
         return extra_inputs

@@ -14,7 +14,7 @@ import numpy
 import torch
 from torch import nn
 
-from .. import _hip
+from .. import _hip, autograd
 from ..amortizable_mlp import AmortizableMLP
 from ..extra_functions import list_from_str
 from ..flow_options import canonical, check_flow_option, layer_class, obtain_default_options, opts_dict
@@ -28,6 +28,18 @@ class HipLinearStack(nn.Sequential):
     def forward(self, x):
         _hip.require_device(x)
         mods = list(self)
+        if autograd._needs_grad(x, *self.parameters()):
+            # training: one dense launch per layer wrapped in autograd (the hidden activations are what backward needs)
+            i = 0
+            while i < len(mods):
+                lin = mods[i]
+                act = 1 if (i + 1 < len(mods) and isinstance(mods[i + 1], nn.Tanh)) else 0
+                w, b = lin.weight, lin.bias
+                if w.dtype != x.dtype:
+                    w, b = w.to(x.dtype), b.to(x.dtype)
+                x = autograd.linear(x, w, b, act)
+                i += 2 if act else 1
+            return x
         if (len(mods) == 3 and isinstance(mods[1], nn.Tanh) and mods[0].in_features <= _hip.MLP2_MAX_IN
                 and mods[0].out_features <= _hip.MLP2_MAX_HIDDEN and mods[0].out_features % 4 == 0):
             # Linear-tanh-Linear (the reference's default "128"): one fused launch, the hidden activations never leave the registers
@@ -647,9 +659,13 @@ class pdf(nn.Module):
         """log-probability at x -> (log_prob (B,), log_prob_base (B,), base_pos (B, D))  (:1059-1117)."""
         assert not self.use_as_passthrough_instead_of_pdf, "The module is only used as a passthrough of all layers, not as actually evaluating the pdf!"
         self._check_cond(x, conditional_input)
-        if torch.is_grad_enabled() and x.requires_grad:
-            # the kernels are forward-only (backward kernels: SURVEY.md section 8f, next row): never build a wrong graph silently
-            raise NotImplementedError("jammy_flows_amd kernels are forward-only in this version; call under torch.no_grad()")
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())
+                                        or any(isinstance(c, torch.Tensor) and c.requires_grad for c in
+                                               (conditional_input if type(conditional_input) == list else [conditional_input]))
+                                        or (amortization_parameters is not None and amortization_parameters.requires_grad)):
+            # training: the same kernels behind torch.autograd Functions (jammy_flows_amd/autograd.py)
+            return self._forward_with_grad(x, conditional_input, amortization_parameters, force_embedding_coordinates,
+                                           force_intrinsic_coordinates, only_last)
         with torch.no_grad():
             self._poll_status()                          # surfaces problems of earlier calls whose status has arrived meanwhile
             status = _hip.new_status(x.device) if self.check_status else None
@@ -658,6 +674,84 @@ class pdf(nn.Module):
             total = log_pdf + log_det
             self._defer_status(status)
         return total, log_pdf, base
+
+    # =========================================================================================== log-prob direction, differentiable
+    def _permanent_row_with_grad(self, layers, like):
+        """the block's permanent parameters side by side in the extra_inputs layout, built with differentiable ops (torch.cat)"""
+        parts = []
+        for l in layers:
+            parts += [t.reshape(-1).to(dtype=like.dtype) for t in l._permanent_tensors()]
+        if not parts:
+            return torch.zeros((1, 0), dtype=like.dtype, device=like.device)
+        return torch.cat(parts).reshape(1, -1)
+
+    def _forward_with_grad(self, x, conditional_input, amortization_parameters, force_embedding_coordinates, force_intrinsic_coordinates,
+                           only_last):
+        """forward() with a torch.autograd graph: d log_prob / d (x, conditional_input, MLP weights, permanent layer parameters).
+        Same launches as the inference path, wrapped in autograd Functions whose backward is a HIP launch (g chains, manifold chains) or
+        rocBLAS GEMMs (dense layers) -- see jammy_flows_amd/autograd.py."""
+        if amortization_parameters is not None or only_last or force_embedding_coordinates or force_intrinsic_coordinates:
+            raise NotImplementedError("gradients with amortization_parameters / only_last / forced coordinate systems are not implemented")
+        _hip.require_device(x)
+        self._poll_status()
+        status = _hip.new_status(x.device) if self.check_status else None
+        B = x.shape[0]
+        log_det = None
+        base_logp = None
+        bases = []
+        embeds = []
+        for si, block in enumerate(self.layer_list):
+            a, b = self.target_dim_indices[si]
+            tgt = x[:, a:b]
+            layers = list(block)
+            kind = self.pdf_defs_list[si][0]
+            mlp = self.mlp_predictors[si] if len(self.mlp_predictors) > si else None
+            inp = None
+            if mlp is not None:
+                pieces = []
+                if conditional_input is not None:
+                    pieces.append(conditional_input[si] if type(conditional_input) == list else conditional_input)
+                pieces += embeds
+                if not pieces:
+                    raise Exception("extra conditional input is empty but required for encoding!")
+                inp = torch.cat(pieces, dim=1) if len(pieces) > 1 else pieces[0]
+            if kind == "e" and gfl.chain_supported(layers):
+                larr = _hip.gf_layer_array([l.c_struct() for l in layers])
+                D = layers[0].dimension
+                fused = self._fusable_block(si, layers, False, None, x.dtype) if mlp is not None else None
+                if fused is not None:
+                    w1, b1, w2, b2 = mlp[0].weight, mlp[0].bias, mlp[2].weight, mlp[2].bias
+                    packed = None
+                    if self.fused_matrix_arithmetic == "split_bf16" and w1.shape[0] <= 128:
+                        packed = self._packed_w2(si, w2.detach(), b2.detach(), larr, len(layers), D)
+                    out, log_det, base_logp = autograd.CondBlockFn.apply(inp, w1, b1, w2, b2, tgt, log_det, base_logp, packed, larr, len(layers), D,
+                                                                         status)
+                else:
+                    params = mlp(inp) if mlp is not None else self._permanent_row_with_grad(layers, x)
+                    out, log_det, base_logp = autograd.GfChainInvFn.apply(tgt, log_det, params, base_logp, larr, len(layers), D, status)
+            else:
+                params = mlp(inp) if mlp is not None else self._permanent_row_with_grad(layers, x)
+                fam = _manifold_family(layers)
+                groups = [layers] if fam is not None else [[l] for l in layers]      # mixed families (e.g. "mo"): one launch per layer
+                out, c1 = tgt, params.shape[1]
+                for gi in range(len(groups) - 1, -1, -1):                            # last layer first, parameters sliced tail-first (:1002-1012)
+                    grp = groups[gi]
+                    f = _manifold_family(grp)
+                    if f is None:
+                        raise NotImplementedError("gradients through %s layers are not implemented" % type(grp[0]).__name__)
+                    n = sum(l.total_param_num for l in grp)
+                    structs = [l.c_struct() if f == "r" else l.c_struct(1 if l.euclidean_to_sphere_as_first else 0) for l in grp]
+                    out, log_det, blp = autograd.MChainInvFn.apply(out, log_det, params[:, c1 - n:c1], base_logp if gi == 0 else None, f, structs,
+                                                                   grp[0].dimension, status)
+                    c1 -= n
+                base_logp = blp
+            bases.append(out)
+            emb = block[-1]._embedding_conditional_return(tgt.detach()) if not tgt.requires_grad else autograd.embed(tgt, kind, layers[-1])
+            embeds.append(emb)
+        base = torch.cat(bases, dim=1) if len(bases) > 1 else bases[0]
+        total = base_logp + log_det
+        self._defer_status(status)
+        return total, base_logp, base
 
     def log_prob(self, x, conditional_input=None, **kwargs):
         """convenience: forward(...)[0]  (the reference has no such method)."""

@@ -132,3 +132,44 @@ def timed_steps(step, steps, warmup, finish=None, device=None, timer=None):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     return dt
+
+
+def allreduce_gradients(parameters, average=True, group=None):
+    """data-parallel training step glue: every rank back-propagates the loss of ITS row shard, then ONE all-reduce (RCCL ncclAllReduce over
+    xGMI) of all parameter gradients packed into a single flat bucket per dtype -- the whole model is < 1 MB (largest BASELINE configuration:
+    16 138 MLP scalars), so one bucket, one collective, no overlap machinery.  With `average` the sum is divided by the world size (loss =
+    mean over the GLOBAL batch when every shard has the same number of rows).  Parameters without a gradient on this rank contribute zeros
+    (they keep grad None only if no rank produced one).  Returns the number of scalars reduced."""
+    params = [p for p in parameters if p.requires_grad]
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return sum(p.grad.numel() for p in params if p.grad is not None)
+    world = dist.get_world_size(group)
+    total = 0
+    by_dtype = {}
+    for p in params:
+        by_dtype.setdefault((p.dtype, p.device), []).append(p)
+    for (dtype, device), ps in by_dtype.items():
+        flat = torch.zeros(sum(p.numel() for p in ps), dtype=dtype, device=device)
+        has = torch.zeros(len(ps), dtype=dtype, device=device)
+        o = 0
+        for i, p in enumerate(ps):
+            if p.grad is not None:
+                flat[o:o + p.numel()] = p.grad.reshape(-1)
+                has[i] = 1
+            o += p.numel()
+        bucket = torch.cat([flat, has])
+        dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=group)
+        flat, has = bucket[:flat.numel()], bucket[flat.numel():]
+        if average:
+            flat = flat / world
+        o = 0
+        for i, p in enumerate(ps):
+            if has[i] > 0:
+                g = flat[o:o + p.numel()].reshape(p.shape)
+                if p.grad is None:
+                    p.grad = g.clone()
+                else:
+                    p.grad.copy_(g)
+            o += p.numel()
+        total += flat.numel()
+    return total

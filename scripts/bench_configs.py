@@ -12,6 +12,8 @@ import torch
 import fixture_io
 import helpers
 
+torch.set_grad_enabled(False)
+
 CONFIGS = [  # (fixture, dtype, rows, label)
     ("c1_e2_gg", torch.float64, 4096, 'C1 pdf("e2","gg") f64'),
     ("c2_e4_gggg", torch.float32, 1 << 20, 'C2 pdf("e4","gggg") f32'),

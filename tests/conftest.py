@@ -26,3 +26,14 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+@pytest.fixture(autouse=True)
+def _inference_mode_by_default():
+    """the parity tests evaluate, they do not train: like a user's ``with torch.no_grad():`` around inference.  (Under grad mode
+    pdf.forward builds an autograd graph, as the reference does; the gradient tests switch it on explicitly.)"""
+    import torch
+    prev = torch.is_grad_enabled()
+    torch.set_grad_enabled(False)
+    yield
+    torch.set_grad_enabled(prev)

@@ -21,6 +21,8 @@ def test_library_exports_every_declared_symbol():
     declared = set(re.findall(r"\bint(?:64_t)?\s+(jf_[a-z0-9_]+)\s*\(", header))
     for fam, suffix in re.findall(r"^JF_DECLARE_MCHAIN\((\w+),\s*\w+,\s*(\w+)\)", header, flags=re.M):   # macro-declared chain entry points
         declared |= {"jf_%s_chain_inv_%s" % (fam, suffix), "jf_%s_chain_fwd_%s" % (fam, suffix)}
+    for fam, suffix in re.findall(r"^JF_DECLARE_MCHAIN_BWD\((\w+),\s*\w+,\s*(\w+)\)", header, flags=re.M):
+        declared.add("jf_%s_chain_inv_bwd_%s" % (fam, suffix))
     assert declared == set(_hip.exported_symbols()), declared ^ set(_hip.exported_symbols())
     lib = _hip.lib()
     for name in declared:

@@ -160,3 +160,47 @@ def test_bench_step_loop_gloo_world2():
         p.join(timeout=60)
     assert sorted(r for r, _ in res) == [0, 1]
     assert all(ok for _, ok in res)
+
+
+def _grad_worker(rank, world, port, q):
+    """row-sharded training step: local backward on the shard + ONE gradient all-reduce == the gradient of the global-batch mean loss"""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(0)
+        net = torch.nn.Sequential(torch.nn.Linear(3, 8), torch.nn.Tanh(), torch.nn.Linear(8, 1)).double()
+        extra = torch.nn.Parameter(torch.ones(2, dtype=torch.float64))       # touched by rank 0 only
+        unused = torch.nn.Parameter(torch.ones(2, dtype=torch.float64))      # touched by nobody
+        x = torch.randn(64, 3, dtype=torch.float64)
+        ref = torch.nn.Sequential(torch.nn.Linear(3, 8), torch.nn.Tanh(), torch.nn.Linear(8, 1)).double()
+        ref.load_state_dict(net.state_dict())
+        ref(x).mean().backward()
+        lo, hi = parallel.shard_bounds(64, rank, world)
+        loss = net(x[lo:hi]).mean()
+        if rank == 0:
+            loss = loss + extra.sum()
+        loss.backward()
+        params = list(net.parameters()) + [extra, unused]
+        n = parallel.allreduce_gradients(params, average=True)
+        ok = n == sum(p.numel() for p in params)
+        for p, r in zip(net.parameters(), ref.parameters()):
+            ok = ok and bool(torch.allclose(p.grad, r.grad, rtol=1e-12, atol=1e-14))
+        ok = ok and bool(torch.allclose(extra.grad, torch.full((2,), 0.5, dtype=torch.float64))) and unused.grad is None
+        q.put((rank, ok))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gradient_allreduce_gloo_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(r for r, _ in res) == [0, 1]
+    assert all(ok for _, ok in res)
