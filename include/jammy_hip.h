@@ -155,6 +155,30 @@ int jf_mlp2_f64(const double* in, int64_t in_stride, const double* W1, int64_t w
                 const double* b2, int64_t B, int32_t K1, int32_t H, int32_t N, double* out, int64_t out_stride, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * 't' affine flow / multivariate normal (replaces mvn_block._inv_flow_mapping / _flow_mapping + the euclidean_base offset:
+ * jammy_flows/layers/euclidean/multivariate_normal.py:226-263, layers/matrix_fns.py:4-146, euclidean_base.py:34-76).
+ * Row: [offset D if model_offset][raw log-diagonal: 1 (diagonal_symmetric) | D (diagonal, full)][strictly-lower entries D(D-1)/2 (full),
+ * sub-diagonal by sub-diagonal from the bottom-left corner, matrix_fns.py:36-50].  log L_ii = the same width regulators as 'g'.  D <= 8.
+ * base_logp_out (nullable) as for jf_gf_chain_inv.  jf_t_layer_inv_bwd: backward of the log-prob direction (same conventions as
+ * jf_<fam>_chain_inv_bwd below: per-sample g_params (B, P), broadcast row sums ADDED into (1, P)).
+ * ------------------------------------------------------------------------------------------------------------ */
+enum { JF_T_IDENTITY = 0, JF_T_DIAGONAL_SYMMETRIC = 1, JF_T_DIAGONAL = 2, JF_T_FULL = 3 };
+typedef struct jf_t_layer { int32_t cov_type, model_offset, width_mode, clamp_widths; double width_min, width_max; } jf_t_layer;
+#define JF_DECLARE_T(T, suffix)                                                                                                          \
+    int jf_t_layer_inv_##suffix(const T* x, int64_t x_stride, const T* log_det_in, const T* params, int64_t param_stride, int32_t param_batch, \
+                                int64_t B, int32_t D, const jf_t_layer* layer, T* x_out, int64_t x_out_stride, T* log_det_out,              \
+                                const T* base_logp_in, T* base_logp_out, int32_t* status, void* stream);                                  \
+    int jf_t_layer_fwd_##suffix(const T* z, int64_t z_stride, const T* log_det_in, const T* params, int64_t param_stride, int32_t param_batch, \
+                                int64_t B, int32_t D, const jf_t_layer* layer, T* x_out, int64_t x_out_stride, T* log_det_out,              \
+                                const T* base_logp_in, T* base_logp_out, int32_t* status, void* stream);                                  \
+    int jf_t_layer_inv_bwd_##suffix(const T* x, int64_t x_stride, const T* params, int64_t param_stride, int32_t param_batch, int64_t B,      \
+                                    int32_t D, const jf_t_layer* layer, const T* g_x_out, int64_t g_x_out_stride, const T* g_log_det,       \
+                                    const T* g_base_logp, T* g_x, int64_t g_x_stride, T* g_params, int64_t g_params_stride,                \
+                                    int32_t* status, void* stream);
+JF_DECLARE_T(float, f32)
+JF_DECLARE_T(double, f64)
+
+/* ------------------------------------------------------------------------------------------------------------
  * Manifold layers (interval / S1 / S2).  All take / return INTRINSIC coordinates (interval value, angle, (theta, phi));
  * `first` = the layer also applies the chart to / from the Euclidean base space (euclidean_to_{interval,sphere}_as_first).
  * A chain = the layers of one sub-manifold block, applied n-1..0 in the log-prob direction and 0..n-1 when sampling;

@@ -79,6 +79,11 @@ class jf_c_layer(ctypes.Structure):
                 ("lo", ctypes.c_double), ("hi", ctypes.c_double)]
 
 
+class jf_t_layer(ctypes.Structure):
+    _fields_ = [("cov_type", ctypes.c_int32), ("model_offset", ctypes.c_int32), ("width_mode", ctypes.c_int32), ("clamp_widths", ctypes.c_int32),
+                ("width_min", ctypes.c_double), ("width_max", ctypes.c_double)]
+
+
 class jf_cond_segment(ctypes.Structure):
     _fields_ = [("src", ctypes.c_void_p), ("stride", ctypes.c_int64), ("kind", ctypes.c_int32), ("n_in", ctypes.c_int32)]
 
@@ -104,6 +109,9 @@ _SIGNATURES = {
     "jf_sphere_to_embedding": [_P, _I64, _P, _I64, _I32, _P, _I64, _P, _P],
     "jf_sphere_from_embedding": [_P, _I64, _P, _I64, _I32, _P, _I64, _P, _P],
     "jf_conditioning_rows": [ctypes.POINTER(jf_cond_segment), _I32, _I64, _P, _I64, _P],
+    "jf_t_layer_inv": [_P, _I64, _P, _P, _I64, _I32, _I64, _I32, ctypes.POINTER(jf_t_layer), _P, _I64, _P, _P, _P, _P, _P],
+    "jf_t_layer_fwd": [_P, _I64, _P, _P, _I64, _I32, _I64, _I32, ctypes.POINTER(jf_t_layer), _P, _I64, _P, _P, _P, _P, _P],
+    "jf_t_layer_inv_bwd": [_P, _I64, _P, _I64, _I32, _I64, _I32, ctypes.POINTER(jf_t_layer), _P, _I64, _P, _P, _P, _I64, _P, _I64, _P, _P],
     "jf_gf_chain_inv_bwd": [_P, _I64, _P, _I64, _I32, _I64, _I32, _I32, ctypes.POINTER(jf_gf_layer), _P, _I64, _P, _P, _P, _I64, _P, _I64, _P, _P],
 }
 # entry points that exist for one precision only: full symbol name -> (argtypes, restype)
@@ -510,6 +518,56 @@ def mchain(fam, direction, x, log_det, params, layer_structs, dim, x_out=None, b
             (_ptr(x), x.stride(0), _ptr(log_det), pptr, pstride, pb, B, n, arr, _ptr(x_out), x_out.stride(0), _ptr(ld_out), _ptr(base_logp_in),
              _ptr(blp_out), _ptr(bins), bins.stride(0) if bins is not None else 0, _ptr(status)), dev)
     return (x_out, ld_out, blp_out) if want_base_logp else (x_out, ld_out)
+
+
+def t_layer(direction, x, log_det, params, struct, D, x_out=None, base_logp_in=None, want_base_logp=False, status=None):
+    """'t' affine layer, direction 'inv' (log-prob) or 'fwd' (sampling).  Returns (x_out, log_det_out[, base_logp])."""
+    dev = require_device(x, log_det, params, x_out, base_logp_in, status)
+    x = _rowmajor(x)
+    B = x.shape[0]
+    if x.shape[1] != D:
+        raise ValueError("expected %d target columns, got %d" % (D, x.shape[1]))
+    pb, pptr, pstride = 1, None, 0
+    if params is not None and params.shape[1] > 0:
+        params = _rowmajor(params)
+        if params.dtype != x.dtype or params.shape[0] not in (1, B):
+            raise ValueError("extra_inputs must be (1 | B, P) of the input dtype")
+        pb = 1 if params.shape[0] == 1 else B
+        pptr, pstride = _ptr(params), params.stride(0)
+    if log_det is not None:
+        log_det = log_det.contiguous()
+    if x_out is None:
+        x_out = torch.empty((B, D), dtype=x.dtype, device=x.device)
+    ld_out = torch.empty((B,), dtype=x.dtype, device=x.device)
+    blp_out = torch.empty((B,), dtype=x.dtype, device=x.device) if want_base_logp else None
+    _launch("jf_t_layer_%s%s" % (direction, _suffix(x)), "bcast" if pb == 1 else "per-sample",
+            (_ptr(x), x.stride(0), _ptr(log_det), pptr, pstride, pb, B, D, ctypes.byref(struct), _ptr(x_out), x_out.stride(0), _ptr(ld_out),
+             _ptr(base_logp_in), _ptr(blp_out), _ptr(status)), dev)
+    return (x_out, ld_out, blp_out) if want_base_logp else (x_out, ld_out)
+
+
+def t_layer_inv_bwd(x, params, struct, D, g_xout, g_ld, g_blp, status=None):
+    dev = require_device(x, params, g_xout, g_ld, g_blp, status)
+    x = _rowmajor(x)
+    B = x.shape[0]
+    P = 0 if params is None else params.shape[1]
+    pb, pptr, pstride, g_p = 1, None, 0, None
+    if P > 0:
+        params = _rowmajor(params)
+        pb = 1 if params.shape[0] == 1 else B
+        pptr, pstride = _ptr(params), params.stride(0)
+        g_p = torch.zeros((1, P), dtype=x.dtype, device=x.device) if pb == 1 else torch.empty((B, P), dtype=x.dtype, device=x.device)
+    if g_xout is not None:
+        g_xout = _rowmajor(g_xout)
+    g_ld = None if g_ld is None else g_ld.contiguous()
+    g_blp = None if g_blp is None else g_blp.contiguous()
+    g_x = torch.empty((B, D), dtype=x.dtype, device=x.device)
+    _launch("jf_t_layer_inv_bwd" + _suffix(x), "bcast" if pb == 1 else "per-sample",
+            (_ptr(x), x.stride(0), pptr, pstride, pb, B, D, ctypes.byref(struct), _ptr(g_xout), g_xout.stride(0) if g_xout is not None else 0,
+             _ptr(g_ld), _ptr(g_blp), _ptr(g_x), g_x.stride(0), _ptr(g_p), g_p.stride(0) if g_p is not None else 0, _ptr(status)), dev)
+    if g_p is None:
+        g_p = torch.zeros((1, 0), dtype=x.dtype, device=x.device)
+    return g_x, g_p
 
 
 def mchain_inv_bwd(fam, x, params, layer_structs, dim, g_xout, g_ld, g_blp, status=None):

@@ -135,3 +135,23 @@ class MChainInvFn(torch.autograd.Function):
         fam, structs, dim = ctx.meta
         g_x, g_params = _hip.mchain_inv_bwd(fam, x, params, structs, dim, g_xout, g_ld, g_blp)
         return (g_x, g_ld if ctx.has[0] else None, g_params, g_blp if ctx.has[1] else None, None, None, None, None)
+
+
+class TLayerInvFn(torch.autograd.Function):
+    """log-prob direction of the affine 't' layer (jf_t_layer_inv) -> (x_out, log_det_out, base_logp_out)"""
+
+    @staticmethod
+    def forward(ctx, x, log_det, params, base_logp_in, struct, D, status):
+        res = _hip.t_layer("inv", x.detach(), None if log_det is None else log_det.detach(), None if params is None else params.detach(), struct, D,
+                           base_logp_in=None if base_logp_in is None else base_logp_in.detach(), want_base_logp=True, status=status)
+        ctx.meta = (struct, D)
+        ctx.has = (log_det is not None, base_logp_in is not None, params is not None)
+        ctx.save_for_backward(x, params)
+        return res
+
+    @staticmethod
+    def backward(ctx, g_xout, g_ld, g_blp):
+        x, params = ctx.saved_tensors
+        struct, D = ctx.meta
+        g_x, g_params = _hip.t_layer_inv_bwd(x, params, struct, D, g_xout, g_ld, g_blp)
+        return (g_x, g_ld if ctx.has[0] else None, g_params if ctx.has[2] else None, g_blp if ctx.has[1] else None, None, None, None)

@@ -3,13 +3,14 @@
 Option names, defaults and validators are the user-visible API of the reference (jammy_flows/flow_options.py:25-240) and are
 kept verbatim; the registry below only lists the layers of the MI355X hot path:
 
-    g  Gaussianization flow (Euclidean)          r  rational-quadratic spline (interval)
+    g  Gaussianization flow (Euclidean)          t  affine flow / multivariate normal (Euclidean)
+    r  rational-quadratic spline (interval)
     o  circular spline (S1)                      m  Moebius (S1)
     f  von-Mises-Fisher + splines (S2)           v  exponential map (S2, float64 only)
     x / y / z  identity layers
     n  legacy name of the S2 autoregressive spline layer; accepted as an alias of "f" 
 
-Out of scope (no kernel, constructing them raises): h (deprecated), t, c, u, w.
+Out of scope (no kernel, constructing them raises): h (deprecated), c, u, w.
 """
 import importlib
 
@@ -44,6 +45,16 @@ _register("g", "jammy_flows_amd.layers.euclidean.gaussianization_flow", "gf_bloc
     "add_skewness": (0, [0, 1]),
     "rotation_mode": ("householder", ["householder", "triangular_combination", "angles", "cayley", "none"]),
     "nonlinear_stretch_type": ("classic", ["classic", "rq_splines"]),
+})
+
+_register("t", "jammy_flows_amd.layers.euclidean.multivariate_normal", "mvn_block", "e", {
+    "skip_model_offset": (0, [0, 1]),
+    "softplus_for_width": (0, [0, 1]),
+    "upper_bound_for_widths": (100, _int_or_m1),
+    "lower_bound_for_widths": (0.01, _pos),
+    "clamp_widths": (0, [0, 1]),
+    "width_smooth_saturation": (1, [0, 1]),
+    "cov_type": ("diagonal", ["identity", "diagonal_symmetric", "diagonal", "full"]),
 })
 
 _register("m", "jammy_flows_amd.layers.spheres.moebius_1d", "moebius", "s", {
@@ -115,7 +126,7 @@ _register("x", "jammy_flows_amd.layers.euclidean.euclidean_do_nothing", "euclide
 _register("y", "jammy_flows_amd.layers.spheres.spherical_do_nothing", "spherical_do_nothing", "s", {"add_rotation": (0, [0, 1])})
 _register("z", "jammy_flows_amd.layers.intervals.interval_do_nothing", "interval_do_nothing", "i", {})
 
-OUT_OF_SCOPE = {"h": "deprecated Gaussianization flow", "t": "affine/MVN layer", "c": "manifold continuous NF (needs torchdiffeq)",
+OUT_OF_SCOPE = {"h": "deprecated Gaussianization flow", "c": "manifold continuous NF (needs torchdiffeq)",
                 "u": "simplex flow", "w": "simplex flow"}
 
 

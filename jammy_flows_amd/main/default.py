@@ -76,6 +76,25 @@ def _manifold_family(layers):
     return None
 
 
+def _layer_groups(layers):
+    """split a block's layers into launch groups: maximal runs of chainable 'g' layers (one fused launch each), every other layer alone"""
+    groups, run = [], []
+    for l in layers:
+        if type(l) is gfl.gf_block and l.dimension <= 8 and len(run) < _hip.JF_MAX_CHAIN:
+            run.append(l)
+            continue
+        if run:
+            groups.append(run)
+            run = []
+        if type(l) is gfl.gf_block:
+            run = [l]
+        else:
+            groups.append([l])
+    if run:
+        groups.append(run)
+    return groups
+
+
 def _manifold_chain(fam, layers, direction, x, log_det, extra, only_last_first, x_out, base_logp_in, want_base_logp, status):
     structs = []
     for l in layers:
@@ -628,16 +647,24 @@ class pdf(nn.Module):
                     log_det = torch.zeros(B, dtype=x.dtype, device=x.device)
                 cur = tgt
                 used = 0
-                for l in reversed(list(block)):
+                for grp in reversed(_layer_groups(list(block))):       # tail-first parameter slices (:1002-1012)
+                    n = sum(l.total_param_num for l in grp)
                     this = None
                     if extra is not None:
                         end = extra.shape[1] - used
-                        this = extra[:, end - l.total_param_num:end]
-                    kw = {}
-                    if only_last and kind == "s":
-                        kw["fix_euclidean_to_sphere_first"] = True
-                    cur, log_det = l.inv_flow_mapping([cur, log_det], extra_inputs=this, **kw)[:2]
-                    used += l.total_param_num
+                        this = extra[:, end - n:end]
+                    if type(grp[0]) is gfl.gf_block and not only_last:
+                        cur, log_det = gfl.run_chain(grp, "inv", cur, log_det, this if this is not None else gfl.chain_permanent_row(grp, x),
+                                                     status=status)[:2]
+                    else:
+                        l = grp[-1]
+                        if this is not None and len(grp) > 1:
+                            this = this[:, n - l.total_param_num:]
+                        kw = {}
+                        if only_last and kind == "s":
+                            kw["fix_euclidean_to_sphere_first"] = True
+                        cur, log_det = l.inv_flow_mapping([cur, log_det], extra_inputs=this, **kw)[:2]
+                    used += n
                     if only_last:
                         break
                 out_view.copy_(cur)
@@ -729,6 +756,27 @@ class pdf(nn.Module):
                 else:
                     params = mlp(inp) if mlp is not None else self._permanent_row_with_grad(layers, x)
                     out, log_det, base_logp = autograd.GfChainInvFn.apply(tgt, log_det, params, base_logp, larr, len(layers), D, status)
+            elif kind == "e":
+                # Euclidean block mixing 'g' runs with other layers ('t'): one launch per group, last group first (:1002-1012)
+                from ..layers.euclidean.multivariate_normal import mvn_block
+                params = mlp(inp) if mlp is not None else self._permanent_row_with_grad(layers, x)
+                groups = _layer_groups(layers)
+                out, c1 = tgt, params.shape[1]
+                for gi in range(len(groups) - 1, -1, -1):
+                    grp = groups[gi]
+                    n = sum(l.total_param_num for l in grp)
+                    this = params[:, c1 - n:c1]
+                    blp_in = base_logp if gi == 0 else None
+                    if type(grp[0]) is gfl.gf_block:
+                        larr = _hip.gf_layer_array([l.c_struct() for l in grp])
+                        out, log_det, blp = autograd.GfChainInvFn.apply(out, log_det, this, blp_in, larr, len(grp), grp[0].dimension, status)
+                    elif type(grp[0]) is mvn_block:
+                        out, log_det, blp = autograd.TLayerInvFn.apply(out, log_det, this if n > 0 else None, blp_in, grp[0].c_struct(),
+                                                                       grp[0].dimension, status)
+                    else:
+                        raise NotImplementedError("gradients through %s layers are not implemented" % type(grp[0]).__name__)
+                    c1 -= n
+                base_logp = blp
             else:
                 params = mlp(inp) if mlp is not None else self._permanent_row_with_grad(layers, x)
                 fam = _manifold_family(layers)
@@ -800,15 +848,22 @@ class pdf(nn.Module):
                 if log_det is None:
                     log_det = torch.zeros(B, dtype=x.dtype, device=x.device)
                 c = 0
-                for li, l in enumerate(block):
-                    this = None if extra is None else extra[:, c:c + l.total_param_num]
-                    c += l.total_param_num
-                    if only_last and li < len(block) - 1:
+                groups = [[l] for l in block] if only_last else _layer_groups(list(block))
+                for gi, grp in enumerate(groups):
+                    n = sum(l.total_param_num for l in grp)
+                    this = None if extra is None else extra[:, c:c + n]
+                    c += n
+                    if only_last and gi < len(groups) - 1:
                         continue
-                    kw = {}
-                    if only_last and kind == "s":
-                        kw["fix_euclidean_to_sphere_first"] = True
-                    cur, log_det = l.flow_mapping([cur, log_det], extra_inputs=this, **kw)[:2]
+                    if type(grp[0]) is gfl.gf_block and not only_last:
+                        _, log_det = gfl.run_chain(grp, "fwd", cur, log_det, this if this is not None else gfl.chain_permanent_row(grp, x),
+                                                   status=status)
+                        cur = _
+                    else:
+                        kw = {}
+                        if only_last and kind == "s":
+                            kw["fix_euclidean_to_sphere_first"] = True
+                        cur, log_det = grp[0].flow_mapping([cur, log_det], extra_inputs=this, **kw)[:2]
                 out_view.copy_(cur)
             embeds.append(block[-1]._embedding_conditional_return(out_view))
         x_new = out

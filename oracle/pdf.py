@@ -9,7 +9,7 @@ import copy
 
 import numpy as np
 
-from . import gf
+from . import gf, mvn
 from .mlp import AmortizableMLP, AmortizableMLPSpec, SequentialMLP, list_from_str
 from .s2_layers import FLayer, VLayer
 from .sphere_layers import MLayer, OLayer, RLayer
@@ -22,6 +22,8 @@ DEFAULTS = {
               lower_bound_for_widths=0.01, upper_bound_for_norms=10, lower_bound_for_norms=1, center_mean=0, clamp_widths=0,
               width_smooth_saturation=1, regulate_normalization=1, add_skewness=0, rotation_mode="householder",
               nonlinear_stretch_type="classic"),
+    "t": dict(skip_model_offset=0, softplus_for_width=0, upper_bound_for_widths=100, lower_bound_for_widths=0.01, clamp_widths=0,
+              width_smooth_saturation=1, cov_type="diagonal"),
     "m": dict(add_rotation=0, num_basis_functions=5, natural_direction=0),
     "o": dict(add_rotation=1, num_basis_functions=2, natural_direction=1, fix_boundary_derivatives=-1.0,
               smooth_second_derivative=1, fix_first_width_n_height_to_zero=0, also_fix_second_width_to_zero=0,
@@ -41,7 +43,7 @@ DEFAULTS = {
               independent_width_height_parametrization=0, min_width=1e-4, min_height=1e-4, min_derivative=1e-4),
     "x": dict(add_offset=0), "y": dict(add_rotation=0), "z": dict(),
 }
-LAYER_KIND = {"g": "e", "x": "e", "m": "s", "o": "s", "v": "s", "f": "s", "y": "s", "r": "i", "z": "i"}
+LAYER_KIND = {"g": "e", "t": "e", "x": "e", "m": "s", "o": "s", "v": "s", "f": "s", "y": "s", "r": "i", "z": "i"}
 
 
 class _Identity:
@@ -72,6 +74,21 @@ class _GLayer:
 
     def forward(self, x, log_det, params):
         return gf.forward(self.spec, x, log_det, params)
+
+
+class _TLayer:
+    def __init__(self, dim, opts, model_offset):
+        self.spec = mvn.TSpec(dim, opts, model_offset)
+        self.total_param_num = self.spec.total_param_num
+
+    def row_from_state(self, sd, prefix):
+        return self.spec.row_from_state(sd, prefix)
+
+    def inverse(self, x, log_det, params):
+        return mvn.inverse(self.spec, x, log_det, params)
+
+    def forward(self, x, log_det, params):
+        return mvn.forward(self.spec, x, log_det, params)
 
 
 def _resolve_options(letter, sub_index, layer_index, overwrite):
@@ -132,9 +149,9 @@ class OraclePdf:
                     model_offset = 0
                     if li == len(letters) - 1 and o["skip_model_offset"] == 0:
                         model_offset = 1
-                    elif li == 0 and o["replace_first_sigmoid_with_icdf"] > 0 and o["inverse_function_type"] == "isigmoid":
+                    elif li == 0 and letter == "g" and o["replace_first_sigmoid_with_icdf"] > 0 and o["inverse_function_type"] == "isigmoid":
                         o["inverse_function_type"] = "inormal_partly_precise"
-                    layers.append(_GLayer(dim, o, model_offset))
+                    layers.append(_GLayer(dim, o, model_offset) if letter == "g" else _TLayer(dim, o, model_offset))
                 elif kind == "i":
                     parts = sub.split("_")
                     lo, hi = (0.0, 1.0) if len(parts) == 1 else (float(parts[1]), float(parts[2]))

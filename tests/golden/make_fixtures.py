@@ -90,6 +90,13 @@ CASES = [
     dict(name="g_e1e2e1_cond_lowrank", pdf="e1+e2+e1", flow="gg+g+ggg", mlp_scale=30.0,
          kwargs=dict(conditional_input_dim=2, amortization_mlp_dims="64-30", amortization_mlp_ranks="2-10-1000",
                      amortization_mlp_use_custom_mode=True)),
+    # affine / multivariate-normal layer 't' (docs/source/usage/suggested_settings.rst:12-42 recommends "gggt")
+    dict(name="t_e3_gggt", pdf="e3", flow="gggt", perturb=0.4),
+    dict(name="t_e3_gt_full_cond", pdf="e3", flow="gt", mlp_scale=300.0,
+         kwargs=dict(conditional_input_dim=2, options_overwrite={"t": {"cov_type": "full"}})),
+    dict(name="t_e2_tt_variants", pdf="e2+e2", flow="t+tg", mlp_scale=300.0,
+         kwargs=dict(options_overwrite={0: {"t": {"cov_type": "diagonal_symmetric", "softplus_for_width": 1}},
+                                        1: {"t": {"cov_type": "full", "clamp_widths": 1, "skip_model_offset": 1}}})),
     # interval splines
     dict(name="r_i1", pdf="i1", flow="r", perturb=0.7),
     dict(name="r_i1_m1p1_rr_cond", pdf="i1_-1.0_1.0", flow="rr", mlp_scale=1000.0, kwargs=dict(conditional_input_dim=2)),

@@ -21,6 +21,8 @@ def test_library_exports_every_declared_symbol():
     declared = set(re.findall(r"\bint(?:64_t)?\s+(jf_[a-z0-9_]+)\s*\(", header))
     for fam, suffix in re.findall(r"^JF_DECLARE_MCHAIN\((\w+),\s*\w+,\s*(\w+)\)", header, flags=re.M):   # macro-declared chain entry points
         declared |= {"jf_%s_chain_inv_%s" % (fam, suffix), "jf_%s_chain_fwd_%s" % (fam, suffix)}
+    for suffix in re.findall(r"^JF_DECLARE_T\(\w+,\s*(\w+)\)", header, flags=re.M):
+        declared |= {"jf_t_layer_inv_" + suffix, "jf_t_layer_fwd_" + suffix, "jf_t_layer_inv_bwd_" + suffix}
     for fam, suffix in re.findall(r"^JF_DECLARE_MCHAIN_BWD\((\w+),\s*\w+,\s*(\w+)\)", header, flags=re.M):
         declared.add("jf_%s_chain_inv_bwd_%s" % (fam, suffix))
     assert declared == set(_hip.exported_symbols()), declared ^ set(_hip.exported_symbols())
@@ -92,7 +94,9 @@ def test_no_cpu_fallback():
 def test_unsupported_things_fail_loudly():
     import jammy_flows_amd
     with pytest.raises(NotImplementedError):
-        jammy_flows_amd.pdf("e2", "t")
+        jammy_flows_amd.pdf("e2", "c")                      # continuous manifold flow: needs torchdiffeq, outside the hot path
+    p = jammy_flows_amd.pdf("e3", "gggt")                   # the docs' recommended Euclidean setting constructs (suggested_settings.rst:12-42)
+    assert [type(l).__name__ for l in p.layer_list[0]] == ["gf_block"] * 3 + ["mvn_block"]
     with pytest.raises(NotImplementedError):
         jammy_flows_amd.pdf("e2", "gg", options_overwrite={"g": {"add_skewness": 1}})
     with pytest.raises(NotImplementedError):
