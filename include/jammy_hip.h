@@ -298,6 +298,22 @@ int jf_conditioning_rows_f64(const jf_cond_segment* segments, int32_t n_segments
 int jf_normal_logp_f32(const float* z, int64_t z_stride, int64_t B, int32_t D, const float* in, float* out, void* stream);
 int jf_normal_logp_f64(const double* z, int64_t z_stride, int64_t B, int32_t D, const double* in, double* out, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Reductions of the analysis utilities, so that 1e5 .. 1e6 evaluated rows never travel to the host:
+ * jf_coverage_histogram: the counting loop of calculate_approximate_coverage (jammy_flows/helper_fns/coverage.py:45-65) behind
+ *   pdf.approximate_coverage (main/default.py:1954-2022).  twice[b] = 2 (log_at_zero - log_prob_base[b]); thresholds = chi2.ppf of the expected
+ *   coverage probabilities (ascending, n <= 1024); hist[i] (i <= n, int64, ADDED to) = rows whose first threshold with twice < thr is i
+ *   (i = n: none), so #(twice < thr[i]) = hist[0] + ... + hist[i].  twice_out nullable.
+ * jf_segment_reduce: the sample means of pdf.entropy (main/default.py:2263-2454): out[g] = -mean_s in[g, s] (mode 0) or
+ *   logsumexp_s in[g, s] - log S (mode 1), in row-major (n_seg, seg_len).
+ * ------------------------------------------------------------------------------------------------------------ */
+int jf_coverage_histogram_f32(const float* log_prob_base, int64_t B, double log_at_zero, const float* thresholds, int32_t n, int64_t* hist,
+                              float* twice_out, void* stream);
+int jf_coverage_histogram_f64(const double* log_prob_base, int64_t B, double log_at_zero, const double* thresholds, int32_t n, int64_t* hist,
+                              double* twice_out, void* stream);
+int jf_segment_reduce_f32(const float* in, int64_t n_seg, int64_t seg_len, int32_t mode, float* out, void* stream);
+int jf_segment_reduce_f64(const double* in, int64_t n_seg, int64_t seg_len, int32_t mode, double* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -109,6 +109,8 @@ _SIGNATURES = {
     "jf_sphere_to_embedding": [_P, _I64, _P, _I64, _I32, _P, _I64, _P, _P],
     "jf_sphere_from_embedding": [_P, _I64, _P, _I64, _I32, _P, _I64, _P, _P],
     "jf_conditioning_rows": [ctypes.POINTER(jf_cond_segment), _I32, _I64, _P, _I64, _P],
+    "jf_coverage_histogram": [_P, _I64, ctypes.c_double, _P, _I32, _P, _P, _P],
+    "jf_segment_reduce": [_P, _I64, _I64, _I32, _P, _P],
     "jf_t_layer_inv": [_P, _I64, _P, _P, _I64, _I32, _I64, _I32, ctypes.POINTER(jf_t_layer), _P, _I64, _P, _P, _P, _P, _P],
     "jf_t_layer_fwd": [_P, _I64, _P, _P, _I64, _I32, _I64, _I32, ctypes.POINTER(jf_t_layer), _P, _I64, _P, _P, _P, _P, _P],
     "jf_t_layer_inv_bwd": [_P, _I64, _P, _I64, _I32, _I64, _I32, ctypes.POINTER(jf_t_layer), _P, _I64, _P, _P, _P, _I64, _P, _I64, _P, _P],
@@ -462,6 +464,29 @@ def conditioning_rows(segments, B, dtype, device):
         width += t.shape[1] if kind == 0 else kind + 1
     out = torch.empty((B, width), dtype=dtype, device=device)
     _launch("jf_conditioning_rows" + _suffix(out), "", (arr, len(segments), B, _ptr(out), out.stride(0)), dev)
+    return out
+
+
+def coverage_histogram(log_prob_base, log_at_zero, thresholds, want_twice=True):
+    """counting step of approximate_coverage on the device -> (counts (n,) int64 on the host: #rows with twice < thresholds[i], twice (B,))"""
+    dev = require_device(log_prob_base, thresholds)
+    lpb = log_prob_base.contiguous()
+    thr = thresholds.to(dtype=lpb.dtype).contiguous()
+    n = thr.shape[0]
+    hist = torch.zeros((n + 1,), dtype=torch.int64, device=lpb.device)
+    twice = torch.empty_like(lpb) if want_twice else None
+    _launch("jf_coverage_histogram" + _suffix(lpb), "", (_ptr(lpb), lpb.shape[0], float(log_at_zero), _ptr(thr), n, _ptr(hist), _ptr(twice)), dev)
+    return torch.cumsum(hist[:n], 0).cpu().numpy(), twice
+
+
+def segment_reduce(values, seg_len, mode):
+    """values (n_seg * seg_len,) -> (n_seg,): mode 'neg_mean' = -mean over each segment, 'logmeanexp' = logsumexp - log(seg_len)"""
+    dev = require_device(values)
+    v = values.contiguous().reshape(-1)
+    assert v.shape[0] % seg_len == 0
+    n_seg = v.shape[0] // seg_len
+    out = torch.empty((n_seg,), dtype=v.dtype, device=v.device)
+    _launch("jf_segment_reduce" + _suffix(v), mode, (_ptr(v), n_seg, seg_len, {"neg_mean": 0, "logmeanexp": 1}[mode], _ptr(out)), dev)
     return out
 
 

@@ -59,6 +59,66 @@ __global__ void __launch_bounds__(256) normal_logp_kernel(const T* __restrict__ 
     out[row] = s;
 }
 
+// ---- coverage: histogram of 2 (log N(0) - log_prob_base) over ascending chi^2 quantile thresholds (helper_fns/coverage.py:45-65)
+constexpr int COV_MAX_T = 1024;
+template <typename T>
+__global__ void __launch_bounds__(256) coverage_hist_kernel(const T* __restrict__ lpb, int64_t B, T log_at_zero, const T* __restrict__ thr, int n,
+                                                            unsigned long long* __restrict__ hist, T* __restrict__ twice_out) {
+    __shared__ unsigned int h[COV_MAX_T + 1];
+    __shared__ T th[COV_MAX_T];
+    for (int i = threadIdx.x; i <= n; i += 256) h[i] = 0u;
+    for (int i = threadIdx.x; i < n; i += 256) th[i] = thr[i];
+    __syncthreads();
+    for (int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x; row < B; row += (int64_t)gridDim.x * 256) {
+        const T tw = T(2) * (log_at_zero - lpb[row]);
+        if (twice_out) twice_out[row] = tw;
+        int lo = 0, hi = n;                                  // first index with tw < th[idx] (n: none; NaN lands there too)
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (tw < th[mid]) hi = mid; else lo = mid + 1; }
+        atomicAdd(&h[(tw == tw) ? lo : n], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i <= n; i += 256) if (h[i]) atomicAdd(hist + i, (unsigned long long)h[i]);
+}
+template <typename T> static int coverage_hist(const T* lpb, int64_t B, double log_at_zero, const T* thr, int32_t n, int64_t* hist, T* twice, void* stream) {
+    if (!lpb || !thr || !hist || n < 1 || B < 0) return JF_ERR_BADARG;
+    if (n > COV_MAX_T) return JF_ERR_UNSUPPORTED;
+    if (B == 0) return JF_OK;
+    int64_t blocks = (B + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(coverage_hist_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, lpb, B, (T)log_at_zero, thr, (int)n,
+                       reinterpret_cast<unsigned long long*>(hist), twice);
+    return check_launch();
+}
+
+// ---- entropy reductions: out[g] = -mean_s in[g, s]  (mode 0)   or   log-mean-exp_s in[g, s]  (mode 1: logsumexp - log S)
+template <typename T>
+__global__ void __launch_bounds__(64) segment_reduce_kernel(const T* __restrict__ in, int64_t n_seg, int64_t seg_len, int mode, T* __restrict__ out) {
+    const int64_t g = blockIdx.x;
+    if (g >= n_seg) return;
+    const T* p = in + g * seg_len;
+    const int lane = threadIdx.x;
+    if (mode == 0) {
+        T s = T(0);
+        for (int64_t i = lane; i < seg_len; i += 64) s += p[i];
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+        if (lane == 0) out[g] = -s / T(seg_len);
+    } else {
+        T m = -INFINITY;
+        for (int64_t i = lane; i < seg_len; i += 64) m = M<T>::max(m, p[i]);
+        for (int off = 32; off > 0; off >>= 1) m = M<T>::max(m, __shfl_xor(m, off, 64));
+        T s = T(0);
+        for (int64_t i = lane; i < seg_len; i += 64) s += M<T>::exp(p[i] - m);
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+        if (lane == 0) out[g] = m + M<T>::log(s) - M<T>::log(T(seg_len));
+    }
+}
+template <typename T> static int segment_reduce(const T* in, int64_t n_seg, int64_t seg_len, int32_t mode, T* out, void* stream) {
+    if (!in || !out || n_seg < 0 || seg_len < 1 || mode < 0 || mode > 1) return JF_ERR_BADARG;
+    if (n_seg == 0) return JF_OK;
+    hipLaunchKernelGGL(segment_reduce_kernel<T>, dim3((unsigned)n_seg), dim3(64), 0, (hipStream_t)stream, in, n_seg, seg_len, (int)mode, out);
+    return check_launch();
+}
+
 template <typename T> static int normal_logp(const T* z, int64_t zs, int64_t B, int32_t D, const T* in, T* out, void* stream) {
     if (!z || !out || D < 0 || B < 0) return JF_ERR_BADARG;
     if (B == 0) return JF_OK;
@@ -74,6 +134,18 @@ int jf_conditioning_rows_f32(const jf_cond_segment* g, int32_t n, int64_t B, flo
 }
 int jf_conditioning_rows_f64(const jf_cond_segment* g, int32_t n, int64_t B, double* out, int64_t os, void* s) {
     return jf::conditioning_rows<double>(g, n, B, out, os, s);
+}
+int jf_coverage_histogram_f32(const float* l, int64_t B, double z0, const float* thr, int32_t n, int64_t* hist, float* tw, void* s) {
+    return jf::coverage_hist<float>(l, B, z0, thr, n, hist, tw, s);
+}
+int jf_coverage_histogram_f64(const double* l, int64_t B, double z0, const double* thr, int32_t n, int64_t* hist, double* tw, void* s) {
+    return jf::coverage_hist<double>(l, B, z0, thr, n, hist, tw, s);
+}
+int jf_segment_reduce_f32(const float* in, int64_t n_seg, int64_t seg_len, int32_t mode, float* out, void* s) {
+    return jf::segment_reduce<float>(in, n_seg, seg_len, mode, out, s);
+}
+int jf_segment_reduce_f64(const double* in, int64_t n_seg, int64_t seg_len, int32_t mode, double* out, void* s) {
+    return jf::segment_reduce<double>(in, n_seg, seg_len, mode, out, s);
 }
 int jf_normal_logp_f32(const float* z, int64_t zs, int64_t B, int32_t D, const float* in, float* out, void* s) {
     return jf::normal_logp<float>(z, zs, B, D, in, out, s);

@@ -570,14 +570,16 @@ class pdf(nn.Module):
 
     # =========================================================================================== log-prob direction
     def _inverse_impl(self, x, log_det, data_summary, amortization_parameters, force_embedding_coordinates, force_intrinsic_coordinates,
-                      only_last, want_base_logp, status):
+                      only_last, want_base_logp, status, per_block=None):
+        """`per_block` (optional list): receives the accumulated log_det after the coordinate transformation of each block (first
+        len(layer_list) entries, only when a transformation is forced) and after each block's flow -- what the marginal entropies need."""
         _hip.require_device(x, log_det)
         if force_embedding_coordinates:
             assert x.shape[1] == self.total_target_dim_embedded, (x.shape[1], self.total_target_dim_embedded)
-            x, log_det = self.transform_target_space(x, log_det, transform_from="embedding", transform_to="default")
+            x, log_det = self.transform_target_space(x, log_det, transform_from="embedding", transform_to="default", per_block=per_block)
         elif force_intrinsic_coordinates:
             assert x.shape[1] == self.total_target_dim_intrinsic
-            x, log_det = self.transform_target_space(x, log_det, transform_from="intrinsic", transform_to="default")
+            x, log_det = self.transform_target_space(x, log_det, transform_from="intrinsic", transform_to="default", per_block=per_block)
         else:
             assert x.shape[1] == self.total_target_dim, (x.shape[1], self.total_target_dim)
         if amortization_parameters is not None:
@@ -617,6 +619,8 @@ class pdf(nn.Module):
                     base_logp = res[2]
                 if lazy:
                     embeds.append(block[-1]._embedding_conditional_return(tgt))
+                if per_block is not None:
+                    per_block.append(log_det)
                 continue
             extra, counter = self._block_params(si, data_summary, embeds, amortization_parameters, counter)
             if only_last:
@@ -672,6 +676,8 @@ class pdf(nn.Module):
                     base_logp = _hip.normal_logp(out_view, base_logp)
             if lazy:
                 embeds.append(block[-1]._embedding_conditional_return(tgt))
+            if per_block is not None:
+                per_block.append(log_det)
         return base, log_det, base_logp
 
     def all_layer_inverse(self, x, log_det, data_summary, amortization_parameters=None, force_embedding_coordinates=False,
@@ -807,8 +813,9 @@ class pdf(nn.Module):
 
     # =========================================================================================== sampling direction
     def all_layer_forward(self, x, log_det, data_summary, amortization_parameters=None, force_embedding_coordinates=False,
-                          force_intrinsic_coordinates=False, only_last=False, status=None):
-        """autoregressive forward mapping base -> target -> (x, log_det)  (:1373-1531)."""
+                          force_intrinsic_coordinates=False, only_last=False, status=None, per_block=None):
+        """autoregressive forward mapping base -> target -> (x, log_det)  (:1373-1531).  `per_block` (optional list) receives the accumulated
+        log_det after each block's flow and then after each block's coordinate transformation (if one is forced)."""
         _hip.require_device(x, log_det)
         if amortization_parameters is not None:
             assert amortization_parameters.shape[1] == self.total_number_amortizable_params
@@ -866,11 +873,13 @@ class pdf(nn.Module):
                         cur, log_det = grp[0].flow_mapping([cur, log_det], extra_inputs=this, **kw)[:2]
                 out_view.copy_(cur)
             embeds.append(block[-1]._embedding_conditional_return(out_view))
+            if per_block is not None:
+                per_block.append(log_det)
         x_new = out
         if force_embedding_coordinates:
-            x_new, log_det = self.transform_target_space(x_new, log_det, transform_from="default", transform_to="embedding")
+            x_new, log_det = self.transform_target_space(x_new, log_det, transform_from="default", transform_to="embedding", per_block=per_block)
         elif force_intrinsic_coordinates:
-            x_new, log_det = self.transform_target_space(x_new, log_det, transform_from="default", transform_to="intrinsic")
+            x_new, log_det = self.transform_target_space(x_new, log_det, transform_from="default", transform_to="intrinsic", per_block=per_block)
         return x_new, log_det
 
     def _obtain_sample(self, conditional_input=None, predefined_target_input=None, samplesize=1, seed=None, amortization_parameters=None,
@@ -928,11 +937,126 @@ class pdf(nn.Module):
                                        failsafe_crosscheck_tolerance=failsafe_crosscheck_tolerance, device=device, dtype=dtype,
                                        only_last=only_last)
 
+    # =========================================================================================== analysis reductions
+    def approximate_coverage(self, target_x, conditional_input=None, amortization_parameters=None, force_embedding_coordinates=False,
+                             force_intrinsic_coordinates=False, num_percentile_points=100, sub_manifolds=[-1]):
+        """approximate coverage through the base distribution: 2 (log p_base(0) - log p_base(z)) is chi^2 distributed for a calibrated pdf
+        (:1954-2022, helper_fns/coverage.py:45-65).  Same return dictionary as the reference ("expected", "true", "logprob_diffs",
+        "chi2_cdf_evals", keyed "total" / sub-manifold index).  The forward pass and the counting run on the device (jf_coverage_histogram):
+        only the histogram -- and the per-row arrays the reference's API hands back -- go to the host."""
+        from scipy import stats
+        expected = numpy.linspace(0, 1.0, num_percentile_points)
+        ret = {"true": {}, "logprob_diffs": {}, "chi2_cdf_evals": {}, "expected": expected}
+        with torch.no_grad():
+            _, logp_base, base = self.forward(target_x, conditional_input=conditional_input, amortization_parameters=amortization_parameters,
+                                              force_embedding_coordinates=force_embedding_coordinates,
+                                              force_intrinsic_coordinates=force_intrinsic_coordinates)
+
+            def one(lpb, dim):
+                thr = torch.from_numpy(stats.chi2.ppf(expected, df=dim)).to(device=lpb.device)
+                counts, twice = _hip.coverage_histogram(lpb, -(dim / 2.0) * numpy.log(2 * numpy.pi), thr)
+                twice = twice.double().cpu().numpy()
+                return counts.astype(numpy.float64) / float(lpb.shape[0]), twice, stats.chi2.cdf(twice, df=dim)
+
+            for sm in sub_manifolds:
+                if sm == -1:
+                    key, (t, d, c) = "total", one(logp_base, self.total_base_dim)
+                else:
+                    assert 0 <= sm < len(self.pdf_defs_list), "Sub manifold index %d is invalid" % sm
+                    a, b = self.target_dim_indices_intrinsic[sm]            # the reference indexes base_points with the intrinsic target ranges
+                    key, (t, d, c) = int(sm), one(_hip.normal_logp(base[:, a:b]), self.target_dims_intrinsic[sm])
+                ret["true"][key], ret["logprob_diffs"][key], ret["chi2_cdf_evals"][key] = t, d, c
+        return ret
+
+    def entropy(self, sub_manifolds=[-1], conditional_input=None, force_embedding_coordinates=True, force_intrinsic_coordinates=False,
+                samplesize=100, failsafe_crosscheck_tolerance=None, dtype=None, device=None, predefined_base=None):
+        """Monte-Carlo entropy of the pdf and of the marginal pdfs of single sub-manifolds (:2263-2454): -mean log p over `samplesize`
+        samples per conditional input; for the marginal of sub-manifold k > 0 the conditional density p(x_k | x_<k) of each of the S
+        samples is averaged over the S draws of x_<k (log-mean-exp over an S x S evaluation).  Sampling, the S^2-row log-prob pass and the
+        sample means (jf_segment_reduce) all stay on the device.  `predefined_base` injects the standard-normal base samples (tests)."""
+        if failsafe_crosscheck_tolerance:
+            raise NotImplementedError("failsafe_crosscheck_tolerance (recheck_sampling) is outside the MI355X hot path")
+        dt, dev = self.obtain_current_dtype_n_device()
+        dev = device if device is not None else dev
+        dt = dtype if dtype is not None else dt
+        S = samplesize
+        data_summary, batch = None, 1
+        if conditional_input is not None:
+            assert self.conditional_input_dim is not None
+            if type(conditional_input) == list:
+                dt, dev, batch = conditional_input[0].dtype, conditional_input[0].device, conditional_input[0].shape[0]
+                data_summary = [ci.repeat_interleave(S, dim=0) for ci in conditional_input]
+            else:
+                dt, dev, batch = conditional_input.dtype, conditional_input.device, conditional_input.shape[0]
+                data_summary = conditional_input.repeat_interleave(S, dim=0)
+        else:
+            assert self.conditional_input_dim is None, "We require conditional input, since this is a conditional PDF."
+        for sm in sub_manifolds:
+            assert sm == -1 or 0 <= sm < len(self.layer_list)
+        nsub = len(self.layer_list)
+        out = {}
+        with torch.no_grad():
+            z = predefined_base if predefined_base is not None else torch.randn((S * batch, self.total_base_dim), dtype=dt, device=dev)
+            assert z.shape == (S * batch, self.total_base_dim)
+            status = _hip.new_status(z.device) if self.check_status else None
+            marks = []
+            targets, log_det = self.all_layer_forward(z, None, data_summary, force_embedding_coordinates=force_embedding_coordinates,
+                                                      force_intrinsic_coordinates=force_intrinsic_coordinates, status=status, per_block=marks)
+            self._report_status(status)
+            forced = force_embedding_coordinates or force_intrinsic_coordinates
+
+            def increments(acc, start):
+                """accumulated log-dets (None = nothing added yet) -> per-block increments"""
+                res, prev = [], start
+                for m in acc:
+                    cur = 0.0 if m is None else m
+                    res.append(cur - (0.0 if prev is None else prev))
+                    prev = m
+                return res
+            # sampling direction: flow marks first, then (if forced) the marks of the coordinate transformation
+            flow_inc = increments(marks[:nsub], None)
+            trans_inc = increments(marks[nsub:], marks[nsub - 1]) if forced else [0.0] * nsub
+            if -1 in sub_manifolds:
+                out["total"] = _hip.segment_reduce(_hip.normal_logp(z) - log_det, S, "neg_mean")
+            for sm in sub_manifolds:
+                if sm == -1:
+                    continue
+                ba, bb = self.base_dim_indices[sm]
+                if sm == 0:
+                    out[0] = _hip.segment_reduce(_hip.normal_logp(z[:, ba:bb]) - (flow_inc[0] + trans_inc[0]), S, "neg_mean")
+                    continue
+                dims = self.target_dims_embedded if force_embedding_coordinates else (
+                    self.target_dims_intrinsic if force_intrinsic_coordinates else self.target_dims)
+                first = sum(dims[:sm])
+                w = dims[sm]
+                # rows (g, i, j): x_<k of sample j, x_k of sample i of conditional input g; later sub-manifolds filled with ones (:2413-2416)
+                tg = targets.reshape(batch, S, -1)
+                prev = tg[:, None, :, :first].expand(batch, S, S, first)
+                fin = tg[:, :, None, first:first + w].expand(batch, S, S, w)
+                fill = torch.ones((batch, S, S, targets.shape[1] - first - w), dtype=targets.dtype, device=targets.device)
+                filled = torch.cat([prev, fin, fill], dim=3).reshape(batch * S * S, -1)
+                ds2 = None
+                if data_summary is not None:
+                    ds2 = ([d.repeat_interleave(S, dim=0) for d in data_summary] if type(data_summary) == list
+                           else data_summary.repeat_interleave(S, dim=0))
+                marks2 = []
+                base2, _, _ = self._inverse_impl(filled, None, ds2, None, force_embedding_coordinates, force_intrinsic_coordinates, False, False, None,
+                                                 per_block=marks2)
+                # log-prob direction: (if forced) transformation marks first, then the flow marks continuing from their total
+                if forced:
+                    t_inc = increments(marks2[:nsub], None)
+                    f_inc = increments(marks2[nsub:], marks2[nsub - 1])
+                else:
+                    t_inc, f_inc = [0.0] * nsub, increments(marks2, None)
+                lp = _hip.normal_logp(base2[:, ba:bb]) + f_inc[sm] + t_inc[sm]
+                out[sm] = _hip.segment_reduce(_hip.segment_reduce(lp, S, "logmeanexp"), S, "neg_mean")
+        return out
+
     # =========================================================================================== coordinate systems
     def transform_target_into_returnable_params(self, target):
         return self.transform_target_space(target)[0]
 
-    def transform_target_space(self, target, log_det=0, transform_from="default", transform_to="embedding"):
+    def transform_target_space(self, target, log_det=0, transform_from="default", transform_to="embedding", per_block=None):
         """default / intrinsic / embedding coordinates of the target tensor (:1737-1813)."""
         new_target = target.unsqueeze(0) if target.dim() == 1 else target
         dims = {"default": self.target_dims, "intrinsic": self.target_dims_intrinsic, "embedding": self.target_dims_embedded}
@@ -946,6 +1070,8 @@ class pdf(nn.Module):
             n = dims[transform_from][si]
             t, log_det = block[-1].transform_target_space(new_target[:, c:c + n], log_det=log_det, transform_from=transform_from,
                                                           transform_to=transform_to)
+            if per_block is not None:
+                per_block.append(log_det)
             vals.append(t)
             c += n
         res = torch.cat(vals, dim=1) if len(vals) > 1 else vals[0]
