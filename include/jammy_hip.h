@@ -146,6 +146,22 @@ int jf_linear_f32(const float* in, int64_t in_stride, const float* W, int64_t w_
 int jf_linear_f64(const double* in, int64_t in_stride, const double* W, int64_t w_stride, const double* bias, int64_t B,
                   int32_t K, int32_t N, int32_t act, double* out, int64_t out_stride, void* stream);
 
+/* One AmortizableMLP stage with PER-SAMPLE weights (amortize_everything / fully_amortized_pdf: _apply_amortized_mlp with extra_inputs,
+ * amortizable_mlp.py:508-578): out[b] = act(W_b in[b] + bias_b) (+ residual[b]); `segment` points at this stage's [U | V | bias] slice of
+ * row 0 of the per-sample parameter block (row stride segment_stride): rank == 0: U = W (n_out x n_in); else U (n_out x rank), V (rank x n_in).
+ * n_in, n_out <= 1024, rank <= 64.  jf_amlp_stage_bwd: g_out -> g_in (nullable) and g_segment (B, n_u + n_v + n_b); `y` = the stage's
+ * activated output (needed for act == 1). */
+#define JF_DECLARE_AMLP(T, suffix)                                                                                                         \
+    int jf_amlp_stage_##suffix(const T* in, int64_t in_stride, const T* segment, int64_t segment_stride, int64_t B, int32_t n_in,            \
+                               int32_t n_out, int32_t rank, int32_t has_bias, int32_t act, const T* residual, int64_t residual_stride,      \
+                               T* out, int64_t out_stride, void* stream);                                                                   \
+    int jf_amlp_stage_bwd_##suffix(const T* in, int64_t in_stride, const T* segment, int64_t segment_stride, int64_t B, int32_t n_in,        \
+                                   int32_t n_out, int32_t rank, int32_t has_bias, int32_t act, const T* y, int64_t y_stride,                \
+                                   const T* g_out, int64_t g_out_stride, T* g_in, int64_t g_in_stride, T* g_segment,                        \
+                                   int64_t g_segment_stride, void* stream);
+JF_DECLARE_AMLP(float, f32)
+JF_DECLARE_AMLP(double, f64)
+
 /* The default amortisation MLP with ONE hidden layer in a single launch: out = tanh(in @ W1^T + b1) @ W2^T + b2
  * (nn.Sequential(Linear, Tanh, Linear), main/default.py:656-670); hidden activations stay in registers (never in HBM).  K1 <= 32, H <= 128,
  * otherwise JF_ERR_UNSUPPORTED (use jf_linear per layer).  W1 (H, K1), W2 (N, H) row-major. */

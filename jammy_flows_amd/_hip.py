@@ -111,6 +111,8 @@ _SIGNATURES = {
     "jf_conditioning_rows": [ctypes.POINTER(jf_cond_segment), _I32, _I64, _P, _I64, _P],
     "jf_coverage_histogram": [_P, _I64, ctypes.c_double, _P, _I32, _P, _P, _P],
     "jf_segment_reduce": [_P, _I64, _I64, _I32, _P, _P],
+    "jf_amlp_stage": [_P, _I64, _P, _I64, _I64, _I32, _I32, _I32, _I32, _I32, _P, _I64, _P, _I64, _P],
+    "jf_amlp_stage_bwd": [_P, _I64, _P, _I64, _I64, _I32, _I32, _I32, _I32, _I32, _P, _I64, _P, _I64, _P, _I64, _P, _I64, _P],
     "jf_t_layer_inv": [_P, _I64, _P, _P, _I64, _I32, _I64, _I32, ctypes.POINTER(jf_t_layer), _P, _I64, _P, _P, _P, _P, _P],
     "jf_t_layer_fwd": [_P, _I64, _P, _P, _I64, _I32, _I64, _I32, ctypes.POINTER(jf_t_layer), _P, _I64, _P, _P, _P, _P, _P],
     "jf_t_layer_inv_bwd": [_P, _I64, _P, _I64, _I32, _I64, _I32, ctypes.POINTER(jf_t_layer), _P, _I64, _P, _P, _P, _I64, _P, _I64, _P, _P],
@@ -488,6 +490,35 @@ def segment_reduce(values, seg_len, mode):
     out = torch.empty((n_seg,), dtype=v.dtype, device=v.device)
     _launch("jf_segment_reduce" + _suffix(v), mode, (_ptr(v), n_seg, seg_len, {"neg_mean": 0, "logmeanexp": 1}[mode], _ptr(out)), dev)
     return out
+
+
+def amlp_stage(x, seg, n_in, n_out, rank, has_bias, act, residual=None):
+    """one AmortizableMLP stage with per-sample weights: seg (B, n_u + n_v + n_b) = this stage's slice of the per-sample parameter block
+    (a strided view is fine).  out = act(W_b x_b + bias_b) (+ residual)."""
+    dev = require_device(x, seg, residual)
+    x, seg = _rowmajor(x), _rowmajor(seg)
+    B = x.shape[0]
+    if x.shape[1] != n_in or seg.shape[0] != B or x.dtype != seg.dtype:
+        raise ValueError("amlp_stage: inconsistent shapes / dtypes")
+    if residual is not None:
+        residual = _rowmajor(residual)
+    out = torch.empty((B, n_out), dtype=x.dtype, device=x.device)
+    _launch("jf_amlp_stage" + _suffix(x), "in%d_out%d_r%d" % (n_in, n_out, rank),
+            (_ptr(x), x.stride(0), _ptr(seg), seg.stride(0), B, n_in, n_out, rank, 1 if has_bias else 0, act, _ptr(residual),
+             residual.stride(0) if residual is not None else 0, _ptr(out), out.stride(0)), dev)
+    return out
+
+
+def amlp_stage_bwd(x, seg, n_in, n_out, rank, has_bias, act, y, g_out, want_g_in=True):
+    dev = require_device(x, seg, y, g_out)
+    x, seg, g_out = _rowmajor(x), _rowmajor(seg), _rowmajor(g_out)
+    B = x.shape[0]
+    g_seg = torch.empty((B, seg.shape[1]), dtype=x.dtype, device=x.device)
+    g_in = torch.empty((B, n_in), dtype=x.dtype, device=x.device) if want_g_in else None
+    _launch("jf_amlp_stage_bwd" + _suffix(x), "in%d_out%d_r%d" % (n_in, n_out, rank),
+            (_ptr(x), x.stride(0), _ptr(seg), seg.stride(0), B, n_in, n_out, rank, 1 if has_bias else 0, act, _ptr(y), y.stride(0) if y is not None else 0,
+             _ptr(g_out), g_out.stride(0), _ptr(g_in), g_in.stride(0) if g_in is not None else 0, _ptr(g_seg), g_seg.stride(0)), dev)
+    return g_in, g_seg
 
 
 def normal_logp(z, acc=None):

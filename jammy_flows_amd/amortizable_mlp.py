@@ -1,11 +1,13 @@
 """AmortizableMLP -- an MLP whose U / V / bias entries live in ONE flat vector (``u_v_b_pars``), optionally with low-rank weight
-matrices W = U V^T.  Same constructor, attribute names and flat-vector layout as jammy_flows/amortizable_mlp.py
-(:11-260 construction, :272-375 layout, :377-484 initialisation, :508-682 forward), so a reference ``state_dict`` loads.
+matrices W = U V^T and with the reference's five "highway" layouts.  Same constructor, attribute names and flat-vector layout as
+jammy_flows/amortizable_mlp.py (:11-260 construction, :272-375 layout, :377-484 initialisation, :508-682 forward), so a reference
+``state_dict`` loads, and the same call convention: permanent parameters, or -- ``use_permanent_parameters=False`` -- per-sample
+parameters handed in as ``extra_inputs`` (B, num_amortization_params) by a hyper-network (``fully_amortized_pdf``).
 
-Compute: every matrix product runs on the matrix cores through ``jf_linear_*`` (csrc/mlp_kernels.hip); low-rank stages are two
-launches (V^T first, then U with bias + tanh fused).  Only ``highway_mode=0`` (a plain MLP, the mode jammy_flows.pdf uses by
-default) has a kernel path.
-"""
+Compute: permanent weights -> every matrix product on the matrix cores through ``jf_linear_*`` (csrc/mlp_kernels.hip; low-rank stages are
+two launches, V^T first, then U with bias + tanh fused).  Per-sample weights -> ``jf_amlp_stage_*`` (csrc/amlp_kernels.hip), a streaming pass
+over the parameter block (no weight is shared between rows, so there is nothing to put on the matrix cores).  Both are wrapped in autograd
+Functions (jammy_flows_amd/autograd.py) when gradients are needed."""
 import math
 
 import numpy
@@ -16,18 +18,39 @@ from . import _hip, autograd
 from .extra_functions import list_from_str
 
 
+def _stage_layout(inputs, outputs, ranks, add_final_bias, svd_mode):
+    """per-stage bookkeeping of one sub-MLP (amortizable_mlp.py:272-375): [U | V | b] sizes, full-matrix flags, total"""
+    stages, total = [], 0
+    for i, (a, b) in enumerate(zip(inputs, outputs)):
+        max_rank = min(a, b)
+        if ranks[i] > 0:
+            used = min(max_rank, ranks[i])
+        else:
+            used = 0 if svd_mode == "naive" else max_rank
+        if svd_mode == "naive":
+            full = used == 0
+        else:
+            full = not ((used * (a + b) < a * b) and ranks[i] > 0)
+        nu = a * b if full else used * b
+        nv = 0 if full else used * a
+        last = i == len(inputs) - 1
+        nb = b if (not last or add_final_bias) else 0
+        stages.append(dict(inp=a, out=b, rank=0 if full else used, full=full, num_u=nu, num_v=nv, num_b=nb, act=0 if last else 1))
+        total += nu + nv + nb
+    return stages, total
+
+
 class AmortizableMLP(nn.Module):
     def __init__(self, input_dim, hidden_dims, output_dim, highway_mode=0, low_rank_approximations=0, nonlinearity="tanh",
                  use_permanent_parameters=True, svd_mode="smart", precise_mlp_structure=dict()):
         super().__init__()
-        if highway_mode != 0:
-            raise NotImplementedError("AmortizableMLP highway_mode %d has no HIP path (only mode 0)" % highway_mode)
         if nonlinearity != "tanh":
-            raise NotImplementedError("AmortizableMLP nonlinearity %s has no HIP path (only tanh)" % nonlinearity)
+            raise NotImplementedError("AmortizableMLP nonlinearity %s has no HIP path (only tanh, the default)" % nonlinearity)
         if svd_mode not in ("smart", "naive"):
             raise Exception("unknown svd mode", svd_mode)
         if len(precise_mlp_structure) > 0:
             raise NotImplementedError("precise_mlp_structure is not supported")
+        assert 0 <= highway_mode <= 4
         self.input_dim = input_dim
         self.output_dim = output_dim
         self.highway_mode = highway_mode
@@ -42,7 +65,8 @@ class AmortizableMLP(nn.Module):
             self.hidden_dims = list(hidden_dims)
         else:
             raise Exception("Unsupported type ", type(hidden_dims), " for hidden_dims .. can be int/str/list of ints")
-        n_mat = len(self.hidden_dims) + 1
+        nh = len(self.hidden_dims)
+        n_mat = nh + 1 if highway_mode == 0 else (nh + 2 if highway_mode == 1 else 2 * nh + 1)
         if type(low_rank_approximations) == int:
             ranks = [low_rank_approximations] * n_mat
         elif type(low_rank_approximations) == str:
@@ -52,26 +76,28 @@ class AmortizableMLP(nn.Module):
         assert len(ranks) == n_mat
         self.total_low_rank_approximations = ranks
 
-        # one entry per dense stage: flat-vector layout [U | V | b] per stage (amortizable_mlp.py:284-375)
-        ins = [input_dim] + self.hidden_dims
-        outs = self.hidden_dims + [output_dim]
-        self.stages = []
-        n = 0
-        for i, (a, b) in enumerate(zip(ins, outs)):
-            max_rank = min(a, b)
-            if ranks[i] > 0:
-                used = min(max_rank, ranks[i])
+        # sub-MLPs in flat-vector order; the linear highway (if any) sits at the very END of the vector (:621-629)
+        self.sub_mlps = []          # list of (stages, n_params, input_kind) with input_kind in {"in", "out", "in+out"}
+        self.linear = None
+        if highway_mode < 2:
+            if highway_mode == 0:
+                st, n = _stage_layout([input_dim] + self.hidden_dims, self.hidden_dims + [output_dim], ranks, True, svd_mode)
+                self.sub_mlps.append((st, n, "in"))
             else:
-                used = 0 if svd_mode == "naive" else max_rank
-            if svd_mode == "naive":
-                full = used == 0
-            else:
-                full = not ((used * (a + b) < a * b) and ranks[i] > 0)
-            nu = a * b if full else used * b
-            nv = 0 if full else used * a
-            self.stages.append(dict(inp=a, out=b, rank=used, full=full, num_u=nu, num_v=nv, num_b=b, offset=n))
-            n += nu + nv + b
-        self.num_amortization_params = n
+                if nh > 0:
+                    st, n = _stage_layout([input_dim] + self.hidden_dims, self.hidden_dims + [output_dim], ranks[:-1], False, svd_mode)
+                    self.sub_mlps.append((st, n, "in"))
+                self.linear = _stage_layout([input_dim], [output_dim], ranks[-1:], True, svd_mode)
+        else:
+            start = {2: input_dim, 3: output_dim, 4: input_dim + output_dim}[highway_mode]
+            kind = {2: "in", 3: "out", 4: "in+out"}[highway_mode]
+            for ind in range(nh):
+                a = input_dim if ind == 0 else start
+                st, n = _stage_layout([a, self.hidden_dims[ind]], [self.hidden_dims[ind], output_dim], ranks[2 * ind:2 * ind + 2], False, svd_mode)
+                self.sub_mlps.append((st, n, "in" if ind == 0 else kind))
+            self.linear = _stage_layout([input_dim], [output_dim], ranks[-1:], True, svd_mode)
+        self.num_amortization_params = sum(n for _, n, _ in self.sub_mlps) + (self.linear[1] if self.linear is not None else 0)
+        self.stages = self.sub_mlps[0][0] if (highway_mode == 0) else None        # plain-MLP view used by the fused low-rank block
         self._cast_cache = None
         if use_permanent_parameters:
             self.u_v_b_pars = nn.Parameter(torch.randn(self.num_amortization_params).type(torch.double).unsqueeze(0))
@@ -80,19 +106,25 @@ class AmortizableMLP(nn.Module):
     # ---- initialisation (amortizable_mlp.py:377-484)
     def obtain_default_init_tensor(self, fix_final_bias=None, prev_damping_factor=1000.0):
         init = torch.randn(self.num_amortization_params, dtype=torch.float64).unsqueeze(0)
-        for st in self.stages:
+        o = 0
+        all_stages = [st for stages, _, _ in self.sub_mlps for st in stages]
+        if self.linear is not None:
+            all_stages += self.linear[0]
+        for st in all_stages:
             if st["full"]:
                 fan_in = st["inp"]
                 gain = nn.init.calculate_gain("leaky_relu", numpy.sqrt(5))
                 bound = math.sqrt(3.0) * gain / math.sqrt(fan_in)
-                o = st["offset"]
                 with torch.no_grad():
                     init[:, o:o + st["num_u"]].uniform_(-bound, bound)
-                    bb = 1 / numpy.sqrt(fan_in)
-                    init[:, o + st["num_u"]:o + st["num_u"] + st["num_b"]].uniform_(-bb, bb)
+                    if st["num_b"] > 0:
+                        bb = 1 / numpy.sqrt(fan_in)
+                        init[:, o + st["num_u"]:o + st["num_u"] + st["num_b"]].uniform_(-bb, bb)
+            o += st["num_u"] + st["num_v"] + st["num_b"]
         if fix_final_bias is not None:
             init = init / prev_damping_factor
-            init[0, -self.stages[-1]["num_b"]:] = fix_final_bias
+            nb = all_stages[-1]["num_b"]
+            init[0, -nb:] = fix_final_bias
         return init.squeeze(0)
 
     def initialize_uvbs(self, fix_total=None, fix_final_bias=None, prev_damping_factor=1000.0):
@@ -111,26 +143,54 @@ class AmortizableMLP(nn.Module):
                 self._cast_cache = (key, p.detach().to(device=like.device, dtype=like.dtype).reshape(-1).contiguous())
         return self._cast_cache[1]
 
-    def forward(self, i, extra_inputs=None):
-        """i: (B, input_dim).  extra_inputs (per-sample U/V/b vectors, amortize_everything) has no kernel yet."""
-        if extra_inputs is not None:
-            raise NotImplementedError("AmortizableMLP with per-sample weights (extra_inputs) has no HIP kernel yet")
-        assert self.use_permanent_parameters
-        _hip.require_device(i)
-        grad = autograd._needs_grad(i, self.u_v_b_pars)
-        flat = self.u_v_b_pars.to(dtype=i.dtype).reshape(-1) if grad else self._flat(i)
-        lin = autograd.linear if grad else _hip.linear
-        x = i
-        last = len(self.stages) - 1
-        for si, st in enumerate(self.stages):
-            o = st["offset"]
-            u = flat[o:o + st["num_u"]]
-            v = flat[o + st["num_u"]:o + st["num_u"] + st["num_v"]]
-            b = flat[o + st["num_u"] + st["num_v"]:o + st["num_u"] + st["num_v"] + st["num_b"]]
-            act = 0 if si == last else 1
-            if st["full"]:
-                x = lin(x, u.view(st["out"], st["inp"]), b, act)
+    def _run(self, stages, x, flat, o, per_sample, residual=None):
+        """one sub-MLP.  flat: 1-d permanent vector or (B, P) per-sample block; o: offset of the sub-MLP's first parameter.
+        `residual` is added to the result of the LAST stage (fused into the launch for per-sample weights)."""
+        last = len(stages) - 1
+        for si, st in enumerate(stages):
+            res = residual if si == last else None
+            n = st["num_u"] + st["num_v"] + st["num_b"]
+            if per_sample:
+                x = autograd.amlp_stage(x, flat[:, o:o + n], st["inp"], st["out"], st["rank"], st["num_b"] > 0, st["act"], res)
             else:
-                t = lin(x, v.view(st["rank"], st["inp"]), None, 0)                # V^T x
-                x = lin(t, u.view(st["out"], st["rank"]), b, act)                 # U (V^T x) + b
-        return x
+                lin = autograd.linear
+                u = flat[o:o + st["num_u"]]
+                v = flat[o + st["num_u"]:o + st["num_u"] + st["num_v"]]
+                b = flat[o + st["num_u"] + st["num_v"]:o + n] if st["num_b"] > 0 else None
+                if st["full"]:
+                    x = lin(x, u.view(st["out"], st["inp"]), b, st["act"])
+                else:
+                    t = lin(x, v.view(st["rank"], st["inp"]), None, 0)                # V^T x
+                    x = lin(t, u.view(st["out"], st["rank"]), b, st["act"])           # U (V^T x) + b
+                if res is not None:
+                    x = x + res
+            o += n
+        return x, o
+
+    def forward(self, i, extra_inputs=None):
+        """i: (B, input_dim).  extra_inputs: None (permanent parameters) or the per-sample (B, num_amortization_params) block."""
+        _hip.require_device(i)
+        per_sample = extra_inputs is not None
+        if per_sample:
+            assert not self.use_permanent_parameters, "MLP uses permanent parameters but extra inputs are given in forward. This is not allowed!"
+            assert extra_inputs.shape[1] == self.num_amortization_params, (
+                "Extra inputs dimension (%d) does not match number of amortization params of MLP (%d) " % (extra_inputs.shape[1],
+                                                                                                            self.num_amortization_params))
+            flat = extra_inputs
+        else:
+            assert self.use_permanent_parameters
+            grad = autograd._needs_grad(i, self.u_v_b_pars)
+            flat = self.u_v_b_pars.to(dtype=i.dtype).reshape(-1) if grad else self._flat(i)
+        prev = None
+        if self.linear is not None:                            # its parameters are the LAST ones of the vector (:621-629)
+            prev, _ = self._run(self.linear[0], i, flat, self.num_amortization_params - self.linear[1], per_sample)
+        o = 0
+        for mi, (stages, n, kind) in enumerate(self.sub_mlps):
+            if kind == "in":
+                inp = i
+            elif kind == "out":
+                inp = prev
+            else:
+                inp = torch.cat([i, prev], dim=1)
+            prev, o = self._run(stages, inp, flat, o, per_sample, residual=prev)
+        return prev

@@ -155,3 +155,27 @@ class TLayerInvFn(torch.autograd.Function):
         struct, D = ctx.meta
         g_x, g_params = _hip.t_layer_inv_bwd(x, params, struct, D, g_xout, g_ld, g_blp)
         return (g_x, g_ld if ctx.has[0] else None, g_params if ctx.has[2] else None, g_blp if ctx.has[1] else None, None, None, None)
+
+
+class AmlpStageFn(torch.autograd.Function):
+    """one AmortizableMLP stage with per-sample weights (jf_amlp_stage): out = act(W_b x_b + bias_b) [+ residual]"""
+
+    @staticmethod
+    def forward(ctx, x, seg, residual, n_in, n_out, rank, has_bias, act):
+        y = _hip.amlp_stage(x.detach(), seg.detach(), n_in, n_out, rank, has_bias, act, None)
+        ctx.meta = (n_in, n_out, rank, has_bias, act)
+        ctx.save_for_backward(x, seg, y if act else None)
+        return y if residual is None else y + residual
+
+    @staticmethod
+    def backward(ctx, g):
+        x, seg, y = ctx.saved_tensors
+        n_in, n_out, rank, has_bias, act = ctx.meta
+        g_x, g_seg = _hip.amlp_stage_bwd(x, seg, n_in, n_out, rank, has_bias, act, y, g.contiguous(), want_g_in=ctx.needs_input_grad[0])
+        return g_x, g_seg, (g if ctx.needs_input_grad[2] else None), None, None, None, None, None
+
+
+def amlp_stage(x, seg, n_in, n_out, rank, has_bias, act, residual=None):
+    if _needs_grad(x, seg, residual):
+        return AmlpStageFn.apply(x, seg, residual, n_in, n_out, rank, has_bias, act)
+    return _hip.amlp_stage(x, seg, n_in, n_out, rank, has_bias, act, residual)

@@ -723,8 +723,30 @@ class pdf(nn.Module):
         """forward() with a torch.autograd graph: d log_prob / d (x, conditional_input, MLP weights, permanent layer parameters).
         Same launches as the inference path, wrapped in autograd Functions whose backward is a HIP launch (g chains, manifold chains) or
         rocBLAS GEMMs (dense layers) -- see jammy_flows_amd/autograd.py."""
-        if amortization_parameters is not None or only_last or force_embedding_coordinates or force_intrinsic_coordinates:
-            raise NotImplementedError("gradients with amortization_parameters / only_last / forced coordinate systems are not implemented")
+        if only_last or force_embedding_coordinates or force_intrinsic_coordinates:
+            raise NotImplementedError("gradients with only_last / forced coordinate systems are not implemented")
+        amort = amortization_parameters
+        if amort is not None:
+            assert amort.shape[1] == self.total_number_amortizable_params
+        counter = 0
+
+        def block_params(si, layers, inp, mlp):
+            """(parameter block with grad, new counter): MLP output (own or per-sample weights), a slice of the amortisation block, or the
+            permanent parameters (:936-993)"""
+            nonlocal counter
+            if mlp is not None:
+                if amort is not None:
+                    n = mlp.num_amortization_params
+                    out = mlp(inp, extra_inputs=amort[:, counter:counter + n])
+                    counter += n
+                    return out
+                return mlp(inp)
+            if self.amortize_everything:
+                n = sum(l.get_total_param_num() for l in layers)
+                out = amort[:, counter:counter + n]
+                counter += n
+                return out
+            return self._permanent_row_with_grad(layers, x)
         _hip.require_device(x)
         self._poll_status()
         status = _hip.new_status(x.device) if self.check_status else None
@@ -751,7 +773,7 @@ class pdf(nn.Module):
             if kind == "e" and gfl.chain_supported(layers):
                 larr = _hip.gf_layer_array([l.c_struct() for l in layers])
                 D = layers[0].dimension
-                fused = self._fusable_block(si, layers, False, None, x.dtype) if mlp is not None else None
+                fused = self._fusable_block(si, layers, False, amort, x.dtype) if mlp is not None else None
                 if fused is not None:
                     w1, b1, w2, b2 = mlp[0].weight, mlp[0].bias, mlp[2].weight, mlp[2].bias
                     packed = None
@@ -760,12 +782,12 @@ class pdf(nn.Module):
                     out, log_det, base_logp = autograd.CondBlockFn.apply(inp, w1, b1, w2, b2, tgt, log_det, base_logp, packed, larr, len(layers), D,
                                                                          status)
                 else:
-                    params = mlp(inp) if mlp is not None else self._permanent_row_with_grad(layers, x)
+                    params = block_params(si, layers, inp, mlp)
                     out, log_det, base_logp = autograd.GfChainInvFn.apply(tgt, log_det, params, base_logp, larr, len(layers), D, status)
             elif kind == "e":
                 # Euclidean block mixing 'g' runs with other layers ('t'): one launch per group, last group first (:1002-1012)
                 from ..layers.euclidean.multivariate_normal import mvn_block
-                params = mlp(inp) if mlp is not None else self._permanent_row_with_grad(layers, x)
+                params = block_params(si, layers, inp, mlp)
                 groups = _layer_groups(layers)
                 out, c1 = tgt, params.shape[1]
                 for gi in range(len(groups) - 1, -1, -1):
@@ -784,7 +806,7 @@ class pdf(nn.Module):
                     c1 -= n
                 base_logp = blp
             else:
-                params = mlp(inp) if mlp is not None else self._permanent_row_with_grad(layers, x)
+                params = block_params(si, layers, inp, mlp)
                 fam = _manifold_family(layers)
                 groups = [layers] if fam is not None else [[l] for l in layers]      # mixed families (e.g. "mo"): one launch per layer
                 out, c1 = tgt, params.shape[1]

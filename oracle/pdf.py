@@ -114,7 +114,7 @@ def _resolve_options(letter, sub_index, layer_index, overwrite):
 class OraclePdf:
     def __init__(self, pdf_defs, flow_defs, options_overwrite=None, conditional_input_dim=None, amortization_mlp_dims="128",
                  amortization_mlp_use_custom_mode=False, amortization_mlp_ranks=0, amortize_everything=False,
-                 use_as_passthrough_instead_of_pdf=False, state_dict=None, **unused):
+                 use_as_passthrough_instead_of_pdf=False, state_dict=None, amortization_mlp_highway_mode=0, **unused):
         overwrite = options_overwrite or {}
         self.pdf_defs = pdf_defs.split("+")
         self.flow_defs = flow_defs.split("+")
@@ -187,7 +187,7 @@ class OraclePdf:
             elif blk["nparams"] > 0:
                 in_dim = prev_embed + (conditional_input_dim or 0)
                 if amortization_mlp_use_custom_mode:
-                    spec = ("custom", AmortizableMLPSpec(in_dim, mlp_dims[si], blk["nparams"], mlp_ranks[si]))
+                    spec = ("custom", AmortizableMLPSpec(in_dim, mlp_dims[si], blk["nparams"], mlp_ranks[si], amortization_mlp_highway_mode))
                     if amortize_everything:
                         self.total_number_amortizable_params += spec[1].num_amortization_params
                 else:
@@ -315,24 +315,24 @@ class OraclePdf:
             c += blk["dim"]
         return np.concatenate(outs, axis=1), log_det, bins
 
-    def forward(self, x, cond=None, force_embedding_coordinates=False, trace=None, return_bins=False):
+    def forward(self, x, cond=None, force_embedding_coordinates=False, trace=None, return_bins=False, amortization_parameters=None):
         """-> (log_prob, log_prob_base, base_pos)  (main/default.py:1059-1117)."""
         assert not self.passthrough
         x = np.asarray(x, dtype=np.float64)
         log_det = np.zeros(x.shape[0])
         x, log_det = self._to_default(x, log_det, force_embedding_coordinates)
-        base, log_det, bins = self.all_layer_inverse(x, log_det, cond, trace=trace)
+        base, log_det, bins = self.all_layer_inverse(x, log_det, cond, amortization_parameters=amortization_parameters, trace=trace)
         lp = normal_logpdf_sum(base)
         if return_bins:
             return lp + log_det, lp, base, bins
         return lp + log_det, lp, base
 
-    def sample_from_base(self, z, cond=None, force_embedding_coordinates=False, trace=None, return_bins=False):
+    def sample_from_base(self, z, cond=None, force_embedding_coordinates=False, trace=None, return_bins=False, amortization_parameters=None):
         """_obtain_sample(predefined_target_input=z) -> (x, log_prob, log_prob_base)  (main/default.py:1634-1707)."""
         assert not self.passthrough
         z = np.asarray(z, dtype=np.float64)
         lg = normal_logpdf_sum(z)
-        x, log_det, bins = self.all_layer_forward(z, np.zeros(z.shape[0]), cond, trace=trace)
+        x, log_det, bins = self.all_layer_forward(z, np.zeros(z.shape[0]), cond, amortization_parameters=amortization_parameters, trace=trace)
         if force_embedding_coordinates:
             x, log_det = self._to_embedding(x, log_det)
         if return_bins:

@@ -1,0 +1,134 @@
+"""fully_amortized_pdf: host bookkeeping + oracle on the CPU, HIP parity (-m gpu) against golden vectors generated from the
+real reference (tests/golden/amortized/*.npz, make_amortized_fixtures.py): forward, sampling with injected base noise, gradients."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import fixture_io
+
+DIR = os.path.join(fixture_io.GOLDEN_DIR, "amortized")
+NAMES = sorted(f[:-4] for f in os.listdir(DIR) if f.endswith(".npz"))
+
+
+def load(name):
+    with np.load(os.path.join(DIR, name + ".npz")) as z:
+        g = {k: z[k] for k in z.files}
+    g["meta"] = json.loads(str(g["meta"]))
+    return g
+
+
+def build(g, dtype=torch.float64, device="cpu"):
+    import jammy_flows_amd
+    m = g["meta"]
+    pdf = jammy_flows_amd.fully_amortized_pdf(m["pdf_defs"], m["flow_defs"], **m["kwargs"])
+    sd = {k[3:]: torch.from_numpy(np.ascontiguousarray(v)) for k, v in g.items() if k.startswith("sd/")}
+    missing, unexpected = pdf.load_state_dict(sd, strict=True)
+    assert not missing and not unexpected
+    return pdf.to(dtype=dtype, device=device)
+
+
+def oracle_forward(g):
+    from oracle import OraclePdf
+    from oracle.mlp import AmortizableMLPSpec
+    m = g["meta"]
+    kw = m["kwargs"]
+    inner = OraclePdf(m["pdf_defs"], m["flow_defs"], amortize_everything=True, amortization_mlp_use_custom_mode=True,
+                      amortization_mlp_dims=kw.get("inner_mlp_dims_sub_pdfs", "128"), amortization_mlp_ranks=kw.get("inner_mlp_ranks", 0),
+                      amortization_mlp_highway_mode=kw.get("inner_mlp_highway_mode", 1))
+    hyper = AmortizableMLPSpec(kw["conditional_input_dim"], kw.get("amortization_mlp_dims", "128"), inner.total_number_amortizable_params,
+                               kw.get("amortization_mlp_ranks", 5), kw.get("amortization_mlp_highway_mode", 0))
+    amort = hyper.apply(g["cond"], g["sd/amortization_mlp.u_v_b_pars"].reshape(1, -1))
+    return inner.forward(g["x"], None, amortization_parameters=amort), inner, amort
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_bookkeeping_and_state_dict_match_the_reference(name):
+    g = load(name)
+    pdf = build(g)
+    assert pdf.pdf_to_amortize.total_number_amortizable_params == g["meta"]["total_number_amortizable_params"]
+    assert pdf.count_parameters() == g["meta"]["count_parameters"]
+    assert len(list(pdf.pdf_to_amortize.parameters())) == 0          # every parameter comes from the hyper-network
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_oracle_vs_golden(name):
+    g = load(name)
+    (logp, logp_base, base), inner, amort = oracle_forward(g)
+    assert inner.total_number_amortizable_params == g["meta"]["total_number_amortizable_params"]
+    assert np.abs(logp - g["logp"]).max() < 1e-8 * (1 + np.abs(g["logp"]).max())
+    assert np.abs(base - g["base"]).max() < 1e-8
+    sx, slogp, _ = inner.sample_from_base(g["z"], None, amortization_parameters=amort)
+    assert np.abs(sx - g["sample_x"]).max() < 1e-7
+    assert np.abs(slogp - g["sample_logp"]).max() < 1e-7 * (1 + np.abs(g["sample_logp"]).max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", NAMES)
+def test_gpu_forward_sampling_and_gradients_vs_reference(name):
+    g = load(name)
+    pdf = build(g, torch.float64, "cuda")
+    x = torch.from_numpy(g["x"]).cuda()
+    cond = torch.from_numpy(g["cond"]).cuda()
+    logp, logp_base, base = pdf(x, conditional_input=cond)
+    assert np.abs(logp.cpu().numpy() - g["logp"]).max() < 1e-7 * (1 + np.abs(g["logp"]).max())
+    assert np.abs(base.cpu().numpy() - g["base"]).max() < 1e-7
+    amort = pdf.amortization_mlp(cond)
+    sx, _, slogp, _ = pdf.pdf_to_amortize._obtain_sample(predefined_target_input=torch.from_numpy(g["z"]).cuda(), amortization_parameters=amort)
+    assert np.abs(sx.cpu().numpy() - g["sample_x"]).max() < 1e-6
+    assert np.abs(slogp.cpu().numpy() - g["sample_logp"]).max() < 1e-6 * (1 + np.abs(g["sample_logp"]).max())
+    # gradients of -mean log p w.r.t. x, conditional input and the hyper-network's weights
+    xg, cg = x.clone().requires_grad_(True), cond.clone().requires_grad_(True)
+    with torch.enable_grad():
+        loss = -pdf(xg, conditional_input=cg)[0].mean()
+    loss.backward()
+    assert abs(loss.item() - float(g["loss"])) < 1e-9 * max(1.0, abs(float(g["loss"])))
+
+    def rel(a, b):
+        return float(np.abs(a.detach().cpu().numpy().reshape(b.shape) - b).max()) / max(float(np.abs(b).max()), 1e-9)
+    worst = {"x": rel(xg.grad, g["x_grad"]), "cond": rel(cg.grad, g["cond_grad"])}
+    for k, p in pdf.named_parameters():
+        worst[k] = rel(p.grad, g["pg/" + k])
+    print(name, "max relative gradient error %.2e" % max(worst.values()))
+    assert max(worst.values()) < 1e-7, worst
+    # float32 evaluation path
+    pdf32 = build(g, torch.float32, "cuda")
+    l32 = pdf32(x.float(), conditional_input=cond.float())[0]
+    assert np.abs(l32.double().cpu().numpy() - g["logp"]).max() < 1e-2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [1, 2, 3, 4])
+def test_gpu_permanent_amortizable_mlp_highway_modes_vs_oracle(mode):
+    """pdf(..., amortization_mlp_use_custom_mode=True, amortization_mlp_highway_mode=k) with PERMANENT weights (MFMA dense launches + the
+    highway sums) against the oracle built from the same state_dict (amortizable_mlp.py:581-682)"""
+    import jammy_flows_amd
+    from oracle import OraclePdf
+    torch.manual_seed(mode)
+    kw = dict(conditional_input_dim=3, amortization_mlp_use_custom_mode=True, amortization_mlp_dims="24-16", amortization_mlp_ranks=5,
+              amortization_mlp_highway_mode=mode)
+    pdf = jammy_flows_amd.pdf("e2+s1", "gg+o", **kw).double()
+    with torch.no_grad():
+        for mlp in pdf.mlp_predictors:
+            nb = mlp.output_dim
+            mlp.u_v_b_pars.data[0, :-nb] *= 300.0
+    sd = {k: v.detach().cpu().numpy() for k, v in pdf.state_dict().items()}
+    pdf = pdf.cuda()
+    g = torch.Generator().manual_seed(2)
+    x = torch.cat([torch.randn(128, 2, generator=g, dtype=torch.float64), torch.rand(128, 1, generator=g, dtype=torch.float64) * 6.0 + 0.1], dim=1)
+    c = torch.randn(128, 3, generator=g, dtype=torch.float64)
+    logp = pdf(x.cuda(), conditional_input=c.cuda())[0]
+    ref = OraclePdf("e2+s1", "gg+o", state_dict=sd, **kw).forward(x.numpy(), c.numpy())[0]
+    assert np.abs(logp.cpu().numpy() - ref).max() < 1e-8 * (1 + np.abs(ref).max())
+    # and its gradient against finite differences of the forward
+    cg = c.cuda().requires_grad_(True)
+    with torch.enable_grad():
+        pdf(x.cuda(), conditional_input=cg)[0].sum().backward()
+    eps = 1e-6
+    c2, c3 = c.clone(), c.clone()
+    c2[:, 1] += eps
+    c3[:, 1] -= eps
+    fd = (pdf(x.cuda(), conditional_input=c2.cuda())[0] - pdf(x.cuda(), conditional_input=c3.cuda())[0]) / (2 * eps)
+    assert float(((cg.grad[:, 1] - fd).abs() / (1 + fd.abs())).max()) < 1e-6
