@@ -135,6 +135,31 @@ int jf_cond_gf_chain_inv_split_f32(const float* in, int64_t in_stride, const flo
                                    int32_t n_layers, const jf_gf_layer* layers, float* x_out, int64_t x_out_stride, float* log_det_out,
                                    const float* base_logp_in, float* base_logp_out, int32_t* status, void* stream);
 
+/* A conditional Euclidean block whose parameters come from a two-stage LOW-RANK AmortizableMLP (highway_mode 0), in ONE launch:
+ * params = U2 (V2 tanh(W1 c + b1)) + b2 with W1 = U1 V1 (rank r1) or a full matrix (V1 == NULL, U1 = W1 (H, K1)) and a rank-r2 last stage
+ * (amortizable_mlp.py:508-578), followed by jf_gf_chain_inv on those parameters.  Every parameter of a row is b2[j] + <U2[j, :], t2> for ONE
+ * r2-vector t2 per row, so the (B, N) block is never formed: lanes regenerate their parameters from U2 / b2 held in LDS.
+ * Limits: K1 <= 32, H <= 128, r1, r2 <= 16, D <= 8, layers at the reference's default options (as jf_cond_gf_chain_inv_split_f32, with up to 8
+ * Householder reflections); otherwise JF_ERR_UNSUPPORTED.  U1 (H, r1), V1 (r1, K1), V2 (r2, H), U2 (N, r2): dense row-major. */
+int jf_amlp_gf_chain_inv_f32(const float* in, int64_t in_stride, const float* V1, const float* U1, const float* b1, const float* V2, const float* U2,
+                             const float* b2, int32_t K1, int32_t H, int32_t r1, int32_t r2, const float* x, int64_t x_stride,
+                             const float* log_det_in, int64_t B, int32_t D, int32_t n_layers, const jf_gf_layer* layers, float* x_out,
+                             int64_t x_out_stride, float* log_det_out, const float* base_logp_in, float* base_logp_out, int32_t* status,
+                             void* stream);
+int jf_amlp_gf_chain_inv_f64(const double* in, int64_t in_stride, const double* V1, const double* U1, const double* b1, const double* V2,
+                             const double* U2, const double* b2, int32_t K1, int32_t H, int32_t r1, int32_t r2, const double* x, int64_t x_stride,
+                             const double* log_det_in, int64_t B, int32_t D, int32_t n_layers, const jf_gf_layer* layers, double* x_out,
+                             int64_t x_out_stride, double* log_det_out, const double* base_logp_in, double* base_logp_out, int32_t* status,
+                             void* stream);
+
+/* The same two-stage low-rank AmortizableMLP alone, ONE launch instead of four dense launches:
+ * out (B, N) = U2 (V2 tanh(W1 in + b1)) + b2 (same operand conventions and limits as jf_amlp_gf_chain_inv). */
+int jf_amlp2_f32(const float* in, int64_t in_stride, const float* V1, const float* U1, const float* b1, const float* V2, const float* U2,
+                 const float* b2, int64_t B, int32_t K1, int32_t H, int32_t r1, int32_t r2, int32_t N, float* out, int64_t out_stride, void* stream);
+int jf_amlp2_f64(const double* in, int64_t in_stride, const double* V1, const double* U1, const double* b1, const double* V2, const double* U2,
+                 const double* b2, int64_t B, int32_t K1, int32_t H, int32_t r1, int32_t r2, int32_t N, double* out, int64_t out_stride,
+                 void* stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * Dense layer of the parameter-emitting MLPs: out = act(in @ W^T + bias)   (MFMA)
  * replaces torch.nn.Linear + tanh of the default nn.Sequential (main/default.py:656-670) and the U / V^T products of

@@ -102,6 +102,9 @@ _SIGNATURES = {
     "jf_gf_chain_inv": [_P, _I64, _P, _P, _I64, _I32, _I64, _I32, _I32, ctypes.POINTER(jf_gf_layer), _P, _I64, _P, _P, _P, _P, _I64, _P, _P],
     "jf_cond_gf_chain_inv": [_P, _I64, _P, _I64, _P, _P, _I64, _P, _I32, _I32, _P, _I64, _P, _I64, _I32, _I32, ctypes.POINTER(jf_gf_layer), _P, _I64,
                              _P, _P, _P, _P, _P],
+    "jf_amlp_gf_chain_inv": [_P, _I64, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P, _I64, _P, _I64, _I32, _I32, ctypes.POINTER(jf_gf_layer), _P,
+                             _I64, _P, _P, _P, _P, _P],
+    "jf_amlp2": [_P, _I64, _P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _I32, _P, _I64, _P],
     "jf_gf_chain_fwd": [_P, _I64, _P, _P, _I64, _I32, _I64, _I32, _I32, ctypes.POINTER(jf_gf_layer), _P, _I64, _P, _P, _I64, _P, _P],
     "jf_linear": [_P, _I64, _P, _I64, _P, _I64, _I32, _I32, _I32, _P, _I64, _P],
     "jf_normal_logp": [_P, _I64, _I64, _I32, _P, _P, _P],
@@ -381,6 +384,48 @@ def cond_gf_chain_inv(inp, w1, b1, w2, b2, x, log_det, layer_array, n_layers, D,
              _ptr(x), x.stride(0), _ptr(log_det), B, D, n_layers, layer_array, _ptr(x_out), x_out.stride(0), _ptr(ld_out), _ptr(base_logp_in),
              _ptr(blp_out), _ptr(status)), dev)
     return (x_out, ld_out, blp_out) if want_base_logp else (x_out, ld_out)
+
+
+def amlp_gf_chain_inv(inp, v1, u1, b1, v2, u2, b2, x, log_det, layer_array, n_layers, D, x_out=None, base_logp_in=None, want_base_logp=False,
+                      status=None):
+    """two-stage low-rank AmortizableMLP (v1 None: full first stage u1 (H, K1)) + the chain of g layers it parametrises in ONE launch; the
+    parameter block is regenerated from the rank-space vector of each row on chip (see include/jammy_hip.h)."""
+    dev = require_device(inp, v1, u1, b1, v2, u2, b2, x, log_det, x_out, base_logp_in, status)
+    inp, x = _rowmajor(inp), _rowmajor(x)
+    B, K1 = inp.shape
+    H, r2 = v2.shape[1], v2.shape[0]
+    r1 = 0 if v1 is None else v1.shape[0]
+    ws = [t.contiguous() for t in (u1, b1, v2, u2, b2)]
+    v1c = None if v1 is None else v1.contiguous()
+    if any(t.dtype != x.dtype for t in ws + [inp]) or x.shape != (B, D) or u2.shape[1] != r2 or b2.shape[0] != u2.shape[0]:
+        raise ValueError("amlp_gf_chain_inv: inconsistent shapes / dtypes")
+    if log_det is not None:
+        log_det = log_det.contiguous()
+    if x_out is None:
+        x_out = torch.empty((B, D), dtype=x.dtype, device=x.device)
+    ld_out = torch.empty((B,), dtype=x.dtype, device=x.device)
+    blp_out = torch.empty((B,), dtype=x.dtype, device=x.device) if want_base_logp else None
+    _launch("jf_amlp_gf_chain_inv" + _suffix(x), "K%d_H%d_N%d_D%d_r%d" % (K1, H, u2.shape[0], D, r2),
+            (_ptr(inp), inp.stride(0), _ptr(v1c), _ptr(ws[0]), _ptr(ws[1]), _ptr(ws[2]), _ptr(ws[3]), _ptr(ws[4]), K1, H, r1, r2, _ptr(x), x.stride(0),
+             _ptr(log_det), B, D, n_layers, layer_array, _ptr(x_out), x_out.stride(0), _ptr(ld_out), _ptr(base_logp_in), _ptr(blp_out), _ptr(status)),
+            dev)
+    return (x_out, ld_out, blp_out) if want_base_logp else (x_out, ld_out)
+
+
+def amlp2(inp, v1, u1, b1, v2, u2, b2):
+    """two-stage low-rank AmortizableMLP with permanent weights in one launch: (B, N) = u2 (v2 tanh(W1 inp + b1)) + b2, W1 = u1 v1 or u1 (v1 None)"""
+    dev = require_device(inp, v1, u1, b1, v2, u2, b2)
+    inp = _rowmajor(inp)
+    B, K1 = inp.shape
+    H, r2, N = v2.shape[1], v2.shape[0], u2.shape[0]
+    r1 = 0 if v1 is None else v1.shape[0]
+    ws = [t.contiguous() for t in (u1, b1, v2, u2, b2)]
+    v1c = None if v1 is None else v1.contiguous()
+    out = torch.empty((B, N), dtype=inp.dtype, device=inp.device)
+    _launch("jf_amlp2" + _suffix(inp), "K%d_H%d_N%d_r%d" % (K1, H, N, r2),
+            (_ptr(inp), inp.stride(0), _ptr(v1c), _ptr(ws[0]), _ptr(ws[1]), _ptr(ws[2]), _ptr(ws[3]), _ptr(ws[4]), B, K1, H, r1, r2, N, _ptr(out),
+             out.stride(0)), dev)
+    return out
 
 
 def cond_gf_packed_bytes(layer_array, n_layers, D):

@@ -143,6 +143,32 @@ class AmortizableMLP(nn.Module):
                 self._cast_cache = (key, p.detach().to(device=like.device, dtype=like.dtype).reshape(-1).contiguous())
         return self._cast_cache[1]
 
+    def lowrank_views(self, flat):
+        """(v1, u1, b1, v2, u2, b2) views into the flat vector when this is a plain two-stage MLP whose last stage is low-rank and whose sizes
+        fit jf_amlp2 / jf_amlp_gf_chain_inv (K1 <= 32, hidden <= 128, ranks <= 16); else None"""
+        if self.highway_mode != 0 or self.stages is None or len(self.stages) != 2:
+            return None
+        s1, s2 = self.stages
+        if s2["full"] or s2["rank"] > 16 or (not s1["full"] and s1["rank"] > 16) or s1["inp"] > 32 or s1["out"] > 128:
+            return None
+        elem = flat.element_size()
+        lds = ((s1["rank"] * s1["inp"] + s1["out"] * s1["rank"] if not s1["full"] else s1["out"] * s1["inp"]) + s1["out"] + s2["rank"] * s2["inp"]
+               + s2["out"] * (s2["rank"] | 1) + s2["out"]) * elem
+        if lds > 160 * 1024:
+            return None
+        o = 0
+        if s1["full"]:
+            v1, u1 = None, flat[o:o + s1["num_u"]].view(s1["out"], s1["inp"])
+        else:
+            u1 = flat[o:o + s1["num_u"]].view(s1["out"], s1["rank"])
+            v1 = flat[o + s1["num_u"]:o + s1["num_u"] + s1["num_v"]].view(s1["rank"], s1["inp"])
+        b1 = flat[o + s1["num_u"] + s1["num_v"]:o + s1["num_u"] + s1["num_v"] + s1["num_b"]]
+        o += s1["num_u"] + s1["num_v"] + s1["num_b"]
+        u2 = flat[o:o + s2["num_u"]].view(s2["out"], s2["rank"])
+        v2 = flat[o + s2["num_u"]:o + s2["num_u"] + s2["num_v"]].view(s2["rank"], s2["inp"])
+        b2 = flat[o + s2["num_u"] + s2["num_v"]:o + s2["num_u"] + s2["num_v"] + s2["num_b"]]
+        return v1, u1, b1, v2, u2, b2
+
     def _run(self, stages, x, flat, o, per_sample, residual=None):
         """one sub-MLP.  flat: 1-d permanent vector or (B, P) per-sample block; o: offset of the sub-MLP's first parameter.
         `residual` is added to the result of the LAST stage (fused into the launch for per-sample weights)."""
@@ -181,6 +207,9 @@ class AmortizableMLP(nn.Module):
             assert self.use_permanent_parameters
             grad = autograd._needs_grad(i, self.u_v_b_pars)
             flat = self.u_v_b_pars.to(dtype=i.dtype).reshape(-1) if grad else self._flat(i)
+            views = None if grad else self.lowrank_views(flat)
+            if views is not None:                          # hidden-128 / rank-r MLP of the reference's custom mode: ONE launch (jf_amlp2)
+                return _hip.amlp2(i, *views)
         prev = None
         if self.linear is not None:                            # its parameters are the LAST ones of the vector (:621-629)
             prev, _ = self._run(self.linear[0], i, flat, self.num_amortization_params - self.linear[1], per_sample)

@@ -10,29 +10,28 @@ namespace jf {
 
 struct CondSegs { int n; jf_cond_segment s[JF_MAX_SEGMENTS]; };
 
+// one thread per OUTPUT element (coalesced stores; a thread-per-row version wrote 24 strided doubles per thread and ran at 0.3 TB/s)
 template <typename T>
-__global__ void __launch_bounds__(256) conditioning_kernel(const CondSegs a, int64_t B, T* __restrict__ out, int64_t os) {
-    const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (row >= B) return;
-    T* o = out + row * os;
+__global__ void __launch_bounds__(256) conditioning_kernel(const CondSegs a, int64_t B, int W, T* __restrict__ out, int64_t os) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * W) return;
+    const int64_t row = idx / W;
+    int col = (int)(idx - row * W);
+    const int out_col = col;
+    T val = T(0);
     for (int i = 0; i < a.n; ++i) {
-        const jf_cond_segment g = a.s[i];                       // uniform
-        const T* r = static_cast<const T*>(g.src) + row * g.stride;
-        if (g.kind == 0) {
-            for (int c = 0; c < g.n_in; ++c) o[c] = r[c];
-            o += g.n_in;
-        } else if (g.kind == 1) {
-            T e[3];
-            s1_to_eucl<T>(r[0], e);
-            o[0] = e[0]; o[1] = e[1];
-            o += 2;
-        } else {
-            T e[3], ld = T(0);
-            s2_to_eucl<T>(r[0], r[1], e, ld);
-            o[0] = e[0]; o[1] = e[1]; o[2] = e[2];
-            o += 3;
+        const jf_cond_segment g = a.s[i];
+        const int w = g.kind == 0 ? g.n_in : g.kind + 1;
+        if (col < w) {
+            const T* r = static_cast<const T*>(g.src) + row * g.stride;
+            if (g.kind == 0) val = r[col];
+            else if (g.kind == 1) { T e[3]; s1_to_eucl<T>(r[0], e); val = e[col]; }
+            else { T e[3], ld = T(0); s2_to_eucl<T>(r[0], r[1], e, ld); val = e[col]; }
+            break;
         }
+        col -= w;
     }
+    out[row * os + out_col] = val;
 }
 
 template <typename T> static int conditioning_rows(const jf_cond_segment* segs, int32_t n, int64_t B, T* out, int64_t os, void* stream) {
@@ -44,7 +43,10 @@ template <typename T> static int conditioning_rows(const jf_cond_segment* segs, 
         a.s[i] = segs[i];
     }
     if (B == 0) return JF_OK;
-    hipLaunchKernelGGL(conditioning_kernel<T>, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, B, out, os);
+    int W = 0;
+    for (int i = 0; i < n; ++i) W += segs[i].kind == 0 ? segs[i].n_in : segs[i].kind + 1;
+    if (W == 0) return JF_OK;
+    hipLaunchKernelGGL(conditioning_kernel<T>, dim3((unsigned)((B * W + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, B, W, out, os);
     return check_launch();
 }
 

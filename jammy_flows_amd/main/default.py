@@ -426,6 +426,8 @@ class pdf(nn.Module):
             segs.append((x[:, a:b], kind))
             width += last._embedding_conditional_return_num()
         need = max([prefix[si] for si, m in enumerate(self.mlp_predictors) if m is not None])
+        if data_summary is not None and need == data_summary.shape[1]:
+            return {"rows": None, "prefix": prefix, "cond": data_summary}       # nothing but the conditional input is ever read
         keep, w = [], 0
         for t, kind in segs:                                                     # only the segments some MLP reads
             if w >= need:
@@ -434,13 +436,15 @@ class pdf(nn.Module):
             w += t.shape[1] if kind == 0 else kind + 1
         if not keep or len(keep) > _hip.JF_MAX_SEGMENTS:
             return None
-        return {"rows": _hip.conditioning_rows(keep, x.shape[0], x.dtype, x.device), "prefix": prefix}
+        return {"rows": _hip.conditioning_rows(keep, x.shape[0], x.dtype, x.device), "prefix": prefix, "cond": data_summary}
 
     def _mlp_input(self, si, data_summary, embeds):
         if isinstance(embeds, dict):
             n = embeds["prefix"][si]
             if n == 0:
                 raise Exception("extra conditional input is empty but required for encoding!")
+            if embeds["cond"] is not None and n == embeds["cond"].shape[1]:
+                return embeds["cond"]                        # the first conditional block reads the conditional input itself
             return embeds["rows"][:, :n]
         if data_summary is not None:
             inp = data_summary[si] if type(data_summary) == list else data_summary
@@ -470,6 +474,26 @@ class pdf(nn.Module):
         if ps[0].dtype != dtype:
             ps = [p.to(dtype) for p in ps]
         return [p.detach() for p in ps]
+
+    def _fusable_lowrank_block(self, si, layers, only_last, amort, like):
+        """sub-pdf si = a two-stage AmortizableMLP with a low-rank last stage + chainable g layers at default options: the weight views for
+        jf_amlp_gf_chain_inv (v1, u1, b1, v2, u2, b2), else None"""
+        if not self.fuse_conditional_blocks or only_last or amort is not None or _hip.BINS_LOG is not None:
+            return None
+        mlp = self.mlp_predictors[si] if len(self.mlp_predictors) > si else None
+        if not isinstance(mlp, AmortizableMLP) or mlp.highway_mode != 0 or not mlp.use_permanent_parameters or len(mlp.stages or []) != 2:
+            return None
+        s1, s2 = mlp.stages
+        if s2["full"] or s2["rank"] > 16 or (not s1["full"] and s1["rank"] > 16) or s1["inp"] > 32 or s1["out"] > 128:
+            return None
+        if not gfl.chain_supported(layers) or layers[0].dimension > 8:
+            return None
+        for l in layers:
+            c = l.c_struct()
+            if not (c.num_kde == 10 and c.hh_iter <= 8 and c.nonlinear_stretch_type == _hip.GF_STRETCH_CLASSIC and c.width_mode == _hip.GF_WIDTH_SMOOTH
+                    and not c.clamp_widths and c.fit_normalization and c.regulate_normalization):
+                return None
+        return mlp.lowrank_views(mlp._flat(like))
 
     def _packed_w2(self, si, w2, b2, layer_array, n_layers, D):
         """packed split-bf16 image of the block's output layer, rebuilt when the weights change (tensor identity + in-place version)."""
@@ -614,6 +638,20 @@ class pdf(nn.Module):
                     res = _hip.cond_gf_chain_inv(self._mlp_input(si, data_summary, embeds), *fused, tgt, log_det, larr, len(layers),
                                                  layers[0].dimension, x_out=out_view, base_logp_in=base_logp, want_base_logp=want_base_logp,
                                                  status=status)
+                log_det = res[1]
+                if want_base_logp:
+                    base_logp = res[2]
+                if lazy:
+                    embeds.append(block[-1]._embedding_conditional_return(tgt))
+                if per_block is not None:
+                    per_block.append(log_det)
+                continue
+            lowrank = self._fusable_lowrank_block(si, layers, only_last, amortization_parameters, x) if kind == "e" else None
+            if lowrank is not None:
+                # low-rank AmortizableMLP + g layers in one launch: the parameter block is regenerated per lane from the row's rank-space vector
+                res = _hip.amlp_gf_chain_inv(self._mlp_input(si, data_summary, embeds), *lowrank, tgt, log_det,
+                                             _hip.gf_layer_array([l.c_struct() for l in layers]), len(layers), layers[0].dimension,
+                                             x_out=out_view, base_logp_in=base_logp, want_base_logp=want_base_logp, status=status)
                 log_det = res[1]
                 if want_base_logp:
                     base_logp = res[2]
