@@ -217,6 +217,36 @@ def test_full_size_metric_configuration_properties(name):
     print("round trip at 2^20 rows: %d rows outside 1e-6 (max |dz| %.3g)" % (int((~good).sum()), float(err_z[ok].max())))
 
 
+def test_full_size_c5_shard_properties():
+    """one GPU's share of BASELINE configs[4] (2^19 rows, conditional e8+s2 / gggg+v, AmortizableMLP rank 8, float64) through the fused
+    low-rank block: every 192-row tile of the tiled fixture batch reproduces the reference's golden log-probs; identical bits on a second
+    launch; the fused launch agrees with the unfused path (four dense launches + g-chain) on the same rows."""
+    from jammy_flows_amd import _hip
+    fx = [f for f in ALL_FIXTURES if f.name == "c5_e8s2_ggggv"][0]
+    pdf = build_product(fx, torch.float64)
+    n = 1 << 19
+    xs, cs = to_dev(fx["x"], torch.float64), to_dev(fx["cond"], torch.float64)
+    reps = n // xs.shape[0] + 1
+    x, c = xs.repeat(reps, 1)[:n].contiguous(), cs.repeat(reps, 1)[:n].contiguous()
+    timer = _hip.KernelTimer()
+    with timer:
+        lp = pdf(x, conditional_input=c)[0]
+    assert any(k[0] == "jf_amlp_gf_chain_inv_f64" for k in timer.summary()), sorted(timer.summary())
+    gold = torch.from_numpy(fx["logp"]).to(lp)
+    tiles = lp[: (n // xs.shape[0]) * xs.shape[0]].reshape(-1, xs.shape[0])
+    fin = torch.isfinite(gold)
+    assert float(((tiles[:, fin] - gold[fin]).abs() / (1 + gold[fin].abs())).max()) < 1e-7
+    assert torch.equal(tiles[0], tiles[-1])
+    assert torch.equal(lp, pdf(x, conditional_input=c)[0])
+    pdf.fuse_conditional_blocks = False
+    timer = _hip.KernelTimer()
+    with timer:
+        lp2 = pdf(x[:4096], conditional_input=c[:4096])[0]
+    assert not any(k[0] == "jf_amlp_gf_chain_inv_f64" for k in timer.summary())
+    ok = torch.isfinite(lp2)
+    assert float(((lp[:4096][ok] - lp2[ok]).abs() / (1 + lp2[ok].abs())).max()) < 1e-9
+
+
 # ----------------------------------------------------------------------------------------------------------------------
 # spline bin indices: bit-exact (north star).  Every searchsorted call of the reference is recorded in the fixtures (raw result, call
 # order); the kernels write the same integers through the `bins` output of the C ABI.
