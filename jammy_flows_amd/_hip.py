@@ -133,6 +133,9 @@ for _fam, _cls in MCHAIN_LAYER_TYPES.items():
     for _d in ("inv", "fwd"):
         _SIGNATURES["jf_%s_chain_%s" % (_fam, _d)] = [_P, _I64, _P, _P, _I64, _I32, _I64, _I32, ctypes.POINTER(_cls), _P, _I64, _P, _P, _P, _P,
                                                       _I64, _P, _P]
+    if _fam in "romf":
+        _SIGNATURES["jf_cond_%s_chain_inv" % _fam] = [_P, _I64, _P, _I64, _P, _P, _I64, _P, _I32, _I32, _P, _I64, _P, _I64, _I32, ctypes.POINTER(_cls),
+                                                      _P, _I64, _P, _P, _P, _P, _P]
     _SIGNATURES["jf_%s_chain_inv_bwd" % _fam] = [_P, _I64, _P, _I64, _I32, _I64, _I32, ctypes.POINTER(_cls), _P, _I64, _P, _P, _P, _I64, _P, _I64,
                                                  _P, _P]
 
@@ -233,7 +236,7 @@ class KernelTimer:
 _TIMER = None
 
 
-def _launch(name, tag, args, dev):
+def _launch(name, tag, args, dev, unsupported_ok=False):
     """call entry point `name` with `args` + the stream argument.  The launch goes to the TENSORS' device (`dev`, from require_device) and to
     torch's current stream OF THAT DEVICE -- not to whatever device happens to be current: the C side sizes grids with hipGetDevice and a
     kernel launched on device 0 with device-1 pointers faults or computes on the wrong GPU."""
@@ -251,8 +254,12 @@ def _launch(name, tag, args, dev):
             e0.record(stream)
             rc = fn(*args)
             e1.record(stream)
-            _TIMER.records.append((name, tag, e0, e1))
+            if not (unsupported_ok and rc == JF_ERR_UNSUPPORTED):
+                _TIMER.records.append((name, tag, e0, e1))
+    if unsupported_ok and rc == JF_ERR_UNSUPPORTED:
+        return False                                  # the caller has another kernel path for this configuration
     _check(rc, name)
+    return True
 
 
 def _check(rc, what):
@@ -618,6 +625,36 @@ def mchain(fam, direction, x, log_det, params, layer_structs, dim, x_out=None, b
     _launch(name, "bcast" if pb == 1 else "per-sample",
             (_ptr(x), x.stride(0), _ptr(log_det), pptr, pstride, pb, B, n, arr, _ptr(x_out), x_out.stride(0), _ptr(ld_out), _ptr(base_logp_in),
              _ptr(blp_out), _ptr(bins), bins.stride(0) if bins is not None else 0, _ptr(status)), dev)
+    return (x_out, ld_out, blp_out) if want_base_logp else (x_out, ld_out)
+
+
+COND_MCHAIN_FAMILIES, COND_MCHAIN_MAX_PARAMS = "romf", 64
+
+
+def cond_mchain_inv(fam, inp, w1, b1, w2, b2, x, log_det, layer_structs, dim, x_out=None, base_logp_in=None, want_base_logp=False, status=None):
+    """default amortisation MLP (Linear-tanh-Linear) + the chain of manifold layers of family `fam` it parametrises in ONE launch"""
+    dev = require_device(inp, w1, b1, w2, b2, x, log_det, x_out, base_logp_in, status)
+    inp, w1, w2, x = _rowmajor(inp), _rowmajor(w1), _rowmajor(w2), _rowmajor(x)
+    B, K1 = inp.shape
+    H = w1.shape[0]
+    if x.shape != (B, dim) or w1.shape[1] != K1 or w2.shape[1] != H or b1.shape[0] != H or b2.shape[0] != w2.shape[0]:
+        raise ValueError("cond_mchain_inv: inconsistent shapes")
+    if any(t.dtype != x.dtype for t in (inp, w1, b1, w2, b2)):
+        raise TypeError("cond_mchain_inv: dtype mismatch")
+    if log_det is not None:
+        log_det = log_det.contiguous()
+    if x_out is None:
+        x_out = torch.empty((B, dim), dtype=x.dtype, device=x.device)
+    ld_out = torch.empty((B,), dtype=x.dtype, device=x.device)
+    blp_out = torch.empty((B,), dtype=x.dtype, device=x.device) if want_base_logp else None
+    n = len(layer_structs)
+    arr = (MCHAIN_LAYER_TYPES[fam] * n)(*layer_structs)
+    ok = _launch("jf_cond_%s_chain_inv%s" % (fam, _suffix(x)), "K%d_H%d_N%d" % (K1, H, w2.shape[0]),
+            (_ptr(inp), inp.stride(0), _ptr(w1), w1.stride(0), _ptr(b1.contiguous()), _ptr(w2), w2.stride(0), _ptr(b2.contiguous()), K1, H, _ptr(x),
+             x.stride(0), _ptr(log_det), B, n, arr, _ptr(x_out), x_out.stride(0), _ptr(ld_out), _ptr(base_logp_in), _ptr(blp_out), _ptr(status)), dev,
+            unsupported_ok=True)
+    if not ok:
+        return None                                   # outside the fused kernel's limits (LDS budget): use the two-launch path
     return (x_out, ld_out, blp_out) if want_base_logp else (x_out, ld_out)
 
 

@@ -1,0 +1,206 @@
+// Conditional MANIFOLD block in ONE launch: the default amortisation MLP (Linear -> tanh -> Linear, main/default.py:656-670) + the chain of
+// 'r' / 'o' / 'm' / 'f' layers it parametrises (main/default.py:998-1031), log-prob direction:  jf_cond_{r,o,m,f}_chain_inv_*.
+//
+// These blocks are small (4 -> 128 -> 10 for the 'f' block of the metric configuration) and were two latency-bound launches (0.17 + 0.06 ms
+// per 2^20 rows against ~0.03 ms of arithmetic).  Here a wave owns 64 rows: per 16-row tile it computes the hidden activations on the
+// matrix cores into registers (transposed products as in mlp_kernels.hip: the first result is the second's B operand), multiplies them
+// with W2 (<= 64 output columns, whole matrix in LDS) and drops the 16 x N parameter rows into its LDS tile; then the 64 lanes run the
+// layers lane-per-row on that tile exactly as the stand-alone chain kernel does (same Fam::apply device code).
+#include <type_traits>
+
+#include "jf_manifold.h"
+#include "jf_mfma.h"
+
+namespace jf {
+
+constexpr int CM_HMAX = 128, CM_K1MAX = 28, CM_NMAX = 64;
+
+template <typename T, typename CLayer> struct CmArgs {
+    const T* in; int64_t in_stride;
+    const T* W1; int64_t w1s; const T* b1;
+    const T* W2; int64_t w2s; const T* b2;
+    int K1, H, N;
+    const T* x; int64_t xs;
+    const T* ld_in;
+    int64_t B;
+    int n_layers, dim, tile_stride, scratch, tab;      // tab: lane-private knot-table elements (0 when no layer of the chain evaluates a spline)
+    int col0[JF_MAX_MCHAIN];
+    CLayer L[JF_MAX_MCHAIN];
+    T* x_out; int64_t xos;
+    T* ld_out;
+    const T* blp_in; T* blp_out;
+    int32_t* status;
+};
+
+// NT threads per workgroup (256 in float32; 128 in float64, whose lane-private knot tables are twice as large)
+template <typename T, class Fam, int NT>
+__global__ void __launch_bounds__(NT) cond_mchain_kernel(const CmArgs<T, typename Fam::CLayer> a) {
+    using MF = Mfma16<T>;
+    constexpr int MT = 16, KS = 4, NREG = 4, JH = CM_HMAX / MT;
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    const int k1p = (a.K1 + KS - 1) / KS * KS, ldk = k1p + 1;
+    const int np = (a.N + MT - 1) / MT * MT;                       // output columns padded to whole MFMA tiles
+    constexpr int LDW = CM_HMAX + 1;
+    T* W1s = reinterpret_cast<T*>(smem_raw);                       // [128][ldk]
+    T* b1s = W1s + CM_HMAX * ldk;                                  // [128]
+    T* W2s = b1s + CM_HMAX;                                        // [np][LDW]
+    T* b2s = W2s + np * LDW;                                       // [np]
+    T* Xs = b2s + np;                                              // [NT][ldk]
+    T* tiles = Xs + NT * ldk;                                      // [NT][tile_stride]
+    T* tabs = tiles + NT * a.tile_stride;                          // [NT][JF_SPLINE_TAB (+ scratch)]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lq = lane >> 4;
+    const int64_t row0 = (int64_t)blockIdx.x * NT;
+    const int64_t last = a.B - 1;
+    for (int i = tid; i < CM_HMAX * k1p; i += NT) {
+        const int r = i / k1p, c = i - r * k1p;
+        W1s[r * ldk + c] = (r < a.H && c < a.K1) ? a.W1[(int64_t)r * a.w1s + c] : T(0);
+    }
+    for (int i = tid; i < CM_HMAX; i += NT) b1s[i] = i < a.H ? a.b1[i] : T(0);
+    for (int i = tid; i < np * CM_HMAX; i += NT) {
+        const int r = i / CM_HMAX, c = i - r * CM_HMAX;
+        W2s[r * LDW + c] = (r < a.N && c < a.H) ? a.W2[(int64_t)r * a.w2s + c] : T(0);
+    }
+    for (int i = tid; i < np; i += NT) b2s[i] = (i < a.N && a.b2) ? a.b2[i] : T(0);
+    for (int i = tid; i < NT * k1p; i += NT) {
+        const int r = i / k1p, c = i - r * k1p;
+        const int64_t gr = row0 + r;
+        Xs[r * ldk + c] = c < a.K1 ? a.in[(gr <= last ? gr : last) * a.in_stride + c] : T(0);
+    }
+    __syncthreads();
+
+    // ---- parameters of the wave's 64 rows -> its LDS tile, 16 rows at a time
+    T* tile = tiles + wave * 64 * a.tile_stride;
+    for (int rt = 0; rt < 4; ++rt) {
+        T hreg[JH][NREG];
+        {
+            typename MF::Acc acc[JH];
+#pragma unroll
+            for (int j = 0; j < JH; ++j)
+#pragma unroll
+                for (int r = 0; r < NREG; ++r) acc[j][r] = T(0);
+            for (int s = 0; s < k1p / KS; ++s) {
+                const int kk = s * KS + lq;
+                const T xb = Xs[(wave * 64 + rt * MT + li) * ldk + kk];
+#pragma unroll
+                for (int j = 0; j < JH; ++j) acc[j] = MF::mma(W1s[(j * MT + li) * ldk + kk], xb, acc[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < JH; ++j)
+#pragma unroll
+                for (int r = 0; r < NREG; ++r) hreg[j][r] = M<T>::tanh_fast(acc[j][r] + b1s[j * MT + MF::row_of(r, lane)]);
+        }
+        for (int ct = 0; ct < np / MT; ++ct) {
+            typename MF::Acc acc;
+#pragma unroll
+            for (int r = 0; r < NREG; ++r) acc[r] = T(0);
+            const T* wrow = W2s + (ct * MT + li) * LDW;
+#pragma unroll
+            for (int j = 0; j < JH; ++j)
+#pragma unroll
+                for (int r = 0; r < NREG; ++r) acc = MF::mma(wrow[j * MT + MF::row_of(r, lane)], hreg[j][r], acc);
+            // acc[v] = parameter (16 ct + row_of(v, lane)) of row (rt * 16 + li)
+#pragma unroll
+            for (int v = 0; v < NREG; ++v) {
+                const int c = ct * MT + MF::row_of(v, lane);
+                tile[(rt * MT + li) * a.tile_stride + c] = acc[v] + b2s[c];
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- the layers, lane-per-row (as mchain_kernel)
+    const int64_t row = row0 + tid;
+    const bool active = row <= last;
+    const int64_t rrow = active ? row : last;
+    T x[3] = {T(0), T(0), T(0)};
+#pragma unroll
+    for (int d = 0; d < Fam::DIM; ++d) if (d < a.dim) x[d] = a.x[rrow * a.xs + d];
+    T ld = a.ld_in ? a.ld_in[rrow] : T(0);
+    LaneCtx<T> ctx;
+    ctx.tab = tabs + tid * (a.tab + a.scratch);
+    ctx.corr = ctx.tab + a.tab;
+    ctx.bins = nullptr; ctx.bin_i = 0;
+    ctx.oob = ctx.nonconv = ctx.nonfinite = false;
+    ctx.lane_valid = active;
+    const T* prow = tiles + tid * a.tile_stride;
+    for (int i = 0; i < a.n_layers; ++i) {
+        const int l = a.n_layers - 1 - i;
+        Fam::template apply<T, false>(a.L[l], prow + a.col0[l], x, ld, ctx);
+    }
+    bool bad = !M<T>::finite(ld);
+#pragma unroll
+    for (int d = 0; d < Fam::DIM; ++d) bad = bad || !M<T>::finite(x[d]);
+    if (active) {
+#pragma unroll
+        for (int d = 0; d < Fam::DIM; ++d) if (d < a.dim) a.x_out[row * a.xos + d] = x[d];
+        a.ld_out[row] = ld;
+        if (a.blp_out) {
+            T s = a.blp_in ? a.blp_in[row] : T(0);
+#pragma unroll
+            for (int d = 0; d < Fam::DIM; ++d) if (d < a.dim) s += T(-0.5) * x[d] * x[d] - M<T>::HALF_LN_2PI;
+            a.blp_out[row] = s;
+        }
+    }
+    status_add(a.status, JF_STATUS_NONFINITE, active && (bad || ctx.nonfinite));
+    status_add(a.status, JF_STATUS_OUT_OF_RANGE, active && ctx.oob);
+    status_add(a.status, JF_STATUS_NONCONVERGED, active && ctx.nonconv);
+}
+
+template <typename T, class Fam>
+static int cond_mchain(const T* in, int64_t in_stride, const T* W1, int64_t w1s, const T* b1, const T* W2, int64_t w2s, const T* b2, int32_t K1, int32_t H,
+                       const T* x, int64_t xs, const T* ld_in, int64_t B, int32_t n_layers, const typename Fam::CLayer* layers, T* x_out, int64_t xos,
+                       T* ld_out, const T* blp_in, T* blp_out, int32_t* status, void* stream) {
+    if (!in || !W1 || !b1 || !W2 || !x || !x_out || !ld_out || !layers) return JF_ERR_BADARG;
+    if (K1 < 1 || H < 1 || B < 0 || n_layers < 1 || n_layers > JF_MAX_MCHAIN) return JF_ERR_BADARG;
+    if (K1 > CM_K1MAX || H > CM_HMAX) return JF_ERR_UNSUPPORTED;
+    CmArgs<T, typename Fam::CLayer> a{};
+    int col = 0;
+    for (int l = 0; l < n_layers; ++l) {
+        a.L[l] = layers[l];
+        a.col0[l] = col;
+        col += Fam::row_len(layers[l]);
+        if constexpr (std::is_same<Fam, FFam>::value) { if (layers[l].correlated) return JF_ERR_UNSUPPORTED; }
+    }
+    if (col < 1 || col > CM_NMAX) return JF_ERR_UNSUPPORTED;
+    if (B == 0) return JF_OK;
+    a.in = in; a.in_stride = in_stride; a.W1 = W1; a.w1s = w1s; a.b1 = b1; a.W2 = W2; a.w2s = w2s; a.b2 = b2; a.K1 = K1; a.H = H; a.N = col;
+    a.x = x; a.xs = xs; a.ld_in = ld_in; a.B = B; a.n_layers = n_layers; a.dim = Fam::DIM;
+    a.x_out = x_out; a.xos = xos; a.ld_out = ld_out; a.blp_in = blp_in; a.blp_out = blp_out; a.status = status;
+    const int np = (col + 15) / 16 * 16;
+    a.tile_stride = np + 1;
+    a.scratch = 0;
+    int n_spl = 0;
+    for (int l = 0; l < n_layers; ++l) n_spl += Fam::n_bins(layers[l]);
+    a.tab = n_spl > 0 ? JF_SPLINE_TAB : 0;             // 54 KB of LDS per 256 lanes that a spline-free chain (default 'f', 'm') does not need:
+                                                       // without it four workgroups fit a CU instead of one
+    const int k1p = (K1 + 3) / 4 * 4, ldk = k1p + 1;
+    constexpr int NT = sizeof(T) == 4 ? 256 : 128;
+    const size_t lds = ((size_t)CM_HMAX * ldk + CM_HMAX + (size_t)np * (CM_HMAX + 1) + np + (size_t)NT * ldk + (size_t)NT * a.tile_stride +
+                        (size_t)NT * a.tab) * sizeof(T);
+    if (lds > 160 * 1024) return JF_ERR_UNSUPPORTED;
+    auto k = cond_mchain_kernel<T, Fam, NT>;
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k, dim3((unsigned)((B + NT - 1) / NT)), dim3(NT), lds, (hipStream_t)stream, a);
+    return check_launch();
+}
+
+}  // namespace jf
+
+using namespace jf;
+
+#define JF_DEFINE_COND_MCHAIN(fam, Fam, T, suffix)                                                                                                 \
+    extern "C" int jf_cond_##fam##_chain_inv_##suffix(const T* in, int64_t is, const T* W1, int64_t w1s, const T* b1, const T* W2, int64_t w2s,       \
+                                                      const T* b2, int32_t K1, int32_t H, const T* x, int64_t xs, const T* ld_in, int64_t B,         \
+                                                      int32_t n, const jf_##fam##_layer* L, T* xo, int64_t xos, T* ldo, const T* bi, T* bo,          \
+                                                      int32_t* st, void* s) {                                                                        \
+        return cond_mchain<T, Fam>(in, is, W1, w1s, b1, W2, w2s, b2, K1, H, x, xs, ld_in, B, n, L, xo, xos, ldo, bi, bo, st, s);                     \
+    }
+JF_DEFINE_COND_MCHAIN(r, RFam, float, f32)
+JF_DEFINE_COND_MCHAIN(r, RFam, double, f64)
+JF_DEFINE_COND_MCHAIN(o, OFam, float, f32)
+JF_DEFINE_COND_MCHAIN(o, OFam, double, f64)
+JF_DEFINE_COND_MCHAIN(m, MFam, float, f32)
+JF_DEFINE_COND_MCHAIN(m, MFam, double, f64)
+JF_DEFINE_COND_MCHAIN(f, FFam, float, f32)
+JF_DEFINE_COND_MCHAIN(f, FFam, double, f64)

@@ -475,6 +475,26 @@ class pdf(nn.Module):
             ps = [p.to(dtype) for p in ps]
         return [p.detach() for p in ps]
 
+    def _fusable_manifold_block(self, si, layers, only_last, amort, dtype):
+        """sub-pdf si = default amortisation MLP (Linear-tanh-Linear) + one chain of 'r' / 'o' / 'm' / 'f' layers with <= 64 parameters per
+        row: (family, [w1, b1, w2, b2]) for jf_cond_<fam>_chain_inv, else None"""
+        if not self.fuse_conditional_blocks or only_last or amort is not None or _hip.BINS_LOG is not None:
+            return None
+        mlp = self.mlp_predictors[si] if len(self.mlp_predictors) > si else None
+        if not isinstance(mlp, HipLinearStack) or len(mlp) != 3 or not isinstance(mlp[1], nn.Tanh):
+            return None
+        fam = _manifold_family(layers)
+        if fam is None or fam not in _hip.COND_MCHAIN_FAMILIES:
+            return None
+        if mlp[0].in_features > _hip.COND_GF_MAX_IN or mlp[0].out_features > _hip.COND_GF_MAX_HIDDEN or mlp[2].out_features > _hip.COND_MCHAIN_MAX_PARAMS:
+            return None
+        if fam == "f" and any(getattr(l, "add_correlated_rq_spline_flow", 0) for l in layers):
+            return None
+        ps = [mlp[0].weight, mlp[0].bias, mlp[2].weight, mlp[2].bias]
+        if ps[0].dtype != dtype:
+            ps = [p.to(dtype) for p in ps]
+        return fam, [p.detach() for p in ps]
+
     def _fusable_lowrank_block(self, si, layers, only_last, amort, like):
         """sub-pdf si = a two-stage AmortizableMLP with a low-rank last stage + chainable g layers at default options: the weight views for
         jf_amlp_gf_chain_inv (v1, u1, b1, v2, u2, b2), else None"""
@@ -660,6 +680,22 @@ class pdf(nn.Module):
                 if per_block is not None:
                     per_block.append(log_det)
                 continue
+            mfused = self._fusable_manifold_block(si, layers, only_last, amortization_parameters, x.dtype) if kind != "e" else None
+            if mfused is not None:
+                # default amortisation MLP + the manifold chain in one launch: the parameter rows stay in LDS
+                fam, ws = mfused
+                structs = [l.c_struct() if fam == "r" else l.c_struct(1 if l.euclidean_to_sphere_as_first else 0) for l in layers]
+                res = _hip.cond_mchain_inv(fam, self._mlp_input(si, data_summary, embeds), *ws, tgt, log_det, structs, layers[0].dimension,
+                                           x_out=out_view, base_logp_in=base_logp, want_base_logp=want_base_logp, status=status)
+                if res is not None:
+                    log_det = res[1]
+                    if want_base_logp:
+                        base_logp = res[2]
+                    if lazy:
+                        embeds.append(block[-1]._embedding_conditional_return(tgt))
+                    if per_block is not None:
+                        per_block.append(log_det)
+                    continue
             extra, counter = self._block_params(si, data_summary, embeds, amortization_parameters, counter)
             if only_last:
                 layers = layers[-1:]
