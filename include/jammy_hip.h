@@ -244,6 +244,9 @@ typedef struct jf_r_layer { jf_spline_opts sp; double lo, hi; int32_t first, res
 typedef struct jf_o_layer { jf_spline_opts sp; int32_t natural_direction, hh_iter, first, reserved; } jf_o_layer;
 /* 'm' Moebius mixture (moebius_1d.py:57-259, bisection_n_newton.py:137-256); row: [householder hh_iter*2][(wx,wy,logit-len,log-w) x nc] */
 typedef struct jf_m_layer { int32_t num_components, natural_direction, hh_iter, first; } jf_m_layer;
+/* hh_iter of every sphere layer also encodes the reference's rotation_mode (sphere_base.py:112-240): >= 0 = that many Householder reflections
+ * (hh_iter * E raw vectors, E = embedding dimension); -1 = "angles" (Givens rotations, E (E - 1) / 2 angles); -2 = "xyz" (3 parameters, S2);
+ * -3 = "quaternion" (4 parameters, S2). */
 /* 'f' von-Mises-Fisher z-scaling + optional vertical 'r' / circular 'o' flows (fvm_2d.py:273-726);
  * row: [householder hh_iter*3][log kappa][vertical rows][circular rows]
  * correlated != 0 (add_correlated_rq_spline_flow, fvm_2d.py:244-262, 406-409, 575-578): the circular rows are not in the row but are
@@ -251,9 +254,13 @@ typedef struct jf_m_layer { int32_t num_components, natural_direction, hh_iter, 
  * (amortize_everything layout of AmortizableMLP, amortizable_mlp.py:284-375: stage 1 [W1 H][b1 H] (input dim 1 => full matrix),
  * stage 2 [U n_out x H][b2] if corr_full2 else [U n_out x rank][V rank x H][b2]); row: [householder][log kappa][vertical rows][MLP];
  * the circular layers then carry their own Householder rotation (hh_iter of jf_o_layer) and no azimuthal scaling is applied. */
+enum { JF_F_KAPPA_DIRECT_LOG = 0, JF_F_KAPPA_SOFTPLUS = 1, JF_F_KAPPA_LOG_BOUNDED = 2, JF_F_KAPPA_MU = 3, JF_F_KAPPA_MU_SQUARED = 4,
+       JF_F_KAPPA_QUATVEC = 5, JF_F_KAPPA_QUATVEC_SQUARED = 6 };
 typedef struct jf_f_layer {
     int32_t hh_iter, first, n_vertical, n_circular;
     int32_t correlated, corr_hidden, corr_rank, corr_full2;
+    int32_t kappa_mode, kappa_clamping; /* JF_F_KAPPA_* (fvm_2d.py:105-139); modes >= JF_F_KAPPA_MU read kappa off the rotation parameters and
+                                           the row has no kappa entry */
     double z_sign, min_kappa, identity_region;
     jf_r_layer vertical[JF_MAX_NESTED];
     jf_o_layer circular[JF_MAX_NESTED];

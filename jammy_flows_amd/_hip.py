@@ -63,10 +63,14 @@ JF_MAX_NESTED = 4
 class jf_f_layer(ctypes.Structure):
     _fields_ = [("hh_iter", ctypes.c_int32), ("first", ctypes.c_int32), ("n_vertical", ctypes.c_int32), ("n_circular", ctypes.c_int32),
                 ("correlated", ctypes.c_int32), ("corr_hidden", ctypes.c_int32), ("corr_rank", ctypes.c_int32), ("corr_full2", ctypes.c_int32),
+                ("kappa_mode", ctypes.c_int32), ("kappa_clamping", ctypes.c_int32),
                 ("z_sign", ctypes.c_double), ("min_kappa", ctypes.c_double), ("identity_region", ctypes.c_double),
                 ("vertical", jf_r_layer * JF_MAX_NESTED), ("circular", jf_o_layer * JF_MAX_NESTED)]
 
 
+F_KAPPA_MODES = {"direct_log_real_bounded": 0, "softplus_real_bounded": 1, "log_bounded": 2, "mu": 3, "mu_squared": 4, "quatvec": 5,
+                 "quatvec_squared": 6}
+ROT_CODES = {"angles": -1, "xyz": -2, "quaternion": -3}      # hh_iter encoding of the non-Householder rotation modes
 V_KINDS = {"linear": 0, "quadratic": 1, "exponential": 2}
 
 

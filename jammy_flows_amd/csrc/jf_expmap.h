@@ -168,11 +168,11 @@ struct VFam {
     using CLayer = jf_v_layer;
     static constexpr int DIM = 2;
     static __host__ int n_pot(const CLayer& L) { return 3 + (L.exp_map_type == JF_V_EXPONENTIAL ? 2 : 1); }
-    static __host__ int row_len(const CLayer& L) { return 3 * L.hh_iter + n_pot(L) * L.num_components; }
+    static __host__ int row_len(const CLayer& L) { return rot_len(L.hh_iter, 3) + n_pot(L) * L.num_components; }
     static __host__ int n_bins(const CLayer&) { return 0; }
 
     template <typename T, bool FWD> static __device__ __forceinline__ void apply(const CLayer& L, const T* __restrict__ p, T (&x)[3], T& ld, LaneCtx<T>& c) {
-        const T* pp = p + 3 * L.hh_iter;
+        const T* pp = p + rot_len(L.hh_iter, 3);
         const int nc = L.num_components, kind = L.exp_map_type;
         T e[3], th, ph;
         ExpMapOut<T> o;
@@ -197,9 +197,9 @@ struct VFam {
             }
             eucl_to_s2<T>(e, th, ph, ld);
             x[0] = th; x[1] = ph;
-            if (L.hh_iter > 0) s2_rotate<T>(p, L.hh_iter, x, ld, false);
+            if (L.hh_iter != 0) s2_rotate<T>(p, L.hh_iter, x, ld, false);
         } else {
-            if (L.hh_iter > 0) s2_rotate<T>(p, L.hh_iter, x, ld, true);
+            if (L.hh_iter != 0) s2_rotate<T>(p, L.hh_iter, x, ld, true);
             s2_to_eucl<T>(x[0], x[1], e, ld);                                        // :459-460
             if (L.natural_direction) {
                 T r[3];

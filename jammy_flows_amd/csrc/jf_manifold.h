@@ -96,16 +96,16 @@ template <typename T> __device__ __forceinline__ T o_core(const jf_o_layer& L, c
 struct OFam {
     using CLayer = jf_o_layer;
     static constexpr int DIM = 1;
-    static __host__ int row_len(const CLayer& L) { return 2 * L.hh_iter + spline_row_len(L.sp); }
+    static __host__ int row_len(const CLayer& L) { return rot_len(L.hh_iter, 2) + spline_row_len(L.sp); }
     static __host__ int n_bins(const CLayer&) { return 1; }
     template <typename T, bool FWD> static __device__ __forceinline__ void apply(const CLayer& L, const T* __restrict__ p, T (&x)[3], T& ld, LaneCtx<T>& c) {
-        const T* sp = p + 2 * L.hh_iter;
+        const T* sp = p + rot_len(L.hh_iter, 2);
         if constexpr (FWD) {
             if (L.first) x[0] = plane_to_s1<T>(x[0], ld);
             x[0] = o_core<T>(L, sp, x[0], ld, c, true, T(1));
-            if (L.hh_iter > 0) x[0] = s1_rotate<T>(p, L.hh_iter, x[0], false);
+            if (L.hh_iter != 0) x[0] = s1_rotate<T>(p, L.hh_iter, x[0], false);
         } else {
-            if (L.hh_iter > 0) x[0] = s1_rotate<T>(p, L.hh_iter, x[0], true);
+            if (L.hh_iter != 0) x[0] = s1_rotate<T>(p, L.hh_iter, x[0], true);
             x[0] = o_core<T>(L, sp, x[0], ld, c, false, T(1));
             if (L.first) x[0] = s1_to_plane<T>(x[0], ld);
         }
@@ -171,7 +171,7 @@ template <typename T> __device__ inline T moebius_solve(const T* __restrict__ p,
 struct MFam {
     using CLayer = jf_m_layer;
     static constexpr int DIM = 1;
-    static __host__ int row_len(const CLayer& L) { return 2 * L.hh_iter + 4 * L.num_components; }
+    static __host__ int row_len(const CLayer& L) { return rot_len(L.hh_iter, 2) + 4 * L.num_components; }
     static __host__ int n_bins(const CLayer&) { return 0; }
     template <typename T> static __device__ __forceinline__ T core(const CLayer& L, const T* __restrict__ mp, T x, T& ld, LaneCtx<T>& c, bool direct) {
         x = x > M<T>::PI ? x - M<T>::TWO_PI : x;                           // moebius_1d.py:73-74
@@ -188,13 +188,13 @@ struct MFam {
         return x < T(0) ? M<T>::TWO_PI + x : x;
     }
     template <typename T, bool FWD> static __device__ __forceinline__ void apply(const CLayer& L, const T* __restrict__ p, T (&x)[3], T& ld, LaneCtx<T>& c) {
-        const T* mp = p + 2 * L.hh_iter;
+        const T* mp = p + rot_len(L.hh_iter, 2);
         if constexpr (FWD) {
             if (L.first) x[0] = plane_to_s1<T>(x[0], ld);
             x[0] = core<T>(L, mp, x[0], ld, c, L.natural_direction != 0);
-            if (L.hh_iter > 0) x[0] = s1_rotate<T>(p, L.hh_iter, x[0], false);
+            if (L.hh_iter != 0) x[0] = s1_rotate<T>(p, L.hh_iter, x[0], false);
         } else {
-            if (L.hh_iter > 0) x[0] = s1_rotate<T>(p, L.hh_iter, x[0], true);
+            if (L.hh_iter != 0) x[0] = s1_rotate<T>(p, L.hh_iter, x[0], true);
             x[0] = core<T>(L, mp, x[0], ld, c, L.natural_direction == 0);
             if (L.first) x[0] = s1_to_plane<T>(x[0], ld);
         }
@@ -207,7 +207,7 @@ struct MFam {
 struct CFam {
     using CLayer = jf_c_layer;
     static constexpr int DIM = 2;      // interval / S1 use column 0 only (the host passes dim)
-    static __host__ int row_len(const CLayer& L) { return L.hh_iter * (L.kind == 2 ? 3 : 2); }
+    static __host__ int row_len(const CLayer& L) { return rot_len(L.hh_iter, L.kind == 2 ? 3 : 2); }
     static __host__ int n_bins(const CLayer&) { return 0; }
     template <typename T, bool FWD> static __device__ __forceinline__ void apply(const CLayer& L, const T* __restrict__ p, T (&x)[3], T& ld, LaneCtx<T>& c) {
         if constexpr (FWD) {
@@ -216,12 +216,12 @@ struct CFam {
                 else if (L.kind == 1) x[0] = plane_to_s1<T>(x[0], ld);
                 else { T pl[3] = {x[0], x[1], T(0)}; plane_to_s2<T>(pl, x[0], x[1], ld); }
             }
-            if (L.hh_iter > 0) {
+            if (L.hh_iter != 0) {
                 if (L.kind == 1) x[0] = s1_rotate<T>(p, L.hh_iter, x[0], false);
                 else if (L.kind == 2) s2_rotate<T>(p, L.hh_iter, x, ld, false);
             }
         } else {
-            if (L.hh_iter > 0) {
+            if (L.hh_iter != 0) {
                 if (L.kind == 1) x[0] = s1_rotate<T>(p, L.hh_iter, x[0], true);
                 else if (L.kind == 2) s2_rotate<T>(p, L.hh_iter, x, ld, true);
             }
@@ -244,15 +244,34 @@ struct FFam {
     static constexpr int DIM = 2;
     static __host__ __device__ int corr_out(const CLayer& L) {      // parameters the correlated MLP emits = rows of the circular layers incl. their rotations
         int n = 0;
-        for (int i = 0; i < L.n_circular; ++i) n += 2 * L.circular[i].hh_iter + spline_row_len(L.circular[i].sp);
+        for (int i = 0; i < L.n_circular; ++i) n += rot_len(L.circular[i].hh_iter, 2) + spline_row_len(L.circular[i].sp);
         return n;
     }
     static __host__ __device__ int corr_len(const CLayer& L) {      // U/V/b vector of the MLP 1 -> H -> n_out (amortizable_mlp.py:284-375)
         const int H = L.corr_hidden, n = corr_out(L);
         return 2 * H + (L.corr_full2 ? n * H : L.corr_rank * (n + H)) + n;
     }
+    // kappa of the von-Mises-Fisher step (fvm_2d.py:105-139, 289-330): from its own parameter (modes 0-2, optionally clamped) or from the
+    // length of the layer's rotation parameters ("mu" / "mu_squared" with rotation_mode xyz, "quatvec" / "quatvec_squared" with quaternion)
+    static __host__ __device__ int n_kappa(const CLayer& L) { return L.kappa_mode <= JF_F_KAPPA_LOG_BOUNDED ? 1 : 0; }
+    template <typename T> static __device__ __forceinline__ T kappa_of(const CLayer& L, const T* __restrict__ rot, const T* __restrict__ fp) {
+        const T mk = (T)L.min_kappa;
+        switch (L.kappa_mode) {
+            case JF_F_KAPPA_DIRECT_LOG: { const T v = L.kappa_clamping ? M<T>::max(fp[0], T(-5)) : fp[0]; return M<T>::exp(v) + mk; }
+            case JF_F_KAPPA_SOFTPLUS: { const T v = L.kappa_clamping ? M<T>::max(fp[0], T(-5)) : fp[0]; return softplus(v) + mk; }
+            case JF_F_KAPPA_LOG_BOUNDED: {
+                T v = softplus(fp[0]);
+                if (L.kappa_clamping) v = M<T>::max(v, T(-5));
+                return M<T>::exp(v + M<T>::log(mk));
+            }
+            case JF_F_KAPPA_MU: return M<T>::sqrt(rot[0] * rot[0] + rot[1] * rot[1] + rot[2] * rot[2]);
+            case JF_F_KAPPA_MU_SQUARED: return rot[0] * rot[0] + rot[1] * rot[1] + rot[2] * rot[2];
+            case JF_F_KAPPA_QUATVEC: return M<T>::sqrt(rot[1] * rot[1] + rot[2] * rot[2] + rot[3] * rot[3]);
+            default: return rot[1] * rot[1] + rot[2] * rot[2] + rot[3] * rot[3];
+        }
+    }
     static __host__ int row_len(const CLayer& L) {
-        int n = 3 * L.hh_iter + 1;
+        int n = rot_len(L.hh_iter, 3) + n_kappa(L);
         for (int i = 0; i < L.n_vertical; ++i) n += spline_row_len(L.vertical[i].sp);
         if (L.correlated) return n + corr_len(L);
         for (int i = 0; i < L.n_circular; ++i) n += spline_row_len(L.circular[i].sp);
@@ -293,15 +312,15 @@ struct FFam {
     }
 
     template <typename T, bool FWD> static __device__ __forceinline__ void apply(const CLayer& L, const T* __restrict__ p, T (&x)[3], T& ld, LaneCtx<T>& c) {
-        const T* fp = p + 3 * L.hh_iter;
+        const T* fp = p + rot_len(L.hh_iter, 3);
         const T zs = (T)L.z_sign, region = (T)L.identity_region;
-        const T kappa = M<T>::exp(fp[0]) + (T)L.min_kappa;                                   // fvm_2d.py:123
+        const T kappa = kappa_of<T>(L, p, fp);                                               // fvm_2d.py:105-139, 289-330
         int nv = 0;
         for (int i = 0; i < L.n_vertical; ++i) nv += spline_row_len(L.vertical[i].sp);
-        const T* vert = fp + 1;
+        const T* vert = fp + n_kappa(L);
         const T* circ = vert + nv;
         if constexpr (!FWD) {
-            if (L.hh_iter > 0) s2_rotate<T>(p, L.hh_iter, x, ld, true);
+            if (L.hh_iter != 0) s2_rotate<T>(p, L.hh_iter, x, ld, true);
             const T prev = M<T>::cos(x[0]);
             ld += M<T>::log(M<T>::sin(safe_angle_pi<T>(x[0])));
             const T e2k = M<T>::exp(T(-2) * kappa);
@@ -323,7 +342,7 @@ struct FFam {
                     corr_mlp<T>(L, vert + nv, z_in, c.corr);
                     int coff = corr_out(L);
                     for (int i = L.n_circular - 1; i >= 0; --i) {
-                        coff -= 2 * L.circular[i].hh_iter + spline_row_len(L.circular[i].sp);
+                        coff -= rot_len(L.circular[i].hh_iter, 2) + spline_row_len(L.circular[i].sp);
                         T xx[3] = {angle, T(0), T(0)};
                         OFam::apply<T, false>(L.circular[i], c.corr + coff, xx, ld, c);
                         angle = xx[0];
@@ -381,7 +400,7 @@ struct FFam {
                         T xx[3] = {angle, T(0), T(0)};
                         OFam::apply<T, true>(L.circular[i], c.corr + coff, xx, ld, c);
                         angle = xx[0];
-                        coff += 2 * L.circular[i].hh_iter + spline_row_len(L.circular[i].sp);
+                        coff += rot_len(L.circular[i].hh_iter, 2) + spline_row_len(L.circular[i].sp);
                     }
                 } else {
                     for (int i = 0; i < L.n_vertical + L.n_circular; ++i) c.put_bin(-2);
@@ -412,7 +431,7 @@ struct FFam {
             x[0] = M<T>::acos(ret);
             ld -= M<T>::log(M<T>::sin(safe_angle_pi<T>(x[0])));
             x[1] = angle;
-            if (L.hh_iter > 0) s2_rotate<T>(p, L.hh_iter, x, ld, false);
+            if (L.hh_iter != 0) s2_rotate<T>(p, L.hh_iter, x, ld, false);
         }
     }
 };

@@ -106,9 +106,58 @@ template <typename T, int E> __device__ __forceinline__ void reflect_raw(const T
 #pragma unroll
     for (int i = 0; i < E; ++i) x[i] -= f * v[i];
 }
-template <typename T, int E> __device__ __forceinline__ void rotate_embed(const T* __restrict__ vs, int n_iter, T (&x)[3], bool transpose) {
-    if (transpose) { for (int i = 0; i < n_iter; ++i) reflect_raw<T, E>(vs + i * E, x); }       // Q^T x : H_0 first
-    else { for (int i = n_iter - 1; i >= 0; --i) reflect_raw<T, E>(vs + i * E, x); }            // Q x
+// Rotation of the embedding vector.  `hh` encodes the reference's rotation_mode (sphere_base.py:112-240) in the layer descriptors' hh_iter field:
+//   hh >= 0  "householder": Q = H_0 H_1 ... H_{hh-1}, hh * E raw reflection vectors
+//   hh == -1 "angles":      product of Givens rotations over all index pairs (a < b) in lexicographic order, E (E - 1) / 2 angles (:132-160)
+//   hh == -2 "xyz":         the rotation that takes e_z to the direction of the 3 parameters (:162-185), S2 only
+//   hh == -3 "quaternion":  unnormalised quaternion (a, i, j, k), 4 parameters (:186-216), S2 only
+// transpose = true applies Q^T (log-prob direction), false applies Q.
+constexpr int JF_ROT_ANGLES = -1, JF_ROT_XYZ = -2, JF_ROT_QUATERNION = -3;
+__host__ __device__ inline int rot_len(int hh, int E) { return hh >= 0 ? hh * E : (hh == JF_ROT_ANGLES ? E * (E - 1) / 2 : (hh == JF_ROT_XYZ ? 3 : 4)); }
+
+template <typename T, int E> __device__ __forceinline__ void rotate_embed(const T* __restrict__ vs, int hh, T (&x)[3], bool transpose) {
+    if (hh >= 0) {
+        if (transpose) { for (int i = 0; i < hh; ++i) reflect_raw<T, E>(vs + i * E, x); }       // Q^T x : H_0 first
+        else { for (int i = hh - 1; i >= 0; --i) reflect_raw<T, E>(vs + i * E, x); }            // Q x
+        return;
+    }
+    T R[3][3] = {{T(1), T(0), T(0)}, {T(0), T(1), T(0)}, {T(0), T(0), T(1)}};
+    if (hh == JF_ROT_ANGLES) {                       // R = G_last ... G_1 G_0 (prev = new @ prev)
+        int ind = 0;
+#pragma unroll
+        for (int a = 0; a < E; ++a)
+#pragma unroll
+            for (int b = a + 1; b < E; ++b) {
+                const T c = M<T>::cos(vs[ind]), s = M<T>::sin(vs[ind]);
+                ++ind;
+#pragma unroll
+                for (int j = 0; j < E; ++j) {        // rows a, b of (G R): G[a][a] = c, G[a][b] = s, G[b][a] = -s, G[b][b] = c
+                    const T ra = R[a][j], rb = R[b][j];
+                    R[a][j] = c * ra + s * rb;
+                    R[b][j] = -s * ra + c * rb;
+                }
+            }
+    } else if (hh == JF_ROT_XYZ) {
+        const T nrm = M<T>::sqrt(vs[0] * vs[0] + vs[1] * vs[1] + vs[2] * vs[2]);
+        const T mx = vs[0] / nrm, my = vs[1] / nrm, mz = vs[2] / nrm;
+        const T d = T(1) + mz;
+        R[0][0] = T(1) - mx * mx / d; R[0][1] = -mx * my / d;      R[0][2] = mx;
+        R[1][0] = -mx * my / d;      R[1][1] = T(1) - my * my / d; R[1][2] = my;
+        R[2][0] = -mx;               R[2][1] = -my;               R[2][2] = mz;
+    } else {
+        const T qa = vs[0], qi = vs[1], qj = vs[2], qk = vs[3];
+        const T n2 = qa * qa + qi * qi + qj * qj + qk * qk;
+        R[0][0] = T(1) - T(2) * (qj * qj + qk * qk) / n2; R[0][1] = T(2) * (qi * qj - qa * qk) / n2;       R[0][2] = T(2) * (qi * qk + qj * qa) / n2;
+        R[1][0] = T(2) * (qi * qj + qa * qk) / n2;       R[1][1] = T(1) - T(2) * (qi * qi + qk * qk) / n2; R[1][2] = T(2) * (qj * qk - qi * qa) / n2;
+        R[2][0] = T(2) * (qi * qk - qj * qa) / n2;       R[2][1] = T(2) * (qj * qk + qi * qa) / n2;       R[2][2] = T(1) - T(2) * (qi * qi + qj * qj) / n2;
+    }
+    T y[3] = {T(0), T(0), T(0)};
+#pragma unroll
+    for (int i = 0; i < E; ++i)
+#pragma unroll
+        for (int j = 0; j < E; ++j) y[i] += (transpose ? R[j][i] : R[i][j]) * x[j];
+#pragma unroll
+    for (int i = 0; i < E; ++i) x[i] = y[i];
 }
 
 }  // namespace jf

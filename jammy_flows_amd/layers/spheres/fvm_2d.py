@@ -33,23 +33,26 @@ class fisher_von_mises_2d(sphere_base.sphere_base):
         if dimension != 2:
             raise Exception("2-D Flow")
         assert fisher_parametrization == "split"
-        unsupported = []
-        if kappa_prediction != "direct_log_real_bounded":
-            unsupported.append("kappa_prediction=%s" % kappa_prediction)
-        if kappa_clamping:
-            unsupported.append("kappa_clamping=1")
         if add_extra_rotation_inbetween:
-            unsupported.append("add_extra_rotation_inbetween=1")
-        if unsupported:
-            raise NotImplementedError("f layer option(s) without a HIP kernel yet: %s" % ", ".join(unsupported))
+            raise NotImplementedError("f layer option add_extra_rotation_inbetween=1 has no HIP kernel yet")
+        if kappa_prediction not in _hip.F_KAPPA_MODES:
+            raise Exception("unknown kappa_prediction", kappa_prediction)
         self.z_scaling_factor = -1.0 if inverse_z_scaling else 1.0
         self.min_kappa = min_kappa
         self.kappa_prediction = kappa_prediction
-        self.kappa_fn = True      # (kappa is predicted from its own parameter; see sphere_base.get_desired_init_parameters)
-        self.num_loglike_kappa_params = 1
-        if use_permanent_parameters:
-            self.loglike_kappa = nn.Parameter(torch.randn(1).unsqueeze(0))
-        self.total_param_num += 1
+        self.kappa_clamping = kappa_clamping
+        # kappa from its own parameter (modes 0-2) or from the length of the rotation parameters (fvm_2d.py:105-139)
+        self.kappa_fn = True if _hip.F_KAPPA_MODES[kappa_prediction] <= 2 else None
+        if kappa_prediction in ("mu", "mu_squared"):
+            assert self.add_rotation and self.rotation_mode == "xyz"
+        if kappa_prediction in ("quatvec", "quatvec_squared"):
+            assert self.add_rotation and self.rotation_mode == "quaternion", ("ROTATION MODE?!", self.rotation_mode)
+        self.num_loglike_kappa_params = 0
+        if self.kappa_fn is not None:
+            self.num_loglike_kappa_params = 1
+            if use_permanent_parameters:
+                self.loglike_kappa = nn.Parameter(torch.randn(1).unsqueeze(0))
+            self.total_param_num += 1
         self.add_vertical_rq_spline_flow = add_vertical_rq_spline_flow
         self.add_circular_rq_spline_flow = add_circular_rq_spline_flow
         self.add_correlated_rq_spline_flow = add_correlated_rq_spline_flow
@@ -135,6 +138,8 @@ class fisher_von_mises_2d(sphere_base.sphere_base):
         L.z_sign = float(self.z_scaling_factor)
         L.min_kappa = float(self.min_kappa)
         L.identity_region = float(self.boundary_cos_theta_identity_region)
+        L.kappa_mode = _hip.F_KAPPA_MODES[self.kappa_prediction]
+        L.kappa_clamping = 1 if self.kappa_clamping else 0
         for i, l in enumerate(self._vertical):
             L.vertical[i] = l.c_struct(0)
         for i, l in enumerate(self._circular):
@@ -148,7 +153,7 @@ class fisher_von_mises_2d(sphere_base.sphere_base):
         return len(self._vertical) + len(self._circular)
 
     def _layer_tensors(self):
-        ts = [self.loglike_kappa]
+        ts = [self.loglike_kappa] if self.kappa_fn is not None else []
         if self.add_vertical_rq_spline_flow:
             ts.append(self.vertical_flow_params)
         if self.add_circular_rq_spline_flow:
@@ -158,9 +163,10 @@ class fisher_von_mises_2d(sphere_base.sphere_base):
         return ts
 
     def _init_params(self, params):
-        self.loglike_kappa.data = params[:1].reshape(1, 1)
-        assert len(params) == 1 + self.total_num_vertical_params + self.total_num_circular_params + self.total_num_correlated_params
-        c = 1
+        c = self.num_loglike_kappa_params
+        if self.kappa_fn is not None:
+            self.loglike_kappa.data = params[:1].reshape(1, 1)
+        assert len(params) == c + self.total_num_vertical_params + self.total_num_circular_params + self.total_num_correlated_params
         if self.add_correlated_rq_spline_flow:
             self.correlated_flow_params.data = params[c:c + self.total_num_correlated_params].reshape(1, -1)
         if self.add_vertical_rq_spline_flow:
@@ -170,7 +176,7 @@ class fisher_von_mises_2d(sphere_base.sphere_base):
             self.circular_flow_params.data = params[c:c + self.total_num_circular_params].reshape(1, -1)
 
     def _get_desired_init_parameters(self):
-        parts = [torch.randn(1) - 3.0]                                   # log kappa (:750)
+        parts = [torch.randn(1) - 3.0] if self.kappa_fn is not None else [torch.zeros(0)]       # log kappa (:750)
         parts += [l.get_desired_init_parameters() for l in self._vertical]
         if self._corr_mlp is not None:       # nested pdf.init_params() (:756-758): the MLP starts damped with the circular init as final bias
             circ = torch.cat([l.get_desired_init_parameters() for l in self._circular])
@@ -181,8 +187,9 @@ class fisher_von_mises_2d(sphere_base.sphere_base):
 
     def _obtain_layer_param_structure(self, param_dict, extra_inputs=None, previous_x=None, extra_prefix=""):
         if extra_inputs is not None:
-            param_dict[extra_prefix + "loglike_kappa"] = extra_inputs[:, :1].data
-            c = 1
+            c = self.num_loglike_kappa_params
+            if c:
+                param_dict[extra_prefix + "loglike_kappa"] = extra_inputs[:, :1].data
             if self.add_vertical_rq_spline_flow:
                 param_dict[extra_prefix + "vertical_params"] = extra_inputs[:, c:c + self.total_num_vertical_params].data
                 c += self.total_num_vertical_params
@@ -191,7 +198,8 @@ class fisher_von_mises_2d(sphere_base.sphere_base):
             if self.add_correlated_rq_spline_flow:
                 param_dict[extra_prefix + "correlated_params"] = extra_inputs[:, c:c + self.total_num_correlated_params].data
         else:
-            param_dict[extra_prefix + "loglike_kappa"] = self.loglike_kappa.data
+            if self.kappa_fn is not None:
+                param_dict[extra_prefix + "loglike_kappa"] = self.loglike_kappa.data
             if self.add_vertical_rq_spline_flow:
                 param_dict[extra_prefix + "vertical_params"] = self.vertical_flow_params.data
             if self.add_circular_rq_spline_flow:

@@ -4,7 +4,7 @@ A sphere layer = optional Householder rotation in embedding space (extra_inputs[
 own map, plus the sphere <-> plane chart when it is the first layer of its block.  In-tree layers ('o', 'm', 'f', 'v', 'y') run
 all of it in ONE HIP kernel on intrinsic coordinates (``_fused``); third-party subclasses that only provide
 ``_flow_mapping`` / ``_inv_flow_mapping`` get the rotation and the chart from the 'c' kernels (``inv_flow_mapping`` below).
-Only ``rotation_mode="householder"`` has a kernel.
+``num_householder_iter`` doubles as the kernels' rotation code: >= 0 Householder reflections, -1 / -2 / -3 = angles / xyz / quaternion.
 """
 import torch
 from torch import nn
@@ -29,10 +29,19 @@ class sphere_base(layer_base.layer_base):
         self.num_householder_params = 0
         self.num_householder_iter = 0
         if add_rotation:
-            if rotation_mode != "householder":
-                raise NotImplementedError("sphere rotation_mode '%s' has no HIP kernel (only 'householder')" % rotation_mode)
-            self.num_householder_iter = dimension + 1 if num_householder_iter == -1 else num_householder_iter
-            self.num_householder_params = self.num_householder_iter * (dimension + 1)
+            emb = dimension + 1
+            if rotation_mode == "householder":
+                self.num_householder_iter = emb if num_householder_iter == -1 else num_householder_iter
+                self.num_householder_params = self.num_householder_iter * emb
+            elif rotation_mode == "angles":                  # Givens rotations (sphere_base.py:132-160)
+                self.num_householder_iter = _hip.ROT_CODES["angles"]
+                self.num_householder_params = emb * (emb - 1) // 2
+            elif rotation_mode in ("xyz", "quaternion"):      # (sphere_base.py:162-216)
+                assert dimension == 2
+                self.num_householder_iter = _hip.ROT_CODES[rotation_mode]
+                self.num_householder_params = 3 if rotation_mode == "xyz" else 4
+            else:
+                raise Exception("Unknown rotation mode for spheres: ", rotation_mode)
         if use_permanent_parameters and self.num_householder_params > 0:
             self.householder_params = nn.Parameter(torch.randn((1, self.num_householder_params)))
         self.total_param_num += self.num_householder_params
@@ -151,7 +160,9 @@ class sphere_base(layer_base.layer_base):
     def get_desired_init_parameters(self):
         parts = []
         if self.num_householder_params > 0:
-            parts.append(torch.randn(self.num_householder_params))
+            # kappa read off the rotation parameters ('f' with kappa_prediction mu / quatvec): start with a tiny kappa (sphere_base.py:716-726)
+            small = hasattr(self, "kappa_fn") and self.kappa_fn is None
+            parts.append(torch.randn(self.num_householder_params) * (0.01 if small else 1.0))
         parts.append(self._get_desired_init_parameters())
         return torch.cat(parts)
 

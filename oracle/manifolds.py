@@ -107,6 +107,35 @@ def plane_to_sphere(x, log_det, dim):
 
 
 # ------------------------------------------------------------------ spheres: rotations
-def rotation_matrix(rot_params, dim, n_iter):
-    """sphere_base.compute_rotation_matrix, householder mode (sphere_base.py:112-127)."""
-    return householder_matrix(rot_params.reshape(-1, n_iter, dim + 1))
+def rotation_matrix(rot_params, dim, n_iter, mode="householder"):
+    """sphere_base.compute_rotation_matrix (sphere_base.py:112-216): householder / angles (Givens) / xyz / quaternion."""
+    if mode == "householder":
+        return householder_matrix(rot_params.reshape(-1, n_iter, dim + 1))
+    B, E = rot_params.shape[0], dim + 1
+    if mode == "angles":
+        R = np.broadcast_to(np.eye(E), (B, E, E)).copy()
+        ind = 0
+        for a in range(E):
+            for b in range(a + 1, E):
+                G = np.broadcast_to(np.eye(E), (B, E, E)).copy()
+                c, s = np.cos(rot_params[:, ind]), np.sin(rot_params[:, ind])
+                G[:, a, a] = c; G[:, b, b] = c; G[:, a, b] = s; G[:, b, a] = -s
+                R = G @ R
+                ind += 1
+        return R
+    R = np.zeros((B, 3, 3))
+    if mode == "xyz":
+        n = rot_params / np.sqrt((rot_params ** 2).sum(axis=1, keepdims=True))
+        mx, my, mz = n[:, 0], n[:, 1], n[:, 2]
+        d = 1.0 + mz
+        R[:, 0, 0] = 1 - mx * mx / d; R[:, 0, 1] = -mx * my / d; R[:, 0, 2] = mx
+        R[:, 1, 0] = -mx * my / d; R[:, 1, 1] = 1 - my * my / d; R[:, 1, 2] = my
+        R[:, 2, 0] = -mx; R[:, 2, 1] = -my; R[:, 2, 2] = mz
+        return R
+    assert mode == "quaternion"
+    a, i, j, k = (rot_params[:, q] for q in range(4))
+    n2 = (rot_params ** 2).sum(axis=1)
+    R[:, 0, 0] = 1 - 2 * (j * j + k * k) / n2; R[:, 0, 1] = 2 * (i * j - a * k) / n2; R[:, 0, 2] = 2 * (i * k + j * a) / n2
+    R[:, 1, 0] = 2 * (i * j + a * k) / n2; R[:, 1, 1] = 1 - 2 * (i * i + k * k) / n2; R[:, 1, 2] = 2 * (j * k - i * a) / n2
+    R[:, 2, 0] = 2 * (i * k - j * a) / n2; R[:, 2, 1] = 2 * (j * k + i * a) / n2; R[:, 2, 2] = 1 - 2 * (i * i + j * j) / n2
+    return R

@@ -20,13 +20,16 @@ class FLayer(_SphereLayer):
     def __init__(self, dimension, o, first, embedding, nested_factory):
         assert dimension == 2
         self._setup_base(o, first, embedding, n_hh_iter=o["num_householder_iter"])
-        if o["kappa_prediction"] != "direct_log_real_bounded" or o["kappa_clamping"] or o["add_extra_rotation_inbetween"]:
-            raise NotImplementedError("oracle: f option")
+        if o["add_extra_rotation_inbetween"]:
+            raise NotImplementedError("oracle: f option add_extra_rotation_inbetween")
+        self.kappa_prediction = o["kappa_prediction"]
+        self.kappa_clamping = o["kappa_clamping"]
+        self.own_kappa = self.kappa_prediction in ("direct_log_real_bounded", "softplus_real_bounded", "log_bounded")
         self.zs = -1.0 if o["inverse_z_scaling"] else 1.0
         self.min_kappa = o["min_kappa"]
         self.region = o["boundary_cos_theta_identity_region"]
         self.vertical = self.circular = self.correlated = None
-        n = 1
+        n = 1 if self.own_kappa else 0
         lo, hi = -(1.0 - self.region), (1.0 - self.region)
         ival = "i1_-%.2f_%.2f" % (1.0 - self.region, 1.0 - self.region)
         if o["add_vertical_rq_spline_flow"]:
@@ -43,7 +46,7 @@ class FLayer(_SphereLayer):
                 fd["r"]["num_basis_functions"] = o["spline_num_basis_functions"]
             self.vertical = nested_factory(ival, o["vertical_flow_defs"], fd)        # fvm_2d.py:193-197
             n += self.vertical.total_number_amortizable_params
-        self.n_vertical = n - 1
+        self.n_vertical = n - (1 if self.own_kappa else 0)
         if o["add_circular_rq_spline_flow"]:
             assert o["circular_add_rotation"] == 0
             fd = {"o": {"num_basis_functions": 2, "smooth_second_derivative": 1,
@@ -62,7 +65,7 @@ class FLayer(_SphereLayer):
         self.total_param_num = self.n_rot + n
 
     def row_from_state(self, sd, prefix):
-        parts = [self.rot_row_from_state(sd, prefix), sd[prefix + "loglike_kappa"].reshape(-1)]
+        parts = [self.rot_row_from_state(sd, prefix)] + ([sd[prefix + "loglike_kappa"].reshape(-1)] if self.own_kappa else [])
         if self.correlated is not None:
             parts.append(sd[prefix + "correlated_flow_params"].reshape(-1))
         if self.vertical is not None:
@@ -72,8 +75,23 @@ class FLayer(_SphereLayer):
         return np.concatenate(parts)[None, :]
 
     def _split(self, params):
-        kappa = np.exp(params[:, 0:1]) + self.min_kappa                  # fvm_2d.py:123
-        rest = params[:, 1:]
+        # kappa_fn / kappa from the rotation parameters (fvm_2d.py:105-139, 289-330)
+        from .special import softplus
+        if self.own_kappa:
+            p0 = params[:, 0:1]
+            if self.kappa_prediction == "direct_log_real_bounded":
+                kappa = np.exp(np.maximum(p0, -5.0) if self.kappa_clamping else p0) + self.min_kappa
+            elif self.kappa_prediction == "softplus_real_bounded":
+                kappa = softplus(np.maximum(p0, -5.0) if self.kappa_clamping else p0) + self.min_kappa
+            else:
+                v = softplus(p0)
+                kappa = np.exp((np.maximum(v, -5.0) if self.kappa_clamping else v) + np.log(self.min_kappa))
+            rest = params[:, 1:]
+        else:
+            rot = self._cur_rot
+            sq = (rot ** 2).sum(axis=1, keepdims=True) if self.kappa_prediction.startswith("mu") else (rot[:, 1:] ** 2).sum(axis=1, keepdims=True)
+            kappa = sq if self.kappa_prediction.endswith("squared") else np.sqrt(sq)
+            rest = params
         vert = rest[:, :self.n_vertical] if self.vertical is not None else None
         circ = rest[:, self.n_vertical:self.n_vertical + self.n_circular] if self.circular is not None else None
         corr = rest if self.correlated is not None else None

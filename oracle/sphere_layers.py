@@ -134,16 +134,19 @@ class _SphereLayer:
         self.add_rotation = o.get("add_rotation", 0)
         self.n_hh_iter = 0
         self.n_rot = 0
+        self.rotation_mode = o.get("rotation_mode", "householder")
         if self.add_rotation:
-            if o.get("rotation_mode", "householder") != "householder":
-                raise NotImplementedError("oracle: sphere rotation_mode %s" % o["rotation_mode"])
-            self.n_hh_iter = self.dim + 1 if n_hh_iter == -1 else n_hh_iter
-            self.n_rot = self.n_hh_iter * (self.dim + 1)
+            E = self.dim + 1
+            if self.rotation_mode == "householder":
+                self.n_hh_iter = E if n_hh_iter == -1 else n_hh_iter
+                self.n_rot = self.n_hh_iter * E
+            else:
+                self.n_rot = {"angles": E * (E - 1) // 2, "xyz": 3, "quaternion": 4}[self.rotation_mode]
 
     def _rotate(self, x, log_det, params, transpose):
         if not self.embedding:
             x, log_det = mf.spherical_to_eucl(x, log_det, self.dim)
-        R = mf.rotation_matrix(params[:, :self.n_rot], self.dim, self.n_hh_iter)
+        R = mf.rotation_matrix(params[:, :self.n_rot], self.dim, self.n_hh_iter, self.rotation_mode)
         x = matvec(R, x, transpose=transpose)
         if not self.embedding:
             x, log_det = mf.eucl_to_spherical(x, log_det, self.dim)
@@ -152,6 +155,7 @@ class _SphereLayer:
     def inverse(self, x, log_det, params, fix_first=None):
         if self.add_rotation:
             x, log_det = self._rotate(x, log_det, params, True)
+        self._cur_rot = params[:, :self.n_rot]        # 'f' may read kappa off the rotation parameters (fvm_2d.py:289-330)
         x, log_det, bins = self._core_inverse(x, log_det, params[:, self.n_rot:])
         first = self.first if fix_first is None else fix_first
         if first:
@@ -166,6 +170,7 @@ class _SphereLayer:
             x, log_det = mf.plane_to_sphere(x, log_det, self.dim)
             if self.embedding:
                 x, log_det = mf.spherical_to_eucl(x, log_det, self.dim)
+        self._cur_rot = params[:, :self.n_rot]
         x, log_det, bins = self._core_forward(x, log_det, params[:, self.n_rot:])
         if self.add_rotation:
             x, log_det = self._rotate(x, log_det, params, False)

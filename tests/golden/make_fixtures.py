@@ -132,6 +132,16 @@ CASES = [
          kwargs=dict(conditional_input_dim=2, options_overwrite={"f": dict(_f_splines()["f"], boundary_cos_theta_identity_region=0.4)})),
     dict(name="f_s2_correlated", pdf="s2", flow="f", mlp_scale=100.0,
          kwargs=dict(conditional_input_dim=2, options_overwrite={"f": {"add_correlated_rq_spline_flow": 1}})),
+    # rotation modes of the sphere base class and kappa parametrisations of 'f' (tests/test_general.py:124-177 of the reference)
+    dict(name="f_s2_rot_angles", pdf="s2", flow="f", mlp_scale=300.0,
+         kwargs=dict(conditional_input_dim=2, options_overwrite={"f": {"rotation_mode": "angles", "kappa_prediction": "softplus_real_bounded"}})),
+    dict(name="f_s2_rot_xyz_mu", pdf="s2", flow="ff", mlp_scale=300.0,
+         kwargs=dict(conditional_input_dim=2, options_overwrite={"f": {"rotation_mode": "xyz", "kappa_prediction": "mu"}})),
+    dict(name="f_s2_rot_quat_sq", pdf="s2", flow="f", mlp_scale=300.0,
+         kwargs=dict(conditional_input_dim=2, options_overwrite={"f": dict(_f_splines()["f"], rotation_mode="quaternion",
+                                                                          kappa_prediction="quatvec_squared")})),
+    dict(name="f_s2_kappa_logb_clamp", pdf="s2", flow="f", perturb=0.5,
+         kwargs=dict(options_overwrite={"f": {"kappa_prediction": "log_bounded", "kappa_clamping": 1, "rotation_mode": "quaternion"}})),
     dict(name="f_s2_emb", pdf="s2", flow="f", mlp_scale=1000.0, embedding=True, kwargs=dict(conditional_input_dim=2)),
     dict(name="v_s2", pdf="s2", flow="v", B=96),
     dict(name="v_s2_cond_vv", pdf="s2", flow="vv", mlp_scale=300.0, B=96, kwargs=dict(conditional_input_dim=2)),
