@@ -75,6 +75,7 @@ template <typename T> struct M<Dual<T>> {
     static __device__ __forceinline__ D exp_fast(D x) { return exp(x); }
     static __device__ __forceinline__ D log(D x) { return D(B::log(x.v), x.d / x.v); }
     static __device__ __forceinline__ D log_fast(D x) { return log(x); }
+    static __device__ __forceinline__ D expm1(D x) { return D(B::expm1(x.v), x.d * B::exp(x.v)); }
     static __device__ __forceinline__ D log1p(D x) { return D(B::log1p(x.v), x.d / (T(1) + x.v)); }
     static __device__ __forceinline__ D sqrt(D x) { const T s = B::sqrt(x.v); return D(s, x.d * T(0.5) / s); }
     static __device__ __forceinline__ D sqrt_fast(D x) { return sqrt(x); }

@@ -324,7 +324,8 @@ struct FFam {
             const T prev = M<T>::cos(x[0]);
             ld += M<T>::log(M<T>::sin(safe_angle_pi<T>(x[0])));
             const T e2k = M<T>::exp(T(-2) * kappa);
-            const T safe = kappa < T(100) ? M<T>::log(M<T>::exp(T(2) * kappa) - T(1)) : T(2) * kappa;      // :352-357
+            const T safe = kappa < T(100) ? M<T>::log(M<T>::expm1(T(2) * kappa)) : T(2) * kappa;          // :352-357 (expm1: a kappa of 1e-10
+                                                                                                                  // -- log_bounded with the default min_kappa -- survives float32)
             ld += M<T>::log(T(2) * kappa) + kappa * (zs * prev + T(1)) - safe;
             T ret = zs * ((T(1) + e2k - T(2) * M<T>::exp(kappa * (zs * prev - T(1)))) / (T(-1) + e2k));       // :361
             if (kappa < M<T>::KAPPA_ID) ret = prev;

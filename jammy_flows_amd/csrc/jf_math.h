@@ -28,6 +28,7 @@ template <> struct M<float> {
     static __device__ __forceinline__ float exp(float x) { return expf(x); }
     static __device__ __forceinline__ float log(float x) { return logf(x); }
     static __device__ __forceinline__ float log1p(float x) { return log1pf(x); }
+    static __device__ __forceinline__ float expm1(float x) { return expm1f(x); }
     static __device__ __forceinline__ float sqrt(float x) { return sqrtf(x); }
     static __device__ __forceinline__ float erf(float x) { return erff(x); }
     static __device__ __forceinline__ float erfinv(float x) { return erfinvf(x); }
@@ -61,6 +62,7 @@ template <> struct M<double> {
     static __device__ __forceinline__ double exp(double x) { return ::exp(x); }
     static __device__ __forceinline__ double log(double x) { return ::log(x); }
     static __device__ __forceinline__ double log1p(double x) { return ::log1p(x); }
+    static __device__ __forceinline__ double expm1(double x) { return ::expm1(x); }
     static __device__ __forceinline__ double sqrt(double x) { return ::sqrt(x); }
     static __device__ __forceinline__ double erf(double x) { return ::erf(x); }
     static __device__ __forceinline__ double erfinv(double x) { return ::erfinv(x); }
