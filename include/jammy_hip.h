@@ -45,6 +45,8 @@ int jf_abi_version(void);
 enum { JF_GF_ISIGMOID = 0, JF_GF_INORMAL_PARTLY_PRECISE = 1, JF_GF_INORMAL_PARTLY_CRUDE = 2, JF_GF_INORMAL_FULL_PADE = 3 };
 enum { JF_GF_WIDTH_SMOOTH_SATURATION = 0, JF_GF_WIDTH_EXP = 1, JF_GF_WIDTH_SOFTPLUS = 2 };
 enum { JF_GF_STRETCH_CLASSIC = 0, JF_GF_STRETCH_RQ_SPLINES = 1 };
+/* rotation_mode of gf_block (gaussianization_flow.py:95-100, 711-799): HOUSEHOLDER with hh_iter == 0 is "none" */
+enum { JF_GF_ROT_HOUSEHOLDER = 0, JF_GF_ROT_ANGLES = 1, JF_GF_ROT_CAYLEY = 2, JF_GF_ROT_TRIANGULAR = 3 };
 
 typedef struct jf_gf_layer {
     int32_t num_kde;                /* K */
@@ -58,10 +60,17 @@ typedef struct jf_gf_layer {
     int32_t nonlinear_stretch_type; /* JF_GF_STRETCH_*: CLASSIC = logistic mixture + inverse-CDF stage; RQ_SPLINES = per-dimension
                                        rational-quadratic spline with learnable box and linear tails (spline_fns.py:188-358), row layout
                                        [offset][rot][log_w D*K][log_h D*K][log_d D*(K+1)][box D*4] (gaussianization_flow.py:873-909) */
-    int32_t reserved;
+    int32_t rotation_mode;          /* JF_GF_ROT_*: ANGLES = D(D-1)/2 Givens angles in itertools.combinations order (:747-780), CAYLEY = one
+                                       parameter (D == 2, :782-798), TRIANGULAR = [lower D(D-1)/2][log-diagonal D-1][upper D(D-1)/2] of
+                                       L diag(e^d) U with unit triangles and sum(d) = 0 (:711-729, 942-964) */
+    int32_t center_mean;            /* the means section holds K-1 rows; the last mean makes the weighted mean vanish (:846-852) */
+    int32_t add_skewness;           /* a trailing K*D section of log-exponents of the skewed-logistic components (:352-368, 411-442);
+                                       float64 only, as in the reference (extra_functions.py:28) */
     double width_min, width_max;    /* width_max <= 0: no upper bound */
     double norm_min, norm_max;
 } jf_gf_layer;
+/* Layers with rotation_mode != HOUSEHOLDER, center_mean or add_skewness run in the general-option kernel of jf_gf_chain_inv / _fwd
+ * (one lane per row); the fused block entry points and jf_gf_chain_inv_bwd return JF_ERR_UNSUPPORTED for them. */
 
 /* log-prob direction of a chain of `n_layers` g layers applied in REVERSE order (layer n-1 first), all in one launch.
  * params row = the layers' rows concatenated in layer order 0..n-1.  log_det_in / base_logp_in may be NULL (= 0);

@@ -21,6 +21,7 @@ JF_MAX_CHAIN = 8
 GF_INV_TYPES = {"isigmoid": 0, "inormal_partly_precise": 1, "inormal_partly_crude": 2, "inormal_full_pade": 3}
 GF_WIDTH_SMOOTH, GF_WIDTH_EXP, GF_WIDTH_SOFTPLUS = 0, 1, 2
 GF_STRETCH_CLASSIC, GF_STRETCH_RQ_SPLINES = 0, 1
+GF_ROT_MODES = {"householder": 0, "angles": 1, "cayley": 2, "triangular_combination": 3}
 JF_SPLINE_MAX_BINS = 16
 JF_CORR_SCRATCH = 81
 
@@ -33,7 +34,8 @@ class jf_gf_layer(ctypes.Structure):
     _fields_ = [("num_kde", ctypes.c_int32), ("hh_iter", ctypes.c_int32), ("model_offset", ctypes.c_int32),
                 ("fit_normalization", ctypes.c_int32), ("regulate_normalization", ctypes.c_int32),
                 ("inverse_function_type", ctypes.c_int32), ("width_mode", ctypes.c_int32), ("clamp_widths", ctypes.c_int32),
-                ("nonlinear_stretch_type", ctypes.c_int32), ("reserved", ctypes.c_int32),
+                ("nonlinear_stretch_type", ctypes.c_int32), ("rotation_mode", ctypes.c_int32),
+                ("center_mean", ctypes.c_int32), ("add_skewness", ctypes.c_int32),
                 ("width_min", ctypes.c_double), ("width_max", ctypes.c_double), ("norm_min", ctypes.c_double),
                 ("norm_max", ctypes.c_double)]
 

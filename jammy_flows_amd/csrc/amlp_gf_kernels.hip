@@ -303,7 +303,7 @@ static int amlp_gf_chain_inv(const T* in, int64_t in_stride, const T* V1, const 
         AgLayer<T>& o = a.L[l];
         if (h.num_kde != AG_K || h.hh_iter < 0 || h.hh_iter > AG_HH || h.nonlinear_stretch_type != JF_GF_STRETCH_CLASSIC ||
             h.width_mode != JF_GF_WIDTH_SMOOTH_SATURATION || h.clamp_widths || !h.fit_normalization || !h.regulate_normalization ||
-            h.width_min <= 0 || h.width_max <= 0)
+            h.width_min <= 0 || h.width_max <= 0 || h.rotation_mode != JF_GF_ROT_HOUSEHOLDER || h.center_mean || h.add_skewness)
             return JF_ERR_UNSUPPORTED;
         const int kd = h.num_kde * D;
         o.hh = h.hh_iter; o.model_offset = h.model_offset; o.inv_type = h.inverse_function_type; o.col0 = col;

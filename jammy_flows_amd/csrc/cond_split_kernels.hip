@@ -382,6 +382,7 @@ __global__ void __launch_bounds__(256, 2) cond_gf_split_kernel(const CsArgs a) {
 // ---------------------------------------------------------------------------------------------------------- host side
 static bool cs_layer_supported(const jf_gf_layer& h, int D) {
     return h.num_kde == CS_K && h.hh_iter >= 0 && h.hh_iter <= CS_HH && h.nonlinear_stretch_type == JF_GF_STRETCH_CLASSIC &&
+           h.rotation_mode == JF_GF_ROT_HOUSEHOLDER && !h.center_mean && !h.add_skewness &&
            h.width_mode == JF_GF_WIDTH_SMOOTH_SATURATION && !h.clamp_widths && h.fit_normalization && h.regulate_normalization &&
            h.width_min > 0 && h.width_max > 0 && D >= 3 && D <= 4;
 }

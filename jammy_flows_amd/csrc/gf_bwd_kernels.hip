@@ -299,6 +299,7 @@ template <typename T> static int gb_fill(GfBwdArgs<T>& a, const T* params, int64
         const jf_gf_layer& h = layers[l];
         GfLayerDev<T>& o = a.L[l];
         if (h.num_kde < 1 || h.hh_iter < 0 || h.width_min <= 0) return JF_ERR_BADARG;
+        if (h.rotation_mode != JF_GF_ROT_HOUSEHOLDER || h.center_mean || h.add_skewness) return JF_ERR_UNSUPPORTED;   // general-option layers: jf_gf_chain_inv only
         if (h.width_mode == JF_GF_WIDTH_SMOOTH_SATURATION && h.width_max <= 0) return JF_ERR_BADARG;
         if (h.nonlinear_stretch_type != JF_GF_STRETCH_CLASSIC || h.hh_iter > GB_MAX_HH) return JF_ERR_UNSUPPORTED;
         o.K = h.num_kde; o.hh = h.hh_iter; o.model_offset = h.model_offset; o.fit_norm = h.fit_normalization;

@@ -15,6 +15,7 @@
 //       KB, so 16+ waves per CU are resident and the HBM latency of one wave's slab is covered by the arithmetic of the others.
 //       HBM traffic is the algorithmic minimum (every parameter byte is read exactly once).
 #include "jf_gf.h"
+#include "jf_gf_ext.h"
 
 namespace jf {
 
@@ -150,6 +151,72 @@ __global__ void __launch_bounds__(BCAST ? 256 : 64, sizeof(T) == 8 ? 2 : 4) gf_c
     }
 }
 
+// General-option chain (jf_gf_ext.h): one lane per row, every option of the layer; launched when a layer of the chain uses a rotation other
+// than Householder reflections, center_mean or add_skewness.  LDS: two coordinate columns per lane (+ the lane's spline knot table).
+template <typename T, bool FWD> __global__ void __launch_bounds__(GX_THREADS) gfx_chain_kernel(const GfChainArgs<T> a, const int64_t pstep) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    T* lds = reinterpret_cast<T*>(smem_raw);
+    const int tid = threadIdx.x, D = a.D;
+    const XCol<T> x{lds + tid}, z{lds + JF_MAX_D_GF * GX_THREADS + tid};
+    T* tab = lds + 2 * JF_MAX_D_GF * GX_THREADS + tid * JF_SPLINE_TAB;
+    const int64_t row = (int64_t)blockIdx.x * GX_THREADS + tid;
+    const bool row_valid = row < a.B;
+    const int64_t rrow = row_valid ? row : a.B - 1;
+    for (int d = 0; d < D; ++d) x[d] = a.x[rrow * a.xs + d];
+    T ld = a.ld_in ? a.ld_in[rrow] : T(0);
+    int spline_calls = 0;
+    for (int li = 0; li < a.n_layers; ++li) {
+        const int l = FWD ? li : a.n_layers - 1 - li;
+        const GfLayerDev<T> o = a.L[l];
+        const T* p = a.params + rrow * pstep + o.col0;
+        if constexpr (!FWD) {
+            if (o.model_offset) for (int d = 0; d < D; ++d) x[d] -= p[d];                       // euclidean_base.py:40-45
+            gx_rotate<T>(o, p, x, D, true);
+        }
+        if (o.stretch == JF_GF_STRETCH_RQ_SPLINES) {
+            for (int d = 0; d < D; ++d) {
+                const SplineOut<T> r = spline_linext<T>(p + o.off_mean + d * o.K, p + o.off_lw + d * o.K, p + o.off_ln + d * (o.K + 1),
+                                                        p + o.off_box + d * 4, o.K, tab, x[d], FWD);
+                x[d] = r.y;
+                ld += r.lad;
+                if (a.bins != nullptr && row_valid) a.bins[row * a.bins_stride + spline_calls * D + d] = (int64_t)r.bin;
+            }
+            ++spline_calls;
+        } else if constexpr (!FWD) {
+            for (int d = 0; d < D; ++d) {
+                const GxCoord<T> c = gx_prepare<T>(o, p, D, d);
+                const IcdfOut<T> s = gf_icdf<T>(o.inv_type, gx_mixture<T>(o, p, D, d, c, x[d]));
+                x[d] = s.y;
+                ld += s.logd;
+            }
+        } else {
+            for (int d = 0; d < D; ++d) z[d] = x[d];
+            gx_solve<T>(o, p, D, z, x, row_valid, a.status);
+            for (int d = 0; d < D; ++d) {                                                          // gaussianization_flow.py:922-924
+                const GxCoord<T> c = gx_prepare<T>(o, p, D, d);
+                ld -= gf_icdf<T>(o.inv_type, gx_mixture<T>(o, p, D, d, c, x[d])).logd;
+            }
+        }
+        if constexpr (FWD) {
+            gx_rotate<T>(o, p, x, D, false);
+            if (o.model_offset) for (int d = 0; d < D; ++d) x[d] += p[d];                       // euclidean_base.py:63-68
+        }
+    }
+    bool bad = !M<T>::finite(ld);
+    T blp = T(0);
+    for (int d = 0; d < D; ++d) {
+        const T v = x[d];
+        if (row_valid) a.x_out[row * a.xos + d] = v;
+        bad = bad || !M<T>::finite(v);
+        blp += T(-0.5) * v * v - M<T>::HALF_LN_2PI;
+    }
+    if (row_valid) {
+        a.ld_out[row] = ld;
+        if (!FWD && a.blp_out) a.blp_out[row] = blp + (a.blp_in ? a.blp_in[row] : T(0));
+    }
+    if constexpr (!FWD) status_add(a.status, JF_STATUS_NONFINITE, row_valid && bad);
+}
+
 // ----------------------------------------------------------------------------------------------------------
 // host side
 // ----------------------------------------------------------------------------------------------------------
@@ -158,7 +225,8 @@ constexpr int LDS_LIMIT = 160 * 1024;
 static inline int group_width(int D) { return D <= 1 ? 1 : D <= 2 ? 2 : D <= 4 ? 4 : 8; }
 
 template <typename T> static int fill_args(GfChainArgs<T>& a, const T* params, int64_t ps, int32_t pb, int64_t B, int32_t D, int32_t n_layers,
-                                           const jf_gf_layer* layers, size_t& lds_bytes, bool& bcast) {
+                                           const jf_gf_layer* layers, size_t& lds_bytes, bool& bcast, bool& ext) {
+    ext = false;
     if (n_layers < 1 || n_layers > JF_MAX_CHAIN || D < 1 || B < 0 || layers == nullptr) return JF_ERR_BADARG;
     if (D > 8) return JF_ERR_UNSUPPORTED;
     if (pb != 1 && pb != B) return JF_ERR_BADARG;
@@ -177,9 +245,17 @@ template <typename T> static int fill_args(GfChainArgs<T>& a, const T* params, i
         const int kd = h.num_kde * D;
         o.stretch = h.nonlinear_stretch_type;
         if (o.stretch != JF_GF_STRETCH_CLASSIC && o.stretch != JF_GF_STRETCH_RQ_SPLINES) return JF_ERR_BADARG;
+        o.rot_mode = h.rotation_mode; o.center_mean = h.center_mean ? 1 : 0; o.skew = h.add_skewness ? 1 : 0; o.off_skew = 0;
+        if (o.rot_mode < JF_GF_ROT_HOUSEHOLDER || o.rot_mode > JF_GF_ROT_TRIANGULAR) return JF_ERR_BADARG;
+        if (o.rot_mode == JF_GF_ROT_CAYLEY && D > 2) return JF_ERR_BADARG;                       // "Cayley requires 2 dims at the moment" (:220)
+        if (o.rot_mode != JF_GF_ROT_HOUSEHOLDER) o.hh = 0;
+        if (o.skew && sizeof(T) != 8) return JF_ERR_UNSUPPORTED;                                 // double precision only (extra_functions.py:28)
+        if ((o.center_mean || o.skew) && o.stretch != JF_GF_STRETCH_CLASSIC) return JF_ERR_BADARG;
+        if (o.center_mean && h.num_kde < 2) return JF_ERR_BADARG;
+        if (o.rot_mode != JF_GF_ROT_HOUSEHOLDER || o.center_mean || o.skew) ext = true;
         o.off_rot = h.model_offset ? D : 0;
-        o.off_mean = o.off_rot + h.hh_iter * D;
-        o.off_lw = o.off_mean + kd;
+        o.off_mean = o.off_rot + gx_rot_len(o.rot_mode, o.hh, D);
+        o.off_lw = o.off_mean + kd - (o.center_mean ? D : 0);
         o.off_ln = o.off_lw + kd;
         if (o.stretch == JF_GF_STRETCH_RQ_SPLINES) {
             if (h.num_kde > JF_SPLINE_MAX_BINS) return JF_ERR_UNSUPPORTED;
@@ -188,7 +264,8 @@ template <typename T> static int fill_args(GfChainArgs<T>& a, const T* params, i
             any_spline = true;
         } else {
             o.off_box = 0;
-            o.n_params = o.off_ln + (h.fit_normalization ? kd : 0);
+            o.off_skew = o.off_ln + (h.fit_normalization ? kd : 0);
+            o.n_params = o.off_skew + (o.skew ? kd : 0);
         }
         o.col0 = col;
         o.vec_ok = (!bcast && aligned16<T>(params, ps, col) && (o.n_params % Vec16<T>::N == 0)) ? 1 : 0;
@@ -211,6 +288,7 @@ template <typename T> static int fill_args(GfChainArgs<T>& a, const T* params, i
     a.tab_offset = (int)elems;
     if (any_spline) elems += (size_t)(bcast ? 256 : 64) * JF_SPLINE_TAB;
     lds_bytes = elems * sizeof(T);
+    if (ext) lds_bytes = ((size_t)2 * JF_MAX_D_GF * GX_THREADS + (any_spline ? (size_t)GX_THREADS * JF_SPLINE_TAB : 0)) * sizeof(T);
     a.tiles_per_block = 1;                               // broadcast: set by launch_g from the kernel's occupancy
     if (lds_bytes > (size_t)LDS_LIMIT) return JF_ERR_UNSUPPORTED;
     return JF_OK;
@@ -247,8 +325,14 @@ template <typename T, int G, bool FWD> static int launch_g(GfChainArgs<T> a, boo
     return check_launch();
 }
 
-template <typename T, bool FWD> static int launch(const GfChainArgs<T>& a, int D, bool bcast, size_t lds_bytes, hipStream_t st) {
+template <typename T, bool FWD> static int launch(const GfChainArgs<T>& a, int D, bool bcast, bool ext, size_t lds_bytes, hipStream_t st) {
     if (a.B == 0) return JF_OK;
+    if (ext) {
+        auto k = gfx_chain_kernel<T, FWD>;
+        if (lds_bytes > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        hipLaunchKernelGGL(k, dim3((unsigned)((a.B + GX_THREADS - 1) / GX_THREADS)), dim3(GX_THREADS), lds_bytes, st, a, bcast ? (int64_t)0 : a.ps);
+        return check_launch();
+    }
     switch (group_width(D)) {
         case 1: return launch_g<T, 1, FWD>(a, bcast, lds_bytes, st);
         case 2: return launch_g<T, 2, FWD>(a, bcast, lds_bytes, st);
@@ -263,12 +347,12 @@ static int gf_chain_inv(const T* x, int64_t xs, const T* ld_in, const T* params,
                         int32_t* status, void* stream) {
     if (!x || !params || !x_out || !ld_out) return JF_ERR_BADARG;
     GfChainArgs<T> a{};
-    size_t lds = 0; bool bcast = false;
-    int rc = fill_args<T>(a, params, ps, pb, B, D, n_layers, layers, lds, bcast);
+    size_t lds = 0; bool bcast = false, ext = false;
+    int rc = fill_args<T>(a, params, ps, pb, B, D, n_layers, layers, lds, bcast, ext);
     if (rc != JF_OK) return rc;
     a.x = x; a.xs = xs; a.ld_in = ld_in; a.x_out = x_out; a.xos = xos; a.ld_out = ld_out; a.blp_in = blp_in; a.blp_out = blp_out; a.status = status;
     a.bins = bins; a.bins_stride = bins_stride;
-    return launch<T, false>(a, D, bcast, lds, (hipStream_t)stream);
+    return launch<T, false>(a, D, bcast, ext, lds, (hipStream_t)stream);
 }
 template <typename T>
 static int gf_chain_fwd(const T* z, int64_t zs, const T* ld_in, const T* params, int64_t ps, int32_t pb, int64_t B, int32_t D, int32_t n_layers,
@@ -276,18 +360,18 @@ static int gf_chain_fwd(const T* z, int64_t zs, const T* ld_in, const T* params,
                         void* stream) {
     if (!z || !params || !x_out || !ld_out) return JF_ERR_BADARG;
     GfChainArgs<T> a{};
-    size_t lds = 0; bool bcast = false;
-    int rc = fill_args<T>(a, params, ps, pb, B, D, n_layers, layers, lds, bcast);
+    size_t lds = 0; bool bcast = false, ext = false;
+    int rc = fill_args<T>(a, params, ps, pb, B, D, n_layers, layers, lds, bcast, ext);
     if (rc != JF_OK) return rc;
     a.x = z; a.xs = zs; a.ld_in = ld_in; a.x_out = x_out; a.xos = xos; a.ld_out = ld_out; a.blp_in = nullptr; a.blp_out = nullptr; a.status = status;
     a.bins = bins; a.bins_stride = bins_stride;
-    return launch<T, true>(a, D, bcast, lds, (hipStream_t)stream);
+    return launch<T, true>(a, D, bcast, ext, lds, (hipStream_t)stream);
 }
 
 }  // namespace jf
 
 extern "C" {
-int jf_abi_version(void) { return 1; }
+int jf_abi_version(void) { return 2; }
 
 int jf_gf_chain_inv_f32(const float* x, int64_t xs, const float* ld_in, const float* p, int64_t ps, int32_t pb, int64_t B, int32_t D, int32_t n,
                         const jf_gf_layer* L, float* xo, int64_t xos, float* ldo, const float* bi, float* bo, int64_t* bins, int64_t bs, int32_t* st,

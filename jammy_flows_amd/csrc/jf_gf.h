@@ -31,6 +31,8 @@ template <typename T> struct GfLayerDev {
     int col0;                                // first column of the layer inside the chain's parameter row
     int off_rot, off_mean, off_lw, off_ln;   // section offsets inside the layer row (elements)
     int vec_ok;                              // 16-byte staging possible
+    int rot_mode, center_mean, skew;         // JF_GF_ROT_* / center_mean / add_skewness: any of them non-zero -> general-option kernel (jf_gf_ext.h)
+    int off_skew;                            // log-exponent section of the skewed components
     T wmin, wmax, inv_wmax, nmin, nmax, lw_lo, lw_hi;
 };
 

@@ -42,15 +42,10 @@ class gf_block(euclidean_base.euclidean_base):
             raise Exception("Unknown non linear stretch type: %s" % nonlinear_stretch_type)
         if inverse_function_type not in _hip.GF_INV_TYPES:
             raise AssertionError("unknown inverse_function_type %s" % inverse_function_type)
-        unsupported = []
-        if center_mean:
-            unsupported.append("center_mean=1")
-        if add_skewness:
-            unsupported.append("add_skewness=1")
-        if rotation_mode not in ("householder", "none"):
-            unsupported.append("rotation_mode=%s" % rotation_mode)
-        if unsupported:
-            raise NotImplementedError("g layer option(s) without a HIP kernel yet: %s (no eager fallback exists)" % ", ".join(unsupported))
+        if rotation_mode not in _hip.GF_ROT_MODES and rotation_mode != "none":
+            raise Exception("Unknown rotation mode: %s" % rotation_mode)
+        if (center_mean or add_skewness) and nonlinear_stretch_type != "classic":
+            raise Exception("center_mean / add_skewness belong to the classic (logistic mixture) stretch")
         assert lower_bound_for_widths > 0.0
         if width_smooth_saturation and not softplus_for_width:
             assert upper_bound_for_widths > 0, "We require a maximum saturation level for smooth saturation!"
@@ -83,18 +78,37 @@ class gf_block(euclidean_base.euclidean_base):
                 if use_permanent_parameters:
                     self.vs = nn.Parameter(torch.randn(self.householder_iter, dimension).unsqueeze(0))
         self.total_param_num += self.num_householder_params
+        # the other rotation parametrisations (:158-170, 198-223); they run in the general-option kernel (csrc/jf_gf_ext.h)
+        self.num_triangle_params = self.num_angle_pars = self.num_cayley_pars = 0
+        if rotation_mode == "triangular_combination":
+            self.num_triangle_params = int(dimension - 1 + dimension * (dimension - 1))
+            if use_permanent_parameters and dimension > 1:
+                self.triangle_trafo_pars = nn.Parameter(torch.randn(self.num_triangle_params).unsqueeze(0))
+        elif rotation_mode == "angles" and dimension > 1:
+            self.num_angle_pars = int(dimension * (dimension - 1) / 2)
+            if use_permanent_parameters:
+                self.angle_pars = nn.Parameter(torch.randn((1, self.num_angle_pars)))
+        elif rotation_mode == "cayley" and dimension > 1:
+            assert dimension == 2, "Cayley requires 2 dims at the moment"
+            self.num_cayley_pars = 1
+            if use_permanent_parameters:
+                self.cayley_pars = nn.Parameter(torch.randn((1, 1)))
+        self.num_rotation_params = self.num_householder_params + self.num_triangle_params + self.num_angle_pars + self.num_cayley_pars
+        self.total_param_num += self.num_triangle_params + self.num_angle_pars + self.num_cayley_pars
 
         self.num_params_datapoints = num_kde * dimension
-        self.total_param_num_means = num_kde * dimension
+        self.total_param_num_means = (num_kde - (1 if center_mean else 0)) * dimension
         bandwidth = (4. * numpy.sqrt(math.pi) / ((math.pi ** 4) * num_kde)) ** 0.2      # Gaussianization-flow paper init (:233)
         self.init_log_width = float(numpy.log(bandwidth))
         if nonlinear_stretch_type == "classic":
             if use_permanent_parameters:
-                self.kde_means = nn.Parameter(torch.randn(num_kde, dimension).unsqueeze(0))
+                self.kde_means = nn.Parameter(torch.randn(num_kde - (1 if center_mean else 0), dimension).unsqueeze(0))
                 self.kde_log_widths = nn.Parameter(torch.ones(num_kde, dimension).unsqueeze(0) * self.init_log_width)
                 if fit_normalization:
                     self.kde_log_weights = nn.Parameter(torch.randn(num_kde, dimension).unsqueeze(0))
-            self.total_param_num += 2 * self.num_params_datapoints + (self.num_params_datapoints if fit_normalization else 0)
+                if add_skewness:                                  # (:352-368) the first int(K/2) components are skewed to one side, the rest mirrored
+                    self.kde_log_skew_exponents = nn.Parameter(torch.randn(num_kde, dimension).unsqueeze(0))
+            self.total_param_num += self.total_param_num_means + self.num_params_datapoints * (1 + (1 if fit_normalization else 0) + (1 if add_skewness else 0))
         else:
             # per-dimension rational-quadratic splines with a learnable box and linear tails (:370-382): (D, K) widths / heights,
             # (D, K+1) derivatives, (D, 4) box = (left, ln(width - 0.5), bottom, ln(height - 0.5))
@@ -134,6 +148,9 @@ class gf_block(euclidean_base.euclidean_base):
             s.width_max = float(self.width_max) if self.width_max is not None else -1.0
             s.norm_min = float(self.lower_bound_for_norms)
             s.norm_max = float(self.upper_bound_for_norms)
+            s.rotation_mode = _hip.GF_ROT_MODES.get(self.rotation_mode, 0)
+            s.center_mean = 1 if self.center_mean else 0
+            s.add_skewness = 1 if self.add_skewness else 0
             self._c_struct = s
         return self._c_struct
 
@@ -143,12 +160,22 @@ class gf_block(euclidean_base.euclidean_base):
             ts.append(self.offsets)
         if self.use_householder:
             ts.append(self.vs)
+        for name, n in (("triangle_trafo_pars", self.num_triangle_params), ("angle_pars", self.num_angle_pars), ("cayley_pars", self.num_cayley_pars)):
+            if n > 0:
+                ts.append(getattr(self, name))
         if self.nonlinear_stretch_type == "rq_splines":
             return ts + [self.log_widths, self.log_heights, self.log_derivatives, self.boundary_points]
         ts += [self.kde_means, self.kde_log_widths]
         if self.fit_normalization:
             ts.append(self.kde_log_weights)
+        if self.add_skewness:
+            ts.append(self.kde_log_skew_exponents)
         return ts
+
+    @property
+    def has_extended_options(self):
+        """options served by the general-option kernel only (no fused block launch, no backward kernel)"""
+        return bool(self.center_mean or self.add_skewness or self.rotation_mode not in ("householder", "none"))
 
     def permanent_row(self, like):
         """the permanent parameters as one (1, total_param_num) row in the extra_inputs layout (cached until a parameter changes)."""
@@ -187,6 +214,7 @@ class gf_block(euclidean_base.euclidean_base):
         vec = []
         if self.num_householder_params > 0:
             vec.append(torch.randn(self.householder_iter * self.dimension))
+        vec.append(torch.zeros(self.num_triangle_params + self.num_angle_pars + self.num_cayley_pars))     # identity rotations (:1123-1134)
         if self.nonlinear_stretch_type == "rq_splines":          # (:1150-1166)
             vec.append(torch.ones(self.num_kde * self.dimension))
             vec.append(torch.ones(self.num_kde * self.dimension))
@@ -197,6 +225,8 @@ class gf_block(euclidean_base.euclidean_base):
         vec.append(torch.ones(self.num_kde * self.dimension) * self.init_log_width)
         if self.fit_normalization:
             vec.append(torch.ones(self.num_kde * self.dimension))
+        if self.add_skewness:
+            vec.append(torch.zeros(self.num_kde * self.dimension))
         return torch.cat(vec)
 
     def _init_params(self, params):
@@ -204,6 +234,10 @@ class gf_block(euclidean_base.euclidean_base):
         if self.use_householder:
             self.vs.data = torch.reshape(params[:self.num_householder_params], [1, self.householder_iter, self.dimension])
             c += self.num_householder_params
+        for name, m in (("triangle_trafo_pars", self.num_triangle_params), ("angle_pars", self.num_angle_pars), ("cayley_pars", self.num_cayley_pars)):
+            if m > 0:          # (:1173-1193; the reference's cayley branch indexes the flat vector as a matrix and cannot run -- the intent is this)
+                getattr(self, name).data = torch.reshape(params[c:c + m], [1, m])
+                c += m
         n = self.num_params_datapoints
         if self.nonlinear_stretch_type == "rq_splines":          # (:1211-1222)
             K, D = self.num_kde, self.dimension
@@ -212,10 +246,13 @@ class gf_block(euclidean_base.euclidean_base):
             self.log_derivatives.data = torch.reshape(params[c:c + (K + 1) * D], [1, D, K + 1]); c += (K + 1) * D
             self.boundary_points.data = torch.reshape(params[c:c + 4 * D], [1, D, 4])
             return
-        self.kde_means.data = torch.reshape(params[c:c + n], [1, self.num_kde, self.dimension]); c += n
+        nm = self.total_param_num_means
+        self.kde_means.data = torch.reshape(params[c:c + nm], [1, self.num_kde - (1 if self.center_mean else 0), self.dimension]); c += nm
         self.kde_log_widths.data = torch.reshape(params[c:c + n], [1, self.num_kde, self.dimension]); c += n
         if self.fit_normalization:
             self.kde_log_weights.data = torch.reshape(params[c:c + n], [1, self.num_kde, self.dimension]); c += n
+        if self.add_skewness:
+            self.kde_log_skew_exponents.data = torch.reshape(params[c:c + n], [1, self.num_kde, self.dimension]); c += n
 
     def _obtain_layer_param_structure(self, param_dict, extra_inputs=None, previous_x=None, extra_prefix=""):
         c = 0
@@ -223,6 +260,11 @@ class gf_block(euclidean_base.euclidean_base):
         if self.use_householder:
             param_dict[extra_prefix + "vs"] = (self.vs.data.reshape(1, -1) if extra_inputs is None else extra_inputs[:, :self.num_householder_params])
             c += self.num_householder_params
+        for key, name, m in (("trianglepars", "triangle_trafo_pars", self.num_triangle_params), ("anglepars", "angle_pars", self.num_angle_pars),
+                             ("cayleypars", "cayley_pars", self.num_cayley_pars)):
+            if m > 0:
+                param_dict[extra_prefix + key] = getattr(self, name).data if extra_inputs is None else extra_inputs[:, c:c + m]
+                c += m if extra_inputs is not None else 0
         if self.nonlinear_stretch_type == "rq_splines":
             K, D = self.num_kde, self.dimension
             names = (("log_widths", K), ("log_heights", K), ("log_derivatives", K + 1), ("boundary_points", 4))
@@ -238,11 +280,16 @@ class gf_block(euclidean_base.euclidean_base):
             param_dict[extra_prefix + "log_widths"] = self.kde_log_widths.data
             if self.fit_normalization:
                 param_dict[extra_prefix + "log_norms"] = self.kde_log_weights.data
+            if self.add_skewness:
+                param_dict[extra_prefix + "exponents"] = self.kde_log_skew_exponents.data
         else:
-            param_dict[extra_prefix + "means"] = extra_inputs[:, c:c + n].reshape(-1, self.num_kde, self.dimension); c += n
+            nm = self.total_param_num_means
+            param_dict[extra_prefix + "means"] = extra_inputs[:, c:c + nm].reshape(-1, self.num_kde - (1 if self.center_mean else 0), self.dimension); c += nm
             param_dict[extra_prefix + "log_widths"] = extra_inputs[:, c:c + n].reshape(-1, self.num_kde, self.dimension); c += n
             if self.fit_normalization:
-                param_dict[extra_prefix + "log_norms"] = extra_inputs[:, c:c + n].reshape(-1, self.num_kde, self.dimension)
+                param_dict[extra_prefix + "log_norms"] = extra_inputs[:, c:c + n].reshape(-1, self.num_kde, self.dimension); c += n
+            if self.add_skewness:
+                param_dict[extra_prefix + "exponents"] = extra_inputs[:, c:c + n].reshape(-1, self.num_kde, self.dimension)
 
 
 # ----------------------------------------------------------------------------------------------------------

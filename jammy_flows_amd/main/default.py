@@ -466,7 +466,7 @@ class pdf(nn.Module):
             return None
         if not (3 <= layers[0].dimension <= 4) or not gfl.chain_supported(layers):
             return None
-        if any(l.nonlinear_stretch_type != "classic" for l in layers):
+        if any(l.nonlinear_stretch_type != "classic" or l.has_extended_options for l in layers):
             return None
         if mlp[0].in_features > _hip.COND_GF_MAX_IN or mlp[0].out_features > _hip.COND_GF_MAX_HIDDEN or mlp[0].out_features % 4:
             return None
@@ -510,6 +510,8 @@ class pdf(nn.Module):
             return None
         for l in layers:
             c = l.c_struct()
+            if l.has_extended_options:
+                return None
             if not (c.num_kde == 10 and c.hh_iter <= 8 and c.nonlinear_stretch_type == _hip.GF_STRETCH_CLASSIC and c.width_mode == _hip.GF_WIDTH_SMOOTH
                     and not c.clamp_widths and c.fit_normalization and c.regulate_normalization):
                 return None

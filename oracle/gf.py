@@ -1,9 +1,12 @@
 """Gaussianization-flow layer 'g' (layers/euclidean/gaussianization_flow.py + euclidean_base.py +
 bisection_n_newton.py:11-135) restated in numpy.  Oracle = test infrastructure only.
 
-Parameter row layout (SURVEY 8a'):  [offset D if model_offset][rotation][means K*D][log_widths K*D][log_weights K*D]
-(K-major (K,D)); rq_splines variant: [offset][rotation][log_w D*K][log_h D*K][log_d D*(K+1)][box D*4].
+Parameter row layout (SURVEY 8a'):  [offset D if model_offset][rotation][means (K-center_mean)*D][log_widths K*D][log_weights K*D]
+[log skew exponents K*D if add_skewness]  (K-major (K,D)); rq_splines variant: [offset][rotation][log_w D*K][log_h D*K][log_d D*(K+1)][box D*4].
+Rotation section: householder hh*D | angles D(D-1)/2 | cayley 1 | triangular_combination [lower D(D-1)/2][diag D-1][upper D(D-1)/2].
 """
+import itertools
+
 import numpy as np
 
 from . import splines
@@ -24,8 +27,15 @@ class GfSpec:
         self.hh_iter = dimension if hh == -1 else hh
         if self.rotation_mode == "householder":
             self.n_rot = self.hh_iter * dimension
-        elif self.rotation_mode == "none":
+        elif self.rotation_mode == "none" or dimension < 2:
             self.n_rot = 0
+        elif self.rotation_mode == "angles":                                     # gaussianization_flow.py:198-209
+            self.n_rot = dimension * (dimension - 1) // 2
+        elif self.rotation_mode == "cayley":                                     # :211-223
+            assert dimension == 2
+            self.n_rot = 1
+        elif self.rotation_mode == "triangular_combination":                     # :158-170
+            self.n_rot = dimension - 1 + dimension * (dimension - 1)
         else:
             raise NotImplementedError("oracle: rotation_mode %s" % self.rotation_mode)
         self.fit_normalization = opts["fit_normalization"]
@@ -40,11 +50,11 @@ class GfSpec:
         self.norm_min = opts["lower_bound_for_norms"]
         self.norm_max = opts["upper_bound_for_norms"]
         self.stretch = opts["nonlinear_stretch_type"]
-        if opts["center_mean"] or opts["add_skewness"]:
-            raise NotImplementedError("oracle: center_mean / add_skewness")
+        self.center_mean = opts["center_mean"]
+        self.add_skewness = opts["add_skewness"]
         kd = self.K * self.D
         if self.stretch == "classic":
-            n = 2 * kd + (kd if self.fit_normalization else 0)
+            n = 2 * kd + (kd if self.fit_normalization else 0) + (kd if self.add_skewness else 0) - (self.D if self.center_mean else 0)
         else:
             n = 2 * kd + (self.K + 1) * self.D + 4 * self.D
         self.total_param_num = (self.D if model_offset else 0) + self.n_rot + n
@@ -55,12 +65,15 @@ class GfSpec:
         if self.model_offset:
             parts.append(np.asarray(sd[prefix + "offsets"], dtype=np.float64).reshape(-1))
         if self.n_rot:
-            parts.append(sd[prefix + "vs"].reshape(-1))
+            name = {"householder": "vs", "angles": "angle_pars", "cayley": "cayley_pars", "triangular_combination": "triangle_trafo_pars"}
+            parts.append(sd[prefix + name[self.rotation_mode]].reshape(-1))
         if self.stretch == "classic":
             parts.append(sd[prefix + "kde_means"].reshape(-1))
             parts.append(sd[prefix + "kde_log_widths"].reshape(-1))
             if self.fit_normalization:
                 parts.append(sd[prefix + "kde_log_weights"].reshape(-1))
+            if self.add_skewness:
+                parts.append(sd[prefix + "kde_log_skew_exponents"].reshape(-1))
         else:
             for k in ("log_widths", "log_heights", "log_derivatives", "boundary_points"):
                 parts.append(sd[prefix + k].reshape(-1))
@@ -87,6 +100,60 @@ def _width_regulator(spec, x):
     return bounded_log_fn(x, spec.width_min, spec.width_max, center=True)
 
 
+def _unit_lower(D, entries):
+    """matrix_fns.obtain_lower_triangular_matrix_and_logdet (layers/matrix_fns.py:27-55) with a unit diagonal: the entries fill the
+    sub-diagonals from the bottom-left corner upwards."""
+    m = np.broadcast_to(np.eye(D), (entries.shape[0], D, D)).copy()
+    c = 0
+    for ind in range(D - 1):
+        off = D - 1 - ind
+        for j in range(ind + 1):
+            m[:, j + off, j] = entries[:, c + j]
+        c += ind + 1
+    return m
+
+
+def rotation(spec, rp):
+    """the rotation section of the row -> ("matrix", Q) or ("triangular", (L, diag, U))  (gaussianization_flow.py:711-799)."""
+    D = spec.D
+    if spec.rotation_mode == "householder":
+        return "matrix", householder_matrix(rp.reshape(-1, spec.hh_iter, D))
+    if spec.rotation_mode == "angles":                                           # Givens rotations, prev = new @ prev (:760-780)
+        q = np.broadcast_to(np.eye(D), (rp.shape[0], D, D)).copy()
+        for ind, (a, b) in enumerate(itertools.combinations(range(D), 2)):
+            g = np.broadcast_to(np.eye(D), (rp.shape[0], D, D)).copy()
+            g[:, a, a] = np.cos(rp[:, ind]); g[:, b, b] = g[:, a, a]
+            g[:, a, b] = np.sin(rp[:, ind]); g[:, b, a] = -g[:, a, b]
+            q = np.matmul(g, q)
+        return "matrix", q
+    if spec.rotation_mode == "cayley":                                           # (:793-798)
+        t = rp[:, 0]
+        m = 1.0 / (1.0 + t ** 2)
+        q = np.zeros((rp.shape[0], 2, 2))
+        q[:, 0, 0] = q[:, 1, 1] = (1.0 - t ** 2) * m
+        q[:, 0, 1] = -2.0 * t * m
+        q[:, 1, 0] = 2.0 * t * m
+        return "matrix", q
+    nt = D * (D - 1) // 2                                                        # triangular_combination (:715-729, 945-951)
+    left, mid, right = rp[:, :nt], rp[:, nt:nt + D - 1], rp[:, nt + D - 1:2 * nt + D - 1]
+    diag = np.concatenate([mid, -mid.sum(axis=1, keepdims=True)], axis=1)
+    return "triangular", (_unit_lower(D, left), diag, np.transpose(_unit_lower(D, right), (0, 2, 1)))
+
+
+def rotate(rot, x, inverse):
+    """x <- R x (sampling direction, :942-987) or R^-1 x (log-prob direction, :1004-1049)."""
+    if rot is None:
+        return x
+    kind, q = rot
+    if kind == "matrix":
+        return matvec(q, x, transpose=inverse)
+    lower, diag, upper = q
+    if not inverse:
+        return matvec(lower, matvec(upper, x) * np.exp(diag))
+    y = matvec(np.linalg.inv(lower), x) / np.exp(diag)
+    return matvec(np.linalg.inv(upper), y)
+
+
 def unpack(spec, params):
     """_obtain_usable_flow_params (gaussianization_flow.py:699-909) + offset split (euclidean_base.py:42-45)."""
     D, K = spec.D, spec.K
@@ -97,19 +164,29 @@ def unpack(spec, params):
         c = D
     Q = None
     if spec.n_rot:
-        Q = householder_matrix(params[:, c:c + spec.n_rot].reshape(-1, spec.hh_iter, D))
+        Q = rotation(spec, params[:, c:c + spec.n_rot])
         c += spec.n_rot
     if spec.stretch == "classic":
-        means = params[:, c:c + K * D].reshape(-1, K, D); c += K * D
+        km = K - (1 if spec.center_mean else 0)
+        means = params[:, c:c + km * D].reshape(-1, km, D); c += km * D
         logw = params[:, c:c + K * D].reshape(-1, K, D); c += K * D
         if spec.fit_normalization:
             lognorm = params[:, c:c + K * D].reshape(-1, K, D); c += K * D
         else:
             lognorm = np.zeros_like(logw)
+        log_skew, signs = None, None
+        if spec.add_skewness:                                                    # (:352-368, 832-834, 856-858)
+            log_skew = bounded_log_fn(params[:, c:c + K * D].reshape(-1, K, D), 0.1, 9.0, center=True); c += K * D
+            signs = np.ones(K)
+            signs[K // 2:] = -1.0
         logw = _width_regulator(spec, logw)
         if spec.fit_normalization and spec.regulate_normalization:
             lognorm = bounded_log_fn(lognorm, spec.norm_min, spec.norm_max, center=False)
-        return offset, Q, (means, logw, lognorm)
+        if spec.center_mean:                                                     # (:846-852)
+            w = np.exp(lognorm)
+            last = -(means * w[:, :-1, :]).sum(axis=1, keepdims=True) / w[:, -1:, :]
+            means = np.concatenate([means, last], axis=1)
+        return offset, Q, (means, logw, lognorm, log_skew, signs)
     lw = params[:, c:c + D * K].reshape(-1, D, K); c += D * K
     lh = params[:, c:c + D * K].reshape(-1, D, K); c += D * K
     ld = params[:, c:c + D * (K + 1)].reshape(-1, D, K + 1); c += D * (K + 1)
@@ -121,10 +198,35 @@ def unpack(spec, params):
     return offset, Q, (lw, lh, ld, left, right, bottom, top)
 
 
-def log_quantities(x, means, logw, lognorm, want_pdf=True):
-    """logistic_kernel_log_pdf_quantities (gaussianization_flow.py:389-454), no skewness."""
+def log_one_plus_exp_x_to_a_minus_1(x, a):
+    """extra_functions.log_one_plus_exp_x_to_a_minus_1 (extra_functions.py:14-61): log(((1+e^x)^a - 1) / (1+e^x)^a), branch for branch."""
+    x, a = np.broadcast_arrays(x, a)
+    sp = a * softplus(x)
+    small = x <= -20
+    res = np.where(small, np.log(a) + x, 0.0)
+    large = sp > 20
+    res = np.where(~small & large, sp, res)
+    tiny = sp < 1e-8
+    with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+        res = np.where(~small & tiny, np.log(sp), res)
+        res = np.where(~small & ~large & ~tiny, np.log(np.exp(np.minimum(sp, 50.0)) - 1.0), res)
+    return res - sp
+
+
+def log_quantities(x, means, logw, lognorm, log_skew=None, signs=None, want_pdf=True):
+    """logistic_kernel_log_pdf_quantities (gaussianization_flow.py:389-454)."""
     u = (x[:, None, :] - means) / np.exp(logw)
     ln_pi = lognorm - logsumexp(lognorm, axis=1, keepdims=True)
+    if log_skew is not None:
+        a = np.exp(log_skew)
+        sg = signs[None, :, None]
+        pos = np.broadcast_to(sg > 0, u.shape)
+        log_pdf = None
+        if want_pdf:
+            log_pdf = logsumexp(-sg * u - logw + log_skew - (a + 1.0) * softplus(-sg * u) + ln_pi, axis=1)
+        log_cdfs = np.where(pos, -a * softplus(-u), log_one_plus_exp_x_to_a_minus_1(u, a))
+        log_sfs = np.where(pos, log_one_plus_exp_x_to_a_minus_1(-u, a), -a * softplus(u))
+        return logsumexp(log_cdfs + ln_pi, axis=1), logsumexp(log_sfs + ln_pi, axis=1), log_pdf
     sp = softplus(-u)
     log_pdf = None
     if want_pdf:
@@ -217,8 +319,7 @@ def inverse(spec, x, log_det, params):
     offset, Q, rest = unpack(spec, params)
     if offset is not None:
         x = x - offset
-    if Q is not None:
-        x = matvec(Q, x, transpose=True)
+    x = rotate(Q, x, True)
     if spec.stretch == "classic":
         y, logd = _value_and_logderiv(spec, x, rest)
         return y, log_det + logd.sum(axis=-1), []
@@ -228,6 +329,8 @@ def inverse(spec, x, log_det, params):
 
 
 def _sel(a, mask):
+    if a is None or a.ndim < 3:          # absent skewness / the per-component signs
+        return a
     return a[mask] if a.shape[0] > 1 else a
 
 
@@ -280,8 +383,7 @@ def forward(spec, z, log_det, params):
         x = y[:, :, 0]
         log_det = log_det + lad[:, :, 0].sum(axis=-1)
         bins = [b]
-    if Q is not None:
-        x = matvec(Q, x)
+    x = rotate(Q, x, False)
     if offset is not None:
         x = x + offset
     return x, log_det, bins

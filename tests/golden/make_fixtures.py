@@ -90,6 +90,18 @@ CASES = [
     dict(name="g_e1e2e1_cond_lowrank", pdf="e1+e2+e1", flow="gg+g+ggg", mlp_scale=30.0,
          kwargs=dict(conditional_input_dim=2, amortization_mlp_dims="64-30", amortization_mlp_ranks="2-10-1000",
                      amortization_mlp_use_custom_mode=True)),
+    # the non-default mixture / rotation options of 'g' (general-option kernel, csrc/jf_gf_ext.h)
+    dict(name="g_e2_skew_cond", pdf="e2", flow="gg", mlp_scale=300.0,
+         kwargs=dict(conditional_input_dim=2, options_overwrite={"g": {"add_skewness": 1}})),
+    dict(name="g_e3_center_mean", pdf="e3", flow="gg", mlp_scale=1000.0,
+         kwargs=dict(conditional_input_dim=2, options_overwrite={"g": {"center_mean": 1}})),
+    dict(name="g_e3_rot_angles", pdf="e3", flow="gg", perturb=0.5, kwargs=dict(options_overwrite={"g": {"rotation_mode": "angles"}})),
+    dict(name="g_e2_rot_cayley_cond", pdf="e2", flow="gg", mlp_scale=1000.0,
+         kwargs=dict(conditional_input_dim=2, options_overwrite={"g": {"rotation_mode": "cayley"}})),
+    dict(name="g_e3_rot_triangular", pdf="e3", flow="gg", mlp_scale=300.0,
+         kwargs=dict(conditional_input_dim=2, options_overwrite={"g": {"rotation_mode": "triangular_combination"}})),
+    dict(name="g_e4_all_options", pdf="e4", flow="ggg", perturb=0.3,
+         kwargs=dict(options_overwrite={"g": {"rotation_mode": "angles", "center_mean": 1, "add_skewness": 1, "num_kde": 7}})),
     # affine / multivariate-normal layer 't' (docs/source/usage/suggested_settings.rst:12-42 recommends "gggt")
     dict(name="t_e3_gggt", pdf="e3", flow="gggt", perturb=0.4),
     dict(name="t_e3_gt_full_cond", pdf="e3", flow="gt", mlp_scale=300.0,

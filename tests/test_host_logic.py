@@ -38,8 +38,9 @@ def test_library_exports_every_declared_symbol():
 
 def test_gf_layer_struct_matches_header():
     from jammy_flows_amd import _hip
-    # 10 int32 + 4 double, no padding surprises: sizeof must be 10*4 + 4*8
-    assert ctypes.sizeof(_hip.jf_gf_layer) == 72
+    # 12 int32 + 4 double, no padding surprises: sizeof must be 12*4 + 4*8
+    assert ctypes.sizeof(_hip.jf_gf_layer) == 80
+    assert _hip.lib().jf_abi_version() >= 2           # the struct grew with ABI 2 (rotation_mode / center_mean / add_skewness)
 
 
 @pytest.mark.parametrize("fx", SUPPORTED, ids=[f.name for f in SUPPORTED])
@@ -101,7 +102,7 @@ def test_unsupported_things_fail_loudly():
         jammy_flows_amd.pdf("e2", "c")                      # continuous manifold flow: needs torchdiffeq, outside the hot path
     p = jammy_flows_amd.pdf("e3", "gggt")                   # the docs' recommended Euclidean setting constructs (suggested_settings.rst:12-42)
     assert [type(l).__name__ for l in p.layer_list[0]] == ["gf_block"] * 3 + ["mvn_block"]
-    with pytest.raises(NotImplementedError):
-        jammy_flows_amd.pdf("e2", "gg", options_overwrite={"g": {"add_skewness": 1}})
+    p = jammy_flows_amd.pdf("e2", "gg", options_overwrite={"g": {"add_skewness": 1, "center_mean": 1, "rotation_mode": "cayley"}})
+    assert [l.total_param_num for l in p.layer_list[0]] == [1 + 18 + 60, 2 + 1 + 18 + 60] and all(l.has_extended_options for l in p.layer_list[0])
     with pytest.raises(NotImplementedError):
         jammy_flows_amd.pdf("e2", "gg", predict_log_normalization=True)
