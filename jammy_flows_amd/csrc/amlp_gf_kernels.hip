@@ -109,7 +109,8 @@ template <typename T> __device__ __forceinline__ MixQ<T> ag_mixture(const T (&P)
 template <typename T, int G> __device__ __forceinline__ T group_bcast(T v, int src) { return __shfl(v, (threadIdx.x & 63 & ~(G - 1)) + src, 64); }
 
 // RM: compiled rank bound (8 or 16): the rank loops are fully unrolled over it
-template <typename T, int G, int RM>
+// MLP_ONLY: the jf_amlp2 instantiation (writes the parameter block, no flow) -- a kernel of its own so that profiles tell the two apart
+template <typename T, int G, int RM, bool MLP_ONLY>
 __global__ void __launch_bounds__(AG_THREADS) amlp_gf_kernel(const AgArgs<T> a) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     T* sV1 = reinterpret_cast<T*>(smem_raw);                       // r1 x K1   (or H x K1 when the first stage is full)
@@ -212,7 +213,7 @@ __global__ void __launch_bounds__(AG_THREADS) amlp_gf_kernel(const AgArgs<T> a) 
         for (int q = 0; q < RM; ++q) if (q < a.r2) acc += u[q] * t2[q];
         return acc;
     };
-    if (a.params_out) {                                            // MLP only: the G lanes of a row write its N outputs
+    if constexpr (MLP_ONLY) {                                      // the G lanes of a row write its N outputs
         if (row_valid) for (int j = g; j < a.N; j += G) a.params_out[row * a.pos + j] = gen(j);
         return;
     }
@@ -264,7 +265,7 @@ template <typename T> static int ag_launch(const AgArgs<T>& a, int D, hipStream_
     const unsigned grid = (unsigned)((a.B + AG_THREADS / G - 1) / (AG_THREADS / G));
 #define JF_AG_GO(G_, RM_)                                                                                                      \
     {                                                                                                                          \
-        auto k = amlp_gf_kernel<T, G_, RM_>;                                                                                   \
+        auto k = a.params_out ? amlp_gf_kernel<T, G_, RM_, true> : amlp_gf_kernel<T, G_, RM_, false>;                            \
         if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);    \
         hipLaunchKernelGGL(k, dim3(grid), dim3(AG_THREADS), lds, st, a);                                                         \
     }

@@ -14,7 +14,7 @@ import numpy
 import torch
 from torch import nn
 
-from .. import _hip, autograd
+from .. import _hip, autograd, init_fns
 from ..amortizable_mlp import AmortizableMLP
 from ..extra_functions import list_from_str
 from ..flow_options import canonical, check_flow_option, layer_class, obtain_default_options, opts_dict
@@ -338,17 +338,27 @@ class pdf(nn.Module):
 
     def init_params(self, data=None, damping_factor=1000.0, mvn_min_max_sv_ratio=1e-4):
         """layer "desired init" vectors become the final bias of each MLP (everything else / damping_factor) or are written into
-        the permanent parameters (:1817-1952).  Data-driven initialisation (scipy.optimize on the host) is out of scope."""
+        the permanent parameters (:1817-1952).  With `data` (B, total_target_dim) the Euclidean blocks are initialised from the data
+        (means, principal axes, percentiles; init_fns.find_init_pars_of_chained_blocks), the data passing through each initialised layer's
+        HIP kernel on the way."""
         if data is not None:
-            raise NotImplementedError("init_params(data=...) (PCA / percentile based initialisation) is outside the MI355X hot path")
+            assert data.shape[1] == self.total_target_dim, "Initialization with data must match the target dimension of the PDF!"
         global_init = torch.zeros(self.total_number_amortizable_params) if self.amortize_everything else None
         gi = 0
+        dim_index = 0
+        module_device = self.obtain_current_dtype_n_device()[1]
         with torch.no_grad():
             for si, block in enumerate(self.layer_list):
-                parts = [l.get_desired_init_parameters() for l in (reversed(block) if self.pdf_defs_list[si][0] == "e" else block)]
+                this_dim = self.target_dims[si]
                 if self.pdf_defs_list[si][0] == "e":
-                    parts = parts[::-1]
-                these = torch.cat(parts) if len(parts) else torch.zeros(0)
+                    these = init_fns.find_init_pars_of_chained_blocks(list(block), data[:, dim_index:dim_index + this_dim] if data is not None else None,
+                                                                      mvn_min_max_sv_ratio=mvn_min_max_sv_ratio)
+                else:
+                    parts = [l.get_desired_init_parameters() for l in block]
+                    these = torch.cat(parts) if len(parts) else torch.zeros(0)
+                dim_index += this_dim
+                if module_device is not None:
+                    these = these.to(module_device)          # the init vector lands in parameters: keep them on the module's device
                 if len(these) == 0:
                     continue
                 mlp = self.mlp_predictors[si] if len(self.mlp_predictors) > si else None
@@ -356,10 +366,10 @@ class pdf(nn.Module):
                     if isinstance(mlp, AmortizableMLP):
                         if self.amortize_everything:
                             n = mlp.num_amortization_params
-                            global_init[gi:gi + n] = mlp.obtain_default_init_tensor(fix_final_bias=these, prev_damping_factor=damping_factor)
+                            global_init[gi:gi + n] = mlp.obtain_default_init_tensor(fix_final_bias=these.cpu(), prev_damping_factor=damping_factor)
                             gi += n
                         else:
-                            mlp.initialize_uvbs(fix_final_bias=these, prev_damping_factor=damping_factor)
+                            mlp.initialize_uvbs(fix_final_bias=these.cpu(), prev_damping_factor=damping_factor)
                     else:
                         for m in mlp:
                             if hasattr(m, "weight"):
@@ -378,7 +388,7 @@ class pdf(nn.Module):
                             l.init_params(these[c:c + n])
                         c += n
                     if self.amortize_everything:
-                        global_init[gi:gi + c] = these
+                        global_init[gi:gi + c] = these.cpu()
                         gi += c
         return global_init
 
