@@ -29,6 +29,8 @@ extern "C" {
 #define JF_STATUS_NONCONVERGED 0 /* rows whose Newton iteration ended above the reference's print threshold */
 #define JF_STATUS_NONFINITE 1    /* non-finite iterates / outputs */
 #define JF_STATUS_OUT_OF_RANGE 2 /* spline inputs outside [left,right] */
+#define JF_STATUS_NEWTON_STEPS 3 /* g layers, sampling direction: row-steps of the Newton stage (sum over iterations of the rows still
+                                    iterating) -- what the reference's masked iteration spends (bisection_n_newton.py:74-120) */
 #define JF_STATUS_WORDS 4
 
 #define JF_MAX_CHAIN 8 /* max layers fused into one launch */

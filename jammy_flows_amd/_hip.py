@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libjammy_hip.so")
 JF_OK, JF_ERR_BADARG, JF_ERR_UNSUPPORTED, JF_ERR_LAUNCH = 0, -1, -2, -3
 JF_ERRORS = {-1: "bad argument", -2: "unsupported configuration (dimension > 8, chain too long, LDS budget ...)", -3: "kernel launch failed"}
 JF_STATUS_WORDS = 4
-JF_STATUS_NONCONVERGED, JF_STATUS_NONFINITE, JF_STATUS_OUT_OF_RANGE = 0, 1, 2
+JF_STATUS_NONCONVERGED, JF_STATUS_NONFINITE, JF_STATUS_OUT_OF_RANGE, JF_STATUS_NEWTON_STEPS = 0, 1, 2, 3
 JF_MAX_CHAIN = 8
 
 GF_INV_TYPES = {"isigmoid": 0, "inormal_partly_precise": 1, "inormal_partly_crude": 2, "inormal_full_pade": 3}

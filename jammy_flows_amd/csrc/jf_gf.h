@@ -385,6 +385,7 @@ template <typename T, int G> __device__ __forceinline__ T gfg_solve(const T* __r
         const T f = s.y - z;
         const T upd = f / M<T>::exp(s.logd);
         const T usum = group_sum<T, G>(live ? M<T>::abs(upd) : T(0));
+        status_add(status, JF_STATUS_NEWTON_STEPS, active && leader);
         if (active) {
             const T nx = x - upd;
             if (M<T>::finite(nx)) x = nx; else nonfinite = nonfinite || live;     // keep the previous iterate (:84-91)

@@ -222,7 +222,10 @@ template <typename T> __device__ inline void gx_solve(const GfLayerDev<T>& o, co
     }
     T ferr = T(0);
     bool nonfinite = false;
-    for (int it = 0; it < 20; ++it) {
+    bool active = row_valid;
+    for (int it = 0; it < 20 && __any(active); ++it) {
+        status_add(status, JF_STATUS_NEWTON_STEPS, active);
+        if (!active) continue;
         T usum = T(0);
         ferr = T(0);
         for (int d = 0; d < D; ++d) {
@@ -235,7 +238,7 @@ template <typename T> __device__ inline void gx_solve(const GfLayerDev<T>& o, co
             if (M<T>::finite(nx)) x[d] = nx; else nonfinite = true;     // keep the previous iterate (:84-91)
             ferr = M<T>::max(ferr, M<T>::abs(f));
         }
-        if (!(usum >= T(1e-14))) break;
+        active = usum >= T(1e-14);
     }
     const T prec = sizeof(T) == 8 ? T(1e-7) : T(1e-4);
     status_add(status, JF_STATUS_NONCONVERGED, row_valid && (ferr > prec));

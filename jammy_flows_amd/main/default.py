@@ -616,7 +616,8 @@ class pdf(nn.Module):
         """kernel status words -> the reference's warnings / exceptions (bisection_n_newton.py:84-133, default.py:1516)."""
         if status is None or not self.check_status:
             return
-        nonconv, nonfinite, oob, _ = status.tolist()
+        nonconv, nonfinite, oob, newton_steps = status.tolist()
+        self.last_status_words = {"nonconverged": nonconv, "nonfinite": nonfinite, "out_of_range": oob, "newton_row_steps": newton_steps}
         if oob > 0:
             raise Exception("outside boundaries in rational-spline flow! (%d rows)" % oob)
         if nonfinite > 0:

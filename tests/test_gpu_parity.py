@@ -5,10 +5,14 @@ Bars (BASELINE.json north_star): |d log p| < 1e-4 in float64, < 1e-2 in float32 
 reference: the reference's own float32 path returns NaN in part of the domain).  The float64 assertions
 here are much tighter than the bar (relative 1e-7) so that a wrong formula cannot hide inside the tolerance.
 """
+import json
+import os
+
 import numpy as np
 import pytest
 import torch
 
+import fixture_io
 import helpers
 from helpers import ALL_FIXTURES, build_oracle, build_product, max_abs, max_rel, to_dev
 
@@ -66,6 +70,7 @@ def test_logprob_float64_vs_reference(fx):
     assert max_rel(logp, o_logp) < tol
 
 
+NEWTON_RECORDS = json.load(open(os.path.join(fixture_io.GOLDEN_DIR, "newton_records.json")))
 F32_ABS_BAR = 1e-2            # north-star float32 bar, absolute
 F32_BIG = 1e4                 # |log p| beyond which a float32 RESULT cannot carry 1e-2 absolute any more (ulp(1e4) = 1e-3, and the sum of
                               # ~20 terms of that size that make up such a log-prob each round at that level): those rows are held to
@@ -127,6 +132,15 @@ def test_sampling_float64_vs_reference(fx):
     assert max_rel(x, fx["sample_x"]) < tol
     assert max_rel(logp, fx["sample_logp"]) < tol
     assert max_abs(logp_base, fx["sample_logp_base"]) < 1e-9
+    # Newton stage of the g layers: the work the reference's masked iteration spent on these very rows (tests/golden/newton_records.json,
+    # make_newton_fixtures.py) against the kernel's own count of row-steps.  Rows that sit on the rounding floor of the 1e-14 stopping rule
+    # (inormal_* layers: they run all 20 iterations in the reference too) may stop an iteration earlier or later, hence a band, not equality.
+    rec = NEWTON_RECORDS.get(fx.name)
+    if rec is not None:
+        got = pdf.last_status_words["newton_row_steps"]
+        print("%s: Newton row-steps %d (reference %d)" % (fx.name, got, rec["row_steps_total"]))
+        assert pdf.last_status_words["nonconverged"] == sum(s["n_above_1e_7"] for s in rec["solves"]) == 0
+        assert 0.7 * rec["row_steps_total"] <= got <= 1.3 * rec["row_steps_total"]
 
 
 @pytest.mark.parametrize("fx", SUPPORTED, ids=IDS)
