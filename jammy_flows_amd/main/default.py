@@ -150,6 +150,7 @@ class pdf(nn.Module):
         # asynchronously and raise at the next call or in flush_status() (saves one host-device round trip per call; throughput loops
         # such as bench.py opt into it and flush inside their timed region).  False: never.
         self.check_status = True
+        self.force_fused_manifold_blocks = False     # tests: run jf_cond_<fam>_chain_inv also where the two-launch path is the faster default
         # conditional e-blocks (Linear-tanh-Linear MLP + g layers, D in {3,4}, float32) as ONE launch with the parameter block kept on chip
         # (jf_cond_gf_chain_inv): +9 % on the C3 step against jf_mlp2 + jf_gf_chain_inv.  False selects the two-launch path.
         self.fuse_conditional_blocks = True
@@ -495,6 +496,10 @@ class pdf(nn.Module):
             return None
         fam = _manifold_family(layers)
         if fam is None or fam not in _hip.COND_MCHAIN_FAMILIES:
+            return None
+        # measured on 2^20 rows (scripts/bench_configs.py): the one-launch form wins for float32 'f' blocks (0.146 ms vs 0.16 + 0.05 ms); for the
+        # 'r' / 'o' / 'm' families and for float64 the two launches (resident narrow-output jf_mlp2 + chain) are faster (f64 'o': 0.48 vs 0.96 ms)
+        if not (fam == "f" and dtype == torch.float32) and not self.force_fused_manifold_blocks:
             return None
         if mlp[0].in_features > _hip.COND_GF_MAX_IN or mlp[0].out_features > _hip.COND_GF_MAX_HIDDEN or mlp[2].out_features > _hip.COND_MCHAIN_MAX_PARAMS:
             return None

@@ -357,6 +357,37 @@ def test_fused_conditional_block_vs_golden_and_two_launch_path(name):
         assert max_abs(out[mode][2][sel], out["two"][2][sel]) < 2e-3, mode
 
 
+FUSED_MANIFOLD = ["c4_i1s1_ro", "r_i1_m1p1_rr_cond", "r_i1_smooth2", "o_s1_cond_oo", "o_s1_nosmooth", "m_s1_cond", "m_s1_nat1_rot",
+                  "f_s2_cond_ff", "f_s2_splines_cond", "f_s2_rot_xyz_mu", "c3_e4s2e4"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64], ids=["f32", "f64"])
+@pytest.mark.parametrize("name", FUSED_MANIFOLD)
+def test_fused_manifold_block_vs_golden(name, dtype):
+    """jf_cond_<family>_chain_inv (amortisation MLP + manifold chain in one launch) is the default only where it measured faster (float32 'f'
+    blocks); here it is forced for every family and both dtypes, the kernel that ran is asserted by name, and the result is held to the same
+    bars as the default path."""
+    from jammy_flows_amd import _hip
+    fx = [f for f in ALL_FIXTURES if f.name == name][0]
+    pdf = build_product(fx, dtype)
+    pdf.force_fused_manifold_blocks = True
+    ok = float32_domain_mask(fx) if dtype == torch.float32 else np.ones(fx["x"].shape[0], dtype=bool)
+    pdf.check_status = bool(ok.all())
+    timer = _hip.KernelTimer()
+    with timer:
+        logp = pdf(to_dev(fx["x"], dtype), conditional_input=to_dev(fx.get("cond"), dtype), force_embedding_coordinates=bool(fx.meta["embedding"]))[0]
+    ran = sorted(set(k[0] for k in timer.summary()))
+    fused = [k for k in ran if k.startswith("jf_cond_") and "gf" not in k]
+    if not fused:           # the only legitimate ways out: a parameter row beyond the kernel's 64 columns, or the C side declining the float64
+        wide = max(sum(blk) for blk in fx.meta["layer_param_nums"]) > _hip.COND_MCHAIN_MAX_PARAMS     # LDS budget (JF_ERR_UNSUPPORTED)
+        assert (wide or dtype == torch.float64) and any(k.startswith("jf_mlp2") for k in ran), ran
+    if dtype == torch.float64:
+        assert max_rel(logp, fx["logp"]) < 1e-7
+    else:
+        assert_float32_parity(logp.double().cpu().numpy(), fx["logp"], ok, "%s [fused manifold block]" % name)
+
+
 def test_packed_image_follows_the_weights():
     """the split-bf16 image of W2 / b2 is rebuilt when the weights change in place (optimizer step) or are replaced (load_state_dict)"""
     fx = [f for f in ALL_FIXTURES if f.name == "g_e3_ggg_cond"][0]
