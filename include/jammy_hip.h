@@ -182,6 +182,17 @@ int jf_linear_f32(const float* in, int64_t in_stride, const float* W, int64_t w_
 int jf_linear_f64(const double* in, int64_t in_stride, const double* W, int64_t w_stride, const double* bias, int64_t B,
                   int32_t K, int32_t N, int32_t act, double* out, int64_t out_stride, void* stream);
 
+/* Backward of jf_linear with respect to the weights: the product that reduces over the batch,
+ *   g_W (N, K) = sum_b g[b, :]^T in[b, :],  g_bias (N) = sum_b g[b, :]        (what autograd's `g.t() @ inp`, `g.sum(0)` compute for nn.Linear)
+ * split over the grid: partials_w (S, N, K) and partials_b (S, N; nullable) receive one slab per row chunk, S = jf_linear_wgrad_splits_<dt>(B, N);
+ * the caller adds the slabs (deterministic, no atomics).  K <= 128, otherwise JF_ERR_UNSUPPORTED (use a library GEMM). */
+int64_t jf_linear_wgrad_splits_f32(int64_t B, int32_t N);
+int64_t jf_linear_wgrad_splits_f64(int64_t B, int32_t N);
+int jf_linear_wgrad_f32(const float* g, int64_t g_stride, const float* in, int64_t in_stride, int64_t B, int32_t K, int32_t N, float* partials_w,
+                        float* partials_b, void* stream);
+int jf_linear_wgrad_f64(const double* g, int64_t g_stride, const double* in, int64_t in_stride, int64_t B, int32_t K, int32_t N, double* partials_w,
+                        double* partials_b, void* stream);
+
 /* One AmortizableMLP stage with PER-SAMPLE weights (amortize_everything / fully_amortized_pdf: _apply_amortized_mlp with extra_inputs,
  * amortizable_mlp.py:508-578): out[b] = act(W_b in[b] + bias_b) (+ residual[b]); `segment` points at this stage's [U | V | bias] slice of
  * row 0 of the per-sample parameter block (row stride segment_stride): rank == 0: U = W (n_out x n_in); else U (n_out x rank), V (rank x n_in).

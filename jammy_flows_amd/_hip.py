@@ -110,6 +110,7 @@ _SIGNATURES = {
                              _P, _P, _P, _P, _P],
     "jf_amlp_gf_chain_inv": [_P, _I64, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P, _I64, _P, _I64, _I32, _I32, ctypes.POINTER(jf_gf_layer), _P,
                              _I64, _P, _P, _P, _P, _P],
+    "jf_linear_wgrad": [_P, _I64, _P, _I64, _I64, _I32, _I32, _P, _P, _P],
     "jf_amlp2": [_P, _I64, _P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _I32, _P, _I64, _P],
     "jf_gf_chain_fwd": [_P, _I64, _P, _P, _I64, _I32, _I64, _I32, _I32, ctypes.POINTER(jf_gf_layer), _P, _I64, _P, _P, _I64, _P, _P],
     "jf_linear": [_P, _I64, _P, _I64, _P, _I64, _I32, _I32, _I32, _P, _I64, _P],
@@ -129,6 +130,8 @@ _SIGNATURES = {
 }
 # entry points that exist for one precision only: full symbol name -> (argtypes, restype)
 _SIGNATURES_SINGLE = {
+    "jf_linear_wgrad_splits_f32": ([_I64, _I32], ctypes.c_int64),
+    "jf_linear_wgrad_splits_f64": ([_I64, _I32], ctypes.c_int64),
     "jf_gf_chain_inv_bwd_partials": ([_I64, _I32], ctypes.c_int64),
     "jf_cond_gf_packed_bytes": ([_I32, _I32, ctypes.POINTER(jf_gf_layer)], ctypes.c_int64),
     "jf_cond_gf_pack_f32": ([_P, _I64, _P, _I32, _I32, _I32, ctypes.POINTER(jf_gf_layer), _P, _P], ctypes.c_int),
@@ -502,6 +505,23 @@ def linear(inp, weight, bias=None, act=0, out=None):
     _launch("jf_linear" + suf, "K%d_N%d" % (K, N),
             (_ptr(inp), inp.stride(0), _ptr(weight), weight.stride(0), _ptr(bias), B, K, N, act, _ptr(out), out.stride(0)), dev)
     return out
+
+
+def linear_wgrad(g, inp, want_bias=True):
+    """(g^T @ inp (N, K), g.sum(0) (N) or None): the batch-reducing products of a dense layer's backward, split over the grid (jf_linear_wgrad);
+    K > 128 goes to the library GEMM."""
+    dev = require_device(g, inp)
+    g = _rowmajor(g)
+    inp = _rowmajor(inp)
+    B, N = g.shape
+    K = inp.shape[1]
+    if K > 128 or B == 0:
+        return g.t() @ inp, (g.sum(0) if want_bias else None)
+    S = int(getattr(lib(), "jf_linear_wgrad_splits" + _suffix(g))(B, N))
+    pw = torch.empty((S, N, K), dtype=g.dtype, device=g.device)
+    pb = torch.empty((S, N), dtype=g.dtype, device=g.device) if want_bias else None
+    _launch("jf_linear_wgrad" + _suffix(g), "K%d_N%d" % (K, N), (_ptr(g), g.stride(0), _ptr(inp), inp.stride(0), B, K, N, _ptr(pw), _ptr(pb)), dev)
+    return (pw.sum(0) if S > 1 else pw[0]), (None if pb is None else (pb.sum(0) if S > 1 else pb[0]))
 
 
 def conditioning_rows(segments, B, dtype, device):

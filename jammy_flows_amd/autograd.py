@@ -4,8 +4,9 @@ examples/jammy_flows.py:381-412, docs/source/usage/training.rst:24-44).
 Every Function's forward is the SAME kernel launch the inference path uses; nothing but the inputs is saved.  Backward:
   * g-layer chains: one hand-written HIP launch (jf_gf_chain_inv_bwd_*, csrc/gf_bwd_kernels.hip) that re-runs the chain and returns the
     gradient of the targets and of the parameter row block -- (B, P) for per-sample blocks, partial sums for permanent parameters;
-  * dense layers: the three products of a linear layer's backward (g W, g^T x, column sums) are plain GEMMs and go to rocBLAS through
-    torch.matmul; the tanh derivative is applied to the saved activation;
+  * dense layers: g W (row-parallel) is a plain library GEMM (torch.matmul); the two products that reduce over the BATCH (g^T x, column sums)
+    run in jf_linear_wgrad (csrc/wgrad_kernels.hip: the batch split over the grid -- the library's output-tiled GEMM walks 1e5..1e6 rows in a
+    handful of workgroups there, 14 ms per call in float64); the tanh derivative is applied to the saved activation;
   * the fused conditional block (MLP + g layers in one launch) recomputes its parameter block with two dense launches in backward and
     then runs the same two steps.
 """
@@ -36,9 +37,10 @@ class LinearFn(torch.autograd.Function):
             g = g * (1.0 - out * out)
         g = g.contiguous()
         g_inp = g @ weight if ctx.needs_input_grad[0] else None
-        g_w = g.t() @ inp if ctx.needs_input_grad[1] else None
-        g_b = g.sum(0) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
-        return g_inp, g_w, g_b, None
+        g_w = g_b = None
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            g_w, g_b = _hip.linear_wgrad(g, inp, want_bias=ctx.has_bias and ctx.needs_input_grad[2])
+        return g_inp, (g_w if ctx.needs_input_grad[1] else None), g_b, None
 
 
 def linear(inp, weight, bias=None, act=0):
@@ -93,12 +95,10 @@ class CondBlockFn(torch.autograd.Function):
         g_x, g_p = _hip.gf_chain_inv_bwd(x, params, layer_array, n_layers, D, g_xout, g_ld, g_blp, status=None)
         del params
         need = ctx.needs_input_grad
-        g_w2 = g_p.t() @ h if need[3] else None
-        g_b2 = g_p.sum(0) if need[4] else None
+        g_w2, g_b2 = _hip.linear_wgrad(g_p, h, want_bias=need[4]) if (need[3] or need[4]) else (None, None)
         g_h = (g_p @ w2) * (1.0 - h * h)
         del g_p
-        g_w1 = g_h.t() @ inp if need[1] else None
-        g_b1 = g_h.sum(0) if need[2] else None
+        g_w1, g_b1 = _hip.linear_wgrad(g_h, inp, want_bias=need[2]) if (need[1] or need[2]) else (None, None)
         g_inp = g_h @ w1 if need[0] else None
         return (g_inp, g_w1, g_b1, g_w2, g_b2, g_x, g_ld if ctx.has[0] else None, g_blp if ctx.has[1] else None, None, None, None, None, None)
 

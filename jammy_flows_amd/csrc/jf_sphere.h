@@ -7,6 +7,7 @@
 #pragma once
 #include "jf_common.h"
 #include "jf_math.h"
+#include "jf_dual.h"
 
 namespace jf {
 
@@ -39,13 +40,25 @@ template <typename T> __device__ __forceinline__ T interval_to_real_line(T x, T 
     return r;
 }
 
+// ---- azimuth of (x, y) in [0, 2 pi): acos(x / rho), mirrored for y < 0 -- the reference's formula (sphere_base.py:260-262, 275-280), kept for
+// value parity.  Its derivative, though, is taken from the geometry, d phi = (x dy - y dx) / rho^2, not from acos': within ~3e-4 (float32;
+// 1.5e-8 float64) of phi = 0 or pi the argument rounds to exactly +-1, acos' is infinite there and one such row (2e-4 of uniformly drawn
+// float32 rows) would turn every gradient of a training step into NaN although the map is perfectly smooth at those points.
+template <typename T> __device__ __forceinline__ T azimuth(T x, T y) {
+    const T rho = M<T>::sqrt(x * x + y * y);
+    T arg = rho == T(0) ? T(1) : x / rho;
+    arg = arg > T(1) ? T(1) : (arg < T(-1) ? T(-1) : arg);
+    const T a = M<T>::acos(arg);
+    return y < T(0) ? M<T>::TWO_PI - a : a;
+}
+template <typename T> __device__ __forceinline__ Dual<T> azimuth(Dual<T> x, Dual<T> y) {
+    const T r2 = x.v * x.v + y.v * y.v;
+    return Dual<T>(azimuth<T>(x.v, y.v), r2 > T(0) ? (x.v * y.d - y.v * x.d) / r2 : T(0));
+}
+
 // ---- S1 <-> embedding
 template <typename T> __device__ __forceinline__ void s1_to_eucl(T phi, T (&e)[3]) { e[0] = M<T>::cos(phi); e[1] = M<T>::sin(phi); }
-template <typename T> __device__ __forceinline__ T eucl_to_s1(const T (&e)[3]) {                        // sphere_base.py:248-265
-    const T r = M<T>::sqrt(e[0] * e[0] + e[1] * e[1]);
-    const T a = M<T>::acos(e[0] / r);
-    return e[1] < T(0) ? M<T>::TWO_PI - a : a;
-}
+template <typename T> __device__ __forceinline__ T eucl_to_s1(const T (&e)[3]) { return azimuth(e[0], e[1]); }      // sphere_base.py:248-265
 // ---- S2 <-> embedding (log_det: +log sin(theta) to the embedding, -log sin(theta) back; sphere_base.py:266-282, 313-332)
 template <typename T> __device__ __forceinline__ void s2_to_eucl(T theta, T phi, T (&e)[3], T& ld) {
     theta = safe_angle_pi(theta);
@@ -58,10 +71,7 @@ template <typename T> __device__ __forceinline__ void s2_to_eucl(T theta, T phi,
 template <typename T> __device__ __forceinline__ void eucl_to_s2(const T (&e)[3], T& theta, T& phi, T& ld) {
     theta = safe_angle_pi(M<T>::acos(e[2] / M<T>::sqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2])));
     ld -= M<T>::log(M<T>::sin(theta));
-    T arg = e[0] / M<T>::sqrt(e[0] * e[0] + e[1] * e[1]);
-    arg = arg > T(1) ? T(1) : (arg < T(-1) ? T(-1) : arg);
-    const T a = M<T>::acos(arg);
-    phi = e[1] < T(0) ? M<T>::TWO_PI - a : a;
+    phi = azimuth(e[0], e[1]);
 }
 
 // ---- charts of the first layer of a sphere block
@@ -90,9 +100,7 @@ template <typename T> __device__ __forceinline__ void s2_to_plane(T theta, T phi
 }
 template <typename T> __device__ __forceinline__ void plane_to_s2(const T (&p)[3], T& theta, T& phi, T& ld) {   // sphere_base.py:569-592, 371-399
     const T r = M<T>::sqrt(p[0] * p[0] + p[1] * p[1]);
-    const T arg = r == T(0) ? T(1) : p[0] / r;
-    const T a = M<T>::acos(arg);
-    phi = p[1] < T(0) ? M<T>::TWO_PI - a : a;
+    phi = azimuth(p[0], p[1]);
     theta = safe_angle_pi(M<T>::acos(T(1) - T(2) * M<T>::exp(T(-0.5) * r * r)));
     ld += M<T>::log(T(1) - M<T>::cos(theta)) - M<T>::log(M<T>::sin(theta));
 }

@@ -1,0 +1,132 @@
+// Weight / bias gradient of a dense layer:  g_W (N, K) = sum_b g[b, :]^T in[b, :],   g_b (N) = sum_b g[b, :]   (B rows, B >> N, K).
+//
+// This is the one product of a linear layer's backward that reduces over the BATCH: an (N x B) (B x K) GEMM whose output is tiny (C5: 1224 x 8,
+// C3: 548 x 128) and whose inner dimension is 1e5..1e6.  rocBLAS picks a 128 x 128 output tiling for it, i.e. a handful of workgroups walking
+// the whole batch serially: 14 ms per call in float64 at 2^17 rows, 8 calls per C5 training step (profiles/r02_train.md).  Here the batch is
+// split over the grid: wave (n-tile, s) reduces rows [s Bc, (s+1) Bc) of a 32..64-column tile of g against all K <= 128 input columns into
+// partials[s] (N, K) / bias_partials[s] (N); the caller adds the few partial slabs (deterministic: no atomics).
+//
+// On the matrix cores (f32 32x32x2 / f64 16x16x4): 2.9e11 flop for C3 at 2^20 rows would be 3.7 ms on the VALU, 1.9 ms at the f32 MFMA peak.
+// Algorithmic bytes = s (B N + ceil(N / 64) B K + S N K): g is read once, `in` once per n-tile.
+#include "jf_common.h"
+#include "jf_mfma.h"
+
+namespace jf {
+
+// One wave per workgroup.  The wave owns NA x MT consecutive columns n of g (MFMA A operand: A[m = n][slot = row]) and all K <= KT x MT input
+// columns (B operand: B[slot = row][n = k]); every MFMA step consumes KS rows of the chunk (f32: 32x32x2, f64: 16x16x4).  Both operand loads are
+// coalesced row segments (lane -> consecutive column).  D[m][n] = g_W[n0 + row_of(reg, lane)][k0 + lane % MT]: stores are coalesced along k.
+template <typename T, int NA, int KT>
+__global__ void __launch_bounds__(64) wgrad_kernel(const T* __restrict__ g, int64_t gs, const T* __restrict__ in, int64_t is, int64_t B, int K, int N,
+                                                   int64_t rows_per_split, T* __restrict__ pw, T* __restrict__ pb) {
+    using MM = Mfma<T>;
+    constexpr int MT = MM::MT, KS = MM::KS;
+    const int lane = threadIdx.x, c = lane % MT, slot = lane / MT;
+    const int n0 = blockIdx.x * NA * MT;
+    const int64_t b0 = (int64_t)blockIdx.y * rows_per_split;
+    const int64_t b1 = b0 + rows_per_split < B ? b0 + rows_per_split : B;
+    int nidx[NA], kidx[KT];
+#pragma unroll
+    for (int a = 0; a < NA; ++a) { const int n = n0 + a * MT + c; nidx[a] = n < N ? n : N - 1; }
+#pragma unroll
+    for (int t = 0; t < KT; ++t) { const int k = t * MT + c; kidx[t] = k < K ? k : K - 1; }
+    typename MM::Acc acc[NA][KT];
+#pragma unroll
+    for (int a = 0; a < NA; ++a)
+#pragma unroll
+        for (int t = 0; t < KT; ++t)
+#pragma unroll
+            for (int r = 0; r < MM::NREG; ++r) acc[a][t][r] = T(0);
+    T bsum[NA];
+#pragma unroll
+    for (int a = 0; a < NA; ++a) bsum[a] = T(0);
+    for (int64_t b = b0; b < b1; b += KS) {
+        const int64_t row = b + slot;
+        const bool valid = row < b1;
+        const int64_t rr = valid ? row : b1 - 1;
+        T av[NA], bv[KT];
+#pragma unroll
+        for (int a = 0; a < NA; ++a) av[a] = g[rr * gs + nidx[a]];
+#pragma unroll
+        for (int t = 0; t < KT; ++t) bv[t] = in[rr * is + kidx[t]];
+#pragma unroll
+        for (int a = 0; a < NA; ++a) { av[a] = valid ? av[a] : T(0); bsum[a] += av[a]; }
+#pragma unroll
+        for (int a = 0; a < NA; ++a)
+#pragma unroll
+            for (int t = 0; t < KT; ++t) acc[a][t] = MM::mma(av[a], bv[t], acc[a][t]);
+    }
+    T* slab = pw + (int64_t)blockIdx.y * N * K;
+#pragma unroll
+    for (int a = 0; a < NA; ++a)
+#pragma unroll
+        for (int t = 0; t < KT; ++t) {
+            const int k = t * MT + c;
+#pragma unroll
+            for (int r = 0; r < MM::NREG; ++r) {
+                const int n = n0 + a * MT + MM::row_of(r, lane);
+                if (n < N && k < K) slab[(int64_t)n * K + k] = acc[a][t][r];
+            }
+        }
+    if (pb != nullptr) {
+#pragma unroll
+        for (int a = 0; a < NA; ++a) {
+            T v = bsum[a];
+            for (int off = MT; off < 64; off <<= 1) v += __shfl_xor(v, off);        // the KS slots of a column sit MT lanes apart
+            const int n = n0 + a * MT + c;
+            if (slot == 0 && n < N) pb[(int64_t)blockIdx.y * N + n] = v;
+        }
+    }
+}
+
+template <typename T> static int wgrad_na(int32_t N) { return N > Mfma<T>::MT ? 2 : 1; }
+
+template <typename T> static int64_t wgrad_splits_t(int64_t B, int32_t N) {
+    const int per_wave = wgrad_na<T>(N) * Mfma<T>::MT;
+    const int64_t tiles = (N + per_wave - 1) / per_wave;
+    int64_t s = (2048 + tiles - 1) / tiles;                    // ~2 waves per SIMD over the n-tiles x splits grid
+    const int64_t max_s = (B + 127) / 128;                      // at least 128 rows per split
+    if (s > max_s) s = max_s;
+    if (s > 65535) s = 65535;
+    return s < 1 ? 1 : s;
+}
+
+template <typename T, int NA, int KT>
+static void wgrad_go(const T* g, int64_t gs, const T* in, int64_t is, int64_t B, int32_t K, int32_t N, int64_t S, T* pw, T* pb, hipStream_t st) {
+    const int64_t rps = (((B + S - 1) / S) + Mfma<T>::KS - 1) / Mfma<T>::KS * Mfma<T>::KS;
+    hipLaunchKernelGGL((wgrad_kernel<T, NA, KT>), dim3((unsigned)((N + NA * Mfma<T>::MT - 1) / (NA * Mfma<T>::MT)), (unsigned)S), dim3(64), 0, st, g, gs, in,
+                       is, B, K, N, rps, pw, pb);
+}
+
+template <typename T>
+static int wgrad(const T* g, int64_t gs, const T* in, int64_t is, int64_t B, int32_t K, int32_t N, T* pw, T* pb, void* stream) {
+    if (!g || !in || !pw || B < 0 || K < 1 || N < 1) return JF_ERR_BADARG;
+    if (K > 128) return JF_ERR_UNSUPPORTED;
+    if (B == 0) return JF_OK;
+    const int64_t S = wgrad_splits_t<T>(B, N);
+    hipStream_t st = (hipStream_t)stream;
+    const int kt = (K + Mfma<T>::MT - 1) / Mfma<T>::MT;        // f32: 1..4, f64: 1..8
+    const bool two = wgrad_na<T>(N) == 2;
+#define JF_WG(KT_)                                                                   \
+    { if (two) wgrad_go<T, 2, KT_>(g, gs, in, is, B, K, N, S, pw, pb, st);           \
+      else wgrad_go<T, 1, KT_>(g, gs, in, is, B, K, N, S, pw, pb, st); }
+    if (kt <= 1) JF_WG(1)
+    else if (kt <= 2) JF_WG(2)
+    else if (kt <= 4) JF_WG(4)
+    else { if constexpr (sizeof(T) == 8) JF_WG(8) else return JF_ERR_UNSUPPORTED; }
+#undef JF_WG
+    return check_launch();
+}
+
+}  // namespace jf
+
+extern "C" {
+int64_t jf_linear_wgrad_splits_f32(int64_t B, int32_t N) { return jf::wgrad_splits_t<float>(B, N); }
+int64_t jf_linear_wgrad_splits_f64(int64_t B, int32_t N) { return jf::wgrad_splits_t<double>(B, N); }
+int jf_linear_wgrad_f32(const float* g, int64_t gs, const float* in, int64_t is, int64_t B, int32_t K, int32_t N, float* pw, float* pb, void* s) {
+    return jf::wgrad<float>(g, gs, in, is, B, K, N, pw, pb, s);
+}
+int jf_linear_wgrad_f64(const double* g, int64_t gs, const double* in, int64_t is, int64_t B, int32_t K, int32_t N, double* pw, double* pb, void* s) {
+    return jf::wgrad<double>(g, gs, in, is, B, K, N, pw, pb, s);
+}
+}
