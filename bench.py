@@ -208,10 +208,13 @@ def committed_traffic():
 
 
 # device-kernel name (as rocprofv3 reports it) of a (C entry point, tag) pair of the host-side timer
-KERNEL_OF = {"jf_cond_gf_chain_inv_split_f32": "cond_gf_split_kernel", "jf_cond_gf_chain_inv_f32": "cond_gf_chain_kernel<float",
+KERNEL_OF = {"jf_cond_f_chain_inv_f32": "cond_mchain_kernel<float, jf::FFam", "jf_cond_f_chain_inv_f64": "cond_mchain_kernel<double, jf::FFam",
+             "jf_conditioning_rows_f32": "conditioning_kernel<float", "jf_conditioning_rows_f64": "conditioning_kernel<double",
+             "jf_v_chain_inv_f64": "mchain_kernel<double, jf::VFam", "jf_amlp2_f64": "amlp_gf_kernel<double, 8, 8, true>",
+             "jf_cond_gf_chain_inv_split_f32": "cond_gf_split_kernel", "jf_cond_gf_chain_inv_f32": "cond_gf_chain_kernel<float",
              "jf_cond_gf_chain_inv_f64": "cond_gf_chain_kernel<double", "jf_mlp2_f32": "mlp2_kernel<float", "jf_mlp2_f64": "mlp2_kernel<double",
              "jf_gf_chain_inv_f32": "gf_chain_kernel<float", "jf_gf_chain_inv_f64": "gf_chain_kernel<double",
-             "jf_amlp_gf_chain_inv_f64": "amlp_gf_kernel"}
+             "jf_amlp_gf_chain_inv_f64": "amlp_gf_kernel<double, 8, 8, false>"}
 
 
 def traffic_of(traffic, kname, ktag):
@@ -427,6 +430,15 @@ def main():
                 mf.update({"arithmetic": "3-way split bf16, 6 MFMA passes, f32 accumulate", "executed_bf16_TFLOPs": executed * B / secs / 1e12,
                            "frac_of_bf16_peak": executed * B / secs / 1e12 / MFMA_BF16_PEAK_TFLOPS,
                            "frac_of_f32_mfma_peak_equivalent": tf / MFMA_F32_PEAK_TFLOPS})
+            elif kname.startswith("jf_amlp_gf_chain"):
+                # low-rank factors on the VALU: the kernel never forms the dense product, and (f64) the matrix rate of MI355X equals the vector rate
+                K1, H, N, D = (int(t[1:]) for t in ktag.split("_")[:4])
+                r = int(ktag.split("_")[4][1:])
+                executed = 2 * (r * K1 + H * r + r * H + N * r)             # V1 c, U1 t1, V2 h, U2 t2 per row (23 936 for C5 block 0)
+                mf = {"dense_equivalent_TFLOPs": tf, "dense_equivalent_flops_per_launch": flops_per_row * B,
+                      "arithmetic": "%s VALU FMAs on the low-rank factors (rank %d); no MFMA instruction is issued" % (main_dt, r),
+                      "executed_flops_per_launch": executed * B, "executed_TFLOPs": executed * B / secs / 1e12,
+                      "frac_of_%s_vector_peak" % main_dt: executed * B / secs / 1e12 / (MFMA_F64_PEAK_TFLOPS if main_dt == "f64" else MFMA_F32_PEAK_TFLOPS)}
             elif main_dt == "f32":
                 mf.update({"arithmetic": "exact f32 MFMA", "frac_of_f32_mfma_peak": tf / MFMA_F32_PEAK_TFLOPS})
             else:

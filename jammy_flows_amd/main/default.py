@@ -1036,13 +1036,49 @@ class pdf(nn.Module):
         self._report_status(status)
         return x, base_ret, -log_det + log_gauss, log_gauss
 
+    def _differentiable_sample(self, conditional_input=None, predefined_target_input=None, samplesize=1, seed=None, amortization_parameters=None,
+                               force_embedding_coordinates=False, force_intrinsic_coordinates=False, dtype=None, device=None, only_last=False):
+        """samples that carry gradients with respect to the pdf's parameters and the conditional input (the reference
+        differentiates through its Newton iterations, bisection_n_newton.py:74-93).
+
+        Here the sample x* = F_theta^-1(z) comes from the sampling kernels without a graph, and the gradient from the implicit-function
+        theorem, written as ONE differentiable Newton correction at the solution:
+
+            x = x* - J^-1 (F_theta(x*) - z),        J = dF/dx at x* (held constant)
+
+        Its value is x* (the bracket vanishes to solver precision), its derivative -J^-1 dF/dtheta is exactly d x*/d theta.  F_theta(x*) is the
+        log-prob direction with a graph (the backward kernels of autograd.py); the rows of J are D_total vector-Jacobian products through those
+        same kernels; the (B, D, D) solve is batched LAPACK.  log_prob gets the matching first-order term: log p_theta(x*) + <grad_x log p, x - x*>."""
+        if force_embedding_coordinates or only_last:
+            raise NotImplementedError("differentiable sampling works in the default (intrinsic) coordinates of the full pdf")
+        with torch.no_grad():
+            x_star, base_ret, _, logp_base = self._obtain_sample(conditional_input=conditional_input, predefined_target_input=predefined_target_input,
+                                                                 samplesize=samplesize, seed=seed, amortization_parameters=amortization_parameters,
+                                                                 force_intrinsic_coordinates=force_intrinsic_coordinates, dtype=dtype, device=device)
+            z = predefined_target_input if predefined_target_input is not None else base_ret
+        x0 = x_star.detach().clone().requires_grad_(True)
+        logp_x, _, y = self._forward_with_grad(x0, conditional_input, amortization_parameters, False, False, False)
+        D = y.shape[1]
+        assert D == x0.shape[1], "differentiable sampling needs a square Jacobian (intrinsic coordinates)"
+        rows = [torch.autograd.grad(y[:, i].sum(), x0, retain_graph=True)[0] for i in range(D)]
+        J = torch.stack(rows, dim=1)                                              # J[b, i, j] = d y_i / d x_j
+        (g_logp,) = torch.autograd.grad(logp_x.sum(), x0, retain_graph=True)
+        delta = torch.linalg.solve(J, (y - z.detach()).unsqueeze(-1)).squeeze(-1)
+        x = x0.detach() - delta
+        logp = logp_x - (g_logp * delta).sum(dim=1)
+        return x, base_ret, logp, logp_base
+
     def sample(self, conditional_input=None, samplesize=1, seed=None, allow_gradients=False, amortization_parameters=None,
                force_embedding_coordinates=False, force_intrinsic_coordinates=False, failsafe_crosscheck_tolerance=None, dtype=None,
                device=None, only_last=False):
         """draw samples -> (x, base, log_prob, log_prob_base)  (:1300-1371)."""
         assert not self.use_as_passthrough_instead_of_pdf
-        if allow_gradients:
-            raise NotImplementedError("differentiable sampling needs the backward kernels (SURVEY.md 8f); not available in this version")
+        if allow_gradients and torch.is_grad_enabled():
+            return self._differentiable_sample(conditional_input=conditional_input, samplesize=samplesize, seed=seed,
+                                               amortization_parameters=amortization_parameters,
+                                               force_embedding_coordinates=force_embedding_coordinates,
+                                               force_intrinsic_coordinates=force_intrinsic_coordinates, device=device, dtype=dtype,
+                                               only_last=only_last)
         with torch.no_grad():
             return self._obtain_sample(conditional_input=conditional_input, seed=seed, samplesize=samplesize,
                                        amortization_parameters=amortization_parameters,
