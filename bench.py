@@ -344,6 +344,7 @@ def main():
     results = {}
     kernel_table = None
     two_launch = None
+    graph_replay = None
     for dname in order:
         dtype = dtypes[dname]
         pdf = helpers.build_product(fx, dtype, dev)
@@ -378,6 +379,25 @@ def main():
         results[dname] = dict(dt=dt, evals_per_s=total_rows * args.steps / dt, ms_per_step=1e3 * dt / args.steps, err=err)
         if timer is not None:
             kernel_table = timer.summary()
+            if rank == 0 and world == 1:
+                # for reference, outside the timed region: the SAME step replayed from a HIP graph (pdf.graphed_forward): one graph launch instead
+                # of the step's kernel launches + host-side preparation; results must be bit-identical to the eager step just timed
+                try:
+                    gf_ = pdf.graphed_forward(x, conditional_input=c)
+                    for _ in range(3):
+                        gf_.graph.replay()
+                    torch.cuda.synchronize()
+                    tg0 = time.perf_counter()
+                    for _ in range(args.steps):
+                        gf_.graph.replay()
+                    torch.cuda.synchronize()
+                    tg = time.perf_counter() - tg0
+                    graph_replay = {"ms_per_step": 1e3 * tg / args.steps, "value": B * args.steps / tg,
+                                    "bit_identical_to_timed_step": bool(torch.equal(gf_.out[0], logp)),
+                                    "note": "pdf.graphed_forward: the step captured once in a HIP graph, replayed (measured after the timed region)"}
+                    del gf_
+                except Exception as e:                 # noqa: BLE001 -- reported, never hidden
+                    graph_replay = {"error": "%s: %s" % (type(e).__name__, e)}
             if rank == 0 and pdf.fuse_conditional_blocks and args.workload == "c3":
                 # for reference, outside the timed region: the same steps with the conditional block as two launches (jf_mlp2 + jf_gf_chain_inv),
                 # whose kernels have clean single-roof accountings (MFMA for the MLP, HBM for the g-chain reading the materialised block)
@@ -466,6 +486,8 @@ def main():
         if "f64" in results and main_dt != "f64":
             r64 = results["f64"]
             line["float64"] = {"value": r64["evals_per_s"], "ms_per_step": r64["ms_per_step"], "max_abs_dlogp_vs_f64_oracle": r64["err"], "bar": 1e-4}
+        if graph_replay is not None:
+            line["hip_graph_replay"] = graph_replay
         if two_launch is not None:
             tb = two_launch["table"]
             ml = tb.get(("jf_mlp2_f32", "K7_H128_N548"))

@@ -39,7 +39,8 @@ template <> struct M<float> {
     static __device__ __forceinline__ float atan2(float y, float x) { return atan2f(y, x); }
     static __device__ __forceinline__ float tanh(float x) { return tanhf(x); }
     // 1 - 2/(e^{2x}+1) on v_exp_f32 / v_rcp_f32: absolute error ~1e-7 (relative accuracy is lost only where |tanh| < 1e-3), saturates cleanly
-    static __device__ __forceinline__ float tanh_fast(float x) { return 1.0f - 2.0f * __frcp_rn(__expf(2.0f * x) + 1.0f); }
+    // (v_rcp_f32 directly: __frcp_rn expands to the 10-instruction correctly-rounded division sequence, 32 times per lane and row tile)
+    static __device__ __forceinline__ float tanh_fast(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(__expf(2.0f * x) + 1.0f); }
     static __device__ __forceinline__ float abs(float x) { return fabsf(x); }
     static __device__ __forceinline__ float max(float a, float b) { return fmaxf(a, b); }
     static __device__ __forceinline__ float min(float a, float b) { return fminf(a, b); }

@@ -150,6 +150,7 @@ class pdf(nn.Module):
         # asynchronously and raise at the next call or in flush_status() (saves one host-device round trip per call; throughput loops
         # such as bench.py opt into it and flush inside their timed region).  False: never.
         self.check_status = True
+        self._capture_status = None
         self.force_fused_manifold_blocks = False     # tests: run jf_cond_<fam>_chain_inv also where the two-launch path is the faster default
         # conditional e-blocks (Linear-tanh-Linear MLP + g layers, D in {3,4}, float32) as ONE launch with the parameter block kept on chip
         # (jf_cond_gf_chain_inv): +9 % on the C3 step against jf_mlp2 + jf_gf_chain_inv.  False selects the two-launch path.
@@ -792,13 +793,26 @@ class pdf(nn.Module):
             return self._forward_with_grad(x, conditional_input, amortization_parameters, force_embedding_coordinates,
                                            force_intrinsic_coordinates, only_last)
         with torch.no_grad():
-            self._poll_status()                          # surfaces problems of earlier calls whose status has arrived meanwhile
-            status = _hip.new_status(x.device) if self.check_status else None
+            capturing = self._capture_status is not None
+            if capturing:                                # inside graphed_forward(): a static status buffer, examined by the replaying side
+                status = self._capture_status.zero_()
+            else:
+                self._poll_status()                      # surfaces problems of earlier calls whose status has arrived meanwhile
+                status = _hip.new_status(x.device) if self.check_status else None
             base, log_det, log_pdf = self._inverse_impl(x, None, conditional_input, amortization_parameters, force_embedding_coordinates,
                                                         force_intrinsic_coordinates, only_last, True, status)
             total = log_pdf + log_det
-            self._defer_status(status)
+            if not capturing:
+                self._defer_status(status)
         return total, log_pdf, base
+
+    def graphed_forward(self, x, conditional_input=None, **kwargs):
+        """forward() for inputs of THIS shape captured once in a HIP graph -> callable(x, conditional_input=None, check=True) returning
+        (log_prob, log_prob_base, base).  A replay is one graph launch instead of 4 .. 12 kernel launches + their host-side preparation:
+        what small batches (C1: 4096 rows, launch bound) and serving loops want.  The returned tensors are the graph's static output buffers
+        (overwritten by the next call).  The graph reads the weights through the caches the eager path builds (packed split-bf16 images,
+        flattened permanent rows): capture again after the parameters change."""
+        return GraphedForward(self, x, conditional_input, kwargs)
 
     # =========================================================================================== log-prob direction, differentiable
     def _permanent_row_with_grad(self, layers, like):
@@ -1229,3 +1243,40 @@ class pdf(nn.Module):
         if target.dim() == 1:
             res = res.squeeze(0)
         return res, log_det
+
+
+class GraphedForward:
+    """pdf.forward captured in a HIP graph for one input shape (see pdf.graphed_forward)."""
+
+    def __init__(self, pdf, x, conditional_input, kwargs):
+        _hip.require_device(x, conditional_input if isinstance(conditional_input, torch.Tensor) else None)
+        self.pdf = pdf
+        self.x = x.detach().clone()
+        self.cond = None if conditional_input is None else conditional_input.detach().clone()
+        self.kwargs = dict(kwargs)
+        self.status = _hip.new_status(x.device)
+        side = torch.cuda.Stream(device=x.device)
+        side.wait_stream(torch.cuda.current_stream(x.device))
+        with torch.no_grad(), torch.cuda.stream(side):
+            for _ in range(2):          # every lazily built cache (permanent rows, packed images, kernel attributes) exists before the capture
+                pdf.forward(self.x, conditional_input=self.cond, **self.kwargs)
+        torch.cuda.current_stream(x.device).wait_stream(side)
+        pdf.flush_status()
+        self.graph = torch.cuda.CUDAGraph()
+        pdf._capture_status = self.status
+        try:
+            with torch.no_grad(), torch.cuda.graph(self.graph):
+                self.out = pdf.forward(self.x, conditional_input=self.cond, **self.kwargs)
+        finally:
+            pdf._capture_status = None
+
+    def __call__(self, x, conditional_input=None, check=True):
+        if x.shape != self.x.shape or x.dtype != self.x.dtype:
+            raise ValueError("graphed_forward was captured for inputs %s %s, got %s %s" % (tuple(self.x.shape), self.x.dtype, tuple(x.shape), x.dtype))
+        self.x.copy_(x)
+        if self.cond is not None:
+            self.cond.copy_(conditional_input)
+        self.graph.replay()
+        if check and self.pdf.check_status:
+            self.pdf._report_status(self.status)         # one host read-back, raises / warns as the eager path does
+        return self.out

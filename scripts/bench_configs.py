@@ -55,8 +55,8 @@ def timeit(fn, n=5):
     return (time.perf_counter() - t0) / n
 
 
-print("| configuration | rows | log-prob ms | evals/s | sampling ms | samples/s |")
-print("|---|---|---|---|---|---|")
+print("| configuration | rows | log-prob ms | evals/s | HIP-graph replay ms | sampling ms | samples/s |")
+print("|---|---|---|---|---|---|---|")
 for name, dtype, n, label in CONFIGS:
     fx = fixture_io.load(name)
     pdf = helpers.build_product(fx, dtype)
@@ -65,10 +65,12 @@ for name, dtype, n, label in CONFIGS:
     x = torch.from_numpy(x).to(device="cuda", dtype=dtype)
     cond = torch.from_numpy(cond).to(device="cuda", dtype=dtype) if cond is not None else None
     t_lp = timeit(lambda: pdf(x, conditional_input=cond))
+    g = pdf.graphed_forward(x, conditional_input=cond)
+    t_g = timeit(lambda: g(x, conditional_input=cond, check=False), n=20)
     z = torch.randn(n, pdf.total_base_dim, device="cuda", dtype=dtype)
     try:
         t_s = timeit(lambda: pdf._obtain_sample(conditional_input=cond, predefined_target_input=z), n=2)
         s_txt = "%.2f | %.3g" % (1e3 * t_s, n / t_s)
     except Exception as e:            # noqa: BLE001 -- report, do not hide
         s_txt = "%s | -" % type(e).__name__
-    print("| %s | %d | %.3f | %.3g | %s |" % (label, n, 1e3 * t_lp, n / t_lp, s_txt))
+    print("| %s | %d | %.3f | %.3g | %.3f | %s |" % (label, n, 1e3 * t_lp, n / t_lp, 1e3 * t_g, s_txt))

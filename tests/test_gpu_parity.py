@@ -539,3 +539,35 @@ def test_random_configurations_vs_oracle_float64(cfg):
     o_lp, o_lpb, o_base = oracle.forward(x.numpy(), None if cond is None else cond.numpy())[:3]
     assert max_rel(lp, o_lp) < 1e-7
     assert max_rel(base, o_base) < 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,dtype", [("c1_e2_gg", torch.float64), ("c3_e4s2e4", torch.float32), ("c4_i1s1_ro", torch.float32), ("c5_e8s2_ggggv", torch.float64)])
+def test_graphed_forward_replays_the_eager_path(name, dtype):
+    """pdf.graphed_forward: the captured HIP graph returns bit for bit what the eager launches return, for the captured inputs and for new ones,
+    and its status buffer still turns kernel-side problems into the reference's exceptions."""
+    fx = [f for f in ALL_FIXTURES if f.name == name][0]
+    pdf = build_product(fx, dtype)
+    ok = float32_domain_mask(fx) if dtype == torch.float32 else np.ones(fx["x"].shape[0], dtype=bool)
+    keep = torch.from_numpy(np.nonzero(ok)[0]).cuda()
+    x = to_dev(fx["x"], dtype)[keep]
+    cond = to_dev(fx["cond"], dtype)[keep] if fx.get("cond") is not None else None
+    g = pdf.graphed_forward(x, conditional_input=cond)
+    eager = pdf(x, conditional_input=cond)
+    out = g(x, conditional_input=cond)
+    for a, b in zip(out, eager):
+        assert torch.equal(a, b)
+    perm = torch.randperm(x.shape[0], device="cuda", generator=torch.Generator(device="cuda").manual_seed(5))
+    x2 = x[perm].contiguous()
+    c2 = cond[perm].contiguous() if cond is not None else None
+    eager2 = [t.clone() for t in pdf(x2, conditional_input=c2)]
+    out2 = g(x2, conditional_input=c2)
+    for a, b in zip(out2, eager2):
+        assert torch.equal(a, b)
+    with pytest.raises(ValueError):
+        g(x2[:-1], conditional_input=None if c2 is None else c2[:-1])
+    if name == "c4_i1s1_ro":                                      # an interval coordinate outside [0, 1]: the graph's status words must raise like the eager path
+        bad = x2.clone()
+        bad[0, 0] = 1.5
+        with pytest.raises(Exception):
+            g(bad, conditional_input=c2)
