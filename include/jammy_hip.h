@@ -283,6 +283,8 @@ typedef struct jf_f_layer {
     int32_t correlated, corr_hidden, corr_rank, corr_full2;
     int32_t kappa_mode, kappa_clamping; /* JF_F_KAPPA_* (fvm_2d.py:105-139); modes >= JF_F_KAPPA_MU read kappa off the rotation parameters and
                                            the row has no kappa entry */
+    int32_t extra_rotation, reserved;   /* add_extra_rotation_inbetween (fvm_2d.py:381-402, 664-688): a fixed quarter turn that moves the pole
+                                           onto the equator between the kappa step and the nested spline flows */
     double z_sign, min_kappa, identity_region;
     jf_r_layer vertical[JF_MAX_NESTED];
     jf_o_layer circular[JF_MAX_NESTED];

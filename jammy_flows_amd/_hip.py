@@ -65,7 +65,7 @@ JF_MAX_NESTED = 4
 class jf_f_layer(ctypes.Structure):
     _fields_ = [("hh_iter", ctypes.c_int32), ("first", ctypes.c_int32), ("n_vertical", ctypes.c_int32), ("n_circular", ctypes.c_int32),
                 ("correlated", ctypes.c_int32), ("corr_hidden", ctypes.c_int32), ("corr_rank", ctypes.c_int32), ("corr_full2", ctypes.c_int32),
-                ("kappa_mode", ctypes.c_int32), ("kappa_clamping", ctypes.c_int32),
+                ("kappa_mode", ctypes.c_int32), ("kappa_clamping", ctypes.c_int32), ("extra_rotation", ctypes.c_int32), ("reserved", ctypes.c_int32),
                 ("z_sign", ctypes.c_double), ("min_kappa", ctypes.c_double), ("identity_region", ctypes.c_double),
                 ("vertical", jf_r_layer * JF_MAX_NESTED), ("circular", jf_o_layer * JF_MAX_NESTED)]
 

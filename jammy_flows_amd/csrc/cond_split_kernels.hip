@@ -127,70 +127,64 @@ __device__ __forceinline__ float cs_rsum(float v) { return cs_rreduce(v, [](floa
 __device__ __forceinline__ float cs_rmax(float v) { return cs_rreduce(v, [](float a, float b) { return fmaxf(a, b); }); }
 
 // ---------------------------------------------------------------------------------------------------------- mixture on register rows
-// gfg_mixture_impl<float, RAW, FAST> / gfg_mixture_scaled (jf_gf.h) with the lane's parameters in registers P[slot]
-__device__ __forceinline__ MixQ<float> cs_mixture_scaled(const float (&P)[CS_SLOTS], const CsLayer& o, float x) {
+// gfg_mixture_impl<float, RAW, FAST> / gfg_mixture_scaled (jf_gf.h) with the lane's parameters in registers P[slot].
+// The regulated 1/width and weight of every component and its u_k = (x - mu_k)/w_k are computed ONCE (2 exp + 2 rcp per component); the
+// distance m = min_k |u_k| to the nearest component then decides -- per wave -- which ONE of the two summations runs (1 exp + 1 rcp per
+// component each): the plain linear-space sums, or the sums scaled by e^{m} when some lane sits further than CS_M_SCALED widths from every
+// component (below that the plain sums cannot underflow: cdf, sf >= pi_min sigma(-m) >= 1e-2 e^{-60}, pdf >= that / (2 w_max)).
+// The first version ran the plain pass always and the scaled pass on top of it whenever a lane underflowed, regulating the parameters again
+// in each (7 exp + 7 rcp per component on the benchmark inputs, two thirds of whose rows sit beyond 12 sigma after three layers).
+constexpr float CS_M_SCALED = 60.0f;
+
+__device__ __forceinline__ MixQ<float> cs_mixture(const float (&P)[CS_SLOTS], const CsLayer& o, float x, bool live) {
     using Mf = M<float>;
-    float iw[CS_K], u[CS_K];
-    float m = INFINITY;
+    float iw[CS_K], wk[CS_K], u[CS_K];
+    float m = INFINITY, Nn = 0.f;
 #pragma unroll
     for (int k = 0; k < CS_K; ++k) {
         const float ae = o.inv_wmax + Mf::exp_fast(-P[CS_SLOT_LW + k]);
         iw[k] = ae * Mf::rcp(o.wmin * ae + 1.0f);
+        wk[k] = o.nmin + o.nmax * Mf::rcp(1.0f + Mf::exp_fast(-P[CS_SLOT_LN + k]));
         u[k] = (x - P[CS_SLOT_MEAN + k]) * iw[k];
         m = fminf(m, fabsf(u[k]));
+        Nn += wk[k];
     }
-    const float em = Mf::exp_fast(-m);
-    float Cu = 0.f, Cs = 0.f, Su = 0.f, Ss = 0.f, Ps = 0.f, Nn = 0.f;
+    const float inv = Mf::rcp(Nn);
+    MixQ<float> q;
+    if (!__any(live && m > CS_M_SCALED)) {                         // wave-uniform branch
+        float C = 0.f, S = 0.f, Pd = 0.f;
+#pragma unroll
+        for (int k = 0; k < CS_K; ++k) {
+            const float t = Mf::exp_fast(-fabsf(u[k]));
+            const float hi = Mf::rcp(1.0f + t);
+            const float lo = t * hi;
+            const bool pos = u[k] >= 0.f;
+            C += wk[k] * (pos ? hi : lo);
+            S += wk[k] * (pos ? lo : hi);
+            Pd += wk[k] * hi * lo * iw[k];
+        }
+        C *= inv; S *= inv; Pd *= inv;
+        q.lc = Mf::log_fast(C); q.ls = Mf::log_fast(S); q.lp = Mf::log_fast(Pd);
+        q.cdf = C; q.sf = S;
+        return q;
+    }
+    const float em = Mf::exp_fast(-m);                             // may underflow to 0: the unscaled parts then stand alone
+    float Cu = 0.f, Cs = 0.f, Su = 0.f, Ss = 0.f, Ps = 0.f;
 #pragma unroll
     for (int k = 0; k < CS_K; ++k) {
-        const float wk = o.nmin + o.nmax * Mf::rcp(1.0f + Mf::exp_fast(-P[CS_SLOT_LN + k]));
         const float t = Mf::exp_fast(m - fabsf(u[k]));
         const float hi = Mf::rcp(1.0f + t * em);
-        const float c1 = wk * hi, c2 = c1 * t;
+        const float c1 = wk[k] * hi, c2 = c1 * t;
         if (u[k] >= 0.f) { Cu += c1; Ss += c2; }
         else { Su += c1; Cs += c2; }
         Ps += c2 * hi * iw[k];
-        Nn += wk;
     }
-    const float inv = Mf::rcp(Nn);
     Cu *= inv; Cs *= inv; Su *= inv; Ss *= inv; Ps *= inv;
-    MixQ<float> q;
     q.cdf = Cu + em * Cs;
     q.sf = Su + em * Ss;
     q.lc = Cu > 0.f ? Mf::log_fast(q.cdf) : Mf::log_fast(Cs) - m;
     q.ls = Su > 0.f ? Mf::log_fast(q.sf) : Mf::log_fast(Ss) - m;
     q.lp = Mf::log_fast(Ps) - m;
-    return q;
-}
-
-__device__ __forceinline__ MixQ<float> cs_mixture(const float (&P)[CS_SLOTS], const CsLayer& o, float x, bool live) {
-    using Mf = M<float>;
-    float C = 0.f, S = 0.f, Pd = 0.f, Nn = 0.f;
-#pragma unroll
-    for (int k = 0; k < CS_K; ++k) {
-        const float ae = o.inv_wmax + Mf::exp_fast(-P[CS_SLOT_LW + k]);
-        const float iw = ae * Mf::rcp(o.wmin * ae + 1.0f);
-        const float wk = o.nmin + o.nmax * Mf::rcp(1.0f + Mf::exp_fast(-P[CS_SLOT_LN + k]));
-        const float u = (x - P[CS_SLOT_MEAN + k]) * iw;
-        const float t = Mf::exp_fast(-fabsf(u));
-        const float hi = Mf::rcp(1.0f + t);
-        const float lo = t * hi;
-        const bool pos = u >= 0.f;
-        C += wk * (pos ? hi : lo);
-        S += wk * (pos ? lo : hi);
-        Pd += wk * hi * lo * iw;
-        Nn += wk;
-    }
-    const float inv = Mf::rcp(Nn);
-    C *= inv; S *= inv; Pd *= inv;
-    MixQ<float> q;
-    q.lc = Mf::log_fast(C); q.ls = Mf::log_fast(S); q.lp = Mf::log_fast(Pd);
-    q.cdf = C; q.sf = S;
-    const bool under = live && !(C > Mf::TINY && S > Mf::TINY && Pd > Mf::TINY);
-    if (__any(under)) {                                            // wave-uniform branch
-        const MixQ<float> qs = cs_mixture_scaled(P, o, x);
-        if (under) q = qs;
-    }
     return q;
 }
 

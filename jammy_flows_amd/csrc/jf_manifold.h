@@ -251,6 +251,20 @@ struct FFam {
         const int H = L.corr_hidden, n = corr_out(L);
         return 2 * H + (L.corr_full2 ? n * H : L.corr_rank * (n + H)) + n;
     }
+    // add_extra_rotation_inbetween (fvm_2d.py:381-402, 664-688): e -> M e (sampling) / M^T e (log-prob) with M = [[0,0,1],[0,1,0],[-1,0,0]], taken
+    // through the angle <-> embedding conversions and their log-dets exactly as the reference does
+    template <typename T> static __device__ __forceinline__ void inbetween(T& cos_theta, T& angle, T& ld, bool inverse) {
+        T th = M<T>::acos(cos_theta);
+        ld -= M<T>::log(M<T>::sin(safe_angle_pi<T>(th)));
+        T e[3];
+        s2_to_eucl<T>(th, angle, e, ld);
+        T r[3];
+        if (inverse) { r[0] = -e[2]; r[1] = e[1]; r[2] = e[0]; }
+        else { r[0] = e[2]; r[1] = e[1]; r[2] = -e[0]; }
+        eucl_to_s2<T>(r, th, angle, ld);
+        cos_theta = M<T>::cos(th);
+        ld += M<T>::log(M<T>::sin(safe_angle_pi<T>(th)));
+    }
     // kappa of the von-Mises-Fisher step (fvm_2d.py:105-139, 289-330): from its own parameter (modes 0-2, optionally clamped) or from the
     // length of the layer's rotation parameters ("mu" / "mu_squared" with rotation_mode xyz, "quatvec" / "quatvec_squared" with quaternion)
     static __host__ __device__ int n_kappa(const CLayer& L) { return L.kappa_mode <= JF_F_KAPPA_LOG_BOUNDED ? 1 : 0; }
@@ -331,6 +345,7 @@ struct FFam {
             if (kappa < M<T>::KAPPA_ID) ret = prev;
             ret = safe_cos<T>(ret, M<T>::EPS_COS);
             T angle = x[1];
+            if (L.extra_rotation) inbetween<T>(ret, angle, ld, true);
             const bool inside = (region == T(0)) || ((ret > T(-1) + region) && (ret < T(1) - region));
             if (L.correlated) {                                                             // :406-409: nested i1+s1 passthrough pdf, inverse direction
                 if (inside) {
@@ -425,6 +440,7 @@ struct FFam {
                 }
             }
             }
+            if (L.extra_rotation) inbetween<T>(prev, angle, ld, false);
             ld -= M<T>::log(kappa * zs * prev + kappa / M<T>::tanh(kappa));                   // :698
             T ret = zs * (T(1) + (T(1) / kappa) * M<T>::log(T(0.5) * (T(1) + zs * prev) + (T(0.5) - T(0.5) * zs * prev) * M<T>::exp(T(-2) * kappa)));
             if (kappa < M<T>::KAPPA_ID) ret = prev;

@@ -33,8 +33,6 @@ class fisher_von_mises_2d(sphere_base.sphere_base):
         if dimension != 2:
             raise Exception("2-D Flow")
         assert fisher_parametrization == "split"
-        if add_extra_rotation_inbetween:
-            raise NotImplementedError("f layer option add_extra_rotation_inbetween=1 has no HIP kernel yet")
         if kappa_prediction not in _hip.F_KAPPA_MODES:
             raise Exception("unknown kappa_prediction", kappa_prediction)
         self.z_scaling_factor = -1.0 if inverse_z_scaling else 1.0
@@ -127,7 +125,7 @@ class fisher_von_mises_2d(sphere_base.sphere_base):
                 self.correlated_flow_params = nn.Parameter(torch.randn(1, self.total_num_correlated_params))
         if len(self._vertical) > _hip.JF_MAX_NESTED or len(self._circular) > _hip.JF_MAX_NESTED:
             raise NotImplementedError("at most %d nested vertical / circular layers are supported by the kernel" % _hip.JF_MAX_NESTED)
-        self.add_extra_rotation_inbetween = 0
+        self.add_extra_rotation_inbetween = add_extra_rotation_inbetween
 
     def c_struct(self, first):
         L = _hip.jf_f_layer()
@@ -140,6 +138,7 @@ class fisher_von_mises_2d(sphere_base.sphere_base):
         L.identity_region = float(self.boundary_cos_theta_identity_region)
         L.kappa_mode = _hip.F_KAPPA_MODES[self.kappa_prediction]
         L.kappa_clamping = 1 if self.kappa_clamping else 0
+        L.extra_rotation = 1 if self.add_extra_rotation_inbetween else 0
         for i, l in enumerate(self._vertical):
             L.vertical[i] = l.c_struct(0)
         for i, l in enumerate(self._circular):

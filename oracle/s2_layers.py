@@ -20,8 +20,7 @@ class FLayer(_SphereLayer):
     def __init__(self, dimension, o, first, embedding, nested_factory):
         assert dimension == 2
         self._setup_base(o, first, embedding, n_hh_iter=o["num_householder_iter"])
-        if o["add_extra_rotation_inbetween"]:
-            raise NotImplementedError("oracle: f option add_extra_rotation_inbetween")
+        self.extra_rotation = bool(o["add_extra_rotation_inbetween"])
         self.kappa_prediction = o["kappa_prediction"]
         self.kappa_clamping = o["kappa_clamping"]
         self.own_kappa = self.kappa_prediction in ("direct_log_real_bounded", "softplus_real_bounded", "log_bounded")
@@ -110,6 +109,20 @@ class FLayer(_SphereLayer):
         log_det[mask] = lds
         return x, log_det, b
 
+    _INBETWEEN = np.array([[0.0, 0.0, 1.0], [0.0, 1.0, 0.0], [-1.0, 0.0, 0.0]])        # fvm_2d.py:392, 679
+
+    def _inbetween(self, cos_theta, angle, log_det, inverse):
+        """add_extra_rotation_inbetween (fvm_2d.py:381-402 inverse with the transposed matrix, :664-688 forward): the pole moves onto the
+        equator between the kappa step and the nested spline flows"""
+        th = np.arccos(cos_theta)
+        log_det = log_det - np.log(np.sin(mf.safe_angle_within_pi(th[:, 0])))
+        comb, log_det = mf.spherical_to_eucl(np.concatenate([th, angle], axis=1), log_det, 2)
+        m = self._INBETWEEN.T if inverse else self._INBETWEEN
+        comb = comb @ m.T
+        comb, log_det = mf.eucl_to_spherical(comb, log_det, 2)
+        log_det = log_det + np.log(np.sin(mf.safe_angle_within_pi(comb[:, 0])))
+        return np.cos(comb[:, :1]), comb[:, 1:], log_det
+
     def _core_inverse(self, x, log_det, params):
         """fisher_von_mises_2d._inv_flow_mapping (fvm_2d.py:273-500)."""
         bins = []
@@ -127,6 +140,8 @@ class FLayer(_SphereLayer):
         log_det = log_det + ld_upd
         ret = mf.safe_costheta(ret)
         angle = x[:, 1:]
+        if self.extra_rotation:
+            ret, angle, log_det = self._inbetween(ret, angle, log_det, True)
         mask = None
         if self.region != 0.0:
             mask = ((ret > (-1.0 + self.region)) & (ret < (1.0 - self.region)))[:, 0]
@@ -178,6 +193,8 @@ class FLayer(_SphereLayer):
                 cp = np.broadcast_to(circ, (prev.shape[0], circ.shape[1])) * sc
                 angle, log_det, b = self._masked(self.circular, "all_layer_forward", angle, log_det, cp, mask)
                 bins += b
+        if self.extra_rotation:
+            prev, angle, log_det = self._inbetween(prev, angle, log_det, False)
         log_det = log_det - np.log(kappa * self.zs * prev + kappa / np.tanh(kappa))[:, 0]
         ret = self.zs * (1.0 + (1.0 / kappa) * np.log(0.5 * (1.0 + self.zs * prev) + (0.5 - 0.5 * self.zs * prev) * np.exp(-2.0 * kappa)))
         ret = np.where(kappa < 1e-8, prev, ret)
@@ -323,6 +340,20 @@ class VLayer(_SphereLayer):
 
     def _pp(self, params):
         return params.reshape(params.shape[0], self.npp, self.nc)
+
+    _INBETWEEN = np.array([[0.0, 0.0, 1.0], [0.0, 1.0, 0.0], [-1.0, 0.0, 0.0]])        # fvm_2d.py:392, 679
+
+    def _inbetween(self, cos_theta, angle, log_det, inverse):
+        """add_extra_rotation_inbetween (fvm_2d.py:381-402 inverse with the transposed matrix, :664-688 forward): the pole moves onto the
+        equator between the kappa step and the nested spline flows"""
+        th = np.arccos(cos_theta)
+        log_det = log_det - np.log(np.sin(mf.safe_angle_within_pi(th[:, 0])))
+        comb, log_det = mf.spherical_to_eucl(np.concatenate([th, angle], axis=1), log_det, 2)
+        m = self._INBETWEEN.T if inverse else self._INBETWEEN
+        comb = comb @ m.T
+        comb, log_det = mf.eucl_to_spherical(comb, log_det, 2)
+        log_det = log_det + np.log(np.sin(mf.safe_angle_within_pi(comb[:, 0])))
+        return np.cos(comb[:, :1]), comb[:, 1:], log_det
 
     def _core_inverse(self, x, log_det, params):
         """exponential_map_s2._inv_flow_mapping (exponential_map_s2.py:446-487)."""

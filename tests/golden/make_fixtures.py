@@ -154,6 +154,8 @@ CASES = [
                                                                           kappa_prediction="quatvec_squared")})),
     dict(name="f_s2_kappa_logb_clamp", pdf="s2", flow="f", perturb=0.5,
          kwargs=dict(options_overwrite={"f": {"kappa_prediction": "log_bounded", "kappa_clamping": 1, "rotation_mode": "quaternion"}})),
+    dict(name="f_s2_extra_rot", pdf="s2", flow="ff", mlp_scale=300.0,
+         kwargs=dict(conditional_input_dim=2, options_overwrite={"f": dict(_f_splines()["f"], add_extra_rotation_inbetween=1)})),
     dict(name="f_s2_emb", pdf="s2", flow="f", mlp_scale=1000.0, embedding=True, kwargs=dict(conditional_input_dim=2)),
     dict(name="v_s2", pdf="s2", flow="v", B=96),
     dict(name="v_s2_cond_vv", pdf="s2", flow="vv", mlp_scale=300.0, B=96, kwargs=dict(conditional_input_dim=2)),
