@@ -291,7 +291,7 @@ typedef struct jf_f_layer {
 } jf_f_layer;
 /* 'v' exponential map on S2, float64 only (exponential_map_s2.py:248-528, bisection_n_newton.py:330-465);
  * row: [householder hh_iter*3][(mu_x,mu_y,mu_z,log-w[,log-beta]) as (n_pot, nc)] */
-enum { JF_V_LINEAR = 0, JF_V_QUADRATIC = 1, JF_V_EXPONENTIAL = 2 };
+enum { JF_V_LINEAR = 0, JF_V_QUADRATIC = 1, JF_V_EXPONENTIAL = 2, JF_V_SPLINES = 3 /* rows: mu 3, log-w, 10 widths, 10 heights, 11 derivatives */ };
 typedef struct jf_v_layer { int32_t num_components, exp_map_type, natural_direction, hh_iter, max_newton_iter, first; } jf_v_layer;
 
 /* base-class steps only: optional Householder rotation in embedding space + optional first-layer chart; kind 0 interval, 1 S1, 2 S2

@@ -73,7 +73,7 @@ class jf_f_layer(ctypes.Structure):
 F_KAPPA_MODES = {"direct_log_real_bounded": 0, "softplus_real_bounded": 1, "log_bounded": 2, "mu": 3, "mu_squared": 4, "quatvec": 5,
                  "quatvec_squared": 6}
 ROT_CODES = {"angles": -1, "xyz": -2, "quaternion": -3}      # hh_iter encoding of the non-Householder rotation modes
-V_KINDS = {"linear": 0, "quadratic": 1, "exponential": 2}
+V_KINDS = {"linear": 0, "quadratic": 1, "exponential": 2, "splines": 3}
 
 
 class jf_v_layer(ctypes.Structure):

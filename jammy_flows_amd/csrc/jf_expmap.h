@@ -15,8 +15,13 @@ template <typename T> struct ExpMapOut { T y[3]; T logdet_half; Mat3<T> jac; };
 // mu_norm_function of the "old" mean parametrisation: generate_normalization_function(stretch 10, max 1)  (exponential_map_s2.py:32-43, 118)
 template <typename T> __device__ __forceinline__ T v_mu_norm(T n) { return -M<T>::log(T(1) + T(1.718281828459045) * M<T>::exp(-n / T(10))) + T(1); }
 
-// get_exp_map_and_jacobian (exponential_map_s2.py:248-442).  pp: (n_pot, nc) row-major for this lane.
-template <typename T> __device__ inline void v_exp_map(const T* __restrict__ pp, int nc, int kind, const T (&x)[3], ExpMapOut<T>& o) {
+constexpr int JF_V_SPLINE_BINS = 10;    // exponential_map_s2.py:111 (num_spline_basis_functions)
+
+// get_exp_map_and_jacobian (exponential_map_s2.py:248-442).  pp: (n_pot, nc) row-major for this lane; tab: the lane's spline knot table
+// (only touched by the "splines" potential: rows 4.. hold 10 widths, 10 heights, 11 derivatives per component, :346-388); oob: spline input
+// outside [-1, 1] (the reference raises, spline_fns.py:57-59)
+template <typename T> __device__ inline void v_exp_map(const T* __restrict__ pp, int nc, int kind, const T (&x)[3], ExpMapOut<T>& o, T* __restrict__ tab,
+                                                      bool& oob) {
     const int w_row = 3, b_row = 4;
     T lmax = pp[w_row * nc];
     for (int k = 1; k < nc; ++k) lmax = M<T>::max(lmax, pp[w_row * nc + k]);
@@ -38,6 +43,20 @@ template <typename T> __device__ inline void v_exp_map(const T* __restrict__ pp,
             fp = beta * f;                                                                       // :306
         } else if (kind == JF_V_LINEAR) {
             f = T(1); fp = T(0);
+        } else if (kind == JF_V_SPLINES) {
+            // the potential's derivative is a monotone rational-quadratic spline [-1, 1] -> [-1, 1] of mu . x (rational_quadratic_spline with
+            // rel_min_bin_width = rel_min_bin_height = min_derivative = 1e-3, :354-362); f = spline value, f' = exp(logabsdet)
+            constexpr int NB = JF_V_SPLINE_BINS;
+            KnotTab<T> t(tab);
+            for (int j = 0; j < NB; ++j) { t.cw[j] = pp[(4 + j) * nc + k]; t.ch[j] = pp[(4 + NB + j) * nc + k]; }
+            for (int j = 0; j <= NB; ++j) t.d[j] = T(1e-3) + softplus<T>(pp[(4 + 2 * NB + j) * nc + k]);
+            spline_cum_knots<T>(t.cw, NB, T(-1), T(1), T(1e-3), true);
+            spline_cum_knots<T>(t.ch, NB, T(-1), T(1), T(1e-3), true);
+            oob = oob || (xmu < T(-1)) || (xmu > T(1));
+            int b = spline_search<T>(t.cw, NB, xmu, T(1e-6));
+            b = b < 0 ? 0 : (b > NB - 1 ? NB - 1 : b);
+            const SplineOut<T> r = spline_core<T>(t, b, xmu, false);
+            f = r.y; fp = M<T>::exp(r.lad);
         } else {
             f = xmu; fp = T(1);                                                                  // :332-335
         }
@@ -136,13 +155,13 @@ template <typename T> __device__ __forceinline__ void v_log_map(const T (&base)[
 //          criterion; here every row stops on its own step (rows that would have kept iterating only because another row of the batch
 //          was still moving change by < 1e-12 per further step).
 template <typename T> __device__ inline void v_newton(const T* __restrict__ pp, int nc, int kind, const T (&target)[3], int max_iter, bool fast,
-                                                     bool lane_valid, T (&x)[3]) {
+                                                     bool lane_valid, T (&x)[3], T* __restrict__ tab, bool& oob) {
     x[0] = T(0); x[1] = T(0); x[2] = T(-1);
     bool active = lane_valid;
     const T damp = fast ? T(0.4) : T(0.1);
     ExpMapOut<T> o;
     for (int it = 0; it < max_iter && __any(active); ++it) {
-        v_exp_map<T>(pp, nc, kind, x, o);
+        v_exp_map<T>(pp, nc, kind, x, o, tab, oob);
         if (active) {
             const T fn = T(1) - (o.y[0] * target[0] + o.y[1] * target[1] + o.y[2] * target[2]);
             T rv[3];
@@ -167,12 +186,16 @@ template <typename T> __device__ inline void v_newton(const T* __restrict__ pp, 
 struct VFam {
     using CLayer = jf_v_layer;
     static constexpr int DIM = 2;
-    static __host__ int n_pot(const CLayer& L) { return 3 + (L.exp_map_type == JF_V_EXPONENTIAL ? 2 : 1); }
+    static __host__ int n_pot(const CLayer& L) {
+        return L.exp_map_type == JF_V_SPLINES ? 4 + 3 * JF_V_SPLINE_BINS + 1 : 3 + (L.exp_map_type == JF_V_EXPONENTIAL ? 2 : 1);
+    }
     static __host__ int row_len(const CLayer& L) { return rot_len(L.hh_iter, 3) + n_pot(L) * L.num_components; }
     static __host__ int n_bins(const CLayer&) { return 0; }
+    static __host__ bool needs_tab(const CLayer& L) { return L.exp_map_type == JF_V_SPLINES; }
 
     template <typename T, bool FWD> static __device__ __forceinline__ void apply(const CLayer& L, const T* __restrict__ p, T (&x)[3], T& ld, LaneCtx<T>& c) {
         const T* pp = p + rot_len(L.hh_iter, 3);
+        bool oob = false;
         const int nc = L.num_components, kind = L.exp_map_type;
         T e[3], th, ph;
         ExpMapOut<T> o;
@@ -183,14 +206,14 @@ struct VFam {
             }
             s2_to_eucl<T>(x[0], x[1], e, ld);                                        // exponential_map_s2.py:495-499
             if (L.natural_direction) {
-                v_exp_map<T>(pp, nc, kind, e, o);
+                v_exp_map<T>(pp, nc, kind, e, o, c.tab, oob);
                 ld += o.logdet_half;
 #pragma unroll
                 for (int i = 0; i < 3; ++i) e[i] = o.y[i];
             } else {
                 T r[3];
-                v_newton<T>(pp, nc, kind, e, L.max_newton_iter, true, c.lane_valid, r);
-                v_exp_map<T>(pp, nc, kind, r, o);
+                v_newton<T>(pp, nc, kind, e, L.max_newton_iter, true, c.lane_valid, r, c.tab, oob);
+                v_exp_map<T>(pp, nc, kind, r, o, c.tab, oob);
                 ld -= o.logdet_half;
 #pragma unroll
                 for (int i = 0; i < 3; ++i) e[i] = r[i];
@@ -203,13 +226,13 @@ struct VFam {
             s2_to_eucl<T>(x[0], x[1], e, ld);                                        // :459-460
             if (L.natural_direction) {
                 T r[3];
-                v_newton<T>(pp, nc, kind, e, L.max_newton_iter, false, c.lane_valid, r);
-                v_exp_map<T>(pp, nc, kind, r, o);
+                v_newton<T>(pp, nc, kind, e, L.max_newton_iter, false, c.lane_valid, r, c.tab, oob);
+                v_exp_map<T>(pp, nc, kind, r, o, c.tab, oob);
                 ld -= o.logdet_half;
 #pragma unroll
                 for (int i = 0; i < 3; ++i) e[i] = r[i];
             } else {
-                v_exp_map<T>(pp, nc, kind, e, o);
+                v_exp_map<T>(pp, nc, kind, e, o, c.tab, oob);
                 ld += o.logdet_half;
 #pragma unroll
                 for (int i = 0; i < 3; ++i) e[i] = o.y[i];
@@ -223,6 +246,7 @@ struct VFam {
         }
         bool bad = !M<T>::finite(x[0]) || !M<T>::finite(x[1]);
         c.nonfinite = c.nonfinite || bad;
+        c.oob = c.oob || oob;
     }
 };
 

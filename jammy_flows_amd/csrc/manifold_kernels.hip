@@ -197,7 +197,7 @@ using namespace jf;
         for (int j = 0; j < L[i].n_vertical; ++j) if (!spline_ok(L[i].vertical[j].sp)) return JF_ERR_UNSUPPORTED;   \
         for (int j = 0; j < L[i].n_circular; ++j) if (!spline_ok(L[i].circular[j].sp)) return JF_ERR_UNSUPPORTED;   \
     }
-#define CHECK_V if (L) for (int i = 0; i < n && i < JF_MAX_MCHAIN; ++i) if (L[i].exp_map_type < 0 || L[i].exp_map_type > 2) return JF_ERR_UNSUPPORTED;
+#define CHECK_V if (L) for (int i = 0; i < n && i < JF_MAX_MCHAIN; ++i) if (L[i].exp_map_type < 0 || L[i].exp_map_type > JF_V_SPLINES) return JF_ERR_UNSUPPORTED;
 
 JF_DEFINE_MCHAIN(r, RFam, float, f32, CHECK_R)
 JF_DEFINE_MCHAIN(r, RFam, double, f64, CHECK_R)

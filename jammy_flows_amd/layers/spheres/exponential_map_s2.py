@@ -19,16 +19,17 @@ class exponential_map_s2(sphere_base.sphere_base):
         if dimension != 2:
             raise Exception("The exponential map flow should be used for dimension 2!")
         if exp_map_type not in _hip.V_KINDS:
-            raise NotImplementedError("exp_map_type '%s' has no HIP kernel (linear / quadratic / exponential do)" % exp_map_type)
+            raise NotImplementedError("exp_map_type '%s' has no HIP kernel (linear / quadratic / exponential / splines do)" % exp_map_type)
         if mean_parametrization != "old":
-            raise NotImplementedError("mean_parametrization '%s' has no HIP kernel" % mean_parametrization)
+            raise NotImplementedError("mean_parametrization '%s' has no HIP kernel (the reference itself raises a TypeError for it: "
+                                      "exponential_map_s2.py:262 calls compute_householder_matrix without hh_iter)" % mean_parametrization)
         self.num_components = num_components
         self.exp_map_type = exp_map_type
         self.natural_direction = natural_direction
         self.max_num_newton_iter = max_num_newton_iter
         self.mean_parametrization = mean_parametrization
         self.num_mu_params = 3
-        self.num_potential_pars = self.num_mu_params + (2 if exp_map_type == "exponential" else 1)
+        self.num_potential_pars = self.num_mu_params + {"exponential": 2, "splines": 1 + 3 * 10 + 1}.get(exp_map_type, 1)      # (:124-129)
         if use_permanent_parameters:
             self.potential_pars = nn.Parameter(torch.randn(self.num_potential_pars, self.num_components).unsqueeze(0))
         self.total_param_num += self.num_potential_pars * self.num_components

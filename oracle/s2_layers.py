@@ -3,6 +3,7 @@ Oracle = test infrastructure only."""
 import numpy as np
 
 from . import manifolds as mf
+from . import splines
 from .sphere_layers import _SphereLayer
 from .special import bounded_log_fn, logsumexp
 
@@ -222,12 +223,12 @@ class VLayer(_SphereLayer):
         if o["mean_parametrization"] != "old":
             raise NotImplementedError("oracle: v mean_parametrization")
         self.kind = o["exp_map_type"]
-        if self.kind not in ("exponential", "linear", "quadratic"):
+        if self.kind not in ("exponential", "linear", "quadratic", "splines"):
             raise NotImplementedError("oracle: v exp_map_type %s" % self.kind)
         self.nc = o["num_components"]
         self.natural_direction = o["natural_direction"]
         self.max_newton = o["max_num_newton_iter"]
-        self.npp = 3 + (2 if self.kind == "exponential" else 1)
+        self.npp = 3 + {"exponential": 2, "splines": 1 + 3 * 10 + 1}.get(self.kind, 1)      # exponential_map_s2.py:124-129
         self.total_param_num = self.n_rot + self.npp * self.nc
 
     def row_from_state(self, sd, prefix):
@@ -246,6 +247,13 @@ class VLayer(_SphereLayer):
             e = np.exp(beta * (xmu - 1.0))
             grad = (w * mu * e).sum(axis=-1)
             gj = np.einsum("biu,bju->bij", beta * w * mu * e, np.broadcast_to(mu, (x.shape[0],) + mu.shape[1:]))
+        elif self.kind == "splines":                                             # (:346-388): d potential / d (mu . x) is an RQ spline on [-1, 1]
+            t = lambda a: np.transpose(a, (0, 2, 1))
+            res, lad, _ = splines.rqs_plain(t(xmu), t(pp[:, 4:14, :]), t(pp[:, 14:24, :]), t(pp[:, 24:35, :]), False, -1.0, 1.0, -1.0, 1.0,
+                                            min_w=1e-3, min_h=1e-3, min_d=1e-3)
+            res, deriv = t(res), t(np.exp(lad))
+            grad = (w * mu * res).sum(axis=-1)
+            gj = np.einsum("biu,bju->bij", w * mu * deriv, np.broadcast_to(mu, (x.shape[0],) + mu.shape[1:]))
         elif self.kind == "linear":
             grad = np.broadcast_to((w * mu).sum(axis=-1), x.shape)
             gj = None
@@ -340,20 +348,6 @@ class VLayer(_SphereLayer):
 
     def _pp(self, params):
         return params.reshape(params.shape[0], self.npp, self.nc)
-
-    _INBETWEEN = np.array([[0.0, 0.0, 1.0], [0.0, 1.0, 0.0], [-1.0, 0.0, 0.0]])        # fvm_2d.py:392, 679
-
-    def _inbetween(self, cos_theta, angle, log_det, inverse):
-        """add_extra_rotation_inbetween (fvm_2d.py:381-402 inverse with the transposed matrix, :664-688 forward): the pole moves onto the
-        equator between the kappa step and the nested spline flows"""
-        th = np.arccos(cos_theta)
-        log_det = log_det - np.log(np.sin(mf.safe_angle_within_pi(th[:, 0])))
-        comb, log_det = mf.spherical_to_eucl(np.concatenate([th, angle], axis=1), log_det, 2)
-        m = self._INBETWEEN.T if inverse else self._INBETWEEN
-        comb = comb @ m.T
-        comb, log_det = mf.eucl_to_spherical(comb, log_det, 2)
-        log_det = log_det + np.log(np.sin(mf.safe_angle_within_pi(comb[:, 0])))
-        return np.cos(comb[:, :1]), comb[:, 1:], log_det
 
     def _core_inverse(self, x, log_det, params):
         """exponential_map_s2._inv_flow_mapping (exponential_map_s2.py:446-487)."""

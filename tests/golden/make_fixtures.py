@@ -161,6 +161,9 @@ CASES = [
     dict(name="v_s2_cond_vv", pdf="s2", flow="vv", mlp_scale=300.0, B=96, kwargs=dict(conditional_input_dim=2)),
     dict(name="v_s2_nat1_rot", pdf="s2", flow="v", mlp_scale=300.0, B=96,
          kwargs=dict(conditional_input_dim=2, options_overwrite={"v": {"natural_direction": 1, "add_rotation": 1}})),
+    # (no_bins: the potential's spline searches once per component and Newton iteration -- an internal of the exponential map, not a layer output)
+    dict(name="v_s2_splines_cond", pdf="s2", flow="v", mlp_scale=100.0, B=96, no_bins=True,
+         kwargs=dict(conditional_input_dim=2, options_overwrite={"v": {"exp_map_type": "splines"}})),
     # mixed extra
     dict(name="mix_e2s1i1", pdf="e2+s1+i1_-2.0_3.0", flow="gg+m+rr", mlp_scale=1000.0, kwargs=dict(conditional_input_dim=3)),
     dict(name="mix_s2e2_emb", pdf="s2+e2", flow="f+gg", mlp_scale=1000.0, embedding=True),
@@ -345,7 +348,7 @@ def make_case(case):
         layer_param_nums=[[int(l.total_param_num) for l in blk] for blk in pdf.layer_list],
         layer_types=[[type(l).__name__ for l in blk] for blk in pdf.layer_list],
         count_parameters=int(pdf.count_parameters()),
-        n_trace_inv=len(inv_layers), n_trace_fwd=len(fwd_layers), n_bins_inv=len(inv_bins), n_bins_fwd=len(fwd_bins),
+        n_trace_inv=len(inv_layers), n_trace_fwd=len(fwd_layers), n_bins_inv=0 if case.get("no_bins") else len(inv_bins), n_bins_fwd=0 if case.get("no_bins") else len(fwd_bins),
         trace_tags_inv=[t for t, _, _ in inv_layers], trace_tags_fwd=[t for t, _, _ in fwd_layers],
         sample_warnings=newton_msgs[:300],
     )
@@ -366,7 +369,7 @@ def make_case(case):
         for i, (_, lx, ld) in enumerate(lay):
             out["trace_%s/%d/x" % (d, i)] = lx
             out["trace_%s/%d/ld" % (d, i)] = ld
-        for i, b in enumerate(bins):
+        for i, b in enumerate(bins if not case.get("no_bins") else []):
             out["bins_%s/%d" % (d, i)] = b
     path = os.path.join(HERE, name + ".npz")
     numpy.savez_compressed(path, **out)
