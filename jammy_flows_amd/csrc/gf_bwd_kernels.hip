@@ -21,6 +21,8 @@
 // and the inverse-CDF stage contributes (dy, d logd) = (A_y, A_H) d log cdf + (B_y, B_H) d log sf + (0, 1) d log pdf  (gf_icdf_coeffs below).
 // Only sums of the form  sum_k (g . d log(.)/d theta)  are formed, never a quotient of two underflowing sums.
 #include "jf_gf.h"
+#include "jf_dual.h"
+#include "jf_gf_ext.h"
 
 namespace jf {
 
@@ -290,29 +292,124 @@ __global__ void __launch_bounds__(BCAST ? 256 : 64) gf_chain_bwd_kernel(const Gf
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------- general-option layers
+// Chains with a layer that uses add_skewness / center_mean / a non-Householder rotation (jf_gf_ext.h) are differentiated in FORWARD mode, like
+// the manifold layers (manifold_bwd_kernels.hip): the very device code of the forward kernel, instantiated on dual numbers, once per input
+// direction (D target coordinates + every parameter of the row), contracted with the upstream gradients.  O(P) replays of the chain per row --
+// these options are off the benchmarked path; what matters is that training with them works and is exact.
+template <typename T> struct SeededRow {               // parameter row as dual numbers: tangent 1 at index `seed`
+    const T* p; int seed;
+    __device__ __forceinline__ Dual<T> operator[](int i) const { return Dual<T>(p[i], i == seed ? T(1) : T(0)); }
+    __device__ __forceinline__ SeededRow operator+(int k) const { return SeededRow{p + k, seed - k}; }
+};
+
+template <typename T> __device__ inline GfLayerDev<Dual<T>> gx_dual_layer(const GfLayerDev<T>& o) {
+    GfLayerDev<Dual<T>> r;
+    r.K = o.K; r.hh = o.hh; r.model_offset = o.model_offset; r.fit_norm = o.fit_norm; r.reg_norm = o.reg_norm; r.inv_type = o.inv_type;
+    r.width_mode = o.width_mode; r.clamp_widths = o.clamp_widths; r.fast = o.fast; r.stretch = o.stretch; r.off_box = o.off_box;
+    r.n_params = o.n_params; r.col0 = o.col0; r.off_rot = o.off_rot; r.off_mean = o.off_mean; r.off_lw = o.off_lw; r.off_ln = o.off_ln;
+    r.vec_ok = o.vec_ok; r.rot_mode = o.rot_mode; r.center_mean = o.center_mean; r.skew = o.skew; r.off_skew = o.off_skew;
+    r.wmin = o.wmin; r.wmax = o.wmax; r.inv_wmax = o.inv_wmax; r.nmin = o.nmin; r.nmax = o.nmax; r.lw_lo = o.lw_lo; r.lw_hi = o.lw_hi;
+    return r;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(GX_THREADS) gfx_chain_bwd_kernel(const GfBwdArgs<T> a, const int64_t pstep, const int64_t tiles_total) {
+    using Du = Dual<T>;
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    Du* lds = reinterpret_cast<Du*>(smem_raw);
+    T* red = reinterpret_cast<T*>(lds + JF_MAX_D_GF * GX_THREADS);       // one partial per wave (broadcast regime)
+    const int tid = threadIdx.x, D = a.D;
+    const XCol<Du> x{lds + tid};
+    const bool bcast = pstep == 0;
+    const int n_dir = D + a.n_params_total;
+    bool first_tile = true;
+    for (int64_t tile = blockIdx.x; tile < tiles_total || (bcast && first_tile); tile += gridDim.x) {
+        const int64_t row = tile * GX_THREADS + tid;
+        const bool active = row < a.B && tile < tiles_total;
+        const int64_t rrow = active ? row : a.B - 1;
+        const T gld = (a.g_ld && active) ? a.g_ld[rrow] : T(0);
+        const T gblp = (a.g_blp && active) ? a.g_blp[rrow] : T(0);
+        const T* prow = a.params + rrow * pstep;
+        bool bad = false;
+        for (int j = 0; j < n_dir; ++j) {
+            for (int d = 0; d < D; ++d) x[d] = Du(a.x[rrow * a.xs + d], d == j ? T(1) : T(0));
+            Du ld(T(0));
+            for (int l = a.n_layers - 1; l >= 0; --l) {
+                const GfLayerDev<Du> o = gx_dual_layer<T>(a.L[l]);
+                const SeededRow<T> p{prow + o.col0, j - D - o.col0};
+                if (o.model_offset) for (int d = 0; d < D; ++d) x[d] = x[d] - p[d];
+                gx_rotate<Du, SeededRow<T>>(o, p, x, D, true);
+                for (int d = 0; d < D; ++d) {
+                    const GxCoord<Du> c = gx_prepare<Du, SeededRow<T>>(o, p, D, d);
+                    const IcdfOut<Du> s = gf_icdf<Du>(o.inv_type, gx_mixture<Du, SeededRow<T>>(o, p, D, d, c, x[d]));
+                    x[d] = s.y;
+                    ld = ld + s.logd;
+                }
+            }
+            T gj = gld * ld.d;
+            for (int d = 0; d < D; ++d) {
+                const Du v = x[d];
+                const T gxo = (a.g_xout && active) ? a.g_xout[rrow * a.gxos + d] : T(0);
+                gj += (gxo - v.v * gblp) * v.d;
+            }
+            if (!active) gj = T(0);
+            bad = bad || !M<T>::finite(gj);
+            if (j < D) {
+                if (active) a.g_x[row * a.gxs + j] = gj;
+            } else if (!bcast) {
+                if (active) a.g_params[row * a.gps + (j - D)] = gj;
+            } else {                                               // this workgroup's partial row: sum over its lanes, over its tiles
+                T s = gj;
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+                __syncthreads();
+                if ((tid & 63) == 0) red[tid >> 6] = s;
+                __syncthreads();
+                if (tid == 0) {
+                    T tot = T(0);
+                    for (int w = 0; w < GX_THREADS / 64; ++w) tot += red[w];
+                    T* dst = a.g_params + (int64_t)blockIdx.x * a.gps + (j - D);
+                    *dst = first_tile ? tot : *dst + tot;
+                }
+            }
+        }
+        status_add(a.status, JF_STATUS_NONFINITE, active && bad);
+        first_tile = false;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------- host side
 static inline int gb_group_width(int D) { return D <= 1 ? 1 : D <= 2 ? 2 : D <= 4 ? 4 : 8; }
 
-template <typename T> static int gb_fill(GfBwdArgs<T>& a, const T* params, int64_t ps, bool bcast, int32_t D, int32_t n_layers, const jf_gf_layer* layers) {
+template <typename T> static int gb_fill(GfBwdArgs<T>& a, const T* params, int64_t ps, bool bcast, int32_t D, int32_t n_layers, const jf_gf_layer* layers,
+                                         bool& ext) {
     int col = 0, maxp = 0;
+    ext = false;
     for (int l = 0; l < n_layers; ++l) {
         const jf_gf_layer& h = layers[l];
         GfLayerDev<T>& o = a.L[l];
         if (h.num_kde < 1 || h.hh_iter < 0 || h.width_min <= 0) return JF_ERR_BADARG;
-        if (h.rotation_mode != JF_GF_ROT_HOUSEHOLDER || h.center_mean || h.add_skewness) return JF_ERR_UNSUPPORTED;   // general-option layers: jf_gf_chain_inv only
+        const bool ext_layer = h.rotation_mode != JF_GF_ROT_HOUSEHOLDER || h.center_mean || h.add_skewness;     // general-option layer (jf_gf_ext.h)
+        if (h.rotation_mode < JF_GF_ROT_HOUSEHOLDER || h.rotation_mode > JF_GF_ROT_TRIANGULAR || (h.rotation_mode == JF_GF_ROT_CAYLEY && D > 2)) return JF_ERR_BADARG;
+        if (h.add_skewness && sizeof(T) != 8) return JF_ERR_UNSUPPORTED;                                        // float64 only, as the forward
+        if (ext_layer) ext = true;
         if (h.width_mode == JF_GF_WIDTH_SMOOTH_SATURATION && h.width_max <= 0) return JF_ERR_BADARG;
-        if (h.nonlinear_stretch_type != JF_GF_STRETCH_CLASSIC || h.hh_iter > GB_MAX_HH) return JF_ERR_UNSUPPORTED;
+        if (h.nonlinear_stretch_type != JF_GF_STRETCH_CLASSIC) return JF_ERR_UNSUPPORTED;
         o.K = h.num_kde; o.hh = h.hh_iter; o.model_offset = h.model_offset; o.fit_norm = h.fit_normalization;
         o.reg_norm = h.regulate_normalization; o.inv_type = h.inverse_function_type; o.width_mode = h.width_mode;
         o.clamp_widths = h.clamp_widths;
         o.fast = (h.width_mode == JF_GF_WIDTH_SMOOTH_SATURATION && !h.clamp_widths && h.fit_normalization && h.regulate_normalization) ? 1 : 0;
         o.stretch = JF_GF_STRETCH_CLASSIC; o.off_box = 0;
         const int kd = h.num_kde * D;
+        o.rot_mode = h.rotation_mode; o.center_mean = h.center_mean ? 1 : 0; o.skew = h.add_skewness ? 1 : 0;
+        if (o.rot_mode != JF_GF_ROT_HOUSEHOLDER) o.hh = 0;
         o.off_rot = h.model_offset ? D : 0;
-        o.off_mean = o.off_rot + h.hh_iter * D;
-        o.off_lw = o.off_mean + kd;
+        o.off_mean = o.off_rot + gx_rot_len(o.rot_mode, o.hh, D);
+        o.off_lw = o.off_mean + kd - (o.center_mean ? D : 0);
         o.off_ln = o.off_lw + kd;
-        o.n_params = o.off_ln + (h.fit_normalization ? kd : 0);
+        o.off_skew = o.off_ln + (h.fit_normalization ? kd : 0);
+        o.n_params = o.off_skew + (o.skew ? kd : 0);
         o.col0 = col;
         o.vec_ok = (!bcast && aligned16<T>(params, ps, col) && (o.n_params % Vec16<T>::N == 0)) ? 1 : 0;
         o.wmin = (T)h.width_min; o.wmax = (T)h.width_max; o.inv_wmax = h.width_max > 0 ? (T)(1.0 / h.width_max) : T(0);
@@ -366,11 +463,22 @@ static int gf_chain_inv_bwd(const T* x, int64_t xs, const T* params, int64_t ps,
     if (pb != 1 && pb != B) return JF_ERR_BADARG;
     const bool bcast = pb == 1;
     GfBwdArgs<T> a{};
-    const int rc = gb_fill<T>(a, params, ps, bcast, D, n_layers, layers);
+    bool ext = false;
+    const int rc = gb_fill<T>(a, params, ps, bcast, D, n_layers, layers, ext);
     if (rc != JF_OK) return rc;
     if (B == 0) return JF_OK;
     a.x = x; a.xs = xs; a.params = params; a.ps = ps; a.B = B; a.D = D; a.n_layers = n_layers;
     a.g_xout = g_xout; a.gxos = gxos; a.g_ld = g_ld; a.g_blp = g_blp; a.g_x = g_x; a.gxs = gxs; a.g_params = g_params; a.gps = gps; a.status = status;
+    if (ext) {                                                     // forward-mode kernel; broadcast: one partial row per workgroup, as the adjoint kernel
+        const int64_t tiles = (B + GX_THREADS - 1) / GX_THREADS;
+        const int64_t blocks = bcast ? gb_partials(B, D) : tiles;
+        const size_t lds = (size_t)JF_MAX_D_GF * GX_THREADS * sizeof(Dual<T>) + 16 * sizeof(T);
+        auto k = gfx_chain_bwd_kernel<T>;
+        if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(GX_THREADS), lds, (hipStream_t)stream, a, bcast ? (int64_t)0 : ps, tiles);
+        return check_launch();
+    }
+    for (int l = 0; l < n_layers; ++l) if (layers[l].hh_iter > GB_MAX_HH) return JF_ERR_UNSUPPORTED;
     switch (gb_group_width(D)) {
         case 1: return gb_launch<T, 1>(a, bcast, (hipStream_t)stream);
         case 2: return gb_launch<T, 2>(a, bcast, (hipStream_t)stream);

@@ -171,7 +171,7 @@ template <typename T, bool FWD> __global__ void __launch_bounds__(GX_THREADS) gf
         const T* p = a.params + rrow * pstep + o.col0;
         if constexpr (!FWD) {
             if (o.model_offset) for (int d = 0; d < D; ++d) x[d] -= p[d];                       // euclidean_base.py:40-45
-            gx_rotate<T>(o, p, x, D, true);
+            gx_rotate<T, const T*>(o, p, x, D, true);
         }
         if (o.stretch == JF_GF_STRETCH_RQ_SPLINES) {
             for (int d = 0; d < D; ++d) {
@@ -184,21 +184,21 @@ template <typename T, bool FWD> __global__ void __launch_bounds__(GX_THREADS) gf
             ++spline_calls;
         } else if constexpr (!FWD) {
             for (int d = 0; d < D; ++d) {
-                const GxCoord<T> c = gx_prepare<T>(o, p, D, d);
-                const IcdfOut<T> s = gf_icdf<T>(o.inv_type, gx_mixture<T>(o, p, D, d, c, x[d]));
+                const GxCoord<T> c = gx_prepare<T, const T*>(o, p, D, d);
+                const IcdfOut<T> s = gf_icdf<T>(o.inv_type, gx_mixture<T, const T*>(o, p, D, d, c, x[d]));
                 x[d] = s.y;
                 ld += s.logd;
             }
         } else {
             for (int d = 0; d < D; ++d) z[d] = x[d];
-            gx_solve<T>(o, p, D, z, x, row_valid, a.status);
+            gx_solve<T, const T*>(o, p, D, z, x, row_valid, a.status);
             for (int d = 0; d < D; ++d) {                                                          // gaussianization_flow.py:922-924
-                const GxCoord<T> c = gx_prepare<T>(o, p, D, d);
-                ld -= gf_icdf<T>(o.inv_type, gx_mixture<T>(o, p, D, d, c, x[d])).logd;
+                const GxCoord<T> c = gx_prepare<T, const T*>(o, p, D, d);
+                ld -= gf_icdf<T>(o.inv_type, gx_mixture<T, const T*>(o, p, D, d, c, x[d])).logd;
             }
         }
         if constexpr (FWD) {
-            gx_rotate<T>(o, p, x, D, false);
+            gx_rotate<T, const T*>(o, p, x, D, false);
             if (o.model_offset) for (int d = 0; d < D; ++d) x[d] += p[d];                       // euclidean_base.py:63-68
         }
     }

@@ -29,13 +29,17 @@ __host__ inline int gx_rot_len(int mode, int hh, int D) {
     return D - 1 + D * (D - 1);              // triangular_combination (:161)
 }
 
+// The parameter row is a template parameter PA of everything below: `const T*` in the forward kernels, and in the backward kernel a proxy
+// (SeededRow, gf_bwd_kernels.hip) that hands out dual numbers whose tangent is 1 at the seeded parameter -- the only operations used on it are
+// `p[i]` and `p + offset`.
+
 // x <- R x (inverse == false, sampling direction :942-987) or x <- R^{-1} x (log-prob direction :1004-1049)
-template <typename T> __device__ inline void gx_rotate(const GfLayerDev<T>& o, const T* __restrict__ p, XCol<T> x, int D, bool inverse) {
-    const T* rp = p + o.off_rot;
+template <typename T, typename PA> __device__ inline void gx_rotate(const GfLayerDev<T>& o, PA p, XCol<T> x, int D, bool inverse) {
+    const PA rp = p + o.off_rot;
     if (o.rot_mode == JF_GF_ROT_HOUSEHOLDER) {
         // Q = H_0 H_1 ... (:457-471): Q^T x applies H_0 first, Q x applies H_{n-1} first
         for (int it = 0; it < o.hh; ++it) {
-            const T* v = rp + (inverse ? it : o.hh - 1 - it) * D;
+            const PA v = rp + (inverse ? it : o.hh - 1 - it) * D;
             T n2 = T(0), dot = T(0);
             for (int d = 0; d < D; ++d) { n2 += v[d] * v[d]; dot += v[d] * x[d]; }
             const T f = T(2) * dot / n2;
@@ -70,9 +74,9 @@ template <typename T> __device__ inline void gx_rotate(const GfLayerDev<T>& o, c
     }
     // triangular_combination: x <- L diag(e^d) U x with unit-diagonal L (lower) and U (upper = transposed lower layout), sum(d) = 0
     const int nt = D * (D - 1) / 2;
-    const T* lower = rp;
-    const T* diag = rp + nt;
-    const T* upper = rp + nt + D - 1;
+    const PA lower = rp;
+    const PA diag = rp + nt;
+    const PA upper = rp + (nt + D - 1);
     T dsum = T(0);
     if (!inverse) {
         for (int i = 0; i < D; ++i) {                      // U x (row i uses x_j, j > i: ascending i reads not-yet-overwritten entries)
@@ -137,7 +141,7 @@ template <typename T> struct Lse {            // stream log-sum-exp
 };
 
 // regulated log-weight of component k (:840-844), 0 without fit_normalization
-template <typename T> __device__ __forceinline__ T gx_log_weight(const GfLayerDev<T>& o, const T* __restrict__ p, int D, int k, int d) {
+template <typename T, typename PA> __device__ __forceinline__ T gx_log_weight(const GfLayerDev<T>& o, PA p, int D, int k, int d) {
     if (!o.fit_norm) return T(0);
     const T raw = p[o.off_ln + k * D + d];
     return o.reg_norm ? M<T>::log(o.nmin + o.nmax / (T(1) + M<T>::exp(-raw))) : raw;
@@ -145,12 +149,12 @@ template <typename T> __device__ __forceinline__ T gx_log_weight(const GfLayerDe
 
 // per-coordinate quantities that do not depend on x: log-sum-exp of the log-weights and, with center_mean, the dependent last mean
 template <typename T> struct GxCoord { T lse_w, last_mean; };
-template <typename T> __device__ inline GxCoord<T> gx_prepare(const GfLayerDev<T>& o, const T* __restrict__ p, int D, int d) {
+template <typename T, typename PA> __device__ inline GxCoord<T> gx_prepare(const GfLayerDev<T>& o, PA p, int D, int d) {
     GxCoord<T> c;
     Lse<T> l;
     T acc = T(0), wl = T(1);
     for (int k = 0; k < o.K; ++k) {
-        const T lw = gx_log_weight(o, p, D, k, d);
+        const T lw = gx_log_weight<T, PA>(o, p, D, k, d);
         l.add(lw);
         if (o.center_mean) {
             const T w = M<T>::exp(lw);
@@ -163,7 +167,7 @@ template <typename T> __device__ inline GxCoord<T> gx_prepare(const GfLayerDev<T
 }
 
 // logistic_kernel_log_pdf_quantities (:389-454) for one coordinate
-template <typename T> __device__ inline MixQ<T> gx_mixture(const GfLayerDev<T>& o, const T* __restrict__ p, int D, int d, const GxCoord<T>& c, T x) {
+template <typename T, typename PA> __device__ inline MixQ<T> gx_mixture(const GfLayerDev<T>& o, PA p, int D, int d, const GxCoord<T>& c, T x) {
     Lse<T> lc, ls, lp;
     const T ln9 = T(2.19722457733621938279), ln01 = T(-2.30258509299404568402);
     const int n_pos = o.K / 2;                                                   // (:356-359): the first int(K/2) components keep sign +1
@@ -171,7 +175,7 @@ template <typename T> __device__ inline MixQ<T> gx_mixture(const GfLayerDev<T>& 
         const T mu = (o.center_mean && k == o.K - 1) ? c.last_mean : p[o.off_mean + k * D + d];
         const T w = gf_width<T>(o, p[o.off_lw + k * D + d]);
         const T logw = M<T>::log(w);
-        const T ln_pi = gx_log_weight(o, p, D, k, d) - c.lse_w;
+        const T ln_pi = gx_log_weight<T, PA>(o, p, D, k, d) - c.lse_w;
         const T u = (x - mu) / w;
         if (o.skew) {
             const T log_a = gx_bounded_log<T>(p[o.off_skew + k * D + d], ln01, ln9, true);      // exponent regulator (:367)
@@ -205,15 +209,15 @@ template <typename T> __device__ inline MixQ<T> gx_mixture(const GfLayerDev<T>& 
 
 // bisection + Newton of the sampling direction (layers/bisection_n_newton.py:11-135; 25 / 20 iterations on [-1e5, 1e5], :921) for one row:
 // z holds the targets, x receives the solution; the Newton stopping rule sums |update| over the row's coordinates
-template <typename T> __device__ inline void gx_solve(const GfLayerDev<T>& o, const T* __restrict__ p, int D, XCol<T> z, XCol<T> x, bool row_valid,
-                                                       int32_t* status) {
+template <typename T, typename PA> __device__ inline void gx_solve(const GfLayerDev<T>& o, PA p, int D, XCol<T> z, XCol<T> x, bool row_valid,
+                                                                   int32_t* status) {
     for (int d = 0; d < D; ++d) {
-        const GxCoord<T> c = gx_prepare(o, p, D, d);
+        const GxCoord<T> c = gx_prepare<T, PA>(o, p, D, d);
         const T zd = z[d];
         T lo = T(-1e5), hi = T(1e5), xm = T(0);
         for (int it = 0; it < 25; ++it) {
             xm = (hi + lo) * T(0.5);
-            const T y = gf_icdf<T>(o.inv_type, gx_mixture(o, p, D, d, c, xm)).y;
+            const T y = gf_icdf<T>(o.inv_type, gx_mixture<T, PA>(o, p, D, d, c, xm)).y;
             if (M<T>::abs(y - zd) <= T(1e-6) * M<T>::abs(zd)) { lo = xm; hi = xm; }
             else if (y < zd) lo = xm;
             else hi = xm;
@@ -229,8 +233,8 @@ template <typename T> __device__ inline void gx_solve(const GfLayerDev<T>& o, co
         T usum = T(0);
         ferr = T(0);
         for (int d = 0; d < D; ++d) {
-            const GxCoord<T> c = gx_prepare(o, p, D, d);
-            const IcdfOut<T> s = gf_icdf<T>(o.inv_type, gx_mixture(o, p, D, d, c, x[d]));
+            const GxCoord<T> c = gx_prepare<T, PA>(o, p, D, d);
+            const IcdfOut<T> s = gf_icdf<T>(o.inv_type, gx_mixture<T, PA>(o, p, D, d, c, x[d]));
             const T f = s.y - z[d];
             const T upd = f / M<T>::exp(s.logd);
             usum += M<T>::abs(upd);
