@@ -210,11 +210,11 @@ def committed_traffic():
 # device-kernel name (as rocprofv3 reports it) of a (C entry point, tag) pair of the host-side timer
 KERNEL_OF = {"jf_cond_f_chain_inv_f32": "cond_mchain_kernel<float, jf::FFam", "jf_cond_f_chain_inv_f64": "cond_mchain_kernel<double, jf::FFam",
              "jf_conditioning_rows_f32": "conditioning_kernel<float", "jf_conditioning_rows_f64": "conditioning_kernel<double",
-             "jf_v_chain_inv_f64": "mchain_kernel<double, jf::VFam", "jf_amlp2_f64": "amlp_gf_kernel<double, 8, 8, true>",
+             "jf_v_chain_inv_f64": "mchain_kernel<double, jf::VFam", "jf_amlp2_f64": "amlp2_mfma_kernel",
              "jf_cond_gf_chain_inv_split_f32": "cond_gf_split_kernel", "jf_cond_gf_chain_inv_f32": "cond_gf_chain_kernel<float",
              "jf_cond_gf_chain_inv_f64": "cond_gf_chain_kernel<double", "jf_mlp2_f32": "mlp2_kernel<float", "jf_mlp2_f64": "mlp2_kernel<double",
              "jf_gf_chain_inv_f32": "gf_chain_kernel<float", "jf_gf_chain_inv_f64": "gf_chain_kernel<double",
-             "jf_amlp_gf_chain_inv_f64": "amlp_gf_kernel<double, 8, 8, false>"}
+             "jf_amlp_gf_chain_inv_f64": "amlp_gf_mfma_kernel"}
 
 
 def traffic_of(traffic, kname, ktag):
@@ -451,14 +451,20 @@ def main():
                            "frac_of_bf16_peak": executed * B / secs / 1e12 / MFMA_BF16_PEAK_TFLOPS,
                            "frac_of_f32_mfma_peak_equivalent": tf / MFMA_F32_PEAK_TFLOPS})
             elif kname.startswith("jf_amlp_gf_chain"):
-                # low-rank factors on the VALU: the kernel never forms the dense product, and (f64) the matrix rate of MI355X equals the vector rate
+                # low-rank factors: the kernel never forms the dense product.  float64 with ranks <= 8 runs on v_mfma_f64_16x16x4 (jf_amlp_mfma.h; on
+                # MI355X the f64 matrix rate equals the f64 vector rate -- the matrix cores are used for their 16x lower LDS operand traffic)
                 K1, H, N, D = (int(t[1:]) for t in ktag.split("_")[:4])
                 r = int(ktag.split("_")[4][1:])
-                executed = 2 * (r * K1 + H * r + r * H + N * r)             # V1 c, U1 t1, V2 h, U2 t2 per row (23 936 for C5 block 0)
+                L = {"c3": 4, "c5": 4}[args.workload]
+                useful = 2 * (r * K1 + H * r + r * H + N * r)               # V1 c, U1 t1, V2 h, U2 t2 per row (23 936 for C5 block 0)
+                on_mfma = main_dt == "f64" and r <= 8 and H % 16 == 0
+                executed = 2 * (16 * 4 * ((K1 + 3) // 4) + H * 8 + 16 * H + L * 21 * 16 * 8) if on_mfma else useful     # padded 16 x 16 x 4 tiles
                 mf = {"dense_equivalent_TFLOPs": tf, "dense_equivalent_flops_per_launch": flops_per_row * B,
-                      "arithmetic": "%s VALU FMAs on the low-rank factors (rank %d); no MFMA instruction is issued" % (main_dt, r),
-                      "executed_flops_per_launch": executed * B, "executed_TFLOPs": executed * B / secs / 1e12,
-                      "frac_of_%s_vector_peak" % main_dt: executed * B / secs / 1e12 / (MFMA_F64_PEAK_TFLOPS if main_dt == "f64" else MFMA_F32_PEAK_TFLOPS)}
+                      "arithmetic": ("f64 MFMA (v_mfma_f64_16x16x4) on the low-rank factors (rank %d), permuted so that results land in the flow's registers" % r)
+                      if on_mfma else "%s VALU FMAs on the low-rank factors (rank %d)" % (main_dt, r),
+                      "useful_flops_per_launch": useful * B, "executed_flops_per_launch": executed * B, "executed_TFLOPs": executed * B / secs / 1e12,
+                      "frac_of_%s_%s_peak" % (main_dt, "mfma" if on_mfma else "vector"):
+                          executed * B / secs / 1e12 / (MFMA_F64_PEAK_TFLOPS if main_dt == "f64" else MFMA_F32_PEAK_TFLOPS)}
             elif main_dt == "f32":
                 mf.update({"arithmetic": "exact f32 MFMA", "frac_of_f32_mfma_peak": tf / MFMA_F32_PEAK_TFLOPS})
             else:

@@ -108,6 +108,10 @@ template <typename T> __device__ __forceinline__ MixQ<T> ag_mixture(const T (&P)
 // lane `src` of the caller's G-lane row group
 template <typename T, int G> __device__ __forceinline__ T group_bcast(T v, int src) { return __shfl(v, (threadIdx.x & 63 & ~(G - 1)) + src, 64); }
 
+}  // namespace jf
+#include "jf_amlp_mfma.h"      // the float64 matrix-core version of the same block (needs AgArgs / ag_mixture above)
+namespace jf {
+
 // RM: compiled rank bound (8 or 16): the rank loops are fully unrolled over it
 // MLP_ONLY: the jf_amlp2 instantiation (writes the parameter block, no flow) -- a kernel of its own so that profiles tell the two apart
 template <typename T, int G, int RM, bool MLP_ONLY>
@@ -287,6 +291,15 @@ static int amlp2(const T* in, int64_t in_stride, const T* V1, const T* U1, const
     a.in = in; a.in_stride = in_stride; a.V1 = V1; a.U1 = U1; a.b1 = b1; a.V2 = V2; a.U2 = U2; a.b2 = b2;
     a.K1 = K1; a.H = H; a.r1 = V1 ? r1 : 0; a.r2 = r2; a.N = N; a.B = B; a.D = 8; a.n_layers = 0;
     a.params_out = out; a.pos = out_stride;
+    if constexpr (sizeof(T) == 8) {                                // float64, ranks <= 8: matrix-core version (jf_amlp_mfma.h)
+        const size_t lds = am_lds_mlp_only(K1, H, V1 != nullptr, N) * sizeof(T);
+        if (r2 <= AM_R && (!V1 || r1 <= AM_R) && H % 16 == 0 && lds <= 160 * 1024) {
+            auto k = amlp2_mfma_kernel<AgArgs<T>>;
+            if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(k, dim3((unsigned)((B + AM_ROWS - 1) / AM_ROWS)), dim3(AM_THREADS), lds, (hipStream_t)stream, a);
+            return check_launch();
+        }
+    }
     return ag_launch<T>(a, 8, (hipStream_t)stream);
 }
 
@@ -320,6 +333,17 @@ static int amlp_gf_chain_inv(const T* in, int64_t in_stride, const T* V1, const 
     a.K1 = K1; a.H = H; a.r1 = V1 ? r1 : 0; a.r2 = r2; a.N = col;
     a.x = x; a.xs = xs; a.ld_in = ld_in; a.B = B; a.D = D; a.n_layers = n_layers;
     a.x_out = x_out; a.xos = xos; a.ld_out = ld_out; a.blp_in = blp_in; a.blp_out = blp_out; a.status = status;
+    if constexpr (sizeof(T) == 8) {
+        // float64 with ranks <= 8: the whole block as a chain of v_mfma_f64_16x16x4 products (jf_amlp_mfma.h) -- same arithmetic, 16x less LDS
+        // traffic; everything else (float32, larger ranks, odd hidden widths) stays on amlp_gf_kernel
+        const size_t lds = am_lds_doubles(K1, H, V1 != nullptr, n_layers) * sizeof(T);
+        if (r2 <= AM_R && (!V1 || r1 <= AM_R) && H % 16 == 0 && lds <= 160 * 1024) {
+            auto k = amlp_gf_mfma_kernel<AgArgs<T>>;
+            if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(k, dim3((unsigned)((B + AM_ROWS - 1) / AM_ROWS)), dim3(AM_THREADS), lds, (hipStream_t)stream, a);
+            return check_launch();
+        }
+    }
     return ag_launch<T>(a, D, (hipStream_t)stream);
 }
 

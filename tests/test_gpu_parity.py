@@ -571,3 +571,48 @@ def test_graphed_forward_replays_the_eager_path(name, dtype):
         bad[0, 0] = 1.5
         with pytest.raises(Exception):
             g(bad, conditional_input=c2)
+
+
+def _default_g_layers(D, n_layers, hh):
+    from jammy_flows_amd import _hip
+    arr = (_hip.jf_gf_layer * n_layers)()
+    for i in range(n_layers):
+        s = arr[i]
+        s.num_kde, s.hh_iter, s.model_offset, s.fit_normalization, s.regulate_normalization = 10, hh, 1 if i == n_layers - 1 else 0, 1, 1
+        s.inverse_function_type = _hip.GF_INV_TYPES["isigmoid" if i else "inormal_partly_precise"]
+        s.width_mode, s.clamp_widths, s.nonlinear_stretch_type = _hip.GF_WIDTH_SMOOTH, 0, _hip.GF_STRETCH_CLASSIC
+        s.width_min, s.width_max, s.norm_min, s.norm_max = 0.01, 100.0, 1.0, 10.0
+    return arr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32], ids=["f64", "f32"])
+@pytest.mark.parametrize("K1,H,r1,r2,D,L,hh", [(16, 128, 8, 8, 8, 4, 8), (5, 32, None, 3, 3, 2, 3), (24, 64, 4, 8, 5, 1, 2), (7, 16, 8, 1, 1, 3, 1),
+                                                (32, 128, None, 8, 8, 2, 0), (3, 48, 2, 5, 4, 2, 4)])
+def test_lowrank_block_kernels_vs_materialised_parameters(K1, H, r1, r2, D, L, hh, dtype):
+    """jf_amlp_gf_chain_inv / jf_amlp2 (float64 with ranks <= 8: the matrix-core kernels of jf_amlp_mfma.h, every other case: amlp_gf_kernel)
+    against the same block with its parameters materialised: the MLP in float64 torch arithmetic, then the plain g-chain kernel.  Shapes cover
+    low-rank and full first stages, ranks below 8, K1 not a multiple of 4, hidden widths 16 .. 128, D = 1 .. 8, rows not a multiple of 128."""
+    from jammy_flows_amd import _hip
+    gen = torch.Generator(device="cpu").manual_seed(11)
+    B = 1000
+    rn = lambda *s: torch.randn(*s, generator=gen, dtype=torch.float64)
+    N = L * (3 * 10 * D + hh * D) + D
+    inp, x = rn(B, K1), rn(B, D) * 1.5
+    v1 = None if r1 is None else rn(r1, K1) * 0.4
+    u1 = rn(H, K1 if r1 is None else r1) * 0.4
+    b1, v2, u2, b2 = rn(H) * 0.2, rn(r2, H) * 0.2, rn(N, r2) * 0.3, rn(N) * 0.5
+    w1 = u1 if v1 is None else u1 @ v1
+    params = (torch.tanh(inp @ w1.T + b1) @ v2.T) @ u2.T + b2
+    layers = _default_g_layers(D, L, hh)
+    ref_x, ref_ld = _hip.gf_chain("inv", x.cuda(), None, params.cuda(), layers, L, D)
+    dev = lambda t: None if t is None else t.to(device="cuda", dtype=dtype)
+    got_x, got_ld = _hip.amlp_gf_chain_inv(dev(inp), dev(v1), dev(u1), dev(b1), dev(v2), dev(u2), dev(b2), dev(x), None, layers, L, D)
+    got_p = _hip.amlp2(dev(inp), dev(v1), dev(u1), dev(b1), dev(v2), dev(u2), dev(b2))
+    if dtype == torch.float64:
+        assert float((got_p.cpu() - params).abs().max()) < 1e-11 * (1 + float(params.abs().max()))
+        assert max_rel(got_x, ref_x) < 1e-9 and max_rel(got_ld, ref_ld) < 1e-9
+    else:
+        assert float((got_p.double().cpu() - params).abs().max()) < 2e-5 * (1 + float(params.abs().max()))
+        ok = ref_ld.abs() < 1e3
+        assert float(((got_ld.double() - ref_ld).abs() / (1 + ref_ld.abs()))[ok].max()) < 1e-3
