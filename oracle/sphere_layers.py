@@ -97,8 +97,8 @@ class RLayer(_SplineParamMixin):
             h = np.concatenate([h, h[:, 0:1]], axis=1)
         if self.smooth == 0:
             if self.fix_bd > 0:
-                fl = np.ones(d.shape[:-1] + (1,)) * self.bd_fixed_value
-                d = np.concatenate([fl, d, fl], axis=-1)
+                fl = np.ones(w.shape[:-1] + (1,)) * self.bd_fixed_value
+                d = np.concatenate([fl, fl] if d is None else [fl, d, fl], axis=-1)      # one bin: both derivatives are the fixed ones
             y, lad, b = splines.rqs_plain(x, w, h, d, inverse, self.lo, self.hi, self.lo, self.hi,
                                           self.min_w, self.min_h, self.min_d, self.ratio)
         else:
@@ -204,8 +204,8 @@ class OLayer(_SphereLayer, _SplineParamMixin):
         w, h, d = self._unpack_whd(params)
         if self.smooth == 0:
             if self.fix_bd > 0.0:
-                fl = np.ones(d.shape[:-1] + (1,)) * self.bd_fixed_value
-                d = np.concatenate([fl, d, fl], axis=-1)
+                fl = np.ones(w.shape[:-1] + (1,)) * self.bd_fixed_value
+                d = np.concatenate([fl, fl] if d is None else [fl, d, fl], axis=-1)
             else:
                 d = np.concatenate([d, d[:, 0:1]], axis=-1)
             return splines.rqs_plain(x, w, h, d, use_inverse, 0.0, TWO_PI, 0.0, TWO_PI, self.min_w, self.min_h, self.min_d)

@@ -52,4 +52,42 @@ for seed in range(fz.N_CASES):
         print("seed %2d D %d pb %2d rows ok %d  inv %.2e  fwd %.2e  %s/%s%s%s" % (seed, D, pb, int(ok.sum()), e, e2, o["inverse_function_type"],
                                                                                     o["rotation_mode"], " skew" if o["add_skewness"] else "",
                                                                                     " center" if o["center_mean"] else ""))
-print("worst relative deviation oracle vs reference: %.3e" % worst)
+print("worst relative deviation oracle vs reference (g layer option products): %.3e" % worst)
+
+# ---- pdf-level cases of test_random_pdf_structures_and_options_vs_oracle: the reference pdf with the product's state_dict vs the oracle
+with contextlib.redirect_stdout(io.StringIO()):
+    import jammy_flows
+from oracle import OraclePdf
+worst = 0.0
+for seed in range(40):
+    rng, pdf_defs, flow_defs, kwargs, pdf = fz.build_fuzz_pdf(seed)
+    sd = {k: v.detach().clone() for k, v in pdf.state_dict().items()}
+    try:
+        with contextlib.redirect_stdout(io.StringIO()):
+            ref = jammy_flows.pdf(pdf_defs, flow_defs, **kwargs).double()
+        ref.load_state_dict(sd, strict=True)
+    except Exception as e:                                  # noqa: BLE001
+        print("seed %2d %s / %s: reference cannot construct / load: %s" % (seed, pdf_defs, flow_defs, repr(e)[:160]))
+        continue
+    oracle = OraclePdf(pdf_defs, flow_defs, state_dict={k: v.numpy() for k, v in sd.items()}, **kwargs)
+    B = 64
+    x = fz.domain_rows(pdf_defs, B, rng)
+    cond = rng.normal(size=(B, 2)) if "conditional_input_dim" in kwargs else None
+    tc = None if cond is None else torch.from_numpy(cond)
+    o_logp, _, o_base = oracle.forward(x, cond)
+    z = rng.normal(size=(B, pdf.total_base_dim))
+    o_x, o_slogp = oracle.sample_from_base(z, cond)[:2]
+    try:
+        with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()):
+            r_logp, _, r_base = ref(torch.from_numpy(x), conditional_input=tc)
+            r_x, _, r_slogp, _ = ref._obtain_sample(conditional_input=tc, predefined_target_input=torch.from_numpy(z).clone())
+    except Exception as e:                                  # noqa: BLE001
+        print("seed %2d %s / %s: reference raised %s" % (seed, pdf_defs, flow_defs, repr(e)[:160]))
+        continue
+    e1 = float((np.abs(r_logp.numpy() - o_logp) / (1 + np.abs(o_logp))).max())
+    e2 = float((np.abs(r_x.numpy() - o_x) / (1 + np.abs(o_x))).max())
+    e3 = float((np.abs(r_slogp.numpy() - o_slogp) / (1 + np.abs(o_slogp))).max())
+    if "v" not in flow_defs:
+        worst = max(worst, e1, e2, e3)
+    print("seed %2d %-22s %-10s %s logp %.2e  sample %.2e  sample logp %.2e" % (seed, pdf_defs, flow_defs, "cond" if cond is not None else "    ", e1, e2, e3))
+print("worst relative deviation oracle vs reference (pdf-level cases without 'v'): %.3e" % worst)
