@@ -222,14 +222,20 @@ __global__ void __launch_bounds__(256, 2) cond_gf_split_kernel(const CsArgs a) {
 
     // ---- chunk streaming: LDS-DMA (global_load_lds_dwordx4: 1 KiB per wave instruction, no register hop) into the buffer that is not being
     //      multiplied; wave w moves KiB pieces w, w + 4, ... of the chunk, the bias tail goes with the last piece of wave 0
+    // buffer form (buffer_load_dwordx4 ... offen lds): resource + per-lane byte offset are fixed for the whole kernel, the chunk / piece offset
+    // is a scalar -- no VALU address arithmetic per DMA instruction (the flat global_load_lds form spent ~8 vector integer instructions on each
+    // of its 64-bit addresses, 230 per layer)
+    const __amdgpu_buffer_rsrc_t packed_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(a.packed), 0, a.n_layers * CS_CPL * CS_CHUNK_BYTES, 0x00027000);
+    const int lane_off = wave * 1024 + lane * 16;
     auto dma = [&](int chunk) {
-        const unsigned char* g = a.packed + (size_t)chunk * CS_CHUNK_BYTES;
+        const int g = chunk * CS_CHUNK_BYTES;
         unsigned char* l = Ws0 + (chunk & 1) * CS_CHUNK_BYTES;
 #pragma unroll
         for (int u = 0; u < CS_W_BYTES / 4096; ++u)
-            __builtin_amdgcn_global_load_lds((cs_gptr)(g + (u * 4 + wave) * 1024 + lane * 16), (cs_lptr)(l + (u * 4 + wave) * 1024), 16, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(packed_rsrc, (cs_lptr)(l + (u * 4 + wave) * 1024), 16, lane_off, g + u * 4096, 0, 0);
         if (wave == 0 && lane < CS_B_BYTES / 16)
-            __builtin_amdgcn_global_load_lds((cs_gptr)(g + CS_W_BYTES + lane * 16), (cs_lptr)(l + CS_W_BYTES), 16, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(packed_rsrc, (cs_lptr)(l + CS_W_BYTES), 16, lane * 16, g + CS_W_BYTES, 0, 0);
     };
     dma(0);                                                        // lands in buffer 0 while phase 1 works in buffer 1
 
