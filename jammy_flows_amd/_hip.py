@@ -207,8 +207,17 @@ def require_device(*tensors):
     return dev
 
 
+_EMPTY_SENTINEL = 16     # see _ptr
+
+
 def _ptr(t):
-    return None if t is None else t.data_ptr()
+    """device address of a tensor for the C ABI; None = absent (NULL).  torch hands out a NULL data_ptr for zero-element tensors, which the C side
+    would read as "absent argument": an empty batch is passed as a non-null sentinel address instead -- never dereferenced, every entry point
+    returns JF_OK before touching memory when B == 0."""
+    if t is None:
+        return None
+    p = t.data_ptr()
+    return p if (p != 0 or t.numel() != 0) else _EMPTY_SENTINEL
 
 
 def _stream(dev=None):
@@ -540,7 +549,7 @@ def conditioning_rows(segments, B, dtype, device):
         if kind != 0 and t.shape[1] != kind:
             raise ValueError("conditioning_rows: an S%d segment needs %d intrinsic columns" % (kind, kind))
         keep.append(t)
-        arr[i] = jf_cond_segment(t.data_ptr(), t.stride(0), kind, t.shape[1])
+        arr[i] = jf_cond_segment(_ptr(t), t.stride(0), kind, t.shape[1])
         width += t.shape[1] if kind == 0 else kind + 1
     out = torch.empty((B, width), dtype=dtype, device=device)
     _launch("jf_conditioning_rows" + _suffix(out), "", (arr, len(segments), B, _ptr(out), out.stride(0)), dev)

@@ -616,3 +616,41 @@ def test_lowrank_block_kernels_vs_materialised_parameters(K1, H, r1, r2, D, L, h
         assert float((got_p.double().cpu() - params).abs().max()) < 2e-5 * (1 + float(params.abs().max()))
         ok = ref_ld.abs() < 1e3
         assert float(((got_ld.double() - ref_ld).abs() / (1 + ref_ld.abs()))[ok].max()) < 1e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,dtype", [("c3_e4s2e4", torch.float32), ("c3_e4s2e4", torch.float64), ("c5_e8s2_ggggv", torch.float64), ("c4_i1s1_ro", torch.float32),
+                                        ("g_e1e2e1_cond", torch.float64)])
+def test_ragged_and_strided_batches(name, dtype):
+    """rows are independent: every batch size (1, one below / at / above the kernels' tile sizes 16 / 64 / 128, odd sizes) returns exactly the
+    rows the full batch returns; inputs that are column slices of wider tensors (row stride != width) and an empty batch are handled."""
+    fx = [f for f in ALL_FIXTURES if f.name == name][0]
+    pdf = build_product(fx, dtype)
+    ok = float32_domain_mask(fx) if dtype == torch.float32 else np.ones(fx["x"].shape[0], dtype=bool)
+    keep = torch.from_numpy(np.nonzero(ok)[0]).cuda()
+    x = to_dev(fx["x"], dtype)[keep]
+    cond = to_dev(fx["cond"], dtype)[keep] if fx.get("cond") is not None else None
+    full = pdf(x, conditional_input=cond)
+    n = x.shape[0]
+    # the same rows through a differently sized launch may take another tiling of the dense kernels (summation order): equal to rounding
+    same = lambda a, f: torch.equal(a, f) or max_rel(a, f) < (1e-12 if dtype == torch.float64 else 2e-6)
+    for b in (1, 2, 15, 16, 17, 63, 64, 65, 127, 128, 129, n - 1):
+        if b > n:
+            continue
+        part = pdf(x[:b].contiguous(), conditional_input=None if cond is None else cond[:b].contiguous())
+        for a, f in zip(part, full):
+            assert same(a, f[:b]), (name, b)
+    wide = torch.zeros(n, x.shape[1] + 5, dtype=dtype, device="cuda")
+    wide[:, 2:2 + x.shape[1]] = x
+    xs = wide[:, 2:2 + x.shape[1]]                                  # row stride = width + 5
+    assert not xs.is_contiguous()
+    cs = None
+    if cond is not None:
+        cw = torch.zeros(n, cond.shape[1] + 3, dtype=dtype, device="cuda")
+        cw[:, 1:1 + cond.shape[1]] = cond
+        cs = cw[:, 1:1 + cond.shape[1]]
+    strided = pdf(xs, conditional_input=cs)
+    for a, f in zip(strided, full):
+        assert same(a, f), name
+    empty = pdf(x[:0], conditional_input=None if cond is None else cond[:0])
+    assert empty[0].shape == (0,) and empty[2].shape == (0, full[2].shape[1])
