@@ -654,3 +654,13 @@ def test_ragged_and_strided_batches(name, dtype):
         assert same(a, f), name
     empty = pdf(x[:0], conditional_input=None if cond is None else cond[:0])
     assert empty[0].shape == (0,) and empty[2].shape == (0, full[2].shape[1])
+    # sampling direction: the same for injected base points
+    if dtype == torch.float64:
+        z = to_dev(fx["z"], dtype)[keep]
+        sfull = pdf._obtain_sample(conditional_input=cond, predefined_target_input=z)
+        tol = LOOSE_SAMPLING.get(name, 1e-9)
+        for b in (1, 17, 64, 65):
+            part = pdf._obtain_sample(conditional_input=None if cond is None else cond[:b].contiguous(), predefined_target_input=z[:b].contiguous())
+            assert max_rel(part[0], sfull[0][:b]) < tol and max_rel(part[2], sfull[2][:b]) < tol, (name, b)
+        es = pdf._obtain_sample(conditional_input=None if cond is None else cond[:0], predefined_target_input=z[:0])
+        assert es[0].shape[0] == 0
