@@ -20,53 +20,79 @@ constexpr int JF_V_SPLINE_BINS = 10;    // exponential_map_s2.py:111 (num_spline
 // get_exp_map_and_jacobian (exponential_map_s2.py:248-442).  pp: (n_pot, nc) row-major for this lane; tab: the lane's spline knot table
 // (only touched by the "splines" potential: rows 4.. hold 10 widths, 10 heights, 11 derivatives per component, :346-388); oob: spline input
 // outside [-1, 1] (the reference raises, spline_fns.py:57-59)
-template <typename T> __device__ inline void v_exp_map(const T* __restrict__ pp, int nc, int kind, const T (&x)[3], ExpMapOut<T>& o, T* __restrict__ tab,
-                                                      bool& oob) {
-    const int w_row = 3, b_row = 4;
+//
+// Two stages (the backward kernel differentiates them separately, manifold_bwd_kernels.hip):
+//   v_potential       (parameters, x) -> g = grad phi (3), gj = its Jacobian (3 x 3): a sum over the components, cheap
+//   v_exp_geometry    (x, g, gj)      -> exp_x(g), its 3 x 3 Jacobian, 1/2 log det of the projected Jacobian: no parameters, the expensive part
+template <typename T> struct VPotential { T g[3]; T gj[3][3]; };
+
+// log-sum-exp of the components' log-weights (row 3)
+template <typename T> __device__ inline T v_lse(const T* __restrict__ pp, int nc) {
+    const int w_row = 3;
     T lmax = pp[w_row * nc];
     for (int k = 1; k < nc; ++k) lmax = M<T>::max(lmax, pp[w_row * nc + k]);
     T lse = T(0);
     for (int k = 0; k < nc; ++k) lse += M<T>::exp(pp[w_row * nc + k] - lmax);
-    lse = lmax + M<T>::log(lse);
-    T g[3] = {T(0), T(0), T(0)};
-    T gj[3][3] = {{T(0), T(0), T(0)}, {T(0), T(0), T(0)}, {T(0), T(0), T(0)}};
-    for (int k = 0; k < nc; ++k) {
-        const T m0 = pp[k], m1 = pp[nc + k], m2 = pp[2 * nc + k];
-        const T nrm = M<T>::sqrt(m0 * m0 + m1 * m1 + m2 * m2);
-        const T mu[3] = {m0 / nrm, m1 / nrm, m2 / nrm};
-        const T w = M<T>::exp(pp[w_row * nc + k] - lse + M<T>::log(v_mu_norm<T>(nrm)));                 // :288-289
-        const T xmu = x[0] * mu[0] + x[1] * mu[1] + x[2] * mu[2];
-        T f, fp;   // grad contribution w * mu * f, Jacobian contribution w * fp * mu mu^T
-        if (kind == JF_V_EXPONENTIAL) {
-            const T beta = M<T>::exp(pp[b_row * nc + k]);
-            f = M<T>::exp(beta * (xmu - T(1)));                                                    // :301
-            fp = beta * f;                                                                       // :306
-        } else if (kind == JF_V_LINEAR) {
-            f = T(1); fp = T(0);
-        } else if (kind == JF_V_SPLINES) {
-            // the potential's derivative is a monotone rational-quadratic spline [-1, 1] -> [-1, 1] of mu . x (rational_quadratic_spline with
-            // rel_min_bin_width = rel_min_bin_height = min_derivative = 1e-3, :354-362); f = spline value, f' = exp(logabsdet)
-            constexpr int NB = JF_V_SPLINE_BINS;
-            KnotTab<T> t(tab);
-            for (int j = 0; j < NB; ++j) { t.cw[j] = pp[(4 + j) * nc + k]; t.ch[j] = pp[(4 + NB + j) * nc + k]; }
-            for (int j = 0; j <= NB; ++j) t.d[j] = T(1e-3) + softplus<T>(pp[(4 + 2 * NB + j) * nc + k]);
-            spline_cum_knots<T>(t.cw, NB, T(-1), T(1), T(1e-3), true);
-            spline_cum_knots<T>(t.ch, NB, T(-1), T(1), T(1e-3), true);
-            oob = oob || (xmu < T(-1)) || (xmu > T(1));
-            int b = spline_search<T>(t.cw, NB, xmu, T(1e-6));
-            b = b < 0 ? 0 : (b > NB - 1 ? NB - 1 : b);
-            const SplineOut<T> r = spline_core<T>(t, b, xmu, false);
-            f = r.y; fp = M<T>::exp(r.lad);
-        } else {
-            f = xmu; fp = T(1);                                                                  // :332-335
-        }
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            g[i] += w * mu[i] * f;
-#pragma unroll
-            for (int j = 0; j < 3; ++j) gj[i][j] += w * fp * mu[i] * mu[j];
-        }
+    return lmax + M<T>::log(lse);
+}
+
+// component k's term of grad phi and of its Jacobian, ADDED to P (the weight normaliser lse is an input: the backward kernel differentiates a
+// single component with lse held fixed and adds the softmax coupling in closed form)
+template <typename T> __device__ inline void v_component(const T* __restrict__ pp, int nc, int k, int kind, T lse, const T (&x)[3], VPotential<T>& P,
+                                                        T* __restrict__ tab, bool& oob) {
+    const int w_row = 3, b_row = 4;
+    const T m0 = pp[k], m1 = pp[nc + k], m2 = pp[2 * nc + k];
+    const T nrm = M<T>::sqrt(m0 * m0 + m1 * m1 + m2 * m2);
+    const T mu[3] = {m0 / nrm, m1 / nrm, m2 / nrm};
+    const T w = M<T>::exp(pp[w_row * nc + k] - lse + M<T>::log(v_mu_norm<T>(nrm)));                 // :288-289
+    const T xmu = x[0] * mu[0] + x[1] * mu[1] + x[2] * mu[2];
+    T f, fp;   // grad contribution w * mu * f, Jacobian contribution w * fp * mu mu^T
+    if (kind == JF_V_EXPONENTIAL) {
+        const T beta = M<T>::exp(pp[b_row * nc + k]);
+        f = M<T>::exp(beta * (xmu - T(1)));                                                    // :301
+        fp = beta * f;                                                                       // :306
+    } else if (kind == JF_V_LINEAR) {
+        f = T(1); fp = T(0);
+    } else if (kind == JF_V_SPLINES) {
+        // the potential's derivative is a monotone rational-quadratic spline [-1, 1] -> [-1, 1] of mu . x (rational_quadratic_spline with
+        // rel_min_bin_width = rel_min_bin_height = min_derivative = 1e-3, :354-362); f = spline value, f' = exp(logabsdet)
+        constexpr int NB = JF_V_SPLINE_BINS;
+        KnotTab<T> t(tab);
+        for (int j = 0; j < NB; ++j) { t.cw[j] = pp[(4 + j) * nc + k]; t.ch[j] = pp[(4 + NB + j) * nc + k]; }
+        for (int j = 0; j <= NB; ++j) t.d[j] = T(1e-3) + softplus<T>(pp[(4 + 2 * NB + j) * nc + k]);
+        spline_cum_knots<T>(t.cw, NB, T(-1), T(1), T(1e-3), true);
+        spline_cum_knots<T>(t.ch, NB, T(-1), T(1), T(1e-3), true);
+        oob = oob || (xmu < T(-1)) || (xmu > T(1));
+        int b = spline_search<T>(t.cw, NB, xmu, T(1e-6));
+        b = b < 0 ? 0 : (b > NB - 1 ? NB - 1 : b);
+        const SplineOut<T> r = spline_core<T>(t, b, xmu, false);
+        f = r.y; fp = M<T>::exp(r.lad);
+    } else {
+        f = xmu; fp = T(1);                                                                  // :332-335
     }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        P.g[i] += w * mu[i] * f;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) P.gj[i][j] += w * fp * mu[i] * mu[j];
+    }
+}
+
+template <typename T> __device__ inline void v_potential(const T* __restrict__ pp, int nc, int kind, const T (&x)[3], VPotential<T>& P, T* __restrict__ tab,
+                                                        bool& oob) {
+    const T lse = v_lse<T>(pp, nc);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        P.g[i] = T(0);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) P.gj[i][j] = T(0);
+    }
+    for (int k = 0; k < nc; ++k) v_component<T>(pp, nc, k, kind, lse, x, P, tab, oob);
+}
+
+template <typename T> __device__ inline void v_exp_geometry(int kind, const T (&x)[3], const VPotential<T>& P, ExpMapOut<T>& o) {
+    const T (&g)[3] = P.g;
+    const T (&gj)[3][3] = P.gj;
     // unnormalized_logarithmic_map with Jacobians (:163-219)
     const T tn = M<T>::sqrt(g[0] * g[0] + g[1] * g[1] + g[2] * g[2]);
     T nt[3], tv[3];
@@ -136,6 +162,13 @@ template <typename T> __device__ inline void v_exp_map(const T* __restrict__ pp,
     o.logdet_half = T(0.5) * M<T>::log(M<T>::abs(a11 * a22 - a12 * a12));
 }
 
+template <typename T> __device__ inline void v_exp_map(const T* __restrict__ pp, int nc, int kind, const T (&x)[3], ExpMapOut<T>& o, T* __restrict__ tab,
+                                                      bool& oob) {
+    VPotential<T> P;
+    v_potential<T>(pp, nc, kind, x, P, tab, oob);
+    v_exp_geometry<T>(kind, x, P, o);
+}
+
 // basic_logarithmic_map (exponential_map_s2.py:221-244): unit tangent at `base` towards `target`, angle alpha (0 when already there)
 template <typename T> __device__ __forceinline__ void v_log_map(const T (&base)[3], const T (&target)[3], T (&tv)[3], T& alpha) {
     T ca = target[0] * base[0] + target[1] * base[1] + target[2] * base[2];
@@ -193,6 +226,22 @@ struct VFam {
     static __host__ int n_bins(const CLayer&) { return 0; }
     static __host__ bool needs_tab(const CLayer& L) { return L.exp_map_type == JF_V_SPLINES; }
 
+    // the two ends of the log-prob direction around the exponential map (exponential_map_s2.py:446-487): rotation + angles -> embedding, and
+    // embedding -> angles (+ the first layer's chart).  Separate functions because the backward kernel differentiates the three stages apart.
+    template <typename T> static __device__ __forceinline__ void inv_pre(const CLayer& L, const T* __restrict__ p, T (&x)[3], T& ld, T (&e)[3]) {
+        if (L.hh_iter != 0) s2_rotate<T>(p, L.hh_iter, x, ld, true);
+        s2_to_eucl<T>(x[0], x[1], e, ld);
+    }
+    template <typename T> static __device__ __forceinline__ void inv_post(const CLayer& L, const T (&y)[3], T (&x)[3], T& ld) {
+        T th, ph;
+        eucl_to_s2<T>(y, th, ph, ld);
+        if (L.first) {
+            T pl[3];
+            s2_to_plane<T>(th, ph, pl, ld);
+            x[0] = pl[0]; x[1] = pl[1];
+        } else { x[0] = th; x[1] = ph; }
+    }
+
     template <typename T, bool FWD> static __device__ __forceinline__ void apply(const CLayer& L, const T* __restrict__ p, T (&x)[3], T& ld, LaneCtx<T>& c) {
         const T* pp = p + rot_len(L.hh_iter, 3);
         bool oob = false;
@@ -222,8 +271,7 @@ struct VFam {
             x[0] = th; x[1] = ph;
             if (L.hh_iter != 0) s2_rotate<T>(p, L.hh_iter, x, ld, false);
         } else {
-            if (L.hh_iter != 0) s2_rotate<T>(p, L.hh_iter, x, ld, true);
-            s2_to_eucl<T>(x[0], x[1], e, ld);                                        // :459-460
+            inv_pre<T>(L, p, x, ld, e);                                              // :459-460
             if (L.natural_direction) {
                 T r[3];
                 v_newton<T>(pp, nc, kind, e, L.max_newton_iter, false, c.lane_valid, r, c.tab, oob);
@@ -237,12 +285,7 @@ struct VFam {
 #pragma unroll
                 for (int i = 0; i < 3; ++i) e[i] = o.y[i];
             }
-            eucl_to_s2<T>(e, th, ph, ld);
-            if (L.first) {
-                T pl[3];
-                s2_to_plane<T>(th, ph, pl, ld);
-                x[0] = pl[0]; x[1] = pl[1];
-            } else { x[0] = th; x[1] = ph; }
+            inv_post<T>(L, e, x, ld);
         }
         bool bad = !M<T>::finite(x[0]) || !M<T>::finite(x[1]);
         c.nonfinite = c.nonfinite || bad;

@@ -34,6 +34,11 @@ template <typename T, typename CLayer> struct MBwdArgs {
     int32_t* status;
 };
 
+__device__ __forceinline__ int VFam_row_len_dev(const jf_v_layer& L) {
+    const int n_pot = L.exp_map_type == JF_V_SPLINES ? 4 + 3 * JF_V_SPLINE_BINS + 1 : 3 + (L.exp_map_type == JF_V_EXPONENTIAL ? 2 : 1);
+    return rot_len(L.hh_iter, 3) + n_pot * L.num_components;
+}
+
 template <typename T> __device__ __forceinline__ T wave_sum(T v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
@@ -122,6 +127,193 @@ __global__ void __launch_bounds__(64) mchain_bwd_kernel(const MBwdArgs<T, typena
     status_add(a.status, JF_STATUS_NONFINITE, active && bad);
 }
 
+// ---------------------------------------------------------------------------------------------------------- 'v' chains, staged
+// The exponential-map layer (natural_direction 0, the default: log-prob direction = one direct evaluation) factors into
+//     pre  : (x, rotation parameters) -> e in R^3                       (rotation, angles -> embedding; cheap)
+//     pot  : (e, potential parameters) -> u = (grad phi (3), its Jacobian (3 x 3))          (a sum over the components; cheap)
+//     geo  : (e, u) -> exp_e(grad phi), 1/2 log det of the projected Jacobian               (no parameters; the expensive part)
+//     post : embedding -> angles (+ chart of the first layer)                               (cheap)
+// The generic kernel above replays ALL of it once per input direction: 2 + 50 passes for the default layer.  Here the expensive stages are
+// replayed only for the 15 directions of (e, u), which gives G = d S / d (e, u) for the upstream-contracted objective S; the parameters and
+// the layer's input then need only pre + pot on dual numbers, contracted with G (chain rule through the 15 intermediates).  Layers of a
+// chain are walked in reverse with the (2 + 1)-component upstream gradient, after one forward sweep that records every layer's input.
+template <typename T>
+__global__ void __launch_bounds__(64) vchain_bwd_kernel(const MBwdArgs<T, jf_v_layer> a) {
+    using Du = Dual<T>;
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    Du* tile = reinterpret_cast<Du*>(smem_raw);
+    const int tid = threadIdx.x;
+    const int rows = a.rows;
+    const int tile_rows = a.bcast ? 1 : rows;
+    const bool lane_in = tid < rows;
+    const int slot = lane_in ? tid : 0;
+    Du* tab = tile + tile_rows * a.tile_stride + slot * JF_SPLINE_TAB;
+    // lane-private scratch in LDS (dynamic indexing without scratch memory): every layer's input (2 per layer) and G (15)
+    T* lane_mem = reinterpret_cast<T*>(tile + tile_rows * a.tile_stride + rows * JF_SPLINE_TAB + slot * a.scratch);
+    T* xin = lane_mem;                                             // [layer][2]
+    T* G = lane_mem + 2 * JF_MAX_MCHAIN;                           // [15]
+    const int64_t row0 = (int64_t)blockIdx.x * rows;
+    const int64_t row = row0 + tid;
+    const bool active = lane_in && row < a.B;
+    const int64_t rrow = active ? row : a.B - 1;
+    if (a.bcast) {
+        for (int j = tid; j < a.P; j += 64) tile[j] = Du(a.params[j]);
+    } else {
+        for (int r = 0; r < rows; ++r) {
+            const int64_t gr = (row0 + r) < a.B ? (row0 + r) : a.B - 1;
+            for (int j = tid; j < a.P; j += 64) tile[r * a.tile_stride + j] = Du(a.params[gr * a.ps + j]);
+        }
+    }
+    __syncthreads();
+    Du* prow = tile + (a.bcast ? 0 : slot * a.tile_stride);
+    const T gld = (a.g_ld && active) ? a.g_ld[rrow] : T(0);
+    const T gblp = (a.g_blp && active) ? a.g_blp[rrow] : T(0);
+    bool oob = false;
+
+    // ---- forward sweep (values only): the input of every layer, the chain's output
+    T up[2];                                                       // d S / d (x after the layer being differentiated)
+    {
+        Du x[3] = {Du(a.x[rrow * a.xs + 0]), Du(a.x[rrow * a.xs + 1]), Du(T(0))};
+        Du ld(T(0));
+        LaneCtx<Du> ctx;
+        ctx.tab = tab; ctx.corr = nullptr; ctx.bins = nullptr; ctx.bin_i = 0;
+        ctx.oob = ctx.nonconv = ctx.nonfinite = false;
+        ctx.lane_valid = active;
+#pragma unroll 1
+        for (int l = a.n_layers - 1; l >= 0; --l) {
+            if (lane_in) { xin[2 * l] = x[0].v; xin[2 * l + 1] = x[1].v; }      // (lanes beyond `rows` share slot 0: they must not write)
+            if (lane_in) VFam::template apply<Du, false>(a.L[l], prow + a.col0[l], x, ld, ctx);
+        }
+        up[0] = ((a.g_xout && active) ? a.g_xout[rrow * a.gxos + 0] : T(0)) - x[0].v * gblp;
+        up[1] = ((a.g_xout && active) ? a.g_xout[rrow * a.gxos + 1] : T(0)) - x[1].v * gblp;
+    }
+
+    bool bad = false;
+#pragma unroll 1
+    for (int l = 0; l < a.n_layers; ++l) {                        // reverse of the order of application (layer n-1 is applied first)
+        {
+            const jf_v_layer L = a.L[l];
+            Du* p = prow + a.col0[l];
+            const Du* pp = p + rot_len(L.hh_iter, 3);
+            const int nc = L.num_components, kind = L.exp_map_type;
+            // values of the intermediates at this layer's input
+            T e0[3];
+            VPotential<T> P0;
+            {
+                Du x[3] = {Du(xin[2 * l]), Du(xin[2 * l + 1]), Du(T(0))};
+                Du ld(T(0)), e[3];
+                VPotential<Du> P;
+                if (lane_in) {
+                    VFam::template inv_pre<Du>(L, p, x, ld, e);
+                    v_potential<Du>(pp, nc, kind, e, P, tab, oob);
+                }
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    e0[i] = e[i].v; P0.g[i] = P.g[i].v;
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) P0.gj[i][j] = P.gj[i][j].v;
+                }
+            }
+            // (1) the expensive stages on the 15 directions of (e, g, gj):  G[i] = d S / d u_i
+#pragma unroll 1
+            for (int i = 0; i < 15; ++i) {
+                Du e[3];
+                VPotential<Du> P;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    e[c] = Du(e0[c], i == c ? T(1) : T(0));
+                    P.g[c] = Du(P0.g[c], i == 3 + c ? T(1) : T(0));
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) P.gj[c][d] = Du(P0.gj[c][d], i == 6 + 3 * c + d ? T(1) : T(0));
+                }
+                ExpMapOut<Du> o;
+                Du x[3], ld(T(0));
+                if (lane_in) {
+                    v_exp_geometry<Du>(kind, e, P, o);
+                    ld = ld + o.logdet_half;
+                    VFam::template inv_post<Du>(L, o.y, x, ld);
+                }
+                if (lane_in) G[i] = up[0] * x[0].d + up[1] * x[1].d + gld * ld.d;
+            }
+            // (2) the cheap stages, contracted with G.  Directions that move e (the layer's input, the rotation parameters) need the whole
+            //     potential on dual numbers; a potential parameter belongs to ONE component, whose term alone carries a tangent -- except the
+            //     log-weights, whose softmax normaliser couples all components: d w_m / d lw_k = w_m (delta_mk - s_k), i.e. the single-component
+            //     tangent (normaliser held fixed) minus s_k times the totals.
+            const int n_rot = rot_len(L.hh_iter, 3);
+            const int n_row = VFam_row_len_dev(L);
+            const T lse0 = lane_in ? v_lse<Du>(pp, nc).v : T(0);
+            T GP0 = T(0);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                GP0 += G[3 + c] * P0.g[c];
+#pragma unroll
+                for (int d = 0; d < 3; ++d) GP0 += G[6 + 3 * c + d] * P0.gj[c][d];
+            }
+            T nup[2] = {T(0), T(0)};
+            for (int j = 0; j < 2 + n_row; ++j) {
+                if (j >= 2) {
+                    if (a.bcast) { if (tid == 0) p[j - 2].d = T(1); }
+                    else if (lane_in) p[j - 2].d = T(1);
+                }
+                __syncthreads();
+                T gj_ = T(0);
+                if (j < 2 + n_rot) {
+                    Du x[3] = {Du(xin[2 * l], j == 0 ? T(1) : T(0)), Du(xin[2 * l + 1], j == 1 ? T(1) : T(0)), Du(T(0))};
+                    Du ld(T(0)), e[3];
+                    VPotential<Du> P;
+                    if (lane_in) {
+                        VFam::template inv_pre<Du>(L, p, x, ld, e);
+                        v_potential<Du>(pp, nc, kind, e, P, tab, oob);
+                    }
+                    gj_ = gld * ld.d;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        gj_ += G[c] * e[c].d + G[3 + c] * P.g[c].d;
+#pragma unroll
+                        for (int d = 0; d < 3; ++d) gj_ += G[6 + 3 * c + d] * P.gj[c][d].d;
+                    }
+                } else {
+                    const int jp = j - 2 - n_rot, k = jp % nc, prow_i = jp / nc;
+                    const Du e[3] = {Du(e0[0]), Du(e0[1]), Du(e0[2])};
+                    VPotential<Du> P;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        P.g[c] = Du(T(0));
+#pragma unroll
+                        for (int d = 0; d < 3; ++d) P.gj[c][d] = Du(T(0));
+                    }
+                    if (lane_in) v_component<Du>(pp, nc, k, kind, Du(lse0), e, P, tab, oob);
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        gj_ += G[3 + c] * P.g[c].d;
+#pragma unroll
+                        for (int d = 0; d < 3; ++d) gj_ += G[6 + 3 * c + d] * P.gj[c][d].d;
+                    }
+                    if (prow_i == 3 && lane_in) gj_ -= M<T>::exp(pp[3 * nc + k].v - lse0) * GP0;       // softmax coupling of the log-weights
+                }
+                if (!active) gj_ = T(0);
+                bad = bad || !M<T>::finite(gj_);
+                if (j < 2) {
+                    nup[j] = gj_;
+                } else if (a.bcast) {
+                    const T s = wave_sum<T>(gj_);
+                    if (tid == 0) atomicAdd(a.g_params + a.col0[l] + (j - 2), s);
+                } else if (active) {
+                    a.g_params[row * a.gps + a.col0[l] + (j - 2)] = gj_;
+                }
+                __syncthreads();
+                if (j >= 2) {
+                    if (a.bcast) { if (tid == 0) p[j - 2].d = T(0); }
+                    else if (lane_in) p[j - 2].d = T(0);
+                }
+            }
+            up[0] = nup[0]; up[1] = nup[1];
+        }
+    }
+    if (active) { a.g_x[row * a.gxs + 0] = up[0]; a.g_x[row * a.gxs + 1] = up[1]; }
+    status_add(a.status, JF_STATUS_NONFINITE, active && bad);
+}
+
 template <typename T, class Fam>
 static int mchain_bwd(const T* x, int64_t xs, const T* params, int64_t ps, int32_t pb, int64_t B, int32_t n_layers, const typename Fam::CLayer* layers,
                       const T* g_xout, int64_t gxos, const T* g_ld, const T* g_blp, T* g_x, int64_t gxs, T* g_params, int64_t gps, int32_t* status,
@@ -151,6 +343,12 @@ static int mchain_bwd(const T* x, int64_t xs, const T* params, int64_t ps, int32
             a.scratch = JF_CORR_SCRATCH;
         }
     }
+    bool staged = false;
+    if constexpr (std::is_same<Fam, VFam>::value) {               // all layers in the default direction: the staged kernel (15 + cheap passes)
+        staged = true;
+        for (int l = 0; l < n_layers; ++l) staged = staged && layers[l].natural_direction == 0;
+        if (staged) a.scratch = (2 * JF_MAX_MCHAIN + 15 + 1) / 2;  // lane-private doubles, counted in Dual<T> units
+    }
     a.rows = 64;
     size_t lds = 0;
     for (;;) {
@@ -159,6 +357,14 @@ static int mchain_bwd(const T* x, int64_t xs, const T* params, int64_t ps, int32
         a.rows >>= 1;
     }
     if (lds > 160 * 1024) return JF_ERR_UNSUPPORTED;
+    if constexpr (std::is_same<Fam, VFam>::value) {
+        if (staged) {
+            auto kv = vchain_bwd_kernel<T>;
+            if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)kv, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(kv, dim3((unsigned)((B + a.rows - 1) / a.rows)), dim3(64), lds, (hipStream_t)stream, a);
+            return check_launch();
+        }
+    }
     auto k = mchain_bwd_kernel<T, Fam>;
     if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k, dim3((unsigned)((B + a.rows - 1) / a.rows)), dim3(64), lds, (hipStream_t)stream, a);
