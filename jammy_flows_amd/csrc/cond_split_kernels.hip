@@ -322,27 +322,34 @@ __global__ void __launch_bounds__(256, 2) cond_gf_split_kernel(const CsArgs a) {
             f32x4 acc[CS_CT];
 #pragma unroll
             for (int t = 0; t < CS_CT; ++t) acc[t] = *reinterpret_cast<const f32x4*>(Bs + t * 16 + 4 * lq);    // bias of columns 4 lq .. 4 lq + 3
-#pragma unroll
-            for (int s = 0; s < CS_KSTEPS; ++s) {
-                bf16x8 A[CS_CT][CS_NP];
+            // A fragments one k-step ahead of the MFMAs that consume them (the LDS latency of a k-step's 9 reads hides behind the previous
+            // k-step's 18 MFMAs instead of being waited for in front of each MFMA)
+            bf16x8 A[2][CS_CT][CS_NP];
+            auto load_a = [&](int s, int buf) {
 #pragma unroll
                 for (int t = 0; t < CS_CT; ++t)
 #pragma unroll
                     for (int p = 0; p < CS_NP; ++p)
-                        A[t][p] = *reinterpret_cast<const bf16x8*>(Ws + ((t * CS_KSTEPS + s) * CS_NP + p) * CS_FRAG + lane * 16);
+                        A[buf][t][p] = *reinterpret_cast<const bf16x8*>(Ws + ((t * CS_KSTEPS + s) * CS_NP + p) * CS_FRAG + lane * 16);
+            };
+            load_a(0, 0);
+#pragma unroll
+            for (int s = 0; s < CS_KSTEPS; ++s) {
+                const int b = s & 1;
+                if (s + 1 < CS_KSTEPS) load_a(s + 1, b ^ 1);
                 // products with piece indices pa + pb <= 2, smallest first
 #pragma unroll
-                for (int t = 0; t < CS_CT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[t][2], hB[s][0], acc[t], 0, 0, 0);
+                for (int t = 0; t < CS_CT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[b][t][2], hB[s][0], acc[t], 0, 0, 0);
 #pragma unroll
-                for (int t = 0; t < CS_CT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[t][1], hB[s][1], acc[t], 0, 0, 0);
+                for (int t = 0; t < CS_CT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[b][t][1], hB[s][1], acc[t], 0, 0, 0);
 #pragma unroll
-                for (int t = 0; t < CS_CT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[t][0], hB[s][2], acc[t], 0, 0, 0);
+                for (int t = 0; t < CS_CT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[b][t][0], hB[s][2], acc[t], 0, 0, 0);
 #pragma unroll
-                for (int t = 0; t < CS_CT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[t][1], hB[s][0], acc[t], 0, 0, 0);
+                for (int t = 0; t < CS_CT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[b][t][1], hB[s][0], acc[t], 0, 0, 0);
 #pragma unroll
-                for (int t = 0; t < CS_CT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[t][0], hB[s][1], acc[t], 0, 0, 0);
+                for (int t = 0; t < CS_CT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[b][t][0], hB[s][1], acc[t], 0, 0, 0);
 #pragma unroll
-                for (int t = 0; t < CS_CT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[t][0], hB[s][0], acc[t], 0, 0, 0);
+                for (int t = 0; t < CS_CT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[b][t][0], hB[s][0], acc[t], 0, 0, 0);
             }
 #pragma unroll
             for (int t = 0; t < CS_CT; ++t)
