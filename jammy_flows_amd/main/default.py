@@ -500,7 +500,8 @@ class pdf(nn.Module):
             return None
         # measured on 2^20 rows (scripts/bench_configs.py): the one-launch form wins for float32 'f' blocks (0.146 ms vs 0.16 + 0.05 ms); for the
         # 'r' / 'o' / 'm' families and for float64 the two launches (resident narrow-output jf_mlp2 + chain) are faster (f64 'o': 0.48 vs 0.96 ms)
-        if not (fam == "f" and dtype == torch.float32) and not self.force_fused_manifold_blocks:
+        plain_f = fam == "f" and not any(l._vertical or l._circular for l in layers)      # with nested spline flows: 0.57 vs 0.21 + 0.28 ms
+        if not (plain_f and dtype == torch.float32) and not self.force_fused_manifold_blocks:
             return None
         if mlp[0].in_features > _hip.COND_GF_MAX_IN or mlp[0].out_features > _hip.COND_GF_MAX_HIDDEN or mlp[2].out_features > _hip.COND_MCHAIN_MAX_PARAMS:
             return None
