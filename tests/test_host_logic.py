@@ -106,3 +106,28 @@ def test_unsupported_things_fail_loudly():
     assert [l.total_param_num for l in p.layer_list[0]] == [1 + 18 + 60, 2 + 1 + 18 + 60] and all(l.has_extended_options for l in p.layer_list[0])
     with pytest.raises(NotImplementedError):
         jammy_flows_amd.pdf("e2", "gg", predict_log_normalization=True)
+
+
+def test_data_init_host_math_matches_the_oracle():
+    """the host-side pieces of init_params(data=...) (init_fns.py: Householder product, 't' lower-triangular matrix at default width options,
+    reverse-KL loss) against the oracle's restatements of the same reference functions"""
+    from jammy_flows_amd import init_fns
+    from oracle import mvn as omvn
+    from oracle.special import householder_matrix
+    rng = np.random.default_rng(3)
+    for D, n_iter in ((2, 2), (3, 3), (5, 2)):
+        vs = rng.normal(size=(n_iter, D))
+        assert np.abs(init_fns._householder_matrix(vs) - householder_matrix(vs[None])[0]).max() < 1e-13
+    for D, cov in ((3, "full"), (4, "diagonal"), (2, "diagonal_symmetric")):
+        n = {"full": D + D * (D - 1) // 2, "diagonal": D, "diagonal_symmetric": 1}[cov]
+        a = rng.normal(size=n)
+        spec = omvn.TSpec(D, {"cov_type": cov, "softplus_for_width": 0, "width_smooth_saturation": 1, "lower_bound_for_widths": 0.01,
+                              "upper_bound_for_widths": 100, "clamp_widths": 0, "skip_model_offset": 0}, 0)
+        L = init_fns._mvn_lower_triangular(D, a, cov)
+        # the oracle applies L to base points in the sampling direction: x = L z
+        z = rng.normal(size=(7, D))
+        x, ld = omvn.forward(spec, z, np.zeros(7), a[None, :])[:2]
+        assert np.abs(z @ L.T - x).max() < 1e-12, cov
+        assert np.abs(ld - np.log(np.abs(np.linalg.det(L)))).max() < 1e-12, cov
+        target = L @ L.T
+        assert abs(init_fns._mvn_loss(target, cov)(a)) < 1e-10          # reverse KL of a distribution with itself
