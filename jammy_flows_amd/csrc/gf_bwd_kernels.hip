@@ -117,9 +117,18 @@ template <typename T> __device__ __forceinline__ void gf_inv_width_grad(const Gf
 // ACC: add into the gradient row (broadcast regime: rows of the tile share it) instead of overwriting.
 template <typename T, int G, bool ACC>
 __device__ __forceinline__ T gf_layer_bwd(const T* __restrict__ p, T* __restrict__ gp, const GfLayerDev<T>& o, int D, bool live, T x_in, T gy, T gl) {
+    // ACC (broadcast parameters): the rows of a wave that share this lane's coordinate all add to the SAME accumulator -- one LDS atomic per
+    // lane would serialise 64 / G ways on that address.  The wave sums over its rows first (butterfly over the lanes with equal lane % G), then
+    // one lane per coordinate adds.  Every lane takes part in the shuffles (put is only called under wave-uniform conditions).
     auto put = [&](int off, T v) {
-        if (!live) return;
-        if constexpr (ACC) atomicAdd(gp + off, v); else gp[off] = v;
+        if constexpr (ACC) {
+            T s = live ? v : T(0);
+#pragma unroll
+            for (int sh = G; sh < 64; sh <<= 1) s += __shfl_xor(s, sh, 64);
+            if (live && (int)(threadIdx.x & 63) < G) atomicAdd(gp + off, s);
+        } else {
+            if (live) gp[off] = v;
+        }
     };
     // ---- recompute: offset, reflections (keeping the vector before each one), mixture
     T xr[GB_MAX_HH];

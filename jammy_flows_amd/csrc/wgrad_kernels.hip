@@ -40,21 +40,36 @@ __global__ void __launch_bounds__(64) wgrad_kernel(const T* __restrict__ g, int6
     T bsum[NA];
 #pragma unroll
     for (int a = 0; a < NA; ++a) bsum[a] = T(0);
-    for (int64_t b = b0; b < b1; b += KS) {
+    // operands of step i + 1 are requested before the MFMAs of step i are issued (one step = 6 dependent-free loads and 8 MFMAs for the widest
+    // shape: without the prefetch every step waited a full HBM round trip in front of its MFMAs)
+    T av[NA], bv[KT], an[NA], bn[KT];
+    auto fetch = [&](int64_t b, T (&a_)[NA], T (&b_)[KT]) {
         const int64_t row = b + slot;
         const bool valid = row < b1;
-        const int64_t rr = valid ? row : b1 - 1;
-        T av[NA], bv[KT];
+        const int64_t rr = valid ? row : (b1 > b0 ? b1 - 1 : 0);
 #pragma unroll
-        for (int a = 0; a < NA; ++a) av[a] = g[rr * gs + nidx[a]];
+        for (int a = 0; a < NA; ++a) a_[a] = g[rr * gs + nidx[a]];
 #pragma unroll
-        for (int t = 0; t < KT; ++t) bv[t] = in[rr * is + kidx[t]];
+        for (int t = 0; t < KT; ++t) b_[t] = in[rr * is + kidx[t]];
 #pragma unroll
-        for (int a = 0; a < NA; ++a) { av[a] = valid ? av[a] : T(0); bsum[a] += av[a]; }
+        for (int a = 0; a < NA; ++a) a_[a] = valid ? a_[a] : T(0);
+    };
+    if (b0 < b1) fetch(b0, av, bv);
+    for (int64_t b = b0; b < b1; b += KS) {
+        const bool more = b + KS < b1;
+        if (more) fetch(b + KS, an, bn);
+#pragma unroll
+        for (int a = 0; a < NA; ++a) bsum[a] += av[a];
 #pragma unroll
         for (int a = 0; a < NA; ++a)
 #pragma unroll
             for (int t = 0; t < KT; ++t) acc[a][t] = MM::mma(av[a], bv[t], acc[a][t]);
+        if (more) {
+#pragma unroll
+            for (int a = 0; a < NA; ++a) av[a] = an[a];
+#pragma unroll
+            for (int t = 0; t < KT; ++t) bv[t] = bn[t];
+        }
     }
     T* slab = pw + (int64_t)blockIdx.y * N * K;
 #pragma unroll
@@ -84,7 +99,7 @@ template <typename T> static int wgrad_na(int32_t N) { return N > Mfma<T>::MT ? 
 template <typename T> static int64_t wgrad_splits_t(int64_t B, int32_t N) {
     const int per_wave = wgrad_na<T>(N) * Mfma<T>::MT;
     const int64_t tiles = (N + per_wave - 1) / per_wave;
-    int64_t s = (2048 + tiles - 1) / tiles;                    // ~2 waves per SIMD over the n-tiles x splits grid
+    int64_t s = (4096 + tiles - 1) / tiles;                    // ~4 waves per SIMD over the n-tiles x splits grid
     const int64_t max_s = (B + 127) / 128;                      // at least 128 rows per split
     if (s > max_s) s = max_s;
     if (s > 65535) s = 65535;
