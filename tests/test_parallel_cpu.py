@@ -30,6 +30,7 @@ def _free_port():
 
 
 def _worker(rank, world, port, n_rows, q):
+    torch.set_num_threads(1)                 # the test host runs several of these process pairs at once (pytest -n): no thread oversubscription
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -68,6 +69,7 @@ def test_sharded_log_prob_gloo_world2(n_rows):
 
 
 def _pipe_worker(rank, world, port, q):
+    torch.set_num_threads(1)                 # the test host runs several of these process pairs at once (pytest -n): no thread oversubscription
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -111,6 +113,7 @@ def test_pipelined_gather_single_process():
 
 
 def _loop_worker(rank, world, port, q):
+    torch.set_num_threads(1)                 # the test host runs several of these process pairs at once (pytest -n): no thread oversubscription
     """the bench.py step loop (parallel.timed_steps + PipelinedGather, weak and strong row sharding) with a stand-in evaluate, world 2 on gloo"""
     import time
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -163,6 +166,7 @@ def test_bench_step_loop_gloo_world2():
 
 
 def _grad_worker(rank, world, port, q):
+    torch.set_num_threads(1)                 # the test host runs several of these process pairs at once (pytest -n): no thread oversubscription
     """row-sharded training step: local backward on the shard + ONE gradient all-reduce == the gradient of the global-batch mean loss"""
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
