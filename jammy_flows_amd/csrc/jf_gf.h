@@ -369,8 +369,26 @@ template <typename T, int G> __device__ __forceinline__ void gfg_derive(T* __res
 template <typename T, int G> __device__ __forceinline__ T gfg_solve(const T* __restrict__ p, const GfLayerDev<T>& o, int D, bool live, T z,
                                                                      bool row_valid, bool leader, int32_t* status) {
     T lo = T(-1e5), hi = T(1e5), x = T(0);
+    // The reference's bracket [-1e5, 1e5] makes the first ~10 midpoints lie hundreds of widths outside every component, where the outcome of
+    // the comparison is known without evaluating the mixture (and those evaluations are the expensive ones: deep-tail arithmetic): more than
+    // FAR widths beyond all components the stage value exceeds +-13 (normal variants: sqrt(2 (FAR - ln K ...)); sigmoid: ~FAR), so for
+    // |z| < 8 the midpoint is on the far side of the root and not within the 1e-6 relative stop.  Same decisions, same iterates, bit for bit;
+    // the evaluation is skipped only when EVERY lane of the wave is in that situation (the early midpoints are the same in all lanes).
+    constexpr T FAR = T(100);
+    T lo_b = T(INFINITY), hi_b = T(-INFINITY);
+    for (int k = 0; k < o.K; ++k) {
+        const T mu = p[o.off_mean + k * D], w = M<T>::rcp(p[o.off_lw + k * D]);      // derived rows hold 1 / width
+        lo_b = M<T>::min(lo_b, mu - FAR * w);
+        hi_b = M<T>::max(hi_b, mu + FAR * w);
+    }
+    const bool can_skip = M<T>::abs(z) < T(8);
     for (int it = 0; it < 25; ++it) {
         x = (hi + lo) * T(0.5);
+        const bool far_r = can_skip && x > hi_b, far_l = can_skip && x < lo_b;
+        if (__all(far_r || far_l)) {                       // wave-uniform
+            if (far_r) hi = x; else lo = x;
+            continue;
+        }
         const T y = gf_icdf<T>(o.inv_type, gfg_mixture<T, false>(p, o, D, x)).y;
         const bool ok = M<T>::abs(y - z) <= T(1e-6) * M<T>::abs(z);
         if (ok) { lo = x; hi = x; }
