@@ -24,6 +24,7 @@
 // regulated weights, <= 4 Householder reflections), H <= 128, K1 <= 28.  Everything else: jf_cond_gf_chain_inv_* / jf_mlp2 + jf_gf_chain_inv.
 #include "jf_gf.h"
 #include "jf_mfma.h"
+#include <cstdlib>
 
 namespace jf {
 
@@ -44,7 +45,7 @@ constexpr int CS_FRAG = 1024;                      // bytes of one A fragment (6
 constexpr int CS_W_BYTES = CS_CT * CS_KSTEPS * CS_NP * CS_FRAG;       // 36864
 constexpr int CS_B_BYTES = CS_CT * 16 * 4;                            // 192: the chunk's bias, permuted column order
 constexpr int CS_CHUNK_BYTES = CS_W_BYTES + CS_B_BYTES;               // 37056 (16-byte multiple)
-constexpr int CS_ROWS = 64;                        // rows per workgroup (4 waves x 16)
+constexpr int CS_ROWS1 = 64;                       // rows per workgroup and row group (4 waves x 16); a wave carries RG row groups
 constexpr int CS_HMAX = 128, CS_K1MAX = 28;
 
 struct CsLayer { int hh, model_offset, inv_type; float wmin, inv_wmax, nmin, nmax; };
@@ -205,7 +206,10 @@ struct CsArgs {
     int32_t* status;
 };
 
-__global__ void __launch_bounds__(256, 2) cond_gf_split_kernel(const CsArgs a) {
+// RG = row groups (16 rows each) per wave.  With RG = 2 every A fragment read from LDS feeds two MFMAs (half the ds_read_b128 per row,
+// six independent accumulators per piece product instead of three) and the chunk barriers are paid once per 128 rows instead of 64.
+template <int RG> __global__ void __launch_bounds__(256, 2) cond_gf_split_kernel(const CsArgs a) {
+    constexpr int CS_ROWS = CS_ROWS1 * RG;
     using MF = Mfma16<float>;
     constexpr int MT = 16, KS = 4, NREG = 4, JH = CS_HMAX / MT;
     extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -272,8 +276,9 @@ __global__ void __launch_bounds__(256, 2) cond_gf_split_kernel(const CsArgs a) {
         if (tid < CS_HMAX) b1s[tid] = tid < a.H ? a.b1[tid < a.H ? tid : 0] : 0.f;
     }
     __syncthreads();
-    bf16x8 hB[CS_KSTEPS][CS_NP];                                   // the hidden activations as MFMA B operands, three bf16 pieces
-    {
+    bf16x8 hB[RG][CS_KSTEPS][CS_NP];                               // the hidden activations as MFMA B operands, three bf16 pieces
+#pragma unroll
+    for (int g = 0; g < RG; ++g) {
         typename MF::Acc acc[JH];
 #pragma unroll
         for (int j = 0; j < JH; ++j)
@@ -281,7 +286,7 @@ __global__ void __launch_bounds__(256, 2) cond_gf_split_kernel(const CsArgs a) {
             for (int r = 0; r < NREG; ++r) acc[j][r] = 0.f;
         for (int s = 0; s < k1p / KS; ++s) {
             const int kk = s * KS + lq;
-            const float xb = Xs[(wave * MT + li) * ldk + kk];
+            const float xb = Xs[((wave * RG + g) * MT + li) * ldk + kk];
 #pragma unroll
             for (int j = 0; j < JH; ++j) acc[j] = MF::mma(W1s[(j * MT + li) * ldk + kk], xb, acc[j]);
         }
@@ -294,18 +299,23 @@ __global__ void __launch_bounds__(256, 2) cond_gf_split_kernel(const CsArgs a) {
                 const float h = M<float>::tanh_fast(acc[j][r] + b1s[j * MT + 4 * lq + r]);
                 __bf16 p0, p1, p2;
                 cs_split(h, p0, p1, p2);
-                hB[s][0][i] = p0; hB[s][1][i] = p1; hB[s][2][i] = p2;
+                hB[g][s][0][i] = p0; hB[g][s][1][i] = p1; hB[g][s][2][i] = p2;
             }
     }
 
-    // ---- flow state: lane = (row li of the wave's 16, coordinate lq)
+    // ---- flow state: lane = (row li of the row group's 16, coordinate lq)
     const bool live = lq < D, leader = lq == 0;
     const int d = live ? lq : D - 1;
-    const int64_t row = row0 + wave * MT + li;
-    const bool row_valid = row <= last;
-    const int64_t rrow = row_valid ? row : last;
-    float x = a.x[rrow * a.xs + d];
-    float ld = a.ld_in ? a.ld_in[rrow] : 0.f;
+    int64_t row[RG]; bool row_valid[RG];
+    float x[RG], ld[RG];
+#pragma unroll
+    for (int g = 0; g < RG; ++g) {
+        row[g] = row0 + (wave * RG + g) * MT + li;
+        row_valid[g] = row[g] <= last;
+        const int64_t rrow = row_valid[g] ? row[g] : last;
+        x[g] = a.x[rrow * a.xs + d];
+        ld[g] = a.ld_in ? a.ld_in[rrow] : 0.f;
+    }
 
     auto landed = [&]() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
 
@@ -313,17 +323,21 @@ __global__ void __launch_bounds__(256, 2) cond_gf_split_kernel(const CsArgs a) {
     landed();                                                      // chunk 0 is in buffer 0 and every wave is done with Xs / W1s / b1s (buffer 1)
     int chunk = 0;
     for (int l = a.n_layers - 1; l >= 0; --l) {
-        float P[CS_SLOTS];
+        float P[RG][CS_SLOTS];
 #pragma unroll
         for (int c = 0; c < CS_CPL; ++c, ++chunk) {
             if (chunk + 1 < n_chunks) dma(chunk + 1);              // in flight while this chunk is multiplied
             const unsigned char* Ws = Ws0 + (chunk & 1) * CS_CHUNK_BYTES;
             const float* Bs = reinterpret_cast<const float*>(Ws + CS_W_BYTES);
-            f32x4 acc[CS_CT];
+            f32x4 acc[RG][CS_CT];
 #pragma unroll
-            for (int t = 0; t < CS_CT; ++t) acc[t] = *reinterpret_cast<const f32x4*>(Bs + t * 16 + 4 * lq);    // bias of columns 4 lq .. 4 lq + 3
+            for (int t = 0; t < CS_CT; ++t) {
+                const f32x4 bias = *reinterpret_cast<const f32x4*>(Bs + t * 16 + 4 * lq);    // bias of columns 4 lq .. 4 lq + 3
+#pragma unroll
+                for (int g = 0; g < RG; ++g) acc[g][t] = bias;
+            }
             // A fragments one k-step ahead of the MFMAs that consume them (the LDS latency of a k-step's 9 reads hides behind the previous
-            // k-step's 18 MFMAs instead of being waited for in front of each MFMA)
+            // k-step's MFMAs instead of being waited for in front of each MFMA)
             bf16x8 A[2][CS_CT][CS_NP];
             auto load_a = [&](int s, int buf) {
 #pragma unroll
@@ -338,52 +352,56 @@ __global__ void __launch_bounds__(256, 2) cond_gf_split_kernel(const CsArgs a) {
                 const int b = s & 1;
                 if (s + 1 < CS_KSTEPS) load_a(s + 1, b ^ 1);
                 // products with piece indices pa + pb <= 2, smallest first
+                constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
 #pragma unroll
-                for (int t = 0; t < CS_CT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[b][t][2], hB[s][0], acc[t], 0, 0, 0);
+                for (int i = 0; i < 6; ++i)
 #pragma unroll
-                for (int t = 0; t < CS_CT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[b][t][1], hB[s][1], acc[t], 0, 0, 0);
+                    for (int t = 0; t < CS_CT; ++t)
 #pragma unroll
-                for (int t = 0; t < CS_CT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[b][t][0], hB[s][2], acc[t], 0, 0, 0);
-#pragma unroll
-                for (int t = 0; t < CS_CT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[b][t][1], hB[s][0], acc[t], 0, 0, 0);
-#pragma unroll
-                for (int t = 0; t < CS_CT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[b][t][0], hB[s][1], acc[t], 0, 0, 0);
-#pragma unroll
-                for (int t = 0; t < CS_CT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[b][t][0], hB[s][0], acc[t], 0, 0, 0);
+                        for (int g = 0; g < RG; ++g)
+                            acc[g][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[b][t][PA[i]], hB[g][s][PB[i]], acc[g][t], 0, 0, 0);
             }
 #pragma unroll
-            for (int t = 0; t < CS_CT; ++t)
+            for (int g = 0; g < RG; ++g)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) P[4 * (c * CS_CT + t) + r] = acc[t][r];
+                for (int t = 0; t < CS_CT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) P[g][4 * (c * CS_CT + t) + r] = acc[g][t][r];
             if (c + 1 < CS_CPL) landed();                          // next chunk in place, every wave has read this one
         }
-        // ---- flow phase on the lane's register row (raw parameters; jf_gf.h arithmetic)
+        // ---- flow phase on the lane's register rows (raw parameters; jf_gf.h arithmetic)
         const CsLayer o = a.L[l];                                  // uniform index: scalar loads from the kernarg segment
-        x -= P[CS_SLOT_OFF];                                       // euclidean_base.py:40-45 (zero column when the layer models no offset)
 #pragma unroll
-        for (int i = 0; i < CS_HH; ++i) {
-            if (i < o.hh) {                                        // x <- Q^T x (gaussianization_flow.py:1038), H_i = I - 2 v v^T / |v|^2
-                const float v = live ? P[CS_SLOT_ROT + i] : 0.f;
-                const float n2 = cs_rsum(v * v), dot = cs_rsum(v * x);
-                x -= 2.0f * dot * M<float>::rcp(n2) * v;
+        for (int g = 0; g < RG; ++g) {
+            float xg = x[g] - P[g][CS_SLOT_OFF];                   // euclidean_base.py:40-45 (zero column when the layer models no offset)
+#pragma unroll
+            for (int i = 0; i < CS_HH; ++i) {
+                if (i < o.hh) {                                    // x <- Q^T x (gaussianization_flow.py:1038), H_i = I - 2 v v^T / |v|^2
+                    const float v = live ? P[g][CS_SLOT_ROT + i] : 0.f;
+                    const float n2 = cs_rsum(v * v), dot = cs_rsum(v * xg);
+                    xg -= 2.0f * dot * M<float>::rcp(n2) * v;
+                }
             }
+            const MixQ<float> q = cs_mixture(P[g], o, xg, live);
+            const IcdfOut<float> sy = gf_icdf<float>(o.inv_type, q);
+            x[g] = sy.y;
+            ld[g] += cs_rsum(live ? sy.logd : 0.f);
         }
-        const MixQ<float> q = cs_mixture(P, o, x, live);
-        const IcdfOut<float> sy = gf_icdf<float>(o.inv_type, q);
-        x = sy.y;
-        ld += cs_rsum(live ? sy.logd : 0.f);
         landed();
     }
 
-    if (row_valid && live) a.x_out[row * a.xos + d] = x;
-    float sb = 0.f;
-    if (a.blp_out) sb = cs_rsum(live ? -0.5f * x * x - M<float>::HALF_LN_2PI : 0.f);
-    if (row_valid && leader) {
-        a.ld_out[row] = ld;
-        if (a.blp_out) a.blp_out[row] = sb + (a.blp_in ? a.blp_in[row] : 0.f);
+#pragma unroll
+    for (int g = 0; g < RG; ++g) {
+        if (row_valid[g] && live) a.x_out[row[g] * a.xos + d] = x[g];
+        float sb = 0.f;
+        if (a.blp_out) sb = cs_rsum(live ? -0.5f * x[g] * x[g] - M<float>::HALF_LN_2PI : 0.f);
+        if (row_valid[g] && leader) {
+            a.ld_out[row[g]] = ld[g];
+            if (a.blp_out) a.blp_out[row[g]] = sb + (a.blp_in ? a.blp_in[row[g]] : 0.f);
+        }
+        const float bad = cs_rmax((live && !M<float>::finite(x[g])) ? 1.f : 0.f);
+        status_add(a.status, JF_STATUS_NONFINITE, row_valid[g] && leader && (bad > 0.f || !M<float>::finite(ld[g])));
     }
-    const float bad = cs_rmax((live && !M<float>::finite(x)) ? 1.f : 0.f);
-    status_add(a.status, JF_STATUS_NONFINITE, row_valid && leader && (bad > 0.f || !M<float>::finite(ld)));
 }
 
 // ---------------------------------------------------------------------------------------------------------- host side
@@ -439,8 +457,16 @@ static int cs_chain(const float* in, int64_t in_stride, const float* W1, int64_t
     a.x_out = x_out; a.xos = xos; a.ld_out = ld_out; a.blp_in = blp_in; a.blp_out = blp_out; a.status = status;
     const size_t lds = 2 * CS_CHUNK_BYTES;
     static bool attr_set = false;
-    if (!attr_set) { (void)hipFuncSetAttribute((const void*)cond_gf_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
-    hipLaunchKernelGGL(cond_gf_split_kernel, dim3((unsigned)((B + CS_ROWS - 1) / CS_ROWS)), dim3(256), lds, (hipStream_t)stream, a);
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)cond_gf_split_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)cond_gf_split_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    // two row groups per wave once that still leaves every CU several workgroups
+    static const int force_rg = getenv("JF_CS_RG") ? atoi(getenv("JF_CS_RG")) : 0;
+    const bool two = force_rg ? force_rg == 2 : B >= (int64_t)CS_ROWS1 * 2 * 2048;
+    if (two) hipLaunchKernelGGL(cond_gf_split_kernel<2>, dim3((unsigned)((B + 2 * CS_ROWS1 - 1) / (2 * CS_ROWS1))), dim3(256), lds, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(cond_gf_split_kernel<1>, dim3((unsigned)((B + CS_ROWS1 - 1) / CS_ROWS1)), dim3(256), lds, (hipStream_t)stream, a);
     return hipPeekAtLastError() == hipSuccess ? JF_OK : JF_ERR_LAUNCH;
 }
 

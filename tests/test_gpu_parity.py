@@ -357,6 +357,42 @@ def test_fused_conditional_block_vs_golden_and_two_launch_path(name):
         assert max_abs(out[mode][2][sel], out["two"][2][sel]) < 2e-3, mode
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["g_e3_ggg_cond", "c3_e4s2e4"])
+def test_fused_block_two_row_groups_per_wave(name):
+    """from 2^18 rows on the split-bf16 block kernel carries two 16-row groups per wave (cond_split_kernels.hip, RG = 2): same arithmetic per
+    row, so the result must agree with the one-group launch of a small batch to rounding, and with the golden values; a ragged tail
+    (rows % 128 != 0) ends inside the second row group of a wave"""
+    from jammy_flows_amd import _hip
+    fx = [f for f in ALL_FIXTURES if f.name == name][0]
+    pdf = build_product(fx, torch.float32)
+    assert name in FUSABLE
+    n = fx["x"].shape[0]
+    reps = (1 << 18) // n + 2
+    big = reps * n - 41
+    assert big >= 1 << 18 and big % 128 != 0
+    x = to_dev(np.tile(fx["x"], (reps, 1))[:big], torch.float32)
+    cond = to_dev(np.tile(fx["cond"], (reps, 1))[:big], torch.float32) if fx.get("cond") is not None else None
+    emb = bool(fx.meta["embedding"])
+    pdf.check_status = False
+    timer = _hip.KernelTimer()
+    with timer:
+        full = pdf(x, conditional_input=cond, force_embedding_coordinates=emb)[0]
+    assert any(k[0] == "jf_cond_gf_chain_inv_split_f32" for k in timer.summary())
+    small = pdf(x[:n], conditional_input=None if cond is None else cond[:n], force_embedding_coordinates=emb)[0]
+    full_np, small_np = full.cpu().numpy(), small.cpu().numpy()
+    def same(a, b, what):     # not bit-identical: the plain / scaled mixture summation is chosen per wave, i.e. depends on the neighbouring rows
+        fin = np.isfinite(a) & np.isfinite(b)
+        assert np.array_equal(np.isfinite(a), np.isfinite(b)), what
+        assert float((np.abs(a - b)[fin] / (1.0 + np.abs(b[fin]))).max()) < 2e-6, what
+    for r in (0, 1, reps // 2):
+        same(full_np[r * n:(r + 1) * n], small_np, "replica %d" % r)
+    tail = full_np[(reps - 1) * n:]
+    same(tail, small_np[:tail.shape[0]], "ragged tail")
+    ok = float32_domain_mask(fx)
+    assert_float32_parity(full_np[n:2 * n].astype(np.float64), fx["logp"], ok, "%s [two row groups]" % name)
+
+
 FUSED_MANIFOLD = ["c4_i1s1_ro", "r_i1_m1p1_rr_cond", "r_i1_smooth2", "o_s1_cond_oo", "o_s1_nosmooth", "m_s1_cond", "m_s1_nat1_rot",
                   "f_s2_cond_ff", "f_s2_splines_cond", "f_s2_rot_xyz_mu", "c3_e4s2e4"]
 
