@@ -464,7 +464,7 @@ static int cs_chain(const float* in, int64_t in_stride, const float* W1, int64_t
     }
     // two row groups per wave once that still leaves every CU several workgroups
     static const int force_rg = getenv("JF_CS_RG") ? atoi(getenv("JF_CS_RG")) : 0;
-    const bool two = force_rg ? force_rg == 2 : B >= (int64_t)CS_ROWS1 * 2 * 2048;
+    const bool two = force_rg ? force_rg == 2 : B >= (int64_t)CS_ROWS1 * 2 * 1024;
     if (two) hipLaunchKernelGGL(cond_gf_split_kernel<2>, dim3((unsigned)((B + 2 * CS_ROWS1 - 1) / (2 * CS_ROWS1))), dim3(256), lds, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(cond_gf_split_kernel<1>, dim3((unsigned)((B + CS_ROWS1 - 1) / CS_ROWS1)), dim3(256), lds, (hipStream_t)stream, a);
     return hipPeekAtLastError() == hipSuccess ? JF_OK : JF_ERR_LAUNCH;

@@ -360,7 +360,7 @@ def test_fused_conditional_block_vs_golden_and_two_launch_path(name):
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", ["g_e3_ggg_cond", "c3_e4s2e4"])
 def test_fused_block_two_row_groups_per_wave(name):
-    """from 2^18 rows on the split-bf16 block kernel carries two 16-row groups per wave (cond_split_kernels.hip, RG = 2): same arithmetic per
+    """from 2^17 rows on the split-bf16 block kernel carries two 16-row groups per wave (cond_split_kernels.hip, RG = 2): same arithmetic per
     row, so the result must agree with the one-group launch of a small batch to rounding, and with the golden values; a ragged tail
     (rows % 128 != 0) ends inside the second row group of a wave"""
     from jammy_flows_amd import _hip
