@@ -16,6 +16,7 @@
 //       HBM traffic is the algorithmic minimum (every parameter byte is read exactly once).
 #include "jf_gf.h"
 #include "jf_gf_ext.h"
+#include <cstdlib>
 
 namespace jf {
 
@@ -148,6 +149,111 @@ __global__ void __launch_bounds__(BCAST ? 256 : 64, sizeof(T) == 8 ? 2 : 4) gf_c
         } else {
             if (row_valid && leader) a.ld_out[row] = ld;
         }
+    }
+}
+
+// Broadcast regime, log-prob direction, classic stretch: lane = ROW, the row's D coordinates in registers.  Every parameter is then the same
+// for all 64 lanes of a wave: the derived (mean, 1/width, pi, pi/width) of a component come from ONE uniform 16-byte (float64: 32-byte) LDS
+// read per 64 rows (the lane = (row, coordinate) kernel above spends 3 ds_read_b32 + 3 address adds per component on 16 rows), the
+// Householder dot products and the sum of the log-derivatives are plain register arithmetic (no DPP butterflies), and x is one row-contiguous
+// load per lane.  Same arithmetic per coordinate as gfg_mixture_impl / gfg_mixture_scaled.
+template <typename T> struct __attribute__((aligned(16))) GfPack { T mean, iw, pi, piw; };
+
+template <typename T, int D> __global__ void __launch_bounds__(256) gfb_chain_inv_kernel(const GfChainArgs<T> a) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    T* lds = reinterpret_cast<T*>(smem_raw);
+    const int tid = threadIdx.x;
+    derive_broadcast<T>(lds, a);
+    // the layer count as a scalar register: derive_broadcast reads it under divergent control flow, and the value the compiler then reuses
+    // lives in a vector register -- which turned the layer loop, its descriptor loads and the component loop into divergent (exec-masked) code
+    const int n_layers = __builtin_amdgcn_readfirstlane(a.n_layers);
+    int max_k = 1;
+    for (int l = 0; l < n_layers; ++l) max_k = a.L[l].K > max_k ? a.L[l].K : max_k;
+    const int pstride = __builtin_amdgcn_readfirstlane(max_k) * D;
+    GfPack<T>* pack = reinterpret_cast<GfPack<T>*>(lds + a.tab_offset);
+    for (int l = 0; l < n_layers; ++l) {
+        const GfLayerDev<T> o = a.L[l];
+        const T* row = lds + l * a.tile_stride;
+        for (int j = tid; j < o.K * D; j += 256) {
+            const int d = j / o.K, k = j - d * o.K;
+            GfPack<T> e;
+            e.mean = row[o.off_mean + k * D + d];
+            e.iw = row[o.off_lw + k * D + d];
+            e.pi = o.fit_norm ? row[o.off_ln + k * D + d] : M<T>::rcp(T(o.K));
+            e.piw = e.pi * e.iw;
+            pack[l * pstride + j] = e;
+        }
+    }
+    __syncthreads();
+
+    for (int t = 0; t < a.tiles_per_block; ++t) {
+        const int64_t row0 = ((int64_t)blockIdx.x * a.tiles_per_block + t) * 256;
+        if (row0 >= a.B) break;                          // block-uniform
+        const int64_t row = row0 + tid;
+        const bool row_valid = row < a.B;
+        const int64_t rrow = row_valid ? row : a.B - 1;
+        T x[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) x[d] = a.x[rrow * a.xs + d];
+        T ld = a.ld_in ? a.ld_in[rrow] : T(0);
+        for (int l = n_layers - 1; l >= 0; --l) {
+            const GfLayerDev<T> o = a.L[l];              // uniform index: scalar loads from the kernarg segment
+            const T* prow = lds + l * a.tile_stride;
+            if (o.model_offset) {                        // euclidean_base.py:40-45
+#pragma unroll
+                for (int d = 0; d < D; ++d) x[d] -= prow[d];
+            }
+            for (int i = 0; i < o.hh; ++i) {             // x <- Q^T x (:1038); derived rows hold sqrt(2) v / |v|
+                const T* v = prow + o.off_rot + i * D;
+                T dot = T(0);
+#pragma unroll
+                for (int d = 0; d < D; ++d) dot += v[d] * x[d];
+#pragma unroll
+                for (int d = 0; d < D; ++d) x[d] -= v[d] * dot;
+            }
+            const GfPack<T>* pk = pack + l * pstride;
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                const GfPack<T>* pd = pk + d * o.K;
+                T C = T(0), S = T(0), P = T(0);
+#pragma unroll 2
+                for (int k = 0; k < o.K; ++k) {
+                    const GfPack<T> e = pd[k];
+                    const T u = (x[d] - e.mean) * e.iw;
+                    const T tt = M<T>::exp_fast(-M<T>::abs(u));
+                    const T hi = M<T>::rcp(T(1) + tt);     // sigma(|u|)
+                    const T lo = tt * hi;                  // sigma(-|u|)
+                    const bool pos = u >= T(0);
+                    C += e.pi * (pos ? hi : lo);
+                    S += e.pi * (pos ? lo : hi);
+                    P += e.piw * (hi * lo);
+                }
+                MixQ<T> q;
+                q.lc = M<T>::log_fast(C); q.ls = M<T>::log_fast(S); q.lp = M<T>::log_fast(P);
+                q.cdf = C; q.sf = S;
+                const bool under = !(C > M<T>::TINY && S > M<T>::TINY && P > M<T>::TINY);
+                if (__any(under)) {                        // wave-uniform branch
+                    const MixQ<T> qs = gfg_mixture_scaled<T, false>(prow + d, o, D, x[d], T(0));
+                    if (under) q = qs;
+                }
+                const IcdfOut<T> sy = gf_icdf<T>(o.inv_type, q);
+                x[d] = sy.y;
+                ld += sy.logd;
+            }
+        }
+        T sb = T(0);
+        bool bad = !M<T>::finite(ld);
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            if (row_valid) a.x_out[row * a.xos + d] = x[d];
+            sb += T(-0.5) * x[d] * x[d] - M<T>::HALF_LN_2PI;
+            bad = bad || !M<T>::finite(x[d]);
+        }
+        if (row_valid) {
+            a.ld_out[row] = ld;
+            if (a.blp_out) a.blp_out[row] = sb + (a.blp_in ? a.blp_in[row] : T(0));
+        }
+        status_add(a.status, JF_STATUS_NONFINITE, row_valid && bad);
     }
 }
 
@@ -325,8 +431,42 @@ template <typename T, int G, bool FWD> static int launch_g(GfChainArgs<T> a, boo
     return check_launch();
 }
 
+template <typename T, int D> static int launch_rows(GfChainArgs<T> a, size_t lds_bytes, hipStream_t st) {
+    auto k = gfb_chain_inv_kernel<T, D>;
+    if (lds_bytes > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    int resident = resident_blocks(k, lds_bytes);           // one wave of workgroups, as for the lane = (row, coordinate) broadcast kernel
+    if (resident < 1) resident = 1;
+    const int64_t n_tiles = (a.B + 255) / 256;
+    const int64_t tpb = (n_tiles + resident - 1) / resident;
+    a.tiles_per_block = (int)(tpb < 1 ? 1 : tpb);
+    hipLaunchKernelGGL(k, dim3((unsigned)((n_tiles + a.tiles_per_block - 1) / a.tiles_per_block)), dim3(256), lds_bytes, st, a);
+    return check_launch();
+}
+
 template <typename T, bool FWD> static int launch(const GfChainArgs<T>& a, int D, bool bcast, bool ext, size_t lds_bytes, hipStream_t st) {
     if (a.B == 0) return JF_OK;
+    if constexpr (!FWD) {
+        static const bool no_rows = getenv("JF_NO_ROWS_KERNEL") != nullptr;    // debugging knob
+        bool classic = bcast && !ext && !no_rows;
+        int pack_elems = 0;
+        for (int l = 0; l < a.n_layers; ++l) {
+            classic = classic && a.L[l].stretch == JF_GF_STRETCH_CLASSIC;
+            pack_elems = a.L[l].K > pack_elems ? a.L[l].K : pack_elems;
+        }
+        const size_t lds_rows = ((size_t)a.tab_offset + (size_t)a.n_layers * pack_elems * D * 4) * sizeof(T);
+        if (classic && lds_rows <= (size_t)LDS_LIMIT) {
+            switch (D) {
+                case 1: return launch_rows<T, 1>(a, lds_rows, st);
+                case 2: return launch_rows<T, 2>(a, lds_rows, st);
+                case 3: return launch_rows<T, 3>(a, lds_rows, st);
+                case 4: return launch_rows<T, 4>(a, lds_rows, st);
+                case 5: return launch_rows<T, 5>(a, lds_rows, st);
+                case 6: return launch_rows<T, 6>(a, lds_rows, st);
+                case 7: return launch_rows<T, 7>(a, lds_rows, st);
+                default: return launch_rows<T, 8>(a, lds_rows, st);
+            }
+        }
+    }
     if (ext) {
         auto k = gfx_chain_kernel<T, FWD>;
         if (lds_bytes > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
