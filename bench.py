@@ -224,9 +224,12 @@ def traffic_of(traffic, kname, ktag):
     if key is None:
         return None
     cands = [(n, v) for n, v in traffic["kernels"].items() if key in n]
-    if kname.startswith("jf_gf_chain_inv"):          # the chain kernel exists as broadcast (..., true, false>) and per-sample (..., false, false>)
-        want = ", true, false>" if ktag == "bcast" else ", false, false>"
-        cands = [(n, v) for n, v in cands if want in n]
+    if kname.startswith("jf_gf_chain_inv"):          # broadcast: the lane = row kernel gfb_chain_inv_kernel<T, D> (classic stretch) or
+        if ktag == "bcast":                          # gf_chain_kernel<..., true, false>; per-sample: gf_chain_kernel<..., false, false>
+            rows_kernel = [(n, v) for n, v in traffic["kernels"].items() if key.replace("gf_chain_kernel", "gfb_chain_inv_kernel") in n]
+            cands = rows_kernel or [(n, v) for n, v in cands if ", true, false>" in n]
+        else:
+            cands = [(n, v) for n, v in cands if ", false, false>" in n]
     if kname.startswith("jf_mlp2") and len(cands) > 1:   # narrow-output variant (TN = 1) for N <= 16, wide otherwise
         narrow = int(ktag.split("_")[-1][1:]) <= 32
         cands = [(n, v) for n, v in cands if (", 1, true" in n) == narrow] or cands
@@ -376,7 +379,14 @@ def main():
             n_chk = min(4096, B)
             o = helpers.build_oracle(fx).forward(x64[:n_chk], None if c64 is None else c64[:n_chk])[0]
             err = float(np.max(np.abs(logp[:n_chk].double().cpu().numpy() - o)))
-        results[dname] = dict(dt=dt, evals_per_s=total_rows * args.steps / dt, ms_per_step=1e3 * dt / args.steps, err=err)
+        # determinism of what was just timed (outside the timed region): the same step again, compared bit for bit over ALL rows -- the check that
+        # exposes rare wrong row groups which a 4096-row oracle sample cannot see
+        repeats, identical = 3, True
+        for _ in range(repeats):
+            again = pdf(x, conditional_input=c)[0]
+            identical = identical and bool(((again == logp) | (again.isnan() & logp.isnan())).all())
+        pdf.flush_status()
+        results[dname] = dict(dt=dt, evals_per_s=total_rows * args.steps / dt, ms_per_step=1e3 * dt / args.steps, err=err, identical=identical, repeats=repeats)
         if timer is not None:
             kernel_table = timer.summary()
             if rank == 0 and world == 1:
@@ -485,7 +495,8 @@ def main():
                                                                                   "per GPU" if args.scaling == "weak" else "in total, row-sharded"),
                        "batch_per_gpu": B, "total_rows": total_rows, "parallelism": "rows sharded over %d GPU(s)" % world},
             "n_ranks_seen": n_ranks_seen, "collective_backend": backend_name,
-            "parity": {"max_abs_dlogp_vs_f64_oracle": rm["err"], "bar": 1e-2 if main_dt == "f32" else 1e-4, "rows_checked": min(4096, B)},
+            "parity": {"max_abs_dlogp_vs_f64_oracle": rm["err"], "bar": 1e-2 if main_dt == "f32" else 1e-4, "rows_checked": min(4096, B),
+                       "repeat_launches_bit_identical": rm["identical"], "repeat_launches": rm["repeats"], "repeat_rows_compared": B},
             "roofline": roofline,
             "cpu_baseline": cpu,
         }
