@@ -462,7 +462,7 @@ static int cs_chain(const float* in, int64_t in_stride, const float* W1, int64_t
         (void)hipFuncSetAttribute((const void*)cond_gf_split_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    // two row groups per wave once that still leaves every CU several workgroups
+    // two row groups per wave once that still leaves every CU several workgroups; JF_CS_RG=1|2 forces a variant (A/B timing, scripts/probe/rg_sweep.py)
     static const int force_rg = getenv("JF_CS_RG") ? atoi(getenv("JF_CS_RG")) : 0;
     const bool two = force_rg ? force_rg == 2 : B >= (int64_t)CS_ROWS1 * 2 * 1024;
     if (two) hipLaunchKernelGGL(cond_gf_split_kernel<2>, dim3((unsigned)((B + 2 * CS_ROWS1 - 1) / (2 * CS_ROWS1))), dim3(256), lds, (hipStream_t)stream, a);

@@ -16,7 +16,6 @@
 //       HBM traffic is the algorithmic minimum (every parameter byte is read exactly once).
 #include "jf_gf.h"
 #include "jf_gf_ext.h"
-#include <cstdlib>
 
 namespace jf {
 
@@ -446,8 +445,7 @@ template <typename T, int D> static int launch_rows(GfChainArgs<T> a, size_t lds
 template <typename T, bool FWD> static int launch(const GfChainArgs<T>& a, int D, bool bcast, bool ext, size_t lds_bytes, hipStream_t st) {
     if (a.B == 0) return JF_OK;
     if constexpr (!FWD) {
-        static const bool no_rows = getenv("JF_NO_ROWS_KERNEL") != nullptr;    // debugging knob
-        bool classic = bcast && !ext && !no_rows;
+        bool classic = bcast && !ext;
         int pack_elems = 0;
         for (int l = 0; l < a.n_layers; ++l) {
             classic = classic && a.L[l].stretch == JF_GF_STRETCH_CLASSIC;

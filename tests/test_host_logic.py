@@ -131,3 +131,26 @@ def test_data_init_host_math_matches_the_oracle():
         assert np.abs(ld - np.log(np.abs(np.linalg.det(L)))).max() < 1e-12, cov
         target = L @ L.T
         assert abs(init_fns._mvn_loss(target, cov)(a)) < 1e-10          # reverse KL of a distribution with itself
+
+
+def test_float64_log_of_the_mixture_sums_formula():
+    """csrc/jf_math.h M<double>::log_fast restated in numpy (same reduction, same constants, without the fused multiply-adds): within 1.5 ulp
+    of numpy's log over 600 decades, denormals included"""
+    rng = np.random.default_rng(0)
+    x = np.concatenate([10.0 ** rng.uniform(-307, 300, 200000), rng.uniform(0.5, 2.0, 200000), 1.0 + rng.uniform(-1e-6, 1e-6, 50000),
+                        np.array([5e-324, 2.2e-308, 1.0, 0.7071067811865475, 0.7071067811865476, 1.7976931348623157e308])])
+    m, e = np.frexp(x)
+    low = m < 0.70710678118654752440
+    m = np.where(low, m + m, m)
+    e = np.where(low, e - 1, e).astype(np.float64)
+    f = m - 1.0
+    s = f / (2.0 + f)
+    z = s * s
+    w = z * z
+    t1 = w * (3.999999999940941908e-01 + w * (2.222219843214978396e-01 + w * 1.531383769920937332e-01))
+    t2 = z * (6.666666666666735130e-01 + w * (2.857142874366239149e-01 + w * (1.818357216161805012e-01 + w * 1.479819860511658591e-01)))
+    R, hfsq = t1 + t2, 0.5 * f * f
+    r = e * 6.93147180369123816490e-01 - ((hfsq - (s * (hfsq + R) + e * 1.90821492927058770002e-10)) - f)
+    ref = np.log(x)
+    ulp = np.spacing(np.abs(ref))
+    assert float((np.abs(r - ref) / np.maximum(ulp, 5e-324)).max()) <= 1.5
