@@ -154,3 +154,27 @@ def test_float64_log_of_the_mixture_sums_formula():
     ref = np.log(x)
     ulp = np.spacing(np.abs(ref))
     assert float((np.abs(r - ref) / np.maximum(ulp, 5e-324)).max()) <= 1.5
+
+
+def test_build_flags_really_disable_packed_f32(tmp_path):
+    """csrc/Makefile passes -packed-fp32-ops through -Xclang; clang prints "not a recognized feature" for it, so check that the
+    backend honours it: a loop that hipcc packs into v_pk_*_f32 by default must come out without them under the library's own CXXFLAGS"""
+    import re
+    import shutil
+    import subprocess
+    hipcc = "/opt/rocm/bin/hipcc" if os.path.exists("/opt/rocm/bin/hipcc") else shutil.which("hipcc")
+    if not hipcc:
+        pytest.skip("hipcc not available")
+    mk = open(os.path.join(ROOT, "jammy_flows_amd", "csrc", "Makefile")).read()
+    flags = re.search(r"^CXXFLAGS := (.*)$", mk, re.M).group(1).replace("$(ARCH)", "gfx950").split()
+    assert "-packed-fp32-ops" in flags
+    src = tmp_path / "pk.hip"
+    src.write_text("#include <hip/hip_runtime.h>\n__global__ void k(float2* o, const float2* a, const float2* b) {\n"
+                   "  const int i = threadIdx.x; float2 x = a[i], y = b[i];\n"
+                   "  for (int j = 0; j < 8; ++j) { x.x = x.x * y.x + y.x; x.y = x.y * y.y + y.y; y.x *= x.x; y.y *= x.y; }\n  o[i] = x; }\n")
+    def count(extra):
+        out = tmp_path / "pk.s"
+        subprocess.check_call([hipcc] + extra + ["-S", "--cuda-device-only", str(src), "-o", str(out)], stderr=subprocess.DEVNULL)
+        return len(re.findall(r"\bv_pk_(?:fma|mul|add)_f32\b", out.read_text()))
+    assert count(["--offload-arch=gfx950", "-O3"]) > 0, "the probe loop is no longer packed by default: pick another one"
+    assert count([f for f in flags if f not in ("-fPIC", "-Wall", "-Wno-unused-function")]) == 0
