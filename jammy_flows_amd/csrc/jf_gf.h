@@ -396,7 +396,7 @@ template <typename T, int G> __device__ __forceinline__ T gfg_solve(const T* __r
         else hi = x;
     }
     bool active = row_valid;
-    T ferr = T(0);
+    T ferr = T(0), prev = T(INFINITY);
     bool nonfinite = false;
     for (int it = 0; it < 20 && __any(active); ++it) {
         const IcdfOut<T> s = gf_icdf<T>(o.inv_type, gfg_mixture<T, false>(p, o, D, x));
@@ -409,6 +409,14 @@ template <typename T, int G> __device__ __forceinline__ T gfg_solve(const T* __r
             if (M<T>::finite(nx)) x = nx; else nonfinite = nonfinite || live;     // keep the previous iterate (:84-91)
             ferr = M<T>::abs(f);
             active = usum >= T(1e-14);
+        }
+        if constexpr (sizeof(T) == 4) {
+            // float32: the reference's absolute 1e-14 fires only on an exactly zero update, i.e. its float32 runs do all 20 steps and the last
+            // ~16 of them move the iterate by rounding noise.  A row is at that floor when its update has reached the resolution of its
+            // coordinates, or has stopped shrinking while already below 1e-4 of them; further steps cannot improve it.
+            const T xs = group_sum<T, G>(live ? M<T>::max(M<T>::abs(x), T(1)) : T(0));
+            if (usum < T(2.5e-7) * xs || (usum >= T(0.5) * prev && usum < T(1e-4) * xs)) active = false;
+            prev = usum;
         }
     }
     const T prec = sizeof(T) == 8 ? T(1e-7) : T(1e-4);
