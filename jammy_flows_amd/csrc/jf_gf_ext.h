@@ -227,10 +227,11 @@ template <typename T, typename PA> __device__ inline void gx_solve(const GfLayer
     T ferr = T(0);
     bool nonfinite = false;
     bool active = row_valid;
+    T prev = T(INFINITY);
     for (int it = 0; it < 20 && __any(active); ++it) {
         status_add(status, JF_STATUS_NEWTON_STEPS, active);
         if (!active) continue;
-        T usum = T(0);
+        T usum = T(0), xs = T(0);
         ferr = T(0);
         for (int d = 0; d < D; ++d) {
             const GxCoord<T> c = gx_prepare<T, PA>(o, p, D, d);
@@ -241,8 +242,13 @@ template <typename T, typename PA> __device__ inline void gx_solve(const GfLayer
             const T nx = x[d] - upd;
             if (M<T>::finite(nx)) x[d] = nx; else nonfinite = true;     // keep the previous iterate (:84-91)
             ferr = M<T>::max(ferr, M<T>::abs(f));
+            xs += M<T>::max(M<T>::abs(x[d]), T(1));
         }
         active = usum >= T(1e-14);
+        if constexpr (sizeof(T) == 4) {          // float32 rounding floor, as in gfg_solve (jf_gf.h)
+            if (usum < T(2.5e-7) * xs || (usum >= T(0.5) * prev && usum < T(1e-4) * xs)) active = false;
+            prev = usum;
+        }
     }
     const T prec = sizeof(T) == 8 ? T(1e-7) : T(1e-4);
     status_add(status, JF_STATUS_NONCONVERGED, row_valid && (ferr > prec));
