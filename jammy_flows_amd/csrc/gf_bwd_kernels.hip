@@ -41,6 +41,8 @@ template <typename T> struct GfBwdArgs {
     T* g_x; int64_t gxs;
     T* g_params; int64_t gps;
     int32_t* status;
+    int pk0[JF_MAX_CHAIN];                    // broadcast regime: first packed component record of every layer (gf_chain_bwd_kernel)
+    int slsh;                                 // broadcast regime: log2 of the accumulator slots per parameter (see gf_chain_bwd_kernel)
 };
 
 // coefficients of the inverse-CDF stage in log space: dy = Ay dlc + By dls,  d(logd - lp) = AH dlc + BH dls
@@ -115,17 +117,13 @@ template <typename T> __device__ __forceinline__ void gf_inv_width_grad(const Gf
 // backward of one layer for the lane's coordinate.  p / gp: parameter row and gradient row (+ d), both in LDS; gy: upstream gradient of this
 // layer's output coordinate, gl: upstream gradient of log_det (the same for every layer); returns the gradient of the layer's input coordinate.
 // ACC: add into the gradient row (broadcast regime: rows of the tile share it) instead of overwriting.
-template <typename T, int G, bool ACC>
-__device__ __forceinline__ T gf_layer_bwd(const T* __restrict__ p, T* __restrict__ gp, const GfLayerDev<T>& o, int D, bool live, T x_in, T gy, T gl) {
-    // ACC (broadcast parameters): the rows of a wave that share this lane's coordinate all add to the SAME accumulator -- one LDS atomic per
-    // lane would serialise 64 / G ways on that address.  The wave sums over its rows first (butterfly over the lanes with equal lane % G), then
-    // one lane per coordinate adds.  Every lane takes part in the shuffles (put is only called under wave-uniform conditions).
+template <typename T, int G, bool ACC, typename GP>
+__device__ __forceinline__ T gf_layer_bwd(const T* __restrict__ p, GP* __restrict__ gp, const GfLayerDev<T>& o, int D, bool live, T x_in, T gy, T gl, int slsh) {
+    // ACC (broadcast parameters): gp points at this lane's accumulator SLOT of the coordinate's first parameter; the 2^slsh slots of a
+    // parameter are dealt to the rows of a wave, so the lanes of one LDS atomic hit distinct addresses (see gf_chain_bwd_kernel).
     auto put = [&](int off, T v) {
         if constexpr (ACC) {
-            T s = live ? v : T(0);
-#pragma unroll
-            for (int sh = G; sh < 64; sh <<= 1) s += __shfl_xor(s, sh, 64);
-            if (live && (int)(threadIdx.x & 63) < G) atomicAdd(gp + off, s);
+            if (live) atomicAdd(gp + (off << slsh), (GP)v);
         } else {
             if (live) gp[off] = v;
         }
@@ -202,6 +200,206 @@ __device__ __forceinline__ T gf_layer_bwd(const T* __restrict__ p, T* __restrict
     return g;
 }
 
+// ---------------------------------------------------------------------------------------------------------- linear-space fast path
+// The log-space loop above spends ~8 exp / log and ~8 divisions per component.  Wherever the linear-space mixture of the forward kernels is
+// valid (cdf, sf, pdf far from underflow -- every row but the deep tails) the responsibilities are plain products,
+//     g_lc rC_k = pi_k sigma(u_k) (g_lc / cdf),  g_ls rS_k = pi_k sigma(-u_k) (g_ls / sf),  g_lp rP_k = pi_k sigma(u_k) sigma(-u_k) (g_lp / (w_k pdf)),
+// with three reciprocals per COORDINATE instead of per component.  A wave in which some live lane is outside that range takes the log-space
+// function for the layer (wave-uniform branch), so both paths see exactly the rows the forward's two paths see.
+template <typename T> struct LinRange;
+template <> struct LinRange<float> { static constexpr float lo = 1e-35f, hi = 1e30f, llo = -80.0f, lhi = 69.0f; };      // lo = M<T>::TINY: the forward's switch
+template <> struct LinRange<double> { static constexpr double lo = 1e-280, hi = 1e280, llo = -644.0, lhi = 644.0; };
+
+// Householder part shared by the two fast paths: reflections last first, g_v written through `put`
+template <typename T, int G, typename PUT>
+__device__ __forceinline__ T gf_reflections_bwd(const T* __restrict__ p, const GfLayerDev<T>& o, int D, bool live, const T* xr, T g, PUT put) {
+#pragma unroll
+    for (int i = GB_MAX_HH - 1; i >= 0; --i) {
+        if (i < o.hh) {
+            const T v = live ? p[o.off_rot + i * D] : T(0);
+            const T n = group_sum<T, G>(v * v), sx = group_sum<T, G>(v * xr[i]), vg = group_sum<T, G>(v * (live ? g : T(0)));
+            const T rn = M<T>::rcp(n);
+            put(o.off_rot + i * D, -T(2) * sx * rn * g - T(2) * vg * rn * xr[i] + T(4) * sx * vg * rn * rn * v);
+            g -= T(2) * vg * rn * v;
+        }
+    }
+    return g;
+}
+
+// per-sample regime, layers with the reference's default options (o.fast): raw row p, gradient row gp (this lane's column of the tile).
+// The first loop is the forward's linear-space mixture; it parks 1/w_k, d log(1/w_k)/d raw and the weight sigmoid in the (still unwritten)
+// gradient slots of the component, so the second loop needs one exp and one reciprocal per component.
+template <typename T, int G>
+__device__ __forceinline__ T gf_layer_bwd_fast(const T* __restrict__ p, T* __restrict__ gp, const GfLayerDev<T>& o, int D, bool live, T x_in, T gy, T gl) {
+    T xr[GB_MAX_HH];
+    T x = x_in;
+    if (o.model_offset) x -= p[0];
+#pragma unroll
+    for (int i = 0; i < GB_MAX_HH; ++i) {
+        xr[i] = x;
+        if (i < o.hh) x = gfg_reflect<T, G, true>(p, o.off_rot + i * D, live, x);
+    }
+    const T* pm = p + o.off_mean;
+    const T* pw = p + o.off_lw;
+    const T* pn = p + o.off_ln;
+    T* gm = gp + o.off_mean;
+    T* gw = gp + o.off_lw;
+    T* gn = gp + o.off_ln;
+    T C = T(0), S = T(0), P = T(0), Nn = T(0);
+#pragma unroll 2
+    for (int k = 0; k < o.K; ++k) {
+        const T mu = pm[k * D], rw = pw[k * D], rn = pn[k * D];
+        const T e = M<T>::exp_fast(-rw);
+        const T ae = o.inv_wmax + e;
+        const T r2 = M<T>::rcp(ae * (o.wmin * ae + T(1)));
+        const T iw = ae * ae * r2;                             // 1 / w
+        const T sgn = M<T>::rcp(T(1) + M<T>::exp_fast(-rn));
+        const T wk = o.nmin + o.nmax * sgn;
+        const T u = (x - mu) * iw;
+        const T t = M<T>::exp_fast(-M<T>::abs(u));
+        const T hi = M<T>::rcp(T(1) + t), lo = t * hi;
+        const bool pos = u >= T(0);
+        C += wk * (pos ? hi : lo);
+        S += wk * (pos ? lo : hi);
+        P += wk * hi * lo * iw;
+        Nn += wk;
+        if (live) { gm[k * D] = -e * r2; gw[k * D] = iw; gn[k * D] = sgn; }
+    }
+    const T invN = M<T>::rcp(Nn);
+    C *= invN; S *= invN; P *= invN;
+    const bool ok = C > LinRange<T>::lo && S > LinRange<T>::lo && P > LinRange<T>::lo && P < LinRange<T>::hi;
+    if (!__all(ok)) return gf_layer_bwd<T, G, false, T>(p, gp, o, D, live, x_in, gy, gl, 0);
+    MixQ<T> q;
+    q.lc = M<T>::log_fast(C); q.ls = M<T>::log_fast(S); q.lp = M<T>::log_fast(P); q.cdf = C; q.sf = S;
+    const IcdfOut<T> s = gf_icdf<T>(o.inv_type, q);
+    const IcdfCoef<T> c = gf_icdf_coeffs<T>(o.inv_type, q, s.y);
+    const T g_lc = gy * c.Ay + gl * c.AH, g_ls = gy * c.By + gl * c.BH, g_lp = gl;
+    const T Gsum = g_lc + g_ls + g_lp;
+    const T icg = g_lc * M<T>::rcp(C), isg = g_ls * M<T>::rcp(S), ipg = g_lp * M<T>::rcp(P);
+    T gx = T(0);
+#pragma unroll 2
+    for (int k = 0; k < o.K; ++k) {
+        const T mu = pm[k * D];
+        const T dliw = gm[k * D], iw = gw[k * D], sgn = gn[k * D];
+        const T pik = (o.nmin + o.nmax * sgn) * invN;
+        const T u = (x - mu) * iw;
+        const T t = M<T>::exp_fast(-M<T>::abs(u));
+        const T hi = M<T>::rcp(T(1) + t), lo = t * hi;
+        const bool pos = u >= T(0);
+        const T sg = pos ? hi : lo, sgc = pos ? lo : hi;
+        const T a = sg * icg, b = sgc * isg, cp = sg * sgc * iw * ipg;           // g . responsibility / pi_k
+        const T gu = pik * (a * sgc - b * sg + cp * (sgc - sg));
+        gx += gu * iw;
+        if (live) {
+            gm[k * D] = -gu * iw;
+            gw[k * D] = (gu * u + pik * cp) * dliw;
+            gn[k * D] = (a + b + cp - Gsum) * (o.nmax * sgn * (T(1) - sgn) * invN);
+        }
+    }
+    const T g = gf_reflections_bwd<T, G>(p, o, D, live, xr, gx, [&](int off, T v) { if (live) gp[off] = v; });
+    if (o.model_offset && live) gp[0] = -g;
+    return g;
+}
+
+// broadcast regime, any options.  Per (component, coordinate) the prologue of the kernel packs one 8-word record
+//     c = {mean, 1/w, pi_k, d log(1/w)/d raw, pi_k d log n_k/d raw, -, -, -}
+// so that a component costs two 16-byte LDS reads, issued one component ahead of their use; the three gradient values of a component go
+// straight to this lane's accumulator slots (unconditional LDS atomics: lanes without a row add 0, nothing in the loop waits for them).
+// v: derived row (the forward's layout: fallback of the mixture, reflections as sqrt(2) v/|v|), p: raw row (offsets, raw Householder vectors).
+template <typename T> __device__ __forceinline__ MixQ<T> gfb_mixture_pk(const T* __restrict__ c0, const T* __restrict__ v, const GfLayerDev<T>& o, int D, T x) {
+    const T* c = (const T*)__builtin_assume_aligned(c0, 16);
+    T C = T(0), S = T(0), P = T(0);
+#pragma unroll 2
+    for (int k = 0; k < o.K; ++k, c += 8 * D) {
+        const T mu = c[0], iw = c[1], wk = c[2];
+        const T u = (x - mu) * iw;
+        const T t = M<T>::exp_fast(-M<T>::abs(u));
+        const T hi = M<T>::rcp(T(1) + t), lo = t * hi;
+        const bool pos = u >= T(0);
+        C += wk * (pos ? hi : lo);
+        S += wk * (pos ? lo : hi);
+        P += wk * hi * lo * iw;
+    }
+    MixQ<T> q;
+    q.lc = M<T>::log_fast(C); q.ls = M<T>::log_fast(S); q.lp = M<T>::log_fast(P);
+    q.cdf = C; q.sf = S;
+    const bool under = !(C > M<T>::TINY && S > M<T>::TINY && P > M<T>::TINY);
+    if (__any(under)) {
+        const MixQ<T> qs = gfg_mixture_scaled<T, false>(v, o, D, x, T(0));
+        if (under) q = qs;
+    }
+    return q;
+}
+
+template <typename T, int G>
+__device__ __forceinline__ T gf_layer_bwd_bcast(const T* __restrict__ p, const T* __restrict__ v, const T* __restrict__ c0, double* __restrict__ gp,
+                                                const GfLayerDev<T>& o, int D, bool live, T x_in, T gy, T gl, int slsh) {
+    T xr[GB_MAX_HH];
+    T x = x_in;
+    if (o.model_offset) x -= p[0];
+#pragma unroll
+    for (int i = 0; i < GB_MAX_HH; ++i) {
+        xr[i] = x;
+        if (i < o.hh) x = gfg_reflect<T, G, false>(v, o.off_rot + i * D, live, x);
+    }
+    const MixQ<T> q = gfb_mixture_pk<T>(c0, v, o, D, x);
+    const bool ok = q.cdf > LinRange<T>::lo && q.sf > LinRange<T>::lo && q.lp > LinRange<T>::llo && q.lp < LinRange<T>::lhi;
+    if (!__all(ok)) return gf_layer_bwd<T, G, true, double>(p, gp, o, D, live, x_in, gy, gl, slsh);
+    const IcdfOut<T> s = gf_icdf<T>(o.inv_type, q);
+    const IcdfCoef<T> cf = gf_icdf_coeffs<T>(o.inv_type, q, s.y);
+    const T g_lc = gy * cf.Ay + gl * cf.AH, g_ls = gy * cf.By + gl * cf.BH, g_lp = gl;
+    const T Gsum = g_lc + g_ls + g_lp;
+    const T icg = g_lc * M<T>::rcp(q.cdf), isg = g_ls * M<T>::rcp(q.sf), ipg = g_lp * M<T>::exp_fast(-q.lp);
+    const bool fit = o.fit_norm != 0;
+    double* am = gp + (o.off_mean << slsh);
+    double* aw = gp + (o.off_lw << slsh);
+    double* an = gp + ((fit ? o.off_ln : o.off_lw) << slsh);          // not fitted: the (zero) weight term lands on the width accumulator
+    const int step = D << slsh;
+    const T* c = (const T*)__builtin_assume_aligned(c0, 16);
+    T mu = c[0], iw = c[1], pik = c[2], flw = c[3], fln = c[4];
+    T gx = T(0);
+    for (int k = 0; k < o.K; ++k) {
+        c += (k + 1 < o.K) ? 8 * D : 0;
+        const T mu_n = c[0], iw_n = c[1], pik_n = c[2], flw_n = c[3], fln_n = c[4];
+        __builtin_amdgcn_sched_barrier(0);                     // keep the reads of the next record ahead of this component's arithmetic
+        const T u = (x - mu) * iw;
+        const T t = M<T>::exp_fast(-M<T>::abs(u));
+        const T hi = M<T>::rcp(T(1) + t), lo = t * hi;
+        const bool pos = u >= T(0);
+        const T sg = pos ? hi : lo, sgc = pos ? lo : hi;
+        const T a = sg * icg, b = sgc * isg, cp = sg * sgc * iw * ipg;
+        const T gu = pik * (a * sgc - b * sg + cp * (sgc - sg));
+        gx += gu * iw;
+        atomicAdd(am, live ? (double)(-gu * iw) : 0.0);         // selected, not multiplied: a shadow lane (g >= D) may hold inf / nan
+        atomicAdd(aw, live ? (double)((gu * u + pik * cp) * flw) : 0.0);
+        atomicAdd(an, live ? (double)((a + b + cp - Gsum) * fln) : 0.0);
+        am += step; aw += step; an += step;
+        mu = mu_n; iw = iw_n; pik = pik_n; flw = flw_n; fln = fln_n;
+    }
+    auto put = [&](int off, T val) { atomicAdd(gp + (off << slsh), live ? (double)val : 0.0); };
+    const T g = gf_reflections_bwd<T, G>(p, o, D, live, xr, gx, put);
+    if (o.model_offset) put(0, -g);
+    return g;
+}
+
+// broadcast regime, prologue: derived values into v (1/w, pi_k), gradient factors into f (see gf_layer_bwd_bcast); one (layer, component,
+// coordinate) per thread, the normalisers of the weights through aux[(l * 8 + d) * 2 + {0: shift, 1: 1/N}]
+template <typename T> __device__ __forceinline__ void gf_derive_bwd_item(const T* __restrict__ raw, T* __restrict__ v, T* __restrict__ f, const GfLayerDev<T>& o,
+                                                                         int i, T shift) {
+    T iw, dliw;
+    gf_inv_width_grad<T>(o, raw[o.off_lw + i], iw, dliw);
+    v[o.off_lw + i] = iw;
+    f[o.off_lw + i] = dliw;
+    if (o.fit_norm) {
+        const T rn = raw[o.off_ln + i];
+        const T nk = gf_weight(o, rn, shift);
+        T ndl = nk;                                              // n_k d log n_k / d raw
+        if (o.reg_norm) { const T sg = M<T>::rcp(T(1) + M<T>::exp(-rn)); ndl = o.nmax * sg * (T(1) - sg); }
+        v[o.off_ln + i] = nk;
+        f[o.off_ln + i] = ndl;
+    }
+}
+
 template <typename T, int G, bool BCAST>
 __global__ void __launch_bounds__(BCAST ? 256 : 64) gf_chain_bwd_kernel(const GfBwdArgs<T> a) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -214,16 +412,87 @@ __global__ void __launch_bounds__(BCAST ? 256 : 64) gf_chain_bwd_kernel(const Gf
     const int D = a.D;
     const bool live = g < D, leader = g == 0;
     const int d = live ? g : D - 1;
-    // LDS: BCAST: [raw rows of all layers: n_layers x tile_stride][gradient accumulators: n_layers x tile_stride]
+    const int ts = a.tile_stride, nl = a.n_layers;
+    // LDS: BCAST: [raw rows of all layers: n_layers x tile_stride][derived rows][gradient factors][accumulators: n_layers x tile_stride x SL]
+    //             [layer inputs: n_layers x NT][normalisers: n_layers x 16]
     //      per-sample: [parameter tile R x tile_stride][gradient tile R x tile_stride]
+    // BCAST: the layer inputs of the forward sweep live in LDS (one word per layer and lane) so that both sweeps are real loops over the layers: the
+    // unrolled form (a register array indexed by the layer) replicated the two layer bodies JF_MAX_CHAIN times -- 190 KB of code.
+    // BCAST accumulators: every parameter has SL = 2^slsh slots and row r of the tile adds into slot r % SL.  With SL = 64 / G the lanes of a
+    // wave own distinct words (lane -> (coordinate, slot) is a bijection onto 64 consecutive words: no bank conflict, no serialised atomic);
+    // only the four waves of the workgroup share an address, which is what the LDS atomic is for.  Round 2 first summed over the rows of a
+    // wave with a 4..6-step butterfly per value (3 values per component) and then issued one atomic per coordinate.
+    // The accumulators are float64 in BOTH precisions: ds_add_f32 costs ~190 cycles per wave instruction on gfx950, ds_add_f64 9 (20 with two
+    // lanes per address), ds_add_u32 3.4 (scripts/probe/lds_atomic.hip) -- the float32 chain with float32 accumulators spent 0.6 of its
+    // 1.04 ms per 2^18 rows inside those atomics.
     T* ptile = lds;
-    T* gtile = lds + (BCAST ? a.n_layers : R) * a.tile_stride;
+    T* gtile = lds + (BCAST ? nl : R) * ts;
+    T* vtile = gtile;                                            // BCAST only
+    T* ftile = vtile + nl * ts;
+    double* acc = reinterpret_cast<double*>(ftile + nl * ts);    // float64 accumulators for both precisions, see below
+    const int slsh = BCAST ? a.slsh : 0;
+    T* xin = reinterpret_cast<T*>(acc + ((nl * ts) << slsh)) + tid;   // BCAST only
+    T* pk = xin - tid + nl * (NT + 16);                          // BCAST only: packed component records (16-byte aligned: every term is a multiple of 4)
     if constexpr (BCAST) {
-        for (int l = 0; l < a.n_layers; ++l) {
+        T* aux = xin - tid + nl * NT;
+        for (int l = 0; l < nl; ++l) {
             const GfLayerDev<T> o = a.L[l];
-            for (int j = tid; j < a.tile_stride; j += NT) {
-                ptile[l * a.tile_stride + j] = j < o.n_params ? a.params[o.col0 + j] : T(0);
-                gtile[l * a.tile_stride + j] = T(0);
+            for (int j = tid; j < ts; j += NT) {
+                const T raw = j < o.n_params ? a.params[o.col0 + j] : T(0);
+                ptile[l * ts + j] = raw;
+                vtile[l * ts + j] = raw;
+                ftile[l * ts + j] = T(0);
+            }
+        }
+        for (int j = tid; j < ((nl * ts) << slsh); j += NT) acc[j] = 0.0;
+        __syncthreads();
+        for (int w = tid; w < nl * 8; w += NT) {                 // unbounded log-weights: shift by the column's maximum
+            const int l = w >> 3, dd = w & 7;
+            const GfLayerDev<T> o = a.L[l];
+            T shift = T(0);
+            if (dd < D && o.fit_norm && !o.reg_norm) {
+                shift = ptile[l * ts + o.off_ln + dd];
+                for (int k = 1; k < o.K; ++k) shift = M<T>::max(shift, ptile[l * ts + o.off_ln + k * D + dd]);
+            }
+            aux[w * 2] = shift;
+        }
+        for (int w = tid; w < nl * GB_MAX_HH; w += NT) {
+            const int l = w / GB_MAX_HH, i = w - l * GB_MAX_HH;
+            if (i < a.L[l].hh) gf_derive_reflection<T>(vtile + l * ts, a.L[l], D, i);
+        }
+        __syncthreads();
+        for (int l = 0; l < nl; ++l) {
+            const GfLayerDev<T> o = a.L[l];
+            for (int i = tid; i < o.K * D; i += NT)
+                gf_derive_bwd_item<T>(ptile + l * ts, vtile + l * ts, ftile + l * ts, o, i, aux[(l * 8 + i % D) * 2]);
+        }
+        __syncthreads();
+        for (int w = tid; w < nl * 8; w += NT) {
+            const int l = w >> 3, dd = w & 7;
+            const GfLayerDev<T> o = a.L[l];
+            T Nn = T(0);
+            if (dd < D && o.fit_norm) for (int k = 0; k < o.K; ++k) Nn += vtile[l * ts + o.off_ln + k * D + dd];
+            aux[w * 2 + 1] = T(1) / Nn;
+        }
+        __syncthreads();
+        for (int l = 0; l < nl; ++l) {
+            const GfLayerDev<T> o = a.L[l];
+            if (o.fit_norm) for (int i = tid; i < o.K * D; i += NT) {
+                const T invN = aux[(l * 8 + i % D) * 2 + 1];
+                vtile[l * ts + o.off_ln + i] *= invN;
+                ftile[l * ts + o.off_ln + i] *= invN;
+            }
+        }
+        __syncthreads();
+        for (int l = 0; l < nl; ++l) {
+            const GfLayerDev<T> o = a.L[l];
+            for (int i = tid; i < o.K * D; i += NT) {
+                T* c = pk + (a.pk0[l] + i) * 8;
+                c[0] = ptile[l * ts + o.off_mean + i];
+                c[1] = vtile[l * ts + o.off_lw + i];
+                c[2] = o.fit_norm ? vtile[l * ts + o.off_ln + i] : T(1) / T(o.K);
+                c[3] = ftile[l * ts + o.off_lw + i];
+                c[4] = o.fit_norm ? ftile[l * ts + o.off_ln + i] : T(0);
             }
         }
         __syncthreads();
@@ -238,25 +507,32 @@ __global__ void __launch_bounds__(BCAST ? 256 : 64) gf_chain_bwd_kernel(const Gf
         const int valid_rows = (int)((a.B - row0) < R ? (a.B - row0) : R);
 
         // ---- forward sweep (layers n-1 .. 0), keeping every layer's input
-        T xin[JF_MAX_CHAIN];
         T x = a.x[rrow * a.xs + d];
-#pragma unroll
-        for (int li = 0; li < JF_MAX_CHAIN; ++li) {
-            xin[li] = x;
-            if (li < a.n_layers) {
-                const int l = a.n_layers - 1 - li;
+        T xreg[JF_MAX_CHAIN];                                    // per-sample regime: layer inputs in registers, both sweeps unrolled (measured faster
+        if constexpr (BCAST) {                                   //   there: 1.58 vs 1.96 ms for the float64 D = 8 chain of C5)
+#pragma unroll 1
+            for (int l = nl - 1; l >= 0; --l) {
+                xin[l * NT] = x;
                 const GfLayerDev<T> o = a.L[l];
-                const T* p;
-                if constexpr (BCAST) p = ptile + l * a.tile_stride + d;
-                else {
-                    __syncthreads();
-                    stage_rows<T>(ptile, a.tile_stride, a.params + row0 * a.ps + o.col0, a.ps, o.n_params, R, valid_rows, tid, NT, o.vec_ok != 0);
-                    __syncthreads();
-                    p = ptile + r * a.tile_stride + d;
-                }
+                const T* p = vtile + l * ts + d;
                 if (o.model_offset) x -= p[0];
-                x = gfg_rotate_inv<T, G, true>(p, o, D, live, x);
-                x = gf_icdf<T>(o.inv_type, gfg_mixture<T, true>(p, o, D, x)).y;
+                x = gfg_rotate_inv<T, G, false>(p, o, D, live, x);
+                x = gf_icdf<T>(o.inv_type, gfb_mixture_pk<T>(pk + (a.pk0[l] + d) * 8, p, o, D, x)).y;
+            }
+        } else {
+#pragma unroll
+            for (int li = 0; li < JF_MAX_CHAIN; ++li) {
+                xreg[li] = x;
+                if (li < nl) {
+                    const GfLayerDev<T> o = a.L[nl - 1 - li];
+                    __syncthreads();
+                    stage_rows<T>(ptile, ts, a.params + row0 * a.ps + o.col0, a.ps, o.n_params, R, valid_rows, tid, NT, o.vec_ok != 0);
+                    __syncthreads();
+                    const T* p = ptile + r * ts + d;
+                    if (o.model_offset) x -= p[0];
+                    x = gfg_rotate_inv<T, G, true>(p, o, D, live, x);
+                    x = gf_icdf<T>(o.inv_type, gfg_mixture<T, true>(p, o, D, x)).y;
+                }
             }
         }
         // ---- upstream gradients: base log-prob = sum_d -x^2/2 - ...  =>  d/dx_out = -x_out
@@ -267,24 +543,30 @@ __global__ void __launch_bounds__(BCAST ? 256 : 64) gf_chain_bwd_kernel(const Gf
         const T glr = row_valid ? gl : T(0);
 
         // ---- backward sweep (layers 0 .. n-1)
-#pragma unroll
-        for (int li = JF_MAX_CHAIN - 1; li >= 0; --li) {
-            if (li < a.n_layers) {
-                const int l = a.n_layers - 1 - li;
+        if constexpr (BCAST) {
+#pragma unroll 1
+            for (int l = 0; l < nl; ++l) {
                 const GfLayerDev<T> o = a.L[l];
-                const T xi = xin[li];
-                if constexpr (BCAST) {
-                    gy = gf_layer_bwd<T, G, true>(ptile + l * a.tile_stride + d, gtile + l * a.tile_stride + d, o, D, live && row_valid, xi, gy, glr);
-                } else {
+                const int c0 = l * ts + d;
+                gy = gf_layer_bwd_bcast<T, G>(ptile + c0, vtile + c0, pk + (a.pk0[l] + d) * 8, acc + (c0 << slsh) + (r & ((1 << slsh) - 1)), o, D, live && row_valid,
+                                              xin[l * NT], gy, glr, slsh);
+            }
+        } else {
+#pragma unroll
+            for (int li = JF_MAX_CHAIN - 1; li >= 0; --li) {
+                if (li < nl) {
+                    const GfLayerDev<T> o = a.L[nl - 1 - li];
+                    const T xi = xreg[li];
                     __syncthreads();
-                    stage_rows<T>(ptile, a.tile_stride, a.params + row0 * a.ps + o.col0, a.ps, o.n_params, R, valid_rows, tid, NT, o.vec_ok != 0);
+                    stage_rows<T>(ptile, ts, a.params + row0 * a.ps + o.col0, a.ps, o.n_params, R, valid_rows, tid, NT, o.vec_ok != 0);
                     __syncthreads();
-                    gy = gf_layer_bwd<T, G, false>(ptile + r * a.tile_stride + d, gtile + r * a.tile_stride + d, o, D, live, xi, gy, glr);
+                    if (o.fast) gy = gf_layer_bwd_fast<T, G>(ptile + r * ts + d, gtile + r * ts + d, o, D, live, xi, gy, glr);
+                    else gy = gf_layer_bwd<T, G, false, T>(ptile + r * ts + d, gtile + r * ts + d, o, D, live, xi, gy, glr, 0);
                     __syncthreads();
                     // gradient tile -> HBM, row by row (consecutive lanes = consecutive columns)
                     for (int rr2 = 0; rr2 < valid_rows; ++rr2)
                         for (int j = tid; j < o.n_params; j += NT)
-                            a.g_params[(row0 + rr2) * a.gps + o.col0 + j] = gtile[rr2 * a.tile_stride + j];
+                            a.g_params[(row0 + rr2) * a.gps + o.col0 + j] = gtile[rr2 * ts + j];
                 }
             }
         }
@@ -292,11 +574,17 @@ __global__ void __launch_bounds__(BCAST ? 256 : 64) gf_chain_bwd_kernel(const Gf
         const T bad = group_max<T, G>((live && !M<T>::finite(gy)) ? T(1) : T(0));
         status_add(a.status, JF_STATUS_NONFINITE, row_valid && leader && bad > T(0));
     }
-    if constexpr (BCAST) {
-        __syncthreads();
-        for (int l = 0; l < a.n_layers; ++l) {
+    if constexpr (BCAST) {                                       // this workgroup's partial row: the slots of every parameter summed (rotated start: the
+        __syncthreads();                                         //   threads of a wave read different banks)
+        const int SL = 1 << slsh;
+        for (int l = 0; l < nl; ++l) {
             const GfLayerDev<T> o = a.L[l];
-            for (int j = tid; j < o.n_params; j += NT) a.g_params[(int64_t)blockIdx.x * a.gps + o.col0 + j] = gtile[l * a.tile_stride + j];
+            for (int j = tid; j < o.n_params; j += NT) {
+                const double* base = acc + ((l * ts + j) << slsh);
+                double sum = 0.0;
+                for (int s2 = 0; s2 < SL; ++s2) sum += base[(s2 + j) & (SL - 1)];
+                a.g_params[(int64_t)blockIdx.x * a.gps + o.col0 + j] = (T)sum;
+            }
         }
     }
 }
@@ -448,7 +736,14 @@ static int gb_launch(GfBwdArgs<T> a, bool bcast, hipStream_t st) {
         const int64_t n_tiles = (a.B + 256 / G - 1) / (256 / G);
         const int64_t blocks = gb_partials(a.B, a.D);
         a.tiles_per_block = (int)((n_tiles + blocks - 1) / blocks);
-        const size_t lds = (size_t)2 * a.n_layers * a.tile_stride * sizeof(T);
+        int slsh = G == 1 ? 6 : G == 2 ? 5 : G == 4 ? 4 : 3;       // one slot per row of a wave, fewer when the accumulators would not fit
+        const size_t cell = (size_t)a.n_layers * a.tile_stride * sizeof(T), acell = (size_t)a.n_layers * a.tile_stride * sizeof(double);
+        while (slsh > 0 && 3 * cell + (acell << slsh) > 56 * 1024) --slsh;
+        a.slsh = slsh;
+        int n_rec = 0;
+        for (int l = 0; l < a.n_layers; ++l) { a.pk0[l] = n_rec; n_rec += a.L[l].K * a.D; }
+        const size_t lds = 3 * cell + (acell << slsh) + ((size_t)a.n_layers * (256 + 16) + (size_t)n_rec * 8) * sizeof(T);
+        if (lds > 160 * 1024) return JF_ERR_UNSUPPORTED;
         auto k = gf_chain_bwd_kernel<T, G, true>;
         if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(256), lds, st, a);
