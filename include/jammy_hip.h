@@ -389,6 +389,14 @@ int jf_normal_logp_f32(const float* z, int64_t z_stride, int64_t B, int32_t D, c
 int jf_normal_logp_f64(const double* z, int64_t z_stride, int64_t B, int32_t D, const double* in, double* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * backward of a tanh activation: out[i] = g[i] * (1 - y[i]^2) for n contiguous elements (y = the saved activation).  What torch.autograd
+ * runs as three elementwise launches (y*y, 1 - ., g * .) behind nn.Tanh in the amortisation MLPs (main/default.py:656-670,
+ * amortizable_mlp.py:508-578); out may alias g.
+ * ------------------------------------------------------------------------------------------------------------ */
+int jf_tanh_bwd_f32(const float* g, const float* y, int64_t n, float* out, void* stream);
+int jf_tanh_bwd_f64(const double* g, const double* y, int64_t n, double* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
  * Reductions of the analysis utilities, so that 1e5 .. 1e6 evaluated rows never travel to the host:
  * jf_coverage_histogram: the counting loop of calculate_approximate_coverage (jammy_flows/helper_fns/coverage.py:45-65) behind
  *   pdf.approximate_coverage (main/default.py:1954-2022).  twice[b] = 2 (log_at_zero - log_prob_base[b]); thresholds = chi2.ppf of the expected

@@ -115,6 +115,7 @@ _SIGNATURES = {
     "jf_gf_chain_fwd": [_P, _I64, _P, _P, _I64, _I32, _I64, _I32, _I32, ctypes.POINTER(jf_gf_layer), _P, _I64, _P, _P, _I64, _P, _P],
     "jf_linear": [_P, _I64, _P, _I64, _P, _I64, _I32, _I32, _I32, _P, _I64, _P],
     "jf_normal_logp": [_P, _I64, _I64, _I32, _P, _P, _P],
+    "jf_tanh_bwd": [_P, _P, _I64, _P, _P],
     "jf_mlp2": [_P, _I64, _P, _I64, _P, _P, _I64, _P, _I64, _I32, _I32, _I32, _P, _I64, _P],
     "jf_sphere_to_embedding": [_P, _I64, _P, _I64, _I32, _P, _I64, _P, _P],
     "jf_sphere_from_embedding": [_P, _I64, _P, _I64, _I32, _P, _I64, _P, _P],
@@ -531,6 +532,17 @@ def linear_wgrad(g, inp, want_bias=True):
     pb = torch.empty((S, N), dtype=g.dtype, device=g.device) if want_bias else None
     _launch("jf_linear_wgrad" + _suffix(g), "K%d_N%d" % (K, N), (_ptr(g), g.stride(0), _ptr(inp), inp.stride(0), B, K, N, _ptr(pw), _ptr(pb)), dev)
     return (pw.sum(0) if S > 1 else pw[0]), (None if pb is None else (pb.sum(0) if S > 1 else pb[0]))
+
+
+def tanh_bwd(g, y, inplace=False):
+    """g * (1 - y^2) in one launch (the backward of a tanh whose output y was saved); inplace=True overwrites g (a fresh temporary)."""
+    dev = require_device(g, y)
+    if g.shape != y.shape or g.dtype != y.dtype:
+        raise ValueError("tanh_bwd: shape / dtype mismatch")
+    g, y = g.contiguous(), y.contiguous()
+    out = g if inplace else torch.empty_like(g)
+    _launch("jf_tanh_bwd" + _suffix(g), "", (_ptr(g), _ptr(y), g.numel(), _ptr(out)), dev)
+    return out
 
 
 def conditioning_rows(segments, B, dtype, device):

@@ -33,9 +33,7 @@ class LinearFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         inp, weight, out = ctx.saved_tensors
-        if ctx.act:
-            g = g * (1.0 - out * out)
-        g = g.contiguous()
+        g = _hip.tanh_bwd(g, out) if ctx.act else g.contiguous()
         g_inp = g @ weight if ctx.needs_input_grad[0] else None
         g_w = g_b = None
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
@@ -96,7 +94,7 @@ class CondBlockFn(torch.autograd.Function):
         del params
         need = ctx.needs_input_grad
         g_w2, g_b2 = _hip.linear_wgrad(g_p, h, want_bias=need[4]) if (need[3] or need[4]) else (None, None)
-        g_h = (g_p @ w2) * (1.0 - h * h)
+        g_h = _hip.tanh_bwd(g_p @ w2, h, inplace=True)
         del g_p
         g_w1, g_b1 = _hip.linear_wgrad(g_h, inp, want_bias=need[2]) if (need[1] or need[2]) else (None, None)
         g_inp = g_h @ w1 if need[0] else None

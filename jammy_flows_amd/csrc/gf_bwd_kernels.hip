@@ -41,6 +41,7 @@ template <typename T> struct GfBwdArgs {
     T* g_x; int64_t gxs;
     T* g_params; int64_t gps;
     int32_t* status;
+    int active_blocks;                        // broadcast regime: workgroups that take tiles (one resident round); the others write a zero row
     int pk0[JF_MAX_CHAIN];                    // broadcast regime: first packed component record of every layer (gf_chain_bwd_kernel)
     int slsh;                                 // broadcast regime: log2 of the accumulator slots per parameter (see gf_chain_bwd_kernel)
 };
@@ -434,6 +435,10 @@ __global__ void __launch_bounds__(BCAST ? 256 : 64) gf_chain_bwd_kernel(const Gf
     T* xin = reinterpret_cast<T*>(acc + ((nl * ts) << slsh)) + tid;   // BCAST only
     T* pk = xin - tid + nl * (NT + 16);                          // BCAST only: packed component records (16-byte aligned: every term is a multiple of 4)
     if constexpr (BCAST) {
+        if ((int)blockIdx.x >= a.active_blocks) {                // more partial rows than resident workgroups: zero rows
+            for (int j = tid; j < a.n_params_total; j += NT) a.g_params[(int64_t)blockIdx.x * a.gps + j] = T(0);
+            return;
+        }
         T* aux = xin - tid + nl * NT;
         for (int l = 0; l < nl; ++l) {
             const GfLayerDev<T> o = a.L[l];
@@ -499,7 +504,7 @@ __global__ void __launch_bounds__(BCAST ? 256 : 64) gf_chain_bwd_kernel(const Gf
     }
     const int tiles = BCAST ? a.tiles_per_block : 1;
     for (int t = 0; t < tiles; ++t) {
-        const int64_t row0 = ((int64_t)blockIdx.x * tiles + t) * R;
+        const int64_t row0 = (BCAST ? (int64_t)blockIdx.x + (int64_t)t * a.active_blocks : (int64_t)blockIdx.x) * R;
         if (row0 >= a.B) break;
         const int64_t row = row0 + r;
         const bool row_valid = row < a.B;
@@ -738,7 +743,7 @@ static int gb_launch(GfBwdArgs<T> a, bool bcast, hipStream_t st) {
         a.tiles_per_block = (int)((n_tiles + blocks - 1) / blocks);
         int slsh = G == 1 ? 6 : G == 2 ? 5 : G == 4 ? 4 : 3;       // one slot per row of a wave, fewer when the accumulators would not fit
         const size_t cell = (size_t)a.n_layers * a.tile_stride * sizeof(T), acell = (size_t)a.n_layers * a.tile_stride * sizeof(double);
-        while (slsh > 0 && 3 * cell + (acell << slsh) > 56 * 1024) --slsh;
+        while (slsh > 0 && 3 * cell + (acell << slsh) > 28 * 1024) --slsh;   // measured flat between 2 and 8 slots (conflicting ds_add_f64 are cheap); occupancy matters more
         a.slsh = slsh;
         int n_rec = 0;
         for (int l = 0; l < a.n_layers; ++l) { a.pk0[l] = n_rec; n_rec += a.L[l].K * a.D; }
@@ -746,6 +751,16 @@ static int gb_launch(GfBwdArgs<T> a, bool bcast, hipStream_t st) {
         if (lds > 160 * 1024) return JF_ERR_UNSUPPORTED;
         auto k = gf_chain_bwd_kernel<T, G, true>;
         if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        // one resident round of workgroups takes all tiles (grid stride): each pays the prologue / epilogue once, no tail round
+        int dev = 0, cus = 256, occ = 1;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)k, 256, lds) != hipSuccess || occ < 1) occ = 1;
+        int64_t active = (int64_t)cus * occ;
+        if (active > blocks) active = blocks;
+        if (active > n_tiles) active = n_tiles < 1 ? 1 : n_tiles;
+        a.active_blocks = (int)active;
+        a.tiles_per_block = (int)((n_tiles + active - 1) / active);
         hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(256), lds, st, a);
     } else {
         a.tiles_per_block = 1;

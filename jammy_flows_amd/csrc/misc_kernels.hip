@@ -128,6 +128,33 @@ template <typename T> static int normal_logp(const T* z, int64_t zs, int64_t B, 
     return check_launch();
 }
 
+// g (1 - y^2), 16 bytes per lane and access
+template <typename T>
+__global__ void __launch_bounds__(256) tanh_bwd_kernel(const T* __restrict__ g, const T* __restrict__ y, int64_t n, T* __restrict__ out, bool vec) {
+    constexpr int N = Vec16<T>::N;
+    using V = typename Vec16<T>::type;
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * N;
+    if (i >= n) return;
+    if (vec && i + N <= n) {
+        const V gv = *reinterpret_cast<const V*>(g + i), yv = *reinterpret_cast<const V*>(y + i);
+        V o;
+        const T* gp = reinterpret_cast<const T*>(&gv); const T* yp = reinterpret_cast<const T*>(&yv); T* op = reinterpret_cast<T*>(&o);
+#pragma unroll
+        for (int j = 0; j < N; ++j) op[j] = gp[j] * (T(1) - yp[j] * yp[j]);
+        *reinterpret_cast<V*>(out + i) = o;
+    } else {
+        for (int64_t j = i; j < n && j < i + N; ++j) out[j] = g[j] * (T(1) - y[j] * y[j]);
+    }
+}
+template <typename T> static int tanh_bwd(const T* g, const T* y, int64_t n, T* out, void* stream) {
+    if (!g || !y || !out || n < 0) return JF_ERR_BADARG;
+    if (n == 0) return JF_OK;
+    constexpr int N = Vec16<T>::N;
+    const bool vec = ((reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
+    hipLaunchKernelGGL(tanh_bwd_kernel<T>, dim3((unsigned)((n + 256 * N - 1) / (256 * N))), dim3(256), 0, (hipStream_t)stream, g, y, n, out, vec);
+    return check_launch();
+}
+
 }  // namespace jf
 
 extern "C" {
@@ -155,4 +182,6 @@ int jf_normal_logp_f32(const float* z, int64_t zs, int64_t B, int32_t D, const f
 int jf_normal_logp_f64(const double* z, int64_t zs, int64_t B, int32_t D, const double* in, double* out, void* s) {
     return jf::normal_logp<double>(z, zs, B, D, in, out, s);
 }
+int jf_tanh_bwd_f32(const float* g, const float* y, int64_t n, float* out, void* s) { return jf::tanh_bwd<float>(g, y, n, out, s); }
+int jf_tanh_bwd_f64(const double* g, const double* y, int64_t n, double* out, void* s) { return jf::tanh_bwd<double>(g, y, n, out, s); }
 }

@@ -38,6 +38,7 @@ def inputs(fx, n, seed):
 ap = argparse.ArgumentParser()
 ap.add_argument("--rows", type=int, default=1 << 18)
 ap.add_argument("--workload", default="c3")
+ap.add_argument("--torch-profile", action="store_true", help="also print the device-time table of torch.profiler for one step (library GEMMs, elementwise glue)")
 args = ap.parse_args()
 name, dtype = ("c3_e4s2e4", torch.float32) if args.workload == "c3" else ("c5_e8s2_ggggv", torch.float64)
 fx = fixture_io.load(name)
@@ -82,3 +83,10 @@ print("workload %s dtype %s rows %d: training step %.3f ms (%.3g rows/s), no-gra
     args.workload, dtype, args.rows, 1e3 * dt, args.rows / dt, 1e3 * dt_fwd, float(loss)))
 for k, v in sorted(timer.summary().items(), key=lambda kv: -kv[1]["total_ms"]):
     print("  %-44s x%d  %.3f ms" % (k[0] + "[" + k[1] + "]", v["launches"], v["total_ms"]))
+if args.torch_profile:
+    from torch.profiler import profile, ProfilerActivity
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+    print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=40, max_name_column_width=70))
