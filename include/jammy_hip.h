@@ -389,6 +389,20 @@ int jf_normal_logp_f32(const float* z, int64_t z_stride, int64_t B, int32_t D, c
 int jf_normal_logp_f64(const double* z, int64_t z_stride, int64_t B, int32_t D, const double* in, double* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * Dense layer on split-bf16 matrix arithmetic (float32 in / out, float32-equivalent accuracy: every operand as three bf16 pieces, six
+ * v_mfma_f32_16x16x32_bf16 per product, f32 accumulation):  out (B, N) = X (B, K) W^T + bias.  Serves the large products of the conditional
+ * block's backward -- the nn.Linear of mlp_predictors (main/default.py:656-670) re-evaluated, and grad_output @ weight of its autograd --
+ * at ~2.5x the rate of the exact-f32 MFMA kernel (jf_linear).
+ *   jf_linear_split_packed_bytes(N, K): size of the packed weight image;  jf_linear_split_pack_f32: W (N, K), element (n, k) at
+ *   W[n * w_row_stride + k * w_col_stride] (so a transposed view packs without a copy) -> packed (16-byte aligned), once per weight version;
+ *   jf_linear_split_f32: the product; needs K % 4 == 0, N % 4 == 0, 16-byte aligned rows (else JF_ERR_UNSUPPORTED: use jf_linear).
+ * ------------------------------------------------------------------------------------------------------------ */
+int64_t jf_linear_split_packed_bytes(int32_t N, int32_t K);
+int jf_linear_split_pack_f32(const float* W, int64_t w_row_stride, int64_t w_col_stride, int32_t N, int32_t K, void* packed, void* stream);
+int jf_linear_split_f32(const float* X, int64_t x_stride, const void* packed, const float* bias, int64_t B, int32_t K, int32_t N, float* out,
+                        int64_t out_stride, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
  * backward of a tanh activation: out[i] = g[i] * (1 - y[i]^2) for n contiguous elements (y = the saved activation).  What torch.autograd
  * runs as three elementwise launches (y*y, 1 - ., g * .) behind nn.Tanh in the amortisation MLPs (main/default.py:656-670,
  * amortizable_mlp.py:508-578); out may alias g.

@@ -134,6 +134,9 @@ _SIGNATURES_SINGLE = {
     "jf_linear_wgrad_splits_f32": ([_I64, _I32], ctypes.c_int64),
     "jf_linear_wgrad_splits_f64": ([_I64, _I32], ctypes.c_int64),
     "jf_gf_chain_inv_bwd_partials": ([_I64, _I32], ctypes.c_int64),
+    "jf_linear_split_packed_bytes": ([_I32, _I32], ctypes.c_int64),
+    "jf_linear_split_pack_f32": ([_P, _I64, _I64, _I32, _I32, _P, _P], ctypes.c_int),
+    "jf_linear_split_f32": ([_P, _I64, _P, _P, _I64, _I32, _I32, _P, _I64, _P], ctypes.c_int),
     "jf_cond_gf_packed_bytes": ([_I32, _I32, ctypes.POINTER(jf_gf_layer)], ctypes.c_int64),
     "jf_cond_gf_pack_f32": ([_P, _I64, _P, _I32, _I32, _I32, ctypes.POINTER(jf_gf_layer), _P, _P], ctypes.c_int),
     "jf_cond_gf_chain_inv_split_f32": ([_P, _I64, _P, _I64, _P, _P, _I32, _I32, _P, _I64, _P, _I64, _I32, _I32, ctypes.POINTER(jf_gf_layer), _P, _I64,
@@ -532,6 +535,31 @@ def linear_wgrad(g, inp, want_bias=True):
     pb = torch.empty((S, N), dtype=g.dtype, device=g.device) if want_bias else None
     _launch("jf_linear_wgrad" + _suffix(g), "K%d_N%d" % (K, N), (_ptr(g), g.stride(0), _ptr(inp), inp.stride(0), B, K, N, _ptr(pw), _ptr(pb)), dev)
     return (pw.sum(0) if S > 1 else pw[0]), (None if pb is None else (pb.sum(0) if S > 1 else pb[0]))
+
+
+def linear_split_ok(x, weight, bias=None):
+    """True when jf_linear_split_f32 can take out = x @ weight^T: float32, K and N multiples of 4, 16-byte aligned rows"""
+    N, K = weight.shape
+    if bias is not None and (bias.dtype != torch.float32 or bias.data_ptr() % 16 or bias.stride(0) != 1):
+        return False
+    return (x.dtype == torch.float32 and weight.dtype == torch.float32 and K % 4 == 0 and N % 4 == 0 and x.dim() == 2 and x.shape[1] == K
+            and x.stride(1) == 1 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0 and x.shape[0] > 0)
+
+
+def linear_split(x, weight, bias=None):
+    """x (B, K) @ weight (N, K)^T + bias on split-bf16 MFMA (float32-equivalent accuracy); weight may be any strided 2-d view (a transposed
+    weight packs without a copy).  The weight image is packed per call (N K elements: microseconds next to the product)."""
+    dev = require_device(x, weight, bias)
+    if not linear_split_ok(x, weight, bias):
+        raise ValueError("linear_split: unsupported shape / dtype / alignment (see linear_split_ok)")
+    B, K = x.shape
+    N = weight.shape[0]
+    nbytes = int(lib().jf_linear_split_packed_bytes(N, K))
+    packed = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    _launch("jf_linear_split_pack_f32", "", (_ptr(weight), weight.stride(0), weight.stride(1), N, K, _ptr(packed)), dev)
+    out = torch.empty((B, N), dtype=x.dtype, device=x.device)
+    _launch("jf_linear_split_f32", "K%d_N%d" % (K, N), (_ptr(x), x.stride(0), _ptr(packed), _ptr(bias), B, K, N, _ptr(out), out.stride(0)), dev)
+    return out
 
 
 def tanh_bwd(g, y, inplace=False):

@@ -87,14 +87,16 @@ class CondBlockFn(torch.autograd.Function):
     def backward(ctx, g_xout, g_ld, g_blp):
         inp, w1, b1, w2, b2, x = ctx.saved_tensors
         layer_array, n_layers, D = ctx.meta
-        # the parameter block is not kept by the forward launch: two dense launches bring it back (exact f32 MFMA)
+        # the parameter block is not kept by the forward launch: two dense launches bring it back (the large one on split-bf16 MFMA, float32:
+        # the arithmetic of the fused forward block)
         h = _hip.linear(inp, w1, b1, 1)
-        params = _hip.linear(h, w2, b2, 0)
+        split = _hip.linear_split_ok(h, w2, b2)
+        params = _hip.linear_split(h, w2, b2) if split else _hip.linear(h, w2, b2, 0)
         g_x, g_p = _hip.gf_chain_inv_bwd(x, params, layer_array, n_layers, D, g_xout, g_ld, g_blp, status=None)
         del params
         need = ctx.needs_input_grad
         g_w2, g_b2 = _hip.linear_wgrad(g_p, h, want_bias=need[4]) if (need[3] or need[4]) else (None, None)
-        g_h = _hip.tanh_bwd(g_p @ w2, h, inplace=True)
+        g_h = _hip.tanh_bwd(_hip.linear_split(g_p, w2.t()) if split and _hip.linear_split_ok(g_p, w2.t()) else g_p @ w2, h, inplace=True)
         del g_p
         g_w1, g_b1 = _hip.linear_wgrad(g_h, inp, want_bias=need[2]) if (need[1] or need[2]) else (None, None)
         g_inp = g_h @ w1 if need[0] else None

@@ -1,0 +1,40 @@
+"""jf_linear_split_f32 (split-bf16 MFMA dense layer, float32-equivalent accuracy) against a float64 product: both loop shapes (wide: N > 128,
+deep: N <= 128), ragged row counts, K not a multiple of 32, a transposed weight view, with and without bias."""
+import numpy as np
+import pytest
+import torch
+
+from jammy_flows_amd import _hip
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("B,K,N,transposed,bias", [(70001, 128, 548, False, True), (5000, 548, 128, True, False), (257, 36, 20, False, True),
+                                                   (1, 4, 4, False, False), (129, 128, 132, True, True), (4097, 548, 128, False, True)])
+def test_linear_split_matches_float64_product(B, K, N, transposed, bias):
+    rng = np.random.default_rng(B + K + N)
+    x = torch.from_numpy(rng.normal(size=(B, K)) * np.exp(rng.normal(size=(B, 1)))).to(device="cuda", dtype=torch.float32)
+    w_full = torch.from_numpy(rng.normal(size=(K, N) if transposed else (N, K)) / np.sqrt(K)).to(device="cuda", dtype=torch.float32)
+    w = w_full.t() if transposed else w_full
+    b = torch.from_numpy(rng.normal(size=(N,))).to(device="cuda", dtype=torch.float32) if bias else None
+    assert _hip.linear_split_ok(x, w, b)
+    out = _hip.linear_split(x, w, b)
+    ref = x.double() @ w.double().t() + (b.double() if bias else 0.0)
+    bound = x.double().abs() @ w.double().abs().t() + (b.double().abs() if bias else 0.0) + 1e-30     # sum |x||w| + |b|: the scale of the rounding of a K-term float32 dot product
+    rel = (out.double() - ref).abs() / bound
+    err, rms = rel.max().item(), rel.pow(2).mean().sqrt().item()
+    exact = x @ w.t() + (b if bias else 0.0)                       # the library's float32 product, for scale
+    rel_lib = (exact.double() - ref).abs() / bound
+    print("B %d K %d N %d: error / sum|x||w|: max %.2e rms %.2e (library float32 GEMM: max %.2e rms %.2e)" % (
+        B, K, N, err, rms, rel_lib.max().item(), rel_lib.pow(2).mean().sqrt().item()))
+    # 6 piece products x K / 32 k-steps, each one float32 accumulation (<= 2^-24 of the running sum): worst case 6 K / 32 * 6e-8
+    assert err < 6 * ((K + 31) // 32) * 6.0e-8 + 1e-7
+    assert err < 4 * rel_lib.max().item() + 1e-7 and rms < 1.0e-7
+
+
+def test_linear_split_rejects_unaligned_shapes():
+    x = torch.zeros((8, 6), device="cuda")
+    w = torch.zeros((8, 6), device="cuda")
+    assert not _hip.linear_split_ok(x, w)
+    with pytest.raises(ValueError):
+        _hip.linear_split(x, w)
