@@ -402,6 +402,13 @@ int jf_linear_split_pack_f32(const float* W, int64_t w_row_stride, int64_t w_col
 int jf_linear_split_f32(const float* X, int64_t x_stride, const void* packed, const float* bias, int64_t B, int32_t K, int32_t N, float* out,
                         int64_t out_stride, void* stream);
 
+/* jf_linear_wgrad on the same split-bf16 arithmetic (float32, K <= 128, K % 4 == 0, N % 4 == 0, 16-byte aligned rows; else
+ * JF_ERR_UNSUPPORTED: use jf_linear_wgrad): partial_w (S, N, K) and partial_b (S, N) or NULL with S = jf_linear_wgrad_split_splits(B, N),
+ * added up by the caller. */
+int64_t jf_linear_wgrad_split_splits(int64_t B, int32_t N);
+int jf_linear_wgrad_split_f32(const float* g, int64_t g_stride, const float* in, int64_t in_stride, int64_t B, int32_t K, int32_t N, float* partial_w,
+                              float* partial_b, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * backward of a tanh activation: out[i] = g[i] * (1 - y[i]^2) for n contiguous elements (y = the saved activation).  What torch.autograd
  * runs as three elementwise launches (y*y, 1 - ., g * .) behind nn.Tanh in the amortisation MLPs (main/default.py:656-670,

@@ -34,6 +34,20 @@ __device__ __forceinline__ void sg_split(float v, __bf16& hi, __bf16& mid, __bf1
     lo = (__bf16)(r1 - (float)mid);                // exact difference, rounded once
 }
 
+// The same split by TRUNCATION, two values at a time, as packed bf16 pairs: a float32 has 24 significant bits, each piece takes the next 8, so
+// v = hi + mid + lo holds exactly here as well.  and / sub / and / sub per value + one v_perm_b32 per packed pair: full-rate VALU only -- the
+// RNE form needs three v_cvt_pk_bf16_f32 per value, which dominated the staging of the weight-gradient kernel.
+__device__ __forceinline__ void sg_split2(float v0, float v1, unsigned& p0, unsigned& p1, unsigned& p2) {
+    const unsigned a0 = __builtin_bit_cast(unsigned, v0), a1 = __builtin_bit_cast(unsigned, v1);
+    const float r0 = v0 - __builtin_bit_cast(float, a0 & 0xffff0000u), r1 = v1 - __builtin_bit_cast(float, a1 & 0xffff0000u);
+    const unsigned b0 = __builtin_bit_cast(unsigned, r0), b1 = __builtin_bit_cast(unsigned, r1);
+    const float s0 = r0 - __builtin_bit_cast(float, b0 & 0xffff0000u), s1 = r1 - __builtin_bit_cast(float, b1 & 0xffff0000u);
+    constexpr unsigned SEL = 0x07060302u;                          // {hi16(first operand), hi16(second operand)}
+    p0 = __builtin_amdgcn_perm(a1, a0, SEL);
+    p1 = __builtin_amdgcn_perm(b1, b0, SEL);
+    p2 = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, s1), __builtin_bit_cast(unsigned, s0), SEL);
+}
+
 struct SgShape { int ng, kc; };
 static inline SgShape sg_shape(int N) { return N <= 128 ? SgShape{8, 1} : SgShape{3, 4}; }
 static inline int64_t sg_groups(int N, int ng) { return ((N + 15) / 16 + ng - 1) / ng; }
@@ -123,17 +137,21 @@ template <int NG, int KC, int TB, int RG> __global__ void __launch_bounds__(256,
                 }
     };
     sg_bf16x8 xB[RG][KC][SG_NP];
+    using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
     auto split_x = [&]() {
 #pragma unroll
         for (int g = 0; g < RG; ++g)
 #pragma unroll
-            for (int s = 0; s < KC; ++s)
+            for (int s = 0; s < KC; ++s) {
+                u32x4 q0, q1, q2;
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    __bf16 p0, p1, p2;
-                    sg_split(xraw[g][s][i >> 2][i & 3], p0, p1, p2);
-                    xB[g][s][0][i] = p0; xB[g][s][1][i] = p1; xB[g][s][2][i] = p2;
+                for (int i = 0; i < 8; i += 2) {
+                    unsigned p0, p1, p2;
+                    sg_split2(xraw[g][s][i >> 2][i & 3], xraw[g][s][i >> 2][(i & 3) + 1], p0, p1, p2);
+                    q0[i >> 1] = p0; q1[i >> 1] = p1; q2[i >> 1] = p2;
                 }
+                xB[g][s][0] = __builtin_bit_cast(sg_bf16x8, q0); xB[g][s][1] = __builtin_bit_cast(sg_bf16x8, q1); xB[g][s][2] = __builtin_bit_cast(sg_bf16x8, q2);
+            }
     };
     load_x(0);
     landed();                                                      // chunk 0 in buffer 0, X slice 0 in registers
@@ -238,5 +256,175 @@ int jf_linear_split_pack_f32(const float* W, int64_t w_row_stride, int64_t w_col
 int jf_linear_split_f32(const float* X, int64_t x_stride, const void* packed, const float* bias, int64_t B, int32_t K, int32_t N, float* out,
                         int64_t out_stride, void* stream) {
     return jf::sg_linear(X, x_stride, packed, bias, B, K, N, out, out_stride, stream);
+}
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------------------
+// Weight gradient on the same arithmetic:  g_W (N, K) = sum_b g[b, :]^T in[b, :]  (+ column sums of g), K <= 128, B >> N.
+// The reduction runs over the BATCH, so both MFMA operands need 8 batch rows per lane for one column -- a transposition of the row-major inputs.
+// A workgroup (4 waves) owns 128 columns n of g and a range of rows; per step of 32 rows every thread loads one 4 x 4 patch (4 rows x 4
+// columns, 16-byte loads) of g and one of `in`, splits its 16 + 16 values ONCE into bf16 pieces and writes them -- transposed in registers --
+// as 8-byte runs of 4 rows into fragment images in LDS; the waves then read ready-made fragments (ds_read_b128) for 2 x 8 tiles each.
+// Inside a fragment the 16-byte slot of lane (m, q) sits at (m & 3) * 16 + (m >> 2) * 4 + q: the 64 lanes of a patch-write instruction then
+// spread over all banks (row-major m would put them 64 bytes apart: 8-way conflicts).  Partial slabs per row range, added by the caller.
+// ------------------------------------------------------------------------------------------------------------------------------------------
+namespace jf {
+
+struct WsArgs {
+    const float* g; int64_t gs;
+    const float* in; int64_t is;
+    int64_t B, rows_per_split;
+    int K, N;
+    float* pw; float* pb;
+};
+
+constexpr int WS_NW = 128;                         // columns of g per workgroup
+constexpr int WS_TILES = WS_NW / 16;               // = k-tiles of `in` (K <= 128)
+constexpr int WS_FRAG = SG_FRAG + 16;              // fragment pitch in LDS: the 8 tiles a patch-write instruction touches start 12 banks apart
+
+__device__ __forceinline__ int ws_slot(int m, int q) { return (m & 3) * 16 + (m >> 2) * 4 + q; }
+
+__global__ void __launch_bounds__(256, 2) wgrad_split_kernel(const WsArgs a) {
+    __shared__ __align__(16) unsigned char Gs[WS_TILES * SG_NP * WS_FRAG];     // 24 KiB: fragments of the g tile
+    __shared__ __align__(16) unsigned char Is[WS_TILES * SG_NP * WS_FRAG];     // 24 KiB: fragments of the `in` tile
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lq = lane >> 4;
+    const int n0 = blockIdx.x * WS_NW;
+    const int64_t b0 = (int64_t)blockIdx.y * a.rows_per_split;
+    const int64_t b1 = b0 + a.rows_per_split < a.B ? b0 + a.rows_per_split : a.B;
+    const int steps = b1 > b0 ? (int)((b1 - b0 + 31) / 32) : 0;
+    // staging patch of this thread: columns 4 pn .. 4 pn + 3, rows 4 b4 .. 4 b4 + 3 of the step
+    const int pn = tid & 31, b4 = tid >> 5, pq = b4 >> 1, phi = b4 & 1;       // rows 16 phi + 4 pq ..: the two halves of a wave differ in phi (+ 8 bytes)
+    const bool gcol = n0 + 4 * pn < a.N, icol = 4 * pn < a.K;
+    const float* gp = a.g + (gcol ? n0 + 4 * pn : 0);
+    const float* ip = a.in + (icol ? 4 * pn : 0);
+    const int woff = ((pn >> 2) * SG_NP) * WS_FRAG + ((pn & 3) * 4 + pq) * 16 + phi * 8;        // + jj * 256 (slot: jj * 16 slots) + piece * 1024
+    // two patch buffers: the loads of step i + 2 are issued when step i has been written to LDS (one step of MFMAs does not cover an HBM round trip)
+    f32x4 gv[2][4], iv[2][4];
+    auto load_patch = [&](int step, f32x4 (&gb)[4], f32x4 (&ib)[4]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t r = b0 + 32 * (int64_t)step + 16 * phi + 4 * pq + j;
+            const bool ok = r < b1;
+            const int64_t rr = ok ? r : b1 - 1;
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            gb[j] = (ok && gcol) ? *reinterpret_cast<const f32x4*>(gp + rr * a.gs) : z;
+            ib[j] = (ok && icol) ? *reinterpret_cast<const f32x4*>(ip + rr * a.is) : z;
+        }
+    };
+    using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
+    auto write_patch = [&](const f32x4 (&v)[4], unsigned char* base) {
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            unsigned a0, a1, a2, c0, c1, c2;
+            sg_split2(v[0][jj], v[1][jj], a0, a1, a2);
+            sg_split2(v[2][jj], v[3][jj], c0, c1, c2);
+            const u32x2 p0 = {a0, c0}, p1 = {a1, c1}, p2 = {a2, c2};
+            unsigned char* w = base + woff + jj * 256;
+            *reinterpret_cast<u32x2*>(w) = p0;
+            *reinterpret_cast<u32x2*>(w + WS_FRAG) = p1;
+            *reinterpret_cast<u32x2*>(w + 2 * WS_FRAG) = p2;
+        }
+    };
+    f32x4 acc[2][WS_TILES];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int k = 0; k < WS_TILES; ++k) acc[t][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
+    const int roff = ws_slot(li, lq) * 16;
+    const bool wave_live = n0 + 16 * (2 * wave) < a.N;             // wave-uniform: some column of this wave's two tiles exists
+    auto one_step = [&](int step, f32x4 (&gb)[4], f32x4 (&ib)[4]) {
+        __syncthreads();                                           // every wave has read the previous step's fragments
+        write_patch(gb, Gs);
+        write_patch(ib, Is);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bsum += gb[j];
+        __syncthreads();
+        if (step + 2 < steps) load_patch(step + 2, gb, ib);        // in flight behind two steps of MFMAs
+        if (!wave_live) return;
+        sg_bf16x8 A[2][SG_NP];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int p = 0; p < SG_NP; ++p) A[t][p] = *reinterpret_cast<const sg_bf16x8*>(Gs + ((2 * wave + t) * SG_NP + p) * WS_FRAG + roff);
+        constexpr int KB = 2;                                      // k-tiles of `in` held at a time
+#pragma unroll
+        for (int kh = 0; kh < WS_TILES / KB; ++kh) {
+            sg_bf16x8 Bf[KB][SG_NP];
+#pragma unroll
+            for (int k = 0; k < KB; ++k)
+#pragma unroll
+                for (int p = 0; p < SG_NP; ++p) Bf[k][p] = *reinterpret_cast<const sg_bf16x8*>(Is + ((kh * KB + k) * SG_NP + p) * WS_FRAG + roff);
+            constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+#pragma unroll
+                for (int k = 0; k < KB; ++k)
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+                        acc[t][kh * KB + k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[t][PA[i]], Bf[k][PB[i]], acc[t][kh * KB + k], 0, 0, 0);
+        }
+    };
+    if (steps > 0) load_patch(0, gv[0], iv[0]);
+    if (steps > 1) load_patch(1, gv[1], iv[1]);
+    for (int step = 0; step < steps; step += 2) {
+        one_step(step, gv[0], iv[0]);
+        if (step + 1 < steps) one_step(step + 1, gv[1], iv[1]);
+    }
+    // acc[t][k][r] = g_W[n0 + 16 (2 wave + t) + 4 lq + r][16 k + li]
+    float* slab = a.pw + (int64_t)blockIdx.y * a.N * a.K;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int k = 0; k < WS_TILES; ++k)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + 16 * (2 * wave + t) + 4 * lq + r, kk = 16 * k + li;
+                if (n < a.N && kk < a.K) slab[(int64_t)n * a.K + kk] = acc[t][k][r];
+            }
+    if (a.pb != nullptr) {                                         // column sums of g: this thread's 4 columns over its rows, then over the 8 row groups
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(Gs);
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) red[b4 * WS_NW + 4 * pn + jj] = bsum[jj];
+        __syncthreads();
+        if (tid < WS_NW && n0 + tid < a.N) {
+            float s = 0.f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) s += red[q * WS_NW + tid];
+            a.pb[(int64_t)blockIdx.y * a.N + n0 + tid] = s;
+        }
+    }
+}
+
+static int64_t ws_splits(int64_t B, int N) {
+    const int64_t cols = (N + WS_NW - 1) / WS_NW;
+    int64_t s = (1024 + cols - 1) / cols;                          // ~2 resident rounds of workgroups
+    const int64_t max_s = (B + 511) / 512;                         // at least 512 rows per split
+    if (s > max_s) s = max_s;
+    if (s > 65535) s = 65535;
+    return s < 1 ? 1 : s;
+}
+
+static int ws_wgrad(const float* g, int64_t gs, const float* in, int64_t is, int64_t B, int K, int N, float* pw, float* pb, void* stream) {
+    if (!g || !in || !pw || B < 0 || K < 1 || N < 1) return JF_ERR_BADARG;
+    if (K > 128 || K % 4 || N % 4 || gs % 4 || is % 4 || ((reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(in)) & 15u)) return JF_ERR_UNSUPPORTED;
+    if (B == 0) return JF_OK;
+    WsArgs a{};
+    a.g = g; a.gs = gs; a.in = in; a.is = is; a.B = B; a.K = K; a.N = N; a.pw = pw; a.pb = pb;
+    const int64_t S = ws_splits(B, N);
+    a.rows_per_split = ((B + S - 1) / S + 31) / 32 * 32;
+    hipLaunchKernelGGL(wgrad_split_kernel, dim3((unsigned)((N + WS_NW - 1) / WS_NW), (unsigned)S), dim3(256), 0, (hipStream_t)stream, a);
+    return check_launch();
+}
+
+}  // namespace jf
+
+extern "C" {
+int64_t jf_linear_wgrad_split_splits(int64_t B, int32_t N) { return jf::ws_splits(B, N); }
+int jf_linear_wgrad_split_f32(const float* g, int64_t g_stride, const float* in, int64_t in_stride, int64_t B, int32_t K, int32_t N, float* partial_w,
+                              float* partial_b, void* stream) {
+    return jf::ws_wgrad(g, g_stride, in, in_stride, B, K, N, partial_w, partial_b, stream);
 }
 }
