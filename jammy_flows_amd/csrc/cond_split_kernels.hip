@@ -292,15 +292,26 @@ template <int RG> __global__ void __launch_bounds__(256, 2) cond_gf_split_kernel
         }
         // acc[j][r] = pre-activation of hidden unit 16 j + 4 lq + r for row li: k-slot i of k-step s <-> (j = 2 s + i / 4, r = i % 4)
 #pragma unroll
-        for (int s = 0; s < CS_KSTEPS; ++s)
+        for (int s = 0; s < CS_KSTEPS; ++s) {
+            // split by truncation, two values at a time (and / sub / and / sub + one v_perm_b32 per packed pair; exact as well: 24 significant
+            // bits = 3 x 8): three v_cvt_pk_bf16_f32 per value were the expensive part of this loop
+            using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+            u32x4 q0, q1, q2;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
+            for (int i = 0; i < 8; i += 2) {
                 const int j = 2 * s + (i >> 2), r = i & 3;
-                const float h = M<float>::tanh_fast(acc[j][r] + b1s[j * MT + 4 * lq + r]);
-                __bf16 p0, p1, p2;
-                cs_split(h, p0, p1, p2);
-                hB[g][s][0][i] = p0; hB[g][s][1][i] = p1; hB[g][s][2][i] = p2;
+                const float h0 = M<float>::tanh_fast(acc[j][r] + b1s[j * MT + 4 * lq + r]);
+                const float h1 = M<float>::tanh_fast(acc[j][r + 1] + b1s[j * MT + 4 * lq + r + 1]);
+                const unsigned a0 = __builtin_bit_cast(unsigned, h0), a1 = __builtin_bit_cast(unsigned, h1);
+                const float r0 = h0 - __builtin_bit_cast(float, a0 & 0xffff0000u), r1 = h1 - __builtin_bit_cast(float, a1 & 0xffff0000u);
+                const unsigned c0 = __builtin_bit_cast(unsigned, r0), c1 = __builtin_bit_cast(unsigned, r1);
+                const float s0 = r0 - __builtin_bit_cast(float, c0 & 0xffff0000u), s1 = r1 - __builtin_bit_cast(float, c1 & 0xffff0000u);
+                q0[i >> 1] = __builtin_amdgcn_perm(a1, a0, 0x07060302u);
+                q1[i >> 1] = __builtin_amdgcn_perm(c1, c0, 0x07060302u);
+                q2[i >> 1] = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, s1), __builtin_bit_cast(unsigned, s0), 0x07060302u);
             }
+            hB[g][s][0] = __builtin_bit_cast(bf16x8, q0); hB[g][s][1] = __builtin_bit_cast(bf16x8, q1); hB[g][s][2] = __builtin_bit_cast(bf16x8, q2);
+        }
     }
 
     // ---- flow state: lane = (row li of the row group's 16, coordinate lq)
