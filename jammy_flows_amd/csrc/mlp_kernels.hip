@@ -465,11 +465,61 @@ static int mlp2(const T* in, int64_t in_stride, const T* W1, int64_t w1_stride, 
     return mlp2_dispatch<T, true>(in, in_stride, W1, w1_stride, b1, W2, w2_stride, b2, B, K1, H, N, out, out_stride, 0, stream);
 }
 
+// ---------------------------------------------------------------------------------------------------------- skinny products
+// The low-rank stages of AmortizableMLP (amortizable_mlp.py:508-578) and their backward are products with ONE tiny dimension (rank 8):
+// (B x 8) (8 x 1224), (B x 1224) (1224 x 8), ...  They are pure HBM streams -- 8 FMAs per written / read element -- and a 16 x 16 MFMA
+// tiling wastes most of every tile on them (jf_linear_f64[K8_N1224] 0.51 ms, [K1224_N8] 0.44 ms per 2^17 rows; 0.17 ms of traffic each).
+// skinny_k: K <= 16.  thread = output column n (W[n][:] in registers, coalesced stores), a workgroup walks SK_ROWS rows whose K inputs are
+//           wave-uniform (scalar loads).  K8_N1224 0.51 -> 0.33 ms, K8_N128 0.078 -> 0.040 ms per 2^17 rows (float64).
+// (The mirrored shape, N <= 16 with a long K, stays on the tiled MFMA kernel below: a lane-per-column streaming version with a wave
+//  reduce-scatter measured slower, 0.54 .. 0.74 vs 0.44 ms -- 32 .. 64 float64 accumulators per lane leave one wave per SIMD.)
+constexpr int SK_ROWS = 32, SK_KMAX = 16;
+template <typename T, int K>
+__global__ void __launch_bounds__(256) skinny_k_kernel(const T* __restrict__ in, int64_t is, const T* __restrict__ W, int64_t ws, const T* __restrict__ bias,
+                                                       int64_t B, int N, int act, T* __restrict__ out, int64_t os, int cb_shift, int rows) {
+    // CB = 2^cb_shift (64, 128 or 256) columns per workgroup; the 256 / CB wave groups take interleaved rows
+    const int CB = 1 << cb_shift;
+    const int n = blockIdx.x * CB + (threadIdx.x & (CB - 1));
+    const int rg = __builtin_amdgcn_readfirstlane(threadIdx.x >> cb_shift), nrg = 256 >> cb_shift;
+    const bool live = n < N;
+    T w[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) w[k] = live ? W[(int64_t)n * ws + k] : T(0);
+    const T b = (live && bias) ? bias[n] : T(0);
+    const int64_t r0 = (int64_t)blockIdx.y * rows;
+    const int64_t r1 = r0 + rows < B ? r0 + rows : B;
+    for (int64_t r = r0 + rg; r < r1; r += nrg) {
+        const T* x = in + r * is;                                // wave-uniform address: scalar loads
+        T acc = b;
+#pragma unroll
+        for (int k = 0; k < K; ++k) acc += x[k] * w[k];
+        if (act) acc = M<T>::tanh_fast(acc);
+        if (live) out[r * os + n] = acc;
+    }
+}
+
+template <typename T> static bool skinny_linear(const T* in, int64_t is, const T* W, int64_t ws, const T* bias, int64_t B, int32_t K, int32_t N, int32_t act,
+                                                T* out, int64_t os, hipStream_t st) {
+    if (K <= SK_KMAX && N >= 32) {
+        const int cb_shift = N <= 64 ? 6 : N <= 128 ? 7 : 8;
+        int64_t rows = SK_ROWS;                                    // rows per workgroup: 32, more when the grid's y extent (65535) would overflow
+        if ((B + rows - 1) / rows > 65535) rows = (B + 65534) / 65535;
+        if (rows > 0x7fffffff) return false;
+        const dim3 grid((unsigned)((N + (1 << cb_shift) - 1) >> cb_shift), (unsigned)((B + rows - 1) / rows));
+#define JF_SK(K_) case K_: hipLaunchKernelGGL((skinny_k_kernel<T, K_>), grid, dim3(256), 0, st, in, is, W, ws, bias, B, (int)N, (int)act, out, os, cb_shift, (int)rows); return true;
+        switch (K) { JF_SK(1) JF_SK(2) JF_SK(3) JF_SK(4) JF_SK(5) JF_SK(6) JF_SK(7) JF_SK(8) JF_SK(9) JF_SK(10) JF_SK(11) JF_SK(12) JF_SK(13) JF_SK(14) JF_SK(15)
+                     JF_SK(16) default: return false; }
+#undef JF_SK
+    }
+    return false;
+}
+
 template <typename T>
 static int linear(const T* in, int64_t in_stride, const T* W, int64_t w_stride, const T* bias, int64_t B, int32_t K, int32_t N, int32_t act, T* out,
                   int64_t out_stride, void* stream) {
     if (!in || !W || !out || K < 1 || N < 1 || B < 0 || (act != 0 && act != 1)) return JF_ERR_BADARG;
     if (B == 0) return JF_OK;
+    if (skinny_linear<T>(in, in_stride, W, w_stride, bias, B, K, N, act, out, out_stride, (hipStream_t)stream)) return check_launch();
     // K <= 128 with 16-byte aligned weight rows: the mlp2 machinery without a first layer (input held in registers as the B operand,
     // transposed product, 16-byte predicate-free stores, resident workgroups for narrow outputs)
     if (K <= HMAX && (K % Vec16<T>::N == 0) && (w_stride % Vec16<T>::N == 0) && ((reinterpret_cast<uintptr_t>(W) & 15u) == 0))

@@ -38,3 +38,20 @@ def test_linear_split_rejects_unaligned_shapes():
     assert not _hip.linear_split_ok(x, w)
     with pytest.raises(ValueError):
         _hip.linear_split(x, w)
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("B,K,N,act", [(5000, 8, 1224, 0), (4099, 1224, 8, 0), (300, 8, 128, 1), (300, 128, 8, 0), (7, 3, 50, 1), (1001, 16, 40, 0),
+                                       (130, 548, 10, 1), (1, 300, 1, 0), (70000, 8, 36, 0)])
+def test_linear_skinny_shapes(dtype, B, K, N, act):
+    """jf_linear with one tiny dimension (the rank-8 stages of AmortizableMLP and their backward: streaming kernels instead of MFMA tiles)"""
+    rng = np.random.default_rng(B + K + N)
+    x = torch.from_numpy(rng.normal(size=(B, K))).to(device="cuda", dtype=dtype)
+    w = torch.from_numpy(rng.normal(size=(N, K)) / np.sqrt(K)).to(device="cuda", dtype=dtype)
+    b = torch.from_numpy(rng.normal(size=(N,))).to(device="cuda", dtype=dtype)
+    out = _hip.linear(x, w, b, act)
+    ref = x.double() @ w.double().t() + b.double()
+    if act:
+        ref = torch.tanh(ref)
+    err = (out.double() - ref).abs().max().item()
+    assert err < (1e-12 if dtype == torch.float64 else 3e-6) * (1 + K ** 0.5), err
