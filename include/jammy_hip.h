@@ -184,10 +184,11 @@ int jf_linear_f64(const double* in, int64_t in_stride, const double* W, int64_t 
 
 /* Backward of jf_linear with respect to the weights: the product that reduces over the batch,
  *   g_W (N, K) = sum_b g[b, :]^T in[b, :],  g_bias (N) = sum_b g[b, :]        (what autograd's `g.t() @ inp`, `g.sum(0)` compute for nn.Linear)
- * split over the grid: partials_w (S, N, K) and partials_b (S, N; nullable) receive one slab per row chunk, S = jf_linear_wgrad_splits_<dt>(B, N);
- * the caller adds the slabs (deterministic, no atomics).  K <= 128, otherwise JF_ERR_UNSUPPORTED (use a library GEMM). */
-int64_t jf_linear_wgrad_splits_f32(int64_t B, int32_t N);
-int64_t jf_linear_wgrad_splits_f64(int64_t B, int32_t N);
+ * split over the grid: partials_w (S, N, K) and partials_b (S, N; nullable) receive one slab per row chunk, S = jf_linear_wgrad_splits_<dt>(B, K, N)
+ * (ABI 3: the shape decides between the tiled MFMA kernel and the streaming kernel for min(N, K) <= 16); the caller adds the slabs
+ * (deterministic, no atomics).  K <= 128 or min(N, K) <= 16, otherwise JF_ERR_UNSUPPORTED (use a library GEMM). */
+int64_t jf_linear_wgrad_splits_f32(int64_t B, int32_t K, int32_t N);
+int64_t jf_linear_wgrad_splits_f64(int64_t B, int32_t K, int32_t N);
 int jf_linear_wgrad_f32(const float* g, int64_t g_stride, const float* in, int64_t in_stride, int64_t B, int32_t K, int32_t N, float* partials_w,
                         float* partials_b, void* stream);
 int jf_linear_wgrad_f64(const double* g, int64_t g_stride, const double* in, int64_t in_stride, int64_t B, int32_t K, int32_t N, double* partials_w,

@@ -131,8 +131,8 @@ _SIGNATURES = {
 }
 # entry points that exist for one precision only: full symbol name -> (argtypes, restype)
 _SIGNATURES_SINGLE = {
-    "jf_linear_wgrad_splits_f32": ([_I64, _I32], ctypes.c_int64),
-    "jf_linear_wgrad_splits_f64": ([_I64, _I32], ctypes.c_int64),
+    "jf_linear_wgrad_splits_f32": ([_I64, _I32, _I32], ctypes.c_int64),
+    "jf_linear_wgrad_splits_f64": ([_I64, _I32, _I32], ctypes.c_int64),
     "jf_gf_chain_inv_bwd_partials": ([_I64, _I32], ctypes.c_int64),
     "jf_linear_split_packed_bytes": ([_I32, _I32], ctypes.c_int64),
     "jf_linear_wgrad_split_splits": ([_I64, _I32], ctypes.c_int64),
@@ -530,9 +530,9 @@ def linear_wgrad(g, inp, want_bias=True):
     inp = _rowmajor(inp)
     B, N = g.shape
     K = inp.shape[1]
-    if K > 128 or B == 0:
+    if (K > 128 and min(K, N) > 16) or B == 0:
         return g.t() @ inp, (g.sum(0) if want_bias else None)
-    split = (g.dtype == torch.float32 and K % 4 == 0 and N % 4 == 0 and N >= 64 and B >= 4096 and g.stride(0) % 4 == 0 and inp.stride(0) % 4 == 0
+    split = (g.dtype == torch.float32 and K % 4 == 0 and N % 4 == 0 and N >= 64 and 16 < K <= 128 and B >= 4096 and g.stride(0) % 4 == 0 and inp.stride(0) % 4 == 0
              and g.data_ptr() % 16 == 0 and inp.data_ptr() % 16 == 0)
     if split:                                         # large float32 products: split-bf16 MFMA (csrc/split_gemm_kernels.hip)
         S = int(lib().jf_linear_wgrad_split_splits(B, N))
@@ -540,7 +540,7 @@ def linear_wgrad(g, inp, want_bias=True):
         pb = torch.empty((S, N), dtype=g.dtype, device=g.device) if want_bias else None
         _launch("jf_linear_wgrad_split_f32", "K%d_N%d" % (K, N), (_ptr(g), g.stride(0), _ptr(inp), inp.stride(0), B, K, N, _ptr(pw), _ptr(pb)), dev)
         return (pw.sum(0) if S > 1 else pw[0]), (None if pb is None else (pb.sum(0) if S > 1 else pb[0]))
-    S = int(getattr(lib(), "jf_linear_wgrad_splits" + _suffix(g))(B, N))
+    S = int(getattr(lib(), "jf_linear_wgrad_splits" + _suffix(g))(B, K, N))
     pw = torch.empty((S, N, K), dtype=g.dtype, device=g.device)
     pb = torch.empty((S, N), dtype=g.dtype, device=g.device) if want_bias else None
     _launch("jf_linear_wgrad" + _suffix(g), "K%d_N%d" % (K, N), (_ptr(g), g.stride(0), _ptr(inp), inp.stride(0), B, K, N, _ptr(pw), _ptr(pb)), dev)

@@ -509,7 +509,7 @@ static int gf_chain_fwd(const T* z, int64_t zs, const T* ld_in, const T* params,
 }  // namespace jf
 
 extern "C" {
-int jf_abi_version(void) { return 2; }
+int jf_abi_version(void) { return 3; }
 
 int jf_gf_chain_inv_f32(const float* x, int64_t xs, const float* ld_in, const float* p, int64_t ps, int32_t pb, int64_t B, int32_t D, int32_t n,
                         const jf_gf_layer* L, float* xo, int64_t xos, float* ldo, const float* bi, float* bo, int64_t* bins, int64_t bs, int32_t* st,

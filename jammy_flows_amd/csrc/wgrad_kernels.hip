@@ -94,9 +94,85 @@ __global__ void __launch_bounds__(64) wgrad_kernel(const T* __restrict__ g, int6
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------- one tiny dimension
+// min(N, K) <= 16 (the rank-8 stages of AmortizableMLP, the 4 / 7 / 10-wide layers of the default MLPs): a pure stream over the wide operand.
+// thread = column c of the WIDE matrix (coalesced loads), the S <= 16 values of the narrow row are wave-uniform (scalar loads), S accumulators
+// per thread; a workgroup (64 .. 256 columns) walks its row range, one partial slab per range.  G_WIDE: the wide operand is g (N = C), the
+// narrow one `in` (K = S); else the wide operand is `in` (K = C) and g the narrow one (N = S).
+template <typename T, int S, bool G_WIDE>
+__global__ void __launch_bounds__(256) wgrad_skinny_kernel(const T* __restrict__ wide, int64_t ws, const T* __restrict__ narrow, int64_t ns, int64_t B, int C,
+                                                           int K, int N, int64_t rows_per_split, T* __restrict__ pw, T* __restrict__ pb) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = c < C;
+    const int cc = live ? c : C - 1;
+    const int64_t b0 = (int64_t)blockIdx.y * rows_per_split;
+    const int64_t b1 = b0 + rows_per_split < B ? b0 + rows_per_split : B;
+    T acc[S], bsum = T(0), nsum[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) { acc[s] = T(0); nsum[s] = T(0); }
+#pragma unroll 8
+    for (int64_t b = b0; b < b1; ++b) {
+        const T v = wide[b * ws + cc];
+        const T* x = narrow + b * ns;                            // uniform: scalar loads
+        bsum += v;
+#pragma unroll
+        for (int s = 0; s < S; ++s) { const T xv = x[s]; acc[s] += v * xv; nsum[s] += xv; }
+    }
+    T* slab = pw + (int64_t)blockIdx.y * N * K;
+    if (live) {
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            if (G_WIDE) slab[(int64_t)c * K + s] = acc[s];       // g_W[n = c][k = s]
+            else slab[(int64_t)s * K + c] = acc[s];              // g_W[n = s][k = c]
+        }
+    }
+    if (pb != nullptr) {
+        if (G_WIDE) { if (live) pb[(int64_t)blockIdx.y * N + c] = bsum; }
+        else if (c == 0) {
+#pragma unroll
+            for (int s = 0; s < S; ++s) pb[(int64_t)blockIdx.y * N + s] = nsum[s];
+        }
+    }
+}
+
+constexpr int WGS_MAX = 16;
+static inline bool wgrad_is_skinny(int32_t K, int32_t N) { return (K <= WGS_MAX || N <= WGS_MAX) && (K >= 32 || N >= 32 || (K <= WGS_MAX && N <= WGS_MAX)); }
+static inline int wgrad_skinny_threads(int C) { return C <= 64 ? 64 : C <= 128 ? 128 : 256; }
+static inline int64_t wgrad_skinny_splits(int64_t B, int32_t K, int32_t N) {
+    const int C = (K <= WGS_MAX && N >= K) ? N : K;              // the wide side
+    const int threads = wgrad_skinny_threads(C);
+    const int64_t waves = (int64_t)((C + threads - 1) / threads) * (threads / 64);
+    int64_t s = (8192 + waves - 1) / waves;                      // ~8 waves per SIMD: every thread walks its rows serially, latency is hidden by waves
+    const int64_t max_s = (B + 31) / 32;                         // at least 32 rows per split
+    if (s > max_s) s = max_s;
+    if (s > 65535) s = 65535;
+    return s < 1 ? 1 : s;
+}
+
+template <typename T, bool G_WIDE>
+static bool wgrad_skinny_go(int S, dim3 grid, dim3 block, hipStream_t st, const T* wide, int64_t ws, const T* narrow, int64_t ns, int64_t B, int C, int K, int N,
+                            int64_t rps, T* pw, T* pb) {
+#define JF_WS(S_) case S_: hipLaunchKernelGGL((wgrad_skinny_kernel<T, S_, G_WIDE>), grid, block, 0, st, wide, ws, narrow, ns, B, C, K, N, rps, pw, pb); return true;
+    switch (S) { JF_WS(1) JF_WS(2) JF_WS(3) JF_WS(4) JF_WS(5) JF_WS(6) JF_WS(7) JF_WS(8) JF_WS(9) JF_WS(10) JF_WS(11) JF_WS(12) JF_WS(13) JF_WS(14) JF_WS(15)
+                 JF_WS(16) default: return false; }
+#undef JF_WS
+}
+
+template <typename T> static bool wgrad_skinny(const T* g, int64_t gs, const T* in, int64_t is, int64_t B, int32_t K, int32_t N, T* pw, T* pb, hipStream_t st) {
+    if (!wgrad_is_skinny(K, N)) return false;
+    const bool g_wide = (K <= WGS_MAX && N >= K);
+    const int C = g_wide ? N : K, S = g_wide ? K : N;
+    const int64_t splits = wgrad_skinny_splits(B, K, N);
+    const int64_t rps = (B + splits - 1) / splits;
+    const int threads = wgrad_skinny_threads(C);
+    const dim3 grid((unsigned)((C + threads - 1) / threads), (unsigned)splits), block(threads);
+    return g_wide ? wgrad_skinny_go<T, true>(S, grid, block, st, g, gs, in, is, B, C, K, N, rps, pw, pb)
+                  : wgrad_skinny_go<T, false>(S, grid, block, st, in, is, g, gs, B, C, K, N, rps, pw, pb);
+}
+
 template <typename T> static int wgrad_na(int32_t N) { return N > Mfma<T>::MT ? 2 : 1; }
 
-template <typename T> static int64_t wgrad_splits_t(int64_t B, int32_t N) {
+template <typename T> static int64_t wgrad_splits_t(int64_t B, int32_t N) {        // (tiled MFMA kernel)
     const int per_wave = wgrad_na<T>(N) * Mfma<T>::MT;
     const int64_t tiles = (N + per_wave - 1) / per_wave;
     int64_t s = (4096 + tiles - 1) / tiles;                    // ~4 waves per SIMD over the n-tiles x splits grid
@@ -116,10 +192,11 @@ static void wgrad_go(const T* g, int64_t gs, const T* in, int64_t is, int64_t B,
 template <typename T>
 static int wgrad(const T* g, int64_t gs, const T* in, int64_t is, int64_t B, int32_t K, int32_t N, T* pw, T* pb, void* stream) {
     if (!g || !in || !pw || B < 0 || K < 1 || N < 1) return JF_ERR_BADARG;
-    if (K > 128) return JF_ERR_UNSUPPORTED;
     if (B == 0) return JF_OK;
-    const int64_t S = wgrad_splits_t<T>(B, N);
     hipStream_t st = (hipStream_t)stream;
+    if (wgrad_skinny<T>(g, gs, in, is, B, K, N, pw, pb, st)) return check_launch();
+    if (K > 128) return JF_ERR_UNSUPPORTED;
+    const int64_t S = wgrad_splits_t<T>(B, N);
     const int kt = (K + Mfma<T>::MT - 1) / Mfma<T>::MT;        // f32: 1..4, f64: 1..8
     const bool two = wgrad_na<T>(N) == 2;
 #define JF_WG(KT_)                                                                   \
@@ -136,8 +213,8 @@ static int wgrad(const T* g, int64_t gs, const T* in, int64_t is, int64_t B, int
 }  // namespace jf
 
 extern "C" {
-int64_t jf_linear_wgrad_splits_f32(int64_t B, int32_t N) { return jf::wgrad_splits_t<float>(B, N); }
-int64_t jf_linear_wgrad_splits_f64(int64_t B, int32_t N) { return jf::wgrad_splits_t<double>(B, N); }
+int64_t jf_linear_wgrad_splits_f32(int64_t B, int32_t K, int32_t N) { return jf::wgrad_is_skinny(K, N) ? jf::wgrad_skinny_splits(B, K, N) : jf::wgrad_splits_t<float>(B, N); }
+int64_t jf_linear_wgrad_splits_f64(int64_t B, int32_t K, int32_t N) { return jf::wgrad_is_skinny(K, N) ? jf::wgrad_skinny_splits(B, K, N) : jf::wgrad_splits_t<double>(B, N); }
 int jf_linear_wgrad_f32(const float* g, int64_t gs, const float* in, int64_t is, int64_t B, int32_t K, int32_t N, float* pw, float* pb, void* s) {
     return jf::wgrad<float>(g, gs, in, is, B, K, N, pw, pb, s);
 }
