@@ -14,4 +14,5 @@ rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_INSTS_MFMA SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_L
 for d in stats fetch write sq1 sq2; do f=$(find $out/$d -name "*.db" | head -1); [ -n "$f" ] && cp $f $out/$d.db; rm -rf $out/$d; done
 python3 scripts/rocprof_summary.py $out/stats.db > $out/kernel_stats.md 2>&1
 python3 scripts/pmc_dump.py $out/fetch.db $out/write.db $out/sq1.db $out/sq2.db > $out/pmc.txt 2>&1
+rm -f $out/stats.db                                 # the kernel trace is the bulk; its summary is kernel_stats.md (gpurun merges <= 64 MiB)
 ls -la $out
