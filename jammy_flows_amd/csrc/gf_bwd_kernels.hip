@@ -228,10 +228,51 @@ __device__ __forceinline__ T gf_reflections_bwd(const T* __restrict__ p, const G
 }
 
 // per-sample regime, layers with the reference's default options (o.fast): raw row p, gradient row gp (this lane's column of the tile).
-// The first loop is the forward's linear-space mixture; it parks 1/w_k, d log(1/w_k)/d raw and the weight sigmoid in the (still unwritten)
-// gradient slots of the component, so the second loop needs one exp and one reciprocal per component.
+// The forward sweep of the kernel keeps the layer's normalised linear-space sums (cdf, sf, pdf) and 1/N in registers (MixSums, 4 per layer),
+// so the backward sweep does not evaluate the mixture again: its single loop regulates width and weight of a component (2 exp + 2 rcp),
+// evaluates the logistic (1 exp + 1 rcp) and forms the three gradient values.  (Round 2 first re-ran the mixture loop here and parked
+// 1/w, its derivative and the weight sigmoid in the gradient slots for a second loop: one more exp + rcp, ~15 more VALU instructions and six
+// LDS accesses per component.)
+template <typename T> struct MixSums { T C, S, P, invN; };
+
+template <typename T> __device__ __forceinline__ MixQ<T> gfb_mixture_fast_raw(const T* __restrict__ p, const GfLayerDev<T>& o, int D, T x, MixSums<T>& m) {
+    const T* pm = p + o.off_mean;
+    const T* pw = p + o.off_lw;
+    const T* pn = p + o.off_ln;
+    T C = T(0), S = T(0), P = T(0), Nn = T(0);
+#pragma unroll 2
+    for (int k = 0; k < o.K; ++k) {
+        const T mu = pm[k * D], rw = pw[k * D], rn = pn[k * D];
+        const T ae = o.inv_wmax + M<T>::exp_fast(-rw);
+        const T iw = ae * M<T>::rcp(o.wmin * ae + T(1));
+        const T wk = o.nmin + o.nmax * M<T>::rcp(T(1) + M<T>::exp_fast(-rn));
+        const T u = (x - mu) * iw;
+        const T t = M<T>::exp_fast(-M<T>::abs(u));
+        const T hi = M<T>::rcp(T(1) + t), lo = t * hi;
+        const bool pos = u >= T(0);
+        C += wk * (pos ? hi : lo);
+        S += wk * (pos ? lo : hi);
+        P += wk * hi * lo * iw;
+        Nn += wk;
+    }
+    const T invN = M<T>::rcp(Nn);
+    C *= invN; S *= invN; P *= invN;
+    m.C = C; m.S = S; m.P = P; m.invN = invN;
+    MixQ<T> q;
+    q.lc = M<T>::log_fast(C); q.ls = M<T>::log_fast(S); q.lp = M<T>::log_fast(P); q.cdf = C; q.sf = S;
+    const bool under = !(C > M<T>::TINY && S > M<T>::TINY && P > M<T>::TINY);
+    if (__any(under)) {                                            // wave-uniform; the backward sweep sees C = 0 and takes the log-space function
+        const MixQ<T> qs = gfg_mixture_scaled<T, true>(p, o, D, x, T(0));
+        if (under) { q = qs; m.C = T(0); }
+    }
+    return q;
+}
+
 template <typename T, int G>
-__device__ __forceinline__ T gf_layer_bwd_fast(const T* __restrict__ p, T* __restrict__ gp, const GfLayerDev<T>& o, int D, bool live, T x_in, T gy, T gl) {
+__device__ __forceinline__ T gf_layer_bwd_fast(const T* __restrict__ p, T* __restrict__ gp, const GfLayerDev<T>& o, int D, bool live, T x_in, T gy, T gl,
+                                               const MixSums<T>& m) {
+    const bool ok = m.C > LinRange<T>::lo && m.S > LinRange<T>::lo && m.P > LinRange<T>::lo && m.P < LinRange<T>::hi;
+    if (!__all(ok)) return gf_layer_bwd<T, G, false, T>(p, gp, o, D, live, x_in, gy, gl, 0);
     T xr[GB_MAX_HH];
     T x = x_in;
     if (o.model_offset) x -= p[0];
@@ -246,30 +287,7 @@ __device__ __forceinline__ T gf_layer_bwd_fast(const T* __restrict__ p, T* __res
     T* gm = gp + o.off_mean;
     T* gw = gp + o.off_lw;
     T* gn = gp + o.off_ln;
-    T C = T(0), S = T(0), P = T(0), Nn = T(0);
-#pragma unroll 2
-    for (int k = 0; k < o.K; ++k) {
-        const T mu = pm[k * D], rw = pw[k * D], rn = pn[k * D];
-        const T e = M<T>::exp_fast(-rw);
-        const T ae = o.inv_wmax + e;
-        const T r2 = M<T>::rcp(ae * (o.wmin * ae + T(1)));
-        const T iw = ae * ae * r2;                             // 1 / w
-        const T sgn = M<T>::rcp(T(1) + M<T>::exp_fast(-rn));
-        const T wk = o.nmin + o.nmax * sgn;
-        const T u = (x - mu) * iw;
-        const T t = M<T>::exp_fast(-M<T>::abs(u));
-        const T hi = M<T>::rcp(T(1) + t), lo = t * hi;
-        const bool pos = u >= T(0);
-        C += wk * (pos ? hi : lo);
-        S += wk * (pos ? lo : hi);
-        P += wk * hi * lo * iw;
-        Nn += wk;
-        if (live) { gm[k * D] = -e * r2; gw[k * D] = iw; gn[k * D] = sgn; }
-    }
-    const T invN = M<T>::rcp(Nn);
-    C *= invN; S *= invN; P *= invN;
-    const bool ok = C > LinRange<T>::lo && S > LinRange<T>::lo && P > LinRange<T>::lo && P < LinRange<T>::hi;
-    if (!__all(ok)) return gf_layer_bwd<T, G, false, T>(p, gp, o, D, live, x_in, gy, gl, 0);
+    const T C = m.C, S = m.S, P = m.P, invN = m.invN;
     MixQ<T> q;
     q.lc = M<T>::log_fast(C); q.ls = M<T>::log_fast(S); q.lp = M<T>::log_fast(P); q.cdf = C; q.sf = S;
     const IcdfOut<T> s = gf_icdf<T>(o.inv_type, q);
@@ -280,8 +298,12 @@ __device__ __forceinline__ T gf_layer_bwd_fast(const T* __restrict__ p, T* __res
     T gx = T(0);
 #pragma unroll 2
     for (int k = 0; k < o.K; ++k) {
-        const T mu = pm[k * D];
-        const T dliw = gm[k * D], iw = gw[k * D], sgn = gn[k * D];
+        const T mu = pm[k * D], rw = pw[k * D], rn = pn[k * D];
+        const T e = M<T>::exp_fast(-rw);
+        const T ae = o.inv_wmax + e;
+        const T r2 = M<T>::rcp(ae * (o.wmin * ae + T(1)));
+        const T iw = ae * ae * r2, dliw = -e * r2;               // 1 / w,  d log(1 / w) / d raw
+        const T sgn = M<T>::rcp(T(1) + M<T>::exp_fast(-rn));
         const T pik = (o.nmin + o.nmax * sgn) * invN;
         const T u = (x - mu) * iw;
         const T t = M<T>::exp_fast(-M<T>::abs(u));
@@ -307,7 +329,8 @@ __device__ __forceinline__ T gf_layer_bwd_fast(const T* __restrict__ p, T* __res
 // so that a component costs two 16-byte LDS reads, issued one component ahead of their use; the three gradient values of a component go
 // straight to this lane's accumulator slots (unconditional LDS atomics: lanes without a row add 0, nothing in the loop waits for them).
 // v: derived row (the forward's layout: fallback of the mixture, reflections as sqrt(2) v/|v|), p: raw row (offsets, raw Householder vectors).
-template <typename T> __device__ __forceinline__ MixQ<T> gfb_mixture_pk(const T* __restrict__ c0, const T* __restrict__ v, const GfLayerDev<T>& o, int D, T x) {
+template <typename T> __device__ __forceinline__ MixQ<T> gfb_mixture_pk(const T* __restrict__ c0, const T* __restrict__ v, const GfLayerDev<T>& o, int D, T x,
+                                                                  T& Cs, T& Ss, T& Ps) {
     const T* c = (const T*)__builtin_assume_aligned(c0, 16);
     T C = T(0), S = T(0), P = T(0);
 #pragma unroll 2
@@ -324,17 +347,21 @@ template <typename T> __device__ __forceinline__ MixQ<T> gfb_mixture_pk(const T*
     MixQ<T> q;
     q.lc = M<T>::log_fast(C); q.ls = M<T>::log_fast(S); q.lp = M<T>::log_fast(P);
     q.cdf = C; q.sf = S;
+    Cs = C; Ss = S; Ps = P;
     const bool under = !(C > M<T>::TINY && S > M<T>::TINY && P > M<T>::TINY);
     if (__any(under)) {
         const MixQ<T> qs = gfg_mixture_scaled<T, false>(v, o, D, x, T(0));
-        if (under) q = qs;
+        if (under) { q = qs; Cs = T(0); }                         // the backward sweep takes the log-space function for this wave
     }
     return q;
 }
 
 template <typename T, int G>
 __device__ __forceinline__ T gf_layer_bwd_bcast(const T* __restrict__ p, const T* __restrict__ v, const T* __restrict__ c0, double* __restrict__ gp,
-                                                const GfLayerDev<T>& o, int D, bool live, T x_in, T gy, T gl, int slsh) {
+                                                const GfLayerDev<T>& o, int D, bool live, T x_in, T gy, T gl, int slsh, T Cs, T Ss, T Ps) {
+    // Cs, Ss, Ps: the layer's linear-space sums from the forward sweep (Cs = 0: the wave needed the scaled evaluation there)
+    const bool ok = Cs > LinRange<T>::lo && Ss > LinRange<T>::lo && Ps > LinRange<T>::lo && Ps < LinRange<T>::hi;
+    if (!__all(ok)) return gf_layer_bwd<T, G, true, double>(p, gp, o, D, live, x_in, gy, gl, slsh);
     T xr[GB_MAX_HH];
     T x = x_in;
     if (o.model_offset) x -= p[0];
@@ -343,14 +370,13 @@ __device__ __forceinline__ T gf_layer_bwd_bcast(const T* __restrict__ p, const T
         xr[i] = x;
         if (i < o.hh) x = gfg_reflect<T, G, false>(v, o.off_rot + i * D, live, x);
     }
-    const MixQ<T> q = gfb_mixture_pk<T>(c0, v, o, D, x);
-    const bool ok = q.cdf > LinRange<T>::lo && q.sf > LinRange<T>::lo && q.lp > LinRange<T>::llo && q.lp < LinRange<T>::lhi;
-    if (!__all(ok)) return gf_layer_bwd<T, G, true, double>(p, gp, o, D, live, x_in, gy, gl, slsh);
+    MixQ<T> q;
+    q.lc = M<T>::log_fast(Cs); q.ls = M<T>::log_fast(Ss); q.lp = M<T>::log_fast(Ps); q.cdf = Cs; q.sf = Ss;
     const IcdfOut<T> s = gf_icdf<T>(o.inv_type, q);
     const IcdfCoef<T> cf = gf_icdf_coeffs<T>(o.inv_type, q, s.y);
     const T g_lc = gy * cf.Ay + gl * cf.AH, g_ls = gy * cf.By + gl * cf.BH, g_lp = gl;
     const T Gsum = g_lc + g_ls + g_lp;
-    const T icg = g_lc * M<T>::rcp(q.cdf), isg = g_ls * M<T>::rcp(q.sf), ipg = g_lp * M<T>::exp_fast(-q.lp);
+    const T icg = g_lc * M<T>::rcp(Cs), isg = g_ls * M<T>::rcp(Ss), ipg = g_lp * M<T>::rcp(Ps);
     const bool fit = o.fit_norm != 0;
     double* am = gp + (o.off_mean << slsh);
     double* aw = gp + (o.off_lw << slsh);
@@ -415,7 +441,7 @@ __global__ void __launch_bounds__(BCAST ? 256 : 64) gf_chain_bwd_kernel(const Gf
     const int d = live ? g : D - 1;
     const int ts = a.tile_stride, nl = a.n_layers;
     // LDS: BCAST: [raw rows of all layers: n_layers x tile_stride][derived rows][gradient factors][accumulators: n_layers x tile_stride x SL]
-    //             [layer inputs: n_layers x NT][normalisers: n_layers x 16]
+    //             [layer inputs and the forward sweep's mixture sums: 4 x n_layers x NT][normalisers: n_layers x 16][packed component records]
     //      per-sample: [parameter tile R x tile_stride][gradient tile R x tile_stride]
     // BCAST: the layer inputs of the forward sweep live in LDS (one word per layer and lane) so that both sweeps are real loops over the layers: the
     // unrolled form (a register array indexed by the layer) replicated the two layer bodies JF_MAX_CHAIN times -- 190 KB of code.
@@ -433,13 +459,13 @@ __global__ void __launch_bounds__(BCAST ? 256 : 64) gf_chain_bwd_kernel(const Gf
     double* acc = reinterpret_cast<double*>(ftile + nl * ts);    // float64 accumulators for both precisions, see below
     const int slsh = BCAST ? a.slsh : 0;
     T* xin = reinterpret_cast<T*>(acc + ((nl * ts) << slsh)) + tid;   // BCAST only
-    T* pk = xin - tid + nl * (NT + 16);                          // BCAST only: packed component records (16-byte aligned: every term is a multiple of 4)
+    T* pk = xin - tid + nl * (4 * NT + 16);                      // BCAST only: packed component records (16-byte aligned: every term is a multiple of 4)
     if constexpr (BCAST) {
         if ((int)blockIdx.x >= a.active_blocks) {                // more partial rows than resident workgroups: zero rows
             for (int j = tid; j < a.n_params_total; j += NT) a.g_params[(int64_t)blockIdx.x * a.gps + j] = T(0);
             return;
         }
-        T* aux = xin - tid + nl * NT;
+        T* aux = xin - tid + nl * 4 * NT;                        // (xin: layer input and the three mixture sums per layer and lane)
         for (int l = 0; l < nl; ++l) {
             const GfLayerDev<T> o = a.L[l];
             for (int j = tid; j < ts; j += NT) {
@@ -513,6 +539,7 @@ __global__ void __launch_bounds__(BCAST ? 256 : 64) gf_chain_bwd_kernel(const Gf
 
         // ---- forward sweep (layers n-1 .. 0), keeping every layer's input
         T x = a.x[rrow * a.xs + d];
+        T msC[JF_MAX_CHAIN], msS[JF_MAX_CHAIN], msP[JF_MAX_CHAIN], msN[JF_MAX_CHAIN];   // per-sample regime: the forward sweep's mixture sums (fast layers)
         T xreg[JF_MAX_CHAIN];                                    // per-sample regime: layer inputs in registers, both sweeps unrolled (measured faster
         if constexpr (BCAST) {                                   //   there: 1.58 vs 1.96 ms for the float64 D = 8 chain of C5)
 #pragma unroll 1
@@ -522,7 +549,9 @@ __global__ void __launch_bounds__(BCAST ? 256 : 64) gf_chain_bwd_kernel(const Gf
                 const T* p = vtile + l * ts + d;
                 if (o.model_offset) x -= p[0];
                 x = gfg_rotate_inv<T, G, false>(p, o, D, live, x);
-                x = gf_icdf<T>(o.inv_type, gfb_mixture_pk<T>(pk + (a.pk0[l] + d) * 8, p, o, D, x)).y;
+                T Cs, Ss, Ps;
+                x = gf_icdf<T>(o.inv_type, gfb_mixture_pk<T>(pk + (a.pk0[l] + d) * 8, p, o, D, x, Cs, Ss, Ps)).y;
+                xin[(nl + l) * NT] = Cs; xin[(2 * nl + l) * NT] = Ss; xin[(3 * nl + l) * NT] = Ps;
             }
         } else {
 #pragma unroll
@@ -536,7 +565,11 @@ __global__ void __launch_bounds__(BCAST ? 256 : 64) gf_chain_bwd_kernel(const Gf
                     const T* p = ptile + r * ts + d;
                     if (o.model_offset) x -= p[0];
                     x = gfg_rotate_inv<T, G, true>(p, o, D, live, x);
-                    x = gf_icdf<T>(o.inv_type, gfg_mixture<T, true>(p, o, D, x)).y;
+                    if (o.fast) {
+                        MixSums<T> m;
+                        x = gf_icdf<T>(o.inv_type, gfb_mixture_fast_raw<T>(p, o, D, x, m)).y;
+                        msC[li] = m.C; msS[li] = m.S; msP[li] = m.P; msN[li] = m.invN;
+                    } else x = gf_icdf<T>(o.inv_type, gfg_mixture<T, true>(p, o, D, x)).y;
                 }
             }
         }
@@ -554,7 +587,7 @@ __global__ void __launch_bounds__(BCAST ? 256 : 64) gf_chain_bwd_kernel(const Gf
                 const GfLayerDev<T> o = a.L[l];
                 const int c0 = l * ts + d;
                 gy = gf_layer_bwd_bcast<T, G>(ptile + c0, vtile + c0, pk + (a.pk0[l] + d) * 8, acc + (c0 << slsh) + (r & ((1 << slsh) - 1)), o, D, live && row_valid,
-                                              xin[l * NT], gy, glr, slsh);
+                                              xin[l * NT], gy, glr, slsh, xin[(nl + l) * NT], xin[(2 * nl + l) * NT], xin[(3 * nl + l) * NT]);
             }
         } else {
 #pragma unroll
@@ -565,7 +598,7 @@ __global__ void __launch_bounds__(BCAST ? 256 : 64) gf_chain_bwd_kernel(const Gf
                     __syncthreads();
                     stage_rows<T>(ptile, ts, a.params + row0 * a.ps + o.col0, a.ps, o.n_params, R, valid_rows, tid, NT, o.vec_ok != 0);
                     __syncthreads();
-                    if (o.fast) gy = gf_layer_bwd_fast<T, G>(ptile + r * ts + d, gtile + r * ts + d, o, D, live, xi, gy, glr);
+                    if (o.fast) gy = gf_layer_bwd_fast<T, G>(ptile + r * ts + d, gtile + r * ts + d, o, D, live, xi, gy, glr, MixSums<T>{msC[li], msS[li], msP[li], msN[li]});
                     else gy = gf_layer_bwd<T, G, false, T>(ptile + r * ts + d, gtile + r * ts + d, o, D, live, xi, gy, glr, 0);
                     __syncthreads();
                     // gradient tile -> HBM, row by row (consecutive lanes = consecutive columns)
@@ -747,7 +780,7 @@ static int gb_launch(GfBwdArgs<T> a, bool bcast, hipStream_t st) {
         a.slsh = slsh;
         int n_rec = 0;
         for (int l = 0; l < a.n_layers; ++l) { a.pk0[l] = n_rec; n_rec += a.L[l].K * a.D; }
-        const size_t lds = 3 * cell + (acell << slsh) + ((size_t)a.n_layers * (256 + 16) + (size_t)n_rec * 8) * sizeof(T);
+        const size_t lds = 3 * cell + (acell << slsh) + ((size_t)a.n_layers * (4 * 256 + 16) + (size_t)n_rec * 8) * sizeof(T);
         if (lds > 160 * 1024) return JF_ERR_UNSUPPORTED;
         auto k = gf_chain_bwd_kernel<T, G, true>;
         if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
