@@ -102,7 +102,9 @@ int jf_gf_chain_fwd_f64(const double* z, int64_t z_stride, const double* log_det
  * gf_block._inv_flow_mapping (gaussianization_flow.py:995-1114) + the offset (euclidean_base.py:34-51) layer by layer.  The kernel re-runs
  * the chain itself (nothing has to be saved by the forward launch) and writes g_x (B, D) and g_params:
  *   param_batch == B: (B, P) rows in the layout of `params` (what the amortisation MLP's backward consumes);
- *   param_batch == 1: jf_gf_chain_inv_bwd_partials(B, D) rows of partial sums (one per workgroup, deterministic), to be added up by the caller.
+ *   param_batch == 1: jf_gf_chain_inv_bwd_partials(B, D) rows of partial sums (one per workgroup; rows of workgroups that took no tile are zero), to be added up by the caller.  Inside a workgroup the
+ *   sums are accumulated in float64 by LDS atomics (both precisions): the float32 result is reproducible in practice, the float64 one to the last
+ *   bits only up to the order of those additions.
  * The gradients of log_det_in and base_logp_in are g_log_det and g_base_logp themselves. */
 int64_t jf_gf_chain_inv_bwd_partials(int64_t B, int32_t D);
 int jf_gf_chain_inv_bwd_f32(const float* x, int64_t x_stride, const float* params, int64_t param_stride, int32_t param_batch, int64_t B,

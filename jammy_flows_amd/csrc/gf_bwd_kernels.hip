@@ -6,7 +6,7 @@
 //   jf_gf_chain_inv_bwd_*   inputs : x, params (as in jf_gf_chain_inv), upstream gradients g_x_out (B, D), g_log_det (B), g_base_logp (B)
 //                           outputs: g_x (B, D); g_params: per-sample regime (B, P) -- one row per sample, the layout of `params`, what the
 //                                    amortisation MLP's backward consumes --, broadcast regime (n_partials, P) partial sums, one row per
-//                                    workgroup, that the caller adds up (deterministic: no floating-point atomics)
+//                                    workgroup, that the caller adds up (inside a workgroup: float64 LDS atomics, see gf_chain_bwd_kernel)
 //   (g_log_det_in = g_log_det and g_base_logp_in = g_base_logp: both are accumulated, the caller passes them through.)
 //
 // Nothing is saved by the forward launch: the kernel first re-runs the chain keeping each layer's input coordinate (one register per layer
