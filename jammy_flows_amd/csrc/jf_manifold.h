@@ -52,6 +52,7 @@ struct RFam {
     static constexpr int DIM = 1;
     static __host__ int row_len(const CLayer& L) { return spline_row_len(L.sp); }
     static __host__ int n_bins(const CLayer&) { return 1; }
+    static __host__ bool needs_tab(const CLayer&) { return true; }       // lane-private knot tables (JF_SPLINE_TAB elements of LDS per lane)
     template <typename T, bool FWD> static __device__ __forceinline__ void apply(const CLayer& L, const T* __restrict__ p, T (&x)[3], T& ld, LaneCtx<T>& c) {
         if constexpr (FWD) {
             if (L.first) x[0] = real_line_to_interval<T>(x[0], (T)L.lo, (T)L.hi, ld);        // interval_base.py:71-79
@@ -98,6 +99,7 @@ struct OFam {
     static constexpr int DIM = 1;
     static __host__ int row_len(const CLayer& L) { return rot_len(L.hh_iter, 2) + spline_row_len(L.sp); }
     static __host__ int n_bins(const CLayer&) { return 1; }
+    static __host__ bool needs_tab(const CLayer&) { return true; }       // lane-private knot tables (JF_SPLINE_TAB elements of LDS per lane)
     template <typename T, bool FWD> static __device__ __forceinline__ void apply(const CLayer& L, const T* __restrict__ p, T (&x)[3], T& ld, LaneCtx<T>& c) {
         const T* sp = p + rot_len(L.hh_iter, 2);
         if constexpr (FWD) {
@@ -173,6 +175,7 @@ struct MFam {
     static constexpr int DIM = 1;
     static __host__ int row_len(const CLayer& L) { return rot_len(L.hh_iter, 2) + 4 * L.num_components; }
     static __host__ int n_bins(const CLayer&) { return 0; }
+    static __host__ bool needs_tab(const CLayer&) { return false; }
     template <typename T> static __device__ __forceinline__ T core(const CLayer& L, const T* __restrict__ mp, T x, T& ld, LaneCtx<T>& c, bool direct) {
         x = x > M<T>::PI ? x - M<T>::TWO_PI : x;                           // moebius_1d.py:73-74
         T val, d;
@@ -209,6 +212,7 @@ struct CFam {
     static constexpr int DIM = 2;      // interval / S1 use column 0 only (the host passes dim)
     static __host__ int row_len(const CLayer& L) { return rot_len(L.hh_iter, L.kind == 2 ? 3 : 2); }
     static __host__ int n_bins(const CLayer&) { return 0; }
+    static __host__ bool needs_tab(const CLayer&) { return false; }
     template <typename T, bool FWD> static __device__ __forceinline__ void apply(const CLayer& L, const T* __restrict__ p, T (&x)[3], T& ld, LaneCtx<T>& c) {
         if constexpr (FWD) {
             if (L.first) {
@@ -292,6 +296,7 @@ struct FFam {
         return n;
     }
     static __host__ int n_bins(const CLayer& L) { return L.n_vertical + L.n_circular; }
+    static __host__ bool needs_tab(const CLayer& L) { return L.n_vertical + L.n_circular > 0; }
     static __host__ int scratch(const CLayer& L) { return L.correlated ? JF_CORR_SCRATCH : 0; }
 
     // the per-sample MLP of the correlated variant: out[0..n_out) = W2 tanh(W1 z + b1) + b2 with this row's own weights

@@ -24,7 +24,7 @@ template <typename T, typename CLayer> struct MBwdArgs {
     const T* params; int64_t ps;
     int bcast;
     int64_t B;
-    int n_layers, dim, P, tile_stride, scratch, rows;
+    int n_layers, dim, P, tile_stride, scratch, rows, tab;       // tab: JF_SPLINE_TAB or 0 (no spline in the chain), as in manifold_kernels.hip
     int col0[JF_MAX_MCHAIN];
     CLayer L[JF_MAX_MCHAIN];
     const T* g_xout; int64_t gxos;
@@ -55,8 +55,8 @@ __global__ void __launch_bounds__(64) mchain_bwd_kernel(const MBwdArgs<T, typena
     const int tile_rows = a.bcast ? 1 : rows;
     const bool lane_in = tid < rows;
     const int slot = lane_in ? tid : 0;
-    Du* tab = tile + tile_rows * a.tile_stride + slot * JF_SPLINE_TAB;
-    Du* corr = tile + tile_rows * a.tile_stride + rows * JF_SPLINE_TAB + slot * a.scratch;
+    Du* tab = tile + tile_rows * a.tile_stride + slot * a.tab;
+    Du* corr = tile + tile_rows * a.tile_stride + rows * a.tab + slot * a.scratch;
     const int64_t row0 = (int64_t)blockIdx.x * rows;
     const int64_t row = row0 + tid;
     const bool active = lane_in && row < a.B;
@@ -147,9 +147,9 @@ __global__ void __launch_bounds__(64) vchain_bwd_kernel(const MBwdArgs<T, jf_v_l
     const int tile_rows = a.bcast ? 1 : rows;
     const bool lane_in = tid < rows;
     const int slot = lane_in ? tid : 0;
-    Du* tab = tile + tile_rows * a.tile_stride + slot * JF_SPLINE_TAB;
+    Du* tab = tile + tile_rows * a.tile_stride + slot * a.tab;
     // lane-private scratch in LDS (dynamic indexing without scratch memory): every layer's input (2 per layer) and G (15)
-    T* lane_mem = reinterpret_cast<T*>(tile + tile_rows * a.tile_stride + rows * JF_SPLINE_TAB + slot * a.scratch);
+    T* lane_mem = reinterpret_cast<T*>(tile + tile_rows * a.tile_stride + rows * a.tab + slot * a.scratch);
     T* xin = lane_mem;                                             // [layer][2]
     T* G = lane_mem + 2 * JF_MAX_MCHAIN;                           // [15]
     const int64_t row0 = (int64_t)blockIdx.x * rows;
@@ -349,10 +349,12 @@ static int mchain_bwd(const T* x, int64_t xs, const T* params, int64_t ps, int32
         for (int l = 0; l < n_layers; ++l) staged = staged && layers[l].natural_direction == 0;
         if (staged) a.scratch = (2 * JF_MAX_MCHAIN + 15 + 1) / 2;  // lane-private doubles, counted in Dual<T> units
     }
+    a.tab = 0;
+    for (int l = 0; l < n_layers; ++l) if (Fam::needs_tab(layers[l])) a.tab = JF_SPLINE_TAB;
     a.rows = 64;
     size_t lds = 0;
     for (;;) {
-        lds = ((size_t)(a.bcast ? 1 : a.rows) * a.tile_stride + (size_t)a.rows * (JF_SPLINE_TAB + a.scratch)) * sizeof(Dual<T>);
+        lds = ((size_t)(a.bcast ? 1 : a.rows) * a.tile_stride + (size_t)a.rows * (a.tab + a.scratch)) * sizeof(Dual<T>);
         if (lds <= 160 * 1024 || a.rows == 4) break;
         a.rows >>= 1;
     }

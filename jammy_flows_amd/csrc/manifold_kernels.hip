@@ -21,6 +21,8 @@ template <typename T, typename CLayer> struct MChainArgs {
     int dim;                 // columns of x actually used (<= Fam::DIM)
     int tile_stride;
     int scratch;             // per-lane elements of the emitted-parameter scratch behind the knot tables (0 = none)
+    int tab;                 // per-lane elements of the knot tables: JF_SPLINE_TAB, or 0 for chains without a spline (default 'f', 'm', 'v', 'c'):
+                             //   53 words of LDS per lane that bound the resident workgroups of these latency-bound kernels
     int rows;                // rows per workgroup (64 unless the parameter tile of 64 rows would not fit in LDS)
     int vec_ok[JF_MAX_MCHAIN];
     int col0[JF_MAX_MCHAIN];
@@ -42,7 +44,7 @@ __global__ void __launch_bounds__(64) mchain_kernel(const MChainArgs<T, typename
     const int tile_rows = a.bcast ? 1 : rows;
     const bool lane_in = tid < rows;                     // lanes beyond the workgroup's rows idle (they own no scratch)
     const int slot = lane_in ? tid : 0;
-    T* tab = tile + tile_rows * a.tile_stride + slot * JF_SPLINE_TAB;
+    T* tab = tile + tile_rows * a.tile_stride + slot * a.tab;
     const int64_t row0 = (int64_t)blockIdx.x * rows;
     const int64_t row = row0 + tid;
     const bool active = lane_in && row < a.B;
@@ -55,7 +57,7 @@ __global__ void __launch_bounds__(64) mchain_kernel(const MChainArgs<T, typename
     T ld = a.ld_in ? a.ld_in[rrow] : T(0);
     LaneCtx<T> ctx;
     ctx.tab = tab;
-    ctx.corr = tile + tile_rows * a.tile_stride + rows * JF_SPLINE_TAB + slot * a.scratch;
+    ctx.corr = tile + tile_rows * a.tile_stride + rows * a.tab + slot * a.scratch;
     ctx.bins = (a.bins && active) ? a.bins + row * a.bins_stride : nullptr;
     ctx.bin_i = 0;
     ctx.oob = ctx.nonconv = ctx.nonfinite = false;
@@ -124,10 +126,12 @@ static int mchain(const T* x, int64_t xs, const T* ld_in, const T* params, int64
             a.scratch = JF_CORR_SCRATCH;
         }
     }
+    a.tab = 0;
+    for (int l = 0; l < n_layers; ++l) if (Fam::needs_tab(layers[l])) a.tab = JF_SPLINE_TAB;
     a.rows = 64;
     size_t lds = 0;
     for (;;) {
-        lds = ((size_t)(a.bcast ? 1 : a.rows) * a.tile_stride + (size_t)a.rows * (JF_SPLINE_TAB + a.scratch)) * sizeof(T);
+        lds = ((size_t)(a.bcast ? 1 : a.rows) * a.tile_stride + (size_t)a.rows * (a.tab + a.scratch)) * sizeof(T);
         if (lds <= 160 * 1024 || a.rows == 8) break;
         a.rows >>= 1;
     }
