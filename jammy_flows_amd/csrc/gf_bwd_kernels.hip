@@ -427,7 +427,10 @@ template <typename T> __device__ __forceinline__ void gf_derive_bwd_item(const T
     }
 }
 
-template <typename T, int G, bool BCAST>
+// DIRECT (per-sample regime): the lanes store their gradient values straight to the (B, P) rows instead of through a gradient tile in LDS.
+// Chosen when the D coordinate lanes of a row cover >= 32 contiguous bytes per store (float64 D >= 4, float32 D = 8): the tile was half of the
+// workgroup's LDS, which bounds the resident waves of this kernel (float64 D = 8: 39 KB per wave -> one wave per SIMD).
+template <typename T, int G, bool BCAST, bool DIRECT = false>
 __global__ void __launch_bounds__(BCAST ? 256 : 64) gf_chain_bwd_kernel(const GfBwdArgs<T> a) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     T* lds = reinterpret_cast<T*>(smem_raw);
@@ -598,13 +601,17 @@ __global__ void __launch_bounds__(BCAST ? 256 : 64) gf_chain_bwd_kernel(const Gf
                     __syncthreads();
                     stage_rows<T>(ptile, ts, a.params + row0 * a.ps + o.col0, a.ps, o.n_params, R, valid_rows, tid, NT, o.vec_ok != 0);
                     __syncthreads();
-                    if (o.fast) gy = gf_layer_bwd_fast<T, G>(ptile + r * ts + d, gtile + r * ts + d, o, D, live, xi, gy, glr, MixSums<T>{msC[li], msS[li], msP[li], msN[li]});
-                    else gy = gf_layer_bwd<T, G, false, T>(ptile + r * ts + d, gtile + r * ts + d, o, D, live, xi, gy, glr, 0);
-                    __syncthreads();
-                    // gradient tile -> HBM, row by row (consecutive lanes = consecutive columns)
-                    for (int rr2 = 0; rr2 < valid_rows; ++rr2)
-                        for (int j = tid; j < o.n_params; j += NT)
-                            a.g_params[(row0 + rr2) * a.gps + o.col0 + j] = gtile[rr2 * ts + j];
+                    T* gp = DIRECT ? a.g_params + rrow * a.gps + o.col0 + d : gtile + r * ts + d;
+                    const bool lw = DIRECT ? (live && row_valid) : live;       // DIRECT: rows past B must not store
+                    if (o.fast) gy = gf_layer_bwd_fast<T, G>(ptile + r * ts + d, gp, o, D, lw, xi, gy, glr, MixSums<T>{msC[li], msS[li], msP[li], msN[li]});
+                    else gy = gf_layer_bwd<T, G, false, T>(ptile + r * ts + d, gp, o, D, lw, xi, gy, glr, 0);
+                    if constexpr (!DIRECT) {
+                        __syncthreads();
+                        // gradient tile -> HBM, row by row (consecutive lanes = consecutive columns)
+                        for (int rr2 = 0; rr2 < valid_rows; ++rr2)
+                            for (int j = tid; j < o.n_params; j += NT)
+                                a.g_params[(row0 + rr2) * a.gps + o.col0 + j] = gtile[rr2 * ts + j];
+                    }
                 }
             }
         }
@@ -797,8 +804,9 @@ static int gb_launch(GfBwdArgs<T> a, bool bcast, hipStream_t st) {
         hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(256), lds, st, a);
     } else {
         a.tiles_per_block = 1;
-        const size_t lds = (size_t)2 * (64 / G) * a.tile_stride * sizeof(T);
-        auto k = gf_chain_bwd_kernel<T, G, false>;
+        const bool direct = (size_t)a.D * sizeof(T) >= 32;
+        const size_t lds = (size_t)(direct ? 1 : 2) * (64 / G) * a.tile_stride * sizeof(T);
+        auto k = direct ? gf_chain_bwd_kernel<T, G, false, true> : gf_chain_bwd_kernel<T, G, false, false>;
         if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(k, dim3((unsigned)((a.B + 64 / G - 1) / (64 / G))), dim3(64), lds, st, a);
     }
