@@ -515,6 +515,12 @@ def main():
                 tf = 2 * (7 * 128 + 128 * 548) * B / (ml["mean_ms"] * 1e-3) / 1e12
                 blk["mlp2"] = {"bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TFLOPS,
                                "mean_launch_ms": ml["mean_ms"]}
+            sp = tb.get(("jf_linear_split_f32", "K128_N548"))
+            if sp is not None:                         # the wide second layer on split-bf16 MFMA (first layer: a streaming jf_linear launch)
+                tf = 6 * 2 * 128 * 548 * B / (sp["mean_ms"] * 1e-3) / 1e12
+                blk["linear_split"] = {"bound": "mfma", "achieved": tf, "peak": 2500.0, "unit": "TFLOP/s", "frac": tf / 2500.0,
+                                       "mean_launch_ms": sp["mean_ms"], "arithmetic": "3-way split bf16, 6 MFMA passes, f32 accumulate (executed bf16 flop)"}
+                blk["note"] = "same steps with the conditional block as jf_linear + jf_linear_split + jf_gf_chain_inv (measured after the timed region, this rank only)"
             if gf is not None:
                 gb = 4 * 558 * B / (gf["mean_ms"] * 1e-3) / 1e9
                 blk["gf_chain_per_sample"] = {"bound": "hbm", "achieved": gb, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gb / HBM_PEAK_GBS,

@@ -114,6 +114,9 @@ template <int NG, int KC, int TB, int RG> __global__ void __launch_bounds__(256,
     };
     auto landed = [&]() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
     dma(0);
+    // the bias, zero-padded to whole tiles, behind the two chunk buffers: the epilogue of a column group must not wait for a global load
+    float* bs = reinterpret_cast<float*>(smem_raw + 2 * CHUNK);
+    for (int i = tid; i < a.n_groups * NG * 16; i += 256) bs[i] = (a.bias && i < a.N) ? a.bias[i] : 0.f;
 
     int64_t row[RG]; const float* xrow[RG];
 #pragma unroll
@@ -195,8 +198,7 @@ template <int NG, int KC, int TB, int RG> __global__ void __launch_bounds__(256,
 #pragma unroll
         for (int t = 0; t < NG; ++t) {                              // the bias joins at the end: one rounding, not one per accumulation step
             const int n0 = 16 * (ng * NG + t) + 4 * lq;
-            f32x4 b = {0.f, 0.f, 0.f, 0.f};
-            if (a.bias && n0 < a.N) b = *reinterpret_cast<const f32x4*>(a.bias + n0);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(bs + n0);
 #pragma unroll
             for (int g = 0; g < RG; ++g)
                 if (row[g] <= last && n0 < a.N) *reinterpret_cast<f32x4*>(a.out + row[g] * a.os + n0) = acc[g][t] + b;
@@ -227,7 +229,7 @@ static int sg_pack(const float* W, int64_t ws, int64_t wks, int N, int K, void* 
 
 template <int NG, int KC, int TB> static int sg_launch(const SgArgs& a, hipStream_t st) {
     constexpr int RG = 2;
-    const size_t lds = (size_t)2 * NG * KC * SG_NP * SG_FRAG;
+    const size_t lds = (size_t)2 * NG * KC * SG_NP * SG_FRAG + (size_t)a.n_groups * NG * 16 * sizeof(float);
     auto k = split_gemm_kernel<NG, KC, TB, RG>;
     if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k, dim3((unsigned)((a.B + 64 * RG - 1) / (64 * RG))), dim3(256), lds, st, a);

@@ -46,7 +46,16 @@ class HipLinearStack(nn.Sequential):
             ps = [mods[0].weight, mods[0].bias, mods[2].weight, mods[2].bias]
             if ps[0].dtype != x.dtype:
                 ps = [p.to(x.dtype) for p in ps]
-            return _hip.mlp2(x, *[p.detach() for p in ps])
+            ps = [p.detach() for p in ps]
+            if x.dtype == torch.float32 and ps[2].shape[0] >= 256 and x.shape[0] >= 4096:
+                # wide float32 output (the 548-column parameter block of an e4 block: sampling, the two-launch log-prob path): the second layer on
+                # split-bf16 MFMA (jf_linear_split_f32, 0.23 ms per 2^18 rows) after a streaming first layer beats the fused exact-f32 MFMA launch
+                # (jf_mlp2: 0.36 .. 0.39 ms per 2^18 rows) although the hidden activations make a round trip through HBM
+                h = _hip.linear(x, ps[0], ps[1], 1)
+                if _hip.linear_split_ok(h, ps[2], ps[3]):
+                    return _hip.linear_split(h, ps[2], ps[3])
+                return _hip.linear(h, ps[2], ps[3], 0)
+            return _hip.mlp2(x, *ps)
         i = 0
         while i < len(mods):
             lin = mods[i]
