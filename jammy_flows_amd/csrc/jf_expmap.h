@@ -27,7 +27,8 @@ constexpr int JF_V_SPLINE_BINS = 10;    // exponential_map_s2.py:111 (num_spline
 template <typename T> struct VPotential { T g[3]; T gj[3][3]; };
 
 // log-sum-exp of the components' log-weights (row 3)
-template <typename T> __device__ inline T v_lse(const T* __restrict__ pp, int nc) {
+// (ROW: anything indexable that yields T -- a plain pointer, or the backward kernel's seeded accessor over a row of plain values)
+template <typename T, typename ROW> __device__ inline T v_lse(ROW pp, int nc) {
     const int w_row = 3;
     T lmax = pp[w_row * nc];
     for (int k = 1; k < nc; ++k) lmax = M<T>::max(lmax, pp[w_row * nc + k]);
@@ -38,8 +39,8 @@ template <typename T> __device__ inline T v_lse(const T* __restrict__ pp, int nc
 
 // component k's term of grad phi and of its Jacobian, ADDED to P (the weight normaliser lse is an input: the backward kernel differentiates a
 // single component with lse held fixed and adds the softmax coupling in closed form)
-template <typename T> __device__ inline void v_component(const T* __restrict__ pp, int nc, int k, int kind, T lse, const T (&x)[3], VPotential<T>& P,
-                                                        T* __restrict__ tab, bool& oob) {
+template <typename T, typename ROW> __device__ inline void v_component(ROW pp, int nc, int k, int kind, T lse, const T (&x)[3], VPotential<T>& P,
+                                                                      T* __restrict__ tab, bool& oob) {
     const int w_row = 3, b_row = 4;
     const T m0 = pp[k], m1 = pp[nc + k], m2 = pp[2 * nc + k];
     const T nrm = M<T>::sqrt(m0 * m0 + m1 * m1 + m2 * m2);
@@ -78,8 +79,8 @@ template <typename T> __device__ inline void v_component(const T* __restrict__ p
     }
 }
 
-template <typename T> __device__ inline void v_potential(const T* __restrict__ pp, int nc, int kind, const T (&x)[3], VPotential<T>& P, T* __restrict__ tab,
-                                                        bool& oob) {
+template <typename T, typename ROW> __device__ inline void v_potential(ROW pp, int nc, int kind, const T (&x)[3], VPotential<T>& P, T* __restrict__ tab,
+                                                                      bool& oob) {
     const T lse = v_lse<T>(pp, nc);
 #pragma unroll
     for (int i = 0; i < 3; ++i) {

@@ -25,6 +25,7 @@ template <typename T, typename CLayer> struct MBwdArgs {
     int bcast;
     int64_t B;
     int n_layers, dim, P, tile_stride, scratch, rows, tab;       // tab: JF_SPLINE_TAB or 0 (no spline in the chain), as in manifold_kernels.hip
+    int rot_max;                                                 // staged 'v' kernel: longest rotation row of the chain (lane-private dual copy)
     int col0[JF_MAX_MCHAIN];
     CLayer L[JF_MAX_MCHAIN];
     const T* g_xout; int64_t gxos;
@@ -137,55 +138,67 @@ __global__ void __launch_bounds__(64) mchain_bwd_kernel(const MBwdArgs<T, typena
 // replayed only for the 15 directions of (e, u), which gives G = d S / d (e, u) for the upstream-contracted objective S; the parameters and
 // the layer's input then need only pre + pot on dual numbers, contracted with G (chain rule through the 15 intermediates).  Layers of a
 // chain are walked in reverse with the (2 + 1)-component upstream gradient, after one forward sweep that records every layer's input.
+// Parameter rows are kept as PLAIN values in LDS; the potential's functions read them through SeededVals (value + a unit tangent at one index),
+// the <= 12 rotation parameters of the layer at hand are copied into a lane-private dual row.  A dual row for all parameters (round 2's first
+// version) was half of the kernel's LDS, and LDS bounds its resident waves: 1040 -> 616 bytes per lane (C5) = four workgroups per CU instead of two.
+template <typename T> struct SeededVals {
+    const T* p; int seed;
+    __device__ __forceinline__ Dual<T> operator[](int i) const { return Dual<T>(p[i], i == seed ? T(1) : T(0)); }
+};
+constexpr int JF_V_ROT_MAX = 12;
+
 template <typename T>
 __global__ void __launch_bounds__(64) vchain_bwd_kernel(const MBwdArgs<T, jf_v_layer> a) {
     using Du = Dual<T>;
     extern __shared__ __align__(16) unsigned char smem_raw[];
-    Du* tile = reinterpret_cast<Du*>(smem_raw);
+    T* tile = reinterpret_cast<T*>(smem_raw);                      // [tile_rows][tile_stride] plain parameter values
     const int tid = threadIdx.x;
     const int rows = a.rows;
     const int tile_rows = a.bcast ? 1 : rows;
     const bool lane_in = tid < rows;
     const int slot = lane_in ? tid : 0;
-    Du* tab = tile + tile_rows * a.tile_stride + slot * a.tab;
+    const int tile_elems = (tile_rows * a.tile_stride + 1) & ~1;   // the dual regions stay 16-byte aligned
+    Du* dual0 = reinterpret_cast<Du*>(tile + tile_elems);
+    Du* tab = dual0 + slot * (a.tab + a.rot_max);                 // lane-private: knot table (spline potentials only), then the rotation row
+    Du* rot = tab + a.tab;
     // lane-private scratch in LDS (dynamic indexing without scratch memory): every layer's input (2 per layer) and G (15)
-    T* lane_mem = reinterpret_cast<T*>(tile + tile_rows * a.tile_stride + rows * a.tab + slot * a.scratch);
+    T* lane_mem = reinterpret_cast<T*>(dual0 + rows * (a.tab + a.rot_max)) + slot * a.scratch;
     T* xin = lane_mem;                                             // [layer][2]
-    T* G = lane_mem + 2 * JF_MAX_MCHAIN;                           // [15]
+    T* G = lane_mem + 2 * a.n_layers;                              // [15]
     const int64_t row0 = (int64_t)blockIdx.x * rows;
     const int64_t row = row0 + tid;
     const bool active = lane_in && row < a.B;
     const int64_t rrow = active ? row : a.B - 1;
     if (a.bcast) {
-        for (int j = tid; j < a.P; j += 64) tile[j] = Du(a.params[j]);
+        for (int j = tid; j < a.P; j += 64) tile[j] = a.params[j];
     } else {
         for (int r = 0; r < rows; ++r) {
             const int64_t gr = (row0 + r) < a.B ? (row0 + r) : a.B - 1;
-            for (int j = tid; j < a.P; j += 64) tile[r * a.tile_stride + j] = Du(a.params[gr * a.ps + j]);
+            for (int j = tid; j < a.P; j += 64) tile[r * a.tile_stride + j] = a.params[gr * a.ps + j];
         }
     }
     __syncthreads();
-    Du* prow = tile + (a.bcast ? 0 : slot * a.tile_stride);
+    const T* prow = tile + (a.bcast ? 0 : slot * a.tile_stride);
     const T gld = (a.g_ld && active) ? a.g_ld[rrow] : T(0);
     const T gblp = (a.g_blp && active) ? a.g_blp[rrow] : T(0);
     bool oob = false;
 
-    // ---- forward sweep (values only): the input of every layer, the chain's output
+    // ---- forward sweep (plain values): the input of every layer, the chain's output
     T up[2];                                                       // d S / d (x after the layer being differentiated)
     {
-        Du x[3] = {Du(a.x[rrow * a.xs + 0]), Du(a.x[rrow * a.xs + 1]), Du(T(0))};
-        Du ld(T(0));
-        LaneCtx<Du> ctx;
-        ctx.tab = tab; ctx.corr = nullptr; ctx.bins = nullptr; ctx.bin_i = 0;
+        T x[3] = {a.x[rrow * a.xs + 0], a.x[rrow * a.xs + 1], T(0)};
+        T ld = T(0);
+        LaneCtx<T> ctx;
+        ctx.tab = reinterpret_cast<T*>(tab); ctx.corr = nullptr; ctx.bins = nullptr; ctx.bin_i = 0;
         ctx.oob = ctx.nonconv = ctx.nonfinite = false;
         ctx.lane_valid = active;
 #pragma unroll 1
         for (int l = a.n_layers - 1; l >= 0; --l) {
-            if (lane_in) { xin[2 * l] = x[0].v; xin[2 * l + 1] = x[1].v; }      // (lanes beyond `rows` share slot 0: they must not write)
-            if (lane_in) VFam::template apply<Du, false>(a.L[l], prow + a.col0[l], x, ld, ctx);
+            if (lane_in) { xin[2 * l] = x[0]; xin[2 * l + 1] = x[1]; }          // (lanes beyond `rows` share slot 0: they must not write)
+            if (lane_in) VFam::template apply<T, false>(a.L[l], prow + a.col0[l], x, ld, ctx);
         }
-        up[0] = ((a.g_xout && active) ? a.g_xout[rrow * a.gxos + 0] : T(0)) - x[0].v * gblp;
-        up[1] = ((a.g_xout && active) ? a.g_xout[rrow * a.gxos + 1] : T(0)) - x[1].v * gblp;
+        up[0] = ((a.g_xout && active) ? a.g_xout[rrow * a.gxos + 0] : T(0)) - x[0] * gblp;
+        up[1] = ((a.g_xout && active) ? a.g_xout[rrow * a.gxos + 1] : T(0)) - x[1] * gblp;
     }
 
     bool bad = false;
@@ -193,26 +206,26 @@ __global__ void __launch_bounds__(64) vchain_bwd_kernel(const MBwdArgs<T, jf_v_l
     for (int l = 0; l < a.n_layers; ++l) {                        // reverse of the order of application (layer n-1 is applied first)
         {
             const jf_v_layer L = a.L[l];
-            Du* p = prow + a.col0[l];
-            const Du* pp = p + rot_len(L.hh_iter, 3);
+            const T* pv = prow + a.col0[l];                        // this layer's plain row: rotation parameters, then the potential's
+            const int n_rot = rot_len(L.hh_iter, 3);
+            const T* ppv = pv + n_rot;
             const int nc = L.num_components, kind = L.exp_map_type;
+            if (lane_in) for (int i = 0; i < n_rot; ++i) rot[i] = Du(pv[i]);
+            const Du* p = rot;
             // values of the intermediates at this layer's input
-            T e0[3];
+            T e0[3] = {T(0), T(0), T(0)};
             VPotential<T> P0;
-            {
-                Du x[3] = {Du(xin[2 * l]), Du(xin[2 * l + 1]), Du(T(0))};
-                Du ld(T(0)), e[3];
-                VPotential<Du> P;
-                if (lane_in) {
-                    VFam::template inv_pre<Du>(L, p, x, ld, e);
-                    v_potential<Du>(pp, nc, kind, e, P, tab, oob);
-                }
 #pragma unroll
-                for (int i = 0; i < 3; ++i) {
-                    e0[i] = e[i].v; P0.g[i] = P.g[i].v;
+            for (int i = 0; i < 3; ++i) {
+                P0.g[i] = T(0);
 #pragma unroll
-                    for (int j = 0; j < 3; ++j) P0.gj[i][j] = P.gj[i][j].v;
-                }
+                for (int j = 0; j < 3; ++j) P0.gj[i][j] = T(0);
+            }
+            if (lane_in) {
+                T x[3] = {xin[2 * l], xin[2 * l + 1], T(0)};
+                T ld = T(0);
+                VFam::template inv_pre<T>(L, pv, x, ld, e0);
+                v_potential<T>(ppv, nc, kind, e0, P0, reinterpret_cast<T*>(tab), oob);
             }
             // (1) the expensive stages on the 15 directions of (e, g, gj):  G[i] = d S / d u_i
 #pragma unroll 1
@@ -239,9 +252,8 @@ __global__ void __launch_bounds__(64) vchain_bwd_kernel(const MBwdArgs<T, jf_v_l
             //     potential on dual numbers; a potential parameter belongs to ONE component, whose term alone carries a tangent -- except the
             //     log-weights, whose softmax normaliser couples all components: d w_m / d lw_k = w_m (delta_mk - s_k), i.e. the single-component
             //     tangent (normaliser held fixed) minus s_k times the totals.
-            const int n_rot = rot_len(L.hh_iter, 3);
             const int n_row = VFam_row_len_dev(L);
-            const T lse0 = lane_in ? v_lse<Du>(pp, nc).v : T(0);
+            const T lse0 = lane_in ? v_lse<T>(ppv, nc) : T(0);
             T GP0 = T(0);
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
@@ -251,19 +263,15 @@ __global__ void __launch_bounds__(64) vchain_bwd_kernel(const MBwdArgs<T, jf_v_l
             }
             T nup[2] = {T(0), T(0)};
             for (int j = 0; j < 2 + n_row; ++j) {
-                if (j >= 2) {
-                    if (a.bcast) { if (tid == 0) p[j - 2].d = T(1); }
-                    else if (lane_in) p[j - 2].d = T(1);
-                }
-                __syncthreads();
                 T gj_ = T(0);
                 if (j < 2 + n_rot) {
+                    if (j >= 2 && lane_in) rot[j - 2].d = T(1);    // lane-private row: no barrier
                     Du x[3] = {Du(xin[2 * l], j == 0 ? T(1) : T(0)), Du(xin[2 * l + 1], j == 1 ? T(1) : T(0)), Du(T(0))};
                     Du ld(T(0)), e[3];
                     VPotential<Du> P;
                     if (lane_in) {
                         VFam::template inv_pre<Du>(L, p, x, ld, e);
-                        v_potential<Du>(pp, nc, kind, e, P, tab, oob);
+                        v_potential<Du>(SeededVals<T>{ppv, -1}, nc, kind, e, P, tab, oob);
                     }
                     gj_ = gld * ld.d;
 #pragma unroll
@@ -272,6 +280,7 @@ __global__ void __launch_bounds__(64) vchain_bwd_kernel(const MBwdArgs<T, jf_v_l
 #pragma unroll
                         for (int d = 0; d < 3; ++d) gj_ += G[6 + 3 * c + d] * P.gj[c][d].d;
                     }
+                    if (j >= 2 && lane_in) rot[j - 2].d = T(0);
                 } else {
                     const int jp = j - 2 - n_rot, k = jp % nc, prow_i = jp / nc;
                     const Du e[3] = {Du(e0[0]), Du(e0[1]), Du(e0[2])};
@@ -282,14 +291,14 @@ __global__ void __launch_bounds__(64) vchain_bwd_kernel(const MBwdArgs<T, jf_v_l
 #pragma unroll
                         for (int d = 0; d < 3; ++d) P.gj[c][d] = Du(T(0));
                     }
-                    if (lane_in) v_component<Du>(pp, nc, k, kind, Du(lse0), e, P, tab, oob);
+                    if (lane_in) v_component<Du>(SeededVals<T>{ppv, jp}, nc, k, kind, Du(lse0), e, P, tab, oob);
 #pragma unroll
                     for (int c = 0; c < 3; ++c) {
                         gj_ += G[3 + c] * P.g[c].d;
 #pragma unroll
                         for (int d = 0; d < 3; ++d) gj_ += G[6 + 3 * c + d] * P.gj[c][d].d;
                     }
-                    if (prow_i == 3 && lane_in) gj_ -= M<T>::exp(pp[3 * nc + k].v - lse0) * GP0;       // softmax coupling of the log-weights
+                    if (prow_i == 3 && lane_in) gj_ -= M<T>::exp(ppv[3 * nc + k] - lse0) * GP0;        // softmax coupling of the log-weights
                 }
                 if (!active) gj_ = T(0);
                 bad = bad || !M<T>::finite(gj_);
@@ -300,11 +309,6 @@ __global__ void __launch_bounds__(64) vchain_bwd_kernel(const MBwdArgs<T, jf_v_l
                     if (tid == 0) atomicAdd(a.g_params + a.col0[l] + (j - 2), s);
                 } else if (active) {
                     a.g_params[row * a.gps + a.col0[l] + (j - 2)] = gj_;
-                }
-                __syncthreads();
-                if (j >= 2) {
-                    if (a.bcast) { if (tid == 0) p[j - 2].d = T(0); }
-                    else if (lane_in) p[j - 2].d = T(0);
                 }
             }
             up[0] = nup[0]; up[1] = nup[1];
@@ -346,14 +350,22 @@ static int mchain_bwd(const T* x, int64_t xs, const T* params, int64_t ps, int32
     bool staged = false;
     if constexpr (std::is_same<Fam, VFam>::value) {               // all layers in the default direction: the staged kernel (15 + cheap passes)
         staged = true;
-        for (int l = 0; l < n_layers; ++l) staged = staged && layers[l].natural_direction == 0;
-        if (staged) a.scratch = (2 * JF_MAX_MCHAIN + 15 + 1) / 2;  // lane-private doubles, counted in Dual<T> units
+        for (int l = 0; l < n_layers; ++l) staged = staged && layers[l].natural_direction == 0 && rot_len(layers[l].hh_iter, 3) <= JF_V_ROT_MAX;
+        if (staged) {
+            a.scratch = (2 * n_layers + 15 + 1) & ~1;              // lane-private values (T units in the staged kernel): layer inputs, G
+            a.rot_max = 0;
+            for (int l = 0; l < n_layers; ++l) a.rot_max = rot_len(layers[l].hh_iter, 3) > a.rot_max ? rot_len(layers[l].hh_iter, 3) : a.rot_max;
+        }
     }
     a.tab = 0;
     for (int l = 0; l < n_layers; ++l) if (Fam::needs_tab(layers[l])) a.tab = JF_SPLINE_TAB;
     a.rows = 64;
     size_t lds = 0;
     for (;;) {
+        if (staged) {                                              // plain-value parameter tile + per lane: knot table, rotation row (duals), scratch (values)
+            const size_t tile_elems = (((size_t)(a.bcast ? 1 : a.rows) * a.tile_stride) + 1) & ~(size_t)1;
+            lds = tile_elems * sizeof(T) + (size_t)a.rows * ((size_t)(a.tab + a.rot_max) * sizeof(Dual<T>) + (size_t)a.scratch * sizeof(T));
+        } else
         lds = ((size_t)(a.bcast ? 1 : a.rows) * a.tile_stride + (size_t)a.rows * (a.tab + a.scratch)) * sizeof(Dual<T>);
         if (lds <= 160 * 1024 || a.rows == 4) break;
         a.rows >>= 1;
