@@ -58,15 +58,18 @@ def step():
     return loss
 
 
-for _ in range(3):
+for _ in range(5):
     step()
-torch.cuda.synchronize()
-t0 = time.perf_counter()
-n = 10
-for _ in range(n):
-    loss = step()
-torch.cuda.synchronize()
-dt = (time.perf_counter() - t0) / n
+n = 20
+reps = []
+for _ in range(5):                                   # the step issues ~100 launches: host jitter shows, so 5 repetitions of 20 steps, median reported
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        loss = step()
+    torch.cuda.synchronize()
+    reps.append((time.perf_counter() - t0) / n)
+dt = sorted(reps)[len(reps) // 2]
 with torch.no_grad():
     for _ in range(3):
         pdf(x, conditional_input=cond)
@@ -79,8 +82,8 @@ with torch.no_grad():
 timer = _hip.KernelTimer()
 with timer:
     step()
-print("workload %s dtype %s rows %d: training step %.3f ms (%.3g rows/s), no-grad forward %.3f ms, loss %.4f" % (
-    args.workload, dtype, args.rows, 1e3 * dt, args.rows / dt, 1e3 * dt_fwd, float(loss)))
+print("workload %s dtype %s rows %d: training step %.3f ms (%.3g rows/s; median of 5 x 20 steps, best %.3f, worst %.3f), no-grad forward %.3f ms, loss %.4f" % (
+    args.workload, dtype, args.rows, 1e3 * dt, args.rows / dt, 1e3 * min(reps), 1e3 * max(reps), 1e3 * dt_fwd, float(loss)))
 for k, v in sorted(timer.summary().items(), key=lambda kv: -kv[1]["total_ms"]):
     print("  %-44s x%d  %.3f ms" % (k[0] + "[" + k[1] + "]", v["launches"], v["total_ms"]))
 if args.torch_profile:
