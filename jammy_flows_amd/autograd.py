@@ -4,9 +4,11 @@ examples/jammy_flows.py:381-412, docs/source/usage/training.rst:24-44).
 Every Function's forward is the SAME kernel launch the inference path uses; nothing but the inputs is saved.  Backward:
   * g-layer chains: one hand-written HIP launch (jf_gf_chain_inv_bwd_*, csrc/gf_bwd_kernels.hip) that re-runs the chain and returns the
     gradient of the targets and of the parameter row block -- (B, P) for per-sample blocks, partial sums for permanent parameters;
-  * dense layers: g W (row-parallel) is a plain library GEMM (torch.matmul); the two products that reduce over the BATCH (g^T x, column sums)
-    run in jf_linear_wgrad (csrc/wgrad_kernels.hip: the batch split over the grid -- the library's output-tiled GEMM walks 1e5..1e6 rows in a
-    handful of workgroups there, 14 ms per call in float64); the tanh derivative is applied to the saved activation;
+  * dense layers: g W (row-parallel) runs on split-bf16 MFMA for aligned float32 shapes (jf_linear_split), on the MFMA dense kernel with the
+    transposed weight in float64, and in the library only for what is left; the two products that reduce over the BATCH (g^T x, column sums)
+    run in jf_linear_wgrad / jf_linear_wgrad_split (csrc/wgrad_kernels.hip, csrc/split_gemm_kernels.hip: the batch split over the grid -- the
+    library's output-tiled GEMM walks 1e5..1e6 rows in a handful of workgroups there, 14 ms per call in float64); the tanh derivative is one
+    launch on the saved activation (jf_tanh_bwd);
   * the fused conditional block (MLP + g layers in one launch) recomputes its parameter block with two dense launches in backward and
     then runs the same two steps.
 """
