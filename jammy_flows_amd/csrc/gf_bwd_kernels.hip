@@ -27,6 +27,8 @@
 namespace jf {
 
 constexpr int GB_MAX_HH = 8;
+constexpr int GB_NT = 512;                  // threads of a broadcast-regime workgroup: the derived rows / accumulators / records in LDS (~40 KB) are
+                                            //   per workgroup, so wider workgroups mean more resident waves per CU (256: 2 per SIMD, 512: 4)
 
 template <typename T> struct GfBwdArgs {
     const T* x; int64_t xs;
@@ -431,10 +433,10 @@ template <typename T> __device__ __forceinline__ void gf_derive_bwd_item(const T
 // Chosen when the D coordinate lanes of a row cover >= 32 contiguous bytes per store (float64 D >= 4, float32 D = 8): the tile was half of the
 // workgroup's LDS, which bounds the resident waves of this kernel (float64 D = 8: 39 KB per wave -> one wave per SIMD).
 template <typename T, int G, bool BCAST, bool DIRECT = false>
-__global__ void __launch_bounds__(BCAST ? 256 : 64) gf_chain_bwd_kernel(const GfBwdArgs<T> a) {
+__global__ void __launch_bounds__(BCAST ? GB_NT : 64) gf_chain_bwd_kernel(const GfBwdArgs<T> a) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     T* lds = reinterpret_cast<T*>(smem_raw);
-    constexpr int NT = BCAST ? 256 : 64;
+    constexpr int NT = BCAST ? GB_NT : 64;
     constexpr int R = NT / G;
     const int tid = threadIdx.x;
     constexpr int LG = G == 1 ? 0 : G == 2 ? 1 : G == 4 ? 2 : 3;
@@ -450,7 +452,7 @@ __global__ void __launch_bounds__(BCAST ? 256 : 64) gf_chain_bwd_kernel(const Gf
     // unrolled form (a register array indexed by the layer) replicated the two layer bodies JF_MAX_CHAIN times -- 190 KB of code.
     // BCAST accumulators: every parameter has SL = 2^slsh slots and row r of the tile adds into slot r % SL.  With SL = 64 / G the lanes of a
     // wave own distinct words (lane -> (coordinate, slot) is a bijection onto 64 consecutive words: no bank conflict, no serialised atomic);
-    // only the four waves of the workgroup share an address, which is what the LDS atomic is for.  Round 2 first summed over the rows of a
+    // only the waves of the workgroup share an address, which is what the LDS atomic is for.  Round 2 first summed over the rows of a
     // wave with a 4..6-step butterfly per value (3 values per component) and then issued one atomic per coordinate.
     // The accumulators are float64 in BOTH precisions: ds_add_f32 costs ~190 cycles per wave instruction on gfx950, ds_add_f64 9 (20 with two
     // lanes per address), ds_add_u32 3.4 (scripts/probe/lds_atomic.hip) -- the float32 chain with float32 accumulators spent 0.6 of its
@@ -770,7 +772,7 @@ template <typename T> static int gb_fill(GfBwdArgs<T>& a, const T* params, int64
 // number of partial-sum rows a broadcast launch writes for B rows (the caller allocates (n, P) and sums over n)
 static int64_t gb_partials(int64_t B, int D) {
     const int G = gb_group_width(D);
-    const int64_t n_tiles = (B + 256 / G - 1) / (256 / G);
+    const int64_t n_tiles = (B + GB_NT / G - 1) / (GB_NT / G);
     const int64_t blocks = n_tiles < 1024 ? (n_tiles < 1 ? 1 : n_tiles) : 1024;
     return blocks;
 }
@@ -778,7 +780,7 @@ static int64_t gb_partials(int64_t B, int D) {
 template <typename T, int G>
 static int gb_launch(GfBwdArgs<T> a, bool bcast, hipStream_t st) {
     if (bcast) {
-        const int64_t n_tiles = (a.B + 256 / G - 1) / (256 / G);
+        const int64_t n_tiles = (a.B + GB_NT / G - 1) / (GB_NT / G);
         const int64_t blocks = gb_partials(a.B, a.D);
         a.tiles_per_block = (int)((n_tiles + blocks - 1) / blocks);
         int slsh = G == 1 ? 6 : G == 2 ? 5 : G == 4 ? 4 : 3;       // one slot per row of a wave, fewer when the accumulators would not fit
@@ -787,7 +789,7 @@ static int gb_launch(GfBwdArgs<T> a, bool bcast, hipStream_t st) {
         a.slsh = slsh;
         int n_rec = 0;
         for (int l = 0; l < a.n_layers; ++l) { a.pk0[l] = n_rec; n_rec += a.L[l].K * a.D; }
-        const size_t lds = 3 * cell + (acell << slsh) + ((size_t)a.n_layers * (4 * 256 + 16) + (size_t)n_rec * 8) * sizeof(T);
+        const size_t lds = 3 * cell + (acell << slsh) + ((size_t)a.n_layers * (4 * GB_NT + 16) + (size_t)n_rec * 8) * sizeof(T);
         if (lds > 160 * 1024) return JF_ERR_UNSUPPORTED;
         auto k = gf_chain_bwd_kernel<T, G, true>;
         if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -795,13 +797,13 @@ static int gb_launch(GfBwdArgs<T> a, bool bcast, hipStream_t st) {
         int dev = 0, cus = 256, occ = 1;
         (void)hipGetDevice(&dev);
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)k, 256, lds) != hipSuccess || occ < 1) occ = 1;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)k, GB_NT, lds) != hipSuccess || occ < 1) occ = 1;
         int64_t active = (int64_t)cus * occ;
         if (active > blocks) active = blocks;
         if (active > n_tiles) active = n_tiles < 1 ? 1 : n_tiles;
         a.active_blocks = (int)active;
         a.tiles_per_block = (int)((n_tiles + active - 1) / active);
-        hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(256), lds, st, a);
+        hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(GB_NT), lds, st, a);
     } else {
         a.tiles_per_block = 1;
         const bool direct = (size_t)a.D * sizeof(T) >= 32;
