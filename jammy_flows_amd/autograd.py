@@ -69,6 +69,7 @@ class GfChainInvFn(torch.autograd.Function):
         res = _hip.gf_chain("inv", x.detach(), None if log_det is None else log_det.detach(), params.detach(), layer_array, n_layers, D,
                             base_logp_in=None if base_logp_in is None else base_logp_in.detach(), want_base_logp=True, status=status)
         ctx.meta = (layer_array, n_layers, D, status)
+        ctx.set_materialize_grads(False)             # unused outputs arrive as None (the kernels take NULL), not as zero-filled tensors
         ctx.save_for_backward(x, params)
         ctx.has = (log_det is not None, base_logp_in is not None)
         return res
@@ -93,6 +94,7 @@ class CondBlockFn(torch.autograd.Function):
         else:
             res = _hip.cond_gf_chain_inv(inp.detach(), w1.detach(), b1.detach(), w2.detach(), b2.detach(), *args, **kw)
         ctx.meta = (layer_array, n_layers, D)
+        ctx.set_materialize_grads(False)             # unused outputs arrive as None (the kernels take NULL), not as zero-filled tensors
         ctx.has = (log_det is not None, base_logp_in is not None)
         ctx.save_for_backward(inp, w1, b1, w2, b2, x)
         return res
@@ -139,6 +141,7 @@ class MChainInvFn(torch.autograd.Function):
         res = _hip.mchain(fam, "inv", x.detach(), None if log_det is None else log_det.detach(), params.detach(), structs, dim,
                           base_logp_in=None if base_logp_in is None else base_logp_in.detach(), want_base_logp=True, status=status)
         ctx.meta = (fam, structs, dim)
+        ctx.set_materialize_grads(False)             # unused outputs arrive as None (the kernels take NULL), not as zero-filled tensors
         ctx.has = (log_det is not None, base_logp_in is not None)
         ctx.save_for_backward(x, params)
         return res
@@ -159,6 +162,7 @@ class TLayerInvFn(torch.autograd.Function):
         res = _hip.t_layer("inv", x.detach(), None if log_det is None else log_det.detach(), None if params is None else params.detach(), struct, D,
                            base_logp_in=None if base_logp_in is None else base_logp_in.detach(), want_base_logp=True, status=status)
         ctx.meta = (struct, D)
+        ctx.set_materialize_grads(False)             # unused outputs arrive as None (the kernels take NULL), not as zero-filled tensors
         ctx.has = (log_det is not None, base_logp_in is not None, params is not None)
         ctx.save_for_backward(x, params)
         return res
