@@ -552,7 +552,7 @@ def linear_split_ok(x, weight, bias=None):
     N, K = weight.shape
     if bias is not None and (bias.dtype != torch.float32 or bias.data_ptr() % 16 or bias.stride(0) != 1):
         return False
-    return (x.dtype == torch.float32 and weight.dtype == torch.float32 and K % 4 == 0 and N % 4 == 0 and x.dim() == 2 and x.shape[1] == K
+    return (x.dtype == torch.float32 and weight.dtype == torch.float32 and K % 4 == 0 and N % 4 == 0 and N <= 8192 and x.dim() == 2 and x.shape[1] == K
             and x.stride(1) == 1 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0 and x.shape[0] > 0)
 
 

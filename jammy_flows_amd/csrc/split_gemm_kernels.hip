@@ -230,6 +230,7 @@ static int sg_pack(const float* W, int64_t ws, int64_t wks, int N, int K, void* 
 template <int NG, int KC, int TB> static int sg_launch(const SgArgs& a, hipStream_t st) {
     constexpr int RG = 2;
     const size_t lds = (size_t)2 * NG * KC * SG_NP * SG_FRAG + (size_t)a.n_groups * NG * 16 * sizeof(float);
+    if (lds > 160 * 1024) return JF_ERR_UNSUPPORTED;              // (the bias row of a very wide layer: N > ~20000)
     auto k = split_gemm_kernel<NG, KC, TB, RG>;
     if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k, dim3((unsigned)((a.B + 64 * RG - 1) / (64 * RG))), dim3(256), lds, st, a);
