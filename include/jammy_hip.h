@@ -196,6 +196,17 @@ int jf_linear_wgrad_f32(const float* g, int64_t g_stride, const float* in, int64
 int jf_linear_wgrad_f64(const double* g, int64_t g_stride, const double* in, int64_t in_stride, int64_t B, int32_t K, int32_t N, double* partials_w,
                         double* partials_b, void* stream);
 
+/* Whole backward of a narrow Linear - tanh - Linear head (K1 <= 32 inputs, H <= 128 hidden units, N <= 16 outputs: e.g. the 4 -> 128 -> 10 MLP
+ * of mlp_predictors (main/default.py:656-670) that parametrises an 'f' layer) in one launch: the hidden activations are recomputed from x, and
+ * the gradients of W1, b1, W2, b2 -- what autograd computes with six launches -- leave as partial slabs, S = jf_mlp2_small_bwd_slabs(B):
+ *   slab (S, H, K1 + 1 + N): per hidden unit j  [g_W1[j][0..K1) | g_b1[j] | g_W2[0..N)[j]],   slab_b2 (S, N);   the caller adds over S.
+ * No gradient with respect to x (JF_ERR_UNSUPPORTED shapes / a needed input gradient: use the per-layer entry points). */
+int64_t jf_mlp2_small_bwd_slabs(int64_t B);
+int jf_mlp2_small_bwd_f32(const float* x, int64_t x_stride, const float* W1, int64_t w1_stride, const float* b1, const float* W2, int64_t w2_stride,
+                          const float* g_out, int64_t g_stride, int64_t B, int32_t K1, int32_t H, int32_t N, float* slab, float* slab_b2, void* stream);
+int jf_mlp2_small_bwd_f64(const double* x, int64_t x_stride, const double* W1, int64_t w1_stride, const double* b1, const double* W2, int64_t w2_stride,
+                          const double* g_out, int64_t g_stride, int64_t B, int32_t K1, int32_t H, int32_t N, double* slab, double* slab_b2, void* stream);
+
 /* One AmortizableMLP stage with PER-SAMPLE weights (amortize_everything / fully_amortized_pdf: _apply_amortized_mlp with extra_inputs,
  * amortizable_mlp.py:508-578): out[b] = act(W_b in[b] + bias_b) (+ residual[b]); `segment` points at this stage's [U | V | bias] slice of
  * row 0 of the per-sample parameter block (row stride segment_stride): rank == 0: U = W (n_out x n_in); else U (n_out x rank), V (rank x n_in).

@@ -116,6 +116,7 @@ _SIGNATURES = {
     "jf_linear": [_P, _I64, _P, _I64, _P, _I64, _I32, _I32, _I32, _P, _I64, _P],
     "jf_normal_logp": [_P, _I64, _I64, _I32, _P, _P, _P],
     "jf_tanh_bwd": [_P, _P, _I64, _P, _P],
+    "jf_mlp2_small_bwd": [_P, _I64, _P, _I64, _P, _P, _I64, _P, _I64, _I64, _I32, _I32, _I32, _P, _P, _P],
     "jf_mlp2": [_P, _I64, _P, _I64, _P, _P, _I64, _P, _I64, _I32, _I32, _I32, _P, _I64, _P],
     "jf_sphere_to_embedding": [_P, _I64, _P, _I64, _I32, _P, _I64, _P, _P],
     "jf_sphere_from_embedding": [_P, _I64, _P, _I64, _I32, _P, _I64, _P, _P],
@@ -135,6 +136,7 @@ _SIGNATURES_SINGLE = {
     "jf_linear_wgrad_splits_f64": ([_I64, _I32, _I32], ctypes.c_int64),
     "jf_gf_chain_inv_bwd_partials": ([_I64, _I32], ctypes.c_int64),
     "jf_linear_split_packed_bytes": ([_I32, _I32], ctypes.c_int64),
+    "jf_mlp2_small_bwd_slabs": ([_I64], ctypes.c_int64),
     "jf_linear_wgrad_split_splits": ([_I64, _I32], ctypes.c_int64),
     "jf_linear_wgrad_split_f32": ([_P, _I64, _P, _I64, _I64, _I32, _I32, _P, _P, _P], ctypes.c_int),
     "jf_linear_split_pack_f32": ([_P, _I64, _I64, _I32, _I32, _P, _P], ctypes.c_int),
@@ -570,6 +572,26 @@ def linear_split(x, weight, bias=None):
     out = torch.empty((B, N), dtype=x.dtype, device=x.device)
     _launch("jf_linear_split_f32", "K%d_N%d" % (K, N), (_ptr(x), x.stride(0), _ptr(packed), _ptr(bias), B, K, N, _ptr(out), out.stride(0)), dev)
     return out
+
+
+MLP2_SMALL_MAX_IN, MLP2_SMALL_MAX_OUT = 32, 16
+
+
+def mlp2_small_bwd(x, w1, b1, w2, g):
+    """gradients (g_w1, g_b1, g_w2, g_b2) of out = tanh(x w1^T + b1) w2^T + b2 for upstream g (B, N), narrow heads only (K1 <= 32, N <= 16,
+    H <= 128): one launch that recomputes the hidden activations (jf_mlp2_small_bwd); no input gradient."""
+    dev = require_device(x, w1, b1, w2, g)
+    x, w1, w2, g = _rowmajor(x), _rowmajor(w1), _rowmajor(w2), _rowmajor(g)
+    B, K1 = x.shape
+    H, N = w1.shape[0], w2.shape[0]
+    S = int(lib().jf_mlp2_small_bwd_slabs(B))
+    slab = torch.empty((S, H, K1 + 1 + N), dtype=x.dtype, device=x.device)
+    slab_b2 = torch.empty((S, N), dtype=x.dtype, device=x.device)
+    _launch("jf_mlp2_small_bwd" + _suffix(x), "K%d_H%d_N%d" % (K1, H, N),
+            (_ptr(x), x.stride(0), _ptr(w1), w1.stride(0), _ptr(b1.contiguous()), _ptr(w2), w2.stride(0), _ptr(g), g.stride(0), B, K1, H, N, _ptr(slab),
+             _ptr(slab_b2)), dev)
+    tot = slab.sum(0)
+    return tot[:, :K1], tot[:, K1], tot[:, K1 + 1:].t(), slab_b2.sum(0)
 
 
 def tanh_bwd(g, y, inplace=False):

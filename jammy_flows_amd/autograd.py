@@ -61,6 +61,27 @@ def linear(inp, weight, bias=None, act=0):
     return _hip.linear(inp, weight, bias, act)
 
 
+class Mlp2SmallFn(torch.autograd.Function):
+    """narrow Linear - tanh - Linear head (<= 32 inputs, <= 16 outputs) whose input rows need no gradient: forward = the fused jf_mlp2 launch,
+    backward = ONE launch (jf_mlp2_small_bwd) instead of tanh', two weight gradients, two bias sums and g W2 of the per-layer path."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2):
+        ctx.save_for_backward(x, w1, b1, w2)
+        return _hip.mlp2(x.detach(), w1.detach(), b1.detach(), w2.detach(), b2.detach())
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w1, b1, w2 = ctx.saved_tensors
+        g_w1, g_b1, g_w2, g_b2 = _hip.mlp2_small_bwd(x, w1, b1, w2, g)
+        return None, g_w1, g_b1, g_w2, g_b2
+
+
+def mlp2_small_ok(x, lin1, lin2):
+    return (not x.requires_grad and lin1.in_features <= _hip.MLP2_SMALL_MAX_IN and lin1.out_features <= _hip.MLP2_MAX_HIDDEN
+            and lin1.out_features % 4 == 0 and lin2.out_features <= _hip.MLP2_SMALL_MAX_OUT and lin1.bias is not None and lin2.bias is not None)
+
+
 class GfChainInvFn(torch.autograd.Function):
     """log-prob direction of a chain of g layers (jf_gf_chain_inv) -> (x_out, log_det_out, base_logp_out)."""
 

@@ -10,6 +10,7 @@
 // Algorithmic bytes = s (B N + ceil(N / 64) B K + S N K): g is read once, `in` once per n-tile.
 #include "jf_common.h"
 #include "jf_mfma.h"
+#include "jf_math.h"
 
 namespace jf {
 
@@ -170,6 +171,93 @@ template <typename T> static bool wgrad_skinny(const T* g, int64_t gs, const T* 
                   : wgrad_skinny_go<T, false>(S, grid, block, st, in, is, g, gs, B, C, K, N, rps, pw, pb);
 }
 
+// ---------------------------------------------------------------------------------------------------------- narrow heads, whole backward
+// Backward of a Linear - tanh - Linear head with few inputs and few outputs (K1 <= 32, N <= 16, H hidden units: the 4 -> 128 -> 10 MLP that
+// parametrises an 'f' layer) in ONE launch: what autograd runs as tanh', two weight gradients, two bias sums and grad_output @ W2.
+// thread = hidden unit j.  Everything a hidden unit needs is its own: W1[j][:], W2[:][j] in registers; the input row and the upstream row are
+// wave-uniform (scalar loads).  Per row: h_j = tanh(W1[j] . x + b1[j]) recomputed (the forward kept nothing), g_j = (g_out . W2[:, j])(1 - h_j^2),
+// and the accumulators  g_W1[j][k] += g_j x[k],  g_b1[j] += g_j,  g_W2[n][j] += g_out[n] h_j  -- no communication between threads at all.
+// A workgroup walks its row range and writes one partial slab [H][K1 + 1 + N] (+ [N] for g_b2), summed by the caller.  No gradient with respect
+// to the input rows (they are data; the caller takes the layer-by-layer path when they require grad).
+constexpr int MS_K1MAX = 32, MS_NMAX = 16;
+// KB / NB: compile-time bounds of the input / output loops (the sizes rounded up to 4, 8, 16, 32 / 4, 8, 16).  Slots beyond the real sizes carry
+// zero weights and read a clamped (duplicate) element, so the row loop has no size-dependent branch and its scalar loads batch up.
+template <typename T, int KB, int NB>
+__global__ void __launch_bounds__(128) mlp2_small_bwd_kernel(const T* __restrict__ x, int64_t xs, const T* __restrict__ W1, int64_t w1s, const T* __restrict__ b1,
+                                                             const T* __restrict__ W2, int64_t w2s, const T* __restrict__ g, int64_t gs, int64_t B, int K1, int H,
+                                                             int N, int64_t rows_per_block, T* __restrict__ slab, T* __restrict__ slab_b2) {
+    const int j = threadIdx.x;
+    const bool live = j < H;
+    const int jj = live ? j : H - 1;
+    T w1[KB], w2[NB], a1[KB], a2[NB], gsum[NB];
+    int kx[KB], nx[NB];
+#pragma unroll
+    for (int k = 0; k < KB; ++k) { w1[k] = k < K1 ? W1[(int64_t)jj * w1s + k] : T(0); a1[k] = T(0); kx[k] = k < K1 ? k : K1 - 1; }
+#pragma unroll
+    for (int n = 0; n < NB; ++n) { w2[n] = n < N ? W2[(int64_t)n * w2s + jj] : T(0); a2[n] = T(0); gsum[n] = T(0); nx[n] = n < N ? n : N - 1; }
+    const T bj = b1[jj];
+    T ab1 = T(0);
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r1 = r0 + rows_per_block < B ? r0 + rows_per_block : B;
+#pragma unroll 4
+    for (int64_t r = r0; r < r1; ++r) {
+        const T* xr = x + r * xs;                                 // uniform addresses: scalar loads
+        const T* gr = g + r * gs;
+        T xv[KB], gv[NB];
+#pragma unroll
+        for (int k = 0; k < KB; ++k) xv[k] = xr[kx[k]];
+#pragma unroll
+        for (int n = 0; n < NB; ++n) gv[n] = gr[nx[n]];
+        T pre = bj;
+#pragma unroll
+        for (int k = 0; k < KB; ++k) pre += w1[k] * xv[k];
+        const T h = M<T>::tanh_fast(pre);                          // the forward kernels' tanh (jf_mlp2 / jf_linear)
+        T gh = T(0);
+#pragma unroll
+        for (int n = 0; n < NB; ++n) { gh += gv[n] * w2[n]; a2[n] += gv[n] * h; gsum[n] += gv[n]; }
+        gh *= T(1) - h * h;
+        ab1 += gh;
+#pragma unroll
+        for (int k = 0; k < KB; ++k) a1[k] += gh * xv[k];
+    }
+    if (live) {
+        T* row = slab + ((int64_t)blockIdx.x * H + j) * (K1 + 1 + N);
+#pragma unroll
+        for (int k = 0; k < KB; ++k) if (k < K1) row[k] = a1[k];
+        row[K1] = ab1;
+#pragma unroll
+        for (int n = 0; n < NB; ++n) if (n < N) row[K1 + 1 + n] = a2[n];
+    }
+    if (j == 0) {
+#pragma unroll
+        for (int n = 0; n < NB; ++n) if (n < N) slab_b2[(int64_t)blockIdx.x * N + n] = gsum[n];
+    }
+}
+
+static int64_t mlp2_small_slabs(int64_t B) {
+    int64_t s = (B + 63) / 64;                                     // >= 64 rows per workgroup, <= 4096 workgroups
+    if (s > 4096) s = 4096;
+    return s < 1 ? 1 : s;
+}
+
+template <typename T>
+static int mlp2_small_bwd(const T* x, int64_t xs, const T* W1, int64_t w1s, const T* b1, const T* W2, int64_t w2s, const T* g, int64_t gs, int64_t B, int32_t K1,
+                          int32_t H, int32_t N, T* slab, T* slab_b2, void* stream) {
+    if (!x || !W1 || !b1 || !W2 || !g || !slab || !slab_b2 || B < 0) return JF_ERR_BADARG;
+    if (K1 < 1 || K1 > MS_K1MAX || N < 1 || N > MS_NMAX || H < 1 || H > 128) return JF_ERR_UNSUPPORTED;
+    if (B == 0) return JF_OK;
+    const int64_t S = mlp2_small_slabs(B);
+    const int64_t rpb = (B + S - 1) / S;
+    const dim3 grid((unsigned)S), block(128);
+    hipStream_t st = (hipStream_t)stream;
+#define JF_MS(KB_, NB_) hipLaunchKernelGGL((mlp2_small_bwd_kernel<T, KB_, NB_>), grid, block, 0, st, x, xs, W1, w1s, b1, W2, w2s, g, gs, B, (int)K1, (int)H, (int)N, rpb, slab, slab_b2)
+#define JF_MS_N(KB_) { if (N <= 4) JF_MS(KB_, 4); else if (N <= 8) JF_MS(KB_, 8); else JF_MS(KB_, 16); }
+    if (K1 <= 4) JF_MS_N(4) else if (K1 <= 8) JF_MS_N(8) else if (K1 <= 16) JF_MS_N(16) else JF_MS_N(32)
+#undef JF_MS_N
+#undef JF_MS
+    return check_launch();
+}
+
 template <typename T> static int wgrad_na(int32_t N) { return N > Mfma<T>::MT ? 2 : 1; }
 
 template <typename T> static int64_t wgrad_splits_t(int64_t B, int32_t N) {        // (tiled MFMA kernel)
@@ -220,5 +308,14 @@ int jf_linear_wgrad_f32(const float* g, int64_t gs, const float* in, int64_t is,
 }
 int jf_linear_wgrad_f64(const double* g, int64_t gs, const double* in, int64_t is, int64_t B, int32_t K, int32_t N, double* pw, double* pb, void* s) {
     return jf::wgrad<double>(g, gs, in, is, B, K, N, pw, pb, s);
+}
+int64_t jf_mlp2_small_bwd_slabs(int64_t B) { return jf::mlp2_small_slabs(B); }
+int jf_mlp2_small_bwd_f32(const float* x, int64_t xs, const float* W1, int64_t w1s, const float* b1, const float* W2, int64_t w2s, const float* g, int64_t gs,
+                          int64_t B, int32_t K1, int32_t H, int32_t N, float* slab, float* slab_b2, void* s) {
+    return jf::mlp2_small_bwd<float>(x, xs, W1, w1s, b1, W2, w2s, g, gs, B, K1, H, N, slab, slab_b2, s);
+}
+int jf_mlp2_small_bwd_f64(const double* x, int64_t xs, const double* W1, int64_t w1s, const double* b1, const double* W2, int64_t w2s, const double* g, int64_t gs,
+                          int64_t B, int32_t K1, int32_t H, int32_t N, double* slab, double* slab_b2, void* s) {
+    return jf::mlp2_small_bwd<double>(x, xs, W1, w1s, b1, W2, w2s, g, gs, B, K1, H, N, slab, slab_b2, s);
 }
 }

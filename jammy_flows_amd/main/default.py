@@ -29,6 +29,10 @@ class HipLinearStack(nn.Sequential):
         _hip.require_device(x)
         mods = list(self)
         if autograd._needs_grad(x, *self.parameters()):
+            if (len(mods) == 3 and isinstance(mods[1], nn.Tanh) and autograd.mlp2_small_ok(x, mods[0], mods[2])
+                    and mods[0].weight.dtype == x.dtype):
+                # narrow head (e.g. 4 -> 128 -> 10 of an 'f' layer) on data rows: fused forward, one-launch backward
+                return autograd.Mlp2SmallFn.apply(x, mods[0].weight, mods[0].bias, mods[2].weight, mods[2].bias)
             # training: one dense launch per layer wrapped in autograd (the hidden activations are what backward needs)
             i = 0
             while i < len(mods):
