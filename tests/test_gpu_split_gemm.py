@@ -55,3 +55,21 @@ def test_linear_skinny_shapes(dtype, B, K, N, act):
         ref = torch.tanh(ref)
     err = (out.double() - ref).abs().max().item()
     assert err < (1e-12 if dtype == torch.float64 else 3e-6) * (1 + K ** 0.5), err
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("B,K1,H,N", [(1000, 4, 128, 10), (4099, 7, 64, 3), (300, 32, 128, 16), (1, 1, 4, 1), (70001, 4, 128, 10)])
+def test_mlp2_small_backward_vs_autograd(dtype, B, K1, H, N):
+    """jf_mlp2_small_bwd (whole backward of a narrow Linear-tanh-Linear head in one launch) against torch autograd in float64"""
+    rng = np.random.default_rng(B + K1 + N)
+    mk = lambda *s: torch.from_numpy(rng.normal(size=s)).to(device="cuda", dtype=torch.float64)
+    x, w1, b1, w2, b2, g = mk(B, K1), mk(H, K1) / np.sqrt(K1), mk(H), mk(N, H) / np.sqrt(H), mk(N), mk(B, N)
+    ps = [t.clone().requires_grad_(True) for t in (w1, b1, w2, b2)]
+    with torch.enable_grad():
+        out = torch.tanh(x @ ps[0].t() + ps[1]) @ ps[2].t() + ps[3]
+        out.backward(g)
+    got = _hip.mlp2_small_bwd(x.to(dtype), w1.to(dtype), b1.to(dtype), w2.to(dtype), g.to(dtype))
+    tol = 1e-11 if dtype == torch.float64 else 3e-5
+    for name, a, p in zip(("w1", "b1", "w2", "b2"), got, ps):
+        err = (a.double() - p.grad).abs().max().item() / max(p.grad.abs().max().item(), 1e-30)
+        assert err < tol * (1 + B ** 0.5 / 30), (name, err)
