@@ -156,8 +156,13 @@ def cpu_baseline(workload, budget_s=15.0, workers=None, chunk=4096):
 
     calibration = {}
     if workers is None:
-        for cand in sorted({min(cores, c) for c in (8, 16, 32, 64, 128)}):
-            n, dt = run(cand, 1.0)
+        quota = cpu_quota()
+        if quota is not None and quota >= 1:                       # the cgroup says how many CPUs there are: that many workers, or twice (SMT)
+            cands = sorted({max(1, min(cores, int(round(quota)))), max(1, min(cores, int(round(2 * quota))))})
+        else:
+            cands = sorted({min(cores, c) for c in (8, 16, 32, 64, 128)})
+        for cand in cands:
+            n, dt = run(cand, 2.0)
             calibration[cand] = n / dt
         workers = max(calibration, key=calibration.get)
     n, dt = run(workers, budget_s)
