@@ -178,3 +178,39 @@ def test_build_flags_really_disable_packed_f32(tmp_path):
         return len(re.findall(r"\bv_pk_(?:fma|mul|add)_f32\b", out.read_text()))
     assert count(["--offload-arch=gfx950", "-O3"]) > 0, "the probe loop is no longer packed by default: pick another one"
     assert count([f for f in flags if f not in ("-fPIC", "-Wall", "-Wno-unused-function")]) == 0
+
+
+def test_dense_kernel_selection_rules():
+    """host-side choice between the split-bf16 / streaming / tiled dense kernels (no launches: shapes, dtypes, alignment only)"""
+    from jammy_flows_amd import _hip
+    x = torch.zeros((4096, 128), dtype=torch.float32)
+    w = torch.zeros((548, 128), dtype=torch.float32)
+    b = torch.zeros(548, dtype=torch.float32)
+    assert _hip.linear_split_ok(x, w, b)
+    assert _hip.linear_split_ok(torch.zeros((5, 548)), w.t())                 # a transposed weight view is fine (packed with its strides)
+    assert not _hip.linear_split_ok(x.double(), w.double())                  # float32 only
+    assert not _hip.linear_split_ok(torch.zeros((8, 6)), torch.zeros((8, 6)))  # K, N must be multiples of 4
+    assert not _hip.linear_split_ok(x[:, 1:125], w[:, 1:125])                # unaligned rows
+    assert not _hip.linear_split_ok(x, torch.zeros((16384, 128)))            # the bias row of such a layer would not fit next to the chunks
+    lib = _hip.lib()
+    assert lib.jf_abi_version() >= 3
+    # the partial-slab count depends on the shape (streaming kernel for min(N, K) <= 16, tiled MFMA kernel otherwise)
+    assert lib.jf_linear_wgrad_splits_f32(1 << 18, 128, 548) >= 1 and lib.jf_linear_wgrad_splits_f64(1 << 17, 8, 1224) >= 1
+    assert lib.jf_linear_wgrad_split_splits(1 << 18, 548) * ((548 + 127) // 128) <= 1030
+    assert lib.jf_mlp2_small_bwd_slabs(1 << 18) == 4096 and lib.jf_mlp2_small_bwd_slabs(10) == 1
+    assert lib.jf_linear_split_packed_bytes(548, 128) == 12 * 3 * 4 * 3 * 1024 and lib.jf_linear_split_packed_bytes(128, 548) == 18 * 8 * 3 * 1024
+
+
+def test_cpu_quota_parsing(tmp_path, monkeypatch):
+    import builtins
+    import bench
+    real_open = builtins.open
+
+    def fake(path, *a, **k):
+        if path == "/sys/fs/cgroup/cpu.max":
+            p = tmp_path / "cpu.max"
+            p.write_text("1600000 100000\n")
+            return real_open(p, *a, **k)
+        return real_open(path, *a, **k)
+    monkeypatch.setattr(builtins, "open", fake)
+    assert bench.cpu_quota() == 16.0
