@@ -207,6 +207,14 @@ int jf_mlp2_small_bwd_f32(const float* x, int64_t x_stride, const float* W1, int
 int jf_mlp2_small_bwd_f64(const double* x, int64_t x_stride, const double* W1, int64_t w1_stride, const double* b1, const double* W2, int64_t w2_stride,
                           const double* g_out, int64_t g_stride, int64_t B, int32_t K1, int32_t H, int32_t N, double* slab, double* slab_b2, void* stream);
 
+/* The first layer of such an MLP alone (K1 <= 32, H <= 128; any second layer): g_hidden (B, H) = the gradient with respect to the tanh OUTPUT
+ * (the second layer's grad_output @ weight) -> tanh derivative + weight / bias gradient of the first layer in one launch, the activations
+ * recomputed from x.  slab (S, H, K1 + 1): [g_W1[j][0..K1) | g_b1[j]], S = jf_mlp2_small_bwd_slabs(B), added up by the caller. */
+int jf_mlp_hidden_bwd_f32(const float* x, int64_t x_stride, const float* W1, int64_t w1_stride, const float* b1, const float* g_hidden,
+                          int64_t g_stride, int64_t B, int32_t K1, int32_t H, float* slab, void* stream);
+int jf_mlp_hidden_bwd_f64(const double* x, int64_t x_stride, const double* W1, int64_t w1_stride, const double* b1, const double* g_hidden,
+                          int64_t g_stride, int64_t B, int32_t K1, int32_t H, double* slab, void* stream);
+
 /* One AmortizableMLP stage with PER-SAMPLE weights (amortize_everything / fully_amortized_pdf: _apply_amortized_mlp with extra_inputs,
  * amortizable_mlp.py:508-578): out[b] = act(W_b in[b] + bias_b) (+ residual[b]); `segment` points at this stage's [U | V | bias] slice of
  * row 0 of the per-sample parameter block (row stride segment_stride): rank == 0: U = W (n_out x n_in); else U (n_out x rank), V (rank x n_in).

@@ -116,6 +116,7 @@ _SIGNATURES = {
     "jf_linear": [_P, _I64, _P, _I64, _P, _I64, _I32, _I32, _I32, _P, _I64, _P],
     "jf_normal_logp": [_P, _I64, _I64, _I32, _P, _P, _P],
     "jf_tanh_bwd": [_P, _P, _I64, _P, _P],
+    "jf_mlp_hidden_bwd": [_P, _I64, _P, _I64, _P, _P, _I64, _I64, _I32, _I32, _P, _P],
     "jf_mlp2_small_bwd": [_P, _I64, _P, _I64, _P, _P, _I64, _P, _I64, _I64, _I32, _I32, _I32, _P, _P, _P],
     "jf_mlp2": [_P, _I64, _P, _I64, _P, _P, _I64, _P, _I64, _I32, _I32, _I32, _P, _I64, _P],
     "jf_sphere_to_embedding": [_P, _I64, _P, _I64, _I32, _P, _I64, _P, _P],
@@ -592,6 +593,21 @@ def mlp2_small_bwd(x, w1, b1, w2, g):
              _ptr(slab_b2)), dev)
     tot = slab.sum(0)
     return tot[:, :K1], tot[:, K1], tot[:, K1 + 1:].t(), slab_b2.sum(0)
+
+
+def mlp_hidden_bwd(x, w1, b1, g_hidden):
+    """(g_w1, g_b1) of h = tanh(x w1^T + b1) for the gradient g_hidden (B, H) with respect to h: tanh derivative + first-layer weight / bias
+    gradient in one launch (jf_mlp_hidden_bwd; K1 <= 32, H <= 128), the activations recomputed from x"""
+    dev = require_device(x, w1, b1, g_hidden)
+    x, w1, g_hidden = _rowmajor(x), _rowmajor(w1), _rowmajor(g_hidden)
+    B, K1 = x.shape
+    H = w1.shape[0]
+    S = int(lib().jf_mlp2_small_bwd_slabs(B))
+    slab = torch.empty((S, H, K1 + 1), dtype=x.dtype, device=x.device)
+    _launch("jf_mlp_hidden_bwd" + _suffix(x), "K%d_H%d" % (K1, H),
+            (_ptr(x), x.stride(0), _ptr(w1), w1.stride(0), _ptr(b1.contiguous()), _ptr(g_hidden), g_hidden.stride(0), B, K1, H, _ptr(slab)), dev)
+    tot = slab.sum(0)
+    return tot[:, :K1], tot[:, K1]
 
 
 def tanh_bwd(g, y, inplace=False):

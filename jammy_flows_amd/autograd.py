@@ -133,10 +133,15 @@ class CondBlockFn(torch.autograd.Function):
         del params
         need = ctx.needs_input_grad
         g_w2, g_b2 = _hip.linear_wgrad(g_p, h, want_bias=need[4]) if (need[3] or need[4]) else (None, None)
-        g_h = _hip.tanh_bwd(_input_grad(g_p, w2), h, inplace=True)
+        if not need[0] and inp.shape[1] <= _hip.MLP2_SMALL_MAX_IN and w1.shape[0] <= _hip.MLP2_MAX_HIDDEN and inp.shape[0] > 0:
+            # data rows in front: tanh derivative + first-layer weight / bias gradient in one launch (the activations recomputed per hidden unit)
+            g_w1, g_b1 = _hip.mlp_hidden_bwd(inp, w1, b1, _input_grad(g_p, w2))
+            g_inp = None
+        else:
+            g_h = _hip.tanh_bwd(_input_grad(g_p, w2), h, inplace=True)
+            g_w1, g_b1 = _hip.linear_wgrad(g_h, inp, want_bias=need[2]) if (need[1] or need[2]) else (None, None)
+            g_inp = _input_grad(g_h, w1) if need[0] else None
         del g_p
-        g_w1, g_b1 = _hip.linear_wgrad(g_h, inp, want_bias=need[2]) if (need[1] or need[2]) else (None, None)
-        g_inp = _input_grad(g_h, w1) if need[0] else None
         return (g_inp, g_w1, g_b1, g_w2, g_b2, g_x, g_ld if ctx.has[0] else None, g_blp if ctx.has[1] else None, None, None, None, None, None)
 
 

@@ -234,6 +234,47 @@ __global__ void __launch_bounds__(128) mlp2_small_bwd_kernel(const T* __restrict
     }
 }
 
+// the first layer alone: the gradient with respect to the hidden activations (B, H) is given (the second layer's input-gradient product), the
+// tanh derivative and the first layer's weight / bias gradient follow in one launch (slab [H][K1 + 1]); same thread = hidden unit scheme
+template <typename T, int KB>
+__global__ void __launch_bounds__(128) mlp_hidden_bwd_kernel(const T* __restrict__ x, int64_t xs, const T* __restrict__ W1, int64_t w1s, const T* __restrict__ b1,
+                                                             const T* __restrict__ gh, int64_t ghs, int64_t B, int K1, int H, int64_t rows_per_block,
+                                                             T* __restrict__ slab) {
+    const int j = threadIdx.x;
+    const bool live = j < H;
+    const int jj = live ? j : H - 1;
+    T w1[KB], a1[KB];
+    int kx[KB];
+#pragma unroll
+    for (int k = 0; k < KB; ++k) { w1[k] = k < K1 ? W1[(int64_t)jj * w1s + k] : T(0); a1[k] = T(0); kx[k] = k < K1 ? k : K1 - 1; }
+    const T bj = b1[jj];
+    T ab1 = T(0);
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r1 = r0 + rows_per_block < B ? r0 + rows_per_block : B;
+#pragma unroll 4
+    for (int64_t r = r0; r < r1; ++r) {
+        const T* xr = x + r * xs;                                 // uniform addresses: scalar loads
+        const T gr = gh[r * ghs + jj];
+        T xv[KB];
+#pragma unroll
+        for (int k = 0; k < KB; ++k) xv[k] = xr[kx[k]];
+        T pre = bj;
+#pragma unroll
+        for (int k = 0; k < KB; ++k) pre += w1[k] * xv[k];
+        const T h = M<T>::tanh_fast(pre);
+        const T g = gr * (T(1) - h * h);
+        ab1 += g;
+#pragma unroll
+        for (int k = 0; k < KB; ++k) a1[k] += g * xv[k];
+    }
+    if (live) {
+        T* row = slab + ((int64_t)blockIdx.x * H + j) * (K1 + 1);
+#pragma unroll
+        for (int k = 0; k < KB; ++k) if (k < K1) row[k] = a1[k];
+        row[K1] = ab1;
+    }
+}
+
 static int64_t mlp2_small_slabs(int64_t B) {
     int64_t s = (B + 63) / 64;                                     // >= 64 rows per workgroup, <= 4096 workgroups
     if (s > 4096) s = 4096;
@@ -255,6 +296,22 @@ static int mlp2_small_bwd(const T* x, int64_t xs, const T* W1, int64_t w1s, cons
     if (K1 <= 4) JF_MS_N(4) else if (K1 <= 8) JF_MS_N(8) else if (K1 <= 16) JF_MS_N(16) else JF_MS_N(32)
 #undef JF_MS_N
 #undef JF_MS
+    return check_launch();
+}
+
+template <typename T>
+static int mlp_hidden_bwd(const T* x, int64_t xs, const T* W1, int64_t w1s, const T* b1, const T* gh, int64_t ghs, int64_t B, int32_t K1, int32_t H, T* slab,
+                          void* stream) {
+    if (!x || !W1 || !b1 || !gh || !slab || B < 0) return JF_ERR_BADARG;
+    if (K1 < 1 || K1 > MS_K1MAX || H < 1 || H > 128) return JF_ERR_UNSUPPORTED;
+    if (B == 0) return JF_OK;
+    const int64_t S = mlp2_small_slabs(B);
+    const int64_t rpb = (B + S - 1) / S;
+    const dim3 grid((unsigned)S), block(128);
+    hipStream_t st = (hipStream_t)stream;
+#define JF_MH(KB_) hipLaunchKernelGGL((mlp_hidden_bwd_kernel<T, KB_>), grid, block, 0, st, x, xs, W1, w1s, b1, gh, ghs, B, (int)K1, (int)H, rpb, slab)
+    if (K1 <= 4) JF_MH(4); else if (K1 <= 8) JF_MH(8); else if (K1 <= 16) JF_MH(16); else JF_MH(32);
+#undef JF_MH
     return check_launch();
 }
 
@@ -317,5 +374,13 @@ int jf_mlp2_small_bwd_f32(const float* x, int64_t xs, const float* W1, int64_t w
 int jf_mlp2_small_bwd_f64(const double* x, int64_t xs, const double* W1, int64_t w1s, const double* b1, const double* W2, int64_t w2s, const double* g, int64_t gs,
                           int64_t B, int32_t K1, int32_t H, int32_t N, double* slab, double* slab_b2, void* s) {
     return jf::mlp2_small_bwd<double>(x, xs, W1, w1s, b1, W2, w2s, g, gs, B, K1, H, N, slab, slab_b2, s);
+}
+int jf_mlp_hidden_bwd_f32(const float* x, int64_t xs, const float* W1, int64_t w1s, const float* b1, const float* gh, int64_t ghs, int64_t B, int32_t K1,
+                          int32_t H, float* slab, void* s) {
+    return jf::mlp_hidden_bwd<float>(x, xs, W1, w1s, b1, gh, ghs, B, K1, H, slab, s);
+}
+int jf_mlp_hidden_bwd_f64(const double* x, int64_t xs, const double* W1, int64_t w1s, const double* b1, const double* gh, int64_t ghs, int64_t B, int32_t K1,
+                          int32_t H, double* slab, void* s) {
+    return jf::mlp_hidden_bwd<double>(x, xs, W1, w1s, b1, gh, ghs, B, K1, H, slab, s);
 }
 }

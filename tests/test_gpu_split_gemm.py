@@ -73,3 +73,20 @@ def test_mlp2_small_backward_vs_autograd(dtype, B, K1, H, N):
     for name, a, p in zip(("w1", "b1", "w2", "b2"), got, ps):
         err = (a.double() - p.grad).abs().max().item() / max(p.grad.abs().max().item(), 1e-30)
         assert err < tol * (1 + B ** 0.5 / 30), (name, err)
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("B,K1,H", [(1000, 7, 128), (4099, 4, 64), (70001, 7, 128), (3, 32, 8)])
+def test_mlp_hidden_backward_vs_autograd(dtype, B, K1, H):
+    """jf_mlp_hidden_bwd (tanh derivative + first-layer weight / bias gradient in one launch) against torch autograd in float64"""
+    rng = np.random.default_rng(B + K1 + H)
+    mk = lambda *s: torch.from_numpy(rng.normal(size=s)).to(device="cuda", dtype=torch.float64)
+    x, w1, b1, gh = mk(B, K1), mk(H, K1) / np.sqrt(K1), mk(H), mk(B, H)
+    ps = [t.clone().requires_grad_(True) for t in (w1, b1)]
+    with torch.enable_grad():
+        torch.tanh(x @ ps[0].t() + ps[1]).backward(gh)
+    got = _hip.mlp_hidden_bwd(x.to(dtype), w1.to(dtype), b1.to(dtype), gh.to(dtype))
+    tol = 1e-11 if dtype == torch.float64 else 3e-5
+    for name, a, p in zip(("w1", "b1"), got, ps):
+        err = (a.double() - p.grad).abs().max().item() / max(p.grad.abs().max().item(), 1e-30)
+        assert err < tol * (1 + B ** 0.5 / 30), (name, err)
