@@ -90,3 +90,20 @@ def test_mlp_hidden_backward_vs_autograd(dtype, B, K1, H):
     for name, a, p in zip(("w1", "b1"), got, ps):
         err = (a.double() - p.grad).abs().max().item() / max(p.grad.abs().max().item(), 1e-30)
         assert err < tol * (1 + B ** 0.5 / 30), (name, err)
+
+
+def test_split_kernels_repeat_bit_identically_at_full_size():
+    """2^18 rows, three launches each: the split-bf16 products and the weight gradient have no atomics and no launch-order dependence, so
+    repeated launches must agree bit for bit (the check that exposed the packed-f32 fault of the fused forward block)"""
+    B = 1 << 18
+    g_ = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.randn(B, 128, device="cuda", generator=g_)
+    w = torch.randn(548, 128, device="cuda", generator=g_) / 11.0
+    b = torch.randn(548, device="cuda", generator=g_)
+    gp = torch.randn(B, 548, device="cuda", generator=g_)
+    first = (_hip.linear_split(x, w, b), _hip.linear_split(gp, w.t()), *_hip.linear_wgrad(gp, x))
+    for _ in range(2):
+        again = (_hip.linear_split(x, w, b), _hip.linear_split(gp, w.t()), *_hip.linear_wgrad(gp, x))
+        for a, c in zip(first, again):
+            assert torch.equal(a, c)
+    assert all(torch.isfinite(t).all() for t in first)
