@@ -199,15 +199,11 @@ __global__ void __launch_bounds__(128) mlp2_small_bwd_kernel(const T* __restrict
     T ab1 = T(0);
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
     const int64_t r1 = r0 + rows_per_block < B ? r0 + rows_per_block : B;
-#pragma unroll 4
-    for (int64_t r = r0; r < r1; ++r) {
-        const T* xr = x + r * xs;                                 // uniform addresses: scalar loads
-        const T* gr = g + r * gs;
-        T xv[KB], gv[NB];
-#pragma unroll
-        for (int k = 0; k < KB; ++k) xv[k] = xr[kx[k]];
-#pragma unroll
-        for (int n = 0; n < NB; ++n) gv[n] = gr[nx[n]];
+    // rows whose KB / NB-element reads stay inside the arrays are read CONTIGUOUSLY (one or two wide scalar loads per row; the slots beyond K1 / N
+    // then hold the neighbouring row's values, which meet zero weights); only the last rows of the arrays take the clamped indices
+    const int64_t safe = B - 1 - ((KB - K1 + xs - 1) / xs > (NB - N + gs - 1) / gs ? (KB - K1 + xs - 1) / xs : (NB - N + gs - 1) / gs);
+    const int64_t rm = r1 < safe ? r1 : (safe > r0 ? safe : r0);
+    auto one_row = [&](const T (&xv)[KB], const T (&gv)[NB]) {
         T pre = bj;
 #pragma unroll
         for (int k = 0; k < KB; ++k) pre += w1[k] * xv[k];
@@ -219,6 +215,27 @@ __global__ void __launch_bounds__(128) mlp2_small_bwd_kernel(const T* __restrict
         ab1 += gh;
 #pragma unroll
         for (int k = 0; k < KB; ++k) a1[k] += gh * xv[k];
+    };
+#pragma unroll 4
+    for (int64_t r = r0; r < rm; ++r) {
+        const T* xr = x + r * xs;                                 // uniform addresses: scalar loads
+        const T* gr = g + r * gs;
+        T xv[KB], gv[NB];
+#pragma unroll
+        for (int k = 0; k < KB; ++k) xv[k] = xr[k];
+#pragma unroll
+        for (int n = 0; n < NB; ++n) gv[n] = gr[n];
+        one_row(xv, gv);
+    }
+    for (int64_t r = rm; r < r1; ++r) {
+        const T* xr = x + r * xs;
+        const T* gr = g + r * gs;
+        T xv[KB], gv[NB];
+#pragma unroll
+        for (int k = 0; k < KB; ++k) xv[k] = xr[kx[k]];
+#pragma unroll
+        for (int n = 0; n < NB; ++n) gv[n] = gr[nx[n]];
+        one_row(xv, gv);
     }
     if (live) {
         T* row = slab + ((int64_t)blockIdx.x * H + j) * (K1 + 1 + N);
@@ -251,13 +268,9 @@ __global__ void __launch_bounds__(128) mlp_hidden_bwd_kernel(const T* __restrict
     T ab1 = T(0);
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
     const int64_t r1 = r0 + rows_per_block < B ? r0 + rows_per_block : B;
-#pragma unroll 4
-    for (int64_t r = r0; r < r1; ++r) {
-        const T* xr = x + r * xs;                                 // uniform addresses: scalar loads
-        const T gr = gh[r * ghs + jj];
-        T xv[KB];
-#pragma unroll
-        for (int k = 0; k < KB; ++k) xv[k] = xr[kx[k]];
+    const int64_t safe = B - 1 - (KB - K1 + xs - 1) / xs;          // contiguous KB-element reads of x stay inside the array up to this row
+    const int64_t rm = r1 < safe ? r1 : (safe > r0 ? safe : r0);
+    auto one_row = [&](const T (&xv)[KB], T gr) {
         T pre = bj;
 #pragma unroll
         for (int k = 0; k < KB; ++k) pre += w1[k] * xv[k];
@@ -266,6 +279,21 @@ __global__ void __launch_bounds__(128) mlp_hidden_bwd_kernel(const T* __restrict
         ab1 += g;
 #pragma unroll
         for (int k = 0; k < KB; ++k) a1[k] += g * xv[k];
+    };
+#pragma unroll 4
+    for (int64_t r = r0; r < rm; ++r) {
+        const T* xr = x + r * xs;                                 // uniform addresses: scalar loads
+        T xv[KB];
+#pragma unroll
+        for (int k = 0; k < KB; ++k) xv[k] = xr[k];
+        one_row(xv, gh[r * ghs + jj]);
+    }
+    for (int64_t r = rm; r < r1; ++r) {
+        const T* xr = x + r * xs;
+        T xv[KB];
+#pragma unroll
+        for (int k = 0; k < KB; ++k) xv[k] = xr[kx[k]];
+        one_row(xv, gh[r * ghs + jj]);
     }
     if (live) {
         T* row = slab + ((int64_t)blockIdx.x * H + j) * (K1 + 1);
