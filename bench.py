@@ -2,7 +2,10 @@
 """Benchmark of the jammy_flows hot path on MI355X (contract: see the task statement / DESIGN.md section "Measurement").
 
     python bench.py --gpus N --steps K --warmup W [--workload c3|c5] [--scaling weak|strong]
-                                                   (N > 1: launched by torch.distributed.run, one rank per GPU)
+                                                   (N > 1: one rank per GPU.  Under torch.distributed.run the ranks read RANK / LOCAL_RANK /
+                                                    WORLD_SIZE / MASTER_* from the environment; started WITHOUT such an environment the script
+                                                    launches `python -m torch.distributed.run --nproc-per-node N bench.py ...` itself as a CHILD
+                                                    process -- before this process has touched the GPU -- relays its output and exits with its code)
 
 One step = one log-prob evaluation (`pdf.forward`) of one batch of synthetic rows: all sub-pdfs, all amortisation MLPs, every layer.
   --workload c3 (default): BASELINE.json's metric configuration `pdf("e4+s2+e4", "gggg+f+gggg")` ("n" of the upstream README = "f"),
@@ -166,8 +169,10 @@ def cpu_baseline(workload, budget_s=15.0, workers=None, chunk=4096):
             calibration[cand] = n / dt
         workers = max(calibration, key=calibration.get)
     n, dt = run(workers, budget_s)
-    return {"value": n / dt, "unit": "log-prob evals/s", "cores": workers, "kind": "port", "cpu_model": cpu_model(),
-            "per_core": n / dt / workers, "host_logical_cpus": cores, "cgroup_cpu_quota": cpu_quota(),
+    quota = cpu_quota()
+    usable = int(round(quota)) if (quota is not None and quota >= 1) else cores       # CPUs this process can actually run on at once
+    return {"value": n / dt, "unit": "log-prob evals/s", "cores": min(usable, workers), "workers": workers, "kind": "port", "cpu_model": cpu_model(),
+            "per_core": n / dt / min(usable, workers), "per_worker": n / dt / workers, "host_logical_cpus": cores, "cgroup_cpu_quota": quota,
             "worker_calibration": {str(k): v for k, v in calibration.items()},
             "sample": "%d rows of %s (float64 numpy oracle, %d single-threaded processes x %d-row chunks), %.1f s"
                       % (n, w["fixture"], workers, chunk, dt),
@@ -292,6 +297,74 @@ def kernel_accounting(kname, ktag, s):
     return 0, 0, False
 
 
+# ---------------------------------------------------------------------------------------------- self-launch for N > 1
+def free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` (N > 1) started without a torch.distributed.run environment: start the N ranks as a CHILD process tree and
+    return its exit code.  This process has not imported torch nor made any HIP call at this point, and it never execs: the pool's boxes go
+    down when a process that has initialised the GPU replaces itself.  Rank 0 of the child prints the JSON line on the inherited stdout."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this pool: RCCL needs it
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + list(argv)
+    sys.stdout.flush()
+    return subprocess.run(cmd, env=env).returncode
+
+
+def dry_run(args, W, rank, world, B, total_rows, lo):
+    """the multi-rank plumbing of this script without a GPU: rendezvous, the rows each rank owns, the contract's timing loop and the per-step
+    all-gather, with a stand-in row function evaluated by torch on the host.  Prints the same line shape with "dry_run": true and value null."""
+    import torch
+    import torch.distributed as dist
+    from jammy_flows_amd import parallel
+    torch.set_num_threads(1)
+    backend = os.environ.get("JF_BENCH_BACKEND", "gloo")
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    n_ranks_seen = dist.get_world_size() if world > 1 else 1
+    x = torch.arange(lo, lo + B, dtype=torch.float64)
+    gather = parallel.PipelinedGather(B, torch.float64, torch.device("cpu")) if (world > 1 and total_rows % world == 0) else None
+
+    def step():
+        y = -0.5 * x * x
+        if gather is not None:
+            gather.submit(y)
+
+    def finish():
+        if gather is not None:
+            gather.wait()
+
+    dt = parallel.timed_steps(step, args.steps, args.warmup, finish=finish, device=None)
+    ok = True
+    if gather is not None:
+        full = gather.wait()
+        ref = torch.arange(0, total_rows, dtype=torch.float64)
+        ok = bool(torch.equal(full, -0.5 * ref * ref))
+    if world > 1:
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps({"metric": W["metric"], "value": None, "unit": "log-prob evals/s", "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": args.scaling,
+                          "vs_baseline": None, "dtype": W["dtype"], "data": "none (dry run: stand-in row function on the host, no kernels)",
+                          "dry_run": True, "config": {"workload": "dry run of %s" % args.workload, "batch_per_gpu": B, "total_rows": total_rows,
+                                                      "parallelism": "rows sharded over %d rank(s)" % world},
+                          "n_ranks_seen": n_ranks_seen, "collective_backend": dist.get_backend() if world > 1 else None,
+                          "gathered_rows_correct": ok}))
+    if world > 1:
+        dist.destroy_process_group()
+    return 0 if ok else 1
+
+
 # ---------------------------------------------------------------------------------------------- main
 def main():
     ap = argparse.ArgumentParser()
@@ -305,13 +378,20 @@ def main():
     ap.add_argument("--no-pmc", action="store_true", help="do not run the rocprofv3 PMC child passes (traffic then comes from the committed profile)")
     ap.add_argument("--no-fuse", action="store_true", help="time the two-launch path (MLP launch + flow launch) instead of the fused conditional block")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--dry-run", action="store_true",
+                    help="exercise launch / rendezvous / row sharding / timing loop / all-gather with a stand-in step on the host (no GPU, no kernels): "
+                         "the line carries \"dry_run\": true and no throughput claim.  For the CPU tests (JF_BENCH_BACKEND=gloo)")
     args = ap.parse_args()
     W = WORKLOADS[args.workload]
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.pmc_child:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    assert world == args.gpus or args.pmc_child, "WORLD_SIZE (%d) != --gpus (%d): launch with torch.distributed.run --nproc-per-node N" % (world, args.gpus)
+    if world != args.gpus and not args.pmc_child:
+        sys.exit("bench.py: WORLD_SIZE (%d) != --gpus (%d): the launcher's --nproc-per-node must equal --gpus" % (world, args.gpus))
 
     # rows of this rank
     if args.scaling == "weak":
@@ -323,6 +403,9 @@ def main():
         base, rem = divmod(total_rows, world)
         lo = rank * base + min(rank, rem)
         B = base + (1 if rank < rem else 0)
+
+    if args.dry_run:
+        return dry_run(args, W, rank, world, B, total_rows, lo)
 
     cpu = None
     traffic = None

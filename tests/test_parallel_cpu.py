@@ -208,3 +208,42 @@ def test_gradient_allreduce_gloo_world2():
         p.join(timeout=60)
     assert sorted(r for r, _ in res) == [0, 1]
     assert all(ok for _, ok in res)
+
+
+def _run_bench(args, env_extra=None, drop=()):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in drop}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                          text=True, timeout=300)
+
+
+def test_bench_launches_its_own_ranks_dry_run():
+    """`python bench.py --gpus 2` without a torch.distributed.run environment starts the ranks itself (child process), rank 0 prints ONE JSON line"""
+    import json
+    r = _run_bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-run", "--batch", "1000"], {"JF_BENCH_BACKEND": "gloo"},
+                   drop=("WORLD_SIZE", "RANK", "LOCAL_RANK"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["n_ranks_seen"] == 2 and line["collective_backend"] == "gloo"
+    assert line["dry_run"] is True and line["gathered_rows_correct"] is True
+    assert line["config"]["total_rows"] == 2000 and line["steps"] == 3 and line["warmup"] == 1
+
+
+def test_bench_c5_strong_scaling_row_split_dry_run():
+    """BASELINE configs[4]: 2^22 rows in total; --gpus 8 weak = 2^19 per rank, strong = the same total split over the ranks (here 2 ranks)"""
+    import json
+    r = _run_bench(["--gpus", "2", "--steps", "1", "--warmup", "0", "--dry-run", "--workload", "c5", "--scaling", "strong", "--batch", "4097"],
+                   {"JF_BENCH_BACKEND": "gloo"}, drop=("WORLD_SIZE", "RANK", "LOCAL_RANK"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert line["config"]["total_rows"] == 4097 and line["config"]["batch_per_gpu"] == 2049 and line["scaling"] == "strong"
+
+
+def test_bench_refuses_a_rank_count_mismatch():
+    r = _run_bench(["--gpus", "2", "--dry-run"], {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "WORLD_SIZE" in r.stderr
