@@ -247,7 +247,8 @@ def committed_traffic():
 KERNEL_OF = {"jf_cond_f_chain_inv_f32": "cond_mchain_kernel<float, jf::FFam", "jf_cond_f_chain_inv_f64": "cond_mchain_kernel<double, jf::FFam",
              "jf_conditioning_rows_f32": "conditioning_kernel<float", "jf_conditioning_rows_f64": "conditioning_kernel<double",
              "jf_v_chain_inv_f64": "mchain_kernel<double, jf::VFam", "jf_amlp2_f64": "amlp2_mfma_kernel",
-             "jf_cond_gf_chain_inv_split_f32": "cond_gf_split_kernel", "jf_cond_gf_chain_inv_f32": "cond_gf_chain_kernel<float",
+             "jf_cond_gf_chain_inv_split_f32": "cond_gf_split_kernel", "jf_cond_gf_chain_inv_pp_f32": "cond_gf_pp_kernel",
+             "jf_cond_gf_chain_inv_f32": "cond_gf_chain_kernel<float",
              "jf_cond_gf_chain_inv_f64": "cond_gf_chain_kernel<double", "jf_mlp2_f32": "mlp2_kernel<float", "jf_mlp2_f64": "mlp2_kernel<double",
              "jf_gf_chain_inv_f32": "gf_chain_kernel<float", "jf_gf_chain_inv_f64": "gf_chain_kernel<double",
              "jf_amlp_gf_chain_inv_f64": "amlp_gf_mfma_kernel"}
@@ -275,7 +276,7 @@ def traffic_of(traffic, kname, ktag):
 # ---------------------------------------------------------------------------------------------- algorithmic accounting
 def kernel_accounting(kname, ktag, s):
     """(algorithmic HBM bytes per row, MFMA flops per row, fused?) of one timed kernel; s = bytes per scalar."""
-    if kname.startswith("jf_cond_gf_chain_inv_split"):
+    if kname.startswith("jf_cond_gf_chain_inv_split") or kname.startswith("jf_cond_gf_chain_inv_pp"):
         K1, H, L, D = (int(t[1:]) for t in ktag.split("_"))
         N = L * (3 * 10 * D + D * D) + D                 # default g rows: 3 K D + D^2 (+ D offsets on the last layer)
         return s * (K1 + N) + s * (D + 1 + N + D + 1), 2 * (K1 * H + H * N), True
@@ -568,9 +569,10 @@ def main():
         if flops_per_row:
             tf = flops_per_row * B / secs / 1e12
             mf = {"algorithmic_TFLOPs": tf, "algorithmic_flops_per_launch": flops_per_row * B}
-            if kname.endswith("_split_f32"):
+            if kname.endswith("_split_f32") or kname.endswith("_pp_f32"):
                 K1, H, L, D = (int(t[1:]) for t in ktag.split("_"))
-                executed = 2 * K1 * 128 + 6 * 2 * 128 * (L * 9 * 16)        # exact-f32 first layer + six bf16 passes over the padded 9 x 16 columns per layer
+                cols = L * 5 * 32 if kname.endswith("_pp_f32") else L * 9 * 16     # padded columns per row: 5 tiles of 32 / 9 tiles of 16 per layer
+                executed = 2 * K1 * 128 + 6 * 2 * 128 * cols               # first layer + six bf16 passes over the padded columns
                 mf.update({"arithmetic": "3-way split bf16, 6 MFMA passes, f32 accumulate", "executed_bf16_TFLOPs": executed * B / secs / 1e12,
                            "frac_of_bf16_peak": executed * B / secs / 1e12 / MFMA_BF16_PEAK_TFLOPS,
                            "frac_of_f32_mfma_peak_equivalent": tf / MFMA_F32_PEAK_TFLOPS})

@@ -10,7 +10,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libjammy_hip.so")
+# JF_LIB_PATH: a private build of the same library (instrumented probes, scripts/probe/pp_trace.sh); the product loads the in-tree one
+LIB_PATH = os.environ.get("JF_LIB_PATH") or os.path.join(_HERE, "libjammy_hip.so")
 
 JF_OK, JF_ERR_BADARG, JF_ERR_UNSUPPORTED, JF_ERR_LAUNCH = 0, -1, -2, -3
 JF_ERRORS = {-1: "bad argument", -2: "unsupported configuration (dimension > 8, chain too long, LDS budget ...)", -3: "kernel launch failed"}
@@ -143,6 +144,11 @@ _SIGNATURES_SINGLE = {
     "jf_linear_split_pack_f32": ([_P, _I64, _I64, _I32, _I32, _P, _P], ctypes.c_int),
     "jf_linear_split_f32": ([_P, _I64, _P, _P, _I64, _I32, _I32, _P, _I64, _P], ctypes.c_int),
     "jf_cond_gf_packed_bytes": ([_I32, _I32, ctypes.POINTER(jf_gf_layer)], ctypes.c_int64),
+    "jf_cond_gf_split_row_groups": ([_I32], ctypes.c_int),
+    "jf_cond_gf_pp_packed_bytes": ([_I32, _I32, ctypes.POINTER(jf_gf_layer)], ctypes.c_int64),
+    "jf_cond_gf_pp_pack_f32": ([_P, _I64, _P, _I32, _I32, _I32, ctypes.POINTER(jf_gf_layer), _P, _P], ctypes.c_int),
+    "jf_cond_gf_chain_inv_pp_f32": ([_P, _I64, _P, _I64, _P, _P, _I32, _I32, _P, _I64, _P, _I64, _I32, _I32, ctypes.POINTER(jf_gf_layer), _P, _I64,
+                                     _P, _P, _P, _P, _P], ctypes.c_int),
     "jf_cond_gf_pack_f32": ([_P, _I64, _P, _I32, _I32, _I32, ctypes.POINTER(jf_gf_layer), _P, _P], ctypes.c_int),
     "jf_cond_gf_chain_inv_split_f32": ([_P, _I64, _P, _I64, _P, _P, _I32, _I32, _P, _I64, _P, _I64, _I32, _I32, ctypes.POINTER(jf_gf_layer), _P, _I64,
                                         _P, _P, _P, _P, _P], ctypes.c_int),
@@ -462,28 +468,36 @@ def amlp2(inp, v1, u1, b1, v2, u2, b2):
     return out
 
 
-def cond_gf_packed_bytes(layer_array, n_layers, D):
-    """size of the packed W2 / b2 image of the split-bf16 fused block, or a negative JF_ERR_* when the chain is not supported by it."""
-    return int(lib().jf_cond_gf_packed_bytes(D, n_layers, layer_array))
+# the two register-resident fused block kernels: "split" (cond_split_kernels.hip, 64 / 128 rows per workgroup) and "pp" (cond_pp_kernels.hip,
+# persistent ping-pong workgroups of 256 rows; large batches)
+_COND_GF_PACK = {"split": ("jf_cond_gf_packed_bytes", "jf_cond_gf_pack_f32", "jf_cond_gf_chain_inv_split_f32", 28),
+                 "pp": ("jf_cond_gf_pp_packed_bytes", "jf_cond_gf_pp_pack_f32", "jf_cond_gf_chain_inv_pp_f32", 32)}
+COND_GF_PP_MIN_ROWS = 1 << 16        # below this the persistent kernel leaves CUs without a row tile
 
 
-def cond_gf_pack(w2, b2, layer_array, n_layers, D):
+def cond_gf_packed_bytes(layer_array, n_layers, D, kind="split"):
+    """size of the packed W2 / b2 image of a register-resident fused block kernel, or a negative JF_ERR_* when the chain is not supported by it."""
+    return int(getattr(lib(), _COND_GF_PACK[kind][0])(D, n_layers, layer_array))
+
+
+def cond_gf_pack(w2, b2, layer_array, n_layers, D, kind="split"):
     """W2 (N, H) / b2 (N,) of the amortisation MLP -> packed image for cond_gf_chain_inv_split (bf16 pieces in MFMA fragment order,
     rows permuted so that the MFMA result registers are the flow's parameter registers).  Redo whenever the weights change."""
     dev = require_device(w2, b2)
     w2 = _rowmajor(w2)
     if w2.dtype != torch.float32 or b2.dtype != torch.float32:
         raise TypeError("cond_gf_pack: float32 only")
-    nbytes = cond_gf_packed_bytes(layer_array, n_layers, D)
-    _check(min(nbytes, 0), "jf_cond_gf_packed_bytes")
+    nbytes = cond_gf_packed_bytes(layer_array, n_layers, D, kind)
+    _check(min(nbytes, 0), _COND_GF_PACK[kind][0])
     packed = torch.empty((nbytes,), dtype=torch.uint8, device=w2.device)
-    _launch("jf_cond_gf_pack_f32", "", (_ptr(w2), w2.stride(0), _ptr(b2.contiguous()), w2.shape[1], D, n_layers, layer_array, _ptr(packed)), dev)
+    _launch(_COND_GF_PACK[kind][1], "", (_ptr(w2), w2.stride(0), _ptr(b2.contiguous()), w2.shape[1], D, n_layers, layer_array, _ptr(packed)), dev)
     return packed
 
 
 def cond_gf_chain_inv_split(inp, w1, b1, packed, x, log_det, layer_array, n_layers, D, x_out=None, base_logp_in=None, want_base_logp=False,
-                            status=None):
-    """as cond_gf_chain_inv with the second product on split-bf16 MFMA and the parameter block in registers (float32, default layer options)."""
+                            status=None, kind="split"):
+    """as cond_gf_chain_inv with the second product on split-bf16 MFMA and the parameter block in registers (float32, default layer options);
+    `kind` selects the kernel the packed image was built for."""
     dev = require_device(inp, w1, b1, packed, x, log_det, x_out, base_logp_in, status)
     inp, w1, x = _rowmajor(inp), _rowmajor(w1), _rowmajor(x)
     B, K1 = inp.shape
@@ -498,7 +512,7 @@ def cond_gf_chain_inv_split(inp, w1, b1, packed, x, log_det, layer_array, n_laye
         x_out = torch.empty((B, D), dtype=x.dtype, device=x.device)
     ld_out = torch.empty((B,), dtype=x.dtype, device=x.device)
     blp_out = torch.empty((B,), dtype=x.dtype, device=x.device) if want_base_logp else None
-    _launch("jf_cond_gf_chain_inv_split_f32", "K%d_H%d_L%d_D%d" % (K1, H, n_layers, D),
+    _launch(_COND_GF_PACK[kind][2], "K%d_H%d_L%d_D%d" % (K1, H, n_layers, D),
             (_ptr(inp), inp.stride(0), _ptr(w1), w1.stride(0), _ptr(b1.contiguous()), _ptr(packed), K1, H, _ptr(x), x.stride(0), _ptr(log_det), B, D,
              n_layers, layer_array, _ptr(x_out), x_out.stride(0), _ptr(ld_out), _ptr(base_logp_in), _ptr(blp_out), _ptr(status)), dev)
     return (x_out, ld_out, blp_out) if want_base_logp else (x_out, ld_out)

@@ -111,7 +111,7 @@ class CondBlockFn(torch.autograd.Function):
         args = (x.detach(), None if log_det is None else log_det.detach(), layer_array, n_layers, D)
         kw = dict(base_logp_in=None if base_logp_in is None else base_logp_in.detach(), want_base_logp=True, status=status)
         if packed is not None:
-            res = _hip.cond_gf_chain_inv_split(inp.detach(), w1.detach(), b1.detach(), packed, *args, **kw)
+            res = _hip.cond_gf_chain_inv_split(inp.detach(), w1.detach(), b1.detach(), packed[1], *args, kind=packed[0], **kw)
         else:
             res = _hip.cond_gf_chain_inv(inp.detach(), w1.detach(), b1.detach(), w2.detach(), b2.detach(), *args, **kw)
         ctx.meta = (layer_array, n_layers, D)

@@ -22,21 +22,14 @@
 //
 // Supported: float32, D in {3, 4}, layers with the reference's default options (K = 10 components, smooth-saturation widths, fitted and
 // regulated weights, <= 4 Householder reflections), H <= 128, K1 <= 28.  Everything else: jf_cond_gf_chain_inv_* / jf_mlp2 + jf_gf_chain_inv.
-#include "jf_gf.h"
+#include "jf_cond_regs.h"
 #include "jf_mfma.h"
 #include <cstdlib>
 
 namespace jf {
 
-using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
-typedef __attribute__((address_space(3))) void* cs_lptr;
-typedef const __attribute__((address_space(1))) void* cs_gptr;
-
-constexpr int CS_K = 10;                           // mixture components (parameter registers are indexed statically)
-constexpr int CS_HH = 4;                           // Householder slots
-constexpr int CS_SLOT_MEAN = 0, CS_SLOT_LW = CS_K, CS_SLOT_LN = 2 * CS_K, CS_SLOT_ROT = 3 * CS_K, CS_SLOT_OFF = 3 * CS_K + CS_HH;
 constexpr int CS_TILES = 9;                        // 16-column MFMA tiles per layer (36 slots x 4 coordinates)
-constexpr int CS_SLOTS = 4 * CS_TILES;
+static_assert(CS_SLOTS == 4 * CS_TILES, "one register per slot, four registers per tile");
 constexpr int CS_CT = 3;                           // tiles per chunk
 constexpr int CS_CPL = CS_TILES / CS_CT;           // chunks per layer
 constexpr int CS_KSTEPS = 4;                       // 128 hidden units = 4 x 32
@@ -48,34 +41,13 @@ constexpr int CS_CHUNK_BYTES = CS_W_BYTES + CS_B_BYTES;               // 37056 (
 constexpr int CS_ROWS1 = 64;                       // rows per workgroup and row group (4 waves x 16); a wave carries RG row groups
 constexpr int CS_HMAX = 128, CS_K1MAX = 28;
 
-struct CsLayer { int hh, model_offset, inv_type; float wmin, inv_wmax, nmin, nmax; };
-
 // ---------------------------------------------------------------------------------------------------------- packing
-struct CsPackLayer { int col0, off_rot, off_mean, off_lw, off_ln, hh, model_offset; };
 struct CsPackArgs {
     const float* W2; int64_t w2s; const float* b2;
     int H, D, n_layers;
     CsPackLayer L[JF_MAX_CHAIN];
     unsigned char* out;
 };
-
-// original column (inside the layer's row) of parameter slot `slot` for coordinate d, or -1
-__device__ __forceinline__ int cs_slot_column(const CsPackLayer& o, int D, int slot, int d) {
-    if (d >= D) return -1;
-    if (slot < CS_SLOT_LW) return o.off_mean + slot * D + d;
-    if (slot < CS_SLOT_LN) return o.off_lw + (slot - CS_SLOT_LW) * D + d;
-    if (slot < CS_SLOT_ROT) return o.off_ln + (slot - CS_SLOT_LN) * D + d;
-    if (slot < CS_SLOT_OFF) return (slot - CS_SLOT_ROT) < o.hh ? o.off_rot + (slot - CS_SLOT_ROT) * D + d : -1;
-    if (slot == CS_SLOT_OFF) return o.model_offset ? d : -1;
-    return -1;
-}
-
-__device__ __forceinline__ void cs_split(float v, __bf16& hi, __bf16& mid, __bf16& lo) {
-    hi = (__bf16)v;
-    const float r1 = v - (float)hi;                // exact
-    mid = (__bf16)r1;
-    lo = (__bf16)(r1 - (float)mid);                // exact difference, rounded once
-}
 
 // one thread per (chunk, tile, k-step, lane): writes the three pieces' fragments (16 bytes each); the first 48 threads of a chunk's
 // first k-step also write the bias
@@ -127,68 +99,6 @@ template <typename Op> __device__ __forceinline__ float cs_rreduce(float v, Op o
 __device__ __forceinline__ float cs_rsum(float v) { return cs_rreduce(v, [](float a, float b) { return a + b; }); }
 __device__ __forceinline__ float cs_rmax(float v) { return cs_rreduce(v, [](float a, float b) { return fmaxf(a, b); }); }
 
-// ---------------------------------------------------------------------------------------------------------- mixture on register rows
-// gfg_mixture_impl<float, RAW, FAST> / gfg_mixture_scaled (jf_gf.h) with the lane's parameters in registers P[slot].
-// The regulated 1/width and weight of every component and its u_k = (x - mu_k)/w_k are computed ONCE (2 exp + 2 rcp per component); the
-// distance m = min_k |u_k| to the nearest component then decides -- per wave -- which ONE of the two summations runs (1 exp + 1 rcp per
-// component each): the plain linear-space sums, or the sums scaled by e^{m} when some lane sits further than CS_M_SCALED widths from every
-// component (below that the plain sums cannot underflow: cdf, sf >= pi_min sigma(-m) >= 1e-2 e^{-60}, pdf >= that / (2 w_max)).
-// The first version ran the plain pass always and the scaled pass on top of it whenever a lane underflowed, regulating the parameters again
-// in each (7 exp + 7 rcp per component on the benchmark inputs, two thirds of whose rows sit beyond 12 sigma after three layers).
-constexpr float CS_M_SCALED = 60.0f;
-
-__device__ __forceinline__ MixQ<float> cs_mixture(const float (&P)[CS_SLOTS], const CsLayer& o, float x, bool live) {
-    using Mf = M<float>;
-    float iw[CS_K], wk[CS_K], u[CS_K];
-    float m = INFINITY, Nn = 0.f;
-#pragma unroll
-    for (int k = 0; k < CS_K; ++k) {
-        const float ae = o.inv_wmax + Mf::exp_fast(-P[CS_SLOT_LW + k]);
-        iw[k] = ae * Mf::rcp(o.wmin * ae + 1.0f);
-        wk[k] = o.nmin + o.nmax * Mf::rcp(1.0f + Mf::exp_fast(-P[CS_SLOT_LN + k]));
-        u[k] = (x - P[CS_SLOT_MEAN + k]) * iw[k];
-        m = fminf(m, fabsf(u[k]));
-        Nn += wk[k];
-    }
-    const float inv = Mf::rcp(Nn);
-    MixQ<float> q;
-    if (!__any(live && m > CS_M_SCALED)) {                         // wave-uniform branch
-        float C = 0.f, S = 0.f, Pd = 0.f;
-#pragma unroll
-        for (int k = 0; k < CS_K; ++k) {
-            const float t = Mf::exp_fast(-fabsf(u[k]));
-            const float hi = Mf::rcp(1.0f + t);
-            const float lo = t * hi;
-            const bool pos = u[k] >= 0.f;
-            C += wk[k] * (pos ? hi : lo);
-            S += wk[k] * (pos ? lo : hi);
-            Pd += wk[k] * hi * lo * iw[k];
-        }
-        C *= inv; S *= inv; Pd *= inv;
-        q.lc = Mf::log_fast(C); q.ls = Mf::log_fast(S); q.lp = Mf::log_fast(Pd);
-        q.cdf = C; q.sf = S;
-        return q;
-    }
-    const float em = Mf::exp_fast(-m);                             // may underflow to 0: the unscaled parts then stand alone
-    float Cu = 0.f, Cs = 0.f, Su = 0.f, Ss = 0.f, Ps = 0.f;
-#pragma unroll
-    for (int k = 0; k < CS_K; ++k) {
-        const float t = Mf::exp_fast(m - fabsf(u[k]));
-        const float hi = Mf::rcp(1.0f + t * em);
-        const float c1 = wk[k] * hi, c2 = c1 * t;
-        if (u[k] >= 0.f) { Cu += c1; Ss += c2; }
-        else { Su += c1; Cs += c2; }
-        Ps += c2 * hi * iw[k];
-    }
-    Cu *= inv; Cs *= inv; Su *= inv; Ss *= inv; Ps *= inv;
-    q.cdf = Cu + em * Cs;
-    q.sf = Su + em * Ss;
-    q.lc = Cu > 0.f ? Mf::log_fast(q.cdf) : Mf::log_fast(Cs) - m;
-    q.ls = Su > 0.f ? Mf::log_fast(q.sf) : Mf::log_fast(Ss) - m;
-    q.lp = Mf::log_fast(Ps) - m;
-    return q;
-}
-
 // ---------------------------------------------------------------------------------------------------------- the fused kernel
 struct CsArgs {
     const float* in; int64_t in_stride;
@@ -223,7 +133,6 @@ template <int RG> __global__ void __launch_bounds__(256, 2) cond_gf_split_kernel
     const int64_t row0 = (int64_t)blockIdx.x * CS_ROWS;
     const int64_t last = a.B - 1;
     const int D = a.D;
-
     // ---- chunk streaming: LDS-DMA (global_load_lds_dwordx4: 1 KiB per wave instruction, no register hop) into the buffer that is not being
     //      multiplied; wave w moves KiB pieces w, w + 4, ... of the chunk, the bias tail goes with the last piece of wave 0
     // buffer form (buffer_load_dwordx4 ... offen lds): resource + per-lane byte offset are fixed for the whole kernel, the chunk / piece offset
@@ -416,6 +325,8 @@ template <int RG> __global__ void __launch_bounds__(256, 2) cond_gf_split_kernel
 }
 
 // ---------------------------------------------------------------------------------------------------------- host side
+static int cs_forced_rg = 0;                     // 0: by batch size
+
 static bool cs_layer_supported(const jf_gf_layer& h, int D) {
     return h.num_kde == CS_K && h.hh_iter >= 0 && h.hh_iter <= CS_HH && h.nonlinear_stretch_type == JF_GF_STRETCH_CLASSIC &&
            h.rotation_mode == JF_GF_ROT_HOUSEHOLDER && !h.center_mean && !h.add_skewness &&
@@ -473,8 +384,10 @@ static int cs_chain(const float* in, int64_t in_stride, const float* W1, int64_t
         (void)hipFuncSetAttribute((const void*)cond_gf_split_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    // two row groups per wave once that still leaves every CU several workgroups; JF_CS_RG=1|2 forces a variant (A/B timing, scripts/probe/rg_sweep.py)
-    static const int force_rg = getenv("JF_CS_RG") ? atoi(getenv("JF_CS_RG")) : 0;
+    // two row groups per wave once that still leaves every CU several workgroups; JF_CS_RG=1|2 (environment, read once) or
+    // jf_cond_gf_split_row_groups() force a variant (A/B timing: scripts/probe/rg_sweep.py; both variants in one process: the stress tests)
+    static const int env_rg = getenv("JF_CS_RG") ? atoi(getenv("JF_CS_RG")) : 0;
+    const int force_rg = cs_forced_rg ? cs_forced_rg : env_rg;
     const bool two = force_rg ? force_rg == 2 : B >= (int64_t)CS_ROWS1 * 2 * 1024;
     if (two) hipLaunchKernelGGL(cond_gf_split_kernel<2>, dim3((unsigned)((B + 2 * CS_ROWS1 - 1) / (2 * CS_ROWS1))), dim3(256), lds, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(cond_gf_split_kernel<1>, dim3((unsigned)((B + CS_ROWS1 - 1) / CS_ROWS1)), dim3(256), lds, (hipStream_t)stream, a);
@@ -489,6 +402,11 @@ int64_t jf_cond_gf_packed_bytes(int32_t D, int32_t n_layers, const jf_gf_layer* 
     for (int l = 0; l < n_layers; ++l)
         if (!jf::cs_layer_supported(layers[l], D)) return JF_ERR_UNSUPPORTED;
     return (int64_t)n_layers * jf::CS_CPL * jf::CS_CHUNK_BYTES;
+}
+int jf_cond_gf_split_row_groups(int32_t rg) {
+    const int prev = jf::cs_forced_rg;
+    if (rg >= 0 && rg <= 2) jf::cs_forced_rg = rg;
+    return prev;
 }
 int jf_cond_gf_pack_f32(const float* W2, int64_t w2s, const float* b2, int32_t H, int32_t D, int32_t n, const jf_gf_layer* L, void* packed, void* s) {
     return jf::cs_pack(W2, w2s, b2, H, D, n, L, packed, s);

@@ -1,0 +1,100 @@
+// Pieces shared by the fused conditional-block kernels that keep the parameter block in MFMA result registers
+// (cond_split_kernels.hip: 16x16x32 tiles, lane = (row, coordinate); cond_pp_kernels.hip: 32x32x16 tiles, lane = (row, coordinate pair)):
+// the parameter-slot numbering of one coordinate, the exact 3-way bf16 split, and the logistic mixture evaluated on a register row.
+#pragma once
+#include "jf_gf.h"
+
+namespace jf {
+
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+typedef __attribute__((address_space(3))) void* cs_lptr;
+typedef const __attribute__((address_space(1))) void* cs_gptr;
+
+constexpr int CS_K = 10;                           // mixture components (parameter registers are indexed statically)
+constexpr int CS_HH = 4;                           // Householder slots
+constexpr int CS_SLOTS = 36;                       // parameter slots of one coordinate and layer (35 used)
+constexpr int CS_SLOT_MEAN = 0, CS_SLOT_LW = CS_K, CS_SLOT_LN = 2 * CS_K, CS_SLOT_ROT = 3 * CS_K, CS_SLOT_OFF = 3 * CS_K + CS_HH;
+struct CsLayer { int hh, model_offset, inv_type; float wmin, inv_wmax, nmin, nmax; };
+
+struct CsPackLayer { int col0, off_rot, off_mean, off_lw, off_ln, hh, model_offset; };
+// original column (inside the layer's row) of parameter slot `slot` for coordinate d, or -1
+__device__ __forceinline__ int cs_slot_column(const CsPackLayer& o, int D, int slot, int d) {
+    if (d >= D) return -1;
+    if (slot < CS_SLOT_LW) return o.off_mean + slot * D + d;
+    if (slot < CS_SLOT_LN) return o.off_lw + (slot - CS_SLOT_LW) * D + d;
+    if (slot < CS_SLOT_ROT) return o.off_ln + (slot - CS_SLOT_LN) * D + d;
+    if (slot < CS_SLOT_OFF) return (slot - CS_SLOT_ROT) < o.hh ? o.off_rot + (slot - CS_SLOT_ROT) * D + d : -1;
+    if (slot == CS_SLOT_OFF) return o.model_offset ? d : -1;
+    return -1;
+}
+
+__device__ __forceinline__ void cs_split(float v, __bf16& hi, __bf16& mid, __bf16& lo) {
+    hi = (__bf16)v;
+    const float r1 = v - (float)hi;                // exact
+    mid = (__bf16)r1;
+    lo = (__bf16)(r1 - (float)mid);                // exact difference, rounded once
+}
+
+// ---------------------------------------------------------------------------------------------------------- mixture on register rows
+// gfg_mixture_impl<float, RAW, FAST> / gfg_mixture_scaled (jf_gf.h) with the lane's parameters in registers P[slot].
+// The regulated 1/width and weight of every component and its u_k = (x - mu_k)/w_k are computed ONCE (2 exp + 2 rcp per component); the
+// distance m = min_k |u_k| to the nearest component then decides -- per wave -- which ONE of the two summations runs (1 exp + 1 rcp per
+// component each): the plain linear-space sums, or the sums scaled by e^{m} when some lane sits further than CS_M_SCALED widths from every
+// component (below that the plain sums cannot underflow: cdf, sf >= pi_min sigma(-m) >= 1e-2 e^{-60}, pdf >= that / (2 w_max)).
+// The first version ran the plain pass always and the scaled pass on top of it whenever a lane underflowed, regulating the parameters again
+// in each (7 exp + 7 rcp per component on the benchmark inputs, two thirds of whose rows sit beyond 12 sigma after three layers).
+constexpr float CS_M_SCALED = 60.0f;
+
+__device__ __forceinline__ MixQ<float> cs_mixture(const float (&P)[CS_SLOTS], const CsLayer& o, float x, bool live) {
+    using Mf = M<float>;
+    float iw[CS_K], wk[CS_K], u[CS_K];
+    float m = INFINITY, Nn = 0.f;
+#pragma unroll
+    for (int k = 0; k < CS_K; ++k) {
+        const float ae = o.inv_wmax + Mf::exp_fast(-P[CS_SLOT_LW + k]);
+        iw[k] = ae * Mf::rcp(o.wmin * ae + 1.0f);
+        wk[k] = o.nmin + o.nmax * Mf::rcp(1.0f + Mf::exp_fast(-P[CS_SLOT_LN + k]));
+        u[k] = (x - P[CS_SLOT_MEAN + k]) * iw[k];
+        m = fminf(m, fabsf(u[k]));
+        Nn += wk[k];
+    }
+    const float inv = Mf::rcp(Nn);
+    MixQ<float> q;
+    if (!__any(live && m > CS_M_SCALED)) {                         // wave-uniform branch
+        float C = 0.f, S = 0.f, Pd = 0.f;
+#pragma unroll
+        for (int k = 0; k < CS_K; ++k) {
+            const float t = Mf::exp_fast(-fabsf(u[k]));
+            const float hi = Mf::rcp(1.0f + t);
+            const float lo = t * hi;
+            const bool pos = u[k] >= 0.f;
+            C += wk[k] * (pos ? hi : lo);
+            S += wk[k] * (pos ? lo : hi);
+            Pd += wk[k] * hi * lo * iw[k];
+        }
+        C *= inv; S *= inv; Pd *= inv;
+        q.lc = Mf::log_fast(C); q.ls = Mf::log_fast(S); q.lp = Mf::log_fast(Pd);
+        q.cdf = C; q.sf = S;
+        return q;
+    }
+    const float em = Mf::exp_fast(-m);                             // may underflow to 0: the unscaled parts then stand alone
+    float Cu = 0.f, Cs = 0.f, Su = 0.f, Ss = 0.f, Ps = 0.f;
+#pragma unroll
+    for (int k = 0; k < CS_K; ++k) {
+        const float t = Mf::exp_fast(m - fabsf(u[k]));
+        const float hi = Mf::rcp(1.0f + t * em);
+        const float c1 = wk[k] * hi, c2 = c1 * t;
+        if (u[k] >= 0.f) { Cu += c1; Ss += c2; }
+        else { Su += c1; Cs += c2; }
+        Ps += c2 * hi * iw[k];
+    }
+    Cu *= inv; Cs *= inv; Su *= inv; Ss *= inv; Ps *= inv;
+    q.cdf = Cu + em * Cs;
+    q.sf = Su + em * Ss;
+    q.lc = Cu > 0.f ? Mf::log_fast(q.cdf) : Mf::log_fast(Cs) - m;
+    q.ls = Su > 0.f ? Mf::log_fast(q.sf) : Mf::log_fast(Ss) - m;
+    q.lp = Mf::log_fast(Ps) - m;
+    return q;
+}
+
+}  // namespace jf

@@ -9,6 +9,7 @@ layer, MFMA launches for the amortisation MLPs) instead of thousands of eager op
 Reference line numbers cited below refer to jammy_flows/main/default.py.
 """
 import copy
+import os
 
 import numpy
 import torch
@@ -171,7 +172,15 @@ class pdf(nn.Module):
         # matrix arithmetic of the fused block's 128 -> P product: "split_bf16" (three bf16 pieces per f32 operand, six MFMA passes with f32
         # accumulation: products exact, result within ~3 * 2^-24 relative of the f32 dot product; parameters stay in registers) or "f32"
         # (exact f32-input MFMA, parameter tile in LDS).  Layer options outside the split kernel's set fall back to "f32" by themselves.
-        self.fused_matrix_arithmetic = "split_bf16"
+        # JF_FUSED_MATRIX_ARITHMETIC=f32 in the environment selects the exact-f32 kernel process-wide (an operational fallback while the
+        # full-batch hazard of DESIGN.md 3.9 has a remedy but no root cause).
+        self.fused_matrix_arithmetic = os.environ.get("JF_FUSED_MATRIX_ARITHMETIC", "split_bf16")
+        # which kernel runs the split-bf16 fused block: "auto" (by batch size), "pp" (cond_pp_kernels.hip) or "split" (cond_split_kernels.hip)
+        self.fused_block_kernel = os.environ.get("JF_FUSED_BLOCK_KERNEL", "auto")
+        if self.fused_block_kernel not in ("auto", "pp", "split"):
+            raise ValueError("JF_FUSED_BLOCK_KERNEL must be 'auto', 'pp' or 'split', got %r" % self.fused_block_kernel)
+        if self.fused_matrix_arithmetic not in ("split_bf16", "f32"):
+            raise ValueError("JF_FUSED_MATRIX_ARITHMETIC must be 'split_bf16' or 'f32', got %r" % self.fused_matrix_arithmetic)
         self._packed_cache = {}
 
         self._read_model_definition(pdf_defs, flow_defs, options_overwrite, conditional_input_dim, amortization_mlp_dims,
@@ -547,17 +556,32 @@ class pdf(nn.Module):
                 return None
         return mlp.lowrank_views(mlp._flat(like))
 
-    def _packed_w2(self, si, w2, b2, layer_array, n_layers, D):
-        """packed split-bf16 image of the block's output layer, rebuilt when the weights change (tensor identity + in-place version)."""
-        key = (w2.data_ptr(), w2._version, b2.data_ptr(), b2._version, str(w2.device))
-        hit = self._packed_cache.get(si)
+    def _fused_kernel_kind(self, n_rows):
+        """which register-resident fused block kernel: "pp" (persistent ping-pong workgroups, cond_pp_kernels.hip) from
+        or "split" (cond_split_kernels.hip, the default "auto" choice at every batch size while the two measure the same);
+        pdf.fused_block_kernel = "pp" / "split" (or JF_FUSED_BLOCK_KERNEL) forces one."""
+        if self.fused_block_kernel in ("pp", "split"):
+            return self.fused_block_kernel
+        # measured at 2^20 rows (profiles/r03_pp_*.md): pp 0.77 ms, split 0.775 ms -- no gain yet, and pp needs >= 256 row tiles to fill the chip
+        return "split"
+
+    def _packed_w2(self, si, w2, b2, layer_array, n_layers, D, n_rows):
+        """(kind, packed split-bf16 image) of the block's output layer for the fused kernel chosen for this batch size, or None when the layer
+        options are outside the kernels' set.  Rebuilt when the weights change: the key is the identity and in-place version of the MODULE's
+        parameters (w2 / b2 may be casts of them made for this call -- fresh temporaries whose own version is always 0 and whose addresses
+        the caching allocator hands out again), plus dtype, device and kernel kind."""
+        kind = self._fused_kernel_kind(n_rows)
+        lin = self.mlp_predictors[si][2]
+        key = (id(lin.weight), lin.weight._version, lin.weight.data_ptr(), id(lin.bias), lin.bias._version, lin.bias.data_ptr(), str(w2.dtype),
+               str(w2.device), kind)
+        hit = self._packed_cache.get((si, kind))
         if hit is not None and hit[0] == key:
             return hit[1]
-        if _hip.cond_gf_packed_bytes(layer_array, n_layers, D) < 0:
-            packed = None                                                    # layer options outside the split kernel's set
+        if _hip.cond_gf_packed_bytes(layer_array, n_layers, D, kind) < 0:
+            packed = None                                                    # layer options outside the kernel's set
         else:
-            packed = _hip.cond_gf_pack(w2, b2, layer_array, n_layers, D)
-        self._packed_cache[si] = (key, packed)
+            packed = (kind, _hip.cond_gf_pack(w2, b2, layer_array, n_layers, D, kind))
+        self._packed_cache[(si, kind)] = (key, packed)
         return packed
 
     def _block_params(self, si, data_summary, embeds, amort, counter):
@@ -682,11 +706,11 @@ class pdf(nn.Module):
                 larr = _hip.gf_layer_array([l.c_struct() for l in layers])
                 packed = None
                 if self.fused_matrix_arithmetic == "split_bf16" and fused[0].shape[0] <= 128:
-                    packed = self._packed_w2(si, fused[2], fused[3], larr, len(layers), layers[0].dimension)
+                    packed = self._packed_w2(si, fused[2], fused[3], larr, len(layers), layers[0].dimension, x.shape[0])
                 if packed is not None:
-                    res = _hip.cond_gf_chain_inv_split(self._mlp_input(si, data_summary, embeds), fused[0], fused[1], packed, tgt, log_det, larr,
+                    res = _hip.cond_gf_chain_inv_split(self._mlp_input(si, data_summary, embeds), fused[0], fused[1], packed[1], tgt, log_det, larr,
                                                        len(layers), layers[0].dimension, x_out=out_view, base_logp_in=base_logp,
-                                                       want_base_logp=want_base_logp, status=status)
+                                                       want_base_logp=want_base_logp, status=status, kind=packed[0])
                 else:
                     res = _hip.cond_gf_chain_inv(self._mlp_input(si, data_summary, embeds), *fused, tgt, log_det, larr, len(layers),
                                                  layers[0].dimension, x_out=out_view, base_logp_in=base_logp, want_base_logp=want_base_logp,
@@ -898,7 +922,7 @@ class pdf(nn.Module):
                     w1, b1, w2, b2 = mlp[0].weight, mlp[0].bias, mlp[2].weight, mlp[2].bias
                     packed = None
                     if self.fused_matrix_arithmetic == "split_bf16" and w1.shape[0] <= 128:
-                        packed = self._packed_w2(si, w2.detach(), b2.detach(), larr, len(layers), D)
+                        packed = self._packed_w2(si, w2.detach(), b2.detach(), larr, len(layers), D, x.shape[0])
                     out, log_det, base_logp = autograd.CondBlockFn.apply(inp, w1, b1, w2, b2, tgt, log_det, base_logp, packed, larr, len(layers), D,
                                                                          status)
                 else:

@@ -368,9 +368,11 @@ def test_fused_conditional_block_vs_golden_and_two_launch_path(name):
     ok = float32_domain_mask(fx)
     pdf.check_status = bool(ok.all())
     out = {}
-    for mode, kernel in (("two", "jf_gf_chain_inv_f32"), ("f32", "jf_cond_gf_chain_inv_f32"), ("split_bf16", "jf_cond_gf_chain_inv_split_f32")):
+    for mode, kernel in (("two", "jf_gf_chain_inv_f32"), ("f32", "jf_cond_gf_chain_inv_f32"), ("split_bf16", "jf_cond_gf_chain_inv_split_f32"),
+                         ("pp", "jf_cond_gf_chain_inv_pp_f32")):
         pdf.fuse_conditional_blocks = mode != "two"
-        pdf.fused_matrix_arithmetic = mode
+        pdf.fused_matrix_arithmetic = "split_bf16" if mode == "pp" else mode
+        pdf.fused_block_kernel = "pp" if mode == "pp" else "auto"          # auto: the split kernel at a fixture's batch size
         timer = _hip.KernelTimer()
         with timer:
             out[mode] = pdf(x, conditional_input=cond, force_embedding_coordinates=emb)
@@ -380,7 +382,7 @@ def test_fused_conditional_block_vs_golden_and_two_launch_path(name):
             assert "jf_cond_gf_chain_inv_split_f32" not in ran
         assert_float32_parity(out[mode][0].double().cpu().numpy(), fx["logp"], ok, "%s [%s]" % (name, mode))
     sel = torch.from_numpy(ok).cuda()
-    for mode in ("f32", "split_bf16"):
+    for mode in ("f32", "split_bf16", "pp"):
         # per row the same flow arithmetic; the parameters differ by the summation order / the 3 * 2^-24 split residue of the 128-term products
         scale = 1.0 + out["two"][0][sel].abs()
         assert float(((out[mode][0][sel] - out["two"][0][sel]).abs() / scale).max()) < 2e-5, mode
@@ -486,6 +488,42 @@ def test_fused_block_two_row_groups_per_wave(name):
     assert float((np.abs(runs[0] - ref)[fin] / (1.0 + np.abs(ref[fin]))).max()) < 2e-6
     ok = float32_domain_mask(fx)
     assert_float32_parity(runs[0][n:2 * n].astype(np.float64), fx["logp"], ok, "%s [two row groups]" % name)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rg", [1, 2, "pp"])
+def test_fused_block_stress_20_launches_at_full_size(rg):
+    """DESIGN.md 3.9 (not root-caused; remedy = no packed f32): the runtime guard.  20 launches of the C3 step at 2^20 rows for EACH row-group
+    variant of the split-bf16 block kernel must be bit-identical over all rows (compared on the device), and every replica of the tiled
+    fixture must carry the small-batch values."""
+    from jammy_flows_amd import _hip
+    fx = [f for f in ALL_FIXTURES if f.name == "c3_e4s2e4"][0]
+    pdf = build_product(fx, torch.float32)
+    pdf.check_status = False
+    n = fx["x"].shape[0]
+    reps = (1 << 20) // n + 1
+    x = to_dev(np.tile(fx["x"], (reps, 1)), torch.float32)
+    pdf.fused_block_kernel = "pp" if rg == "pp" else "split"           # "pp": the persistent ping-pong kernel (cond_pp_kernels.hip)
+    prev = _hip.lib().jf_cond_gf_split_row_groups(0 if rg == "pp" else rg)
+    try:
+        timer = _hip.KernelTimer()
+        with torch.no_grad():
+            with timer:
+                first = pdf(x)[0]
+            assert any(k[0] == ("jf_cond_gf_chain_inv_pp_f32" if rg == "pp" else "jf_cond_gf_chain_inv_split_f32") for k in timer.summary())
+            small = pdf(x[:n])[0]
+            differing = 0
+            for _ in range(19):
+                again = pdf(x)[0]
+                differing += int((~((again == first) | (again.isnan() & first.isnan()))).sum())
+        assert differing == 0, "row groups per wave = %s: %d rows differed between launches" % (rg, differing)
+        got = first.reshape(reps, n)
+        fin = torch.isfinite(small)
+        assert bool((torch.isfinite(got) == fin).all())
+        err = ((got - small).abs() / (1.0 + small.abs()))[:, fin].max().item()
+        assert err < 2e-6, "row groups per wave = %s: replicas deviate from the small batch by %.3g" % (rg, err)
+    finally:
+        _hip.lib().jf_cond_gf_split_row_groups(prev)
 
 
 FUSED_MANIFOLD = ["c4_i1s1_ro", "r_i1_m1p1_rr_cond", "r_i1_smooth2", "o_s1_cond_oo", "o_s1_nosmooth", "m_s1_cond", "m_s1_nat1_rot",

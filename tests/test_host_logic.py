@@ -214,3 +214,56 @@ def test_cpu_quota_parsing(tmp_path, monkeypatch):
         return real_open(path, *a, **k)
     monkeypatch.setattr(builtins, "open", fake)
     assert bench.cpu_quota() == 16.0
+
+
+def _device_code_objects(lib_path):
+    """the gfx950 code objects inside a HIP shared library: .hip_fatbin holds one uncompressed clang offload bundle per translation unit
+    (magic, u64 entry count, then per entry u64 offset / u64 size / u64 triple length / triple)"""
+    import struct
+    import subprocess
+    import tempfile
+    objcopy = "/opt/rocm/lib/llvm/bin/llvm-objcopy"
+    with tempfile.TemporaryDirectory() as tmp:
+        fat = os.path.join(tmp, "fat.bin")
+        subprocess.check_call([objcopy, "-O", "binary", "--only-section=.hip_fatbin", lib_path, fat])
+        data = open(fat, "rb").read()
+    magic = b"__CLANG_OFFLOAD_BUNDLE__"
+    out = []
+    pos = data.find(magic)
+    while pos >= 0:
+        n, = struct.unpack_from("<Q", data, pos + len(magic))
+        q = pos + len(magic) + 8
+        for _ in range(n):
+            off, size, tl = struct.unpack_from("<QQQ", data, q)
+            triple = data[q + 24:q + 24 + tl].decode()
+            q += 24 + tl
+            if "gfx950" in triple and size:
+                out.append(data[pos + off:pos + off + size])
+        pos = data.find(magic, pos + len(magic))
+    return out
+
+
+def test_shipped_library_has_no_packed_f32_instructions(tmp_path):
+    """with v_pk_{fma,mul,add}_f32 in the instruction stream the fused conditional block produced rare wrong log-dets of whole
+    16-row groups.  The remedy is a build flag clang calls "not a recognized feature", so the SHIPPED libjammy_hip.so itself is disassembled:
+    every gfx950 code object in it must be free of packed-f32 arithmetic (a toolchain update that drops the flag fails here, on the CPU box)."""
+    import re
+    import subprocess
+    lib = os.path.join(ROOT, "jammy_flows_amd", "libjammy_hip.so")
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not (os.path.exists(lib) and os.path.exists(objdump)):
+        pytest.skip("library or llvm-objdump not available")
+    cos = _device_code_objects(lib)
+    n_src = len([f for f in os.listdir(os.path.join(ROOT, "jammy_flows_amd", "csrc")) if f.endswith(".hip")])
+    assert len(cos) == n_src, "expected one gfx950 code object per .hip translation unit (%d), found %d" % (n_src, len(cos))
+    pat = re.compile(rb"\bv_pk_(?:fma|mul|add)_f32\b")
+    mfma = 0
+    for i, co in enumerate(cos):
+        p = tmp_path / ("dev%d.co" % i)
+        p.write_bytes(co)
+        asm = subprocess.run([objdump, "-d", "--mcpu=gfx950", str(p)], stdout=subprocess.PIPE, check=True).stdout
+        assert len(asm) > 1000
+        hits = pat.findall(asm)
+        assert not hits, "code object %d of libjammy_hip.so contains %d packed-f32 instructions" % (i, len(hits))
+        mfma += len(re.findall(rb"\bv_mfma_f32_16x16x32_bf16\b", asm))
+    assert mfma > 0, "the disassembly did not see the fused block's bf16 MFMAs: wrong code objects?"
