@@ -65,7 +65,9 @@ class fully_amortized_pdf(nn.Module):
                force_intrinsic_coordinates=False):
         """(x, base, log_prob, log_prob_base) (:173-213)"""
         assert conditional_input is not None, "This is by design a conditional PDF .. we require conditional input!"
-        with torch.no_grad():
+        # the hyper-network runs WITH a graph when gradients are asked for (:173-215: reparameterised training of a fully amortised pdf
+        # back-propagates from the samples into amortization_mlp), without one otherwise
+        with torch.set_grad_enabled(bool(allow_gradients) and torch.is_grad_enabled()):
             all_flow_params = self.amortization_mlp(conditional_input)
         return self.pdf_to_amortize.sample(amortization_parameters=all_flow_params, seed=seed, allow_gradients=allow_gradients,
                                            force_embedding_coordinates=force_embedding_coordinates,

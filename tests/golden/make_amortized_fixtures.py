@@ -65,6 +65,27 @@ def make(case):
     with contextlib.redirect_stdout(io.StringIO()):
         loss = -pdf(xg, conditional_input=cg)[0].mean()
     loss.backward()
+    # gradients THROUGH SAMPLING into the hyper-network (fully_amortized.py:173-215 with allow_gradients): injected base points z, the
+    # reference differentiates through its Newton iterations; loss = mean <w, x> + 0.1 mean log p
+    for p_ in pdf.parameters():
+        p_.grad = None
+    cs = cond.clone().requires_grad_(True)
+    with contextlib.redirect_stdout(io.StringIO()):
+        amort_g = pdf.amortization_mlp(cs)
+        gx, _, glogp, _ = pdf.pdf_to_amortize._obtain_sample(predefined_target_input=z.clone(), amortization_parameters=amort_g)
+    sw = torch.linspace(0.5, 1.5, gx.shape[1], dtype=torch.float64)
+    sloss = (gx * sw).sum(dim=1).mean() + 0.1 * glogp.mean()
+    sloss.backward()
+    sample_grads = {"sg/" + k: p_.grad.detach().numpy().copy() for k, p_ in pdf.named_parameters()}
+    sample_grads["sg_cond"] = cs.grad.numpy().copy()
+    sample_grads["sg_loss"] = numpy.array(sloss.item())
+    for p_ in pdf.parameters():
+        p_.grad = None
+    xg = x.clone().requires_grad_(True)
+    cg = cond.clone().requires_grad_(True)
+    with contextlib.redirect_stdout(io.StringIO()):
+        loss = -pdf(xg, conditional_input=cg)[0].mean()
+    loss.backward()
     out = {"meta": numpy.array(json.dumps(dict(name=case["name"], pdf_defs=case["pdf"], flow_defs=case["flow"], kwargs=case["kwargs"],
                                                total_number_amortizable_params=int(pdf.pdf_to_amortize.total_number_amortizable_params),
                                                count_parameters=int(pdf.count_parameters())))),
@@ -75,6 +96,7 @@ def make(case):
         out["sd/" + k] = v.detach().numpy()
     for k, p in pdf.named_parameters():
         out["pg/" + k] = p.grad.detach().numpy()
+    out.update(sample_grads)
     path = os.path.join(HERE, "amortized", case["name"] + ".npz")
     numpy.savez_compressed(path, **out)
     print("%-18s T=%d hyper-net params=%d logp[min,max]=(%.3f, %.3f) loss=%.5f bytes=%d" % (

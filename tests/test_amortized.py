@@ -132,3 +132,41 @@ def test_gpu_permanent_amortizable_mlp_highway_modes_vs_oracle(mode):
     c3[:, 1] -= eps
     fd = (pdf(x.cuda(), conditional_input=c2.cuda())[0] - pdf(x.cuda(), conditional_input=c3.cuda())[0]) / (2 * eps)
     assert float(((cg.grad[:, 1] - fd).abs() / (1 + fd.abs())).max()) < 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", NAMES)
+def test_gpu_gradients_through_sampling_reach_the_hyper_network(name):
+    """reparameterised training of a fully amortised pdf (fully_amortized.py:173-215): gradients of a loss on the SAMPLES with respect to the
+    hyper-network's weights and the conditional input, against the reference's autograd through its own sampling (injected base points)"""
+    g = load(name)
+    pdf = build(g, torch.float64, "cuda")
+    z = torch.from_numpy(g["z"]).cuda()
+    cs = torch.from_numpy(g["cond"]).cuda().requires_grad_(True)
+    with torch.enable_grad():
+        amort = pdf.amortization_mlp(cs)
+        x, _, logp, _ = pdf.pdf_to_amortize._differentiable_sample(predefined_target_input=z, amortization_parameters=amort)
+        w = torch.linspace(0.5, 1.5, x.shape[1], dtype=torch.float64, device="cuda")
+        loss = (x * w).sum(dim=1).mean() + 0.1 * logp.mean()
+    loss.backward()
+    assert abs(loss.item() - float(g["sg_loss"])) < 1e-7 * max(1.0, abs(float(g["sg_loss"])))
+
+    def rel(a, b):
+        return float(np.abs(a.detach().cpu().numpy().reshape(b.shape) - b).max()) / max(float(np.abs(b).max()), 1e-9)
+    worst = {"cond": rel(cs.grad, g["sg_cond"])}
+    for k, p in pdf.named_parameters():
+        worst[k] = rel(p.grad, g["sg/" + k])
+    assert max(worst.values()) < 1e-5, worst
+    # the public entry point: sample(allow_gradients=True) must connect the samples to amortization_mlp (ADVICE r2: it ran the
+    # hyper-network under no_grad and handed back samples without a path to it)
+    for p in pdf.parameters():
+        p.grad = None
+    with torch.enable_grad():
+        xs, _, lp, _ = pdf.sample(conditional_input=torch.from_numpy(g["cond"]).cuda(), seed=5, allow_gradients=True)
+        assert xs.requires_grad and lp.requires_grad
+        (xs.sum() + lp.sum()).backward()
+    grads = [p.grad for p in pdf.parameters()]
+    assert all(gr is not None for gr in grads) and max(float(gr.abs().max()) for gr in grads) > 0
+    with torch.no_grad():
+        xn = pdf.sample(conditional_input=torch.from_numpy(g["cond"]).cuda(), seed=5)[0]
+    assert not xn.requires_grad and float((xn - xs.detach()).abs().max()) < 1e-9
