@@ -72,13 +72,21 @@ typedef struct jf_gf_layer {
     double norm_min, norm_max;
 } jf_gf_layer;
 /* Layers with rotation_mode != HOUSEHOLDER, center_mean or add_skewness run in the general-option kernel of jf_gf_chain_inv / _fwd
- * (one lane per row); the fused block entry points and jf_gf_chain_inv_bwd return JF_ERR_UNSUPPORTED for them. */
+ * (one lane per row, D <= 8); the fused block entry points and jf_gf_chain_inv_bwd return JF_ERR_UNSUPPORTED for them.  D <= 32 for layers at the
+ * other options (groups of up to 32 lanes per row). */
 
 /* log-prob direction of a chain of `n_layers` g layers applied in REVERSE order (layer n-1 first), all in one launch.
  * params row = the layers' rows concatenated in layer order 0..n-1.  log_det_in / base_logp_in may be NULL (= 0);
  * base_logp_out (nullable) receives base_logp_in + sum_d N(0,1).log_prob(x_out_d)  (main/default.py:1110-1115).
  * bins (nullable, row stride bins_stride): raw searchsorted result of every rq_splines layer in execution order, D columns per such
  * layer (spline_fns.py:13-19, 252-258) -- the integer output the bit-exact parity tests compare. */
+/* LDS bytes one launch of this chain needs in the log-prob / sampling direction (jf_gf_chain_lds_bytes_*) and in the backward direction
+ * (jf_gf_chain_inv_bwd_lds_bytes_*), or a negative JF_ERR_* (JF_ERR_UNSUPPORTED: more than the 160 KB of a CU).  param_batch_is_one: the
+ * broadcast regime.  The host cuts chains of wide layers (D up to 32: groups of 16 / 32 lanes per row) into launches that fit. */
+int64_t jf_gf_chain_lds_bytes_f32(int32_t D, int32_t n_layers, const jf_gf_layer* layers, int32_t param_batch_is_one);
+int64_t jf_gf_chain_lds_bytes_f64(int32_t D, int32_t n_layers, const jf_gf_layer* layers, int32_t param_batch_is_one);
+int64_t jf_gf_chain_inv_bwd_lds_bytes_f32(int32_t D, int32_t n_layers, const jf_gf_layer* layers, int32_t param_batch_is_one);
+int64_t jf_gf_chain_inv_bwd_lds_bytes_f64(int32_t D, int32_t n_layers, const jf_gf_layer* layers, int32_t param_batch_is_one);
 int jf_gf_chain_inv_f32(const float* x, int64_t x_stride, const float* log_det_in, const float* params, int64_t param_stride,
                         int32_t param_batch, int64_t B, int32_t D, int32_t n_layers, const jf_gf_layer* layers, float* x_out,
                         int64_t x_out_stride, float* log_det_out, const float* base_logp_in, float* base_logp_out,

@@ -134,6 +134,10 @@ _SIGNATURES = {
 }
 # entry points that exist for one precision only: full symbol name -> (argtypes, restype)
 _SIGNATURES_SINGLE = {
+    "jf_gf_chain_lds_bytes_f32": ([_I32, _I32, ctypes.POINTER(jf_gf_layer), _I32], ctypes.c_int64),
+    "jf_gf_chain_lds_bytes_f64": ([_I32, _I32, ctypes.POINTER(jf_gf_layer), _I32], ctypes.c_int64),
+    "jf_gf_chain_inv_bwd_lds_bytes_f32": ([_I32, _I32, ctypes.POINTER(jf_gf_layer), _I32], ctypes.c_int64),
+    "jf_gf_chain_inv_bwd_lds_bytes_f64": ([_I32, _I32, ctypes.POINTER(jf_gf_layer), _I32], ctypes.c_int64),
     "jf_linear_wgrad_splits_f32": ([_I64, _I32, _I32], ctypes.c_int64),
     "jf_linear_wgrad_splits_f64": ([_I64, _I32, _I32], ctypes.c_int64),
     "jf_gf_chain_inv_bwd_partials": ([_I64, _I32], ctypes.c_int64),
@@ -308,6 +312,8 @@ def _rowmajor(t):
         t = t.contiguous()
     if t.shape[1] == 1 and t.stride(0) < 1:
         t = t.contiguous()
+    if t.shape[0] > 1 and t.stride(0) == 0:      # expanded rows (stride 0): kernels that derive row counts from the stride divide by it
+        t = t.contiguous()
     return t
 
 
@@ -401,6 +407,16 @@ def gf_chain_inv_bwd(x, params, layer_array, n_layers, D, g_xout, g_ld, g_blp, s
 
 
 COND_GF_MAX_IN, COND_GF_MAX_HIDDEN = 28, 128
+GF_MAX_DIM = 32              # 'g' / 't' layers: coordinates per row (groups of up to 32 lanes; fused blocks: 8)
+LDS_BYTES_PER_CU = 160 * 1024
+
+
+def gf_chain_fits(layer_array, n_layers, D, dtype, bcast, backward=False):
+    """does ONE launch of this chain fit the LDS of a CU (log-prob / sampling direction, or its backward)?"""
+    suf = "_f32" if dtype == torch.float32 else "_f64"
+    fn = getattr(lib(), ("jf_gf_chain_inv_bwd_lds_bytes" if backward else "jf_gf_chain_lds_bytes") + suf)
+    n = int(fn(D, n_layers, layer_array, 1 if bcast else 0))
+    return 0 <= n <= LDS_BYTES_PER_CU
 
 
 def cond_gf_chain_inv(inp, w1, b1, w2, b2, x, log_det, layer_array, n_layers, D, x_out=None, base_logp_in=None, want_base_logp=False, status=None):

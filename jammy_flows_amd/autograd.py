@@ -158,6 +158,72 @@ def embed(tgt, kind, layer):
     return torch.cat([st * torch.cos(ph), st * torch.sin(ph), torch.cos(th)], dim=1)
 
 
+class SphereEmbeddingFn(torch.autograd.Function):
+    """S1 / S2 chart change angles <-> embedding coordinates (sphere_base.py:242-335) with its log-det term: forward = the kernel of the
+    inference path (jf_sphere_to/from_embedding), backward = the closed-form Jacobian applied to the incoming gradients.  What training in
+    embedding coordinates (pdf(x_xyz, force_embedding_coordinates=True)) back-propagates through ahead of the block loop."""
+
+    @staticmethod
+    def forward(ctx, x, log_det, dim, to_embedding):
+        out, ld = _hip.sphere_embedding(x.detach(), None if log_det is None else log_det.detach(), dim, to_embedding)
+        ctx.meta = (dim, to_embedding, log_det is not None)
+        ctx.save_for_backward(x.detach(), out)
+        ctx.set_materialize_grads(False)
+        if dim != 2 and log_det is None:
+            ld = None
+        return out, ld
+
+    @staticmethod
+    def backward(ctx, g_out, g_ld):
+        dim, to_embedding, has_ld = ctx.meta
+        x, out = ctx.saved_tensors
+        g_x = None
+        if dim == 1:
+            if to_embedding:                     # phi -> (cos phi, sin phi)
+                if g_out is not None:
+                    g_x = (-g_out[:, 0:1] * out[:, 1:2] + g_out[:, 1:2] * out[:, 0:1])
+            elif g_out is not None:              # (x, y) -> phi: d phi = (x dy - y dx) / rho^2
+                rho2 = (x * x).sum(dim=1, keepdim=True)
+                g_x = g_out * torch.cat([-x[:, 1:2], x[:, 0:1]], dim=1) / rho2
+        else:
+            if to_embedding:                     # (theta, phi) -> (sin t cos p, sin t sin p, cos t), log_det += log sin t
+                st, ct = torch.sin(x[:, 0:1]), torch.cos(x[:, 0:1])
+                sp, cp = torch.sin(x[:, 1:2]), torch.cos(x[:, 1:2])
+                g_t = torch.zeros_like(st)
+                g_p = torch.zeros_like(st)
+                if g_out is not None:
+                    g_t = g_out[:, 0:1] * ct * cp + g_out[:, 1:2] * ct * sp - g_out[:, 2:3] * st
+                    g_p = -g_out[:, 0:1] * st * sp + g_out[:, 1:2] * st * cp
+                if g_ld is not None:
+                    g_t = g_t + g_ld.unsqueeze(1) * ct / st
+                g_x = torch.cat([g_t, g_p], dim=1)
+            else:                                # (x, y, z) -> theta = acos(z / r), phi; log_det -= log sin theta
+                rho2 = (x[:, 0:2] ** 2).sum(dim=1, keepdim=True)
+                r2 = rho2 + x[:, 2:3] ** 2
+                rho = rho2.sqrt()
+                g_t = torch.zeros_like(rho) if g_out is None else g_out[:, 0:1]
+                if g_ld is not None:
+                    g_t = g_t - g_ld.unsqueeze(1) * x[:, 2:3] / rho          # d(-log sin theta)/d theta = -cot theta = -z / rho
+                dt = torch.cat([x[:, 0:1] * x[:, 2:3] / (r2 * rho), x[:, 1:2] * x[:, 2:3] / (r2 * rho), -rho / r2], dim=1)
+                g_x = g_t * dt
+                if g_out is not None:
+                    g_x = g_x + g_out[:, 1:2] * torch.cat([-x[:, 1:2] / rho2, x[:, 0:1] / rho2, torch.zeros_like(rho)], dim=1)
+        return g_x, (g_ld if has_ld else None), None, None
+
+
+def sphere_embedding(x, log_det, dim, to_embedding):
+    """chart change with a graph when one is needed, the plain launch otherwise; log_det: tensor, None or a python number (= offset)"""
+    ld_t = log_det if isinstance(log_det, torch.Tensor) else None
+    if torch.is_grad_enabled() and _needs_grad(x, ld_t):
+        out, ld = SphereEmbeddingFn.apply(x, ld_t, dim, to_embedding)
+        if dim != 2:
+            return out, log_det
+        if ld_t is None and log_det is not None and log_det != 0:
+            ld = ld + log_det
+        return out, ld
+    return _hip.sphere_embedding(x, log_det, dim, to_embedding)
+
+
 class MChainInvFn(torch.autograd.Function):
     """log-prob direction of a chain of manifold layers (jf_{r,o,m,f,v,c}_chain_inv) -> (x_out, log_det_out, base_logp_out).
     Backward: jf_*_chain_inv_jvp launches (forward-mode passes through the very same device code instantiated on dual numbers)."""

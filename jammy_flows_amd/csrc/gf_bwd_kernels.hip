@@ -26,7 +26,8 @@
 
 namespace jf {
 
-constexpr int GB_MAX_HH = 8;
+constexpr int GB_MAX_HH = 8;                // reflections kept in registers for groups of up to 8 lanes; wider groups keep G (gb_max_hh)
+template <int G> constexpr int gb_max_hh() { return G > GB_MAX_HH ? G : GB_MAX_HH; }
 constexpr int GB_NT = 512;                  // threads of a broadcast-regime workgroup: the derived rows / accumulators / records in LDS (~40 KB) are
                                             //   per workgroup, so wider workgroups mean more resident waves per CU (256: 2 per SIMD, 512: 4)
 
@@ -132,11 +133,11 @@ __device__ __forceinline__ T gf_layer_bwd(const T* __restrict__ p, GP* __restric
         }
     };
     // ---- recompute: offset, reflections (keeping the vector before each one), mixture
-    T xr[GB_MAX_HH];
+    T xr[gb_max_hh<G>()];
     T x = x_in;
     if (o.model_offset) x -= p[0];
 #pragma unroll
-    for (int i = 0; i < GB_MAX_HH; ++i) {
+    for (int i = 0; i < gb_max_hh<G>(); ++i) {
         xr[i] = x;
         if (i < o.hh) x = gfg_reflect<T, G, true>(p, o.off_rot + i * D, live, x);
     }
@@ -190,7 +191,7 @@ __device__ __forceinline__ T gf_layer_bwd(const T* __restrict__ p, GP* __restric
     // ---- reflections, last first:  y = x - c v, c = 2 (v.x)/(v.v):  g_x = H g,  g_v = -c g - (2 (v.g)/n) x + (4 (v.x)(v.g)/n^2) v
     T g = gx;
 #pragma unroll
-    for (int i = GB_MAX_HH - 1; i >= 0; --i) {
+    for (int i = gb_max_hh<G>() - 1; i >= 0; --i) {
         if (i < o.hh) {
             const T v = live ? p[o.off_rot + i * D] : T(0);
             const T n = group_sum<T, G>(v * v), sx = group_sum<T, G>(v * xr[i]), vg = group_sum<T, G>(v * (live ? g : T(0)));
@@ -217,7 +218,7 @@ template <> struct LinRange<double> { static constexpr double lo = 1e-280, hi = 
 template <typename T, int G, typename PUT>
 __device__ __forceinline__ T gf_reflections_bwd(const T* __restrict__ p, const GfLayerDev<T>& o, int D, bool live, const T* xr, T g, PUT put) {
 #pragma unroll
-    for (int i = GB_MAX_HH - 1; i >= 0; --i) {
+    for (int i = gb_max_hh<G>() - 1; i >= 0; --i) {
         if (i < o.hh) {
             const T v = live ? p[o.off_rot + i * D] : T(0);
             const T n = group_sum<T, G>(v * v), sx = group_sum<T, G>(v * xr[i]), vg = group_sum<T, G>(v * (live ? g : T(0)));
@@ -275,11 +276,11 @@ __device__ __forceinline__ T gf_layer_bwd_fast(const T* __restrict__ p, T* __res
                                                const MixSums<T>& m) {
     const bool ok = m.C > LinRange<T>::lo && m.S > LinRange<T>::lo && m.P > LinRange<T>::lo && m.P < LinRange<T>::hi;
     if (!__all(ok)) return gf_layer_bwd<T, G, false, T>(p, gp, o, D, live, x_in, gy, gl, 0);
-    T xr[GB_MAX_HH];
+    T xr[gb_max_hh<G>()];
     T x = x_in;
     if (o.model_offset) x -= p[0];
 #pragma unroll
-    for (int i = 0; i < GB_MAX_HH; ++i) {
+    for (int i = 0; i < gb_max_hh<G>(); ++i) {
         xr[i] = x;
         if (i < o.hh) x = gfg_reflect<T, G, true>(p, o.off_rot + i * D, live, x);
     }
@@ -364,11 +365,11 @@ __device__ __forceinline__ T gf_layer_bwd_bcast(const T* __restrict__ p, const T
     // Cs, Ss, Ps: the layer's linear-space sums from the forward sweep (Cs = 0: the wave needed the scaled evaluation there)
     const bool ok = Cs > LinRange<T>::lo && Ss > LinRange<T>::lo && Ps > LinRange<T>::lo && Ps < LinRange<T>::hi;
     if (!__all(ok)) return gf_layer_bwd<T, G, true, double>(p, gp, o, D, live, x_in, gy, gl, slsh);
-    T xr[GB_MAX_HH];
+    T xr[gb_max_hh<G>()];
     T x = x_in;
     if (o.model_offset) x -= p[0];
 #pragma unroll
-    for (int i = 0; i < GB_MAX_HH; ++i) {
+    for (int i = 0; i < gb_max_hh<G>(); ++i) {
         xr[i] = x;
         if (i < o.hh) x = gfg_reflect<T, G, false>(v, o.off_rot + i * D, live, x);
     }
@@ -439,7 +440,8 @@ __global__ void __launch_bounds__(BCAST ? GB_NT : 64) gf_chain_bwd_kernel(const 
     constexpr int NT = BCAST ? GB_NT : 64;
     constexpr int R = NT / G;
     const int tid = threadIdx.x;
-    constexpr int LG = G == 1 ? 0 : G == 2 ? 1 : G == 4 ? 2 : 3;
+    constexpr int LG = G == 1 ? 0 : G == 2 ? 1 : G == 4 ? 2 : G == 8 ? 3 : G == 16 ? 4 : 5;
+    constexpr int DM = G > 8 ? G : 8, LDM = G > 8 ? LG : 3;      // coordinate slots per layer of the normaliser table (aux)
     const int g = tid & (G - 1), r = tid >> LG;
     const int D = a.D;
     const bool live = g < D, leader = g == 0;
@@ -464,7 +466,7 @@ __global__ void __launch_bounds__(BCAST ? GB_NT : 64) gf_chain_bwd_kernel(const 
     double* acc = reinterpret_cast<double*>(ftile + nl * ts);    // float64 accumulators for both precisions, see below
     const int slsh = BCAST ? a.slsh : 0;
     T* xin = reinterpret_cast<T*>(acc + ((nl * ts) << slsh)) + tid;   // BCAST only
-    T* pk = xin - tid + nl * (4 * NT + 16);                      // BCAST only: packed component records (16-byte aligned: every term is a multiple of 4)
+    T* pk = xin - tid + nl * (4 * NT + 2 * DM);                      // BCAST only: packed component records (16-byte aligned: every term is a multiple of 4)
     if constexpr (BCAST) {
         if ((int)blockIdx.x >= a.active_blocks) {                // more partial rows than resident workgroups: zero rows
             for (int j = tid; j < a.n_params_total; j += NT) a.g_params[(int64_t)blockIdx.x * a.gps + j] = T(0);
@@ -482,8 +484,8 @@ __global__ void __launch_bounds__(BCAST ? GB_NT : 64) gf_chain_bwd_kernel(const 
         }
         for (int j = tid; j < ((nl * ts) << slsh); j += NT) acc[j] = 0.0;
         __syncthreads();
-        for (int w = tid; w < nl * 8; w += NT) {                 // unbounded log-weights: shift by the column's maximum
-            const int l = w >> 3, dd = w & 7;
+        for (int w = tid; w < nl * DM; w += NT) {                // unbounded log-weights: shift by the column's maximum
+            const int l = w >> LDM, dd = w & (DM - 1);
             const GfLayerDev<T> o = a.L[l];
             T shift = T(0);
             if (dd < D && o.fit_norm && !o.reg_norm) {
@@ -492,19 +494,19 @@ __global__ void __launch_bounds__(BCAST ? GB_NT : 64) gf_chain_bwd_kernel(const 
             }
             aux[w * 2] = shift;
         }
-        for (int w = tid; w < nl * GB_MAX_HH; w += NT) {
-            const int l = w / GB_MAX_HH, i = w - l * GB_MAX_HH;
+        for (int w = tid; w < nl * gb_max_hh<G>(); w += NT) {
+            const int l = w / gb_max_hh<G>(), i = w - l * gb_max_hh<G>();
             if (i < a.L[l].hh) gf_derive_reflection<T>(vtile + l * ts, a.L[l], D, i);
         }
         __syncthreads();
         for (int l = 0; l < nl; ++l) {
             const GfLayerDev<T> o = a.L[l];
             for (int i = tid; i < o.K * D; i += NT)
-                gf_derive_bwd_item<T>(ptile + l * ts, vtile + l * ts, ftile + l * ts, o, i, aux[(l * 8 + i % D) * 2]);
+                gf_derive_bwd_item<T>(ptile + l * ts, vtile + l * ts, ftile + l * ts, o, i, aux[(l * DM + i % D) * 2]);
         }
         __syncthreads();
-        for (int w = tid; w < nl * 8; w += NT) {
-            const int l = w >> 3, dd = w & 7;
+        for (int w = tid; w < nl * DM; w += NT) {
+            const int l = w >> LDM, dd = w & (DM - 1);
             const GfLayerDev<T> o = a.L[l];
             T Nn = T(0);
             if (dd < D && o.fit_norm) for (int k = 0; k < o.K; ++k) Nn += vtile[l * ts + o.off_ln + k * D + dd];
@@ -514,7 +516,7 @@ __global__ void __launch_bounds__(BCAST ? GB_NT : 64) gf_chain_bwd_kernel(const 
         for (int l = 0; l < nl; ++l) {
             const GfLayerDev<T> o = a.L[l];
             if (o.fit_norm) for (int i = tid; i < o.K * D; i += NT) {
-                const T invN = aux[(l * 8 + i % D) * 2 + 1];
+                const T invN = aux[(l * DM + i % D) * 2 + 1];
                 vtile[l * ts + o.off_ln + i] *= invN;
                 ftile[l * ts + o.off_ln + i] *= invN;
             }
@@ -724,7 +726,7 @@ __global__ void __launch_bounds__(GX_THREADS) gfx_chain_bwd_kernel(const GfBwdAr
 }
 
 // ---------------------------------------------------------------------------------------------------------- host side
-static inline int gb_group_width(int D) { return D <= 1 ? 1 : D <= 2 ? 2 : D <= 4 ? 4 : 8; }
+static inline int gb_group_width(int D) { return D <= 1 ? 1 : D <= 2 ? 2 : D <= 4 ? 4 : D <= 8 ? 8 : D <= 16 ? 16 : 32; }
 
 template <typename T> static int gb_fill(GfBwdArgs<T>& a, const T* params, int64_t ps, bool bcast, int32_t D, int32_t n_layers, const jf_gf_layer* layers,
                                          bool& ext) {
@@ -738,6 +740,7 @@ template <typename T> static int gb_fill(GfBwdArgs<T>& a, const T* params, int64
         if (h.rotation_mode < JF_GF_ROT_HOUSEHOLDER || h.rotation_mode > JF_GF_ROT_TRIANGULAR || (h.rotation_mode == JF_GF_ROT_CAYLEY && D > 2)) return JF_ERR_BADARG;
         if (h.add_skewness && sizeof(T) != 8) return JF_ERR_UNSUPPORTED;                                        // float64 only, as the forward
         if (ext_layer) ext = true;
+        if (ext_layer && D > JF_MAX_D_GF) return JF_ERR_UNSUPPORTED;
         if (h.width_mode == JF_GF_WIDTH_SMOOTH_SATURATION && h.width_max <= 0) return JF_ERR_BADARG;
         if (h.nonlinear_stretch_type != JF_GF_STRETCH_CLASSIC) return JF_ERR_UNSUPPORTED;
         o.K = h.num_kde; o.hh = h.hh_iter; o.model_offset = h.model_offset; o.fit_norm = h.fit_normalization;
@@ -783,13 +786,13 @@ static int gb_launch(GfBwdArgs<T> a, bool bcast, hipStream_t st) {
         const int64_t n_tiles = (a.B + GB_NT / G - 1) / (GB_NT / G);
         const int64_t blocks = gb_partials(a.B, a.D);
         a.tiles_per_block = (int)((n_tiles + blocks - 1) / blocks);
-        int slsh = G == 1 ? 6 : G == 2 ? 5 : G == 4 ? 4 : 3;       // one slot per row of a wave, fewer when the accumulators would not fit
+        int slsh = G == 1 ? 6 : G == 2 ? 5 : G == 4 ? 4 : G == 8 ? 3 : G == 16 ? 2 : 1;       // one slot per row of a wave, fewer when the accumulators would not fit
         const size_t cell = (size_t)a.n_layers * a.tile_stride * sizeof(T), acell = (size_t)a.n_layers * a.tile_stride * sizeof(double);
         while (slsh > 0 && 3 * cell + (acell << slsh) > 28 * 1024) --slsh;   // measured flat between 2 and 8 slots (conflicting ds_add_f64 are cheap); occupancy matters more
         a.slsh = slsh;
         int n_rec = 0;
         for (int l = 0; l < a.n_layers; ++l) { a.pk0[l] = n_rec; n_rec += a.L[l].K * a.D; }
-        const size_t lds = 3 * cell + (acell << slsh) + ((size_t)a.n_layers * (4 * GB_NT + 16) + (size_t)n_rec * 8) * sizeof(T);
+        const size_t lds = 3 * cell + (acell << slsh) + ((size_t)a.n_layers * (4 * GB_NT + 2 * (G > 8 ? G : 8)) + (size_t)n_rec * 8) * sizeof(T);
         if (lds > 160 * 1024) return JF_ERR_UNSUPPORTED;
         auto k = gf_chain_bwd_kernel<T, G, true>;
         if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -821,7 +824,7 @@ static int gf_chain_inv_bwd(const T* x, int64_t xs, const T* params, int64_t ps,
                             int64_t gps, int32_t* status, void* stream) {
     if (!x || !params || !g_x || !g_params || !layers) return JF_ERR_BADARG;
     if (n_layers < 1 || n_layers > JF_MAX_CHAIN || D < 1 || B < 0) return JF_ERR_BADARG;
-    if (D > 8) return JF_ERR_UNSUPPORTED;
+    if (D > JF_MAX_D_G) return JF_ERR_UNSUPPORTED;
     if (pb != 1 && pb != B) return JF_ERR_BADARG;
     const bool bcast = pb == 1;
     GfBwdArgs<T> a{};
@@ -840,19 +843,42 @@ static int gf_chain_inv_bwd(const T* x, int64_t xs, const T* params, int64_t ps,
         hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(GX_THREADS), lds, (hipStream_t)stream, a, bcast ? (int64_t)0 : ps, tiles);
         return check_launch();
     }
-    for (int l = 0; l < n_layers; ++l) if (layers[l].hh_iter > GB_MAX_HH) return JF_ERR_UNSUPPORTED;
+    for (int l = 0; l < n_layers; ++l) if (layers[l].hh_iter > (gb_group_width(D) > GB_MAX_HH ? gb_group_width(D) : GB_MAX_HH)) return JF_ERR_UNSUPPORTED;
     switch (gb_group_width(D)) {
         case 1: return gb_launch<T, 1>(a, bcast, (hipStream_t)stream);
         case 2: return gb_launch<T, 2>(a, bcast, (hipStream_t)stream);
         case 4: return gb_launch<T, 4>(a, bcast, (hipStream_t)stream);
-        default: return gb_launch<T, 8>(a, bcast, (hipStream_t)stream);
+        case 8: return gb_launch<T, 8>(a, bcast, (hipStream_t)stream);
+        case 16: return gb_launch<T, 16>(a, bcast, (hipStream_t)stream);
+        default: return gb_launch<T, 32>(a, bcast, (hipStream_t)stream);
     }
+}
+
+// LDS bytes a backward launch of this chain needs (smallest accumulator-slot count), or a negative JF_ERR_*: what the host uses to cut a long
+// chain of wide layers into launches that fit the 160 KB of a CU
+template <typename T> static int64_t gb_lds_query(int32_t D, int32_t n_layers, const jf_gf_layer* layers, int bcast) {
+    if (!layers || n_layers < 1 || n_layers > JF_MAX_CHAIN || D < 1) return JF_ERR_BADARG;
+    if (D > JF_MAX_D_G) return JF_ERR_UNSUPPORTED;
+    GfBwdArgs<T> a{};
+    bool ext = false;
+    const int rc = gb_fill<T>(a, nullptr, 0, bcast != 0, D, n_layers, layers, ext);
+    if (rc != JF_OK) return rc;
+    if (ext) return (int64_t)((size_t)JF_MAX_D_GF * GX_THREADS * sizeof(Dual<T>) + 16 * sizeof(T));
+    const int G = gb_group_width(D);
+    for (int l = 0; l < n_layers; ++l) if (layers[l].hh_iter > (G > GB_MAX_HH ? G : GB_MAX_HH)) return JF_ERR_UNSUPPORTED;
+    if (!bcast) return (int64_t)((size_t)(((size_t)D * sizeof(T) >= 32) ? 1 : 2) * (64 / G) * a.tile_stride * sizeof(T));
+    const size_t cell = (size_t)n_layers * a.tile_stride * sizeof(T), acell = (size_t)n_layers * a.tile_stride * sizeof(double);
+    size_t n_rec = 0;
+    for (int l = 0; l < n_layers; ++l) n_rec += (size_t)a.L[l].K * D;
+    return (int64_t)(3 * cell + acell + ((size_t)n_layers * (4 * GB_NT + 2 * (G > 8 ? G : 8)) + n_rec * 8) * sizeof(T));
 }
 
 }  // namespace jf
 
 extern "C" {
 int64_t jf_gf_chain_inv_bwd_partials(int64_t B, int32_t D) { return jf::gb_partials(B, D); }
+int64_t jf_gf_chain_inv_bwd_lds_bytes_f32(int32_t D, int32_t n, const jf_gf_layer* L, int32_t pb1) { return jf::gb_lds_query<float>(D, n, L, pb1); }
+int64_t jf_gf_chain_inv_bwd_lds_bytes_f64(int32_t D, int32_t n, const jf_gf_layer* L, int32_t pb1) { return jf::gb_lds_query<double>(D, n, L, pb1); }
 int jf_gf_chain_inv_bwd_f32(const float* x, int64_t xs, const float* p, int64_t ps, int32_t pb, int64_t B, int32_t D, int32_t n, const jf_gf_layer* L,
                             const float* gxo, int64_t gxos, const float* gld, const float* gblp, float* gx, int64_t gxs, float* gp, int64_t gps,
                             int32_t* st, void* s) {

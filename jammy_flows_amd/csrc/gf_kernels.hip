@@ -37,7 +37,7 @@ template <typename T> struct GfChainArgs {
     int32_t* status;
 };
 
-template <int G> struct Log2 { static constexpr int v = (G == 1) ? 0 : (G == 2) ? 1 : (G == 4) ? 2 : 3; };
+template <int G> struct Log2 { static constexpr int v = (G == 1) ? 0 : (G == 2) ? 1 : (G == 4) ? 2 : (G == 8) ? 3 : (G == 16) ? 4 : 5; };
 
 // broadcast regime: raw rows -> LDS, then wave w derives layers w, w+4, ... (columns on lanes 0..D-1, reflections on lanes 32..)
 template <typename T> __device__ __forceinline__ void derive_broadcast(T* lds, const GfChainArgs<T>& a) {
@@ -327,13 +327,13 @@ template <typename T, bool FWD> __global__ void __launch_bounds__(GX_THREADS) gf
 // ----------------------------------------------------------------------------------------------------------
 constexpr int LDS_LIMIT = 160 * 1024;
 
-static inline int group_width(int D) { return D <= 1 ? 1 : D <= 2 ? 2 : D <= 4 ? 4 : 8; }
+static inline int group_width(int D) { return D <= 1 ? 1 : D <= 2 ? 2 : D <= 4 ? 4 : D <= 8 ? 8 : D <= 16 ? 16 : 32; }
 
 template <typename T> static int fill_args(GfChainArgs<T>& a, const T* params, int64_t ps, int32_t pb, int64_t B, int32_t D, int32_t n_layers,
                                            const jf_gf_layer* layers, size_t& lds_bytes, bool& bcast, bool& ext) {
     ext = false;
     if (n_layers < 1 || n_layers > JF_MAX_CHAIN || D < 1 || B < 0 || layers == nullptr) return JF_ERR_BADARG;
-    if (D > 8) return JF_ERR_UNSUPPORTED;
+    if (D > JF_MAX_D_G) return JF_ERR_UNSUPPORTED;
     if (pb != 1 && pb != B) return JF_ERR_BADARG;
     bcast = (pb == 1);
     int col = 0, maxp = 0;
@@ -358,6 +358,7 @@ template <typename T> static int fill_args(GfChainArgs<T>& a, const T* params, i
         if ((o.center_mean || o.skew) && o.stretch != JF_GF_STRETCH_CLASSIC) return JF_ERR_BADARG;
         if (o.center_mean && h.num_kde < 2) return JF_ERR_BADARG;
         if (o.rot_mode != JF_GF_ROT_HOUSEHOLDER || o.center_mean || o.skew) ext = true;
+        if (ext && D > JF_MAX_D_GF) return JF_ERR_UNSUPPORTED;                                 // the general-option kernel keeps a row's coordinates in an LDS column of 8
         o.off_rot = h.model_offset ? D : 0;
         o.off_mean = o.off_rot + gx_rot_len(o.rot_mode, o.hh, D);
         o.off_lw = o.off_mean + kd - (o.center_mean ? D : 0);
@@ -452,7 +453,7 @@ template <typename T, bool FWD> static int launch(const GfChainArgs<T>& a, int D
             pack_elems = a.L[l].K > pack_elems ? a.L[l].K : pack_elems;
         }
         const size_t lds_rows = ((size_t)a.tab_offset + (size_t)a.n_layers * pack_elems * D * 4) * sizeof(T);
-        if (classic && lds_rows <= (size_t)LDS_LIMIT) {
+        if (classic && D <= 8 && lds_rows <= (size_t)LDS_LIMIT) {
             switch (D) {
                 case 1: return launch_rows<T, 1>(a, lds_rows, st);
                 case 2: return launch_rows<T, 2>(a, lds_rows, st);
@@ -475,7 +476,9 @@ template <typename T, bool FWD> static int launch(const GfChainArgs<T>& a, int D
         case 1: return launch_g<T, 1, FWD>(a, bcast, lds_bytes, st);
         case 2: return launch_g<T, 2, FWD>(a, bcast, lds_bytes, st);
         case 4: return launch_g<T, 4, FWD>(a, bcast, lds_bytes, st);
-        default: return launch_g<T, 8, FWD>(a, bcast, lds_bytes, st);
+        case 8: return launch_g<T, 8, FWD>(a, bcast, lds_bytes, st);
+        case 16: return launch_g<T, 16, FWD>(a, bcast, lds_bytes, st);
+        default: return launch_g<T, 32, FWD>(a, bcast, lds_bytes, st);
     }
 }
 
@@ -506,10 +509,20 @@ static int gf_chain_fwd(const T* z, int64_t zs, const T* ld_in, const T* params,
     return launch<T, true>(a, D, bcast, ext, lds, (hipStream_t)stream);
 }
 
+// LDS bytes a log-prob / sampling launch of this chain needs, or a negative JF_ERR_* (JF_ERR_UNSUPPORTED: more than a CU has -- cut the chain)
+template <typename T> static int64_t gf_lds_query(int32_t D, int32_t n_layers, const jf_gf_layer* layers, int bcast) {
+    GfChainArgs<T> a{};
+    size_t lds = 0; bool b = false, ext = false;
+    const int rc = fill_args<T>(a, nullptr, 0, bcast ? 1 : 2, 2, D, n_layers, layers, lds, b, ext);
+    return rc != JF_OK ? (int64_t)rc : (int64_t)lds;
+}
+
 }  // namespace jf
 
 extern "C" {
-int jf_abi_version(void) { return 3; }
+int jf_abi_version(void) { return 4; }
+int64_t jf_gf_chain_lds_bytes_f32(int32_t D, int32_t n, const jf_gf_layer* L, int32_t pb1) { return jf::gf_lds_query<float>(D, n, L, pb1); }
+int64_t jf_gf_chain_lds_bytes_f64(int32_t D, int32_t n, const jf_gf_layer* L, int32_t pb1) { return jf::gf_lds_query<double>(D, n, L, pb1); }
 
 int jf_gf_chain_inv_f32(const float* x, int64_t xs, const float* ld_in, const float* p, int64_t ps, int32_t pb, int64_t B, int32_t D, int32_t n,
                         const jf_gf_layer* L, float* xo, int64_t xos, float* ldo, const float* bi, float* bo, int64_t* bins, int64_t bs, int32_t* st,

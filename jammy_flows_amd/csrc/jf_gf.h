@@ -220,16 +220,25 @@ constexpr int DPP_XOR1 = 0xB1;          // quad_perm [1,0,3,2]
 constexpr int DPP_XOR2 = 0x4E;          // quad_perm [2,3,0,1]
 constexpr int DPP_HALF_MIRROR = 0x141;  // lane i <-> 7-i inside each 8 lanes (after the quad steps both quads hold their sums)
 
+constexpr int DPP_ROW_ROR8 = 0x128;     // row_ror:8: lane i <-> i ^ 8 inside each row of 16 lanes (both 8-lane halves hold their sums by then)
+
+// lanes 16 apart (G = 32: coordinates 16..31 of a row): no DPP form crosses the 16-lane rows; ds_bpermute does
+template <typename T> __device__ __forceinline__ T xor16(T v) { return __shfl_xor(v, 16, 64); }
+
 template <typename T, int G> __device__ __forceinline__ T group_sum(T v) {
     if constexpr (G >= 2) v += dpp_swap<DPP_XOR1>(v);
     if constexpr (G >= 4) v += dpp_swap<DPP_XOR2>(v);
     if constexpr (G >= 8) v += dpp_swap<DPP_HALF_MIRROR>(v);
+    if constexpr (G >= 16) v += dpp_swap<DPP_ROW_ROR8>(v);
+    if constexpr (G >= 32) v += xor16(v);
     return v;
 }
 template <typename T, int G> __device__ __forceinline__ T group_max(T v) {
     if constexpr (G >= 2) v = M<T>::max(v, dpp_swap<DPP_XOR1>(v));
     if constexpr (G >= 4) v = M<T>::max(v, dpp_swap<DPP_XOR2>(v));
     if constexpr (G >= 8) v = M<T>::max(v, dpp_swap<DPP_HALF_MIRROR>(v));
+    if constexpr (G >= 16) v = M<T>::max(v, dpp_swap<DPP_ROW_ROR8>(v));
+    if constexpr (G >= 32) v = M<T>::max(v, xor16(v));
     return v;
 }
 

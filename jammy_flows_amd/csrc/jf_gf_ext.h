@@ -12,7 +12,8 @@
 namespace jf {
 
 constexpr int GX_THREADS = 128;
-constexpr int JF_MAX_D_GF = 8;           // the g-chain entry points take D <= 8
+constexpr int JF_MAX_D_GF = 8;           // the general-option kernel (this file) takes D <= 8
+constexpr int JF_MAX_D_G = 32;           // the lane = (row, coordinate) kernels: groups of up to 32 lanes per row
 
 template <typename T> struct XCol {           // the lane's coordinate vector: element d at b[d * GX_THREADS]
     T* b;

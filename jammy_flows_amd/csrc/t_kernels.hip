@@ -5,14 +5,14 @@
 // L lower triangular: log L_ii = make_log_positive(raw_i) (the same width regulators as 'g': smooth saturation / exp / softplus, optional
 // clamps), strictly-lower entries stored sub-diagonal by sub-diagonal starting from the bottom-left corner (matrix_fns.py:36-50).
 // The reference multiplies by an explicit inverse built from sub-determinants (matrix_fns.py:88-141); here the triangular system is solved by
-// forward substitution in registers (same result, D <= 8).  One sample per lane; row: [offset D if model_offset][log-diagonal 1 | D][lower D(D-1)/2].
+// forward substitution in registers (same result; D <= 32, kernels instantiated for 8 / 16 / 32 coordinates).  One sample per lane; row: [offset D if model_offset][log-diagonal 1 | D][lower D(D-1)/2].
 //   jf_t_layer_inv_* / jf_t_layer_fwd_* / jf_t_layer_inv_bwd_* (backward in forward mode on dual numbers, like the manifold chains)
 #include "jf_dual.h"
 #include "jf_gf.h"
 
 namespace jf {
 
-constexpr int T_MAXD = 8;
+constexpr int T_MAXD = 32;                  // the kernels are instantiated for register arrays of 8, 16 and 32 coordinates (MD)
 
 template <typename T> struct TDev {
     int cov, model_offset, D;
@@ -24,51 +24,51 @@ template <typename T> __device__ __forceinline__ T t_log_diag(const TDev<T>& o, 
 // index of L[i][j] (i > j) inside the strictly-lower block
 __host__ __device__ inline int t_lower_index(int D, int i, int j) { const int ind = D - 1 - (i - j); return ind * (ind + 1) / 2 + j; }
 
-template <typename T, bool FWD> __device__ __forceinline__ void t_apply(const TDev<T>& o, const T* __restrict__ p, int64_t pstep, T (&x)[T_MAXD], T& ld) {
+template <typename T, bool FWD, int MD> __device__ __forceinline__ void t_apply(const TDev<T>& o, const T* __restrict__ p, int64_t pstep, T (&x)[MD], T& ld) {
     const int D = o.D;
     auto P = [&](int i) -> T { return p[i * pstep]; };
     int c = 0;
-    T off[T_MAXD];
+    T off[MD];
 #pragma unroll
-    for (int d = 0; d < T_MAXD; ++d) off[d] = (o.model_offset && d < D) ? P(d) : T(0);
+    for (int d = 0; d < MD; ++d) off[d] = (o.model_offset && d < D) ? P(d) : T(0);
     if (o.model_offset) c = D;
     if constexpr (!FWD) {
 #pragma unroll
-        for (int d = 0; d < T_MAXD; ++d) x[d] = x[d] - off[d];
+        for (int d = 0; d < MD; ++d) x[d] = x[d] - off[d];
     }
     if (o.cov == JF_T_DIAGONAL_SYMMETRIC) {
         const T s = t_log_diag<T>(o, P(c));
         const T f = M<T>::exp(FWD ? s : -s);
 #pragma unroll
-        for (int d = 0; d < T_MAXD; ++d) if (d < D) x[d] = x[d] * f;
+        for (int d = 0; d < MD; ++d) if (d < D) x[d] = x[d] * f;
         ld = FWD ? ld + s * T(D) : ld - s * T(D);
     } else if (o.cov == JF_T_DIAGONAL) {
 #pragma unroll
-        for (int d = 0; d < T_MAXD; ++d) if (d < D) {
+        for (int d = 0; d < MD; ++d) if (d < D) {
             const T s = t_log_diag<T>(o, P(c + d));
             x[d] = x[d] * M<T>::exp(FWD ? s : -s);
             ld = FWD ? ld + s : ld - s;
         }
     } else if (o.cov == JF_T_FULL) {
-        T s[T_MAXD];
+        T s[MD];
 #pragma unroll
-        for (int d = 0; d < T_MAXD; ++d) s[d] = d < D ? t_log_diag<T>(o, P(c + d)) : T(0);
+        for (int d = 0; d < MD; ++d) s[d] = d < D ? t_log_diag<T>(o, P(c + d)) : T(0);
         const int lo = c + D;
         if constexpr (FWD) {               // x = L z, bottom row first so that z is still intact
 #pragma unroll
-            for (int i = T_MAXD - 1; i >= 0; --i) if (i < D) {
+            for (int i = MD - 1; i >= 0; --i) if (i < D) {
                 T acc = x[i] * M<T>::exp(s[i]);
 #pragma unroll
-                for (int j = 0; j < T_MAXD; ++j) if (j < i) acc = acc + P(lo + t_lower_index(D, i, j)) * x[j];
+                for (int j = 0; j < MD; ++j) if (j < i) acc = acc + P(lo + t_lower_index(D, i, j)) * x[j];
                 x[i] = acc;
                 ld = ld + s[i];
             }
         } else {                           // forward substitution L z = x
 #pragma unroll
-            for (int i = 0; i < T_MAXD; ++i) if (i < D) {
+            for (int i = 0; i < MD; ++i) if (i < D) {
                 T acc = x[i];
 #pragma unroll
-                for (int j = 0; j < T_MAXD; ++j) if (j < i) acc = acc - P(lo + t_lower_index(D, i, j)) * x[j];
+                for (int j = 0; j < MD; ++j) if (j < i) acc = acc - P(lo + t_lower_index(D, i, j)) * x[j];
                 x[i] = acc * M<T>::exp(-s[i]);
                 ld = ld - s[i];
             }
@@ -76,7 +76,7 @@ template <typename T, bool FWD> __device__ __forceinline__ void t_apply(const TD
     }
     if constexpr (FWD) {
 #pragma unroll
-        for (int d = 0; d < T_MAXD; ++d) x[d] = x[d] + off[d];
+        for (int d = 0; d < MD; ++d) x[d] = x[d] + off[d];
     }
 }
 
@@ -89,19 +89,19 @@ template <typename T> struct TArgs {
     int32_t* status;
 };
 
-template <typename T, bool FWD> __global__ void __launch_bounds__(256) t_kernel(const TArgs<T> a) {
+template <typename T, bool FWD, int MD> __global__ void __launch_bounds__(256) t_kernel(const TArgs<T> a) {
     const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (row >= a.B) return;
-    T x[T_MAXD];
+    T x[MD];
 #pragma unroll
-    for (int d = 0; d < T_MAXD; ++d) x[d] = d < a.o.D ? a.x[row * a.xs + d] : T(0);
+    for (int d = 0; d < MD; ++d) x[d] = d < a.o.D ? a.x[row * a.xs + d] : T(0);
     T ld = a.ld_in ? a.ld_in[row] : T(0);
     const T* p = a.params ? a.params + (a.bcast ? 0 : row * a.ps) : nullptr;
-    if (a.o.cov != JF_T_IDENTITY || a.o.model_offset) t_apply<T, FWD>(a.o, p, 1, x, ld);
+    if (a.o.cov != JF_T_IDENTITY || a.o.model_offset) t_apply<T, FWD, MD>(a.o, p, 1, x, ld);
     bool bad = !M<T>::finite(ld);
     T s = a.blp_in ? a.blp_in[row] : T(0);
 #pragma unroll
-    for (int d = 0; d < T_MAXD; ++d) if (d < a.o.D) {
+    for (int d = 0; d < MD; ++d) if (d < a.o.D) {
         a.x_out[row * a.xos + d] = x[d];
         bad = bad || !M<T>::finite(x[d]);
         s += T(-0.5) * x[d] * x[d] - M<T>::HALF_LN_2PI;
@@ -112,7 +112,7 @@ template <typename T, bool FWD> __global__ void __launch_bounds__(256) t_kernel(
 }
 
 // backward of the log-prob direction, forward mode: one pass per input direction (D coordinates + P parameters) on dual numbers
-template <typename T> __global__ void __launch_bounds__(64) t_bwd_kernel(const TArgs<T> a) {
+template <typename T, int MD> __global__ void __launch_bounds__(64) t_bwd_kernel(const TArgs<T> a) {
     using Du = Dual<T>;
     extern __shared__ __align__(16) unsigned char smem_raw[];
     Du* tile = reinterpret_cast<Du*>(smem_raw);                       // [P][64] (per-sample) or [P] (broadcast): lane-contiguous columns
@@ -130,9 +130,9 @@ template <typename T> __global__ void __launch_bounds__(64) t_bwd_kernel(const T
     o.cov = a.o.cov; o.model_offset = a.o.model_offset; o.D = D;
     o.w.width_mode = a.o.w.width_mode; o.w.clamp_widths = a.o.w.clamp_widths;
     o.w.wmin = Du(a.o.w.wmin); o.w.inv_wmax = Du(a.o.w.inv_wmax); o.w.lw_lo = Du(a.o.w.lw_lo); o.w.lw_hi = Du(a.o.w.lw_hi);
-    T x0[T_MAXD], gxo[T_MAXD];
+    T x0[MD], gxo[MD];
 #pragma unroll
-    for (int d = 0; d < T_MAXD; ++d) {
+    for (int d = 0; d < MD; ++d) {
         x0[d] = d < D ? a.x[rrow * a.xs + d] : T(0);
         gxo[d] = (d < D && a.g_xout && active) ? a.g_xout[rrow * a.gxos + d] : T(0);
     }
@@ -143,14 +143,14 @@ template <typename T> __global__ void __launch_bounds__(64) t_bwd_kernel(const T
     for (int j = 0; j < D + a.P; ++j) {
         if (j >= D) { if (a.bcast) { if (tid == 0) tile[j - D].d = T(1); } else tile[(j - D) * 64 + tid].d = T(1); }
         __syncthreads();
-        Du x[T_MAXD];
+        Du x[MD];
 #pragma unroll
-        for (int d = 0; d < T_MAXD; ++d) x[d] = Du(x0[d], d == j ? T(1) : T(0));
+        for (int d = 0; d < MD; ++d) x[d] = Du(x0[d], d == j ? T(1) : T(0));
         Du ld(T(0));
-        if (a.o.cov != JF_T_IDENTITY || a.o.model_offset) t_apply<Du, false>(o, p, pstep, x, ld);
+        if (a.o.cov != JF_T_IDENTITY || a.o.model_offset) t_apply<Du, false, MD>(o, p, pstep, x, ld);
         T gj = gld * ld.d;
 #pragma unroll
-        for (int d = 0; d < T_MAXD; ++d) if (d < D) gj += (gxo[d] - x[d].v * gblp) * x[d].d;
+        for (int d = 0; d < MD; ++d) if (d < D) gj += (gxo[d] - x[d].v * gblp) * x[d].d;
         if (!active) gj = T(0);
         if (j < D) { if (active) a.g_x[row * a.gxs + j] = gj; }
         else if (a.bcast) {
@@ -191,7 +191,9 @@ static int t_layer(const T* x, int64_t xs, const T* ld_in, const T* params, int6
     if (B == 0) return JF_OK;
     a.x = x; a.xs = xs; a.ld_in = ld_in; a.params = params; a.ps = ps; a.bcast = pb == 1; a.B = B;
     a.x_out = x_out; a.xos = xos; a.ld_out = ld_out; a.blp_in = blp_in; a.blp_out = blp_out; a.status = status;
-    hipLaunchKernelGGL((t_kernel<T, FWD>), dim3((unsigned)((B + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+    if (D <= 8) hipLaunchKernelGGL((t_kernel<T, FWD, 8>), dim3((unsigned)((B + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+    else if (D <= 16) hipLaunchKernelGGL((t_kernel<T, FWD, 16>), dim3((unsigned)((B + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((t_kernel<T, FWD, 32>), dim3((unsigned)((B + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
     return check_launch();
 }
 
@@ -207,7 +209,8 @@ static int t_layer_bwd(const T* x, int64_t xs, const T* params, int64_t ps, int3
     a.x = x; a.xs = xs; a.params = params; a.ps = ps; a.bcast = pb == 1; a.B = B;
     a.g_xout = g_xout; a.gxos = gxos; a.g_ld = g_ld; a.g_blp = g_blp; a.g_x = g_x; a.gxs = gxs; a.g_params = g_params; a.gps = gps; a.status = status;
     const size_t lds = (size_t)(a.P > 0 ? a.P : 1) * (a.bcast ? 1 : 64) * sizeof(Dual<T>);
-    auto k = t_bwd_kernel<T>;
+    if (lds > 160 * 1024) return JF_ERR_UNSUPPORTED;
+    auto k = D <= 8 ? t_bwd_kernel<T, 8> : D <= 16 ? t_bwd_kernel<T, 16> : t_bwd_kernel<T, 32>;
     if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k, dim3((unsigned)((B + 63) / 64)), dim3(64), lds, (hipStream_t)stream, a);
     return check_launch();

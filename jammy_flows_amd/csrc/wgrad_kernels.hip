@@ -222,9 +222,9 @@ __global__ void __launch_bounds__(128) mlp2_small_bwd_kernel(const T* __restrict
         const T* gr = g + r * gs;
         T xv[KB], gv[NB];
 #pragma unroll
-        for (int k = 0; k < KB; ++k) xv[k] = xr[k];
+        for (int k = 0; k < KB; ++k) xv[k] = k < K1 ? xr[k] : T(0);      // slots beyond K1 hold the neighbouring row: SELECT zero (0 * NaN = NaN)
 #pragma unroll
-        for (int n = 0; n < NB; ++n) gv[n] = gr[n];
+        for (int n = 0; n < NB; ++n) gv[n] = n < N ? gr[n] : T(0);
         one_row(xv, gv);
     }
     for (int64_t r = rm; r < r1; ++r) {
@@ -285,7 +285,7 @@ __global__ void __launch_bounds__(128) mlp_hidden_bwd_kernel(const T* __restrict
         const T* xr = x + r * xs;                                 // uniform addresses: scalar loads
         T xv[KB];
 #pragma unroll
-        for (int k = 0; k < KB; ++k) xv[k] = xr[k];
+        for (int k = 0; k < KB; ++k) xv[k] = k < K1 ? xr[k] : T(0);      // slots beyond K1 hold the neighbouring row: SELECT zero (0 * NaN = NaN)
         one_row(xv, gh[r * ghs + jj]);
     }
     for (int64_t r = rm; r < r1; ++r) {

@@ -293,9 +293,31 @@ class gf_block(euclidean_base.euclidean_base):
 
 
 # ----------------------------------------------------------------------------------------------------------
+def chain_fits(layers):
+    """does ONE launch of these 'g' layers fit a CU's LDS in every direction the host may ask for (log-prob, sampling, backward; float64,
+    broadcast parameters: the most demanding case)?  Wide layers (D > 8: groups of 16 / 32 lanes per row, parameter rows of thousands of
+    values) run as several shorter launches.  Cached per layer list (a ctypes query of the library's own bookkeeping)."""
+    key = tuple(id(l) for l in layers)
+    cache = layers[0].__dict__.setdefault("_chain_fits_cache", {})
+    hit = cache.get(key)
+    if hit is None:
+        try:
+            arr = _hip.gf_layer_array([l.c_struct() for l in layers])
+            D = layers[0].dimension
+            ext = any(l.has_extended_options for l in layers)
+            hit = all(_hip.gf_chain_fits(arr, len(layers), D, torch.float64, bcast, backward)
+                      for bcast in (True, False) for backward in ((False,) if (ext or any(l.nonlinear_stretch_type != "classic" for l in layers))
+                                                                   else (False, True)))
+        except _hip.HipUnavailable:
+            hit = layers[0].dimension <= 8
+        cache[key] = hit
+    return hit
+
+
 def chain_supported(layers):
     """can this list of layers of one e-block be run as one fused launch?"""
-    return 1 <= len(layers) <= _hip.JF_MAX_CHAIN and all(type(l) is gf_block for l in layers) and layers[0].dimension <= 8
+    return (1 <= len(layers) <= _hip.JF_MAX_CHAIN and all(type(l) is gf_block for l in layers) and layers[0].dimension <= _hip.GF_MAX_DIM
+            and chain_fits(layers))
 
 
 def chain_permanent_row(layers, like):

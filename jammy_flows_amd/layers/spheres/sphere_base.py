@@ -49,10 +49,12 @@ class sphere_base(layer_base.layer_base):
 
     # ------------------------------------------------------------------------------------------ embedding conversions
     def spherical_to_eucl_embedding(self, x, log_det):
-        return _hip.sphere_embedding(x, log_det, self.dimension, True)
+        from ... import autograd
+        return autograd.sphere_embedding(x, log_det, self.dimension, True)
 
     def eucl_to_spherical_embedding(self, x, log_det):
-        return _hip.sphere_embedding(x, log_det, self.dimension, False)
+        from ... import autograd
+        return autograd.sphere_embedding(x, log_det, self.dimension, False)
 
     # ------------------------------------------------------------------------------------------ fused path of in-tree layers
     def _layer_tensors(self):

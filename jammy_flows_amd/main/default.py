@@ -94,7 +94,8 @@ def _layer_groups(layers):
     """split a block's layers into launch groups: maximal runs of chainable 'g' layers (one fused launch each), every other layer alone"""
     groups, run = [], []
     for l in layers:
-        if type(l) is gfl.gf_block and l.dimension <= 8 and len(run) < _hip.JF_MAX_CHAIN:
+        if (type(l) is gfl.gf_block and l.dimension <= _hip.GF_MAX_DIM and len(run) < _hip.JF_MAX_CHAIN
+                and gfl.chain_fits(run + [l])):          # wide layers: a run ends where one launch would no longer fit a CU's LDS
             run.append(l)
             continue
         if run:
@@ -867,8 +868,15 @@ class pdf(nn.Module):
         """forward() with a torch.autograd graph: d log_prob / d (x, conditional_input, MLP weights, permanent layer parameters).
         Same launches as the inference path, wrapped in autograd Functions whose backward is a HIP launch (g chains, manifold chains) or
         rocBLAS GEMMs (dense layers) -- see jammy_flows_amd/autograd.py."""
-        if only_last or force_embedding_coordinates or force_intrinsic_coordinates:
-            raise NotImplementedError("gradients with only_last / forced coordinate systems are not implemented")
+        if only_last:
+            raise NotImplementedError("gradients with only_last are not implemented: evaluate under torch.no_grad(), or without only_last")
+        log_det0 = None
+        if force_embedding_coordinates:          # the chart changes ahead of the block loop, with a graph (autograd.SphereEmbeddingFn)
+            assert x.shape[1] == self.total_target_dim_embedded, (x.shape[1], self.total_target_dim_embedded)
+            x, log_det0 = self.transform_target_space(x, None, transform_from="embedding", transform_to="default")
+        elif force_intrinsic_coordinates:
+            assert x.shape[1] == self.total_target_dim_intrinsic
+            x, log_det0 = self.transform_target_space(x, None, transform_from="intrinsic", transform_to="default")
         amort = amortization_parameters
         if amort is not None:
             assert amort.shape[1] == self.total_number_amortizable_params
@@ -895,7 +903,7 @@ class pdf(nn.Module):
         self._poll_status()
         status = _hip.new_status(x.device) if self.check_status else None
         B = x.shape[0]
-        log_det = None
+        log_det = log_det0
         base_logp = None
         bases = []
         embeds = []

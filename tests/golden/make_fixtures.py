@@ -109,6 +109,18 @@ CASES = [
     dict(name="t_e2_tt_variants", pdf="e2+e2", flow="t+tg", mlp_scale=300.0,
          kwargs=dict(options_overwrite={0: {"t": {"cov_type": "diagonal_symmetric", "softplus_for_width": 1}},
                                         1: {"t": {"cov_type": "full", "clamp_widths": 1, "skip_model_offset": 1}}})),
+    # more than 8 Euclidean dimensions (examples/jammy_flows.py:308 defaults to e10 / ggggg; tests/test_general.py:364 lists e10 / t entries):
+    # groups of 16 / 32 lanes per row in the 'g' kernels, 16- / 32-coordinate instantiations of the 't' kernels
+    dict(name="g_e10_gg", pdf="e10", flow="gg", perturb=0.3),
+    dict(name="g_e10_ggggg", pdf="e10", flow="ggggg", perturb=0.2),
+    dict(name="g_e12_cond", pdf="e12", flow="gg", mlp_scale=300.0, kwargs=dict(conditional_input_dim=3)),
+    dict(name="g_e20_g", pdf="e20", flow="g", perturb=0.3),
+    dict(name="t_e10_full", pdf="e10", flow="t", perturb=0.4, kwargs=dict(options_overwrite={"t": {"cov_type": "full"}})),
+    dict(name="t_e10_diagonal", pdf="e10", flow="gt", perturb=0.4, kwargs=dict(options_overwrite={"t": {"cov_type": "diagonal"}})),
+    dict(name="t_e10_diagonal_symmetric", pdf="e10", flow="t", perturb=0.4, kwargs=dict(options_overwrite={"t": {"cov_type": "diagonal_symmetric"}})),
+    dict(name="t_e10_identity", pdf="e10", flow="gt", perturb=0.4, kwargs=dict(options_overwrite={"t": {"cov_type": "identity"}})),
+    dict(name="t_e12_full_cond", pdf="e12", flow="gt", mlp_scale=300.0,
+         kwargs=dict(conditional_input_dim=2, options_overwrite={"t": {"cov_type": "full"}})),
     # interval splines
     dict(name="r_i1", pdf="i1", flow="r", perturb=0.7),
     dict(name="r_i1_m1p1_rr_cond", pdf="i1_-1.0_1.0", flow="rr", mlp_scale=1000.0, kwargs=dict(conditional_input_dim=2)),

@@ -36,7 +36,11 @@ import fixture_io  # noqa: E402
 CASES = ["c1_e2_gg", "c2_e4_gggg", "c3_e4s2e4", "g_e1_g", "g_e3_ggg_cond", "g_e2_precise", "g_e2_crude", "g_e2_fullpade", "g_e2_softplusw",
          "g_e2_clampw", "g_e2_nosat", "g_e3_nonorm_hh2", "g_e3_norot_noreg", "g_e1e2e1_cond", "g_e1e2e1_cond_lowrank", "c5_e8s2_ggggv",
          "t_e3_gggt", "t_e3_gt_full_cond", "t_e2_tt_variants", "f_s2", "f_s2_cond_ff", "c4_i1s1_ro", "r_i1_m1p1_rr_cond", "o_s1_cond_oo", "m_s1_cond", "v_s2_cond_vv",
-         "g_e2_skew_cond", "g_e3_center_mean", "g_e3_rot_angles", "g_e2_rot_cayley_cond", "g_e3_rot_triangular", "g_e4_all_options"]
+         "g_e2_skew_cond", "g_e3_center_mean", "g_e3_rot_angles", "g_e2_rot_cayley_cond", "g_e3_rot_triangular", "g_e4_all_options",
+         # evaluated in EMBEDDING coordinates (force_embedding_coordinates=True: x = (x, y, z) on the sphere): the chart change sits inside the graph
+         "f_s2_emb", "mix_s2e2_emb",
+         # more than 8 Euclidean dimensions
+         "g_e10_gg", "g_e10_ggggg", "g_e12_cond", "t_e10_full", "t_e10_diagonal", "t_e12_full_cond"]
 N_ADV = 8
 ADAM_STEPS = 10
 

@@ -165,7 +165,9 @@ def test_sampling_float32_vs_float64_reference(fx):
     # r maps to cos(theta) = 1 - 2 exp(-r^2 / 2), which is 1 - 2.5e-4 at |z| = (3, 3) (phi ill-conditioned) and rounds to 1 from (4, 4) on
     # (the reference's own 1e-6 safety margin, sphere_base.py:501-502); those rows are excluded, every drawn row is kept
     ok = np.isfinite(rl) & (np.abs(np.asarray(fx["z"])).max(axis=1) < 2.99)
-    assert ok.sum() >= rl.shape[0] - 16, "%d of %d rows usable" % (ok.sum(), rl.shape[0])
+    # (drawn rows go too where one of their D coordinates happens to exceed 2.99: P = 0.0028 per coordinate, noticeable from D ~ 10 on)
+    allowance = 16 + int(2 * 0.0028 * rl.shape[0] * np.asarray(fx["z"]).shape[1])
+    assert ok.sum() >= rl.shape[0] - allowance, "%d of %d rows usable" % (ok.sum(), rl.shape[0])
     assert np.isfinite(gl[ok]).all()
     ex = (np.abs(gx - rx) / (1.0 + np.abs(rx)))[ok].max()
     el = np.abs(gl - rl)[ok].max()
@@ -575,6 +577,43 @@ def test_packed_image_follows_the_weights():
     assert float(((b - c)[fin].abs() / (1 + c[fin].abs())).max()) < 2e-5
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("kernel", ["split", "pp"])
+def test_packed_image_follows_the_weights_when_the_module_dtype_differs(kernel):
+    """float64 module, float32 inputs: the fused block then works on per-call float32 CASTS of the weights -- fresh temporaries whose own
+    in-place version is always 0 and whose addresses the caching allocator reuses.  The packed image must still follow the module's
+    parameters through an optimizer-style in-place update and a load_state_dict (it was keyed on the temporaries)."""
+    from jammy_flows_amd import _hip
+    fx = [f for f in ALL_FIXTURES if f.name == "g_e3_ggg_cond"][0]
+    pdf = build_product(fx, torch.float64)                       # module stays float64
+    pdf.fused_block_kernel = kernel
+    x = to_dev(fx["x"], torch.float32)
+    cond = to_dev(fx.get("cond"), torch.float32)
+    pdf.check_status = False
+    timer = _hip.KernelTimer()
+    with timer:
+        a = pdf(x, conditional_input=cond)[0]
+    assert any(k[0] == "jf_cond_gf_chain_inv_%s_f32" % kernel for k in timer.summary()), sorted(timer.summary())
+    for _ in range(3):                                           # same weights: same image, same result
+        assert torch.equal(a, pdf(x, conditional_input=cond)[0])
+    with torch.no_grad():
+        pdf.mlp_predictors[0][2].bias.add_(0.01)
+        pdf.mlp_predictors[0][2].weight.mul_(1.001)
+    b = pdf(x, conditional_input=cond)[0]
+    pdf.fused_matrix_arithmetic = "f32"
+    c = pdf(x, conditional_input=cond)[0]
+    pdf.fused_matrix_arithmetic = "split_bf16"
+    fin = torch.isfinite(a) & torch.isfinite(b) & torch.isfinite(c)
+    assert float((a - b)[fin].abs().max()) > 1e-4, "stale packed weights were used"
+    assert float(((b - c)[fin].abs() / (1 + c[fin].abs())).max()) < 2e-5
+    sd = {k: v.clone() for k, v in pdf.state_dict().items()}
+    sd["mlp_predictors.0.2.bias"] = sd["mlp_predictors.0.2.bias"] - 0.01
+    sd["mlp_predictors.0.2.weight"] = sd["mlp_predictors.0.2.weight"] / 1.001
+    pdf.load_state_dict(sd)
+    d = pdf(x, conditional_input=cond)[0]
+    assert float(((a - d)[fin].abs() / (1 + a[fin].abs())).max()) < 1e-5
+
+
 def test_transform_target_space_keeps_the_s2_jacobian_for_scalar_log_det():
     """public default log_det=0 (a python number): the +-log sin(theta) of S2 must come back as a tensor (sphere_base.py:242-335, 796-841)"""
     import jammy_flows_amd
@@ -642,7 +681,7 @@ def test_c_abi_error_codes():
     assert call(n_layers=_hip.JF_MAX_CHAIN + 1) == _hip.JF_ERR_BADARG
     assert call(xptr=None) == _hip.JF_ERR_BADARG
     assert call(pb=3) == _hip.JF_ERR_BADARG                      # param_batch must be 1 or B
-    assert call(D=9) == _hip.JF_ERR_UNSUPPORTED
+    assert call(D=33) == _hip.JF_ERR_UNSUPPORTED           # groups of up to 32 lanes per row
     assert call(B=0) == _hip.JF_OK                                # empty batch: nothing launched
     L.width_min = 0.0
     assert call(layers=(_hip.jf_gf_layer * 1)(L)) == _hip.JF_ERR_BADARG
