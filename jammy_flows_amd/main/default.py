@@ -1128,6 +1128,53 @@ class pdf(nn.Module):
         logp = logp_x - (g_logp * delta).sum(dim=1)
         return x, base_ret, logp, logp_base
 
+    def obtain_flow_param_structure(self, conditional_input=None, predefined_target_input=None, seed=None, dtype=None, device=None):
+        """names and values of every layer's parameters for the given conditional input, walking the sampling direction layer by layer
+        (:1119-1287; debugging / plotting).  Keys: "<sub-pdf index>_<flow def>.<layer index>" -> ordered dict of named tensors."""
+        import collections
+        p0 = next(iter(self.parameters()), None)
+        data_type = dtype if dtype is not None else (p0.dtype if p0 is not None else torch.float64)
+        used_device = device if device is not None else (p0.device if p0 is not None else torch.device("cuda"))
+        n = 1
+        if conditional_input is not None:
+            first = conditional_input[0] if type(conditional_input) == list else conditional_input
+            n, data_type, used_device = first.shape[0], first.dtype, first.device
+        if predefined_target_input is not None:
+            x = predefined_target_input
+            if conditional_input is None:
+                n, data_type, used_device = x.shape[0], x.dtype, x.device
+        else:
+            if seed is not None:
+                numpy.random.seed(seed)
+            x = torch.from_numpy(numpy.random.normal(size=(n, self.total_base_dim))).to(dtype=data_type, device=used_device)
+        log_det = torch.zeros(n, dtype=data_type, device=used_device)
+        structure = collections.OrderedDict()
+        embeds = []
+        with torch.no_grad():
+            for si, block in enumerate(self.layer_list):
+                mlp = self.mlp_predictors[si] if len(self.mlp_predictors) > si else None
+                extra = None
+                if mlp is not None:
+                    pieces = []
+                    if conditional_input is not None:
+                        pieces.append(conditional_input[si] if type(conditional_input) == list else conditional_input)
+                    pieces += embeds
+                    if not pieces:
+                        raise Exception("SAMPLE: extra conditional input is empty but required for encoding!")
+                    extra = mlp(torch.cat(pieces, dim=1) if len(pieces) > 1 else pieces[0])
+                a, b = self.base_dim_indices[si]
+                cur = x[:, a:b]
+                c = 0
+                for li, layer in enumerate(block):
+                    this = None if extra is None else extra[:, c:c + layer.total_param_num]
+                    d = collections.OrderedDict()
+                    layer.obtain_layer_param_structure(d, extra_inputs=this, previous_x=cur)
+                    structure[("%.3d" % si) + "_" + self.flow_defs_list[si] + ".%.3d" % li] = d
+                    cur, log_det = layer.flow_mapping([cur, log_det], extra_inputs=this)[:2]
+                    c += layer.total_param_num
+                embeds.append(block[-1]._embedding_conditional_return(cur))
+        return structure
+
     def sample(self, conditional_input=None, samplesize=1, seed=None, allow_gradients=False, amortization_parameters=None,
                force_embedding_coordinates=False, force_intrinsic_coordinates=False, failsafe_crosscheck_tolerance=None, dtype=None,
                device=None, only_last=False):
