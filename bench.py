@@ -298,6 +298,170 @@ def kernel_accounting(kname, ktag, s):
     return 0, 0, False
 
 
+# ---------------------------------------------------------------------------------------------- sampling / training directions
+def _oracle_sample_chunk(args):
+    z, c = args
+    return _ORACLE.sample_from_base(z, c)[0]
+
+
+def cpu_baseline_sampling(workload, budget_s=12.0, chunk=1024):
+    """the numpy oracle's sampling direction (25 bisection + <= 20 Newton steps per layer, oracle/gf.py) on this box's host cores: bounded
+    sample, one single-threaded process per CPU of the cgroup quota"""
+    import multiprocessing as mp
+    w = WORKLOADS[workload]
+    quota = cpu_quota()
+    workers = max(1, int(round(quota))) if (quota is not None and quota >= 1) else min(os.cpu_count() or 1, 16)
+    ctx = mp.get_context("fork")
+    rng = np.random.default_rng(11)
+    fx_dim = {"c3": 10, "c5": 10}[workload]
+
+    def work(n_chunks):
+        _, c = make_inputs(workload, chunk * n_chunks, w["seed"])
+        z = rng.normal(size=(chunk * n_chunks, fx_dim))
+        return [(z[i * chunk:(i + 1) * chunk], None if c is None else c[i * chunk:(i + 1) * chunk]) for i in range(n_chunks)]
+    with ctx.Pool(workers, initializer=_oracle_init, initargs=(w["fixture"],)) as pool:
+        pool.map(_oracle_sample_chunk, work(workers))
+        t0 = time.time()
+        pool.map(_oracle_sample_chunk, work(workers))
+        est = time.time() - t0
+        rounds = int(max(1, min(64, budget_s / max(est, 1e-3))))
+        jobs = work(workers * rounds)
+        t0 = time.time()
+        pool.map(_oracle_sample_chunk, jobs, chunksize=1)
+        dt = time.time() - t0
+    n = chunk * workers * rounds
+    return {"value": n / dt, "unit": "samples/s", "cores": workers, "workers": workers, "kind": "port", "cpu_model": cpu_model(),
+            "cgroup_cpu_quota": quota, "host_logical_cpus": os.cpu_count(),
+            "sample": "%d rows of %s through the float64 numpy oracle's sampling direction (%d single-threaded processes x %d-row chunks), %.1f s"
+                      % (n, w["fixture"], workers, chunk, dt)}
+
+
+def other_direction(args, W, rank, local_rank, world):
+    """--direction sample | train: same launch / sharding / timing contract as the log-prob benchmark, one JSON line of the same shape."""
+    direction = args.direction
+    rows_default = W["rows"] if direction == "sample" else W["rows"] // 4          # training: 2^18 (c3) / 2^17 (c5) rows per GPU
+    if args.scaling == "weak":
+        B = args.batch if args.batch is not None else rows_default
+        total_rows = B * world
+    else:
+        total_rows = args.batch if args.batch is not None else rows_default
+        base, rem = divmod(total_rows, world)
+        B = base + (1 if rank < rem else 0)
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and direction == "sample":
+        cpu = cpu_baseline_sampling(args.workload)                      # before the GPU is touched (fork safety)
+
+    import torch
+    import torch.distributed as dist
+    import fixture_io
+    import helpers
+    from jammy_flows_amd import _hip, parallel
+
+    backend = os.environ.get("JF_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    n_ranks_seen = dist.get_world_size() if world > 1 else 1
+    fx = fixture_io.load(W["fixture"])
+    dtype = torch.float32 if W["dtype"] == "f32" else torch.float64
+    s = 4 if W["dtype"] == "f32" else 8
+    x64, c64 = make_inputs(args.workload, B, W["seed"] + rank)
+    pdf = helpers.build_product(fx, dtype, dev)
+    c = None if c64 is None else torch.from_numpy(c64).to(device=dev, dtype=dtype)
+    extra = {}
+    if direction == "sample":
+        torch.set_grad_enabled(False)
+        pdf.check_status = False
+        g = torch.Generator(device=dev).manual_seed(17 + rank)
+        z = torch.randn((B, pdf.total_base_dim), dtype=dtype, device=dev, generator=g)       # base points resident in HBM
+        gather = parallel.PipelinedGather(B, dtype, dev, tail_shape=(pdf.total_target_dim,)) if (world > 1 and total_rows % world == 0) else None
+        last = {}
+
+        def step():
+            xs, _, lp, _ = pdf._obtain_sample(conditional_input=c, predefined_target_input=z)
+            if gather is not None:
+                gather.submit(xs)
+            last["x"], last["lp"] = xs, lp
+
+        def finish():
+            if gather is not None:
+                gather.wait()
+        unit, metric = "samples/s", W["metric"].replace("log-prob evals/sec", "samples/sec")
+    else:
+        x = torch.from_numpy(x64).to(device=dev, dtype=dtype)
+        pdf.check_status = False
+        opt = torch.optim.Adam(pdf.parameters(), lr=1e-4)
+        last = {}
+
+        def step():
+            opt.zero_grad(set_to_none=True)
+            with torch.enable_grad():
+                loss = -pdf(x, conditional_input=c)[0].mean()
+            loss.backward()
+            if world > 1:
+                parallel.allreduce_gradients(pdf.parameters(), average=True)
+            opt.step()
+            last["loss"] = loss
+
+        def finish():
+            pass
+        unit, metric = "training rows/s", W["metric"].replace("log-prob evals/sec", "training rows/sec (forward + backward + Adam)")
+    timer = _hip.KernelTimer()
+    dt = parallel.timed_steps(step, args.steps, args.warmup, finish=finish, device=dev, timer=timer)
+    table = timer.summary()
+    parity = None
+    if rank == 0:
+        if direction == "sample":                                         # what was just timed, against the float64 oracle (2048 rows)
+            n_chk = min(2048, B)
+            ox, olp, _ = helpers.build_oracle(fx).sample_from_base(z[:n_chk].double().cpu().numpy(), None if c64 is None else c64[:n_chk])
+            ex = np.abs(last["x"][:n_chk].double().cpu().numpy() - ox)
+            fin = np.isfinite(ox).all(axis=1) & np.isfinite(ex).all(axis=1)
+            parity = {"max_abs_dx_vs_f64_oracle": float(ex[fin].max()), "rows_checked": int(fin.sum()),
+                      "max_abs_dlogp_vs_f64_oracle": float(np.abs(last["lp"][:n_chk].double().cpu().numpy() - olp)[fin].max()),
+                      "note": "float32 samples of rows whose float64 solution sits on a chart edge differ by the chart's float32 resolution" if s == 4 else None}
+        else:
+            extra["final_loss"] = float(last["loss"].item())
+    if world > 1:
+        dist.barrier()
+    if rank == 0:
+        dom = max(table.items(), key=lambda kv: kv[1]["total_ms"])
+        (kname, ktag), kstat = dom
+        secs = kstat["mean_ms"] * 1e-3
+        bytes_per_row, flops_per_row, fused = kernel_accounting(kname.replace("_fwd", "_inv"), ktag, s)
+        if bytes_per_row is None or bytes_per_row == 0:
+            P = {"c3": 548, "c5": 1224}[args.workload]
+            D = {"c3": 4, "c5": 8}[args.workload]
+            mult = 3 if kname.endswith("_bwd" + ("_f32" if s == 4 else "_f64")) else 1      # adjoint: parameters read twice, their gradient written
+            bytes_per_row = s * (mult * P + (2 + mult) * (D + 1))
+        gbs = bytes_per_row * B / secs / 1e9
+        roofline = {"bound": "hbm", "kernel": "%s[%s]" % (kname, ktag), "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                    "traffic": None, "mean_launch_ms": kstat["mean_ms"], "launches_per_step": kstat["launches"] / args.steps,
+                    "algorithmic_bytes_per_launch": bytes_per_row * B,
+                    "all_kernels_ms_per_step": {"%s[%s]" % k: round(v["total_ms"] / args.steps, 4) for k, v in sorted(table.items())}}
+        line = {"metric": metric, "value": total_rows * args.steps / dt, "unit": unit, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": W["dtype"],
+                "data": "synthetic (seeded; weights = frozen golden-fixture state_dict)",
+                "config": {"workload": 'pdf("%s","%s") %s, %s, %d rows %s' % (W["defs"][0], W["defs"][1], direction, W["desc"],
+                                                                            B if args.scaling == "weak" else total_rows,
+                                                                            "per GPU" if args.scaling == "weak" else "in total, row-sharded"),
+                           "direction": direction, "batch_per_gpu": B, "total_rows": total_rows, "parallelism": "rows sharded over %d GPU(s)" % world},
+                "n_ranks_seen": n_ranks_seen, "collective_backend": dist.get_backend() if world > 1 else None, "parity": parity,
+                "roofline": roofline, "cpu_baseline": cpu}
+        if direction == "train":
+            line["cpu_baseline_note"] = "the oracle restates the forward arithmetic only: no CPU training baseline travels to the GPU box"
+        line.update(extra)
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+    return 0
+
+
 # ---------------------------------------------------------------------------------------------- self-launch for N > 1
 def free_port():
     import socket
@@ -377,12 +541,19 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="rows per GPU (weak) / total rows (strong); default: the BASELINE configuration")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="do not run the rocprofv3 PMC child passes (traffic then comes from the committed profile)")
+    ap.add_argument("--direction", choices=("logprob", "sample", "train"), default="logprob",
+                    help="logprob (default; the contract metric): pdf.forward.  sample: pdf sampling from resident base points (bisection + Newton "
+                         "kernels).  train: forward + backward + Adam step of -mean(log p) (the reference's training objective), rows = 1/4 of the "
+                         "log-prob batch, gradients all-reduced over the ranks")
+    ap.add_argument("--train", action="store_true", help="same as --direction train")
     ap.add_argument("--no-fuse", action="store_true", help="time the two-launch path (MLP launch + flow launch) instead of the fused conditional block")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--dry-run", action="store_true",
                     help="exercise launch / rendezvous / row sharding / timing loop / all-gather with a stand-in step on the host (no GPU, no kernels): "
                          "the line carries \"dry_run\": true and no throughput claim.  For the CPU tests (JF_BENCH_BACKEND=gloo)")
     args = ap.parse_args()
+    if args.train:
+        args.direction = "train"
     W = WORKLOADS[args.workload]
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.pmc_child:
@@ -407,6 +578,8 @@ def main():
 
     if args.dry_run:
         return dry_run(args, W, rank, world, B, total_rows, lo)
+    if args.direction != "logprob":
+        return other_direction(args, W, rank, local_rank, world)
 
     cpu = None
     traffic = None

@@ -149,6 +149,14 @@ int jf_cond_gf_chain_inv_f64(const double* in, int64_t in_stride, const double* 
  * JF_ERR_UNSUPPORTED; jf_cond_gf_pack_f32 builds it from W2 (N, H) / b2 (N) -- redo whenever the weights change (one small launch);
  * jf_cond_gf_chain_inv_split_f32 = jf_cond_gf_chain_inv_f32 with (W2, b2) replaced by the packed image. */
 int64_t jf_cond_gf_packed_bytes(int32_t D, int32_t n_layers, const jf_gf_layer* layers);
+/* The SAMPLING direction of the same block in one launch (amortisation MLP + the g layers' bisection / Newton solves, first layer first;
+ * main/default.py:1420-1506 with gaussianization_flow.py:911-989 and bisection_n_newton.py:11-135): same packed image, same limits.  Each
+ * layer's parameters are regulated once in the MFMA result registers and the 25 + <= 20 mixture evaluations of its solve read registers only.
+ * z: base points (B, D); status counts Newton row-steps / non-converged / non-finite rows like jf_gf_chain_fwd. */
+int jf_cond_gf_chain_fwd_split_f32(const float* in, int64_t in_stride, const float* W1, int64_t w1_stride, const float* b1, const void* packed,
+                                   int32_t K1, int32_t H, const float* z, int64_t z_stride, const float* log_det_in, int64_t B, int32_t D,
+                                   int32_t n_layers, const jf_gf_layer* layers, float* x_out, int64_t x_out_stride, float* log_det_out,
+                                   int32_t* status, void* stream);
 /* Third generation of the same block ("ping-pong", cond_pp_kernels.hip): 32x32x16 bf16 tiles (one MFMA per 32 cycles leaves the vector ALU
  * ~20 free issue cycles, a 16x16x32 one ~4), persistent 512-thread workgroups whose two four-wave teams run the same program half a layer
  * apart, so that on every SIMD one wave multiplies while its partner evaluates the flow.  Same arithmetic (3-way split bf16, six products, f32

@@ -149,6 +149,8 @@ _SIGNATURES_SINGLE = {
     "jf_linear_split_f32": ([_P, _I64, _P, _P, _I64, _I32, _I32, _P, _I64, _P], ctypes.c_int),
     "jf_cond_gf_packed_bytes": ([_I32, _I32, ctypes.POINTER(jf_gf_layer)], ctypes.c_int64),
     "jf_cond_gf_split_row_groups": ([_I32], ctypes.c_int),
+    "jf_cond_gf_chain_fwd_split_f32": ([_P, _I64, _P, _I64, _P, _P, _I32, _I32, _P, _I64, _P, _I64, _I32, _I32, ctypes.POINTER(jf_gf_layer), _P, _I64,
+                                        _P, _P, _P], ctypes.c_int),
     "jf_cond_gf_pp_packed_bytes": ([_I32, _I32, ctypes.POINTER(jf_gf_layer)], ctypes.c_int64),
     "jf_cond_gf_pp_pack_f32": ([_P, _I64, _P, _I32, _I32, _I32, ctypes.POINTER(jf_gf_layer), _P, _P], ctypes.c_int),
     "jf_cond_gf_chain_inv_pp_f32": ([_P, _I64, _P, _I64, _P, _P, _I32, _I32, _P, _I64, _P, _I64, _I32, _I32, ctypes.POINTER(jf_gf_layer), _P, _I64,
@@ -532,6 +534,28 @@ def cond_gf_chain_inv_split(inp, w1, b1, packed, x, log_det, layer_array, n_laye
             (_ptr(inp), inp.stride(0), _ptr(w1), w1.stride(0), _ptr(b1.contiguous()), _ptr(packed), K1, H, _ptr(x), x.stride(0), _ptr(log_det), B, D,
              n_layers, layer_array, _ptr(x_out), x_out.stride(0), _ptr(ld_out), _ptr(base_logp_in), _ptr(blp_out), _ptr(status)), dev)
     return (x_out, ld_out, blp_out) if want_base_logp else (x_out, ld_out)
+
+
+def cond_gf_chain_fwd_split(inp, w1, b1, packed, z, log_det, layer_array, n_layers, D, x_out=None, status=None):
+    """sampling direction of a conditional e-block in one launch (amortisation MLP + bisection / Newton solves on register-resident
+    parameters); `packed`: the "split" image of cond_gf_pack."""
+    dev = require_device(inp, w1, b1, packed, z, log_det, x_out, status)
+    inp, w1, z = _rowmajor(inp), _rowmajor(w1), _rowmajor(z)
+    B, K1 = inp.shape
+    H = w1.shape[0]
+    if z.shape[0] != B or z.shape[1] != D or w1.shape[1] != K1 or b1.shape[0] != H:
+        raise ValueError("cond_gf_chain_fwd_split: inconsistent shapes")
+    if any(t.dtype != torch.float32 for t in (inp, w1, b1, z)) or packed.dtype != torch.uint8:
+        raise TypeError("cond_gf_chain_fwd_split: float32 inputs and a uint8 packed image expected")
+    if log_det is not None:
+        log_det = log_det.contiguous()
+    if x_out is None:
+        x_out = torch.empty((B, D), dtype=z.dtype, device=z.device)
+    ld_out = torch.empty((B,), dtype=z.dtype, device=z.device)
+    _launch("jf_cond_gf_chain_fwd_split_f32", "K%d_H%d_L%d_D%d" % (K1, H, n_layers, D),
+            (_ptr(inp), inp.stride(0), _ptr(w1), w1.stride(0), _ptr(b1.contiguous()), _ptr(packed), K1, H, _ptr(z), z.stride(0), _ptr(log_det), B, D,
+             n_layers, layer_array, _ptr(x_out), x_out.stride(0), _ptr(ld_out), _ptr(status)), dev)
+    return x_out, ld_out
 
 
 def linear(inp, weight, bias=None, act=0, out=None):

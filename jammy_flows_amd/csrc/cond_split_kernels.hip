@@ -118,7 +118,7 @@ struct CsArgs {
 
 // RG = row groups (16 rows each) per wave.  With RG = 2 every A fragment read from LDS feeds two MFMAs (half the ds_read_b128 per row,
 // six independent accumulators per piece product instead of three) and the chunk barriers are paid once per 128 rows instead of 64.
-template <int RG> __global__ void __launch_bounds__(256, 2) cond_gf_split_kernel(const CsArgs a) {
+template <int RG, bool FWD> __global__ void __launch_bounds__(256, 2) cond_gf_split_kernel(const CsArgs a) {
     constexpr int CS_ROWS = CS_ROWS1 * RG;
     using MF = Mfma16<float>;
     constexpr int MT = 16, KS = 4, NREG = 4, JH = CS_HMAX / MT;
@@ -142,7 +142,9 @@ template <int RG> __global__ void __launch_bounds__(256, 2) cond_gf_split_kernel
         __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(a.packed), 0, a.n_layers * CS_CPL * CS_CHUNK_BYTES, 0x00027000);
     const int lane_off = wave * 1024 + lane * 16;
     auto dma = [&](int chunk) {
-        const int g = chunk * CS_CHUNK_BYTES;
+        // the packed image is in the log-prob direction's consumption order (last layer first); the sampling direction walks the layers forwards
+        const int img = FWD ? (a.n_layers - 1 - chunk / CS_CPL) * CS_CPL + chunk % CS_CPL : chunk;
+        const int g = img * CS_CHUNK_BYTES;
         unsigned char* l = Ws0 + (chunk & 1) * CS_CHUNK_BYTES;
 #pragma unroll
         for (int u = 0; u < CS_W_BYTES / 4096; ++u)
@@ -242,7 +244,8 @@ template <int RG> __global__ void __launch_bounds__(256, 2) cond_gf_split_kernel
     const int n_chunks = a.n_layers * CS_CPL;
     landed();                                                      // chunk 0 is in buffer 0 and every wave is done with Xs / W1s / b1s (buffer 1)
     int chunk = 0;
-    for (int l = a.n_layers - 1; l >= 0; --l) {
+    for (int li = 0; li < a.n_layers; ++li) {
+        const int l = FWD ? li : a.n_layers - 1 - li;
         float P[RG][CS_SLOTS];
 #pragma unroll
         for (int c = 0; c < CS_CPL; ++c, ++chunk) {
@@ -293,19 +296,37 @@ template <int RG> __global__ void __launch_bounds__(256, 2) cond_gf_split_kernel
         const CsLayer o = a.L[l];                                  // uniform index: scalar loads from the kernarg segment
 #pragma unroll
         for (int g = 0; g < RG; ++g) {
-            float xg = x[g] - P[g][CS_SLOT_OFF];                   // euclidean_base.py:40-45 (zero column when the layer models no offset)
+            if constexpr (!FWD) {
+                float xg = x[g] - P[g][CS_SLOT_OFF];               // euclidean_base.py:40-45 (zero column when the layer models no offset)
 #pragma unroll
-            for (int i = 0; i < CS_HH; ++i) {
-                if (i < o.hh) {                                    // x <- Q^T x (gaussianization_flow.py:1038), H_i = I - 2 v v^T / |v|^2
-                    const float v = live ? P[g][CS_SLOT_ROT + i] : 0.f;
-                    const float n2 = cs_rsum(v * v), dot = cs_rsum(v * xg);
-                    xg -= 2.0f * dot * M<float>::rcp(n2) * v;
+                for (int i = 0; i < CS_HH; ++i) {
+                    if (i < o.hh) {                                // x <- Q^T x (gaussianization_flow.py:1038), H_i = I - 2 v v^T / |v|^2
+                        const float v = live ? P[g][CS_SLOT_ROT + i] : 0.f;
+                        const float n2 = cs_rsum(v * v), dot = cs_rsum(v * xg);
+                        xg -= 2.0f * dot * M<float>::rcp(n2) * v;
+                    }
                 }
+                const MixQ<float> q = cs_mixture(P[g], o, xg, live);
+                const IcdfOut<float> sy = gf_icdf<float>(o.inv_type, q);
+                x[g] = sy.y;
+                ld[g] += cs_rsum(live ? sy.logd : 0.f);
+            } else {
+                // sampling direction (gaussianization_flow.py:911-989): regulate the row once in its registers, solve stage(mixture(x)) = z by
+                // 25 bisection + <= 20 Newton steps, log-det from the solution, then x <- Q x and the offset (euclidean_base.py:63-68)
+                cs_derive(P[g], o);
+                float xs = cs_solve(P[g], o, live, x[g], row_valid[g], leader, a.status, [](float v) { return cs_rsum(v); },
+                                    [](float v) { return cs_rmax(v); });
+                ld[g] -= cs_rsum(live ? gf_icdf<float>(o.inv_type, cs_mixture_derived(P[g], xs)).logd : 0.f);
+#pragma unroll
+                for (int i = CS_HH - 1; i >= 0; --i) {
+                    if (i < o.hh) {
+                        const float v = live ? P[g][CS_SLOT_ROT + i] : 0.f;
+                        const float n2 = cs_rsum(v * v), dot = cs_rsum(v * xs);
+                        xs -= 2.0f * dot * M<float>::rcp(n2) * v;
+                    }
+                }
+                x[g] = xs + P[g][CS_SLOT_OFF];
             }
-            const MixQ<float> q = cs_mixture(P[g], o, xg, live);
-            const IcdfOut<float> sy = gf_icdf<float>(o.inv_type, q);
-            x[g] = sy.y;
-            ld[g] += cs_rsum(live ? sy.logd : 0.f);
         }
         landed();
     }
@@ -313,14 +334,18 @@ template <int RG> __global__ void __launch_bounds__(256, 2) cond_gf_split_kernel
 #pragma unroll
     for (int g = 0; g < RG; ++g) {
         if (row_valid[g] && live) a.x_out[row[g] * a.xos + d] = x[g];
-        float sb = 0.f;
-        if (a.blp_out) sb = cs_rsum(live ? -0.5f * x[g] * x[g] - M<float>::HALF_LN_2PI : 0.f);
-        if (row_valid[g] && leader) {
-            a.ld_out[row[g]] = ld[g];
-            if (a.blp_out) a.blp_out[row[g]] = sb + (a.blp_in ? a.blp_in[row[g]] : 0.f);
+        if constexpr (FWD) {
+            if (row_valid[g] && leader) a.ld_out[row[g]] = ld[g];
+        } else {
+            float sb = 0.f;
+            if (a.blp_out) sb = cs_rsum(live ? -0.5f * x[g] * x[g] - M<float>::HALF_LN_2PI : 0.f);
+            if (row_valid[g] && leader) {
+                a.ld_out[row[g]] = ld[g];
+                if (a.blp_out) a.blp_out[row[g]] = sb + (a.blp_in ? a.blp_in[row[g]] : 0.f);
+            }
+            const float bad = cs_rmax((live && !M<float>::finite(x[g])) ? 1.f : 0.f);
+            status_add(a.status, JF_STATUS_NONFINITE, row_valid[g] && leader && (bad > 0.f || !M<float>::finite(ld[g])));
         }
-        const float bad = cs_rmax((live && !M<float>::finite(x[g])) ? 1.f : 0.f);
-        status_add(a.status, JF_STATUS_NONFINITE, row_valid[g] && leader && (bad > 0.f || !M<float>::finite(ld[g])));
     }
 }
 
@@ -359,6 +384,7 @@ static int cs_pack(const float* W2, int64_t w2s, const float* b2, int32_t H, int
     return hipPeekAtLastError() == hipSuccess ? JF_OK : JF_ERR_LAUNCH;
 }
 
+template <bool FWD>
 static int cs_chain(const float* in, int64_t in_stride, const float* W1, int64_t w1s, const float* b1, const void* packed, int32_t K1, int32_t H,
                     const float* x, int64_t xs, const float* ld_in, int64_t B, int32_t D, int32_t n_layers, const jf_gf_layer* layers, float* x_out,
                     int64_t xos, float* ld_out, const float* blp_in, float* blp_out, int32_t* status, void* stream) {
@@ -380,8 +406,8 @@ static int cs_chain(const float* in, int64_t in_stride, const float* W1, int64_t
     const size_t lds = 2 * CS_CHUNK_BYTES;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)cond_gf_split_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute((const void*)cond_gf_split_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)cond_gf_split_kernel<1, FWD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)cond_gf_split_kernel<2, FWD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     // two row groups per wave once that still leaves every CU several workgroups; JF_CS_RG=1|2 (environment, read once) or
@@ -389,8 +415,8 @@ static int cs_chain(const float* in, int64_t in_stride, const float* W1, int64_t
     static const int env_rg = getenv("JF_CS_RG") ? atoi(getenv("JF_CS_RG")) : 0;
     const int force_rg = cs_forced_rg ? cs_forced_rg : env_rg;
     const bool two = force_rg ? force_rg == 2 : B >= (int64_t)CS_ROWS1 * 2 * 1024;
-    if (two) hipLaunchKernelGGL(cond_gf_split_kernel<2>, dim3((unsigned)((B + 2 * CS_ROWS1 - 1) / (2 * CS_ROWS1))), dim3(256), lds, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(cond_gf_split_kernel<1>, dim3((unsigned)((B + CS_ROWS1 - 1) / CS_ROWS1)), dim3(256), lds, (hipStream_t)stream, a);
+    if (two) hipLaunchKernelGGL((cond_gf_split_kernel<2, FWD>), dim3((unsigned)((B + 2 * CS_ROWS1 - 1) / (2 * CS_ROWS1))), dim3(256), lds, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((cond_gf_split_kernel<1, FWD>), dim3((unsigned)((B + CS_ROWS1 - 1) / CS_ROWS1)), dim3(256), lds, (hipStream_t)stream, a);
     return hipPeekAtLastError() == hipSuccess ? JF_OK : JF_ERR_LAUNCH;
 }
 
@@ -414,6 +440,11 @@ int jf_cond_gf_pack_f32(const float* W2, int64_t w2s, const float* b2, int32_t H
 int jf_cond_gf_chain_inv_split_f32(const float* in, int64_t is, const float* W1, int64_t w1s, const float* b1, const void* packed, int32_t K1,
                                    int32_t H, const float* x, int64_t xs, const float* ld_in, int64_t B, int32_t D, int32_t n,
                                    const jf_gf_layer* L, float* xo, int64_t xos, float* ldo, const float* bi, float* bo, int32_t* st, void* s) {
-    return jf::cs_chain(in, is, W1, w1s, b1, packed, K1, H, x, xs, ld_in, B, D, n, L, xo, xos, ldo, bi, bo, st, s);
+    return jf::cs_chain<false>(in, is, W1, w1s, b1, packed, K1, H, x, xs, ld_in, B, D, n, L, xo, xos, ldo, bi, bo, st, s);
+}
+int jf_cond_gf_chain_fwd_split_f32(const float* in, int64_t is, const float* W1, int64_t w1s, const float* b1, const void* packed, int32_t K1,
+                                   int32_t H, const float* z, int64_t zs, const float* ld_in, int64_t B, int32_t D, int32_t n,
+                                   const jf_gf_layer* L, float* xo, int64_t xos, float* ldo, int32_t* st, void* s) {
+    return jf::cs_chain<true>(in, is, W1, w1s, b1, packed, K1, H, z, zs, ld_in, B, D, n, L, xo, xos, ldo, nullptr, nullptr, st, s);
 }
 }

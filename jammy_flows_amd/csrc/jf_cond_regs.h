@@ -97,4 +97,128 @@ __device__ __forceinline__ MixQ<float> cs_mixture(const float (&P)[CS_SLOTS], co
     return q;
 }
 
+// ---------------------------------------------------------------------------------------------------------- sampling direction on register rows
+// gf_derive_column / gfg_mixture_impl<float, false, true> / gfg_mixture_scaled<float, false> / gfg_solve (jf_gf.h) with the lane's parameters in
+// registers: the raw row P is regulated ONCE in place (log-width slots -> 1 / width, log-weight slots -> normalised weight), then the 25
+// bisection + <= 20 Newton evaluations of a layer (bisection_n_newton.py:11-135, called from gaussianization_flow.py:921) read registers only
+// -- the staged-row kernel reads three LDS words per component and evaluation.
+__device__ __forceinline__ void cs_derive(float (&P)[CS_SLOTS], const CsLayer& o) {
+    using Mf = M<float>;
+    float Nn = 0.f;
+#pragma unroll
+    for (int k = 0; k < CS_K; ++k) {
+        const float ae = o.inv_wmax + Mf::exp_fast(-P[CS_SLOT_LW + k]);
+        P[CS_SLOT_LW + k] = ae * Mf::rcp(o.wmin * ae + 1.0f);
+        const float w = o.nmin + o.nmax * Mf::rcp(1.0f + Mf::exp_fast(-P[CS_SLOT_LN + k]));
+        P[CS_SLOT_LN + k] = w;
+        Nn += w;
+    }
+    const float inv = Mf::rcp(Nn);
+#pragma unroll
+    for (int k = 0; k < CS_K; ++k) P[CS_SLOT_LN + k] *= inv;
+}
+
+__device__ __forceinline__ MixQ<float> cs_mixture_derived(const float (&P)[CS_SLOTS], float x) {
+    using Mf = M<float>;
+    float C = 0.f, S = 0.f, Pd = 0.f;
+#pragma unroll
+    for (int k = 0; k < CS_K; ++k) {
+        const float iw = P[CS_SLOT_LW + k], wk = P[CS_SLOT_LN + k];
+        const float u = (x - P[CS_SLOT_MEAN + k]) * iw;
+        const float t = Mf::exp_fast(-fabsf(u));
+        const float hi = Mf::rcp(1.0f + t);
+        const float lo = t * hi;
+        const bool pos = u >= 0.f;
+        C += wk * (pos ? hi : lo);
+        S += wk * (pos ? lo : hi);
+        Pd += wk * hi * lo * iw;
+    }
+    MixQ<float> q;
+    q.lc = Mf::log_fast(C); q.ls = Mf::log_fast(S); q.lp = Mf::log_fast(Pd);
+    q.cdf = C; q.sf = S;
+    const bool under = !(C > Mf::TINY && S > Mf::TINY && Pd > Mf::TINY);
+    if (__any(under)) {                                            // wave-uniform: sums scaled by e^{m}, m = distance to the nearest component
+        float m = INFINITY;
+#pragma unroll
+        for (int k = 0; k < CS_K; ++k) m = fminf(m, fabsf((x - P[CS_SLOT_MEAN + k]) * P[CS_SLOT_LW + k]));
+        const float em = Mf::exp_fast(-m);
+        float Cu = 0.f, Cs = 0.f, Su = 0.f, Ss = 0.f, Ps = 0.f;
+#pragma unroll
+        for (int k = 0; k < CS_K; ++k) {
+            const float iw = P[CS_SLOT_LW + k], wk = P[CS_SLOT_LN + k];
+            const float u = (x - P[CS_SLOT_MEAN + k]) * iw;
+            const float t = Mf::exp_fast(m - fabsf(u));
+            const float hi = Mf::rcp(1.0f + t * em);
+            const float c1 = wk * hi, c2 = c1 * t;
+            if (u >= 0.f) { Cu += c1; Ss += c2; }
+            else { Su += c1; Cs += c2; }
+            Ps += c2 * hi * iw;
+        }
+        if (under) {
+            q.cdf = Cu + em * Cs;
+            q.sf = Su + em * Ss;
+            q.lc = Cu > 0.f ? Mf::log_fast(q.cdf) : Mf::log_fast(Cs) - m;
+            q.ls = Su > 0.f ? Mf::log_fast(q.sf) : Mf::log_fast(Ss) - m;
+            q.lp = Mf::log_fast(Ps) - m;
+        }
+    }
+    return q;
+}
+
+// x with stage(mixture(x)) = z: gfg_solve's decisions step for step (far-midpoint skip, stopping rules, status counters); RSUM / RMAX reduce
+// over the lanes that hold the coordinates of one row
+template <typename RSUM, typename RMAX>
+__device__ __forceinline__ float cs_solve(const float (&P)[CS_SLOTS], const CsLayer& o, bool live, float z, bool row_valid, bool leader, int32_t* status,
+                                          RSUM rsum, RMAX rmax) {
+    using Mf = M<float>;
+    float lo = -1e5f, hi = 1e5f, x = 0.f;
+    constexpr float FAR = 100.f;
+    float lo_b = INFINITY, hi_b = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < CS_K; ++k) {
+        const float mu = P[CS_SLOT_MEAN + k], w = Mf::rcp(P[CS_SLOT_LW + k]);
+        lo_b = fminf(lo_b, mu - FAR * w);
+        hi_b = fmaxf(hi_b, mu + FAR * w);
+    }
+    const bool can_skip = fabsf(z) < 8.f;
+    for (int it = 0; it < 25; ++it) {
+        x = (hi + lo) * 0.5f;
+        const bool far_r = can_skip && x > hi_b, far_l = can_skip && x < lo_b;
+        if (__all(far_r || far_l)) {                               // wave-uniform
+            if (far_r) hi = x; else lo = x;
+            continue;
+        }
+        const float y = gf_icdf<float>(o.inv_type, cs_mixture_derived(P, x)).y;
+        const bool ok = fabsf(y - z) <= 1e-6f * fabsf(z);
+        if (ok) { lo = x; hi = x; }
+        else if (y < z) lo = x;
+        else hi = x;
+    }
+    bool active = row_valid;
+    float ferr = 0.f, prev = INFINITY;
+    bool nonfinite = false;
+    for (int it = 0; it < 20 && __any(active); ++it) {
+        const IcdfOut<float> s = gf_icdf<float>(o.inv_type, cs_mixture_derived(P, x));
+        const float f = s.y - z;
+        const float upd = f / Mf::exp(s.logd);
+        const float usum = rsum(live ? fabsf(upd) : 0.f);
+        status_add(status, JF_STATUS_NEWTON_STEPS, active && leader);
+        if (active) {
+            const float nx = x - upd;
+            if (Mf::finite(nx)) x = nx; else nonfinite = nonfinite || live;
+            ferr = fabsf(f);
+            active = usum >= 1e-14f;
+        }
+        // float32 floor of the update (see gfg_solve): the reference's float32 runs spend their last ~16 Newton steps on rounding noise
+        const float xs = rsum(live ? fmaxf(fabsf(x), 1.f) : 0.f);
+        if (usum < 2.5e-7f * xs || (usum >= 0.5f * prev && usum < 1e-4f * xs)) active = false;
+        prev = usum;
+    }
+    const float ferr_row = rmax(live ? ferr : 0.f);
+    const float nf_row = rmax(nonfinite ? 1.f : 0.f);
+    status_add(status, JF_STATUS_NONCONVERGED, row_valid && leader && (ferr_row > 1e-4f));
+    status_add(status, JF_STATUS_NONFINITE, row_valid && leader && (nf_row > 0.f));
+    return x;
+}
+
 }  // namespace jf

@@ -566,12 +566,12 @@ class pdf(nn.Module):
         # measured at 2^20 rows (profiles/r03_pp_*.md): pp 0.77 ms, split 0.775 ms -- no gain yet, and pp needs >= 256 row tiles to fill the chip
         return "split"
 
-    def _packed_w2(self, si, w2, b2, layer_array, n_layers, D, n_rows):
+    def _packed_w2(self, si, w2, b2, layer_array, n_layers, D, n_rows, kind=None):
         """(kind, packed split-bf16 image) of the block's output layer for the fused kernel chosen for this batch size, or None when the layer
         options are outside the kernels' set.  Rebuilt when the weights change: the key is the identity and in-place version of the MODULE's
         parameters (w2 / b2 may be casts of them made for this call -- fresh temporaries whose own version is always 0 and whose addresses
         the caching allocator hands out again), plus dtype, device and kernel kind."""
-        kind = self._fused_kernel_kind(n_rows)
+        kind = kind or self._fused_kernel_kind(n_rows)
         lin = self.mlp_predictors[si][2]
         key = (id(lin.weight), lin.weight._version, lin.weight.data_ptr(), id(lin.bias), lin.bias._version, lin.bias.data_ptr(), str(w2.dtype),
                str(w2.device), kind)
@@ -1000,13 +1000,27 @@ class pdf(nn.Module):
         embeds = []
         counter = 0
         for si, block in enumerate(self.layer_list):
+            kind = self.pdf_defs_list[si][0]
+            layers = list(block)
+            fused = self._fusable_block(si, layers, only_last, amortization_parameters, x.dtype) if kind == "e" else None
+            if fused is not None and self.fused_matrix_arithmetic == "split_bf16" and fused[0].shape[0] <= 128:
+                # amortisation MLP + the g layers' solves in one launch, parameters regulated once in the MFMA result registers
+                larr = _hip.gf_layer_array([l.c_struct() for l in layers])
+                packed = self._packed_w2(si, fused[2], fused[3], larr, len(layers), layers[0].dimension, 0, kind="split")
+                if packed is not None:
+                    ba, bb = self.base_dim_indices[si]
+                    a, b = self.target_dim_indices[si]
+                    _, log_det = _hip.cond_gf_chain_fwd_split(self._mlp_input(si, data_summary, embeds), fused[0], fused[1], packed[1], x[:, ba:bb],
+                                                              log_det, larr, len(layers), layers[0].dimension, x_out=out[:, a:b], status=status)
+                    embeds.append(block[-1]._embedding_conditional_return(out[:, a:b]))
+                    if per_block is not None:
+                        per_block.append(log_det)
+                    continue
             extra, counter = self._block_params(si, data_summary, embeds, amortization_parameters, counter)
             ba, bb = self.base_dim_indices[si]
             cur = x[:, ba:bb]
             a, b = self.target_dim_indices[si]
             out_view = out[:, a:b]
-            kind = self.pdf_defs_list[si][0]
-            layers = list(block)
             if only_last:
                 if kind not in "es":
                     raise Exception("Flow type ", kind, " does not supported *only_last*!")
@@ -1083,9 +1097,11 @@ class pdf(nn.Module):
                 assert z.shape[0] == ci.shape[0] and z.dtype == ci.dtype and z.device == ci.device
             base_ret = 0.0
         else:
-            if seed is not None:
+            if seed is not None:                 # reproducible draws: the reference's own generator and call (:1634-1657), on the host
                 numpy.random.seed(seed)
-            z = torch.from_numpy(numpy.random.normal(size=(used, self.total_base_dim))).type(dt).to(dev)
+                z = torch.from_numpy(numpy.random.normal(size=(used, self.total_base_dim))).type(dt).to(dev)
+            else:                                # unseeded: drawn on the device (the host generator + copy cost 30x the sampling kernels)
+                z = torch.randn((used, self.total_base_dim), dtype=dt, device=dev)
             base_ret = z
         _hip.require_device(z)
         status = _hip.new_status(z.device) if self.check_status else None

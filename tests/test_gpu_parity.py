@@ -391,6 +391,42 @@ def test_fused_conditional_block_vs_golden_and_two_launch_path(name):
         assert max_abs(out[mode][2][sel], out["two"][2][sel]) < 2e-3, mode
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(FUSABLE))
+def test_fused_sampling_block_vs_golden_and_two_launch_path(name):
+    """sampling direction of a conditional e-block in one launch (jf_cond_gf_chain_fwd_split_f32: amortisation MLP on split-bf16 MFMA, the
+    layers' bisection / Newton solves on register-resident parameters): asserted by kernel name, held to the float64 reference samples like
+    the staged-row path, compared with that path row by row, and its Newton row-step count stays in the band of the staged-row kernel's"""
+    from jammy_flows_amd import _hip
+    fx = [f for f in ALL_FIXTURES if f.name == name][0]
+    pdf = build_product(fx, torch.float32)
+    pdf.check_status = False
+    rx, rl = np.asarray(fx["sample_x"], dtype=np.float64), np.asarray(fx["sample_logp"], dtype=np.float64)
+    ok = np.isfinite(rl) & (np.abs(np.asarray(fx["z"])).max(axis=1) < 2.99)      # the drawn rows (the adversarial |z| >= 3 rows overflow float32 charts)
+    rx, rl = rx[ok], rl[ok]
+    z = to_dev(fx["z"][ok], torch.float32)
+    cond = to_dev(None if fx.get("cond") is None else fx["cond"][ok], torch.float32)
+    emb = bool(fx.meta["embedding"])
+    out, steps = {}, {}
+    for mode in ("two", "fused"):
+        pdf.fuse_conditional_blocks = mode == "fused"
+        pdf.check_status = True
+        timer = _hip.KernelTimer()
+        with timer:
+            out[mode] = pdf._obtain_sample(conditional_input=cond, predefined_target_input=z, force_embedding_coordinates=emb)
+        steps[mode] = pdf.last_status_words["newton_row_steps"]
+        ran = sorted(set(k[0] for k in timer.summary()))
+        assert ("jf_cond_gf_chain_fwd_split_f32" in ran) == (mode == "fused"), (mode, ran)
+    for mode in ("two", "fused"):
+        gx, gl = out[mode][0].double().cpu().numpy(), out[mode][2].double().cpu().numpy()
+        ex = np.abs(gx - rx) / (1.0 + np.abs(rx))
+        assert float(ex.max()) < 2e-4, "%s [%s]: samples off by %.3g" % (name, mode, float(ex.max()))
+        assert float((np.abs(gl - rl) / (1.0 + np.abs(rl))).max()) < 2e-4, (name, mode)
+    dx = ((out["fused"][0] - out["two"][0]).abs() / (1.0 + out["two"][0].abs()))
+    assert float(dx.max()) < 5e-5, "fused and staged-row samples differ by %.3g" % float(dx.max())
+    assert 0.7 * steps["two"] <= steps["fused"] <= 1.3 * steps["two"], steps
+
+
 def _tiled_run(fx, dtype, log2_rows, launches=3):
     """the fixture's rows tiled to > 2^log2_rows rows (ragged: not a multiple of 128); returns the log-probs of `launches` evaluations of the
     big batch, the log-probs of the fixture batch alone, and the replica count"""
