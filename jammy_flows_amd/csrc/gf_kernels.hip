@@ -16,6 +16,7 @@
 //       HBM traffic is the algorithmic minimum (every parameter byte is read exactly once).
 #include "jf_gf.h"
 #include "jf_gf_ext.h"
+#include "jf_cond_regs.h"
 
 namespace jf {
 
@@ -128,9 +129,25 @@ __global__ void __launch_bounds__(BCAST ? 256 : 64, sizeof(T) == 8 ? 2 : 4) gf_c
                 x = s.y;
                 ld += group_sum<T, G>(live ? s.logd : T(0));
             } else {
-                x = gfg_solve<T, G>(p, o, D, live, x, row_valid, leader, a.status);
-                const MixQ<T> q = gfg_mixture<T, false>(p, o, D, x);                                // gaussianization_flow.py:922-924
-                ld -= group_sum<T, G>(live ? gf_icdf<T>(o.inv_type, q).logd : T(0));
+                if (o.K == CS_K && o.fit_norm) {
+                    // ten components (the reference's default): the lane's derived column -- mean, 1 / width, weight of every component -- goes
+                    // into registers once, and the 25 + <= 20 mixture evaluations of the solve read registers instead of three LDS words per
+                    // component and evaluation (same arithmetic: cs_solve restates gfg_solve on a register row, jf_cond_regs.h)
+                    T R[CS_SLOTS];
+#pragma unroll
+                    for (int k = 0; k < CS_K; ++k) {
+                        R[CS_SLOT_MEAN + k] = p[o.off_mean + k * D];
+                        R[CS_SLOT_LW + k] = p[o.off_lw + k * D];
+                        R[CS_SLOT_LN + k] = p[o.off_ln + k * D];
+                    }
+                    x = cs_solve<T>(R, o.inv_type, live, x, row_valid, leader, a.status, [](T v) { return group_sum<T, G>(v); },
+                                    [](T v) { return group_max<T, G>(v); });
+                    ld -= group_sum<T, G>(live ? gf_icdf<T>(o.inv_type, cs_mixture_derived<T>(R, x)).logd : T(0));
+                } else {
+                    x = gfg_solve<T, G>(p, o, D, live, x, row_valid, leader, a.status);
+                    const MixQ<T> q = gfg_mixture<T, false>(p, o, D, x);                            // gaussianization_flow.py:922-924
+                    ld -= group_sum<T, G>(live ? gf_icdf<T>(o.inv_type, q).logd : T(0));
+                }
                 x = gfg_rotate_fwd<T, G, false>(p, o, D, live, x);
                 if (o.model_offset) x += p[0];                                               // euclidean_base.py:63-68
             }

@@ -118,47 +118,47 @@ __device__ __forceinline__ void cs_derive(float (&P)[CS_SLOTS], const CsLayer& o
     for (int k = 0; k < CS_K; ++k) P[CS_SLOT_LN + k] *= inv;
 }
 
-__device__ __forceinline__ MixQ<float> cs_mixture_derived(const float (&P)[CS_SLOTS], float x) {
-    using Mf = M<float>;
-    float C = 0.f, S = 0.f, Pd = 0.f;
+template <typename T> __device__ __forceinline__ MixQ<T> cs_mixture_derived(const T (&P)[CS_SLOTS], T x) {
+    using Mf = M<T>;
+    T C = T(0), S = T(0), Pd = T(0);
 #pragma unroll
     for (int k = 0; k < CS_K; ++k) {
-        const float iw = P[CS_SLOT_LW + k], wk = P[CS_SLOT_LN + k];
-        const float u = (x - P[CS_SLOT_MEAN + k]) * iw;
-        const float t = Mf::exp_fast(-fabsf(u));
-        const float hi = Mf::rcp(1.0f + t);
-        const float lo = t * hi;
-        const bool pos = u >= 0.f;
+        const T iw = P[CS_SLOT_LW + k], wk = P[CS_SLOT_LN + k];
+        const T u = (x - P[CS_SLOT_MEAN + k]) * iw;
+        const T t = Mf::exp_fast(-Mf::abs(u));
+        const T hi = Mf::rcp(T(1) + t);
+        const T lo = t * hi;
+        const bool pos = u >= T(0);
         C += wk * (pos ? hi : lo);
         S += wk * (pos ? lo : hi);
         Pd += wk * hi * lo * iw;
     }
-    MixQ<float> q;
+    MixQ<T> q;
     q.lc = Mf::log_fast(C); q.ls = Mf::log_fast(S); q.lp = Mf::log_fast(Pd);
     q.cdf = C; q.sf = S;
     const bool under = !(C > Mf::TINY && S > Mf::TINY && Pd > Mf::TINY);
     if (__any(under)) {                                            // wave-uniform: sums scaled by e^{m}, m = distance to the nearest component
-        float m = INFINITY;
+        T m = T(INFINITY);
 #pragma unroll
-        for (int k = 0; k < CS_K; ++k) m = fminf(m, fabsf((x - P[CS_SLOT_MEAN + k]) * P[CS_SLOT_LW + k]));
-        const float em = Mf::exp_fast(-m);
-        float Cu = 0.f, Cs = 0.f, Su = 0.f, Ss = 0.f, Ps = 0.f;
+        for (int k = 0; k < CS_K; ++k) m = Mf::min(m, Mf::abs((x - P[CS_SLOT_MEAN + k]) * P[CS_SLOT_LW + k]));
+        const T em = Mf::exp_fast(-m);
+        T Cu = T(0), Cs = T(0), Su = T(0), Ss = T(0), Ps = T(0);
 #pragma unroll
         for (int k = 0; k < CS_K; ++k) {
-            const float iw = P[CS_SLOT_LW + k], wk = P[CS_SLOT_LN + k];
-            const float u = (x - P[CS_SLOT_MEAN + k]) * iw;
-            const float t = Mf::exp_fast(m - fabsf(u));
-            const float hi = Mf::rcp(1.0f + t * em);
-            const float c1 = wk * hi, c2 = c1 * t;
-            if (u >= 0.f) { Cu += c1; Ss += c2; }
+            const T iw = P[CS_SLOT_LW + k], wk = P[CS_SLOT_LN + k];
+            const T u = (x - P[CS_SLOT_MEAN + k]) * iw;
+            const T t = Mf::exp_fast(m - Mf::abs(u));
+            const T hi = Mf::rcp(T(1) + t * em);
+            const T c1 = wk * hi, c2 = c1 * t;
+            if (u >= T(0)) { Cu += c1; Ss += c2; }
             else { Su += c1; Cs += c2; }
             Ps += c2 * hi * iw;
         }
         if (under) {
             q.cdf = Cu + em * Cs;
             q.sf = Su + em * Ss;
-            q.lc = Cu > 0.f ? Mf::log_fast(q.cdf) : Mf::log_fast(Cs) - m;
-            q.ls = Su > 0.f ? Mf::log_fast(q.sf) : Mf::log_fast(Ss) - m;
+            q.lc = Cu > T(0) ? Mf::log_fast(q.cdf) : Mf::log_fast(Cs) - m;
+            q.ls = Su > T(0) ? Mf::log_fast(q.sf) : Mf::log_fast(Ss) - m;
             q.lp = Mf::log_fast(Ps) - m;
         }
     }
@@ -166,58 +166,61 @@ __device__ __forceinline__ MixQ<float> cs_mixture_derived(const float (&P)[CS_SL
 }
 
 // x with stage(mixture(x)) = z: gfg_solve's decisions step for step (far-midpoint skip, stopping rules, status counters); RSUM / RMAX reduce
-// over the lanes that hold the coordinates of one row
-template <typename RSUM, typename RMAX>
-__device__ __forceinline__ float cs_solve(const float (&P)[CS_SLOTS], const CsLayer& o, bool live, float z, bool row_valid, bool leader, int32_t* status,
-                                          RSUM rsum, RMAX rmax) {
-    using Mf = M<float>;
-    float lo = -1e5f, hi = 1e5f, x = 0.f;
-    constexpr float FAR = 100.f;
-    float lo_b = INFINITY, hi_b = -INFINITY;
+// over the lanes that hold the coordinates of one row.  P: DERIVED row (mean, 1 / width, normalised weight per component).
+template <typename T, typename RSUM, typename RMAX>
+__device__ __forceinline__ T cs_solve(const T (&P)[CS_SLOTS], int inv_type, bool live, T z, bool row_valid, bool leader, int32_t* status,
+                                      RSUM rsum, RMAX rmax) {
+    using Mf = M<T>;
+    T lo = T(-1e5), hi = T(1e5), x = T(0);
+    constexpr T FAR = T(100);
+    T lo_b = T(INFINITY), hi_b = T(-INFINITY);
 #pragma unroll
     for (int k = 0; k < CS_K; ++k) {
-        const float mu = P[CS_SLOT_MEAN + k], w = Mf::rcp(P[CS_SLOT_LW + k]);
-        lo_b = fminf(lo_b, mu - FAR * w);
-        hi_b = fmaxf(hi_b, mu + FAR * w);
+        const T mu = P[CS_SLOT_MEAN + k], w = Mf::rcp(P[CS_SLOT_LW + k]);
+        lo_b = Mf::min(lo_b, mu - FAR * w);
+        hi_b = Mf::max(hi_b, mu + FAR * w);
     }
-    const bool can_skip = fabsf(z) < 8.f;
+    const bool can_skip = Mf::abs(z) < T(8);
     for (int it = 0; it < 25; ++it) {
-        x = (hi + lo) * 0.5f;
+        x = (hi + lo) * T(0.5);
         const bool far_r = can_skip && x > hi_b, far_l = can_skip && x < lo_b;
         if (__all(far_r || far_l)) {                               // wave-uniform
             if (far_r) hi = x; else lo = x;
             continue;
         }
-        const float y = gf_icdf<float>(o.inv_type, cs_mixture_derived(P, x)).y;
-        const bool ok = fabsf(y - z) <= 1e-6f * fabsf(z);
+        const T y = gf_icdf<T>(inv_type, cs_mixture_derived<T>(P, x)).y;
+        const bool ok = Mf::abs(y - z) <= T(1e-6) * Mf::abs(z);
         if (ok) { lo = x; hi = x; }
         else if (y < z) lo = x;
         else hi = x;
     }
     bool active = row_valid;
-    float ferr = 0.f, prev = INFINITY;
+    T ferr = T(0), prev = T(INFINITY);
     bool nonfinite = false;
     for (int it = 0; it < 20 && __any(active); ++it) {
-        const IcdfOut<float> s = gf_icdf<float>(o.inv_type, cs_mixture_derived(P, x));
-        const float f = s.y - z;
-        const float upd = f / Mf::exp(s.logd);
-        const float usum = rsum(live ? fabsf(upd) : 0.f);
+        const IcdfOut<T> s = gf_icdf<T>(inv_type, cs_mixture_derived<T>(P, x));
+        const T f = s.y - z;
+        const T upd = f / Mf::exp(s.logd);
+        const T usum = rsum(live ? Mf::abs(upd) : T(0));
         status_add(status, JF_STATUS_NEWTON_STEPS, active && leader);
         if (active) {
-            const float nx = x - upd;
+            const T nx = x - upd;
             if (Mf::finite(nx)) x = nx; else nonfinite = nonfinite || live;
-            ferr = fabsf(f);
-            active = usum >= 1e-14f;
+            ferr = Mf::abs(f);
+            active = usum >= T(1e-14);
         }
-        // float32 floor of the update (see gfg_solve): the reference's float32 runs spend their last ~16 Newton steps on rounding noise
-        const float xs = rsum(live ? fmaxf(fabsf(x), 1.f) : 0.f);
-        if (usum < 2.5e-7f * xs || (usum >= 0.5f * prev && usum < 1e-4f * xs)) active = false;
-        prev = usum;
+        if constexpr (sizeof(T) == 4) {
+            // float32 floor of the update (see gfg_solve): the reference's float32 runs spend their last ~16 Newton steps on rounding noise
+            const T xs = rsum(live ? Mf::max(Mf::abs(x), T(1)) : T(0));
+            if (usum < T(2.5e-7) * xs || (usum >= T(0.5) * prev && usum < T(1e-4) * xs)) active = false;
+            prev = usum;
+        }
     }
-    const float ferr_row = rmax(live ? ferr : 0.f);
-    const float nf_row = rmax(nonfinite ? 1.f : 0.f);
-    status_add(status, JF_STATUS_NONCONVERGED, row_valid && leader && (ferr_row > 1e-4f));
-    status_add(status, JF_STATUS_NONFINITE, row_valid && leader && (nf_row > 0.f));
+    const T prec = sizeof(T) == 8 ? T(1e-7) : T(1e-4);
+    const T ferr_row = rmax(live ? ferr : T(0));
+    const T nf_row = rmax(nonfinite ? T(1) : T(0));
+    status_add(status, JF_STATUS_NONCONVERGED, row_valid && leader && (ferr_row > prec));
+    status_add(status, JF_STATUS_NONFINITE, row_valid && leader && (nf_row > T(0)));
     return x;
 }
 
