@@ -469,6 +469,18 @@ int jf_linear_wgrad_split_f32(const float* g, int64_t g_stride, const float* in,
  * ------------------------------------------------------------------------------------------------------------ */
 int jf_tanh_bwd_f32(const float* g, const float* y, int64_t n, float* out, void* stream);
 int jf_tanh_bwd_f64(const double* g, const double* y, int64_t n, double* out, void* stream);
+/* AmortizableMLP nonlinearities other than tanh (extra_functions.py:81-89; tanh is fused into the dense kernels): out = act(z) on the layer's
+ * pre-activation, and the backward out = g * act'(z).  n elements, contiguous. */
+#define JF_ACT_RELU 2
+#define JF_ACT_SOFTPLUS 3
+#define JF_ACT_ELU 4
+#define JF_ACT_SWISH 5
+#define JF_ACT_SQUARE 6
+#define JF_ACT_IDENTITY 7
+int jf_activation_f32(const float* z, int64_t n, int32_t code, float* out, void* stream);
+int jf_activation_f64(const double* z, int64_t n, int32_t code, double* out, void* stream);
+int jf_activation_bwd_f32(const float* g, const float* z, int64_t n, int32_t code, float* out, void* stream);
+int jf_activation_bwd_f64(const double* g, const double* z, int64_t n, int32_t code, double* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Reductions of the analysis utilities, so that 1e5 .. 1e6 evaluated rows never travel to the host:

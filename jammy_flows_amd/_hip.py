@@ -119,6 +119,8 @@ _SIGNATURES = {
     "jf_tanh_bwd": [_P, _P, _I64, _P, _P],
     "jf_mlp_hidden_bwd": [_P, _I64, _P, _I64, _P, _P, _I64, _I64, _I32, _I32, _P, _P],
     "jf_mlp2_small_bwd": [_P, _I64, _P, _I64, _P, _P, _I64, _P, _I64, _I64, _I32, _I32, _I32, _P, _P, _P],
+    "jf_activation": [_P, _I64, _I32, _P, _P],
+    "jf_activation_bwd": [_P, _P, _I64, _I32, _P, _P],
     "jf_mlp2": [_P, _I64, _P, _I64, _P, _P, _I64, _P, _I64, _I32, _I32, _I32, _P, _I64, _P],
     "jf_sphere_to_embedding": [_P, _I64, _P, _I64, _I32, _P, _I64, _P, _P],
     "jf_sphere_from_embedding": [_P, _I64, _P, _I64, _I32, _P, _I64, _P, _P],
@@ -672,6 +674,26 @@ def tanh_bwd(g, y, inplace=False):
     g, y = g.contiguous(), y.contiguous()
     out = g if inplace else torch.empty_like(g)
     _launch("jf_tanh_bwd" + _suffix(g), "", (_ptr(g), _ptr(y), g.numel(), _ptr(out)), dev)
+    return out
+
+
+ACT_CODES = {"relu": 2, "softplus": 3, "elu": 4, "swish": 5, "square": 6, "identity": 7}      # include/jammy_hip.h JF_ACT_*
+
+
+def activation(z, code):
+    """act(z), elementwise, for the AmortizableMLP nonlinearities other than tanh."""
+    dev = require_device(z)
+    z = z.contiguous()
+    out = torch.empty_like(z)
+    _launch("jf_activation" + _suffix(z), "", (_ptr(z), z.numel(), code, _ptr(out)), dev)
+    return out
+
+
+def activation_bwd(g, z, code):
+    dev = require_device(g, z)
+    g, z = g.contiguous(), z.contiguous()
+    out = torch.empty_like(z)
+    _launch("jf_activation_bwd" + _suffix(z), "", (_ptr(g), _ptr(z), z.numel(), code, _ptr(out)), dev)
     return out
 
 

@@ -15,7 +15,7 @@ import torch
 from torch import nn
 
 from . import _hip, autograd
-from .extra_functions import list_from_str
+from .extra_functions import NONLINEARITIES, list_from_str
 
 
 def _stage_layout(inputs, outputs, ranks, add_final_bias, svd_mode):
@@ -44,8 +44,8 @@ class AmortizableMLP(nn.Module):
     def __init__(self, input_dim, hidden_dims, output_dim, highway_mode=0, low_rank_approximations=0, nonlinearity="tanh",
                  use_permanent_parameters=True, svd_mode="smart", precise_mlp_structure=dict()):
         super().__init__()
-        if nonlinearity != "tanh":
-            raise NotImplementedError("AmortizableMLP nonlinearity %s has no HIP path (only tanh, the default)" % nonlinearity)
+        if nonlinearity not in NONLINEARITIES:
+            raise KeyError(nonlinearity)
         if svd_mode not in ("smart", "naive"):
             raise Exception("unknown svd mode", svd_mode)
         if len(precise_mlp_structure) > 0:
@@ -146,7 +146,7 @@ class AmortizableMLP(nn.Module):
     def lowrank_views(self, flat):
         """(v1, u1, b1, v2, u2, b2) views into the flat vector when this is a plain two-stage MLP whose last stage is low-rank and whose sizes
         fit jf_amlp2 / jf_amlp_gf_chain_inv (K1 <= 32, hidden <= 128, ranks <= 16); else None"""
-        if self.highway_mode != 0 or self.stages is None or len(self.stages) != 2:
+        if self.highway_mode != 0 or self.stages is None or len(self.stages) != 2 or self.nonlinearity != "tanh":
             return None
         s1, s2 = self.stages
         if s2["full"] or s2["rank"] > 16 or (not s1["full"] and s1["rank"] > 16) or s1["inp"] > 32 or s1["out"] > 128:
@@ -176,20 +176,23 @@ class AmortizableMLP(nn.Module):
         for si, st in enumerate(stages):
             res = residual if si == last else None
             n = st["num_u"] + st["num_v"] + st["num_b"]
+            act = st["act"] if self.nonlinearity == "tanh" else 0          # tanh: fused into the launch; others: a pass on the pre-activation
             if per_sample:
-                x = autograd.amlp_stage(x, flat[:, o:o + n], st["inp"], st["out"], st["rank"], st["num_b"] > 0, st["act"], res)
+                x = autograd.amlp_stage(x, flat[:, o:o + n], st["inp"], st["out"], st["rank"], st["num_b"] > 0, act, res)
             else:
                 lin = autograd.linear
                 u = flat[o:o + st["num_u"]]
                 v = flat[o + st["num_u"]:o + st["num_u"] + st["num_v"]]
                 b = flat[o + st["num_u"] + st["num_v"]:o + n] if st["num_b"] > 0 else None
                 if st["full"]:
-                    x = lin(x, u.view(st["out"], st["inp"]), b, st["act"])
+                    x = lin(x, u.view(st["out"], st["inp"]), b, act)
                 else:
                     t = lin(x, v.view(st["rank"], st["inp"]), None, 0)                # V^T x
-                    x = lin(t, u.view(st["out"], st["rank"]), b, st["act"])           # U (V^T x) + b
+                    x = lin(t, u.view(st["out"], st["rank"]), b, act)                 # U (V^T x) + b
                 if res is not None:
                     x = x + res
+            if st["act"] and self.nonlinearity != "tanh":
+                x = autograd.activation(x, _hip.ACT_CODES[self.nonlinearity])
             o += n
         return x, o
 

@@ -61,6 +61,27 @@ def linear(inp, weight, bias=None, act=0):
     return _hip.linear(inp, weight, bias, act)
 
 
+class ActivationFn(torch.autograd.Function):
+    """AmortizableMLP nonlinearity other than tanh on a layer's pre-activation (jf_activation / jf_activation_bwd)."""
+
+    @staticmethod
+    def forward(ctx, z, code):
+        ctx.code = code
+        ctx.save_for_backward(z)
+        return _hip.activation(z.detach(), code)
+
+    @staticmethod
+    def backward(ctx, g):
+        (z,) = ctx.saved_tensors
+        return _hip.activation_bwd(g, z, ctx.code), None
+
+
+def activation(z, code):
+    if torch.is_grad_enabled() and z.requires_grad:
+        return ActivationFn.apply(z, code)
+    return _hip.activation(z, code)
+
+
 class Mlp2SmallFn(torch.autograd.Function):
     """narrow Linear - tanh - Linear head (<= 32 inputs, <= 16 outputs) whose input rows need no gradient: forward = the fused jf_mlp2 launch,
     backward = ONE launch (jf_mlp2_small_bwd) instead of tanh', two weight gradients, two bias sums and g W2 of the per-layer path."""

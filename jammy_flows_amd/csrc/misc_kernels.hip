@@ -155,6 +155,43 @@ template <typename T> static int tanh_bwd(const T* g, const T* y, int64_t n, T* 
     return check_launch();
 }
 
+// ---------------------------------------------------------------------------------------------------------- AmortizableMLP nonlinearities
+// The activations of extra_functions.py:81-89 other than tanh (which is fused into the dense kernels): an elementwise pass on the layer's
+// pre-activation z, and its backward g * act'(z).  code: JF_ACT_RELU .. JF_ACT_IDENTITY (include/jammy_hip.h).
+template <typename T> __device__ __forceinline__ T act_value(int code, T z) {
+    switch (code) {
+        case JF_ACT_RELU: return z > T(0) ? z : T(0);
+        case JF_ACT_SOFTPLUS: return z > T(20) ? z : M<T>::log1p(M<T>::exp(z));                 // torch.nn.Softplus(beta=1, threshold=20)
+        case JF_ACT_ELU: return z > T(0) ? z : M<T>::expm1(z);                                  // alpha = 1
+        case JF_ACT_SWISH: return z / (T(1) + M<T>::exp(-z));                                   // x sigmoid(beta x), beta = 1 (extra_functions.py:62-68)
+        case JF_ACT_SQUARE: return z * z;
+        default: return z;
+    }
+}
+template <typename T> __device__ __forceinline__ T act_deriv(int code, T z) {
+    switch (code) {
+        case JF_ACT_RELU: return z > T(0) ? T(1) : T(0);
+        case JF_ACT_SOFTPLUS: return z > T(20) ? T(1) : T(1) / (T(1) + M<T>::exp(-z));
+        case JF_ACT_ELU: return z > T(0) ? T(1) : M<T>::exp(z);
+        case JF_ACT_SWISH: { const T sg = T(1) / (T(1) + M<T>::exp(-z)); return sg * (T(1) + z * (T(1) - sg)); }
+        case JF_ACT_SQUARE: return T(2) * z;
+        default: return T(1);
+    }
+}
+template <typename T, bool BWD> __global__ void __launch_bounds__(256) act_kernel(const T* __restrict__ g, const T* __restrict__ z, int64_t n, int code,
+                                                                                  T* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    out[i] = BWD ? g[i] * act_deriv<T>(code, z[i]) : act_value<T>(code, z[i]);
+}
+template <typename T, bool BWD> static int activation(const T* g, const T* z, int64_t n, int code, T* out, void* stream) {
+    if (!z || !out || (BWD && !g) || n < 0) return JF_ERR_BADARG;
+    if (code < JF_ACT_RELU || code > JF_ACT_IDENTITY) return JF_ERR_BADARG;
+    if (n == 0) return JF_OK;
+    hipLaunchKernelGGL((act_kernel<T, BWD>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g, z, n, code, out);
+    return check_launch();
+}
+
 }  // namespace jf
 
 extern "C" {
@@ -184,4 +221,8 @@ int jf_normal_logp_f64(const double* z, int64_t zs, int64_t B, int32_t D, const 
 }
 int jf_tanh_bwd_f32(const float* g, const float* y, int64_t n, float* out, void* s) { return jf::tanh_bwd<float>(g, y, n, out, s); }
 int jf_tanh_bwd_f64(const double* g, const double* y, int64_t n, double* out, void* s) { return jf::tanh_bwd<double>(g, y, n, out, s); }
+int jf_activation_f32(const float* z, int64_t n, int32_t code, float* out, void* s) { return jf::activation<float, false>(nullptr, z, n, code, out, s); }
+int jf_activation_f64(const double* z, int64_t n, int32_t code, double* out, void* s) { return jf::activation<double, false>(nullptr, z, n, code, out, s); }
+int jf_activation_bwd_f32(const float* g, const float* z, int64_t n, int32_t code, float* out, void* s) { return jf::activation<float, true>(g, z, n, code, out, s); }
+int jf_activation_bwd_f64(const double* g, const double* z, int64_t n, int32_t code, double* out, void* s) { return jf::activation<double, true>(g, z, n, code, out, s); }
 }

@@ -9,4 +9,6 @@ def list_from_str(spec):
     return [int(s) for s in spec.split("-")]
 
 
-NONLINEARITIES = {"tanh": nn.Tanh()}
+# the names the reference offers (extra_functions.py:81-89); tanh is fused into the dense kernels, the others run as an elementwise launch on the
+# pre-activation (jf_activation; "swish" with the reference's fixed beta = 1)
+NONLINEARITIES = ("tanh", "relu", "softplus", "elu", "swish", "square", "identity")

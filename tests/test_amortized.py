@@ -170,3 +170,32 @@ def test_gpu_gradients_through_sampling_reach_the_hyper_network(name):
     with torch.no_grad():
         xn = pdf.sample(conditional_input=torch.from_numpy(g["cond"]).cuda(), seed=5)[0]
     assert not xn.requires_grad and float((xn - xs.detach()).abs().max()) < 1e-9
+
+
+NONLIN = np.load(os.path.join(fixture_io.GOLDEN_DIR, "nonlin", "amlp_nonlinearities.npz"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hw", [0, 1])
+@pytest.mark.parametrize("name", [str(n) for n in NONLIN["names"]])
+def test_gpu_amortizable_mlp_nonlinearities_vs_reference(name, hw):
+    """every nonlinearity the reference offers (extra_functions.py:81-89; only tanh is used by pdf): outputs and autograd gradients of a
+    low-rank AmortizableMLP against vectors from the reference (tests/golden/make_amlp_nonlin_fixtures.py)"""
+    from jammy_flows_amd.amortizable_mlp import AmortizableMLP
+    k = "%s_hw%d" % (name, hw)
+    mlp = AmortizableMLP(5, "12-9", 7, low_rank_approximations=3, nonlinearity=name, highway_mode=hw, use_permanent_parameters=True).double().cuda()
+    with torch.no_grad():
+        mlp.u_v_b_pars.copy_(torch.from_numpy(NONLIN[k + "/pars"]).cuda())
+    x = torch.from_numpy(NONLIN["x"]).cuda().requires_grad_(True)
+    with torch.enable_grad():
+        y = mlp(x)
+        loss = (y ** 2).mean()
+    loss.backward()
+
+    def rel(a, b):
+        return float(np.abs(a.detach().cpu().numpy().reshape(b.shape) - b).max()) / max(float(np.abs(b).max()), 1e-30)
+    assert rel(y, NONLIN[k + "/y"]) < 1e-10, k
+    assert rel(x.grad, NONLIN[k + "/gx"]) < 1e-8, k
+    assert rel(mlp.u_v_b_pars.grad, NONLIN[k + "/gp"]) < 1e-8, k
+    with torch.no_grad():
+        assert rel(mlp(x.detach()), NONLIN[k + "/y"]) < 1e-10      # the no-grad path (plain launches)
