@@ -318,7 +318,9 @@ typedef struct jf_r_layer { jf_spline_opts sp; double lo, hi; int32_t first, res
 /* 'o' circular spline (splines_1d.py:111-306 + sphere_base.py:601-695); row: [householder hh_iter*2][spline row] */
 typedef struct jf_o_layer { jf_spline_opts sp; int32_t natural_direction, hh_iter, first, reserved; } jf_o_layer;
 /* 'm' Moebius mixture (moebius_1d.py:57-259, bisection_n_newton.py:137-256); row: [householder hh_iter*2][(wx,wy,logit-len,log-w) x nc] */
-typedef struct jf_m_layer { int32_t num_components, natural_direction, hh_iter, first; } jf_m_layer;
+typedef struct jf_m_layer { int32_t num_components, natural_direction, hh_iter, first, omega_pars; } jf_m_layer;
+/* omega_pars: 4 = (omega_x, omega_y, logit length, log weight) per component (use_moebius_xyz_parametrization, the default); 3 = (omega angle,
+ * logit length, log weight) (moebius_1d.py:39-46, 175-178); 0 is read as 4. */
 /* hh_iter of every sphere layer also encodes the reference's rotation_mode (sphere_base.py:112-240): >= 0 = that many Householder reflections
  * (hh_iter * E raw vectors, E = embedding dimension); -1 = "angles" (Givens rotations, E (E - 1) / 2 angles); -2 = "xyz" (3 parameters, S2);
  * -3 = "quaternion" (4 parameters, S2). */

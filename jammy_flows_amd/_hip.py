@@ -56,7 +56,8 @@ class jf_o_layer(ctypes.Structure):
 
 
 class jf_m_layer(ctypes.Structure):
-    _fields_ = [("num_components", ctypes.c_int32), ("natural_direction", ctypes.c_int32), ("hh_iter", ctypes.c_int32), ("first", ctypes.c_int32)]
+    _fields_ = [("num_components", ctypes.c_int32), ("natural_direction", ctypes.c_int32), ("hh_iter", ctypes.c_int32), ("first", ctypes.c_int32),
+                ("omega_pars", ctypes.c_int32)]
 
 
 JF_MAX_MCHAIN = 4

@@ -116,18 +116,24 @@ struct OFam {
 
 // =================================================================================================  'm'
 // moebius_1d.py:140-259.  x in [-pi, pi].  value: sum_k pi_k * arg(Moebius_k(e^{ix})) normalised so that -pi -> -pi; deriv: sum_k pi_k (1-|w|^2)/|e^{ix}-w|^2
-template <typename T> __device__ inline void moebius_eval(const T* __restrict__ p, int nc, T x, T& val, T& deriv) {
+// np: parameters per component, 4 = (omega_x, omega_y, logit length, log weight), 3 = (omega angle, logit length, log weight) (:175-178)
+template <typename T> __device__ inline void moebius_eval(const T* __restrict__ p, int nc, int np, T x, T& val, T& deriv) {
     const T cx = M<T>::cos(x), sx = M<T>::sin(x);
     const T cmp = T(-1), smp = (T)(-1.2246467991473532e-16);          // numpy.cos(-pi), numpy.sin(-pi)
-    T lmax = p[3];
-    for (int k = 1; k < nc; ++k) lmax = M<T>::max(lmax, p[4 * k + 3]);
+    T lmax = p[np - 1];
+    for (int k = 1; k < nc; ++k) lmax = M<T>::max(lmax, p[np * k + np - 1]);
     T wsum = T(0), vsum = T(0), dsum = T(0);
     for (int k = 0; k < nc; ++k) {
-        const T* q = p + 4 * k;
-        const T denom = logaddexp<T>(T(0), -q[2]);
+        const T* q = p + np * k;
+        const T denom = logaddexp<T>(T(0), -q[np - 2]);
         const T len = T(0.001) + M<T>::exp(T(-0.0020020026706730793) - denom);      // ln(0.999 - 0.001)
-        const T nrm = len / M<T>::sqrt(q[0] * q[0] + q[1] * q[1]);
-        const T ox = q[0] * nrm, oy = q[1] * nrm;
+        T ox, oy;
+        if (np == 4) {
+            const T nrm = len / M<T>::sqrt(q[0] * q[0] + q[1] * q[1]);
+            ox = q[0] * nrm; oy = q[1] * nrm;
+        } else {
+            ox = M<T>::cos(q[0]) * len; oy = M<T>::sin(q[0]) * len;
+        }
         const T omo = T(1) - len * len;
         const T opo = T(1) + len * len - T(2) * (cx * ox + sx * oy);
         const T opo_mp = T(1) + len * len - T(2) * (cmp * ox + smp * oy);
@@ -138,7 +144,7 @@ template <typename T> __device__ inline void moebius_eval(const T* __restrict__ 
         const T xv = omo * (cx - ox) - ox * opo;
         const T cr = M<T>::cos(rot), sr = M<T>::sin(rot);
         const T arc = M<T>::atan2(sr * xv + cr * yv, cr * xv - sr * yv) + M<T>::PI;
-        const T w = M<T>::exp(q[3] - lmax);
+        const T w = M<T>::exp(q[np - 1] - lmax);
         wsum += w;
         vsum += w * arc;
         dsum += w * (omo / opo);
@@ -146,11 +152,11 @@ template <typename T> __device__ inline void moebius_eval(const T* __restrict__ 
     val = vsum / wsum - M<T>::PI;
     deriv = dsum / wsum;
 }
-template <typename T> __device__ inline T moebius_solve(const T* __restrict__ p, int nc, T z, LaneCtx<T>& c) {
+template <typename T> __device__ inline T moebius_solve(const T* __restrict__ p, int nc, int np, T z, LaneCtx<T>& c) {
     T lo = -M<T>::PI, hi = M<T>::PI, x = T(0), f, d;
     for (int it = 0; it < 20; ++it) {                                     // bisection_n_newton.py:171-182
         x = (hi + lo) * T(0.5);
-        moebius_eval<T>(p, nc, x, f, d);
+        moebius_eval<T>(p, nc, np, x, f, d);
         if (M<T>::abs(f - z) <= T(1e-6) * M<T>::abs(z)) { lo = x; hi = x; }
         else if (f < z) lo = x;
         else hi = x;
@@ -158,7 +164,7 @@ template <typename T> __device__ inline T moebius_solve(const T* __restrict__ p,
     bool active = c.lane_valid;
     T ferr = T(0);
     for (int it = 0; it < 20 && __any(active); ++it) {                    // :192-238
-        moebius_eval<T>(p, nc, x, f, d);
+        moebius_eval<T>(p, nc, np, x, f, d);
         if (active) {
             const T upd = (f - z) / d;
             x -= upd;
@@ -173,19 +179,20 @@ template <typename T> __device__ inline T moebius_solve(const T* __restrict__ p,
 struct MFam {
     using CLayer = jf_m_layer;
     static constexpr int DIM = 1;
-    static __host__ int row_len(const CLayer& L) { return rot_len(L.hh_iter, 2) + 4 * L.num_components; }
+    static __host__ __device__ int omega_pars(const CLayer& L) { return L.omega_pars == 3 ? 3 : 4; }
+    static __host__ int row_len(const CLayer& L) { return rot_len(L.hh_iter, 2) + omega_pars(L) * L.num_components; }
     static __host__ int n_bins(const CLayer&) { return 0; }
     static __host__ bool needs_tab(const CLayer&) { return false; }
     template <typename T> static __device__ __forceinline__ T core(const CLayer& L, const T* __restrict__ mp, T x, T& ld, LaneCtx<T>& c, bool direct) {
         x = x > M<T>::PI ? x - M<T>::TWO_PI : x;                           // moebius_1d.py:73-74
         T val, d;
         if (direct) {
-            moebius_eval<T>(mp, L.num_components, x, val, d);
+            moebius_eval<T>(mp, L.num_components, omega_pars(L), x, val, d);
             ld += M<T>::log(d);
             x = val;
         } else {
-            x = moebius_solve<T>(mp, L.num_components, x, c);
-            moebius_eval<T>(mp, L.num_components, x, val, d);
+            x = moebius_solve<T>(mp, L.num_components, omega_pars(L), x, c);
+            moebius_eval<T>(mp, L.num_components, omega_pars(L), x, val, d);
             ld -= M<T>::log(d);
         }
         return x < T(0) ? M<T>::TWO_PI + x : x;

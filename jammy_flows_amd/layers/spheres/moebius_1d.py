@@ -17,11 +17,9 @@ class moebius(sphere_base.sphere_base):
                          use_permanent_parameters=use_permanent_parameters)
         if dimension != 1:
             raise Exception("The moebius flow is defined for dimension 1, but dimension %d is handed over" % dimension)
-        if not use_moebius_xyz_parametrization:
-            raise NotImplementedError("moebius angle parametrisation has no HIP kernel")
         self.use_moebius_xyz_parametrization = use_moebius_xyz_parametrization
         self.num_basis_functions = num_basis_functions
-        self.num_omega_pars = 4
+        self.num_omega_pars = 4 if use_moebius_xyz_parametrization else 3        # (x, y) or the angle of omega, + length + weight (:39-46)
         self.total_param_num += self.num_basis_functions * self.num_omega_pars
         if use_permanent_parameters:
             self.moebius_pars = nn.Parameter(torch.randn(self.num_basis_functions, self.num_omega_pars).type(torch.double).unsqueeze(0))
@@ -33,6 +31,7 @@ class moebius(sphere_base.sphere_base):
         L.natural_direction = int(self.natural_direction)
         L.hh_iter = self.num_householder_iter
         L.first = int(first)
+        L.omega_pars = self.num_omega_pars
         return L
 
     def _layer_tensors(self):

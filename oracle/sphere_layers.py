@@ -241,11 +241,15 @@ MIN_OMEGA, MAX_OMEGA = 0.001, 0.999
 
 
 def _moebius_omega(pars):
-    """omega vector / length from (B,nc,4) = (wx, wy, logit-length, log-weight)  (moebius_1d.py:157-177)."""
-    loglen = pars[:, :, 2:3]
+    """omega vector / length from (B,nc,4) = (wx, wy, logit-length, log-weight), or (B,nc,3) = (omega angle, logit-length, log-weight) for
+    use_moebius_xyz_parametrization=False  (moebius_1d.py:157-178)."""
+    loglen = pars[:, :, -2:-1]
     denom = np.logaddexp(0.0, -loglen)
     length = MIN_OMEGA + np.exp(np.log(MAX_OMEGA - MIN_OMEGA) - denom)
-    vec = pars[:, :, :2] / np.sqrt((pars[:, :, :2] ** 2).sum(axis=2, keepdims=True)) * length
+    if pars.shape[2] == 4:
+        vec = pars[:, :, :2] / np.sqrt((pars[:, :, :2] ** 2).sum(axis=2, keepdims=True)) * length
+    else:
+        vec = np.concatenate([np.cos(pars[:, :, 0:1]) * length, np.sin(pars[:, :, 0:1]) * length], axis=2)
     return vec, length
 
 
@@ -265,7 +269,7 @@ def moebius_trafo(x, pars):
     xp = np.cos(rot) * xv - np.sin(rot) * yv
     yp = np.sin(rot) * xv + np.cos(rot) * yv
     arc = np.arctan2(yp, xp)[:, :, -1:] + PI
-    ln = pars[:, :, 3:4]
+    ln = pars[:, :, -1:]
     weighted = arc * np.exp(ln - logsumexp(ln, axis=1, keepdims=True))
     return weighted.sum(axis=1) - PI
 
@@ -276,7 +280,7 @@ def moebius_deriv(x, pars):
     vec, length = _moebius_omega(pars)
     omo = 1.0 - length ** 2
     opo = 1.0 + length ** 2 - 2 * (cx * vec[:, :, 0:1] + sx * vec[:, :, 1:2])
-    ln = pars[:, :, 3:4]
+    ln = pars[:, :, -1:]
     wd = (np.log(omo / opo) + ln) - logsumexp(ln, axis=1, keepdims=True)
     return np.exp(logsumexp(wd, axis=1))
 
@@ -316,13 +320,14 @@ class MLayer(_SphereLayer):
         self._setup_base(o, first, embedding)
         self.nc = o["num_basis_functions"]
         self.natural_direction = o["natural_direction"]
-        self.total_param_num = self.n_rot + 4 * self.nc
+        self.n_omega = 4 if o.get("use_moebius_xyz_parametrization", 1) else 3
+        self.total_param_num = self.n_rot + self.n_omega * self.nc
 
     def row_from_state(self, sd, prefix):
         return np.concatenate([self.rot_row_from_state(sd, prefix), sd[prefix + "moebius_pars"].reshape(-1)])[None, :]
 
     def _run(self, x, log_det, params, do_direct):
-        pars = params.reshape(params.shape[0], self.nc, 4)
+        pars = params.reshape(params.shape[0], self.nc, self.n_omega)
         if self.embedding:
             x, log_det = mf.eucl_to_spherical(x, log_det, 1)
         x = np.where(x > PI, x - TWO_PI, x)                        # 0..2pi -> -pi..pi   (moebius_1d.py:73-74)

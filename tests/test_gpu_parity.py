@@ -908,3 +908,37 @@ def test_ragged_and_strided_batches(name, dtype):
             assert max_rel(part[0], sfull[0][:b]) < tol and max_rel(part[2], sfull[2][:b]) < tol, (name, b)
         es = pdf._obtain_sample(conditional_input=None if cond is None else cond[:0], predefined_target_input=z[:0])
         assert es[0].shape[0] == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nd", [0, 1])
+def test_moebius_angle_parametrisation_vs_reference(nd):
+    """'m' with use_moebius_xyz_parametrization=False (omega by its angle, three parameters per component; moebius_1d.py:39-46, 175-178): both
+    directions, permanent and per-sample parameters, against vectors from the reference's layer class (make_moebius_angle_fixture.py) and
+    against the oracle"""
+    from jammy_flows_amd.layers.spheres.moebius_1d import moebius
+    from oracle import sphere_layers as osl
+    g = np.load(os.path.join(fixture_io.GOLDEN_DIR, "nonlin", "m_angle_layer.npz"))
+    layer = moebius(dimension=1, euclidean_to_sphere_as_first=False, add_rotation=0, natural_direction=nd, use_permanent_parameters=True,
+                    use_moebius_xyz_parametrization=False, num_basis_functions=5).double().cuda()
+    assert layer.total_param_num == 15
+    with torch.no_grad():
+        layer.moebius_pars.copy_(torch.from_numpy(g["nd%d/pars" % nd]).cuda())
+    x = torch.from_numpy(g["x"]).cuda()
+    # per-sample parameters: the reference ADDS extra_inputs to the layer's own tensor (moebius_1d.py:63-66); inside a pdf that tensor is zero
+    # for amortised layers, and here the kernels take the per-sample rows as they are -- so the sum is what is handed over
+    amortised = moebius(dimension=1, euclidean_to_sphere_as_first=False, add_rotation=0, natural_direction=nd, use_permanent_parameters=False,
+                        use_moebius_xyz_parametrization=False, num_basis_functions=5).double().cuda()
+    rows = torch.from_numpy(g["extra"] + g["nd%d/pars" % nd].reshape(1, -1)).cuda()
+    for tag, lay, extra in (("perm", layer, None), ("cond", amortised, rows)):
+        zero = torch.zeros(x.shape[0], dtype=torch.float64, device="cuda")
+        y, ld = lay.inv_flow_mapping([x.clone(), zero.clone()], extra_inputs=extra)[:2]
+        xs, lds = lay.flow_mapping([x.clone(), zero.clone()], extra_inputs=extra)[:2]
+        for got, key in ((y, "inv_y"), (ld, "inv_ld"), (xs, "fwd_x"), (lds, "fwd_ld")):
+            ref = g["nd%d/%s/%s" % (nd, tag, key)]
+            assert float(np.abs(got.cpu().numpy().reshape(ref.shape) - ref).max()) < 1e-8, (nd, tag, key)
+    # the oracle's restatement of the same parametrisation
+    pars = (g["nd%d/pars" % nd] + g["extra"].reshape(-1, 5, 3))
+    xr = np.where(g["x"] > np.pi, g["x"] - 2 * np.pi, g["x"])
+    if nd == 0:              # natural direction 0: the log-prob direction evaluates the map directly at x
+        assert np.abs(np.log(osl.moebius_deriv(xr, pars)).sum(axis=-1) - g["nd0/cond/inv_ld"]).max() < 1e-9
