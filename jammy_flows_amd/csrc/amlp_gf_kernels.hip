@@ -284,7 +284,7 @@ template <typename T>
 static int amlp2(const T* in, int64_t in_stride, const T* V1, const T* U1, const T* b1, const T* V2, const T* U2, const T* b2, int64_t B, int32_t K1,
                  int32_t H, int32_t r1, int32_t r2, int32_t N, T* out, int64_t out_stride, void* stream) {
     if (!in || !U1 || !b1 || !V2 || !U2 || !b2 || !out) return JF_ERR_BADARG;
-    if (K1 < 1 || H < 1 || r2 < 1 || N < 1 || B < 0 || (V1 && r1 < 1)) return JF_ERR_BADARG;
+    if (!width_ok(K1) || !width_ok(H) || !width_ok(r2) || !width_ok(N) || !rows_ok(B) || (V1 && r1 < 1)) return JF_ERR_BADARG;
     if (K1 > AG_K1MAX || H > AG_HMAX || r2 > AG_RMAX || (V1 && r1 > AG_RMAX)) return JF_ERR_UNSUPPORTED;
     if (B == 0) return JF_OK;
     AgArgs<T> a{};
@@ -308,7 +308,7 @@ static int amlp_gf_chain_inv(const T* in, int64_t in_stride, const T* V1, const 
                              int32_t H, int32_t r1, int32_t r2, const T* x, int64_t xs, const T* ld_in, int64_t B, int32_t D, int32_t n_layers,
                              const jf_gf_layer* layers, T* x_out, int64_t xos, T* ld_out, const T* blp_in, T* blp_out, int32_t* status, void* stream) {
     if (!in || !U1 || !b1 || !V2 || !U2 || !b2 || !x || !x_out || !ld_out || !layers) return JF_ERR_BADARG;
-    if (K1 < 1 || H < 1 || r2 < 1 || B < 0 || n_layers < 1 || n_layers > JF_MAX_CHAIN || D < 1 || (V1 && r1 < 1)) return JF_ERR_BADARG;
+    if (!width_ok(K1) || !width_ok(H) || !width_ok(r2) || !rows_ok(B) || n_layers < 1 || n_layers > JF_MAX_CHAIN || D < 1 || (V1 && r1 < 1)) return JF_ERR_BADARG;
     if (K1 > AG_K1MAX || H > AG_HMAX || r2 > AG_RMAX || (V1 && r1 > AG_RMAX) || D > 8) return JF_ERR_UNSUPPORTED;
     AgArgs<T> a{};
     int col = 0;

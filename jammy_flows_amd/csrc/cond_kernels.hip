@@ -271,7 +271,7 @@ static int cond_gf_chain_inv(const T* in, int64_t in_stride, const T* W1, int64_
                              int32_t H, const T* x, int64_t xs, const T* ld_in, int64_t B, int32_t D, int32_t n_layers, const jf_gf_layer* layers,
                              T* x_out, int64_t xos, T* ld_out, const T* blp_in, T* blp_out, int32_t* status, void* stream) {
     if (!in || !W1 || !b1 || !W2 || !x || !x_out || !ld_out || !layers) return JF_ERR_BADARG;
-    if (K1 < 1 || H < 1 || B < 0 || n_layers < 1 || n_layers > JF_MAX_CHAIN) return JF_ERR_BADARG;
+    if (!width_ok(K1) || !width_ok(H) || !rows_ok(B) || n_layers < 1 || n_layers > JF_MAX_CHAIN) return JF_ERR_BADARG;
     if (K1 > CG_K1MAX || H > CG_HMAX || D < 3 || D > 4) return JF_ERR_UNSUPPORTED;          // 4-lane row groups only (16 rows per MFMA tile)
     if ((H % Vec16<T>::N) || (w2s % Vec16<T>::N) || (reinterpret_cast<uintptr_t>(W2) & 15u)) return JF_ERR_UNSUPPORTED;
     if (B == 0) return JF_OK;

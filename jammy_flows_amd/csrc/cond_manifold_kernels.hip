@@ -152,11 +152,12 @@ static int cond_mchain(const T* in, int64_t in_stride, const T* W1, int64_t w1s,
                        const T* x, int64_t xs, const T* ld_in, int64_t B, int32_t n_layers, const typename Fam::CLayer* layers, T* x_out, int64_t xos,
                        T* ld_out, const T* blp_in, T* blp_out, int32_t* status, void* stream) {
     if (!in || !W1 || !b1 || !W2 || !x || !x_out || !ld_out || !layers) return JF_ERR_BADARG;
-    if (K1 < 1 || H < 1 || B < 0 || n_layers < 1 || n_layers > JF_MAX_MCHAIN) return JF_ERR_BADARG;
+    if (!width_ok(K1) || !width_ok(H) || !rows_ok(B) || n_layers < 1 || n_layers > JF_MAX_MCHAIN) return JF_ERR_BADARG;
     if (K1 > CM_K1MAX || H > CM_HMAX) return JF_ERR_UNSUPPORTED;
     CmArgs<T, typename Fam::CLayer> a{};
     int col = 0;
     for (int l = 0; l < n_layers; ++l) {
+        if (!Fam::sane(layers[l])) return JF_ERR_BADARG;
         a.L[l] = layers[l];
         a.col0[l] = col;
         col += Fam::row_len(layers[l]);

@@ -649,7 +649,7 @@ static int64_t pp_packed_bytes(int n_layers) { return (int64_t)n_layers * (2 * P
 static int pp_pack(const float* W2, int64_t w2s, const float* b2, int32_t H, int32_t D, int32_t n_layers, const jf_gf_layer* layers, void* packed,
                    void* stream) {
     if (!W2 || !layers || !packed) return JF_ERR_BADARG;
-    if (H < 1 || n_layers < 1 || n_layers > JF_MAX_CHAIN) return JF_ERR_BADARG;
+    if (!width_ok(H) || n_layers < 1 || n_layers > JF_MAX_CHAIN) return JF_ERR_BADARG;
     if (H > PP_HMAX) return JF_ERR_UNSUPPORTED;
     PpPackArgs a{};
     int col = 0;
@@ -675,7 +675,7 @@ static int pp_chain(const float* in, int64_t in_stride, const float* W1, int64_t
                     const float* x, int64_t xs, const float* ld_in, int64_t B, int32_t D, int32_t n_layers, const jf_gf_layer* layers, float* x_out,
                     int64_t xos, float* ld_out, const float* blp_in, float* blp_out, int32_t* status, void* stream) {
     if (!in || !W1 || !b1 || !packed || !x || !x_out || !ld_out || !layers) return JF_ERR_BADARG;
-    if (K1 < 1 || H < 1 || B < 0 || n_layers < 1 || n_layers > JF_MAX_CHAIN) return JF_ERR_BADARG;
+    if (!width_ok(K1) || !width_ok(H) || !rows_ok(B) || n_layers < 1 || n_layers > JF_MAX_CHAIN) return JF_ERR_BADARG;
     if (K1 > PP_K1MAX || H > PP_HMAX || (reinterpret_cast<uintptr_t>(packed) & 15u)) return JF_ERR_UNSUPPORTED;
     if (B > ((int64_t)1 << 31) * PP_ROWS_WG / 4) return JF_ERR_UNSUPPORTED;
     PpArgs a{};

@@ -362,7 +362,7 @@ static bool cs_layer_supported(const jf_gf_layer& h, int D) {
 static int cs_pack(const float* W2, int64_t w2s, const float* b2, int32_t H, int32_t D, int32_t n_layers, const jf_gf_layer* layers, void* packed,
                    void* stream) {
     if (!W2 || !layers || !packed) return JF_ERR_BADARG;
-    if (H < 1 || n_layers < 1 || n_layers > JF_MAX_CHAIN) return JF_ERR_BADARG;
+    if (!width_ok(H) || n_layers < 1 || n_layers > JF_MAX_CHAIN) return JF_ERR_BADARG;
     if (H > CS_HMAX) return JF_ERR_UNSUPPORTED;
     CsPackArgs a{};
     int col = 0;
@@ -389,7 +389,7 @@ static int cs_chain(const float* in, int64_t in_stride, const float* W1, int64_t
                     const float* x, int64_t xs, const float* ld_in, int64_t B, int32_t D, int32_t n_layers, const jf_gf_layer* layers, float* x_out,
                     int64_t xos, float* ld_out, const float* blp_in, float* blp_out, int32_t* status, void* stream) {
     if (!in || !W1 || !b1 || !packed || !x || !x_out || !ld_out || !layers) return JF_ERR_BADARG;
-    if (K1 < 1 || H < 1 || B < 0 || n_layers < 1 || n_layers > JF_MAX_CHAIN) return JF_ERR_BADARG;
+    if (!width_ok(K1) || !width_ok(H) || !rows_ok(B) || n_layers < 1 || n_layers > JF_MAX_CHAIN) return JF_ERR_BADARG;
     if (K1 > CS_K1MAX || H > CS_HMAX || (reinterpret_cast<uintptr_t>(packed) & 15u)) return JF_ERR_UNSUPPORTED;
     CsArgs a{};
     for (int l = 0; l < n_layers; ++l) {

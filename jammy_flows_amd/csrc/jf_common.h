@@ -11,6 +11,12 @@
 
 namespace jf {
 
+// host-side argument sanity: matrix widths / row counts beyond these are refused (JF_ERR_BADARG) before any size arithmetic
+constexpr int64_t JF_MAX_WIDTH = 1 << 24, JF_MAX_ROWS = (int64_t)1 << 40;
+inline bool width_ok(int64_t v) { return v >= 1 && v <= JF_MAX_WIDTH; }
+inline bool rows_ok(int64_t v) { return v >= 0 && v <= JF_MAX_ROWS; }
+
+
 // ---------------------------------------------------------------------------------------------
 // vector types: 16-byte accesses are what both HBM (global_load_dwordx4) and LDS (ds_read_b128) want
 // ---------------------------------------------------------------------------------------------

@@ -223,6 +223,7 @@ struct VFam {
     static __host__ int n_pot(const CLayer& L) {
         return L.exp_map_type == JF_V_SPLINES ? 4 + 3 * JF_V_SPLINE_BINS + 1 : 3 + (L.exp_map_type == JF_V_EXPONENTIAL ? 2 : 1);
     }
+    static __host__ bool sane(const CLayer& L) { return L.num_components >= 1 && L.num_components <= 4096 && sane_hh(L.hh_iter); }
     static __host__ int row_len(const CLayer& L) { return rot_len(L.hh_iter, 3) + n_pot(L) * L.num_components; }
     static __host__ int n_bins(const CLayer&) { return 0; }
     static __host__ bool needs_tab(const CLayer& L) { return L.exp_map_type == JF_V_SPLINES; }

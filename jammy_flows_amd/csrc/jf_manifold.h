@@ -36,6 +36,14 @@ template <typename T> __device__ __forceinline__ SplineDev<T> to_dev(const jf_sp
 }
 __host__ __device__ inline int spline_row_len(const jf_spline_opts& s) { return s.n_w + s.n_h + s.n_d; }
 
+// descriptor sanity (host): field ranges checked BEFORE any row-length arithmetic, so that nonsense descriptors (a fuzzer's, a corrupted one's)
+// end in JF_ERR_BADARG instead of integer overflow or an out-of-bounds index into the nested layer arrays (tests/test_abi_asan.py)
+__host__ inline bool sane_hh(int hh) { return hh >= JF_ROT_QUATERNION && hh <= 64; }
+__host__ inline bool sane_spline(const jf_spline_opts& s) {
+    return s.num_bins >= 1 && s.num_bins <= JF_SPLINE_MAX_BINS && s.n_w >= 0 && s.n_w <= 4 * JF_SPLINE_MAX_BINS && s.n_h >= 0 &&
+           s.n_h <= 4 * JF_SPLINE_MAX_BINS && s.n_d >= 0 && s.n_d <= 4 * JF_SPLINE_MAX_BINS;
+}
+
 // =================================================================================================  'r'
 template <typename T> __device__ __forceinline__ T r_core(const jf_r_layer& L, const T* __restrict__ p, T x, T& ld, LaneCtx<T>& c, bool inverse) {
     x = x > T(1) ? T(1) : (x < T(-1) ? T(-1) : x);                         // rational_quadratic_spline.py:185-186, 295-296
@@ -50,6 +58,7 @@ template <typename T> __device__ __forceinline__ T r_core(const jf_r_layer& L, c
 struct RFam {
     using CLayer = jf_r_layer;
     static constexpr int DIM = 1;
+    static __host__ bool sane(const CLayer& L) { return sane_spline(L.sp); }
     static __host__ int row_len(const CLayer& L) { return spline_row_len(L.sp); }
     static __host__ int n_bins(const CLayer&) { return 1; }
     static __host__ bool needs_tab(const CLayer&) { return true; }       // lane-private knot tables (JF_SPLINE_TAB elements of LDS per lane)
@@ -97,6 +106,7 @@ template <typename T> __device__ __forceinline__ T o_core(const jf_o_layer& L, c
 struct OFam {
     using CLayer = jf_o_layer;
     static constexpr int DIM = 1;
+    static __host__ bool sane(const CLayer& L) { return sane_spline(L.sp) && sane_hh(L.hh_iter); }
     static __host__ int row_len(const CLayer& L) { return rot_len(L.hh_iter, 2) + spline_row_len(L.sp); }
     static __host__ int n_bins(const CLayer&) { return 1; }
     static __host__ bool needs_tab(const CLayer&) { return true; }       // lane-private knot tables (JF_SPLINE_TAB elements of LDS per lane)
@@ -180,6 +190,7 @@ struct MFam {
     using CLayer = jf_m_layer;
     static constexpr int DIM = 1;
     static __host__ __device__ int omega_pars(const CLayer& L) { return L.omega_pars == 3 ? 3 : 4; }
+    static __host__ bool sane(const CLayer& L) { return L.num_components >= 1 && L.num_components <= 4096 && sane_hh(L.hh_iter); }
     static __host__ int row_len(const CLayer& L) { return rot_len(L.hh_iter, 2) + omega_pars(L) * L.num_components; }
     static __host__ int n_bins(const CLayer&) { return 0; }
     static __host__ bool needs_tab(const CLayer&) { return false; }
@@ -217,6 +228,7 @@ struct MFam {
 struct CFam {
     using CLayer = jf_c_layer;
     static constexpr int DIM = 2;      // interval / S1 use column 0 only (the host passes dim)
+    static __host__ bool sane(const CLayer& L) { return L.kind >= 0 && L.kind <= 2 && sane_hh(L.hh_iter); }
     static __host__ int row_len(const CLayer& L) { return rot_len(L.hh_iter, L.kind == 2 ? 3 : 2); }
     static __host__ int n_bins(const CLayer&) { return 0; }
     static __host__ bool needs_tab(const CLayer&) { return false; }
@@ -294,6 +306,13 @@ struct FFam {
             case JF_F_KAPPA_QUATVEC: return M<T>::sqrt(rot[1] * rot[1] + rot[2] * rot[2] + rot[3] * rot[3]);
             default: return rot[1] * rot[1] + rot[2] * rot[2] + rot[3] * rot[3];
         }
+    }
+    static __host__ bool sane(const CLayer& L) {
+        if (!sane_hh(L.hh_iter) || L.n_vertical < 0 || L.n_vertical > JF_MAX_NESTED || L.n_circular < 0 || L.n_circular > JF_MAX_NESTED) return false;
+        if (L.corr_hidden < 0 || L.corr_hidden > 65536 || L.corr_rank < 0 || L.corr_rank > 65536) return false;
+        for (int i = 0; i < L.n_vertical; ++i) if (!sane_spline(L.vertical[i].sp)) return false;
+        for (int i = 0; i < L.n_circular; ++i) if (!sane_spline(L.circular[i].sp) || !sane_hh(L.circular[i].hh_iter)) return false;
+        return true;
     }
     static __host__ int row_len(const CLayer& L) {
         int n = rot_len(L.hh_iter, 3) + n_kappa(L);

@@ -328,6 +328,7 @@ static int mchain_bwd(const T* x, int64_t xs, const T* params, int64_t ps, int32
     MBwdArgs<T, typename Fam::CLayer> a{};
     int col = 0;
     for (int l = 0; l < n_layers; ++l) {
+        if (!Fam::sane(layers[l])) return JF_ERR_BADARG;
         a.L[l] = layers[l];
         a.col0[l] = col;
         col += Fam::row_len(layers[l]);

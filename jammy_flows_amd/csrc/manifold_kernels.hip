@@ -105,6 +105,7 @@ static int mchain(const T* x, int64_t xs, const T* ld_in, const T* params, int64
     a.x = x; a.xs = xs; a.ld_in = ld_in; a.params = params; a.ps = ps; a.bcast = (pb == 1) ? 1 : 0; a.B = B; a.n_layers = n_layers;
     int col = 0, maxp = 0;
     for (int l = 0; l < n_layers; ++l) {
+        if (!Fam::sane(layers[l])) return JF_ERR_BADARG;
         a.L[l] = layers[l];
         const int n = Fam::row_len(layers[l]);
         a.col0[l] = col; a.ncols[l] = n;

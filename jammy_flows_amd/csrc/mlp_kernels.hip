@@ -458,7 +458,7 @@ static int mlp2_dispatch(const T* in, int64_t in_stride, const T* W1, int64_t w1
 template <typename T>
 static int mlp2(const T* in, int64_t in_stride, const T* W1, int64_t w1_stride, const T* b1, const T* W2, int64_t w2_stride, const T* b2, int64_t B,
                 int32_t K1, int32_t H, int32_t N, T* out, int64_t out_stride, void* stream) {
-    if (!in || !W1 || !b1 || !W2 || !out || K1 < 1 || N < 1 || H < 1 || B < 0) return JF_ERR_BADARG;
+    if (!in || !W1 || !b1 || !W2 || !out || !width_ok(K1) || !width_ok(N) || !width_ok(H) || !rows_ok(B)) return JF_ERR_BADARG;
     if (K1 > K1MAX || H > HMAX) return JF_ERR_UNSUPPORTED;
     if ((H % Vec16<T>::N) || (w2_stride % Vec16<T>::N) || (reinterpret_cast<uintptr_t>(W2) & 15u)) return JF_ERR_UNSUPPORTED;   // 16-byte W2 rows
     if (B == 0) return JF_OK;
@@ -517,7 +517,7 @@ template <typename T> static bool skinny_linear(const T* in, int64_t is, const T
 template <typename T>
 static int linear(const T* in, int64_t in_stride, const T* W, int64_t w_stride, const T* bias, int64_t B, int32_t K, int32_t N, int32_t act, T* out,
                   int64_t out_stride, void* stream) {
-    if (!in || !W || !out || K < 1 || N < 1 || B < 0 || (act != 0 && act != 1)) return JF_ERR_BADARG;
+    if (!in || !W || !out || !width_ok(K) || !width_ok(N) || !rows_ok(B) || (act != 0 && act != 1)) return JF_ERR_BADARG;
     if (B == 0) return JF_OK;
     if (skinny_linear<T>(in, in_stride, W, w_stride, bias, B, K, N, act, out, out_stride, (hipStream_t)stream)) return check_launch();
     // K <= 128 with 16-byte aligned weight rows: the mlp2 machinery without a first layer (input held in registers as the B operand,

@@ -212,13 +212,13 @@ static bool sg_supported(const void* X, int64_t xs, const float* bias, const voi
 }
 
 static int64_t sg_packed_bytes(int N, int K) {
-    if (N < 1 || K < 1) return JF_ERR_BADARG;
+    if (!width_ok(N) || !width_ok(K)) return JF_ERR_BADARG;
     const SgShape sh = sg_shape(N);
     return sg_groups(N, sh.ng) * sg_kchunks(K, sh.kc) * (int64_t)sh.ng * sh.kc * SG_NP * SG_FRAG;
 }
 
 static int sg_pack(const float* W, int64_t ws, int64_t wks, int N, int K, void* packed, void* stream) {
-    if (!W || !packed || N < 1 || K < 1) return JF_ERR_BADARG;
+    if (!W || !packed || !width_ok(N) || !width_ok(K)) return JF_ERR_BADARG;
     const SgShape sh = sg_shape(N);
     const int n_kc = (int)sg_kchunks(K, sh.kc);
     const int64_t total = sg_groups(N, sh.ng) * n_kc * sh.ng * sh.kc * 64;
@@ -238,7 +238,7 @@ template <int NG, int KC, int TB> static int sg_launch(const SgArgs& a, hipStrea
 }
 
 static int sg_linear(const float* X, int64_t xs, const void* packed, const float* bias, int64_t B, int K, int N, float* out, int64_t os, void* stream) {
-    if (!X || !packed || !out || B < 0 || K < 1 || N < 1) return JF_ERR_BADARG;
+    if (!X || !packed || !out || !rows_ok(B) || !width_ok(K) || !width_ok(N)) return JF_ERR_BADARG;
     if (!sg_supported(X, xs, bias, out, os, K, N) || (reinterpret_cast<uintptr_t>(packed) & 15u)) return JF_ERR_UNSUPPORTED;
     if (B == 0) return JF_OK;
     const SgShape sh = sg_shape(N);
@@ -252,7 +252,7 @@ static int sg_linear(const float* X, int64_t xs, const void* packed, const float
 }  // namespace jf
 
 extern "C" {
-int64_t jf_linear_split_packed_bytes(int32_t N, int32_t K) { return jf::sg_packed_bytes(N, K); }
+int64_t jf_linear_split_packed_bytes(int32_t N, int32_t K) { return (jf::width_ok(N) && jf::width_ok(K)) ? jf::sg_packed_bytes(N, K) : (int64_t)JF_ERR_BADARG; }
 int jf_linear_split_pack_f32(const float* W, int64_t w_row_stride, int64_t w_col_stride, int32_t N, int32_t K, void* packed, void* stream) {
     return jf::sg_pack(W, w_row_stride, w_col_stride, N, K, packed, stream);
 }
@@ -402,6 +402,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_split_kernel(const WsArgs a) {
 }
 
 static int64_t ws_splits(int64_t B, int N) {
+    if (N < 1 || B < 1) return 1;                                  // (the entry points reject such shapes; the query must not divide by zero)
     const int64_t cols = (N + WS_NW - 1) / WS_NW;
     int64_t s = (1024 + cols - 1) / cols;                          // ~2 resident rounds of workgroups
     const int64_t max_s = (B + 511) / 512;                         // at least 512 rows per split
@@ -411,7 +412,7 @@ static int64_t ws_splits(int64_t B, int N) {
 }
 
 static int ws_wgrad(const float* g, int64_t gs, const float* in, int64_t is, int64_t B, int K, int N, float* pw, float* pb, void* stream) {
-    if (!g || !in || !pw || B < 0 || K < 1 || N < 1) return JF_ERR_BADARG;
+    if (!g || !in || !pw || !rows_ok(B) || !width_ok(K) || !width_ok(N)) return JF_ERR_BADARG;
     if (K > 128 || K % 4 || N % 4 || gs % 4 || is % 4 || ((reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(in)) & 15u)) return JF_ERR_UNSUPPORTED;
     if (B == 0) return JF_OK;
     WsArgs a{};
@@ -425,7 +426,7 @@ static int ws_wgrad(const float* g, int64_t gs, const float* in, int64_t is, int
 }  // namespace jf
 
 extern "C" {
-int64_t jf_linear_wgrad_split_splits(int64_t B, int32_t N) { return jf::ws_splits(B, N); }
+int64_t jf_linear_wgrad_split_splits(int64_t B, int32_t N) { return (jf::width_ok(N) && jf::rows_ok(B)) ? jf::ws_splits(B, N) : (int64_t)JF_ERR_BADARG; }
 int jf_linear_wgrad_split_f32(const float* g, int64_t g_stride, const float* in, int64_t in_stride, int64_t B, int32_t K, int32_t N, float* partial_w,
                               float* partial_b, void* stream) {
     return jf::ws_wgrad(g, g_stride, in, in_stride, B, K, N, partial_w, partial_b, stream);

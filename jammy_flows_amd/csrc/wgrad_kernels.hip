@@ -364,7 +364,7 @@ static void wgrad_go(const T* g, int64_t gs, const T* in, int64_t is, int64_t B,
 
 template <typename T>
 static int wgrad(const T* g, int64_t gs, const T* in, int64_t is, int64_t B, int32_t K, int32_t N, T* pw, T* pb, void* stream) {
-    if (!g || !in || !pw || B < 0 || K < 1 || N < 1) return JF_ERR_BADARG;
+    if (!g || !in || !pw || !rows_ok(B) || !width_ok(K) || !width_ok(N)) return JF_ERR_BADARG;
     if (B == 0) return JF_OK;
     hipStream_t st = (hipStream_t)stream;
     if (wgrad_skinny<T>(g, gs, in, is, B, K, N, pw, pb, st)) return check_launch();
@@ -386,15 +386,15 @@ static int wgrad(const T* g, int64_t gs, const T* in, int64_t is, int64_t B, int
 }  // namespace jf
 
 extern "C" {
-int64_t jf_linear_wgrad_splits_f32(int64_t B, int32_t K, int32_t N) { return jf::wgrad_is_skinny(K, N) ? jf::wgrad_skinny_splits(B, K, N) : jf::wgrad_splits_t<float>(B, N); }
-int64_t jf_linear_wgrad_splits_f64(int64_t B, int32_t K, int32_t N) { return jf::wgrad_is_skinny(K, N) ? jf::wgrad_skinny_splits(B, K, N) : jf::wgrad_splits_t<double>(B, N); }
+int64_t jf_linear_wgrad_splits_f32(int64_t B, int32_t K, int32_t N) { if (!jf::width_ok(K) || !jf::width_ok(N) || !jf::rows_ok(B)) return JF_ERR_BADARG; return jf::wgrad_is_skinny(K, N) ? jf::wgrad_skinny_splits(B, K, N) : jf::wgrad_splits_t<float>(B, N); }
+int64_t jf_linear_wgrad_splits_f64(int64_t B, int32_t K, int32_t N) { if (!jf::width_ok(K) || !jf::width_ok(N) || !jf::rows_ok(B)) return JF_ERR_BADARG; return jf::wgrad_is_skinny(K, N) ? jf::wgrad_skinny_splits(B, K, N) : jf::wgrad_splits_t<double>(B, N); }
 int jf_linear_wgrad_f32(const float* g, int64_t gs, const float* in, int64_t is, int64_t B, int32_t K, int32_t N, float* pw, float* pb, void* s) {
     return jf::wgrad<float>(g, gs, in, is, B, K, N, pw, pb, s);
 }
 int jf_linear_wgrad_f64(const double* g, int64_t gs, const double* in, int64_t is, int64_t B, int32_t K, int32_t N, double* pw, double* pb, void* s) {
     return jf::wgrad<double>(g, gs, in, is, B, K, N, pw, pb, s);
 }
-int64_t jf_mlp2_small_bwd_slabs(int64_t B) { return jf::mlp2_small_slabs(B); }
+int64_t jf_mlp2_small_bwd_slabs(int64_t B) { return jf::rows_ok(B) ? jf::mlp2_small_slabs(B) : (int64_t)JF_ERR_BADARG; }
 int jf_mlp2_small_bwd_f32(const float* x, int64_t xs, const float* W1, int64_t w1s, const float* b1, const float* W2, int64_t w2s, const float* g, int64_t gs,
                           int64_t B, int32_t K1, int32_t H, int32_t N, float* slab, float* slab_b2, void* s) {
     return jf::mlp2_small_bwd<float>(x, xs, W1, w1s, b1, W2, w2s, g, gs, B, K1, H, N, slab, slab_b2, s);
