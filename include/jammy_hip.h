@@ -157,6 +157,31 @@ int jf_cond_gf_chain_fwd_split_f32(const float* in, int64_t in_stride, const flo
                                    int32_t K1, int32_t H, const float* z, int64_t z_stride, const float* log_det_in, int64_t B, int32_t D,
                                    int32_t n_layers, const jf_gf_layer* layers, float* x_out, int64_t x_out_stride, float* log_det_out,
                                    int32_t* status, void* stream);
+/* Training step of the same block (float32; replaces torch.autograd's replay of main/default.py:656-670, 946-962, 998-1031 +
+ * gaussianization_flow.py:995-1114 for the loss of examples/jammy_flows.py:381-412).
+ * jf_cond_gf_chain_inv_split_save_f32 = jf_cond_gf_chain_inv_split_f32 that also leaves, per (layer, row, coordinate lane), the layer's input
+ * coordinate and its normalised mixture sums (cdf, sf, pdf, 1 / N) in aux (jf_cond_gf_aux_floats(B, n_layers) floats, 16-byte aligned).
+ * jf_cond_gf_chain_inv_split_bwd_f32 recomputes the hidden activations and each layer's parameters like the forward launch, overwrites the
+ * parameter registers with their gradients and returns, for upstream gradients g_x_out (B, D) / g_log_det (B) / g_base_logp (B) (each may be
+ * NULL = zero):  g_x (B, D);  h (B, H), the hidden activations;  g_h (B, H) = g_params W2, the gradient arriving at them;  g_pp
+ * (B, n_layers * 144), the gradient of the parameter rows in PACKED column order [layer][coordinate lane 0..3][slot 0..35] (slot order: 10
+ * means, 10 log-widths, 10 log-weights, 4 Householder vectors, offset, pad; absent columns are zero).  g_W2 / g_b2 are then one
+ * jf_linear_wgrad_split_f32(g_pp, h) whose rows the caller gathers back into W2's row order; g_W1 / g_b1 one jf_mlp_hidden_bwd_f32(g_h).
+ * packedT: W2^T as MFMA fragments (jf_cond_gf_bwd_packed_bytes / jf_cond_gf_bwd_pack_f32, redo whenever W2 changes).  z: x_out of the
+ * forward launch.  Same limits as jf_cond_gf_chain_inv_split_f32, H % 4 == 0. */
+int jf_cond_gf_chain_inv_split_save_f32(const float* in, int64_t in_stride, const float* W1, int64_t w1_stride, const float* b1, const void* packed,
+                                        int32_t K1, int32_t H, const float* x, int64_t x_stride, const float* log_det_in, int64_t B, int32_t D,
+                                        int32_t n_layers, const jf_gf_layer* layers, float* x_out, int64_t x_out_stride, float* log_det_out,
+                                        const float* base_logp_in, float* base_logp_out, float* aux, int32_t* status, void* stream);
+int64_t jf_cond_gf_aux_floats(int64_t B, int32_t n_layers);
+int64_t jf_cond_gf_bwd_packed_bytes(int32_t D, int32_t n_layers, const jf_gf_layer* layers);
+int jf_cond_gf_bwd_pack_f32(const float* W2, int64_t w2_stride, int32_t H, int32_t D, int32_t n_layers, const jf_gf_layer* layers, void* packedT,
+                            void* stream);
+int jf_cond_gf_chain_inv_split_bwd_f32(const float* in, int64_t in_stride, const float* W1, int64_t w1_stride, const float* b1, const void* packed,
+                                       const void* packedT, int32_t K1, int32_t H, const float* z, int64_t z_stride, const float* aux, int64_t B,
+                                       int32_t D, int32_t n_layers, const jf_gf_layer* layers, const float* g_x_out, int64_t g_x_out_stride,
+                                       const float* g_log_det, const float* g_base_logp, float* g_x, int64_t g_x_stride, float* g_pp,
+                                       int64_t g_pp_stride, float* h_out, int64_t h_stride, float* g_h, int64_t g_h_stride, void* stream);
 /* Third generation of the same block ("ping-pong", cond_pp_kernels.hip): 32x32x16 bf16 tiles (one MFMA per 32 cycles leaves the vector ALU
  * ~20 free issue cycles, a 16x16x32 one ~4), persistent 512-thread workgroups whose two four-wave teams run the same program half a layer
  * apart, so that on every SIMD one wave multiplies while its partner evaluates the flow.  Same arithmetic (3-way split bf16, six products, f32

@@ -159,6 +159,13 @@ _SIGNATURES_SINGLE = {
     "jf_cond_gf_chain_inv_pp_f32": ([_P, _I64, _P, _I64, _P, _P, _I32, _I32, _P, _I64, _P, _I64, _I32, _I32, ctypes.POINTER(jf_gf_layer), _P, _I64,
                                      _P, _P, _P, _P, _P], ctypes.c_int),
     "jf_cond_gf_pack_f32": ([_P, _I64, _P, _I32, _I32, _I32, ctypes.POINTER(jf_gf_layer), _P, _P], ctypes.c_int),
+    "jf_cond_gf_chain_inv_split_save_f32": ([_P, _I64, _P, _I64, _P, _P, _I32, _I32, _P, _I64, _P, _I64, _I32, _I32, ctypes.POINTER(jf_gf_layer), _P,
+                                             _I64, _P, _P, _P, _P, _P, _P], ctypes.c_int),
+    "jf_cond_gf_aux_floats": ([_I64, _I32], ctypes.c_int64),
+    "jf_cond_gf_bwd_packed_bytes": ([_I32, _I32, ctypes.POINTER(jf_gf_layer)], ctypes.c_int64),
+    "jf_cond_gf_bwd_pack_f32": ([_P, _I64, _I32, _I32, _I32, ctypes.POINTER(jf_gf_layer), _P, _P], ctypes.c_int),
+    "jf_cond_gf_chain_inv_split_bwd_f32": ([_P, _I64, _P, _I64, _P, _P, _P, _I32, _I32, _P, _I64, _P, _I64, _I32, _I32, ctypes.POINTER(jf_gf_layer),
+                                            _P, _I64, _P, _P, _P, _I64, _P, _I64, _P, _I64, _P, _I64, _P], ctypes.c_int),
     "jf_cond_gf_chain_inv_split_f32": ([_P, _I64, _P, _I64, _P, _P, _I32, _I32, _P, _I64, _P, _I64, _I32, _I32, ctypes.POINTER(jf_gf_layer), _P, _I64,
                                         _P, _P, _P, _P, _P], ctypes.c_int),
 }
@@ -516,9 +523,10 @@ def cond_gf_pack(w2, b2, layer_array, n_layers, D, kind="split"):
 
 
 def cond_gf_chain_inv_split(inp, w1, b1, packed, x, log_det, layer_array, n_layers, D, x_out=None, base_logp_in=None, want_base_logp=False,
-                            status=None, kind="split"):
+                            status=None, kind="split", aux=None):
     """as cond_gf_chain_inv with the second product on split-bf16 MFMA and the parameter block in registers (float32, default layer options);
-    `kind` selects the kernel the packed image was built for."""
+    `kind` selects the kernel the packed image was built for.  aux (cond_gf_aux, "split" only): the launch also leaves what
+    cond_gf_chain_inv_split_bwd starts from."""
     dev = require_device(inp, w1, b1, packed, x, log_det, x_out, base_logp_in, status)
     inp, w1, x = _rowmajor(inp), _rowmajor(w1), _rowmajor(x)
     B, K1 = inp.shape
@@ -533,10 +541,84 @@ def cond_gf_chain_inv_split(inp, w1, b1, packed, x, log_det, layer_array, n_laye
         x_out = torch.empty((B, D), dtype=x.dtype, device=x.device)
     ld_out = torch.empty((B,), dtype=x.dtype, device=x.device)
     blp_out = torch.empty((B,), dtype=x.dtype, device=x.device) if want_base_logp else None
+    if aux is not None:
+        if kind != "split" or aux.dtype != torch.float32 or aux.numel() < n_layers * B * 20 or not aux.is_contiguous():
+            raise ValueError("cond_gf_chain_inv_split: aux needs the 'split' kernel and cond_gf_aux(B, n_layers)")
+        _launch("jf_cond_gf_chain_inv_split_save_f32", "K%d_H%d_L%d_D%d" % (K1, H, n_layers, D),
+                (_ptr(inp), inp.stride(0), _ptr(w1), w1.stride(0), _ptr(b1.contiguous()), _ptr(packed), K1, H, _ptr(x), x.stride(0), _ptr(log_det),
+                 B, D, n_layers, layer_array, _ptr(x_out), x_out.stride(0), _ptr(ld_out), _ptr(base_logp_in), _ptr(blp_out), _ptr(aux),
+                 _ptr(status)), dev)
+        return (x_out, ld_out, blp_out) if want_base_logp else (x_out, ld_out)
     _launch(_COND_GF_PACK[kind][2], "K%d_H%d_L%d_D%d" % (K1, H, n_layers, D),
             (_ptr(inp), inp.stride(0), _ptr(w1), w1.stride(0), _ptr(b1.contiguous()), _ptr(packed), K1, H, _ptr(x), x.stride(0), _ptr(log_det), B, D,
              n_layers, layer_array, _ptr(x_out), x_out.stride(0), _ptr(ld_out), _ptr(base_logp_in), _ptr(blp_out), _ptr(status)), dev)
     return (x_out, ld_out, blp_out) if want_base_logp else (x_out, ld_out)
+
+
+COND_GF_SLOTS = 36                   # parameter slots per coordinate lane and layer in the packed gradient rows (csrc/jf_cond_regs.h)
+
+
+def cond_gf_aux(B, n_layers, device):
+    """buffer the gradient-mode forward launch of the fused block fills: per (layer, row, coordinate lane) the layer's input coordinate and
+    its mixture sums"""
+    return torch.empty((int(lib().jf_cond_gf_aux_floats(B, n_layers)),), dtype=torch.float32, device=device)
+
+
+def cond_gf_bwd_pack(w2, layer_array, n_layers, D):
+    """W2 (N, H) -> W2^T as MFMA fragments for cond_gf_chain_inv_split_bwd's g_h product.  Redo whenever the weights change."""
+    dev = require_device(w2)
+    w2 = _rowmajor(w2)
+    if w2.dtype != torch.float32:
+        raise TypeError("cond_gf_bwd_pack: float32 only")
+    nbytes = int(lib().jf_cond_gf_bwd_packed_bytes(D, n_layers, layer_array))
+    _check(min(nbytes, 0), "jf_cond_gf_bwd_packed_bytes")
+    packed = torch.empty((nbytes,), dtype=torch.uint8, device=w2.device)
+    _launch("jf_cond_gf_bwd_pack_f32", "", (_ptr(w2), w2.stride(0), w2.shape[1], D, n_layers, layer_array, _ptr(packed)), dev)
+    return packed
+
+
+def cond_gf_packed_rows(layer_array, n_layers, D):
+    """index (list of ints, one per column of the natural parameter row) into the packed gradient row [layer][coordinate lane][slot] that
+    cond_gf_chain_inv_split_bwd writes: natural order per layer = offset (D, if modelled), Householder vectors (hh_iter x D), means, log-widths,
+    log-weights (num_kde x D each) -- gaussianization_flow.py:63-215; slots = csrc/jf_cond_regs.h."""
+    idx = []
+    for l in range(n_layers):
+        o = layer_array[l]
+        K = o.num_kde
+        base = l * 4 * COND_GF_SLOTS
+        if o.model_offset:
+            idx += [base + d * COND_GF_SLOTS + 3 * K + 4 for d in range(D)]
+        for i in range(o.hh_iter):
+            idx += [base + d * COND_GF_SLOTS + 3 * K + i for d in range(D)]
+        for sec in range(3):
+            for k in range(K):
+                idx += [base + d * COND_GF_SLOTS + sec * K + k for d in range(D)]
+    return idx
+
+
+def cond_gf_chain_inv_split_bwd(inp, w1, b1, packed, packed_t, z, aux, layer_array, n_layers, D, g_xout, g_ld, g_blp):
+    """adjoint of cond_gf_chain_inv_split(..., aux=aux) in one launch -> (g_x (B, D), g_pp (B, n_layers * 144) packed parameter-row gradient,
+    h (B, H) hidden activations, g_h (B, H)); see include/jammy_hip.h."""
+    dev = require_device(inp, w1, b1, packed, packed_t, z, aux, g_xout, g_ld, g_blp)
+    inp, w1, z = _rowmajor(inp), _rowmajor(w1), _rowmajor(z)
+    B, K1 = inp.shape
+    H = w1.shape[0]
+    if z.shape[0] != B or z.shape[1] != D or w1.shape[1] != K1 or b1.shape[0] != H or aux.numel() < n_layers * B * 20:
+        raise ValueError("cond_gf_chain_inv_split_bwd: inconsistent shapes")
+    if any(t is not None and t.dtype != torch.float32 for t in (inp, w1, b1, z, aux, g_xout, g_ld, g_blp)):
+        raise TypeError("cond_gf_chain_inv_split_bwd: float32 only")
+    g_xout = None if g_xout is None else _rowmajor(g_xout)
+    g_ld = None if g_ld is None else g_ld.contiguous()
+    g_blp = None if g_blp is None else g_blp.contiguous()
+    g_x = torch.empty((B, D), dtype=z.dtype, device=z.device)
+    g_pp = torch.empty((B, n_layers * 4 * COND_GF_SLOTS), dtype=z.dtype, device=z.device)
+    h = torch.empty((B, H), dtype=z.dtype, device=z.device)
+    g_h = torch.empty((B, H), dtype=z.dtype, device=z.device)
+    _launch("jf_cond_gf_chain_inv_split_bwd_f32", "K%d_H%d_L%d_D%d" % (K1, H, n_layers, D),
+            (_ptr(inp), inp.stride(0), _ptr(w1), w1.stride(0), _ptr(b1.contiguous()), _ptr(packed), _ptr(packed_t), K1, H, _ptr(z), z.stride(0),
+             _ptr(aux), B, D, n_layers, layer_array, _ptr(g_xout), 0 if g_xout is None else g_xout.stride(0), _ptr(g_ld), _ptr(g_blp),
+             _ptr(g_x), g_x.stride(0), _ptr(g_pp), g_pp.stride(0), _ptr(h), h.stride(0), _ptr(g_h), g_h.stride(0)), dev)
+    return g_x, g_pp, h, g_h
 
 
 def cond_gf_chain_fwd_split(inp, w1, b1, packed, z, log_det, layer_array, n_layers, D, x_out=None, status=None):

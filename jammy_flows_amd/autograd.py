@@ -12,6 +12,8 @@ Every Function's forward is the SAME kernel launch the inference path uses; noth
   * the fused conditional block (MLP + g layers in one launch) recomputes its parameter block with two dense launches in backward and
     then runs the same two steps.
 """
+import os
+
 import torch
 
 from . import _hip
@@ -124,6 +126,22 @@ class GfChainInvFn(torch.autograd.Function):
         return (g_x, g_ld if ctx.has[0] else None, g_params, g_blp if ctx.has[1] else None, None, None, None, None)
 
 
+# the fused block's backward in one launch (csrc/cond_bwd_kernels.hip) wherever the "split" kernel ran the forward; "0" = the round-2 sequence
+# of dense launches around a materialised parameter block (kept for A/B timing and as the path of the other kernels)
+FUSED_BLOCK_BACKWARD = os.environ.get("JF_FUSED_BLOCK_BACKWARD", "1") != "0"
+_packed_row_index = {}
+
+
+def _packed_rows(layer_array, n_layers, D, device):
+    """device index tensor: natural parameter column -> column of the packed gradient row of the fused backward kernel"""
+    idx = _hip.cond_gf_packed_rows(layer_array, n_layers, D)
+    key = (tuple(idx), str(device))
+    t = _packed_row_index.get(key)
+    if t is None:
+        t = _packed_row_index[key] = torch.tensor(idx, dtype=torch.int64, device=device)
+    return t
+
+
 class CondBlockFn(torch.autograd.Function):
     """conditional e-block in one launch (jf_cond_gf_chain_inv[_split]): amortisation MLP Linear-tanh-Linear + its g layers."""
 
@@ -131,35 +149,55 @@ class CondBlockFn(torch.autograd.Function):
     def forward(ctx, inp, w1, b1, w2, b2, x, log_det, base_logp_in, packed, layer_array, n_layers, D, status):
         args = (x.detach(), None if log_det is None else log_det.detach(), layer_array, n_layers, D)
         kw = dict(base_logp_in=None if base_logp_in is None else base_logp_in.detach(), want_base_logp=True, status=status)
+        aux = None
         if packed is not None:
-            res = _hip.cond_gf_chain_inv_split(inp.detach(), w1.detach(), b1.detach(), packed[1], *args, kind=packed[0], **kw)
+            if FUSED_BLOCK_BACKWARD and packed[0] == "split" and w1.shape[0] % 4 == 0 and x.shape[0] > 0:
+                aux = _hip.cond_gf_aux(x.shape[0], n_layers, x.device)
+            res = _hip.cond_gf_chain_inv_split(inp.detach(), w1.detach(), b1.detach(), packed[1], *args, kind=packed[0], aux=aux, **kw)
         else:
             res = _hip.cond_gf_chain_inv(inp.detach(), w1.detach(), b1.detach(), w2.detach(), b2.detach(), *args, **kw)
         ctx.meta = (layer_array, n_layers, D)
         ctx.set_materialize_grads(False)             # unused outputs arrive as None (the kernels take NULL), not as zero-filled tensors
         ctx.has = (log_det is not None, base_logp_in is not None)
-        ctx.save_for_backward(inp, w1, b1, w2, b2, x)
+        ctx.fused = None if aux is None else (packed[1], aux)
+        ctx.save_for_backward(inp, w1, b1, w2, b2, x, res[0] if aux is not None else None)
         return res
 
     @staticmethod
     def backward(ctx, g_xout, g_ld, g_blp):
-        inp, w1, b1, w2, b2, x = ctx.saved_tensors
+        inp, w1, b1, w2, b2, x, z = ctx.saved_tensors
         layer_array, n_layers, D = ctx.meta
-        # the parameter block is not kept by the forward launch: two dense launches bring it back (the large one on split-bf16 MFMA, float32:
-        # the arithmetic of the fused forward block)
-        h = _hip.linear(inp, w1, b1, 1)
-        split = _hip.linear_split_ok(h, w2, b2)
-        params = _hip.linear_split(h, w2, b2) if split else _hip.linear(h, w2, b2, 0)
-        g_x, g_p = _hip.gf_chain_inv_bwd(x, params, layer_array, n_layers, D, g_xout, g_ld, g_blp, status=None)
-        del params
         need = ctx.needs_input_grad
-        g_w2, g_b2 = _hip.linear_wgrad(g_p, h, want_bias=need[4]) if (need[3] or need[4]) else (None, None)
+        if ctx.fused is not None:
+            # ONE launch: hidden activations and parameters recomputed in the forward kernel's register layout, each layer's adjoint in place,
+            # g_h accumulated from the same registers; the parameter-row gradient leaves in packed column order for the weight-gradient product
+            packed, aux = ctx.fused
+            packed_t = _hip.cond_gf_bwd_pack(w2, layer_array, n_layers, D)
+            g_x, g_p, h, g_hid = _hip.cond_gf_chain_inv_split_bwd(inp, w1, b1, packed, packed_t, z, aux, layer_array, n_layers, D, g_xout, g_ld, g_blp)
+            ctx.fused = None
+            del aux
+            g_w2 = g_b2 = None
+            if need[3] or need[4]:
+                rows = _packed_rows(layer_array, n_layers, D, g_p.device)
+                g_w2, g_b2 = _hip.linear_wgrad(g_p, h, want_bias=need[4])
+                g_w2 = g_w2.index_select(0, rows)
+                g_b2 = None if g_b2 is None else g_b2.index_select(0, rows)
+        else:
+            # the parameter block is not kept by the forward launch: two dense launches bring it back (the large one on split-bf16 MFMA, float32:
+            # the arithmetic of the fused forward block)
+            h = _hip.linear(inp, w1, b1, 1)
+            split = _hip.linear_split_ok(h, w2, b2)
+            params = _hip.linear_split(h, w2, b2) if split else _hip.linear(h, w2, b2, 0)
+            g_x, g_p = _hip.gf_chain_inv_bwd(x, params, layer_array, n_layers, D, g_xout, g_ld, g_blp, status=None)
+            del params
+            g_w2, g_b2 = _hip.linear_wgrad(g_p, h, want_bias=need[4]) if (need[3] or need[4]) else (None, None)
+            g_hid = None
         if not need[0] and inp.shape[1] <= _hip.MLP2_SMALL_MAX_IN and w1.shape[0] <= _hip.MLP2_MAX_HIDDEN and inp.shape[0] > 0:
             # data rows in front: tanh derivative + first-layer weight / bias gradient in one launch (the activations recomputed per hidden unit)
-            g_w1, g_b1 = _hip.mlp_hidden_bwd(inp, w1, b1, _input_grad(g_p, w2))
+            g_w1, g_b1 = _hip.mlp_hidden_bwd(inp, w1, b1, g_hid if g_hid is not None else _input_grad(g_p, w2))
             g_inp = None
         else:
-            g_h = _hip.tanh_bwd(_input_grad(g_p, w2), h, inplace=True)
+            g_h = _hip.tanh_bwd(g_hid if g_hid is not None else _input_grad(g_p, w2), h, inplace=True)
             g_w1, g_b1 = _hip.linear_wgrad(g_h, inp, want_bias=need[2]) if (need[1] or need[2]) else (None, None)
             g_inp = _input_grad(g_h, w1) if need[0] else None
         del g_p

@@ -22,24 +22,10 @@
 //
 // Supported: float32, D in {3, 4}, layers with the reference's default options (K = 10 components, smooth-saturation widths, fitted and
 // regulated weights, <= 4 Householder reflections), H <= 128, K1 <= 28.  Everything else: jf_cond_gf_chain_inv_* / jf_mlp2 + jf_gf_chain_inv.
-#include "jf_cond_regs.h"
-#include "jf_mfma.h"
+#include "jf_cond_split.h"
 #include <cstdlib>
 
 namespace jf {
-
-constexpr int CS_TILES = 9;                        // 16-column MFMA tiles per layer (36 slots x 4 coordinates)
-static_assert(CS_SLOTS == 4 * CS_TILES, "one register per slot, four registers per tile");
-constexpr int CS_CT = 3;                           // tiles per chunk
-constexpr int CS_CPL = CS_TILES / CS_CT;           // chunks per layer
-constexpr int CS_KSTEPS = 4;                       // 128 hidden units = 4 x 32
-constexpr int CS_NP = 3;                           // bf16 pieces per f32 operand
-constexpr int CS_FRAG = 1024;                      // bytes of one A fragment (64 lanes x 8 bf16)
-constexpr int CS_W_BYTES = CS_CT * CS_KSTEPS * CS_NP * CS_FRAG;       // 36864
-constexpr int CS_B_BYTES = CS_CT * 16 * 4;                            // 192: the chunk's bias, permuted column order
-constexpr int CS_CHUNK_BYTES = CS_W_BYTES + CS_B_BYTES;               // 37056 (16-byte multiple)
-constexpr int CS_ROWS1 = 64;                       // rows per workgroup and row group (4 waves x 16); a wave carries RG row groups
-constexpr int CS_HMAX = 128, CS_K1MAX = 28;
 
 // ---------------------------------------------------------------------------------------------------------- packing
 struct CsPackArgs {
@@ -83,22 +69,6 @@ __global__ void __launch_bounds__(256) cs_pack_kernel(const CsPackArgs a) {
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------- row-group reductions
-// the 4 coordinate lanes of a row are l, l^16, l^32, l^48.  v_permlane16_swap(vdst, src) exchanges vdst's odd 16-lane rows with src's even
-// rows, v_permlane32_swap the upper half of vdst with the lower half of src (scripts/probe/swapsem.hip), so with both operands = v the
-// two results are "my pair's even member" and "my pair's odd member" in every lane.  Written as inline asm: hipcc (ROCm 7.2) miscompiles
-// __builtin_amdgcn_permlane{16,32}_swap(v, v) followed by op(r[0], r[1]) into op(r[0], r[0]) (scripts/probe/layout16x32.hip caught it).
-// s_nop 1 = the two wait states the swap needs after a VALU write of its operands.
-template <typename Op> __device__ __forceinline__ float cs_rreduce(float v, Op op) {
-    float a = v, b = v;
-    asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
-    float c = op(a, b), e = c;
-    asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(c), "+v"(e));
-    return op(c, e);
-}
-__device__ __forceinline__ float cs_rsum(float v) { return cs_rreduce(v, [](float a, float b) { return a + b; }); }
-__device__ __forceinline__ float cs_rmax(float v) { return cs_rreduce(v, [](float a, float b) { return fmaxf(a, b); }); }
-
 // ---------------------------------------------------------------------------------------------------------- the fused kernel
 struct CsArgs {
     const float* in; int64_t in_stride;
@@ -114,20 +84,19 @@ struct CsArgs {
     float* ld_out;
     const float* blp_in; float* blp_out;
     int32_t* status;
+    float* aux;                                // SAVE: what the adjoint launch starts from (see cond_bwd_kernels.hip), else unused
 };
 
 // RG = row groups (16 rows each) per wave.  With RG = 2 every A fragment read from LDS feeds two MFMAs (half the ds_read_b128 per row,
 // six independent accumulators per piece product instead of three) and the chunk barriers are paid once per 128 rows instead of 64.
-template <int RG, bool FWD> __global__ void __launch_bounds__(256, 2) cond_gf_split_kernel(const CsArgs a) {
+// SAVE (log-prob direction with gradients wanted): every layer's input coordinate and mixture sums go to a.aux, 5 floats per (layer, row,
+// coordinate lane) -- 320 bytes per row of a 4-layer block instead of the 2.2 KB parameter row the adjoint would otherwise need.
+template <int RG, bool FWD, bool SAVE = false> __global__ void __launch_bounds__(256, 2) cond_gf_split_kernel(const CsArgs a) {
     constexpr int CS_ROWS = CS_ROWS1 * RG;
-    using MF = Mfma16<float>;
-    constexpr int MT = 16, KS = 4, NREG = 4, JH = CS_HMAX / MT;
+    constexpr int MT = 16;
     extern __shared__ __align__(16) unsigned char smem_raw[];
     unsigned char* Ws0 = smem_raw;                                 // two packed chunks (double buffer)
-    const int k1p = (a.K1 + KS - 1) / KS * KS, ldk = k1p + 1;
     float* Xs = reinterpret_cast<float*>(smem_raw + CS_CHUNK_BYTES);   // phase 1 only (overlays buffer 1 while chunk 0 lands in buffer 0)
-    float* W1s = Xs + CS_ROWS * ldk;
-    float* b1s = W1s + CS_HMAX * ldk;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lq = lane >> 4;
     const int64_t row0 = (int64_t)blockIdx.x * CS_ROWS;
@@ -154,77 +123,9 @@ template <int RG, bool FWD> __global__ void __launch_bounds__(256, 2) cond_gf_sp
     };
     dma(0);                                                        // lands in buffer 0 while phase 1 works in buffer 1
 
-    // ---- phase 1: h^T = tanh(W1 x^T + b1) for the wave's 16 rows (exact f32 MFMA); rows past B replicate row B-1
-    {
-        const int nx = CS_ROWS * k1p, nw = CS_HMAX * k1p;
-        for (int base = 0; base < nx; base += 4 * 256) {
-            float v[4]; int o[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int idx = base + u * 256 + tid;
-                const int r = idx / k1p, c = idx - r * k1p;
-                const int64_t gr = row0 + r;
-                const float t = a.in[(gr <= last ? gr : last) * a.in_stride + (c < a.K1 ? c : 0)];
-                v[u] = c < a.K1 ? t : 0.f;
-                o[u] = idx < nx ? r * ldk + c : -1;
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) if (o[u] >= 0) Xs[o[u]] = v[u];
-        }
-        for (int base = 0; base < nw; base += 4 * 256) {
-            float v[4]; int o[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int idx = base + u * 256 + tid;
-                const int r = idx / k1p, c = idx - r * k1p;
-                const float t = a.W1[(int64_t)(r < a.H ? r : a.H - 1) * a.w1s + (c < a.K1 ? c : 0)];
-                v[u] = (r < a.H && c < a.K1) ? t : 0.f;
-                o[u] = idx < nw ? r * ldk + c : -1;
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) if (o[u] >= 0) W1s[o[u]] = v[u];
-        }
-        if (tid < CS_HMAX) b1s[tid] = tid < a.H ? a.b1[tid < a.H ? tid : 0] : 0.f;
-    }
-    __syncthreads();
-    bf16x8 hB[RG][CS_KSTEPS][CS_NP];                               // the hidden activations as MFMA B operands, three bf16 pieces
-#pragma unroll
-    for (int g = 0; g < RG; ++g) {
-        typename MF::Acc acc[JH];
-#pragma unroll
-        for (int j = 0; j < JH; ++j)
-#pragma unroll
-            for (int r = 0; r < NREG; ++r) acc[j][r] = 0.f;
-        for (int s = 0; s < k1p / KS; ++s) {
-            const int kk = s * KS + lq;
-            const float xb = Xs[((wave * RG + g) * MT + li) * ldk + kk];
-#pragma unroll
-            for (int j = 0; j < JH; ++j) acc[j] = MF::mma(W1s[(j * MT + li) * ldk + kk], xb, acc[j]);
-        }
-        // acc[j][r] = pre-activation of hidden unit 16 j + 4 lq + r for row li: k-slot i of k-step s <-> (j = 2 s + i / 4, r = i % 4)
-#pragma unroll
-        for (int s = 0; s < CS_KSTEPS; ++s) {
-            // split by truncation, two values at a time (and / sub / and / sub + one v_perm_b32 per packed pair; exact as well: 24 significant
-            // bits = 3 x 8): three v_cvt_pk_bf16_f32 per value were the expensive part of this loop
-            using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
-            u32x4 q0, q1, q2;
-#pragma unroll
-            for (int i = 0; i < 8; i += 2) {
-                const int j = 2 * s + (i >> 2), r = i & 3;
-                const float h0 = M<float>::tanh_fast(acc[j][r] + b1s[j * MT + 4 * lq + r]);
-                const float h1 = M<float>::tanh_fast(acc[j][r + 1] + b1s[j * MT + 4 * lq + r + 1]);
-                const unsigned a0 = __builtin_bit_cast(unsigned, h0), a1 = __builtin_bit_cast(unsigned, h1);
-                const float r0 = h0 - __builtin_bit_cast(float, a0 & 0xffff0000u), r1 = h1 - __builtin_bit_cast(float, a1 & 0xffff0000u);
-                const unsigned c0 = __builtin_bit_cast(unsigned, r0), c1 = __builtin_bit_cast(unsigned, r1);
-                const float s0 = r0 - __builtin_bit_cast(float, c0 & 0xffff0000u), s1 = r1 - __builtin_bit_cast(float, c1 & 0xffff0000u);
-                q0[i >> 1] = __builtin_amdgcn_perm(a1, a0, 0x07060302u);
-                q1[i >> 1] = __builtin_amdgcn_perm(c1, c0, 0x07060302u);
-                q2[i >> 1] = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, s1), __builtin_bit_cast(unsigned, s0), 0x07060302u);
-            }
-            hB[g][s][0] = __builtin_bit_cast(bf16x8, q0); hB[g][s][1] = __builtin_bit_cast(bf16x8, q1); hB[g][s][2] = __builtin_bit_cast(bf16x8, q2);
-        }
-    }
-
+    // ---- phase 1: h^T = tanh(W1 x^T + b1) for the wave's rows as MFMA B operands, three bf16 pieces (jf_cond_split.h)
+    bf16x8 hB[RG][CS_KSTEPS][CS_NP];
+    cs_hidden<RG, false>(a.in, a.in_stride, a.W1, a.w1s, a.b1, a.K1, a.H, row0, last, Xs, hB, nullptr, 0);
     // ---- flow state: lane = (row li of the row group's 16, coordinate lq)
     const bool live = lq < D, leader = lq == 0;
     const int d = live ? lq : D - 1;
@@ -306,7 +207,15 @@ template <int RG, bool FWD> __global__ void __launch_bounds__(256, 2) cond_gf_sp
                         xg -= 2.0f * dot * M<float>::rcp(n2) * v;
                     }
                 }
-                const MixQ<float> q = cs_mixture(P[g], o, xg, live);
+                CsSums sums;
+                const MixQ<float> q = cs_mixture(P[g], o, xg, live, SAVE ? &sums : nullptr);
+                if constexpr (SAVE) {
+                    if (row_valid[g]) {
+                        const int64_t slot = ((int64_t)l * a.B + row[g]) * 4 + lq;
+                        reinterpret_cast<f32x4*>(a.aux)[slot] = f32x4{sums.C, sums.S, sums.P, sums.invN};
+                        a.aux[(int64_t)a.n_layers * a.B * 16 + slot] = x[g];
+                    }
+                }
                 const IcdfOut<float> sy = gf_icdf<float>(o.inv_type, q);
                 x[g] = sy.y;
                 ld[g] += cs_rsum(live ? sy.logd : 0.f);
@@ -352,13 +261,6 @@ template <int RG, bool FWD> __global__ void __launch_bounds__(256, 2) cond_gf_sp
 // ---------------------------------------------------------------------------------------------------------- host side
 static int cs_forced_rg = 0;                     // 0: by batch size
 
-static bool cs_layer_supported(const jf_gf_layer& h, int D) {
-    return h.num_kde == CS_K && h.hh_iter >= 0 && h.hh_iter <= CS_HH && h.nonlinear_stretch_type == JF_GF_STRETCH_CLASSIC &&
-           h.rotation_mode == JF_GF_ROT_HOUSEHOLDER && !h.center_mean && !h.add_skewness &&
-           h.width_mode == JF_GF_WIDTH_SMOOTH_SATURATION && !h.clamp_widths && h.fit_normalization && h.regulate_normalization &&
-           h.width_min > 0 && h.width_max > 0 && D >= 3 && D <= 4;
-}
-
 static int cs_pack(const float* W2, int64_t w2s, const float* b2, int32_t H, int32_t D, int32_t n_layers, const jf_gf_layer* layers, void* packed,
                    void* stream) {
     if (!W2 || !layers || !packed) return JF_ERR_BADARG;
@@ -387,7 +289,7 @@ static int cs_pack(const float* W2, int64_t w2s, const float* b2, int32_t H, int
 template <bool FWD>
 static int cs_chain(const float* in, int64_t in_stride, const float* W1, int64_t w1s, const float* b1, const void* packed, int32_t K1, int32_t H,
                     const float* x, int64_t xs, const float* ld_in, int64_t B, int32_t D, int32_t n_layers, const jf_gf_layer* layers, float* x_out,
-                    int64_t xos, float* ld_out, const float* blp_in, float* blp_out, int32_t* status, void* stream) {
+                    int64_t xos, float* ld_out, const float* blp_in, float* blp_out, int32_t* status, void* stream, float* aux = nullptr) {
     if (!in || !W1 || !b1 || !packed || !x || !x_out || !ld_out || !layers) return JF_ERR_BADARG;
     if (!width_ok(K1) || !width_ok(H) || !rows_ok(B) || n_layers < 1 || n_layers > JF_MAX_CHAIN) return JF_ERR_BADARG;
     if (K1 > CS_K1MAX || H > CS_HMAX || (reinterpret_cast<uintptr_t>(packed) & 15u)) return JF_ERR_UNSUPPORTED;
@@ -402,12 +304,17 @@ static int cs_chain(const float* in, int64_t in_stride, const float* W1, int64_t
     if (B == 0) return JF_OK;
     a.in = in; a.in_stride = in_stride; a.W1 = W1; a.w1s = w1s; a.b1 = b1; a.packed = static_cast<const unsigned char*>(packed); a.K1 = K1; a.H = H;
     a.x = x; a.xs = xs; a.ld_in = ld_in; a.B = B; a.D = D; a.n_layers = n_layers;
-    a.x_out = x_out; a.xos = xos; a.ld_out = ld_out; a.blp_in = blp_in; a.blp_out = blp_out; a.status = status;
+    a.x_out = x_out; a.xos = xos; a.ld_out = ld_out; a.blp_in = blp_in; a.blp_out = blp_out; a.status = status; a.aux = aux;
+    if (aux && (FWD || (reinterpret_cast<uintptr_t>(aux) & 15u))) return JF_ERR_BADARG;
     const size_t lds = 2 * CS_CHUNK_BYTES;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)cond_gf_split_kernel<1, FWD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute((const void*)cond_gf_split_kernel<2, FWD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if constexpr (!FWD) {
+            (void)hipFuncSetAttribute((const void*)cond_gf_split_kernel<1, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute((const void*)cond_gf_split_kernel<2, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        }
         attr_set = true;
     }
     // two row groups per wave once that still leaves every CU several workgroups; JF_CS_RG=1|2 (environment, read once) or
@@ -415,8 +322,16 @@ static int cs_chain(const float* in, int64_t in_stride, const float* W1, int64_t
     static const int env_rg = getenv("JF_CS_RG") ? atoi(getenv("JF_CS_RG")) : 0;
     const int force_rg = cs_forced_rg ? cs_forced_rg : env_rg;
     const bool two = force_rg ? force_rg == 2 : B >= (int64_t)CS_ROWS1 * 2 * 1024;
-    if (two) hipLaunchKernelGGL((cond_gf_split_kernel<2, FWD>), dim3((unsigned)((B + 2 * CS_ROWS1 - 1) / (2 * CS_ROWS1))), dim3(256), lds, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL((cond_gf_split_kernel<1, FWD>), dim3((unsigned)((B + CS_ROWS1 - 1) / CS_ROWS1)), dim3(256), lds, (hipStream_t)stream, a);
+    const dim3 grid2((unsigned)((B + 2 * CS_ROWS1 - 1) / (2 * CS_ROWS1))), grid1((unsigned)((B + CS_ROWS1 - 1) / CS_ROWS1));
+    if constexpr (!FWD) {
+        if (aux) {
+            if (two) hipLaunchKernelGGL((cond_gf_split_kernel<2, false, true>), grid2, dim3(256), lds, (hipStream_t)stream, a);
+            else hipLaunchKernelGGL((cond_gf_split_kernel<1, false, true>), grid1, dim3(256), lds, (hipStream_t)stream, a);
+            return hipPeekAtLastError() == hipSuccess ? JF_OK : JF_ERR_LAUNCH;
+        }
+    }
+    if (two) hipLaunchKernelGGL((cond_gf_split_kernel<2, FWD>), grid2, dim3(256), lds, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((cond_gf_split_kernel<1, FWD>), grid1, dim3(256), lds, (hipStream_t)stream, a);
     return hipPeekAtLastError() == hipSuccess ? JF_OK : JF_ERR_LAUNCH;
 }
 
@@ -441,6 +356,16 @@ int jf_cond_gf_chain_inv_split_f32(const float* in, int64_t is, const float* W1,
                                    int32_t H, const float* x, int64_t xs, const float* ld_in, int64_t B, int32_t D, int32_t n,
                                    const jf_gf_layer* L, float* xo, int64_t xos, float* ldo, const float* bi, float* bo, int32_t* st, void* s) {
     return jf::cs_chain<false>(in, is, W1, w1s, b1, packed, K1, H, x, xs, ld_in, B, D, n, L, xo, xos, ldo, bi, bo, st, s);
+}
+int jf_cond_gf_chain_inv_split_save_f32(const float* in, int64_t is, const float* W1, int64_t w1s, const float* b1, const void* packed, int32_t K1,
+                                        int32_t H, const float* x, int64_t xs, const float* ld_in, int64_t B, int32_t D, int32_t n,
+                                        const jf_gf_layer* L, float* xo, int64_t xos, float* ldo, const float* bi, float* bo, float* aux,
+                                        int32_t* st, void* s) {
+    if (!aux) return JF_ERR_BADARG;
+    return jf::cs_chain<false>(in, is, W1, w1s, b1, packed, K1, H, x, xs, ld_in, B, D, n, L, xo, xos, ldo, bi, bo, st, s, aux);
+}
+int64_t jf_cond_gf_aux_floats(int64_t B, int32_t n_layers) {
+    return (jf::rows_ok(B) && n_layers >= 1 && n_layers <= JF_MAX_CHAIN) ? (int64_t)n_layers * B * 20 : (int64_t)JF_ERR_BADARG;
 }
 int jf_cond_gf_chain_fwd_split_f32(const float* in, int64_t is, const float* W1, int64_t w1s, const float* b1, const void* packed, int32_t K1,
                                    int32_t H, const float* z, int64_t zs, const float* ld_in, int64_t B, int32_t D, int32_t n,

@@ -45,7 +45,10 @@ __device__ __forceinline__ void cs_split(float v, __bf16& hi, __bf16& mid, __bf1
 // in each (7 exp + 7 rcp per component on the benchmark inputs, two thirds of whose rows sit beyond 12 sigma after three layers).
 constexpr float CS_M_SCALED = 60.0f;
 
-__device__ __forceinline__ MixQ<float> cs_mixture(const float (&P)[CS_SLOTS], const CsLayer& o, float x, bool live) {
+// sums (optional): the normalised linear-space cdf, sf, pdf and 1 / N -- what the adjoint kernel's linear-space path starts from (a pdf that
+// underflows there sends the row's wave to the log-space path)
+struct CsSums { float C, S, P, invN; };
+__device__ __forceinline__ MixQ<float> cs_mixture(const float (&P)[CS_SLOTS], const CsLayer& o, float x, bool live, CsSums* sums = nullptr) {
     using Mf = M<float>;
     float iw[CS_K], wk[CS_K], u[CS_K];
     float m = INFINITY, Nn = 0.f;
@@ -75,6 +78,7 @@ __device__ __forceinline__ MixQ<float> cs_mixture(const float (&P)[CS_SLOTS], co
         C *= inv; S *= inv; Pd *= inv;
         q.lc = Mf::log_fast(C); q.ls = Mf::log_fast(S); q.lp = Mf::log_fast(Pd);
         q.cdf = C; q.sf = S;
+        if (sums) *sums = CsSums{C, S, Pd, inv};
         return q;
     }
     const float em = Mf::exp_fast(-m);                             // may underflow to 0: the unscaled parts then stand alone
@@ -94,6 +98,7 @@ __device__ __forceinline__ MixQ<float> cs_mixture(const float (&P)[CS_SLOTS], co
     q.lc = Cu > 0.f ? Mf::log_fast(q.cdf) : Mf::log_fast(Cs) - m;
     q.ls = Su > 0.f ? Mf::log_fast(q.sf) : Mf::log_fast(Ss) - m;
     q.lp = Mf::log_fast(Ps) - m;
+    if (sums) *sums = CsSums{q.cdf, q.sf, Ps * em, inv};
     return q;
 }
 
