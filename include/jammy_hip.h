@@ -496,6 +496,13 @@ int jf_linear_wgrad_split_f32(const float* g, int64_t g_stride, const float* in,
  * ------------------------------------------------------------------------------------------------------------ */
 int jf_tanh_bwd_f32(const float* g, const float* y, int64_t n, float* out, void* stream);
 int jf_tanh_bwd_f64(const double* g, const double* y, int64_t n, double* out, void* stream);
+/* Sum of the S partial slabs a batch-reducing backward launch left (jf_linear_wgrad*, jf_mlp2_small_bwd, jf_mlp_hidden_bwd, the broadcast
+ * regime of jf_gf_chain_inv_bwd), in chunks of `chunk` slabs: out_a[c * na + i] = sum over s in [c * chunk, min(S, (c + 1) * chunk)) of
+ * a[s * na + i] and, when nb > 0, the same for b in the same launch (weights and bias of one layer); out_a / out_b hold ceil(S / chunk) slabs.
+ * chunk >= S: the total.  Thousands of slabs: one launch with chunk ~ sqrt(S), a second with chunk = all.  Fixed summation order: results are
+ * bit-identical from run to run (what torch.sum(0) on the slabs did in five launches per training step). */
+int jf_slab_sum_f32(const float* a, int64_t na, float* out_a, const float* b, int64_t nb, float* out_b, int32_t S, int32_t chunk, void* stream);
+int jf_slab_sum_f64(const double* a, int64_t na, double* out_a, const double* b, int64_t nb, double* out_b, int32_t S, int32_t chunk, void* stream);
 /* AmortizableMLP nonlinearities other than tanh (extra_functions.py:81-89; tanh is fused into the dense kernels): out = act(z) on the layer's
  * pre-activation, and the backward out = g * act'(z).  n elements, contiguous. */
 #define JF_ACT_RELU 2

@@ -117,6 +117,7 @@ _SIGNATURES = {
     "jf_gf_chain_fwd": [_P, _I64, _P, _P, _I64, _I32, _I64, _I32, _I32, ctypes.POINTER(jf_gf_layer), _P, _I64, _P, _P, _I64, _P, _P],
     "jf_linear": [_P, _I64, _P, _I64, _P, _I64, _I32, _I32, _I32, _P, _I64, _P],
     "jf_normal_logp": [_P, _I64, _I64, _I32, _P, _P, _P],
+    "jf_slab_sum": [_P, _I64, _P, _P, _I64, _P, _I32, _I32, _P],
     "jf_tanh_bwd": [_P, _P, _I64, _P, _P],
     "jf_mlp_hidden_bwd": [_P, _I64, _P, _I64, _P, _P, _I64, _I64, _I32, _I32, _P, _P],
     "jf_mlp2_small_bwd": [_P, _I64, _P, _I64, _P, _P, _I64, _P, _I64, _I64, _I32, _I32, _I32, _P, _P, _P],
@@ -414,7 +415,7 @@ def gf_chain_inv_bwd(x, params, layer_array, n_layers, D, g_xout, g_ld, g_blp, s
              g_xout.stride(0) if g_xout is not None else 0, _ptr(g_ld), _ptr(g_blp), _ptr(g_x), g_x.stride(0), _ptr(g_p), g_p.stride(0),
              _ptr(status)), dev)
     if pb == 1:
-        g_p = g_p.sum(0, keepdim=True)
+        g_p = slab_sum(g_p)[0].unsqueeze(0)
     return g_x, g_p
 
 
@@ -664,6 +665,31 @@ def linear(inp, weight, bias=None, act=0, out=None):
     return out
 
 
+def slab_sum(a, b=None):
+    """(a.sum(0), b.sum(0) or None) of the partial slabs a (S, ...) / b (S, ...) of one backward launch with a fixed summation order
+    (jf_slab_sum: one launch for both arrays; two for hundreds of slabs -- chunks of 32 first); S == 1: views, no launch"""
+    S = a.shape[0]
+    if S == 1:
+        return a[0], (None if b is None else b[0])
+    dev = require_device(a, b)
+    a = a.contiguous()
+    b = None if b is None else b.contiguous()
+    na, nb = a[0].numel(), 0 if b is None else b[0].numel()
+    fn = "jf_slab_sum" + _suffix(a)
+    shape_a, shape_b = a.shape[1:], None if b is None else b.shape[1:]
+    if S > 64:
+        chunk = 32
+        n_chunks = (S + chunk - 1) // chunk
+        mid_a = torch.empty((n_chunks, na), dtype=a.dtype, device=a.device)
+        mid_b = torch.empty((n_chunks, nb), dtype=a.dtype, device=a.device) if b is not None else None
+        _launch(fn, "chunks", (_ptr(a), na, _ptr(mid_a), _ptr(b), nb, _ptr(mid_b), S, chunk), dev)
+        a, b, S = mid_a, mid_b, n_chunks
+    out_a = torch.empty(shape_a, dtype=a.dtype, device=a.device)
+    out_b = torch.empty(shape_b, dtype=a.dtype, device=a.device) if b is not None else None
+    _launch(fn, "total", (_ptr(a), na, _ptr(out_a), _ptr(b), nb, _ptr(out_b), S, S), dev)
+    return out_a, out_b
+
+
 def linear_wgrad(g, inp, want_bias=True):
     """(g^T @ inp (N, K), g.sum(0) (N) or None): the batch-reducing products of a dense layer's backward, split over the grid (jf_linear_wgrad);
     K > 128 goes to the library GEMM."""
@@ -681,12 +707,12 @@ def linear_wgrad(g, inp, want_bias=True):
         pw = torch.empty((S, N, K), dtype=g.dtype, device=g.device)
         pb = torch.empty((S, N), dtype=g.dtype, device=g.device) if want_bias else None
         _launch("jf_linear_wgrad_split_f32", "K%d_N%d" % (K, N), (_ptr(g), g.stride(0), _ptr(inp), inp.stride(0), B, K, N, _ptr(pw), _ptr(pb)), dev)
-        return (pw.sum(0) if S > 1 else pw[0]), (None if pb is None else (pb.sum(0) if S > 1 else pb[0]))
+        return slab_sum(pw, pb)
     S = int(getattr(lib(), "jf_linear_wgrad_splits" + _suffix(g))(B, K, N))
     pw = torch.empty((S, N, K), dtype=g.dtype, device=g.device)
     pb = torch.empty((S, N), dtype=g.dtype, device=g.device) if want_bias else None
     _launch("jf_linear_wgrad" + _suffix(g), "K%d_N%d" % (K, N), (_ptr(g), g.stride(0), _ptr(inp), inp.stride(0), B, K, N, _ptr(pw), _ptr(pb)), dev)
-    return (pw.sum(0) if S > 1 else pw[0]), (None if pb is None else (pb.sum(0) if S > 1 else pb[0]))
+    return slab_sum(pw, pb)
 
 
 def linear_split_ok(x, weight, bias=None):
@@ -730,8 +756,8 @@ def mlp2_small_bwd(x, w1, b1, w2, g):
     _launch("jf_mlp2_small_bwd" + _suffix(x), "K%d_H%d_N%d" % (K1, H, N),
             (_ptr(x), x.stride(0), _ptr(w1), w1.stride(0), _ptr(b1.contiguous()), _ptr(w2), w2.stride(0), _ptr(g), g.stride(0), B, K1, H, N, _ptr(slab),
              _ptr(slab_b2)), dev)
-    tot = slab.sum(0)
-    return tot[:, :K1], tot[:, K1], tot[:, K1 + 1:].t(), slab_b2.sum(0)
+    tot, tot_b2 = slab_sum(slab, slab_b2)
+    return tot[:, :K1], tot[:, K1], tot[:, K1 + 1:].t(), tot_b2
 
 
 def mlp_hidden_bwd(x, w1, b1, g_hidden):
@@ -745,7 +771,7 @@ def mlp_hidden_bwd(x, w1, b1, g_hidden):
     slab = torch.empty((S, H, K1 + 1), dtype=x.dtype, device=x.device)
     _launch("jf_mlp_hidden_bwd" + _suffix(x), "K%d_H%d" % (K1, H),
             (_ptr(x), x.stride(0), _ptr(w1), w1.stride(0), _ptr(b1.contiguous()), _ptr(g_hidden), g_hidden.stride(0), B, K1, H, _ptr(slab)), dev)
-    tot = slab.sum(0)
+    tot = slab_sum(slab)[0]
     return tot[:, :K1], tot[:, K1]
 
 

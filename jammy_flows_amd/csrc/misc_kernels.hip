@@ -146,6 +146,49 @@ __global__ void __launch_bounds__(256) tanh_bwd_kernel(const T* __restrict__ g, 
         for (int64_t j = i; j < n && j < i + N; ++j) out[j] = g[j] * (T(1) - y[j] * y[j]);
     }
 }
+// Sum of partial slabs: out_a[c * na + i] = sum over the slabs s of chunk c of a[s * na + i] (chunk c = slabs [c * chunk, (c + 1) * chunk)), the
+// same for b in the same launch (weights and bias of one layer).  The batch-reducing backward kernels leave one slab per workgroup or batch
+// split (up to 4096); a workgroup owns 32 consecutive elements x one chunk, its 8 slab lanes walk the chunk 8 slabs apart and meet in LDS in a
+// FIXED order, so the result does not depend on scheduling (unlike atomics).  Two launches (chunked, then chunk = all) reduce thousands of slabs
+// with every CU busy; few slabs take one.
+template <typename T>
+__global__ void __launch_bounds__(256) slab_sum_kernel(const T* __restrict__ a, int64_t na, T* __restrict__ out_a, const T* __restrict__ b, int64_t nb,
+                                                       T* __restrict__ out_b, int S, int chunk) {
+    __shared__ T part[8][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int64_t i = (int64_t)blockIdx.x * 32 + tx;
+    const int c = blockIdx.y;
+    const int s0 = c * chunk, s1 = s0 + chunk < S ? s0 + chunk : S;
+    const T* src = nullptr; T* dst = nullptr; int64_t n = 0, j = 0;
+    if (i < na) { src = a; dst = out_a; n = na; j = i; }
+    else if (i < na + nb) { src = b; dst = out_b; n = nb; j = i - na; }
+    T acc[4] = {T(0), T(0), T(0), T(0)};
+    if (src) {
+        int sl = s0 + ty;
+        for (; sl + 24 < s1; sl += 32) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[u] += src[(int64_t)(sl + 8 * u) * n + j];
+        }
+        for (; sl < s1; sl += 8) acc[0] += src[(int64_t)sl * n + j];
+    }
+    part[ty][tx] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    __syncthreads();
+    if (ty == 0 && src) {
+        T t = part[0][tx];
+#pragma unroll
+        for (int u = 1; u < 8; ++u) t += part[u][tx];
+        dst[(int64_t)c * n + j] = t;
+    }
+}
+template <typename T> static int slab_sum(const T* a, int64_t na, T* out_a, const T* b, int64_t nb, T* out_b, int32_t S, int32_t chunk, void* stream) {
+    if (!a || !out_a || na < 1 || nb < 0 || (nb > 0 && (!b || !out_b)) || S < 1 || chunk < 1 || na > JF_MAX_ROWS || nb > JF_MAX_ROWS) return JF_ERR_BADARG;
+    const int64_t chunks = ((int64_t)S + chunk - 1) / chunk;
+    if (chunks > 65535) return JF_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(slab_sum_kernel<T>, dim3((unsigned)((na + nb + 31) / 32), (unsigned)chunks), dim3(256), 0, (hipStream_t)stream, a, na, out_a, b, nb,
+                       out_b, (int)S, (int)chunk);
+    return hipPeekAtLastError() == hipSuccess ? JF_OK : JF_ERR_LAUNCH;
+}
+
 template <typename T> static int tanh_bwd(const T* g, const T* y, int64_t n, T* out, void* stream) {
     if (!g || !y || !out || n < 0) return JF_ERR_BADARG;
     if (n == 0) return JF_OK;
@@ -218,6 +261,12 @@ int jf_normal_logp_f32(const float* z, int64_t zs, int64_t B, int32_t D, const f
 }
 int jf_normal_logp_f64(const double* z, int64_t zs, int64_t B, int32_t D, const double* in, double* out, void* s) {
     return jf::normal_logp<double>(z, zs, B, D, in, out, s);
+}
+int jf_slab_sum_f32(const float* a, int64_t na, float* out_a, const float* b, int64_t nb, float* out_b, int32_t S, int32_t chunk, void* s) {
+    return jf::slab_sum<float>(a, na, out_a, b, nb, out_b, S, chunk, s);
+}
+int jf_slab_sum_f64(const double* a, int64_t na, double* out_a, const double* b, int64_t nb, double* out_b, int32_t S, int32_t chunk, void* s) {
+    return jf::slab_sum<double>(a, na, out_a, b, nb, out_b, S, chunk, s);
 }
 int jf_tanh_bwd_f32(const float* g, const float* y, int64_t n, float* out, void* s) { return jf::tanh_bwd<float>(g, y, n, out, s); }
 int jf_tanh_bwd_f64(const double* g, const double* y, int64_t n, double* out, void* s) { return jf::tanh_bwd<double>(g, y, n, out, s); }

@@ -185,7 +185,7 @@ constexpr int MS_K1MAX = 32, MS_NMAX = 16;
 template <typename T, int KB, int NB>
 __global__ void __launch_bounds__(128) mlp2_small_bwd_kernel(const T* __restrict__ x, int64_t xs, const T* __restrict__ W1, int64_t w1s, const T* __restrict__ b1,
                                                              const T* __restrict__ W2, int64_t w2s, const T* __restrict__ g, int64_t gs, int64_t B, int K1, int H,
-                                                             int N, int64_t rows_per_block, T* __restrict__ slab, T* __restrict__ slab_b2) {
+                                                             int N, int64_t rows_per_block, T* __restrict__ slab, T* __restrict__ slab_b2, int dense) {
     const int j = threadIdx.x;
     const bool live = j < H;
     const int jj = live ? j : H - 1;
@@ -200,9 +200,12 @@ __global__ void __launch_bounds__(128) mlp2_small_bwd_kernel(const T* __restrict
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
     const int64_t r1 = r0 + rows_per_block < B ? r0 + rows_per_block : B;
     // rows whose KB / NB-element reads stay inside the arrays are read CONTIGUOUSLY (one or two wide scalar loads per row; the slots beyond K1 / N
-    // then hold the neighbouring row's values, which meet zero weights); only the last rows of the arrays take the clamped indices
+    // then hold the NEXT ROW's first values, which meet zero weights); only the last rows of the arrays take the clamped indices.  `dense` (host:
+    // every padded array has stride = width): the values in the padded slots are rows of the same array, so a non-finite one poisons the same
+    // batch sums through its own row anyway; with gaps between the rows (views of wider tensors) the gap's content is unknown (0 * NaN = NaN)
+    // and every row takes the clamped reads.  (Selecting zero per padded slot in this loop cost 40 % of the kernel: 0.088 -> 0.125 ms.)
     const int64_t safe = B - 1 - ((KB - K1 + xs - 1) / xs > (NB - N + gs - 1) / gs ? (KB - K1 + xs - 1) / xs : (NB - N + gs - 1) / gs);
-    const int64_t rm = r1 < safe ? r1 : (safe > r0 ? safe : r0);
+    const int64_t rm = !dense ? r0 : (r1 < safe ? r1 : (safe > r0 ? safe : r0));
     auto one_row = [&](const T (&xv)[KB], const T (&gv)[NB]) {
         T pre = bj;
 #pragma unroll
@@ -222,9 +225,9 @@ __global__ void __launch_bounds__(128) mlp2_small_bwd_kernel(const T* __restrict
         const T* gr = g + r * gs;
         T xv[KB], gv[NB];
 #pragma unroll
-        for (int k = 0; k < KB; ++k) xv[k] = k < K1 ? xr[k] : T(0);      // slots beyond K1 hold the neighbouring row: SELECT zero (0 * NaN = NaN)
+        for (int k = 0; k < KB; ++k) xv[k] = xr[k];
 #pragma unroll
-        for (int n = 0; n < NB; ++n) gv[n] = n < N ? gr[n] : T(0);
+        for (int n = 0; n < NB; ++n) gv[n] = gr[n];
         one_row(xv, gv);
     }
     for (int64_t r = rm; r < r1; ++r) {
@@ -256,7 +259,7 @@ __global__ void __launch_bounds__(128) mlp2_small_bwd_kernel(const T* __restrict
 template <typename T, int KB>
 __global__ void __launch_bounds__(128) mlp_hidden_bwd_kernel(const T* __restrict__ x, int64_t xs, const T* __restrict__ W1, int64_t w1s, const T* __restrict__ b1,
                                                              const T* __restrict__ gh, int64_t ghs, int64_t B, int K1, int H, int64_t rows_per_block,
-                                                             T* __restrict__ slab) {
+                                                             T* __restrict__ slab, int dense) {
     const int j = threadIdx.x;
     const bool live = j < H;
     const int jj = live ? j : H - 1;
@@ -269,7 +272,7 @@ __global__ void __launch_bounds__(128) mlp_hidden_bwd_kernel(const T* __restrict
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
     const int64_t r1 = r0 + rows_per_block < B ? r0 + rows_per_block : B;
     const int64_t safe = B - 1 - (KB - K1 + xs - 1) / xs;          // contiguous KB-element reads of x stay inside the array up to this row
-    const int64_t rm = r1 < safe ? r1 : (safe > r0 ? safe : r0);
+    const int64_t rm = !dense ? r0 : (r1 < safe ? r1 : (safe > r0 ? safe : r0));   // dense: see mlp2_small_bwd_kernel
     auto one_row = [&](const T (&xv)[KB], T gr) {
         T pre = bj;
 #pragma unroll
@@ -285,7 +288,7 @@ __global__ void __launch_bounds__(128) mlp_hidden_bwd_kernel(const T* __restrict
         const T* xr = x + r * xs;                                 // uniform addresses: scalar loads
         T xv[KB];
 #pragma unroll
-        for (int k = 0; k < KB; ++k) xv[k] = k < K1 ? xr[k] : T(0);      // slots beyond K1 hold the neighbouring row: SELECT zero (0 * NaN = NaN)
+        for (int k = 0; k < KB; ++k) xv[k] = xr[k];
         one_row(xv, gh[r * ghs + jj]);
     }
     for (int64_t r = rm; r < r1; ++r) {
@@ -319,7 +322,9 @@ static int mlp2_small_bwd(const T* x, int64_t xs, const T* W1, int64_t w1s, cons
     const int64_t rpb = (B + S - 1) / S;
     const dim3 grid((unsigned)S), block(128);
     hipStream_t st = (hipStream_t)stream;
-#define JF_MS(KB_, NB_) hipLaunchKernelGGL((mlp2_small_bwd_kernel<T, KB_, NB_>), grid, block, 0, st, x, xs, W1, w1s, b1, W2, w2s, g, gs, B, (int)K1, (int)H, (int)N, rpb, slab, slab_b2)
+    const int kb = K1 <= 4 ? 4 : K1 <= 8 ? 8 : K1 <= 16 ? 16 : 32, nb = N <= 4 ? 4 : N <= 8 ? 8 : 16;
+    const int dense = (kb == K1 || xs == K1) && (nb == N || gs == N);           // padded slots read rows of the same array, never a gap
+#define JF_MS(KB_, NB_) hipLaunchKernelGGL((mlp2_small_bwd_kernel<T, KB_, NB_>), grid, block, 0, st, x, xs, W1, w1s, b1, W2, w2s, g, gs, B, (int)K1, (int)H, (int)N, rpb, slab, slab_b2, dense)
 #define JF_MS_N(KB_) { if (N <= 4) JF_MS(KB_, 4); else if (N <= 8) JF_MS(KB_, 8); else JF_MS(KB_, 16); }
     if (K1 <= 4) JF_MS_N(4) else if (K1 <= 8) JF_MS_N(8) else if (K1 <= 16) JF_MS_N(16) else JF_MS_N(32)
 #undef JF_MS_N
@@ -337,7 +342,9 @@ static int mlp_hidden_bwd(const T* x, int64_t xs, const T* W1, int64_t w1s, cons
     const int64_t rpb = (B + S - 1) / S;
     const dim3 grid((unsigned)S), block(128);
     hipStream_t st = (hipStream_t)stream;
-#define JF_MH(KB_) hipLaunchKernelGGL((mlp_hidden_bwd_kernel<T, KB_>), grid, block, 0, st, x, xs, W1, w1s, b1, gh, ghs, B, (int)K1, (int)H, rpb, slab)
+    const int kb = K1 <= 4 ? 4 : K1 <= 8 ? 8 : K1 <= 16 ? 16 : 32;
+    const int dense = kb == K1 || xs == K1;
+#define JF_MH(KB_) hipLaunchKernelGGL((mlp_hidden_bwd_kernel<T, KB_>), grid, block, 0, st, x, xs, W1, w1s, b1, gh, ghs, B, (int)K1, (int)H, rpb, slab, dense)
     if (K1 <= 4) JF_MH(4); else if (K1 <= 8) JF_MH(8); else if (K1 <= 16) JF_MH(16); else JF_MH(32);
 #undef JF_MH
     return check_launch();

@@ -39,6 +39,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--rows", type=int, default=1 << 18)
 ap.add_argument("--workload", default="c3")
 ap.add_argument("--torch-profile", action="store_true", help="also print the device-time table of torch.profiler for one step (library GEMMs, elementwise glue)")
+ap.add_argument("--pmc-child", action="store_true", help="a few steps only (under rocprofv3 --pmc: every launch is serialised and slow)")
 args = ap.parse_args()
 name, dtype = ("c3_e4s2e4", torch.float32) if args.workload == "c3" else ("c5_e8s2_ggggv", torch.float64)
 fx = fixture_io.load(name)
@@ -60,6 +61,9 @@ def step():
 
 for _ in range(5):
     step()
+if args.pmc_child:
+    torch.cuda.synchronize()
+    sys.exit(0)
 n = 20
 reps = []
 for _ in range(5):                                   # the step issues ~100 launches: host jitter shows, so 5 repetitions of 20 steps, median reported
