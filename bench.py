@@ -248,6 +248,7 @@ KERNEL_OF = {"jf_cond_f_chain_inv_f32": "cond_mchain_kernel<float, jf::FFam", "j
              "jf_conditioning_rows_f32": "conditioning_kernel<float", "jf_conditioning_rows_f64": "conditioning_kernel<double",
              "jf_v_chain_inv_f64": "mchain_kernel<double, jf::VFam", "jf_amlp2_f64": "amlp2_mfma_kernel",
              "jf_cond_gf_chain_inv_split_f32": "cond_gf_split_kernel", "jf_cond_gf_chain_inv_pp_f32": "cond_gf_pp_kernel",
+             "jf_cond_gf_chain_split2_f32": "cond_gf_split_kernel",
              "jf_cond_gf_chain_inv_f32": "cond_gf_chain_kernel<float",
              "jf_cond_gf_chain_inv_f64": "cond_gf_chain_kernel<double", "jf_mlp2_f32": "mlp2_kernel<float", "jf_mlp2_f64": "mlp2_kernel<double",
              "jf_gf_chain_inv_f32": "gf_chain_kernel<float", "jf_gf_chain_inv_f64": "gf_chain_kernel<double",
@@ -276,8 +277,8 @@ def traffic_of(traffic, kname, ktag):
 # ---------------------------------------------------------------------------------------------- algorithmic accounting
 def kernel_accounting(kname, ktag, s):
     """(algorithmic HBM bytes per row, MFMA flops per row, fused?) of one timed kernel; s = bytes per scalar."""
-    if kname.startswith("jf_cond_gf_chain_inv_split") or kname.startswith("jf_cond_gf_chain_inv_pp"):
-        K1, H, L, D = (int(t[1:]) for t in ktag.split("_"))
+    if kname.startswith("jf_cond_gf_chain_inv_split") or kname.startswith("jf_cond_gf_chain_inv_pp") or kname.startswith("jf_cond_gf_chain_split2"):
+        K1, H, L, D = (int(t[1:]) for t in ktag.split("_")[:4])
         N = L * (3 * 10 * D + D * D) + D                 # default g rows: 3 K D + D^2 (+ D offsets on the last layer)
         return s * (K1 + N) + s * (D + 1 + N + D + 1), 2 * (K1 * H + H * N), True
     if kname.startswith("jf_cond_gf_chain") or kname.startswith("jf_amlp_gf_chain"):

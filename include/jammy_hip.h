@@ -157,6 +157,27 @@ int jf_cond_gf_chain_fwd_split_f32(const float* in, int64_t in_stride, const flo
                                    int32_t K1, int32_t H, const float* z, int64_t z_stride, const float* log_det_in, int64_t B, int32_t D,
                                    int32_t n_layers, const jf_gf_layer* layers, float* x_out, int64_t x_out_stride, float* log_det_out,
                                    int32_t* status, void* stream);
+/* The same block with a selectable split arithmetic for the 128 -> N product (pack and launch must name the same one):
+ *   JF_SPLIT_BF16X3  three bf16 pieces per operand, six products (exact f32 products, dropped terms <= 3 * 2^-24) -- what the entry points
+ *                    without the suffix 2 use;
+ *   JF_SPLIT_F16X2   two f16 pieces per operand (11 + 11 bits; W2 and h scaled by powers of two so that the pieces are normal numbers, the
+ *                    low pieces by another 2^11), three products, half the MFMA work and two thirds of the LDS traffic.  Representation
+ *                    error <= 2^-22 per operand: below the rounding of the f32 accumulation (measured rms error of a parameter 2.4e-8 vs
+ *                    6.8e-8 for a plain f32 matrix product of the same operands).
+ * jf_cond_gf_chain_split2_f32: direction JF_DIR_INV (x -> z; base_logp_* and aux as in jf_cond_gf_chain_inv_split_save_f32, aux may be NULL)
+ * or JF_DIR_FWD (sampling; base_logp_in / base_logp_out / aux must be NULL). */
+#define JF_SPLIT_BF16X3 0
+#define JF_SPLIT_F16X2 1
+#define JF_DIR_INV 0
+#define JF_DIR_FWD 1
+int64_t jf_cond_gf_packed_bytes2(int32_t D, int32_t n_layers, const jf_gf_layer* layers, int32_t arithmetic);
+int jf_cond_gf_pack2_f32(const float* W2, int64_t w2_stride, const float* b2, int32_t H, int32_t D, int32_t n_layers, const jf_gf_layer* layers,
+                         int32_t arithmetic, void* packed, void* stream);
+int jf_cond_gf_chain_split2_f32(int32_t direction, int32_t arithmetic, const float* in, int64_t in_stride, const float* W1, int64_t w1_stride,
+                                const float* b1, const void* packed, int32_t K1, int32_t H, const float* x, int64_t x_stride,
+                                const float* log_det_in, int64_t B, int32_t D, int32_t n_layers, const jf_gf_layer* layers, float* x_out,
+                                int64_t x_out_stride, float* log_det_out, const float* base_logp_in, float* base_logp_out, float* aux,
+                                int32_t* status, void* stream);
 /* Training step of the same block (float32; replaces torch.autograd's replay of main/default.py:656-670, 946-962, 998-1031 +
  * gaussianization_flow.py:995-1114 for the loss of examples/jammy_flows.py:381-412).
  * jf_cond_gf_chain_inv_split_save_f32 = jf_cond_gf_chain_inv_split_f32 that also leaves, per (layer, row, coordinate lane), the layer's input

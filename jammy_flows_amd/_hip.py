@@ -160,6 +160,10 @@ _SIGNATURES_SINGLE = {
     "jf_cond_gf_chain_inv_pp_f32": ([_P, _I64, _P, _I64, _P, _P, _I32, _I32, _P, _I64, _P, _I64, _I32, _I32, ctypes.POINTER(jf_gf_layer), _P, _I64,
                                      _P, _P, _P, _P, _P], ctypes.c_int),
     "jf_cond_gf_pack_f32": ([_P, _I64, _P, _I32, _I32, _I32, ctypes.POINTER(jf_gf_layer), _P, _P], ctypes.c_int),
+    "jf_cond_gf_packed_bytes2": ([_I32, _I32, ctypes.POINTER(jf_gf_layer), _I32], ctypes.c_int64),
+    "jf_cond_gf_pack2_f32": ([_P, _I64, _P, _I32, _I32, _I32, ctypes.POINTER(jf_gf_layer), _I32, _P, _P], ctypes.c_int),
+    "jf_cond_gf_chain_split2_f32": ([_I32, _I32, _P, _I64, _P, _I64, _P, _P, _I32, _I32, _P, _I64, _P, _I64, _I32, _I32, ctypes.POINTER(jf_gf_layer),
+                                     _P, _I64, _P, _P, _P, _P, _P, _P], ctypes.c_int),
     "jf_cond_gf_chain_inv_split_save_f32": ([_P, _I64, _P, _I64, _P, _P, _I32, _I32, _P, _I64, _P, _I64, _I32, _I32, ctypes.POINTER(jf_gf_layer), _P,
                                              _I64, _P, _P, _P, _P, _P, _P], ctypes.c_int),
     "jf_cond_gf_aux_floats": ([_I64, _I32], ctypes.c_int64),
@@ -500,12 +504,17 @@ def amlp2(inp, v1, u1, b1, v2, u2, b2):
 # the two register-resident fused block kernels: "split" (cond_split_kernels.hip, 64 / 128 rows per workgroup) and "pp" (cond_pp_kernels.hip,
 # persistent ping-pong workgroups of 256 rows; large batches)
 _COND_GF_PACK = {"split": ("jf_cond_gf_packed_bytes", "jf_cond_gf_pack_f32", "jf_cond_gf_chain_inv_split_f32", 28),
+                 "split16": ("jf_cond_gf_packed_bytes2", "jf_cond_gf_pack2_f32", "jf_cond_gf_chain_split2_f32", 28),
                  "pp": ("jf_cond_gf_pp_packed_bytes", "jf_cond_gf_pp_pack_f32", "jf_cond_gf_chain_inv_pp_f32", 32)}
+SPLIT_BF16X3, SPLIT_F16X2 = 0, 1     # include/jammy_hip.h: JF_SPLIT_*; kind "split" = bf16 triple, "split16" = f16 pair (same kernels)
+DIR_INV, DIR_FWD = 0, 1
 COND_GF_PP_MIN_ROWS = 1 << 16        # below this the persistent kernel leaves CUs without a row tile
 
 
 def cond_gf_packed_bytes(layer_array, n_layers, D, kind="split"):
     """size of the packed W2 / b2 image of a register-resident fused block kernel, or a negative JF_ERR_* when the chain is not supported by it."""
+    if kind == "split16":
+        return int(lib().jf_cond_gf_packed_bytes2(D, n_layers, layer_array, SPLIT_F16X2))
     return int(getattr(lib(), _COND_GF_PACK[kind][0])(D, n_layers, layer_array))
 
 
@@ -519,6 +528,10 @@ def cond_gf_pack(w2, b2, layer_array, n_layers, D, kind="split"):
     nbytes = cond_gf_packed_bytes(layer_array, n_layers, D, kind)
     _check(min(nbytes, 0), _COND_GF_PACK[kind][0])
     packed = torch.empty((nbytes,), dtype=torch.uint8, device=w2.device)
+    if kind == "split16":
+        _launch("jf_cond_gf_pack2_f32", "f16x2", (_ptr(w2), w2.stride(0), _ptr(b2.contiguous()), w2.shape[1], D, n_layers, layer_array, SPLIT_F16X2,
+                                                  _ptr(packed)), dev)
+        return packed
     _launch(_COND_GF_PACK[kind][1], "", (_ptr(w2), w2.stride(0), _ptr(b2.contiguous()), w2.shape[1], D, n_layers, layer_array, _ptr(packed)), dev)
     return packed
 
@@ -542,6 +555,14 @@ def cond_gf_chain_inv_split(inp, w1, b1, packed, x, log_det, layer_array, n_laye
         x_out = torch.empty((B, D), dtype=x.dtype, device=x.device)
     ld_out = torch.empty((B,), dtype=x.dtype, device=x.device)
     blp_out = torch.empty((B,), dtype=x.dtype, device=x.device) if want_base_logp else None
+    if kind == "split16":
+        if aux is not None and (aux.dtype != torch.float32 or aux.numel() < n_layers * B * 20 or not aux.is_contiguous()):
+            raise ValueError("cond_gf_chain_inv_split: aux = cond_gf_aux(B, n_layers)")
+        _launch("jf_cond_gf_chain_split2_f32", "K%d_H%d_L%d_D%d" % (K1, H, n_layers, D),
+                (DIR_INV, SPLIT_F16X2, _ptr(inp), inp.stride(0), _ptr(w1), w1.stride(0), _ptr(b1.contiguous()), _ptr(packed), K1, H, _ptr(x), x.stride(0),
+                 _ptr(log_det), B, D, n_layers, layer_array, _ptr(x_out), x_out.stride(0), _ptr(ld_out), _ptr(base_logp_in), _ptr(blp_out), _ptr(aux),
+                 _ptr(status)), dev)
+        return (x_out, ld_out, blp_out) if want_base_logp else (x_out, ld_out)
     if aux is not None:
         if kind != "split" or aux.dtype != torch.float32 or aux.numel() < n_layers * B * 20 or not aux.is_contiguous():
             raise ValueError("cond_gf_chain_inv_split: aux needs the 'split' kernel and cond_gf_aux(B, n_layers)")
@@ -622,9 +643,9 @@ def cond_gf_chain_inv_split_bwd(inp, w1, b1, packed, packed_t, z, aux, layer_arr
     return g_x, g_pp, h, g_h
 
 
-def cond_gf_chain_fwd_split(inp, w1, b1, packed, z, log_det, layer_array, n_layers, D, x_out=None, status=None):
+def cond_gf_chain_fwd_split(inp, w1, b1, packed, z, log_det, layer_array, n_layers, D, x_out=None, status=None, kind="split"):
     """sampling direction of a conditional e-block in one launch (amortisation MLP + bisection / Newton solves on register-resident
-    parameters); `packed`: the "split" image of cond_gf_pack."""
+    parameters); `packed`: the "split" / "split16" image of cond_gf_pack (`kind` names which)."""
     dev = require_device(inp, w1, b1, packed, z, log_det, x_out, status)
     inp, w1, z = _rowmajor(inp), _rowmajor(w1), _rowmajor(z)
     B, K1 = inp.shape
@@ -638,6 +659,11 @@ def cond_gf_chain_fwd_split(inp, w1, b1, packed, z, log_det, layer_array, n_laye
     if x_out is None:
         x_out = torch.empty((B, D), dtype=z.dtype, device=z.device)
     ld_out = torch.empty((B,), dtype=z.dtype, device=z.device)
+    if kind == "split16":
+        _launch("jf_cond_gf_chain_split2_f32", "K%d_H%d_L%d_D%d_fwd" % (K1, H, n_layers, D),
+                (DIR_FWD, SPLIT_F16X2, _ptr(inp), inp.stride(0), _ptr(w1), w1.stride(0), _ptr(b1.contiguous()), _ptr(packed), K1, H, _ptr(z), z.stride(0),
+                 _ptr(log_det), B, D, n_layers, layer_array, _ptr(x_out), x_out.stride(0), _ptr(ld_out), None, None, None, _ptr(status)), dev)
+        return x_out, ld_out
     _launch("jf_cond_gf_chain_fwd_split_f32", "K%d_H%d_L%d_D%d" % (K1, H, n_layers, D),
             (_ptr(inp), inp.stride(0), _ptr(w1), w1.stride(0), _ptr(b1.contiguous()), _ptr(packed), K1, H, _ptr(z), z.stride(0), _ptr(log_det), B, D,
              n_layers, layer_array, _ptr(x_out), x_out.stride(0), _ptr(ld_out), _ptr(status)), dev)

@@ -151,7 +151,7 @@ class CondBlockFn(torch.autograd.Function):
         kw = dict(base_logp_in=None if base_logp_in is None else base_logp_in.detach(), want_base_logp=True, status=status)
         aux = None
         if packed is not None:
-            if FUSED_BLOCK_BACKWARD and packed[0] == "split" and w1.shape[0] % 4 == 0 and x.shape[0] > 0:
+            if FUSED_BLOCK_BACKWARD and packed[0] in ("split", "split16") and w1.shape[0] % 4 == 0 and x.shape[0] > 0:
                 aux = _hip.cond_gf_aux(x.shape[0], n_layers, x.device)
             res = _hip.cond_gf_chain_inv_split(inp.detach(), w1.detach(), b1.detach(), packed[1], *args, kind=packed[0], aux=aux, **kw)
         else:
@@ -159,7 +159,7 @@ class CondBlockFn(torch.autograd.Function):
         ctx.meta = (layer_array, n_layers, D)
         ctx.set_materialize_grads(False)             # unused outputs arrive as None (the kernels take NULL), not as zero-filled tensors
         ctx.has = (log_det is not None, base_logp_in is not None)
-        ctx.fused = None if aux is None else (packed[1], aux)
+        ctx.fused = None if aux is None else (packed, aux)
         ctx.save_for_backward(inp, w1, b1, w2, b2, x, res[0] if aux is not None else None)
         return res
 
@@ -171,7 +171,9 @@ class CondBlockFn(torch.autograd.Function):
         if ctx.fused is not None:
             # ONE launch: hidden activations and parameters recomputed in the forward kernel's register layout, each layer's adjoint in place,
             # g_h accumulated from the same registers; the parameter-row gradient leaves in packed column order for the weight-gradient product
-            packed, aux = ctx.fused
+            (kind, packed), aux = ctx.fused
+            if kind != "split":                       # the adjoint kernel multiplies bf16 triples: its own image of the same weights
+                packed = _hip.cond_gf_pack(w2, b2, layer_array, n_layers, D, "split")
             packed_t = _hip.cond_gf_bwd_pack(w2, layer_array, n_layers, D)
             g_x, g_p, h, g_hid = _hip.cond_gf_chain_inv_split_bwd(inp, w1, b1, packed, packed_t, z, aux, layer_array, n_layers, D, g_xout, g_ld, g_blp)
             ctx.fused = None

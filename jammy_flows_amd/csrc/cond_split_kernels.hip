@@ -30,14 +30,27 @@ namespace jf {
 // ---------------------------------------------------------------------------------------------------------- packing
 struct CsPackArgs {
     const float* W2; int64_t w2s; const float* b2;
-    int H, D, n_layers;
+    int H, D, n_layers, N;
     CsPackLayer L[JF_MAX_CHAIN];
     unsigned char* out;
 };
 
+// JF_SPLIT_F16X2: largest |W2| entry (bit pattern of a non-negative float orders like an unsigned) into the 16-byte tail of the image
+__global__ void __launch_bounds__(256) cs_absmax_kernel(const CsPackArgs a) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    float m = 0.f;
+    if (idx < (int64_t)a.N * a.H) m = fabsf(a.W2[(idx / a.H) * a.w2s + idx % a.H]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned*>(a.out + (size_t)a.n_layers * CS_CPL * CS_CHUNK16_BYTES), __builtin_bit_cast(unsigned, m));
+}
+// power-of-two scale of W2 for the f16 pieces: the largest entry lands in [2^14, 2^15)
+__device__ __forceinline__ int cs_w_exponent(float wmax) { return (wmax > 0.f && wmax < INFINITY) ? 14 - ilogbf(wmax) : 0; }
+
 // one thread per (chunk, tile, k-step, lane): writes the three pieces' fragments (16 bytes each); the first 48 threads of a chunk's
 // first k-step also write the bias
-__global__ void __launch_bounds__(256) cs_pack_kernel(const CsPackArgs a) {
+template <int NP> __global__ void __launch_bounds__(256) cs_pack_kernel(const CsPackArgs a) {
+    using G = CsGeom<NP>;
     const int idx = blockIdx.x * 256 + threadIdx.x;
     const int lane = idx & 63;
     int rest = idx >> 6;
@@ -50,22 +63,35 @@ __global__ void __launch_bounds__(256) cs_pack_kernel(const CsPackArgs a) {
     const CsPackLayer o = a.L[l];
     const int m = lane & 15, q = lane >> 4;
     const int col = cs_slot_column(o, a.D, 4 * tile + (m & 3), m >> 2);
-    bf16x8 f[CS_NP];
+    bf16x8 f[NP];
+    int e = 0;
+    if constexpr (NP == 2) e = cs_w_exponent(*reinterpret_cast<const float*>(a.out + (size_t)a.n_layers * CS_CPL * G::CHUNK));
+    const float wscale = ldexpf(1.0f, e);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int k = 16 * (2 * s + (i >> 2)) + 4 * q + (i & 3);    // hidden unit of k-slot i of lane group q in k-step s (matches the h layout)
         const float w = (col >= 0 && k < a.H) ? a.W2[(int64_t)(o.col0 + col) * a.w2s + k] : 0.0f;
-        __bf16 p0, p1, p2;
-        cs_split(w, p0, p1, p2);
-        f[0][i] = p0; f[1][i] = p1; f[2][i] = p2;
+        if constexpr (NP == 3) {
+            __bf16 p0, p1, p2;
+            cs_split(w, p0, p1, p2);
+            f[0][i] = p0; f[1][i] = p1; f[2][i] = p2;
+        } else {
+            const float ws = w * wscale;                            // exact (power of two)
+            const _Float16 hi = (_Float16)ws;
+            const _Float16 lo = (_Float16)(ws - (float)hi);
+            f[0][i] = __builtin_bit_cast(__bf16, hi); f[1][i] = __builtin_bit_cast(__bf16, lo);
+        }
     }
-    unsigned char* base = a.out + (size_t)chunk * CS_CHUNK_BYTES;
+    unsigned char* base = a.out + (size_t)chunk * G::CHUNK;
 #pragma unroll
-    for (int p = 0; p < CS_NP; ++p)
-        *reinterpret_cast<bf16x8*>(base + (size_t)((tc * CS_KSTEPS + s) * CS_NP + p) * CS_FRAG + lane * 16) = f[p];
+    for (int p = 0; p < NP; ++p)
+        *reinterpret_cast<bf16x8*>(base + (size_t)((tc * CS_KSTEPS + s) * NP + p) * CS_FRAG + lane * 16) = f[p];
     if (s == 0 && lane < 16) {
         const float b = (col >= 0 && a.b2 != nullptr) ? a.b2[o.col0 + col] : 0.0f;
-        reinterpret_cast<float*>(base + CS_W_BYTES)[tc * 16 + m] = b;
+        reinterpret_cast<float*>(base + G::W)[tc * 16 + m] = NP == 2 ? b * ldexpf(1.0f, e + 14) : b;      // f16 pieces: in the accumulators' units
+    }
+    if constexpr (NP == 2) {
+        if (s == 0 && tc == 0 && lane < 4) reinterpret_cast<float*>(base + G::W + CS_B_BYTES)[lane] = lane == 0 ? ldexpf(1.0f, -(e + 14)) : 0.f;
     }
 }
 
@@ -91,12 +117,13 @@ struct CsArgs {
 // six independent accumulators per piece product instead of three) and the chunk barriers are paid once per 128 rows instead of 64.
 // SAVE (log-prob direction with gradients wanted): every layer's input coordinate and mixture sums go to a.aux, 5 floats per (layer, row,
 // coordinate lane) -- 320 bytes per row of a 4-layer block instead of the 2.2 KB parameter row the adjoint would otherwise need.
-template <int RG, bool FWD, bool SAVE = false> __global__ void __launch_bounds__(256, 2) cond_gf_split_kernel(const CsArgs a) {
+template <int RG, bool FWD, bool SAVE = false, int NP = CS_NP> __global__ void __launch_bounds__(256, 2) cond_gf_split_kernel(const CsArgs a) {
+    using G = CsGeom<NP>;
     constexpr int CS_ROWS = CS_ROWS1 * RG;
     constexpr int MT = 16;
     extern __shared__ __align__(16) unsigned char smem_raw[];
     unsigned char* Ws0 = smem_raw;                                 // two packed chunks (double buffer)
-    float* Xs = reinterpret_cast<float*>(smem_raw + CS_CHUNK_BYTES);   // phase 1 only (overlays buffer 1 while chunk 0 lands in buffer 0)
+    float* Xs = reinterpret_cast<float*>(smem_raw + G::CHUNK);   // phase 1 only (overlays buffer 1 while chunk 0 lands in buffer 0)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lq = lane >> 4;
     const int64_t row0 = (int64_t)blockIdx.x * CS_ROWS;
@@ -108,24 +135,19 @@ template <int RG, bool FWD, bool SAVE = false> __global__ void __launch_bounds__
     // is a scalar -- no VALU address arithmetic per DMA instruction (the flat global_load_lds form spent ~8 vector integer instructions on each
     // of its 64-bit addresses, 230 per layer)
     const __amdgpu_buffer_rsrc_t packed_rsrc =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(a.packed), 0, a.n_layers * CS_CPL * CS_CHUNK_BYTES, 0x00027000);
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(a.packed), 0, a.n_layers * CS_CPL * G::CHUNK, 0x00027000);
     const int lane_off = wave * 1024 + lane * 16;
     auto dma = [&](int chunk) {
         // the packed image is in the log-prob direction's consumption order (last layer first); the sampling direction walks the layers forwards
         const int img = FWD ? (a.n_layers - 1 - chunk / CS_CPL) * CS_CPL + chunk % CS_CPL : chunk;
-        const int g = img * CS_CHUNK_BYTES;
-        unsigned char* l = Ws0 + (chunk & 1) * CS_CHUNK_BYTES;
-#pragma unroll
-        for (int u = 0; u < CS_W_BYTES / 4096; ++u)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(packed_rsrc, (cs_lptr)(l + (u * 4 + wave) * 1024), 16, lane_off, g + u * 4096, 0, 0);
-        if (wave == 0 && lane < CS_B_BYTES / 16)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(packed_rsrc, (cs_lptr)(l + CS_W_BYTES), 16, lane * 16, g + CS_W_BYTES, 0, 0);
+        const int g = img * G::CHUNK;
+        cs_dma_chunk(packed_rsrc, Ws0 + (chunk & 1) * G::CHUNK, g, lane_off, wave, lane, G::W, G::B);
     };
     dma(0);                                                        // lands in buffer 0 while phase 1 works in buffer 1
 
     // ---- phase 1: h^T = tanh(W1 x^T + b1) for the wave's rows as MFMA B operands, three bf16 pieces (jf_cond_split.h)
-    bf16x8 hB[RG][CS_KSTEPS][CS_NP];
-    cs_hidden<RG, false>(a.in, a.in_stride, a.W1, a.w1s, a.b1, a.K1, a.H, row0, last, Xs, hB, nullptr, 0);
+    bf16x8 hB[RG][CS_KSTEPS][NP];
+    cs_hidden<RG, false, NP>(a.in, a.in_stride, a.W1, a.w1s, a.b1, a.K1, a.H, row0, last, Xs, hB, nullptr, 0);
     // ---- flow state: lane = (row li of the row group's 16, coordinate lq)
     const bool live = lq < D, leader = lq == 0;
     const int d = live ? lq : D - 1;
@@ -151,8 +173,8 @@ template <int RG, bool FWD, bool SAVE = false> __global__ void __launch_bounds__
 #pragma unroll
         for (int c = 0; c < CS_CPL; ++c, ++chunk) {
             if (chunk + 1 < n_chunks) dma(chunk + 1);              // in flight while this chunk is multiplied
-            const unsigned char* Ws = Ws0 + (chunk & 1) * CS_CHUNK_BYTES;
-            const float* Bs = reinterpret_cast<const float*>(Ws + CS_W_BYTES);
+            const unsigned char* Ws = Ws0 + (chunk & 1) * G::CHUNK;
+            const float* Bs = reinterpret_cast<const float*>(Ws + G::W);
             f32x4 acc[RG][CS_CT];
 #pragma unroll
             for (int t = 0; t < CS_CT; ++t) {
@@ -162,35 +184,58 @@ template <int RG, bool FWD, bool SAVE = false> __global__ void __launch_bounds__
             }
             // A fragments one k-step ahead of the MFMAs that consume them (the LDS latency of a k-step's 9 reads hides behind the previous
             // k-step's MFMAs instead of being waited for in front of each MFMA)
-            bf16x8 A[2][CS_CT][CS_NP];
+            bf16x8 A[2][CS_CT][NP];
             auto load_a = [&](int s, int buf) {
 #pragma unroll
                 for (int t = 0; t < CS_CT; ++t)
 #pragma unroll
-                    for (int p = 0; p < CS_NP; ++p)
-                        A[buf][t][p] = *reinterpret_cast<const bf16x8*>(Ws + ((t * CS_KSTEPS + s) * CS_NP + p) * CS_FRAG + lane * 16);
+                    for (int p = 0; p < NP; ++p)
+                        A[buf][t][p] = *reinterpret_cast<const bf16x8*>(Ws + ((t * CS_KSTEPS + s) * NP + p) * CS_FRAG + lane * 16);
             };
             load_a(0, 0);
 #pragma unroll
             for (int s = 0; s < CS_KSTEPS; ++s) {
                 const int b = s & 1;
                 if (s + 1 < CS_KSTEPS) load_a(s + 1, b ^ 1);
-                // products with piece indices pa + pb <= 2, smallest first
-                constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
+                if constexpr (NP == 3) {
+                    // products with piece indices pa + pb <= 2, smallest first
+                    constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
 #pragma unroll
-                for (int i = 0; i < 6; ++i)
+                    for (int i = 0; i < 6; ++i)
+#pragma unroll
+                        for (int t = 0; t < CS_CT; ++t)
+#pragma unroll
+                            for (int g = 0; g < RG; ++g)
+                                acc[g][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[b][t][PA[i]], hB[g][s][PB[i]], acc[g][t], 0, 0, 0);
+                } else {
+                    // lo x hi, hi x lo, hi x hi
+#pragma unroll
+                    for (int i = 0; i < 3; ++i)
+#pragma unroll
+                        for (int t = 0; t < CS_CT; ++t)
+#pragma unroll
+                            for (int g = 0; g < RG; ++g) {
+                                const f16x8 af = __builtin_bit_cast(f16x8, A[b][t][i == 0 ? 1 : 0]), bf = __builtin_bit_cast(f16x8, hB[g][s][i == 1 ? 1 : 0]);
+                                acc[g][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf, acc[g][t], 0, 0, 0);
+                            }
+                }
+            }
+            if constexpr (NP == 3) {
+#pragma unroll
+                for (int g = 0; g < RG; ++g)
 #pragma unroll
                     for (int t = 0; t < CS_CT; ++t)
 #pragma unroll
-                        for (int g = 0; g < RG; ++g)
-                            acc[g][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[b][t][PA[i]], hB[g][s][PB[i]], acc[g][t], 0, 0, 0);
+                        for (int r = 0; r < 4; ++r) P[g][4 * (c * CS_CT + t) + r] = acc[g][t][r];
+            } else {
+                const float inv = Bs[CS_B_BYTES / 4];                // 2^-(e + 14): the scales of W2 and h undone (exact)
+#pragma unroll
+                for (int g = 0; g < RG; ++g)
+#pragma unroll
+                    for (int t = 0; t < CS_CT; ++t)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) P[g][4 * (c * CS_CT + t) + r] = acc[g][t][r] * inv;
             }
-#pragma unroll
-            for (int g = 0; g < RG; ++g)
-#pragma unroll
-                for (int t = 0; t < CS_CT; ++t)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) P[g][4 * (c * CS_CT + t) + r] = acc[g][t][r];
             if (c + 1 < CS_CPL) landed();                          // next chunk in place, every wave has read this one
         }
         // ---- flow phase on the lane's register rows (raw parameters; jf_gf.h arithmetic)
@@ -261,9 +306,14 @@ template <int RG, bool FWD, bool SAVE = false> __global__ void __launch_bounds__
 // ---------------------------------------------------------------------------------------------------------- host side
 static int cs_forced_rg = 0;                     // 0: by batch size
 
-static int cs_pack(const float* W2, int64_t w2s, const float* b2, int32_t H, int32_t D, int32_t n_layers, const jf_gf_layer* layers, void* packed,
-                   void* stream) {
-    if (!W2 || !layers || !packed) return JF_ERR_BADARG;
+static bool cs_arith_ok(int arithmetic) { return arithmetic == JF_SPLIT_BF16X3 || arithmetic == JF_SPLIT_F16X2; }
+static int64_t cs_image_bytes(int n_layers, int arithmetic) {
+    return arithmetic == JF_SPLIT_F16X2 ? (int64_t)n_layers * CS_CPL * CS_CHUNK16_BYTES + 16 : (int64_t)n_layers * CS_CPL * CS_CHUNK_BYTES;
+}
+
+static int cs_pack(const float* W2, int64_t w2s, const float* b2, int32_t H, int32_t D, int32_t n_layers, const jf_gf_layer* layers, int arithmetic,
+                   void* packed, void* stream) {
+    if (!W2 || !layers || !packed || !cs_arith_ok(arithmetic)) return JF_ERR_BADARG;
     if (!width_ok(H) || n_layers < 1 || n_layers > JF_MAX_CHAIN) return JF_ERR_BADARG;
     if (H > CS_HMAX) return JF_ERR_UNSUPPORTED;
     CsPackArgs a{};
@@ -280,17 +330,50 @@ static int cs_pack(const float* W2, int64_t w2s, const float* b2, int32_t H, int
         o.off_ln = o.off_lw + kd;
         col += o.off_ln + kd;
     }
-    a.W2 = W2; a.w2s = w2s; a.b2 = b2; a.H = H; a.D = D; a.n_layers = n_layers; a.out = static_cast<unsigned char*>(packed);
+    a.W2 = W2; a.w2s = w2s; a.b2 = b2; a.H = H; a.D = D; a.n_layers = n_layers; a.N = col; a.out = static_cast<unsigned char*>(packed);
     const int threads = n_layers * CS_CPL * CS_CT * CS_KSTEPS * 64;
-    hipLaunchKernelGGL(cs_pack_kernel, dim3((threads + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
+    hipStream_t st = (hipStream_t)stream;
+    if (arithmetic == JF_SPLIT_F16X2) {
+        if (hipMemsetAsync(a.out + (size_t)n_layers * CS_CPL * CS_CHUNK16_BYTES, 0, 16, st) != hipSuccess) return JF_ERR_LAUNCH;
+        hipLaunchKernelGGL(cs_absmax_kernel, dim3((unsigned)(((int64_t)col * H + 255) / 256)), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(cs_pack_kernel<2>, dim3((threads + 255) / 256), dim3(256), 0, st, a);
+    } else {
+        hipLaunchKernelGGL(cs_pack_kernel<3>, dim3((threads + 255) / 256), dim3(256), 0, st, a);
+    }
+    return hipPeekAtLastError() == hipSuccess ? JF_OK : JF_ERR_LAUNCH;
+}
+
+template <bool FWD, bool SAVE, int NP>
+static int cs_launch(const CsArgs& a, int64_t B, hipStream_t st) {
+    // phase 1's scratch overlays chunk buffer 1 and may be larger than it (K1 = 28 with two row groups: 30 KB)
+    const int k1p = (a.K1 + 3) / 4 * 4;
+    auto lds_of = [&](int rg) {
+        const size_t scratch = ((size_t)(CS_ROWS1 * rg + CS_HMAX) * (k1p + 1) + CS_HMAX) * 4;
+        const size_t second = scratch > (size_t)CsGeom<NP>::CHUNK ? (scratch + 15) / 16 * 16 : (size_t)CsGeom<NP>::CHUNK;
+        return (size_t)CsGeom<NP>::CHUNK + second;
+    };
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)cond_gf_split_kernel<1, FWD, SAVE, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        (void)hipFuncSetAttribute((const void*)cond_gf_split_kernel<2, FWD, SAVE, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        attr_set = true;
+    }
+    // two row groups per wave once that still leaves every CU several workgroups; JF_CS_RG=1|2 (environment, read once) or
+    // jf_cond_gf_split_row_groups() force a variant (A/B timing: scripts/probe/rg_sweep.py; both variants in one process: the stress tests)
+    static const int env_rg = getenv("JF_CS_RG") ? atoi(getenv("JF_CS_RG")) : 0;
+    const int force_rg = cs_forced_rg ? cs_forced_rg : env_rg;
+    const bool two = force_rg ? force_rg == 2 : B >= (int64_t)CS_ROWS1 * 2 * 1024;
+    if (two) hipLaunchKernelGGL((cond_gf_split_kernel<2, FWD, SAVE, NP>), dim3((unsigned)((B + 2 * CS_ROWS1 - 1) / (2 * CS_ROWS1))), dim3(256), lds_of(2), st, a);
+    else hipLaunchKernelGGL((cond_gf_split_kernel<1, FWD, SAVE, NP>), dim3((unsigned)((B + CS_ROWS1 - 1) / CS_ROWS1)), dim3(256), lds_of(1), st, a);
     return hipPeekAtLastError() == hipSuccess ? JF_OK : JF_ERR_LAUNCH;
 }
 
 template <bool FWD>
 static int cs_chain(const float* in, int64_t in_stride, const float* W1, int64_t w1s, const float* b1, const void* packed, int32_t K1, int32_t H,
                     const float* x, int64_t xs, const float* ld_in, int64_t B, int32_t D, int32_t n_layers, const jf_gf_layer* layers, float* x_out,
-                    int64_t xos, float* ld_out, const float* blp_in, float* blp_out, int32_t* status, void* stream, float* aux = nullptr) {
-    if (!in || !W1 || !b1 || !packed || !x || !x_out || !ld_out || !layers) return JF_ERR_BADARG;
+                    int64_t xos, float* ld_out, const float* blp_in, float* blp_out, int32_t* status, void* stream, float* aux = nullptr,
+                    int arithmetic = JF_SPLIT_BF16X3) {
+    if (!in || !W1 || !b1 || !packed || !x || !x_out || !ld_out || !layers || !cs_arith_ok(arithmetic)) return JF_ERR_BADARG;
     if (!width_ok(K1) || !width_ok(H) || !rows_ok(B) || n_layers < 1 || n_layers > JF_MAX_CHAIN) return JF_ERR_BADARG;
     if (K1 > CS_K1MAX || H > CS_HMAX || (reinterpret_cast<uintptr_t>(packed) & 15u)) return JF_ERR_UNSUPPORTED;
     CsArgs a{};
@@ -301,56 +384,39 @@ static int cs_chain(const float* in, int64_t in_stride, const float* W1, int64_t
         o.hh = h.hh_iter; o.model_offset = h.model_offset; o.inv_type = h.inverse_function_type;
         o.wmin = (float)h.width_min; o.inv_wmax = (float)(1.0 / h.width_max); o.nmin = (float)h.norm_min; o.nmax = (float)h.norm_max;
     }
+    if (aux && (FWD || (reinterpret_cast<uintptr_t>(aux) & 15u))) return JF_ERR_BADARG;
     if (B == 0) return JF_OK;
     a.in = in; a.in_stride = in_stride; a.W1 = W1; a.w1s = w1s; a.b1 = b1; a.packed = static_cast<const unsigned char*>(packed); a.K1 = K1; a.H = H;
     a.x = x; a.xs = xs; a.ld_in = ld_in; a.B = B; a.D = D; a.n_layers = n_layers;
     a.x_out = x_out; a.xos = xos; a.ld_out = ld_out; a.blp_in = blp_in; a.blp_out = blp_out; a.status = status; a.aux = aux;
-    if (aux && (FWD || (reinterpret_cast<uintptr_t>(aux) & 15u))) return JF_ERR_BADARG;
-    const size_t lds = 2 * CS_CHUNK_BYTES;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)cond_gf_split_kernel<1, FWD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute((const void*)cond_gf_split_kernel<2, FWD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if constexpr (!FWD) {
-            (void)hipFuncSetAttribute((const void*)cond_gf_split_kernel<1, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            (void)hipFuncSetAttribute((const void*)cond_gf_split_kernel<2, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        }
-        attr_set = true;
-    }
-    // two row groups per wave once that still leaves every CU several workgroups; JF_CS_RG=1|2 (environment, read once) or
-    // jf_cond_gf_split_row_groups() force a variant (A/B timing: scripts/probe/rg_sweep.py; both variants in one process: the stress tests)
-    static const int env_rg = getenv("JF_CS_RG") ? atoi(getenv("JF_CS_RG")) : 0;
-    const int force_rg = cs_forced_rg ? cs_forced_rg : env_rg;
-    const bool two = force_rg ? force_rg == 2 : B >= (int64_t)CS_ROWS1 * 2 * 1024;
-    const dim3 grid2((unsigned)((B + 2 * CS_ROWS1 - 1) / (2 * CS_ROWS1))), grid1((unsigned)((B + CS_ROWS1 - 1) / CS_ROWS1));
+    hipStream_t st = (hipStream_t)stream;
     if constexpr (!FWD) {
-        if (aux) {
-            if (two) hipLaunchKernelGGL((cond_gf_split_kernel<2, false, true>), grid2, dim3(256), lds, (hipStream_t)stream, a);
-            else hipLaunchKernelGGL((cond_gf_split_kernel<1, false, true>), grid1, dim3(256), lds, (hipStream_t)stream, a);
-            return hipPeekAtLastError() == hipSuccess ? JF_OK : JF_ERR_LAUNCH;
-        }
+        if (aux) return arithmetic == JF_SPLIT_F16X2 ? cs_launch<false, true, 2>(a, B, st) : cs_launch<false, true, 3>(a, B, st);
     }
-    if (two) hipLaunchKernelGGL((cond_gf_split_kernel<2, FWD>), grid2, dim3(256), lds, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL((cond_gf_split_kernel<1, FWD>), grid1, dim3(256), lds, (hipStream_t)stream, a);
-    return hipPeekAtLastError() == hipSuccess ? JF_OK : JF_ERR_LAUNCH;
+    return arithmetic == JF_SPLIT_F16X2 ? cs_launch<FWD, false, 2>(a, B, st) : cs_launch<FWD, false, 3>(a, B, st);
 }
 
 }  // namespace jf
 
 extern "C" {
-int64_t jf_cond_gf_packed_bytes(int32_t D, int32_t n_layers, const jf_gf_layer* layers) {
-    if (!layers || n_layers < 1 || n_layers > JF_MAX_CHAIN) return JF_ERR_BADARG;
+int64_t jf_cond_gf_packed_bytes2(int32_t D, int32_t n_layers, const jf_gf_layer* layers, int32_t arithmetic) {
+    if (!layers || n_layers < 1 || n_layers > JF_MAX_CHAIN || !jf::cs_arith_ok(arithmetic)) return JF_ERR_BADARG;
     for (int l = 0; l < n_layers; ++l)
         if (!jf::cs_layer_supported(layers[l], D)) return JF_ERR_UNSUPPORTED;
-    return (int64_t)n_layers * jf::CS_CPL * jf::CS_CHUNK_BYTES;
+    return jf::cs_image_bytes(n_layers, arithmetic);
 }
+int64_t jf_cond_gf_packed_bytes(int32_t D, int32_t n_layers, const jf_gf_layer* layers) { return jf_cond_gf_packed_bytes2(D, n_layers, layers, JF_SPLIT_BF16X3); }
 int jf_cond_gf_split_row_groups(int32_t rg) {
     const int prev = jf::cs_forced_rg;
     if (rg >= 0 && rg <= 2) jf::cs_forced_rg = rg;
     return prev;
 }
+int jf_cond_gf_pack2_f32(const float* W2, int64_t w2s, const float* b2, int32_t H, int32_t D, int32_t n, const jf_gf_layer* L, int32_t arithmetic,
+                         void* packed, void* s) {
+    return jf::cs_pack(W2, w2s, b2, H, D, n, L, arithmetic, packed, s);
+}
 int jf_cond_gf_pack_f32(const float* W2, int64_t w2s, const float* b2, int32_t H, int32_t D, int32_t n, const jf_gf_layer* L, void* packed, void* s) {
-    return jf::cs_pack(W2, w2s, b2, H, D, n, L, packed, s);
+    return jf::cs_pack(W2, w2s, b2, H, D, n, L, JF_SPLIT_BF16X3, packed, s);
 }
 int jf_cond_gf_chain_inv_split_f32(const float* in, int64_t is, const float* W1, int64_t w1s, const float* b1, const void* packed, int32_t K1,
                                    int32_t H, const float* x, int64_t xs, const float* ld_in, int64_t B, int32_t D, int32_t n,
@@ -363,6 +429,15 @@ int jf_cond_gf_chain_inv_split_save_f32(const float* in, int64_t is, const float
                                         int32_t* st, void* s) {
     if (!aux) return JF_ERR_BADARG;
     return jf::cs_chain<false>(in, is, W1, w1s, b1, packed, K1, H, x, xs, ld_in, B, D, n, L, xo, xos, ldo, bi, bo, st, s, aux);
+}
+int jf_cond_gf_chain_split2_f32(int32_t direction, int32_t arithmetic, const float* in, int64_t is, const float* W1, int64_t w1s, const float* b1,
+                                const void* packed, int32_t K1, int32_t H, const float* x, int64_t xs, const float* ld_in, int64_t B, int32_t D,
+                                int32_t n, const jf_gf_layer* L, float* xo, int64_t xos, float* ldo, const float* bi, float* bo, float* aux,
+                                int32_t* st, void* s) {
+    if (direction == JF_DIR_INV) return jf::cs_chain<false>(in, is, W1, w1s, b1, packed, K1, H, x, xs, ld_in, B, D, n, L, xo, xos, ldo, bi, bo, st, s, aux, arithmetic);
+    if (direction == JF_DIR_FWD && !bi && !bo && !aux)
+        return jf::cs_chain<true>(in, is, W1, w1s, b1, packed, K1, H, x, xs, ld_in, B, D, n, L, xo, xos, ldo, nullptr, nullptr, st, s, nullptr, arithmetic);
+    return JF_ERR_BADARG;
 }
 int64_t jf_cond_gf_aux_floats(int64_t B, int32_t n_layers) {
     return (jf::rows_ok(B) && n_layers >= 1 && n_layers <= JF_MAX_CHAIN) ? (int64_t)n_layers * B * 20 : (int64_t)JF_ERR_BADARG;

@@ -16,6 +16,32 @@ constexpr int CS_FRAG = 1024;                      // bytes of one A fragment (6
 constexpr int CS_W_BYTES = CS_CT * CS_KSTEPS * CS_NP * CS_FRAG;       // 36864
 constexpr int CS_B_BYTES = CS_CT * 16 * 4;                            // 192: the chunk's bias, permuted column order
 constexpr int CS_CHUNK_BYTES = CS_W_BYTES + CS_B_BYTES;               // 37056 (16-byte multiple)
+// second arithmetic (JF_SPLIT_F16X2): every operand = TWO f16 pieces (11 + 11 significant bits), three products (lo hi, hi lo, hi hi) instead of
+// six, two fragments per (tile, k-step) instead of three.  Representation error <= 2^-22 per operand -- below the rounding of the f32
+// accumulation either arithmetic ends in (scripts/probe/f16split.py: rms error of the 128-term products 2.4e-8 vs 6.8e-8 for a plain f32 matrix
+// product, 1.8e-9 for the bf16 triple).  Range: W2 is scaled by a power of two so that its largest entry sits in [2^14, 2^15), h (in (-1, 1)) by
+// 2^14, so a low piece leaves the normal f16 range only below 2^-28 of the largest weight / 2^-28 absolute in h -- whether the matrix core
+// keeps or flushes such subnormals is then immaterial (<= 4e-9 |w| per term).  The chunk's bias tail carries the bias in scaled units (the
+// accumulators start from it) and the inverse scale 2^-(e + 14) that brings the result back (exact).
+constexpr int CS_NP16 = 2;
+constexpr int CS_W16_BYTES = CS_CT * CS_KSTEPS * CS_NP16 * CS_FRAG;  // 24576
+constexpr int CS_B16_BYTES = CS_B_BYTES + 16;                         // bias + {2^-(e + 14), pad}
+constexpr int CS_CHUNK16_BYTES = CS_W16_BYTES + CS_B16_BYTES;         // 24784 (16-byte multiple)
+constexpr float CS_H_SCALE = 16384.0f;
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+using f16x2 = __attribute__((ext_vector_type(2))) _Float16;
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+template <int NP> struct CsGeom;
+template <> struct CsGeom<3> { static constexpr int W = CS_W_BYTES, B = CS_B_BYTES, CHUNK = CS_CHUNK_BYTES; };
+template <> struct CsGeom<2> { static constexpr int W = CS_W16_BYTES, B = CS_B16_BYTES, CHUNK = CS_CHUNK16_BYTES; };
+// v (two values) -> packed f16 pairs {hi0, hi1} and {lo0, lo1}: hi = RN_f16(v), lo = RN_f16(v - hi)
+__device__ __forceinline__ void cs_split16(float v0, float v1, unsigned& hi, unsigned& lo) {
+    const f16x2 h = __builtin_convertvector(f32x2{v0, v1}, f16x2);
+    const f32x2 back = __builtin_convertvector(h, f32x2);
+    const f16x2 l = __builtin_convertvector(f32x2{v0 - back[0], v1 - back[1]}, f16x2);
+    hi = __builtin_bit_cast(unsigned, h);
+    lo = __builtin_bit_cast(unsigned, l);
+}
 constexpr int CS_ROWS1 = 64;                       // rows per workgroup and row group (4 waves x 16); a wave carries RG row groups
 constexpr int CS_HMAX = 128, CS_K1MAX = 28;
 
@@ -42,16 +68,28 @@ static inline bool cs_layer_supported(const jf_gf_layer& h, int D) {
            h.width_min > 0 && h.width_max > 0 && D >= 3 && D <= 4;
 }
 
+// one chunk of a packed image -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds: 1 KiB per wave instruction, no register hop): wave w of the 4 moves
+// KiB pieces w, w + 4, ...; the bias tail goes with wave 0.  A plain function with the sizes as arguments (constants after inlining): the same
+// builtin inside a lambda of a kernel TEMPLATE whose sizes depend on a template parameter made hipcc's host pass drop the kernel's stub
+// without a diagnostic (undefined __device_stub__ symbols when the library loads).
+__device__ __forceinline__ void cs_dma_chunk(__amdgpu_buffer_rsrc_t rsrc, unsigned char* dst, int g, int lane_off, int wave, int lane, int w_bytes,
+                                             int b_bytes) {
+#pragma unroll
+    for (int u = 0; u < CS_W_BYTES / 4096; ++u)
+        if (u < w_bytes / 4096) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (cs_lptr)(dst + (u * 4 + wave) * 1024), 16, lane_off, g + u * 4096, 0, 0);
+    if (wave == 0 && lane < b_bytes / 16) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (cs_lptr)(dst + w_bytes), 16, lane * 16, g + w_bytes, 0, 0);
+}
+
 // ---------------------------------------------------------------------------------------------------------- phase 1
 // h^T = tanh(W1 x^T + b1) for the wave's RG x 16 rows (exact f32 MFMA; rows past B replicate row B-1), returned as MFMA B operands: three
 // bf16 pieces per value, k-slot i of lane group q in k-step s = hidden unit 16 (2 s + i / 4) + 4 q + i % 4.  Xs: LDS scratch of
 // (CS_ROWS1 RG + CS_HMAX) (k1p + 1) + CS_HMAX floats.  STORE_H: the f32 activations also go to h_out (B, H) -- the adjoint's weight-gradient
 // product reads them.  Ends with every wave past the barrier that follows the staging, NOT past one after the MFMA reads: the caller's next
 // barrier covers those.
-template <int RG, bool STORE_H>
+template <int RG, bool STORE_H, int NP = CS_NP>
 __device__ __forceinline__ void cs_hidden(const float* __restrict__ in, int64_t in_stride, const float* __restrict__ W1, int64_t w1s,
                                           const float* __restrict__ b1, int K1, int H, int64_t row0, int64_t last, float* Xs,
-                                          bf16x8 (&hB)[RG][CS_KSTEPS][CS_NP], float* __restrict__ h_out, int64_t hs) {
+                                          bf16x8 (&hB)[RG][CS_KSTEPS][NP], float* __restrict__ h_out, int64_t hs) {
     using MF = Mfma16<float>;
     constexpr int CS_ROWS = CS_ROWS1 * RG;
     constexpr int MT = 16, KS = 4, NREG = 4, JH = CS_HMAX / MT;
@@ -118,6 +156,12 @@ __device__ __forceinline__ void cs_hidden(const float* __restrict__ in, int64_t 
                 const float h0 = M<float>::tanh_fast(acc[j][r] + b1s[j * MT + 4 * lq + r]);
                 const float h1 = M<float>::tanh_fast(acc[j][r + 1] + b1s[j * MT + 4 * lq + r + 1]);
                 if constexpr (STORE_H) { acc[j][r] = h0; acc[j][r + 1] = h1; }
+                if constexpr (NP == 2) {
+                    unsigned ph, pl;
+                    cs_split16(h0 * CS_H_SCALE, h1 * CS_H_SCALE, ph, pl);
+                    q0[i >> 1] = ph; q1[i >> 1] = pl;
+                    continue;
+                }
                 const unsigned a0 = __builtin_bit_cast(unsigned, h0), a1 = __builtin_bit_cast(unsigned, h1);
                 const float r0 = h0 - __builtin_bit_cast(float, a0 & 0xffff0000u), r1 = h1 - __builtin_bit_cast(float, a1 & 0xffff0000u);
                 const unsigned c0 = __builtin_bit_cast(unsigned, r0), c1 = __builtin_bit_cast(unsigned, r1);
@@ -126,7 +170,8 @@ __device__ __forceinline__ void cs_hidden(const float* __restrict__ in, int64_t 
                 q1[i >> 1] = __builtin_amdgcn_perm(c1, c0, 0x07060302u);
                 q2[i >> 1] = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, s1), __builtin_bit_cast(unsigned, s0), 0x07060302u);
             }
-            hB[g][s][0] = __builtin_bit_cast(bf16x8, q0); hB[g][s][1] = __builtin_bit_cast(bf16x8, q1); hB[g][s][2] = __builtin_bit_cast(bf16x8, q2);
+            hB[g][s][0] = __builtin_bit_cast(bf16x8, q0); hB[g][s][1] = __builtin_bit_cast(bf16x8, q1);
+            if constexpr (NP == 3) hB[g][s][2] = __builtin_bit_cast(bf16x8, q2);
         }
         if constexpr (STORE_H) {
             const int64_t r = row0 + (wave * RG + g) * MT + li;

@@ -170,18 +170,20 @@ class pdf(nn.Module):
         # conditional e-blocks (Linear-tanh-Linear MLP + g layers, D in {3,4}, float32) as ONE launch with the parameter block kept on chip
         # (jf_cond_gf_chain_inv): +9 % on the C3 step against jf_mlp2 + jf_gf_chain_inv.  False selects the two-launch path.
         self.fuse_conditional_blocks = True
-        # matrix arithmetic of the fused block's 128 -> P product: "split_bf16" (three bf16 pieces per f32 operand, six MFMA passes with f32
-        # accumulation: products exact, result within ~3 * 2^-24 relative of the f32 dot product; parameters stay in registers) or "f32"
-        # (exact f32-input MFMA, parameter tile in LDS).  Layer options outside the split kernel's set fall back to "f32" by themselves.
+        # matrix arithmetic of the fused block's 128 -> P product: "split_f16" (two f16 pieces per f32 operand, operands scaled into the normal
+        # f16 range, three MFMA passes with f32 accumulation: representation error <= 2^-22 per operand, below the rounding of the f32
+        # accumulation itself), "split_bf16" (three bf16 pieces, six passes: products exact, result within ~3 * 2^-24 relative of the f32 dot
+        # product) -- both keep the parameters in registers -- or "f32" (exact f32-input MFMA, parameter tile in LDS).  Layer options outside
+        # the split kernel's set fall back to "f32" by themselves.
         # JF_FUSED_MATRIX_ARITHMETIC=f32 in the environment selects the exact-f32 kernel process-wide (an operational fallback while the
         # full-batch hazard of DESIGN.md 3.9 has a remedy but no root cause).
-        self.fused_matrix_arithmetic = os.environ.get("JF_FUSED_MATRIX_ARITHMETIC", "split_bf16")
+        self.fused_matrix_arithmetic = os.environ.get("JF_FUSED_MATRIX_ARITHMETIC", "split_f16")
         # which kernel runs the split-bf16 fused block: "auto" (by batch size), "pp" (cond_pp_kernels.hip) or "split" (cond_split_kernels.hip)
         self.fused_block_kernel = os.environ.get("JF_FUSED_BLOCK_KERNEL", "auto")
         if self.fused_block_kernel not in ("auto", "pp", "split"):
             raise ValueError("JF_FUSED_BLOCK_KERNEL must be 'auto', 'pp' or 'split', got %r" % self.fused_block_kernel)
-        if self.fused_matrix_arithmetic not in ("split_bf16", "f32"):
-            raise ValueError("JF_FUSED_MATRIX_ARITHMETIC must be 'split_bf16' or 'f32', got %r" % self.fused_matrix_arithmetic)
+        if self.fused_matrix_arithmetic not in ("split_f16", "split_bf16", "f32"):
+            raise ValueError("JF_FUSED_MATRIX_ARITHMETIC must be 'split_f16', 'split_bf16' or 'f32', got %r" % self.fused_matrix_arithmetic)
         self._packed_cache = {}
 
         self._read_model_definition(pdf_defs, flow_defs, options_overwrite, conditional_input_dim, amortization_mlp_dims,
@@ -561,6 +563,8 @@ class pdf(nn.Module):
         """which register-resident fused block kernel: "pp" (persistent ping-pong workgroups, cond_pp_kernels.hip) from
         or "split" (cond_split_kernels.hip, the default "auto" choice at every batch size while the two measure the same);
         pdf.fused_block_kernel = "pp" / "split" (or JF_FUSED_BLOCK_KERNEL) forces one."""
+        if self.fused_matrix_arithmetic == "split_f16":
+            return "split16"                                                  # cond_split_kernels.hip with f16 pairs
         if self.fused_block_kernel in ("pp", "split"):
             return self.fused_block_kernel
         # measured at 2^20 rows (profiles/r03_pp_*.md): pp 0.77 ms, split 0.775 ms -- no gain yet, and pp needs >= 256 row tiles to fill the chip
@@ -706,7 +710,7 @@ class pdf(nn.Module):
                 # amortisation MLP + g layers in one launch: the per-sample parameter block never reaches HBM
                 larr = _hip.gf_layer_array([l.c_struct() for l in layers])
                 packed = None
-                if self.fused_matrix_arithmetic == "split_bf16" and fused[0].shape[0] <= 128:
+                if self.fused_matrix_arithmetic != "f32" and fused[0].shape[0] <= 128:
                     packed = self._packed_w2(si, fused[2], fused[3], larr, len(layers), layers[0].dimension, x.shape[0])
                 if packed is not None:
                     res = _hip.cond_gf_chain_inv_split(self._mlp_input(si, data_summary, embeds), fused[0], fused[1], packed[1], tgt, log_det, larr,
@@ -929,7 +933,7 @@ class pdf(nn.Module):
                 if fused is not None:
                     w1, b1, w2, b2 = mlp[0].weight, mlp[0].bias, mlp[2].weight, mlp[2].bias
                     packed = None
-                    if self.fused_matrix_arithmetic == "split_bf16" and w1.shape[0] <= 128:
+                    if self.fused_matrix_arithmetic != "f32" and w1.shape[0] <= 128:
                         packed = self._packed_w2(si, w2.detach(), b2.detach(), larr, len(layers), D, x.shape[0])
                     out, log_det, base_logp = autograd.CondBlockFn.apply(inp, w1, b1, w2, b2, tgt, log_det, base_logp, packed, larr, len(layers), D,
                                                                          status)
@@ -1003,15 +1007,17 @@ class pdf(nn.Module):
             kind = self.pdf_defs_list[si][0]
             layers = list(block)
             fused = self._fusable_block(si, layers, only_last, amortization_parameters, x.dtype) if kind == "e" else None
-            if fused is not None and self.fused_matrix_arithmetic == "split_bf16" and fused[0].shape[0] <= 128:
+            if fused is not None and self.fused_matrix_arithmetic != "f32" and fused[0].shape[0] <= 128:
                 # amortisation MLP + the g layers' solves in one launch, parameters regulated once in the MFMA result registers
                 larr = _hip.gf_layer_array([l.c_struct() for l in layers])
-                packed = self._packed_w2(si, fused[2], fused[3], larr, len(layers), layers[0].dimension, 0, kind="split")
+                packed = self._packed_w2(si, fused[2], fused[3], larr, len(layers), layers[0].dimension, 0,
+                                         kind="split16" if self.fused_matrix_arithmetic == "split_f16" else "split")
                 if packed is not None:
                     ba, bb = self.base_dim_indices[si]
                     a, b = self.target_dim_indices[si]
                     _, log_det = _hip.cond_gf_chain_fwd_split(self._mlp_input(si, data_summary, embeds), fused[0], fused[1], packed[1], x[:, ba:bb],
-                                                              log_det, larr, len(layers), layers[0].dimension, x_out=out[:, a:b], status=status)
+                                                              log_det, larr, len(layers), layers[0].dimension, x_out=out[:, a:b], status=status,
+                                                              kind=packed[0])
                     embeds.append(block[-1]._embedding_conditional_return(out[:, a:b]))
                     if per_block is not None:
                         per_block.append(log_det)

@@ -39,6 +39,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--rows", type=int, default=1 << 18)
 ap.add_argument("--workload", default="c3")
 ap.add_argument("--torch-profile", action="store_true", help="also print the device-time table of torch.profiler for one step (library GEMMs, elementwise glue)")
+ap.add_argument("--graph", action="store_true", help="capture the whole step (forward, backward, Adam) in one HIP graph and time its replays")
+ap.add_argument("--fused-adam", action="store_true", help="torch.optim.Adam(fused=True): one optimizer launch instead of ~8")
 ap.add_argument("--pmc-child", action="store_true", help="a few steps only (under rocprofv3 --pmc: every launch is serialised and slow)")
 args = ap.parse_args()
 name, dtype = ("c3_e4s2e4", torch.float32) if args.workload == "c3" else ("c5_e8s2_ggggv", torch.float64)
@@ -47,7 +49,9 @@ pdf = helpers.build_product(fx, dtype)
 x, cond = inputs(fx, args.rows, 7)
 x = torch.from_numpy(x).to(device="cuda", dtype=dtype)
 cond = torch.from_numpy(cond).to(device="cuda", dtype=dtype) if cond is not None else None
-opt = torch.optim.Adam(pdf.parameters(), lr=1e-4)
+opt = torch.optim.Adam(pdf.parameters(), lr=1e-4, capturable=args.graph, fused=args.fused_adam or None)
+if args.graph:
+    pdf.check_status = False                          # reading the status words is a host synchronisation: not capturable
 
 
 def step():
@@ -59,6 +63,22 @@ def step():
     return loss
 
 
+if args.graph:
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(5):
+            step()
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    opt.zero_grad(set_to_none=True)
+    with torch.cuda.graph(graph):
+        static_loss = step()
+    eager_step = step
+
+    def step():
+        graph.replay()
+        return static_loss
 for _ in range(5):
     step()
 if args.pmc_child:

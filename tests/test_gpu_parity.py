@@ -117,7 +117,7 @@ def test_logprob_float32_vs_float64_reference(fx):
     with timer:
         logp, logp_base, base = pdf(x, conditional_input=cond, force_embedding_coordinates=fx.meta["embedding"])
     if fx.name in FUSABLE:       # the default float32 hot kernel is what these golden values are compared with
-        assert any(k[0] == "jf_cond_gf_chain_inv_split_f32" for k in timer.summary()), sorted(timer.summary())
+        assert any(k[0] == "jf_cond_gf_chain_split2_f32" for k in timer.summary()), sorted(timer.summary())
     assert_float32_parity(logp.double().cpu().numpy(), fx["logp"], ok, fx.name)
 
 
@@ -371,7 +371,7 @@ def test_fused_conditional_block_vs_golden_and_two_launch_path(name):
     pdf.check_status = bool(ok.all())
     out = {}
     for mode, kernel in (("two", "jf_gf_chain_inv_f32"), ("f32", "jf_cond_gf_chain_inv_f32"), ("split_bf16", "jf_cond_gf_chain_inv_split_f32"),
-                         ("pp", "jf_cond_gf_chain_inv_pp_f32")):
+                         ("split_f16", "jf_cond_gf_chain_split2_f32"), ("pp", "jf_cond_gf_chain_inv_pp_f32")):
         pdf.fuse_conditional_blocks = mode != "two"
         pdf.fused_matrix_arithmetic = "split_bf16" if mode == "pp" else mode
         pdf.fused_block_kernel = "pp" if mode == "pp" else "auto"          # auto: the split kernel at a fixture's batch size
@@ -384,8 +384,9 @@ def test_fused_conditional_block_vs_golden_and_two_launch_path(name):
             assert "jf_cond_gf_chain_inv_split_f32" not in ran
         assert_float32_parity(out[mode][0].double().cpu().numpy(), fx["logp"], ok, "%s [%s]" % (name, mode))
     sel = torch.from_numpy(ok).cuda()
-    for mode in ("f32", "split_bf16", "pp"):
-        # per row the same flow arithmetic; the parameters differ by the summation order / the 3 * 2^-24 split residue of the 128-term products
+    for mode in ("f32", "split_bf16", "split_f16", "pp"):
+        # per row the same flow arithmetic; the parameters differ by the summation order / the 3 * 2^-24 (bf16 triples) or 3 * 2^-22 (f16 pairs)
+        # split residue of the 128-term products
         scale = 1.0 + out["two"][0][sel].abs()
         assert float(((out[mode][0][sel] - out["two"][0][sel]).abs() / scale).max()) < 2e-5, mode
         assert max_abs(out[mode][2][sel], out["two"][2][sel]) < 2e-3, mode
@@ -416,7 +417,7 @@ def test_fused_sampling_block_vs_golden_and_two_launch_path(name):
             out[mode] = pdf._obtain_sample(conditional_input=cond, predefined_target_input=z, force_embedding_coordinates=emb)
         steps[mode] = pdf.last_status_words["newton_row_steps"]
         ran = sorted(set(k[0] for k in timer.summary()))
-        assert ("jf_cond_gf_chain_fwd_split_f32" in ran) == (mode == "fused"), (mode, ran)
+        assert ("jf_cond_gf_chain_split2_f32" in ran) == (mode == "fused"), (mode, ran)
     for mode in ("two", "fused"):
         gx, gl = out[mode][0].double().cpu().numpy(), out[mode][2].double().cpu().numpy()
         ex = np.abs(gx - rx) / (1.0 + np.abs(rx))
@@ -519,7 +520,7 @@ def test_fused_block_two_row_groups_per_wave(name):
     timer = _hip.KernelTimer()
     with timer:
         runs, small, reps, n, big = _tiled_run(fx, torch.float32, 18, launches=1)
-    assert any(k[0] == "jf_cond_gf_chain_inv_split_f32" for k in timer.summary())
+    assert any(k[0] == "jf_cond_gf_chain_split2_f32" for k in timer.summary())
     ref = np.tile(small, reps)[:big]
     fin = np.isfinite(ref)
     assert np.array_equal(np.isfinite(runs[0]), fin)
@@ -529,7 +530,7 @@ def test_fused_block_two_row_groups_per_wave(name):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("rg", [1, 2, "pp"])
+@pytest.mark.parametrize("rg", [1, 2, "pp", "bf16_1", "bf16_2"])
 def test_fused_block_stress_20_launches_at_full_size(rg):
     """DESIGN.md 3.9 (not root-caused; remedy = no packed f32): the runtime guard.  20 launches of the C3 step at 2^20 rows for EACH row-group
     variant of the split-bf16 block kernel must be bit-identical over all rows (compared on the device), and every replica of the tiled
@@ -542,13 +543,17 @@ def test_fused_block_stress_20_launches_at_full_size(rg):
     reps = (1 << 20) // n + 1
     x = to_dev(np.tile(fx["x"], (reps, 1)), torch.float32)
     pdf.fused_block_kernel = "pp" if rg == "pp" else "split"           # "pp": the persistent ping-pong kernel (cond_pp_kernels.hip)
+    # 1 / 2: the default f16-pair arithmetic with one / two row groups per wave; "bf16_*": the bf16-triple arithmetic; "pp" multiplies bf16 triples
+    pdf.fused_matrix_arithmetic = "split_f16" if rg in (1, 2) else "split_bf16"
+    expect = {"pp": "jf_cond_gf_chain_inv_pp_f32", 1: "jf_cond_gf_chain_split2_f32", 2: "jf_cond_gf_chain_split2_f32"}.get(rg, "jf_cond_gf_chain_inv_split_f32")
+    rg = int(rg[-1]) if isinstance(rg, str) and rg.startswith("bf16") else rg
     prev = _hip.lib().jf_cond_gf_split_row_groups(0 if rg == "pp" else rg)
     try:
         timer = _hip.KernelTimer()
         with torch.no_grad():
             with timer:
                 first = pdf(x)[0]
-            assert any(k[0] == ("jf_cond_gf_chain_inv_pp_f32" if rg == "pp" else "jf_cond_gf_chain_inv_split_f32") for k in timer.summary())
+            assert any(k[0] == expect for k in timer.summary()), sorted(timer.summary())
             small = pdf(x[:n])[0]
             differing = 0
             for _ in range(19):
@@ -614,7 +619,7 @@ def test_packed_image_follows_the_weights():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kernel", ["split", "pp"])
+@pytest.mark.parametrize("kernel", ["split16", "split", "pp"])
 def test_packed_image_follows_the_weights_when_the_module_dtype_differs(kernel):
     """float64 module, float32 inputs: the fused block then works on per-call float32 CASTS of the weights -- fresh temporaries whose own
     in-place version is always 0 and whose addresses the caching allocator reuses.  The packed image must still follow the module's
@@ -622,14 +627,17 @@ def test_packed_image_follows_the_weights_when_the_module_dtype_differs(kernel):
     from jammy_flows_amd import _hip
     fx = [f for f in ALL_FIXTURES if f.name == "g_e3_ggg_cond"][0]
     pdf = build_product(fx, torch.float64)                       # module stays float64
-    pdf.fused_block_kernel = kernel
+    arithmetic = "split_f16" if kernel == "split16" else "split_bf16"      # "split16": the default (f16 pairs on the split kernel)
+    pdf.fused_matrix_arithmetic = arithmetic
+    pdf.fused_block_kernel = "auto" if kernel == "split16" else kernel
     x = to_dev(fx["x"], torch.float32)
     cond = to_dev(fx.get("cond"), torch.float32)
     pdf.check_status = False
     timer = _hip.KernelTimer()
     with timer:
         a = pdf(x, conditional_input=cond)[0]
-    assert any(k[0] == "jf_cond_gf_chain_inv_%s_f32" % kernel for k in timer.summary()), sorted(timer.summary())
+    expect = "jf_cond_gf_chain_split2_f32" if kernel == "split16" else "jf_cond_gf_chain_inv_%s_f32" % kernel
+    assert any(k[0] == expect for k in timer.summary()), sorted(timer.summary())
     for _ in range(3):                                           # same weights: same image, same result
         assert torch.equal(a, pdf(x, conditional_input=cond)[0])
     with torch.no_grad():
@@ -638,7 +646,7 @@ def test_packed_image_follows_the_weights_when_the_module_dtype_differs(kernel):
     b = pdf(x, conditional_input=cond)[0]
     pdf.fused_matrix_arithmetic = "f32"
     c = pdf(x, conditional_input=cond)[0]
-    pdf.fused_matrix_arithmetic = "split_bf16"
+    pdf.fused_matrix_arithmetic = arithmetic
     fin = torch.isfinite(a) & torch.isfinite(b) & torch.isfinite(c)
     assert float((a - b)[fin].abs().max()) > 1e-4, "stale packed weights were used"
     assert float(((b - c)[fin].abs() / (1 + c[fin].abs())).max()) < 2e-5
