@@ -172,8 +172,8 @@ class CondBlockFn(torch.autograd.Function):
             # ONE launch: hidden activations and parameters recomputed in the forward kernel's register layout, each layer's adjoint in place,
             # g_h accumulated from the same registers; the parameter-row gradient leaves in packed column order for the weight-gradient product
             (kind, packed), aux = ctx.fused
-            if kind != "split":                       # the adjoint kernel multiplies bf16 triples: its own image of the same weights
-                packed = _hip.cond_gf_pack(w2, b2, layer_array, n_layers, D, "split")
+            if kind != "split16":                     # the adjoint kernel multiplies f16 pairs: its own image of the same weights
+                packed = _hip.cond_gf_pack(w2, b2, layer_array, n_layers, D, "split16")
             packed_t = _hip.cond_gf_bwd_pack(w2, layer_array, n_layers, D)
             g_x, g_p, h, g_hid = _hip.cond_gf_chain_inv_split_bwd(inp, w1, b1, packed, packed_t, z, aux, layer_array, n_layers, D, g_xout, g_ld, g_blp)
             ctx.fused = None

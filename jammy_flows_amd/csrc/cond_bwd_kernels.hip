@@ -14,13 +14,15 @@
 // (jf_linear_split), the weight gradient, the hidden layer's adjoint: 1.22 of the 2.47 ms of a C3 training step at 2^18 rows.  Here
 //  * the forward launch of a training step (cond_gf_split_kernel<.., SAVE>) leaves every layer's input coordinate and mixture sums behind:
 //    20 floats per row and layer;
-//  * this kernel recomputes h and each layer's parameters exactly as the forward kernel does (split-bf16 MFMA, result layout = flow layout),
+//  * this kernel recomputes h and each layer's parameters exactly as the forward kernel does (f16-pair MFMA, result layout = flow layout),
 //    so the parameter row of lane (row, coordinate) is in 36 registers when the layer's adjoint starts, and the adjoint OVERWRITES it in
 //    place with the gradient of those 36 raw parameters;
 //  * in that layout the gradient row is already an MFMA B operand: lane (row n, coordinate q) supplies k-slots 8 q .. 8 q + 7 of k-step s
 //    = its own slots 8 s .. 8 s + 7.  g_h^T (hidden x rows) += W2_l^T (hidden x slots) g_P^T (slots x rows) therefore needs no transpose and
-//    no LDS: 5 k-steps x 8 hidden tiles x 6 piece products per layer, accumulated over the layers in 32 registers whose layout is the one
-//    phase 1 produced h in;
+//    no LDS: 5 k-steps x 8 hidden tiles x 3 piece products per layer, accumulated over the layers in 32 registers whose layout is the one
+//    phase 1 produced h in.  Arithmetic: f16 pairs as in the forward kernel (jf_cond_split.h); W2^T carries the forward image's power-of-two
+//    scale, a row's gradient its own (largest entry of the row and layer into [2^14, 2^15)), and the accumulator is moved into and out of
+//    the layer's units around each layer's products (exact);
 //  * the layers run first to last (the reverse of the log-prob direction), the gradient of a layer's input coordinate feeding the next.
 #include "jf_cond_split.h"
 #include "jf_gf_bwd.h"
@@ -29,18 +31,29 @@ namespace jf {
 
 constexpr int CB_KSTEPS = 5;                        // 36 slots (+ 4 of padding) = 5 x 8 k-slots per coordinate lane
 constexpr int CB_JT = CS_HMAX / 16;                 // hidden tiles
-constexpr int CB_T_BYTES = CB_JT * CS_NP * CS_FRAG; // 24576: one k-step of W2_l^T
+constexpr int CB_T_BYTES = CB_JT * CS_NP16 * CS_FRAG; // 16384: one k-step of W2_l^T (f16 pairs)
 constexpr int CB_STEPS = CS_CPL + CB_KSTEPS;        // chunk steps per layer (even: a layer starts in buffer 0)
 constexpr int CB_PROW = 4 * CS_SLOTS;               // packed gradient columns per layer
-static_assert(CB_STEPS % 2 == 0 && CB_T_BYTES <= CS_CHUNK_BYTES, "double buffer of the forward kernel");
+constexpr int CB_BUF = CS_CHUNK16_BYTES;           // one of the two chunk buffers
+static_assert(CB_STEPS % 2 == 0 && CB_T_BYTES <= CB_BUF, "double buffer of the forward kernel");
 
 // ---------------------------------------------------------------------------------------------------------- packing
 struct CbPackArgs {
     const float* W2; int64_t w2s;
-    int H, D, n_layers;
+    int H, D, n_layers, N;
     CsPackLayer L[JF_MAX_CHAIN];
     unsigned char* out;
 };
+
+// largest |W2| entry into the image's 16-byte tail (as in cs_absmax_kernel); the pack kernel leaves the inverse scale 2^-e next to it
+__global__ void __launch_bounds__(256) cb_absmax_kernel(const CbPackArgs a) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    float m = 0.f;
+    if (idx < (int64_t)a.N * a.H) m = fabsf(a.W2[(idx / a.H) * a.w2s + idx % a.H]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned*>(a.out + (size_t)a.n_layers * CB_KSTEPS * CB_T_BYTES), __builtin_bit_cast(unsigned, m));
+}
 
 // one thread per (layer, k-step, hidden tile, lane): fragment value i of lane (m, q) = W2[column of slot 8 s + i of coordinate q][16 j + m]
 __global__ void __launch_bounds__(256) cb_pack_kernel(const CbPackArgs a) {
@@ -54,19 +67,25 @@ __global__ void __launch_bounds__(256) cb_pack_kernel(const CbPackArgs a) {
     const CsPackLayer o = a.L[l];
     const int m = lane & 15, q = lane >> 4;
     const int k = 16 * j + m;
-    bf16x8 f[CS_NP];
+    float* tail = reinterpret_cast<float*>(a.out + (size_t)a.n_layers * CB_KSTEPS * CB_T_BYTES);
+    const float wmax = tail[0];
+    const int e = cs_w_exponent(wmax);                               // the forward image's scale
+    const float wscale = ldexpf(1.0f, e);
+    bf16x8 f[CS_NP16];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int slot = 8 * s + i;
         const int col = slot < CS_SLOTS ? cs_slot_column(o, a.D, slot, q) : -1;
         const float w = (col >= 0 && k < a.H) ? a.W2[(int64_t)(o.col0 + col) * a.w2s + k] : 0.0f;
-        __bf16 p0, p1, p2;
-        cs_split(w, p0, p1, p2);
-        f[0][i] = p0; f[1][i] = p1; f[2][i] = p2;
+        const float ws = w * wscale;
+        const _Float16 hi = (_Float16)ws;
+        const _Float16 lo = (_Float16)(ws - (float)hi);
+        f[0][i] = __builtin_bit_cast(__bf16, hi); f[1][i] = __builtin_bit_cast(__bf16, lo);
     }
     unsigned char* base = a.out + (size_t)(l * CB_KSTEPS + s) * CB_T_BYTES;
 #pragma unroll
-    for (int p = 0; p < CS_NP; ++p) *reinterpret_cast<bf16x8*>(base + (size_t)(j * CS_NP + p) * CS_FRAG + lane * 16) = f[p];
+    for (int p = 0; p < CS_NP16; ++p) *reinterpret_cast<bf16x8*>(base + (size_t)(j * CS_NP16 + p) * CS_FRAG + lane * 16) = f[p];
+    if (idx == 0) tail[1] = (float)e;
 }
 
 // ---------------------------------------------------------------------------------------------------------- one layer's adjoint on a register row
@@ -196,38 +215,28 @@ __global__ void __launch_bounds__(256, 2) cond_gf_split_bwd_kernel(const CbArgs 
     constexpr int MT = 16;
     extern __shared__ __align__(16) unsigned char smem_raw[];
     unsigned char* Ws0 = smem_raw;                                 // two chunk buffers
-    float* Xs = reinterpret_cast<float*>(smem_raw + CS_CHUNK_BYTES);
+    float* Xs = reinterpret_cast<float*>(smem_raw + CB_BUF);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, lq = lane >> 4;
     const int64_t row0 = (int64_t)blockIdx.x * CS_ROWS1;
     const int64_t last = a.B - 1;
     const int D = a.D;
     const __amdgpu_buffer_rsrc_t p_rsrc =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(a.packed), 0, a.n_layers * CS_CPL * CS_CHUNK_BYTES, 0x00027000);
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(a.packed), 0, a.n_layers * CS_CPL * CS_CHUNK16_BYTES, 0x00027000);
     const __amdgpu_buffer_rsrc_t t_rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(a.packedT), 0, a.n_layers * CB_KSTEPS * CB_T_BYTES, 0x00027000);
     const int lane_off = wave * 1024 + lane * 16;
     // step c of layer l: c < 3 parameter chunk c of the layer (forward image, stored last layer first), else k-step c - 3 of W2_l^T
     auto dma = [&](int l, int c, int buf) {
-        unsigned char* dst = Ws0 + buf * CS_CHUNK_BYTES;
-        if (c < CS_CPL) {
-            const int g = ((a.n_layers - 1 - l) * CS_CPL + c) * CS_CHUNK_BYTES;
-#pragma unroll
-            for (int u = 0; u < CS_W_BYTES / 4096; ++u)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(p_rsrc, (cs_lptr)(dst + (u * 4 + wave) * 1024), 16, lane_off, g + u * 4096, 0, 0);
-            if (wave == 0 && lane < CS_B_BYTES / 16)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(p_rsrc, (cs_lptr)(dst + CS_W_BYTES), 16, lane * 16, g + CS_W_BYTES, 0, 0);
-        } else {
-            const int g = (l * CB_KSTEPS + c - CS_CPL) * CB_T_BYTES;
-#pragma unroll
-            for (int u = 0; u < CB_T_BYTES / 4096; ++u)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(t_rsrc, (cs_lptr)(dst + (u * 4 + wave) * 1024), 16, lane_off, g + u * 4096, 0, 0);
-        }
+        unsigned char* dst = Ws0 + buf * CB_BUF;
+        if (c < CS_CPL) cs_dma_chunk(p_rsrc, dst, ((a.n_layers - 1 - l) * CS_CPL + c) * CS_CHUNK16_BYTES, lane_off, wave, lane, CS_W16_BYTES, CS_B16_BYTES);
+        else cs_dma_chunk(t_rsrc, dst, (l * CB_KSTEPS + c - CS_CPL) * CB_T_BYTES, lane_off, wave, lane, CB_T_BYTES, 0);
     };
     dma(0, 0, 0);                                                  // lands in buffer 0 while phase 1 works in buffer 1
 
-    bf16x8 hB[1][CS_KSTEPS][CS_NP];
-    cs_hidden<1, true>(a.in, a.in_stride, a.W1, a.w1s, a.b1, a.K1, a.H, row0, last, Xs, hB, a.h_out, a.hs);
+    const int w_exp = (int)reinterpret_cast<const float*>(a.packedT + (size_t)a.n_layers * CB_KSTEPS * CB_T_BYTES)[1];   // W2^T's scale 2^w_exp
+    bf16x8 hB[1][CS_KSTEPS][CS_NP16];
+    cs_hidden<1, true, CS_NP16>(a.in, a.in_stride, a.W1, a.w1s, a.b1, a.K1, a.H, row0, last, Xs, hB, a.h_out, a.hs);
 
     // ---- flow state: lane = (row li of the wave's 16, coordinate lq)
     const bool live = lq < D;
@@ -244,7 +253,7 @@ __global__ void __launch_bounds__(256, 2) cond_gf_split_bwd_kernel(const CbArgs 
     for (int j = 0; j < CB_JT; ++j) gh[j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     auto landed = [&]() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
-    constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};       // products with piece indices pa + pb <= 2, smallest first
+    constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};                        // lo x hi, hi x lo, hi x hi
 
     landed();                                                      // chunk 0 is in buffer 0 and every wave is done with the phase-1 scratch
     for (int l = 0; l < a.n_layers; ++l) {
@@ -256,18 +265,18 @@ __global__ void __launch_bounds__(256, 2) cond_gf_split_bwd_kernel(const CbArgs 
 #pragma unroll
         for (int c = 0; c < CS_CPL; ++c) {
             dma(l, c + 1, (c + 1) & 1);                            // in flight while this chunk is multiplied
-            const unsigned char* Ws = Ws0 + (c & 1) * CS_CHUNK_BYTES;
-            const float* Bs = reinterpret_cast<const float*>(Ws + CS_W_BYTES);
+            const unsigned char* Ws = Ws0 + (c & 1) * CB_BUF;
+            const float* Bs = reinterpret_cast<const float*>(Ws + CS_W16_BYTES);
             f32x4 acc[CS_CT];
 #pragma unroll
-            for (int t = 0; t < CS_CT; ++t) acc[t] = *reinterpret_cast<const f32x4*>(Bs + t * 16 + 4 * lq);
-            bf16x8 A[2][CS_CT][CS_NP];
+            for (int t = 0; t < CS_CT; ++t) acc[t] = *reinterpret_cast<const f32x4*>(Bs + t * 16 + 4 * lq);      // bias in the accumulators' units
+            bf16x8 A[2][CS_CT][CS_NP16];
             auto load_a = [&](int s, int buf) {
 #pragma unroll
                 for (int t = 0; t < CS_CT; ++t)
 #pragma unroll
-                    for (int p = 0; p < CS_NP; ++p)
-                        A[buf][t][p] = *reinterpret_cast<const bf16x8*>(Ws + ((t * CS_KSTEPS + s) * CS_NP + p) * CS_FRAG + lane * 16);
+                    for (int p = 0; p < CS_NP16; ++p)
+                        A[buf][t][p] = *reinterpret_cast<const bf16x8*>(Ws + ((t * CS_KSTEPS + s) * CS_NP16 + p) * CS_FRAG + lane * 16);
             };
             load_a(0, 0);
 #pragma unroll
@@ -275,15 +284,17 @@ __global__ void __launch_bounds__(256, 2) cond_gf_split_bwd_kernel(const CbArgs 
                 const int b = s & 1;
                 if (s + 1 < CS_KSTEPS) load_a(s + 1, b ^ 1);
 #pragma unroll
-                for (int i = 0; i < 6; ++i)
+                for (int i = 0; i < 3; ++i)
 #pragma unroll
                     for (int t = 0; t < CS_CT; ++t)
-                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[b][t][PA[i]], hB[0][s][PB[i]], acc[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, A[b][t][PA[i]]), __builtin_bit_cast(f16x8, hB[0][s][PB[i]]),
+                                                                        acc[t], 0, 0, 0);
             }
+            const float inv = Bs[CS_B_BYTES / 4];                    // 2^-(e + 14)
 #pragma unroll
             for (int t = 0; t < CS_CT; ++t)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) P[4 * (c * CS_CT + t) + r] = acc[t][r];
+                for (int r = 0; r < 4; ++r) P[4 * (c * CS_CT + t) + r] = acc[t][r] * inv;
             if (c + 1 < CS_CPL) landed();
         }
         // ---- the layer's adjoint: P becomes the gradient row
@@ -295,6 +306,19 @@ __global__ void __launch_bounds__(256, 2) cond_gf_split_bwd_kernel(const CbArgs 
 #pragma unroll
             for (int t = 0; t < CS_TILES; ++t) *reinterpret_cast<f32x4*>(dst + 4 * t) = f32x4{P[4 * t], P[4 * t + 1], P[4 * t + 2], P[4 * t + 3]};
         }
+        // the row's scale for this layer: largest gradient entry into [2^14, 2^15); the accumulator goes into the products' units
+        float gmax = 0.f;
+#pragma unroll
+        for (int k = 0; k < CS_SLOTS; ++k) gmax = fmaxf(gmax, fabsf(P[k]));
+        gmax = cs_rmax(gmax);
+        // (exponents clamped to +-60 like W2's: the two together stay inside the f32 exponent range, and an entry 2^-60 below that is noise)
+        const int g_exp = (gmax > 0.f && gmax < INFINITY) ? max(-60, min(60, 14 - ((int)((__builtin_bit_cast(unsigned, gmax) >> 23) & 0xff) - 127))) : 0;
+        const float g_scale = __builtin_bit_cast(float, (unsigned)(127 + g_exp) << 23);
+        {
+            const float up = ldexpf(1.0f, w_exp + g_exp);
+#pragma unroll
+            for (int j = 0; j < CB_JT; ++j) gh[j] *= up;
+        }
         landed();                                                  // k-step 0 of W2_l^T is in buffer 1
         // ---- g_h^T += W2_l^T g_P^T
 #pragma unroll
@@ -302,39 +326,40 @@ __global__ void __launch_bounds__(256, 2) cond_gf_split_bwd_kernel(const CbArgs 
             const int c = CS_CPL + s;
             if (s + 1 < CB_KSTEPS) dma(l, c + 1, (c + 1) & 1);
             else if (l + 1 < a.n_layers) dma(l + 1, 0, 0);
-            const unsigned char* Ws = Ws0 + (c & 1) * CS_CHUNK_BYTES;
-            // the lane's slots 8 s .. 8 s + 7 as three bf16 pieces (split by truncation: exact, 24 = 3 x 8 bits)
+            const unsigned char* Ws = Ws0 + (c & 1) * CB_BUF;
+            // the lane's slots 8 s .. 8 s + 7 as f16 pairs
             using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
-            u32x4 q0, q1, q2;
+            u32x4 q0, q1;
 #pragma unroll
             for (int i = 0; i < 8; i += 2) {
                 const float v0 = 8 * s + i < CS_SLOTS ? P[8 * s + i < CS_SLOTS ? 8 * s + i : 0] : 0.f;
                 const float v1 = 8 * s + i + 1 < CS_SLOTS ? P[8 * s + i + 1 < CS_SLOTS ? 8 * s + i + 1 : 0] : 0.f;
-                const unsigned a0 = __builtin_bit_cast(unsigned, v0), a1 = __builtin_bit_cast(unsigned, v1);
-                const float r0 = v0 - __builtin_bit_cast(float, a0 & 0xffff0000u), r1 = v1 - __builtin_bit_cast(float, a1 & 0xffff0000u);
-                const unsigned c0 = __builtin_bit_cast(unsigned, r0), c1 = __builtin_bit_cast(unsigned, r1);
-                const float s0 = r0 - __builtin_bit_cast(float, c0 & 0xffff0000u), s1 = r1 - __builtin_bit_cast(float, c1 & 0xffff0000u);
-                q0[i >> 1] = __builtin_amdgcn_perm(a1, a0, 0x07060302u);
-                q1[i >> 1] = __builtin_amdgcn_perm(c1, c0, 0x07060302u);
-                q2[i >> 1] = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, s1), __builtin_bit_cast(unsigned, s0), 0x07060302u);
+                unsigned ph, pl;
+                cs_split16(v0 * g_scale, v1 * g_scale, ph, pl);
+                q0[i >> 1] = ph; q1[i >> 1] = pl;
             }
-            const bf16x8 Gb[CS_NP] = {__builtin_bit_cast(bf16x8, q0), __builtin_bit_cast(bf16x8, q1), __builtin_bit_cast(bf16x8, q2)};
+            const f16x8 Gb[CS_NP16] = {__builtin_bit_cast(f16x8, q0), __builtin_bit_cast(f16x8, q1)};
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
-                bf16x8 A[CB_JT / 2][CS_NP];
+                bf16x8 A[CB_JT / 2][CS_NP16];
 #pragma unroll
                 for (int jj = 0; jj < CB_JT / 2; ++jj)
 #pragma unroll
-                    for (int p = 0; p < CS_NP; ++p)
-                        A[jj][p] = *reinterpret_cast<const bf16x8*>(Ws + ((half * (CB_JT / 2) + jj) * CS_NP + p) * CS_FRAG + lane * 16);
+                    for (int p = 0; p < CS_NP16; ++p)
+                        A[jj][p] = *reinterpret_cast<const bf16x8*>(Ws + ((half * (CB_JT / 2) + jj) * CS_NP16 + p) * CS_FRAG + lane * 16);
 #pragma unroll
-                for (int i = 0; i < 6; ++i)
+                for (int i = 0; i < 3; ++i)
 #pragma unroll
                     for (int jj = 0; jj < CB_JT / 2; ++jj)
-                        gh[half * (CB_JT / 2) + jj] =
-                            __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[jj][PA[i]], Gb[PB[i]], gh[half * (CB_JT / 2) + jj], 0, 0, 0);
+                        gh[half * (CB_JT / 2) + jj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, A[jj][PA[i]]), Gb[PB[i]],
+                                                                                             gh[half * (CB_JT / 2) + jj], 0, 0, 0);
             }
             if (s + 1 < CB_KSTEPS || l + 1 < a.n_layers) landed();
+        }
+        {
+            const float down = ldexpf(1.0f, -(w_exp + g_exp));
+#pragma unroll
+            for (int j = 0; j < CB_JT; ++j) gh[j] *= down;
         }
     }
 
@@ -367,9 +392,12 @@ static int cb_pack(const float* W2, int64_t w2s, int32_t H, int32_t D, int32_t n
         o.off_ln = o.off_lw + kd;
         col += o.off_ln + kd;
     }
-    a.W2 = W2; a.w2s = w2s; a.H = H; a.D = D; a.n_layers = n_layers; a.out = static_cast<unsigned char*>(packed);
+    a.W2 = W2; a.w2s = w2s; a.H = H; a.D = D; a.n_layers = n_layers; a.N = col; a.out = static_cast<unsigned char*>(packed);
     const int threads = n_layers * CB_KSTEPS * CB_JT * 64;
-    hipLaunchKernelGGL(cb_pack_kernel, dim3((threads + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(a.out + (size_t)n_layers * CB_KSTEPS * CB_T_BYTES, 0, 16, st) != hipSuccess) return JF_ERR_LAUNCH;
+    hipLaunchKernelGGL(cb_absmax_kernel, dim3((unsigned)(((int64_t)col * H + 255) / 256)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(cb_pack_kernel, dim3((threads + 255) / 256), dim3(256), 0, st, a);
     return hipPeekAtLastError() == hipSuccess ? JF_OK : JF_ERR_LAUNCH;
 }
 
@@ -397,7 +425,7 @@ static int cb_chain(const float* in, int64_t in_stride, const float* W1, int64_t
     a.z = z; a.zs = zs; a.aux = aux; a.B = B; a.D = D; a.n_layers = n_layers;
     a.g_xout = g_xout; a.gxos = gxos; a.g_ld = g_ld; a.g_blp = g_blp; a.g_x = g_x; a.gxs = gxs; a.g_pp = g_pp; a.gpps = gpps;
     a.h_out = h_out; a.hs = hs; a.g_h = g_h; a.ghs = ghs;
-    const size_t lds = 2 * CS_CHUNK_BYTES;
+    const size_t lds = 2 * CB_BUF;                                 // (phase 1's scratch, <= 22.8 KB at K1 = 28, fits buffer 1)
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)cond_gf_split_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -414,7 +442,7 @@ int64_t jf_cond_gf_bwd_packed_bytes(int32_t D, int32_t n_layers, const jf_gf_lay
     if (!layers || n_layers < 1 || n_layers > JF_MAX_CHAIN) return JF_ERR_BADARG;
     for (int l = 0; l < n_layers; ++l)
         if (!jf::cs_layer_supported(layers[l], D)) return JF_ERR_UNSUPPORTED;
-    return (int64_t)n_layers * jf::CB_KSTEPS * jf::CB_T_BYTES;
+    return (int64_t)n_layers * jf::CB_KSTEPS * jf::CB_T_BYTES + 16;
 }
 int jf_cond_gf_bwd_pack_f32(const float* W2, int64_t w2s, int32_t H, int32_t D, int32_t n, const jf_gf_layer* L, void* packed, void* s) {
     return jf::cb_pack(W2, w2s, H, D, n, L, packed, s);

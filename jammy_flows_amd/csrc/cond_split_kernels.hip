@@ -44,8 +44,6 @@ __global__ void __launch_bounds__(256) cs_absmax_kernel(const CsPackArgs a) {
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
     if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned*>(a.out + (size_t)a.n_layers * CS_CPL * CS_CHUNK16_BYTES), __builtin_bit_cast(unsigned, m));
 }
-// power-of-two scale of W2 for the f16 pieces: the largest entry lands in [2^14, 2^15)
-__device__ __forceinline__ int cs_w_exponent(float wmax) { return (wmax > 0.f && wmax < INFINITY) ? 14 - ilogbf(wmax) : 0; }
 
 // one thread per (chunk, tile, k-step, lane): writes the three pieces' fragments (16 bytes each); the first 48 threads of a chunk's
 // first k-step also write the bias

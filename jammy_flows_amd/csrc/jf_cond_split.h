@@ -31,6 +31,13 @@ constexpr float CS_H_SCALE = 16384.0f;
 using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
 using f16x2 = __attribute__((ext_vector_type(2))) _Float16;
 using f32x2 = __attribute__((ext_vector_type(2))) float;
+// power-of-two scale of W2 for the f16 pieces: the largest entry lands in [2^14, 2^15) (exponent clamped: a matrix whose largest entry is
+// below 2^-46 or above 2^74 keeps its pieces inside the f16 range only partly -- not a weight matrix)
+__device__ __forceinline__ int cs_w_exponent(float wmax) {
+    if (!(wmax > 0.f && wmax < INFINITY)) return 0;
+    const int e = 14 - ilogbf(wmax);
+    return e < -60 ? -60 : (e > 60 ? 60 : e);
+}
 template <int NP> struct CsGeom;
 template <> struct CsGeom<3> { static constexpr int W = CS_W_BYTES, B = CS_B_BYTES, CHUNK = CS_CHUNK_BYTES; };
 template <> struct CsGeom<2> { static constexpr int W = CS_W16_BYTES, B = CS_B16_BYTES, CHUNK = CS_CHUNK16_BYTES; };
