@@ -268,8 +268,10 @@ int jf_linear_split_f32(const float* X, int64_t x_stride, const void* packed, co
 // A workgroup (4 waves) owns 128 columns n of g and a range of rows; per step of 32 rows every thread loads one 4 x 4 patch (4 rows x 4
 // columns, 16-byte loads) of g and one of `in`, splits its 16 + 16 values ONCE into bf16 pieces and writes them -- transposed in registers --
 // as 8-byte runs of 4 rows into fragment images in LDS; the waves then read ready-made fragments (ds_read_b128) for 2 x 8 tiles each.
-// Inside a fragment the 16-byte slot of lane (m, q) sits at (m & 3) * 16 + (m >> 2) * 4 + q: the 64 lanes of a patch-write instruction then
-// spread over all banks (row-major m would put them 64 bytes apart: 8-way conflicts).  Partial slabs per row range, added by the caller.
+// Inside a fragment the 16-byte slot of lane (m, q) is the lane's own (16 q + m): the fragment READS (30 per wave and step, 1 KiB each) are then
+// conflict-free; the patch writes (12 KB per wave and step) take 2-way conflicts.  (Round 2 had the slots permuted for conflict-free writes,
+// (m & 3) * 16 + (m >> 2) * 4 + q, which made every fragment read a 4-way conflict: 6.9e7 conflict cycles per launch, the LDS pipe 2.5x
+// longer busy than the matrix pipe.)  Partial slabs per row range, added by the caller.
 // ------------------------------------------------------------------------------------------------------------------------------------------
 namespace jf {
 
@@ -285,7 +287,7 @@ constexpr int WS_NW = 128;                         // columns of g per workgroup
 constexpr int WS_TILES = WS_NW / 16;               // = k-tiles of `in` (K <= 128)
 constexpr int WS_FRAG = SG_FRAG + 16;              // fragment pitch in LDS: the 8 tiles a patch-write instruction touches start 12 banks apart
 
-__device__ __forceinline__ int ws_slot(int m, int q) { return (m & 3) * 16 + (m >> 2) * 4 + q; }
+__device__ __forceinline__ int ws_slot(int m, int q) { return q * 16 + m; }    // = the lane: the 8 lanes a ds_read_b128 serves per cycle read 128 contiguous bytes
 
 __global__ void __launch_bounds__(256, 2) wgrad_split_kernel(const WsArgs a) {
     __shared__ __align__(16) unsigned char Gs[WS_TILES * SG_NP * WS_FRAG];     // 24 KiB: fragments of the g tile
@@ -301,7 +303,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_split_kernel(const WsArgs a) {
     const bool gcol = n0 + 4 * pn < a.N, icol = 4 * pn < a.K;
     const float* gp = a.g + (gcol ? n0 + 4 * pn : 0);
     const float* ip = a.in + (icol ? 4 * pn : 0);
-    const int woff = ((pn >> 2) * SG_NP) * WS_FRAG + ((pn & 3) * 4 + pq) * 16 + phi * 8;        // + jj * 256 (slot: jj * 16 slots) + piece * 1024
+    const int woff = ((pn >> 2) * SG_NP) * WS_FRAG + (pq * 16 + (pn & 3) * 4) * 16 + phi * 8;   // + jj * 16 (slot m = 4 (pn & 3) + jj of lane group pq) + piece * WS_FRAG
     // two patch buffers: the loads of step i + 2 are issued when step i has been written to LDS (one step of MFMAs does not cover an HBM round trip)
     f32x4 gv[2][4], iv[2][4];
     auto load_patch = [&](int step, f32x4 (&gb)[4], f32x4 (&ib)[4]) {
@@ -323,7 +325,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_split_kernel(const WsArgs a) {
             sg_split2(v[0][jj], v[1][jj], a0, a1, a2);
             sg_split2(v[2][jj], v[3][jj], c0, c1, c2);
             const u32x2 p0 = {a0, c0}, p1 = {a1, c1}, p2 = {a2, c2};
-            unsigned char* w = base + woff + jj * 256;
+            unsigned char* w = base + woff + jj * 16;
             *reinterpret_cast<u32x2*>(w) = p0;
             *reinterpret_cast<u32x2*>(w + WS_FRAG) = p1;
             *reinterpret_cast<u32x2*>(w + 2 * WS_FRAG) = p2;
