@@ -432,6 +432,12 @@ def other_direction(args, W, rank, local_rank, world):
                 # the same step (forward, backward, Adam with device-side step counters) captured once in a HIP graph and replayed: what a
                 # training loop with static shapes would run; measured after the timed region, reported beside it
                 try:
+                    # nothing of the eager steps' autograd graphs may stay alive: their AccumulateGrad nodes belong to the default stream
+                    last.clear()
+                    opt.zero_grad(set_to_none=True)
+                    import gc
+                    gc.collect()
+                    torch.cuda.synchronize(dev)
                     gopt = torch.optim.Adam(pdf.parameters(), lr=1e-4, capturable=True)
 
                     def gstep():

@@ -395,7 +395,7 @@ static int cb_pack(const float* W2, int64_t w2s, int32_t H, int32_t D, int32_t n
     a.W2 = W2; a.w2s = w2s; a.H = H; a.D = D; a.n_layers = n_layers; a.N = col; a.out = static_cast<unsigned char*>(packed);
     const int threads = n_layers * CB_KSTEPS * CB_JT * 64;
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(a.out + (size_t)n_layers * CB_KSTEPS * CB_T_BYTES, 0, 16, st) != hipSuccess) return JF_ERR_LAUNCH;
+    hipLaunchKernelGGL(cs_zero16_kernel, dim3(1), dim3(64), 0, st, reinterpret_cast<unsigned*>(a.out + (size_t)n_layers * CB_KSTEPS * CB_T_BYTES));
     hipLaunchKernelGGL(cb_absmax_kernel, dim3((unsigned)(((int64_t)col * H + 255) / 256)), dim3(256), 0, st, a);
     hipLaunchKernelGGL(cb_pack_kernel, dim3((threads + 255) / 256), dim3(256), 0, st, a);
     return hipPeekAtLastError() == hipSuccess ? JF_OK : JF_ERR_LAUNCH;

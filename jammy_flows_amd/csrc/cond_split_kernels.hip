@@ -332,7 +332,7 @@ static int cs_pack(const float* W2, int64_t w2s, const float* b2, int32_t H, int
     const int threads = n_layers * CS_CPL * CS_CT * CS_KSTEPS * 64;
     hipStream_t st = (hipStream_t)stream;
     if (arithmetic == JF_SPLIT_F16X2) {
-        if (hipMemsetAsync(a.out + (size_t)n_layers * CS_CPL * CS_CHUNK16_BYTES, 0, 16, st) != hipSuccess) return JF_ERR_LAUNCH;
+        hipLaunchKernelGGL(cs_zero16_kernel, dim3(1), dim3(64), 0, st, reinterpret_cast<unsigned*>(a.out + (size_t)n_layers * CS_CPL * CS_CHUNK16_BYTES));
         hipLaunchKernelGGL(cs_absmax_kernel, dim3((unsigned)(((int64_t)col * H + 255) / 256)), dim3(256), 0, st, a);
         hipLaunchKernelGGL(cs_pack_kernel<2>, dim3((threads + 255) / 256), dim3(256), 0, st, a);
     } else {

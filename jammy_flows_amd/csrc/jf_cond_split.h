@@ -38,6 +38,9 @@ __device__ __forceinline__ int cs_w_exponent(float wmax) {
     const int e = 14 - ilogbf(wmax);
     return e < -60 ? -60 : (e > 60 ? 60 : e);
 }
+// 16 zero bytes (the tail of a packed image, before the absmax pass): a kernel rather than hipMemsetAsync, whose node made the capture of a
+// training step in a HIP graph crash on ROCm 7.2
+static __global__ void __launch_bounds__(64) cs_zero16_kernel(unsigned* p) { if (threadIdx.x < 4) p[threadIdx.x] = 0u; }
 template <int NP> struct CsGeom;
 template <> struct CsGeom<3> { static constexpr int W = CS_W_BYTES, B = CS_B_BYTES, CHUNK = CS_CHUNK_BYTES; };
 template <> struct CsGeom<2> { static constexpr int W = CS_W16_BYTES, B = CS_B16_BYTES, CHUNK = CS_CHUNK16_BYTES; };
