@@ -268,10 +268,11 @@ int jf_linear_split_f32(const float* X, int64_t x_stride, const void* packed, co
 // A workgroup (4 waves) owns 128 columns n of g and a range of rows; per step of 32 rows every thread loads one 4 x 4 patch (4 rows x 4
 // columns, 16-byte loads) of g and one of `in`, splits its 16 + 16 values ONCE into bf16 pieces and writes them -- transposed in registers --
 // as 8-byte runs of 4 rows into fragment images in LDS; the waves then read ready-made fragments (ds_read_b128) for 2 x 8 tiles each.
-// Inside a fragment the 16-byte slot of lane (m, q) is the lane's own (16 q + m): the fragment READS (30 per wave and step, 1 KiB each) are then
-// conflict-free; the patch writes (12 KB per wave and step) take 2-way conflicts.  (Round 2 had the slots permuted for conflict-free writes,
-// (m & 3) * 16 + (m >> 2) * 4 + q, which made every fragment read a 4-way conflict: 6.9e7 conflict cycles per launch, the LDS pipe 2.5x
-// longer busy than the matrix pipe.)  Partial slabs per row range, added by the caller.
+// Inside a fragment the 16-byte slot of lane (m, q) is the lane's own (16 q + m): the fragment reads (30 per wave and step, 1 KiB each) are
+// conflict-free, the patch writes (12 KB per wave and step) take 2-way conflicts.  (Round 2 had the slots permuted for conflict-free writes,
+// (m & 3) * 16 + (m >> 2) * 4 + q, which makes every fragment read a 4-way conflict -- 6.9e7 conflict cycles per launch in the counters; the
+// kernel time is the same either way, 0.287 ms per 2^18 x 576 x 128: the two barriers per 32-row step and the split arithmetic bound it.)
+// Partial slabs per row range, added by the caller.
 // ------------------------------------------------------------------------------------------------------------------------------------------
 namespace jf {
 
