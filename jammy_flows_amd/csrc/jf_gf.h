@@ -114,18 +114,42 @@ template <typename T> __device__ __forceinline__ Pade<T> pade_terms(const MixQ<T
     const T c = T(2.0 / (3.14159265358979323846 * PADE_A));
     // ln(4 cdf sf) = log1p(-(sf-cdf)^2) in the centre (no cancellation), log-space sum in the tails
     const T dlt = q.sf - q.cdf;
+    Pade<T> p;
+    if constexpr (sizeof(T) == 4) {
+        // float32: hardware sqrt / rcp (1 ulp) and the log1p only for waves that hold a centre lane at all -- the tail branch of the partly
+        // precise inverse (the only caller with rows beyond the bound) never does, and the select below would otherwise evaluate the ~25
+        // instructions of log1pf for every lane.  (Round 3: this stage had grown to half of the flow's vector instructions on inputs whose
+        // waves mix centre and tail rows -- both sides of the region branch run there.)
+        const bool centre = M<T>::min(q.cdf, q.sf) > T(0.01);
+        T ln_fac = q.lc + q.ls + T(1.38629436111989061883);
+        if (__any(centre)) {
+            const T l1p = M<T>::log1p(-dlt * dlt);
+            ln_fac = centre ? l1p : ln_fac;
+        }
+        const T F = ln_fac * T(0.5) + c;
+        const T rad = -ln_fac * T(1.0 / PADE_A);
+        p.F2 = M<T>::sqrt_fast(F * F + rad);
+        p.F2mF = F > T(0) ? rad * M<T>::rcp(p.F2 + F) : p.F2 - F;
+        return p;
+    }
     const T ln_fac = (M<T>::min(q.cdf, q.sf) > T(0.01)) ? M<T>::log1p(-dlt * dlt) : q.lc + q.ls + T(1.38629436111989061883);
     const T F = ln_fac * T(0.5) + c;
     const T rad = -ln_fac / a;
-    Pade<T> p;
     p.F2 = M<T>::sqrt(F * F + rad);
     p.F2mF = F > T(0) ? rad / (p.F2 + F) : p.F2 - F;
     return p;
 }
 template <typename T> __device__ __forceinline__ T pade_value(const Pade<T>& p) {       // sqrt(2 (F2 - F)), clamped at 0 (:517-522)
+    if constexpr (sizeof(T) == 4) return M<T>::sqrt_fast(M<T>::max(T(2) * p.F2mF, T(0)));
     return M<T>::sqrt(M<T>::max(T(2) * p.F2mF, T(0)));
 }
 template <typename T> __device__ __forceinline__ T pade_logderiv(const Pade<T>& p, const MixQ<T>& q) {   // (:597-619) without + log_pdf
+    if constexpr (sizeof(T) == 4) {
+        // v_log_f32 (1 ulp on normal inputs; all three arguments are: F2mF >= 3e-10 outside the pinned centre window, F2 >= sqrt(rad))
+        const T log_num = M<T>::log_fast(p.F2mF + T(1.0 / PADE_A));
+        const T log_den = T(1.03972077083991796413) + T(0.5) * M<T>::log_fast(p.F2mF) + M<T>::log_fast(p.F2);
+        return log_num - log_den - q.ls - q.lc + M<T>::log_fast(M<T>::abs(q.sf - q.cdf));
+    }
     const T log_num = M<T>::log(p.F2mF + T(1.0 / PADE_A));
     const T log_den = T(1.03972077083991796413) + T(0.5) * M<T>::log(p.F2mF) + M<T>::log(p.F2);   // 0.5 ln 8
     return log_num - log_den - q.ls - q.lc + M<T>::log(M<T>::abs(q.sf - q.cdf));
@@ -182,8 +206,13 @@ template <typename T> __device__ __forceinline__ T gf_inverse_cdf(int inv_type, 
     T tot;
     if (inv_type == JF_GF_INORMAL_PARTLY_CRUDE) {
         const T lsum = q.lc + q.ls;
-        tot = M<T>::sqrt(T(-2) * lsum) - T(0.4717);
-        logd = T(-0.5) * M<T>::log(T(-2) * lsum) - lsum + q.lp;
+        if constexpr (sizeof(T) == 4) {
+            tot = M<T>::sqrt_fast(T(-2) * lsum) - T(0.4717);
+            logd = T(-0.5) * M<T>::log_fast(T(-2) * lsum) - lsum + q.lp;
+        } else {
+            tot = M<T>::sqrt(T(-2) * lsum) - T(0.4717);
+            logd = T(-0.5) * M<T>::log(T(-2) * lsum) - lsum + q.lp;
+        }
     } else {
         const Pade<T> p = pade_terms(q);
         tot = pade_value(p);
