@@ -55,6 +55,14 @@ template <typename T> __device__ __forceinline__ Dual<T> azimuth(Dual<T> x, Dual
     const T r2 = x.v * x.v + y.v * y.v;
     return Dual<T>(azimuth<T>(x.v, y.v), r2 > T(0) ? (x.v * y.d - y.v * x.d) / r2 : T(0));
 }
+template <typename T, int N> __device__ __forceinline__ DualN<T, N> azimuth(DualN<T, N> x, DualN<T, N> y) {
+    const T r2 = x.v * x.v + y.v * y.v;
+    DualN<T, N> r;
+    r.v = azimuth<T>(x.v, y.v);
+#pragma unroll
+    for (int c = 0; c < N; ++c) r.d[c] = r2 > T(0) ? (x.v * y.d[c] - y.v * x.d[c]) / r2 : T(0);
+    return r;
+}
 
 // ---- S1 <-> embedding
 template <typename T> __device__ __forceinline__ void s1_to_eucl(T phi, T (&e)[3]) { e[0] = M<T>::cos(phi); e[1] = M<T>::sin(phi); }

@@ -46,9 +46,10 @@ template <typename T> __device__ __forceinline__ T wave_sum(T v) {
     return v;
 }
 
-template <typename T, class Fam>
+// N: input directions per pass (DualN<T, N>, jf_dual.h): the value part of the chain is evaluated once per pass
+template <typename T, class Fam, int N>
 __global__ void __launch_bounds__(64) mchain_bwd_kernel(const MBwdArgs<T, typename Fam::CLayer> a) {
-    using Du = Dual<T>;
+    using Du = DualN<T, N>;
     extern __shared__ __align__(16) unsigned char smem_raw[];
     Du* tile = reinterpret_cast<Du*>(smem_raw);
     const int tid = threadIdx.x;
@@ -63,7 +64,7 @@ __global__ void __launch_bounds__(64) mchain_bwd_kernel(const MBwdArgs<T, typena
     const bool active = lane_in && row < a.B;
     const int64_t rrow = active ? row : a.B - 1;
 
-    // parameters of all layers -> dual rows (tangent 0)
+    // parameters of all layers -> dual rows (tangents 0)
     if (a.bcast) {
         for (int j = tid; j < a.P; j += 64) tile[j] = Du(a.params[j]);
     } else {
@@ -86,16 +87,24 @@ __global__ void __launch_bounds__(64) mchain_bwd_kernel(const MBwdArgs<T, typena
 
     bool bad = false;
     const int n_dir = a.dim + a.P;
-    for (int j = 0; j < n_dir; ++j) {
-        // ---- seed direction j
-        if (j >= a.dim) {
-            if (a.bcast) { if (tid == 0) prow[j - a.dim].d = T(1); }
-            else if (lane_in) prow[j - a.dim].d = T(1);
+    for (int j0 = 0; j0 < n_dir; j0 += N) {
+        // ---- seed directions j0 .. j0 + N - 1 (tangent c = direction j0 + c)
+#pragma unroll
+        for (int c = 0; c < N; ++c) {
+            const int j = j0 + c;
+            if (j >= a.dim && j < n_dir) {
+                if (a.bcast) { if (tid == 0) prow[j - a.dim].d[c] = T(1); }
+                else if (lane_in) prow[j - a.dim].d[c] = T(1);
+            }
         }
         __syncthreads();
         Du x[3];
 #pragma unroll
-        for (int d = 0; d < 3; ++d) x[d] = Du(x0[d], (d == j) ? T(1) : T(0));
+        for (int d = 0; d < 3; ++d) {
+            x[d] = Du(x0[d]);
+#pragma unroll
+            for (int c = 0; c < N; ++c) if (d == j0 + c) x[d].d[c] = T(1);
+        }
         Du ld(T(0));
         LaneCtx<Du> ctx;
         ctx.tab = tab; ctx.corr = corr; ctx.bins = nullptr; ctx.bin_i = 0;
@@ -105,24 +114,33 @@ __global__ void __launch_bounds__(64) mchain_bwd_kernel(const MBwdArgs<T, typena
             const int l = a.n_layers - 1 - i;
             if (lane_in) Fam::template apply<Du, false>(a.L[l], prow + a.col0[l], x, ld, ctx);
         }
-        T gj = gld * ld.d;
 #pragma unroll
-        for (int d = 0; d < Fam::DIM; ++d) if (d < a.dim) gj += (gxo[d] - x[d].v * gblp) * x[d].d;
-        if (!active) gj = T(0);
-        bad = bad || !M<T>::finite(gj);
-        if (j < a.dim) {
-            if (active) a.g_x[row * a.gxs + j] = gj;
-        } else if (a.bcast) {
-            const T s = wave_sum<T>(gj);
-            if (tid == 0) atomicAdd(a.g_params + (j - a.dim), s);
-        } else if (active) {
-            a.g_params[row * a.gps + (j - a.dim)] = gj;
+        for (int c = 0; c < N; ++c) {
+            const int j = j0 + c;
+            if (j >= n_dir) break;
+            T gj = gld * ld.d[c];
+#pragma unroll
+            for (int d = 0; d < Fam::DIM; ++d) if (d < a.dim) gj += (gxo[d] - x[d].v * gblp) * x[d].d[c];
+            if (!active) gj = T(0);
+            bad = bad || !M<T>::finite(gj);
+            if (j < a.dim) {
+                if (active) a.g_x[row * a.gxs + j] = gj;
+            } else if (a.bcast) {
+                const T s = wave_sum<T>(gj);
+                if (tid == 0) atomicAdd(a.g_params + (j - a.dim), s);
+            } else if (active) {
+                a.g_params[row * a.gps + (j - a.dim)] = gj;
+            }
         }
         __syncthreads();
         // ---- unseed
-        if (j >= a.dim) {
-            if (a.bcast) { if (tid == 0) prow[j - a.dim].d = T(0); }
-            else if (lane_in) prow[j - a.dim].d = T(0);
+#pragma unroll
+        for (int c = 0; c < N; ++c) {
+            const int j = j0 + c;
+            if (j >= a.dim && j < n_dir) {
+                if (a.bcast) { if (tid == 0) prow[j - a.dim].d[c] = T(0); }
+                else if (lane_in) prow[j - a.dim].d[c] = T(0);
+            }
         }
     }
     status_add(a.status, JF_STATUS_NONFINITE, active && bad);
@@ -362,12 +380,20 @@ static int mchain_bwd(const T* x, int64_t xs, const T* params, int64_t ps, int32
     for (int l = 0; l < n_layers; ++l) if (Fam::needs_tab(layers[l])) a.tab = JF_SPLINE_TAB;
     a.rows = 64;
     size_t lds = 0;
+    // generic kernel: four directions per pass when a full wave of rows still fits the LDS with the wider dual rows, else one
+    constexpr int NW = std::is_same<Fam, FFam>::value && sizeof(T) == 4 ? 6 : 4;    // 'f' float32 (2 + 10 directions by default): two passes
+    bool wide = false;
+    if (!staged) {
+        const size_t lds4 = ((size_t)(a.bcast ? 1 : 64) * a.tile_stride + (size_t)64 * (a.tab + a.scratch)) * sizeof(DualN<T, NW>);
+        wide = lds4 <= 64 * 1024;                                  // (also leaves room for two workgroups per CU)
+    }
     for (;;) {
+        if (wide) { lds = ((size_t)(a.bcast ? 1 : a.rows) * a.tile_stride + (size_t)a.rows * (a.tab + a.scratch)) * sizeof(DualN<T, NW>); break; }
         if (staged) {                                              // plain-value parameter tile + per lane: knot table, rotation row (duals), scratch (values)
             const size_t tile_elems = (((size_t)(a.bcast ? 1 : a.rows) * a.tile_stride) + 1) & ~(size_t)1;
             lds = tile_elems * sizeof(T) + (size_t)a.rows * ((size_t)(a.tab + a.rot_max) * sizeof(Dual<T>) + (size_t)a.scratch * sizeof(T));
         } else
-        lds = ((size_t)(a.bcast ? 1 : a.rows) * a.tile_stride + (size_t)a.rows * (a.tab + a.scratch)) * sizeof(Dual<T>);
+        lds = ((size_t)(a.bcast ? 1 : a.rows) * a.tile_stride + (size_t)a.rows * (a.tab + a.scratch)) * sizeof(DualN<T, 1>);
         if (lds <= 160 * 1024 || a.rows == 4) break;
         a.rows >>= 1;
     }
@@ -380,7 +406,13 @@ static int mchain_bwd(const T* x, int64_t xs, const T* params, int64_t ps, int32
             return check_launch();
         }
     }
-    auto k = mchain_bwd_kernel<T, Fam>;
+    if (wide) {
+        auto k4 = mchain_bwd_kernel<T, Fam, NW>;
+        if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k4, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k4, dim3((unsigned)((B + a.rows - 1) / a.rows)), dim3(64), lds, (hipStream_t)stream, a);
+        return check_launch();
+    }
+    auto k = mchain_bwd_kernel<T, Fam, 1>;
     if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k, dim3((unsigned)((B + a.rows - 1) / a.rows)), dim3(64), lds, (hipStream_t)stream, a);
     return check_launch();
