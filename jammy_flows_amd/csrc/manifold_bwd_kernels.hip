@@ -245,26 +245,42 @@ __global__ void __launch_bounds__(64) vchain_bwd_kernel(const MBwdArgs<T, jf_v_l
                 VFam::template inv_pre<T>(L, pv, x, ld, e0);
                 v_potential<T>(ppv, nc, kind, e0, P0, reinterpret_cast<T*>(tab), oob);
             }
-            // (1) the expensive stages on the 15 directions of (e, g, gj):  G[i] = d S / d u_i
+            // (1) the expensive stages on the 15 directions of (e, g, gj):  G[i] = d S / d u_i, NG directions per pass (DualN: the geometry's
+            //     value part -- square roots, trigonometric functions, the 3 x 3 determinant -- once per pass)
+            constexpr int NG = 3;
+            using DG = DualN<T, NG>;
 #pragma unroll 1
-            for (int i = 0; i < 15; ++i) {
-                Du e[3];
-                VPotential<Du> P;
+            for (int i0 = 0; i0 < 15; i0 += NG) {
+                DG e[3];
+                VPotential<DG> P;
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
-                    e[c] = Du(e0[c], i == c ? T(1) : T(0));
-                    P.g[c] = Du(P0.g[c], i == 3 + c ? T(1) : T(0));
+                    e[c] = DG(e0[c]);
+                    P.g[c] = DG(P0.g[c]);
 #pragma unroll
-                    for (int d = 0; d < 3; ++d) P.gj[c][d] = Du(P0.gj[c][d], i == 6 + 3 * c + d ? T(1) : T(0));
+                    for (int d = 0; d < 3; ++d) P.gj[c][d] = DG(P0.gj[c][d]);
                 }
-                ExpMapOut<Du> o;
-                Du x[3], ld(T(0));
+#pragma unroll
+                for (int t = 0; t < NG; ++t) {
+                    const int i = i0 + t;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        if (i == c) e[c].d[t] = T(1);
+                        if (i == 3 + c) P.g[c].d[t] = T(1);
+#pragma unroll
+                        for (int d = 0; d < 3; ++d) if (i == 6 + 3 * c + d) P.gj[c][d].d[t] = T(1);
+                    }
+                }
+                ExpMapOut<DG> o;
+                DG x[3], ld(T(0));
                 if (lane_in) {
-                    v_exp_geometry<Du>(kind, e, P, o);
+                    v_exp_geometry<DG>(kind, e, P, o);
                     ld = ld + o.logdet_half;
-                    VFam::template inv_post<Du>(L, o.y, x, ld);
+                    VFam::template inv_post<DG>(L, o.y, x, ld);
                 }
-                if (lane_in) G[i] = up[0] * x[0].d + up[1] * x[1].d + gld * ld.d;
+#pragma unroll
+                for (int t = 0; t < NG; ++t)
+                    if (lane_in) G[i0 + t] = up[0] * x[0].d[t] + up[1] * x[1].d[t] + gld * ld.d[t];
             }
             // (2) the cheap stages, contracted with G.  Directions that move e (the layer's input, the rotation parameters) need the whole
             //     potential on dual numbers; a potential parameter belongs to ONE component, whose term alone carries a tangent -- except the
