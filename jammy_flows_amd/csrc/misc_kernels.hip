@@ -10,28 +10,37 @@ namespace jf {
 
 struct CondSegs { int n; jf_cond_segment s[JF_MAX_SEGMENTS]; };
 
-// one thread per OUTPUT element (coalesced stores; a thread-per-row version wrote 24 strided doubles per thread and ran at 0.3 TB/s)
+// one thread per OUTPUT element (coalesced stores; a thread-per-row version wrote 24 strided doubles per thread and ran at 0.3 TB/s).  A
+// workgroup owns 256 whole rows and walks their 256 W elements with 32-bit index arithmetic (round 2 divided a 64-bit global element index by
+// W per thread: ~60 vector instructions, 90 % VALU busy for a copy kernel).
 template <typename T>
 __global__ void __launch_bounds__(256) conditioning_kernel(const CondSegs a, int64_t B, int W, T* __restrict__ out, int64_t os) {
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= B * W) return;
-    const int64_t row = idx / W;
-    int col = (int)(idx - row * W);
-    const int out_col = col;
-    T val = T(0);
-    for (int i = 0; i < a.n; ++i) {
-        const jf_cond_segment g = a.s[i];
-        const int w = g.kind == 0 ? g.n_in : g.kind + 1;
-        if (col < w) {
-            const T* r = static_cast<const T*>(g.src) + row * g.stride;
-            if (g.kind == 0) val = r[col];
-            else if (g.kind == 1) { T e[3]; s1_to_eucl<T>(r[0], e); val = e[col]; }
-            else { T e[3], ld = T(0); s2_to_eucl<T>(r[0], r[1], e, ld); val = e[col]; }
-            break;
+    const int64_t row0 = (int64_t)blockIdx.x * 256;
+    const unsigned n_rows = (unsigned)(B - row0 < 256 ? B - row0 : 256);
+    const unsigned n = n_rows * (unsigned)W;
+    for (unsigned e = threadIdx.x; e < n; e += 256) {
+        const unsigned rl = e / (unsigned)W;
+        int col = (int)(e - rl * (unsigned)W);
+        const int out_col = col;
+        const int64_t row = row0 + rl;
+        T val = T(0);
+        for (int i = 0; i < a.n; ++i) {
+            const jf_cond_segment g = a.s[i];
+            const int w = g.kind == 0 ? g.n_in : g.kind + 1;
+            if (col < w) {
+                const T* r = static_cast<const T*>(g.src) + row * g.stride;
+                if (g.kind == 0) val = r[col];
+                // only the column's own factors of s1_to_eucl / s2_to_eucl (same operations, same values): the dynamic e[col] made every
+                // thread evaluate all four trigonometric functions of the row for one of them
+                else if (g.kind == 1) val = col == 0 ? M<T>::cos(r[0]) : M<T>::sin(r[0]);
+                else if (col == 2) val = M<T>::cos(safe_angle_pi(r[0]));
+                else val = M<T>::sin(safe_angle_pi(r[0])) * (col == 0 ? M<T>::cos(r[1]) : M<T>::sin(r[1]));
+                break;
+            }
+            col -= w;
         }
-        col -= w;
+        out[row * os + out_col] = val;
     }
-    out[row * os + out_col] = val;
 }
 
 template <typename T> static int conditioning_rows(const jf_cond_segment* segs, int32_t n, int64_t B, T* out, int64_t os, void* stream) {
@@ -46,7 +55,7 @@ template <typename T> static int conditioning_rows(const jf_cond_segment* segs, 
     int W = 0;
     for (int i = 0; i < n; ++i) W += segs[i].kind == 0 ? segs[i].n_in : segs[i].kind + 1;
     if (W == 0) return JF_OK;
-    hipLaunchKernelGGL(conditioning_kernel<T>, dim3((unsigned)((B * W + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, B, W, out, os);
+    hipLaunchKernelGGL(conditioning_kernel<T>, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, B, W, out, os);
     return check_launch();
 }
 
