@@ -170,6 +170,58 @@ template <typename T> __device__ __forceinline__ MixQ<T> cs_mixture_derived(cons
     return q;
 }
 
+// log cdf and log sf only (no pdf, no third logarithm): what the bisection stage of cs_solve compares -- cs_mixture_derived without the density
+template <typename T> __device__ __forceinline__ void cs_mixture_lcls(const T (&P)[CS_SLOTS], T x, T& lc, T& ls) {
+    using Mf = M<T>;
+    T C = T(0), S = T(0);
+#pragma unroll
+    for (int k = 0; k < CS_K; ++k) {
+        const T wk = P[CS_SLOT_LN + k];
+        const T u = (x - P[CS_SLOT_MEAN + k]) * P[CS_SLOT_LW + k];
+        const T t = Mf::exp_fast(-Mf::abs(u));
+        const T hi = Mf::rcp(T(1) + t);
+        const T lo = t * hi;
+        const bool pos = u >= T(0);
+        C += wk * (pos ? hi : lo);
+        S += wk * (pos ? lo : hi);
+    }
+    lc = Mf::log_fast(C); ls = Mf::log_fast(S);
+    const bool under = !(C > Mf::TINY && S > Mf::TINY);
+    if (__any(under)) {                                            // wave-uniform: sums scaled by e^{m}, m = distance to the nearest component
+        T m = T(INFINITY);
+#pragma unroll
+        for (int k = 0; k < CS_K; ++k) m = Mf::min(m, Mf::abs((x - P[CS_SLOT_MEAN + k]) * P[CS_SLOT_LW + k]));
+        const T em = Mf::exp_fast(-m);
+        T Cu = T(0), Cs = T(0), Su = T(0), Ss = T(0);
+#pragma unroll
+        for (int k = 0; k < CS_K; ++k) {
+            const T wk = P[CS_SLOT_LN + k];
+            const T u = (x - P[CS_SLOT_MEAN + k]) * P[CS_SLOT_LW + k];
+            const T t = Mf::exp_fast(m - Mf::abs(u));
+            const T hi = Mf::rcp(T(1) + t * em);
+            const T c1 = wk * hi, c2 = c1 * t;
+            if (u >= T(0)) { Cu += c1; Ss += c2; }
+            else { Su += c1; Cs += c2; }
+        }
+        if (under) {
+            lc = Cu > T(0) ? Mf::log_fast(Cu + em * Cs) : Mf::log_fast(Cs) - m;
+            ls = Su > T(0) ? Mf::log_fast(Su + em * Ss) : Mf::log_fast(Ss) - m;
+        }
+    }
+}
+
+// log Phi(-a), a >= 0: the bisection target in log space (erfc until it would underflow, then the asymptotic series; the bisection only
+// needs a bracket of 6e-3 in x, the Newton stage then solves the layer's own inverse-CDF equation)
+template <typename T> __device__ __forceinline__ T cs_log_ndtr_neg(T a) {
+    using Mf = M<T>;
+    T near;
+    if constexpr (sizeof(T) == 4) near = Mf::log(0.5f * erfcf(fminf(a, 12.0f) * 0.70710678118654752440f));
+    else near = Mf::log(0.5 * ::erfc(::fmin(a, 36.0) * 0.70710678118654752440));
+    const T a2 = Mf::max(a * a, T(1));
+    const T far = T(-0.5) * a * a - Mf::log(Mf::max(a, T(1))) - Mf::HALF_LN_2PI + Mf::log1p((T(3) / a2 - T(1)) / a2);
+    return a < (sizeof(T) == 4 ? T(12) : T(36)) ? near : far;
+}
+
 // x with stage(mixture(x)) = z: gfg_solve's decisions step for step (far-midpoint skip, stopping rules, status counters); RSUM / RMAX reduce
 // over the lanes that hold the coordinates of one row.  P: DERIVED row (mean, 1 / width, normalised weight per component).
 template <typename T, typename RSUM, typename RMAX>
@@ -186,11 +238,24 @@ __device__ __forceinline__ T cs_solve(const T (&P)[CS_SLOTS], int inv_type, bool
         hi_b = Mf::max(hi_b, mu + FAR * w);
     }
     const bool can_skip = Mf::abs(z) < T(8);
+    const bool proxy = inv_type != JF_GF_ISIGMOID;                 // normal-type stages: bisect on the mixture's log cdf / log sf (uniform)
+    const T tz = proxy ? cs_log_ndtr_neg<T>(Mf::abs(z)) : T(0);
     for (int it = 0; it < 25; ++it) {
         x = (hi + lo) * T(0.5);
         const bool far_r = can_skip && x > hi_b, far_l = can_skip && x < lo_b;
         if (__all(far_r || far_l)) {                               // wave-uniform
             if (far_r) hi = x; else lo = x;
+            continue;
+        }
+        if (proxy) {
+            // y(x) < z  <=>  cdf(x) < Phi(z): compared in log space on the side that does not cancel.  The inverse-CDF stage, the density and
+            // its logarithm (a third of an evaluation) are not needed to halve the bracket; the reference's early freeze of a midpoint that
+            // happens to sit within 1e-6 |z| of the root (bisection_n_newton.py:40-60) is skipped -- the Newton stage starts from the
+            // 6e-3-wide bracket either way.
+            T lc, ls;
+            cs_mixture_lcls<T>(P, x, lc, ls);
+            const bool below = z <= T(0) ? lc < tz : ls > tz;
+            if (below) lo = x; else hi = x;
             continue;
         }
         const T y = gf_icdf<T>(inv_type, cs_mixture_derived<T>(P, x)).y;
@@ -205,7 +270,9 @@ __device__ __forceinline__ T cs_solve(const T (&P)[CS_SLOTS], int inv_type, bool
     for (int it = 0; it < 20 && __any(active); ++it) {
         const IcdfOut<T> s = gf_icdf<T>(inv_type, cs_mixture_derived<T>(P, x));
         const T f = s.y - z;
-        const T upd = f / Mf::exp(s.logd);
+        T upd;
+        if constexpr (sizeof(T) == 4) upd = f * Mf::exp_fast(-s.logd);      // (v_exp_f32: the step's relative error ~1e-6 does not move a Newton iterate's limit)
+        else upd = f / Mf::exp(s.logd);
         const T usum = rsum(live ? Mf::abs(upd) : T(0));
         status_add(status, JF_STATUS_NEWTON_STEPS, active && leader);
         if (active) {
