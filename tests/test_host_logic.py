@@ -267,3 +267,31 @@ def test_shipped_library_has_no_packed_f32_instructions(tmp_path):
         assert not hits, "code object %d of libjammy_hip.so contains %d packed-f32 instructions" % (i, len(hits))
         mfma += len(re.findall(rb"\bv_mfma_f32_16x16x32_bf16\b", asm))
     assert mfma > 0, "the disassembly did not see the fused block's bf16 MFMAs: wrong code objects?"
+
+
+def test_packed_gradient_rows_index_every_parameter_column_once():
+    """host side of the one-launch block adjoint: cond_gf_packed_rows maps the natural column order of a g block's parameter row (offset,
+    Householder vectors, means, log-widths, log-weights: gaussianization_flow.py:63-215) into the packed rows [layer][coordinate][slot] the
+    kernel writes (csrc/jf_cond_regs.h) -- one packed column per parameter, the rest of the 144 per layer padding"""
+    from jammy_flows_amd import _hip
+    import jammy_flows_amd
+    pdf = jammy_flows_amd.pdf("e4+e4", "gggg+gggg")
+    for layers in (list(pdf.layer_list[1]), list(pdf.layer_list[1])[:2]):
+        D = layers[0].dimension
+        arr = _hip.gf_layer_array([l.c_struct() for l in layers])
+        idx = _hip.cond_gf_packed_rows(arr, len(layers), D)
+        n_params = sum(l.total_param_num for l in layers)
+        assert len(idx) == n_params and len(set(idx)) == n_params
+        assert min(idx) >= 0 and max(idx) < len(layers) * 4 * _hip.COND_GF_SLOTS
+        col = 0
+        for li, l in enumerate(layers):
+            c = l.c_struct()
+            base = li * 4 * _hip.COND_GF_SLOTS
+            if c.model_offset:
+                assert idx[col:col + D] == [base + d * _hip.COND_GF_SLOTS + 34 for d in range(D)]      # slot 34: offset
+                col += D
+            col += c.hh_iter * D
+            first_mean = idx[col:col + D]
+            assert first_mean == [base + d * _hip.COND_GF_SLOTS + 0 for d in range(D)]               # slot 0: mean of component 0
+            col += 3 * c.num_kde * D
+        assert col == n_params
