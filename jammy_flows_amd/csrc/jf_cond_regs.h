@@ -240,6 +240,17 @@ __device__ __forceinline__ T cs_solve(const T (&P)[CS_SLOTS], int inv_type, bool
     const bool can_skip = Mf::abs(z) < T(8);
     const bool proxy = inv_type != JF_GF_ISIGMOID;                 // normal-type stages: bisect on the mixture's log cdf / log sf (uniform)
     const T tz = proxy ? cs_log_ndtr_neg<T>(Mf::abs(z)) : T(0);
+    // float64: the bracket phase evaluates the mixture in FLOAT32 (a float copy of the derived row): the comparison only has to order
+    // cdf(x) and Phi(z) to the 6e-3 resolution of the bracket, a float64 mixture costs ~4x the instructions, and the Newton phase -- which
+    // fixes the result -- stays in float64
+    float Pf[sizeof(T) == 8 ? CS_SLOTS : 1];
+    if constexpr (sizeof(T) == 8) {
+#pragma unroll
+        for (int k = 0; k < 3 * CS_K; ++k) Pf[k] = (float)P[k];
+#pragma unroll
+        for (int k = 3 * CS_K; k < CS_SLOTS; ++k) Pf[k] = 0.f;
+    }
+    const float tzf = (float)tz;
     for (int it = 0; it < 25; ++it) {
         x = (hi + lo) * T(0.5);
         const bool far_r = can_skip && x > hi_b, far_l = can_skip && x < lo_b;
@@ -252,9 +263,16 @@ __device__ __forceinline__ T cs_solve(const T (&P)[CS_SLOTS], int inv_type, bool
             // its logarithm (a third of an evaluation) are not needed to halve the bracket; the reference's early freeze of a midpoint that
             // happens to sit within 1e-6 |z| of the root (bisection_n_newton.py:40-60) is skipped -- the Newton stage starts from the
             // 6e-3-wide bracket either way.
-            T lc, ls;
-            cs_mixture_lcls<T>(P, x, lc, ls);
-            const bool below = z <= T(0) ? lc < tz : ls > tz;
+            bool below;
+            if constexpr (sizeof(T) == 8) {
+                float lc, ls;
+                cs_mixture_lcls<float>(Pf, (float)x, lc, ls);
+                below = z <= T(0) ? lc < tzf : ls > tzf;
+            } else {
+                T lc, ls;
+                cs_mixture_lcls<T>(P, x, lc, ls);
+                below = z <= T(0) ? lc < tz : ls > tz;
+            }
             if (below) lo = x; else hi = x;
             continue;
         }
