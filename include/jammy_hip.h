@@ -241,6 +241,13 @@ int jf_amlp_gf_chain_inv_f64(const double* in, int64_t in_stride, const double* 
                              const double* log_det_in, int64_t B, int32_t D, int32_t n_layers, const jf_gf_layer* layers, double* x_out,
                              int64_t x_out_stride, double* log_det_out, const double* base_logp_in, double* base_logp_out, int32_t* status,
                              void* stream);
+/* The SAMPLING direction of the same block in one launch (float64, both ranks <= 8, H % 16 == 0: the matrix-core variant; otherwise
+ * JF_ERR_UNSUPPORTED and the caller runs jf_amlp2 + jf_gf_chain_fwd): the (B, N) parameter block is never materialised, every layer's
+ * bisection / Newton solves read register-resident derived rows.  z: base points (B, D); status as jf_gf_chain_fwd. */
+int jf_amlp_gf_chain_fwd_f64(const double* in, int64_t in_stride, const double* V1, const double* U1, const double* b1, const double* V2,
+                             const double* U2, const double* b2, int32_t K1, int32_t H, int32_t r1, int32_t r2, const double* z, int64_t z_stride,
+                             const double* log_det_in, int64_t B, int32_t D, int32_t n_layers, const jf_gf_layer* layers, double* x_out,
+                             int64_t x_out_stride, double* log_det_out, int32_t* status, void* stream);
 
 /* The same two-stage low-rank AmortizableMLP alone, ONE launch instead of four dense launches:
  * out (B, N) = U2 (V2 tanh(W1 in + b1)) + b2 (same operand conventions and limits as jf_amlp_gf_chain_inv). */

@@ -160,6 +160,8 @@ _SIGNATURES_SINGLE = {
     "jf_cond_gf_chain_inv_pp_f32": ([_P, _I64, _P, _I64, _P, _P, _I32, _I32, _P, _I64, _P, _I64, _I32, _I32, ctypes.POINTER(jf_gf_layer), _P, _I64,
                                      _P, _P, _P, _P, _P], ctypes.c_int),
     "jf_cond_gf_pack_f32": ([_P, _I64, _P, _I32, _I32, _I32, ctypes.POINTER(jf_gf_layer), _P, _P], ctypes.c_int),
+    "jf_amlp_gf_chain_fwd_f64": ([_P, _I64, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P, _I64, _P, _I64, _I32, _I32, ctypes.POINTER(jf_gf_layer),
+                                  _P, _I64, _P, _P, _P], ctypes.c_int),
     "jf_cond_gf_packed_bytes2": ([_I32, _I32, ctypes.POINTER(jf_gf_layer), _I32], ctypes.c_int64),
     "jf_cond_gf_pack2_f32": ([_P, _I64, _P, _I32, _I32, _I32, ctypes.POINTER(jf_gf_layer), _I32, _P, _P], ctypes.c_int),
     "jf_cond_gf_chain_split2_f32": ([_I32, _I32, _P, _I64, _P, _I64, _P, _P, _I32, _I32, _P, _I64, _P, _I64, _I32, _I32, ctypes.POINTER(jf_gf_layer),
@@ -483,6 +485,31 @@ def amlp_gf_chain_inv(inp, v1, u1, b1, v2, u2, b2, x, log_det, layer_array, n_la
              _ptr(log_det), B, D, n_layers, layer_array, _ptr(x_out), x_out.stride(0), _ptr(ld_out), _ptr(base_logp_in), _ptr(blp_out), _ptr(status)),
             dev)
     return (x_out, ld_out, blp_out) if want_base_logp else (x_out, ld_out)
+
+
+def amlp_gf_chain_fwd(inp, v1, u1, b1, v2, u2, b2, z, log_det, layer_array, n_layers, D, x_out=None, status=None):
+    """sampling direction of the low-rank block in one launch (float64, ranks <= 8: jf_amlp_gf_chain_fwd_f64) -> (x, log_det), or None when
+    the configuration is outside the matrix-core kernel's set (the caller then runs amlp2 + gf_chain)"""
+    dev = require_device(inp, v1, u1, b1, v2, u2, b2, z, log_det, x_out, status)
+    if z.dtype != torch.float64:
+        return None
+    inp, z = _rowmajor(inp), _rowmajor(z)
+    B, K1 = inp.shape
+    H, r2 = v2.shape[1], v2.shape[0]
+    r1 = 0 if v1 is None else v1.shape[0]
+    ws = [t.contiguous() for t in (u1, b1, v2, u2, b2)]
+    v1c = None if v1 is None else v1.contiguous()
+    if any(t.dtype != z.dtype for t in ws + [inp]) or z.shape != (B, D) or u2.shape[1] != r2 or b2.shape[0] != u2.shape[0]:
+        raise ValueError("amlp_gf_chain_fwd: inconsistent shapes / dtypes")
+    if log_det is not None:
+        log_det = log_det.contiguous()
+    if x_out is None:
+        x_out = torch.empty((B, D), dtype=z.dtype, device=z.device)
+    ld_out = torch.empty((B,), dtype=z.dtype, device=z.device)
+    ok = _launch("jf_amlp_gf_chain_fwd_f64", "K%d_H%d_N%d_D%d_r%d" % (K1, H, u2.shape[0], D, r2),
+                 (_ptr(inp), inp.stride(0), _ptr(v1c), _ptr(ws[0]), _ptr(ws[1]), _ptr(ws[2]), _ptr(ws[3]), _ptr(ws[4]), K1, H, r1, r2, _ptr(z), z.stride(0),
+                  _ptr(log_det), B, D, n_layers, layer_array, _ptr(x_out), x_out.stride(0), _ptr(ld_out), _ptr(status)), dev, unsupported_ok=True)
+    return (x_out, ld_out) if ok else None
 
 
 def amlp2(inp, v1, u1, b1, v2, u2, b2):

@@ -303,7 +303,7 @@ static int amlp2(const T* in, int64_t in_stride, const T* V1, const T* U1, const
     return ag_launch<T>(a, 8, (hipStream_t)stream);
 }
 
-template <typename T>
+template <typename T, bool FWD = false>
 static int amlp_gf_chain_inv(const T* in, int64_t in_stride, const T* V1, const T* U1, const T* b1, const T* V2, const T* U2, const T* b2, int32_t K1,
                              int32_t H, int32_t r1, int32_t r2, const T* x, int64_t xs, const T* ld_in, int64_t B, int32_t D, int32_t n_layers,
                              const jf_gf_layer* layers, T* x_out, int64_t xos, T* ld_out, const T* blp_in, T* blp_out, int32_t* status, void* stream) {
@@ -338,13 +338,14 @@ static int amlp_gf_chain_inv(const T* in, int64_t in_stride, const T* V1, const 
         // traffic; everything else (float32, larger ranks, odd hidden widths) stays on amlp_gf_kernel
         const size_t lds = am_lds_doubles(K1, H, V1 != nullptr, n_layers) * sizeof(T);
         if (r2 <= AM_R && (!V1 || r1 <= AM_R) && H % 16 == 0 && lds <= 160 * 1024) {
-            auto k = amlp_gf_mfma_kernel<AgArgs<T>>;
+            auto k = amlp_gf_mfma_kernel<AgArgs<T>, FWD>;
             if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             hipLaunchKernelGGL(k, dim3((unsigned)((B + AM_ROWS - 1) / AM_ROWS)), dim3(AM_THREADS), lds, (hipStream_t)stream, a);
             return check_launch();
         }
     }
-    return ag_launch<T>(a, D, (hipStream_t)stream);
+    if constexpr (FWD) return JF_ERR_UNSUPPORTED;                  // sampling direction: matrix-core variant only (float64, ranks <= 8)
+    else return ag_launch<T>(a, D, (hipStream_t)stream);
 }
 
 }  // namespace jf
@@ -363,6 +364,12 @@ int jf_amlp_gf_chain_inv_f32(const float* in, int64_t is, const float* V1, const
                              int32_t D, int32_t n, const jf_gf_layer* L, float* xo, int64_t xos, float* ldo, const float* bi, float* bo, int32_t* st,
                              void* s) {
     return jf::amlp_gf_chain_inv<float>(in, is, V1, U1, b1, V2, U2, b2, K1, H, r1, r2, x, xs, ld_in, B, D, n, L, xo, xos, ldo, bi, bo, st, s);
+}
+int jf_amlp_gf_chain_fwd_f64(const double* in, int64_t is, const double* V1, const double* U1, const double* b1, const double* V2, const double* U2,
+                             const double* b2, int32_t K1, int32_t H, int32_t r1, int32_t r2, const double* z, int64_t zs, const double* ld_in,
+                             int64_t B, int32_t D, int32_t n, const jf_gf_layer* L, double* xo, int64_t xos, double* ldo, int32_t* st, void* s) {
+    return jf::amlp_gf_chain_inv<double, true>(in, is, V1, U1, b1, V2, U2, b2, K1, H, r1, r2, z, zs, ld_in, B, D, n, L, xo, xos, ldo, nullptr, nullptr,
+                                               st, s);
 }
 int jf_amlp_gf_chain_inv_f64(const double* in, int64_t is, const double* V1, const double* U1, const double* b1, const double* V2, const double* U2,
                              const double* b2, int32_t K1, int32_t H, int32_t r1, int32_t r2, const double* x, int64_t xs, const double* ld_in,

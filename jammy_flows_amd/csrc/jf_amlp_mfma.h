@@ -21,7 +21,7 @@
 // ds_read_b64 (fragment f of a product = 64 consecutive doubles).  The flow arithmetic is jf_gf.h's, on registers; the three reductions over a
 // row's coordinates (reflections, log-det) are two cross-group shuffles.
 #pragma once
-#include "jf_gf.h"
+#include "jf_cond_regs.h"
 
 namespace jf {
 
@@ -56,6 +56,10 @@ __device__ __forceinline__ double am_xsum(double v) {                    // sum 
     v += __shfl_xor(v, 16, 64);
     v += __shfl_xor(v, 32, 64);
     return v;
+}
+__device__ __forceinline__ double am_xmax(double v) {
+    v = fmax(v, __shfl_xor(v, 16, 64));
+    return fmax(v, __shfl_xor(v, 32, 64));
 }
 
 // the MLP's own weights in fragment order + the rank-r2 vector t2 of the wave's 16 rows -- shared by the block kernel and the MLP-only kernel
@@ -180,7 +184,10 @@ __global__ void __launch_bounds__(AM_THREADS) amlp2_mfma_kernel(const Args a) {
     }
 }
 
-template <typename Args>
+// FWD: the SAMPLING direction of the block (main/default.py:1420-1506 with gaussianization_flow.py:911-989, bisection_n_newton.py:11-135): layers
+// first to last; per layer the two coordinates of a lane are solved one after the other on register-resident derived rows (cs_solve,
+// jf_cond_regs.h: float32 bracket phase, float64 Newton phase), then the reflections in reverse and the offset.
+template <typename Args, bool FWD = false>
 __global__ void __launch_bounds__(AM_THREADS) amlp_gf_mfma_kernel(const Args a) {
     using T = double;
     extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -225,6 +232,68 @@ __global__ void __launch_bounds__(AM_THREADS) amlp_gf_mfma_kernel(const Args a) 
         p = __builtin_amdgcn_mfma_f64_16x16x4f64(fU2[(2 * tl) * 64 + lane], t2a, p, 0, 0, 0);
         return __builtin_amdgcn_mfma_f64_16x16x4f64(fU2[(2 * tl + 1) * 64 + lane], t2b, p, 0, 0, 0);
     };
+    if constexpr (FWD) {
+        for (int l = 0; l < a.n_layers; ++l) {
+            const auto o = a.L[l];
+            T logd = T(0);
+            CsSolveInfo inf[2];
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                T R[CS_SLOTS];
+#pragma unroll
+                for (int k = 0; k < CS_SLOTS; ++k) R[k] = T(0);
+#pragma unroll
+                for (int tt = 0; tt < AM_TILES_M; ++tt) {
+                    const f64x4_t p = tile(l, AM_TILES_R + half * AM_TILES_M + tt);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) if (4 * tt + r < 30) R[4 * tt + r] = p[r];
+                }
+                // regulate once: log-width slots -> 1 / width, log-weight slots -> normalised weight (ag_mixture's formulas)
+                T Nn = T(0);
+#pragma unroll
+                for (int k = 0; k < CS_K; ++k) {
+                    const T ae = o.inv_wmax + M<T>::exp_fast(-R[CS_SLOT_LW + k]);
+                    R[CS_SLOT_LW + k] = ae * M<T>::rcp(o.wmin * ae + T(1));
+                    const T w = o.nmin + o.nmax * M<T>::rcp(T(1) + M<T>::exp_fast(-R[CS_SLOT_LN + k]));
+                    R[CS_SLOT_LN + k] = w;
+                    Nn += w;
+                }
+                const T invN = M<T>::rcp(Nn);
+#pragma unroll
+                for (int k = 0; k < CS_K; ++k) R[CS_SLOT_LN + k] *= invN;
+                const bool live = half == 0 ? v0 : v1;
+                const T xs = cs_solve<T>(R, o.inv_type, live, half == 0 ? x0 : x1, row_valid, q == 0, a.status, [](T v) { return am_xsum(v); },
+                                        [](T v) { return am_xmax(v); }, &inf[half]);
+                logd += live ? gf_icdf<T>(o.inv_type, cs_mixture_derived<T>(R, xs)).logd : T(0);
+                if (half == 0) x0 = xs; else x1 = xs;
+            }
+            ld -= am_xsum(logd);
+            // the row's status: Newton row-steps = the longer of its two solves
+            const int steps = inf[0].steps > inf[1].steps ? inf[0].steps : inf[1].steps;
+            for (int i = 0; i < 20; ++i) status_add(a.status, JF_STATUS_NEWTON_STEPS, row_valid && q == 0 && i < steps);
+            status_add(a.status, JF_STATUS_NONCONVERGED, row_valid && q == 0 && (inf[0].nonconv || inf[1].nonconv));
+            status_add(a.status, JF_STATUS_NONFINITE, row_valid && q == 0 && (inf[0].nonfinite || inf[1].nonfinite));
+            {
+                T R[AM_TILES_R * 4];
+#pragma unroll
+                for (int tt = 0; tt < AM_TILES_R; ++tt) {
+                    const f64x4_t p = tile(l, tt);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) R[4 * tt + r] = p[r];
+                }
+#pragma unroll
+                for (int i = AG_HH - 1; i >= 0; --i) {
+                    if (i < o.hh) {                                       // x <- Q x: the reflections of the log-prob direction in reverse
+                        const T va = R[i], vb = R[8 + i];
+                        const T n2 = am_xsum(va * va + vb * vb), dot = am_xsum(va * x0 + vb * x1);
+                        const T f = T(2) * dot / n2;
+                        x0 -= f * va; x1 -= f * vb;
+                    }
+                }
+                x0 += R[16]; x1 += R[17];                                 // euclidean_base.py:63-68
+            }
+        }
+    } else
     for (int l = a.n_layers - 1; l >= 0; --l) {
         const auto o = a.L[l];
         {
@@ -267,7 +336,7 @@ __global__ void __launch_bounds__(AM_THREADS) amlp_gf_mfma_kernel(const Args a) 
     if (row_valid && v0) a.x_out[row * a.xos + q] = x0;
     if (row_valid && v1) a.x_out[row * a.xos + q + 4] = x1;
     T sb = T(0);
-    if (a.blp_out) sb = am_xsum((v0 ? T(-0.5) * x0 * x0 - M<T>::HALF_LN_2PI : T(0)) + (v1 ? T(-0.5) * x1 * x1 - M<T>::HALF_LN_2PI : T(0)));
+    if (!FWD && a.blp_out) sb = am_xsum((v0 ? T(-0.5) * x0 * x0 - M<T>::HALF_LN_2PI : T(0)) + (v1 ? T(-0.5) * x1 * x1 - M<T>::HALF_LN_2PI : T(0)));
     if (row_valid && q == 0) {
         a.ld_out[row] = ld;
         if (a.blp_out) a.blp_out[row] = sb + (a.blp_in ? a.blp_in[row] : T(0));

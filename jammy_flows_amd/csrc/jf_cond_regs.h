@@ -224,9 +224,12 @@ template <typename T> __device__ __forceinline__ T cs_log_ndtr_neg(T a) {
 
 // x with stage(mixture(x)) = z: gfg_solve's decisions step for step (far-midpoint skip, stopping rules, status counters); RSUM / RMAX reduce
 // over the lanes that hold the coordinates of one row.  P: DERIVED row (mean, 1 / width, normalised weight per component).
+// info (optional): the caller solves the coordinates of a row in more than one call (two coordinates per lane) and books the row's status
+// itself -- Newton row-steps = the longest of the calls, non-converged / non-finite = any of them; the counters are then not touched here.
+struct CsSolveInfo { int steps; bool nonconv, nonfinite; };
 template <typename T, typename RSUM, typename RMAX>
 __device__ __forceinline__ T cs_solve(const T (&P)[CS_SLOTS], int inv_type, bool live, T z, bool row_valid, bool leader, int32_t* status,
-                                      RSUM rsum, RMAX rmax) {
+                                      RSUM rsum, RMAX rmax, CsSolveInfo* info = nullptr) {
     using Mf = M<T>;
     T lo = T(-1e5), hi = T(1e5), x = T(0);
     constexpr T FAR = T(100);
@@ -285,6 +288,7 @@ __device__ __forceinline__ T cs_solve(const T (&P)[CS_SLOTS], int inv_type, bool
     bool active = row_valid;
     T ferr = T(0), prev = T(INFINITY);
     bool nonfinite = false;
+    int n_steps = 0;
     for (int it = 0; it < 20 && __any(active); ++it) {
         const IcdfOut<T> s = gf_icdf<T>(inv_type, cs_mixture_derived<T>(P, x));
         const T f = s.y - z;
@@ -292,7 +296,8 @@ __device__ __forceinline__ T cs_solve(const T (&P)[CS_SLOTS], int inv_type, bool
         if constexpr (sizeof(T) == 4) upd = f * Mf::exp_fast(-s.logd);      // (v_exp_f32: the step's relative error ~1e-6 does not move a Newton iterate's limit)
         else upd = f / Mf::exp(s.logd);
         const T usum = rsum(live ? Mf::abs(upd) : T(0));
-        status_add(status, JF_STATUS_NEWTON_STEPS, active && leader);
+        if (info == nullptr) status_add(status, JF_STATUS_NEWTON_STEPS, active && leader);
+        n_steps += active ? 1 : 0;
         if (active) {
             const T nx = x - upd;
             if (Mf::finite(nx)) x = nx; else nonfinite = nonfinite || live;
@@ -309,6 +314,10 @@ __device__ __forceinline__ T cs_solve(const T (&P)[CS_SLOTS], int inv_type, bool
     const T prec = sizeof(T) == 8 ? T(1e-7) : T(1e-4);
     const T ferr_row = rmax(live ? ferr : T(0));
     const T nf_row = rmax(nonfinite ? T(1) : T(0));
+    if (info != nullptr) {
+        info->steps = n_steps; info->nonconv = ferr_row > prec; info->nonfinite = nf_row > T(0);
+        return x;
+    }
     status_add(status, JF_STATUS_NONCONVERGED, row_valid && leader && (ferr_row > prec));
     status_add(status, JF_STATUS_NONFINITE, row_valid && leader && (nf_row > T(0)));
     return x;

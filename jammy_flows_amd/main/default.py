@@ -1022,6 +1022,20 @@ class pdf(nn.Module):
                     if per_block is not None:
                         per_block.append(log_det)
                     continue
+            lowrank = self._fusable_lowrank_block(si, layers, only_last, amortization_parameters, x) if kind == "e" else None
+            if lowrank is not None:
+                # low-rank AmortizableMLP + the g layers' solves in one launch (float64, ranks <= 8): no (B, N) parameter block in HBM
+                ba, bb = self.base_dim_indices[si]
+                a, b = self.target_dim_indices[si]
+                res = _hip.amlp_gf_chain_fwd(self._mlp_input(si, data_summary, embeds), *lowrank, x[:, ba:bb], log_det,
+                                             _hip.gf_layer_array([l.c_struct() for l in layers]), len(layers), layers[0].dimension,
+                                             x_out=out[:, a:b], status=status)
+                if res is not None:
+                    log_det = res[1]
+                    embeds.append(block[-1]._embedding_conditional_return(out[:, a:b]))
+                    if per_block is not None:
+                        per_block.append(log_det)
+                    continue
             extra, counter = self._block_params(si, data_summary, embeds, amortization_parameters, counter)
             ba, bb = self.base_dim_indices[si]
             cur = x[:, ba:bb]

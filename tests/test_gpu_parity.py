@@ -428,6 +428,41 @@ def test_fused_sampling_block_vs_golden_and_two_launch_path(name):
     assert 0.7 * steps["two"] <= steps["fused"] <= 1.3 * steps["two"], steps
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["c5_e8s2_ggggv", "g_e1e2e1_cond_lowrank"])
+def test_fused_lowrank_sampling_block_vs_reference_and_two_launch_path(name):
+    """sampling direction of a conditional e-block whose parameters come from a low-rank AmortizableMLP, in one launch
+    (jf_amlp_gf_chain_fwd_f64: float64, ranks <= 8; the g_e1e2e1 fixture's 1- and 2-dimensional blocks exercise padded coordinate lanes):
+    asserted by kernel name where the configuration is inside the kernel's set, held to the reference's float64 samples, compared with the
+    materialised-block path row by row, Newton row-steps of both inside the reference band"""
+    from jammy_flows_amd import _hip
+    fx = [f for f in ALL_FIXTURES if f.name == name][0]
+    pdf = build_product(fx, torch.float64)
+    z = to_dev(fx["z"], torch.float64)
+    cond = to_dev(fx.get("cond"), torch.float64)
+    emb = bool(fx.meta["embedding"])
+    out, steps, ran = {}, {}, {}
+    for mode in ("two", "fused"):
+        pdf.fuse_conditional_blocks = mode == "fused"
+        timer = _hip.KernelTimer()
+        with timer:
+            out[mode] = pdf._obtain_sample(conditional_input=cond, predefined_target_input=z, force_embedding_coordinates=emb)
+        steps[mode] = pdf.last_status_words["newton_row_steps"]
+        ran[mode] = sorted(set(k[0] for k in timer.summary()))
+    assert "jf_amlp_gf_chain_fwd_f64" not in ran["two"]
+    if name == "c5_e8s2_ggggv":                      # (the other fixture's MLP stages are outside the kernel's set: the paths must coincide)
+        assert "jf_amlp_gf_chain_fwd_f64" in ran["fused"], ran["fused"]
+    tol = LOOSE_SAMPLING.get(fx.name, 1e-6)
+    for mode in ("two", "fused"):
+        assert max_rel(out[mode][0], fx["sample_x"]) < tol, mode
+        assert max_rel(out[mode][2], fx["sample_logp"]) < tol, mode
+    assert max_rel(out["fused"][0], out["two"][0].double().cpu().numpy()) < 1e-8
+    rec = NEWTON_RECORDS.get(fx.name)
+    if rec is not None:
+        for mode in ("two", "fused"):
+            assert 0.7 * rec["row_steps_total"] <= steps[mode] <= 1.3 * rec["row_steps_total"], (mode, steps, rec["row_steps_total"])
+
+
 def _tiled_run(fx, dtype, log2_rows, launches=3):
     """the fixture's rows tiled to > 2^log2_rows rows (ragged: not a multiple of 128); returns the log-probs of `launches` evaluations of the
     big batch, the log-probs of the fixture batch alone, and the replica count"""
