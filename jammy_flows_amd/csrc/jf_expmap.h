@@ -193,6 +193,8 @@ template <typename T> __device__ inline void v_newton(const T* __restrict__ pp, 
     x[0] = T(0); x[1] = T(0); x[2] = T(-1);
     bool active = lane_valid;
     const T damp = fast ? T(0.4) : T(0.1);
+    bool gn_ok = true, last_gn = false;
+    T fn_prev = T(INFINITY);
     ExpMapOut<T> o;
     for (int it = 0; it < max_iter && __any(active); ++it) {
         v_exp_map<T>(pp, nc, kind, x, o, tab, oob);
@@ -211,13 +213,18 @@ template <typename T> __device__ inline void v_newton(const T* __restrict__ pp, 
             if (!fast && !(step >= T(1e-12))) { active = false; continue; }      // reference breaks BEFORE applying the step (:384-389)
             // The objective fn = 1 - cos(angle(y, target)) has a double root, so the reference's update (a damped gradient step of Polyak
             // length: 0.4 / 0.1 x fn / |grad|) shrinks the error by ~0.8 / ~0.95 per evaluation: 120 / 540 evaluations of the map until its
-            // 1e-12 rule fires.  Same iteration here until the image is within 1.4e-2 rad of the target (fn < 1e-4); from there ONE
+            // 1e-12 rule fires.  Same iteration here until the image is within 0.45 rad of the target (fn < 0.1); from there ONE
             // Gauss-Newton step per evaluation on the 2-d system y(x) = target (least squares of J delta = target - y over the tangent plane
             // at x) converges quadratically to the same root -- 3 evaluations instead of ~100 / ~430 -- and the reference's stopping rule then
-            // ends the row.  A step that would be long (> 0.1 rad: not the neighbourhood assumed) falls back to the damped update.
+            // ends the row.  A step that would be long (> 0.5 rad) falls back to the damped update, and a row whose Gauss-Newton step did not reduce fn
+            // keeps the reference's iteration for good (none of the fixtures / fuzz cases needs either guard).
             T arc = damp * step;
             bool gn_done = false;
-            if (fn < T(1e-4)) {
+            // a Gauss-Newton step that did not bring the image closer (above the rounding noise of fn): damped updates from here on
+            if (last_gn && !(fn < fn_prev) && fn > T(1e-12)) gn_ok = false;
+            fn_prev = fn;
+            last_gn = false;
+            if (gn_ok && fn < T(1e-1)) {
                 const int ax = (M<T>::abs(x[0]) <= M<T>::abs(x[1]) && M<T>::abs(x[0]) <= M<T>::abs(x[2])) ? 0 : (M<T>::abs(x[1]) <= M<T>::abs(x[2]) ? 1 : 2);
                 const T a3[3] = {ax == 0 ? T(1) : T(0), ax == 1 ? T(1) : T(0), ax == 2 ? T(1) : T(0)};
                 T e1[3] = {a3[1] * x[2] - a3[2] * x[1], a3[2] * x[0] - a3[0] * x[2], a3[0] * x[1] - a3[1] * x[0]};
@@ -238,8 +245,9 @@ template <typename T> __device__ inline void v_newton(const T* __restrict__ pp, 
                 const T det = g11 * g22 - g12 * g12;
                 const T c1 = (g22 * b1 - g12 * b2) / det, c2 = (g11 * b2 - g12 * b1) / det;
                 const T len = M<T>::sqrt(c1 * c1 + c2 * c2);
-                if (len > T(0) && len < T(0.1)) {                  // (NaN fails both comparisons: damped update)
+                if (len > T(0) && len < T(0.5)) {                  // (NaN fails both comparisons: damped update)
                     arc = len;
+                    last_gn = true;
 #pragma unroll
                     for (int i = 0; i < 3; ++i) nv[i] = (c1 * e1[i] + c2 * e2[i]) / len;
                     // a Gauss-Newton step below the reference's own 1e-12 threshold ends the row: at the root fn = 1 - y.t is rounding noise
