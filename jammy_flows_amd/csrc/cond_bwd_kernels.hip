@@ -45,16 +45,6 @@ struct CbPackArgs {
     unsigned char* out;
 };
 
-// largest |W2| entry into the image's 16-byte tail (as in cs_absmax_kernel); the pack kernel leaves the inverse scale 2^-e next to it
-__global__ void __launch_bounds__(256) cb_absmax_kernel(const CbPackArgs a) {
-    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    float m = 0.f;
-    if (idx < (int64_t)a.N * a.H) m = fabsf(a.W2[(idx / a.H) * a.w2s + idx % a.H]);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-    if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned*>(a.out + (size_t)a.n_layers * CB_KSTEPS * CB_T_BYTES), __builtin_bit_cast(unsigned, m));
-}
-
 // one thread per (layer, k-step, hidden tile, lane): fragment value i of lane (m, q) = W2[column of slot 8 s + i of coordinate q][16 j + m]
 __global__ void __launch_bounds__(256) cb_pack_kernel(const CbPackArgs a) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
@@ -395,8 +385,8 @@ static int cb_pack(const float* W2, int64_t w2s, int32_t H, int32_t D, int32_t n
     a.W2 = W2; a.w2s = w2s; a.H = H; a.D = D; a.n_layers = n_layers; a.N = col; a.out = static_cast<unsigned char*>(packed);
     const int threads = n_layers * CB_KSTEPS * CB_JT * 64;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(cs_zero16_kernel, dim3(1), dim3(64), 0, st, reinterpret_cast<unsigned*>(a.out + (size_t)n_layers * CB_KSTEPS * CB_T_BYTES));
-    hipLaunchKernelGGL(cb_absmax_kernel, dim3((unsigned)(((int64_t)col * H + 255) / 256)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(cs_absmax_kernel, dim3(1), dim3(1024), 0, st, W2, w2s, col, (int)H,
+                       reinterpret_cast<float*>(a.out + (size_t)n_layers * CB_KSTEPS * CB_T_BYTES));
     hipLaunchKernelGGL(cb_pack_kernel, dim3((threads + 255) / 256), dim3(256), 0, st, a);
     return hipPeekAtLastError() == hipSuccess ? JF_OK : JF_ERR_LAUNCH;
 }

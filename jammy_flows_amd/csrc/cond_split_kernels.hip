@@ -35,16 +35,6 @@ struct CsPackArgs {
     unsigned char* out;
 };
 
-// JF_SPLIT_F16X2: largest |W2| entry (bit pattern of a non-negative float orders like an unsigned) into the 16-byte tail of the image
-__global__ void __launch_bounds__(256) cs_absmax_kernel(const CsPackArgs a) {
-    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    float m = 0.f;
-    if (idx < (int64_t)a.N * a.H) m = fabsf(a.W2[(idx / a.H) * a.w2s + idx % a.H]);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-    if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned*>(a.out + (size_t)a.n_layers * CS_CPL * CS_CHUNK16_BYTES), __builtin_bit_cast(unsigned, m));
-}
-
 // one thread per (chunk, tile, k-step, lane): writes the three pieces' fragments (16 bytes each); the first 48 threads of a chunk's
 // first k-step also write the bias
 template <int NP> __global__ void __launch_bounds__(256) cs_pack_kernel(const CsPackArgs a) {
@@ -332,8 +322,8 @@ static int cs_pack(const float* W2, int64_t w2s, const float* b2, int32_t H, int
     const int threads = n_layers * CS_CPL * CS_CT * CS_KSTEPS * 64;
     hipStream_t st = (hipStream_t)stream;
     if (arithmetic == JF_SPLIT_F16X2) {
-        hipLaunchKernelGGL(cs_zero16_kernel, dim3(1), dim3(64), 0, st, reinterpret_cast<unsigned*>(a.out + (size_t)n_layers * CS_CPL * CS_CHUNK16_BYTES));
-        hipLaunchKernelGGL(cs_absmax_kernel, dim3((unsigned)(((int64_t)col * H + 255) / 256)), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(cs_absmax_kernel, dim3(1), dim3(1024), 0, st, W2, w2s, col, (int)H,
+                           reinterpret_cast<float*>(a.out + (size_t)n_layers * CS_CPL * CS_CHUNK16_BYTES));
         hipLaunchKernelGGL(cs_pack_kernel<2>, dim3((threads + 255) / 256), dim3(256), 0, st, a);
     } else {
         hipLaunchKernelGGL(cs_pack_kernel<3>, dim3((threads + 255) / 256), dim3(256), 0, st, a);

@@ -38,9 +38,50 @@ __device__ __forceinline__ int cs_w_exponent(float wmax) {
     const int e = 14 - ilogbf(wmax);
     return e < -60 ? -60 : (e > 60 ? 60 : e);
 }
-// 16 zero bytes (the tail of a packed image, before the absmax pass): a kernel rather than hipMemsetAsync, whose node made the capture of a
-// training step in a HIP graph crash on ROCm 7.2
-static __global__ void __launch_bounds__(64) cs_zero16_kernel(unsigned* p) { if (threadIdx.x < 4) p[threadIdx.x] = 0u; }
+// largest |W[n][k]| of an (N, H) matrix with row stride ws -> out[0] (out[1..3] = 0): ONE workgroup of 1024 threads walks the matrix (70 K
+// elements for the C3 block: ~4 us).  The first version used one atomicMax per wave of a 274-block grid on a zeroed word: 14 us of
+// serialised atomics per pack, and a memset node that broke HIP-graph capture on ROCm 7.2.
+static __global__ void __launch_bounds__(1024) cs_absmax_kernel(const float* __restrict__ W, int64_t ws, int N, int H, float* __restrict__ out) {
+    __shared__ float part[16];
+    float m = 0.f;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (H == 128 && ws % 4 == 0 && (reinterpret_cast<uintptr_t>(W) & 15u) == 0) {
+        // 16-byte loads: half a wave covers a row, a wave takes 8 rows per turn (4 independent loads in flight), 16 waves 128 rows
+        const int half = lane >> 5, l4 = (lane & 31) * 4;
+        for (int n0 = 8 * wave; n0 < N; n0 += 128) {
+            f32x4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int n = n0 + 2 * u + half;
+                v[u] = n < N ? *reinterpret_cast<const f32x4*>(W + (int64_t)n * ws + l4) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) m = fmaxf(fmaxf(m, fmaxf(fabsf(v[u][0]), fabsf(v[u][1]))), fmaxf(fabsf(v[u][2]), fabsf(v[u][3])));
+        }
+    } else {
+        for (int n0 = 4 * wave; n0 < N; n0 += 64) {                // a wave takes 4 rows per turn: independent loads, no index division
+            for (int k = lane; k < H; k += 64) {
+                float v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = n0 + u < N ? W[(int64_t)(n0 + u) * ws + k] : 0.f;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) m = fmaxf(m, fabsf(v[u]));
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        float t = 0.f;
+        if (threadIdx.x == 0) {
+#pragma unroll
+            for (int w = 0; w < 16; ++w) t = fmaxf(t, part[w]);
+        }
+        out[threadIdx.x] = t;
+    }
+}
 template <int NP> struct CsGeom;
 template <> struct CsGeom<3> { static constexpr int W = CS_W_BYTES, B = CS_B_BYTES, CHUNK = CS_CHUNK_BYTES; };
 template <> struct CsGeom<2> { static constexpr int W = CS_W16_BYTES, B = CS_B16_BYTES, CHUNK = CS_CHUNK16_BYTES; };
