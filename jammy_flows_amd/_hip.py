@@ -413,7 +413,7 @@ def gf_chain_inv_bwd(x, params, layer_array, n_layers, D, g_xout, g_ld, g_blp, s
     P = params.shape[1]
     if pb == 1:
         n_part = int(lib().jf_gf_chain_inv_bwd_partials(B, D))
-        g_p = torch.empty((n_part, P), dtype=x.dtype, device=x.device)
+        g_p = (torch.zeros if B == 0 else torch.empty)((n_part, P), dtype=x.dtype, device=x.device)     # (no rows: no launch writes the partials)
     else:
         g_p = torch.empty((B, P), dtype=x.dtype, device=x.device)
     _launch("jf_gf_chain_inv_bwd" + _suffix(x), "bcast" if pb == 1 else "per-sample",
@@ -803,6 +803,9 @@ def mlp2_small_bwd(x, w1, b1, w2, g):
     x, w1, w2, g = _rowmajor(x), _rowmajor(w1), _rowmajor(w2), _rowmajor(g)
     B, K1 = x.shape
     H, N = w1.shape[0], w2.shape[0]
+    if B == 0:                                         # no rows: the kernels do not launch, the gradients are exact zeros
+        z = torch.zeros((H, K1 + 1 + N), dtype=x.dtype, device=x.device)
+        return z[:, :K1], z[:, K1], z[:, K1 + 1:].t(), torch.zeros((N,), dtype=x.dtype, device=x.device)
     S = int(lib().jf_mlp2_small_bwd_slabs(B))
     slab = torch.empty((S, H, K1 + 1 + N), dtype=x.dtype, device=x.device)
     slab_b2 = torch.empty((S, N), dtype=x.dtype, device=x.device)
@@ -820,6 +823,9 @@ def mlp_hidden_bwd(x, w1, b1, g_hidden):
     x, w1, g_hidden = _rowmajor(x), _rowmajor(w1), _rowmajor(g_hidden)
     B, K1 = x.shape
     H = w1.shape[0]
+    if B == 0:
+        z = torch.zeros((H, K1 + 1), dtype=x.dtype, device=x.device)
+        return z[:, :K1], z[:, K1]
     S = int(lib().jf_mlp2_small_bwd_slabs(B))
     slab = torch.empty((S, H, K1 + 1), dtype=x.dtype, device=x.device)
     _launch("jf_mlp_hidden_bwd" + _suffix(x), "K%d_H%d" % (K1, H),

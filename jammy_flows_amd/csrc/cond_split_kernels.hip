@@ -105,7 +105,11 @@ struct CsArgs {
 // six independent accumulators per piece product instead of three) and the chunk barriers are paid once per 128 rows instead of 64.
 // SAVE (log-prob direction with gradients wanted): every layer's input coordinate and mixture sums go to a.aux, 5 floats per (layer, row,
 // coordinate lane) -- 320 bytes per row of a 4-layer block instead of the 2.2 KB parameter row the adjoint would otherwise need.
-template <int RG, bool FWD, bool SAVE = false, int NP = CS_NP> __global__ void __launch_bounds__(256, 2) cond_gf_split_kernel(const CsArgs a) {
+// Occupancy: the f16-pair log-prob variants are held to 168 VGPRs (8 spilled with two row groups) so that THREE workgroups share a CU (3 x 49.6 KB
+// of LDS): a third wave per SIMD fills issue slots the other two leave while they sit in the same phase -- 0.66 -> 0.60 ms per 2^20 rows on
+// the same box.  The bf16-triple variants (246 VGPRs) and the sampling direction (solver loops) keep two.
+template <int RG, bool FWD, bool SAVE = false, int NP = CS_NP>
+__global__ void __launch_bounds__(256, (NP == 2 && !FWD) ? 3 : 2) cond_gf_split_kernel(const CsArgs a) {
     using G = CsGeom<NP>;
     constexpr int CS_ROWS = CS_ROWS1 * RG;
     constexpr int MT = 16;
