@@ -354,7 +354,9 @@ static int cs_launch(const CsArgs& a, int64_t B, hipStream_t st) {
     // jf_cond_gf_split_row_groups() force a variant (A/B timing: scripts/probe/rg_sweep.py; both variants in one process: the stress tests)
     static const int env_rg = getenv("JF_CS_RG") ? atoi(getenv("JF_CS_RG")) : 0;
     const int force_rg = cs_forced_rg ? cs_forced_rg : env_rg;
-    const bool two = force_rg ? force_rg == 2 : B >= (int64_t)CS_ROWS1 * 2 * 1024;
+    // sampling: one row group per wave at every size -- 132 VGPRs let three workgroups share a CU, and the solver loops (divergent exits,
+    // quarter-rate transcendentals) gain more from the third wave per SIMD than from halving the fragment reads (1.91 vs 2.12 ms per 2^20 rows)
+    const bool two = force_rg ? force_rg == 2 : (!FWD && B >= (int64_t)CS_ROWS1 * 2 * 1024);
     if (two) hipLaunchKernelGGL((cond_gf_split_kernel<2, FWD, SAVE, NP>), dim3((unsigned)((B + 2 * CS_ROWS1 - 1) / (2 * CS_ROWS1))), dim3(256), lds_of(2), st, a);
     else hipLaunchKernelGGL((cond_gf_split_kernel<1, FWD, SAVE, NP>), dim3((unsigned)((B + CS_ROWS1 - 1) / CS_ROWS1)), dim3(256), lds_of(1), st, a);
     return hipPeekAtLastError() == hipSuccess ? JF_OK : JF_ERR_LAUNCH;
