@@ -296,7 +296,7 @@ static int amlp2(const T* in, int64_t in_stride, const T* V1, const T* U1, const
         if (r2 <= AM_R && (!V1 || r1 <= AM_R) && H % 16 == 0 && lds <= 160 * 1024) {
             auto k = amlp2_mfma_kernel<AgArgs<T>>;
             if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL(k, dim3((unsigned)((B + AM_ROWS - 1) / AM_ROWS)), dim3(AM_THREADS), lds, (hipStream_t)stream, a);
+            hipLaunchKernelGGL(k, dim3((unsigned)((B + am_rows(AM_THREADS) - 1) / am_rows(AM_THREADS))), dim3(AM_THREADS), lds, (hipStream_t)stream, a);
             return check_launch();
         }
     }
@@ -339,8 +339,9 @@ static int amlp_gf_chain_inv(const T* in, int64_t in_stride, const T* V1, const 
         const size_t lds = am_lds_doubles(K1, H, V1 != nullptr, n_layers) * sizeof(T);
         if (r2 <= AM_R && (!V1 || r1 <= AM_R) && H % 16 == 0 && lds <= 160 * 1024) {
             auto k = amlp_gf_mfma_kernel<AgArgs<T>, FWD>;
+            constexpr int NT = FWD ? AM_THREADS_FWD : AM_THREADS, ROWS = am_rows(NT);
             if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL(k, dim3((unsigned)((B + AM_ROWS - 1) / AM_ROWS)), dim3(AM_THREADS), lds, (hipStream_t)stream, a);
+            hipLaunchKernelGGL(k, dim3((unsigned)((B + ROWS - 1) / ROWS)), dim3(NT), lds, (hipStream_t)stream, a);
             return check_launch();
         }
     }

@@ -25,8 +25,11 @@
 
 namespace jf {
 
-constexpr int AM_THREADS = 512;                  // 8 waves x 16 rows
-constexpr int AM_ROWS = AM_THREADS / 64 * 16;
+// threads per workgroup: the waves of a workgroup share ONE LDS copy of the weights (115 KB for C5: one workgroup per CU).  Log-prob direction and
+// the MLP alone: 12 waves (165 VGPRs: three per SIMD; with 8 the kernel ran 1.43 instead of 1.34 ms per 2^19 rows).  Sampling direction:
+// 8 waves (its two register-resident solver rows need 256 VGPRs).  The kernels take the count from blockDim.
+constexpr int AM_THREADS = 768, AM_THREADS_FWD = 512;
+__host__ __device__ constexpr int am_rows(int threads) { return threads / 64 * 16; }
 constexpr int AM_TILES_R = 5, AM_TILES_M = 8, AM_TILES = AM_TILES_R + 2 * AM_TILES_M;     // per layer
 constexpr int AM_R = 8;                          // rank bound (two K steps)
 
@@ -81,17 +84,17 @@ template <typename Args> __device__ inline AmMlp<double> am_build_mlp(const Args
     I.fV2 = I.sb1 + H;                                                    // H / 4 fragments
     I.next = I.fV2 + (H / 4) * 64;
     const T* W = I.lowrank1 ? a.V1 : a.U1;
-    for (int e = tid; e < nV1; e += AM_THREADS) {
+    for (int e = tid; e < nV1; e += (int)blockDim.x) {
         const int f = e >> 6, l = e & 63, m = l & 15, k = 4 * (I.lowrank1 ? f : f % I.k1s) + (l >> 4);
         const int rowi = I.lowrank1 ? m : 16 * (f / I.k1s) + m;
         I.fV1[e] = (k < a.K1 && (I.lowrank1 ? m < a.r1 : true)) ? W[rowi * a.K1 + k] : T(0);
     }
-    for (int e = tid; e < nU1; e += AM_THREADS) {
+    for (int e = tid; e < nU1; e += (int)blockDim.x) {
         const int f = e >> 6, l = e & 63, unit = 16 * (f >> 1) + (l & 15), k = 4 * (f & 1) + (l >> 4);
         I.fU1[e] = k < a.r1 ? a.U1[unit * a.r1 + k] : T(0);
     }
-    for (int e = tid; e < H; e += AM_THREADS) I.sb1[e] = a.b1[e];
-    for (int e = tid; e < (H / 4) * 64; e += AM_THREADS) {
+    for (int e = tid; e < H; e += (int)blockDim.x) I.sb1[e] = a.b1[e];
+    for (int e = tid; e < (H / 4) * 64; e += (int)blockDim.x) {
         const int f = e >> 6, l = e & 63, m = l & 15, unit = 4 * f + (l >> 4);              // step f = 4 t + r covers units 16 t + 4 r + k
         I.fV2[e] = m < a.r2 ? a.V2[m * H + unit] : T(0);
     }
@@ -160,13 +163,13 @@ __global__ void __launch_bounds__(AM_THREADS) amlp2_mfma_kernel(const Args a) {
     const int NT = (a.N + 15) / 16;
     T* fU2 = I.next;
     T* sb2 = fU2 + NT * 2 * 64;
-    for (int e = tid; e < NT * 2 * 64; e += AM_THREADS) {
+    for (int e = tid; e < NT * 2 * 64; e += (int)blockDim.x) {
         const int f = e >> 6, l = e & 63, j = 16 * (f >> 1) + (l & 15), k = 4 * (f & 1) + (l >> 4);
         fU2[e] = (j < a.N && k < a.r2) ? a.U2[(int64_t)j * a.r2 + k] : T(0);
     }
-    for (int e = tid; e < NT * 16; e += AM_THREADS) sb2[e] = e < a.N ? a.b2[e] : T(0);
+    for (int e = tid; e < NT * 16; e += (int)blockDim.x) sb2[e] = e < a.N ? a.b2[e] : T(0);
     __syncthreads();
-    const int64_t row = (int64_t)blockIdx.x * AM_ROWS + wave * 16 + n;
+    const int64_t row = (int64_t)blockIdx.x * am_rows((int)blockDim.x) + wave * 16 + n;
     const bool row_valid = row < a.B;
     const int64_t rrow = row_valid ? row : a.B - 1;
     T t2a, t2b;
@@ -188,7 +191,7 @@ __global__ void __launch_bounds__(AM_THREADS) amlp2_mfma_kernel(const Args a) {
 // first to last; per layer the two coordinates of a lane are solved one after the other on register-resident derived rows (cs_solve,
 // jf_cond_regs.h: float32 bracket phase, float64 Newton phase), then the reflections in reverse and the offset.
 template <typename Args, bool FWD = false>
-__global__ void __launch_bounds__(AM_THREADS) amlp_gf_mfma_kernel(const Args a) {
+__global__ void __launch_bounds__(FWD ? AM_THREADS_FWD : AM_THREADS) amlp_gf_mfma_kernel(const Args a) {
     using T = double;
     extern __shared__ __align__(16) unsigned char smem_raw[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -199,14 +202,14 @@ __global__ void __launch_bounds__(AM_THREADS) amlp_gf_mfma_kernel(const Args a) 
     T* sb2 = fU2 + a.n_layers * AM_TILES * 2 * 64;                        // n_layers * AM_TILES * 16
     {
         const int nU2 = a.n_layers * AM_TILES * 2 * 64;
-        for (int e = tid; e < nU2; e += AM_THREADS) {
+        for (int e = tid; e < nU2; e += (int)blockDim.x) {
             const int f = e >> 6, l = e & 63, m = l & 15, k = 4 * (f & 1) + (l >> 4);
             const int tl = f >> 1, layer = tl / AM_TILES, tt = tl % AM_TILES;
             const int col = am_col(a.L[layer], D, tt, m & 3, m >> 2);
             fU2[e] = (col >= 0 && k < a.r2) ? a.U2[(int64_t)col * a.r2 + k] : T(0);
         }
         const int nb2 = a.n_layers * AM_TILES * 16;
-        for (int e = tid; e < nb2; e += AM_THREADS) {
+        for (int e = tid; e < nb2; e += (int)blockDim.x) {
             const int tl = e >> 4, m = e & 15, layer = tl / AM_TILES, tt = tl % AM_TILES;
             const int col = am_col(a.L[layer], D, tt, m & 3, m >> 2);
             sb2[e] = col >= 0 ? a.b2[col] : T(0);
@@ -214,7 +217,7 @@ __global__ void __launch_bounds__(AM_THREADS) amlp_gf_mfma_kernel(const Args a) 
     }
     __syncthreads();
 
-    const int64_t row = (int64_t)blockIdx.x * AM_ROWS + wave * 16 + n;
+    const int64_t row = (int64_t)blockIdx.x * am_rows((int)blockDim.x) + wave * 16 + n;
     const bool row_valid = row < a.B;
     const int64_t rrow = row_valid ? row : a.B - 1;
     T t2a, t2b;

@@ -11,12 +11,13 @@ namespace jf {
 struct CondSegs { int n; jf_cond_segment s[JF_MAX_SEGMENTS]; };
 
 // one thread per OUTPUT element (coalesced stores; a thread-per-row version wrote 24 strided doubles per thread and ran at 0.3 TB/s).  A
-// workgroup owns 256 whole rows and walks their 256 W elements with 32-bit index arithmetic (round 2 divided a 64-bit global element index by
+// workgroup owns 64 whole rows and walks their 64 W elements with 32-bit index arithmetic (round 2 divided a 64-bit global element index by
 // W per thread: ~60 vector instructions, 90 % VALU busy for a copy kernel).
+constexpr int COND_ROWS = 64;
 template <typename T>
 __global__ void __launch_bounds__(256) conditioning_kernel(const CondSegs a, int64_t B, int W, T* __restrict__ out, int64_t os) {
-    const int64_t row0 = (int64_t)blockIdx.x * 256;
-    const unsigned n_rows = (unsigned)(B - row0 < 256 ? B - row0 : 256);
+    const int64_t row0 = (int64_t)blockIdx.x * COND_ROWS;
+    const unsigned n_rows = (unsigned)(B - row0 < COND_ROWS ? B - row0 : COND_ROWS);
     const unsigned n = n_rows * (unsigned)W;
     for (unsigned e = threadIdx.x; e < n; e += 256) {
         const unsigned rl = e / (unsigned)W;
@@ -55,7 +56,7 @@ template <typename T> static int conditioning_rows(const jf_cond_segment* segs, 
     int W = 0;
     for (int i = 0; i < n; ++i) W += segs[i].kind == 0 ? segs[i].n_in : segs[i].kind + 1;
     if (W == 0) return JF_OK;
-    hipLaunchKernelGGL(conditioning_kernel<T>, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, B, W, out, os);
+    hipLaunchKernelGGL(conditioning_kernel<T>, dim3((unsigned)((B + COND_ROWS - 1) / COND_ROWS)), dim3(256), 0, (hipStream_t)stream, a, B, W, out, os);
     return check_launch();
 }
 
