@@ -428,15 +428,20 @@ JF_DECLARE_MCHAIN(v, double, f64)
 JF_DECLARE_MCHAIN(c, float, f32) /* x has 2 columns for kind 2, else 1 */
 JF_DECLARE_MCHAIN(c, double, f64)
 
-/* A conditional manifold block in ONE launch, log-prob direction: the default amortisation MLP params = tanh(in @ W1^T + b1) @ W2^T + b2
- * (main/default.py:656-670) followed by jf_<fam>_chain_inv on those per-sample parameters.  The (B, N) block stays in LDS.
+/* A conditional manifold block in ONE launch: the default amortisation MLP params = tanh(in @ W1^T + b1) @ W2^T + b2
+ * (main/default.py:656-670) followed by jf_<fam>_chain_inv (log-prob direction) or jf_<fam>_chain_fwd (sampling direction,
+ * main/default.py:1482-1506: z = base points, no base log-prob) on those per-sample parameters.  The (B, N) block stays in LDS.
  * Limits: K1 <= 28, H <= 128, N = sum of the layers' row lengths <= 64, no correlated 'f'; otherwise JF_ERR_UNSUPPORTED. */
 #define JF_DECLARE_COND_MCHAIN(fam, T, suffix)                                                                                            \
     int jf_cond_##fam##_chain_inv_##suffix(const T* in, int64_t in_stride, const T* W1, int64_t w1_stride, const T* b1, const T* W2,        \
                                            int64_t w2_stride, const T* b2, int32_t K1, int32_t H, const T* x, int64_t x_stride,            \
                                            const T* log_det_in, int64_t B, int32_t n_layers, const jf_##fam##_layer* layers, T* x_out,      \
                                            int64_t x_out_stride, T* log_det_out, const T* base_logp_in, T* base_logp_out, int32_t* status, \
-                                           void* stream);
+                                           void* stream);                                                                                   \
+    int jf_cond_##fam##_chain_fwd_##suffix(const T* in, int64_t in_stride, const T* W1, int64_t w1_stride, const T* b1, const T* W2,        \
+                                           int64_t w2_stride, const T* b2, int32_t K1, int32_t H, const T* z, int64_t z_stride,            \
+                                           const T* log_det_in, int64_t B, int32_t n_layers, const jf_##fam##_layer* layers, T* x_out,      \
+                                           int64_t x_out_stride, T* log_det_out, int32_t* status, void* stream);
 JF_DECLARE_COND_MCHAIN(r, float, f32)
 JF_DECLARE_COND_MCHAIN(r, double, f64)
 JF_DECLARE_COND_MCHAIN(o, float, f32)

@@ -183,6 +183,8 @@ for _fam, _cls in MCHAIN_LAYER_TYPES.items():
     if _fam in "romf":
         _SIGNATURES["jf_cond_%s_chain_inv" % _fam] = [_P, _I64, _P, _I64, _P, _P, _I64, _P, _I32, _I32, _P, _I64, _P, _I64, _I32, ctypes.POINTER(_cls),
                                                       _P, _I64, _P, _P, _P, _P, _P]
+        _SIGNATURES["jf_cond_%s_chain_fwd" % _fam] = [_P, _I64, _P, _I64, _P, _P, _I64, _P, _I32, _I32, _P, _I64, _P, _I64, _I32, ctypes.POINTER(_cls),
+                                                      _P, _I64, _P, _P, _P]
     _SIGNATURES["jf_%s_chain_inv_bwd" % _fam] = [_P, _I64, _P, _I64, _I32, _I64, _I32, ctypes.POINTER(_cls), _P, _I64, _P, _P, _P, _I64, _P, _I64,
                                                  _P, _P]
 
@@ -1023,6 +1025,30 @@ def cond_mchain_inv(fam, inp, w1, b1, w2, b2, x, log_det, layer_structs, dim, x_
     if not ok:
         return None                                   # outside the fused kernel's limits (LDS budget): use the two-launch path
     return (x_out, ld_out, blp_out) if want_base_logp else (x_out, ld_out)
+
+
+def cond_mchain_fwd(fam, inp, w1, b1, w2, b2, z, log_det, layer_structs, dim, x_out=None, status=None):
+    """sampling direction of cond_mchain_inv: default amortisation MLP + the manifold chain forwards in ONE launch -> (x, log_det), or None
+    outside the fused kernel's limits"""
+    dev = require_device(inp, w1, b1, w2, b2, z, log_det, x_out, status)
+    inp, w1, w2, z = _rowmajor(inp), _rowmajor(w1), _rowmajor(w2), _rowmajor(z)
+    B, K1 = inp.shape
+    H = w1.shape[0]
+    if z.shape != (B, dim) or w1.shape[1] != K1 or w2.shape[1] != H or b1.shape[0] != H or b2.shape[0] != w2.shape[0]:
+        raise ValueError("cond_mchain_fwd: inconsistent shapes")
+    if any(t.dtype != z.dtype for t in (inp, w1, b1, w2, b2)):
+        raise TypeError("cond_mchain_fwd: dtype mismatch")
+    if log_det is not None:
+        log_det = log_det.contiguous()
+    if x_out is None:
+        x_out = torch.empty((B, dim), dtype=z.dtype, device=z.device)
+    ld_out = torch.empty((B,), dtype=z.dtype, device=z.device)
+    n = len(layer_structs)
+    arr = (MCHAIN_LAYER_TYPES[fam] * n)(*layer_structs)
+    ok = _launch("jf_cond_%s_chain_fwd%s" % (fam, _suffix(z)), "K%d_H%d_N%d" % (K1, H, w2.shape[0]),
+                 (_ptr(inp), inp.stride(0), _ptr(w1), w1.stride(0), _ptr(b1.contiguous()), _ptr(w2), w2.stride(0), _ptr(b2.contiguous()), K1, H, _ptr(z),
+                  z.stride(0), _ptr(log_det), B, n, arr, _ptr(x_out), x_out.stride(0), _ptr(ld_out), _ptr(status)), dev, unsupported_ok=True)
+    return (x_out, ld_out) if ok else None
 
 
 def t_layer(direction, x, log_det, params, struct, D, x_out=None, base_logp_in=None, want_base_logp=False, status=None):

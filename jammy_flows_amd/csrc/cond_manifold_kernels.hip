@@ -33,7 +33,8 @@ template <typename T, typename CLayer> struct CmArgs {
 };
 
 // NT threads per workgroup (256 in float32; 128 in float64, whose lane-private knot tables are twice as large)
-template <typename T, class Fam, int NT>
+// FWD: the sampling direction (layers first to last, Fam::apply<T, true>: main/default.py:1482-1506); no base log-prob there
+template <typename T, class Fam, int NT, bool FWD = false>
 __global__ void __launch_bounds__(NT) cond_mchain_kernel(const CmArgs<T, typename Fam::CLayer> a) {
     using MF = Mfma16<T>;
     constexpr int MT = 16, KS = 4, NREG = 4, JH = CM_HMAX / MT;
@@ -125,8 +126,8 @@ __global__ void __launch_bounds__(NT) cond_mchain_kernel(const CmArgs<T, typenam
     ctx.lane_valid = active;
     const T* prow = tiles + tid * a.tile_stride;
     for (int i = 0; i < a.n_layers; ++i) {
-        const int l = a.n_layers - 1 - i;
-        Fam::template apply<T, false>(a.L[l], prow + a.col0[l], x, ld, ctx);
+        const int l = FWD ? i : a.n_layers - 1 - i;
+        Fam::template apply<T, FWD>(a.L[l], prow + a.col0[l], x, ld, ctx);
     }
     bool bad = !M<T>::finite(ld);
 #pragma unroll
@@ -147,7 +148,7 @@ __global__ void __launch_bounds__(NT) cond_mchain_kernel(const CmArgs<T, typenam
     status_add(a.status, JF_STATUS_NONCONVERGED, active && ctx.nonconv);
 }
 
-template <typename T, class Fam>
+template <typename T, class Fam, bool FWD = false>
 static int cond_mchain(const T* in, int64_t in_stride, const T* W1, int64_t w1s, const T* b1, const T* W2, int64_t w2s, const T* b2, int32_t K1, int32_t H,
                        const T* x, int64_t xs, const T* ld_in, int64_t B, int32_t n_layers, const typename Fam::CLayer* layers, T* x_out, int64_t xos,
                        T* ld_out, const T* blp_in, T* blp_out, int32_t* status, void* stream) {
@@ -180,7 +181,7 @@ static int cond_mchain(const T* in, int64_t in_stride, const T* W1, int64_t w1s,
     const size_t lds = ((size_t)CM_HMAX * ldk + CM_HMAX + (size_t)np * (CM_HMAX + 1) + np + (size_t)NT * ldk + (size_t)NT * a.tile_stride +
                         (size_t)NT * a.tab) * sizeof(T);
     if (lds > 160 * 1024) return JF_ERR_UNSUPPORTED;
-    auto k = cond_mchain_kernel<T, Fam, NT>;
+    auto k = cond_mchain_kernel<T, Fam, NT, FWD>;
     if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k, dim3((unsigned)((B + NT - 1) / NT)), dim3(NT), lds, (hipStream_t)stream, a);
     return check_launch();
@@ -197,6 +198,20 @@ using namespace jf;
                                                       int32_t* st, void* s) {                                                                        \
         return cond_mchain<T, Fam>(in, is, W1, w1s, b1, W2, w2s, b2, K1, H, x, xs, ld_in, B, n, L, xo, xos, ldo, bi, bo, st, s);                     \
     }
+#define JF_DEFINE_COND_MCHAIN_FWD(fam, Fam, T, suffix)                                                                                             \
+    extern "C" int jf_cond_##fam##_chain_fwd_##suffix(const T* in, int64_t is, const T* W1, int64_t w1s, const T* b1, const T* W2, int64_t w2s,       \
+                                                      const T* b2, int32_t K1, int32_t H, const T* z, int64_t zs, const T* ld_in, int64_t B,         \
+                                                      int32_t n, const jf_##fam##_layer* L, T* xo, int64_t xos, T* ldo, int32_t* st, void* s) {      \
+        return cond_mchain<T, Fam, true>(in, is, W1, w1s, b1, W2, w2s, b2, K1, H, z, zs, ld_in, B, n, L, xo, xos, ldo, nullptr, nullptr, st, s);     \
+    }
+JF_DEFINE_COND_MCHAIN_FWD(r, RFam, float, f32)
+JF_DEFINE_COND_MCHAIN_FWD(r, RFam, double, f64)
+JF_DEFINE_COND_MCHAIN_FWD(o, OFam, float, f32)
+JF_DEFINE_COND_MCHAIN_FWD(o, OFam, double, f64)
+JF_DEFINE_COND_MCHAIN_FWD(m, MFam, float, f32)
+JF_DEFINE_COND_MCHAIN_FWD(m, MFam, double, f64)
+JF_DEFINE_COND_MCHAIN_FWD(f, FFam, float, f32)
+JF_DEFINE_COND_MCHAIN_FWD(f, FFam, double, f64)
 JF_DEFINE_COND_MCHAIN(r, RFam, float, f32)
 JF_DEFINE_COND_MCHAIN(r, RFam, double, f64)
 JF_DEFINE_COND_MCHAIN(o, OFam, float, f32)

@@ -1036,6 +1036,21 @@ class pdf(nn.Module):
                     if per_block is not None:
                         per_block.append(log_det)
                     continue
+            mfused = self._fusable_manifold_block(si, layers, only_last, amortization_parameters, x.dtype) if kind != "e" else None
+            if mfused is not None:
+                # default amortisation MLP + the manifold chain forwards in one launch: the parameter rows stay in LDS
+                fam, ws = mfused
+                structs = [l.c_struct() if fam == "r" else l.c_struct(1 if l.euclidean_to_sphere_as_first else 0) for l in layers]
+                ba, bb = self.base_dim_indices[si]
+                a, b = self.target_dim_indices[si]
+                res = _hip.cond_mchain_fwd(fam, self._mlp_input(si, data_summary, embeds), *ws, x[:, ba:bb], log_det, structs, layers[0].dimension,
+                                           x_out=out[:, a:b], status=status)
+                if res is not None:
+                    log_det = res[1]
+                    embeds.append(block[-1]._embedding_conditional_return(out[:, a:b]))
+                    if per_block is not None:
+                        per_block.append(log_det)
+                    continue
             extra, counter = self._block_params(si, data_summary, embeds, amortization_parameters, counter)
             ba, bb = self.base_dim_indices[si]
             cur = x[:, ba:bb]

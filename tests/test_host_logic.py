@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for suffix in re.findall(r"^JF_DECLARE_AMLP\(\w+,\s*(\w+)\)", header, flags=re.M):
         declared |= {"jf_amlp_stage_" + suffix, "jf_amlp_stage_bwd_" + suffix}
     for fam, suffix in re.findall(r"^JF_DECLARE_COND_MCHAIN\((\w+),\s*\w+,\s*(\w+)\)", header, flags=re.M):
-        declared.add("jf_cond_%s_chain_inv_%s" % (fam, suffix))
+        declared |= {"jf_cond_%s_chain_inv_%s" % (fam, suffix), "jf_cond_%s_chain_fwd_%s" % (fam, suffix)}
     for fam, suffix in re.findall(r"^JF_DECLARE_MCHAIN_BWD\((\w+),\s*\w+,\s*(\w+)\)", header, flags=re.M):
         declared.add("jf_%s_chain_inv_bwd_%s" % (fam, suffix))
     assert declared == set(_hip.exported_symbols()), declared ^ set(_hip.exported_symbols())
