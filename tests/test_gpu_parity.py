@@ -393,6 +393,35 @@ def test_fused_conditional_block_vs_golden_and_two_launch_path(name):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("scale", [1e-6, 1e-3, 1.0, 8.0])
+def test_f16_pair_arithmetic_follows_the_weight_scale(scale):
+    """the f16-pair product scales W2 by a power of two taken from its largest entry: weights far from O(1) (and a matrix whose rows differ by
+    six orders of magnitude) must give the parameters -- hence log-probs -- of the exact-f32 kernel; the log-prob direction and the sampling
+    direction both go through the scaled image"""
+    fx = [f for f in ALL_FIXTURES if f.name == "g_e3_ggg_cond"][0]
+    pdf = build_product(fx, torch.float32)
+    pdf.check_status = False
+    x = to_dev(fx["x"], torch.float32)
+    cond = to_dev(fx.get("cond"), torch.float32)
+    lin = pdf.mlp_predictors[0][2]
+    with torch.no_grad():
+        # the same function of the hidden activations with a rescaled matrix: W2 -> W2 * scale on even hidden units, / scale compensated in W1's
+        # tanh is not possible, so the comparison is between the two arithmetics on the SAME rescaled weights
+        lin.weight.mul_(scale)
+        lin.weight[::7].mul_(1e3 if scale < 1.0 else 1e-3)         # rows of very different magnitude inside one matrix
+    out = {}
+    for mode in ("f32", "split_f16", "split_bf16"):
+        pdf.fused_matrix_arithmetic = mode
+        out[mode] = pdf(x, conditional_input=cond)[0]
+    fin = torch.isfinite(out["f32"])
+    assert int(fin.sum()) > 0.25 * fin.numel(), int(fin.sum())
+    for mode in ("split_f16", "split_bf16"):
+        assert torch.equal(torch.isfinite(out[mode]), fin), mode
+        err = ((out[mode] - out["f32"])[fin].abs() / (1.0 + out["f32"][fin].abs())).max().item()
+        assert err < 2e-5 * max(1.0, scale), (mode, scale, err)      # (the summation-order difference of the parameters grows with the weights)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("name", sorted(FUSABLE))
 def test_fused_sampling_block_vs_golden_and_two_launch_path(name):
     """sampling direction of a conditional e-block in one launch (jf_cond_gf_chain_fwd_split_f32: amortisation MLP on split-bf16 MFMA, the
