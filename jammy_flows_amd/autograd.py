@@ -9,8 +9,11 @@ Every Function's forward is the SAME kernel launch the inference path uses; noth
     run in jf_linear_wgrad / jf_linear_wgrad_split (csrc/wgrad_kernels.hip, csrc/split_gemm_kernels.hip: the batch split over the grid -- the
     library's output-tiled GEMM walks 1e5..1e6 rows in a handful of workgroups there, 14 ms per call in float64); the tanh derivative is one
     launch on the saved activation (jf_tanh_bwd);
-  * the fused conditional block (MLP + g layers in one launch) recomputes its parameter block with two dense launches in backward and
-    then runs the same two steps.
+  * the fused conditional block (MLP + g layers in one launch): its gradient-mode forward keeps every layer's input coordinate and mixture
+    sums (20 floats per row and layer), its backward is ONE launch (jf_cond_gf_chain_inv_split_bwd: parameters recomputed in MFMA registers,
+    each layer's adjoint in place, g_h accumulated from the same registers) + the weight-gradient product on the packed gradient rows + the
+    hidden layer's one-launch backward; JF_FUSED_BLOCK_BACKWARD=0 selects the round-2 sequence (parameter block recomputed by two dense
+    launches, then the same two steps as a per-sample block).
 """
 import os
 
