@@ -202,7 +202,13 @@ int jf_cond_gf_chain_inv_split_bwd_f32(const float* in, int64_t in_stride, const
                                        const void* packedT, int32_t K1, int32_t H, const float* z, int64_t z_stride, const float* aux, int64_t B,
                                        int32_t D, int32_t n_layers, const jf_gf_layer* layers, const float* g_x_out, int64_t g_x_out_stride,
                                        const float* g_log_det, const float* g_base_logp, float* g_x, int64_t g_x_stride, float* g_pp,
-                                       int64_t g_pp_stride, float* h_out, int64_t h_stride, float* g_h, int64_t g_h_stride, void* stream);
+                                       int64_t g_pp_stride, float* h_out, int64_t h_stride, float* g_h, int64_t g_h_stride, float* g_absmax,
+                                       void* stream);
+/* g_absmax (optional, one float the caller zeroed): the launch leaves max |g_pp| there (atomic max), the power-of-two scale for
+ * jf_linear_wgrad_split16_f32 = jf_linear_wgrad_split_f32 on f16 pairs (three products instead of six): g scaled so that g_absmax lands in
+ * [2^14, 2^15), `in` by 2^in_exp (14 for activations in (-1, 1)); absolute error of an entry <= max(2^-22 |g|, 2^-39 g_absmax). */
+int jf_linear_wgrad_split16_f32(const float* g, int64_t g_stride, const float* in, int64_t in_stride, int64_t B, int32_t K, int32_t N,
+                                const float* g_absmax, int32_t in_exp, float* partial_w, float* partial_b, void* stream);
 /* Third generation of the same block ("ping-pong", cond_pp_kernels.hip): 32x32x16 bf16 tiles (one MFMA per 32 cycles leaves the vector ALU
  * ~20 free issue cycles, a 16x16x32 one ~4), persistent 512-thread workgroups whose two four-wave teams run the same program half a layer
  * apart, so that on every SIMD one wave multiplies while its partner evaluates the flow.  Same arithmetic (3-way split bf16, six products, f32

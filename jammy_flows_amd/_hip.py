@@ -172,7 +172,8 @@ _SIGNATURES_SINGLE = {
     "jf_cond_gf_bwd_packed_bytes": ([_I32, _I32, ctypes.POINTER(jf_gf_layer)], ctypes.c_int64),
     "jf_cond_gf_bwd_pack_f32": ([_P, _I64, _I32, _I32, _I32, ctypes.POINTER(jf_gf_layer), _P, _P], ctypes.c_int),
     "jf_cond_gf_chain_inv_split_bwd_f32": ([_P, _I64, _P, _I64, _P, _P, _P, _I32, _I32, _P, _I64, _P, _I64, _I32, _I32, ctypes.POINTER(jf_gf_layer),
-                                            _P, _I64, _P, _P, _P, _I64, _P, _I64, _P, _I64, _P, _I64, _P], ctypes.c_int),
+                                            _P, _I64, _P, _P, _P, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _P], ctypes.c_int),
+    "jf_linear_wgrad_split16_f32": ([_P, _I64, _P, _I64, _I64, _I32, _I32, _P, _I32, _P, _P, _P], ctypes.c_int),
     "jf_cond_gf_chain_inv_split_f32": ([_P, _I64, _P, _I64, _P, _P, _I32, _I32, _P, _I64, _P, _I64, _I32, _I32, ctypes.POINTER(jf_gf_layer), _P, _I64,
                                         _P, _P, _P, _P, _P], ctypes.c_int),
 }
@@ -647,9 +648,9 @@ def cond_gf_packed_rows(layer_array, n_layers, D):
     return idx
 
 
-def cond_gf_chain_inv_split_bwd(inp, w1, b1, packed, packed_t, z, aux, layer_array, n_layers, D, g_xout, g_ld, g_blp):
+def cond_gf_chain_inv_split_bwd(inp, w1, b1, packed, packed_t, z, aux, layer_array, n_layers, D, g_xout, g_ld, g_blp, want_absmax=False):
     """adjoint of cond_gf_chain_inv_split(..., aux=aux) in one launch -> (g_x (B, D), g_pp (B, n_layers * 144) packed parameter-row gradient,
-    h (B, H) hidden activations, g_h (B, H)); see include/jammy_hip.h."""
+    h (B, H) hidden activations, g_h (B, H)[, max |g_pp| as a 1-element tensor]); see include/jammy_hip.h."""
     dev = require_device(inp, w1, b1, packed, packed_t, z, aux, g_xout, g_ld, g_blp)
     inp, w1, z = _rowmajor(inp), _rowmajor(w1), _rowmajor(z)
     B, K1 = inp.shape
@@ -665,11 +666,27 @@ def cond_gf_chain_inv_split_bwd(inp, w1, b1, packed, packed_t, z, aux, layer_arr
     g_pp = torch.empty((B, n_layers * 4 * COND_GF_SLOTS), dtype=z.dtype, device=z.device)
     h = torch.empty((B, H), dtype=z.dtype, device=z.device)
     g_h = torch.empty((B, H), dtype=z.dtype, device=z.device)
+    absmax = torch.zeros((1,), dtype=z.dtype, device=z.device) if want_absmax else None
     _launch("jf_cond_gf_chain_inv_split_bwd_f32", "K%d_H%d_L%d_D%d" % (K1, H, n_layers, D),
             (_ptr(inp), inp.stride(0), _ptr(w1), w1.stride(0), _ptr(b1.contiguous()), _ptr(packed), _ptr(packed_t), K1, H, _ptr(z), z.stride(0),
              _ptr(aux), B, D, n_layers, layer_array, _ptr(g_xout), 0 if g_xout is None else g_xout.stride(0), _ptr(g_ld), _ptr(g_blp),
-             _ptr(g_x), g_x.stride(0), _ptr(g_pp), g_pp.stride(0), _ptr(h), h.stride(0), _ptr(g_h), g_h.stride(0)), dev)
-    return g_x, g_pp, h, g_h
+             _ptr(g_x), g_x.stride(0), _ptr(g_pp), g_pp.stride(0), _ptr(h), h.stride(0), _ptr(g_h), g_h.stride(0), _ptr(absmax)), dev)
+    return (g_x, g_pp, h, g_h, absmax) if want_absmax else (g_x, g_pp, h, g_h)
+
+
+def linear_wgrad_split16(g, inp, g_absmax, in_exp=14, want_bias=True):
+    """linear_wgrad's split path on f16 pairs (jf_linear_wgrad_split16_f32): g scaled by the power of two that brings g_absmax (a device
+    scalar >= max |g|) into [2^14, 2^15), inp by 2^in_exp; for the packed gradient rows and tanh activations of the fused block's adjoint"""
+    dev = require_device(g, inp, g_absmax)
+    g, inp = _rowmajor(g), _rowmajor(inp)
+    B, N = g.shape
+    K = inp.shape[1]
+    S = int(lib().jf_linear_wgrad_split_splits(B, N))
+    pw = torch.empty((S, N, K), dtype=g.dtype, device=g.device)
+    pb = torch.empty((S, N), dtype=g.dtype, device=g.device) if want_bias else None
+    _launch("jf_linear_wgrad_split16_f32", "K%d_N%d" % (K, N), (_ptr(g), g.stride(0), _ptr(inp), inp.stride(0), B, K, N, _ptr(g_absmax), in_exp,
+                                                             _ptr(pw), _ptr(pb)), dev)
+    return slab_sum(pw, pb)
 
 
 def cond_gf_chain_fwd_split(inp, w1, b1, packed, z, log_det, layer_array, n_layers, D, x_out=None, status=None, kind="split"):

@@ -132,6 +132,8 @@ class GfChainInvFn(torch.autograd.Function):
 # the fused block's backward in one launch (csrc/cond_bwd_kernels.hip) wherever the "split" kernel ran the forward; "0" = the round-2 sequence
 # of dense launches around a materialised parameter block (kept for A/B timing and as the path of the other kernels)
 FUSED_BLOCK_BACKWARD = os.environ.get("JF_FUSED_BLOCK_BACKWARD", "1") != "0"
+# its weight-gradient product on f16 pairs (three MFMA passes) instead of bf16 triples (six): JF_WGRAD_F16_PAIRS=0 selects the triples
+WGRAD_F16_PAIRS = os.environ.get("JF_WGRAD_F16_PAIRS", "1") != "0"
 _packed_row_index = {}
 
 
@@ -178,13 +180,19 @@ class CondBlockFn(torch.autograd.Function):
             if kind != "split16":                     # the adjoint kernel multiplies f16 pairs: its own image of the same weights
                 packed = _hip.cond_gf_pack(w2, b2, layer_array, n_layers, D, "split16")
             packed_t = _hip.cond_gf_bwd_pack(w2, layer_array, n_layers, D)
-            g_x, g_p, h, g_hid = _hip.cond_gf_chain_inv_split_bwd(inp, w1, b1, packed, packed_t, z, aux, layer_array, n_layers, D, g_xout, g_ld, g_blp)
+            f16_wgrad = WGRAD_F16_PAIRS and (need[3] or need[4]) and w1.shape[0] % 4 == 0 and 16 < w1.shape[0] <= 128 and inp.shape[0] >= 4096
+            res = _hip.cond_gf_chain_inv_split_bwd(inp, w1, b1, packed, packed_t, z, aux, layer_array, n_layers, D, g_xout, g_ld, g_blp,
+                                                   want_absmax=f16_wgrad)
+            g_x, g_p, h, g_hid = res[:4]
             ctx.fused = None
             del aux
             g_w2 = g_b2 = None
             if need[3] or need[4]:
                 rows = _packed_rows(layer_array, n_layers, D, g_p.device)
-                g_w2, g_b2 = _hip.linear_wgrad(g_p, h, want_bias=need[4])
+                if f16_wgrad:                          # the packed rows' largest entry comes with them: weight gradient on f16 pairs
+                    g_w2, g_b2 = _hip.linear_wgrad_split16(g_p, h, res[4], 14, want_bias=need[4])
+                else:
+                    g_w2, g_b2 = _hip.linear_wgrad(g_p, h, want_bias=need[4])
                 g_w2 = g_w2.index_select(0, rows)
                 g_b2 = None if g_b2 is None else g_b2.index_select(0, rows)
         else:

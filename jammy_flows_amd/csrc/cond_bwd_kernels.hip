@@ -199,6 +199,7 @@ struct CbArgs {
     float* g_pp; int64_t gpps;                 // (B, n_layers * 144): [layer][coordinate lane][slot]
     float* h_out; int64_t hs;                  // (B, H)
     float* g_h; int64_t ghs;                   // (B, H)
+    float* g_absmax;                           // optional: max |g_pp| over the launch (atomic max of its bit pattern; the caller zeroes it)
 };
 
 __global__ void __launch_bounds__(256, 2) cond_gf_split_bwd_kernel(const CbArgs a) {
@@ -301,6 +302,14 @@ __global__ void __launch_bounds__(256, 2) cond_gf_split_bwd_kernel(const CbArgs 
 #pragma unroll
         for (int k = 0; k < CS_SLOTS; ++k) gmax = fmaxf(gmax, fabsf(P[k]));
         gmax = cs_rmax(gmax);
+        if (a.g_absmax != nullptr) {                               // the weight-gradient product on f16 pairs scales the packed rows by one power of two
+            float wm = row_valid ? gmax : 0.f;
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) wm = fmaxf(wm, __shfl_xor(wm, o));
+            // (a plain read first: after the first waves almost none raises the maximum, and 65 K atomics on one address cost 0.3 ms)
+            if (lane == 0 && wm < INFINITY && __builtin_bit_cast(unsigned, wm) > __atomic_load_n(reinterpret_cast<unsigned*>(a.g_absmax), __ATOMIC_RELAXED))
+                atomicMax(reinterpret_cast<unsigned*>(a.g_absmax), __builtin_bit_cast(unsigned, wm));
+        }
         // (exponents clamped to +-60 like W2's: the two together stay inside the f32 exponent range, and an entry 2^-60 below that is noise)
         const int g_exp = (gmax > 0.f && gmax < INFINITY) ? max(-60, min(60, 14 - ((int)((__builtin_bit_cast(unsigned, gmax) >> 23) & 0xff) - 127))) : 0;
         const float g_scale = __builtin_bit_cast(float, (unsigned)(127 + g_exp) << 23);
@@ -394,7 +403,7 @@ static int cb_pack(const float* W2, int64_t w2s, int32_t H, int32_t D, int32_t n
 static int cb_chain(const float* in, int64_t in_stride, const float* W1, int64_t w1s, const float* b1, const void* packed, const void* packedT,
                     int32_t K1, int32_t H, const float* z, int64_t zs, const float* aux, int64_t B, int32_t D, int32_t n_layers,
                     const jf_gf_layer* layers, const float* g_xout, int64_t gxos, const float* g_ld, const float* g_blp, float* g_x, int64_t gxs,
-                    float* g_pp, int64_t gpps, float* h_out, int64_t hs, float* g_h, int64_t ghs, void* stream) {
+                    float* g_pp, int64_t gpps, float* h_out, int64_t hs, float* g_h, int64_t ghs, float* g_absmax, void* stream) {
     if (!in || !W1 || !b1 || !packed || !packedT || !z || !aux || !layers || !g_x || !g_pp || !h_out || !g_h) return JF_ERR_BADARG;
     if (!width_ok(K1) || !width_ok(H) || !rows_ok(B) || n_layers < 1 || n_layers > JF_MAX_CHAIN) return JF_ERR_BADARG;
     if (K1 > CS_K1MAX || H > CS_HMAX || H % 4) return JF_ERR_UNSUPPORTED;
@@ -414,7 +423,7 @@ static int cb_chain(const float* in, int64_t in_stride, const float* W1, int64_t
     a.packed = static_cast<const unsigned char*>(packed); a.packedT = static_cast<const unsigned char*>(packedT); a.K1 = K1; a.H = H;
     a.z = z; a.zs = zs; a.aux = aux; a.B = B; a.D = D; a.n_layers = n_layers;
     a.g_xout = g_xout; a.gxos = gxos; a.g_ld = g_ld; a.g_blp = g_blp; a.g_x = g_x; a.gxs = gxs; a.g_pp = g_pp; a.gpps = gpps;
-    a.h_out = h_out; a.hs = hs; a.g_h = g_h; a.ghs = ghs;
+    a.h_out = h_out; a.hs = hs; a.g_h = g_h; a.ghs = ghs; a.g_absmax = g_absmax;
     const size_t lds = 2 * CB_BUF;                                 // (phase 1's scratch, <= 22.8 KB at K1 = 28, fits buffer 1)
     static bool attr_set = false;
     if (!attr_set) {
@@ -441,8 +450,8 @@ int jf_cond_gf_chain_inv_split_bwd_f32(const float* in, int64_t is, const float*
                                        const void* packedT, int32_t K1, int32_t H, const float* z, int64_t zs, const float* aux, int64_t B,
                                        int32_t D, int32_t n, const jf_gf_layer* L, const float* g_xout, int64_t gxos, const float* g_ld,
                                        const float* g_blp, float* g_x, int64_t gxs, float* g_pp, int64_t gpps, float* h_out, int64_t hs,
-                                       float* g_h, int64_t ghs, void* s) {
+                                       float* g_h, int64_t ghs, float* g_absmax, void* s) {
     return jf::cb_chain(in, is, W1, w1s, b1, packed, packedT, K1, H, z, zs, aux, B, D, n, L, g_xout, gxos, g_ld, g_blp, g_x, gxs, g_pp, gpps,
-                        h_out, hs, g_h, ghs, s);
+                        h_out, hs, g_h, ghs, g_absmax, s);
 }
 }

@@ -282,7 +282,25 @@ struct WsArgs {
     int64_t B, rows_per_split;
     int K, N;
     float* pw; float* pb;
+    const float* gmax;                          // NP = 2: device scalar, an upper bound of |g| (power-of-two scale of the f16 pieces)
+    int in_exp;                                 // NP = 2: `in` is scaled by 2^in_exp (14 for activations in (-1, 1))
 };
+
+// NP = 2: f16 pairs instead of bf16 triples (three products instead of six, two fragments per tile instead of three), for the one caller
+// whose operands have a known range: the packed gradient rows of the conditional block's adjoint (scaled by the power of two that brings
+// their largest entry, handed over by that kernel, into [2^14, 2^15)) and its tanh activations (2^14).  An entry's absolute error is
+// <= max(2^-22 |g|, 2^-39 max|g|): entries more than 2^-18 below the batch's largest gradient entry keep fewer than 22 bits -- their
+// contribution to a batch sum is below the rounding of the f32 accumulation of the larger ones.
+using ws_f16x2 = __attribute__((ext_vector_type(2))) _Float16;
+using ws_f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+using ws_f32x2 = __attribute__((ext_vector_type(2))) float;
+__device__ __forceinline__ void ws_split16(float v0, float v1, unsigned& hi, unsigned& lo) {
+    const ws_f16x2 h = __builtin_convertvector(ws_f32x2{v0, v1}, ws_f16x2);
+    const ws_f32x2 back = __builtin_convertvector(h, ws_f32x2);
+    const ws_f16x2 l = __builtin_convertvector(ws_f32x2{v0 - back[0], v1 - back[1]}, ws_f16x2);
+    hi = __builtin_bit_cast(unsigned, h);
+    lo = __builtin_bit_cast(unsigned, l);
+}
 
 constexpr int WS_NW = 128;                         // columns of g per workgroup
 constexpr int WS_TILES = WS_NW / 16;               // = k-tiles of `in` (K <= 128)
@@ -290,9 +308,9 @@ constexpr int WS_FRAG = SG_FRAG + 16;              // fragment pitch in LDS: the
 
 __device__ __forceinline__ int ws_slot(int m, int q) { return q * 16 + m; }    // = the lane: the 8 lanes a ds_read_b128 serves per cycle read 128 contiguous bytes
 
-__global__ void __launch_bounds__(256, 2) wgrad_split_kernel(const WsArgs a) {
-    __shared__ __align__(16) unsigned char Gs[WS_TILES * SG_NP * WS_FRAG];     // 24 KiB: fragments of the g tile
-    __shared__ __align__(16) unsigned char Is[WS_TILES * SG_NP * WS_FRAG];     // 24 KiB: fragments of the `in` tile
+template <int NP> __global__ void __launch_bounds__(256, 2) wgrad_split_kernel(const WsArgs a) {
+    __shared__ __align__(16) unsigned char Gs[WS_TILES * NP * WS_FRAG];        // 24 KiB (NP = 3): fragments of the g tile
+    __shared__ __align__(16) unsigned char Is[WS_TILES * NP * WS_FRAG];        // 24 KiB: fragments of the `in` tile
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lq = lane >> 4;
     const int n0 = blockIdx.x * WS_NW;
@@ -304,7 +322,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_split_kernel(const WsArgs a) {
     const bool gcol = n0 + 4 * pn < a.N, icol = 4 * pn < a.K;
     const float* gp = a.g + (gcol ? n0 + 4 * pn : 0);
     const float* ip = a.in + (icol ? 4 * pn : 0);
-    const int woff = ((pn >> 2) * SG_NP) * WS_FRAG + (pq * 16 + (pn & 3) * 4) * 16 + phi * 8;   // + jj * 16 (slot m = 4 (pn & 3) + jj of lane group pq) + piece * WS_FRAG
+    const int woff = ((pn >> 2) * NP) * WS_FRAG + (pq * 16 + (pn & 3) * 4) * 16 + phi * 8;   // + jj * 16 (slot m = 4 (pn & 3) + jj of lane group pq) + piece * WS_FRAG
     // two patch buffers: the loads of step i + 2 are issued when step i has been written to LDS (one step of MFMAs does not cover an HBM round trip)
     f32x4 gv[2][4], iv[2][4];
     auto load_patch = [&](int step, f32x4 (&gb)[4], f32x4 (&ib)[4]) {
@@ -319,17 +337,33 @@ __global__ void __launch_bounds__(256, 2) wgrad_split_kernel(const WsArgs a) {
         }
     };
     using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
-    auto write_patch = [&](const f32x4 (&v)[4], unsigned char* base) {
+    float g_scale = 1.f, in_scale = 1.f, out_scale = 1.f;
+    if constexpr (NP == 2) {
+        const float gm = *a.gmax;
+        int eg = 0;
+        if (gm > 0.f && gm < INFINITY) { eg = 14 - ilogbf(gm); eg = eg < -60 ? -60 : (eg > 60 ? 60 : eg); }
+        g_scale = ldexpf(1.f, eg); in_scale = ldexpf(1.f, a.in_exp); out_scale = ldexpf(1.f, -(eg + a.in_exp));
+    }
+    auto write_patch = [&](const f32x4 (&v)[4], unsigned char* base, float scale) {
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
-            unsigned a0, a1, a2, c0, c1, c2;
-            sg_split2(v[0][jj], v[1][jj], a0, a1, a2);
-            sg_split2(v[2][jj], v[3][jj], c0, c1, c2);
-            const u32x2 p0 = {a0, c0}, p1 = {a1, c1}, p2 = {a2, c2};
             unsigned char* w = base + woff + jj * 16;
-            *reinterpret_cast<u32x2*>(w) = p0;
-            *reinterpret_cast<u32x2*>(w + WS_FRAG) = p1;
-            *reinterpret_cast<u32x2*>(w + 2 * WS_FRAG) = p2;
+            if constexpr (NP == 3) {
+                unsigned a0, a1, a2, c0, c1, c2;
+                sg_split2(v[0][jj], v[1][jj], a0, a1, a2);
+                sg_split2(v[2][jj], v[3][jj], c0, c1, c2);
+                const u32x2 p0 = {a0, c0}, p1 = {a1, c1}, p2 = {a2, c2};
+                *reinterpret_cast<u32x2*>(w) = p0;
+                *reinterpret_cast<u32x2*>(w + WS_FRAG) = p1;
+                *reinterpret_cast<u32x2*>(w + 2 * WS_FRAG) = p2;
+            } else {
+                unsigned h0, l0, h1, l1;
+                ws_split16(v[0][jj] * scale, v[1][jj] * scale, h0, l0);
+                ws_split16(v[2][jj] * scale, v[3][jj] * scale, h1, l1);
+                const u32x2 p0 = {h0, h1}, p1 = {l0, l1};
+                *reinterpret_cast<u32x2*>(w) = p0;
+                *reinterpret_cast<u32x2*>(w + WS_FRAG) = p1;
+            }
         }
     };
     f32x4 acc[2][WS_TILES];
@@ -342,34 +376,46 @@ __global__ void __launch_bounds__(256, 2) wgrad_split_kernel(const WsArgs a) {
     const bool wave_live = n0 + 16 * (2 * wave) < a.N;             // wave-uniform: some column of this wave's two tiles exists
     auto one_step = [&](int step, f32x4 (&gb)[4], f32x4 (&ib)[4]) {
         __syncthreads();                                           // every wave has read the previous step's fragments
-        write_patch(gb, Gs);
-        write_patch(ib, Is);
+        write_patch(gb, Gs, g_scale);
+        write_patch(ib, Is, in_scale);
 #pragma unroll
         for (int j = 0; j < 4; ++j) bsum += gb[j];
         __syncthreads();
         if (step + 2 < steps) load_patch(step + 2, gb, ib);        // in flight behind two steps of MFMAs
         if (!wave_live) return;
-        sg_bf16x8 A[2][SG_NP];
+        sg_bf16x8 A[2][NP];
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int p = 0; p < SG_NP; ++p) A[t][p] = *reinterpret_cast<const sg_bf16x8*>(Gs + ((2 * wave + t) * SG_NP + p) * WS_FRAG + roff);
+            for (int p = 0; p < NP; ++p) A[t][p] = *reinterpret_cast<const sg_bf16x8*>(Gs + ((2 * wave + t) * NP + p) * WS_FRAG + roff);
         constexpr int KB = 2;                                      // k-tiles of `in` held at a time
 #pragma unroll
         for (int kh = 0; kh < WS_TILES / KB; ++kh) {
-            sg_bf16x8 Bf[KB][SG_NP];
+            sg_bf16x8 Bf[KB][NP];
 #pragma unroll
             for (int k = 0; k < KB; ++k)
 #pragma unroll
-                for (int p = 0; p < SG_NP; ++p) Bf[k][p] = *reinterpret_cast<const sg_bf16x8*>(Is + ((kh * KB + k) * SG_NP + p) * WS_FRAG + roff);
-            constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
+                for (int p = 0; p < NP; ++p) Bf[k][p] = *reinterpret_cast<const sg_bf16x8*>(Is + ((kh * KB + k) * NP + p) * WS_FRAG + roff);
+            if constexpr (NP == 3) {
+                constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
 #pragma unroll
-            for (int i = 0; i < 6; ++i)
+                for (int i = 0; i < 6; ++i)
 #pragma unroll
-                for (int k = 0; k < KB; ++k)
+                    for (int k = 0; k < KB; ++k)
 #pragma unroll
-                    for (int t = 0; t < 2; ++t)
-                        acc[t][kh * KB + k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[t][PA[i]], Bf[k][PB[i]], acc[t][kh * KB + k], 0, 0, 0);
+                        for (int t = 0; t < 2; ++t)
+                            acc[t][kh * KB + k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[t][PA[i]], Bf[k][PB[i]], acc[t][kh * KB + k], 0, 0, 0);
+            } else {
+                constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};   // lo x hi, hi x lo, hi x hi
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int k = 0; k < KB; ++k)
+#pragma unroll
+                        for (int t = 0; t < 2; ++t)
+                            acc[t][kh * KB + k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(ws_f16x8, A[t][PA[i]]), __builtin_bit_cast(ws_f16x8, Bf[k][PB[i]]),
+                                                                                       acc[t][kh * KB + k], 0, 0, 0);
+            }
         }
     };
     if (steps > 0) load_patch(0, gv[0], iv[0]);
@@ -387,7 +433,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_split_kernel(const WsArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int n = n0 + 16 * (2 * wave + t) + 4 * lq + r, kk = 16 * k + li;
-                if (n < a.N && kk < a.K) slab[(int64_t)n * a.K + kk] = acc[t][k][r];
+                if (n < a.N && kk < a.K) slab[(int64_t)n * a.K + kk] = NP == 2 ? acc[t][k][r] * out_scale : acc[t][k][r];
             }
     if (a.pb != nullptr) {                                         // column sums of g: this thread's 4 columns over its rows, then over the 8 row groups
         __syncthreads();
@@ -414,15 +460,18 @@ static int64_t ws_splits(int64_t B, int N) {
     return s < 1 ? 1 : s;
 }
 
-static int ws_wgrad(const float* g, int64_t gs, const float* in, int64_t is, int64_t B, int K, int N, float* pw, float* pb, void* stream) {
+static int ws_wgrad(const float* g, int64_t gs, const float* in, int64_t is, int64_t B, int K, int N, float* pw, float* pb, void* stream,
+                    const float* gmax = nullptr, int in_exp = 0) {
     if (!g || !in || !pw || !rows_ok(B) || !width_ok(K) || !width_ok(N)) return JF_ERR_BADARG;
     if (K > 128 || K % 4 || N % 4 || gs % 4 || is % 4 || ((reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(in)) & 15u)) return JF_ERR_UNSUPPORTED;
     if (B == 0) return JF_OK;
     WsArgs a{};
-    a.g = g; a.gs = gs; a.in = in; a.is = is; a.B = B; a.K = K; a.N = N; a.pw = pw; a.pb = pb;
+    a.g = g; a.gs = gs; a.in = in; a.is = is; a.B = B; a.K = K; a.N = N; a.pw = pw; a.pb = pb; a.gmax = gmax; a.in_exp = in_exp;
     const int64_t S = ws_splits(B, N);
     a.rows_per_split = ((B + S - 1) / S + 31) / 32 * 32;
-    hipLaunchKernelGGL(wgrad_split_kernel, dim3((unsigned)((N + WS_NW - 1) / WS_NW), (unsigned)S), dim3(256), 0, (hipStream_t)stream, a);
+    const dim3 grid((unsigned)((N + WS_NW - 1) / WS_NW), (unsigned)S);
+    if (gmax) hipLaunchKernelGGL(wgrad_split_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(wgrad_split_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, a);
     return check_launch();
 }
 
@@ -433,5 +482,10 @@ int64_t jf_linear_wgrad_split_splits(int64_t B, int32_t N) { return (jf::width_o
 int jf_linear_wgrad_split_f32(const float* g, int64_t g_stride, const float* in, int64_t in_stride, int64_t B, int32_t K, int32_t N, float* partial_w,
                               float* partial_b, void* stream) {
     return jf::ws_wgrad(g, g_stride, in, in_stride, B, K, N, partial_w, partial_b, stream);
+}
+int jf_linear_wgrad_split16_f32(const float* g, int64_t g_stride, const float* in, int64_t in_stride, int64_t B, int32_t K, int32_t N,
+                                const float* g_absmax, int32_t in_exp, float* partial_w, float* partial_b, void* stream) {
+    if (!g_absmax || in_exp < -60 || in_exp > 60) return JF_ERR_BADARG;
+    return jf::ws_wgrad(g, g_stride, in, in_stride, B, K, N, partial_w, partial_b, stream, g_absmax, in_exp);
 }
 }
