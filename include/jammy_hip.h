@@ -328,6 +328,18 @@ int jf_mlp2_f32(const float* in, int64_t in_stride, const float* W1, int64_t w1_
                 const float* b2, int64_t B, int32_t K1, int32_t H, int32_t N, float* out, int64_t out_stride, void* stream);
 int jf_mlp2_f64(const double* in, int64_t in_stride, const double* W1, int64_t w1_stride, const double* b1, const double* W2, int64_t w2_stride,
                 const double* b2, int64_t B, int32_t K1, int32_t H, int32_t N, double* out, int64_t out_stride, void* stream);
+/* jf_mlp2_f64 with the second product on the INT8 matrix cores (float64 matrix cores run at the float64 vector rate on MI355X: 2.94 ms per 2^20
+ * rows for the 128 -> 548 block of the benchmark configuration; int8 MFMA: 50x that rate, exact int32 accumulation).  h = tanh(..) in [-1, 1]
+ * and every row of W2 (scaled by its own power of two) are cut into `slices` balanced base-128 digits, the digit pairs (i, j) with
+ * i + j < slices are multiplied with v_mfma_i32_16x16x64_i8 and the levels i + j recombined in float64: an error-free product of the
+ * truncated operands.  slices = 6: operands kept to 2^-41, ~2e-12 |w|_max per output; slices = 5: 2^-34, ~3e-10.
+ * jf_mlp2_i8_packed_bytes / jf_mlp2_i8_pack_f64: size and contents of the digit image of W2 (N, H) / b2 (N; may be NULL) -- device memory,
+ * 16-byte aligned, rebuilt whenever the weights change.  jf_mlp2_i8_f64: arguments as jf_mlp2_f64 with the image in place of W2 / b2.
+ * K1 <= 28, H <= 128, otherwise JF_ERR_UNSUPPORTED.  Weights must be finite (the exact path propagates non-finite weights, this one cannot). */
+int64_t jf_mlp2_i8_packed_bytes(int32_t N, int32_t slices);
+int jf_mlp2_i8_pack_f64(const double* W2, int64_t w2_stride, const double* b2, int32_t H, int32_t N, int32_t slices, void* packed, void* stream);
+int jf_mlp2_i8_f64(const double* in, int64_t in_stride, const double* W1, int64_t w1_stride, const double* b1, const void* packed, int64_t B,
+                   int32_t K1, int32_t H, int32_t N, int32_t slices, double* out, int64_t out_stride, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * 't' affine flow / multivariate normal (replaces mvn_block._inv_flow_mapping / _flow_mapping + the euclidean_base offset:

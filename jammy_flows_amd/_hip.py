@@ -147,6 +147,9 @@ _SIGNATURES_SINGLE = {
     "jf_gf_chain_inv_bwd_partials": ([_I64, _I32], ctypes.c_int64),
     "jf_linear_split_packed_bytes": ([_I32, _I32], ctypes.c_int64),
     "jf_mlp2_small_bwd_slabs": ([_I64], ctypes.c_int64),
+    "jf_mlp2_i8_packed_bytes": ([_I32, _I32], ctypes.c_int64),
+    "jf_mlp2_i8_pack_f64": ([_P, _I64, _P, _I32, _I32, _I32, _P, _P], ctypes.c_int),
+    "jf_mlp2_i8_f64": ([_P, _I64, _P, _I64, _P, _P, _I64, _I32, _I32, _I32, _I32, _P, _I64, _P], ctypes.c_int),
     "jf_linear_wgrad_split_splits": ([_I64, _I32], ctypes.c_int64),
     "jf_linear_wgrad_split_f32": ([_P, _I64, _P, _I64, _I64, _I32, _I32, _P, _P, _P], ctypes.c_int),
     "jf_linear_split_pack_f32": ([_P, _I64, _I64, _I32, _I32, _P, _P], ctypes.c_int),
@@ -1191,4 +1194,40 @@ def mlp2(inp, w1, b1, w2, b2, out=None):
     _launch("jf_mlp2" + _suffix(inp), "K%d_H%d_N%d" % (K1, H, N),
             (_ptr(inp), inp.stride(0), _ptr(w1), w1.stride(0), _ptr(b1.contiguous()), _ptr(w2), w2.stride(0), _ptr(b2.contiguous()), B, K1, H, N,
              _ptr(out), out.stride(0)), dev)
+    return out
+
+
+MLP2_I8_MAX_IN, MLP2_I8_MAX_HIDDEN = 28, 128
+
+
+def mlp2_i8_pack(w2, b2, slices=6):
+    """W2 (N, H) / b2 (N,) float64 -> the int8 digit image mlp2_i8 streams (csrc/mlp_i8_kernels.hip).  Redo whenever the weights change."""
+    dev = require_device(w2, b2)
+    w2 = _rowmajor(w2)
+    if w2.dtype != torch.float64 or b2.dtype != torch.float64:
+        raise TypeError("mlp2_i8_pack: float64 only")
+    N, H = w2.shape
+    nbytes = int(lib().jf_mlp2_i8_packed_bytes(N, slices))
+    _check(min(nbytes, 0), "jf_mlp2_i8_packed_bytes")
+    packed = torch.empty((nbytes,), dtype=torch.uint8, device=w2.device)
+    _launch("jf_mlp2_i8_pack_f64", "x%d" % slices, (_ptr(w2), w2.stride(0), _ptr(b2.contiguous()), H, N, slices, _ptr(packed)), dev)
+    return packed
+
+
+def mlp2_i8(inp, w1, b1, packed, N, slices=6, out=None):
+    """mlp2 in float64 with the second product as int8 digit-slice products on the matrix cores; `packed` = mlp2_i8_pack(w2, b2, slices)."""
+    dev = require_device(inp, w1, b1, packed, out)
+    inp, w1 = _rowmajor(inp), _rowmajor(w1)
+    B, K1 = inp.shape
+    H = w1.shape[0]
+    if w1.shape[1] != K1 or b1.shape[0] != H:
+        raise ValueError("mlp2_i8: inconsistent shapes")
+    if any(t.dtype != torch.float64 for t in (inp, w1, b1)) or packed.dtype != torch.uint8:
+        raise TypeError("mlp2_i8: float64 inputs and a uint8 packed image expected")
+    if packed.numel() != int(lib().jf_mlp2_i8_packed_bytes(N, slices)):
+        raise ValueError("mlp2_i8: the packed image does not belong to N = %d, slices = %d" % (N, slices))
+    if out is None:
+        out = torch.empty((B, (N + 15) // 16 * 16), dtype=inp.dtype, device=inp.device)[:, :N]      # rows of whole 128-byte lines (see mlp2)
+    _launch("jf_mlp2_i8_f64", "K%d_H%d_N%d_x%d" % (K1, H, N, slices),
+            (_ptr(inp), inp.stride(0), _ptr(w1), w1.stride(0), _ptr(b1.contiguous()), _ptr(packed), B, K1, H, N, slices, _ptr(out), out.stride(0)), dev)
     return out

@@ -22,6 +22,14 @@ from ..flow_options import canonical, check_flow_option, layer_class, obtain_def
 from ..layers.euclidean import gaussianization_flow as gfl
 
 
+# float64 amortisation MLPs with a wide output: "i8x6" / "i8x5" = second product as int8 digit-slice products (operands kept to 2^-41 / 2^-34,
+# csrc/mlp_i8_kernels.hip), "f64" = jf_mlp2_f64 on the float64 matrix cores.  A one-element list so that tests and benchmarks can switch it.
+MLP_MATRIX_ARITHMETIC_F64 = [os.environ.get("JF_MLP_MATRIX_ARITHMETIC_F64", "i8x6")]
+MLP_I8_MIN_ROWS, MLP_I8_MIN_COLS = [4096], [128]         # below these the exact kernel costs microseconds and the digit image is not worth building
+if MLP_MATRIX_ARITHMETIC_F64[0] not in ("i8x6", "i8x5", "f64"):
+    raise ValueError("JF_MLP_MATRIX_ARITHMETIC_F64 must be 'i8x6', 'i8x5' or 'f64', got %r" % MLP_MATRIX_ARITHMETIC_F64[0])
+
+
 class HipLinearStack(nn.Sequential):
     """nn.Sequential(Linear, Tanh, ..., Linear) of the default amortisation MLP (:656-670) -- identical module names, so the
     reference's ``mlp_predictors.N.{0,2,..}.{weight,bias}`` state loads -- evaluated with the MFMA dense kernel (tanh fused)."""
@@ -52,6 +60,22 @@ class HipLinearStack(nn.Sequential):
             if ps[0].dtype != x.dtype:
                 ps = [p.to(x.dtype) for p in ps]
             ps = [p.detach() for p in ps]
+            if (x.dtype == torch.float64 and MLP_MATRIX_ARITHMETIC_F64[0] != "f64" and ps[2].shape[0] >= MLP_I8_MIN_COLS[0]
+                    and x.shape[0] >= MLP_I8_MIN_ROWS[0] and mods[0].in_features <= _hip.MLP2_I8_MAX_IN):
+                # wide float64 output (the 548-column parameter block of an e4 block): the float64 matrix cores run at the float64 vector rate, so
+                # the second product goes to the int8 matrix cores as an error-free product of digit slices (csrc/mlp_i8_kernels.hip: 2.9 -> 1.2 ms
+                # per 2^20 rows of the C3 block); the digit image of the weights is rebuilt when they change
+                slices = 6 if MLP_MATRIX_ARITHMETIC_F64[0] == "i8x6" else 5
+                lin = mods[2]
+                key = (lin.weight._version, lin.weight.data_ptr(), lin.bias._version, lin.bias.data_ptr(), str(lin.weight.device), slices)
+                hit = getattr(self, "_i8_image", None)
+                if hit is None or hit[0] != key:
+                    # non-finite weights cannot be cut into digits: they take the exact path, which propagates them
+                    ok = bool(torch.isfinite(ps[2]).all()) and bool(torch.isfinite(ps[3]).all())
+                    hit = (key, _hip.mlp2_i8_pack(ps[2], ps[3], slices) if ok else None)
+                    self._i8_image = hit
+                if hit[1] is not None:
+                    return _hip.mlp2_i8(x, ps[0], ps[1], hit[1], ps[2].shape[0], slices)
             if x.dtype == torch.float32 and ps[2].shape[0] >= 256 and x.shape[0] >= 4096:
                 # wide float32 output (the 548-column parameter block of an e4 block: sampling, the two-launch log-prob path): the second layer on
                 # split-bf16 MFMA (jf_linear_split_f32, 0.23 ms per 2^18 rows) after a streaming first layer beats the fused exact-f32 MFMA launch
