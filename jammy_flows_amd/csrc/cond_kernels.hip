@@ -280,7 +280,7 @@ static int cond_gf_chain_inv(const T* in, int64_t in_stride, const T* W1, int64_
     for (int l = 0; l < n_layers; ++l) {
         const jf_gf_layer& h = layers[l];
         GfLayerDev<T>& o = a.L[l];
-        if (h.num_kde < 1 || h.hh_iter < 0 || h.width_min <= 0) return JF_ERR_BADARG;
+        if (h.num_kde < 1 || h.num_kde > (1 << 16) || h.hh_iter < 0 || h.hh_iter > (1 << 16) || h.width_min <= 0) return JF_ERR_BADARG;   // (bounded: the column offsets below are ints)
         if (h.rotation_mode != JF_GF_ROT_HOUSEHOLDER || h.center_mean || h.add_skewness) return JF_ERR_UNSUPPORTED;   // general-option layers: jf_gf_chain_inv only
         if (h.width_mode == JF_GF_WIDTH_SMOOTH_SATURATION && h.width_max <= 0) return JF_ERR_BADARG;
         if (h.nonlinear_stretch_type != JF_GF_STRETCH_CLASSIC) return JF_ERR_UNSUPPORTED;     // per-lane knot tables do not fit beside the tiles

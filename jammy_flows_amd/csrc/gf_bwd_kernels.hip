@@ -683,7 +683,7 @@ template <typename T> static int gb_fill(GfBwdArgs<T>& a, const T* params, int64
     for (int l = 0; l < n_layers; ++l) {
         const jf_gf_layer& h = layers[l];
         GfLayerDev<T>& o = a.L[l];
-        if (h.num_kde < 1 || h.hh_iter < 0 || h.width_min <= 0) return JF_ERR_BADARG;
+        if (h.num_kde < 1 || h.num_kde > (1 << 16) || h.hh_iter < 0 || h.hh_iter > (1 << 16) || h.width_min <= 0) return JF_ERR_BADARG;   // (bounded: the column offsets below are ints)
         const bool ext_layer = h.rotation_mode != JF_GF_ROT_HOUSEHOLDER || h.center_mean || h.add_skewness;     // general-option layer (jf_gf_ext.h)
         if (h.rotation_mode < JF_GF_ROT_HOUSEHOLDER || h.rotation_mode > JF_GF_ROT_TRIANGULAR || (h.rotation_mode == JF_GF_ROT_CAYLEY && D > 2)) return JF_ERR_BADARG;
         if (h.add_skewness && sizeof(T) != 8) return JF_ERR_UNSUPPORTED;                                        // float64 only, as the forward

@@ -358,7 +358,7 @@ template <typename T> static int fill_args(GfChainArgs<T>& a, const T* params, i
     for (int l = 0; l < n_layers; ++l) {
         const jf_gf_layer& h = layers[l];
         GfLayerDev<T>& o = a.L[l];
-        if (h.num_kde < 1 || h.hh_iter < 0 || h.width_min <= 0) return JF_ERR_BADARG;
+        if (h.num_kde < 1 || h.num_kde > (1 << 16) || h.hh_iter < 0 || h.hh_iter > (1 << 16) || h.width_min <= 0) return JF_ERR_BADARG;   // (bounded: the column offsets below are ints)
         if (h.width_mode == JF_GF_WIDTH_SMOOTH_SATURATION && h.width_max <= 0) return JF_ERR_BADARG;
         o.K = h.num_kde; o.hh = h.hh_iter; o.model_offset = h.model_offset; o.fit_norm = h.fit_normalization;
         o.reg_norm = h.regulate_normalization; o.inv_type = h.inverse_function_type; o.width_mode = h.width_mode;
