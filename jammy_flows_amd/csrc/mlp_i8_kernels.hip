@@ -52,13 +52,6 @@ template <int S> __device__ __forceinline__ void ci_digits(double v, int (&d)[S]
         r = (r - q) * 128.0;
     }
 }
-// tanh to an ABSOLUTE error of ~2e-16 (the digits are cut on an absolute grid, so the relative accuracy of M<double>::tanh_fast for small
-// arguments -- expm1 and a full division, twice the instructions -- buys nothing here): (1 - t) / (1 + t), t = e^{-2 |x|}
-__device__ __forceinline__ double ci_tanh(double x) {
-    const double t = ::exp(-2.0 * fabs(x));
-    const double h = (1.0 - t) * M<double>::rcp(1.0 + t);
-    return x < 0.0 ? -h : (x == x ? h : x);
-}
 __device__ __forceinline__ int ci_pack4(int a, int b, int c, int d) {
     return (a & 0xff) | ((b & 0xff) << 8) | ((c & 0xff) << 16) | (d << 24);
 }
@@ -202,7 +195,7 @@ __device__ __forceinline__ void ci_hidden(const CiArgs& a, int64_t row0, int64_t
             const int j = 4 * s + g;
             int d[4][S];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) ci_digits<S>(ci_tanh(acc[g][r] + b1s[j * MT + lq + 4 * r]), d[r]);
+            for (int r = 0; r < 4; ++r) ci_digits<S>(M<double>::tanh_fast(acc[g][r] + b1s[j * MT + lq + 4 * r]), d[r]);
 #pragma unroll
             for (int i = 0; i < S; ++i) hd[s][i][g] = ci_pack4(d[0][i], d[1][i], d[2][i], d[3][i]);
         }

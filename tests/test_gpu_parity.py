@@ -506,9 +506,17 @@ def _tiled_run(fx, dtype, log2_rows, launches=3):
     cond = to_dev(np.tile(fx["cond"], (reps, 1))[:big], dtype) if fx.get("cond") is not None else None
     emb = bool(fx.meta["embedding"])
     pdf.check_status = False
+    from jammy_flows_amd.main import default as jf_default
+    prev = jf_default.MLP_I8_MIN_ROWS[0]
     with torch.no_grad():
         runs = [pdf(x, conditional_input=cond, force_embedding_coordinates=emb)[0].cpu().numpy() for _ in range(launches)]
-        small = pdf(x[:n], conditional_input=None if cond is None else cond[:n], force_embedding_coordinates=emb)[0].cpu().numpy()
+        try:
+            # float64: the big batch takes its wide amortisation MLPs through the int8 digit-slice kernel; the small batch must use the same
+            # arithmetic to be comparable at 1e-12 (the two kernels agree to ~3e-12 of log p, tests/test_gpu_mlp_i8.py)
+            jf_default.MLP_I8_MIN_ROWS[0] = 1
+            small = pdf(x[:n], conditional_input=None if cond is None else cond[:n], force_embedding_coordinates=emb)[0].cpu().numpy()
+        finally:
+            jf_default.MLP_I8_MIN_ROWS[0] = prev
     return runs, small, reps, n, big
 
 
