@@ -122,6 +122,7 @@ _SIGNATURES = {
     "jf_mlp_hidden_bwd": [_P, _I64, _P, _I64, _P, _P, _I64, _I64, _I32, _I32, _P, _P],
     "jf_mlp2_small_bwd": [_P, _I64, _P, _I64, _P, _P, _I64, _P, _I64, _I64, _I32, _I32, _I32, _P, _P, _P],
     "jf_activation": [_P, _I64, _I32, _P, _P],
+    "jf_device_math": [_P, _I64, _I32, _P, _P],
     "jf_activation_bwd": [_P, _P, _I64, _I32, _P, _P],
     "jf_mlp2": [_P, _I64, _P, _I64, _P, _P, _I64, _P, _I64, _I32, _I32, _I32, _P, _I64, _P],
     "jf_sphere_to_embedding": [_P, _I64, _P, _I64, _I32, _P, _I64, _P, _P],
@@ -1194,6 +1195,18 @@ def mlp2(inp, w1, b1, w2, b2, out=None):
     _launch("jf_mlp2" + _suffix(inp), "K%d_H%d_N%d" % (K1, H, N),
             (_ptr(inp), inp.stride(0), _ptr(w1), w1.stride(0), _ptr(b1.contiguous()), _ptr(w2), w2.stride(0), _ptr(b2.contiguous()), B, K1, H, N,
              _ptr(out), out.stride(0)), dev)
+    return out
+
+
+MATH_EXP_FAST, MATH_LOG_FAST, MATH_TANH_FAST, MATH_RCP, MATH_EXP_TABLE = 0, 1, 2, 3, 4
+
+
+def device_math(x, fn):
+    """elementwise M<T>::{exp_fast, log_fast, tanh_fast, rcp} of the flow kernels (csrc/jf_math.h) -- for accuracy tests"""
+    dev = require_device(x)
+    x = x.contiguous()
+    out = torch.empty_like(x)
+    _launch("jf_device_math" + _suffix(x), "", (_ptr(x), x.numel(), fn, _ptr(out)), dev)
     return out
 
 

@@ -245,9 +245,26 @@ template <typename T, bool BWD> static int activation(const T* g, const T* z, in
     return check_launch();
 }
 
+// the scalar math policy of the flow kernels (jf_math.h), elementwise: what tests/test_gpu_math.py measures against torch
+template <typename T> __global__ void __launch_bounds__(256) math_kernel(const T* __restrict__ x, int64_t n, int fn, T* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const T v = x[i];
+    out[i] = fn == JF_MATH_EXP_FAST ? M<T>::exp_fast(v) : fn == JF_MATH_LOG_FAST ? M<T>::log_fast(v) : fn == JF_MATH_TANH_FAST ? M<T>::tanh_fast(v)
+           : fn == JF_MATH_RCP ? M<T>::rcp(v) : M<T>::exp_table(v);
+}
+template <typename T> static int device_math(const T* x, int64_t n, int fn, T* out, void* stream) {
+    if (!x || !out || n < 0 || fn < JF_MATH_EXP_FAST || fn > JF_MATH_EXP_TABLE) return JF_ERR_BADARG;
+    if (n == 0) return JF_OK;
+    hipLaunchKernelGGL((math_kernel<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, n, fn, out);
+    return check_launch();
+}
+
 }  // namespace jf
 
 extern "C" {
+int jf_device_math_f32(const float* x, int64_t n, int32_t fn, float* out, void* s) { return jf::device_math<float>(x, n, fn, out, s); }
+int jf_device_math_f64(const double* x, int64_t n, int32_t fn, double* out, void* s) { return jf::device_math<double>(x, n, fn, out, s); }
 int jf_conditioning_rows_f32(const jf_cond_segment* g, int32_t n, int64_t B, float* out, int64_t os, void* s) {
     return jf::conditioning_rows<float>(g, n, B, out, os, s);
 }

@@ -32,4 +32,9 @@ done
   echo '## C5 conditional `pdf("e8+s2","gggg+v")`, AmortizableMLP rank 8, float64, 2^17 rows'; echo; echo '```'
   grep -v "Warn\|amdgpu.ids\|args.workload\|Consider" gpurun_out/prof_train_c5/bench_train.txt; echo '```'; echo
   head -24 gpurun_out/prof_train_c5/kernel_stats.md | tail -22; } > profiles/r03_train.md
+{ echo "# Float64 C3 step — \`rocprofv3 --kernel-trace --stats -- python3 scripts/probe/stress.py c3_e4s2e4 f64 30\` (round 3, 2^20 rows)"; echo
+  head -14 gpurun_out/prof_r03_c3_f64/kernel_stats.md; echo
+  echo 'SQ / HBM counters per launch (separate `--pmc` passes; FETCH_SIZE / WRITE_SIZE in raw KB):'; echo; echo '```'
+  cat gpurun_out/prof_r03_c3_f64/pmc.txt; echo '```'; } > profiles/r03_c3_f64.md
+cp gpurun_out/bench_configs_r03.txt profiles/r03_bench_configs.txt
 ls profiles | grep r03
