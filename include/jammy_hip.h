@@ -567,13 +567,11 @@ int jf_activation_f64(const double* z, int64_t n, int32_t code, double* out, voi
 int jf_activation_bwd_f32(const float* g, const float* z, int64_t n, int32_t code, float* out, void* stream);
 int jf_activation_bwd_f64(const double* g, const double* z, int64_t n, int32_t code, double* out, void* stream);
 /* The device math functions the flow kernels are built on (csrc/jf_math.h), elementwise -- so that their accuracy can be measured from the
- * host: exp_fast, log_fast, tanh_fast (hidden layers: absolute accuracy), rcp, exp_table (float64: the table-driven exp of the broadcast `g`
- * kernel, <= 1 ulp; float32: v_exp_f32 like exp_fast). */
+ * host: exp_fast (float32: v_exp_f32), log_fast, tanh_fast (hidden layers: absolute accuracy), rcp. */
 #define JF_MATH_EXP_FAST 0
 #define JF_MATH_LOG_FAST 1
 #define JF_MATH_TANH_FAST 2
 #define JF_MATH_RCP 3
-#define JF_MATH_EXP_TABLE 4
 int jf_device_math_f32(const float* x, int64_t n, int32_t fn, float* out, void* stream);
 int jf_device_math_f64(const double* x, int64_t n, int32_t fn, double* out, void* stream);
 

@@ -1198,7 +1198,7 @@ def mlp2(inp, w1, b1, w2, b2, out=None):
     return out
 
 
-MATH_EXP_FAST, MATH_LOG_FAST, MATH_TANH_FAST, MATH_RCP, MATH_EXP_TABLE = 0, 1, 2, 3, 4
+MATH_EXP_FAST, MATH_LOG_FAST, MATH_TANH_FAST, MATH_RCP = 0, 1, 2, 3
 
 
 def device_math(x, fn):

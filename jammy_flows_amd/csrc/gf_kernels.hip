@@ -236,7 +236,7 @@ template <typename T, int D> __global__ void __launch_bounds__(256) gfb_chain_in
                 for (int k = 0; k < o.K; ++k) {
                     const GfPack<T> e = pd[k];
                     const T u = (x[d] - e.mean) * e.iw;
-                    const T tt = M<T>::exp_table(-M<T>::abs(u));                 // float64: table-driven (jf_math.h), one per component
+                    const T tt = M<T>::exp_fast(-M<T>::abs(u));
                     const T hi = M<T>::rcp(T(1) + tt);     // sigma(|u|)
                     const T lo = tt * hi;                  // sigma(-|u|)
                     const bool pos = u >= T(0);

@@ -3,7 +3,7 @@
 //  float : hardware transcendentals (v_exp_f32 / v_log_f32 / v_rcp_f32, quarter-rate on CDNA4) on the hot
 //          linear-space path -- the fp32 bar is |dlogp| < 1e-2 against the fp64 reference, these are ~1e-6;
 //          accurate OCML functions on the rare log-space (tail) path and in the iterative solvers.
-//  double: OCML double functions, except log_fast, rcp, tanh_fast and the table-driven exp of the broadcast kernel (below);
+//  double: OCML double functions, except log_fast, rcp and tanh_fast (below);
 //          fp64 bar: |dlogp| < 1e-4, measured ~2e-8.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -13,26 +13,6 @@ namespace jf {
 
 template <typename T> struct M;
 
-// 2^(j/64), j = 0..63, nearest doubles: the table of M<double>::exp_table.  One 512-byte copy per translation unit in constant memory (four
-// cache lines, resident in every CU's vector L1 after the first touch).
-static __constant__ double JF_EXP2_64[64] = {
-    0x1.0000000000000p+0, 0x1.02c9a3e778061p+0, 0x1.059b0d3158574p+0, 0x1.0874518759bc8p+0,
-    0x1.0b5586cf9890fp+0, 0x1.0e3ec32d3d1a2p+0, 0x1.11301d0125b51p+0, 0x1.1429aaea92de0p+0,
-    0x1.172b83c7d517bp+0, 0x1.1a35beb6fcb75p+0, 0x1.1d4873168b9aap+0, 0x1.2063b88628cd6p+0,
-    0x1.2387a6e756238p+0, 0x1.26b4565e27cddp+0, 0x1.29e9df51fdee1p+0, 0x1.2d285a6e4030bp+0,
-    0x1.306fe0a31b715p+0, 0x1.33c08b26416ffp+0, 0x1.371a7373aa9cbp+0, 0x1.3a7db34e59ff7p+0,
-    0x1.3dea64c123422p+0, 0x1.4160a21f72e2ap+0, 0x1.44e086061892dp+0, 0x1.486a2b5c13cd0p+0,
-    0x1.4bfdad5362a27p+0, 0x1.4f9b2769d2ca7p+0, 0x1.5342b569d4f82p+0, 0x1.56f4736b527dap+0,
-    0x1.5ab07dd485429p+0, 0x1.5e76f15ad2148p+0, 0x1.6247eb03a5585p+0, 0x1.6623882552225p+0,
-    0x1.6a09e667f3bcdp+0, 0x1.6dfb23c651a2fp+0, 0x1.71f75e8ec5f74p+0, 0x1.75feb564267c9p+0,
-    0x1.7a11473eb0187p+0, 0x1.7e2f336cf4e62p+0, 0x1.82589994cce13p+0, 0x1.868d99b4492edp+0,
-    0x1.8ace5422aa0dbp+0, 0x1.8f1ae99157736p+0, 0x1.93737b0cdc5e5p+0, 0x1.97d829fde4e50p+0,
-    0x1.9c49182a3f090p+0, 0x1.a0c667b5de565p+0, 0x1.a5503b23e255dp+0, 0x1.a9e6b5579fdbfp+0,
-    0x1.ae89f995ad3adp+0, 0x1.b33a2b84f15fbp+0, 0x1.b7f76f2fb5e47p+0, 0x1.bcc1e904bc1d2p+0,
-    0x1.c199bdd85529cp+0, 0x1.c67f12e57d14bp+0, 0x1.cb720dcef9069p+0, 0x1.d072d4a07897cp+0,
-    0x1.d5818dcfba487p+0, 0x1.da9e603db3285p+0, 0x1.dfc97337b9b5fp+0, 0x1.e502ee78b3ff6p+0,
-    0x1.ea4afa2a490dap+0, 0x1.efa1bee615a27p+0, 0x1.f50765b6e4540p+0, 0x1.fa7c1819e90d8p+0,
-};
 
 
 template <> struct M<float> {
@@ -45,7 +25,6 @@ template <> struct M<float> {
     static constexpr float EPS_S1 = 1e-5f;      // sphere_base.sphere_to_plane float32 clamp
     static constexpr float KAPPA_ID = 1e-4f;    // fvm_2d small-kappa identity switch (float32)
     static __device__ __forceinline__ float exp_fast(float x) { return __expf(x); }
-    static __device__ __forceinline__ float exp_table(float x) { return __expf(x); }
     static __device__ __forceinline__ float log_fast(float x) { return 0.69314718056f * __builtin_amdgcn_logf(x); }   // v_log_f32 (normal-range inputs only)
     static __device__ __forceinline__ float sqrt_fast(float x) { return __builtin_amdgcn_sqrtf(x); }
     static __device__ __forceinline__ float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
@@ -81,29 +60,6 @@ template <> struct M<double> {
     static constexpr double EPS_S1 = 1e-8;
     static constexpr double KAPPA_ID = 1e-8;
     static __device__ __forceinline__ double exp_fast(double x) { return ::exp(x); }
-    // e^x with a table: x = k ln2/64 + r, |r| <= ln2/128, e^x = 2^(k >> 6) 2^((k & 63)/64) (1 + r + r^2 (1/2 + r/6 + r^2/24 + r^3/120)) -- the
-    // degree-5 tail is below 3.5e-17 -- with the reduction in two fused multiply-adds (ln2/64 split into a 32-bit head, exact against
-    // |k| < 2^17, and a tail).  21 instructions and one 8-byte read against the 42 of OCML's table-free exp; <= 1 ulp measured against torch.exp
-    // (tests/test_gpu_math.py); exp(-inf) = 0, exp(inf) = inf, exp(nan) = nan, gradual underflow through v_ldexp_f64.
-    // Used where exponentials are SPARSE in the instruction stream -- the broadcast `g` kernel (one per component, lane = row): 0.72 -> 0.51 ms
-    // per 2^20 rows of the e4 block.  NOT the general exp_fast: where a lane evaluates 30 exponentials per coordinate and layer (per-sample
-    // parameters) the vector L1 serialises every wave's 64 distinct table addresses and the kernel got slower (1.35 -> 1.77 ms), and a
-    // conflict-free 16-entry LDS table (staged by every kernel) only broke even (1.41 ms; C5 block 1.26 -> 1.32): those kernels are bound by
-    // the latency of their dependent float64 chains at two waves per SIMD, not by instruction count.
-    static __device__ __forceinline__ double exp_table(double x) {
-        const double xc = ::fmin(::fmax(x, -746.0), 710.0);                  // keeps the reduction finite (nan: restored below)
-        const double kd = __builtin_rint(xc * 92.332482616893656877);        // 64 / ln 2
-        double r = ::fma(kd, -0x1.62e42fee00000p-7, xc);
-        r = ::fma(kd, -0x1.a39ef35793c76p-39, r);
-        const int ki = (int)kd;
-        const double t = JF_EXP2_64[ki & 63];
-        double q = ::fma(r, 8.3333333333333332e-03, 4.1666666666666664e-02);
-        q = ::fma(r, q, 1.6666666666666666e-01);
-        q = ::fma(r, q, 0.5);
-        const double p = ::fma(r * r, q, r);
-        const double res = ::ldexp(::fma(t, p, t), ki >> 6);
-        return x != x ? x : res;
-    }
     // Natural logarithm for the mixture sums (three per coordinate and layer; OCML's log is 98 VALU instructions, this one ~40): the classic
     // reduction x = 2^e m, m in [sqrt(1/2), sqrt(2)), f = m - 1, s = f / (2 + f), log m = f - f^2/2 + s (f^2/2 + R(s^2)) with the degree-7 even
     // minimax polynomial R of FreeBSD msun's e_log.c (public domain constants Lg1..Lg7), < 1 ulp.  The division is rcp() above.

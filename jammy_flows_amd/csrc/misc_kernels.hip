@@ -250,11 +250,10 @@ template <typename T> __global__ void __launch_bounds__(256) math_kernel(const T
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const T v = x[i];
-    out[i] = fn == JF_MATH_EXP_FAST ? M<T>::exp_fast(v) : fn == JF_MATH_LOG_FAST ? M<T>::log_fast(v) : fn == JF_MATH_TANH_FAST ? M<T>::tanh_fast(v)
-           : fn == JF_MATH_RCP ? M<T>::rcp(v) : M<T>::exp_table(v);
+    out[i] = fn == JF_MATH_EXP_FAST ? M<T>::exp_fast(v) : fn == JF_MATH_LOG_FAST ? M<T>::log_fast(v) : fn == JF_MATH_TANH_FAST ? M<T>::tanh_fast(v) : M<T>::rcp(v);
 }
 template <typename T> static int device_math(const T* x, int64_t n, int fn, T* out, void* stream) {
-    if (!x || !out || n < 0 || fn < JF_MATH_EXP_FAST || fn > JF_MATH_EXP_TABLE) return JF_ERR_BADARG;
+    if (!x || !out || n < 0 || fn < JF_MATH_EXP_FAST || fn > JF_MATH_RCP) return JF_ERR_BADARG;
     if (n == 0) return JF_OK;
     hipLaunchKernelGGL((math_kernel<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, n, fn, out);
     return check_launch();
