@@ -313,7 +313,7 @@ static int ci_mlp2(const double* in, int64_t in_stride, const double* W1, int64_
     if (!in || !W1 || !b1 || !packed || !out || !ci_slices_ok(S)) return JF_ERR_BADARG;
     if (!width_ok(K1) || !width_ok(H) || !width_ok(N) || !rows_ok(B)) return JF_ERR_BADARG;
     if (K1 > CS_K1MAX || H > CS_HMAX || (reinterpret_cast<uintptr_t>(packed) & 15u)) return JF_ERR_UNSUPPORTED;
-    if (os < N || os > (1 << 21)) return JF_ERR_UNSUPPORTED;       // 32-bit byte offsets inside a workgroup's 128 rows
+    if (os < N || os > (1 << 20)) return JF_ERR_UNSUPPORTED;       // 31-bit byte counts inside a workgroup's 128 rows
     if (B == 0) return JF_OK;
     const CiArgs a{in, in_stride, W1, w1s, b1, static_cast<const unsigned char*>(packed), K1, H, N, B, out, os};
     return S == 6 ? ci_launch<6>(a, (hipStream_t)stream) : ci_launch<5>(a, (hipStream_t)stream);

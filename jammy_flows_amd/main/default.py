@@ -60,7 +60,7 @@ class HipLinearStack(nn.Sequential):
             if ps[0].dtype != x.dtype:
                 ps = [p.to(x.dtype) for p in ps]
             ps = [p.detach() for p in ps]
-            if (x.dtype == torch.float64 and MLP_MATRIX_ARITHMETIC_F64[0] != "f64" and ps[2].shape[0] >= MLP_I8_MIN_COLS[0]
+            if (x.dtype == torch.float64 and MLP_MATRIX_ARITHMETIC_F64[0] != "f64" and MLP_I8_MIN_COLS[0] <= ps[2].shape[0] <= (1 << 20)
                     and x.shape[0] >= MLP_I8_MIN_ROWS[0] and mods[0].in_features <= _hip.MLP2_I8_MAX_IN):
                 # wide float64 output (the 548-column parameter block of an e4 block): the float64 matrix cores run at the float64 vector rate, so
                 # the second product goes to the int8 matrix cores as an error-free product of digit slices (csrc/mlp_i8_kernels.hip: 2.9 -> 1.2 ms
