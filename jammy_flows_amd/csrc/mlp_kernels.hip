@@ -70,18 +70,22 @@ __device__ __forceinline__ void stage_chunk(T* __restrict__ dst, const T* __rest
     }
 }
 
-template <typename T>
+// BNT: output columns per workgroup tile.  BN (64) in general; ONE mfma column tile (16 for float64, 32 for float32) when the whole output is
+// that narrow -- g_params (B, 1224) @ U2 (1224, 8) of the low-rank AmortizableMLP's backward spent 8x the float64 matrix work on padding
+// columns and was bound by it (0.445 ms per 2^17 rows; the 1.28 GB it reads take 0.25 ms).
+template <typename T, int BNT = BN>
 __global__ void __launch_bounds__(256) linear_kernel(const T* __restrict__ in, int64_t in_stride, const T* __restrict__ W, int64_t w_stride,
                                                      const T* __restrict__ bias, int64_t B, int K, int N, int act, T* __restrict__ out,
                                                      int64_t out_stride) {
     using MF = Mfma<T>;
     constexpr int MT = MF::MT, KS = MF::KS, NREG = MF::NREG;
-    constexpr int TM = WM / MT, TN = WN / MT;   // mfma tiles per wave
+    constexpr int TM = WM / MT, TN = BNT / MT;   // mfma tiles per wave
+    static_assert(BNT % MT == 0 && BNT >= MT, "whole mfma column tiles");
     __shared__ T As[BM * LDP];
-    __shared__ T Ws[BN * LDP];
+    __shared__ T Ws[BNT * LDP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n_tiles = (N + BN - 1) / BN;                 // 1-D grid, N tile is the fast index: the blocks that share an activation
-    const int col0 = (int)(blockIdx.x % n_tiles) * BN;     // tile are dispatched back to back and find it in L2
+    const int n_tiles = (N + BNT - 1) / BNT;               // 1-D grid, N tile is the fast index: the blocks that share an activation
+    const int col0 = (int)(blockIdx.x % n_tiles) * BNT;    // tile are dispatched back to back and find it in L2
     const int64_t row0 = (int64_t)(blockIdx.x / n_tiles) * BM;
     const bool vec_in = (K % Vec16<T>::N == 0) && (in_stride % Vec16<T>::N == 0) && ((reinterpret_cast<uintptr_t>(in) & 15u) == 0);
     const bool vec_w = (K % Vec16<T>::N == 0) && (w_stride % Vec16<T>::N == 0) && ((reinterpret_cast<uintptr_t>(W) & 15u) == 0);
@@ -100,7 +104,7 @@ __global__ void __launch_bounds__(256) linear_kernel(const T* __restrict__ in, i
         __syncthreads();
         // stage the A chunk [BM x KC] and the W chunk [BN x KC] (zero padded); all global loads of a thread are issued before its LDS writes
         stage_chunk<T, BM>(As, in, in_stride, row0, B, k0, kc, tid, vec_in);
-        stage_chunk<T, BN>(Ws, W, w_stride, (int64_t)col0, (int64_t)N, k0, kc, tid, vec_w);
+        stage_chunk<T, BNT>(Ws, W, w_stride, (int64_t)col0, (int64_t)N, k0, kc, tid, vec_w);
         __syncthreads();
         const int ksteps = (kc + KS - 1) / KS;
         for (int s = 0; s < ksteps; ++s) {
@@ -524,11 +528,17 @@ static int linear(const T* in, int64_t in_stride, const T* W, int64_t w_stride, 
     // transposed product, 16-byte predicate-free stores, resident workgroups for narrow outputs)
     if (K <= HMAX && (K % Vec16<T>::N == 0) && (w_stride % Vec16<T>::N == 0) && ((reinterpret_cast<uintptr_t>(W) & 15u) == 0))
         return mlp2_dispatch<T, false>(in, in_stride, nullptr, 0, nullptr, W, w_stride, bias, B, K, K, N, out, out_stride, act, stream);
-    const int64_t blocks = ((B + BM - 1) / BM) * ((N + BN - 1) / BN);
+    constexpr int NARROW = Mfma<T>::MT;                          // one mfma column tile
+    const int bn = N <= NARROW ? NARROW : BN;
+    const int64_t blocks = ((B + BM - 1) / BM) * ((N + bn - 1) / bn);
     if (blocks > 0x7fffffffLL) return JF_ERR_UNSUPPORTED;
     dim3 grid((unsigned)blocks);
-    hipLaunchKernelGGL(linear_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, in, in_stride, W, w_stride, bias, B, (int)K, (int)N, (int)act, out,
-                       out_stride);
+    if (N <= NARROW)
+        hipLaunchKernelGGL((linear_kernel<T, NARROW>), grid, dim3(256), 0, (hipStream_t)stream, in, in_stride, W, w_stride, bias, B, (int)K, (int)N,
+                           (int)act, out, out_stride);
+    else
+        hipLaunchKernelGGL((linear_kernel<T, BN>), grid, dim3(256), 0, (hipStream_t)stream, in, in_stride, W, w_stride, bias, B, (int)K, (int)N, (int)act,
+                           out, out_stride);
     return check_launch();
 }
 
