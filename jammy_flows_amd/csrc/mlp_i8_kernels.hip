@@ -28,16 +28,19 @@
 // the accumulators to HBM, whole 128-byte lines per store instruction.  <= 128 VGPRs: four waves per SIMD.
 //
 // Supported: float64, H <= 128, K1 <= 28.
-#include "jf_cond_split.h"
+#include "jf_cond_regs.h"
+#include "jf_mfma.h"
 
 namespace jf {
 
 using i32x4 = __attribute__((ext_vector_type(4))) int;
 using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
 constexpr int CI_CT = 3;                                           // 16-column tiles per chunk
+constexpr int CI_FRAG = 1024;                                      // bytes of one MFMA operand fragment (64 lanes x 16 int8)
+constexpr int CI_HMAX = 128, CI_K1MAX = 28;                        // hidden units (two k-steps of 64), inputs
 constexpr int CI_WAVES = 8, CI_THREADS = 64 * CI_WAVES, CI_ROWS = 16 * CI_WAVES;
 constexpr int CI_TAIL = CI_CT * 16 * 2 * 8;                        // per chunk: 48 scales 2^(e_n - 19) + 48 biases, float64
-__host__ __device__ constexpr int ci_w_bytes(int S) { return CI_CT * 2 * S * CS_FRAG; }         // 3 tiles x 2 k-steps x S slices x 1 KiB
+__host__ __device__ constexpr int ci_w_bytes(int S) { return CI_CT * 2 * S * CI_FRAG; }         // 3 tiles x 2 k-steps x S slices x 1 KiB
 __host__ __device__ constexpr int ci_chunk_bytes(int S) { return ci_w_bytes(S) + CI_TAIL; }
 __host__ __device__ constexpr int ci_chunks(int N) { return ((N + 15) / 16 + CI_CT - 1) / CI_CT; }
 static bool ci_slices_ok(int S) { return S == 5 || S == 6; }
@@ -99,7 +102,7 @@ template <int S> __global__ void __launch_bounds__(256) ci_pack_kernel(const CiP
             for (int j = 0; j < S; ++j) f[j][g] = ci_pack4(d[0][j], d[1][j], d[2][j], d[3][j]);
         }
 #pragma unroll
-        for (int j = 0; j < S; ++j) *reinterpret_cast<i32x4*>(base + (size_t)((tc * 2 + s) * S + j) * CS_FRAG + lane * 16) = f[j];
+        for (int j = 0; j < S; ++j) *reinterpret_cast<i32x4*>(base + (size_t)((tc * 2 + s) * S + j) * CI_FRAG + lane * 16) = f[j];
     }
     if (lane < 16) {
         double* tail = reinterpret_cast<double*>(base + ci_w_bytes(S));
@@ -119,7 +122,7 @@ struct CiArgs {
 };
 
 // one chunk of the image -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds: 1 KiB per wave instruction, no register hop): wave w of the 8 moves
-// KiB pieces w, w + 8, ...; the tail goes with wave 0.  A plain template function, not a lambda inside the kernel (see cs_dma_chunk).
+// KiB pieces w, w + 8, ...; the tail goes with wave 0.  A plain template function, not a lambda inside the kernel (see cs_dma_chunk, jf_cond_split.h).
 template <int S>
 __device__ __forceinline__ void ci_dma_chunk(__amdgpu_buffer_rsrc_t rsrc, unsigned char* dst, int g, int wave, int lane) {
     constexpr int PIECES = ci_w_bytes(S) / 1024;
@@ -131,20 +134,20 @@ __device__ __forceinline__ void ci_dma_chunk(__amdgpu_buffer_rsrc_t rsrc, unsign
 }
 
 // phase 1: h^T = tanh(W1 x^T + b1) for the wave's 16 rows on exact f64 MFMA (rows past B replicate row B-1), returned as the B operands of
-// the int8 products: hd[s][i] = digit slice i of the 16 hidden units ci_unit(s, 0..15, lq).  Xs: LDS scratch of (CI_ROWS + CS_HMAX) (k1p + 1) +
-// CS_HMAX doubles.  Ends past the barrier that follows the staging, not past one after the MFMA reads (the caller's next barrier covers those).
+// the int8 products: hd[s][i] = digit slice i of the 16 hidden units ci_unit(s, 0..15, lq).  Xs: LDS scratch of (CI_ROWS + CI_HMAX) (k1p + 1) +
+// CI_HMAX doubles.  Ends past the barrier that follows the staging, not past one after the MFMA reads (the caller's next barrier covers those).
 template <int S>
 __device__ __forceinline__ void ci_hidden(const CiArgs& a, int64_t row0, int64_t last, double* Xs, i32x4 (&hd)[2][S]) {
     using MF = Mfma16<double>;
-    constexpr int MT = 16, KS = 4, JH = CS_HMAX / MT;
+    constexpr int MT = 16, KS = 4, JH = CI_HMAX / MT;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lq = lane >> 4;
     const int K1 = a.K1, H = a.H;
     const int k1p = (K1 + KS - 1) / KS * KS, ldk = k1p + 1;
     double* W1s = Xs + CI_ROWS * ldk;
-    double* b1s = W1s + CS_HMAX * ldk;
+    double* b1s = W1s + CI_HMAX * ldk;
     {
-        const int nx = CI_ROWS * k1p, nw = CS_HMAX * k1p;
+        const int nx = CI_ROWS * k1p, nw = CI_HMAX * k1p;
         for (int base = 0; base < nx; base += 4 * CI_THREADS) {
             double v[4]; int o[4];
 #pragma unroll
@@ -172,7 +175,7 @@ __device__ __forceinline__ void ci_hidden(const CiArgs& a, int64_t row0, int64_t
 #pragma unroll
             for (int u = 0; u < 4; ++u) if (o[u] >= 0) W1s[o[u]] = v[u];
         }
-        if (tid < CS_HMAX) b1s[tid] = tid < H ? a.b1[tid < H ? tid : 0] : 0.0;
+        if (tid < CI_HMAX) b1s[tid] = tid < H ? a.b1[tid < H ? tid : 0] : 0.0;
     }
     __syncthreads();
     // two halves of 4 unit tiles (= the two k-steps of the int8 products): acc[g][r] = pre-activation of hidden unit 16 (4 s + g) + lq + 4 r for
@@ -244,7 +247,7 @@ __global__ void __launch_bounds__(CI_THREADS, 4) mlp2_i8_kernel(const CiArgs a) 
         // accumulators).
         constexpr int NF = CI_CT * 2 * S;
         i32x4 Wf[3];
-        auto load_w = [&](int f) { Wf[f % 3] = *reinterpret_cast<const i32x4*>(Ws + f * CS_FRAG + lane * 16); };   // fragment order (tile, k-step, slice)
+        auto load_w = [&](int f) { Wf[f % 3] = *reinterpret_cast<const i32x4*>(Ws + f * CI_FRAG + lane * 16); };   // fragment order (tile, k-step, slice)
         load_w(0);
         load_w(1);
 #pragma unroll
@@ -284,7 +287,7 @@ __global__ void __launch_bounds__(CI_THREADS, 4) mlp2_i8_kernel(const CiArgs a) 
 static int ci_pack(const double* W2, int64_t w2s, const double* b2, int32_t H, int32_t N, int S, void* packed, void* stream) {
     if (!W2 || !packed || !ci_slices_ok(S)) return JF_ERR_BADARG;
     if (!width_ok(H) || !width_ok(N)) return JF_ERR_BADARG;
-    if (H > CS_HMAX || (reinterpret_cast<uintptr_t>(packed) & 15u)) return JF_ERR_UNSUPPORTED;
+    if (H > CI_HMAX || (reinterpret_cast<uintptr_t>(packed) & 15u)) return JF_ERR_UNSUPPORTED;
     CiPackArgs a{W2, w2s, b2, H, N, static_cast<unsigned char*>(packed)};
     const int threads = ci_chunks(N) * CI_CT * 64;
     hipStream_t st = (hipStream_t)stream;
@@ -296,7 +299,7 @@ static int ci_pack(const double* W2, int64_t w2s, const double* b2, int32_t H, i
 template <int S> static int ci_launch(const CiArgs& a, hipStream_t st) {
     // phase 1's scratch overlays chunk buffer 1 and may be larger than it (K1 = 28: 60 KB)
     const int k1p = (a.K1 + 3) / 4 * 4;
-    const size_t scratch = ((size_t)(CI_ROWS + CS_HMAX) * (k1p + 1) + CS_HMAX) * 8;
+    const size_t scratch = ((size_t)(CI_ROWS + CI_HMAX) * (k1p + 1) + CI_HMAX) * 8;
     const size_t second = scratch > (size_t)ci_chunk_bytes(S) ? (scratch + 15) / 16 * 16 : (size_t)ci_chunk_bytes(S);
     const size_t lds = (size_t)ci_chunk_bytes(S) + second;
     static bool attr_set = false;
@@ -312,7 +315,7 @@ static int ci_mlp2(const double* in, int64_t in_stride, const double* W1, int64_
                    int32_t H, int32_t N, int S, double* out, int64_t os, void* stream) {
     if (!in || !W1 || !b1 || !packed || !out || !ci_slices_ok(S)) return JF_ERR_BADARG;
     if (!width_ok(K1) || !width_ok(H) || !width_ok(N) || !rows_ok(B)) return JF_ERR_BADARG;
-    if (K1 > CS_K1MAX || H > CS_HMAX || (reinterpret_cast<uintptr_t>(packed) & 15u)) return JF_ERR_UNSUPPORTED;
+    if (K1 > CI_K1MAX || H > CI_HMAX || (reinterpret_cast<uintptr_t>(packed) & 15u)) return JF_ERR_UNSUPPORTED;
     if (os < N || os > (1 << 20)) return JF_ERR_UNSUPPORTED;       // 31-bit byte counts inside a workgroup's 128 rows
     if (B == 0) return JF_OK;
     const CiArgs a{in, in_stride, W1, w1s, b1, static_cast<const unsigned char*>(packed), K1, H, N, B, out, os};
