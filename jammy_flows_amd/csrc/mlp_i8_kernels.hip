@@ -84,7 +84,7 @@ template <int S> __global__ void __launch_bounds__(256) ci_pack_kernel(const CiP
     // |w| 2^-e < 1 strictly; a zero, non-finite or absent row gets e = 0 (non-finite weights then give garbage digits: the exact paths report
     // such weights, this one is only chosen for finite ones -- see jf_mlp2_i8_pack_f64)
     int e = (wmax > 0.0 && wmax < INFINITY) ? ilogb(wmax) + 1 : 0;
-    e = e < -900 ? -900 : (e > 900 ? 900 : e);
+    e = e < -1000 ? -1000 : e;                                     // (e <= 1024 for every finite double; below -1000 the row is zero to 2^-1000 anyway, and 2^(e - 19) stays normal)
     unsigned char* base = a.out + (size_t)chunk * ci_chunk_bytes(S);
 #pragma unroll
     for (int s = 0; s < 2; ++s) {

@@ -52,6 +52,22 @@ def test_mlp2_i8_rows_of_very_different_scale():
     assert ((out - ref).abs() <= bound).all(), ((out - ref).abs() / bound).max().item()
 
 
+def test_mlp2_i8_extreme_weight_magnitudes():
+    """every finite double can be cut into digits: rows near the overflow threshold and denormal rows"""
+    x, w1, b1, w2, b2 = _case(500, 7, 128, 48, 13)
+    w2 = w2.clone()
+    w2[0] *= 1e300
+    w2[1] *= 1e-300
+    w2[2] *= 1e-320                                                 # denormal weights: the row is zero to every digit, like its exact product to 1e-300
+    b2 = torch.zeros_like(b2)
+    out = _hip.mlp2_i8(x, w1, b1, _hip.mlp2_i8_pack(w2, b2, 6), 48, 6)
+    ref = torch.tanh(x @ w1.t() + b1) @ w2.t()
+    assert torch.isfinite(out).all()
+    for r in (0, 1, 3):
+        assert ((out[:, r] - ref[:, r]).abs() <= 4e-12 * w2[r].abs().max() * 128).all(), r
+    assert (out[:, 2].abs() <= 1e-300).all()
+
+
 def test_mlp2_i8_strided_input_and_output_and_zero_rows():
     x, w1, b1, w2, b2 = _case(777, 7, 128, 137, 3)
     wide_x = torch.zeros((777, 19), dtype=torch.float64, device="cuda")
