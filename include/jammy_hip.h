@@ -574,6 +574,44 @@ int jf_activation_bwd_f64(const double* g, const double* z, int64_t n, int32_t c
 #define JF_MATH_RCP 3
 int jf_device_math_f32(const float* x, int64_t n, int32_t fn, float* out, void* stream);
 int jf_device_math_f64(const double* x, int64_t n, int32_t fn, double* out, void* stream);
+/* out = a + b (n elements): the last operation of pdf.forward, log_prob = log_prob_base + log_det (main/default.py:1110-1117) */
+int jf_add_rows_f32(const float* a, const float* b, int64_t n, float* out, void* stream);
+int jf_add_rows_f64(const double* a, const double* b, int64_t n, double* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Step plans (ABI v5): a whole evaluation step -- every launch pdf.forward / pdf.sample makes for one input shape, i.e. the loop over the
+ * sub-manifolds and their layers that the reference runs in Python on every call (jammy_flows/main/default.py:879-1057 all_layer_inverse,
+ * :1059-1117 forward, :1373-1531 all_layer_forward) -- recorded once and re-issued from C by ONE call.
+ *
+ *   p = jf_plan_create();
+ *   jf_plan_add_slot(p, x, bytes_of_x); ... one slot per buffer whose ADDRESS changes between replays (inputs, outputs)
+ *   jf_plan_record_begin(p);
+ *       jf_plan_add_memset(p, status, 0, 16);                 optional explicit ops
+ *       jf_gf_chain_inv_f32(...); jf_cond_f_chain_inv_f32(...); ...   ANY entry points of this header, on this thread: recorded, not launched
+ *       jf_plan_add_copy_to_host(p, pinned_host_status, status, 16);
+ *   n_ops = jf_plan_record_end(p);
+ *   jf_plan_launch(p, slot_bases, n_slots, stream);            as often as wanted: re-issues the ops on `stream`, every device pointer that
+ *                                                              pointed into slot i at record time now points to slot_bases[i] + same offset
+ * Everything an entry point decides on the host (kernel variant, grid, occupancy query, attribute setting) is decided at record time; a plan
+ * is therefore valid for the shapes, strides, options and non-slot addresses (weights, packed images, intermediate buffers) it was recorded
+ * with.  jf_plan_launch never allocates or synchronises.  One host thread replays a plan at a time.
+ * Timing: with jf_plan_set_timing(p, 1) a replay records a HIP event before and after every op on the launch stream;
+ * jf_plan_read_timing waits for them and returns the summed milliseconds per op and the number of replays they cover.
+ * ------------------------------------------------------------------------------------------------------------ */
+/* plans are named by int64 HANDLES (never by addresses): a stale or random value is answered with JF_ERR_BADARG */
+int64_t jf_plan_create(void);                                               /* -> handle (> 0) or a negative error */
+int32_t jf_plan_destroy(int64_t plan);
+int32_t jf_plan_add_slot(int64_t plan, const void* base, int64_t bytes);    /* -> slot index, or a negative error (overlapping slots are refused) */
+int32_t jf_plan_record_begin(int64_t plan);
+int32_t jf_plan_record_end(int64_t plan);                                   /* -> number of recorded ops */
+int32_t jf_plan_add_memset(int64_t plan, void* dst, int32_t value, int64_t bytes);
+int32_t jf_plan_add_copy_to_host(int64_t plan, void* host_dst, const void* src, int64_t bytes);
+int32_t jf_plan_num_ops(int64_t plan);
+int32_t jf_plan_num_relocations(int64_t plan);
+int32_t jf_plan_launch(int64_t plan, const void* const* slot_bases, int32_t n_slots, void* stream);
+int32_t jf_plan_set_timing(int64_t plan, int32_t on);
+int32_t jf_plan_debug_words(int64_t plan, int32_t op, uint64_t* out, int32_t cap);   /* argument storage of one op (debugging aid) */
+int32_t jf_plan_read_timing(int64_t plan, double* ms_sum_per_op, int32_t n_ops, int64_t* replays, int32_t reset);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Reductions of the analysis utilities, so that 1e5 .. 1e6 evaluated rows never travel to the host:

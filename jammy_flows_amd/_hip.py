@@ -123,6 +123,7 @@ _SIGNATURES = {
     "jf_mlp2_small_bwd": [_P, _I64, _P, _I64, _P, _P, _I64, _P, _I64, _I64, _I32, _I32, _I32, _P, _P, _P],
     "jf_activation": [_P, _I64, _I32, _P, _P],
     "jf_device_math": [_P, _I64, _I32, _P, _P],
+    "jf_add_rows": [_P, _P, _I64, _P, _P],
     "jf_activation_bwd": [_P, _P, _I64, _I32, _P, _P],
     "jf_mlp2": [_P, _I64, _P, _I64, _P, _P, _I64, _P, _I64, _I32, _I32, _I32, _P, _I64, _P],
     "jf_sphere_to_embedding": [_P, _I64, _P, _I64, _I32, _P, _I64, _P, _P],
@@ -139,6 +140,19 @@ _SIGNATURES = {
 }
 # entry points that exist for one precision only: full symbol name -> (argtypes, restype)
 _SIGNATURES_SINGLE = {
+    "jf_plan_create": ([], ctypes.c_int64),
+    "jf_plan_destroy": ([_I64], ctypes.c_int32),
+    "jf_plan_add_slot": ([_I64, _P, _I64], ctypes.c_int32),
+    "jf_plan_record_begin": ([_I64], ctypes.c_int32),
+    "jf_plan_record_end": ([_I64], ctypes.c_int32),
+    "jf_plan_add_memset": ([_I64, _P, _I32, _I64], ctypes.c_int32),
+    "jf_plan_add_copy_to_host": ([_I64, _P, _P, _I64], ctypes.c_int32),
+    "jf_plan_num_ops": ([_I64], ctypes.c_int32),
+    "jf_plan_num_relocations": ([_I64], ctypes.c_int32),
+    "jf_plan_launch": ([_I64, ctypes.POINTER(ctypes.c_void_p), _I32, _P], ctypes.c_int32),
+    "jf_plan_set_timing": ([_I64, _I32], ctypes.c_int32),
+    "jf_plan_debug_words": ([_I64, _I32, ctypes.POINTER(ctypes.c_uint64), _I32], ctypes.c_int32),
+    "jf_plan_read_timing": ([_I64, ctypes.POINTER(ctypes.c_double), _I32, ctypes.POINTER(ctypes.c_int64), _I32], ctypes.c_int32),
     "jf_gf_chain_lds_bytes_f32": ([_I32, _I32, ctypes.POINTER(jf_gf_layer), _I32], ctypes.c_int64),
     "jf_gf_chain_lds_bytes_f64": ([_I32, _I32, ctypes.POINTER(jf_gf_layer), _I32], ctypes.c_int64),
     "jf_gf_chain_inv_bwd_lds_bytes_f32": ([_I32, _I32, ctypes.POINTER(jf_gf_layer), _I32], ctypes.c_int64),
@@ -275,6 +289,7 @@ class KernelTimer:
 
     def __init__(self):
         self.records = []
+        self.plans = []
 
     def __enter__(self):
         global _TIMER
@@ -293,10 +308,16 @@ class KernelTimer:
             d = out.setdefault((name, tag), [0, 0.0])
             d[0] += 1
             d[1] += e0.elapsed_time(e1)
-        return {k: {"launches": v[0], "mean_ms": v[1] / v[0], "total_ms": v[1]} for k, v in out.items()}
+        for plan in self.plans:                     # steps replayed from a plan while this timer was active (events recorded by jf_plan_launch)
+            for (name, tag), (n, ms) in plan.read_timing().items():
+                d = out.setdefault((name, tag), [0, 0.0])
+                d[0] += n
+                d[1] += ms
+        return {k: {"launches": v[0], "mean_ms": v[1] / v[0], "total_ms": v[1]} for k, v in out.items() if v[0]}
 
 
 _TIMER = None
+_RECORDING = None          # the StepPlan being recorded on this thread (entry points then append to it instead of launching)
 
 
 def _launch(name, tag, args, dev, unsupported_ok=False):
@@ -309,7 +330,12 @@ def _launch(name, tag, args, dev, unsupported_ok=False):
     with torch.cuda.device(dev):
         stream = torch.cuda.current_stream(dev)
         args = tuple(args) + (stream.cuda_stream,)
-        if _TIMER is None:
+        if _RECORDING is not None:
+            n0 = _RECORDING.num_ops()
+            rc = fn(*args)
+            if rc == JF_OK:
+                _RECORDING.calls.append((name, tag, n0, _RECORDING.num_ops()))
+        elif _TIMER is None:
             rc = fn(*args)
         else:
             e0 = torch.cuda.Event(enable_timing=True)
@@ -348,6 +374,102 @@ def new_status(device):
 
 
 # --------------------------------------------------------------------------------------------------------------
+class StepPlan:
+    """a recorded step (include/jammy_hip.h "step plans", csrc/plan.hip): every launch the entry points make between begin() and end() is
+    stored instead of issued; launch(bases) re-issues all of them from C in one call, with the device pointers into the declared slots
+    (buffers whose address changes between replays) rebound."""
+
+    def __init__(self):
+        self.handle = int(lib().jf_plan_create())
+        if self.handle <= 0:
+            raise RuntimeError("jf_plan_create failed (%d)" % self.handle)
+        self.calls = []            # (entry point, tag, first op, one past last op) per recorded entry-point call
+        self.n_slots = 0
+        self._bases = None
+        self._timing = False
+
+    def __del__(self):
+        try:
+            if _lib is not None and self.handle > 0:
+                _lib.jf_plan_destroy(self.handle)
+        except Exception:           # noqa: BLE001 -- interpreter shutdown
+            pass
+
+    def add_slot(self, t):
+        """declare tensor `t`'s memory [data_ptr, data_ptr + span) as rebindable; returns the slot index"""
+        span = (sum((n - 1) * st for n, st in zip(t.shape, t.stride())) + 1) * t.element_size() if t.numel() else 0
+        rc = int(lib().jf_plan_add_slot(self.handle, _ptr(t), span))
+        _check(min(rc, 0), "jf_plan_add_slot")
+        self.n_slots = rc + 1
+        return rc
+
+    def begin(self):
+        global _RECORDING
+        if _RECORDING is not None:
+            raise RuntimeError("a step plan is already being recorded on this thread")
+        _check(int(lib().jf_plan_record_begin(self.handle)), "jf_plan_record_begin")
+        _RECORDING = self
+
+    def abort(self):
+        global _RECORDING
+        if _RECORDING is self:
+            _RECORDING = None
+            lib().jf_plan_record_end(self.handle)
+
+    def end(self):
+        global _RECORDING
+        _RECORDING = None
+        rc = int(lib().jf_plan_record_end(self.handle))
+        _check(min(rc, 0), "jf_plan_record_end")
+        self._bases = (ctypes.c_void_p * max(1, self.n_slots))()
+        self._ms = (ctypes.c_double * max(1, rc))()
+        self.n_ops = rc
+        return rc
+
+    def num_ops(self):
+        return int(lib().jf_plan_num_ops(self.handle))
+
+    def memset(self, t, value=0):
+        _check(int(lib().jf_plan_add_memset(self.handle, _ptr(t), value, t.numel() * t.element_size())), "jf_plan_add_memset")
+
+    def copy_to_host(self, host_t, dev_t):
+        _check(int(lib().jf_plan_add_copy_to_host(self.handle, host_t.data_ptr(), _ptr(dev_t), dev_t.numel() * dev_t.element_size())), "jf_plan_add_copy_to_host")
+
+    def launch(self, tensors, dev):
+        """re-issue the step; tensors[i] takes the place of slot i (same shape / strides as the tensor the slot was declared with)"""
+        b = self._bases
+        for i, t in enumerate(tensors):
+            b[i] = t.data_ptr()
+        timed = _TIMER is not None
+        if timed != self._timing:
+            lib().jf_plan_set_timing(self.handle, 1 if timed else 0)
+            self._timing = timed
+        if timed and self not in _TIMER.plans:
+            _TIMER.plans.append(self)
+        with torch.cuda.device(dev):
+            rc = lib().jf_plan_launch(self.handle, b, self.n_slots, torch.cuda.current_stream(dev).cuda_stream)
+        _check(rc, "jf_plan_launch")
+
+    def read_timing(self):
+        """{(entry point, tag): (launches, summed ms)} of the timed replays since the last read (waits for their events)"""
+        n = ctypes.c_int64(0)
+        _check(int(lib().jf_plan_read_timing(self.handle, self._ms, self.n_ops, ctypes.byref(n), 1)), "jf_plan_read_timing")
+        out = {}
+        for name, tag, a, b in self.calls:
+            if b > a:
+                out[(name, tag)] = (int(n.value), sum(self._ms[i] for i in range(a, b)))
+        return out
+
+
+def add_rows(a, b):
+    """a + b of two (n,) tensors as a library launch (the last operation of pdf.forward; part of a recorded step)"""
+    dev = require_device(a, b)
+    a, b = a.contiguous(), b.contiguous()
+    out = torch.empty_like(a)
+    _launch("jf_add_rows" + _suffix(a), "", (_ptr(a), _ptr(b), a.numel(), _ptr(out)), dev)
+    return out
+
+
 def gf_layer_array(structs):
     arr = (jf_gf_layer * len(structs))()
     for i, s in enumerate(structs):

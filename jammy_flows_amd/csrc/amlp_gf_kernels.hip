@@ -271,7 +271,7 @@ template <typename T> static int ag_launch(const AgArgs<T>& a, int D, hipStream_
     {                                                                                                                          \
         auto k = a.params_out ? amlp_gf_kernel<T, G_, RM_, true> : amlp_gf_kernel<T, G_, RM_, false>;                            \
         if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);    \
-        hipLaunchKernelGGL(k, dim3(grid), dim3(AG_THREADS), lds, st, a);                                                         \
+        jf::launch(k, dim3(grid), dim3(AG_THREADS), lds, st, a);                                                         \
     }
     if (G == 4) { if (small) JF_AG_GO(4, 8) else JF_AG_GO(4, 16) }
     else { if (small) JF_AG_GO(8, 8) else JF_AG_GO(8, 16) }
@@ -296,7 +296,7 @@ static int amlp2(const T* in, int64_t in_stride, const T* V1, const T* U1, const
         if (r2 <= AM_R && (!V1 || r1 <= AM_R) && H % 16 == 0 && lds <= 160 * 1024) {
             auto k = amlp2_mfma_kernel<AgArgs<T>>;
             if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL(k, dim3((unsigned)((B + am_rows(AM_THREADS) - 1) / am_rows(AM_THREADS))), dim3(AM_THREADS), lds, (hipStream_t)stream, a);
+            jf::launch(k, dim3((unsigned)((B + am_rows(AM_THREADS) - 1) / am_rows(AM_THREADS))), dim3(AM_THREADS), lds, (hipStream_t)stream, a);
             return check_launch();
         }
     }
@@ -341,7 +341,7 @@ static int amlp_gf_chain_inv(const T* in, int64_t in_stride, const T* V1, const 
             auto k = amlp_gf_mfma_kernel<AgArgs<T>, FWD>;
             constexpr int NT = FWD ? AM_THREADS_FWD : AM_THREADS, ROWS = am_rows(NT);
             if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL(k, dim3((unsigned)((B + ROWS - 1) / ROWS)), dim3(NT), lds, (hipStream_t)stream, a);
+            jf::launch(k, dim3((unsigned)((B + ROWS - 1) / ROWS)), dim3(NT), lds, (hipStream_t)stream, a);
             return check_launch();
         }
     }

@@ -125,7 +125,7 @@ static int amlp_stage(const T* in, int64_t ins, const T* seg, int64_t segs, int6
     if (rc != JF_OK) return rc;
     if (!out) return JF_ERR_BADARG;
     if (B == 0) return JF_OK;
-    hipLaunchKernelGGL(amlp_stage_kernel<T>, dim3((unsigned)B), dim3(64), 0, (hipStream_t)stream, a);
+    jf::launch(amlp_stage_kernel<T>, dim3((unsigned)B), dim3(64), 0, (hipStream_t)stream, a);
     return check_launch();
 }
 
@@ -139,7 +139,7 @@ static int amlp_stage_bwd(const T* in, int64_t ins, const T* seg, int64_t segs, 
     if (rc != JF_OK) return rc;
     if (!g_out || !g_seg || (act && !y)) return JF_ERR_BADARG;
     if (B == 0) return JF_OK;
-    hipLaunchKernelGGL(amlp_stage_bwd_kernel<T>, dim3((unsigned)B), dim3(64), 0, (hipStream_t)stream, a);
+    jf::launch(amlp_stage_bwd_kernel<T>, dim3((unsigned)B), dim3(64), 0, (hipStream_t)stream, a);
     return check_launch();
 }
 

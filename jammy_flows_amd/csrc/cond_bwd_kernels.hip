@@ -394,9 +394,9 @@ static int cb_pack(const float* W2, int64_t w2s, int32_t H, int32_t D, int32_t n
     a.W2 = W2; a.w2s = w2s; a.H = H; a.D = D; a.n_layers = n_layers; a.N = col; a.out = static_cast<unsigned char*>(packed);
     const int threads = n_layers * CB_KSTEPS * CB_JT * 64;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(cs_absmax_kernel, dim3(1), dim3(1024), 0, st, W2, w2s, col, (int)H,
+    jf::launch(cs_absmax_kernel, dim3(1), dim3(1024), 0, st, W2, w2s, col, (int)H,
                        reinterpret_cast<float*>(a.out + (size_t)n_layers * CB_KSTEPS * CB_T_BYTES));
-    hipLaunchKernelGGL(cb_pack_kernel, dim3((threads + 255) / 256), dim3(256), 0, st, a);
+    jf::launch(cb_pack_kernel, dim3((threads + 255) / 256), dim3(256), 0, st, a);
     return hipPeekAtLastError() == hipSuccess ? JF_OK : JF_ERR_LAUNCH;
 }
 
@@ -425,12 +425,9 @@ static int cb_chain(const float* in, int64_t in_stride, const float* W1, int64_t
     a.g_xout = g_xout; a.gxos = gxos; a.g_ld = g_ld; a.g_blp = g_blp; a.g_x = g_x; a.gxs = gxs; a.g_pp = g_pp; a.gpps = gpps;
     a.h_out = h_out; a.hs = hs; a.g_h = g_h; a.ghs = ghs; a.g_absmax = g_absmax;
     const size_t lds = 2 * CB_BUF;                                 // (phase 1's scratch, <= 22.8 KB at K1 = 28, fits buffer 1)
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)cond_gf_split_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(cond_gf_split_bwd_kernel, dim3((unsigned)((B + CS_ROWS1 - 1) / CS_ROWS1)), dim3(256), lds, (hipStream_t)stream, a);
+    static LdsAttrOnce attr;
+    attr.set((const void*)cond_gf_split_bwd_kernel, (int)lds);
+    jf::launch(cond_gf_split_bwd_kernel, dim3((unsigned)((B + CS_ROWS1 - 1) / CS_ROWS1)), dim3(256), lds, (hipStream_t)stream, a);
     return hipPeekAtLastError() == hipSuccess ? JF_OK : JF_ERR_LAUNCH;
 }
 

@@ -262,7 +262,7 @@ __global__ void __launch_bounds__(256, 2) cond_gf_chain_kernel(const CondArgs<T>
 template <typename T, int JH> static int cond_launch(const CondArgs<T>& a, size_t lds, hipStream_t st) {
     auto k = cond_gf_chain_kernel<T, JH>;
     if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k, dim3((unsigned)((a.B + CG_ROWS - 1) / CG_ROWS)), dim3(256), lds, st, a);
+    jf::launch(k, dim3((unsigned)((a.B + CG_ROWS - 1) / CG_ROWS)), dim3(256), lds, st, a);
     return check_launch();
 }
 

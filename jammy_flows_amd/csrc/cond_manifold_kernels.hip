@@ -183,7 +183,7 @@ static int cond_mchain(const T* in, int64_t in_stride, const T* W1, int64_t w1s,
     if (lds > 160 * 1024) return JF_ERR_UNSUPPORTED;
     auto k = cond_mchain_kernel<T, Fam, NT, FWD>;
     if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k, dim3((unsigned)((B + NT - 1) / NT)), dim3(NT), lds, (hipStream_t)stream, a);
+    jf::launch(k, dim3((unsigned)((B + NT - 1) / NT)), dim3(NT), lds, (hipStream_t)stream, a);
     return check_launch();
 }
 

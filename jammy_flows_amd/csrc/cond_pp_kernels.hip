@@ -667,7 +667,7 @@ static int pp_pack(const float* W2, int64_t w2s, const float* b2, int32_t H, int
     }
     a.W2 = W2; a.w2s = w2s; a.b2 = b2; a.H = H; a.D = D; a.n_layers = n_layers; a.out = static_cast<unsigned char*>(packed);
     const int threads = 2 * n_layers * PP_TILES * PP_HALF * 64;
-    hipLaunchKernelGGL(pp_pack_kernel, dim3((threads + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
+    jf::launch(pp_pack_kernel, dim3((threads + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
     return hipPeekAtLastError() == hipSuccess ? JF_OK : JF_ERR_LAUNCH;
 }
 
@@ -699,7 +699,7 @@ static int pp_chain(const float* in, int64_t in_stride, const float* W1, int64_t
         (void)hipFuncSetAttribute((const void*)cond_gf_pp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES);
     }
     const int grid = a.n_tiles < n_cu ? a.n_tiles : n_cu;          // persistent: one workgroup per CU (the LDS admits no second one)
-    hipLaunchKernelGGL(cond_gf_pp_kernel, dim3((unsigned)grid), dim3(512), PP_LDS_BYTES, (hipStream_t)stream, a);
+    jf::launch(cond_gf_pp_kernel, dim3((unsigned)grid), dim3(512), PP_LDS_BYTES, (hipStream_t)stream, a);
     return hipPeekAtLastError() == hipSuccess ? JF_OK : JF_ERR_LAUNCH;
 }
 

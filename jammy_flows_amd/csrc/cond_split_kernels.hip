@@ -326,11 +326,11 @@ static int cs_pack(const float* W2, int64_t w2s, const float* b2, int32_t H, int
     const int threads = n_layers * CS_CPL * CS_CT * CS_KSTEPS * 64;
     hipStream_t st = (hipStream_t)stream;
     if (arithmetic == JF_SPLIT_F16X2) {
-        hipLaunchKernelGGL(cs_absmax_kernel, dim3(1), dim3(1024), 0, st, W2, w2s, col, (int)H,
+        jf::launch(cs_absmax_kernel, dim3(1), dim3(1024), 0, st, W2, w2s, col, (int)H,
                            reinterpret_cast<float*>(a.out + (size_t)n_layers * CS_CPL * CS_CHUNK16_BYTES));
-        hipLaunchKernelGGL(cs_pack_kernel<2>, dim3((threads + 255) / 256), dim3(256), 0, st, a);
+        jf::launch(cs_pack_kernel<2>, dim3((threads + 255) / 256), dim3(256), 0, st, a);
     } else {
-        hipLaunchKernelGGL(cs_pack_kernel<3>, dim3((threads + 255) / 256), dim3(256), 0, st, a);
+        jf::launch(cs_pack_kernel<3>, dim3((threads + 255) / 256), dim3(256), 0, st, a);
     }
     return hipPeekAtLastError() == hipSuccess ? JF_OK : JF_ERR_LAUNCH;
 }
@@ -344,12 +344,9 @@ static int cs_launch(const CsArgs& a, int64_t B, hipStream_t st) {
         const size_t second = scratch > (size_t)CsGeom<NP>::CHUNK ? (scratch + 15) / 16 * 16 : (size_t)CsGeom<NP>::CHUNK;
         return (size_t)CsGeom<NP>::CHUNK + second;
     };
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)cond_gf_split_kernel<1, FWD, SAVE, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-        (void)hipFuncSetAttribute((const void*)cond_gf_split_kernel<2, FWD, SAVE, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-        attr_set = true;
-    }
+    static LdsAttrOnce attr1, attr2;                               // per template instance and per device
+    attr1.set((const void*)cond_gf_split_kernel<1, FWD, SAVE, NP>, 80 * 1024);
+    attr2.set((const void*)cond_gf_split_kernel<2, FWD, SAVE, NP>, 80 * 1024);
     // two row groups per wave once that still leaves every CU several workgroups; JF_CS_RG=1|2 (environment, read once) or
     // jf_cond_gf_split_row_groups() force a variant (A/B timing: scripts/probe/rg_sweep.py; both variants in one process: the stress tests)
     static const int env_rg = getenv("JF_CS_RG") ? atoi(getenv("JF_CS_RG")) : 0;
@@ -357,8 +354,8 @@ static int cs_launch(const CsArgs& a, int64_t B, hipStream_t st) {
     // sampling: one row group per wave at every size -- 132 VGPRs let three workgroups share a CU, and the solver loops (divergent exits,
     // quarter-rate transcendentals) gain more from the third wave per SIMD than from halving the fragment reads (1.91 vs 2.12 ms per 2^20 rows)
     const bool two = force_rg ? force_rg == 2 : (!FWD && B >= (int64_t)CS_ROWS1 * 2 * 1024);
-    if (two) hipLaunchKernelGGL((cond_gf_split_kernel<2, FWD, SAVE, NP>), dim3((unsigned)((B + 2 * CS_ROWS1 - 1) / (2 * CS_ROWS1))), dim3(256), lds_of(2), st, a);
-    else hipLaunchKernelGGL((cond_gf_split_kernel<1, FWD, SAVE, NP>), dim3((unsigned)((B + CS_ROWS1 - 1) / CS_ROWS1)), dim3(256), lds_of(1), st, a);
+    if (two) jf::launch((cond_gf_split_kernel<2, FWD, SAVE, NP>), dim3((unsigned)((B + 2 * CS_ROWS1 - 1) / (2 * CS_ROWS1))), dim3(256), lds_of(2), st, a);
+    else jf::launch((cond_gf_split_kernel<1, FWD, SAVE, NP>), dim3((unsigned)((B + CS_ROWS1 - 1) / CS_ROWS1)), dim3(256), lds_of(1), st, a);
     return hipPeekAtLastError() == hipSuccess ? JF_OK : JF_ERR_LAUNCH;
 }
 

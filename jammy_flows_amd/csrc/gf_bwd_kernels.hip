@@ -754,14 +754,14 @@ static int gb_launch(GfBwdArgs<T> a, bool bcast, hipStream_t st) {
         if (active > n_tiles) active = n_tiles < 1 ? 1 : n_tiles;
         a.active_blocks = (int)active;
         a.tiles_per_block = (int)((n_tiles + active - 1) / active);
-        hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(GB_NT), lds, st, a);
+        jf::launch(k, dim3((unsigned)blocks), dim3(GB_NT), lds, st, a);
     } else {
         a.tiles_per_block = 1;
         const bool direct = (size_t)a.D * sizeof(T) >= 32;
         const size_t lds = (size_t)(direct ? 1 : 2) * (64 / G) * a.tile_stride * sizeof(T);
         auto k = direct ? gf_chain_bwd_kernel<T, G, false, true> : gf_chain_bwd_kernel<T, G, false, false>;
         if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(k, dim3((unsigned)((a.B + 64 / G - 1) / (64 / G))), dim3(64), lds, st, a);
+        jf::launch(k, dim3((unsigned)((a.B + 64 / G - 1) / (64 / G))), dim3(64), lds, st, a);
     }
     return check_launch();
 }
@@ -788,7 +788,7 @@ static int gf_chain_inv_bwd(const T* x, int64_t xs, const T* params, int64_t ps,
         const size_t lds = (size_t)JF_MAX_D_GF * GX_THREADS * sizeof(Dual<T>) + 16 * sizeof(T);
         auto k = gfx_chain_bwd_kernel<T>;
         if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(GX_THREADS), lds, (hipStream_t)stream, a, bcast ? (int64_t)0 : ps, tiles);
+        jf::launch(k, dim3((unsigned)blocks), dim3(GX_THREADS), lds, (hipStream_t)stream, a, bcast ? (int64_t)0 : ps, tiles);
         return check_launch();
     }
     for (int l = 0; l < n_layers; ++l) if (layers[l].hh_iter > (gb_group_width(D) > GB_MAX_HH ? gb_group_width(D) : GB_MAX_HH)) return JF_ERR_UNSUPPORTED;

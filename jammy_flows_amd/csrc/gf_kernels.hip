@@ -438,12 +438,12 @@ template <typename T, int G, bool FWD> static int launch_g(GfChainArgs<T> a, boo
         const int64_t tpb = (n_tiles + resident - 1) / resident;
         a.tiles_per_block = (int)(tpb < 1 ? 1 : tpb);
         const unsigned grid = (unsigned)((n_tiles + a.tiles_per_block - 1) / a.tiles_per_block);
-        hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds_bytes, st, a);
+        jf::launch(k, dim3(grid), dim3(256), lds_bytes, st, a);
     } else {
         auto k = gf_chain_kernel<T, G, false, FWD>;
         if (lds_bytes > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         const unsigned grid = (unsigned)((a.B + 64 / G - 1) / (64 / G));
-        hipLaunchKernelGGL(k, dim3(grid), dim3(64), lds_bytes, st, a);
+        jf::launch(k, dim3(grid), dim3(64), lds_bytes, st, a);
     }
     return check_launch();
 }
@@ -456,7 +456,7 @@ template <typename T, int D> static int launch_rows(GfChainArgs<T> a, size_t lds
     const int64_t n_tiles = (a.B + 255) / 256;
     const int64_t tpb = (n_tiles + resident - 1) / resident;
     a.tiles_per_block = (int)(tpb < 1 ? 1 : tpb);
-    hipLaunchKernelGGL(k, dim3((unsigned)((n_tiles + a.tiles_per_block - 1) / a.tiles_per_block)), dim3(256), lds_bytes, st, a);
+    jf::launch(k, dim3((unsigned)((n_tiles + a.tiles_per_block - 1) / a.tiles_per_block)), dim3(256), lds_bytes, st, a);
     return check_launch();
 }
 
@@ -486,7 +486,7 @@ template <typename T, bool FWD> static int launch(const GfChainArgs<T>& a, int D
     if (ext) {
         auto k = gfx_chain_kernel<T, FWD>;
         if (lds_bytes > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        hipLaunchKernelGGL(k, dim3((unsigned)((a.B + GX_THREADS - 1) / GX_THREADS)), dim3(GX_THREADS), lds_bytes, st, a, bcast ? (int64_t)0 : a.ps);
+        jf::launch(k, dim3((unsigned)((a.B + GX_THREADS - 1) / GX_THREADS)), dim3(GX_THREADS), lds_bytes, st, a, bcast ? (int64_t)0 : a.ps);
         return check_launch();
     }
     switch (group_width(D)) {
@@ -537,7 +537,7 @@ template <typename T> static int64_t gf_lds_query(int32_t D, int32_t n_layers, c
 }  // namespace jf
 
 extern "C" {
-int jf_abi_version(void) { return 4; }
+int jf_abi_version(void) { return 5; }
 int64_t jf_gf_chain_lds_bytes_f32(int32_t D, int32_t n, const jf_gf_layer* L, int32_t pb1) { return jf::gf_lds_query<float>(D, n, L, pb1); }
 int64_t jf_gf_chain_lds_bytes_f64(int32_t D, int32_t n, const jf_gf_layer* L, int32_t pb1) { return jf::gf_lds_query<double>(D, n, L, pb1); }
 

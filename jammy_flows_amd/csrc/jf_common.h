@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+#include <tuple>
 #include <type_traits>
 
 #include "../../include/jammy_hip.h"
@@ -16,6 +18,46 @@ constexpr int64_t JF_MAX_WIDTH = 1 << 24, JF_MAX_ROWS = (int64_t)1 << 40;
 inline bool width_ok(int64_t v) { return v >= 1 && v <= JF_MAX_WIDTH; }
 inline bool rows_ok(int64_t v) { return v >= 0 && v <= JF_MAX_ROWS; }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is an attribute of a kernel PER DEVICE: a `static bool` guard sets it on the first device a process
+// touches only, and a later launch on another GPU fails.  One of these per call site: a bit per device, set once, safe from several
+// host threads (at worst two threads set the same value).
+struct LdsAttrOnce {
+    std::atomic<uint64_t> done{0};
+    void set(const void* fn, int bytes) {
+        int dev = 0;
+        const bool known = hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64;
+        if (known && (done.load(std::memory_order_acquire) >> dev & 1)) return;
+        (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (known) done.fetch_or(1ull << dev, std::memory_order_release);
+    }
+};
+
+
+// ---------------------------------------------------------------------------------------------
+// Kernel launches.  Every entry point launches through jf::launch(kernel, grid, block, lds, stream, args...).  Normally that is
+// hipLaunchKernel; while a step plan is being RECORDED on this thread (jf_plan_record_begin .. _end, plan.hip) the launch is not issued but
+// copied into the plan -- kernel address, geometry and the bytes of every argument -- so that jf_plan_launch can re-issue the whole step from
+// C in one call, with the device pointers into the caller's input / output buffers rebound (include/jammy_hip.h, "step plans").
+// ---------------------------------------------------------------------------------------------
+struct PlanSink {
+    virtual void add_launch(const void* fn, dim3 grid, dim3 block, size_t lds, void** args, const size_t* sizes, const size_t* aligns, int n) = 0;
+    virtual ~PlanSink() {}
+};
+PlanSink*& plan_sink();                                            // thread-local (plan.hip); nullptr = launch for real
+
+template <typename... KArgs, typename... Args>
+inline void launch(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t lds, hipStream_t st, Args&&... args) {
+    static_assert(sizeof...(KArgs) == sizeof...(Args), "kernel argument count");
+    std::tuple<std::remove_cv_t<KArgs>...> vals{static_cast<KArgs>(args)...};      // converted exactly as a <<<>>> launch would convert them
+    void* ptrs[sizeof...(KArgs) ? sizeof...(KArgs) : 1];
+    std::apply([&](auto&... v) { int i = 0; ((ptrs[i++] = (void*)&v), ...); }, vals);
+    if (PlanSink* sink = plan_sink()) {
+        static constexpr size_t sizes[] = {sizeof(KArgs)..., 0}, aligns[] = {alignof(KArgs)..., 0};
+        sink->add_launch((const void*)kernel, grid, block, lds, ptrs, sizes, aligns, (int)sizeof...(KArgs));
+        return;
+    }
+    (void)hipLaunchKernel((const void*)kernel, grid, block, ptrs, lds, st);
+}
 
 // ---------------------------------------------------------------------------------------------
 // vector types: 16-byte accesses are what both HBM (global_load_dwordx4) and LDS (ds_read_b128) want

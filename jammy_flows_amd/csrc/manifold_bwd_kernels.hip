@@ -418,19 +418,19 @@ static int mchain_bwd(const T* x, int64_t xs, const T* params, int64_t ps, int32
         if (staged) {
             auto kv = vchain_bwd_kernel<T>;
             if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)kv, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL(kv, dim3((unsigned)((B + a.rows - 1) / a.rows)), dim3(64), lds, (hipStream_t)stream, a);
+            jf::launch(kv, dim3((unsigned)((B + a.rows - 1) / a.rows)), dim3(64), lds, (hipStream_t)stream, a);
             return check_launch();
         }
     }
     if (wide) {
         auto k4 = mchain_bwd_kernel<T, Fam, NW>;
         if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k4, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(k4, dim3((unsigned)((B + a.rows - 1) / a.rows)), dim3(64), lds, (hipStream_t)stream, a);
+        jf::launch(k4, dim3((unsigned)((B + a.rows - 1) / a.rows)), dim3(64), lds, (hipStream_t)stream, a);
         return check_launch();
     }
     auto k = mchain_bwd_kernel<T, Fam, 1>;
     if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k, dim3((unsigned)((B + a.rows - 1) / a.rows)), dim3(64), lds, (hipStream_t)stream, a);
+    jf::launch(k, dim3((unsigned)((B + a.rows - 1) / a.rows)), dim3(64), lds, (hipStream_t)stream, a);
     return check_launch();
 }
 

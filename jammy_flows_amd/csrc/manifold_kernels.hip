@@ -139,7 +139,7 @@ static int mchain(const T* x, int64_t xs, const T* ld_in, const T* params, int64
     if (lds > 160 * 1024) return JF_ERR_UNSUPPORTED;
     auto k = mchain_kernel<T, Fam, FWD>;
     if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k, dim3((unsigned)((B + a.rows - 1) / a.rows)), dim3(64), lds, (hipStream_t)stream, a);
+    jf::launch(k, dim3((unsigned)((B + a.rows - 1) / a.rows)), dim3(64), lds, (hipStream_t)stream, a);
     return check_launch();
 }
 
@@ -170,7 +170,7 @@ template <typename T, bool TO_EMB>
 static int embed(const T* x, int64_t xs, const T* ld_in, int64_t B, int32_t dim, T* x_out, int64_t xos, T* ld_out, void* stream) {
     if (!x || !x_out || (dim != 1 && dim != 2) || B < 0) return JF_ERR_BADARG;
     if (B == 0) return JF_OK;
-    hipLaunchKernelGGL((embed_kernel<T, TO_EMB>), dim3((unsigned)((B + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, xs, ld_in, B, (int)dim, x_out,
+    jf::launch((embed_kernel<T, TO_EMB>), dim3((unsigned)((B + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, xs, ld_in, B, (int)dim, x_out,
                        xos, ld_out);
     return check_launch();
 }

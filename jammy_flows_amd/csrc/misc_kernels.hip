@@ -56,7 +56,7 @@ template <typename T> static int conditioning_rows(const jf_cond_segment* segs, 
     int W = 0;
     for (int i = 0; i < n; ++i) W += segs[i].kind == 0 ? segs[i].n_in : segs[i].kind + 1;
     if (W == 0) return JF_OK;
-    hipLaunchKernelGGL(conditioning_kernel<T>, dim3((unsigned)((B + COND_ROWS - 1) / COND_ROWS)), dim3(256), 0, (hipStream_t)stream, a, B, W, out, os);
+    jf::launch(conditioning_kernel<T>, dim3((unsigned)((B + COND_ROWS - 1) / COND_ROWS)), dim3(256), 0, (hipStream_t)stream, a, B, W, out, os);
     return check_launch();
 }
 
@@ -97,7 +97,7 @@ template <typename T> static int coverage_hist(const T* lpb, int64_t B, double l
     if (B == 0) return JF_OK;
     int64_t blocks = (B + 255) / 256;
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(coverage_hist_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, lpb, B, (T)log_at_zero, thr, (int)n,
+    jf::launch(coverage_hist_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, lpb, B, (T)log_at_zero, thr, (int)n,
                        reinterpret_cast<unsigned long long*>(hist), twice);
     return check_launch();
 }
@@ -127,14 +127,14 @@ __global__ void __launch_bounds__(64) segment_reduce_kernel(const T* __restrict_
 template <typename T> static int segment_reduce(const T* in, int64_t n_seg, int64_t seg_len, int32_t mode, T* out, void* stream) {
     if (!in || !out || n_seg < 0 || seg_len < 1 || mode < 0 || mode > 1) return JF_ERR_BADARG;
     if (n_seg == 0) return JF_OK;
-    hipLaunchKernelGGL(segment_reduce_kernel<T>, dim3((unsigned)n_seg), dim3(64), 0, (hipStream_t)stream, in, n_seg, seg_len, (int)mode, out);
+    jf::launch(segment_reduce_kernel<T>, dim3((unsigned)n_seg), dim3(64), 0, (hipStream_t)stream, in, n_seg, seg_len, (int)mode, out);
     return check_launch();
 }
 
 template <typename T> static int normal_logp(const T* z, int64_t zs, int64_t B, int32_t D, const T* in, T* out, void* stream) {
     if (!z || !out || D < 0 || B < 0) return JF_ERR_BADARG;
     if (B == 0) return JF_OK;
-    hipLaunchKernelGGL(normal_logp_kernel<T>, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, (hipStream_t)stream, z, zs, B, (int)D, in, out);
+    jf::launch(normal_logp_kernel<T>, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, (hipStream_t)stream, z, zs, B, (int)D, in, out);
     return check_launch();
 }
 
@@ -194,7 +194,7 @@ template <typename T> static int slab_sum(const T* a, int64_t na, T* out_a, cons
     if (!a || !out_a || na < 1 || nb < 0 || (nb > 0 && (!b || !out_b)) || S < 1 || chunk < 1 || na > JF_MAX_ROWS || nb > JF_MAX_ROWS) return JF_ERR_BADARG;
     const int64_t chunks = ((int64_t)S + chunk - 1) / chunk;
     if (chunks > 65535) return JF_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(slab_sum_kernel<T>, dim3((unsigned)((na + nb + 31) / 32), (unsigned)chunks), dim3(256), 0, (hipStream_t)stream, a, na, out_a, b, nb,
+    jf::launch(slab_sum_kernel<T>, dim3((unsigned)((na + nb + 31) / 32), (unsigned)chunks), dim3(256), 0, (hipStream_t)stream, a, na, out_a, b, nb,
                        out_b, (int)S, (int)chunk);
     return hipPeekAtLastError() == hipSuccess ? JF_OK : JF_ERR_LAUNCH;
 }
@@ -204,7 +204,7 @@ template <typename T> static int tanh_bwd(const T* g, const T* y, int64_t n, T* 
     if (n == 0) return JF_OK;
     constexpr int N = Vec16<T>::N;
     const bool vec = ((reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
-    hipLaunchKernelGGL(tanh_bwd_kernel<T>, dim3((unsigned)((n + 256 * N - 1) / (256 * N))), dim3(256), 0, (hipStream_t)stream, g, y, n, out, vec);
+    jf::launch(tanh_bwd_kernel<T>, dim3((unsigned)((n + 256 * N - 1) / (256 * N))), dim3(256), 0, (hipStream_t)stream, g, y, n, out, vec);
     return check_launch();
 }
 
@@ -241,7 +241,20 @@ template <typename T, bool BWD> static int activation(const T* g, const T* z, in
     if (!z || !out || (BWD && !g) || n < 0) return JF_ERR_BADARG;
     if (code < JF_ACT_RELU || code > JF_ACT_IDENTITY) return JF_ERR_BADARG;
     if (n == 0) return JF_OK;
-    hipLaunchKernelGGL((act_kernel<T, BWD>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g, z, n, code, out);
+    jf::launch((act_kernel<T, BWD>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g, z, n, code, out);
+    return check_launch();
+}
+
+// out = a + b: the last operation of pdf.forward, log_prob = log_prob_base + log_det (main/default.py:1110-1117), as a library launch so that a
+// recorded step plan (plan.hip) holds the WHOLE step
+template <typename T> __global__ void __launch_bounds__(256) add_rows_kernel(const T* __restrict__ a, const T* __restrict__ b, int64_t n, T* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = a[i] + b[i];
+}
+template <typename T> static int add_rows(const T* a, const T* b, int64_t n, T* out, void* stream) {
+    if (!a || !b || !out || n < 0) return JF_ERR_BADARG;
+    if (n == 0) return JF_OK;
+    jf::launch(add_rows_kernel<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, b, n, out);
     return check_launch();
 }
 
@@ -255,7 +268,7 @@ template <typename T> __global__ void __launch_bounds__(256) math_kernel(const T
 template <typename T> static int device_math(const T* x, int64_t n, int fn, T* out, void* stream) {
     if (!x || !out || n < 0 || fn < JF_MATH_EXP_FAST || fn > JF_MATH_RCP) return JF_ERR_BADARG;
     if (n == 0) return JF_OK;
-    hipLaunchKernelGGL((math_kernel<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, n, fn, out);
+    jf::launch((math_kernel<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, n, fn, out);
     return check_launch();
 }
 
@@ -264,6 +277,8 @@ template <typename T> static int device_math(const T* x, int64_t n, int fn, T* o
 extern "C" {
 int jf_device_math_f32(const float* x, int64_t n, int32_t fn, float* out, void* s) { return jf::device_math<float>(x, n, fn, out, s); }
 int jf_device_math_f64(const double* x, int64_t n, int32_t fn, double* out, void* s) { return jf::device_math<double>(x, n, fn, out, s); }
+int jf_add_rows_f32(const float* a, const float* b, int64_t n, float* out, void* s) { return jf::add_rows<float>(a, b, n, out, s); }
+int jf_add_rows_f64(const double* a, const double* b, int64_t n, double* out, void* s) { return jf::add_rows<double>(a, b, n, out, s); }
 int jf_conditioning_rows_f32(const jf_cond_segment* g, int32_t n, int64_t B, float* out, int64_t os, void* s) {
     return jf::conditioning_rows<float>(g, n, B, out, os, s);
 }

@@ -136,8 +136,10 @@ __device__ __forceinline__ void ci_dma_chunk(__amdgpu_buffer_rsrc_t rsrc, unsign
 // phase 1: h^T = tanh(W1 x^T + b1) for the wave's 16 rows on exact f64 MFMA (rows past B replicate row B-1), returned as the B operands of
 // the int8 products: hd[s][i] = digit slice i of the 16 hidden units ci_unit(s, 0..15, lq).  Xs: LDS scratch of (CI_ROWS + CI_HMAX) (k1p + 1) +
 // CI_HMAX doubles.  Ends past the barrier that follows the staging, not past one after the MFMA reads (the caller's next barrier covers those).
+// Returns (wave-uniform) the mask of the wave's 16 rows with a NaN hidden activation: NaN cannot be cut into digits ((int)rint(NaN) = 0 would
+// turn the row into out = b2), so the caller stores NaN for those rows -- what jf_mlp2_f64 and the reference's nn.Linear propagate.
 template <int S>
-__device__ __forceinline__ void ci_hidden(const CiArgs& a, int64_t row0, int64_t last, double* Xs, i32x4 (&hd)[2][S]) {
+__device__ __forceinline__ unsigned ci_hidden(const CiArgs& a, int64_t row0, int64_t last, double* Xs, i32x4 (&hd)[2][S]) {
     using MF = Mfma16<double>;
     constexpr int MT = 16, KS = 4, JH = CI_HMAX / MT;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -180,6 +182,7 @@ __device__ __forceinline__ void ci_hidden(const CiArgs& a, int64_t row0, int64_t
     __syncthreads();
     // two halves of 4 unit tiles (= the two k-steps of the int8 products): acc[g][r] = pre-activation of hidden unit 16 (4 s + g) + lq + 4 r for
     // row li (f64 C/D layout) = byte 4 g + r of k-step s
+    bool nan_h = false;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
         typename MF::Acc acc[JH / 2];
@@ -198,11 +201,18 @@ __device__ __forceinline__ void ci_hidden(const CiArgs& a, int64_t row0, int64_t
             const int j = 4 * s + g;
             int d[4][S];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) ci_digits<S>(M<double>::tanh_fast(acc[g][r] + b1s[j * MT + lq + 4 * r]), d[r]);
+            for (int r = 0; r < 4; ++r) {
+                const double h = M<double>::tanh_fast(acc[g][r] + b1s[j * MT + lq + 4 * r]);
+                nan_h |= h != h;                                   // (an infinite pre-activation is a legitimate h = +-1)
+                ci_digits<S>(h, d[r]);
+            }
 #pragma unroll
             for (int i = 0; i < S; ++i) hd[s][i][g] = ci_pack4(d[0][i], d[1][i], d[2][i], d[3][i]);
         }
     }
+    // lane (li, lq) holds 32 of row li's 128 units: a row is bad when any of its four lanes saw a NaN
+    const unsigned long long m = __ballot(nan_h);
+    return (unsigned)((m | (m >> 16) | (m >> 32) | (m >> 48)) & 0xffffu);
 }
 
 template <int S>
@@ -220,7 +230,7 @@ __global__ void __launch_bounds__(CI_THREADS, 4) mlp2_i8_kernel(const CiArgs a) 
     ci_dma_chunk<S>(packed_rsrc, Ws0, 0, wave, lane);              // lands in buffer 0 while phase 1 works in buffer 1
 
     i32x4 hd[2][S];
-    ci_hidden<S>(a, row0, last, Xs, hd);
+    const unsigned nan_rows = ci_hidden<S>(a, row0, last, Xs, hd);
 
     // result layout: the digit slices of h are the A operand (matrix rows = the wave's 16 batch rows), W2's the B operand (matrix columns =
     // the tile's 16 output columns), so lane (n = lane % 16, lq) holds output column n of batch rows 4 lq + r, r = 0..3: every store
@@ -235,6 +245,7 @@ __global__ void __launch_bounds__(CI_THREADS, 4) mlp2_i8_kernel(const CiArgs a) 
         a.out + row0 * a.os, 0, (int)((((int64_t)rows_here - 1) * a.os + a.N) * 8), 0x00027000);
     const unsigned obase = (unsigned)(((wave * 16 + 4 * lq) * a.os + li) * 8);       // byte offset of (first of this lane's 4 rows, column li)
     const unsigned ostep = (unsigned)(a.os * 8);
+    const unsigned my_nan = (nan_rows >> (4 * lq)) & 0xfu;         // this lane stores rows 4 lq + r of the wave's 16
     auto landed = [&]() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
     auto next_landed = [&]() { asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
     landed();                                                      // chunk 0 is in buffer 0 and every wave is done with Xs / W1s / b1s (buffer 1)
@@ -275,7 +286,8 @@ __global__ void __launch_bounds__(CI_THREADS, 4) mlp2_i8_kernel(const CiArgs a) 
                     v = v * 6.103515625e-05 + (double)pair;                                   // 2^-14 per pair of levels
                 }
                 const unsigned off = col < a.N ? obase + r * ostep + 128u * (chunk * CI_CT + t) : 0xfffffff0u;
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v * scale + bias), out_rsrc, off, 0, 0);
+                const double res = (my_nan >> r & 1u) ? __builtin_nan("") : v * scale + bias;
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, res), out_rsrc, off, 0, 0);
             }
         }
         static_assert(CI_CT * 4 == 12, "next_landed waits for everything but this chunk's 12 stores");
@@ -291,8 +303,8 @@ static int ci_pack(const double* W2, int64_t w2s, const double* b2, int32_t H, i
     CiPackArgs a{W2, w2s, b2, H, N, static_cast<unsigned char*>(packed)};
     const int threads = ci_chunks(N) * CI_CT * 64;
     hipStream_t st = (hipStream_t)stream;
-    if (S == 6) hipLaunchKernelGGL(ci_pack_kernel<6>, dim3((threads + 255) / 256), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(ci_pack_kernel<5>, dim3((threads + 255) / 256), dim3(256), 0, st, a);
+    if (S == 6) jf::launch(ci_pack_kernel<6>, dim3((threads + 255) / 256), dim3(256), 0, st, a);
+    else jf::launch(ci_pack_kernel<5>, dim3((threads + 255) / 256), dim3(256), 0, st, a);
     return hipPeekAtLastError() == hipSuccess ? JF_OK : JF_ERR_LAUNCH;
 }
 
@@ -302,12 +314,9 @@ template <int S> static int ci_launch(const CiArgs& a, hipStream_t st) {
     const size_t scratch = ((size_t)(CI_ROWS + CI_HMAX) * (k1p + 1) + CI_HMAX) * 8;
     const size_t second = scratch > (size_t)ci_chunk_bytes(S) ? (scratch + 15) / 16 * 16 : (size_t)ci_chunk_bytes(S);
     const size_t lds = (size_t)ci_chunk_bytes(S) + second;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)mlp2_i8_kernel<S>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-        attr_set = true;
-    }
-    hipLaunchKernelGGL((mlp2_i8_kernel<S>), dim3((unsigned)((a.B + CI_ROWS - 1) / CI_ROWS)), dim3(CI_THREADS), lds, st, a);
+    static LdsAttrOnce attr;                                       // per template instance (S) and per device
+    attr.set((const void*)mlp2_i8_kernel<S>, 128 * 1024);
+    jf::launch((mlp2_i8_kernel<S>), dim3((unsigned)((a.B + CI_ROWS - 1) / CI_ROWS)), dim3(CI_THREADS), lds, st, a);
     return hipPeekAtLastError() == hipSuccess ? JF_OK : JF_ERR_LAUNCH;
 }
 

@@ -438,7 +438,7 @@ static int mlp2_launch(const T* in, int64_t in_stride, const T* W1, int64_t w1_s
         const int64_t resident = (int64_t)cus * per_cu;
         if (grid > resident) grid = resident;
     }
-    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream, in, in_stride, W1, w1_stride, b1, W2, w2_stride, b2, B,
+    jf::launch(k, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream, in, in_stride, W1, w1_stride, b1, W2, w2_stride, b2, B,
                        (int)K1, (int)H, (int)N, out, out_stride, act);
     return check_launch();
 }
@@ -510,7 +510,7 @@ template <typename T> static bool skinny_linear(const T* in, int64_t is, const T
         if ((B + rows - 1) / rows > 65535) rows = (B + 65534) / 65535;
         if (rows > 0x7fffffff) return false;
         const dim3 grid((unsigned)((N + (1 << cb_shift) - 1) >> cb_shift), (unsigned)((B + rows - 1) / rows));
-#define JF_SK(K_) case K_: hipLaunchKernelGGL((skinny_k_kernel<T, K_>), grid, dim3(256), 0, st, in, is, W, ws, bias, B, (int)N, (int)act, out, os, cb_shift, (int)rows); return true;
+#define JF_SK(K_) case K_: jf::launch((skinny_k_kernel<T, K_>), grid, dim3(256), 0, st, in, is, W, ws, bias, B, (int)N, (int)act, out, os, cb_shift, (int)rows); return true;
         switch (K) { JF_SK(1) JF_SK(2) JF_SK(3) JF_SK(4) JF_SK(5) JF_SK(6) JF_SK(7) JF_SK(8) JF_SK(9) JF_SK(10) JF_SK(11) JF_SK(12) JF_SK(13) JF_SK(14) JF_SK(15)
                      JF_SK(16) default: return false; }
 #undef JF_SK
@@ -534,10 +534,10 @@ static int linear(const T* in, int64_t in_stride, const T* W, int64_t w_stride, 
     if (blocks > 0x7fffffffLL) return JF_ERR_UNSUPPORTED;
     dim3 grid((unsigned)blocks);
     if (N <= NARROW)
-        hipLaunchKernelGGL((linear_kernel<T, NARROW>), grid, dim3(256), 0, (hipStream_t)stream, in, in_stride, W, w_stride, bias, B, (int)K, (int)N,
+        jf::launch((linear_kernel<T, NARROW>), grid, dim3(256), 0, (hipStream_t)stream, in, in_stride, W, w_stride, bias, B, (int)K, (int)N,
                            (int)act, out, out_stride);
     else
-        hipLaunchKernelGGL((linear_kernel<T, BN>), grid, dim3(256), 0, (hipStream_t)stream, in, in_stride, W, w_stride, bias, B, (int)K, (int)N, (int)act,
+        jf::launch((linear_kernel<T, BN>), grid, dim3(256), 0, (hipStream_t)stream, in, in_stride, W, w_stride, bias, B, (int)K, (int)N, (int)act,
                            out, out_stride);
     return check_launch();
 }

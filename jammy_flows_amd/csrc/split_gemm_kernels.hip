@@ -222,7 +222,7 @@ static int sg_pack(const float* W, int64_t ws, int64_t wks, int N, int K, void* 
     const SgShape sh = sg_shape(N);
     const int n_kc = (int)sg_kchunks(K, sh.kc);
     const int64_t total = sg_groups(N, sh.ng) * n_kc * sh.ng * sh.kc * 64;
-    hipLaunchKernelGGL(sg_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, W, ws, wks, N, K, sh.ng, sh.kc, n_kc, total,
+    jf::launch(sg_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, W, ws, wks, N, K, sh.ng, sh.kc, n_kc, total,
                        static_cast<unsigned char*>(packed));
     return check_launch();
 }
@@ -233,7 +233,7 @@ template <int NG, int KC, int TB> static int sg_launch(const SgArgs& a, hipStrea
     if (lds > 160 * 1024) return JF_ERR_UNSUPPORTED;              // (the bias row of a very wide layer: N > ~20000)
     auto k = split_gemm_kernel<NG, KC, TB, RG>;
     if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k, dim3((unsigned)((a.B + 64 * RG - 1) / (64 * RG))), dim3(256), lds, st, a);
+    jf::launch(k, dim3((unsigned)((a.B + 64 * RG - 1) / (64 * RG))), dim3(256), lds, st, a);
     return check_launch();
 }
 
@@ -470,8 +470,8 @@ static int ws_wgrad(const float* g, int64_t gs, const float* in, int64_t is, int
     const int64_t S = ws_splits(B, N);
     a.rows_per_split = ((B + S - 1) / S + 31) / 32 * 32;
     const dim3 grid((unsigned)((N + WS_NW - 1) / WS_NW), (unsigned)S);
-    if (gmax) hipLaunchKernelGGL(wgrad_split_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(wgrad_split_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    if (gmax) jf::launch(wgrad_split_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    else jf::launch(wgrad_split_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, a);
     return check_launch();
 }
 

@@ -191,9 +191,9 @@ static int t_layer(const T* x, int64_t xs, const T* ld_in, const T* params, int6
     if (B == 0) return JF_OK;
     a.x = x; a.xs = xs; a.ld_in = ld_in; a.params = params; a.ps = ps; a.bcast = pb == 1; a.B = B;
     a.x_out = x_out; a.xos = xos; a.ld_out = ld_out; a.blp_in = blp_in; a.blp_out = blp_out; a.status = status;
-    if (D <= 8) hipLaunchKernelGGL((t_kernel<T, FWD, 8>), dim3((unsigned)((B + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
-    else if (D <= 16) hipLaunchKernelGGL((t_kernel<T, FWD, 16>), dim3((unsigned)((B + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL((t_kernel<T, FWD, 32>), dim3((unsigned)((B + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+    if (D <= 8) jf::launch((t_kernel<T, FWD, 8>), dim3((unsigned)((B + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+    else if (D <= 16) jf::launch((t_kernel<T, FWD, 16>), dim3((unsigned)((B + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+    else jf::launch((t_kernel<T, FWD, 32>), dim3((unsigned)((B + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
     return check_launch();
 }
 
@@ -212,7 +212,7 @@ static int t_layer_bwd(const T* x, int64_t xs, const T* params, int64_t ps, int3
     if (lds > 160 * 1024) return JF_ERR_UNSUPPORTED;
     auto k = D <= 8 ? t_bwd_kernel<T, 8> : D <= 16 ? t_bwd_kernel<T, 16> : t_bwd_kernel<T, 32>;
     if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k, dim3((unsigned)((B + 63) / 64)), dim3(64), lds, (hipStream_t)stream, a);
+    jf::launch(k, dim3((unsigned)((B + 63) / 64)), dim3(64), lds, (hipStream_t)stream, a);
     return check_launch();
 }
 

@@ -153,7 +153,7 @@ static inline int64_t wgrad_skinny_splits(int64_t B, int32_t K, int32_t N) {
 template <typename T, bool G_WIDE>
 static bool wgrad_skinny_go(int S, dim3 grid, dim3 block, hipStream_t st, const T* wide, int64_t ws, const T* narrow, int64_t ns, int64_t B, int C, int K, int N,
                             int64_t rps, T* pw, T* pb) {
-#define JF_WS(S_) case S_: hipLaunchKernelGGL((wgrad_skinny_kernel<T, S_, G_WIDE>), grid, block, 0, st, wide, ws, narrow, ns, B, C, K, N, rps, pw, pb); return true;
+#define JF_WS(S_) case S_: jf::launch((wgrad_skinny_kernel<T, S_, G_WIDE>), grid, block, 0, st, wide, ws, narrow, ns, B, C, K, N, rps, pw, pb); return true;
     switch (S) { JF_WS(1) JF_WS(2) JF_WS(3) JF_WS(4) JF_WS(5) JF_WS(6) JF_WS(7) JF_WS(8) JF_WS(9) JF_WS(10) JF_WS(11) JF_WS(12) JF_WS(13) JF_WS(14) JF_WS(15)
                  JF_WS(16) default: return false; }
 #undef JF_WS
@@ -324,7 +324,7 @@ static int mlp2_small_bwd(const T* x, int64_t xs, const T* W1, int64_t w1s, cons
     hipStream_t st = (hipStream_t)stream;
     const int kb = K1 <= 4 ? 4 : K1 <= 8 ? 8 : K1 <= 16 ? 16 : 32, nb = N <= 4 ? 4 : N <= 8 ? 8 : 16;
     const int dense = (kb == K1 || xs == K1) && (nb == N || gs == N);           // padded slots read rows of the same array, never a gap
-#define JF_MS(KB_, NB_) hipLaunchKernelGGL((mlp2_small_bwd_kernel<T, KB_, NB_>), grid, block, 0, st, x, xs, W1, w1s, b1, W2, w2s, g, gs, B, (int)K1, (int)H, (int)N, rpb, slab, slab_b2, dense)
+#define JF_MS(KB_, NB_) jf::launch((mlp2_small_bwd_kernel<T, KB_, NB_>), grid, block, 0, st, x, xs, W1, w1s, b1, W2, w2s, g, gs, B, (int)K1, (int)H, (int)N, rpb, slab, slab_b2, dense)
 #define JF_MS_N(KB_) { if (N <= 4) JF_MS(KB_, 4); else if (N <= 8) JF_MS(KB_, 8); else JF_MS(KB_, 16); }
     if (K1 <= 4) JF_MS_N(4) else if (K1 <= 8) JF_MS_N(8) else if (K1 <= 16) JF_MS_N(16) else JF_MS_N(32)
 #undef JF_MS_N
@@ -344,7 +344,7 @@ static int mlp_hidden_bwd(const T* x, int64_t xs, const T* W1, int64_t w1s, cons
     hipStream_t st = (hipStream_t)stream;
     const int kb = K1 <= 4 ? 4 : K1 <= 8 ? 8 : K1 <= 16 ? 16 : 32;
     const int dense = kb == K1 || xs == K1;
-#define JF_MH(KB_) hipLaunchKernelGGL((mlp_hidden_bwd_kernel<T, KB_>), grid, block, 0, st, x, xs, W1, w1s, b1, gh, ghs, B, (int)K1, (int)H, rpb, slab, dense)
+#define JF_MH(KB_) jf::launch((mlp_hidden_bwd_kernel<T, KB_>), grid, block, 0, st, x, xs, W1, w1s, b1, gh, ghs, B, (int)K1, (int)H, rpb, slab, dense)
     if (K1 <= 4) JF_MH(4); else if (K1 <= 8) JF_MH(8); else if (K1 <= 16) JF_MH(16); else JF_MH(32);
 #undef JF_MH
     return check_launch();
@@ -365,7 +365,7 @@ template <typename T> static int64_t wgrad_splits_t(int64_t B, int32_t N) {     
 template <typename T, int NA, int KT>
 static void wgrad_go(const T* g, int64_t gs, const T* in, int64_t is, int64_t B, int32_t K, int32_t N, int64_t S, T* pw, T* pb, hipStream_t st) {
     const int64_t rps = (((B + S - 1) / S) + Mfma<T>::KS - 1) / Mfma<T>::KS * Mfma<T>::KS;
-    hipLaunchKernelGGL((wgrad_kernel<T, NA, KT>), dim3((unsigned)((N + NA * Mfma<T>::MT - 1) / (NA * Mfma<T>::MT)), (unsigned)S), dim3(64), 0, st, g, gs, in,
+    jf::launch((wgrad_kernel<T, NA, KT>), dim3((unsigned)((N + NA * Mfma<T>::MT - 1) / (NA * Mfma<T>::MT)), (unsigned)S), dim3(64), 0, st, g, gs, in,
                        is, B, K, N, rps, pw, pb);
 }
 

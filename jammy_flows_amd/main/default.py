@@ -13,6 +13,8 @@ import os
 
 import numpy
 import torch
+import torch.utils._python_dispatch
+import torch.utils._pytree
 from torch import nn
 
 from .. import _hip, autograd, init_fns
@@ -209,6 +211,8 @@ class pdf(nn.Module):
         if self.fused_matrix_arithmetic not in ("split_f16", "split_bf16", "f32"):
             raise ValueError("JF_FUSED_MATRIX_ARITHMETIC must be 'split_f16', 'split_bf16' or 'f32', got %r" % self.fused_matrix_arithmetic)
         self._packed_cache = {}
+        self._step_plans = {}
+        self.use_step_plans = os.environ.get("JF_STEP_PLANS", "0") == "1"      # forward() through recorded step plans (planned_forward)
 
         self._read_model_definition(pdf_defs, flow_defs, options_overwrite, conditional_input_dim, amortization_mlp_dims,
                                     amortization_mlp_ranks)
@@ -684,6 +688,9 @@ class pdf(nn.Module):
     def flush_status(self):
         """wait for every deferred status read-back and raise / warn exactly as an immediate check would have."""
         self._poll_status(block=True)
+        for plan in self._step_plans.values():
+            if plan:
+                plan.flush()
 
     def _report_status(self, status):
         """kernel status words -> the reference's warnings / exceptions (bisection_n_newton.py:84-133, default.py:1516)."""
@@ -861,17 +868,63 @@ class pdf(nn.Module):
                                            force_intrinsic_coordinates, only_last)
         with torch.no_grad():
             capturing = self._capture_status is not None
-            if capturing:                                # inside graphed_forward(): a static status buffer, examined by the replaying side
-                status = self._capture_status.zero_()
+            if (self.use_step_plans and not capturing and amortization_parameters is None and not only_last and _hip.BINS_LOG is None
+                    and (conditional_input is None or isinstance(conditional_input, torch.Tensor))):
+                # the whole step re-issued from C by one call (jf_plan_launch): one plan per input signature, recorded at its first use
+                plan = self._step_plan(x, conditional_input, force_embedding_coordinates, force_intrinsic_coordinates)
+                if plan is not None:
+                    return plan(x, conditional_input)
+            if capturing:                                # inside graphed_forward() / a plan recording: a static status buffer, examined by the replaying side
+                status = self._capture_status if _hip._RECORDING is not None else self._capture_status.zero_()
             else:
                 self._poll_status()                      # surfaces problems of earlier calls whose status has arrived meanwhile
                 status = _hip.new_status(x.device) if self.check_status else None
             base, log_det, log_pdf = self._inverse_impl(x, None, conditional_input, amortization_parameters, force_embedding_coordinates,
                                                         force_intrinsic_coordinates, only_last, True, status)
-            total = log_pdf + log_det
+            total = _hip.add_rows(log_pdf, log_det)      # (:1110-1117) a library launch, so that a recorded plan holds the whole step
             if not capturing:
                 self._defer_status(status)
         return total, log_pdf, base
+
+    def planned_forward(self, x, conditional_input=None, **kwargs):
+        """forward() for inputs of THIS signature (shape, strides, dtype, device) recorded once as a step plan (include/jammy_hip.h "step
+        plans") -> callable(x, conditional_input=None) returning fresh (log_prob, log_prob_base, base) tensors.  A call is ONE ctypes call
+        that issues every launch of the step from C; unlike graphed_forward() the inputs are read where they are (no copy into static
+        buffers) and the outputs are new tensors.  The plan holds the addresses of the weights and of the caches built from them (packed
+        images, flattened permanent rows); a call after a parameter update records again by itself (parameter version counters)."""
+        return PlannedForward(self, x, conditional_input, kwargs)
+
+    def _step_plan(self, x, conditional_input, force_embedding_coordinates, force_intrinsic_coordinates):
+        if not x.is_cuda or x.dim() != 2:
+            return None
+        key = (tuple(x.shape), x.stride(), x.dtype, x.device,
+               None if conditional_input is None else (tuple(conditional_input.shape), conditional_input.stride(), conditional_input.dtype),
+               bool(force_embedding_coordinates), bool(force_intrinsic_coordinates))
+        plan = self._step_plans.get(key)
+        if plan is None:
+            if len(self._step_plans) >= 8:               # a few signatures per pdf (each plan keeps its intermediate buffers)
+                self._step_plans.pop(next(iter(self._step_plans)))
+            try:
+                plan = PlannedForward(self, x, conditional_input, dict(force_embedding_coordinates=force_embedding_coordinates,
+                                                                       force_intrinsic_coordinates=force_intrinsic_coordinates))
+            except PlanNotApplicable:
+                plan = False
+            self._step_plans[key] = plan
+        return plan or None
+
+    def invalidate_packed_caches(self):
+        """forget everything derived from the parameters: packed split images, int8 digit images, flattened permanent rows, step plans.  The
+        caches follow the parameters' in-place version counters by themselves; writes that bypass them (`p.data.copy_(...)`, EMA weight
+        swapping through `.data`) need this call."""
+        self._packed_cache.clear()
+        self._step_plans.clear()
+        for m in self.modules():
+            for attr in ("_i8_cache", "_packed", "_perm_row_cache", "_chain_cache"):
+                if hasattr(m, attr):
+                    try:
+                        delattr(m, attr)
+                    except AttributeError:
+                        pass
 
     def graphed_forward(self, x, conditional_input=None, **kwargs):
         """forward() for inputs of THIS shape captured once in a HIP graph -> callable(x, conditional_input=None, check=True) returning
@@ -1411,6 +1464,158 @@ class pdf(nn.Module):
         if target.dim() == 1:
             res = res.squeeze(0)
         return res, log_det
+
+
+class PlanNotApplicable(RuntimeError):
+    """the step of this configuration cannot be replayed from a plan (it leaves the library between launches)"""
+
+
+class _RecordingPass(torch.utils._python_dispatch.TorchDispatchMode):
+    """active while a step is recorded.  Two jobs, both through the dispatcher (every ATen call of this thread passes here):
+    (1) every tensor the pass creates stays alive until the pass is over, so the caching allocator cannot hand the memory of a dead
+        intermediate to a later allocation OF THE SAME PASS -- the plan tells buffers apart by address range, and an output tensor carved out of
+        a dead, larger intermediate would capture the pointers to that intermediate;
+    (2) any ATen operation on device tensors other than allocations and views is work the plan cannot replay (it ran once, now): noted in
+        `foreign`, the configuration then stays on the eager path."""
+    ALLOWED = {"aten.empty.memory_format", "aten.empty_strided.default", "aten.empty_like.default", "aten.new_empty.default",
+               "aten.slice.Tensor", "aten.select.int", "aten.as_strided.default", "aten.view.default", "aten._unsafe_view.default",
+               "aten.unsqueeze.default", "aten.squeeze.dim", "aten.squeeze.default", "aten.expand.default", "aten.t.default",
+               "aten.transpose.int", "aten.detach.default", "aten.alias.default", "aten.narrow.default", "aten.permute.default",
+               "aten.lift_fresh.default", "aten.is_pinned.default", "aten._reshape_alias.default"}
+
+    def __init__(self):
+        super().__init__()
+        self.keep, self.foreign = [], []
+
+    def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+        out = func(*args, **(kwargs or {}))
+        flat = [t for t in torch.utils._pytree.tree_leaves((args, kwargs, out)) if isinstance(t, torch.Tensor)]
+        if any(t.is_cuda for t in flat):
+            self.keep.append(out)
+            if str(func) not in self.ALLOWED:
+                self.foreign.append(str(func))
+        return out
+
+
+class PlannedForward:
+    """pdf.forward recorded as a step plan for one input signature (see pdf.planned_forward)."""
+
+    def __init__(self, pdf, x, conditional_input, kwargs):
+        dev = _hip.require_device(x, conditional_input if isinstance(conditional_input, torch.Tensor) else None)
+        if x.dim() != 2 or (conditional_input is not None and not isinstance(conditional_input, torch.Tensor)):
+            raise PlanNotApplicable("step plans take one (B, D) target tensor and at most one conditional-input tensor")
+        self.pdf, self.kwargs, self.dev = pdf, dict(kwargs), dev
+        self.sig = self._signature(x, conditional_input)
+        self.status = _hip.new_status(dev)                                     # accumulates over the replays; examined lazily
+        self.host_status = torch.zeros(_hip.JF_STATUS_WORDS, dtype=torch.int32).pin_memory()
+        self.pool = torch.cuda.MemPool()
+        self._record(x, conditional_input)
+
+    @staticmethod
+    def _signature(x, c):
+        return (tuple(x.shape), x.stride(), x.dtype, x.device, None if c is None else (tuple(c.shape), c.stride(), c.dtype, c.device))
+
+    def _param_key(self):
+        return tuple(p._version for p in self.pdf.parameters())
+
+    def _record(self, x, cond):
+        pdf = self.pdf
+        dbg = os.environ.get("JF_PLAN_DEBUG")
+
+        def say(*a):
+            if dbg:
+                torch.cuda.synchronize()
+                print("[plan]", *a, flush=True)
+        with torch.no_grad():
+            saved = pdf.use_step_plans
+            pdf.use_step_plans = False
+            try:
+                for _ in range(2):      # every lazily built cache (permanent rows, packed images, kernel attributes) exists before the recording
+                    ref = pdf.forward(x, conditional_input=cond, **self.kwargs)
+                pdf.flush_status()
+                say("warm-up done")
+                self.key = self._param_key()
+                plan = _hip.StepPlan()
+                pdf._capture_status = self.status
+                try:
+                    # intermediate buffers of the recorded pass must keep their addresses for the life of the plan: a private memory pool
+                    with torch.cuda.use_mem_pool(self.pool, device=self.dev), _RecordingPass() as rec:
+                        plan.begin()
+                        try:
+                            out = pdf.forward(x, conditional_input=cond, **self.kwargs)
+                            plan.copy_to_host(self.host_status, self.status)
+                        except BaseException:
+                            plan.abort()
+                            raise
+                        if rec.foreign:
+                            plan.abort()
+                            raise PlanNotApplicable("the step runs torch operations between the library's launches: %s" % sorted(set(rec.foreign)))
+                        self.slot_x = plan.add_slot(x)
+                        self.slot_c = plan.add_slot(cond) if cond is not None else None
+                        self.slot_out = [plan.add_slot(t) for t in out]
+                        plan.end()
+                finally:
+                    pdf._capture_status = None
+                self.plan, self.out_like = plan, out
+                if dbg:
+                    import ctypes
+                    buf = (ctypes.c_uint64 * 512)()
+                    for op in range(plan.n_ops):
+                        n = int(_hip.lib().jf_plan_debug_words(plan.handle, op, buf, 512))
+                        print("[plan] op", op, " ".join("%x" % buf[i] for i in range(n) if buf[i] >> 40), flush=True)
+                    print("[plan] pool tensors alive:", [(hex(t.data_ptr()), t.numel() * t.element_size()) for t in out], "status", hex(self.status.data_ptr()),
+                          "host", hex(self.host_status.data_ptr()), flush=True)
+                say("recorded", plan.n_ops, "ops", int(_hip.lib().jf_plan_num_relocations(plan.handle)), "relocations", plan.calls,
+                    [hex(t.data_ptr()) for t in out], hex(x.data_ptr()))
+                # self-check on DIFFERENT inputs (rows rotated by one): a step that left the library between two launches (a torch op on
+                # the way) would replay that part with the recorded pass's values
+                x2 = torch.roll(x, 1, 0)
+                c2 = None if cond is None else torch.roll(cond, 1, 0)
+                if x2.stride() != x.stride():
+                    x2 = torch.empty_strided(x.shape, x.stride(), dtype=x.dtype, device=x.device).copy_(x2)
+                if c2 is not None and c2.stride() != cond.stride():
+                    c2 = torch.empty_strided(cond.shape, cond.stride(), dtype=cond.dtype, device=cond.device).copy_(c2)
+                want = pdf.forward(x2, conditional_input=c2, **self.kwargs)
+                pdf.flush_status()
+                say("eager on rotated rows done")
+                got = self._replay(x2, c2)
+                torch.cuda.synchronize(self.dev)
+                say("replay on rotated rows done")
+                for g, w in zip(got, want):
+                    if not bool(((g == w) | (g.isnan() & w.isnan())).all()):
+                        raise PlanNotApplicable("replaying the recorded step does not reproduce pdf.forward for this configuration")
+                self.status.zero_()
+                self.host_status.zero_()
+            finally:
+                pdf.use_step_plans = saved
+
+    def _replay(self, x, cond):
+        out = [torch.empty_strided(t.shape, t.stride(), dtype=t.dtype, device=t.device) for t in self.out_like]
+        tensors = [x] + ([cond] if self.slot_c is not None else []) + out
+        self.plan.launch(tensors, self.dev)
+        return tuple(out)
+
+    def __call__(self, x, conditional_input=None):
+        if self._signature(x, conditional_input) != self.sig:
+            raise ValueError("this plan was recorded for inputs %s, got %s" % (self.sig, self._signature(x, conditional_input)))
+        pdf = self.pdf
+        if pdf.check_status and self.host_status.any():                 # words a finished replay copied back: non-zero = a problem in some earlier step
+            self.flush()
+        if self._param_key() != self.key:                               # parameters updated in place since the recording: the caches moved
+            self._record(x, conditional_input)
+        out = self._replay(x, conditional_input)
+        if pdf.check_status and pdf.check_status != "deferred":
+            self.flush()
+        return out
+
+    def flush(self):
+        """wait for the replays so far and raise / warn as the eager path does (the status words accumulate over the replays)"""
+        torch.cuda.current_stream(self.dev).synchronize()
+        if self.host_status.any():
+            words = self.host_status.clone()
+            self.status.zero_()
+            self.host_status.zero_()
+            self.pdf._report_status(words)
 
 
 class GraphedForward:

@@ -11,6 +11,8 @@ import numpy as np
 import torch
 import fixture_io
 import helpers
+sys.path.insert(0, os.path.join(ROOT, "scripts"))
+from bench_configs_inputs import inputs
 
 torch.set_grad_enabled(False)
 
@@ -24,26 +26,6 @@ CONFIGS = [  # (fixture, dtype, rows, label)
     ("c4_i1s1_ro", torch.float64, 1 << 20, 'C4 f64'),
     ("c5_e8s2_ggggv", torch.float64, 1 << 19, 'C5 conditional pdf("e8+s2","gggg+v"), AmortizableMLP rank 8, f64, 2^19 rows (one GPU share)'),
 ]
-
-
-def inputs(fx, n, seed):
-    rng = np.random.default_rng(seed)
-    cols = []
-    for part in fx.pdf_defs.split("+"):
-        kind, dim = part[0], int(part[1:].split("_")[0])
-        if kind == "e":
-            cols.append(rng.normal(size=(n, dim)) * 1.5)
-        elif kind == "i":
-            cols.append(rng.uniform(1e-6, 1 - 1e-6, size=(n, 1)))
-        elif dim == 1:
-            cols.append(rng.uniform(0, 2 * np.pi, size=(n, 1)))
-        else:
-            cols.append(np.arccos(rng.uniform(-1, 1, size=(n, 1))).clip(1e-3, np.pi - 1e-3))
-            cols.append(rng.uniform(0, 2 * np.pi, size=(n, 1)))
-    x = np.concatenate(cols, axis=1)
-    c = fx.get("cond")
-    cond = rng.normal(size=(n, c.shape[1])) if c is not None else None
-    return x, cond
 
 
 def timeit(fn, n=5):

@@ -47,6 +47,8 @@ def rand_arg(t):
         return v
     if t is ctypes.c_double:
         return rng.choice([0.0, 1.0, -1.0, 1e300, float("nan")])
+    if hasattr(t, "_type_") and not hasattr(t._type_, "_fields_"):      # POINTER(scalar): host arrays the step-plan entry points read / write
+        return None if rng.random() < 0.3 else (t._type_ * 64)()
     if hasattr(t, "_type_"):                       # POINTER(struct)
         return rand_struct_array(t)
     raise TypeError(t)
