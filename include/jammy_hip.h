@@ -37,6 +37,12 @@ extern "C" {
 
 int jf_abi_version(void);
 
+/* one column range of an MLP input row cat[conditional_input, embed(x_0), embed(x_1), ...] (main/default.py:946-962): `src` row-major with row
+ * stride `stride` (elements); kind 0 = n_in columns copied, 1 = an S1 angle -> (cos, sin), 2 = S2 (theta, phi) -> (x, y, z)
+ * (sphere_base.py:305-332, 786-794).  Used by jf_conditioning_rows (the rows materialised) and by the *_seg / split3 entry points (read in place). */
+#define JF_MAX_SEGMENTS 16
+typedef struct jf_cond_segment { const void* src; int64_t stride; int32_t kind; int32_t n_in; } jf_cond_segment;
+
 /* ------------------------------------------------------------------------------------------------------------
  * 'g' Gaussianization flow (replaces gf_block._inv_flow_mapping / _flow_mapping + euclidean_base offset handling:
  * jammy_flows/layers/euclidean/gaussianization_flow.py:911-989, 995-1114; euclidean_base.py:34-76;
@@ -175,6 +181,14 @@ int jf_cond_gf_pack2_f32(const float* W2, int64_t w2_stride, const float* b2, in
                          int32_t arithmetic, void* packed, void* stream);
 int jf_cond_gf_chain_split2_f32(int32_t direction, int32_t arithmetic, const float* in, int64_t in_stride, const float* W1, int64_t w1_stride,
                                 const float* b1, const void* packed, int32_t K1, int32_t H, const float* x, int64_t x_stride,
+                                const float* log_det_in, int64_t B, int32_t D, int32_t n_layers, const jf_gf_layer* layers, float* x_out,
+                                int64_t x_out_stride, float* log_det_out, const float* base_logp_in, float* base_logp_out, float* aux,
+                                int32_t* status, void* stream);
+/* the same launch with the MLP's input rows READ WHERE THEY ARE: `segments` (<= 4, widths adding up to K1) describe
+ * cat[conditional_input, embed(x_0), ...] (main/default.py:946-962) as column ranges of the caller's tensors -- see jf_conditioning_rows --, so
+ * neither a conditioning launch nor the (B, K1) matrix exists */
+int jf_cond_gf_chain_split3_f32(int32_t direction, int32_t arithmetic, const jf_cond_segment* segments, int32_t n_segments, const float* W1,
+                                int64_t w1_stride, const float* b1, const void* packed, int32_t K1, int32_t H, const float* x, int64_t x_stride,
                                 const float* log_det_in, int64_t B, int32_t D, int32_t n_layers, const jf_gf_layer* layers, float* x_out,
                                 int64_t x_out_stride, float* log_det_out, const float* base_logp_in, float* base_logp_out, float* aux,
                                 int32_t* status, void* stream);
@@ -340,6 +354,9 @@ int64_t jf_mlp2_i8_packed_bytes(int32_t N, int32_t slices);
 int jf_mlp2_i8_pack_f64(const double* W2, int64_t w2_stride, const double* b2, int32_t H, int32_t N, int32_t slices, void* packed, void* stream);
 int jf_mlp2_i8_f64(const double* in, int64_t in_stride, const double* W1, int64_t w1_stride, const double* b1, const void* packed, int64_t B,
                    int32_t K1, int32_t H, int32_t N, int32_t slices, double* out, int64_t out_stride, void* stream);
+/* the same with the input rows read in place from `segments` (see jf_cond_gf_chain_split3_f32) */
+int jf_mlp2_i8_seg_f64(const jf_cond_segment* segments, int32_t n_segments, const double* W1, int64_t w1_stride, const double* b1, const void* packed,
+                       int64_t B, int32_t K1, int32_t H, int32_t N, int32_t slices, double* out, int64_t out_stride, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * 't' affine flow / multivariate normal (replaces mvn_block._inv_flow_mapping / _flow_mapping + the euclidean_base offset:
@@ -507,8 +524,7 @@ int jf_sphere_from_embedding_f64(const double* x, int64_t x_stride, const double
  * cat[conditional_input, embed(x_0), embed(x_1), ...] of main/default.py:946-962 with embed = identity for Euclidean / interval targets
  * (kind 0, n_in columns copied), (cos, sin) for an S1 angle (kind 1) and (x, y, z) for S2 (theta, phi) (kind 2)
  * (sphere_base.py:305-332, 786-794).  Block i's MLP reads a prefix of the row (autoregressive conditioning). */
-#define JF_MAX_SEGMENTS 16
-typedef struct jf_cond_segment { const void* src; int64_t stride; int32_t kind; int32_t n_in; } jf_cond_segment;
+/* (jf_cond_segment / JF_MAX_SEGMENTS: declared at the top of this header) */
 int jf_conditioning_rows_f32(const jf_cond_segment* segments, int32_t n_segments, int64_t B, float* out, int64_t out_stride, void* stream);
 int jf_conditioning_rows_f64(const jf_cond_segment* segments, int32_t n_segments, int64_t B, double* out, int64_t out_stride, void* stream);
 
@@ -574,7 +590,17 @@ int jf_activation_bwd_f64(const double* g, const double* z, int64_t n, int32_t c
 #define JF_MATH_RCP 3
 int jf_device_math_f32(const float* x, int64_t n, int32_t fn, float* out, void* stream);
 int jf_device_math_f64(const double* x, int64_t n, int32_t fn, double* out, void* stream);
-/* out = a + b (n elements): the last operation of pdf.forward, log_prob = log_prob_base + log_det (main/default.py:1110-1117) */
+/* The last operations of pdf.forward / all_layer_inverse (main/default.py:1110-1117): the sub-manifold blocks of the log-prob direction are
+ * independent given the targets, so every block returns its OWN log-det and base log-prob (ld_in = blp_in = NULL) and one launch adds them up,
+ * in list order: ld_out[b] = sum_i ld.p[i][b], blp_out[b] = sum_i blp.p[i][b], total_out[b] = blp_out[b] + ld_out[b] (each output nullable). */
+#define JF_MAX_ROW_LISTS 16
+typedef struct jf_row_list {
+    const void* p[JF_MAX_ROW_LISTS];
+    int32_t n;
+} jf_row_list;
+int jf_combine_rows_f32(const jf_row_list* ld, const jf_row_list* blp, int64_t B, float* ld_out, float* blp_out, float* total_out, void* stream);
+int jf_combine_rows_f64(const jf_row_list* ld, const jf_row_list* blp, int64_t B, double* ld_out, double* blp_out, double* total_out, void* stream);
+/* out = a + b (n elements) */
 int jf_add_rows_f32(const float* a, const float* b, int64_t n, float* out, void* stream);
 int jf_add_rows_f64(const double* a, const double* b, int64_t n, double* out, void* stream);
 
@@ -606,6 +632,16 @@ int32_t jf_plan_record_begin(int64_t plan);
 int32_t jf_plan_record_end(int64_t plan);                                   /* -> number of recorded ops */
 int32_t jf_plan_add_memset(int64_t plan, void* dst, int32_t value, int64_t bytes);
 int32_t jf_plan_add_copy_to_host(int64_t plan, void* host_dst, const void* src, int64_t bytes);
+/* lanes: ops recorded after jf_plan_set_lane(plan, l), 0 < l < 4, are issued on side stream l of the plan (0 = the caller's stream).  Between
+ * jf_plan_add_fork and the next jf_plan_add_join the ops of different lanes must be independent of each other: the fork makes the side streams
+ * wait for everything given to the caller's stream so far, the join makes the caller's stream wait for them.  (Small batches: the blocks of a
+ * log-prob step are independent given the targets, and their launch / drain tails overlap.) */
+/* any_order: launches recorded while it is on are issued without the queue's barrier bit (hipExtAnyOrderLaunch) and may run beside the launches
+ * recorded before them; the first launch recorded after it is switched off waits for all of them.  Same independence contract as for lanes. */
+int32_t jf_plan_set_any_order(int64_t plan, int32_t on);
+int32_t jf_plan_set_lane(int64_t plan, int32_t lane);
+int32_t jf_plan_add_fork(int64_t plan);
+int32_t jf_plan_add_join(int64_t plan);
 int32_t jf_plan_num_ops(int64_t plan);
 int32_t jf_plan_num_relocations(int64_t plan);
 int32_t jf_plan_launch(int64_t plan, const void* const* slot_bases, int32_t n_slots, void* stream);

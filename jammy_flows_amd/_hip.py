@@ -92,6 +92,10 @@ class jf_t_layer(ctypes.Structure):
                 ("width_min", ctypes.c_double), ("width_max", ctypes.c_double)]
 
 
+class jf_row_list(ctypes.Structure):
+    _fields_ = [("p", ctypes.c_void_p * 16), ("n", ctypes.c_int32)]
+
+
 class jf_cond_segment(ctypes.Structure):
     _fields_ = [("src", ctypes.c_void_p), ("stride", ctypes.c_int64), ("kind", ctypes.c_int32), ("n_in", ctypes.c_int32)]
 
@@ -124,6 +128,7 @@ _SIGNATURES = {
     "jf_activation": [_P, _I64, _I32, _P, _P],
     "jf_device_math": [_P, _I64, _I32, _P, _P],
     "jf_add_rows": [_P, _P, _I64, _P, _P],
+    "jf_combine_rows": [ctypes.POINTER(jf_row_list), ctypes.POINTER(jf_row_list), _I64, _P, _P, _P, _P],
     "jf_activation_bwd": [_P, _P, _I64, _I32, _P, _P],
     "jf_mlp2": [_P, _I64, _P, _I64, _P, _P, _I64, _P, _I64, _I32, _I32, _I32, _P, _I64, _P],
     "jf_sphere_to_embedding": [_P, _I64, _P, _I64, _I32, _P, _I64, _P, _P],
@@ -148,6 +153,10 @@ _SIGNATURES_SINGLE = {
     "jf_plan_add_memset": ([_I64, _P, _I32, _I64], ctypes.c_int32),
     "jf_plan_add_copy_to_host": ([_I64, _P, _P, _I64], ctypes.c_int32),
     "jf_plan_num_ops": ([_I64], ctypes.c_int32),
+    "jf_plan_set_lane": ([_I64, _I32], ctypes.c_int32),
+    "jf_plan_set_any_order": ([_I64, _I32], ctypes.c_int32),
+    "jf_plan_add_fork": ([_I64], ctypes.c_int32),
+    "jf_plan_add_join": ([_I64], ctypes.c_int32),
     "jf_plan_num_relocations": ([_I64], ctypes.c_int32),
     "jf_plan_launch": ([_I64, ctypes.POINTER(ctypes.c_void_p), _I32, _P], ctypes.c_int32),
     "jf_plan_set_timing": ([_I64, _I32], ctypes.c_int32),
@@ -165,6 +174,9 @@ _SIGNATURES_SINGLE = {
     "jf_mlp2_i8_packed_bytes": ([_I32, _I32], ctypes.c_int64),
     "jf_mlp2_i8_pack_f64": ([_P, _I64, _P, _I32, _I32, _I32, _P, _P], ctypes.c_int),
     "jf_mlp2_i8_f64": ([_P, _I64, _P, _I64, _P, _P, _I64, _I32, _I32, _I32, _I32, _P, _I64, _P], ctypes.c_int),
+    "jf_mlp2_i8_seg_f64": ([ctypes.POINTER(jf_cond_segment), _I32, _P, _I64, _P, _P, _I64, _I32, _I32, _I32, _I32, _P, _I64, _P], ctypes.c_int),
+    "jf_cond_gf_chain_split3_f32": ([_I32, _I32, ctypes.POINTER(jf_cond_segment), _I32, _P, _I64, _P, _P, _I32, _I32, _P, _I64, _P, _I64, _I32, _I32,
+                                     ctypes.POINTER(jf_gf_layer), _P, _I64, _P, _P, _P, _P, _P, _P], ctypes.c_int),
     "jf_linear_wgrad_split_splits": ([_I64, _I32], ctypes.c_int64),
     "jf_linear_wgrad_split_f32": ([_P, _I64, _P, _I64, _I64, _I32, _I32, _P, _P, _P], ctypes.c_int),
     "jf_linear_split_pack_f32": ([_P, _I64, _I64, _I32, _I32, _P, _P], ctypes.c_int),
@@ -429,6 +441,18 @@ class StepPlan:
     def num_ops(self):
         return int(lib().jf_plan_num_ops(self.handle))
 
+    def set_any_order(self, on):
+        _check(int(lib().jf_plan_set_any_order(self.handle, 1 if on else 0)), "jf_plan_set_any_order")
+
+    def set_lane(self, lane):
+        _check(int(lib().jf_plan_set_lane(self.handle, lane)), "jf_plan_set_lane")
+
+    def fork(self):
+        _check(int(lib().jf_plan_add_fork(self.handle)), "jf_plan_add_fork")
+
+    def join(self):
+        _check(int(lib().jf_plan_add_join(self.handle)), "jf_plan_add_join")
+
     def memset(self, t, value=0):
         _check(int(lib().jf_plan_add_memset(self.handle, _ptr(t), value, t.numel() * t.element_size())), "jf_plan_add_memset")
 
@@ -459,6 +483,30 @@ class StepPlan:
             if b > a:
                 out[(name, tag)] = (int(n.value), sum(self._ms[i] for i in range(a, b)))
         return out
+
+
+def combine_rows(ld_list, blp_list, want_total=True):
+    """sums of the per-block log-dets and base log-probs in list order (one launch) -> (log_det, base_logp, total); a single entry is returned
+    as it is, an empty list gives None"""
+    ts = [t for t in list(ld_list) + list(blp_list)]
+    dev = require_device(*ts)
+    like = ts[0]
+    B = like.shape[0]
+
+    def lst(items):
+        r = jf_row_list()
+        r.n = len(items)
+        for i, t in enumerate(items):
+            r.p[i] = _ptr(t.contiguous())
+        return r
+    ld_out = torch.empty_like(like) if len(ld_list) > 1 else None
+    blp_out = torch.empty_like(like) if len(blp_list) > 1 else None
+    total = torch.empty_like(like) if (want_total and ld_list and blp_list) else None
+    if ld_out is not None or blp_out is not None or total is not None:
+        a, b = lst(ld_list), lst(blp_list)
+        _launch("jf_combine_rows" + _suffix(like), "", (ctypes.byref(a), ctypes.byref(b), B, _ptr(ld_out), _ptr(blp_out), _ptr(total)), dev)
+    return (ld_out if ld_out is not None else (ld_list[0] if ld_list else None),
+            blp_out if blp_out is not None else (blp_list[0] if blp_list else None), total)
 
 
 def add_rows(a, b):
@@ -697,9 +745,16 @@ def cond_gf_chain_inv_split(inp, w1, b1, packed, x, log_det, layer_array, n_laye
     """as cond_gf_chain_inv with the second product on split-bf16 MFMA and the parameter block in registers (float32, default layer options);
     `kind` selects the kernel the packed image was built for.  aux (cond_gf_aux, "split" only): the launch also leaves what
     cond_gf_chain_inv_split_bwd starts from."""
-    dev = require_device(inp, w1, b1, packed, x, log_det, x_out, base_logp_in, status)
+    seg = None
+    if isinstance(inp, SegInput):
+        if kind == "split16" and inp.in_place_ok and inp.dtype == torch.float32:
+            seg = inp                                      # read in place by jf_cond_gf_chain_split3_f32
+            inp = seg.segments[0][0]
+        else:
+            inp = inp.materialize()
+    dev = require_device(inp, w1, b1, packed, x, log_det, x_out, base_logp_in, status, *(seg.tensors() if seg else []))
     inp, w1, x = _rowmajor(inp), _rowmajor(w1), _rowmajor(x)
-    B, K1 = inp.shape
+    B, K1 = seg.shape if seg else inp.shape
     H = w1.shape[0]
     if x.shape[0] != B or x.shape[1] != D or w1.shape[1] != K1 or b1.shape[0] != H:
         raise ValueError("cond_gf_chain_inv_split: inconsistent shapes")
@@ -714,6 +769,13 @@ def cond_gf_chain_inv_split(inp, w1, b1, packed, x, log_det, layer_array, n_laye
     if kind == "split16":
         if aux is not None and (aux.dtype != torch.float32 or aux.numel() < n_layers * B * 20 or not aux.is_contiguous()):
             raise ValueError("cond_gf_chain_inv_split: aux = cond_gf_aux(B, n_layers)")
+        if seg is not None:
+            arr = seg.c_array()
+            _launch("jf_cond_gf_chain_split3_f32", "K%d_H%d_L%d_D%d" % (K1, H, n_layers, D),
+                    (DIR_INV, SPLIT_F16X2, arr, len(seg.segments), _ptr(w1), w1.stride(0), _ptr(b1.contiguous()), _ptr(packed), K1, H, _ptr(x), x.stride(0),
+                     _ptr(log_det), B, D, n_layers, layer_array, _ptr(x_out), x_out.stride(0), _ptr(ld_out), _ptr(base_logp_in), _ptr(blp_out), _ptr(aux),
+                     _ptr(status)), dev)
+            return (x_out, ld_out, blp_out) if want_base_logp else (x_out, ld_out)
         _launch("jf_cond_gf_chain_split2_f32", "K%d_H%d_L%d_D%d" % (K1, H, n_layers, D),
                 (DIR_INV, SPLIT_F16X2, _ptr(inp), inp.stride(0), _ptr(w1), w1.stride(0), _ptr(b1.contiguous()), _ptr(packed), K1, H, _ptr(x), x.stride(0),
                  _ptr(log_det), B, D, n_layers, layer_array, _ptr(x_out), x_out.stride(0), _ptr(ld_out), _ptr(base_logp_in), _ptr(blp_out), _ptr(aux),
@@ -1008,6 +1070,53 @@ def activation_bwd(g, z, code):
     out = torch.empty_like(z)
     _launch("jf_activation_bwd" + _suffix(z), "", (_ptr(g), _ptr(z), z.numel(), code, _ptr(out)), dev)
     return out
+
+
+class SegInput:
+    """an MLP input row block cat[conditional_input, embed(x_0), ...] (main/default.py:946-962) described by its segments instead of being
+    materialised: list of (tensor (B, n), kind) as for conditioning_rows.  Consumers with a *_seg / split3 entry point read the segments in
+    place (csrc/jf_cond_in.h); every other consumer gets .materialize() (one jf_conditioning_rows launch)."""
+    MAX_IN_PLACE = 4          # csrc/jf_cond_in.h: JF_COND_IN_MAX
+
+    def __init__(self, segments, B, dtype, device):
+        self.segments = [(_rowmajor(t), kind) for t, kind in segments]
+        self.width = sum(t.shape[1] if kind == 0 else kind + 1 for t, kind in self.segments)
+        self.shape = (B, self.width)
+        self.dtype, self.device = dtype, device
+        self._rows = None
+        for i, (t, kind) in enumerate(self.segments):
+            if t.dtype != dtype or t.shape[0] != B:
+                raise TypeError("SegInput: segment %d has dtype %s / %d rows, expected %s / %d" % (i, t.dtype, t.shape[0], dtype, B))
+            if kind != 0 and t.shape[1] != kind:
+                raise ValueError("SegInput: an S%d segment needs %d intrinsic columns" % (kind, kind))
+
+    @property
+    def in_place_ok(self):
+        """worth reading in place?  float32: yes (the consumer embeds angles with the hardware sine / cosine while it stages its tile).
+        float64: only plain column ranges -- double-precision sines in a consumer's serial prologue cost more than the launch they replace
+        (jf_mlp2_i8 1.39 -> 1.57 ms per 2^20 rows against 0.09 ms for jf_conditioning_rows)."""
+        if not 1 <= len(self.segments) <= self.MAX_IN_PLACE:
+            return False
+        return self.dtype == torch.float32 or all(kind == 0 for _, kind in self.segments)
+
+    def c_array(self):
+        arr = (jf_cond_segment * len(self.segments))()
+        for i, (t, kind) in enumerate(self.segments):
+            arr[i] = jf_cond_segment(_ptr(t), t.stride(0), kind, t.shape[1])
+        return arr
+
+    def tensors(self):
+        return [t for t, _ in self.segments]
+
+    def materialize(self):
+        if self._rows is None:
+            self._rows = conditioning_rows(self.segments, self.shape[0], self.dtype, self.device)
+        return self._rows
+
+
+def as_matrix(inp):
+    """a consumer without segment support: the (B, K1) input matrix itself (one jf_conditioning_rows launch for a SegInput)"""
+    return inp.materialize() if isinstance(inp, SegInput) else inp
 
 
 def conditioning_rows(segments, B, dtype, device):
@@ -1351,9 +1460,16 @@ def mlp2_i8_pack(w2, b2, slices=6):
 
 def mlp2_i8(inp, w1, b1, packed, N, slices=6, out=None):
     """mlp2 in float64 with the second product as int8 digit-slice products on the matrix cores; `packed` = mlp2_i8_pack(w2, b2, slices)."""
-    dev = require_device(inp, w1, b1, packed, out)
+    seg = None
+    if isinstance(inp, SegInput):
+        if inp.in_place_ok and inp.dtype == torch.float64:
+            seg = inp                                      # read in place by jf_mlp2_i8_seg_f64
+            inp = seg.segments[0][0]
+        else:
+            inp = inp.materialize()
+    dev = require_device(inp, w1, b1, packed, out, *(seg.tensors() if seg else []))
     inp, w1 = _rowmajor(inp), _rowmajor(w1)
-    B, K1 = inp.shape
+    B, K1 = seg.shape if seg else inp.shape
     H = w1.shape[0]
     if w1.shape[1] != K1 or b1.shape[0] != H:
         raise ValueError("mlp2_i8: inconsistent shapes")
@@ -1363,6 +1479,11 @@ def mlp2_i8(inp, w1, b1, packed, N, slices=6, out=None):
         raise ValueError("mlp2_i8: the packed image does not belong to N = %d, slices = %d" % (N, slices))
     if out is None:
         out = torch.empty((B, (N + 15) // 16 * 16), dtype=inp.dtype, device=inp.device)[:, :N]      # rows of whole 128-byte lines (see mlp2)
+    if seg is not None:
+        arr = seg.c_array()
+        _launch("jf_mlp2_i8_seg_f64", "K%d_H%d_N%d_x%d" % (K1, H, N, slices),
+                (arr, len(seg.segments), _ptr(w1), w1.stride(0), _ptr(b1.contiguous()), _ptr(packed), B, K1, H, N, slices, _ptr(out), out.stride(0)), dev)
+        return out
     _launch("jf_mlp2_i8_f64", "K%d_H%d_N%d_x%d" % (K1, H, N, slices),
             (_ptr(inp), inp.stride(0), _ptr(w1), w1.stride(0), _ptr(b1.contiguous()), _ptr(packed), B, K1, H, N, slices, _ptr(out), out.stride(0)), dev)
     return out

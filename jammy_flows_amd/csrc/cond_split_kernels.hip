@@ -99,6 +99,7 @@ struct CsArgs {
     const float* blp_in; float* blp_out;
     int32_t* status;
     float* aux;                                // SAVE: what the adjoint launch starts from (see cond_bwd_kernels.hip), else unused
+    CondIn cin;                                // n > 0: the MLP's input rows are these segments of the targets / conditional input (jf_cond_in.h)
 };
 
 // RG = row groups (16 rows each) per wave.  With RG = 2 every A fragment read from LDS feeds two MFMAs (half the ds_read_b128 per row,
@@ -139,7 +140,7 @@ __global__ void __launch_bounds__(256, (NP == 2 && !FWD) ? 3 : 2) cond_gf_split_
 
     // ---- phase 1: h^T = tanh(W1 x^T + b1) for the wave's rows as MFMA B operands, three bf16 pieces (jf_cond_split.h)
     bf16x8 hB[RG][CS_KSTEPS][NP];
-    cs_hidden<RG, false, NP>(a.in, a.in_stride, a.W1, a.w1s, a.b1, a.K1, a.H, row0, last, Xs, hB, nullptr, 0);
+    cs_hidden<RG, false, NP>(a.in, a.in_stride, a.W1, a.w1s, a.b1, a.K1, a.H, row0, last, Xs, hB, nullptr, 0, a.cin.n ? &a.cin : nullptr);
     // ---- flow state: lane = (row li of the row group's 16, coordinate lq)
     const bool live = lq < D, leader = lq == 0;
     const int d = live ? lq : D - 1;
@@ -363,7 +364,13 @@ template <bool FWD>
 static int cs_chain(const float* in, int64_t in_stride, const float* W1, int64_t w1s, const float* b1, const void* packed, int32_t K1, int32_t H,
                     const float* x, int64_t xs, const float* ld_in, int64_t B, int32_t D, int32_t n_layers, const jf_gf_layer* layers, float* x_out,
                     int64_t xos, float* ld_out, const float* blp_in, float* blp_out, int32_t* status, void* stream, float* aux = nullptr,
-                    int arithmetic = JF_SPLIT_BF16X3) {
+                    int arithmetic = JF_SPLIT_BF16X3, const jf_cond_segment* segs = nullptr, int32_t n_segs = 0) {
+    CondIn cin{};
+    if (segs || n_segs) {                                          // segmented input: `in` is not used
+        const int rc = cond_in_make(segs, n_segs, K1, cin);
+        if (rc != JF_OK) return rc;
+        in = static_cast<const float*>(cin.s[0].src);
+    }
     if (!in || !W1 || !b1 || !packed || !x || !x_out || !ld_out || !layers || !cs_arith_ok(arithmetic)) return JF_ERR_BADARG;
     if (!width_ok(K1) || !width_ok(H) || !rows_ok(B) || n_layers < 1 || n_layers > JF_MAX_CHAIN) return JF_ERR_BADARG;
     if (K1 > CS_K1MAX || H > CS_HMAX || (reinterpret_cast<uintptr_t>(packed) & 15u)) return JF_ERR_UNSUPPORTED;
@@ -379,7 +386,7 @@ static int cs_chain(const float* in, int64_t in_stride, const float* W1, int64_t
     if (B == 0) return JF_OK;
     a.in = in; a.in_stride = in_stride; a.W1 = W1; a.w1s = w1s; a.b1 = b1; a.packed = static_cast<const unsigned char*>(packed); a.K1 = K1; a.H = H;
     a.x = x; a.xs = xs; a.ld_in = ld_in; a.B = B; a.D = D; a.n_layers = n_layers;
-    a.x_out = x_out; a.xos = xos; a.ld_out = ld_out; a.blp_in = blp_in; a.blp_out = blp_out; a.status = status; a.aux = aux;
+    a.x_out = x_out; a.xos = xos; a.ld_out = ld_out; a.blp_in = blp_in; a.blp_out = blp_out; a.status = status; a.aux = aux; a.cin = cin;
     hipStream_t st = (hipStream_t)stream;
     if constexpr (!FWD) {
         if (aux) return arithmetic == JF_SPLIT_F16X2 ? cs_launch<false, true, 2>(a, B, st) : cs_launch<false, true, 3>(a, B, st);
@@ -428,6 +435,18 @@ int jf_cond_gf_chain_split2_f32(int32_t direction, int32_t arithmetic, const flo
     if (direction == JF_DIR_INV) return jf::cs_chain<false>(in, is, W1, w1s, b1, packed, K1, H, x, xs, ld_in, B, D, n, L, xo, xos, ldo, bi, bo, st, s, aux, arithmetic);
     if (direction == JF_DIR_FWD && !bi && !bo && !aux)
         return jf::cs_chain<true>(in, is, W1, w1s, b1, packed, K1, H, x, xs, ld_in, B, D, n, L, xo, xos, ldo, nullptr, nullptr, st, s, nullptr, arithmetic);
+    return JF_ERR_BADARG;
+}
+int jf_cond_gf_chain_split3_f32(int32_t direction, int32_t arithmetic, const jf_cond_segment* segs, int32_t n_segs, const float* W1, int64_t w1s,
+                                const float* b1, const void* packed, int32_t K1, int32_t H, const float* x, int64_t xs, const float* ld_in, int64_t B,
+                                int32_t D, int32_t n, const jf_gf_layer* L, float* xo, int64_t xos, float* ldo, const float* bi, float* bo, float* aux,
+                                int32_t* st, void* s) {
+    if (!segs || n_segs < 1) return JF_ERR_BADARG;
+    if (direction == JF_DIR_INV)
+        return jf::cs_chain<false>(nullptr, 0, W1, w1s, b1, packed, K1, H, x, xs, ld_in, B, D, n, L, xo, xos, ldo, bi, bo, st, s, aux, arithmetic, segs, n_segs);
+    if (direction == JF_DIR_FWD && !bi && !bo && !aux)
+        return jf::cs_chain<true>(nullptr, 0, W1, w1s, b1, packed, K1, H, x, xs, ld_in, B, D, n, L, xo, xos, ldo, nullptr, nullptr, st, s, nullptr, arithmetic,
+                                  segs, n_segs);
     return JF_ERR_BADARG;
 }
 int64_t jf_cond_gf_aux_floats(int64_t B, int32_t n_layers) {

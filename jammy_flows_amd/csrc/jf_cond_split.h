@@ -1,6 +1,7 @@
 // Shared by the split-bf16 conditional-block kernels (cond_split_kernels.hip: log-prob and sampling direction; cond_bwd_kernels.hip: the
 // adjoint): chunk geometry of the packed W2 image, the reductions over the four coordinate lanes of a row, the supported layer options.
 #pragma once
+#include "jf_cond_in.h"
 #include "jf_cond_regs.h"
 #include "jf_mfma.h"
 
@@ -140,7 +141,7 @@ __device__ __forceinline__ void cs_dma_chunk(__amdgpu_buffer_rsrc_t rsrc, unsign
 template <int RG, bool STORE_H, int NP = CS_NP>
 __device__ __forceinline__ void cs_hidden(const float* __restrict__ in, int64_t in_stride, const float* __restrict__ W1, int64_t w1s,
                                           const float* __restrict__ b1, int K1, int H, int64_t row0, int64_t last, float* Xs,
-                                          bf16x8 (&hB)[RG][CS_KSTEPS][NP], float* __restrict__ h_out, int64_t hs) {
+                                          bf16x8 (&hB)[RG][CS_KSTEPS][NP], float* __restrict__ h_out, int64_t hs, const CondIn* cin = nullptr) {
     using MF = Mfma16<float>;
     constexpr int CS_ROWS = CS_ROWS1 * RG;
     constexpr int MT = 16, KS = 4, NREG = 4, JH = CS_HMAX / MT;
@@ -151,6 +152,29 @@ __device__ __forceinline__ void cs_hidden(const float* __restrict__ in, int64_t 
     float* b1s = W1s + CS_HMAX * ldk;
     {
         const int nx = CS_ROWS * k1p, nw = CS_HMAX * k1p;
+        if (cin) {
+            // segments (jf_cond_in.h): locate, then every load of the batch, then the embedding arithmetic -- straight-line, one wait
+            const bool any_embed = cond_in_any_embed(*cin);
+            for (int base = 0; base < nx; base += 4 * 256) {
+                CondLoc<float> loc[4]; float va[4], vb[4]; int o[4]; bool keep[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int idx = base + u * 256 + tid;
+                    const int r = idx / k1p, c = idx - r * k1p;
+                    const int64_t gr = row0 + r;
+                    loc[u] = cond_in_locate<float>(*cin, gr <= last ? gr : last, c < K1 ? c : 0);
+                    keep[u] = c < K1;
+                    o[u] = idx < nx ? r * ldk + c : -1;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { va[u] = *loc[u].pa; vb[u] = *loc[u].pb; }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float t = cond_in_finish<float, true>(loc[u], va[u], vb[u], any_embed);
+                    if (o[u] >= 0) Xs[o[u]] = keep[u] ? t : 0.f;
+                }
+            }
+        } else
         for (int base = 0; base < nx; base += 4 * 256) {
             float v[4]; int o[4];
 #pragma unroll

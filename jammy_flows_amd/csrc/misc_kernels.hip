@@ -2,9 +2,7 @@
 //   jf_normal_logp_*: out[b] = (in ? in[b] : 0) + sum_d N(0,1).log_prob(z[b,d])      (jammy_flows/main/default.py:1110-1115, 1657, 1670)
 //   jf_conditioning_rows_*: the input rows of the amortisation MLPs, cat[conditional_input, embed(x_0), embed(x_1), ...]
 //                            (main/default.py:946-962; embed = identity / (cos, sin) / (x, y, z): sphere_base.py:305-332, 786-794), one launch
-#include "jf_common.h"
-#include "jf_math.h"
-#include "jf_sphere.h"
+#include "jf_cond_in.h"
 
 namespace jf {
 
@@ -29,13 +27,7 @@ __global__ void __launch_bounds__(256) conditioning_kernel(const CondSegs a, int
             const jf_cond_segment g = a.s[i];
             const int w = g.kind == 0 ? g.n_in : g.kind + 1;
             if (col < w) {
-                const T* r = static_cast<const T*>(g.src) + row * g.stride;
-                if (g.kind == 0) val = r[col];
-                // only the column's own factors of s1_to_eucl / s2_to_eucl (same operations, same values): the dynamic e[col] made every
-                // thread evaluate all four trigonometric functions of the row for one of them
-                else if (g.kind == 1) val = col == 0 ? M<T>::cos(r[0]) : M<T>::sin(r[0]);
-                else if (col == 2) val = M<T>::cos(safe_angle_pi(r[0]));
-                else val = M<T>::sin(safe_angle_pi(r[0])) * (col == 0 ? M<T>::cos(r[1]) : M<T>::sin(r[1]));
+                val = cond_seg_value<T>(g, row, col);
                 break;
             }
             col -= w;
@@ -258,6 +250,31 @@ template <typename T> static int add_rows(const T* a, const T* b, int64_t n, T* 
     return check_launch();
 }
 
+// sums of the per-block log-dets / base log-probs (include/jammy_hip.h: jf_combine_rows), list order, one row per thread
+struct RowLists { const void* ld[JF_MAX_ROW_LISTS]; const void* blp[JF_MAX_ROW_LISTS]; int n_ld, n_blp; };
+template <typename T> __global__ void __launch_bounds__(256) combine_rows_kernel(const RowLists a, int64_t B, T* __restrict__ ld_out, T* __restrict__ blp_out,
+                                                                                 T* __restrict__ total_out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= B) return;
+    T ld = T(0), blp = T(0);
+    for (int k = 0; k < a.n_ld; ++k) { const T v = static_cast<const T*>(a.ld[k])[i]; ld = k == 0 ? v : ld + v; }
+    for (int k = 0; k < a.n_blp; ++k) { const T v = static_cast<const T*>(a.blp[k])[i]; blp = k == 0 ? v : blp + v; }
+    if (ld_out) ld_out[i] = ld;
+    if (blp_out) blp_out[i] = blp;
+    if (total_out) total_out[i] = blp + ld;
+}
+template <typename T> static int combine_rows(const jf_row_list* ld, const jf_row_list* blp, int64_t B, T* ld_out, T* blp_out, T* total_out, void* stream) {
+    if (!rows_ok(B) || (!ld_out && !blp_out && !total_out)) return JF_ERR_BADARG;
+    RowLists a{};
+    a.n_ld = ld ? ld->n : 0; a.n_blp = blp ? blp->n : 0;
+    if (a.n_ld < 0 || a.n_ld > JF_MAX_ROW_LISTS || a.n_blp < 0 || a.n_blp > JF_MAX_ROW_LISTS) return JF_ERR_BADARG;
+    for (int k = 0; k < a.n_ld; ++k) { if (!ld->p[k]) return JF_ERR_BADARG; a.ld[k] = ld->p[k]; }
+    for (int k = 0; k < a.n_blp; ++k) { if (!blp->p[k]) return JF_ERR_BADARG; a.blp[k] = blp->p[k]; }
+    if (B == 0) return JF_OK;
+    jf::launch(combine_rows_kernel<T>, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, B, ld_out, blp_out, total_out);
+    return check_launch();
+}
+
 // the scalar math policy of the flow kernels (jf_math.h), elementwise: what tests/test_gpu_math.py measures against torch
 template <typename T> __global__ void __launch_bounds__(256) math_kernel(const T* __restrict__ x, int64_t n, int fn, T* __restrict__ out) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -277,6 +294,8 @@ template <typename T> static int device_math(const T* x, int64_t n, int fn, T* o
 extern "C" {
 int jf_device_math_f32(const float* x, int64_t n, int32_t fn, float* out, void* s) { return jf::device_math<float>(x, n, fn, out, s); }
 int jf_device_math_f64(const double* x, int64_t n, int32_t fn, double* out, void* s) { return jf::device_math<double>(x, n, fn, out, s); }
+int jf_combine_rows_f32(const jf_row_list* ld, const jf_row_list* blp, int64_t B, float* lo, float* bo, float* to, void* s) { return jf::combine_rows<float>(ld, blp, B, lo, bo, to, s); }
+int jf_combine_rows_f64(const jf_row_list* ld, const jf_row_list* blp, int64_t B, double* lo, double* bo, double* to, void* s) { return jf::combine_rows<double>(ld, blp, B, lo, bo, to, s); }
 int jf_add_rows_f32(const float* a, const float* b, int64_t n, float* out, void* s) { return jf::add_rows<float>(a, b, n, out, s); }
 int jf_add_rows_f64(const double* a, const double* b, int64_t n, double* out, void* s) { return jf::add_rows<double>(a, b, n, out, s); }
 int jf_conditioning_rows_f32(const jf_cond_segment* g, int32_t n, int64_t B, float* out, int64_t os, void* s) {

@@ -28,6 +28,7 @@
 // the accumulators to HBM, whole 128-byte lines per store instruction.  <= 128 VGPRs: four waves per SIMD.
 //
 // Supported: float64, H <= 128, K1 <= 28.
+#include "jf_cond_in.h"
 #include "jf_cond_regs.h"
 #include "jf_mfma.h"
 
@@ -119,6 +120,7 @@ struct CiArgs {
     int K1, H, N;
     int64_t B;
     double* out; int64_t os;
+    CondIn cin;                                                    // n > 0: the input rows are these segments (jf_cond_in.h)
 };
 
 // one chunk of the image -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds: 1 KiB per wave instruction, no register hop): wave w of the 8 moves
@@ -150,6 +152,28 @@ __device__ __forceinline__ unsigned ci_hidden(const CiArgs& a, int64_t row0, int
     double* b1s = W1s + CI_HMAX * ldk;
     {
         const int nx = CI_ROWS * k1p, nw = CI_HMAX * k1p;
+        if (a.cin.n) {
+            const bool any_embed = cond_in_any_embed(a.cin);
+            for (int base = 0; base < nx; base += 4 * CI_THREADS) {
+                CondLoc<double> loc[4]; double va[4], vb[4]; int o[4]; bool keep[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int idx = base + u * CI_THREADS + tid;
+                    const int r = idx / k1p, c = idx - r * k1p;
+                    const int64_t gr = row0 + r;
+                    loc[u] = cond_in_locate<double>(a.cin, gr <= last ? gr : last, c < K1 ? c : 0);
+                    keep[u] = c < K1;
+                    o[u] = idx < nx ? r * ldk + c : -1;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { va[u] = *loc[u].pa; vb[u] = *loc[u].pb; }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const double t = cond_in_finish<double, false>(loc[u], va[u], vb[u], any_embed);
+                    if (o[u] >= 0) Xs[o[u]] = keep[u] ? t : 0.0;
+                }
+            }
+        } else
         for (int base = 0; base < nx; base += 4 * CI_THREADS) {
             double v[4]; int o[4];
 #pragma unroll
@@ -321,13 +345,19 @@ template <int S> static int ci_launch(const CiArgs& a, hipStream_t st) {
 }
 
 static int ci_mlp2(const double* in, int64_t in_stride, const double* W1, int64_t w1s, const double* b1, const void* packed, int64_t B, int32_t K1,
-                   int32_t H, int32_t N, int S, double* out, int64_t os, void* stream) {
+                   int32_t H, int32_t N, int S, double* out, int64_t os, void* stream, const jf_cond_segment* segs = nullptr, int32_t n_segs = 0) {
+    CondIn cin{};
+    if (segs || n_segs) {
+        const int rc = cond_in_make(segs, n_segs, K1, cin);
+        if (rc != JF_OK) return rc;
+        in = static_cast<const double*>(cin.s[0].src);
+    }
     if (!in || !W1 || !b1 || !packed || !out || !ci_slices_ok(S)) return JF_ERR_BADARG;
     if (!width_ok(K1) || !width_ok(H) || !width_ok(N) || !rows_ok(B)) return JF_ERR_BADARG;
     if (K1 > CI_K1MAX || H > CI_HMAX || (reinterpret_cast<uintptr_t>(packed) & 15u)) return JF_ERR_UNSUPPORTED;
     if (os < N || os > (1 << 20)) return JF_ERR_UNSUPPORTED;       // 31-bit byte counts inside a workgroup's 128 rows
     if (B == 0) return JF_OK;
-    const CiArgs a{in, in_stride, W1, w1s, b1, static_cast<const unsigned char*>(packed), K1, H, N, B, out, os};
+    const CiArgs a{in, in_stride, W1, w1s, b1, static_cast<const unsigned char*>(packed), K1, H, N, B, out, os, cin};
     return S == 6 ? ci_launch<6>(a, (hipStream_t)stream) : ci_launch<5>(a, (hipStream_t)stream);
 }
 
@@ -344,5 +374,10 @@ int jf_mlp2_i8_pack_f64(const double* W2, int64_t w2s, const double* b2, int32_t
 int jf_mlp2_i8_f64(const double* in, int64_t is, const double* W1, int64_t w1s, const double* b1, const void* packed, int64_t B, int32_t K1, int32_t H,
                    int32_t N, int32_t slices, double* out, int64_t os, void* s) {
     return jf::ci_mlp2(in, is, W1, w1s, b1, packed, B, K1, H, N, slices, out, os, s);
+}
+int jf_mlp2_i8_seg_f64(const jf_cond_segment* segs, int32_t n_segs, const double* W1, int64_t w1s, const double* b1, const void* packed, int64_t B, int32_t K1,
+                       int32_t H, int32_t N, int32_t slices, double* out, int64_t os, void* s) {
+    if (!segs || n_segs < 1) return JF_ERR_BADARG;
+    return jf::ci_mlp2(nullptr, 0, W1, w1s, b1, packed, B, K1, H, N, slices, out, os, s, segs, n_segs);
 }
 }

@@ -19,6 +19,8 @@
 //            jf_plan_read_timing returns the summed elapsed time per op (what bench.py's roofline needs: per-kernel time inside the timed region).
 //
 // A plan is replayed by one host thread at a time (the relocations are written into the plan's own argument storage).
+#include <hip/hip_ext.h>
+
 #include <cstring>
 #include <mutex>
 #include <vector>
@@ -35,9 +37,12 @@ PlanSink*& plan_sink() { return g_sink; }
 }  // namespace jf
 
 struct jf_plan : jf::PlanSink {
-    enum Kind { LAUNCH = 0, MEMSET = 1, COPY_D2H = 2 };
+    enum Kind { LAUNCH = 0, MEMSET = 1, COPY_D2H = 2, FORK = 3, JOIN = 4 };
+    static constexpr int MAX_LANES = 4;                            // lane 0 = the caller's stream
     struct Op {
         int kind;
+        int lane;
+        int any_order;                                             // LAUNCH: issued without the queue's barrier bit (hipExtAnyOrderLaunch): may overlap its predecessors
         const void* fn; dim3 grid, block; unsigned lds;
         int first_arg, n_args;                                     // LAUNCH: indices into arg_off; MEMSET / COPY: two pointer "arguments" (dst, src)
         int value; int64_t bytes;
@@ -52,9 +57,14 @@ struct jf_plan : jf::PlanSink {
     std::vector<Reloc> relocs;
     bool recording = false, finalised = false;
     int error = 0;
+    int cur_lane = 0;                                              // lane of the ops being recorded
+    int cur_any_order = 0;
+    hipStream_t lane_stream[MAX_LANES] = {};                       // [0] unused; created at the first replay that needs them
+    hipEvent_t fork_event = nullptr, lane_event[MAX_LANES] = {};
+    int lanes_device = -1;
     // timing
     bool timing = false;
-    std::vector<std::vector<hipEvent_t>> pending;                  // per timed replay: n_ops + 1 events
+    std::vector<std::vector<hipEvent_t>> pending;                  // per timed replay: 2 n_ops events
     std::vector<hipEvent_t> pool;
     std::vector<double> ms_sum;
     int64_t timed_replays = 0;
@@ -70,14 +80,14 @@ struct jf_plan : jf::PlanSink {
     void add_launch(const void* fn, dim3 grid, dim3 block, size_t lds, void** args, const size_t* sizes, const size_t* aligns, int n) override {
         if (grid.x == 0 || grid.y == 0 || grid.z == 0) return;       // (an empty launch is an error for hipLaunchKernel; entry points return before it for B = 0)
         Op o{};
-        o.kind = LAUNCH; o.fn = fn; o.grid = grid; o.block = block; o.lds = (unsigned)lds; o.first_arg = (int)arg_off.size(); o.n_args = n;
+        o.kind = LAUNCH; o.lane = cur_lane; o.any_order = cur_any_order; o.fn = fn; o.grid = grid; o.block = block; o.lds = (unsigned)lds; o.first_arg = (int)arg_off.size(); o.n_args = n;
         for (int i = 0; i < n; ++i) push_arg(args[i], sizes[i], aligns[i]);
         ops.push_back(o);
     }
     int add_mem(int kind, const void* dst, const void* src, int value, int64_t bytes) {
         if (!recording || !dst || bytes < 0 || (kind == COPY_D2H && !src)) return JF_ERR_BADARG;
         Op o{};
-        o.kind = kind; o.first_arg = (int)arg_off.size(); o.n_args = 2; o.value = value; o.bytes = bytes;
+        o.kind = kind; o.lane = cur_lane; o.first_arg = (int)arg_off.size(); o.n_args = 2; o.value = value; o.bytes = bytes;
         push_arg(&dst, sizeof(void*), alignof(void*));
         push_arg(&src, sizeof(void*), alignof(void*));
         ops.push_back(o);
@@ -105,8 +115,31 @@ struct jf_plan : jf::PlanSink {
                 }
             }
         }
+        // a fork / join concerns the side lanes used between the fork and its join
+        for (size_t i = 0; i < ops.size(); ++i) {
+            if (ops[i].kind != FORK) continue;
+            int mask = 0;
+            size_t j = i + 1;
+            for (; j < ops.size() && ops[j].kind != JOIN; ++j) mask |= 1 << ops[j].lane;
+            ops[i].value = mask;
+            if (j < ops.size()) ops[j].value = mask;
+        }
         ms_sum.assign(ops.size(), 0.0);
         finalised = true;
+    }
+    // side streams + their events, on the device the plan is replayed on (created once)
+    bool ensure_lanes() {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return false;
+        if (lanes_device == dev) return true;
+        if (lanes_device >= 0) return false;                        // a plan stays on the device of its first replay
+        if (hipEventCreateWithFlags(&fork_event, hipEventDisableTiming) != hipSuccess) return false;
+        for (int l = 1; l < MAX_LANES; ++l) {
+            if (hipStreamCreateWithFlags(&lane_stream[l], hipStreamNonBlocking) != hipSuccess) return false;
+            if (hipEventCreateWithFlags(&lane_event[l], hipEventDisableTiming) != hipSuccess) return false;
+        }
+        lanes_device = dev;
+        return true;
     }
     hipEvent_t get_event() {
         if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
@@ -117,6 +150,11 @@ struct jf_plan : jf::PlanSink {
     ~jf_plan() override {
         for (auto& v : pending) for (hipEvent_t e : v) if (e) (void)hipEventDestroy(e);
         for (hipEvent_t e : pool) if (e) (void)hipEventDestroy(e);
+        if (fork_event) (void)hipEventDestroy(fork_event);
+        for (int l = 1; l < MAX_LANES; ++l) {
+            if (lane_event[l]) (void)hipEventDestroy(lane_event[l]);
+            if (lane_stream[l]) (void)hipStreamDestroy(lane_stream[l]);
+        }
     }
 };
 
@@ -204,6 +242,34 @@ int32_t jf_plan_add_copy_to_host(int64_t h, void* host_dst, const void* src, int
     return p ? p->add_mem(jf_plan::COPY_D2H, host_dst, src, 0, bytes) : JF_ERR_BADARG;
 }
 
+// lanes: ops recorded after jf_plan_set_lane(p, l) are issued on side stream l (0 = the caller's stream).  Between a jf_plan_add_fork and the next
+// jf_plan_add_join the ops of different lanes must be independent of each other; the fork makes every side stream wait for what the caller's
+// stream has been given so far, the join makes the caller's stream wait for the side streams.
+int32_t jf_plan_set_lane(int64_t h, int32_t lane) {
+    jf_plan* p = lookup(h);
+    if (!p || !p->recording || lane < 0 || lane >= jf_plan::MAX_LANES) return JF_ERR_BADARG;
+    p->cur_lane = lane;
+    return JF_OK;
+}
+// launches recorded while any_order is on are issued without the queue's barrier bit (hipExtAnyOrderLaunch): they may start before, and run
+// beside, the launches recorded before them -- for the INDEPENDENT blocks of a step at small batches, where each kernel leaves the chip
+// half empty while it drains.  The first launch after any_order is switched off again is an ordinary (ordered) one: it waits for all of them.
+int32_t jf_plan_set_any_order(int64_t h, int32_t on) {
+    jf_plan* p = lookup(h);
+    if (!p || !p->recording) return JF_ERR_BADARG;
+    p->cur_any_order = on != 0;
+    return JF_OK;
+}
+static int32_t plan_sync_op(jf_plan* p, int kind) {
+    if (!p || !p->recording) return JF_ERR_BADARG;
+    jf_plan::Op o{};
+    o.kind = kind; o.first_arg = (int)p->arg_off.size(); o.n_args = 0; o.value = 0;
+    p->ops.push_back(o);
+    return JF_OK;
+}
+int32_t jf_plan_add_fork(int64_t h) { return plan_sync_op(lookup(h), jf_plan::FORK); }
+int32_t jf_plan_add_join(int64_t h) { return plan_sync_op(lookup(h), jf_plan::JOIN); }
+
 int32_t jf_plan_num_ops(int64_t h) { const jf_plan* p = lookup(h); return p ? (int32_t)p->ops.size() : JF_ERR_BADARG; }
 int32_t jf_plan_num_relocations(int64_t h) { const jf_plan* p = lookup(h); return (p && p->finalised) ? (int32_t)p->relocs.size() : JF_ERR_BADARG; }
 
@@ -221,24 +287,43 @@ int32_t jf_plan_launch(int64_t h, const void* const* slot_bases, int32_t n_slots
     if (p->timing) {
         p->pending.emplace_back();
         ev = &p->pending.back();
-        for (size_t i = 0; i <= p->ops.size(); ++i) ev->push_back(p->get_event());
-        if ((*ev)[0]) (void)hipEventRecord((*ev)[0], st);
+        for (size_t i = 0; i < 2 * p->ops.size(); ++i) ev->push_back(p->get_event());     // (start, end) of every op, on the op's own stream
     }
     int rc = JF_OK;
+    bool lanes = false;
+    for (const auto& o : p->ops) lanes = lanes || o.kind == jf_plan::FORK;
+    if (lanes && !p->ensure_lanes()) return JF_ERR_LAUNCH;
     for (size_t i = 0; i < p->ops.size(); ++i) {
         const jf_plan::Op& o = p->ops[i];
         hipError_t e = hipSuccess;
-        if (o.kind == jf_plan::LAUNCH) {
-            e = hipLaunchKernel(o.fn, o.grid, o.block, p->ptrs.data() + o.first_arg, o.lds, st);
+        hipStream_t os = (lanes && o.lane > 0) ? p->lane_stream[o.lane] : st;
+        if (ev && o.kind != jf_plan::LAUNCH && (*ev)[2 * i]) (void)hipEventRecord((*ev)[2 * i], os);
+        if (o.kind == jf_plan::FORK) {                              // the side streams continue from here: everything issued so far on the caller's stream comes first
+            e = hipEventRecord(p->fork_event, st);
+            for (int l = 1; l < jf_plan::MAX_LANES && e == hipSuccess; ++l)
+                if (o.value >> l & 1) e = hipStreamWaitEvent(p->lane_stream[l], p->fork_event, 0);
+        } else if (o.kind == jf_plan::JOIN) {                       // the caller's stream continues after every side stream used since the fork
+            for (int l = 1; l < jf_plan::MAX_LANES && e == hipSuccess; ++l)
+                if (o.value >> l & 1) {
+                    e = hipEventRecord(p->lane_event[l], p->lane_stream[l]);
+                    if (e == hipSuccess) e = hipStreamWaitEvent(st, p->lane_event[l], 0);
+                }
+        } else if (o.kind == jf_plan::LAUNCH) {
+            // (timed replays take the kernel's own start / stop events: an event recorded behind an any-order launch would be a barrier)
+            if (o.any_order || ev)
+                e = hipExtLaunchKernel(o.fn, o.grid, o.block, p->ptrs.data() + o.first_arg, o.lds, os, ev ? (*ev)[2 * i] : nullptr,
+                                       ev ? (*ev)[2 * i + 1] : nullptr, o.any_order ? hipExtAnyOrderLaunch : 0);
+            else
+                e = hipLaunchKernel(o.fn, o.grid, o.block, p->ptrs.data() + o.first_arg, o.lds, os);
         } else {
             void* dst; const void* src;
             std::memcpy(&dst, p->ptrs[o.first_arg], 8);
             std::memcpy(&src, p->ptrs[o.first_arg + 1], 8);
-            e = o.kind == jf_plan::MEMSET ? hipMemsetAsync(dst, o.value, (size_t)o.bytes, st)
-                                          : hipMemcpyAsync(dst, src, (size_t)o.bytes, hipMemcpyDeviceToHost, st);
+            e = o.kind == jf_plan::MEMSET ? hipMemsetAsync(dst, o.value, (size_t)o.bytes, os)
+                                          : hipMemcpyAsync(dst, src, (size_t)o.bytes, hipMemcpyDeviceToHost, os);
         }
         if (e != hipSuccess) rc = JF_ERR_LAUNCH;
-        if (ev && (*ev)[i + 1]) (void)hipEventRecord((*ev)[i + 1], st);
+        if (ev && o.kind != jf_plan::LAUNCH && (*ev)[2 * i + 1]) (void)hipEventRecord((*ev)[2 * i + 1], os);
     }
     return rc;
 }
@@ -274,10 +359,10 @@ int32_t jf_plan_read_timing(int64_t h, double* ms_sum_per_op, int32_t n_ops, int
     for (auto& ev : p->pending) {
         bool ok = true;
         for (hipEvent_t e : ev) ok = ok && e != nullptr;
-        if (ok && hipEventSynchronize(ev.back()) == hipSuccess) {
+        if (ok) {
             for (size_t i = 0; i < p->ops.size(); ++i) {
                 float ms = 0.f;
-                if (hipEventElapsedTime(&ms, ev[i], ev[i + 1]) == hipSuccess) p->ms_sum[i] += ms;
+                if (hipEventSynchronize(ev[2 * i + 1]) == hipSuccess && hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]) == hipSuccess) p->ms_sum[i] += ms;
             }
             ++p->timed_replays;
         }

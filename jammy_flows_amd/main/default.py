@@ -37,9 +37,19 @@ class HipLinearStack(nn.Sequential):
     reference's ``mlp_predictors.N.{0,2,..}.{weight,bias}`` state loads -- evaluated with the MFMA dense kernel (tanh fused)."""
 
     def forward(self, x):
-        _hip.require_device(x)
+        seg = x if isinstance(x, _hip.SegInput) else None      # input rows described by their segments (read in place by the int8-slice kernel)
+        if seg is not None:
+            mods = list(self)
+            i8 = (len(mods) == 3 and isinstance(mods[1], nn.Tanh) and seg.dtype == torch.float64 and MLP_MATRIX_ARITHMETIC_F64[0] != "f64"
+                  and mods[0].weight.dtype == torch.float64 and MLP_I8_MIN_COLS[0] <= mods[2].out_features and seg.shape[0] >= MLP_I8_MIN_ROWS[0]
+                  and mods[0].in_features <= _hip.MLP2_I8_MAX_IN and mods[0].out_features <= _hip.MLP2_MAX_HIDDEN and mods[0].out_features % 4 == 0
+                  and not torch.is_grad_enabled())
+            if not i8:
+                x = seg.materialize()
+                seg = None
+        _hip.require_device(*(seg.tensors() if seg is not None else [x]))
         mods = list(self)
-        if autograd._needs_grad(x, *self.parameters()):
+        if seg is None and autograd._needs_grad(x, *self.parameters()):
             if (len(mods) == 3 and isinstance(mods[1], nn.Tanh) and autograd.mlp2_small_ok(x, mods[0], mods[2])
                     and mods[0].weight.dtype == x.dtype):
                 # narrow head (e.g. 4 -> 128 -> 10 of an 'f' layer) on data rows: fused forward, one-launch backward
@@ -78,6 +88,7 @@ class HipLinearStack(nn.Sequential):
                     self._i8_image = hit
                 if hit[1] is not None:
                     return _hip.mlp2_i8(x, ps[0], ps[1], hit[1], ps[2].shape[0], slices)
+            x = _hip.as_matrix(x)                                # (non-finite weights: the exact kernel)
             if x.dtype == torch.float32 and ps[2].shape[0] >= 256 and x.shape[0] >= 4096:
                 # wide float32 output (the 548-column parameter block of an e4 block: sampling, the two-launch log-prob path): the second layer on
                 # split-bf16 MFMA (jf_linear_split_f32, 0.23 ms per 2^18 rows) after a streaming first layer beats the fused exact-f32 MFMA launch
@@ -212,6 +223,13 @@ class pdf(nn.Module):
             raise ValueError("JF_FUSED_MATRIX_ARITHMETIC must be 'split_f16', 'split_bf16' or 'f32', got %r" % self.fused_matrix_arithmetic)
         self._packed_cache = {}
         self._step_plans = {}
+        # side streams a recorded step may use for its (independent) blocks at batches up to plan_lane_max_rows.  Default 1 = none: measured on C3,
+        # 2^15 .. 2^18 rows, three lanes stretch every kernel (each fills the chip on its own) and the step gets no shorter
+        self.plan_lanes = int(os.environ.get("JF_PLAN_LANES", "1"))
+        self.plan_lane_max_rows = int(os.environ.get("JF_PLAN_LANE_MAX_ROWS", str(1 << 18)))
+        # the same idea without streams: the blocks after the first are launched without the queue's barrier bit (csrc/plan.hip any_order)
+        self.plan_overlap_blocks = os.environ.get("JF_PLAN_OVERLAP", "0") == "1"
+        self.plan_overlap_max_rows = int(os.environ.get("JF_PLAN_OVERLAP_MAX_ROWS", str(1 << 40)))
         self.use_step_plans = os.environ.get("JF_STEP_PLANS", "0") == "1"      # forward() through recorded step plans (planned_forward)
 
         self._read_model_definition(pdf_defs, flow_defs, options_overwrite, conditional_input_dim, amortization_mlp_dims,
@@ -472,9 +490,11 @@ class pdf(nn.Module):
 
     # =========================================================================================== parameter routing
     def _conditioning_rows(self, x, data_summary):
-        """log-prob direction: every target is known up front, so the input rows of all amortisation MLPs,
-        cat[conditional_input, embed(x_0), embed(x_1), ...] (:946-962), are laid out by ONE launch; block si reads the prefix
-        ``rows[:, :prefix[si]]`` (no torch.cat, no separate embedding launches).  None when nothing needs them / a per-block summary list."""
+        """log-prob direction: every target is known up front, so the input row of every amortisation MLP,
+        cat[conditional_input, embed(x_0), embed(x_1), ...] (:946-962), is a list of SEGMENTS of the caller's tensors: column ranges copied as they
+        are, S1 / S2 angles embedded (sphere_base.py:786-794).  Block si reads the first ``prefix[si]`` columns.  Nothing is launched here: a block
+        whose prefix is one plain column range reads that view, a consumer kernel with segment support reads the segments in place
+        (_hip.SegInput), anything else materialises the rows once (jf_conditioning_rows).  None when nothing needs them / a per-block summary list."""
         if type(data_summary) == list or len(self.mlp_predictors) == 0 or all(m is None for m in self.mlp_predictors):
             return None
         segs, prefix, width = [], [], 0
@@ -490,27 +510,39 @@ class pdf(nn.Module):
                 kind = last.dimension                                            # intrinsic angles -> embedding (sphere_base.py:786-794)
             segs.append((x[:, a:b], kind))
             width += last._embedding_conditional_return_num()
-        need = max([prefix[si] for si, m in enumerate(self.mlp_predictors) if m is not None])
-        if data_summary is not None and need == data_summary.shape[1]:
-            return {"rows": None, "prefix": prefix, "cond": data_summary}       # nothing but the conditional input is ever read
-        keep, w = [], 0
-        for t, kind in segs:                                                     # only the segments some MLP reads
-            if w >= need:
-                break
-            keep.append((t, kind))
-            w += t.shape[1] if kind == 0 else kind + 1
-        if not keep or len(keep) > _hip.JF_MAX_SEGMENTS:
+        if len(segs) > _hip.JF_MAX_SEGMENTS:
             return None
-        return {"rows": _hip.conditioning_rows(keep, x.shape[0], x.dtype, x.device), "prefix": prefix, "cond": data_summary}
+        return {"segs": segs, "prefix": prefix, "cond": data_summary, "B": x.shape[0], "dtype": x.dtype, "device": x.device, "inputs": {}}
 
     def _mlp_input(self, si, data_summary, embeds):
         if isinstance(embeds, dict):
             n = embeds["prefix"][si]
             if n == 0:
                 raise Exception("extra conditional input is empty but required for encoding!")
-            if embeds["cond"] is not None and n == embeds["cond"].shape[1]:
-                return embeds["cond"]                        # the first conditional block reads the conditional input itself
-            return embeds["rows"][:, :n]
+            hit = embeds["inputs"].get(n)
+            if hit is None:
+                keep, w = [], 0
+                for t, kind in embeds["segs"]:                                   # the segments that make up the first n columns
+                    if w >= n:
+                        break
+                    keep.append((t, kind))
+                    w += t.shape[1] if kind == 0 else kind + 1
+                assert w == n, (w, n)
+                # neighbouring plain column ranges of one tensor are one range (x[:, 0:4] + x[:, 4:8] = x[:, 0:8])
+                merged = []
+                for t, kind in keep:
+                    if (merged and kind == 0 and merged[-1][1] == 0 and t.dim() == 2 and merged[-1][0].stride() == t.stride()
+                            and merged[-1][0].data_ptr() + merged[-1][0].shape[1] * t.element_size() * t.stride(1) == t.data_ptr()):
+                        p = merged[-1][0]
+                        merged[-1] = (torch.as_strided(p, (p.shape[0], p.shape[1] + t.shape[1]), p.stride(), p.storage_offset()), 0)
+                    else:
+                        merged.append((t, kind))
+                if len(merged) == 1 and merged[0][1] == 0:
+                    hit = merged[0][0]                                           # one plain column range: the view itself
+                else:
+                    hit = _hip.SegInput(merged, embeds["B"], embeds["dtype"], embeds["device"])
+                embeds["inputs"][n] = hit
+            return hit
         if data_summary is not None:
             inp = data_summary[si] if type(data_summary) == list else data_summary
             if len(embeds) > 0:
@@ -622,6 +654,8 @@ class pdf(nn.Module):
         mlp = self.mlp_predictors[si] if len(self.mlp_predictors) > si else None
         if mlp is not None:
             inp = self._mlp_input(si, data_summary, embeds)
+            if not isinstance(mlp, HipLinearStack):
+                inp = _hip.as_matrix(inp)
             if amort is not None:
                 n = mlp.num_amortization_params
                 out = mlp(inp, extra_inputs=amort[:, counter:counter + n])
@@ -729,7 +763,30 @@ class pdf(nn.Module):
         if lazy:
             embeds = []
         counter = 0
+        # The blocks of the log-prob direction are independent given the targets (every MLP input is a function of x and the conditional
+        # input alone, :946-962): each block returns its OWN log-det / base log-prob and one launch adds them up at the end
+        # (_hip.combine_rows), instead of threading the running sums through the blocks as the reference does (:1020-1031).  A recorded plan
+        # can then issue the blocks of a SMALL batch on side streams (csrc/plan.hip lanes): their launch / drain tails overlap.
+        independent = per_block is None and not lazy and len(self.layer_list) > 1
+        ld_parts = [] if log_det is None else [log_det]
+        blp_parts = []
+        rec = _hip._RECORDING
+        lanes = rec is not None and independent and self.plan_lanes > 1 and B <= self.plan_lane_max_rows
+        overlap = rec is not None and independent and not lanes and self.plan_overlap_blocks and B <= self.plan_overlap_max_rows
+        if lanes:
+            rec.fork()
+        n_blocks = len(self.layer_list)
         for si, block in enumerate(self.layer_list):
+            if independent:
+                if si > 0:
+                    ld_parts.append(log_det)
+                    if want_base_logp:
+                        blp_parts.append(base_logp)
+                log_det, base_logp = None, None
+                if lanes:                                 # the last block stays on the caller's stream
+                    rec.set_lane(0 if si == n_blocks - 1 else 1 + si % (self.plan_lanes - 1))
+                if overlap and si == 1:                   # the blocks after the first may run beside their predecessors (no barrier bit)
+                    rec.set_any_order(True)
             a, b = self.target_dim_indices[si]
             tgt = x[:, a:b]
             ba, bb = self.base_dim_indices[si]
@@ -748,7 +805,7 @@ class pdf(nn.Module):
                                                        len(layers), layers[0].dimension, x_out=out_view, base_logp_in=base_logp,
                                                        want_base_logp=want_base_logp, status=status, kind=packed[0])
                 else:
-                    res = _hip.cond_gf_chain_inv(self._mlp_input(si, data_summary, embeds), *fused, tgt, log_det, larr, len(layers),
+                    res = _hip.cond_gf_chain_inv(_hip.as_matrix(self._mlp_input(si, data_summary, embeds)), *fused, tgt, log_det, larr, len(layers),
                                                  layers[0].dimension, x_out=out_view, base_logp_in=base_logp, want_base_logp=want_base_logp,
                                                  status=status)
                 log_det = res[1]
@@ -762,7 +819,7 @@ class pdf(nn.Module):
             lowrank = self._fusable_lowrank_block(si, layers, only_last, amortization_parameters, x) if kind == "e" else None
             if lowrank is not None:
                 # low-rank AmortizableMLP + g layers in one launch: the parameter block is regenerated per lane from the row's rank-space vector
-                res = _hip.amlp_gf_chain_inv(self._mlp_input(si, data_summary, embeds), *lowrank, tgt, log_det,
+                res = _hip.amlp_gf_chain_inv(_hip.as_matrix(self._mlp_input(si, data_summary, embeds)), *lowrank, tgt, log_det,
                                              _hip.gf_layer_array([l.c_struct() for l in layers]), len(layers), layers[0].dimension,
                                              x_out=out_view, base_logp_in=base_logp, want_base_logp=want_base_logp, status=status)
                 log_det = res[1]
@@ -778,7 +835,7 @@ class pdf(nn.Module):
                 # default amortisation MLP + the manifold chain in one launch: the parameter rows stay in LDS
                 fam, ws = mfused
                 structs = [l.c_struct() if fam == "r" else l.c_struct(1 if l.euclidean_to_sphere_as_first else 0) for l in layers]
-                res = _hip.cond_mchain_inv(fam, self._mlp_input(si, data_summary, embeds), *ws, tgt, log_det, structs, layers[0].dimension,
+                res = _hip.cond_mchain_inv(fam, _hip.as_matrix(self._mlp_input(si, data_summary, embeds)), *ws, tgt, log_det, structs, layers[0].dimension,
                                            x_out=out_view, base_logp_in=base_logp, want_base_logp=want_base_logp, status=status)
                 if res is not None:
                     log_det = res[1]
@@ -845,13 +902,27 @@ class pdf(nn.Module):
                 embeds.append(block[-1]._embedding_conditional_return(tgt))
             if per_block is not None:
                 per_block.append(log_det)
-        return base, log_det, base_logp
+        total = None
+        if independent:
+            ld_parts.append(log_det)
+            if want_base_logp:
+                blp_parts.append(base_logp)
+            if lanes:
+                rec.set_lane(0)
+                rec.join()
+            if overlap:
+                rec.set_any_order(False)                  # the combine launch is ordered: it waits for every block
+            log_det, base_logp, total = _hip.combine_rows([t for t in ld_parts if t is not None], [t for t in blp_parts if t is not None],
+                                                          want_total=want_base_logp)
+        elif want_base_logp:
+            total = _hip.add_rows(base_logp, log_det)     # (:1110-1117)
+        return base, log_det, base_logp, total
 
     def all_layer_inverse(self, x, log_det, data_summary, amortization_parameters=None, force_embedding_coordinates=False,
                           force_intrinsic_coordinates=False, only_last=False):
         """autoregressive backward mapping of all sub-manifold flows -> (base_pos, log_det)  (:879-1057)."""
-        base, log_det, _ = self._inverse_impl(x, log_det, data_summary, amortization_parameters, force_embedding_coordinates,
-                                              force_intrinsic_coordinates, only_last, False, None)
+        base, log_det, _, _ = self._inverse_impl(x, log_det, data_summary, amortization_parameters, force_embedding_coordinates,
+                                                 force_intrinsic_coordinates, only_last, False, None)
         return base, log_det
 
     def forward(self, x, conditional_input=None, amortization_parameters=None, force_embedding_coordinates=False,
@@ -879,9 +950,8 @@ class pdf(nn.Module):
             else:
                 self._poll_status()                      # surfaces problems of earlier calls whose status has arrived meanwhile
                 status = _hip.new_status(x.device) if self.check_status else None
-            base, log_det, log_pdf = self._inverse_impl(x, None, conditional_input, amortization_parameters, force_embedding_coordinates,
-                                                        force_intrinsic_coordinates, only_last, True, status)
-            total = _hip.add_rows(log_pdf, log_det)      # (:1110-1117) a library launch, so that a recorded plan holds the whole step
+            base, log_det, log_pdf, total = self._inverse_impl(x, None, conditional_input, amortization_parameters, force_embedding_coordinates,
+                                                               force_intrinsic_coordinates, only_last, True, status)
             if not capturing:
                 self._defer_status(status)
         return total, log_pdf, base
@@ -1425,7 +1495,7 @@ class pdf(nn.Module):
                     ds2 = ([d.repeat_interleave(S, dim=0) for d in data_summary] if type(data_summary) == list
                            else data_summary.repeat_interleave(S, dim=0))
                 marks2 = []
-                base2, _, _ = self._inverse_impl(filled, None, ds2, None, force_embedding_coordinates, force_intrinsic_coordinates, False, False, None,
+                base2, _, _, _ = self._inverse_impl(filled, None, ds2, None, force_embedding_coordinates, force_intrinsic_coordinates, False, False, None,
                                                  per_block=marks2)
                 # log-prob direction: (if forced) transformation marks first, then the flow marks continuing from their total
                 if forced:
@@ -1497,8 +1567,26 @@ class _RecordingPass(torch.utils._python_dispatch.TorchDispatchMode):
         return out
 
 
+# Memory pools of dead plans.  torch frees a MemPool's cached blocks in its destructor (emptyCache), which ASSERTS that no allocate-to-pool
+# context is active: a cyclic-GC pass that happens to collect an old PlannedForward while another one is being recorded aborted the process.
+# A dying plan therefore parks its pool here; the pools are released at a safe point (before the next recording, or on request).
+_RETIRED_POOLS = []
+
+
+def release_plan_memory():
+    """free the private memory pools of step plans that are no longer referenced"""
+    while _RETIRED_POOLS:
+        _RETIRED_POOLS.pop()
+
+
 class PlannedForward:
     """pdf.forward recorded as a step plan for one input signature (see pdf.planned_forward)."""
+
+    def __del__(self):
+        try:
+            _RETIRED_POOLS.append((getattr(self, "out_like", None), getattr(self, "pool", None)))
+        except Exception:           # noqa: BLE001 -- interpreter shutdown
+            pass
 
     def __init__(self, pdf, x, conditional_input, kwargs):
         dev = _hip.require_device(x, conditional_input if isinstance(conditional_input, torch.Tensor) else None)
@@ -1539,6 +1627,12 @@ class PlannedForward:
                 pdf._capture_status = self.status
                 try:
                     # intermediate buffers of the recorded pass must keep their addresses for the life of the plan: a private memory pool
+                    # (no garbage collection while allocations are routed to it: see _RETIRED_POOLS)
+                    import gc
+                    gc.collect()
+                    release_plan_memory()
+                    gc_was_on = gc.isenabled()
+                    gc.disable()
                     with torch.cuda.use_mem_pool(self.pool, device=self.dev), _RecordingPass() as rec:
                         plan.begin()
                         try:
@@ -1556,6 +1650,8 @@ class PlannedForward:
                         plan.end()
                 finally:
                     pdf._capture_status = None
+                    if "gc_was_on" in locals() and gc_was_on:
+                        gc.enable()
                 self.plan, self.out_like = plan, out
                 if dbg:
                     import ctypes

@@ -116,5 +116,44 @@ def test_kernel_timer_sees_the_kernels_of_a_replayed_plan():
             pf(x)
     table = t.summary()
     names = {k[0] for k in table}
-    assert "jf_cond_gf_chain_split2_f32" in names and "jf_gf_chain_inv_f32" in names, names
+    assert "jf_cond_gf_chain_split3_f32" in names and "jf_gf_chain_inv_f32" in names, names
     assert all(v["launches"] == 5 and v["mean_ms"] > 0 for v in table.values()), table
+
+
+def test_mlp_inputs_read_in_place_equal_the_materialised_rows():
+    """_hip.SegInput: cat[conditional_input, embed(x_0), ...] (main/default.py:946-962) read by the consumer kernel from the segments themselves
+    (csrc/jf_cond_in.h).  float32: angles embedded with the hardware sine / cosine -> within 1e-4 of the materialised path on log p (bar 1e-2);
+    plain column ranges in float64: identical."""
+    from jammy_flows_amd import _hip
+    fx = [f for f in SUPPORTED if f.name == "c3_e4s2e4"][0]
+    pdf = build_product(fx, torch.float32)
+    pdf.check_status = False
+    x = to_dev(np.tile(fx["x"], (30, 1)), torch.float32)
+    t = _hip.KernelTimer()
+    with t:
+        a = pdf(x)[0]
+    assert any(k[0] == "jf_cond_gf_chain_split3_f32" for k in t.summary()) and not any(k[0].startswith("jf_conditioning_rows") for k in t.summary())
+    saved = _hip.SegInput.in_place_ok
+    try:
+        _hip.SegInput.in_place_ok = property(lambda self: False)
+        t = _hip.KernelTimer()
+        with t:
+            b = pdf(x)[0]
+        assert any(k[0].startswith("jf_conditioning_rows") for k in t.summary())
+    finally:
+        _hip.SegInput.in_place_ok = saved
+    fin = torch.isfinite(a) & torch.isfinite(b)
+    assert bool((torch.isfinite(a) == torch.isfinite(b)).all())
+    assert float(((a - b).abs() / (1 + b.abs()))[fin].max()) < 2e-6       # (one float32 ulp of the largest |log p| is 1.2e-4)
+    # float64, two plain column ranges, the int8-slice MLP
+    g = torch.Generator(device="cuda").manual_seed(3)
+    B = 5000
+    u, v = torch.randn(B, 9, generator=g, device="cuda", dtype=torch.float64), torch.randn(B, 6, generator=g, device="cuda", dtype=torch.float64)
+    w1, b1 = torch.randn(128, 7, generator=g, device="cuda", dtype=torch.float64) * 0.3, torch.randn(128, generator=g, device="cuda", dtype=torch.float64)
+    w2, b2 = torch.randn(200, 128, generator=g, device="cuda", dtype=torch.float64), torch.randn(200, generator=g, device="cuda", dtype=torch.float64)
+    img = _hip.mlp2_i8_pack(w2, b2)
+    seg = _hip.SegInput([(u[:, 2:5], 0), (v[:, 1:5], 0)], B, torch.float64, u.device)
+    assert seg.in_place_ok
+    got = _hip.mlp2_i8(seg, w1, b1, img, 200)
+    want = _hip.mlp2_i8(torch.cat([u[:, 2:5], v[:, 1:5]], dim=1), w1, b1, img, 200)
+    assert torch.equal(got, want)
