@@ -12,8 +12,8 @@ One step = one log-prob evaluation (`pdf.forward`) of one batch of synthetic row
                 float32 `value` (+ the float64 rate beside it), 2^20 rows per GPU
   --workload c5: BASELINE configs[4], conditional `pdf("e8+s2", "gggg+v")`, 16 conditioning inputs, AmortizableMLP hidden 128 rank 8, float64
                 ('v' asserts float64 in the reference), 2^19 rows per GPU (= 2^22 over 8)
-  --scaling weak (default): the per-GPU batch is fixed as N grows;  strong: the TOTAL batch is fixed (2^20 for c3, 2^22 for c5) and row-sharded
-                over the ranks -- BASELINE.md section 3 defines efficiency = T_1 / (G T_G) on that.
+  --scaling strong (default): the TOTAL batch is fixed (2^20 for c3, 2^22 for c5 -- at N = 1 the one GPU's 2^19 share) and row-sharded over the
+                ranks: BASELINE.md section 3 defines efficiency = T_1 / (G T_G) on that;  weak: the per-GPU batch is fixed as N grows.
 Inputs are synthetic (seeded) and resident in HBM before the timed region; weights are the frozen golden-fixture state_dicts
 (tests/golden/*.npz: reference init with the MLP damping undone, so parameter blocks really vary per row).
 For N > 1 every step all-gathers its log-probs (ONE RCCL all_gather, asynchronous, overlapping the next step; all waited for in the timed region).
@@ -53,8 +53,19 @@ MFMA_F32_PEAK_TFLOPS = 157.3   # dense f32-input MFMA peak (v_mfma_f32_32x32x2_f
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak, MI355X_MICROARCH.md
 MFMA_F64_PEAK_TFLOPS = 78.6    # v_mfma_f64_16x16x4_f64: 256 flop/clk/CU x 256 CUs x 2.4 GHz / 2 -- measured: scripts/probe/mfma64.hip
 
+TRANS_PEAK_PER_S = 256 * 32 * 2.4e9   # quarter-rate transcendental issue (v_exp / v_log / v_rcp / v_sqrt _f32): 256 CUs x 128 lanes / 4 per clock x 2.4 GHz = 1.97e13 / s
+
 WORKLOADS = {
     # fixture, pdf/flow strings, dtype of `value`, rows per GPU (weak), total rows (strong), SURVEY 8d algorithmic bytes per eval by dtype
+    "c1": dict(fixture="c1_e2_gg", defs=("e2", "gg"), dtype="f64", rows=4096, total=4096, seed=1, bytes_per_eval={"f64": 48, "f32": 24}, flops_per_eval=0,
+               metric="log-prob evals/sec (batch 4096), e2 / gg", desc="unconditional, the reference's CPU-runnable plumbing case"),
+    "c2": dict(fixture="c2_e4_gggg", defs=("e4", "gggg"), dtype="f32", rows=1 << 20, total=1 << 20, seed=2, bytes_per_eval={"f32": 40, "f64": 80},
+               flops_per_eval=0, metric="log-prob evals/sec (batch 2^20 per GPU), e4 / gggg", desc="Gaussianization flow only, unconditional",
+               # transcendental instructions per evaluation of the broadcast g kernel at these options (csrc/gf_kernels.hip gfb_chain_inv_kernel):
+               # exp + rcp per (component, coordinate, layer), three logs per (coordinate, layer), ~6 in the inverse-normal stage of layer 0
+               trans_per_eval=2 * 10 * 4 * 4 + 3 * 4 * 4 + 6 * 4),
+    "c4": dict(fixture="c4_i1s1_ro", defs=("i1+s1", "r+o"), dtype="f32", rows=1 << 20, total=1 << 20, seed=4, bytes_per_eval={"f32": 100, "f64": 200},
+               flops_per_eval=2304, metric="log-prob evals/sec (batch 2^20 per GPU), i1+s1 / r+o", desc="RQ spline on the interval + circular spline on S1"),
     "c3": dict(fixture="c3_e4s2e4", defs=("e4+s2+e4", "gggg+f+gggg"), dtype="f32", rows=1 << 20, total=1 << 20, seed=3,
                bytes_per_eval={"f32": 4612, "f64": 9224}, flops_per_eval=145664,
                metric="log-prob evals/sec (batch 2^20 per GPU), e4+s2+e4 / gggg+f+gggg",
@@ -64,13 +75,21 @@ WORKLOADS = {
                metric="log-prob evals/sec (batch 2^19 per GPU = 2^22 over 8), conditional e8+s2 / gggg+v, AmortizableMLP rank 8",
                desc="conditional pdf (16 inputs), AmortizableMLP hidden 128 rank 8"),
 }
-REFERENCE_8THREAD = {"c3": {"value": 3.71e4, "what": "true reference, float64, batch 2^18, 8 threads of the survey container (BASELINE.md section 2)"},
+REFERENCE_8THREAD = {"c1": {"value": 5.95e5, "what": "true reference, float64, batch 4096, 8 threads of the survey container (BASELINE.md section 2)"},
+                     "c2": {"value": 3.97e5, "what": "true reference, float32, batch 2^20, 8 threads of the survey container (BASELINE.md section 2)"},
+                     "c4": {"value": 1.09e6, "what": "true reference, float64, batch 2^20, 8 threads of the survey container (BASELINE.md section 2)"},
+                     "c3": {"value": 3.71e4, "what": "true reference, float64, batch 2^18, 8 threads of the survey container (BASELINE.md section 2)"},
                      "c5": {"value": 2.44e4, "what": "true reference, float64, batch 2^16, 8 threads of the survey container (BASELINE.md section 2)"}}
 
 
 def make_inputs(workload, n, seed):
-    """SURVEY 8d inputs.  c3: x = [N(0,1.5^2)^4, theta = acos(U(-1,1)) clamped to [1e-3, pi-1e-3], phi = U(0,2pi), N(0,1.5^2)^4];
+    """SURVEY 8d inputs (c1 / c2 / c4: scripts/bench_configs_inputs.py, the same recipe for any pdf definition).  c3: x = [N(0,1.5^2)^4, theta = acos(U(-1,1)) clamped to [1e-3, pi-1e-3], phi = U(0,2pi), N(0,1.5^2)^4];
     c5: c ~ N(0, I_16), x = [N(0,1.5^2)^8, uniform on S2 as (theta, phi)].  Returns (x, cond or None)."""
+    if workload in ("c1", "c2", "c4"):
+        sys.path.insert(0, os.path.join(ROOT, "scripts"))
+        import fixture_io
+        from bench_configs_inputs import inputs
+        return inputs(fixture_io.load(WORKLOADS[workload]["fixture"]), n, seed)
     rng = np.random.default_rng(seed)
     if workload == "c3":
         return np.concatenate([rng.normal(size=(n, 4)) * 1.5,
@@ -179,6 +198,16 @@ def cpu_baseline(workload, budget_s=15.0, workers=None, chunk=4096):
             "reference_container_8thread": REFERENCE_8THREAD[workload]}
 
 
+def oracle_rows(workload, x, c, workers, chunk=4096):
+    """float64 oracle log-probs of the given rows (single-threaded worker processes, forked before any GPU call): the reference values of the
+    UNTILED full-size parity check -- rows strided across the whole timed batch, not a leading sample and not a tiled fixture"""
+    import multiprocessing as mp
+    ctx = mp.get_context("fork")
+    jobs = [(x[i:i + chunk], None if c is None else c[i:i + chunk]) for i in range(0, x.shape[0], chunk)]
+    with ctx.Pool(max(1, min(workers, len(jobs))), initializer=_oracle_init, initargs=(WORKLOADS[workload]["fixture"],)) as pool:
+        return np.concatenate(pool.map(_oracle_chunk, jobs, chunksize=1))
+
+
 # ---------------------------------------------------------------------------------------------- HBM traffic (rocprofv3 PMC)
 PROFILE_TRAFFIC = os.path.join(ROOT, "profiles", "r03_traffic.json")
 WRITE_CAL = 0.965     # WRITE_SIZE calibration on scripts/probe/wstore (16-byte lane-per-row tile stores); FETCH_SIZE x 2 on gfx950 (guide)
@@ -248,7 +277,9 @@ KERNEL_OF = {"jf_cond_f_chain_inv_f32": "cond_mchain_kernel<float, jf::FFam", "j
              "jf_conditioning_rows_f32": "conditioning_kernel<float", "jf_conditioning_rows_f64": "conditioning_kernel<double",
              "jf_v_chain_inv_f64": "mchain_kernel<double, jf::VFam", "jf_amlp2_f64": "amlp2_mfma_kernel",
              "jf_cond_gf_chain_inv_split_f32": "cond_gf_split_kernel", "jf_cond_gf_chain_inv_pp_f32": "cond_gf_pp_kernel",
-             "jf_cond_gf_chain_split2_f32": "cond_gf_split_kernel",
+             "jf_cond_gf_chain_split2_f32": "cond_gf_split_kernel", "jf_cond_gf_chain_split3_f32": "cond_gf_split_kernel",
+             "jf_mlp2_i8_f64": "mlp2_i8_kernel", "jf_mlp2_i8_seg_f64": "mlp2_i8_kernel",
+             "jf_r_chain_inv_f32": "mchain_kernel<float, jf::RFam", "jf_o_chain_inv_f32": "mchain_kernel<float, jf::OFam",
              "jf_cond_gf_chain_inv_f32": "cond_gf_chain_kernel<float",
              "jf_cond_gf_chain_inv_f64": "cond_gf_chain_kernel<double", "jf_mlp2_f32": "mlp2_kernel<float", "jf_mlp2_f64": "mlp2_kernel<double",
              "jf_gf_chain_inv_f32": "gf_chain_kernel<float", "jf_gf_chain_inv_f64": "gf_chain_kernel<double",
@@ -277,7 +308,8 @@ def traffic_of(traffic, kname, ktag):
 # ---------------------------------------------------------------------------------------------- algorithmic accounting
 def kernel_accounting(kname, ktag, s):
     """(algorithmic HBM bytes per row, MFMA flops per row, fused?) of one timed kernel; s = bytes per scalar."""
-    if kname.startswith("jf_cond_gf_chain_inv_split") or kname.startswith("jf_cond_gf_chain_inv_pp") or kname.startswith("jf_cond_gf_chain_split2"):
+    if (kname.startswith("jf_cond_gf_chain_inv_split") or kname.startswith("jf_cond_gf_chain_inv_pp") or kname.startswith("jf_cond_gf_chain_split2")
+            or kname.startswith("jf_cond_gf_chain_split3")):
         K1, H, L, D = (int(t[1:]) for t in ktag.split("_")[:4])
         N = L * (3 * 10 * D + D * D) + D                 # default g rows: 3 K D + D^2 (+ D offsets on the last layer)
         return s * (K1 + N) + s * (D + 1 + N + D + 1), 2 * (K1 * H + H * N), True
@@ -572,6 +604,81 @@ def dry_run(args, W, rank, world, B, total_rows, lo):
     return 0 if ok else 1
 
 
+# ---------------------------------------------------------------------------------------------- after the timed region: sweeps and the other configurations
+def _time_steps(fn, flush, steps, warm=5):
+    import torch
+    for _ in range(warm):
+        fn()
+    flush()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    flush()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps
+
+
+def rows_sweep(pdf, x, c, steps=50):
+    """the step time against the batch size on this one GPU (prefixes of the resident inputs): what strong scaling over G GPUs needs is
+    t(B / G) <= t(B) / (G x 0.85), BASELINE.md section 3.  Every size runs through its own recorded step plan, like the timed step."""
+    B = x.shape[0]
+    out = []
+    for lg in (20, 19, 18, 17, 16):
+        n = 1 << lg
+        if n > B:
+            continue
+        xs, cs = x[:n], (None if c is None else c[:n])
+        dt = _time_steps(lambda: pdf(xs, conditional_input=cs), pdf.flush_status, steps if lg >= 19 else 4 * steps)
+        out.append({"log2_rows": lg, "ms_per_step": 1e3 * dt, "evals_per_s": n / dt})
+    if out:
+        top = out[0]
+        for r in out:
+            r["efficiency_vs_largest"] = top["ms_per_step"] / (r["ms_per_step"] * (1 << (top["log2_rows"] - r["log2_rows"])))
+    return out
+
+
+def side_config(key, dev, steps=20):
+    """one of the other BASELINE configurations, measured after the timed region on rank 0: step time through a recorded plan, parity against
+    the float64 oracle on 2048 rows, the roof fraction on that configuration's own accounting."""
+    import torch
+    import fixture_io
+    import helpers
+    from jammy_flows_amd import _hip
+    W = WORKLOADS[key]
+    fx = fixture_io.load(W["fixture"])
+    dtype = torch.float32 if W["dtype"] == "f32" else torch.float64
+    s = 4 if W["dtype"] == "f32" else 8
+    B = W["rows"]
+    x64, c64 = make_inputs(key, B, W["seed"])
+    pdf = helpers.build_product(fx, dtype, dev)
+    pdf.check_status = "deferred"
+    pdf.use_step_plans = True
+    x = torch.from_numpy(x64).to(device=dev, dtype=dtype)
+    c = None if c64 is None else torch.from_numpy(c64).to(device=dev, dtype=dtype)
+    dt = _time_steps(lambda: pdf(x, conditional_input=c), pdf.flush_status, steps)
+    timer = _hip.KernelTimer()
+    with timer:
+        for _ in range(5):
+            logp = pdf(x, conditional_input=c)[0]
+    table = timer.summary()
+    n_chk = min(2048, B)
+    o = helpers.build_oracle(fx).forward(x64[:n_chk], None if c64 is None else c64[:n_chk])[0]
+    got = logp[:n_chk].double().cpu().numpy()
+    fin = np.isfinite(o)
+    row = {"workload": 'pdf("%s","%s")' % W["defs"], "dtype": W["dtype"], "rows": B, "ms_per_step": 1e3 * dt, "evals_per_s": B / dt,
+           "max_abs_dlogp_vs_f64_oracle": float(np.abs(got - o)[fin].max()), "bar": 1e-2 if s == 4 else 1e-4,
+           "whole_step_hbm_frac": W["bytes_per_eval"][W["dtype"]] * B / dt / 1e9 / HBM_PEAK_GBS,
+           "kernels_ms": {"%s[%s]" % k: round(v["mean_ms"], 4) for k, v in sorted(table.items())}}
+    if "trans_per_eval" in W:                              # the unconditional g kernel is bound by transcendental / vector issue, not by its 40 B per row (SURVEY 8d, D6)
+        kt = max(table.items(), key=lambda kv: kv[1]["total_ms"])[1]["mean_ms"] * 1e-3
+        row["roofline"] = {"bound": "transcendental", "achieved": W["trans_per_eval"] * B / kt / 1e12, "peak": TRANS_PEAK_PER_S / 1e12,
+                           "unit": "T transcendental instructions/s", "frac": W["trans_per_eval"] * B / kt / TRANS_PEAK_PER_S,
+                           "transcendentals_per_eval": W["trans_per_eval"]}
+    del pdf, x, c
+    return row
+
+
 # ---------------------------------------------------------------------------------------------- main
 def main():
     ap = argparse.ArgumentParser()
@@ -579,7 +686,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c3")
-    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="strong",
+                    help="strong (default, BASELINE.md section 3: efficiency = T_1 / (G T_G) at FIXED TOTAL batch): the configuration's batch is row-sharded "
+                         "over the ranks;  weak: every rank gets the full per-GPU batch")
     ap.add_argument("--batch", type=int, default=None, help="rows per GPU (weak) / total rows (strong); default: the BASELINE configuration")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="do not run the rocprofv3 PMC child passes (traffic then comes from the committed profile)")
@@ -589,6 +698,10 @@ def main():
                          "log-prob batch, gradients all-reduced over the ranks")
     ap.add_argument("--train", action="store_true", help="same as --direction train")
     ap.add_argument("--no-fuse", action="store_true", help="time the two-launch path (MLP launch + flow launch) instead of the fused conditional block")
+    ap.add_argument("--preheat-ms", type=float, default=300.0,
+                    help="run the step untimed for this long before the warm-up steps, so that the timed region sees the chip's sustained clocks (0 = off)")
+    ap.add_argument("--no-sweep", action="store_true", help="skip the rows sweep and the table of the other BASELINE configurations (measured after the timed region)")
+    ap.add_argument("--no-plan", action="store_true", help="eager pdf.forward (one ctypes call per launch) instead of the recorded step plan")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--dry-run", action="store_true",
                     help="exercise launch / rendezvous / row sharding / timing loop / all-gather with a stand-in step on the host (no GPU, no kernels): "
@@ -625,9 +738,20 @@ def main():
 
     cpu = None
     traffic = None
+    strided = None
     if rank == 0 and world == 1 and not args.pmc_child:
         if not args.no_cpu_baseline:
             cpu = cpu_baseline(args.workload)                        # before the GPU is touched (fork safety)
+            # untiled full-size parity: 2^16 rows strided across the whole batch through the float64 oracle (a few seconds on the box's cores)
+            n_str = min(1 << 16, B)
+            stride = max(1, B // n_str)
+            xs64, cs64 = make_inputs(args.workload, B, W["seed"] + rank)
+            idx = np.arange(n_str) * stride
+            t0 = time.time()
+            strided = {"idx": idx, "logp": oracle_rows(args.workload, xs64[idx], None if cs64 is None else cs64[idx], cpu["workers"]),
+                       "stride": int(stride)}
+            strided["oracle_s"] = time.time() - t0
+            del xs64, cs64
         if not args.no_pmc:
             traffic = measure_traffic(args.workload, B, not args.no_fuse)   # child processes; this process has not touched the GPU yet
     if traffic is None:
@@ -684,6 +808,7 @@ def main():
         pdf = helpers.build_product(fx, dtype, dev)
         pdf.check_status = "deferred"                 # throughput loop: status words are read back asynchronously and flushed inside the timed region
         pdf.fuse_conditional_blocks = not args.no_fuse
+        pdf.use_step_plans = not args.no_plan         # pdf.forward through a recorded step plan: ONE ctypes call issues every launch of the step
         x = torch.from_numpy(x64).to(device=dev, dtype=dtype)
         c = None if c64 is None else torch.from_numpy(c64).to(device=dev, dtype=dtype)
         # N > 1: the per-row log-probs of every step are all-gathered (RCCL), asynchronously, while the next step computes
@@ -702,6 +827,16 @@ def main():
                 gather.wait()                         # every step's gather has landed inside the timed region
 
         timer = _hip.KernelTimer() if dname == main_dt else None
+        # bring the chip to its sustained clocks first: a 20-step region of 0.8 ms steps starts ~20 ms after the GPU sat idle (inputs were being
+        # generated on the host), inside the power-management ramp -- the same plan measured 0.86 ms per step there and 0.78 ms once it had run for
+        # 50 ms.  Untimed, before the contract's own W warm-up steps; reported in the line (`preheat_ms`).
+        if args.preheat_ms > 0:
+            t_pre = time.perf_counter()
+            while time.perf_counter() - t_pre < args.preheat_ms * 1e-3:
+                for _ in range(8):
+                    step()
+                torch.cuda.synchronize(dev)
+            finish()
         dt = parallel.timed_steps(step, args.steps, args.warmup, finish=finish, device=dev, timer=timer)
         if timer is None and rank == 0:
             # the secondary (float64) leg: per-kernel HIP-event times of two more steps, outside its timed region
@@ -717,6 +852,13 @@ def main():
             n_chk = min(4096, B)
             o = helpers.build_oracle(fx).forward(x64[:n_chk], None if c64 is None else c64[:n_chk])[0]
             err = float(np.max(np.abs(logp[:n_chk].double().cpu().numpy() - o)))
+        # untiled full-size parity: rows strided across the WHOLE timed batch against the float64 oracle (computed before the GPU was touched)
+        untiled = None
+        if rank == 0 and strided is not None:
+            got = logp[torch.from_numpy(strided["idx"]).to(dev)].double().cpu().numpy()
+            fin = np.isfinite(strided["logp"])
+            untiled = {"rows_checked": int(fin.sum()), "row_stride": strided["stride"], "max_abs_dlogp_vs_f64_oracle": float(np.abs(got - strided["logp"])[fin].max()),
+                       "finiteness_mismatches": int((np.isfinite(got) != fin).sum()), "oracle_seconds": round(strided["oracle_s"], 2)}
         # determinism of what was just timed (outside the timed region): the same step again, compared bit for bit over ALL rows -- the check that
         # exposes rare wrong row groups which a 4096-row oracle sample cannot see
         repeats, identical = 3, True
@@ -724,7 +866,10 @@ def main():
             again = pdf(x, conditional_input=c)[0]
             identical = identical and bool(((again == logp) | (again.isnan() & logp.isnan())).all())
         pdf.flush_status()
-        results[dname] = dict(dt=dt, evals_per_s=total_rows * args.steps / dt, ms_per_step=1e3 * dt / args.steps, err=err, identical=identical, repeats=repeats)
+        results[dname] = dict(dt=dt, evals_per_s=total_rows * args.steps / dt, ms_per_step=1e3 * dt / args.steps, err=err, identical=identical, repeats=repeats,
+                              untiled=untiled)
+        if rank == 0 and world == 1 and dname == main_dt and not args.no_sweep:
+            results[dname]["rows_sweep"] = rows_sweep(pdf, x, c)
         if timer is not None:
             kernel_table = timer.summary()
             if rank == 0 and world == 1:
@@ -788,11 +933,18 @@ def main():
         if fused:
             roofline["fused"] = True
             roofline["note"] = ("amortisation MLP + its g layers in one launch: the per-sample parameter block never leaves the chip, so the SURVEY 8d "
-                                "(materialised-block) bytes are far more than the kernel moves -- see `traffic`")
+                                "(materialised-block) bytes are far more than the kernel moves -- see `traffic`; HBM does not bind this kernel: the vector "
+                                "issue of the flow arithmetic and the matrix pipe do (`bound`), `hbm_materialised_*` keep the SURVEY 8d figure")
+        if args.workload == "c2" and "trans_per_eval" in W:
+            roofline.update({"bound": "transcendental", "achieved": W["trans_per_eval"] * B / secs / 1e12, "peak": TRANS_PEAK_PER_S / 1e12,
+                             "unit": "T transcendental instructions/s", "frac": W["trans_per_eval"] * B / secs / TRANS_PEAK_PER_S,
+                             "transcendentals_per_eval": W["trans_per_eval"], "hbm_frac": hbm_gbs / HBM_PEAK_GBS,
+                             "note": "the unconditional g chain evaluates ~%d exp / log / rcp-class instructions per 40-byte row: bound by quarter-rate "
+                                     "transcendental + vector issue (SURVEY 8d, D6), the 40 %% HBM bar does not apply" % W["trans_per_eval"]})
         if flops_per_row:
             tf = flops_per_row * B / secs / 1e12
             mf = {"algorithmic_TFLOPs": tf, "algorithmic_flops_per_launch": flops_per_row * B}
-            if kname.endswith("_split2_f32"):
+            if kname.endswith("_split2_f32") or kname.endswith("_split3_f32"):
                 # the default: two f16 pieces per operand, three f16 MFMA passes (lo hi, hi lo, hi hi) over the padded columns
                 K1, H, L, D = (int(t[1:]) for t in ktag.split("_")[:4])
                 cols = L * 9 * 16
@@ -828,6 +980,15 @@ def main():
             else:
                 mf.update({"arithmetic": "f64 MFMA", "frac_of_f64_mfma_peak": tf / MFMA_F64_PEAK_TFLOPS})
             roofline["mfma"] = mf
+            if fused and ("executed_f16_TFLOPs" in mf or "executed_bf16_TFLOPs" in mf or "executed_TFLOPs" in mf):
+                # the fused block: report it against what binds it.  achieved / peak = the executed matrix rate against the pipe the kernel uses;
+                # the SURVEY 8d (materialised-block) HBM figure moves to hbm_materialised_*
+                ex = mf.get("executed_f16_TFLOPs", mf.get("executed_bf16_TFLOPs", mf.get("executed_TFLOPs")))
+                pk = MFMA_F64_PEAK_TFLOPS if kname.startswith("jf_amlp_gf_chain") and main_dt == "f64" else MFMA_BF16_PEAK_TFLOPS
+                roofline.update({"hbm_materialised_GBs": hbm_gbs, "hbm_materialised_frac": hbm_gbs / HBM_PEAK_GBS,
+                                 "bound": "valu+mfma", "achieved": ex, "peak": pk, "unit": "TFLOP/s (executed on the matrix pipe)", "frac": ex / pk,
+                                 "valu_busy_frac_committed_profile": {"c3": 0.66, "c5": 0.60}.get(args.workload),
+                                 "mfma_busy_frac_committed_profile": {"c3": 0.37, "c5": 0.16}.get(args.workload)})
         step_bytes = W["bytes_per_eval"][main_dt]
         roofline["whole_step"] = {"algorithmic_bytes_per_eval": step_bytes, "achieved_GBs": step_bytes * B / (rm["ms_per_step"] * 1e-3) / 1e9,
                                   "frac": step_bytes * B / (rm["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -844,16 +1005,30 @@ def main():
                        "batch_per_gpu": B, "total_rows": total_rows, "parallelism": "rows sharded over %d GPU(s)" % world},
             "n_ranks_seen": n_ranks_seen, "collective_backend": backend_name,
             "parity": {"max_abs_dlogp_vs_f64_oracle": rm["err"], "bar": 1e-2 if main_dt == "f32" else 1e-4, "rows_checked": min(4096, B),
-                       "repeat_launches_bit_identical": rm["identical"], "repeat_launches": rm["repeats"], "repeat_rows_compared": B},
+                       "repeat_launches_bit_identical": rm["identical"], "repeat_launches": rm["repeats"], "repeat_rows_compared": B,
+                       "untiled_full_size": rm["untiled"]},
+            "dtype_note": ("float32 value: the 128 -> N product of the conditional block runs as 3 f16 MFMA passes over 2-piece splits of the f32 operands "
+                           "(f32 accumulation; measured deviation from the float64 oracle in `parity`, bar 1e-2 -- the reference's own fp32-vs-fp64 "
+                           "agreement is ~3e-5); `cpu_baseline` is the float64 oracle; the like-for-like float64 rate is under `float64`")
+                          if main_dt == "f32" else None,
+            "preheat_ms": args.preheat_ms,
+            "step_issue": "recorded step plan: one ctypes call per step (jf_plan_launch)" if not args.no_plan else "eager: one ctypes call per launch",
             "roofline": roofline,
             "cpu_baseline": cpu,
         }
         if "f64" in results and main_dt != "f64":
             r64 = results["f64"]
-            line["float64"] = {"value": r64["evals_per_s"], "ms_per_step": r64["ms_per_step"], "max_abs_dlogp_vs_f64_oracle": r64["err"], "bar": 1e-4}
+            line["float64"] = {"value": r64["evals_per_s"], "ms_per_step": r64["ms_per_step"], "max_abs_dlogp_vs_f64_oracle": r64["err"], "bar": 1e-4,
+                               "untiled_full_size": r64["untiled"]}
+            b64 = W["bytes_per_eval"].get("f64")
+            if b64:
+                g64 = b64 * B / (r64["ms_per_step"] * 1e-3) / 1e9
+                line["float64"]["roofline"] = {"bound": "hbm", "achieved": g64, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": g64 / HBM_PEAK_GBS,
+                                               "algorithmic_bytes_per_eval": b64,
+                                               "note": "whole float64 step on the SURVEY 8d bytes (the north-star >= 40 % figure, like-for-like with the float64 CPU baseline)"}
             if side_table:
                 line["float64"]["all_kernels_ms_per_step"] = {"%s[%s]" % k: round(v["mean_ms"] * v["launches"] / 2, 4) for k, v in sorted(side_table.items())}
-                i8 = [(k, v) for k, v in side_table.items() if k[0] == "jf_mlp2_i8_f64"]
+                i8 = [(k, v) for k, v in side_table.items() if k[0] in ("jf_mlp2_i8_f64", "jf_mlp2_i8_seg_f64")]
                 if i8:
                     # the wide amortisation MLP of the float64 step on the int8 matrix cores (csrc/mlp_i8_kernels.hip): executed integer
                     # multiply-adds = slice pairs x 2 x rows x 128 hidden units x output columns padded to 16-column tiles
@@ -867,6 +1042,31 @@ def main():
                                                  "arithmetic": "%d int8 digit slices per operand, %d slice-pair products, exact int32 accumulation" % (slices, pairs),
                                                  "float64_equivalent_TFLOPs": 2.0 * B * 128 * n_out / sec / 1e12,
                                                  "f64_mfma_peak_TFLOPs": 78.6}
+        if rm.get("rows_sweep"):
+            sw = rm["rows_sweep"]
+            line["rows_sweep"] = {"what": "step time of this workload against the batch size on this ONE GPU (prefixes of the resident inputs, each size "
+                                          "through its own recorded plan), measured after the timed region",
+                                  "sizes": [{k: (round(v, 5) if isinstance(v, float) else v) for k, v in r.items()} for r in sw]}
+            by = {r["log2_rows"]: r for r in sw}
+            top = sw[0]["log2_rows"]
+            if top - 3 in by:
+                line["rows_sweep"]["predicted_8gpu_strong_scaling_efficiency"] = by[top]["ms_per_step"] / (8 * by[top - 3]["ms_per_step"])
+                line["rows_sweep"]["note"] = ("T_1 / (8 T_8) with T_8 = this GPU's time on an eighth of the batch: compute only, the per-step log-prob "
+                                              "all-gather (512 KiB per rank) comes on top")
+        if rank == 0 and world == 1 and not args.no_sweep:
+            # the other BASELINE configurations, after the timed region (C3 float64 is the `float64` object above)
+            table = {}
+            for key in ("c1", "c2", "c3", "c4", "c5"):
+                if key == args.workload:
+                    table[key] = {"workload": 'pdf("%s","%s")' % W["defs"], "dtype": main_dt, "rows": B, "ms_per_step": rm["ms_per_step"], "evals_per_s": rm["evals_per_s"],
+                                  "max_abs_dlogp_vs_f64_oracle": rm["err"], "bar": 1e-2 if main_dt == "f32" else 1e-4,
+                                  "whole_step_hbm_frac": roofline["whole_step"]["frac"], "note": "the timed run of this line"}
+                    continue
+                try:
+                    table[key] = side_config(key, dev)
+                except Exception as e:                     # noqa: BLE001 -- reported, never hidden
+                    table[key] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+            line["configs"] = table
         if graph_replay is not None:
             line["hip_graph_replay"] = graph_replay
         if two_launch is not None:

@@ -621,7 +621,7 @@ int jf_add_rows_f64(const double* a, const double* b, int64_t n, double* out, vo
  * Everything an entry point decides on the host (kernel variant, grid, occupancy query, attribute setting) is decided at record time; a plan
  * is therefore valid for the shapes, strides, options and non-slot addresses (weights, packed images, intermediate buffers) it was recorded
  * with.  jf_plan_launch never allocates or synchronises.  One host thread replays a plan at a time.
- * Timing: with jf_plan_set_timing(p, 1) a replay records a HIP event before and after every op on the launch stream;
+ * Timing: with jf_plan_set_timing(p, n), n >= 1, every n-th replay records HIP events around every op on the launch stream (0 = off);
  * jf_plan_read_timing waits for them and returns the summed milliseconds per op and the number of replays they cover.
  * ------------------------------------------------------------------------------------------------------------ */
 /* plans are named by int64 HANDLES (never by addresses): a stale or random value is answered with JF_ERR_BADARG */

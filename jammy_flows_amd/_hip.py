@@ -299,9 +299,10 @@ class KernelTimer:
     """records a pair of HIP events (on torch's current stream = the stream the kernels are launched on) around every kernel launch
     made through this module while active; `summary()` (after a synchronize) gives per-kernel launch counts and mean durations."""
 
-    def __init__(self):
+    def __init__(self, plan_every=1):
         self.records = []
         self.plans = []
+        self.plan_every = plan_every        # steps replayed from a plan: events on every n-th replay (the instrumentation then costs 1 / n of ~2 %)
 
     def __enter__(self):
         global _TIMER
@@ -398,7 +399,7 @@ class StepPlan:
         self.calls = []            # (entry point, tag, first op, one past last op) per recorded entry-point call
         self.n_slots = 0
         self._bases = None
-        self._timing = False
+        self._timing = 0
 
     def __del__(self):
         try:
@@ -464,9 +465,9 @@ class StepPlan:
         b = self._bases
         for i, t in enumerate(tensors):
             b[i] = t.data_ptr()
-        timed = _TIMER is not None
+        timed = _TIMER.plan_every if _TIMER is not None else 0
         if timed != self._timing:
-            lib().jf_plan_set_timing(self.handle, 1 if timed else 0)
+            lib().jf_plan_set_timing(self.handle, timed)
             self._timing = timed
         if timed and self not in _TIMER.plans:
             _TIMER.plans.append(self)

@@ -59,6 +59,10 @@ template <> struct M<double> {
     static constexpr double EPS_COS = 1e-10;
     static constexpr double EPS_S1 = 1e-8;
     static constexpr double KAPPA_ID = 1e-8;
+    // (round 4 tried a bar-aware replacement -- Cody-Waite reduction + degree-9 polynomial + v_ldexp_f64, 1.8e-14 relative, ~20 instructions
+    // against OCML's 42, no table: scripts/probe/exp_poly.py -- together with a one-Newton-step reciprocal.  The float64 kernels did not move
+    // (per-sample g chain 1.335 -> 1.36 ms, broadcast 0.545 -> 0.56, C5 block 1.25 -> 1.21 per 2^19 rows): both exponentials carry the same
+    // ~12 float64 FMAs, which issue at half rate on MI355X, and those -- not the instruction count -- are the cycles.  OCML's stays: < 1 ulp.)
     static __device__ __forceinline__ double exp_fast(double x) { return ::exp(x); }
     // Natural logarithm for the mixture sums (three per coordinate and layer; OCML's log is 98 VALU instructions, this one ~40): the classic
     // reduction x = 2^e m, m in [sqrt(1/2), sqrt(2)), f = m - 1, s = f / (2 + f), log m = f - f^2/2 + s (f^2/2 + R(s^2)) with the degree-7 even

@@ -969,7 +969,10 @@ class pdf(nn.Module):
             return None
         key = (tuple(x.shape), x.stride(), x.dtype, x.device,
                None if conditional_input is None else (tuple(conditional_input.shape), conditional_input.stride(), conditional_input.dtype),
-               bool(force_embedding_coordinates), bool(force_intrinsic_coordinates))
+               bool(force_embedding_coordinates), bool(force_intrinsic_coordinates),
+               # the switches that choose kernels: a plan replays the choice made when it was recorded
+               self.fuse_conditional_blocks, self.fused_matrix_arithmetic, self.fused_block_kernel, self.force_fused_manifold_blocks,
+               self.plan_lanes, self.plan_overlap_blocks)
         plan = self._step_plans.get(key)
         if plan is None:
             if len(self._step_plans) >= 8:               # a few signatures per pdf (each plan keeps its intermediate buffers)

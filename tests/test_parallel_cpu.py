@@ -223,7 +223,7 @@ def _run_bench(args, env_extra=None, drop=()):
 def test_bench_launches_its_own_ranks_dry_run():
     """`python bench.py --gpus 2` without a torch.distributed.run environment starts the ranks itself (child process), rank 0 prints ONE JSON line"""
     import json
-    r = _run_bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-run", "--batch", "1000"], {"JF_BENCH_BACKEND": "gloo"},
+    r = _run_bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-run", "--batch", "1000", "--scaling", "weak"], {"JF_BENCH_BACKEND": "gloo"},
                    drop=("WORLD_SIZE", "RANK", "LOCAL_RANK"))
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -231,7 +231,13 @@ def test_bench_launches_its_own_ranks_dry_run():
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["n_ranks_seen"] == 2 and line["collective_backend"] == "gloo"
     assert line["dry_run"] is True and line["gathered_rows_correct"] is True
-    assert line["config"]["total_rows"] == 2000 and line["steps"] == 3 and line["warmup"] == 1
+    assert line["config"]["total_rows"] == 2000 and line["steps"] == 3 and line["warmup"] == 1 and line["scaling"] == "weak"
+    # the default is STRONG scaling (efficiency at fixed total batch): --batch is then the total, split over the ranks
+    r = _run_bench(["--gpus", "2", "--steps", "1", "--warmup", "0", "--dry-run", "--batch", "1000"], {"JF_BENCH_BACKEND": "gloo"},
+                   drop=("WORLD_SIZE", "RANK", "LOCAL_RANK"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert line["scaling"] == "strong" and line["config"]["total_rows"] == 1000 and line["config"]["batch_per_gpu"] == 500
 
 
 def test_bench_c5_strong_scaling_row_split_dry_run():
