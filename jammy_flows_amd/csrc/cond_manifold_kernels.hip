@@ -6,8 +6,14 @@
 // matrix cores into registers (transposed products as in mlp_kernels.hip: the first result is the second's B operand), multiplies them
 // with W2 (<= 64 output columns, whole matrix in LDS) and drops the 16 x N parameter rows into its LDS tile; then the 64 lanes run the
 // layers lane-per-row on that tile exactly as the stand-alone chain kernel does (same Fam::apply device code).
+//
+// Round 4, float32: the SECOND product (128 -> N) runs on the f16 matrix pipe with the arithmetic of the fused g block (jf_cond_split.h: every
+// f32 operand as two f16 pieces scaled into the normal range, three v_mfma_f32_16x16x32_f16 passes, f32 accumulation; error below a plain f32
+// matrix product's own rounding).  Exact-f32 MFMA issues at the VECTOR rate on CDNA4 and each of its operands was a scalar LDS read: the block
+// spent 0.06 of its 0.108 ms per 2^20 rows there.  W2 is cut into fragments by the workgroup itself (<= 64 x 128 values, L2-resident).
 #include <type_traits>
 
+#include "jf_cond_split.h"
 #include "jf_manifold.h"
 #include "jf_mfma.h"
 
@@ -46,23 +52,63 @@ __global__ void __launch_bounds__(NT) cond_mchain_kernel(const CmArgs<T, typenam
     T* b1s = W1s + CM_HMAX * ldk;                                  // [128]
     T* W2s = b1s + CM_HMAX;                                        // [np][LDW]
     T* b2s = W2s + np * LDW;                                       // [np]
-    T* Xs = b2s + np;                                              // [NT][ldk]
+    T* Xs = b2s + np + 8;                                          // [NT][ldk]  (8: the absmax partials of the float32 path)
     T* tiles = Xs + NT * ldk;                                      // [NT][tile_stride]
     T* tabs = tiles + NT * a.tile_stride;                          // [NT][JF_SPLINE_TAB (+ scratch)]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lq = lane >> 4;
-    const int64_t row0 = (int64_t)blockIdx.x * NT;
     const int64_t last = a.B - 1;
     for (int i = tid; i < CM_HMAX * k1p; i += NT) {
         const int r = i / k1p, c = i - r * k1p;
         W1s[r * ldk + c] = (r < a.H && c < a.K1) ? a.W1[(int64_t)r * a.w1s + c] : T(0);
     }
     for (int i = tid; i < CM_HMAX; i += NT) b1s[i] = i < a.H ? a.b1[i] : T(0);
-    for (int i = tid; i < np * CM_HMAX; i += NT) {
-        const int r = i / CM_HMAX, c = i - r * CM_HMAX;
-        W2s[r * LDW + c] = (r < a.N && c < a.H) ? a.W2[(int64_t)r * a.w2s + c] : T(0);
+    float w2_inv = 1.f;                                              // float32: 2^-(e + 14), undoes the scales of W2 and h
+    if constexpr (std::is_same<T, float>::value) {
+        // absmax of W2 -> the power of two that puts it into [2^14, 2^15) (f16 normal range for the low pieces as well: jf_cond_split.h)
+        float amax = 0.f;
+        for (int i = tid; i < a.N * a.H; i += NT) {
+            const int r = i / a.H, c = i - r * a.H;
+            amax = fmaxf(amax, fabsf(a.W2[(int64_t)r * a.w2s + c]));
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) amax = fmaxf(amax, __shfl_xor(amax, m));
+        float* red = reinterpret_cast<float*>(b2s + np);               // NT / 64 partial maxima (the host reserves them behind the bias)
+        if (lane == 0) red[wave] = amax;
+        __syncthreads();
+        amax = red[0];
+        for (int w = 1; w < NT / 64; ++w) amax = fmaxf(amax, red[w]);
+        const int e = (amax > 0.f && amax < INFINITY) ? 14 - ilogbf(amax) : 0;
+        const float wscale = ldexpf(1.0f, e);
+        w2_inv = ldexpf(1.0f, -(e + 14));
+        // fragment (column tile ct, k-step s, piece p) = the A operand of one v_mfma_f32_16x16x32_f16: lane (m, q) carries output column 16 ct + m,
+        // hidden units 16 (2 s + i / 4) + 4 q + i % 4, i = 0..7 (the k order phase 1 leaves the activations in)
+        unsigned char* W2p = reinterpret_cast<unsigned char*>(W2s);
+        for (int f = tid; f < (np / MT) * CS_KSTEPS * 64; f += NT) {
+            const int fl = f & 63, s = (f >> 6) % CS_KSTEPS, ct = (f >> 6) / CS_KSTEPS;
+            const int m = fl & 15, q = fl >> 4, col = ct * MT + m;
+            f16x8 hi, lo;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int k = 16 * (2 * s + (i >> 2)) + 4 * q + (i & 3);
+                const float w = (col < a.N && k < a.H) ? a.W2[(int64_t)col * a.w2s + k] * wscale : 0.f;
+                const _Float16 h16 = (_Float16)w;
+                hi[i] = h16; lo[i] = (_Float16)(w - (float)h16);
+            }
+            *reinterpret_cast<f16x8*>(W2p + (size_t)((ct * CS_KSTEPS + s) * 2 + 0) * CS_FRAG + fl * 16) = hi;
+            *reinterpret_cast<f16x8*>(W2p + (size_t)((ct * CS_KSTEPS + s) * 2 + 1) * CS_FRAG + fl * 16) = lo;
+        }
+    } else {
+        for (int i = tid; i < np * CM_HMAX; i += NT) {
+            const int r = i / CM_HMAX, c = i - r * CM_HMAX;
+            W2s[r * LDW + c] = (r < a.N && c < a.H) ? a.W2[(int64_t)r * a.w2s + c] : T(0);
+        }
     }
     for (int i = tid; i < np; i += NT) b2s[i] = (i < a.N && a.b2) ? a.b2[i] : T(0);
+    // a resident set of workgroups walks the row tiles: the weights (and the float32 path's fragment image of W2) are staged once per workgroup,
+    // not once per 256 rows (4096 workgroups each spent ~5 us on three dependent rounds of L2 loads before their first MFMA)
+    for (int64_t row0 = (int64_t)blockIdx.x * NT; row0 < a.B; row0 += (int64_t)gridDim.x * NT) {
+    __syncthreads();                                               // the previous tile's readers of Xs / tiles are done
     for (int i = tid; i < NT * k1p; i += NT) {
         const int r = i / k1p, c = i - r * k1p;
         const int64_t gr = row0 + r;
@@ -91,6 +137,41 @@ __global__ void __launch_bounds__(NT) cond_mchain_kernel(const CmArgs<T, typenam
 #pragma unroll
                 for (int r = 0; r < NREG; ++r) hreg[j][r] = M<T>::tanh_fast(acc[j][r] + b1s[j * MT + MF::row_of(r, lane)]);
         }
+        if constexpr (std::is_same<T, float>::value) {
+            // activations -> f16 pairs in the B-operand layout (as cs_hidden), then three MFMA passes per (column tile, k-step): lo x hi, hi x lo, hi x hi
+            f16x8 hH[CS_KSTEPS], hL[CS_KSTEPS];
+#pragma unroll
+            for (int s = 0; s < CS_KSTEPS; ++s) {
+                using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+                u32x4 q0, q1;
+#pragma unroll
+                for (int i = 0; i < 8; i += 2) {
+                    const int j = 2 * s + (i >> 2), r = i & 3;
+                    unsigned ph, pl;
+                    cs_split16(hreg[j][r] * CS_H_SCALE, hreg[j][r + 1] * CS_H_SCALE, ph, pl);
+                    q0[i >> 1] = ph; q1[i >> 1] = pl;
+                }
+                hH[s] = __builtin_bit_cast(f16x8, q0); hL[s] = __builtin_bit_cast(f16x8, q1);
+            }
+            const unsigned char* W2p = reinterpret_cast<const unsigned char*>(W2s);
+            for (int ct = 0; ct < np / MT; ++ct) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < CS_KSTEPS; ++s) {
+                    const f16x8 aH = *reinterpret_cast<const f16x8*>(W2p + (size_t)((ct * CS_KSTEPS + s) * 2 + 0) * CS_FRAG + lane * 16);
+                    const f16x8 aL = *reinterpret_cast<const f16x8*>(W2p + (size_t)((ct * CS_KSTEPS + s) * 2 + 1) * CS_FRAG + lane * 16);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(aL, hH[s], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(aH, hL[s], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(aH, hH[s], acc, 0, 0, 0);
+                }
+                // acc[v] = parameter (16 ct + 4 lq + v) of row (rt * 16 + li), in units of 2^(e + 14)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int c = ct * MT + 4 * lq + v;
+                    tile[(rt * MT + li) * a.tile_stride + c] = acc[v] * w2_inv + b2s[c];
+                }
+            }
+        } else
         for (int ct = 0; ct < np / MT; ++ct) {
             typename MF::Acc acc;
 #pragma unroll
@@ -146,6 +227,7 @@ __global__ void __launch_bounds__(NT) cond_mchain_kernel(const CmArgs<T, typenam
     status_add(a.status, JF_STATUS_NONFINITE, active && (bad || ctx.nonfinite));
     status_add(a.status, JF_STATUS_OUT_OF_RANGE, active && ctx.oob);
     status_add(a.status, JF_STATUS_NONCONVERGED, active && ctx.nonconv);
+    }                                                              // row tiles
 }
 
 template <typename T, class Fam, bool FWD = false>
@@ -178,12 +260,20 @@ static int cond_mchain(const T* in, int64_t in_stride, const T* W1, int64_t w1s,
                                                        // without it four workgroups fit a CU instead of one
     const int k1p = (K1 + 3) / 4 * 4, ldk = k1p + 1;
     constexpr int NT = sizeof(T) == 4 ? 256 : 128;
-    const size_t lds = ((size_t)CM_HMAX * ldk + CM_HMAX + (size_t)np * (CM_HMAX + 1) + np + (size_t)NT * ldk + (size_t)NT * a.tile_stride +
+    // (float32: the W2 region holds np / 16 x 4 k-steps x 2 pieces x 1 KiB of f16 fragments = np x 128 floats, less than the np x 129 reserved;
+    //  8 more elements behind the bias for the workgroup's absmax reduction)
+    const size_t lds = ((size_t)CM_HMAX * ldk + CM_HMAX + (size_t)np * (CM_HMAX + 1) + np + 8 + (size_t)NT * ldk + (size_t)NT * a.tile_stride +
                         (size_t)NT * a.tab) * sizeof(T);
     if (lds > 160 * 1024) return JF_ERR_UNSUPPORTED;
     auto k = cond_mchain_kernel<T, Fam, NT, FWD>;
     if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    jf::launch(k, dim3((unsigned)((B + NT - 1) / NT)), dim3(NT), lds, (hipStream_t)stream, a);
+    // one resident round of workgroups (occupancy x CUs, at most one per row tile)
+    int dev = 0, cus = 256, per_cu = 0;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, NT, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+    const int64_t n_tiles = (B + NT - 1) / NT, resident = (int64_t)cus * per_cu;
+    jf::launch(k, dim3((unsigned)(n_tiles < resident ? n_tiles : resident)), dim3(NT), lds, (hipStream_t)stream, a);
     return check_launch();
 }
 

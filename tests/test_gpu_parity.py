@@ -643,6 +643,51 @@ def test_fused_block_stress_20_launches_at_full_size(rg):
         _hip.lib().jf_cond_gf_split_row_groups(prev)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["c5_logprob_f64", "g_e3_ggg_cond_f32", "c3_sampling_f32", "c3_logprob_plan_f32", "c3_logprob_f64"])
+def test_full_size_stress_20_launches_other_paths(case):
+    """the 20-launch full-size determinism gate for the kernels beside the C3 float32 log-prob block -- the C5 low-rank
+    block (float64, 2^19 rows), the D = 3 fused block (g_e3_ggg_cond), the SAMPLING direction of the fused block (cond_gf_split_kernel<.., FWD>)
+    and the step replayed from a recorded plan.  Wrong rows of DESIGN.md 3.9 were whole 16-row groups in a few launches out of tens: every launch
+    must equal the first bit for bit over all rows, and every replica of the tiled fixture the small-batch values."""
+    name, dtype, rows, sample, plan = {"c5_logprob_f64": ("c5_e8s2_ggggv", torch.float64, 1 << 19, False, False),
+                                       "g_e3_ggg_cond_f32": ("g_e3_ggg_cond", torch.float32, 1 << 20, False, False),
+                                       "c3_sampling_f32": ("c3_e4s2e4", torch.float32, 1 << 19, True, False),
+                                       "c3_logprob_plan_f32": ("c3_e4s2e4", torch.float32, 1 << 20, False, True),
+                                       "c3_logprob_f64": ("c3_e4s2e4", torch.float64, 1 << 19, False, False)}[case]
+    fx = [f for f in ALL_FIXTURES if f.name == name][0]
+    pdf = build_product(fx, dtype)
+    pdf.check_status = False
+    pdf.use_step_plans = plan
+    n = fx["x"].shape[0]
+    reps = rows // n + 1
+    cond = to_dev(None if fx.get("cond") is None else np.tile(fx["cond"], (reps, 1)), dtype)
+    emb = bool(fx.meta["embedding"])
+    with torch.no_grad():
+        if sample:
+            z = to_dev(np.tile(fx["z"], (reps, 1)), dtype)
+            run = lambda zz, cc: pdf._obtain_sample(conditional_input=cc, predefined_target_input=zz, force_embedding_coordinates=emb)[0]     # noqa: E731
+            big_in, small_in = z, z[:n]
+        else:
+            x = to_dev(np.tile(fx["x"], (reps, 1)), dtype)
+            run = lambda xx, cc: pdf(xx, conditional_input=cc, force_embedding_coordinates=emb)[0]                                          # noqa: E731
+            big_in, small_in = x, x[:n].contiguous()
+        first = run(big_in, cond)
+        small = run(small_in, None if cond is None else cond[:n].contiguous())
+        differing = 0
+        for _ in range(19):
+            again = run(big_in, cond)
+            differing += int((~((again == first) | (again.isnan() & first.isnan()))).sum())
+    assert differing == 0, "%s: %d values differed between launches" % (case, differing)
+    got = first.reshape((reps, n) + tuple(first.shape[1:]))
+    fin = torch.isfinite(small)
+    assert bool((torch.isfinite(got) == fin).all()), case
+    err = ((got - small).abs() / (1.0 + small.abs()))[:, fin].max().item()
+    # (C3 float64: the 192-row batch takes the exact float64 MLP kernel, the big one the int8-slice kernel -- 3e-10 apart, DESIGN.md 3.2h)
+    tol = 2e-6 if dtype == torch.float32 else (1e-8 if case == "c3_logprob_f64" else 1e-12)
+    assert err < tol, "%s: replicas deviate from the small batch by %.3g" % (case, err)
+
+
 FUSED_MANIFOLD = ["c4_i1s1_ro", "r_i1_m1p1_rr_cond", "r_i1_smooth2", "o_s1_cond_oo", "o_s1_nosmooth", "m_s1_cond", "m_s1_nat1_rot",
                   "f_s2_cond_ff", "f_s2_splines_cond", "f_s2_rot_xyz_mu", "c3_e4s2e4"]
 
