@@ -209,7 +209,7 @@ def oracle_rows(workload, x, c, workers, chunk=4096):
 
 
 # ---------------------------------------------------------------------------------------------- HBM traffic (rocprofv3 PMC)
-PROFILE_TRAFFIC = os.path.join(ROOT, "profiles", "r03_traffic.json")
+PROFILE_TRAFFIC = os.path.join(ROOT, "profiles", "r04_traffic.json")
 WRITE_CAL = 0.965     # WRITE_SIZE calibration on scripts/probe/wstore (16-byte lane-per-row tile stores); FETCH_SIZE x 2 on gfx950 (guide)
 
 
@@ -267,8 +267,8 @@ def committed_traffic():
     except (OSError, ValueError):
         return None
     if t.get("kernel_source_hash") != kernel_source_hash():
-        return {"stale": True, "source": "profiles/r02_traffic.json (taken at kernel sources %s, now %s)" % (t.get("kernel_source_hash"), kernel_source_hash())}
-    t["source"] = "profiles/r02_traffic.json (committed rocprofv3 --pmc passes of this command; kernel sources unchanged since)"
+        return {"stale": True, "source": "profiles/r04_traffic.json (taken at kernel sources %s, now %s)" % (t.get("kernel_source_hash"), kernel_source_hash())}
+    t["source"] = "profiles/r04_traffic.json (committed rocprofv3 --pmc passes of this command; kernel sources unchanged since)"
     return t
 
 
@@ -698,7 +698,7 @@ def main():
                          "log-prob batch, gradients all-reduced over the ranks")
     ap.add_argument("--train", action="store_true", help="same as --direction train")
     ap.add_argument("--no-fuse", action="store_true", help="time the two-launch path (MLP launch + flow launch) instead of the fused conditional block")
-    ap.add_argument("--preheat-ms", type=float, default=300.0,
+    ap.add_argument("--preheat-ms", type=float, default=1000.0,
                     help="run the step untimed for this long before the warm-up steps, so that the timed region sees the chip's sustained clocks (0 = off)")
     ap.add_argument("--no-sweep", action="store_true", help="skip the rows sweep and the table of the other BASELINE configurations (measured after the timed region)")
     ap.add_argument("--no-plan", action="store_true", help="eager pdf.forward (one ctypes call per launch) instead of the recorded step plan")

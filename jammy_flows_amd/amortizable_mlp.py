@@ -48,8 +48,6 @@ class AmortizableMLP(nn.Module):
             raise KeyError(nonlinearity)
         if svd_mode not in ("smart", "naive"):
             raise Exception("unknown svd mode", svd_mode)
-        if len(precise_mlp_structure) > 0:
-            raise NotImplementedError("precise_mlp_structure is not supported")
         assert 0 <= highway_mode <= 4
         self.input_dim = input_dim
         self.output_dim = output_dim
@@ -57,6 +55,10 @@ class AmortizableMLP(nn.Module):
         self.use_permanent_parameters = use_permanent_parameters
         self.nonlinearity = nonlinearity
         self.svd_mode = svd_mode
+        if len(precise_mlp_structure) > 0:
+            # the caller hands in the sub-MLP table itself (amortizable_mlp.py:20, 56-62): per-matrix ranks, widths no `hidden_dims` string gives
+            self._init_from_table(precise_mlp_structure)
+            return
         if type(hidden_dims) == str:
             self.hidden_dims = list_from_str(hidden_dims)
         elif type(hidden_dims) == int:
@@ -100,6 +102,58 @@ class AmortizableMLP(nn.Module):
         self.stages = self.sub_mlps[0][0] if (highway_mode == 0) else None        # plain-MLP view used by the fused low-rank block
         self._cast_cache = None
         if use_permanent_parameters:
+            self.u_v_b_pars = nn.Parameter(torch.randn(self.num_amortization_params).type(torch.double).unsqueeze(0))
+            self.initialize_uvbs()
+
+    def _init_from_table(self, table):
+        """`precise_mlp_structure`: {"mlp_list": [sub-MLP dicts], "linear_highway": dict (highway modes > 0)}, each dict with `inputs`, `outputs`,
+        `low_rank_approximations` (one entry per matrix), `add_final_bias`, `svd_mode` -- the reference's own `sub_mlp_structures` (:118-246).
+        The reference keeps the activations as callables inside the table; the kernels know the named ones, so a table's `activations` (if
+        present) must be the module's nonlinearity everywhere but after a sub-MLP's last matrix, as the reference itself fills them (:258-270)."""
+        assert "mlp_list" in table
+        if self.highway_mode > 0:
+            assert "linear_highway" in table
+        probe = torch.linspace(-2.0, 2.0, 9, dtype=torch.float64)
+        named = {"tanh": torch.tanh, "relu": torch.relu, "softplus": torch.nn.functional.softplus, "elu": torch.nn.functional.elu,
+                 "swish": lambda t: t * torch.sigmoid(t), "square": lambda t: t * t, "identity": lambda t: t}[self.nonlinearity]
+
+        def check_acts(d):
+            acts = d.get("activations")
+            if not acts:
+                return
+            assert len(acts) == len(d["inputs"])
+            for i, f in enumerate(acts):
+                want = probe if i == len(acts) - 1 else named(probe)
+                if not torch.allclose(f(probe), want, rtol=1e-12, atol=1e-12):
+                    raise NotImplementedError("precise_mlp_structure: activation %d of a sub-MLP is neither the module's nonlinearity (%s) nor the "
+                                              "identity after the last matrix" % (i, self.nonlinearity))
+        self.hidden_dims = []
+        self.sub_mlps, self.linear = [], None
+        later = {0: "in", 1: "in", 2: "in", 3: "out", 4: "in+out"}[self.highway_mode]
+        ranks_all = []
+        for ind, d in enumerate(table["mlp_list"]):
+            check_acts(d)
+            ranks = [int(r) for r in d["low_rank_approximations"]]
+            assert len(d["inputs"]) == len(d["outputs"]) == len(ranks)
+            st, n = _stage_layout([int(v) for v in d["inputs"]], [int(v) for v in d["outputs"]], ranks, bool(d["add_final_bias"]), d.get("svd_mode", self.svd_mode))
+            want_in = self.input_dim if (ind == 0 or later == "in") else (self.output_dim if later == "out" else self.input_dim + self.output_dim)
+            assert st[0]["inp"] == want_in and st[-1]["out"] == self.output_dim, "sub-MLP %d does not fit highway_mode %d" % (ind, self.highway_mode)
+            self.sub_mlps.append((st, n, "in" if ind == 0 else later))
+            ranks_all += ranks
+        if "linear_highway" in table:
+            d = table["linear_highway"]
+            check_acts(d)
+            ranks = [int(r) for r in d["low_rank_approximations"]]
+            self.linear = _stage_layout([int(v) for v in d["inputs"]], [int(v) for v in d["outputs"]], ranks, bool(d["add_final_bias"]), d.get("svd_mode", self.svd_mode))
+            assert self.linear[0][0]["inp"] == self.input_dim and self.linear[0][-1]["out"] == self.output_dim
+            ranks_all += ranks
+        if self.highway_mode < 2:
+            assert len(self.sub_mlps) <= 1
+        self.total_low_rank_approximations = ranks_all
+        self.num_amortization_params = sum(n for _, n, _ in self.sub_mlps) + (self.linear[1] if self.linear is not None else 0)
+        self.stages = self.sub_mlps[0][0] if (self.highway_mode == 0 and self.sub_mlps) else None
+        self._cast_cache = None
+        if self.use_permanent_parameters:
             self.u_v_b_pars = nn.Parameter(torch.randn(self.num_amortization_params).type(torch.double).unsqueeze(0))
             self.initialize_uvbs()
 

@@ -183,10 +183,16 @@ class pdf(nn.Module):
                  verbose=False):
         """Arguments as documented for the reference (:63-100)."""
         super().__init__()
-        if predict_log_normalization:
-            raise NotImplementedError("predict_log_normalization (Poisson log-mean head) is outside the MI355X hot path")
         self.amortization_mlp_use_custom_mode = amortization_mlp_use_custom_mode
-        self.predict_log_normalization = False
+        # Poisson head (:51, 104-110, 467-477, 675-716, 836-877): the pdf also predicts the log-mean of a Poisson count -- a parameter when the
+        # pdf is unconditional, the LAST output column of the first amortisation MLP with join_poisson_and_pdf_description, or (the reference's
+        # "outdated" separate form: built for state_dict compatibility, log_mean_poisson raises for it as the reference's does) an MLP of its own
+        self.predict_log_normalization = bool(predict_log_normalization)
+        if self.predict_log_normalization:
+            assert not amortize_everything, ("Log Poisson prediction works only without full amortization in the default PDF. It can be used in the "
+                                             "*fully_amortized_pdf*!")
+        self.hidden_mlp_dims_poisson = hidden_mlp_dims_poisson
+        self.rank_of_mlp_mappings_poisson = rank_of_mlp_mappings_poisson
         self.join_poisson_and_pdf_description = join_poisson_and_pdf_description
         self.amortization_mlp_highway_mode = amortization_mlp_highway_mode
         self.amortize_everything = amortize_everything
@@ -330,6 +336,13 @@ class pdf(nn.Module):
             self.layer_list.append(block)
             self.num_parameter_list.append([l.get_total_param_num() for l in block])
         self.log_normalization = None
+        if self.predict_log_normalization:
+            assert len(self.pdf_defs_list) == 1, ("You chose to predict log-lambda, which is only allowed with a single sub-pdf (no autoregressive "
+                                                  "structure). For autoregressive PDFs with log-lambda prediction, use fully amortized PDFs.")
+            if self.force_permanent_parameters_in_first_subpdf:
+                self.log_normalization = nn.Parameter(torch.randn(1).unsqueeze(0))
+            else:
+                self.log_normalization = torch.zeros(1).unsqueeze(0)
         self.update_embedding_structure()
 
     def get_embedding_flags(self):
@@ -374,11 +387,15 @@ class pdf(nn.Module):
         self.mlp_predictors = nn.ModuleList()
         self.log_normalization_mlp = None
         if self.skip_mlp_initialization:
+            if self.predict_log_normalization:          # external MLPs must predict the Poisson and pdf description jointly (:717-721)
+                assert self.join_poisson_and_pdf_description
             return
         prev = 0
         for si in range(len(self.pdf_defs_list)):
             emb = self.layer_list[si][-1]._embedding_conditional_return_num()
             npar = sum(self.num_parameter_list[si])
+            if self.predict_log_normalization and si == 0 and self.join_poisson_and_pdf_description and self.conditional_input_dim is not None:
+                npar += 1                                   # log-lambda = the last output of the first MLP (:624-627)
             if si == 0 and self.conditional_input_dim is None:
                 self.mlp_predictors.append(None)
                 if self.amortize_everything:
@@ -408,6 +425,43 @@ class pdf(nn.Module):
                     mlp = HipLinearStack(*mods)
                 self.mlp_predictors.append(mlp)
             prev += emb
+        if self.predict_log_normalization and self.conditional_input_dim is not None and not self.join_poisson_and_pdf_description:
+            # a predictor of its own (:675-716) -- same modules as the reference builds, so that its state_dict loads
+            in_dim = self.conditional_input_dim if type(self.conditional_input_dim) == int else self.conditional_input_dim[0]
+            if self.amortization_mlp_use_custom_mode:
+                self.log_normalization_mlp = AmortizableMLP(in_dim, self.hidden_mlp_dims_poisson, 1, low_rank_approximations=self.rank_of_mlp_mappings_poisson,
+                                                            use_permanent_parameters=True, highway_mode=self.amortization_mlp_highway_mode, svd_mode="smart")
+            else:
+                hidden = list_from_str(self.amortization_mlp_dims[0])
+                dims_in, dims_out = [in_dim] + hidden, hidden + [1]
+                mods = []
+                for i in range(len(dims_in)):
+                    mods.append(nn.Linear(dims_in[i], dims_out[i]))
+                    if i < len(dims_in) - 1:
+                        mods.append(nn.Tanh())
+                    else:
+                        mods[-1].weight.data /= 1000.0
+                        mods[-1].bias.data[0] = -1.0
+                self.log_normalization_mlp = HipLinearStack(*mods)
+
+    def log_mean_poisson(self, conditional_input=None, amortization_parameters=None):
+        """log-lambda of the Poisson head, (B, 1) (or the (1, 1) parameter of an unconditional pdf)  (:836-877)."""
+        if self.log_normalization is None:
+            raise Exception("This PDF does not predict the log-mean of a Poisson distriution. Initialize with 'predict_log_normalization'=True for this "
+                            "possibility.")
+        if amortization_parameters is not None:
+            assert amortization_parameters.shape[1] == self.total_number_amortizable_params
+        if conditional_input is None:
+            if amortization_parameters is not None:
+                raise Exception("Currently there is no support for the prediction of log-lambda and simultanesouly passing amortization_parameters")
+            return self.log_normalization
+        if self.join_poisson_and_pdf_description:
+            mlp = self.mlp_predictors[0]
+            if amortization_parameters is not None:
+                assert isinstance(mlp, AmortizableMLP) and not mlp.use_permanent_parameters
+                return mlp(conditional_input, extra_inputs=amortization_parameters[:, :mlp.num_amortization_params])[:, -1:]
+            return mlp(conditional_input)[:, -1:]           # the last parameter of the first MLP is log-lambda (convention)
+        raise NotImplementedError("This way of independenly predicting the normalization (from all other parameters) is outdated!")
 
     def init_params(self, data=None, damping_factor=1000.0, mvn_min_max_sv_ratio=1e-4):
         """layer "desired init" vectors become the final bias of each MLP (everything else / damping_factor) or are written into
@@ -435,6 +489,8 @@ class pdf(nn.Module):
                 if len(these) == 0:
                     continue
                 mlp = self.mlp_predictors[si] if len(self.mlp_predictors) > si else None
+                if mlp is not None and self.predict_log_normalization and self.join_poisson_and_pdf_description and si == 0:
+                    these = torch.cat([these, torch.tensor([0.1], dtype=these.dtype, device=these.device)])      # log-lambda at initialisation (:1893-1896)
                 if mlp is not None:
                     if isinstance(mlp, AmortizableMLP):
                         if self.amortize_everything:
@@ -471,6 +527,8 @@ class pdf(nn.Module):
         for m in self.mlp_predictors:
             if m is not None:
                 tot += sum(int(numpy.prod(p.size())) for p in m.parameters() if p.requires_grad)
+        if self.log_normalization_mlp is not None:
+            tot += sum(int(numpy.prod(p.size())) for p in self.log_normalization_mlp.parameters() if p.requires_grad)
         for block in self.layer_list:
             for l in block:
                 tot += sum(int(numpy.prod(p.size())) for p in l.parameters() if p.requires_grad)
@@ -554,6 +612,8 @@ class pdf(nn.Module):
 
     def _fusable_block(self, si, layers, only_last, amort, dtype):
         """can sub-pdf si run as ONE fused launch (amortisation MLP + its g layers, parameter block kept on chip)?"""
+        if self._poisson_column(si):                       # the MLP emits one more column than the block has parameters
+            return None
         if not self.fuse_conditional_blocks or only_last or amort is not None or _hip.BINS_LOG is not None:
             return None
         if dtype != torch.float32:      # measured: in float64 the two-launch path (jf_mlp2 + jf_gf_chain_inv) is faster
@@ -575,6 +635,8 @@ class pdf(nn.Module):
     def _fusable_manifold_block(self, si, layers, only_last, amort, dtype):
         """sub-pdf si = default amortisation MLP (Linear-tanh-Linear) + one chain of 'r' / 'o' / 'm' / 'f' layers with <= 64 parameters per
         row: (family, [w1, b1, w2, b2]) for jf_cond_<fam>_chain_inv, else None"""
+        if self._poisson_column(si):                       # the MLP emits one more column than the block has parameters
+            return None
         if not self.fuse_conditional_blocks or only_last or amort is not None or _hip.BINS_LOG is not None:
             return None
         mlp = self.mlp_predictors[si] if len(self.mlp_predictors) > si else None
@@ -600,6 +662,8 @@ class pdf(nn.Module):
     def _fusable_lowrank_block(self, si, layers, only_last, amort, like):
         """sub-pdf si = a two-stage AmortizableMLP with a low-rank last stage + chainable g layers at default options: the weight views for
         jf_amlp_gf_chain_inv (v1, u1, b1, v2, u2, b2), else None"""
+        if self._poisson_column(si):                       # the MLP emits one more column than the block has parameters
+            return None
         if not self.fuse_conditional_blocks or only_last or amort is not None or _hip.BINS_LOG is not None:
             return None
         mlp = self.mlp_predictors[si] if len(self.mlp_predictors) > si else None
@@ -662,6 +726,8 @@ class pdf(nn.Module):
                 counter += n
             else:
                 out = mlp(inp)
+            if self._poisson_column(si):
+                out = out[:, :-1]                           # the last output of the first MLP is log-lambda, not a flow parameter (:976-978)
             return out, counter
         if self.amortize_everything:
             assert amort is not None
@@ -670,6 +736,10 @@ class pdf(nn.Module):
                 out = amort[:, counter:counter + n]
                 return out, counter + n
         return None, counter
+
+    def _poisson_column(self, si):
+        """does the amortisation MLP of sub-pdf si carry log-lambda as an extra last output column?"""
+        return self.predict_log_normalization and self.join_poisson_and_pdf_description and si == 0 and self.conditional_input_dim is not None
 
     def _check_cond(self, x, conditional_input):
         if conditional_input is None:
@@ -1022,8 +1092,6 @@ class pdf(nn.Module):
         """forward() with a torch.autograd graph: d log_prob / d (x, conditional_input, MLP weights, permanent layer parameters).
         Same launches as the inference path, wrapped in autograd Functions whose backward is a HIP launch (g chains, manifold chains) or
         rocBLAS GEMMs (dense layers) -- see jammy_flows_amd/autograd.py."""
-        if only_last:
-            raise NotImplementedError("gradients with only_last are not implemented: evaluate under torch.no_grad(), or without only_last")
         log_det0 = None
         if force_embedding_coordinates:          # the chart changes ahead of the block loop, with a graph (autograd.SphereEmbeddingFn)
             assert x.shape[1] == self.total_target_dim_embedded, (x.shape[1], self.total_target_dim_embedded)
@@ -1036,6 +1104,12 @@ class pdf(nn.Module):
             assert amort.shape[1] == self.total_number_amortizable_params
         counter = 0
 
+        def last_only(layers, params, kind):
+            """only_last (:1018): the block's last layer alone, with the tail of the block's parameter row (:1002-1012)"""
+            if kind not in ("e", "s", "i"):
+                raise Exception("Flow type ", kind, " does not supported *only_last*!")
+            return layers[-1:], params[:, params.shape[1] - layers[-1].total_param_num:]
+
         def block_params(si, layers, inp, mlp):
             """(parameter block with grad, new counter): MLP output (own or per-sample weights), a slice of the amortisation block, or the
             permanent parameters (:936-993)"""
@@ -1045,8 +1119,9 @@ class pdf(nn.Module):
                     n = mlp.num_amortization_params
                     out = mlp(inp, extra_inputs=amort[:, counter:counter + n])
                     counter += n
-                    return out
-                return mlp(inp)
+                else:
+                    out = mlp(inp)
+                return out[:, :-1] if self._poisson_column(si) else out
             if self.amortize_everything:
                 n = sum(l.get_total_param_num() for l in layers)
                 out = amort[:, counter:counter + n]
@@ -1077,10 +1152,10 @@ class pdf(nn.Module):
                     raise Exception("extra conditional input is empty but required for encoding!")
                 inp = torch.cat(pieces, dim=1) if len(pieces) > 1 else pieces[0]
             if kind == "e" and gfl.chain_supported(layers):
-                larr = _hip.gf_layer_array([l.c_struct() for l in layers])
                 D = layers[0].dimension
-                fused = self._fusable_block(si, layers, False, amort, x.dtype) if mlp is not None else None
+                fused = self._fusable_block(si, layers, only_last, amort, x.dtype) if mlp is not None else None
                 if fused is not None:
+                    larr = _hip.gf_layer_array([l.c_struct() for l in layers])
                     w1, b1, w2, b2 = mlp[0].weight, mlp[0].bias, mlp[2].weight, mlp[2].bias
                     packed = None
                     if self.fused_matrix_arithmetic != "f32" and w1.shape[0] <= 128:
@@ -1089,12 +1164,19 @@ class pdf(nn.Module):
                                                                          status)
                 else:
                     params = block_params(si, layers, inp, mlp)
-                    out, log_det, base_logp = autograd.GfChainInvFn.apply(tgt, log_det, params, base_logp, larr, len(layers), D, status)
+                    used = layers
+                    if only_last:
+                        used, params = last_only(layers, params, kind)
+                    larr = _hip.gf_layer_array([l.c_struct() for l in used])
+                    out, log_det, base_logp = autograd.GfChainInvFn.apply(tgt, log_det, params, base_logp, larr, len(used), D, status)
             elif kind == "e":
                 # Euclidean block mixing 'g' runs with other layers ('t'): one launch per group, last group first (:1002-1012)
                 from ..layers.euclidean.multivariate_normal import mvn_block
                 params = block_params(si, layers, inp, mlp)
-                groups = _layer_groups(layers)
+                used = layers
+                if only_last:
+                    used, params = last_only(layers, params, kind)
+                groups = _layer_groups(used)
                 out, c1 = tgt, params.shape[1]
                 for gi in range(len(groups) - 1, -1, -1):
                     grp = groups[gi]
@@ -1113,8 +1195,11 @@ class pdf(nn.Module):
                 base_logp = blp
             else:
                 params = block_params(si, layers, inp, mlp)
-                fam = _manifold_family(layers)
-                groups = [layers] if fam is not None else [[l] for l in layers]      # mixed families (e.g. "mo"): one launch per layer
+                used = layers
+                if only_last:
+                    used, params = last_only(layers, params, kind)
+                fam = _manifold_family(used)
+                groups = [used] if fam is not None else [[l] for l in used]          # mixed families (e.g. "mo"): one launch per layer
                 out, c1 = tgt, params.shape[1]
                 for gi in range(len(groups) - 1, -1, -1):                            # last layer first, parameters sliced tail-first (:1002-1012)
                     grp = groups[gi]
@@ -1122,7 +1207,9 @@ class pdf(nn.Module):
                     if f is None:
                         raise NotImplementedError("gradients through %s layers are not implemented" % type(grp[0]).__name__)
                     n = sum(l.total_param_num for l in grp)
-                    structs = [l.c_struct() if f == "r" else l.c_struct(1 if l.euclidean_to_sphere_as_first else 0) for l in grp]
+                    # (only_last on a sphere: the last layer also takes the sphere -> plane chart, fix_euclidean_to_sphere_first, :1018-1031)
+                    structs = [l.c_struct() if f == "r" else l.c_struct(1 if (l.euclidean_to_sphere_as_first or (only_last and kind == "s")) else 0)
+                               for l in grp]
                     out, log_det, blp = autograd.MChainInvFn.apply(out, log_det, params[:, c1 - n:c1], base_logp if gi == 0 else None, f, structs,
                                                                    grp[0].dimension, status)
                     c1 -= n
@@ -1363,6 +1450,8 @@ class pdf(nn.Module):
                     if not pieces:
                         raise Exception("SAMPLE: extra conditional input is empty but required for encoding!")
                     extra = mlp(torch.cat(pieces, dim=1) if len(pieces) > 1 else pieces[0])
+                    if self._poisson_column(si):
+                        extra = extra[:, :-1]                   # (:1257-1260)
                 a, b = self.base_dim_indices[si]
                 cur = x[:, a:b]
                 c = 0

@@ -40,7 +40,9 @@ CASES = ["c1_e2_gg", "c2_e4_gggg", "c3_e4s2e4", "g_e1_g", "g_e3_ggg_cond", "g_e2
          # evaluated in EMBEDDING coordinates (force_embedding_coordinates=True: x = (x, y, z) on the sphere): the chart change sits inside the graph
          "f_s2_emb", "mix_s2e2_emb",
          # more than 8 Euclidean dimensions
-         "g_e10_gg", "g_e10_ggggg", "g_e12_cond", "t_e10_full", "t_e10_diagonal", "t_e12_full_cond"]
+         "g_e10_gg", "g_e10_ggggg", "g_e12_cond", "t_e10_full", "t_e10_diagonal", "t_e12_full_cond",
+         # only_last=True (main/default.py:1018, 1490: only the last layer of every sub-pdf is applied), with gradients
+         "c3_e4s2e4@only_last", "g_e3_ggg_cond@only_last", "c4_i1s1_ro@only_last"]
 N_ADV = 8
 ADAM_STEPS = 10
 
@@ -55,6 +57,8 @@ def build(fx):
 
 
 def make(name):
+    name, _, flag = name.partition("@")
+    extra_kw = {"only_last": True} if flag == "only_last" else {}
     fx = fixture_io.load(name)
     pdf = build(fx)
     emb = bool(fx.meta["embedding"])
@@ -80,11 +84,11 @@ def make(name):
     if fx.get("cond") is not None:
         cond = torch.from_numpy(fx["cond"][rows]).clone().requires_grad_(True)
     with contextlib.redirect_stdout(io.StringIO()):
-        logp = pdf(x, conditional_input=cond, force_embedding_coordinates=emb)[0]
+        logp = pdf(x, conditional_input=cond, force_embedding_coordinates=emb, **extra_kw)[0]
     assert torch.isfinite(logp).all(), name
     loss = -logp.mean()
     loss.backward()
-    out = {"rows": rows, "loss": numpy.array(loss.item()), "x_grad": x.grad.numpy()}
+    out = {"rows": rows, "loss": numpy.array(loss.item()), "x_grad": x.grad.numpy(), "logp": logp.detach().numpy()}
     if cond is not None:
         out["cond_grad"] = cond.grad.numpy()
     n_none = 0
@@ -102,12 +106,12 @@ def make(name):
     for _ in range(ADAM_STEPS):
         opt.zero_grad()
         with contextlib.redirect_stdout(io.StringIO()):
-            l2 = -pdf2(xs, conditional_input=cs, force_embedding_coordinates=emb)[0].mean()
+            l2 = -pdf2(xs, conditional_input=cs, force_embedding_coordinates=emb, **extra_kw)[0].mean()
         l2.backward()
         opt.step()
         traj.append(l2.item())
     out["adam_losses"] = numpy.array(traj)
-    path = os.path.join(HERE, "grads", name + ".npz")
+    path = os.path.join(HERE, "grads", name + ("_" + flag if flag else "") + ".npz")
     numpy.savez_compressed(path, **out)
     gmax = max(float(numpy.abs(v).max()) for k, v in out.items() if k.startswith("pg/"))
     print("%-26s rows=%d loss=%.6f max|dL/dparam|=%.3e max|dL/dx|=%.3e params without grad=%d adam: %.5f -> %.5f bytes=%d" % (

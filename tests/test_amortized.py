@@ -199,3 +199,45 @@ def test_gpu_amortizable_mlp_nonlinearities_vs_reference(name, hw):
     assert rel(mlp.u_v_b_pars.grad, NONLIN[k + "/gp"]) < 1e-8, k
     with torch.no_grad():
         assert rel(mlp(x.detach()), NONLIN[k + "/y"]) < 1e-10      # the no-grad path (plain launches)
+
+
+PRECISE = np.load(os.path.join(fixture_io.GOLDEN_DIR, "nonlin", "amlp_precise_structure.npz"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["hw0", "hw2", "hw4"])
+def test_gpu_amortizable_mlp_precise_structure_vs_reference(case):
+    """AmortizableMLP(precise_mlp_structure=...) (amortizable_mlp.py:20, 56-62: the sub-MLP table handed in by the caller -- per-matrix ranks and
+    svd modes, widths no `hidden_dims` string produces): parameter count, outputs and autograd gradients against vectors from the reference
+    (tests/golden/make_amlp_precise_fixtures.py)"""
+    import json
+    from jammy_flows_amd.amortizable_mlp import AmortizableMLP
+    spec = json.loads(str(PRECISE["structures"]))[case]
+    mlp = AmortizableMLP(6, "3", 4, highway_mode=spec["highway_mode"], nonlinearity="tanh", use_permanent_parameters=True,
+                         precise_mlp_structure=spec["structure"]).double().cuda()
+    assert mlp.num_amortization_params == PRECISE[case + "/pars"].shape[1]
+    with torch.no_grad():
+        mlp.u_v_b_pars.copy_(torch.from_numpy(PRECISE[case + "/pars"]).cuda())
+    x = torch.from_numpy(PRECISE["x"]).cuda().requires_grad_(True)
+    with torch.enable_grad():
+        y = mlp(x)
+        loss = (y ** 2).mean()
+    loss.backward()
+
+    def rel(a, b):
+        return float(np.abs(a.detach().cpu().numpy().reshape(b.shape) - b).max()) / max(float(np.abs(b).max()), 1e-30)
+    assert rel(y, PRECISE[case + "/y"]) < 1e-10
+    assert rel(x.grad, PRECISE[case + "/gx"]) < 1e-8
+    assert rel(mlp.u_v_b_pars.grad, PRECISE[case + "/gp"]) < 1e-8
+    with torch.no_grad():
+        assert rel(mlp(x.detach()), PRECISE[case + "/y"]) < 1e-10
+
+
+def test_precise_structure_refuses_unknown_activations():
+    from jammy_flows_amd.amortizable_mlp import AmortizableMLP
+    table = {"mlp_list": [dict(inputs=[3, 5], outputs=[5, 2], low_rank_approximations=[0, 0], add_final_bias=True, svd_mode="smart",
+                               activations=[lambda t: t ** 3, lambda t: t])]}
+    with pytest.raises(NotImplementedError):
+        AmortizableMLP(3, "1", 2, precise_mlp_structure=table)
+    table["mlp_list"][0]["activations"] = [torch.tanh, lambda t: t]
+    assert AmortizableMLP(3, "1", 2, precise_mlp_structure=table).num_amortization_params == 3 * 5 + 5 + 5 * 2 + 2
