@@ -142,6 +142,37 @@ def test_linear_stack_dispatch_and_image_cache():
     assert not torch.isfinite(out5[:, 3]).any() and torch.isfinite(out5[:, 4]).all()
 
 
+def test_nan_rows_propagate_through_the_int8_path():
+    """(int)rint(NaN) is 0, so a NaN hidden activation used to become digit 0 and the row came out as b2 -- finite, no status
+    flag, and only above the 4096-row switch to this kernel.  A NaN input row, a NaN in W1 and an inf - inf in the first layer must give NaN
+    outputs for exactly the affected rows, as jf_mlp2_f64 and nn.Linear do; every other row is untouched."""
+    st = _stack(7, 128, 548, 3)
+    x = torch.randn(6000, 7, dtype=torch.float64, device="cuda")
+    with torch.no_grad():
+        clean = st(x)
+        xb = x.clone()
+        xb[17, 2] = float("nan")
+        xb[4100, 0] = float("inf")                                   # inf * w + (-inf) * w' in the first layer: NaN pre-activations
+        xb[4100, 1] = float("-inf")
+        timer = _hip.KernelTimer()
+        with timer:
+            out = st(xb)
+        assert any(k[0] == "jf_mlp2_i8_f64" for k in timer.summary())
+        bad = torch.zeros(6000, dtype=torch.bool, device="cuda")
+        bad[17] = True
+        bad[4100] = True
+        assert torch.isnan(out[bad]).all(), "rows with a NaN hidden activation must be NaN in every column"
+        assert torch.equal(out[~bad], clean[~bad])
+        ref = torch.tanh(xb @ st[0].weight.t() + st[0].bias) @ st[2].weight.t() + st[2].bias
+        assert torch.equal(torch.isnan(ref).all(dim=1), bad)
+        # an infinite (not NaN) pre-activation is a legitimate h = +-1
+        xi = x.clone()
+        xi[5, 3] = float("inf")
+        oi = st(xi)
+        ri = torch.tanh(xi @ st[0].weight.t() + st[0].bias) @ st[2].weight.t() + st[2].bias
+        assert torch.isfinite(oi[5]).all() and (oi[5] - ri[5]).abs().max().item() < 1e-10
+
+
 def test_c3_golden_fixture_through_the_int8_path():
     from helpers import ALL_FIXTURES, build_product, max_rel, to_dev
     fx = [f for f in ALL_FIXTURES if f.name == "c3_e4s2e4"][0]
