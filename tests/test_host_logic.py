@@ -104,8 +104,13 @@ def test_unsupported_things_fail_loudly():
     assert [type(l).__name__ for l in p.layer_list[0]] == ["gf_block"] * 3 + ["mvn_block"]
     p = jammy_flows_amd.pdf("e2", "gg", options_overwrite={"g": {"add_skewness": 1, "center_mean": 1, "rotation_mode": "cayley"}})
     assert [l.total_param_num for l in p.layer_list[0]] == [1 + 18 + 60, 2 + 1 + 18 + 60] and all(l.has_extended_options for l in p.layer_list[0])
-    with pytest.raises(NotImplementedError):
-        jammy_flows_amd.pdf("e2", "gg", predict_log_normalization=True)
+    # round 4: the Poisson head constructs (main/default.py:467-477, 624-627) -- and keeps the reference's own restrictions
+    p = jammy_flows_amd.pdf("e2", "gg", predict_log_normalization=True)
+    assert tuple(p.log_normalization.shape) == (1, 1) and "log_normalization" in p.state_dict()
+    p = jammy_flows_amd.pdf("e2", "gg", conditional_input_dim=3, predict_log_normalization=True, join_poisson_and_pdf_description=True)
+    assert p.mlp_predictors[0][2].out_features == sum(p.num_parameter_list[0]) + 1
+    with pytest.raises(AssertionError):
+        jammy_flows_amd.pdf("e2+e1", "gg+g", predict_log_normalization=True)          # one sub-pdf only (:471-472)
 
 
 def test_data_init_host_math_matches_the_oracle():
