@@ -369,6 +369,50 @@ def cpu_baseline_sampling(workload, budget_s=12.0, chunk=1024):
                       % (n, w["fixture"], workers, chunk, dt)}
 
 
+def train_parity(name, dtype, dev, torch_adam):
+    """The training step's parity: the gradient of -mean(log p) at the golden fixture's rows against the REAL reference's autograd
+    (tests/golden/grads/<fixture>.npz, made by tests/golden/make_grad_fixtures.py), and 10 Adam steps (lr 1e-3) against the reference's loss
+    trajectory -- with the optimiser the timed step uses, in the timed dtype, on a fresh model with the fixture's frozen weights."""
+    import numpy as np
+    import torch
+    import fixture_io
+    import helpers
+    from jammy_flows_amd import optim as jf_optim
+    fx = fixture_io.load(name)
+    with np.load(os.path.join(fixture_io.GOLDEN_DIR, "grads", name + ".npz")) as z:
+        g = {k: z[k] for k in z.files}
+    pdf = helpers.build_product(fx, dtype, dev)
+    rows = g["rows"]
+    x = torch.from_numpy(fx["x"][rows]).to(device=dev, dtype=dtype).requires_grad_(True)
+    cond = None if fx.get("cond") is None else torch.from_numpy(fx["cond"][rows]).to(device=dev, dtype=dtype).requires_grad_(True)
+
+    def rel(got, ref):
+        return float(np.abs(got.detach().double().cpu().numpy().reshape(ref.shape) - ref).max()) / max(float(np.abs(ref).max()), 1e-6)
+    with torch.enable_grad():
+        loss = -pdf(x, conditional_input=cond, force_embedding_coordinates=bool(fx.meta["embedding"]))[0].mean()
+    loss.backward()
+    worst = {"x": rel(x.grad, g["x_grad"])}
+    if cond is not None and "cond_grad" in g:
+        worst["cond"] = rel(cond.grad, g["cond_grad"])
+    named = dict(pdf.named_parameters())
+    for k in (k[3:] for k in g if k.startswith("pg/")):
+        worst[k] = rel(named[k].grad, g["pg/" + k])
+    opt = torch.optim.Adam(pdf.parameters(), lr=1e-3) if torch_adam else jf_optim.Adam(pdf.parameters(), lr=1e-3)
+    xs, cs = x.detach(), None if cond is None else cond.detach()
+    losses = []
+    for _ in range(len(g["adam_losses"])):
+        opt.zero_grad(set_to_none=True)
+        with torch.enable_grad():
+            ls = -pdf(xs, conditional_input=cs, force_embedding_coordinates=bool(fx.meta["embedding"]))[0].mean()
+        ls.backward()
+        opt.step()
+        losses.append(float(ls.item()))
+    return {"fixture": "tests/golden/grads/%s.npz (reference autograd, float64)" % name, "rows": int(len(rows)),
+            "loss_abs_err": abs(float(loss.item()) - float(g["loss"])), "max_rel_gradient_err": max(worst.values()), "worst_tensor": max(worst, key=worst.get),
+            "tensors_compared": len(worst), "adam_10_steps_max_loss_dev": float(np.abs(np.array(losses) - g["adam_losses"]).max()),
+            "adam_losses_first_last": [losses[0], losses[-1]], "reference_first_last": [float(g["adam_losses"][0]), float(g["adam_losses"][-1])]}
+
+
 def other_direction(args, W, rank, local_rank, world):
     """--direction sample | train: same launch / sharding / timing contract as the log-prob benchmark, one JSON line of the same shape."""
     direction = args.direction
@@ -429,7 +473,10 @@ def other_direction(args, W, rank, local_rank, world):
     else:
         x = torch.from_numpy(x64).to(device=dev, dtype=dtype)
         pdf.check_status = False
-        opt = torch.optim.Adam(pdf.parameters(), lr=1e-4)
+        from jammy_flows_amd import optim as jf_optim
+        # one launch over all parameter tensors (csrc/misc_kernels.hip: jf_adam_step); --torch-adam times torch.optim.Adam's foreach launches
+        opt = torch.optim.Adam(pdf.parameters(), lr=1e-4) if args.torch_adam else jf_optim.Adam(pdf.parameters(), lr=1e-4)
+        extra["optimizer"] = "torch.optim.Adam (foreach)" if args.torch_adam else "jammy_flows_amd.optim.Adam (one launch per step)"
         last = {}
 
         def step():
@@ -460,6 +507,7 @@ def other_direction(args, W, rank, local_rank, world):
                       "note": "float32 samples of rows whose float64 solution sits on a chart edge differ by the chart's float32 resolution" if s == 4 else None}
         else:
             extra["final_loss"] = float(last["loss"].item())
+            parity = train_parity(W["fixture"], dtype, dev, args.torch_adam)
             if world == 1:
                 # the same step (forward, backward, Adam with device-side step counters) captured once in a HIP graph and replayed: what a
                 # training loop with static shapes would run; measured after the timed region, reported beside it
@@ -697,6 +745,7 @@ def main():
                          "kernels).  train: forward + backward + Adam step of -mean(log p) (the reference's training objective), rows = 1/4 of the "
                          "log-prob batch, gradients all-reduced over the ranks")
     ap.add_argument("--train", action="store_true", help="same as --direction train")
+    ap.add_argument("--torch-adam", action="store_true", help="training: torch.optim.Adam (foreach) instead of jammy_flows_amd.optim.Adam")
     ap.add_argument("--no-fuse", action="store_true", help="time the two-launch path (MLP launch + flow launch) instead of the fused conditional block")
     ap.add_argument("--preheat-ms", type=float, default=1000.0,
                     help="run the step untimed for this long before the warm-up steps, so that the timed region sees the chip's sustained clocks (0 = off)")

@@ -600,6 +600,13 @@ typedef struct jf_row_list {
 } jf_row_list;
 int jf_combine_rows_f32(const jf_row_list* ld, const jf_row_list* blp, int64_t B, float* ld_out, float* blp_out, float* total_out, void* stream);
 int jf_combine_rows_f64(const jf_row_list* ld, const jf_row_list* blp, int64_t B, double* ld_out, double* blp_out, double* total_out, void* stream);
+/* torch.optim.Adam (amsgrad off, no weight decay: what examples/jammy_flows.py:381-412 trains with) over up to JF_ADAM_MAX_TENSORS parameter
+ * tensors in ONE launch: m <- m + (g - m)(1 - b1); v <- v b2 + (1 - b2) g^2; p <- p - lr / (1 - b1^step) m / (sqrt(v) / sqrt(1 - b2^step) + eps).
+ * `step` counts from 1.  All four arrays of a tensor are contiguous, n elements, of the function's precision. */
+#define JF_ADAM_MAX_TENSORS 64
+typedef struct jf_adam_tensor { void* param; const void* grad; void* exp_avg; void* exp_avg_sq; int64_t n; } jf_adam_tensor;
+int jf_adam_step_f32(const jf_adam_tensor* tensors, int32_t n_tensors, double lr, double beta1, double beta2, double eps, int64_t step, void* stream);
+int jf_adam_step_f64(const jf_adam_tensor* tensors, int32_t n_tensors, double lr, double beta1, double beta2, double eps, int64_t step, void* stream);
 /* out = a + b (n elements) */
 int jf_add_rows_f32(const float* a, const float* b, int64_t n, float* out, void* stream);
 int jf_add_rows_f64(const double* a, const double* b, int64_t n, double* out, void* stream);

@@ -96,6 +96,13 @@ class jf_row_list(ctypes.Structure):
     _fields_ = [("p", ctypes.c_void_p * 16), ("n", ctypes.c_int32)]
 
 
+class jf_adam_tensor(ctypes.Structure):
+    _fields_ = [("param", ctypes.c_void_p), ("grad", ctypes.c_void_p), ("exp_avg", ctypes.c_void_p), ("exp_avg_sq", ctypes.c_void_p), ("n", ctypes.c_int64)]
+
+
+JF_ADAM_MAX_TENSORS = 64
+
+
 class jf_cond_segment(ctypes.Structure):
     _fields_ = [("src", ctypes.c_void_p), ("stride", ctypes.c_int64), ("kind", ctypes.c_int32), ("n_in", ctypes.c_int32)]
 
@@ -128,6 +135,7 @@ _SIGNATURES = {
     "jf_activation": [_P, _I64, _I32, _P, _P],
     "jf_device_math": [_P, _I64, _I32, _P, _P],
     "jf_add_rows": [_P, _P, _I64, _P, _P],
+    "jf_adam_step": [ctypes.POINTER(jf_adam_tensor), _I32, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, _I64, _P],
     "jf_combine_rows": [ctypes.POINTER(jf_row_list), ctypes.POINTER(jf_row_list), _I64, _P, _P, _P, _P],
     "jf_activation_bwd": [_P, _P, _I64, _I32, _P, _P],
     "jf_mlp2": [_P, _I64, _P, _I64, _P, _P, _I64, _P, _I64, _I32, _I32, _I32, _P, _I64, _P],

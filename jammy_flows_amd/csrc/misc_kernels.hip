@@ -275,6 +275,48 @@ template <typename T> static int combine_rows(const jf_row_list* ld, const jf_ro
     return check_launch();
 }
 
+// Adam over ALL parameter tensors of a model in one launch.  The models of this path have < 1 MB of parameters in ~40 tensors; torch's foreach
+// implementation walks them with 6-7 multi_tensor_apply launches of 10-20 us each (0.09 ms of a 1.85 ms C3 training step, profiles/r03_train.md).
+// Same update as torch.optim.Adam (amsgrad off, no weight decay), same operation order:
+//   m <- m + (g - m) (1 - b1);  v <- v b2 + (1 - b2) g g;  p <- p - (lr / bc1) m / (sqrt(v) / sqrt(bc2) + eps)
+template <typename T> struct AdamTable {
+    T* p[JF_ADAM_MAX_TENSORS]; const T* g[JF_ADAM_MAX_TENSORS]; T* m[JF_ADAM_MAX_TENSORS]; T* v[JF_ADAM_MAX_TENSORS];
+    int first_block[JF_ADAM_MAX_TENSORS + 1];
+    int64_t n[JF_ADAM_MAX_TENSORS];
+    int count;
+};
+template <typename T> __global__ void __launch_bounds__(256) adam_kernel(const AdamTable<T> t, double step_size, double b1, double b2, double inv_sqrt_bc2,
+                                                                          double eps) {
+    int k = 0;
+    while (k + 1 < t.count && (int)blockIdx.x >= t.first_block[k + 1]) ++k;                 // block-uniform: <= 96 scalar compares
+    const int64_t i = (int64_t)((int)blockIdx.x - t.first_block[k]) * 256 + threadIdx.x;
+    if (i >= t.n[k]) return;
+    const T g = t.g[k][i];
+    T m = t.m[k][i], v = t.v[k][i];
+    m = m + (g - m) * (T)(1.0 - b1);
+    v = v * (T)b2 + (T)(1.0 - b2) * g * g;
+    t.m[k][i] = m; t.v[k][i] = v;
+    const T denom = M<T>::sqrt(v) * (T)inv_sqrt_bc2 + (T)eps;
+    t.p[k][i] = t.p[k][i] - (T)step_size * (m / denom);
+}
+template <typename T> static int adam_step(const jf_adam_tensor* tensors, int32_t n, double lr, double b1, double b2, double eps, int64_t step, void* stream) {
+    if (!tensors || n < 1 || n > JF_ADAM_MAX_TENSORS || step < 1 || !(lr >= 0) || !(b1 >= 0 && b1 < 1) || !(b2 >= 0 && b2 < 1) || !(eps >= 0)) return JF_ERR_BADARG;
+    AdamTable<T> t{};
+    int blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        const jf_adam_tensor& e = tensors[i];
+        if (!e.param || !e.grad || !e.exp_avg || !e.exp_avg_sq || e.n < 0 || e.n > ((int64_t)1 << 31)) return JF_ERR_BADARG;
+        t.p[i] = static_cast<T*>(e.param); t.g[i] = static_cast<const T*>(e.grad); t.m[i] = static_cast<T*>(e.exp_avg); t.v[i] = static_cast<T*>(e.exp_avg_sq);
+        t.n[i] = e.n; t.first_block[i] = blocks;
+        blocks += (int)((e.n + 255) / 256);
+    }
+    t.first_block[n] = blocks; t.count = n;
+    if (blocks == 0) return JF_OK;
+    const double bc1 = 1.0 - pow(b1, (double)step), bc2 = 1.0 - pow(b2, (double)step);
+    jf::launch(adam_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, t, lr / bc1, b1, b2, 1.0 / sqrt(bc2), eps);
+    return check_launch();
+}
+
 // the scalar math policy of the flow kernels (jf_math.h), elementwise: what tests/test_gpu_math.py measures against torch
 template <typename T> __global__ void __launch_bounds__(256) math_kernel(const T* __restrict__ x, int64_t n, int fn, T* __restrict__ out) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -296,6 +338,8 @@ int jf_device_math_f32(const float* x, int64_t n, int32_t fn, float* out, void* 
 int jf_device_math_f64(const double* x, int64_t n, int32_t fn, double* out, void* s) { return jf::device_math<double>(x, n, fn, out, s); }
 int jf_combine_rows_f32(const jf_row_list* ld, const jf_row_list* blp, int64_t B, float* lo, float* bo, float* to, void* s) { return jf::combine_rows<float>(ld, blp, B, lo, bo, to, s); }
 int jf_combine_rows_f64(const jf_row_list* ld, const jf_row_list* blp, int64_t B, double* lo, double* bo, double* to, void* s) { return jf::combine_rows<double>(ld, blp, B, lo, bo, to, s); }
+int jf_adam_step_f32(const jf_adam_tensor* t, int32_t n, double lr, double b1, double b2, double eps, int64_t step, void* s) { return jf::adam_step<float>(t, n, lr, b1, b2, eps, step, s); }
+int jf_adam_step_f64(const jf_adam_tensor* t, int32_t n, double lr, double b1, double b2, double eps, int64_t step, void* s) { return jf::adam_step<double>(t, n, lr, b1, b2, eps, step, s); }
 int jf_add_rows_f32(const float* a, const float* b, int64_t n, float* out, void* s) { return jf::add_rows<float>(a, b, n, out, s); }
 int jf_add_rows_f64(const double* a, const double* b, int64_t n, double* out, void* s) { return jf::add_rows<double>(a, b, n, out, s); }
 int jf_conditioning_rows_f32(const jf_cond_segment* g, int32_t n, int64_t B, float* out, int64_t os, void* s) {
