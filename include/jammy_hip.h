@@ -268,6 +268,23 @@ int jf_amlp_gf_chain_fwd_f64(const double* in, int64_t in_stride, const double* 
                              const double* U2, const double* b2, int32_t K1, int32_t H, int32_t r1, int32_t r2, const double* z, int64_t z_stride,
                              const double* log_det_in, int64_t B, int32_t D, int32_t n_layers, const jf_gf_layer* layers, double* x_out,
                              int64_t x_out_stride, double* log_det_out, int32_t* status, void* stream);
+/* Training on a low-rank last MLP stage (float64, r2 <= 8, D <= 8, default layer options -- else JF_ERR_UNSUPPORTED): the chain of g layers on
+ * the parameter rows U2 t2[row] + b2 (t2 (B, r2), U2 (N, r2), b2 (N): amortizable_mlp.py:508-578), the (B, N) block never materialised.
+ * jf_lowrank_gf_chain_inv_f64: jf_gf_chain_inv's outputs; aux (nullable) receives (n_layers, 5, 2, B, 4) doubles -- every layer's input
+ * coordinates and normalised mixture sums -- which jf_lowrank_gf_chain_inv_bwd_f64 reads instead of re-running the chain.
+ * jf_lowrank_gf_chain_inv_bwd_f64: what torch.autograd returns for (x, t2, U2, b2) given the upstream gradients of (x_out, log_det_out,
+ * base_logp_out) (each nullable): g_x (B, D), g_t2 (B, 8: columns >= r2 are zero), g_U2 (N, r2), g_b2 (N).  One launch per layer (the
+ * parameter gradients are contracted with U2 and [t2 | 1] in the matrix-core registers) + one reduction; `workspace` holds
+ * jf_lowrank_gf_workspace_doubles(B, n_layers) doubles.  x_out: the forward's output (needed when g_base_logp is given). */
+int jf_lowrank_gf_chain_inv_f64(const double* t2, int64_t t2_stride, const double* U2, const double* b2, int32_t r2, const double* x, int64_t x_stride,
+                                const double* log_det_in, int64_t B, int32_t D, int32_t n_layers, const jf_gf_layer* layers, double* x_out,
+                                int64_t x_out_stride, double* log_det_out, const double* base_logp_in, double* base_logp_out, double* aux,
+                                int32_t* status, void* stream);
+int64_t jf_lowrank_gf_workspace_doubles(int64_t B, int32_t n_layers);
+int jf_lowrank_gf_chain_inv_bwd_f64(const double* t2, int64_t t2_stride, const double* U2, const double* b2, int32_t r2, const double* aux,
+                                    const double* x_out, int64_t x_out_stride, int64_t B, int32_t D, int32_t n_layers, const jf_gf_layer* layers,
+                                    const double* g_x_out, int64_t g_x_out_stride, const double* g_log_det, const double* g_base_logp, double* g_x,
+                                    int64_t g_x_stride, double* g_t2, double* g_U2, double* g_b2, double* workspace, int32_t* status, void* stream);
 
 /* The same two-stage low-rank AmortizableMLP alone, ONE launch instead of four dense launches:
  * out (B, N) = U2 (V2 tanh(W1 in + b1)) + b2 (same operand conventions and limits as jf_amlp_gf_chain_inv). */

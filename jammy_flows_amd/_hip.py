@@ -200,6 +200,11 @@ _SIGNATURES_SINGLE = {
     "jf_cond_gf_pack_f32": ([_P, _I64, _P, _I32, _I32, _I32, ctypes.POINTER(jf_gf_layer), _P, _P], ctypes.c_int),
     "jf_amlp_gf_chain_fwd_f64": ([_P, _I64, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P, _I64, _P, _I64, _I32, _I32, ctypes.POINTER(jf_gf_layer),
                                   _P, _I64, _P, _P, _P], ctypes.c_int),
+    "jf_lowrank_gf_chain_inv_f64": ([_P, _I64, _P, _P, _I32, _P, _I64, _P, _I64, _I32, _I32, ctypes.POINTER(jf_gf_layer), _P, _I64, _P, _P, _P, _P, _P, _P],
+                                    ctypes.c_int),
+    "jf_lowrank_gf_workspace_doubles": ([_I64, _I32], ctypes.c_int64),
+    "jf_lowrank_gf_chain_inv_bwd_f64": ([_P, _I64, _P, _P, _I32, _P, _P, _I64, _I64, _I32, _I32, ctypes.POINTER(jf_gf_layer), _P, _I64, _P, _P, _P, _I64,
+                                         _P, _P, _P, _P, _P, _P], ctypes.c_int),
     "jf_cond_gf_packed_bytes2": ([_I32, _I32, ctypes.POINTER(jf_gf_layer), _I32], ctypes.c_int64),
     "jf_cond_gf_pack2_f32": ([_P, _I64, _P, _I32, _I32, _I32, ctypes.POINTER(jf_gf_layer), _I32, _P, _P], ctypes.c_int),
     "jf_cond_gf_chain_split2_f32": ([_I32, _I32, _P, _I64, _P, _I64, _P, _P, _I32, _I32, _P, _I64, _P, _I64, _I32, _I32, ctypes.POINTER(jf_gf_layer),
@@ -671,6 +676,58 @@ def amlp_gf_chain_inv(inp, v1, u1, b1, v2, u2, b2, x, log_det, layer_array, n_la
              _ptr(log_det), B, D, n_layers, layer_array, _ptr(x_out), x_out.stride(0), _ptr(ld_out), _ptr(base_logp_in), _ptr(blp_out), _ptr(status)),
             dev)
     return (x_out, ld_out, blp_out) if want_base_logp else (x_out, ld_out)
+
+
+LOWRANK_GF_MAX_RANK = 8
+LOWRANK_GF_AUX = 5
+
+
+def lowrank_gf_chain_inv(t2, u2, b2, x, log_det, layer_array, n_layers, D, base_logp_in=None, want_base_logp=False, want_aux=False, status=None):
+    """log-prob direction of a chain of g layers whose parameter rows are u2 t2[row] + b2 (the low-rank last stage of an AmortizableMLP,
+    float64, rank <= 8), the block never materialised: jf_lowrank_gf_chain_inv_f64.  want_aux: also the (n_layers, 5, B, 8) block of layer
+    inputs and mixture sums its backward launch reads.  -> (x_out, log_det_out[, base_logp_out][, aux]) or None when unsupported."""
+    dev = require_device(t2, u2, b2, x, log_det, base_logp_in, status)
+    t2, x = _rowmajor(t2), _rowmajor(x)
+    u2, b2 = u2.contiguous(), b2.contiguous()
+    B, r2 = t2.shape
+    if x.dtype != torch.float64 or any(t.dtype != torch.float64 for t in (t2, u2, b2)) or x.shape != (B, D) or u2.shape[1] != r2 or b2.shape[0] != u2.shape[0]:
+        raise ValueError("lowrank_gf_chain_inv: inconsistent shapes / dtypes")
+    if log_det is not None:
+        log_det = log_det.contiguous()
+    x_out = torch.empty((B, D), dtype=x.dtype, device=x.device)
+    ld_out = torch.empty((B,), dtype=x.dtype, device=x.device)
+    blp_out = torch.empty((B,), dtype=x.dtype, device=x.device) if want_base_logp else None
+    aux = torch.empty((n_layers, LOWRANK_GF_AUX, 2, B, 4), dtype=x.dtype, device=x.device) if want_aux else None
+    ok = _launch("jf_lowrank_gf_chain_inv_f64", "N%d_D%d_r%d" % (u2.shape[0], D, r2),
+                 (_ptr(t2), t2.stride(0), _ptr(u2), _ptr(b2), r2, _ptr(x), x.stride(0), _ptr(log_det), B, D, n_layers, layer_array, _ptr(x_out),
+                  x_out.stride(0), _ptr(ld_out), _ptr(base_logp_in), _ptr(blp_out), _ptr(aux), _ptr(status)), dev, unsupported_ok=True)
+    if ok is False:
+        return None
+    return (x_out, ld_out) + ((blp_out,) if want_base_logp else ()) + ((aux,) if want_aux else ())
+
+
+def lowrank_gf_chain_inv_bwd(t2, u2, b2, aux, x_out, layer_array, n_layers, D, g_xout, g_ld, g_blp, status=None):
+    """adjoint of lowrank_gf_chain_inv: one launch per layer + one reduction -> (g_x (B, D), g_t2 (B, r2), g_u2 (N, r2), g_b2 (N))"""
+    dev = require_device(t2, u2, b2, aux, x_out, g_xout, g_ld, g_blp)
+    t2, x_out = _rowmajor(t2), _rowmajor(x_out)
+    u2, b2 = u2.contiguous(), b2.contiguous()
+    B, r2 = t2.shape
+    N = u2.shape[0]
+    g_xout = None if g_xout is None else _rowmajor(g_xout)
+    g_ld = None if g_ld is None else g_ld.contiguous()
+    g_blp = None if g_blp is None else g_blp.contiguous()
+    g_x = torch.empty((B, D), dtype=t2.dtype, device=t2.device)
+    g_t2 = torch.empty((B, LOWRANK_GF_MAX_RANK), dtype=t2.dtype, device=t2.device)
+    g_u2 = torch.empty((N, r2), dtype=t2.dtype, device=t2.device)
+    g_b2 = torch.empty((N,), dtype=t2.dtype, device=t2.device)
+    if B == 0:
+        return g_x, g_t2[:, :r2], g_u2.zero_(), g_b2.zero_()
+    work = torch.empty((int(lib().jf_lowrank_gf_workspace_doubles(B, n_layers)),), dtype=t2.dtype, device=t2.device)
+    _launch("jf_lowrank_gf_chain_inv_bwd_f64", "N%d_D%d_r%d" % (N, D, r2),
+            (_ptr(t2), t2.stride(0), _ptr(u2), _ptr(b2), r2, _ptr(aux), _ptr(x_out), x_out.stride(0), B, D, n_layers, layer_array, _ptr(g_xout),
+             0 if g_xout is None else g_xout.stride(0), _ptr(g_ld), _ptr(g_blp), _ptr(g_x), g_x.stride(0), _ptr(g_t2), _ptr(g_u2), _ptr(g_b2),
+             _ptr(work), _ptr(status)), dev)
+    return g_x, g_t2[:, :r2], g_u2, g_b2
 
 
 def amlp_gf_chain_fwd(inp, v1, u1, b1, v2, u2, b2, z, log_det, layer_array, n_layers, D, x_out=None, status=None):

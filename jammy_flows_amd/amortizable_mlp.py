@@ -250,6 +250,24 @@ class AmortizableMLP(nn.Module):
             o += n
         return x, o
 
+    def forward_to_last_rank(self, i):
+        """(t, u, b) with t (B, rank) = V^T x of the LAST stage -- the rank-space vector of every row -- and that stage's u (out, rank), b (out)
+        as views of the parameter vector, all three inside the autograd graph: for a caller that fuses u t + b into its own launch
+        (autograd.LowRankGfChainFn, which never writes the (B, out) block).  None unless this is a plain MLP (no highway connections) on permanent
+        parameters whose last stage is low-rank with a bias."""
+        if not self.use_permanent_parameters or self.highway_mode != 0 or self.stages is None or self.linear is not None or len(self.sub_mlps) != 1:
+            return None
+        last = self.stages[-1]
+        if last["full"] or last["num_b"] == 0 or last["act"]:
+            return None
+        _hip.require_device(i)
+        flat = self.u_v_b_pars.to(dtype=i.dtype).reshape(-1)
+        x, o = self._run(self.stages[:-1], i, flat, 0, False)
+        u = flat[o:o + last["num_u"]].view(last["out"], last["rank"])
+        v = flat[o + last["num_u"]:o + last["num_u"] + last["num_v"]].view(last["rank"], last["inp"])
+        b = flat[o + last["num_u"] + last["num_v"]:o + last["num_u"] + last["num_v"] + last["num_b"]]
+        return autograd.linear(x, v, None, 0), u, b
+
     def forward(self, i, extra_inputs=None):
         """i: (B, input_dim).  extra_inputs: None (permanent parameters) or the per-sample (B, num_amortization_params) block."""
         _hip.require_device(i)

@@ -129,6 +129,34 @@ class GfChainInvFn(torch.autograd.Function):
         return (g_x, g_ld if ctx.has[0] else None, g_params, g_blp if ctx.has[1] else None, None, None, None, None)
 
 
+class LowRankGfChainFn(torch.autograd.Function):
+    """chain of g layers on the rows u2 t2 + b2 of a low-rank last MLP stage (float64, rank <= 8), the (B, N) parameter block and its gradient
+    never materialised: forward jf_lowrank_gf_chain_inv (keeps each layer's inputs and mixture sums, 320 bytes per row and layer), backward
+    jf_lowrank_gf_chain_inv_bwd (per-layer launches that contract the parameter gradients with u2 and t2 on the matrix cores)."""
+
+    @staticmethod
+    def forward(ctx, t2, u2, b2, x, log_det, base_logp_in, layer_array, n_layers, D, status):
+        res = _hip.lowrank_gf_chain_inv(t2.detach(), u2.detach(), b2.detach(), x.detach(), None if log_det is None else log_det.detach(), layer_array,
+                                        n_layers, D, base_logp_in=None if base_logp_in is None else base_logp_in.detach(), want_base_logp=True,
+                                        want_aux=True, status=status)
+        if res is None:
+            raise RuntimeError("jf_lowrank_gf_chain_inv: unsupported configuration (the caller checks lowrank_chain_ok first)")
+        ctx.meta = (layer_array, n_layers, D)
+        ctx.set_materialize_grads(False)
+        ctx.has = (log_det is not None, base_logp_in is not None)
+        ctx.aux = res[3]
+        ctx.save_for_backward(t2, u2, b2, res[0])
+        return res[:3]
+
+    @staticmethod
+    def backward(ctx, g_xout, g_ld, g_blp):
+        t2, u2, b2, z = ctx.saved_tensors
+        layer_array, n_layers, D = ctx.meta
+        g_x, g_t2, g_u2, g_b2 = _hip.lowrank_gf_chain_inv_bwd(t2, u2, b2, ctx.aux, z, layer_array, n_layers, D, g_xout, g_ld, g_blp)
+        ctx.aux = None
+        return (g_t2, g_u2, g_b2, g_x, g_ld if ctx.has[0] else None, g_blp if ctx.has[1] else None, None, None, None, None)
+
+
 # the fused block's backward in one launch (csrc/cond_bwd_kernels.hip) wherever the "split" kernel ran the forward; "0" = the round-2 sequence
 # of dense launches around a materialised parameter block (kept for A/B timing and as the path of the other kernels)
 FUSED_BLOCK_BACKWARD = os.environ.get("JF_FUSED_BLOCK_BACKWARD", "1") != "0"

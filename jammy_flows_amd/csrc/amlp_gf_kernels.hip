@@ -110,6 +110,7 @@ template <typename T, int G> __device__ __forceinline__ T group_bcast(T v, int s
 
 }  // namespace jf
 #include "jf_amlp_mfma.h"      // the float64 matrix-core version of the same block (needs AgArgs / ag_mixture above)
+#include "jf_lowrank_gf.h"     // training: the chain on a low-rank last stage, forward with saved layer inputs + per-layer adjoint launches
 namespace jf {
 
 // RM: compiled rank bound (8 or 16): the rank loops are fully unrolled over it
@@ -303,18 +304,12 @@ static int amlp2(const T* in, int64_t in_stride, const T* V1, const T* U1, const
     return ag_launch<T>(a, 8, (hipStream_t)stream);
 }
 
-template <typename T, bool FWD = false>
-static int amlp_gf_chain_inv(const T* in, int64_t in_stride, const T* V1, const T* U1, const T* b1, const T* V2, const T* U2, const T* b2, int32_t K1,
-                             int32_t H, int32_t r1, int32_t r2, const T* x, int64_t xs, const T* ld_in, int64_t B, int32_t D, int32_t n_layers,
-                             const jf_gf_layer* layers, T* x_out, int64_t xos, T* ld_out, const T* blp_in, T* blp_out, int32_t* status, void* stream) {
-    if (!in || !U1 || !b1 || !V2 || !U2 || !b2 || !x || !x_out || !ld_out || !layers) return JF_ERR_BADARG;
-    if (!width_ok(K1) || !width_ok(H) || !width_ok(r2) || !rows_ok(B) || n_layers < 1 || n_layers > JF_MAX_CHAIN || D < 1 || (V1 && r1 < 1)) return JF_ERR_BADARG;
-    if (K1 > AG_K1MAX || H > AG_HMAX || r2 > AG_RMAX || (V1 && r1 > AG_RMAX) || D > 8) return JF_ERR_UNSUPPORTED;
-    AgArgs<T> a{};
+// the chain's layer table (offsets of every layer's sections inside the parameter row) -> L; returns the row length or JF_ERR_UNSUPPORTED
+template <typename T> static int ag_make_layers(const jf_gf_layer* layers, int n_layers, int D, AgLayer<T>* L) {
     int col = 0;
     for (int l = 0; l < n_layers; ++l) {
         const jf_gf_layer& h = layers[l];
-        AgLayer<T>& o = a.L[l];
+        AgLayer<T>& o = L[l];
         if (h.num_kde != AG_K || h.hh_iter < 0 || h.hh_iter > AG_HH || h.nonlinear_stretch_type != JF_GF_STRETCH_CLASSIC ||
             h.width_mode != JF_GF_WIDTH_SMOOTH_SATURATION || h.clamp_widths || !h.fit_normalization || !h.regulate_normalization ||
             h.width_min <= 0 || h.width_max <= 0 || h.rotation_mode != JF_GF_ROT_HOUSEHOLDER || h.center_mean || h.add_skewness)
@@ -328,6 +323,19 @@ static int amlp_gf_chain_inv(const T* in, int64_t in_stride, const T* V1, const 
         o.wmin = (T)h.width_min; o.inv_wmax = (T)(1.0 / h.width_max); o.nmin = (T)h.norm_min; o.nmax = (T)h.norm_max;
         col += o.off_ln + kd;
     }
+    return col;
+}
+
+template <typename T, bool FWD = false>
+static int amlp_gf_chain_inv(const T* in, int64_t in_stride, const T* V1, const T* U1, const T* b1, const T* V2, const T* U2, const T* b2, int32_t K1,
+                             int32_t H, int32_t r1, int32_t r2, const T* x, int64_t xs, const T* ld_in, int64_t B, int32_t D, int32_t n_layers,
+                             const jf_gf_layer* layers, T* x_out, int64_t xos, T* ld_out, const T* blp_in, T* blp_out, int32_t* status, void* stream) {
+    if (!in || !U1 || !b1 || !V2 || !U2 || !b2 || !x || !x_out || !ld_out || !layers) return JF_ERR_BADARG;
+    if (!width_ok(K1) || !width_ok(H) || !width_ok(r2) || !rows_ok(B) || n_layers < 1 || n_layers > JF_MAX_CHAIN || D < 1 || (V1 && r1 < 1)) return JF_ERR_BADARG;
+    if (K1 > AG_K1MAX || H > AG_HMAX || r2 > AG_RMAX || (V1 && r1 > AG_RMAX) || D > 8) return JF_ERR_UNSUPPORTED;
+    AgArgs<T> a{};
+    const int col = ag_make_layers<T>(layers, n_layers, D, a.L);
+    if (col < 0) return col;
     if (B == 0) return JF_OK;
     a.in = in; a.in_stride = in_stride; a.V1 = V1; a.U1 = U1; a.b1 = b1; a.V2 = V2; a.U2 = U2; a.b2 = b2;
     a.K1 = K1; a.H = H; a.r1 = V1 ? r1 : 0; a.r2 = r2; a.N = col;
@@ -349,9 +357,75 @@ static int amlp_gf_chain_inv(const T* in, int64_t in_stride, const T* V1, const 
     else return ag_launch<T>(a, D, (hipStream_t)stream);
 }
 
+static int lowrank_gf_chain_inv(const double* t2, int64_t t2s, const double* U2, const double* b2, int32_t r2, const double* x, int64_t xs,
+                               const double* ld_in, int64_t B, int32_t D, int32_t n_layers, const jf_gf_layer* layers, double* x_out, int64_t xos,
+                               double* ld_out, const double* blp_in, double* blp_out, double* aux, int32_t* status, void* stream) {
+    if (!t2 || !U2 || !b2 || !x || !x_out || !ld_out || !layers) return JF_ERR_BADARG;
+    if (!rows_ok(B) || n_layers < 1 || n_layers > JF_MAX_CHAIN || D < 1 || r2 < 1) return JF_ERR_BADARG;
+    if (r2 > AM_R || D > 8) return JF_ERR_UNSUPPORTED;
+    LrFwdArgs<double> a{};
+    const int col = ag_make_layers<double>(layers, n_layers, D, a.L);
+    if (col < 0) return col;
+    const size_t lds = (size_t)n_layers * (AM_TILES * 2 * 64 + AM_TILES * 16) * sizeof(double);
+    if (lds > 160 * 1024) return JF_ERR_UNSUPPORTED;
+    if (B == 0) return JF_OK;
+    a.t2 = t2; a.t2s = t2s; a.U2 = U2; a.b2 = b2; a.r2 = r2; a.x = x; a.xs = xs; a.ld_in = ld_in; a.B = B; a.D = D; a.n_layers = n_layers;
+    a.x_out = x_out; a.xos = xos; a.ld_out = ld_out; a.blp_in = blp_in; a.blp_out = blp_out; a.aux = aux; a.status = status;
+    auto k = lr_gf_fwd_kernel<LrFwdArgs<double>>;
+    static LdsAttrOnce attr;
+    if (lds > 48 * 1024) attr.set((const void*)k, (int)lds);
+    constexpr int ROWS = am_rows(AM_THREADS);
+    jf::launch(k, dim3((unsigned)((B + ROWS - 1) / ROWS)), dim3(AM_THREADS), lds, (hipStream_t)stream, a);
+    return check_launch();
+}
+
+static int lowrank_gf_chain_inv_bwd(const double* t2, int64_t t2s, const double* U2, const double* b2, int32_t r2, const double* aux, const double* x_out,
+                                   int64_t xos, int64_t B, int32_t D, int32_t n_layers, const jf_gf_layer* layers, const double* g_xout, int64_t gxos,
+                                   const double* g_ld, const double* g_blp, double* g_x, int64_t gxs, double* g_t2, double* g_U2, double* g_b2,
+                                   double* workspace, int32_t* status, void* stream) {
+    if (!t2 || !U2 || !b2 || !aux || !g_x || !g_t2 || !g_U2 || !g_b2 || !workspace || !layers || (g_blp && !x_out)) return JF_ERR_BADARG;
+    if (!rows_ok(B) || B < 1 || n_layers < 1 || n_layers > JF_MAX_CHAIN || D < 1 || r2 < 1) return JF_ERR_BADARG;
+    if (r2 > AM_R || D > 8) return JF_ERR_UNSUPPORTED;
+    LrReduceArgs red{};
+    const int col = ag_make_layers<double>(layers, n_layers, D, red.L);
+    if (col < 0) return col;
+    const int n_wg = lr_n_wg(B);
+    const size_t lds = (size_t)(LR_TILES * 2 * 64 + LR_TILES * 16 + LR_PSZ + LR_NW * 2 * 16 * 17) * sizeof(double);
+    static LdsAttrOnce attr;
+    attr.set((const void*)lr_gf_bwd_layer_kernel, (int)lds);
+    for (int l = 0; l < n_layers; ++l) {
+        LrBwdArgs<double> a{};
+        a.t2 = t2; a.t2s = t2s; a.U2 = U2; a.b2 = b2; a.r2 = r2; a.aux = aux; a.x_out = x_out; a.xos = xos;
+        a.B = B; a.n_row_tiles = (B + 15) / 16; a.D = D; a.layer = l; a.n_layers = n_layers; a.first = l == 0;
+        a.L = red.L[l];
+        a.g_xout = g_xout; a.gxos = gxos; a.g_ld = g_ld; a.g_blp = g_blp; a.g_x = g_x; a.gxs = gxs; a.g_t2 = g_t2;
+        a.partial = workspace + (size_t)l * n_wg * LR_PSZ; a.status = status;
+        jf::launch(lr_gf_bwd_layer_kernel, dim3((unsigned)n_wg), dim3(LR_NW * 64), lds, (hipStream_t)stream, a);
+    }
+    red.partial = workspace; red.n_wg = n_wg; red.n_layers = n_layers; red.D = D; red.r2 = r2; red.g_U2 = g_U2; red.g_b2 = g_b2;
+    jf::launch(lr_reduce_kernel, dim3((unsigned)((n_layers * LR_PSZ + 63) / 64)), dim3(256), 0, (hipStream_t)stream, red);
+    return check_launch();
+}
+
 }  // namespace jf
 
 extern "C" {
+int jf_lowrank_gf_chain_inv_f64(const double* t2, int64_t t2s, const double* U2, const double* b2, int32_t r2, const double* x, int64_t xs,
+                                const double* ld_in, int64_t B, int32_t D, int32_t n, const jf_gf_layer* L, double* xo, int64_t xos, double* ldo,
+                                const double* bi, double* bo, double* aux, int32_t* st, void* s) {
+    return jf::lowrank_gf_chain_inv(t2, t2s, U2, b2, r2, x, xs, ld_in, B, D, n, L, xo, xos, ldo, bi, bo, aux, st, s);
+}
+int64_t jf_lowrank_gf_workspace_doubles(int64_t B, int32_t n_layers) {
+    if (B < 1 || n_layers < 1 || n_layers > JF_MAX_CHAIN) return 0;
+    return (int64_t)n_layers * jf::lr_n_wg(B) * jf::LR_PSZ;
+}
+int jf_lowrank_gf_chain_inv_bwd_f64(const double* t2, int64_t t2s, const double* U2, const double* b2, int32_t r2, const double* aux, const double* x_out,
+                                    int64_t xos, int64_t B, int32_t D, int32_t n, const jf_gf_layer* L, const double* g_xout, int64_t gxos,
+                                    const double* g_ld, const double* g_blp, double* g_x, int64_t gxs, double* g_t2, double* g_U2, double* g_b2,
+                                    double* workspace, int32_t* st, void* s) {
+    return jf::lowrank_gf_chain_inv_bwd(t2, t2s, U2, b2, r2, aux, x_out, xos, B, D, n, L, g_xout, gxos, g_ld, g_blp, g_x, gxs, g_t2, g_U2, g_b2,
+                                        workspace, st, s);
+}
 int jf_amlp2_f32(const float* in, int64_t is, const float* V1, const float* U1, const float* b1, const float* V2, const float* U2, const float* b2,
                  int64_t B, int32_t K1, int32_t H, int32_t r1, int32_t r2, int32_t N, float* out, int64_t os, void* s) {
     return jf::amlp2<float>(in, is, V1, U1, b1, V2, U2, b2, B, K1, H, r1, r2, N, out, os, s);

@@ -236,6 +236,8 @@ class pdf(nn.Module):
         # the same idea without streams: the blocks after the first are launched without the queue's barrier bit (csrc/plan.hip any_order)
         self.plan_overlap_blocks = os.environ.get("JF_PLAN_OVERLAP", "0") == "1"
         self.plan_overlap_max_rows = int(os.environ.get("JF_PLAN_OVERLAP_MAX_ROWS", str(1 << 40)))
+        # gradient mode, float64: chains on a low-rank last MLP stage never materialise their (B, P) parameter / gradient blocks
+        self.lowrank_chain_training = os.environ.get("JF_LOWRANK_CHAIN_TRAINING", "1") != "0"
         self.use_step_plans = os.environ.get("JF_STEP_PLANS", "0") == "1"      # forward() through recorded step plans (planned_forward)
 
         self._read_model_definition(pdf_defs, flow_defs, options_overwrite, conditional_input_dim, amortization_mlp_dims,
@@ -682,6 +684,27 @@ class pdf(nn.Module):
                     and not c.clamp_widths and c.fit_normalization and c.regulate_normalization):
                 return None
         return mlp.lowrank_views(mlp._flat(like))
+
+    def _lowrank_chain_ok(self, si, layers, only_last, amort, x, mlp):
+        """gradient mode: sub-pdf si can run autograd.LowRankGfChainFn (float64, last MLP stage low-rank with rank <= 8, <= 8 dimensions,
+        g layers at default options; pdf.lowrank_chain_training = False or JF_LOWRANK_CHAIN_TRAINING=0: the (B, P)-block sequence)"""
+        if not self.lowrank_chain_training or x.dtype != torch.float64 or only_last or amort is not None or self._poisson_column(si):
+            return False
+        if not isinstance(mlp, AmortizableMLP) or mlp.highway_mode != 0 or not mlp.use_permanent_parameters or not mlp.stages or mlp.linear is not None:
+            return False
+        last = mlp.stages[-1]
+        if last["full"] or last["num_b"] == 0 or last["act"] or last["rank"] > _hip.LOWRANK_GF_MAX_RANK or len(mlp.sub_mlps) != 1:
+            return False
+        if layers[0].dimension > 8 or x.shape[0] == 0:
+            return False
+        for l in layers:
+            c = l.c_struct()
+            if l.has_extended_options:
+                return False
+            if not (c.num_kde == 10 and c.hh_iter <= 8 and c.nonlinear_stretch_type == _hip.GF_STRETCH_CLASSIC and c.width_mode == _hip.GF_WIDTH_SMOOTH
+                    and not c.clamp_widths and c.fit_normalization and c.regulate_normalization):
+                return False
+        return True
 
     def _fused_kernel_kind(self, n_rows):
         """which register-resident fused block kernel: "pp" (persistent ping-pong workgroups, cond_pp_kernels.hip) from
@@ -1162,6 +1185,11 @@ class pdf(nn.Module):
                         packed = self._packed_w2(si, w2.detach(), b2.detach(), larr, len(layers), D, x.shape[0])
                     out, log_det, base_logp = autograd.CondBlockFn.apply(inp, w1, b1, w2, b2, tgt, log_det, base_logp, packed, larr, len(layers), D,
                                                                          status)
+                elif self._lowrank_chain_ok(si, layers, only_last, amort, x, mlp):
+                    # low-rank last stage (float64): the chain regenerates its parameters from the rank-space vector, forward and backward
+                    t2, u2, b2 = mlp.forward_to_last_rank(inp)
+                    larr = _hip.gf_layer_array([l.c_struct() for l in layers])
+                    out, log_det, base_logp = autograd.LowRankGfChainFn.apply(t2, u2, b2, tgt, log_det, base_logp, larr, len(layers), D, status)
                 else:
                     params = block_params(si, layers, inp, mlp)
                     used = layers
