@@ -13,18 +13,21 @@
 //                                                                  LDS scratch), summed over the workgroup's rows with float64 LDS atomics
 //                           (the column of ones makes g_b2 the 9th column).  Persistent workgroups; one partial image per workgroup.
 //   lr_reduce_kernel        partial images -> g_U2 (N, r2), g_b2 (N) in natural column order, fixed summation order
-// Per-layer launches keep the LDS at the image and the accumulators of ONE layer (48 KB + scratch): two workgroups of 6 waves per CU.  The
-// upstream gradient of the coordinates travels through g_x between the launches (64 bytes per row), g_t2 is accumulated in place.
+// Per-layer launches keep the LDS at the image and the accumulators of ONE layer (67 KB + 4 KB of scratch per wave): one workgroup of 8 waves
+// per CU, 256 workgroups -- at 2^17 rows every wave walks exactly 4 row tiles (230 VGPRs; 12 waves at 168 VGPRs spilled 70 and left the waves
+// with 2 or 3 tiles: 0.84 instead of 0.70 ms).  The upstream gradient of the coordinates travels through g_x between the launches (64 bytes
+// per row), g_t2 is accumulated in place.
+// Where the 0.70 ms of the four layer launches + reduction go at 2^17 rows of C5 (parts switched off one at a time, round 4): LDS atomics
+// 0.19 (36 lanes x float64 per instruction at about one lane per clock), the mixture arithmetic 0.23, the reflections 0.17, the products
+// ~0.06, launches + staging + partial images 0.06, reduction 0.01 (0.13 as one thread per entry walking 512 images), the rest is the latency
+// of the row tiles' first loads.  The (B, P)-block kernel it replaces took 1.21 ms, the three dense launches around it another 0.93.
 // Supported: what jf_amlp_gf_chain_inv_f64's matrix-core kernel supports (float64, r2 <= 8, D <= 8, default layer options).
 #pragma once
 #include "jf_gf_bwd.h"
 
 namespace jf {
 
-#ifndef LR_PROBE
-#define LR_PROBE 0
-#endif
-constexpr int LR_NW = 12;                        // waves of a backward workgroup (one workgroup per CU: three waves per SIMD)
+constexpr int LR_NW = 8;                        // waves of a backward workgroup (one workgroup per CU: three waves per SIMD)
 constexpr int LR_RS = AM_R + 1;                  // accumulator row: r2 <= 8 rank columns + the bias column
 constexpr int LR_TILES = AG_HH + 1 + 2 * AG_K;   // tiles of a layer in the BACKWARD kernel's order (lr_col)
 constexpr int LR_PSZ = LR_TILES * 16 * LR_RS;    // doubles of one layer's partial image
@@ -249,7 +252,7 @@ __global__ void __launch_bounds__(LR_NW * 64) lr_gf_bwd_layer_kernel(const LrBwd
     const int ga = ((n >> 2) & 1) * 64 + (n & 3) * 16 + q;
     const bool ga_ok = n < AM_R;
     const bool acc_lane = n <= a.r2;
-    for (int64_t rt = (int64_t)blockIdx.x * LR_NW + wave; rt < ((LR_PROBE & 32) ? 0 : a.n_row_tiles); rt += (int64_t)gridDim.x * LR_NW) {
+    for (int64_t rt = (int64_t)blockIdx.x * LR_NW + wave; rt < a.n_row_tiles; rt += (int64_t)gridDim.x * LR_NW) {
         const int64_t row = rt * 16 + n;
         const bool row_valid = row < a.B;
         const int64_t rrow = row_valid ? row : a.B - 1;
@@ -298,18 +301,15 @@ __global__ void __launch_bounds__(LR_NW * 64) lr_gf_bwd_layer_kernel(const LrBwd
             for (int r = 0; r < 4; ++r) {
                 if (r < NR) {
                     const T ua = ga_ok ? fU2[(2 * ta) * 64 + ga + 4 * r] : T(0);
-                    if (!(LR_PROBE & 4)) dta = __builtin_amdgcn_mfma_f64_16x16x4f64(ua, GA[r], dta, 0, 0, 0);
-                    else dta[0] += ua * GA[r];
-                    if (!(LR_PROBE & 2)) scr[(q + 4 * r) * 17 + n] = GA[r];
+                    dta = __builtin_amdgcn_mfma_f64_16x16x4f64(ua, GA[r], dta, 0, 0, 0);
+                    scr[(q + 4 * r) * 17 + n] = GA[r];
                     if (two) {
                         const T ub = ga_ok ? fU2[(2 * tb2) * 64 + ga + 4 * r] : T(0);
-                        if (!(LR_PROBE & 4)) dtb = __builtin_amdgcn_mfma_f64_16x16x4f64(ub, GB[r], dtb, 0, 0, 0);
-                        else dtb[0] += ub * GB[r];
-                        if (!(LR_PROBE & 2)) scr[16 * 17 + (q + 4 * r) * 17 + n] = GB[r];
+                        dtb = __builtin_amdgcn_mfma_f64_16x16x4f64(ub, GB[r], dtb, 0, 0, 0);
+                        scr[16 * 17 + (q + 4 * r) * 17 + n] = GB[r];
                     }
                 }
             }
-            if (LR_PROBE & 2) { dta[1] += GA[2] + (two ? GB[2] : 0.0); return; }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             f64x4_t wa = {0.0, 0.0, 0.0, 0.0}, wb = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -318,12 +318,11 @@ __global__ void __launch_bounds__(LR_NW * 64) lr_gf_bwd_layer_kernel(const LrBwd
                 if (two) wb = __builtin_amdgcn_mfma_f64_16x16x4f64(scr[16 * 17 + n * 17 + 4 * s + q], tb[s], wb, 0, 0, 0);
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (acc_lane && !(LR_PROBE & 1)) {
+            if (acc_lane) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) if (r < NR) {
-                    constexpr int SH = (LR_PROBE & 16) ? 40 : 0;          // probe: every wave its own addresses (wrong sums, timing only)
-                    atomicAdd(acc + ((ta * 16 + q + 4 * r) * LR_RS + n + wave * SH) % LR_PSZ, wa[r]);
-                    if (two) atomicAdd(acc + ((tb2 * 16 + q + 4 * r) * LR_RS + n + wave * SH) % LR_PSZ, wb[r]);
+                    atomicAdd(acc + (ta * 16 + q + 4 * r) * LR_RS + n, wa[r]);
+                    if (two) atomicAdd(acc + (tb2 * 16 + q + 4 * r) * LR_RS + n, wb[r]);
                 }
             }
         };
@@ -334,7 +333,7 @@ __global__ void __launch_bounds__(LR_NW * 64) lr_gf_bwd_layer_kernel(const LrBwd
             x0 -= p[0]; x1 -= p[1];
         }
 #pragma unroll 1
-        for (int i = 0; i < ((LR_PROBE & 64) ? 0 : o.hh); ++i) {
+        for (int i = 0; i < o.hh; ++i) {
             const f64x4_t p = tile(i);
             const T va = p[0], vb = p[1];
             const T n2 = lr_xsum(va * va + vb * vb), dot = lr_xsum(va * x0 + vb * x1);
@@ -372,7 +371,6 @@ __global__ void __launch_bounds__(LR_NW * 64) lr_gf_bwd_layer_kernel(const LrBwd
                         const T x = h ? x1 : x0, invN = h ? N1 : N0;
                         const bool live = h ? w1 : w0;
                         const T mu = p[0], rw = p[1], rn = p[2];
-                        if (LR_PROBE & 8) { G[h][0] = mu * icg[h]; G[h][1] = rw * isg[h]; G[h][2] = rn; G[h][3] = T(0); continue; }
                         const T e = M<T>::exp_fast(-rw);
                         const T ae = o.inv_wmax + e;
                         const T r2 = M<T>::rcp(ae * (o.wmin * ae + T(1)));
@@ -477,7 +475,7 @@ __global__ void __launch_bounds__(LR_NW * 64) lr_gf_bwd_layer_kernel(const LrBwd
         //      vector in front of each reflection brought back by applying it again (H is an involution; v . x_before = -v . x_after); the offset
         T g0 = gx0, g1 = gx1;
 #pragma unroll 1
-        for (int i = ((LR_PROBE & 64) ? 0 : o.hh) - 1; i >= 0; --i) {
+        for (int i = o.hh - 1; i >= 0; --i) {
             const f64x4_t p = tile(i);
             const T va = p[0], vb = p[1];
             const T nn = lr_xsum(va * va + vb * vb), da = lr_xsum(va * x0 + vb * x1), vg = lr_xsum(va * g0 + vb * g1);
