@@ -71,6 +71,7 @@ def test_logprob_float64_vs_reference(fx):
 
 
 NEWTON_RECORDS = json.load(open(os.path.join(fixture_io.GOLDEN_DIR, "newton_records.json")))
+NEWTON_BAND = (0.45, 1.3)         # kernel row-steps of the Newton stage / the reference's (see test_sampling_float64_vs_reference)
 F32_ABS_BAR = 1e-2            # north-star float32 bar, absolute
 F32_BIG = 1e4                 # |log p| beyond which a float32 RESULT cannot carry 1e-2 absolute any more (ulp(1e4) = 1e-3, and the sum of
                               # ~20 terms of that size that make up such a log-prob each round at that level): those rows are held to
@@ -135,12 +136,16 @@ def test_sampling_float64_vs_reference(fx):
     # Newton stage of the g layers: the work the reference's masked iteration spent on these very rows (tests/golden/newton_records.json,
     # make_newton_fixtures.py) against the kernel's own count of row-steps.  Rows that sit on the rounding floor of the 1e-14 stopping rule
     # (inormal_* layers: they run all 20 iterations in the reference too) may stop an iteration earlier or later, hence a band, not equality.
+    # Round 4: the ten-component register-row solver (cs_solve, csrc/jf_cond_regs.h) reaches the Newton stage through a safeguarded Newton
+    # approach phase instead of the reference's 25 bisections and starts it ~1e-5 instead of ~3e-3 from the root: the same stage, the same
+    # stopping rule, 1.5-2 steps fewer per row (measured 0.55-0.62 of the reference's count on every fixture) -- the band's lower edge is
+    # 0.45 for it; layers that take the generic solver (gfg_solve: other component counts) still sit at 1.0.
     rec = NEWTON_RECORDS.get(fx.name)
     if rec is not None:
         got = pdf.last_status_words["newton_row_steps"]
         print("%s: Newton row-steps %d (reference %d)" % (fx.name, got, rec["row_steps_total"]))
         assert pdf.last_status_words["nonconverged"] == sum(s["n_above_1e_7"] for s in rec["solves"]) == 0
-        assert 0.7 * rec["row_steps_total"] <= got <= 1.3 * rec["row_steps_total"]
+        assert NEWTON_BAND[0] * rec["row_steps_total"] <= got <= NEWTON_BAND[1] * rec["row_steps_total"]
 
 
 @pytest.mark.parametrize("fx", SUPPORTED, ids=IDS)
@@ -491,7 +496,7 @@ def test_fused_lowrank_sampling_block_vs_reference_and_two_launch_path(name):
     rec = NEWTON_RECORDS.get(fx.name)
     if rec is not None:
         for mode in ("two", "fused"):
-            assert 0.7 * rec["row_steps_total"] <= steps[mode] <= 1.3 * rec["row_steps_total"], (mode, steps, rec["row_steps_total"])
+            assert NEWTON_BAND[0] * rec["row_steps_total"] <= steps[mode] <= NEWTON_BAND[1] * rec["row_steps_total"], (mode, steps, rec["row_steps_total"])
 
 
 def _tiled_run(fx, dtype, log2_rows, launches=3):
