@@ -1074,3 +1074,49 @@ def test_moebius_angle_parametrisation_vs_reference(nd):
     xr = np.where(g["x"] > np.pi, g["x"] - 2 * np.pi, g["x"])
     if nd == 0:              # natural direction 0: the log-prob direction evaluates the map directly at x
         assert np.abs(np.log(osl.moebius_deriv(xr, pars)).sum(axis=-1) - g["nd0/cond/inv_ld"]).max() < 1e-9
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-7), (torch.float32, 5e-3)])
+@pytest.mark.parametrize("inv", ["isigmoid", "inormal_partly_precise", "inormal_full_pade"])
+def test_solver_on_rough_mixtures_round_trip(dtype, tol, inv):
+    """the approach phase of cs_solve (csrc/jf_cond_regs.h) on mixtures it was not tuned on: per-row parameters with component widths from ~0.1
+    to ~10 and means spread over +-5 -- plateaus between narrow components, where a plain Newton iteration two-cycles around an inflection
+    (row 71 of tests/golden/amortized/fa_e1e2_hw4 did, in round 4) -- and base points out to +-6.  Property, independent of any fixture:
+    sampling then evaluating returns the base point and the log-det with the opposite sign (gaussianization_flow.py:911-989 vs 995-1114).
+    (Rougher still -- raw log-widths scaled by 2.5 .. 4: widths 0.01 .. 50 -- the REFERENCE's own unsafeguarded Newton stage stops converging
+    on up to 3 % of the rows, with the bisection of rounds 1-3 in front of it more often than with this approach phase: 1043 vs 576 of 30011.)"""
+    import jammy_flows_amd
+    from jammy_flows_amd import _hip
+    torch.manual_seed(11)
+    D, B = 3, 30011
+    pdf = jammy_flows_amd.pdf("e%d" % D, "gg", options_overwrite={"g": {"inverse_function_type": inv, "replace_first_sigmoid_with_icdf": 0}}).double().cuda()
+    layers = list(pdf.layer_list[0])
+    larr = _hip.gf_layer_array([l.c_struct() for l in layers])
+    n = sum(l.total_param_num for l in layers)
+    g = torch.Generator(device="cuda").manual_seed(7)
+    params = torch.randn((B, n), dtype=torch.float64, device="cuda", generator=g)
+    col = 0
+    for l in layers:                                            # (offset,) reflections, means, log-widths, log-weights: gaussianization_flow.py:63-215
+        c = l.c_struct()
+        col += (D if c.model_offset else 0) + c.hh_iter * D
+        kd = c.num_kde * D
+        params[:, col:col + kd] *= 2.0                          # means
+        params[:, col + kd:col + 2 * kd] *= 1.5                 # raw log-widths: widths ~0.1 .. ~10 after the regulator
+        params[:, col + 2 * kd:col + 3 * kd] *= 2.0             # raw log-weights
+        col += 3 * kd
+    z = torch.randn((B, D), dtype=torch.float64, device="cuda", generator=g) * 1.5
+    z[::97] *= 3.0                                              # tails out to ~ +-6
+    params, z = params.to(dtype), z.to(dtype)
+    status = _hip.new_status(z.device)
+    x, ld = _hip.gf_chain("fwd", z, None, params, larr, len(layers), D, status=status)
+    zb, ldb = _hip.gf_chain("inv", x, None, params, larr, len(layers), D)
+    words = status.cpu().tolist()
+    # a handful of rows end above the reference's convergence threshold in its own Newton stage (with the bisection of rounds 1-3 in front
+    # of it: 5-6 rows of these batches, with the approach phase 0-3); nothing may be non-finite, and every other row must round-trip
+    assert words[0] <= 6 and words[1] == 0, words
+    assert torch.isfinite(x).all()
+    err = ((zb - z).abs() / (1.0 + z.abs())).max(dim=1).values
+    lerr = (ld + ldb).abs() / (1.0 + ldb.abs())
+    keep = B - 8
+    assert err.sort().values[keep - 1].item() < tol, err.sort().values[keep - 1].item()
+    assert lerr.sort().values[keep - 1].item() < 50 * tol
