@@ -55,15 +55,19 @@ template <typename L> __device__ __forceinline__ int am_col(const L& o, int D, i
     return o.col0 + (sec == 0 ? o.off_mean : sec == 1 ? o.off_lw : o.off_ln) + k * D + d;
 }
 
-__device__ __forceinline__ double am_xsum(double v) {                    // sum over the 4 lane groups of a row (lanes 16 apart)
-    v += __shfl_xor(v, 16, 64);
-    v += __shfl_xor(v, 32, 64);
-    return v;
+// reductions over the 4 lane groups of a row (lanes l, l^16, l^32, l^48) on the permlane swaps of gfx950, both dwords of the double (inline asm
+// for the reason given at cs_rreduce, jf_cond_split.h).  Rounds 2-3 used __shfl_xor here: two ds_bpermute_b32 per step through the LDS pipe,
+// ~70 of them per row tile and layer chain.
+template <typename Op> __device__ __forceinline__ double am_xreduce(double v, Op op) {
+    unsigned a0 = (unsigned)__double2loint(v), a1 = (unsigned)__double2hiint(v), b0 = a0, b1 = a1;
+    asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3" : "+v"(a0), "+v"(b0), "+v"(a1), "+v"(b1));
+    const double c = op(__hiloint2double((int)a1, (int)a0), __hiloint2double((int)b1, (int)b0));
+    a0 = (unsigned)__double2loint(c); a1 = (unsigned)__double2hiint(c); b0 = a0; b1 = a1;
+    asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\tv_permlane32_swap_b32 %2, %3" : "+v"(a0), "+v"(b0), "+v"(a1), "+v"(b1));
+    return op(__hiloint2double((int)a1, (int)a0), __hiloint2double((int)b1, (int)b0));
 }
-__device__ __forceinline__ double am_xmax(double v) {
-    v = fmax(v, __shfl_xor(v, 16, 64));
-    return fmax(v, __shfl_xor(v, 32, 64));
-}
+__device__ __forceinline__ double am_xsum(double v) { return am_xreduce(v, [](double a, double b) { return a + b; }); }
+__device__ __forceinline__ double am_xmax(double v) { return am_xreduce(v, [](double a, double b) { return fmax(a, b); }); }
 
 // the MLP's own weights in fragment order + the rank-r2 vector t2 of the wave's 16 rows -- shared by the block kernel and the MLP-only kernel
 template <typename T> struct AmMlp {

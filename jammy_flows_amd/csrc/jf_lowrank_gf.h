@@ -212,16 +212,6 @@ template <typename L> __device__ __forceinline__ int lr_col(const L& o, int D, i
     return o.col0 + (reg == 0 ? o.off_mean : reg == 1 ? o.off_lw : o.off_ln) + k * D + d;
 }
 
-// sum over the 4 lane groups of a row (lanes l, l^16, l^32, l^48) on the permlane swaps of gfx950 (jf_cond_split.h: cs_rreduce), both dwords
-__device__ __forceinline__ double lr_xsum(double v) {
-    unsigned a0 = (unsigned)__double2loint(v), a1 = (unsigned)__double2hiint(v), b0 = a0, b1 = a1;
-    asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3" : "+v"(a0), "+v"(b0), "+v"(a1), "+v"(b1));
-    const double c = __hiloint2double((int)a1, (int)a0) + __hiloint2double((int)b1, (int)b0);
-    a0 = (unsigned)__double2loint(c); a1 = (unsigned)__double2hiint(c); b0 = a0; b1 = a1;
-    asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\tv_permlane32_swap_b32 %2, %3" : "+v"(a0), "+v"(b0), "+v"(a1), "+v"(b1));
-    return __hiloint2double((int)a1, (int)a0) + __hiloint2double((int)b1, (int)b0);
-}
-
 __global__ void __launch_bounds__(LR_NW * 64) lr_gf_bwd_layer_kernel(const LrBwdArgs<double> a) {
     using T = double;
     extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -336,7 +326,7 @@ __global__ void __launch_bounds__(LR_NW * 64) lr_gf_bwd_layer_kernel(const LrBwd
         for (int i = 0; i < o.hh; ++i) {
             const f64x4_t p = tile(i);
             const T va = p[0], vb = p[1];
-            const T n2 = lr_xsum(va * va + vb * vb), dot = lr_xsum(va * x0 + vb * x1);
+            const T n2 = am_xsum(va * va + vb * vb), dot = am_xsum(va * x0 + vb * x1);
             const T f = T(2) * dot * M<T>::rcp(n2);
             x0 -= f * va; x1 -= f * vb;
         }
@@ -478,7 +468,7 @@ __global__ void __launch_bounds__(LR_NW * 64) lr_gf_bwd_layer_kernel(const LrBwd
         for (int i = o.hh - 1; i >= 0; --i) {
             const f64x4_t p = tile(i);
             const T va = p[0], vb = p[1];
-            const T nn = lr_xsum(va * va + vb * vb), da = lr_xsum(va * x0 + vb * x1), vg = lr_xsum(va * g0 + vb * g1);
+            const T nn = am_xsum(va * va + vb * vb), da = am_xsum(va * x0 + vb * x1), vg = am_xsum(va * g0 + vb * g1);
             const T rn = M<T>::rcp(nn);
             x0 -= T(2) * da * rn * va; x1 -= T(2) * da * rn * vb;
             const T sx = -da;
@@ -498,7 +488,7 @@ __global__ void __launch_bounds__(LR_NW * 64) lr_gf_bwd_layer_kernel(const LrBwd
         if (w1) a.g_x[row * a.gxs + q + 4] = g1;
         {
             const bool badg = (w0 && !M<T>::finite(g0)) || (w1 && !M<T>::finite(g1));
-            const T bad = lr_xsum(badg ? T(1) : T(0));
+            const T bad = am_xsum(badg ? T(1) : T(0));
             status_add(a.status, JF_STATUS_NONFINITE, row_valid && q == 0 && bad > T(0));
         }
         if (row_valid) {
