@@ -544,7 +544,7 @@ template <typename T> static int64_t gf_lds_query(int32_t D, int32_t n_layers, c
 }  // namespace jf
 
 extern "C" {
-int jf_abi_version(void) { return 5; }
+int jf_abi_version(void) { return 6; }
 int64_t jf_gf_chain_lds_bytes_f32(int32_t D, int32_t n, const jf_gf_layer* L, int32_t pb1) { return jf::gf_lds_query<float>(D, n, L, pb1); }
 int64_t jf_gf_chain_lds_bytes_f64(int32_t D, int32_t n, const jf_gf_layer* L, int32_t pb1) { return jf::gf_lds_query<double>(D, n, L, pb1); }
 
