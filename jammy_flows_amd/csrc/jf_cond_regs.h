@@ -211,21 +211,6 @@ template <typename T> __device__ __forceinline__ void cs_mixture_lcls(const T (&
     }
 }
 
-// log Phi(-a) = log(erfc(a / sqrt 2) / 2), a >= 0: right-hand side of the log-space equation of the approach phase of cs_solve.  That phase only
-// has to land within ~1e-3 of the root (the Newton stage then solves the layer's own inverse-CDF equation), so float32 and a fractional
-// error of 1.2e-7 are plenty: erfc(x) = t exp(-x^2 + c0 + c1 t + .. + c9 t^9), t = 1 / (1 + x / 2) -- the Chebyshev fit of Numerical Recipes
-// ("erfcc", Press et al., section 6.2) -- taken in LOG space, where it needs no exponential and cannot underflow at any a: 1 reciprocal,
-// 1 logarithm, 12 FMAs (rounds 1-3: OCML erfc + log + log1p + two divisions, exact to an ulp).
-__device__ __forceinline__ float cs_log_ndtr_neg(float a) {
-    const float x = a * 0.70710678118654752440f;
-    const float t = M<float>::rcp(1.0f + 0.5f * x);
-    float p = 0.17087277f;
-    p = fmaf(p, t, -0.82215223f); p = fmaf(p, t, 1.48851587f); p = fmaf(p, t, -1.13520398f); p = fmaf(p, t, 0.27886807f);
-    p = fmaf(p, t, -0.18628806f); p = fmaf(p, t, 0.09678418f); p = fmaf(p, t, 0.37409196f); p = fmaf(p, t, 1.00002368f);
-    p = fmaf(p, t, -1.26551223f);
-    return M<float>::log_fast(t) - x * x + p - 0.69314718055994530942f;
-}
-
 // x with stage(mixture(x)) = z: an approach phase (below) + gfg_solve's Newton stage step for step (stopping rules, status counters); RSUM /
 // RMAX reduce over the lanes that hold the coordinates of one row.  P: DERIVED row (mean, 1 / width, normalised weight per component).
 // info (optional): the caller solves the coordinates of a row in more than one call (two coordinates per lane) and books the row's status
@@ -235,69 +220,15 @@ template <typename T, typename RSUM, typename RMAX>
 __device__ __forceinline__ T cs_solve(const T (&P)[CS_SLOTS], int inv_type, bool live, T z, bool row_valid, bool leader, int32_t* status,
                                       RSUM rsum, RMAX rmax, CsSolveInfo* info = nullptr) {
     using Mf = M<T>;
-    // ---- approach phase.  The reference brackets the root with 25 bisections of [-1e5, 1e5] (bisection_n_newton.py:11-72) before its Newton
-    // stage; rounds 1-3 restated that (~17 mixture evaluations per solve outside the far-midpoint skips -- 0.8 of the sampling kernels' time).
-    // Round 4: a SAFEGUARDED NEWTON iteration on the stage's equation in the space where it is nearly linear:
-    //   isigmoid stages     g(x) = log cdf - log sf - z            slope pdf / cdf + pdf / sf   (exactly linear for one component)
-    //   normal-type stages  g(x) = log cdf - log Phi(z)  (z <= 0)  slope pdf / cdf              (the side that does not cancel; linear in the
-    //                       g(x) = log Phi(-z) - log sf  (z > 0)   slope pdf / sf                tail the root of a small z lies in)
-    // g is increasing; where the mixture's cdf is log-concave a tangent's zero lands left of the root and the iterates then approach it
-    // monotonically and quadratically.  A proposal outside the bracket of the signs seen so far (flat stretches between distant components) is
-    // replaced by the bracket's midpoint, which keeps bisection's guarantee.  It starts at the mixture's mean and ends where the bisection
-    // ended: with the root inside a bracket of 6e-3 (a converging one-sided sequence closes it by stepping 4e-3 past its proposal once the
-    // steps are short) -- typically after 4-6 evaluations.  float64 rows run it in float32 (a float copy of the derived row), as they ran
-    // the bisection.  The Newton stage below is the reference's, unchanged.
+    // ---- approach phase (gf_approach, jf_gf.h): float64 rows run it in float32 on a float copy of the derived row, as they ran the bisection
     using F = typename std::conditional<sizeof(T) == 8, float, T>::type;
     F PF[CS_SLOTS];
 #pragma unroll
     for (int k = 0; k < CS_SLOTS; ++k) PF[k] = k < 3 * CS_K ? (F)P[k] : F(0);
-    const bool proxy = inv_type != JF_GF_ISIGMOID;
-    const bool neg = z <= T(0);
-    const F tz = proxy ? cs_log_ndtr_neg((float)Mf::abs(z)) : F(0);
-    const F zf = (F)z;
     F xf = F(0);
 #pragma unroll
     for (int k = 0; k < CS_K; ++k) xf += PF[CS_SLOT_LN + k] * PF[CS_SLOT_MEAN + k];           // the mixture's mean: cdf ~ 1/2
-    {
-        F blo = F(-1e5), bhi = F(1e5), dxold = F(2e5);
-        bool act = live;
-        for (int it = 0; it < 40 && __any(act); ++it) {
-            const MixQ<F> q = cs_mixture_derived<F>(PF, xf);
-            F g, sl;
-            if (proxy) {
-                g = neg ? q.lc - tz : tz - q.ls;
-                sl = M<F>::exp_fast(q.lp - (neg ? q.lc : q.ls));
-            } else {
-                g = q.lc - q.ls - zf;
-                sl = M<F>::exp_fast(q.lp - q.lc) + M<F>::exp_fast(q.lp - q.ls);
-            }
-            if (act) {
-                if (g < F(0)) blo = xf; else bhi = xf;
-                F xn = xf - g * M<F>::rcp(sl);
-                const bool inside = xn >= blo && xn <= bhi;                      // false also for a non-finite proposal
-                if (bhi - blo <= F(6e-3)) {                                      // the root is bracketed as tightly as the 25 bisections did: done
-                    xf = inside ? xn : F(0.5) * (blo + bhi);
-                    act = false;
-                } else {
-                    // Newton's classic two-cycle around an inflection (both proposals inside the bracket, which then shrinks by 1e-4 per
-                    // step): a step that is not at most half the one before it is replaced by the midpoint once both ends are known (rtsafe's rule)
-                    const bool slow = blo > F(-1e5) && bhi < F(1e5) && M<F>::abs(xn - xf) > F(0.5) * M<F>::abs(dxold);
-                    const F step = M<F>::abs(xn - xf);
-                    if (!inside || slow) xn = F(0.5) * (blo + bhi);
-                    // a short step that is also at most a quarter of the one before it is Newton's quadratic tail: the root is within step^2-ish
-                    else if (step < F(2e-3) && step <= F(0.25) * M<F>::abs(dxold)) act = false;
-                    // any other short step says "the root is here" only if g is as linear as its tangent: step 4e-3 PAST the proposal instead, so
-                    // that the next evaluation either closes the bracket around the root or shows that it lies further on
-                    else if (step < F(2e-3)) {
-                        const F over = xn + (xn >= xf ? F(4e-3) : F(-4e-3));
-                        xn = (over > blo && over < bhi) ? over : F(0.5) * (blo + bhi);
-                    }
-                    dxold = xn - xf;
-                    xf = xn;
-                }
-            }
-        }
-    }
+    xf = gf_approach<F>([&](F xx) { return cs_mixture_derived<F>(PF, xx); }, inv_type != JF_GF_ISIGMOID, (F)z, xf, live);
     T x = (T)xf;
     bool active = row_valid;
     T ferr = T(0), prev = T(INFINITY);

@@ -401,38 +401,86 @@ template <typename T, int G> __device__ __forceinline__ void gfg_derive(T* __res
     for (int i = g; i < o.hh; i += G) gf_derive_reflection<T>(row, o, D, i);
 }
 
+// log Phi(-a) = log(erfc(a / sqrt 2) / 2), a >= 0: right-hand side of the log-space equation of gf_approach.  That phase only
+// has to land within ~1e-3 of the root (the Newton stage then solves the layer's own inverse-CDF equation), so float32 and a fractional
+// error of 1.2e-7 are plenty: erfc(x) = t exp(-x^2 + c0 + c1 t + .. + c9 t^9), t = 1 / (1 + x / 2) -- the Chebyshev fit of Numerical Recipes
+// ("erfcc", Press et al., section 6.2) -- taken in LOG space, where it needs no exponential and cannot underflow at any a: 1 reciprocal,
+// 1 logarithm, 12 FMAs (rounds 1-3: OCML erfc + log + log1p + two divisions, exact to an ulp).
+__device__ __forceinline__ float gf_log_ndtr_neg(float a) {
+    const float x = a * 0.70710678118654752440f;
+    const float t = M<float>::rcp(1.0f + 0.5f * x);
+    float p = 0.17087277f;
+    p = fmaf(p, t, -0.82215223f); p = fmaf(p, t, 1.48851587f); p = fmaf(p, t, -1.13520398f); p = fmaf(p, t, 0.27886807f);
+    p = fmaf(p, t, -0.18628806f); p = fmaf(p, t, 0.09678418f); p = fmaf(p, t, 0.37409196f); p = fmaf(p, t, 1.00002368f);
+    p = fmaf(p, t, -1.26551223f);
+    return M<float>::log_fast(t) - x * x + p - 0.69314718055994530942f;
+}
+
+
+// ---- approach phase of the sampling solvers.  The reference brackets the root of stage(mixture(x)) = z with 25 bisections of [-1e5, 1e5]
+// (bisection_n_newton.py:11-72) before its Newton stage; rounds 1-3 restated that (~17 mixture evaluations per solve outside the far-midpoint
+// skips -- 0.8 of the sampling kernels' time).  Round 4: a SAFEGUARDED NEWTON iteration on the stage's equation in the space where it is nearly
+// linear:
+//   isigmoid stages     g(x) = log cdf - log sf - z            slope pdf / cdf + pdf / sf   (exactly linear for one component)
+//   normal-type stages  g(x) = log cdf - log Phi(z)  (z <= 0)  slope pdf / cdf              (the side that does not cancel; linear in the
+//                       g(x) = log Phi(-z) - log sf  (z > 0)   slope pdf / sf                tail the root of a small z lies in)
+// g is increasing; where the mixture's cdf is log-concave a tangent's zero lands left of the root and the iterates then approach it monotonically
+// and quadratically.  A proposal outside the bracket of the signs seen so far (flat stretches between distant components) is replaced by the
+// bracket's midpoint, which keeps bisection's guarantee; so is -- rtsafe's rule -- a step that is not at most half the one before it once both
+// ends are known (Newton's two-cycle around an inflection: both proposals inside a bracket that then shrinks by 1e-4 per step).  It ends where
+// the bisection ended: with the root inside a bracket of 6e-3, or on Newton's quadratic tail (a step below 2e-3 that is at most a quarter of the
+// one before it); any other short step says "the root is here" only if g is as linear as its tangent, so the iterate steps 4e-3 PAST the
+// proposal and the next evaluation either closes the bracket around the root or shows that it lies further on.  Typically 4-6 evaluations.
+// eval(x) -> MixQ<F> (log cdf, log sf, log pdf); x0: the mixture's mean.  The Newton stage after it is the reference's, unchanged.
+template <typename F, typename EVAL> __device__ __forceinline__ F gf_approach(EVAL eval, bool proxy, F z, F x0, bool live) {
+    const bool neg = z <= F(0);
+    const F tz = proxy ? (F)gf_log_ndtr_neg((float)M<F>::abs(z)) : F(0);
+    F xf = x0, blo = F(-1e5), bhi = F(1e5), dxold = F(2e5);
+    bool act = live;
+    for (int it = 0; it < 40 && __any(act); ++it) {
+        const MixQ<F> q = eval(xf);
+        F g, sl;
+        if (proxy) {
+            g = neg ? q.lc - tz : tz - q.ls;
+            sl = M<F>::exp_fast(q.lp - (neg ? q.lc : q.ls));
+        } else {
+            g = q.lc - q.ls - z;
+            sl = M<F>::exp_fast(q.lp - q.lc) + M<F>::exp_fast(q.lp - q.ls);
+        }
+        if (act) {
+            if (g < F(0)) blo = xf; else bhi = xf;
+            F xn = xf - g * M<F>::rcp(sl);
+            const bool inside = xn >= blo && xn <= bhi;                      // false also for a non-finite proposal
+            if (bhi - blo <= F(6e-3)) {                                      // the root is bracketed as tightly as the 25 bisections did: done
+                xf = inside ? xn : F(0.5) * (blo + bhi);
+                act = false;
+            } else {
+                const bool slow = blo > F(-1e5) && bhi < F(1e5) && M<F>::abs(xn - xf) > F(0.5) * M<F>::abs(dxold);
+                const F step = M<F>::abs(xn - xf);
+                if (!inside || slow) xn = F(0.5) * (blo + bhi);
+                else if (step < F(2e-3) && step <= F(0.25) * M<F>::abs(dxold)) act = false;
+                else if (step < F(2e-3)) {
+                    const F over = xn + (xn >= xf ? F(4e-3) : F(-4e-3));
+                    xn = (over > blo && over < bhi) ? over : F(0.5) * (blo + bhi);
+                }
+                dxold = xn - xf;
+                xf = xn;
+            }
+        }
+    }
+    return xf;
+}
+
 // ---------------------------------------------------------------------------------------------------------- sampling direction
-// bisection + Newton (layers/bisection_n_newton.py:11-135, called with 25 / 20 iterations on [-1e5, 1e5], :921) for one coordinate;
+// approach phase + the reference's Newton stage (layers/bisection_n_newton.py:11-135, called with 25 / 20 iterations on [-1e5, 1e5], :921) for
+// one coordinate;
 // the Newton stopping rule sums |update| over the row's coordinates (group butterfly), so the D lanes of a row stop together.
 template <typename T, int G> __device__ __forceinline__ T gfg_solve(const T* __restrict__ p, const GfLayerDev<T>& o, int D, bool live, T z,
                                                                      bool row_valid, bool leader, int32_t* status) {
-    T lo = T(-1e5), hi = T(1e5), x = T(0);
-    // The reference's bracket [-1e5, 1e5] makes the first ~10 midpoints lie hundreds of widths outside every component, where the outcome of
-    // the comparison is known without evaluating the mixture (and those evaluations are the expensive ones: deep-tail arithmetic): more than
-    // FAR widths beyond all components the stage value exceeds +-13 (normal variants: sqrt(2 (FAR - ln K ...)); sigmoid: ~FAR), so for
-    // |z| < 8 the midpoint is on the far side of the root and not within the 1e-6 relative stop.  Same decisions, same iterates, bit for bit;
-    // the evaluation is skipped only when EVERY lane of the wave is in that situation (the early midpoints are the same in all lanes).
-    constexpr T FAR = T(100);
-    T lo_b = T(INFINITY), hi_b = T(-INFINITY);
-    for (int k = 0; k < o.K; ++k) {
-        const T mu = p[o.off_mean + k * D], w = M<T>::rcp(p[o.off_lw + k * D]);      // derived rows hold 1 / width
-        lo_b = M<T>::min(lo_b, mu - FAR * w);
-        hi_b = M<T>::max(hi_b, mu + FAR * w);
-    }
-    const bool can_skip = M<T>::abs(z) < T(8);
-    for (int it = 0; it < 25; ++it) {
-        x = (hi + lo) * T(0.5);
-        const bool far_r = can_skip && x > hi_b, far_l = can_skip && x < lo_b;
-        if (__all(far_r || far_l)) {                       // wave-uniform
-            if (far_r) hi = x; else lo = x;
-            continue;
-        }
-        const T y = gf_icdf<T>(o.inv_type, gfg_mixture<T, false>(p, o, D, x)).y;
-        const bool ok = M<T>::abs(y - z) <= T(1e-6) * M<T>::abs(z);
-        if (ok) { lo = x; hi = x; }
-        else if (y < z) lo = x;
-        else hi = x;
-    }
+    // approach phase (gf_approach above) from the mixture's mean, on the derived row in LDS
+    T x = T(0);
+    for (int k = 0; k < o.K; ++k) x += (o.fit_norm ? p[o.off_ln + k * D] : T(1) / T(o.K)) * p[o.off_mean + k * D];
+    x = gf_approach<T>([&](T xx) { return gfg_mixture<T, false>(p, o, D, xx); }, o.inv_type != JF_GF_ISIGMOID, z, x, live);
     bool active = row_valid;
     T ferr = T(0), prev = T(INFINITY);
     bool nonfinite = false;
