@@ -268,6 +268,18 @@ int jf_amlp_gf_chain_fwd_f64(const double* in, int64_t in_stride, const double* 
                              const double* U2, const double* b2, int32_t K1, int32_t H, int32_t r1, int32_t r2, const double* z, int64_t z_stride,
                              const double* log_det_in, int64_t B, int32_t D, int32_t n_layers, const jf_gf_layer* layers, double* x_out,
                              int64_t x_out_stride, double* log_det_out, int32_t* status, void* stream);
+/* Training: the head of a two-stage low-rank AmortizableMLP -- t1 = V1 c, h = tanh(U1 t1 + b1), t2 = V2 h (amortizable_mlp.py:508-578: everything
+ * in front of the last stage's U product; V1 (r1, K1), U1 (H, r1), b1 (H), V2 (r2, H) dense row-major; K1 <= 32, H <= 128 and a multiple of 16,
+ * ranks <= 8, float64 -- else JF_ERR_UNSUPPORTED).  jf_lowrank_head_f64 writes t1 (B, 8), h (B, H) and t2 (B, 8) (columns >= the rank are zero)
+ * in one launch; jf_lowrank_head_bwd_f64 takes g_t2 (B rows, stride g_t2_stride) and returns g_V1, g_U1, g_b1, g_V2 (the shapes of the weights) and,
+ * when g_in is not NULL, g_in (B, K1) -- one launch + one reduction, nothing of size (B, H) written.  `workspace`: jf_lowrank_head_workspace_doubles. */
+int jf_lowrank_head_f64(const double* in, int64_t in_stride, const double* V1, const double* U1, const double* b1, const double* V2, int64_t B,
+                        int32_t K1, int32_t H, int32_t r1, int32_t r2, double* t1, double* h, double* t2, void* stream);
+int64_t jf_lowrank_head_workspace_doubles(int64_t B, int32_t K1, int32_t H);
+int jf_lowrank_head_bwd_f64(const double* in, int64_t in_stride, const double* V1, const double* U1, const double* V2, int64_t B, int32_t K1,
+                            int32_t H, int32_t r1, int32_t r2, const double* t1, const double* h, const double* g_t2, int64_t g_t2_stride,
+                            double* g_in, int64_t g_in_stride, double* g_V1, double* g_U1, double* g_b1, double* g_V2, double* workspace,
+                            void* stream);
 /* Training on a low-rank last MLP stage (float64, r2 <= 8, D <= 8, default layer options -- else JF_ERR_UNSUPPORTED): the chain of g layers on
  * the parameter rows U2 t2[row] + b2 (t2 (B, r2), U2 (N, r2), b2 (N): amortizable_mlp.py:508-578), the (B, N) block never materialised.
  * jf_lowrank_gf_chain_inv_f64: jf_gf_chain_inv's outputs; aux (nullable) receives (n_layers, 5, 2, B, 4) doubles -- every layer's input

@@ -203,6 +203,9 @@ _SIGNATURES_SINGLE = {
     "jf_lowrank_gf_chain_inv_f64": ([_P, _I64, _P, _P, _I32, _P, _I64, _P, _I64, _I32, _I32, ctypes.POINTER(jf_gf_layer), _P, _I64, _P, _P, _P, _P, _P, _P],
                                     ctypes.c_int),
     "jf_lowrank_gf_workspace_doubles": ([_I64, _I32], ctypes.c_int64),
+    "jf_lowrank_head_f64": ([_P, _I64, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _P, _P, _P, _P], ctypes.c_int),
+    "jf_lowrank_head_workspace_doubles": ([_I64, _I32, _I32], ctypes.c_int64),
+    "jf_lowrank_head_bwd_f64": ([_P, _I64, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _P, _P, _P, _I64, _P, _I64, _P, _P, _P, _P, _P, _P], ctypes.c_int),
     "jf_lowrank_gf_chain_inv_bwd_f64": ([_P, _I64, _P, _P, _I32, _P, _P, _I64, _I64, _I32, _I32, ctypes.POINTER(jf_gf_layer), _P, _I64, _P, _P, _P, _I64,
                                          _P, _P, _P, _P, _P, _P], ctypes.c_int),
     "jf_cond_gf_packed_bytes2": ([_I32, _I32, ctypes.POINTER(jf_gf_layer), _I32], ctypes.c_int64),
@@ -680,6 +683,45 @@ def amlp_gf_chain_inv(inp, v1, u1, b1, v2, u2, b2, x, log_det, layer_array, n_la
 
 LOWRANK_GF_MAX_RANK = 8
 LOWRANK_GF_AUX = 5
+
+
+def lowrank_head_ok(inp, v1, u1, b1, v2):
+    """shapes jf_lowrank_head_f64 takes: float64, low-rank first stage, K1 <= 32, hidden <= 128 and a multiple of 16, ranks <= 8"""
+    H = u1.shape[0]
+    return (inp.dtype == torch.float64 and v1 is not None and b1 is not None and inp.shape[1] <= 32 and 16 <= H <= 128 and H % 16 == 0
+            and v1.shape[0] <= LOWRANK_GF_MAX_RANK and v2.shape[0] <= LOWRANK_GF_MAX_RANK and inp.shape[0] > 0)
+
+
+def lowrank_head(inp, v1, u1, b1, v2):
+    """t1 = v1 c, h = tanh(u1 t1 + b1), t2 = v2 h in one launch -> (t2 (B, r2), t1 (B, 8), h (B, H)); None when the shapes are not supported"""
+    dev = require_device(inp, v1, u1, b1, v2)
+    inp = _rowmajor(inp)
+    v1, u1, b1, v2 = v1.contiguous(), u1.contiguous(), b1.contiguous(), v2.contiguous()
+    B, K1 = inp.shape
+    H, r1, r2 = u1.shape[0], v1.shape[0], v2.shape[0]
+    t1 = torch.empty((B, LOWRANK_GF_MAX_RANK), dtype=inp.dtype, device=inp.device)
+    h = torch.empty((B, H), dtype=inp.dtype, device=inp.device)
+    t2 = torch.empty((B, LOWRANK_GF_MAX_RANK), dtype=inp.dtype, device=inp.device)
+    ok = _launch("jf_lowrank_head_f64", "K%d_H%d_r%d_r%d" % (K1, H, r1, r2),
+                 (_ptr(inp), inp.stride(0), _ptr(v1), _ptr(u1), _ptr(b1), _ptr(v2), B, K1, H, r1, r2, _ptr(t1), _ptr(h), _ptr(t2)), dev, unsupported_ok=True)
+    return None if ok is False else (t2[:, :r2], t1, h)
+
+
+def lowrank_head_bwd(inp, v1, u1, v2, t1, h, g_t2, want_input_grad):
+    """adjoint of lowrank_head in one launch + one reduction -> (g_inp or None, g_v1, g_u1, g_b1, g_v2)"""
+    dev = require_device(inp, v1, u1, v2, t1, h, g_t2)
+    inp, g_t2 = _rowmajor(inp), _rowmajor(g_t2)
+    v1, u1, v2 = v1.contiguous(), u1.contiguous(), v2.contiguous()
+    B, K1 = inp.shape
+    H, r1, r2 = u1.shape[0], v1.shape[0], v2.shape[0]
+    g_inp = torch.empty((B, K1), dtype=inp.dtype, device=inp.device) if want_input_grad else None
+    g_v1, g_u1, g_v2 = torch.empty_like(v1), torch.empty_like(u1), torch.empty_like(v2)
+    g_b1 = torch.empty((H,), dtype=inp.dtype, device=inp.device)
+    work = torch.empty((int(lib().jf_lowrank_head_workspace_doubles(B, K1, H)),), dtype=inp.dtype, device=inp.device)
+    _launch("jf_lowrank_head_bwd_f64", "K%d_H%d_r%d_r%d" % (K1, H, r1, r2),
+            (_ptr(inp), inp.stride(0), _ptr(v1), _ptr(u1), _ptr(v2), B, K1, H, r1, r2, _ptr(t1), _ptr(h), _ptr(g_t2), g_t2.stride(0), _ptr(g_inp),
+             K1, _ptr(g_v1), _ptr(g_u1), _ptr(g_b1), _ptr(g_v2), _ptr(work)), dev)
+    return g_inp, g_v1, g_u1, g_b1, g_v2
 
 
 def lowrank_gf_chain_inv(t2, u2, b2, x, log_det, layer_array, n_layers, D, base_logp_in=None, want_base_logp=False, want_aux=False, status=None):

@@ -12,6 +12,8 @@ import math
 
 import numpy
 import torch
+import os
+
 from torch import nn
 
 from . import _hip, autograd
@@ -55,6 +57,8 @@ class AmortizableMLP(nn.Module):
         self.use_permanent_parameters = use_permanent_parameters
         self.nonlinearity = nonlinearity
         self.svd_mode = svd_mode
+        # gradient mode, float64, two low-rank stages: the head in one launch forward / backward (JF_LOWRANK_HEAD=0: the per-stage launches)
+        self.head_one_launch = os.environ.get("JF_LOWRANK_HEAD", "1") != "0"
         if len(precise_mlp_structure) > 0:
             # the caller hands in the sub-MLP table itself (amortizable_mlp.py:20, 56-62): per-matrix ranks, widths no `hidden_dims` string gives
             self._init_from_table(precise_mlp_structure)
@@ -262,6 +266,10 @@ class AmortizableMLP(nn.Module):
             return None
         _hip.require_device(i)
         flat = self.u_v_b_pars.to(dtype=i.dtype).reshape(-1)
+        views = self.lowrank_views(flat) if self.head_one_launch else None
+        if views is not None and _hip.lowrank_head_ok(i, *views[:4]):          # the whole head in one launch (csrc/jf_lowrank_mlp.h)
+            v1, u1, b1, v2, u2, b2 = views
+            return autograd.lowrank_head(i, v1, u1, b1, v2), u2, b2
         x, o = self._run(self.stages[:-1], i, flat, 0, False)
         u = flat[o:o + last["num_u"]].view(last["out"], last["rank"])
         v = flat[o + last["num_u"]:o + last["num_u"] + last["num_v"]].view(last["rank"], last["inp"])
@@ -282,9 +290,13 @@ class AmortizableMLP(nn.Module):
             assert self.use_permanent_parameters
             grad = autograd._needs_grad(i, self.u_v_b_pars)
             flat = self.u_v_b_pars.to(dtype=i.dtype).reshape(-1) if grad else self._flat(i)
-            views = None if grad else self.lowrank_views(flat)
-            if views is not None:                          # hidden-128 / rank-r MLP of the reference's custom mode: ONE launch (jf_amlp2)
+            views = self.lowrank_views(flat) if (not grad or self.head_one_launch) else None
+            if views is not None and not grad:             # hidden-128 / rank-r MLP of the reference's custom mode: ONE launch (jf_amlp2)
                 return _hip.amlp2(i, *views)
+            if views is not None and _hip.lowrank_head_ok(i, *views[:4]):
+                # gradient mode: the head (everything in front of the last U product) forward and backward in one launch each, then the last product
+                v1, u1, b1, v2, u2, b2 = views
+                return autograd.linear(autograd.lowrank_head(i, v1, u1, b1, v2), u2, b2, 0)
         prev = None
         if self.linear is not None:                            # its parameters are the LAST ones of the vector (:621-629)
             prev, _ = self._run(self.linear[0], i, flat, self.num_amortization_params - self.linear[1], per_sample)

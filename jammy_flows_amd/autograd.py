@@ -129,6 +129,27 @@ class GfChainInvFn(torch.autograd.Function):
         return (g_x, g_ld if ctx.has[0] else None, g_params, g_blp if ctx.has[1] else None, None, None, None, None)
 
 
+class LowRankHeadFn(torch.autograd.Function):
+    """t2 = V2 tanh(U1 (V1 c) + b1): the two-stage low-rank AmortizableMLP up to the input of its last U product (float64), forward and backward
+    one launch each (csrc/jf_lowrank_mlp.h) instead of three dense launches forward and eight dense / elementwise launches backward."""
+
+    @staticmethod
+    def forward(ctx, inp, v1, u1, b1, v2):
+        t2, t1, h = _hip.lowrank_head(inp.detach(), v1.detach(), u1.detach(), b1.detach(), v2.detach())
+        ctx.save_for_backward(inp, v1, u1, v2, t1, h)
+        return t2
+
+    @staticmethod
+    def backward(ctx, g_t2):
+        inp, v1, u1, v2, t1, h = ctx.saved_tensors
+        g_inp, g_v1, g_u1, g_b1, g_v2 = _hip.lowrank_head_bwd(inp, v1, u1, v2, t1, h, g_t2, ctx.needs_input_grad[0])
+        return g_inp, g_v1, g_u1, g_b1, g_v2
+
+
+def lowrank_head(inp, v1, u1, b1, v2):
+    return LowRankHeadFn.apply(inp, v1, u1, b1, v2)
+
+
 class LowRankGfChainFn(torch.autograd.Function):
     """chain of g layers on the rows u2 t2 + b2 of a low-rank last MLP stage (float64, rank <= 8), the (B, N) parameter block and its gradient
     never materialised: forward jf_lowrank_gf_chain_inv (keeps each layer's inputs and mixture sums, 320 bytes per row and layer), backward

@@ -111,6 +111,7 @@ template <typename T, int G> __device__ __forceinline__ T group_bcast(T v, int s
 }  // namespace jf
 #include "jf_amlp_mfma.h"      // the float64 matrix-core version of the same block (needs AgArgs / ag_mixture above)
 #include "jf_lowrank_gf.h"     // training: the chain on a low-rank last stage, forward with saved layer inputs + per-layer adjoint launches
+#include "jf_lowrank_mlp.h"    // training: the MLP in front of that stage, forward and backward in one launch each
 namespace jf {
 
 // RM: compiled rank bound (8 or 16): the rank loops are fully unrolled over it
@@ -407,9 +408,65 @@ static int lowrank_gf_chain_inv_bwd(const double* t2, int64_t t2s, const double*
     return check_launch();
 }
 
+static bool lrm_shape_ok(int32_t K1, int32_t H, int32_t r1, int32_t r2) {
+    return K1 >= 1 && K1 <= AG_K1MAX && H >= 16 && H <= AG_HMAX && H % 16 == 0 && r1 >= 1 && r1 <= AM_R && r2 >= 1 && r2 <= AM_R;
+}
+
+static int lowrank_head(const double* in, int64_t is, const double* V1, const double* U1, const double* b1, const double* V2, int64_t B, int32_t K1,
+                        int32_t H, int32_t r1, int32_t r2, double* t1, double* h, double* t2, void* stream) {
+    if (!in || !V1 || !U1 || !b1 || !V2 || !t1 || !h || !t2 || !rows_ok(B)) return JF_ERR_BADARG;
+    if (!lrm_shape_ok(K1, H, r1, r2)) return JF_ERR_UNSUPPORTED;
+    if (B == 0) return JF_OK;
+    LrmFwdArgs a{};
+    a.in = in; a.in_stride = is; a.V1 = V1; a.U1 = U1; a.b1 = b1; a.V2 = V2; a.K1 = K1; a.H = H; a.r1 = r1; a.r2 = r2; a.B = B;
+    a.t1 = t1; a.h = h; a.t2 = t2;
+    const size_t lds = am_lds_mlp(K1, H, true) * sizeof(double);
+    constexpr int ROWS = am_rows(AM_THREADS);
+    jf::launch(lrm_head_fwd_kernel, dim3((unsigned)((B + ROWS - 1) / ROWS)), dim3(AM_THREADS), lds, (hipStream_t)stream, a);
+    return check_launch();
+}
+
+static int lowrank_head_bwd(const double* in, int64_t is, const double* V1, const double* U1, const double* V2, int64_t B, int32_t K1, int32_t H,
+                            int32_t r1, int32_t r2, const double* t1, const double* h, const double* g_t2, int64_t gs, double* g_c, int64_t gcs,
+                            double* g_V1, double* g_U1, double* g_b1, double* g_V2, double* workspace, void* stream) {
+    if (!in || !V1 || !U1 || !V2 || !t1 || !h || !g_t2 || !g_V1 || !g_U1 || !g_b1 || !g_V2 || !workspace || !rows_ok(B) || B < 1) return JF_ERR_BADARG;
+    if (!lrm_shape_ok(K1, H, r1, r2)) return JF_ERR_UNSUPPORTED;
+    const int KT = (K1 + 15) / 16, psz = lrm_psz(H, KT), n_wg = lrm_n_wg(B);
+    LrmBwdArgs a{};
+    a.in = in; a.in_stride = is; a.V1 = V1; a.U1 = U1; a.V2 = V2; a.K1 = K1; a.H = H; a.r1 = r1; a.r2 = r2; a.B = B; a.n_row_tiles = (B + 15) / 16;
+    a.t1 = t1; a.h = h; a.g_t2 = g_t2; a.gs = gs; a.g_c = g_c; a.gcs = gcs; a.partial = workspace;
+    const size_t lds = ((size_t)(H / 16) * 2 * 64 + (size_t)(H / 4) * 64 + (size_t)KT * 2 * 64 + psz + (size_t)LRM_NW * 2 * 16 * 17) * sizeof(double);
+    static LdsAttrOnce attr1, attr2;
+    if (KT == 1) {
+        attr1.set((const void*)lrm_head_bwd_kernel<1>, (int)lds);
+        jf::launch(lrm_head_bwd_kernel<1>, dim3((unsigned)n_wg), dim3(LRM_NW * 64), lds, (hipStream_t)stream, a);
+    } else {
+        attr2.set((const void*)lrm_head_bwd_kernel<2>, (int)lds);
+        jf::launch(lrm_head_bwd_kernel<2>, dim3((unsigned)n_wg), dim3(LRM_NW * 64), lds, (hipStream_t)stream, a);
+    }
+    LrmReduceArgs red{};
+    red.partial = workspace; red.n_wg = n_wg; red.H = H; red.K1 = K1; red.r1 = r1; red.r2 = r2;
+    red.g_V1 = g_V1; red.g_U1 = g_U1; red.g_b1 = g_b1; red.g_V2 = g_V2;
+    jf::launch(lrm_reduce_kernel, dim3((unsigned)((psz + 63) / 64)), dim3(256), 0, (hipStream_t)stream, red);
+    return check_launch();
+}
+
 }  // namespace jf
 
 extern "C" {
+int jf_lowrank_head_f64(const double* in, int64_t is, const double* V1, const double* U1, const double* b1, const double* V2, int64_t B, int32_t K1,
+                        int32_t H, int32_t r1, int32_t r2, double* t1, double* h, double* t2, void* s) {
+    return jf::lowrank_head(in, is, V1, U1, b1, V2, B, K1, H, r1, r2, t1, h, t2, s);
+}
+int64_t jf_lowrank_head_workspace_doubles(int64_t B, int32_t K1, int32_t H) {
+    if (B < 1 || K1 < 1 || K1 > jf::AG_K1MAX || H < 16 || H > jf::AG_HMAX) return 0;
+    return (int64_t)jf::lrm_n_wg(B) * jf::lrm_psz(H, (K1 + 15) / 16);
+}
+int jf_lowrank_head_bwd_f64(const double* in, int64_t is, const double* V1, const double* U1, const double* V2, int64_t B, int32_t K1, int32_t H,
+                            int32_t r1, int32_t r2, const double* t1, const double* h, const double* g_t2, int64_t gs, double* g_c, int64_t gcs,
+                            double* g_V1, double* g_U1, double* g_b1, double* g_V2, double* workspace, void* s) {
+    return jf::lowrank_head_bwd(in, is, V1, U1, V2, B, K1, H, r1, r2, t1, h, g_t2, gs, g_c, gcs, g_V1, g_U1, g_b1, g_V2, workspace, s);
+}
 int jf_lowrank_gf_chain_inv_f64(const double* t2, int64_t t2s, const double* U2, const double* b2, int32_t r2, const double* x, int64_t xs,
                                 const double* ld_in, int64_t B, int32_t D, int32_t n, const jf_gf_layer* L, double* xo, int64_t xos, double* ldo,
                                 const double* bi, double* bo, double* aux, int32_t* st, void* s) {

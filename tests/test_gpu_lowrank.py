@@ -26,6 +26,9 @@ def _pdf(D, flow, rank, cond=6, hidden=64, **opts):
 
 def _grads(pdf, x, c, flag):
     pdf.lowrank_chain_training = flag
+    for m in pdf.mlp_predictors:                               # flag False: round 3's sequence throughout (per-stage MLP launches too)
+        if hasattr(m, "head_one_launch"):
+            m.head_one_launch = flag
     for p in pdf.parameters():
         p.grad = None
     xs = x.clone().requires_grad_(True)
@@ -85,6 +88,43 @@ def test_lowrank_chain_dimensions_ranks_and_layer_options(D, flow, rank, opts):
     b, _ = _grads(pdf, x, c, False)
     assert "jf_lowrank_gf_chain_inv_bwd_f64" in names_a, names_a
     _compare(a, b, 2e-11)
+
+
+@pytest.mark.parametrize("K1,H,r1,r2,N,B", [(16, 128, 8, 8, 1224, 4099), (24, 128, 8, 8, 50, 777), (1, 16, 1, 1, 3, 1), (6, 64, 4, 3, 40, 17), (32, 128, 8, 5, 64, 130),
+                                            (17, 48, 2, 8, 9, 33), (9, 112, 7, 7, 300, 16)])
+def test_lowrank_head_equals_the_stage_sequence(K1, H, r1, r2, N, B):
+    """AmortizableMLP in gradient mode: head in one launch forward / backward (jf_lowrank_head[_bwd]_f64, csrc/jf_lowrank_mlp.h) against the
+    per-stage launches -- output, gradient of the input and of every weight; ragged batches, 1..32 inputs, 16..128 hidden units, ranks 1..8"""
+    from jammy_flows_amd.amortizable_mlp import AmortizableMLP
+    torch.manual_seed(K1 * 1000 + H)
+    mlp = AmortizableMLP(K1, str(H), N, low_rank_approximations=[r1, r2], use_permanent_parameters=True).double().cuda()
+    with torch.no_grad():
+        mlp.u_v_b_pars.add_(0.2 * torch.randn_like(mlp.u_v_b_pars))
+    s1, s2 = mlp.stages
+    if s1["full"] or s2["full"]:
+        pytest.skip("the rank is not smaller than the full matrix: stage stored full (amortizable_mlp.py:272-375)")
+    x = torch.randn(B, K1, dtype=torch.float64, device="cuda")
+    w = torch.randn(B, N, dtype=torch.float64, device="cuda")
+    res = {}
+    for flag in (True, False):
+        mlp.head_one_launch = flag
+        mlp.u_v_b_pars.grad = None
+        xs = x.clone().requires_grad_(True)
+        timer = _hip.KernelTimer()
+        with torch.enable_grad(), timer:
+            out = mlp(xs)
+            (out * w).sum().backward()
+        res[flag] = (out.detach(), xs.grad, mlp.u_v_b_pars.grad.clone(), {k[0] for k in timer.summary()})
+    assert "jf_lowrank_head_f64" in res[True][3] and "jf_lowrank_head_bwd_f64" in res[True][3], res[True][3]
+    assert not any("lowrank_head" in n for n in res[False][3])
+    for a, b in zip(res[True][:3], res[False][:3]):
+        assert (a - b).abs().max().item() <= 2e-12 * max(1.0, b.abs().max().item()), (a - b).abs().max().item()
+    # the input needs no gradient: same weight gradients, no g_c written
+    mlp.head_one_launch = True
+    mlp.u_v_b_pars.grad = None
+    with torch.enable_grad():
+        (mlp(x) * w).sum().backward()
+    assert (mlp.u_v_b_pars.grad - res[False][2]).abs().max().item() <= 2e-12 * max(1.0, res[False][2].abs().max().item())
 
 
 def test_rows_in_the_far_tails_take_the_log_space_adjoint():
