@@ -686,6 +686,28 @@ def rows_sweep(pdf, x, c, steps=50):
     return out
 
 
+def other_directions_summary(workload):
+    """`bench.py --train` and `bench.py --direction sample` of the same configuration as child processes (fresh GPU contexts, started after this
+    process's timed region; nothing re-execs): their ms per step, rate and parity, compact."""
+    out = {}
+    for key, flags in (("train", ["--train"]), ("sample", ["--direction", "sample"])):
+        cmd = [sys.executable, os.path.abspath(__file__), "--workload", workload, "--scaling", "weak", "--no-cpu-baseline", "--no-pmc", "--steps", "20",
+               "--warmup", "5"] + flags
+        try:
+            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+            d = json.loads(r.stdout.decode().strip().splitlines()[-1])
+            par = d.get("parity") or {}
+            out[key] = {"ms_per_step": round(d["ms_per_step"], 4), "value": d["value"], "unit": d["unit"], "rows": d["config"]["total_rows"], "dtype": d["dtype"],
+                        "parity": {k: par[k] for k in ("max_rel_gradient_err", "adam_10_steps_max_loss_dev", "max_abs_dx_vs_f64_oracle",
+                                                       "max_abs_dlogp_vs_f64_oracle") if k in par},
+                        "command": "python bench.py --workload %s %s" % (workload, " ".join(flags))}
+            if d.get("optimizer"):
+                out[key]["optimizer"] = d["optimizer"]
+        except Exception as e:                                 # noqa: BLE001 -- reported, never hidden
+            out[key] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+    return out
+
+
 def side_config(key, dev, steps=20):
     """one of the other BASELINE configurations, measured after the timed region on rank 0: step time through a recorded plan, parity against
     the float64 oracle on 2048 rows, the roof fraction on that configuration's own accounting."""
@@ -1116,6 +1138,10 @@ def main():
                 except Exception as e:                     # noqa: BLE001 -- reported, never hidden
                     table[key] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
             line["configs"] = table
+        if rank == 0 and world == 1 and not args.no_sweep and args.workload in ("c3", "c5"):
+            # the other two directions of this configuration (training step, sampling step): child runs of this script after the timed region,
+            # so that the driver's record of the default command carries them too (their own lines: --train / --direction sample)
+            line["other_directions"] = other_directions_summary(args.workload)
         if graph_replay is not None:
             line["hip_graph_replay"] = graph_replay
         if two_launch is not None:
