@@ -173,8 +173,8 @@ class LowRankGfChainFn(torch.autograd.Function):
     def backward(ctx, g_xout, g_ld, g_blp):
         t2, u2, b2, z = ctx.saved_tensors
         layer_array, n_layers, D = ctx.meta
+        # (ctx.aux stays: differentiable sampling runs several backward passes through the same graph, main/default.py: _differentiable_sample)
         g_x, g_t2, g_u2, g_b2 = _hip.lowrank_gf_chain_inv_bwd(t2, u2, b2, ctx.aux, z, layer_array, n_layers, D, g_xout, g_ld, g_blp)
-        ctx.aux = None
         return (g_t2, g_u2, g_b2, g_x, g_ld if ctx.has[0] else None, g_blp if ctx.has[1] else None, None, None, None, None)
 
 

@@ -198,6 +198,29 @@ def test_entry_points_directly_strided_inputs_and_argument_checks():
         _hip.lowrank_gf_chain_inv(t2.float(), u2, b2, x, None, larr, 2, 8)
 
 
+def test_differentiable_sampling_through_the_lowrank_chain():
+    """pdf.sample(allow_gradients=True) on the C5 configuration: _differentiable_sample runs D + 1 backward passes through ONE graph that contains
+    LowRankGfChainFn and LowRankHeadFn (retain_graph) -- the saved layer inputs must survive them; gradients equal the block sequence's"""
+    import fixture_io
+    import helpers
+    fx = fixture_io.load("c5_e8s2_ggggv")
+    res = {}
+    for flag in (True, False):
+        pdf = helpers.build_product(fx, torch.float64)
+        pdf.lowrank_chain_training = flag
+        for m in pdf.mlp_predictors:
+            if hasattr(m, "head_one_launch"):
+                m.head_one_launch = flag
+        c = torch.from_numpy(fx["cond"][:64]).cuda().requires_grad_(True)
+        z = torch.from_numpy(fx["z"][:64]).cuda()
+        with torch.enable_grad():
+            x, _, logp, _ = pdf._differentiable_sample(conditional_input=c, predefined_target_input=z)
+            loss = (x * torch.linspace(-1.0, 1.0, x.shape[1], dtype=x.dtype, device=x.device)).sum() + 0.1 * logp.sum()
+        loss.backward()
+        res[flag] = {"x": x.detach(), "c": c.grad.clone(), **{k: p.grad.clone() for k, p in pdf.named_parameters() if p.grad is not None}}
+    _compare(res[True], res[False], 1e-9)
+
+
 def test_full_size_training_step_c5():
     """2^17 rows of the C5 configuration (the bench's --train --workload c5 batch): loss and every gradient of the two paths agree; the gradient of
     the weights is the sum over 131072 rows -- tolerance relative to each tensor's largest entry"""
