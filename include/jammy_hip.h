@@ -104,6 +104,17 @@ int jf_gf_chain_inv_f64(const double* x, int64_t x_stride, const double* log_det
 
 /* sampling direction: layers applied in order 0..n-1; each solves its mixture-CDF map by 25 bisection steps on [-1e5,1e5]
  * + <= 20 Newton steps (row stops when sum_d |update| < 1e-14).  log_det_out = log_det_in - sum log-derivatives. */
+/* Co-vector transport through the log-prob direction (ABI v6): cot_out = J^{-T} cot_in with J = d x_out / d x the chain's Jacobian at x -- per
+ * layer the same reflections as x and a division by the stage's derivative.  What the implicit-function adjoint of SAMPLING needs: the
+ * gradient of a loss on samples x*(theta) is -(dF/dtheta)^T lambda with J^T lambda = g (bisection_n_newton.py:74-93 differentiates through the
+ * Newton iterations instead).  x_out / log_det_out receive the chain's values.  Default-option layers and rq_splines stretch; layers with the
+ * general options (jf_gf_ext.h) return JF_ERR_UNSUPPORTED. */
+int jf_gf_chain_inv_cot_f32(const float* x, int64_t x_stride, const float* params, int64_t param_stride, int32_t param_batch, int64_t B, int32_t D,
+                            int32_t n_layers, const jf_gf_layer* layers, const float* cot_in, int64_t cot_in_stride, float* cot_out,
+                            int64_t cot_out_stride, float* x_out, int64_t x_out_stride, float* log_det_out, void* stream);
+int jf_gf_chain_inv_cot_f64(const double* x, int64_t x_stride, const double* params, int64_t param_stride, int32_t param_batch, int64_t B, int32_t D,
+                            int32_t n_layers, const jf_gf_layer* layers, const double* cot_in, int64_t cot_in_stride, double* cot_out,
+                            int64_t cot_out_stride, double* x_out, int64_t x_out_stride, double* log_det_out, void* stream);
 int jf_gf_chain_fwd_f32(const float* z, int64_t z_stride, const float* log_det_in, const float* params, int64_t param_stride,
                         int32_t param_batch, int64_t B, int32_t D, int32_t n_layers, const jf_gf_layer* layers, float* x_out,
                         int64_t x_out_stride, float* log_det_out, int64_t* bins, int64_t bins_stride, int32_t* status, void* stream);

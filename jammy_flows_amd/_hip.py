@@ -135,6 +135,7 @@ _SIGNATURES = {
     "jf_activation": [_P, _I64, _I32, _P, _P],
     "jf_device_math": [_P, _I64, _I32, _P, _P],
     "jf_add_rows": [_P, _P, _I64, _P, _P],
+    "jf_gf_chain_inv_cot": [_P, _I64, _P, _I64, _I32, _I64, _I32, _I32, ctypes.POINTER(jf_gf_layer), _P, _I64, _P, _I64, _P, _I64, _P, _P],
     "jf_adam_step": [ctypes.POINTER(jf_adam_tensor), _I32, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, _I64, _P],
     "jf_combine_rows": [ctypes.POINTER(jf_row_list), ctypes.POINTER(jf_row_list), _I64, _P, _P, _P, _P],
     "jf_activation_bwd": [_P, _P, _I64, _I32, _P, _P],
@@ -588,6 +589,25 @@ def gf_chain(direction, x, log_det, params, layer_array, n_layers, D, x_out=None
             (_ptr(x), x.stride(0), _ptr(log_det), _ptr(params), params.stride(0), pb, B, D, n_layers, layer_array, _ptr(x_out), x_out.stride(0),
              _ptr(ld_out), _ptr(bins), bs, _ptr(status)), dev)
     return x_out, ld_out
+
+
+def gf_chain_inv_cot(x, params, layer_array, n_layers, D, cot):
+    """J^{-T} cot for the Jacobian J of gf_chain('inv', x, ...) at x (the co-vector carried through the layers: jf_gf_chain_inv_cot); None for layers
+    with the general options (the caller then solves with a dense Jacobian)"""
+    dev = require_device(x, params, cot)
+    x, params, cot = _rowmajor(x), _rowmajor(params), _rowmajor(cot)
+    B = x.shape[0]
+    if params.dtype != x.dtype or cot.dtype != x.dtype or cot.shape != (B, D) or x.shape != (B, D) or params.shape[0] not in (1, B):
+        raise ValueError("gf_chain_inv_cot: inconsistent shapes / dtypes")
+    out = torch.empty((B, D), dtype=x.dtype, device=x.device)
+    if B == 0:
+        return out
+    x_out = torch.empty((B, D), dtype=x.dtype, device=x.device)
+    ld_out = torch.empty((B,), dtype=x.dtype, device=x.device)
+    ok = _launch("jf_gf_chain_inv_cot" + _suffix(x), "bcast" if params.shape[0] == 1 else "per-sample",
+                 (_ptr(x), x.stride(0), _ptr(params), params.stride(0), 1 if params.shape[0] == 1 else B, B, D, n_layers, layer_array, _ptr(cot),
+                  cot.stride(0), _ptr(out), out.stride(0), _ptr(x_out), x_out.stride(0), _ptr(ld_out)), dev, unsupported_ok=True)
+    return out if ok is not False else None
 
 
 def gf_chain_inv_bwd(x, params, layer_array, n_layers, D, g_xout, g_ld, g_blp, status=None):

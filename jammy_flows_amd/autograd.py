@@ -129,6 +129,44 @@ class GfChainInvFn(torch.autograd.Function):
         return (g_x, g_ld if ctx.has[0] else None, g_params, g_blp if ctx.has[1] else None, None, None, None, None)
 
 
+class InverseJacobianFn(torch.autograd.Function):
+    """delta = J^-1 r for the Jacobian J = dy/dx of the log-prob direction at a SOLUTION of y(x) = z (r = y - z: zero to solver precision, so the
+    forward returns zeros); what matters is the backward, lambda = J^-T g -- the adjoint of sampling by the implicit-function theorem
+    (the reference differentiates through its Newton iterations instead, bisection_n_newton.py:74-93).  J is block lower triangular over the
+    autoregressive sub-pdfs (block j sees the earlier blocks' coordinates through its conditioning MLP), J^T block upper triangular:
+
+        for block j = last .. first:   lambda_j = J_jj^-T (g_j - sum_{k > j} (dy_k / dx_j)^T lambda_k)
+
+    J_jj^-T v: one co-vector launch through the block's g layers (blocks[j]["cot"]), or -- manifold / 't' blocks of 1-3 dimensions -- the dense
+    (B, d, d) block from d vector-Jacobian products; the coupling sum is the x-gradient of ONE input-gradient pass through block k with
+    upstream lambda_k.  Autograd then continues into the graph of y with lambda: the parameter gradients need no further work here."""
+
+    @staticmethod
+    def forward(ctx, r, x0, blocks):
+        ctx.x0, ctx.blocks = x0, blocks
+        return torch.zeros_like(r)
+
+    @staticmethod
+    def backward(ctx, g):
+        x0, blocks = ctx.x0, ctx.blocks
+        rhs = g.clone()
+        lam = torch.empty_like(g)
+        with torch.enable_grad():
+            for blk in reversed(blocks):
+                a, b, y = blk["a"], blk["b"], blk["y"]
+                v = rhs[:, a:b].contiguous()
+                lj = blk["cot"](v) if blk["cot"] is not None else None
+                if lj is None:
+                    rows = [torch.autograd.grad(y[:, k].sum(), x0, retain_graph=True)[0][:, a:b] for k in range(b - a)]
+                    J = torch.stack(rows, dim=1)                                       # J[n, k, i] = d y_k / d x_i inside the block
+                    lj = torch.linalg.solve(J.transpose(1, 2), v.unsqueeze(-1)).squeeze(-1)
+                lam[:, a:b] = lj
+                if blk["coupled"] and a > 0:
+                    (gx,) = torch.autograd.grad(y, x0, grad_outputs=lj, retain_graph=True)
+                    rhs[:, :a] -= gx[:, :a]
+        return lam, None, None
+
+
 class LowRankHeadFn(torch.autograd.Function):
     """t2 = V2 tanh(U1 (V1 c) + b1): the two-stage low-rank AmortizableMLP up to the input of its last U product (float64), forward and backward
     one launch each (csrc/jf_lowrank_mlp.h) instead of three dense launches forward and eight dense / elementwise launches backward."""

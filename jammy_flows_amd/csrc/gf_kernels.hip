@@ -36,6 +36,10 @@ template <typename T> struct GfChainArgs {
     const T* blp_in; T* blp_out;
     int64_t* bins; int64_t bins_stride;
     int32_t* status;
+    // log-prob direction only: a co-vector carried along with x -- v <- J_l^{-T} v per layer (J_l = diag(dy/dx) Q_l^T: the same reflections as x,
+    // then a division by the stage's derivative), i.e. cot_out = J^{-T} cot_in for the chain's Jacobian J = dy/dx (jf_gf_chain_inv_cot)
+    const T* cot_in; int64_t cis;
+    T* cot_out; int64_t cos;
 };
 
 template <int G> struct Log2 { static constexpr int v = (G == 1) ? 0 : (G == 2) ? 1 : (G == 4) ? 2 : (G == 8) ? 3 : (G == 16) ? 4 : 5; };
@@ -82,6 +86,8 @@ __global__ void __launch_bounds__(BCAST ? 256 : 64, sizeof(T) == 8 ? 2 : 4) gf_c
 
         T x = a.x[rrow * a.xs + d];
         T ld = a.ld_in ? a.ld_in[rrow] : T(0);
+        T cv = T(0);
+        if constexpr (!FWD) { if (a.cot_in) cv = live ? a.cot_in[rrow * a.cis + d] : T(0); }
 
         int spline_calls = 0;
         for (int li = 0; li < a.n_layers; ++li) {
@@ -110,11 +116,13 @@ __global__ void __launch_bounds__(BCAST ? 256 : 64, sizeof(T) == 8 ? 2 : 4) gf_c
                 if constexpr (!FWD) {
                     if (o.model_offset) x -= p[0];
                     x = gfg_rotate_inv<T, G, !BCAST>(p, o, D, live, x);
+                    if (a.cot_in) cv = gfg_rotate_inv<T, G, !BCAST>(p, o, D, live, cv);
                 }
                 const SplineOut<T> r = spline_linext<T>(pr + o.off_mean + d * o.K, pr + o.off_lw + d * o.K, pr + o.off_ln + d * (o.K + 1),
                                                         pr + o.off_box + d * 4, o.K, tab, x, FWD);
                 x = r.y;
                 ld += group_sum<T, G>(live ? r.lad : T(0));
+                if constexpr (!FWD) { if (a.cot_in) cv *= M<T>::exp(-r.lad); }
                 if (a.bins != nullptr && row_valid && live) a.bins[row * a.bins_stride + spline_calls * D + d] = (int64_t)r.bin;
                 ++spline_calls;
                 if constexpr (FWD) {
@@ -128,6 +136,7 @@ __global__ void __launch_bounds__(BCAST ? 256 : 64, sizeof(T) == 8 ? 2 : 4) gf_c
                 const IcdfOut<T> s = gf_icdf<T>(o.inv_type, q);
                 x = s.y;
                 ld += group_sum<T, G>(live ? s.logd : T(0));
+                if (a.cot_in) cv = gfg_rotate_inv<T, G, !BCAST>(p, o, D, live, cv) * M<T>::exp(-s.logd);
             } else {
                 if (o.K == CS_K && o.fit_norm) {
                     // ten components (the reference's default): the lane's derived column -- mean, 1 / width, weight of every component -- goes
@@ -154,6 +163,7 @@ __global__ void __launch_bounds__(BCAST ? 256 : 64, sizeof(T) == 8 ? 2 : 4) gf_c
         }
         if (row_valid && live) a.x_out[row * a.xos + d] = x;
         if constexpr (!FWD) {
+            if (a.cot_out && row_valid && live) a.cot_out[row * a.cos + d] = cv;
             T s = T(0);
             if (a.blp_out) s = group_sum<T, G>(live ? T(-0.5) * x * x - M<T>::HALF_LN_2PI : T(0));
             if (row_valid && leader) {
@@ -463,7 +473,7 @@ template <typename T, int D> static int launch_rows(GfChainArgs<T> a, size_t lds
 template <typename T, bool FWD> static int launch(const GfChainArgs<T>& a, int D, bool bcast, bool ext, size_t lds_bytes, hipStream_t st) {
     if (a.B == 0) return JF_OK;
     if constexpr (!FWD) {
-        bool classic = bcast && !ext;
+        bool classic = bcast && !ext && a.cot_in == nullptr;       // (the lane = row kernel does not carry the co-vector)
         int pack_elems = 0;
         for (int l = 0; l < a.n_layers; ++l) {
             classic = classic && a.L[l].stretch == JF_GF_STRETCH_CLASSIC;
@@ -490,6 +500,7 @@ template <typename T, bool FWD> static int launch(const GfChainArgs<T>& a, int D
             }
         }
     }
+    if (ext && a.cot_in != nullptr) return JF_ERR_UNSUPPORTED;
     if (ext) {
         auto k = gfx_chain_kernel<T, FWD>;
         if (lds_bytes > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
@@ -517,6 +528,20 @@ static int gf_chain_inv(const T* x, int64_t xs, const T* ld_in, const T* params,
     if (rc != JF_OK) return rc;
     a.x = x; a.xs = xs; a.ld_in = ld_in; a.x_out = x_out; a.xos = xos; a.ld_out = ld_out; a.blp_in = blp_in; a.blp_out = blp_out; a.status = status;
     a.bins = bins; a.bins_stride = bins_stride;
+    return launch<T, false>(a, D, bcast, ext, lds, (hipStream_t)stream);
+}
+// J^{-T} cot for the Jacobian J = d x_out / d x of the log-prob direction (the chain is evaluated along the way: x_out, ld_out are scratch outputs)
+template <typename T>
+static int gf_chain_inv_cot(const T* x, int64_t xs, const T* params, int64_t ps, int32_t pb, int64_t B, int32_t D, int32_t n_layers,
+                            const jf_gf_layer* layers, const T* cot_in, int64_t cis, T* cot_out, int64_t cos, T* x_out, int64_t xos, T* ld_out,
+                            void* stream) {
+    if (!x || !params || !x_out || !ld_out || !cot_in || !cot_out) return JF_ERR_BADARG;
+    GfChainArgs<T> a{};
+    size_t lds = 0; bool bcast = false, ext = false;
+    int rc = fill_args<T>(a, params, ps, pb, B, D, n_layers, layers, lds, bcast, ext);
+    if (rc != JF_OK) return rc;
+    a.x = x; a.xs = xs; a.x_out = x_out; a.xos = xos; a.ld_out = ld_out;
+    a.cot_in = cot_in; a.cis = cis; a.cot_out = cot_out; a.cos = cos;
     return launch<T, false>(a, D, bcast, ext, lds, (hipStream_t)stream);
 }
 template <typename T>
@@ -557,6 +582,14 @@ int jf_gf_chain_inv_f64(const double* x, int64_t xs, const double* ld_in, const 
                         const jf_gf_layer* L, double* xo, int64_t xos, double* ldo, const double* bi, double* bo, int64_t* bins, int64_t bs,
                         int32_t* st, void* s) {
     return jf::gf_chain_inv<double>(x, xs, ld_in, p, ps, pb, B, D, n, L, xo, xos, ldo, bi, bo, bins, bs, st, s);
+}
+int jf_gf_chain_inv_cot_f32(const float* x, int64_t xs, const float* p, int64_t ps, int32_t pb, int64_t B, int32_t D, int32_t n, const jf_gf_layer* L,
+                            const float* ci, int64_t cis, float* co, int64_t cos, float* xo, int64_t xos, float* ldo, void* s) {
+    return jf::gf_chain_inv_cot<float>(x, xs, p, ps, pb, B, D, n, L, ci, cis, co, cos, xo, xos, ldo, s);
+}
+int jf_gf_chain_inv_cot_f64(const double* x, int64_t xs, const double* p, int64_t ps, int32_t pb, int64_t B, int32_t D, int32_t n, const jf_gf_layer* L,
+                            const double* ci, int64_t cis, double* co, int64_t cos, double* xo, int64_t xos, double* ldo, void* s) {
+    return jf::gf_chain_inv_cot<double>(x, xs, p, ps, pb, B, D, n, L, ci, cis, co, cos, xo, xos, ldo, s);
 }
 int jf_gf_chain_fwd_f32(const float* z, int64_t zs, const float* ld_in, const float* p, int64_t ps, int32_t pb, int64_t B, int32_t D, int32_t n,
                         const jf_gf_layer* L, float* xo, int64_t xos, float* ldo, int64_t* bins, int64_t bs, int32_t* st, void* s) {

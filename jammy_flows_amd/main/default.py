@@ -1111,10 +1111,13 @@ class pdf(nn.Module):
         return torch.cat(parts).reshape(1, -1)
 
     def _forward_with_grad(self, x, conditional_input, amortization_parameters, force_embedding_coordinates, force_intrinsic_coordinates,
-                           only_last):
+                           only_last, collect=None):
         """forward() with a torch.autograd graph: d log_prob / d (x, conditional_input, MLP weights, permanent layer parameters).
         Same launches as the inference path, wrapped in autograd Functions whose backward is a HIP launch (g chains, manifold chains) or
-        rocBLAS GEMMs (dense layers) -- see jammy_flows_amd/autograd.py."""
+        rocBLAS GEMMs (dense layers) -- see jammy_flows_amd/autograd.py.
+        collect (optional list): receives one dict per sub-pdf -- its target columns (a, b), its base coordinates y WITH their graph, and for
+        pure g chains `cot`: v -> J_block^-T v, the co-vector carried through the block's layers by one launch (jf_gf_chain_inv_cot) -- what
+        the implicit-function adjoint of sampling needs (_differentiable_sample)."""
         log_det0 = None
         if force_embedding_coordinates:          # the chart changes ahead of the block loop, with a graph (autograd.SphereEmbeddingFn)
             assert x.shape[1] == self.total_target_dim_embedded, (x.shape[1], self.total_target_dim_embedded)
@@ -1243,6 +1246,19 @@ class pdf(nn.Module):
                     c1 -= n
                 base_logp = blp
             bases.append(out)
+            if collect is not None:
+                cot = None
+                if kind == "e" and gfl.chain_supported(layers) and not only_last and amort is None:
+                    def cot(v, si=si, layers=layers, tgt=tgt.detach(), inp=None if inp is None else inp.detach(), mlp=mlp):
+                        with torch.no_grad():
+                            if mlp is not None:
+                                params = mlp(inp)
+                                params = params[:, :-1] if self._poisson_column(si) else params
+                            else:
+                                params = gfl.chain_permanent_row(layers, tgt)
+                            return _hip.gf_chain_inv_cot(tgt, params, _hip.gf_layer_array([l.c_struct() for l in layers]), len(layers),
+                                                         layers[0].dimension, v)
+                collect.append({"a": a, "b": b, "y": out, "cot": cot, "coupled": mlp is not None and len(embeds) > 0})
             emb = block[-1]._embedding_conditional_return(tgt.detach()) if not tgt.requires_grad else autograd.embed(tgt, kind, layers[-1])
             embeds.append(emb)
         base = torch.cat(bases, dim=1) if len(bases) > 1 else bases[0]
@@ -1423,25 +1439,34 @@ class pdf(nn.Module):
             x = x* - J^-1 (F_theta(x*) - z),        J = dF/dx at x* (held constant)
 
         Its value is x* (the bracket vanishes to solver precision), its derivative -J^-1 dF/dtheta is exactly d x*/d theta.  F_theta(x*) is the
-        log-prob direction with a graph (the backward kernels of autograd.py); the rows of J are D_total vector-Jacobian products through those
-        same kernels; the (B, D, D) solve is batched LAPACK.  log_prob gets the matching first-order term: log p_theta(x*) + <grad_x log p, x - x*>."""
-        if force_embedding_coordinates or only_last:
-            raise NotImplementedError("differentiable sampling works in the default (intrinsic) coordinates of the full pdf")
+        log-prob direction with a graph (the backward kernels of autograd.py).  J is never formed: the backward of the correction needs
+        lambda = J^-T g, and J is block lower triangular over the autoregressive sub-pdfs, so lambda comes from ONE back-substitution -- per
+        block a co-vector launch through its g layers (J_block^-T: the layers' reflections and a division by each stage's derivative) and one
+        input-gradient pass for the coupling to the earlier blocks (autograd.InverseJacobianFn); blocks without that launch (manifold layers,
+        't' layers) use their small dense Jacobian block.  log_prob gets the matching first-order term:
+        log p_theta(x*) + <grad_x log p, x - x*>."""
+        if only_last:
+            raise NotImplementedError("differentiable sampling works on the full pdf (only_last is not supported)")
         with torch.no_grad():
             x_star, base_ret, _, logp_base = self._obtain_sample(conditional_input=conditional_input, predefined_target_input=predefined_target_input,
                                                                  samplesize=samplesize, seed=seed, amortization_parameters=amortization_parameters,
                                                                  force_intrinsic_coordinates=force_intrinsic_coordinates, dtype=dtype, device=device)
             z = predefined_target_input if predefined_target_input is not None else base_ret
         x0 = x_star.detach().clone().requires_grad_(True)
-        logp_x, _, y = self._forward_with_grad(x0, conditional_input, amortization_parameters, False, False, False)
+        blocks = []
+        logp_x, _, y = self._forward_with_grad(x0, conditional_input, amortization_parameters, False, False, False, collect=blocks)
         D = y.shape[1]
         assert D == x0.shape[1], "differentiable sampling needs a square Jacobian (intrinsic coordinates)"
-        rows = [torch.autograd.grad(y[:, i].sum(), x0, retain_graph=True)[0] for i in range(D)]
-        J = torch.stack(rows, dim=1)                                              # J[b, i, j] = d y_i / d x_j
         (g_logp,) = torch.autograd.grad(logp_x.sum(), x0, retain_graph=True)
-        delta = torch.linalg.solve(J, (y - z.detach()).unsqueeze(-1)).squeeze(-1)
+        # delta = J^-1 (y - z) is zero to solver precision; its BACKWARD is lambda = J^-T g, found by back-substitution over the autoregressive
+        # blocks (autograd.InverseJacobianFn), after which autograd walks the graph of y once with upstream lambda: ~3 backward passes in all
+        # (rounds 2-3: D + 2 -- one per row of a dense Jacobian -- and a batched LAPACK solve)
+        delta = autograd.InverseJacobianFn.apply(y - z.detach(), x0, blocks)
         x = x0.detach() - delta
         logp = logp_x - (g_logp * delta).sum(dim=1)
+        if force_embedding_coordinates:          # the chart change behind the flow, with its graph (:1508-1531): log p picks up its log-det
+            x, ld_emb = self.transform_target_space(x, torch.zeros_like(logp), transform_from="default", transform_to="embedding")
+            logp = logp - ld_emb
         return x, base_ret, logp, logp_base
 
     def obtain_flow_param_structure(self, conditional_input=None, predefined_target_input=None, seed=None, dtype=None, device=None):
