@@ -171,46 +171,6 @@ template <typename T> __device__ __forceinline__ MixQ<T> cs_mixture_derived(cons
     return q;
 }
 
-// log cdf and log sf only (no pdf, no third logarithm): what the bisection stage of cs_solve compares -- cs_mixture_derived without the density
-template <typename T> __device__ __forceinline__ void cs_mixture_lcls(const T (&P)[CS_SLOTS], T x, T& lc, T& ls) {
-    using Mf = M<T>;
-    T C = T(0), S = T(0);
-#pragma unroll
-    for (int k = 0; k < CS_K; ++k) {
-        const T wk = P[CS_SLOT_LN + k];
-        const T u = (x - P[CS_SLOT_MEAN + k]) * P[CS_SLOT_LW + k];
-        const T t = Mf::exp_fast(-Mf::abs(u));
-        const T hi = Mf::rcp(T(1) + t);
-        const T lo = t * hi;
-        const bool pos = u >= T(0);
-        C += wk * (pos ? hi : lo);
-        S += wk * (pos ? lo : hi);
-    }
-    lc = Mf::log_fast(C); ls = Mf::log_fast(S);
-    const bool under = !(C > Mf::TINY && S > Mf::TINY);
-    if (__any(under)) {                                            // wave-uniform: sums scaled by e^{m}, m = distance to the nearest component
-        T m = T(INFINITY);
-#pragma unroll
-        for (int k = 0; k < CS_K; ++k) m = Mf::min(m, Mf::abs((x - P[CS_SLOT_MEAN + k]) * P[CS_SLOT_LW + k]));
-        const T em = Mf::exp_fast(-m);
-        T Cu = T(0), Cs = T(0), Su = T(0), Ss = T(0);
-#pragma unroll
-        for (int k = 0; k < CS_K; ++k) {
-            const T wk = P[CS_SLOT_LN + k];
-            const T u = (x - P[CS_SLOT_MEAN + k]) * P[CS_SLOT_LW + k];
-            const T t = Mf::exp_fast(m - Mf::abs(u));
-            const T hi = Mf::rcp(T(1) + t * em);
-            const T c1 = wk * hi, c2 = c1 * t;
-            if (u >= T(0)) { Cu += c1; Ss += c2; }
-            else { Su += c1; Cs += c2; }
-        }
-        if (under) {
-            lc = Cu > T(0) ? Mf::log_fast(Cu + em * Cs) : Mf::log_fast(Cs) - m;
-            ls = Su > T(0) ? Mf::log_fast(Su + em * Ss) : Mf::log_fast(Ss) - m;
-        }
-    }
-}
-
 // x with stage(mixture(x)) = z: an approach phase (below) + gfg_solve's Newton stage step for step (stopping rules, status counters); RSUM /
 // RMAX reduce over the lanes that hold the coordinates of one row.  P: DERIVED row (mean, 1 / width, normalised weight per component).
 // info (optional): the caller solves the coordinates of a row in more than one call (two coordinates per lane) and books the row's status
