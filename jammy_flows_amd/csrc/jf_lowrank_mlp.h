@@ -12,7 +12,8 @@
 //     g_U1 | g_b1 tile += g_pre^T [t1 | 1]         4 products over the wave's 16 rows (g_pre transposed through 2 KB of LDS scratch)
 //     g_V2^T tile += h^T g_t2                      4 products over the rows (h transposed the same way)
 // and after the eight tiles  g_c^T = V1^T g_t1^T (2 products per 16 inputs) and  g_V1 += g_t1^T c  (4 per 16 inputs).  The three weight
-// gradients accumulate in MFMA result registers over all row tiles of the wave (144 VGPRs) and meet in LDS once per wave; one partial image
+// gradients of U1, b1, V2 accumulate in MFMA result registers over all row tiles of the wave (128 VGPRs) and meet in LDS once per wave (the small
+// g_V1 tile goes there per row tile); one partial image
 // per workgroup, summed in a fixed order by lrm_reduce_kernel.
 #pragma once
 
@@ -81,7 +82,7 @@ __global__ void __launch_bounds__(AM_THREADS) lrm_head_fwd_kernel(const LrmFwdAr
     if (row_valid) { a.t2[row * AM_R + q] = t2[0]; a.t2[row * AM_R + q + 4] = t2[1]; }
 }
 
-// KTM: compiled bound of the 16-input tiles (1 for K1 <= 16: 252 VGPRs and two waves per SIMD; 2: 272 and one)
+// KTM: compiled bound of the 16-input tiles (1 for K1 <= 16, 2 up to 32)
 template <int KTM> __global__ void __launch_bounds__(LRM_NW * 64) lrm_head_bwd_kernel(const LrmBwdArgs a) {
     using T = double;
     extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -110,18 +111,16 @@ template <int KTM> __global__ void __launch_bounds__(LRM_NW * 64) lrm_head_bwd_k
     for (int e = tid; e < psz; e += LRM_NW * 64) acc[e] = T(0);
     __syncthreads();
     const f64x4_t zero4 = {0.0, 0.0, 0.0, 0.0};
-    f64x4_t aU[LRM_HT], aV[LRM_HT], aW[KTM];
+    f64x4_t aU[LRM_HT], aV[LRM_HT];
 #pragma unroll
     for (int t = 0; t < LRM_HT; ++t) { aU[t] = zero4; aV[t] = zero4; }
-#pragma unroll
-    for (int i = 0; i < KTM; ++i) aW[i] = zero4;
     for (int64_t rt = (int64_t)blockIdx.x * LRM_NW + wave; rt < a.n_row_tiles; rt += (int64_t)gridDim.x * LRM_NW) {
         const int64_t row = rt * 16 + n;
         const bool row_valid = row < a.B;
         const int64_t rrow = row_valid ? row : a.B - 1;
         const T ga = (row_valid && q < a.r2) ? a.g_t2[rrow * a.gs + q] : T(0);
         const T gb = (row_valid && q + 4 < a.r2) ? a.g_t2[rrow * a.gs + q + 4] : T(0);
-        T g2op[4], t1op[4], cop[4][KTM];              // B operands of the products over the rows: lane (j = n, k = q) of step s: row 4 s + k
+        T g2op[4], t1op[4];                             // B operands of the products over the rows: lane (j = n, k = q) of step s: row 4 s + k
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const int64_t rr = rt * 16 + 4 * s + q;
@@ -129,8 +128,6 @@ template <int KTM> __global__ void __launch_bounds__(LRM_NW * 64) lrm_head_bwd_k
             g2op[s] = (okr && n < a.r2) ? a.g_t2[rr * a.gs + n] : T(0);
             const T tv = (okr && n < a.r1) ? a.t1[rr * AM_R + n] : T(0);
             t1op[s] = (okr && n == a.r1) ? T(1) : tv;   // column r1: the bias
-#pragma unroll
-            for (int i = 0; i < KTM; ++i) cop[s][i] = (okr && i < KT && 16 * i + n < a.K1) ? a.in[rr * a.in_stride + 16 * i + n] : T(0);
         }
         f64x4_t gt1 = zero4;
 #pragma unroll
@@ -170,14 +167,21 @@ template <int KTM> __global__ void __launch_bounds__(LRM_NW * 64) lrm_head_bwd_k
                         if (row_valid && j < a.K1) a.g_c[row * a.gcs + j] = gc[r];
                     }
                 }
+                f64x4_t aw = zero4;                        // g_V1 tile of this row tile: straight into the workgroup's image (2 atomics per tile)
 #pragma unroll
-                for (int s = 0; s < 4; ++s) aW[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(scrA[n * 17 + 4 * s + q], cop[s][i], aW[i], 0, 0, 0);
+                for (int s = 0; s < 4; ++s) {              // (the inputs are loaded here, not ahead of the hidden tiles: 16 registers less across them)
+                    const int64_t rr = rt * 16 + 4 * s + q;
+                    const T cv = (rr < a.B && 16 * i + n < a.K1) ? a.in[rr * a.in_stride + 16 * i + n] : T(0);
+                    aw = __builtin_amdgcn_mfma_f64_16x16x4f64(scrA[n * 17 + 4 * s + q], cv, aw, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 2; ++r) atomicAdd(acc + H * AM_R + H * (AM_R + 1) + (q + 4 * r) * (16 * KT) + 16 * i + n, aw[r]);
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     // the wave's accumulators -> the workgroup's image (result layout: lane (n = column j, q), register r = row q + 4 r of the product)
-    T* accV = acc; T* accU = acc + H * AM_R; T* accW = accU + H * (AM_R + 1);
+    T* accV = acc; T* accU = acc + H * AM_R;
 #pragma unroll
     for (int t = 0; t < LRM_HT; ++t) {
         if (t < HT) {
@@ -187,13 +191,6 @@ template <int KTM> __global__ void __launch_bounds__(LRM_NW * 64) lrm_head_bwd_k
                 if (n < AM_R) atomicAdd(accV + unit * AM_R + n, aV[t][r]);
                 if (n <= AM_R) atomicAdd(accU + unit * (AM_R + 1) + n, aU[t][r]);
             }
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < KTM; ++i) {
-        if (i < KT) {
-#pragma unroll
-            for (int r = 0; r < 2; ++r) atomicAdd(accW + (q + 4 * r) * (16 * KT) + 16 * i + n, aW[i][r]);
         }
     }
     __syncthreads();
