@@ -5,7 +5,8 @@
 // the 4.3 ms of a C5 step at 2^17 rows.  Here neither block exists:
 //   lr_gf_fwd_kernel        the chain's log-prob direction with every parameter regenerated from t2 on the f64 matrix cores (the layout of
 //                           jf_amlp_mfma.h: a wave owns 16 rows, lane = (row n, group q), group q owns coordinates q and q + 4); it also keeps
-//                           each layer's input coordinates and linear-space mixture sums (5 doubles per coordinate and layer: `aux`)
+//                           each layer's rotated coordinates (behind its offset and reflections) and linear-space mixture sums (5 doubles per
+//                           coordinate and layer: `aux`)
 //   lr_gf_bwd_layer_kernel  ONE layer's adjoint per launch (layer 0 -- the last one applied -- first): parameters regenerated the same way, the
 //                           gradient of a parameter tile stays in the MFMA result registers and is contracted twice right there:
 //                             g_t2^T (r2 x rows)  += U2'^T G       4 products per tile, A gathered from the same LDS image of U2
@@ -32,7 +33,7 @@ constexpr int LR_RS = AM_R + 1;                  // accumulator row: r2 <= 8 ran
 constexpr int LR_TILES = AG_HH + 1 + 2 * AG_K;   // tiles of a layer in the BACKWARD kernel's order (lr_col)
 constexpr int LR_PSZ = LR_TILES * 16 * LR_RS;    // doubles of one layer's partial image
 constexpr int LR_MAX_WG = 256;                   // one resident workgroup per CU of an MI355X
-constexpr int LR_AUX = 5;                        // per layer and coordinate: input, cdf, sf, pdf sums (normalised), 1 / sum of weights
+constexpr int LR_AUX = 5;                        // per layer and coordinate: rotated input, cdf, sf, pdf sums (normalised), 1 / sum of weights
 
 template <typename T> struct LrFwdArgs {
     const T* t2; int64_t t2s; const T* U2; const T* b2; int r2;
@@ -134,10 +135,6 @@ __global__ void __launch_bounds__(AM_THREADS) lr_gf_fwd_kernel(const Args a) {
         // aux[l][slot][half][row][q]: every store of a wave covers 512 contiguous bytes
         T* ax = a.aux ? a.aux + (int64_t)l * LR_AUX * 2 * a.B * 4 + row * 4 + q : nullptr;
         const int64_t hst = a.B * 4;                                  // stride between the two coordinate halves; 2 hst between slots
-        if (ax && row_valid) {
-            if (v0) ax[0] = x0;
-            if (v1) ax[hst] = x1;
-        }
         {
             T R[AM_TILES_R * 4];
 #pragma unroll
@@ -156,6 +153,10 @@ __global__ void __launch_bounds__(AM_THREADS) lr_gf_fwd_kernel(const Args a) {
                     x0 -= f * va; x1 -= f * vb;
                 }
             }
+        }
+        if (ax && row_valid) {                                        // slot 0: the coordinates BEHIND the offset and the reflections -- what the
+            if (v0) ax[0] = x0;                                       //   mixture stage sees; the adjoint walks the reflections back from here
+            if (v1) ax[hst] = x1;
         }
         T logd = T(0);
 #pragma unroll
@@ -317,19 +318,6 @@ __global__ void __launch_bounds__(LR_NW * 64) lr_gf_bwd_layer_kernel(const LrBwd
             }
         };
 
-        // ---- recompute the offset and the reflections of the layer's input
-        {
-            const f64x4_t p = tile(AG_HH);
-            x0 -= p[0]; x1 -= p[1];
-        }
-#pragma unroll 1
-        for (int i = 0; i < o.hh; ++i) {
-            const f64x4_t p = tile(i);
-            const T va = p[0], vb = p[1];
-            const T n2 = am_xsum(va * va + vb * vb), dot = am_xsum(va * x0 + vb * x1);
-            const T f = T(2) * dot * M<T>::rcp(n2);
-            x0 -= f * va; x1 -= f * vb;
-        }
         // ---- mixture + inverse-CDF stage of the two coordinates: linear-space responsibilities (gf_layer_bwd_fast, gf_bwd_kernels.hip) when every
         //      live lane of the wave is in their range, else log space (gf_layer_bwd) -- the switch of the (B, P)-block kernel on the same saved sums
         T gx0 = T(0), gx1 = T(0);
