@@ -301,3 +301,32 @@ def test_packed_gradient_rows_index_every_parameter_column_once():
             assert first_mean == [base + d * _hip.COND_GF_SLOTS + 0 for d in range(D)]               # slot 0: mean of component 0
             col += 3 * c.num_kde * D
         assert col == n_params
+
+
+def test_one_launch_adam_host_side():
+    """jammy_flows_amd.optim.Adam without a device: torch's defaults and state layout, hyper-parameter checks, and no CPU fallback -- a host
+    parameter with a gradient is refused loudly (the update itself is csrc/misc_kernels.hip: jf_adam_step, tests/test_gpu_grad.py)"""
+    import torch
+    from jammy_flows_amd import optim as jf_optim
+    p = torch.nn.Parameter(torch.zeros(5))
+    opt = jf_optim.Adam([p])
+    ref = torch.optim.Adam([torch.nn.Parameter(torch.zeros(5))])
+    for k in ("lr", "betas", "eps"):
+        assert opt.param_groups[0][k] == ref.param_groups[0][k]
+    opt.step()                                                   # no gradient anywhere: nothing to do, nothing raised
+    assert len(opt.state) == 0
+    p.grad = torch.ones(5)
+    with pytest.raises(RuntimeError, match="HIP device"):
+        opt.step()
+    for bad in (dict(lr=-1.0), dict(betas=(1.0, 0.9)), dict(betas=(0.9, -0.1)), dict(eps=-1e-8)):
+        with pytest.raises(ValueError):
+            jf_optim.Adam([p], **bad)
+    # a torch state_dict loads (same keys: step / exp_avg / exp_avg_sq)
+    q = torch.nn.Parameter(torch.zeros(3))
+    topt = torch.optim.Adam([q], lr=2e-3)
+    q.grad = torch.ones(3)
+    topt.step()
+    mine = jf_optim.Adam([q], lr=1e-3)
+    mine.load_state_dict(topt.state_dict())
+    st = mine.state[q]
+    assert set(st) == {"step", "exp_avg", "exp_avg_sq"} and int(st["step"]) == 1 and mine.param_groups[0]["lr"] == 2e-3
