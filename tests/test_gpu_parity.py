@@ -1120,3 +1120,32 @@ def test_solver_on_rough_mixtures_round_trip(dtype, tol, inv):
     keep = B - 8
     assert err.sort().values[keep - 1].item() < tol, err.sort().values[keep - 1].item()
     assert lerr.sort().values[keep - 1].item() < 50 * tol
+
+
+@pytest.mark.parametrize("name,dtype,n,tol", [("c3_e4s2e4", torch.float32, 1 << 20, 2e-2), ("c5_e8s2_ggggv", torch.float64, 1 << 19, 1e-6)])
+def test_full_size_sampling_round_trip_in_the_benchmarked_precision(name, dtype, n, tol):
+    """the sampling direction at the sizes and precisions `bench.py --direction sample` times (C3 float32 2^20, C5 float64 2^19; round 4 changed
+    its solver): decode -> encode returns the injected base points and the sampler's log-probs (tests/test_general.py:554-556 at
+    full size), a second launch gives identical bits, and no row is non-finite or flagged non-converged beyond the handful the reference's
+    own Pade-gap rows produce"""
+    fx = [f for f in ALL_FIXTURES if f.name == name][0]
+    pdf = build_product(fx, dtype)
+    g = torch.Generator(device="cpu").manual_seed(9)
+    z = torch.randn(n, pdf.total_base_dim, generator=g, dtype=torch.float64).to(device="cuda", dtype=dtype)
+    cond = None
+    if fx.get("cond") is not None:
+        cs = to_dev(fx["cond"], dtype)
+        cond = cs.repeat(n // cs.shape[0] + 1, 1)[:n].contiguous()
+    xs, _, lps, lpb = pdf._obtain_sample(conditional_input=cond, predefined_target_input=z)
+    words = dict(pdf.last_status_words)
+    xs2, _, lps2, _ = pdf._obtain_sample(conditional_input=cond, predefined_target_input=z)
+    assert torch.equal(xs, xs2) and torch.equal(lps, lps2)
+    assert words["nonfinite"] == 0 and words["nonconverged"] <= n // 5000, words
+    lp2, lpb2, base = pdf(xs, conditional_input=cond)
+    ok = torch.isfinite(lps) & torch.isfinite(lp2)
+    err_z = (base - z).abs().amax(dim=1) / (1 + z.abs().amax(dim=1))
+    err_lp = (lp2 - lps).abs() / (1 + lps.abs())
+    good = ok & (err_z < tol) & (err_lp < tol)
+    frac = float(good.float().mean())
+    print("%s %s: round trip at %d rows: %d rows outside %.0e, non-converged %d" % (name, dtype, n, int((~good).sum()), tol, words["nonconverged"]))
+    assert frac > 0.999, frac
