@@ -149,9 +149,10 @@ __global__ void __launch_bounds__(BCAST ? 256 : 64, sizeof(T) == 8 ? 2 : 4) gf_c
                         R[CS_SLOT_LW + k] = p[o.off_lw + k * D];
                         R[CS_SLOT_LN + k] = p[o.off_ln + k * D];
                     }
+                    T slogd;
                     x = cs_solve<T>(R, o.inv_type, live, x, row_valid, leader, a.status, [](T v) { return group_sum<T, G>(v); },
-                                    [](T v) { return group_max<T, G>(v); });
-                    ld -= group_sum<T, G>(live ? gf_icdf<T>(o.inv_type, cs_mixture_derived<T>(R, x)).logd : T(0));
+                                    [](T v) { return group_max<T, G>(v); }, nullptr, &slogd);
+                    ld -= group_sum<T, G>(live ? slogd : T(0));
                 } else {
                     x = gfg_solve<T, G>(p, o, D, live, x, row_valid, leader, a.status);
                     const MixQ<T> q = gfg_mixture<T, false>(p, o, D, x);                            // gaussianization_flow.py:922-924

@@ -269,9 +269,10 @@ __global__ void __launch_bounds__(FWD ? AM_THREADS_FWD : AM_THREADS) amlp_gf_mfm
 #pragma unroll
                 for (int k = 0; k < CS_K; ++k) R[CS_SLOT_LN + k] *= invN;
                 const bool live = half == 0 ? v0 : v1;
+                T slogd;
                 const T xs = cs_solve<T>(R, o.inv_type, live, half == 0 ? x0 : x1, row_valid, q == 0, a.status, [](T v) { return am_xsum(v); },
-                                        [](T v) { return am_xmax(v); }, &inf[half]);
-                logd += live ? gf_icdf<T>(o.inv_type, cs_mixture_derived<T>(R, xs)).logd : T(0);
+                                        [](T v) { return am_xmax(v); }, &inf[half], &slogd);
+                logd += live ? slogd : T(0);
                 if (half == 0) x0 = xs; else x1 = xs;
             }
             ld -= am_xsum(logd);

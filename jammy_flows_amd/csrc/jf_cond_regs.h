@@ -178,7 +178,7 @@ template <typename T> __device__ __forceinline__ MixQ<T> cs_mixture_derived(cons
 struct CsSolveInfo { int steps; bool nonconv, nonfinite; };
 template <typename T, typename RSUM, typename RMAX>
 __device__ __forceinline__ T cs_solve(const T (&P)[CS_SLOTS], int inv_type, bool live, T z, bool row_valid, bool leader, int32_t* status,
-                                      RSUM rsum, RMAX rmax, CsSolveInfo* info = nullptr) {
+                                      RSUM rsum, RMAX rmax, CsSolveInfo* info = nullptr, T* logd_out = nullptr) {
     using Mf = M<T>;
     // ---- approach phase (gf_approach, jf_gf.h): float64 rows run it in float32 on a float copy of the derived row, as they ran the bisection
     using F = typename std::conditional<sizeof(T) == 8, float, T>::type;
@@ -194,6 +194,7 @@ __device__ __forceinline__ T cs_solve(const T (&P)[CS_SLOTS], int inv_type, bool
     T ferr = T(0), prev = T(INFINITY);
     bool nonfinite = false;
     int n_steps = 0;
+    T last_logd = T(0);
     for (int it = 0; it < 20 && __any(active); ++it) {
         const IcdfOut<T> s = gf_icdf<T>(inv_type, cs_mixture_derived<T>(P, x));
         const T f = s.y - z;
@@ -207,6 +208,7 @@ __device__ __forceinline__ T cs_solve(const T (&P)[CS_SLOTS], int inv_type, bool
             const T nx = x - upd;
             if (Mf::finite(nx)) x = nx; else nonfinite = nonfinite || live;
             ferr = Mf::abs(f);
+            last_logd = s.logd;
             active = usum >= T(1e-14);
         }
         if constexpr (sizeof(T) == 4) {
@@ -215,6 +217,15 @@ __device__ __forceinline__ T cs_solve(const T (&P)[CS_SLOTS], int inv_type, bool
             if (usum < T(2.5e-7) * xs || (usum >= T(0.5) * prev && usum < T(1e-4) * xs)) active = false;
             prev = usum;
         }
+    }
+    if (logd_out != nullptr) {
+        // the stage's log-derivative at the solution (the caller's log-det term).  float64: a converged row's last update was below 1e-14, so the
+        // value of its last evaluation IS the value at the returned point to rounding -- one float64 evaluation (mixture + inverse normal CDF,
+        // a fifth of the solve) saved; a wave with a row that ran out of iterations, and float32 (whose floor rules accept updates up to 1e-4 of
+        // the coordinate), evaluate at the returned point as the reference does (gaussianization_flow.py:922-924)
+        const bool stale = sizeof(T) == 4 || (row_valid && (active || n_steps == 0));
+        if (__any(stale)) *logd_out = gf_icdf<T>(inv_type, cs_mixture_derived<T>(P, x)).logd;
+        else *logd_out = last_logd;
     }
     const T prec = sizeof(T) == 8 ? T(1e-7) : T(1e-4);
     const T ferr_row = rmax(live ? ferr : T(0));
