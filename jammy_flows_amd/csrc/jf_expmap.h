@@ -190,7 +190,16 @@ template <typename T> __device__ __forceinline__ void v_log_map(const T (&base)[
 //          was still moving change by < 1e-12 per further step).
 template <typename T> __device__ inline void v_newton(const T* __restrict__ pp, int nc, int kind, const T (&target)[3], int max_iter, bool fast,
                                                      bool lane_valid, T (&x)[3], T* __restrict__ tab, bool& oob) {
-    x[0] = T(0); x[1] = T(0); x[2] = T(-1);
+    // start AT the target: the layer is exp_x(grad phi(x)) with a bounded potential gradient, i.e. a perturbation of the identity, so the image of
+    // the target is usually already within the Gauss-Newton radius (fn < 0.1) and the damped approach from the south pole (the reference's
+    // start: ~10 evaluations until fn < 0.1) is skipped; the map is a diffeomorphism of the sphere, the root is the same (round 4: 1.29 -> see
+    // DESIGN 3.3b)
+    {
+        const T tn2 = target[0] * target[0] + target[1] * target[1] + target[2] * target[2];
+        const bool ok = tn2 > T(0.25) && tn2 < T(4);
+        const T inv = ok ? T(1) / M<T>::sqrt(tn2) : T(0);
+        x[0] = ok ? target[0] * inv : T(0); x[1] = ok ? target[1] * inv : T(0); x[2] = ok ? target[2] * inv : T(-1);
+    }
     bool active = lane_valid;
     const T damp = fast ? T(0.4) : T(0.1);
     bool gn_ok = true, last_gn = false;
