@@ -261,9 +261,10 @@ __global__ void __launch_bounds__(256, (NP == 2 && !FWD) ? 3 : 2) cond_gf_split_
                 // sampling direction (gaussianization_flow.py:911-989): regulate the row once in its registers, solve stage(mixture(x)) = z by
                 // 25 bisection + <= 20 Newton steps, log-det from the solution, then x <- Q x and the offset (euclidean_base.py:63-68)
                 cs_derive(P[g], o);
+                float slogd;
                 float xs = cs_solve<float>(P[g], o.inv_type, live, x[g], row_valid[g], leader, a.status, [](float v) { return cs_rsum(v); },
-                                    [](float v) { return cs_rmax(v); });
-                ld[g] -= cs_rsum(live ? gf_icdf<float>(o.inv_type, cs_mixture_derived<float>(P[g], xs)).logd : 0.f);
+                                    [](float v) { return cs_rmax(v); }, nullptr, &slogd);
+                ld[g] -= cs_rsum(live ? slogd : 0.f);
 #pragma unroll
                 for (int i = CS_HH - 1; i >= 0; --i) {
                     if (i < o.hh) {

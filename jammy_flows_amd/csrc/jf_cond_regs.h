@@ -195,6 +195,7 @@ __device__ __forceinline__ T cs_solve(const T (&P)[CS_SLOTS], int inv_type, bool
     bool nonfinite = false;
     int n_steps = 0;
     T last_logd = T(0);
+    bool coarse_end = false;
     for (int it = 0; it < 20 && __any(active); ++it) {
         const IcdfOut<T> s = gf_icdf<T>(inv_type, cs_mixture_derived<T>(P, x));
         const T f = s.y - z;
@@ -214,16 +215,18 @@ __device__ __forceinline__ T cs_solve(const T (&P)[CS_SLOTS], int inv_type, bool
         if constexpr (sizeof(T) == 4) {
             // float32 floor of the update (see gfg_solve): the reference's float32 runs spend their last ~16 Newton steps on rounding noise
             const T xs = rsum(live ? Mf::max(Mf::abs(x), T(1)) : T(0));
+            if (active && usum >= T(0.5) * prev && usum < T(1e-4) * xs && !(usum < T(2.5e-7) * xs)) coarse_end = true;   // stopped on stagnation
             if (usum < T(2.5e-7) * xs || (usum >= T(0.5) * prev && usum < T(1e-4) * xs)) active = false;
             prev = usum;
         }
     }
     if (logd_out != nullptr) {
-        // the stage's log-derivative at the solution (the caller's log-det term).  float64: a converged row's last update was below 1e-14, so the
-        // value of its last evaluation IS the value at the returned point to rounding -- one float64 evaluation (mixture + inverse normal CDF,
-        // a fifth of the solve) saved; a wave with a row that ran out of iterations, and float32 (whose floor rules accept updates up to 1e-4 of
-        // the coordinate), evaluate at the returned point as the reference does (gaussianization_flow.py:922-924)
-        const bool stale = sizeof(T) == 4 || (row_valid && (active || n_steps == 0));
+        // the stage's log-derivative at the solution (the caller's log-det term).  A converged row's last update was below 1e-14 (float32: below
+        // 2.5e-7 of the coordinate -- its rounding), so the value of its last evaluation IS the value at the returned point to rounding: one
+        // evaluation (mixture + inverse CDF; a fifth of a float64 solve) saved.  A wave with a row that ran out of iterations, or -- float32 --
+        // stopped on the stagnation rule (updates up to 1e-4 of the coordinate), evaluates at the returned point as the reference does
+        // (gaussianization_flow.py:922-924)
+        const bool stale = row_valid && (active || n_steps == 0 || coarse_end);
         if (__any(stale)) *logd_out = gf_icdf<T>(inv_type, cs_mixture_derived<T>(P, x)).logd;
         else *logd_out = last_logd;
     }
