@@ -185,9 +185,18 @@ __device__ __forceinline__ T cs_solve(const T (&P)[CS_SLOTS], int inv_type, bool
     F PF[CS_SLOTS];
 #pragma unroll
     for (int k = 0; k < CS_SLOTS; ++k) PF[k] = k < 3 * CS_K ? (F)P[k] : F(0);
-    F xf = F(0);
+    // start: the mixture's mean moved by z mean-widths -- exact for one component of an isigmoid stage (x = mu + w z), and for a normal-type
+    // stage with the classic logistic / normal match x = mu + 1.702 w z
+    F xf = F(0), wbar = F(0);
 #pragma unroll
-    for (int k = 0; k < CS_K; ++k) xf += PF[CS_SLOT_LN + k] * PF[CS_SLOT_MEAN + k];           // the mixture's mean: cdf ~ 1/2
+    for (int k = 0; k < CS_K; ++k) {
+        xf += PF[CS_SLOT_LN + k] * PF[CS_SLOT_MEAN + k];
+        wbar += PF[CS_SLOT_LN + k] * M<F>::rcp(PF[CS_SLOT_LW + k]);
+    }
+    {
+        const F zc = M<F>::min(M<F>::max((F)z, F(-8)), F(8));
+        xf += wbar * zc * (inv_type != JF_GF_ISIGMOID ? F(1.702) : F(1));
+    }
     xf = gf_approach<F>([&](F xx) { return cs_mixture_derived<F>(PF, xx); }, inv_type != JF_GF_ISIGMOID, (F)z, xf, live);
     T x = (T)xf;
     bool active = row_valid;
