@@ -349,8 +349,9 @@ __device__ __forceinline__ T gf_layer_bwd_bcast(const T* __restrict__ p, const T
         const T gu = pik * (a * sgc - b * sg + cp * (sgc - sg));
         gx += gu * iw;
         // (round 4: summing the wave's rows in registers first -- rotations + permlane swaps, 3 values per component -- and leaving the atomics to
-        // the first row's lanes made this kernel SLOWER, 0.264 -> 0.291 ms at 2^18 rows of C3's block 0: the slotted atomics below are not what
-        // it waits for)
+        // the first row's lanes made this kernel SLOWER, 0.264 -> 0.291 ms at 2^18 rows of C3's block 0; summing only the 4 rows of a 16-lane DPP
+        // row and issuing the three values as ONE atomic instruction -- a third of the instructions, a quarter of the lanes -- left it at 0.2646:
+        // the slotted atomics below are not what it waits for)
         atomicAdd(am, live ? (double)(-gu * iw) : 0.0);         // selected, not multiplied: a shadow lane (g >= D) may hold inf / nan
         atomicAdd(aw, live ? (double)((gu * u + pik * cp) * flw) : 0.0);
         atomicAdd(an, live ? (double)((a + b + cp - Gsum) * fln) : 0.0);
