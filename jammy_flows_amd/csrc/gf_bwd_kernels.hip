@@ -312,7 +312,6 @@ __device__ __forceinline__ T gf_layer_bwd_bcast(const T* __restrict__ p, const T
                                                 const GfLayerDev<T>& o, int D, bool live, T x_in, T gy, T gl, int slsh, T Cs, T Ss, T Ps) {
     // Cs, Ss, Ps: the layer's linear-space sums from the forward sweep (Cs = 0: the wave needed the scaled evaluation there)
     const bool ok = Cs > LinRange<T>::lo && Ss > LinRange<T>::lo && Ps > LinRange<T>::lo && Ps < LinRange<T>::hi;
-    if (!__all(ok)) return gf_layer_bwd<T, G, true, double>(p, gp, o, D, live, x_in, gy, gl, slsh);
     T xr[gb_max_hh<G>()];
     T x = x_in;
     if (o.model_offset) x -= p[0];
@@ -320,6 +319,71 @@ __device__ __forceinline__ T gf_layer_bwd_bcast(const T* __restrict__ p, const T
     for (int i = 0; i < gb_max_hh<G>(); ++i) {
         xr[i] = x;
         if (i < o.hh) x = gfg_reflect<T, G, false>(v, o.off_rot + i * D, live, x);
+    }
+    if (!__all(ok)) {
+        // A lane of the wave sits where the linear-space sums under- or overflow (a target tens of widths from every component).  Rounds 2-3 sent
+        // the whole wave through the log-space loop of gf_layer_bwd (8 exp / log and 8 divisions per component); measured in round 4 on the
+        // SURVEY inputs of C3's block 0 that was HALF of this kernel (0.265 ms against 0.121 on the model's own samples: one tail row per 16
+        // is enough to send every wave there).  The responsibilities only need the sums of gfg_mixture_scaled -- everything scaled by e^{m},
+        // m = distance to the nearest component -- because every ratio that occurs has e^{-m} on both sides:
+        //     s (1 - s) = e^{-m} t' h^2        (t' = e^{m - |u|}, h = sigma(|u|)),     e^{-m} / cdf = em / (Cu + em Cs)  or  1 / Cs  when Cu = 0,
+        //     pdf = e^{-m} Ps   =>   s (1 - s) / (w pdf) = t' h^2 / (w Ps),           the same for sf.
+        // Three passes over the component records (distance, sums, gradients): ~55 instructions per component.
+        const T* c = (const T*)__builtin_assume_aligned(c0, 16);
+        T m = T(INFINITY);
+        for (int k = 0; k < o.K; ++k) m = M<T>::min(m, M<T>::abs((x - c[8 * D * k]) * c[8 * D * k + 1]));
+        const T em = M<T>::exp_fast(-m);
+        T Cu = T(0), Cq = T(0), Su = T(0), Sq = T(0), Pq = T(0);
+        for (int k = 0; k < o.K; ++k) {
+            const T iwk = c[8 * D * k + 1], pk = c[8 * D * k + 2];
+            const T u = (x - c[8 * D * k]) * iwk;
+            const T tp = M<T>::exp_fast(m - M<T>::abs(u));
+            const T h = M<T>::rcp(T(1) + tp * em);
+            const T c1 = pk * h, c2 = c1 * tp;
+            if (u >= T(0)) { Cu += c1; Sq += c2; } else { Su += c1; Cq += c2; }
+            Pq += c2 * h * iwk;
+        }
+        MixQ<T> q;
+        q.cdf = Cu + em * Cq;
+        q.sf = Su + em * Sq;
+        q.lc = Cu > T(0) ? M<T>::log_fast(q.cdf) : M<T>::log_fast(Cq) - m;
+        q.ls = Su > T(0) ? M<T>::log_fast(q.sf) : M<T>::log_fast(Sq) - m;
+        q.lp = M<T>::log_fast(Pq) - m;
+        const IcdfOut<T> s = gf_icdf<T>(o.inv_type, q);
+        const IcdfCoef<T> cf = gf_icdf_coeffs<T>(o.inv_type, q, s.y);
+        const T g_lc = gy * cf.Ay + gl * cf.AH, g_ls = gy * cf.By + gl * cf.BH, g_lp = gl;
+        const T Gsum = g_lc + g_ls + g_lp;
+        const T r1c = Cu > T(0) ? M<T>::rcp(q.cdf) : T(0), r1s = Su > T(0) ? M<T>::rcp(q.sf) : T(0);   // 1 / cdf, 1 / sf: for components on their side
+        const T a2c = Cu > T(0) ? em * r1c : M<T>::rcp(Cq), a2s = Su > T(0) ? em * r1s : M<T>::rcp(Sq);  // e^{-m} / cdf, e^{-m} / sf
+        const T ap = M<T>::rcp(Pq);
+        const bool fit = o.fit_norm != 0;
+        double* am = gp + (o.off_mean << slsh);
+        double* aw = gp + (o.off_lw << slsh);
+        double* an = gp + ((fit ? o.off_ln : o.off_lw) << slsh);
+        const int step = D << slsh;
+        T gx = T(0);
+        for (int k = 0; k < o.K; ++k, c += 8 * D) {
+            const T mu = c[0], iwk = c[1], pk = c[2], flw = c[3], fln = c[4];
+            const T u = (x - mu) * iwk;
+            const T tp = M<T>::exp_fast(m - M<T>::abs(u));
+            const T h = M<T>::rcp(T(1) + tp * em);
+            const bool pos = u >= T(0);
+            const T th = tp * h, w2 = th * h;                    // s (1 - s) = em w2
+            const T sk = pos ? h : em * th;                      // sigma(u)
+            const T pp = w2 * iwk * ap;                          // s (1 - s) / (w pdf)
+            const T sc = pos ? h * r1c : th * a2c;               // s / cdf
+            const T ss = pos ? th * a2s : h * r1s;               // (1 - s) / sf
+            const T gu = pk * (w2 * (g_lc * a2c - g_ls * a2s) + g_lp * pp * (T(1) - T(2) * sk));
+            gx += gu * iwk;
+            atomicAdd(am, live ? (double)(-gu * iwk) : 0.0);
+            atomicAdd(aw, live ? (double)((gu * u + g_lp * pk * pp) * flw) : 0.0);
+            atomicAdd(an, live ? (double)((g_lc * sc + g_ls * ss + g_lp * pp - Gsum) * fln) : 0.0);     // (fln carries pi_k d log n_k / d raw)
+            am += step; aw += step; an += step;
+        }
+        auto put = [&](int off, T val) { atomicAdd(gp + (off << slsh), live ? (double)val : 0.0); };
+        const T g = gf_reflections_bwd<T, G>(p, o, D, live, xr, gx, put);
+        if (o.model_offset) put(0, -g);
+        return g;
     }
     MixQ<T> q;
     q.lc = M<T>::log_fast(Cs); q.ls = M<T>::log_fast(Ss); q.lp = M<T>::log_fast(Ps); q.cdf = Cs; q.sf = Ss;
