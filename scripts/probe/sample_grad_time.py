@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""time of a reparameterised-sampling training step (pdf._differentiable_sample + backward) -- python3 scripts/probe/sample_grad_time.py [fixture] [rows] [old]"""
+"""time of a reparameterised-sampling training step (pdf._differentiable_sample + backward) -- python3 scripts/probe/sample_grad_time.py [fixture] [rows] [old]
+`old`: import the package from scripts/probe/oldtree/ instead (an A/B against an earlier commit: `git archive <rev> jammy_flows_amd | tar -x -C
+scripts/probe/oldtree` and copy the current libjammy_hip.so next to its _hip.py; the directory is not kept in the tree)."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 old = len(sys.argv) > 3 and sys.argv[3] == "old"
