@@ -1065,7 +1065,7 @@ def slab_sum(a, b=None):
     na, nb = a[0].numel(), 0 if b is None else b[0].numel()
     fn = "jf_slab_sum" + _suffix(a)
     shape_a, shape_b = a.shape[1:], None if b is None else b.shape[1:]
-    if S > 64:
+    if S > 128:
         chunk = 32
         n_chunks = (S + chunk - 1) // chunk
         mid_a = torch.empty((n_chunks, na), dtype=a.dtype, device=a.device)

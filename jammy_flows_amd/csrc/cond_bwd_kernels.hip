@@ -127,39 +127,64 @@ __device__ __forceinline__ float cb_layer_bwd(float (&P)[CS_SLOTS], const CsLaye
             P[CS_SLOT_LN + k] = live ? (a + b + cp - Gsum) * (o.nmax * sgn * (1.0f - sgn) * m.invN) : 0.f;
         }
     } else {
-        // some row of the wave sits where the linear-space sums underflow: responsibilities in log space (gf_layer_bwd)
-        const MixQ<float> q = cs_mixture(P, o, x, live);
+        // Some row of the wave sits where the linear-space sums under- or overflow.  Rounds 2-3 took the responsibilities in log space here
+        // (gf_layer_bwd: 8 exp / log and 8 divisions per component, after a full cs_mixture); on the SURVEY inputs, two thirds of whose rows
+        // sit beyond 12 sigma after three layers, nearly every wave holds such a row.  Sums scaled by e^{m}, m = distance to the nearest
+        // component, are enough (gf_layer_bwd_bcast, gf_bwd_kernels.hip, has the algebra): every ratio has e^{-m} on both sides.
+        float iw[CS_K], u[CS_K], sgn[CS_K];
+        float mm = INFINITY;
+#pragma unroll
+        for (int k = 0; k < CS_K; ++k) {
+            const float e = Mf::exp_fast(-P[CS_SLOT_LW + k]);
+            const float ae = o.inv_wmax + e;
+            iw[k] = ae * Mf::rcp(o.wmin * ae + 1.0f);
+            sgn[k] = Mf::rcp(1.0f + Mf::exp_fast(-P[CS_SLOT_LN + k]));
+            u[k] = (x - P[CS_SLOT_MEAN + k]) * iw[k];
+            mm = fminf(mm, fabsf(u[k]));
+        }
+        const float em = Mf::exp_fast(-mm);                        // may underflow to 0: the unscaled parts then stand alone
+        float Cu = 0.f, Cq = 0.f, Su = 0.f, Sq = 0.f, Pq = 0.f;
+#pragma unroll
+        for (int k = 0; k < CS_K; ++k) {
+            const float pk = (o.nmin + o.nmax * sgn[k]) * m.invN;
+            const float tp = Mf::exp_fast(mm - fabsf(u[k]));
+            const float h = Mf::rcp(1.0f + tp * em);
+            const float c1 = pk * h, c2 = c1 * tp;
+            if (u[k] >= 0.f) { Cu += c1; Sq += c2; } else { Su += c1; Cq += c2; }
+            Pq += c2 * h * iw[k];
+        }
+        MixQ<float> q;
+        q.cdf = Cu + em * Cq;
+        q.sf = Su + em * Sq;
+        q.lc = Cu > 0.f ? Mf::log_fast(q.cdf) : Mf::log_fast(Cq) - mm;
+        q.ls = Su > 0.f ? Mf::log_fast(q.sf) : Mf::log_fast(Sq) - mm;
+        q.lp = Mf::log_fast(Pq) - mm;
         const IcdfOut<float> s = gf_icdf<float>(o.inv_type, q);
         const IcdfCoef<float> c = gf_icdf_coeffs<float>(o.inv_type, q, s.y);
         const float g_lc = gy * c.Ay + gl * c.AH, g_ls = gy * c.By + gl * c.BH, g_lp = gl;
         const float Gsum = g_lc + g_ls + g_lp;
-        float Nn = 0.f;
-#pragma unroll
-        for (int k = 0; k < CS_K; ++k) Nn += o.nmin + o.nmax / (1.0f + Mf::exp(-P[CS_SLOT_LN + k]));
-        const float lN = Mf::log(Nn);
+        const float r1c = Cu > 0.f ? Mf::rcp(q.cdf) : 0.f, r1s = Su > 0.f ? Mf::rcp(q.sf) : 0.f;      // 1 / cdf, 1 / sf: components on their side
+        const float a2c = Cu > 0.f ? em * r1c : Mf::rcp(Cq), a2s = Su > 0.f ? em * r1s : Mf::rcp(Sq);  // e^{-m} / cdf, e^{-m} / sf
+        const float ap = Mf::rcp(Pq);
 #pragma unroll
         for (int k = 0; k < CS_K; ++k) {
-            const float mu = P[CS_SLOT_MEAN + k], rw = P[CS_SLOT_LW + k], rn = P[CS_SLOT_LN + k];
-            const float e = Mf::exp(-rw);
+            const float e = Mf::exp_fast(-P[CS_SLOT_LW + k]);
             const float ae = o.inv_wmax + e;
-            const float den = o.wmin * ae + 1.0f;
-            const float iw = ae / den, dliw = -e / (ae * den);
-            const float sgm = 1.0f / (1.0f + Mf::exp(-rn));
-            const float nk = o.nmin + o.nmax * sgm;
-            const float lpi = Mf::log(nk) - lN, pik = nk / Nn, dlnn = o.nmax * sgm * (1.0f - sgm) / nk;
-            const float u = (x - mu) * iw;
-            const float t = Mf::exp(-fabsf(u));
-            const float hi = 1.0f / (1.0f + t), lo = t * hi;
-            const bool pos = u >= 0.f;
-            const float sg = pos ? hi : lo, sgc = pos ? lo : hi;
-            const float l1p = Mf::log1p(t);
-            const float lsp = (pos ? 0.f : u) - l1p, lsm = (pos ? -u : 0.f) - l1p;
-            const float rC = Mf::exp(lpi + lsp - q.lc), rS = Mf::exp(lpi + lsm - q.ls), rP = Mf::exp(lpi + lsp + lsm + Mf::log(iw) - q.lp);
-            const float gu = g_lc * rC * sgc - g_ls * rS * sg + g_lp * rP * (sgc - sg);
-            gx += gu * iw;
-            P[CS_SLOT_MEAN + k] = live ? -gu * iw : 0.f;
-            P[CS_SLOT_LW + k] = live ? (gu * u + g_lp * rP) * dliw : 0.f;
-            P[CS_SLOT_LN + k] = live ? ((g_lc * rC + g_ls * rS + g_lp * rP) - pik * Gsum) * dlnn : 0.f;
+            const float dliw = -e * Mf::rcp(ae * (o.wmin * ae + 1.0f));
+            const float pk = (o.nmin + o.nmax * sgn[k]) * m.invN;
+            const float tp = Mf::exp_fast(mm - fabsf(u[k]));
+            const float h = Mf::rcp(1.0f + tp * em);
+            const bool pos = u[k] >= 0.f;
+            const float th = tp * h, w2 = th * h;                  // s (1 - s) = em w2
+            const float sk = pos ? h : em * th;                    // sigma(u)
+            const float pp = w2 * iw[k] * ap;                      // s (1 - s) / (w pdf)
+            const float sc = pos ? h * r1c : th * a2c;             // s / cdf
+            const float ss = pos ? th * a2s : h * r1s;             // (1 - s) / sf
+            const float gu = pk * (w2 * (g_lc * a2c - g_ls * a2s) + g_lp * pp * (1.0f - 2.0f * sk));
+            gx += gu * iw[k];
+            P[CS_SLOT_MEAN + k] = live ? -gu * iw[k] : 0.f;
+            P[CS_SLOT_LW + k] = live ? (gu * u[k] + g_lp * pk * pp) * dliw : 0.f;
+            P[CS_SLOT_LN + k] = live ? (g_lc * sc + g_ls * ss + g_lp * pp - Gsum) * (o.nmax * sgn[k] * (1.0f - sgn[k]) * m.invN) : 0.f;
         }
     }
     // reflections, last first:  y = x - c v, c = 2 (v.x)/(v.v):  g_x = H g,  g_v = -c g - (2 (v.g)/n) x + (4 (v.x)(v.g)/n^2) v

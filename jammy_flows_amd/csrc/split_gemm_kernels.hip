@@ -453,7 +453,8 @@ template <int NP> __global__ void __launch_bounds__(256, 2) wgrad_split_kernel(c
 static int64_t ws_splits(int64_t B, int N) {
     if (N < 1 || B < 1) return 1;                                  // (the entry points reject such shapes; the query must not divide by zero)
     const int64_t cols = (N + WS_NW - 1) / WS_NW;
-    int64_t s = (1024 + cols - 1) / cols;                          // ~2 resident rounds of workgroups
+    int64_t s = 512 / cols;                                        // ONE resident round (2 workgroups per CU): every slab is 4 N K bytes written and read
+    if (s < 1) s = 1;                                              // again by jf_slab_sum (round 4: two rounds -> one, 205 -> 102 slabs of 295 KB for C3)
     const int64_t max_s = (B + 511) / 512;                         // at least 512 rows per split
     if (s > max_s) s = max_s;
     if (s > 65535) s = 65535;
