@@ -529,7 +529,8 @@ def other_direction(args, W, rank, local_rank, world):
                     import gc
                     gc.collect()
                     torch.cuda.synchronize(dev)
-                    gopt = torch.optim.Adam(pdf.parameters(), lr=1e-4, capturable=True)
+                    gopt = (torch.optim.Adam(pdf.parameters(), lr=1e-4, capturable=True) if args.torch_adam
+                            else jf_optim.Adam(pdf.parameters(), lr=1e-4, capturable=True))
 
                     def gstep():
                         gopt.zero_grad(set_to_none=True)
@@ -557,7 +558,8 @@ def other_direction(args, W, rank, local_rank, world):
                     torch.cuda.synchronize(dev)
                     gdt = time.perf_counter() - t0
                     extra["hip_graph_replay"] = {"ms_per_step": 1e3 * gdt / args.steps, "value": total_rows * args.steps / gdt, "loss": float(gloss.item()),
-                                                 "note": "forward + backward + Adam(capturable=True) captured once in a HIP graph, replayed (measured after the timed region)"}
+                                                 "optimizer": "torch.optim.Adam(capturable=True)" if args.torch_adam else "jammy_flows_amd.optim.Adam(capturable=True): step count on the device",
+                                                 "note": "forward + backward + Adam captured once in a HIP graph, replayed (measured after the timed region)"}
                 except Exception as e:          # a capture failure must not cost the timed line
                     extra["hip_graph_replay"] = {"error": repr(e)[:200]}
     if world > 1:

@@ -647,6 +647,11 @@ int jf_combine_rows_f64(const jf_row_list* ld, const jf_row_list* blp, int64_t B
 typedef struct jf_adam_tensor { void* param; const void* grad; void* exp_avg; void* exp_avg_sq; int64_t n; } jf_adam_tensor;
 int jf_adam_step_f32(const jf_adam_tensor* tensors, int32_t n_tensors, double lr, double beta1, double beta2, double eps, int64_t step, void* stream);
 int jf_adam_step_f64(const jf_adam_tensor* tensors, int32_t n_tensors, double lr, double beta1, double beta2, double eps, int64_t step, void* stream);
+/* the same update with the step count read from DEVICE memory at execution time (*step_dev >= 1, already incremented for this step): a launch
+ * recorded in a HIP graph then replays with the count of the replay (torch.optim.Adam(capturable=True) keeps its step on the device for the
+ * same reason).  The caller increments *step_dev on the same stream before the launch. */
+int jf_adam_step_dev_f32(const jf_adam_tensor* tensors, int32_t n_tensors, double lr, double beta1, double beta2, double eps, const int64_t* step_dev, void* stream);
+int jf_adam_step_dev_f64(const jf_adam_tensor* tensors, int32_t n_tensors, double lr, double beta1, double beta2, double eps, const int64_t* step_dev, void* stream);
 /* out = a + b (n elements) */
 int jf_add_rows_f32(const float* a, const float* b, int64_t n, float* out, void* stream);
 int jf_add_rows_f64(const double* a, const double* b, int64_t n, double* out, void* stream);

@@ -137,6 +137,7 @@ _SIGNATURES = {
     "jf_add_rows": [_P, _P, _I64, _P, _P],
     "jf_gf_chain_inv_cot": [_P, _I64, _P, _I64, _I32, _I64, _I32, _I32, ctypes.POINTER(jf_gf_layer), _P, _I64, _P, _I64, _P, _I64, _P, _P],
     "jf_adam_step": [ctypes.POINTER(jf_adam_tensor), _I32, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, _I64, _P],
+    "jf_adam_step_dev": [ctypes.POINTER(jf_adam_tensor), _I32, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, _P, _P],
     "jf_combine_rows": [ctypes.POINTER(jf_row_list), ctypes.POINTER(jf_row_list), _I64, _P, _P, _P, _P],
     "jf_activation_bwd": [_P, _P, _I64, _I32, _P, _P],
     "jf_mlp2": [_P, _I64, _P, _I64, _P, _P, _I64, _P, _I64, _I32, _I32, _I32, _P, _I64, _P],

@@ -299,8 +299,34 @@ template <typename T> __global__ void __launch_bounds__(256) adam_kernel(const A
     const T denom = M<T>::sqrt(v) * (T)inv_sqrt_bc2 + (T)eps;
     t.p[k][i] = t.p[k][i] - (T)step_size * (m / denom);
 }
-template <typename T> static int adam_step(const jf_adam_tensor* tensors, int32_t n, double lr, double b1, double b2, double eps, int64_t step, void* stream) {
-    if (!tensors || n < 1 || n > JF_ADAM_MAX_TENSORS || step < 1 || !(lr >= 0) || !(b1 >= 0 && b1 < 1) || !(b2 >= 0 && b2 < 1) || !(eps >= 0)) return JF_ERR_BADARG;
+// the step count read from device memory (a launch recorded in a HIP graph replays with the count of the replay, not of the capture): the bias
+// corrections are computed by the first thread of every block
+template <typename T> __global__ void __launch_bounds__(256) adam_dev_kernel(const AdamTable<T> t, double lr, double b1, double b2, double eps,
+                                                                              const int64_t* __restrict__ step_dev) {
+    __shared__ double corr[2];
+    if (threadIdx.x == 0) {
+        const double step = (double)(*step_dev < 1 ? (int64_t)1 : *step_dev);
+        corr[0] = lr / (1.0 - pow(b1, step));
+        corr[1] = 1.0 / sqrt(1.0 - pow(b2, step));
+    }
+    __syncthreads();
+    const double step_size = corr[0], inv_sqrt_bc2 = corr[1];
+    int k = 0;
+    while (k + 1 < t.count && (int)blockIdx.x >= t.first_block[k + 1]) ++k;
+    const int64_t i = (int64_t)((int)blockIdx.x - t.first_block[k]) * 256 + threadIdx.x;
+    if (i >= t.n[k]) return;
+    const T g = t.g[k][i];
+    T m = t.m[k][i], v = t.v[k][i];
+    m = m + (g - m) * (T)(1.0 - b1);
+    v = v * (T)b2 + (T)(1.0 - b2) * g * g;
+    t.m[k][i] = m; t.v[k][i] = v;
+    const T denom = M<T>::sqrt(v) * (T)inv_sqrt_bc2 + (T)eps;
+    t.p[k][i] = t.p[k][i] - (T)step_size * (m / denom);
+}
+template <typename T> static int adam_step(const jf_adam_tensor* tensors, int32_t n, double lr, double b1, double b2, double eps, int64_t step,
+                                           const int64_t* step_dev, void* stream) {
+    if (!tensors || n < 1 || n > JF_ADAM_MAX_TENSORS || (!step_dev && step < 1) || !(lr >= 0) || !(b1 >= 0 && b1 < 1) || !(b2 >= 0 && b2 < 1) || !(eps >= 0))
+        return JF_ERR_BADARG;
     AdamTable<T> t{};
     int blocks = 0;
     for (int i = 0; i < n; ++i) {
@@ -312,6 +338,10 @@ template <typename T> static int adam_step(const jf_adam_tensor* tensors, int32_
     }
     t.first_block[n] = blocks; t.count = n;
     if (blocks == 0) return JF_OK;
+    if (step_dev) {
+        jf::launch(adam_dev_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, t, lr, b1, b2, eps, step_dev);
+        return check_launch();
+    }
     const double bc1 = 1.0 - pow(b1, (double)step), bc2 = 1.0 - pow(b2, (double)step);
     jf::launch(adam_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, t, lr / bc1, b1, b2, 1.0 / sqrt(bc2), eps);
     return check_launch();
@@ -338,8 +368,14 @@ int jf_device_math_f32(const float* x, int64_t n, int32_t fn, float* out, void* 
 int jf_device_math_f64(const double* x, int64_t n, int32_t fn, double* out, void* s) { return jf::device_math<double>(x, n, fn, out, s); }
 int jf_combine_rows_f32(const jf_row_list* ld, const jf_row_list* blp, int64_t B, float* lo, float* bo, float* to, void* s) { return jf::combine_rows<float>(ld, blp, B, lo, bo, to, s); }
 int jf_combine_rows_f64(const jf_row_list* ld, const jf_row_list* blp, int64_t B, double* lo, double* bo, double* to, void* s) { return jf::combine_rows<double>(ld, blp, B, lo, bo, to, s); }
-int jf_adam_step_f32(const jf_adam_tensor* t, int32_t n, double lr, double b1, double b2, double eps, int64_t step, void* s) { return jf::adam_step<float>(t, n, lr, b1, b2, eps, step, s); }
-int jf_adam_step_f64(const jf_adam_tensor* t, int32_t n, double lr, double b1, double b2, double eps, int64_t step, void* s) { return jf::adam_step<double>(t, n, lr, b1, b2, eps, step, s); }
+int jf_adam_step_f32(const jf_adam_tensor* t, int32_t n, double lr, double b1, double b2, double eps, int64_t step, void* s) { return jf::adam_step<float>(t, n, lr, b1, b2, eps, step, nullptr, s); }
+int jf_adam_step_f64(const jf_adam_tensor* t, int32_t n, double lr, double b1, double b2, double eps, int64_t step, void* s) { return jf::adam_step<double>(t, n, lr, b1, b2, eps, step, nullptr, s); }
+int jf_adam_step_dev_f32(const jf_adam_tensor* t, int32_t n, double lr, double b1, double b2, double eps, const int64_t* step_dev, void* s) {
+    return step_dev ? jf::adam_step<float>(t, n, lr, b1, b2, eps, 0, step_dev, s) : JF_ERR_BADARG;
+}
+int jf_adam_step_dev_f64(const jf_adam_tensor* t, int32_t n, double lr, double b1, double b2, double eps, const int64_t* step_dev, void* s) {
+    return step_dev ? jf::adam_step<double>(t, n, lr, b1, b2, eps, 0, step_dev, s) : JF_ERR_BADARG;
+}
 int jf_add_rows_f32(const float* a, const float* b, int64_t n, float* out, void* s) { return jf::add_rows<float>(a, b, n, out, s); }
 int jf_add_rows_f64(const double* a, const double* b, int64_t n, double* out, void* s) { return jf::add_rows<double>(a, b, n, out, s); }
 int jf_conditioning_rows_f32(const jf_cond_segment* g, int32_t n, int64_t B, float* out, int64_t os, void* s) {

@@ -308,8 +308,8 @@ __global__ void __launch_bounds__(128) mlp_hidden_bwd_kernel(const T* __restrict
 
 static int64_t mlp2_small_slabs(int64_t B) {
     int64_t s = (B + 63) / 64;                                     // >= 64 rows per workgroup, <= 4096 workgroups
-    if (s > 4096) s = 4096;
-    return s < 1 ? 1 : s;
+    if (s > 4096) s = 4096;                                        // (round 4: 2048 / 1024 / 512 slabs make both kernels slower -- 0.081 -> 0.097 / 0.110 /
+    return s < 1 ? 1 : s;                                          //  0.163 ms at 2^18 rows -- and leave the two slab-sum launches where they are)
 }
 
 template <typename T>
