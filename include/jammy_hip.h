@@ -121,6 +121,20 @@ int jf_gf_chain_fwd_f32(const float* z, int64_t z_stride, const float* log_det_i
 int jf_gf_chain_fwd_f64(const double* z, int64_t z_stride, const double* log_det_in, const double* params, int64_t param_stride,
                         int32_t param_batch, int64_t B, int32_t D, int32_t n_layers, const jf_gf_layer* layers, double* x_out,
                         int64_t x_out_stride, double* log_det_out, int64_t* bins, int64_t bins_stride, int32_t* status, void* stream);
+/* jf_gf_chain_fwd with a START TABLE for broadcast parameters (param_batch == 1): every (layer, coordinate) then inverts one fixed monotone
+ * function x(z) for all rows (gaussianization_flow.py:921 calls the bisection / Newton solver per row regardless).  A first launch solves it on
+ * 512 intervals of z (+-20 for isigmoid stages, +-8 for the normal-type stages) and keeps each interval's cubic Hermite polynomial in `table`
+ * (jf_gf_chain_fwd_table_elems(D, n_layers) elements of the function's precision, scratch of this call); the chain launch starts the
+ * reference's Newton stage from the polynomial's value wherever it reproduces the solved interval midpoint to 2e-5, and solves every other
+ * lane as jf_gf_chain_fwd does.  Same results to the solver's tolerance, fewer Newton row-steps in `status`.  Ten-component layers at default
+ * options use the table; other layers, per-sample parameters and the general-option kernel ignore it.  Worth it from ~10^4 rows. */
+int64_t jf_gf_chain_fwd_table_elems(int32_t D, int32_t n_layers);
+int jf_gf_chain_fwd_tab_f32(const float* z, int64_t z_stride, const float* log_det_in, const float* params, int64_t param_stride,
+                            int32_t param_batch, int64_t B, int32_t D, int32_t n_layers, const jf_gf_layer* layers, float* x_out,
+                            int64_t x_out_stride, float* log_det_out, int64_t* bins, int64_t bins_stride, int32_t* status, float* table, void* stream);
+int jf_gf_chain_fwd_tab_f64(const double* z, int64_t z_stride, const double* log_det_in, const double* params, int64_t param_stride,
+                            int32_t param_batch, int64_t B, int32_t D, int32_t n_layers, const jf_gf_layer* layers, double* x_out,
+                            int64_t x_out_stride, double* log_det_out, int64_t* bins, int64_t bins_stride, int32_t* status, double* table, void* stream);
 
 /* Backward of jf_gf_chain_inv_* (classic stretch): vector-Jacobian product for upstream gradients g_x_out (B, D; nullable = 0),
  * g_log_det (B; nullable) and g_base_logp (B; nullable) of the three outputs -- what torch.autograd computes by replaying

@@ -126,6 +126,7 @@ _SIGNATURES = {
     "jf_linear_wgrad": [_P, _I64, _P, _I64, _I64, _I32, _I32, _P, _P, _P],
     "jf_amlp2": [_P, _I64, _P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _I32, _P, _I64, _P],
     "jf_gf_chain_fwd": [_P, _I64, _P, _P, _I64, _I32, _I64, _I32, _I32, ctypes.POINTER(jf_gf_layer), _P, _I64, _P, _P, _I64, _P, _P],
+    "jf_gf_chain_fwd_tab": [_P, _I64, _P, _P, _I64, _I32, _I64, _I32, _I32, ctypes.POINTER(jf_gf_layer), _P, _I64, _P, _P, _I64, _P, _P, _P],
     "jf_linear": [_P, _I64, _P, _I64, _P, _I64, _I32, _I32, _I32, _P, _I64, _P],
     "jf_normal_logp": [_P, _I64, _I64, _I32, _P, _P, _P],
     "jf_slab_sum": [_P, _I64, _P, _P, _I64, _P, _I32, _I32, _P],
@@ -179,6 +180,7 @@ _SIGNATURES_SINGLE = {
     "jf_linear_wgrad_splits_f32": ([_I64, _I32, _I32], ctypes.c_int64),
     "jf_linear_wgrad_splits_f64": ([_I64, _I32, _I32], ctypes.c_int64),
     "jf_gf_chain_inv_bwd_partials": ([_I64, _I32], ctypes.c_int64),
+    "jf_gf_chain_fwd_table_elems": ([_I32, _I32], ctypes.c_int64),
     "jf_linear_split_packed_bytes": ([_I32, _I32], ctypes.c_int64),
     "jf_mlp2_small_bwd_slabs": ([_I64], ctypes.c_int64),
     "jf_mlp2_i8_packed_bytes": ([_I32, _I32], ctypes.c_int64),
@@ -549,6 +551,11 @@ def gf_layer_array(structs):
 BINS_LOG = None
 
 
+# sampling with broadcast parameters: from this many rows on the solves start from a table of the layer's inverse functions (the table costs
+# 1025 solves per layer and coordinate: ~1000 rows' worth of a four-layer chain); JF_FWD_TABLE_MIN_ROWS overrides, 0 = never
+FWD_TABLE_MIN_ROWS = int(os.environ.get("JF_FWD_TABLE_MIN_ROWS", "8192")) or (1 << 62)
+
+
 def gf_chain(direction, x, log_det, params, layer_array, n_layers, D, x_out=None, base_logp_in=None, want_base_logp=False, status=None):
     """run a chain of g layers.  direction 'inv' (log-prob) or 'fwd' (sampling).
     x (B, D) view (row stride arbitrary), log_det (B,) or None, params (1|B, P).  Returns (x_out, log_det_out[, base_logp])."""
@@ -586,6 +593,14 @@ def gf_chain(direction, x, log_det, params, layer_array, n_layers, D, x_out=None
                 (_ptr(x), x.stride(0), _ptr(log_det), _ptr(params), params.stride(0), pb, B, D, n_layers, layer_array, _ptr(x_out),
                  x_out.stride(0), _ptr(ld_out), _ptr(base_logp_in), _ptr(blp_out), _ptr(bins), bs, _ptr(status)), dev)
         return (x_out, ld_out, blp_out) if want_base_logp else (x_out, ld_out)
+    if pb == 1 and B >= FWD_TABLE_MIN_ROWS:
+        # row-independent parameters: every (layer, coordinate) inverts one fixed function for all rows -- the library tabulates it first and
+        # the solves start from the interpolated value (jf_gf_chain_fwd_tab); the table is a temporary of this call
+        table = torch.empty((int(lib().jf_gf_chain_fwd_table_elems(D, n_layers)),), dtype=x.dtype, device=x.device)
+        _launch("jf_gf_chain_fwd_tab" + suf, "bcast",
+                (_ptr(x), x.stride(0), _ptr(log_det), _ptr(params), params.stride(0), pb, B, D, n_layers, layer_array, _ptr(x_out), x_out.stride(0),
+                 _ptr(ld_out), _ptr(bins), bs, _ptr(status), _ptr(table)), dev)
+        return x_out, ld_out
     _launch("jf_gf_chain_fwd" + suf, "bcast" if pb == 1 else "per-sample",
             (_ptr(x), x.stride(0), _ptr(log_det), _ptr(params), params.stride(0), pb, B, D, n_layers, layer_array, _ptr(x_out), x_out.stride(0),
              _ptr(ld_out), _ptr(bins), bs, _ptr(status)), dev)

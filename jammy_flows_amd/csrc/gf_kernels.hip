@@ -40,7 +40,80 @@ template <typename T> struct GfChainArgs {
     // then a division by the stage's derivative), i.e. cot_out = J^{-T} cot_in for the chain's Jacobian J = dy/dx (jf_gf_chain_inv_cot)
     const T* cot_in; int64_t cis;
     T* cot_out; int64_t cos;
+    // sampling direction, broadcast parameters only: interpolation table of every (layer, coordinate)'s inverse x(z) (gf_fwd_table_kernel), or null
+    T* table;
 };
+
+// ---- the start table of the broadcast sampler.  With row-independent parameters the solve of (layer l, coordinate d) inverts ONE fixed monotone
+// function for every row: x_{l,d}(z).  gf_fwd_table_kernel solves it on GT_N + 1 knots of z in [-zmax, zmax] (plus the interval midpoints),
+// keeps each interval's cubic Hermite polynomial (values and slopes dx/dz = 1 / (dy/dx) at its ends) and marks the intervals whose polynomial
+// misses the solved midpoint by more than 2e-5, or over which x(z) is far from linear (gaps between distant components, where x(z) is nearly a step).  A lane of the sampler whose z
+// falls into a good interval starts the reference's Newton stage from the polynomial's value and skips the approach phase (4-6 of its ~9
+// mixture evaluations); every other lane takes the approach phase as before.  16 B per interval (float32): 128 KB for C3's block 0, L2-resident.
+constexpr int GT_N = 512;
+template <typename T> __host__ __device__ inline T gt_zmax(int inv_type) { return inv_type == JF_GF_ISIGMOID ? T(20) : T(8); }
+template <typename T> __host__ __device__ inline bool gt_layer_ok(const GfLayerDev<T>& o) {
+    return o.K == CS_K && o.fit_norm && o.stretch == JF_GF_STRETCH_CLASSIC;
+}
+
+// grid (layer x coordinate, GT_N / GT_CH): a workgroup of 192 threads solves the 65 knots (wave 0 + the first lane of wave 2) and 64 midpoints
+// (wave 1) of GT_CH = 64 intervals -- one solve per thread, so the table costs one solve's latency, not a serial walk over the knots
+constexpr int GT_CH = 64;
+template <typename T> __global__ void __launch_bounds__(192) gf_fwd_table_kernel(const GfChainArgs<T> a) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    T* row = reinterpret_cast<T*>(smem_raw);
+    T* xs = row + a.tile_stride;                          // [GT_CH + 1] solutions at the knots
+    T* hm = xs + GT_CH + 1;                               // [GT_CH + 1] h dx/dz at the knots
+    T* xm = hm + GT_CH + 1;                               // [GT_CH] solutions at the interval midpoints
+    const int tid = threadIdx.x;
+    const int D = a.D, l = blockIdx.x / D, d = blockIdx.x - l * D, i0 = blockIdx.y * GT_CH;
+    const GfLayerDev<T> o = a.L[l];
+    T* out = a.table + ((size_t)blockIdx.x * GT_N + i0) * 4;
+    if (!gt_layer_ok<T>(o)) {                              // block-uniform: the sampler does not consult the table for this layer
+        for (int i = tid; i < GT_CH * 4; i += 192) out[i] = T(NAN);
+        return;
+    }
+    for (int j = tid; j < o.n_params; j += 192) row[j] = a.params[o.col0 + j];
+    __syncthreads();
+    if (tid == 0) gf_derive_column<T>(row, o, D, d);
+    __syncthreads();
+    const T zmax = gt_zmax<T>(o.inv_type), h = T(2) * zmax / T(GT_N);
+    const bool knot = tid < GT_CH || tid == 2 * GT_CH, mid = tid >= GT_CH && tid < 2 * GT_CH;
+    if (knot || mid) {                                     // wave-uniform except for the last wave's single lane
+        T R[CS_SLOTS];
+#pragma unroll
+        for (int k = 0; k < CS_K; ++k) {
+            R[CS_SLOT_MEAN + k] = row[o.off_mean + k * D + d];
+            R[CS_SLOT_LW + k] = row[o.off_lw + k * D + d];
+            R[CS_SLOT_LN + k] = row[o.off_ln + k * D + d];
+        }
+        const int i = knot ? (tid < GT_CH ? tid : GT_CH) : tid - GT_CH;
+        const T z = -zmax + (T(i0 + i) + (mid ? T(0.5) : T(0))) * h;
+        CsSolveInfo info;
+        T logd;
+        T x = cs_solve<T>(R, o.inv_type, true, z, true, false, nullptr, [](T v) { return v; }, [](T v) { return v; }, &info, &logd);
+        if (info.nonconv || info.nonfinite) x = T(NAN);
+        if (knot) { xs[i] = x; hm[i] = h * M<T>::exp(-logd); }
+        else xm[i] = x;
+    }
+    __syncthreads();
+    if (tid < GT_CH) {
+        const int i = tid;
+        const T dx = xs[i + 1] - xs[i];
+        T c0 = xs[i];
+        const T c1 = hm[i], c2 = T(3) * dx - T(2) * hm[i] - hm[i + 1], c3 = T(-2) * dx + hm[i] + hm[i + 1];
+        const T pm = c0 + T(0.5) * c1 + T(0.25) * c2 + T(0.125) * c3;
+        const T tol = T(2e-5) * M<T>::max(T(1), M<T>::abs(xm[i]));
+        // usable: the polynomial reproduces the solved midpoint AND x(z) is close to linear over the interval (both end slopes within a factor
+        // 1.25 of the secant) -- on the flank of a plateau (a gap between distant components, where x(z) is nearly a step) a cubic can hit the
+        // midpoint and still be off elsewhere, and a Newton stage started there ended above the reference's convergence threshold on 11 rows of
+        // 40 000 in the rough-mixture test; those intervals go to the approach phase
+        const bool regular = dx > T(0) && hm[i] > T(0) && hm[i + 1] > T(0) && hm[i] < T(1.25) * dx && dx < T(1.25) * hm[i] && hm[i + 1] < T(1.25) * dx &&
+                             dx < T(1.25) * hm[i + 1];
+        if (!(M<T>::abs(pm - xm[i]) <= tol) || !regular || !M<T>::finite(c2) || !M<T>::finite(c3)) c0 = T(NAN);     // (false also for a NaN anywhere)
+        out[4 * i + 0] = c0; out[4 * i + 1] = c1; out[4 * i + 2] = c2; out[4 * i + 3] = c3;
+    }
+}
 
 template <int G> struct Log2 { static constexpr int v = (G == 1) ? 0 : (G == 2) ? 1 : (G == 4) ? 2 : (G == 8) ? 3 : (G == 16) ? 4 : 5; };
 
@@ -150,8 +223,23 @@ __global__ void __launch_bounds__(BCAST ? 256 : 64, sizeof(T) == 8 ? 2 : 4) gf_c
                         R[CS_SLOT_LN + k] = p[o.off_ln + k * D];
                     }
                     T slogd;
+                    bool have = false;
+                    T xstart = T(0);
+                    if constexpr (BCAST) {
+                        if (a.table != nullptr) {                  // uniform
+                            const T zmax = gt_zmax<T>(o.inv_type);
+                            const T tq = (x + zmax) * (T(GT_N) / (T(2) * zmax));
+                            if (tq >= T(0) && tq < T(GT_N)) {
+                                const int iq = (int)tq;
+                                const T fr = tq - T(iq);
+                                const T* c = a.table + ((size_t)(l * D + d) * GT_N + iq) * 4;
+                                xstart = c[0] + fr * (c[1] + fr * (c[2] + fr * c[3]));
+                                have = live && M<T>::finite(xstart);
+                            }
+                        }
+                    }
                     x = cs_solve<T>(R, o.inv_type, live, x, row_valid, leader, a.status, [](T v) { return group_sum<T, G>(v); },
-                                    [](T v) { return group_max<T, G>(v); }, nullptr, &slogd);
+                                    [](T v) { return group_max<T, G>(v); }, nullptr, &slogd, have, xstart);
                     ld -= group_sum<T, G>(live ? slogd : T(0));
                 } else {
                     x = gfg_solve<T, G>(p, o, D, live, x, row_valid, leader, a.status);
@@ -548,7 +636,7 @@ static int gf_chain_inv_cot(const T* x, int64_t xs, const T* params, int64_t ps,
 template <typename T>
 static int gf_chain_fwd(const T* z, int64_t zs, const T* ld_in, const T* params, int64_t ps, int32_t pb, int64_t B, int32_t D, int32_t n_layers,
                         const jf_gf_layer* layers, T* x_out, int64_t xos, T* ld_out, int64_t* bins, int64_t bins_stride, int32_t* status,
-                        void* stream) {
+                        void* stream, T* table = nullptr) {
     if (!z || !params || !x_out || !ld_out) return JF_ERR_BADARG;
     GfChainArgs<T> a{};
     size_t lds = 0; bool bcast = false, ext = false;
@@ -556,6 +644,17 @@ static int gf_chain_fwd(const T* z, int64_t zs, const T* ld_in, const T* params,
     if (rc != JF_OK) return rc;
     a.x = z; a.xs = zs; a.ld_in = ld_in; a.x_out = x_out; a.xos = xos; a.ld_out = ld_out; a.blp_in = nullptr; a.blp_out = nullptr; a.status = status;
     a.bins = bins; a.bins_stride = bins_stride;
+    if (table != nullptr && bcast && !ext && B > 0) {          // (per-sample parameters / the general-option kernel: the table is not used)
+        bool any = false;
+        for (int l = 0; l < n_layers; ++l) any = any || gt_layer_ok<T>(a.L[l]);
+        if (any) {
+            a.table = table;
+            const size_t tl = ((size_t)a.tile_stride + 3 * (GT_CH + 1)) * sizeof(T);
+            jf::launch(gf_fwd_table_kernel<T>, dim3((unsigned)(n_layers * D), GT_N / GT_CH), dim3(192), tl, (hipStream_t)stream, a);
+            rc = check_launch();
+            if (rc != JF_OK) return rc;
+        }
+    }
     return launch<T, true>(a, D, bcast, ext, lds, (hipStream_t)stream);
 }
 
@@ -599,5 +698,19 @@ int jf_gf_chain_fwd_f32(const float* z, int64_t zs, const float* ld_in, const fl
 int jf_gf_chain_fwd_f64(const double* z, int64_t zs, const double* ld_in, const double* p, int64_t ps, int32_t pb, int64_t B, int32_t D, int32_t n,
                         const jf_gf_layer* L, double* xo, int64_t xos, double* ldo, int64_t* bins, int64_t bs, int32_t* st, void* s) {
     return jf::gf_chain_fwd<double>(z, zs, ld_in, p, ps, pb, B, D, n, L, xo, xos, ldo, bins, bs, st, s);
+}
+int64_t jf_gf_chain_fwd_table_elems(int32_t D, int32_t n) {
+    if (D < 1 || D > jf::JF_MAX_D_G || n < 1 || n > JF_MAX_CHAIN) return JF_ERR_BADARG;
+    return (int64_t)D * n * jf::GT_N * 4;
+}
+int jf_gf_chain_fwd_tab_f32(const float* z, int64_t zs, const float* ld_in, const float* p, int64_t ps, int32_t pb, int64_t B, int32_t D, int32_t n,
+                            const jf_gf_layer* L, float* xo, int64_t xos, float* ldo, int64_t* bins, int64_t bs, int32_t* st, float* table, void* s) {
+    if (!table) return JF_ERR_BADARG;
+    return jf::gf_chain_fwd<float>(z, zs, ld_in, p, ps, pb, B, D, n, L, xo, xos, ldo, bins, bs, st, s, table);
+}
+int jf_gf_chain_fwd_tab_f64(const double* z, int64_t zs, const double* ld_in, const double* p, int64_t ps, int32_t pb, int64_t B, int32_t D, int32_t n,
+                            const jf_gf_layer* L, double* xo, int64_t xos, double* ldo, int64_t* bins, int64_t bs, int32_t* st, double* table, void* s) {
+    if (!table) return JF_ERR_BADARG;
+    return jf::gf_chain_fwd<double>(z, zs, ld_in, p, ps, pb, B, D, n, L, xo, xos, ldo, bins, bs, st, s, table);
 }
 }

@@ -178,27 +178,32 @@ template <typename T> __device__ __forceinline__ MixQ<T> cs_mixture_derived(cons
 struct CsSolveInfo { int steps; bool nonconv, nonfinite; };
 template <typename T, typename RSUM, typename RMAX>
 __device__ __forceinline__ T cs_solve(const T (&P)[CS_SLOTS], int inv_type, bool live, T z, bool row_valid, bool leader, int32_t* status,
-                                      RSUM rsum, RMAX rmax, CsSolveInfo* info = nullptr, T* logd_out = nullptr) {
+                                      RSUM rsum, RMAX rmax, CsSolveInfo* info = nullptr, T* logd_out = nullptr, bool have_start = false, T start = T(0)) {
     using Mf = M<T>;
     // ---- approach phase (gf_approach, jf_gf.h): float64 rows run it in float32 on a float copy of the derived row, as they ran the bisection
+    // have_start (per lane): the caller knows the solution to ~1e-3 already (broadcast parameters: the interpolated table of jf_gf_chain_fwd_tab,
+    // gf_kernels.hip) -- the lane skips the approach phase; a wave none of whose lanes needs it skips the phase altogether
     using F = typename std::conditional<sizeof(T) == 8, float, T>::type;
-    F PF[CS_SLOTS];
+    T x = have_start ? start : T(0);                               // (a lane without a start may have been handed a NaN: shadow lanes keep 0)
+    if (__any(live && !have_start)) {
+        F PF[CS_SLOTS];
 #pragma unroll
-    for (int k = 0; k < CS_SLOTS; ++k) PF[k] = k < 3 * CS_K ? (F)P[k] : F(0);
-    // start: the mixture's mean moved by z mean-widths -- exact for one component of an isigmoid stage (x = mu + w z), and for a normal-type
-    // stage with the classic logistic / normal match x = mu + 1.702 w z
-    F xf = F(0), wbar = F(0);
+        for (int k = 0; k < CS_SLOTS; ++k) PF[k] = k < 3 * CS_K ? (F)P[k] : F(0);
+        // start: the mixture's mean moved by z mean-widths -- exact for one component of an isigmoid stage (x = mu + w z), and for a normal-type
+        // stage with the classic logistic / normal match x = mu + 1.702 w z
+        F xf = F(0), wbar = F(0);
 #pragma unroll
-    for (int k = 0; k < CS_K; ++k) {
-        xf += PF[CS_SLOT_LN + k] * PF[CS_SLOT_MEAN + k];
-        wbar += PF[CS_SLOT_LN + k] * M<F>::rcp(PF[CS_SLOT_LW + k]);
+        for (int k = 0; k < CS_K; ++k) {
+            xf += PF[CS_SLOT_LN + k] * PF[CS_SLOT_MEAN + k];
+            wbar += PF[CS_SLOT_LN + k] * M<F>::rcp(PF[CS_SLOT_LW + k]);
+        }
+        {
+            const F zc = M<F>::min(M<F>::max((F)z, F(-8)), F(8));
+            xf += wbar * zc * (inv_type != JF_GF_ISIGMOID ? F(1.702) : F(1));
+        }
+        xf = gf_approach<F>([&](F xx) { return cs_mixture_derived<F>(PF, xx); }, inv_type != JF_GF_ISIGMOID, (F)z, xf, live && !have_start);
+        if (!have_start) x = (T)xf;
     }
-    {
-        const F zc = M<F>::min(M<F>::max((F)z, F(-8)), F(8));
-        xf += wbar * zc * (inv_type != JF_GF_ISIGMOID ? F(1.702) : F(1));
-    }
-    xf = gf_approach<F>([&](F xx) { return cs_mixture_derived<F>(PF, xx); }, inv_type != JF_GF_ISIGMOID, (F)z, xf, live);
-    T x = (T)xf;
     bool active = row_valid;
     T ferr = T(0), prev = T(INFINITY);
     bool nonfinite = false;

@@ -689,7 +689,9 @@ def test_full_size_stress_20_launches_other_paths(case):
     assert bool((torch.isfinite(got) == fin).all()), case
     err = ((got - small).abs() / (1.0 + small.abs()))[:, fin].max().item()
     # (C3 float64: the 192-row batch takes the exact float64 MLP kernel, the big one the int8-slice kernel -- 3e-10 apart)
-    tol = 2e-6 if dtype == torch.float32 else (1e-8 if case == "c3_logprob_f64" else 1e-12)
+    # (C3 sampling: the big batch starts block 0's Newton stage from the start table -- jf_gf_chain_fwd_tab, from 8192 rows on -- and the 192-row
+    #  batch from the approach phase: both stop inside the stage's float32 stopping rule, 2.5e-7 .. 1e-4 of a coordinate)
+    tol = (1e-4 if sample else 2e-6) if dtype == torch.float32 else (1e-8 if case == "c3_logprob_f64" else 1e-12)
     assert err < tol, "%s: replicas deviate from the small batch by %.3g" % (case, err)
 
 
@@ -1149,3 +1151,111 @@ def test_full_size_sampling_round_trip_in_the_benchmarked_precision(name, dtype,
     frac = float(good.float().mean())
     print("%s %s: round trip at %d rows: %d rows outside %.0e, non-converged %d" % (name, dtype, n, int((~good).sum()), tol, words["nonconverged"]))
     assert frac > 0.999, frac
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-9), (torch.float32, 1e-4)])
+@pytest.mark.parametrize("case", ["rough_isigmoid", "rough_normal", "three_components"])
+def test_broadcast_sampler_start_table_equals_the_plain_solves(dtype, tol, case):
+    """jf_gf_chain_fwd_tab (round 4): with broadcast parameters the sampler tabulates every (layer, coordinate)'s inverse function and starts the
+    reference's Newton stage from the interpolated value.  Against the same launch without the table (JF entry jf_gf_chain_fwd): the samples and
+    log-dets agree to the solver's tolerance, the convergence flags are the same, the Newton row-steps drop, decode -> encode round-trips; on
+    base points out to +-30 (beyond the table: those lanes take the approach phase) and on rough mixtures, whose gaps between distant
+    components are intervals the table marks as unusable.  Layers with other than ten components ignore the table (same bits)."""
+    import jammy_flows_amd
+    from jammy_flows_amd import _hip
+    torch.manual_seed(3)
+    B = 40000
+    D = 3
+    opts = {"g": {"inverse_function_type": "isigmoid" if case != "rough_normal" else "inormal_partly_precise", "replace_first_sigmoid_with_icdf": 0}}
+    if case == "three_components":
+        opts["g"]["num_kde"] = 3
+    pdf = jammy_flows_amd.pdf("e%d" % D, "ggg", options_overwrite=opts).to(dtype).cuda()
+    layers = list(pdf.layer_list[0])
+    larr = _hip.gf_layer_array([l.c_struct() for l in layers])
+    n = sum(l.total_param_num for l in layers)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    params = torch.randn((1, n), dtype=torch.float64, device="cuda", generator=g)
+    col = 0
+    for l in layers:
+        c = l.c_struct()
+        col += (D if c.model_offset else 0) + c.hh_iter * D
+        kd = c.num_kde * D
+        params[:, col:col + kd] *= 3.0                          # means over +-6: gaps between components
+        params[:, col + kd:col + 2 * kd] *= 1.5                 # widths ~0.1 .. ~10
+        col += 3 * kd
+    params = params.to(dtype)
+    g = torch.Generator(device="cuda").manual_seed(9)
+    z = torch.randn((B, D), dtype=torch.float64, device="cuda", generator=g)
+    z[::50] *= 4.0
+    z[::1000] *= 2.5                                            # out to ~ +-30
+    z = z.to(dtype)
+
+    def run(min_rows):
+        prev = _hip.FWD_TABLE_MIN_ROWS
+        _hip.FWD_TABLE_MIN_ROWS = min_rows
+        try:
+            status = _hip.new_status(z.device)
+            timer = _hip.KernelTimer()
+            with timer:
+                x, ld = _hip.gf_chain("fwd", z, None, params, larr, len(layers), D, status=status)
+            return x, ld, status.cpu().tolist(), {k[0] for k in timer.summary()}
+        finally:
+            _hip.FWD_TABLE_MIN_ROWS = prev
+    suf = "_f32" if dtype == torch.float32 else "_f64"
+    x0, ld0, w0, k0 = run(1 << 62)
+    x1, ld1, w1, k1 = run(1)
+    assert k0 == {"jf_gf_chain_fwd" + suf} and k1 == {"jf_gf_chain_fwd_tab" + suf}
+    assert torch.isfinite(x1).all() and torch.isfinite(ld1).all()
+    # both runs end in the reference's Newton stage, from different starts: they meet within the stage's stopping rule -- 2.5e-7 of the coordinate
+    # in float32, which a row on a plateau between two components (dy/dx ~ 1e-3) turns into ~1e-4 of x; all but a few rows agree much closer
+    # (rows the Newton stage leaves unconverged -- flagged in status, a handful per batch, Pade-gap rows of the normal-type stages among them --
+    #  end wherever their start sent them: the comparison is over quantiles)
+    rel = ((x1 - x0).abs() / (1.0 + x0.abs())).max(dim=1).values.sort().values
+    assert rel[int(0.99 * B)].item() < tol and rel[B - 41].item() < 10 * tol, (rel[int(0.99 * B)].item(), rel[B - 41].item())
+    lrel = ((ld1 - ld0).abs() / (1.0 + ld0.abs())).sort().values
+    assert lrel[int(0.99 * B)].item() < 20 * tol and lrel[B - 41].item() < 200 * tol
+    assert w1[0] <= w0[0] + max(3, w0[0] // 100) and w1[1] == w0[1] == 0, (w0, w1)     # non-converged rows (a Pade-gap row may flip), non-finite rows
+    if case == "three_components":
+        assert torch.equal(x1, x0) and w1 == w0                   # the table is not consulted
+    else:
+        # Newton row-steps: float64 rows start at least as close as the float32 approach phase left them; a float32 row whose approach phase
+        # ended AT the float32 floor (one confirming evaluation) may now need a second step -- in exchange for the 4-6 approach evaluations
+        assert w1[3] <= (1.0 if dtype == torch.float64 else 1.7) * w0[3], (w0, w1)
+    zb, ldb = _hip.gf_chain("inv", x1, None, params, larr, len(layers), D)
+    rt = ((zb - z).abs() / (1.0 + z.abs())).max(dim=1).values
+    # (rows flagged non-converged are exempt: float32 normal-type stages cannot represent the cdf of base points beyond ~ +-8 at all)
+    assert rt.sort().values[B - 9 - w1[0]].item() < (1e-7 if dtype == torch.float64 else 5e-3)
+    x2 = run(1)[0]
+    assert torch.equal(x1, x2)                                    # deterministic
+
+
+@pytest.mark.parametrize("name,dtype,tol", [("c2_e4_gggg", torch.float32, 2e-5), ("c3_e4s2e4", torch.float32, 2e-4), ("c1_e2_gg", torch.float64, 1e-9)])
+def test_pdf_sampling_with_and_without_the_start_table(name, dtype, tol):
+    """pdf-level: the samples and log-probs of 2^15 injected base points with the broadcast blocks' start table (default from 8192 rows on)
+    and without it (JF_FWD_TABLE_MIN_ROWS = 0) agree to the solver's tolerance (C3: the conditional blocks see the block-0 samples, so their
+    differences are amplified by the later blocks' sensitivity)"""
+    from jammy_flows_amd import _hip
+    fx = [f for f in ALL_FIXTURES if f.name == name][0]
+    pdf = build_product(fx, dtype)
+    pdf.check_status = False
+    B = 1 << 15
+    g = torch.Generator(device="cuda").manual_seed(2)
+    z = torch.randn((B, pdf.total_base_dim), dtype=torch.float64, device="cuda", generator=g).to(dtype)
+    out = {}
+    for min_rows in (1 << 62, 8192):
+        prev = _hip.FWD_TABLE_MIN_ROWS
+        _hip.FWD_TABLE_MIN_ROWS = min_rows
+        try:
+            timer = _hip.KernelTimer()
+            with timer:
+                x, _, lp, _ = pdf._obtain_sample(predefined_target_input=z)
+            names = {k[0] for k in timer.summary()}
+            assert any(k.startswith("jf_gf_chain_fwd_tab") for k in names) == (min_rows == 8192), names
+            out[min_rows] = (x.double(), lp.double())
+        finally:
+            _hip.FWD_TABLE_MIN_ROWS = prev
+    (xa, la), (xb, lb) = out[1 << 62], out[8192]
+    assert torch.isfinite(xb).all() and torch.isfinite(lb).all()
+    err = ((xa - xb).abs() / (1.0 + xa.abs())).max(dim=1).values
+    assert err.sort().values[B - 5].item() < tol, err.sort().values[B - 5].item()
+    assert ((la - lb).abs() / (1.0 + la.abs())).sort().values[B - 5].item() < 50 * tol
