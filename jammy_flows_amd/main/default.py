@@ -649,6 +649,7 @@ class pdf(nn.Module):
             return None
         # measured on 2^20 rows (scripts/bench_configs.py): the one-launch form wins for float32 'f' blocks (0.146 ms vs 0.16 + 0.05 ms); for the
         # 'r' / 'o' / 'm' families and for float64 the two launches (resident narrow-output jf_mlp2 + chain) are faster (f64 'o': 0.48 vs 0.96 ms)
+        # (re-measured at the end of round 4, C4's float32 'o' block: one launch 0.171 ms, jf_mlp2 0.117 + jf_o_chain_inv 0.041 -- scripts/probe/c4_fused_ab.py)
         plain_f = fam == "f" and not any(l._vertical or l._circular for l in layers)      # with nested spline flows: 0.57 vs 0.21 + 0.28 ms
         if not (plain_f and dtype == torch.float32) and not self.force_fused_manifold_blocks:
             return None
