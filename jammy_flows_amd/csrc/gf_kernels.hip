@@ -274,6 +274,61 @@ __global__ void __launch_bounds__(BCAST ? 256 : 64, sizeof(T) == 8 ? 2 : 4) gf_c
 // load per lane.  Same arithmetic per coordinate as gfg_mixture_impl / gfg_mixture_scaled.
 template <typename T> struct __attribute__((aligned(16))) GfPack { T mean, iw, pi, piw; };
 
+// Rows of a wave whose plain sums underflowed (a target tens of widths from every component), lane = row kernel.  On the SURVEY inputs that is
+// 1 % of the (row, coordinate, layer) evaluations but a lane in 22 % of the waves -- 2.5 lanes of 64 on average -- and rounds 1-3 sent the whole
+// wave through gfg_mixture_scaled for them (a second walk over the components with a distance pass in front: +30 % on the kernel).  Here the
+// wave turns ITS LANES to those few rows instead: four rows per pass, one per 16-lane DPP row, lane k of a row takes component k (K <= 16) of
+// the row's target, and the distance minimum and the five scaled sums are row all-reductions by rotation (row_ror 8 / 4 / 2 / 1).  Same
+// arithmetic per component as gfg_mixture_scaled, the sums in tree order: a row's result still depends on nothing but its own target.
+constexpr int DPP_ROW_ROR4 = 0x124, DPP_ROW_ROR2 = 0x122, DPP_ROW_ROR1 = 0x121;
+template <typename T> __device__ __forceinline__ T row16_sum(T v) {
+    v += dpp_swap<DPP_ROW_ROR8>(v); v += dpp_swap<DPP_ROW_ROR4>(v); v += dpp_swap<DPP_ROW_ROR2>(v); v += dpp_swap<DPP_ROW_ROR1>(v);
+    return v;
+}
+template <typename T> __device__ __forceinline__ T row16_min(T v) {
+    v = M<T>::min(v, dpp_swap<DPP_ROW_ROR8>(v)); v = M<T>::min(v, dpp_swap<DPP_ROW_ROR4>(v));
+    v = M<T>::min(v, dpp_swap<DPP_ROW_ROR2>(v)); v = M<T>::min(v, dpp_swap<DPP_ROW_ROR1>(v));
+    return v;
+}
+template <typename T> __device__ __forceinline__ void gfb_scaled_rows(const GfPack<T>* __restrict__ pd, int K, T xd, bool under, MixQ<T>& q) {
+    unsigned long long mask = __ballot(under);
+    const int lane = threadIdx.x & 63, grp = lane >> 4, k = lane & 15;
+    const bool comp = k < K;
+    const GfPack<T> e = pd[comp ? k : 0];
+    const T pk = comp ? e.pi : T(0);
+    while (mask != 0ull) {                                      // wave-uniform
+        const int rank = __popcll(mask & ((1ull << lane) - 1ull));     // this lane's row is the rank-th underflowed row still to do
+        unsigned long long mm = mask;
+        int s[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) { s[g] = mm != 0ull ? __ffsll((long long)mm) - 1 : 0; mm &= mm - 1ull; }    // (no row left: lane 0's target, result unused)
+        const int src = grp == 0 ? s[0] : grp == 1 ? s[1] : grp == 2 ? s[2] : s[3];
+        const T xs = __shfl(xd, src, 64);
+        const T u = (xs - e.mean) * e.iw;
+        const T au = comp ? M<T>::abs(u) : T(INFINITY);
+        const T m = row16_min<T>(au);
+        const T em = M<T>::exp_fast(-m);                       // may underflow to 0: the unscaled parts then stand alone
+        const T tp = M<T>::exp_fast(m - au);                   // <= 1; 0 for the lanes without a component
+        const T hi = M<T>::rcp(T(1) + tp * em);
+        const T c1 = pk * hi, c2 = c1 * tp;
+        const bool pos = u >= T(0);
+        const T Cu = row16_sum<T>(pos ? c1 : T(0)), Su = row16_sum<T>(pos ? T(0) : c1);
+        const T Ss = row16_sum<T>(pos ? c2 : T(0)), Cs = row16_sum<T>(pos ? T(0) : c2);
+        const T Ps = row16_sum<T>(c2 * hi * e.iw);
+        MixQ<T> r;
+        r.cdf = Cu + em * Cs;
+        r.sf = Su + em * Ss;
+        r.lc = Cu > T(0) ? M<T>::log_fast(r.cdf) : M<T>::log_fast(Cs) - m;
+        r.ls = Su > T(0) ? M<T>::log_fast(r.sf) : M<T>::log_fast(Ss) - m;
+        r.lp = M<T>::log_fast(Ps) - m;
+        // the row groups hand their results to the rows they worked for
+        const int from = 16 * (rank < 4 ? rank : 0);
+        const T lc = __shfl(r.lc, from, 64), ls = __shfl(r.ls, from, 64), lp = __shfl(r.lp, from, 64), cd = __shfl(r.cdf, from, 64), sf = __shfl(r.sf, from, 64);
+        if (under && ((mask >> lane) & 1ull) != 0ull && rank < 4) { q.lc = lc; q.ls = ls; q.lp = lp; q.cdf = cd; q.sf = sf; }
+        mask = mm;                                              // the four lowest rows are done
+    }
+}
+
 template <typename T, int D> __global__ void __launch_bounds__(256) gfb_chain_inv_kernel(const GfChainArgs<T> a) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     T* lds = reinterpret_cast<T*>(smem_raw);
@@ -331,7 +386,7 @@ template <typename T, int D> __global__ void __launch_bounds__(256) gfb_chain_in
             for (int d = 0; d < D; ++d) {
                 const GfPack<T>* pd = pk + d * o.K;
                 T C = T(0), S = T(0), P = T(0);
-#pragma unroll 2
+#pragma unroll 5
                 for (int k = 0; k < o.K; ++k) {
                     const GfPack<T> e = pd[k];
                     const T u = (x[d] - e.mean) * e.iw;
@@ -348,8 +403,12 @@ template <typename T, int D> __global__ void __launch_bounds__(256) gfb_chain_in
                 q.cdf = C; q.sf = S;
                 const bool under = !(C > M<T>::TINY && S > M<T>::TINY && P > M<T>::TINY);
                 if (__any(under)) {                        // wave-uniform branch
-                    const MixQ<T> qs = gfg_mixture_scaled<T, false>(prow + d, o, D, x[d], T(0));
-                    if (under) q = qs;
+                    if (o.K <= 16) {
+                        gfb_scaled_rows<T>(pd, o.K, x[d], under, q);
+                    } else {
+                        const MixQ<T> qs = gfg_mixture_scaled<T, false>(prow + d, o, D, x[d], T(0));
+                        if (under) q = qs;
+                    }
                 }
                 const IcdfOut<T> sy = gf_icdf<T>(o.inv_type, q);
                 x[d] = sy.y;

@@ -1427,7 +1427,7 @@ class pdf(nn.Module):
                                             force_embedding_coordinates=force_embedding_coordinates,
                                             force_intrinsic_coordinates=force_intrinsic_coordinates, only_last=only_last, status=status)
         self._report_status(status)
-        return x, base_ret, -log_det + log_gauss, log_gauss
+        return x, base_ret, log_gauss - log_det, log_gauss          # (one launch; equal to -log_det + log_gauss bit for bit)
 
     def _differentiable_sample(self, conditional_input=None, predefined_target_input=None, samplesize=1, seed=None, amortization_parameters=None,
                                force_embedding_coordinates=False, force_intrinsic_coordinates=False, dtype=None, device=None, only_last=False):
