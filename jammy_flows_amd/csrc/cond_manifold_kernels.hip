@@ -40,8 +40,9 @@ template <typename T, typename CLayer> struct CmArgs {
 
 // NT threads per workgroup (256 in float32; 128 in float64, whose lane-private knot tables are twice as large)
 // FWD: the sampling direction (layers first to last, Fam::apply<T, true>: main/default.py:1482-1506); no base log-prob there
+// (float32: a register budget for three waves per SIMD -- 140 + 32 AGPRs -> 112 VGPRs, the `f` block of C3 0.109 -> 0.105 ms per 2^20 rows)
 template <typename T, class Fam, int NT, bool FWD = false>
-__global__ void __launch_bounds__(NT) cond_mchain_kernel(const CmArgs<T, typename Fam::CLayer> a) {
+__global__ void __launch_bounds__(NT, NT == 256 ? 3 : 1) cond_mchain_kernel(const CmArgs<T, typename Fam::CLayer> a) {
     using MF = Mfma16<T>;
     constexpr int MT = 16, KS = 4, NREG = 4, JH = CM_HMAX / MT;
     extern __shared__ __align__(16) unsigned char smem_raw[];
