@@ -1259,3 +1259,31 @@ def test_pdf_sampling_with_and_without_the_start_table(name, dtype, tol):
     err = ((xa - xb).abs() / (1.0 + xa.abs())).max(dim=1).values
     assert err.sort().values[B - 5].item() < tol, err.sort().values[B - 5].item()
     assert ((la - lb).abs() / (1.0 + la.abs())).sort().values[B - 5].item() < 50 * tol
+
+
+@pytest.mark.parametrize("frac_far", [0.02, 0.3, 1.0])
+def test_broadcast_logprob_underflowed_rows_depend_on_their_own_target_only(frac_far):
+    """gfb_scaled_rows (round 4): rows whose plain float32 sums underflow are re-evaluated four per pass by the wave's lanes.  With 2 % / 30 % /
+    100 % of the rows far out (1, ~20 and 64 such rows per wave: one to sixteen passes), (a) the float32 log-probs agree with the float64
+    kernel's, which never underflows there, (b) a row's result does not depend on its neighbours: the same rows in another order, and alone
+    among central rows, give the same bits."""
+    fx = [f for f in ALL_FIXTURES if f.name == "c2_e4_gggg"][0]
+    pdf32, pdf64 = build_product(fx, torch.float32), build_product(fx, torch.float64)
+    n = 1 << 14
+    g = torch.Generator(device="cuda").manual_seed(4)
+    x = torch.randn((n, 4), dtype=torch.float64, device="cuda", generator=g) * 1.5
+    far = torch.rand((n,), device="cuda", generator=g) < frac_far
+    x[far] *= torch.empty((int(far.sum()), 1), dtype=torch.float64, device="cuda").uniform_(8.0, 60.0, generator=g)
+    lp32 = pdf32(x.float())[0]
+    lp64 = pdf64(x)[0]
+    assert torch.isfinite(lp32).all() and torch.isfinite(lp64).all()
+    rel = (lp32.double() - lp64).abs() / (1.0 + lp64.abs())
+    assert rel.max().item() < 2e-4, rel.max().item()
+    perm = torch.randperm(n, device="cuda", generator=g)
+    assert torch.equal(pdf32(x.float()[perm].contiguous())[0], lp32[perm])
+    # every far row alone in a wave of central rows
+    idx = torch.nonzero(far).flatten()[:64]
+    if idx.numel():
+        centre = torch.randn((64 * idx.numel(), 4), dtype=torch.float32, device="cuda", generator=g)
+        centre[::64] = x.float()[idx]
+        assert torch.equal(pdf32(centre)[0][::64], lp32[idx])
