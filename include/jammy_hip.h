@@ -211,12 +211,21 @@ int jf_cond_gf_chain_split2_f32(int32_t direction, int32_t arithmetic, const flo
                                 int32_t* status, void* stream);
 /* the same launch with the MLP's input rows READ WHERE THEY ARE: `segments` (<= 4, widths adding up to K1) describe
  * cat[conditional_input, embed(x_0), ...] (main/default.py:946-962) as column ranges of the caller's tensors -- see jf_conditioning_rows --, so
- * neither a conditioning launch nor the (B, K1) matrix exists */
+ * neither a conditioning launch nor the (B, K1) matrix exists.
+ * ld_pre / blp_pre / total (all nullable; log-prob direction with base_logp_out only): this block is the LAST of a pdf whose blocks were
+ * evaluated independently (see jf_combine_rows) -- the lists (<= 4 entries each) hold the log-dets / base log-probs of the blocks before it,
+ * log_det_out / base_logp_out then receive the pdf's totals, summed in list order with this block last, and total = base_logp_out +
+ * log_det_out: bit for bit what jf_combine_rows returns, without its launch (main/default.py:1110-1117: log_prob = log_prob_base + log_det). */
+#define JF_MAX_ROW_LISTS 16
+typedef struct jf_row_list {
+    const void* p[JF_MAX_ROW_LISTS];
+    int32_t n;
+} jf_row_list;
 int jf_cond_gf_chain_split3_f32(int32_t direction, int32_t arithmetic, const jf_cond_segment* segments, int32_t n_segments, const float* W1,
                                 int64_t w1_stride, const float* b1, const void* packed, int32_t K1, int32_t H, const float* x, int64_t x_stride,
                                 const float* log_det_in, int64_t B, int32_t D, int32_t n_layers, const jf_gf_layer* layers, float* x_out,
                                 int64_t x_out_stride, float* log_det_out, const float* base_logp_in, float* base_logp_out, float* aux,
-                                int32_t* status, void* stream);
+                                const jf_row_list* ld_pre, const jf_row_list* blp_pre, float* total, int32_t* status, void* stream);
 /* Training step of the same block (float32; replaces torch.autograd's replay of main/default.py:656-670, 946-962, 998-1031 +
  * gaussianization_flow.py:995-1114 for the loss of examples/jammy_flows.py:381-412).
  * jf_cond_gf_chain_inv_split_save_f32 = jf_cond_gf_chain_inv_split_f32 that also leaves, per (layer, row, coordinate lane), the layer's input
@@ -647,11 +656,7 @@ int jf_device_math_f64(const double* x, int64_t n, int32_t fn, double* out, void
 /* The last operations of pdf.forward / all_layer_inverse (main/default.py:1110-1117): the sub-manifold blocks of the log-prob direction are
  * independent given the targets, so every block returns its OWN log-det and base log-prob (ld_in = blp_in = NULL) and one launch adds them up,
  * in list order: ld_out[b] = sum_i ld.p[i][b], blp_out[b] = sum_i blp.p[i][b], total_out[b] = blp_out[b] + ld_out[b] (each output nullable). */
-#define JF_MAX_ROW_LISTS 16
-typedef struct jf_row_list {
-    const void* p[JF_MAX_ROW_LISTS];
-    int32_t n;
-} jf_row_list;
+/* (jf_row_list / JF_MAX_ROW_LISTS: defined above, before jf_cond_gf_chain_split3_f32) */
 int jf_combine_rows_f32(const jf_row_list* ld, const jf_row_list* blp, int64_t B, float* ld_out, float* blp_out, float* total_out, void* stream);
 int jf_combine_rows_f64(const jf_row_list* ld, const jf_row_list* blp, int64_t B, double* ld_out, double* blp_out, double* total_out, void* stream);
 /* torch.optim.Adam (amsgrad off, no weight decay: what examples/jammy_flows.py:381-412 trains with) over up to JF_ADAM_MAX_TENSORS parameter

@@ -188,7 +188,7 @@ _SIGNATURES_SINGLE = {
     "jf_mlp2_i8_f64": ([_P, _I64, _P, _I64, _P, _P, _I64, _I32, _I32, _I32, _I32, _P, _I64, _P], ctypes.c_int),
     "jf_mlp2_i8_seg_f64": ([ctypes.POINTER(jf_cond_segment), _I32, _P, _I64, _P, _P, _I64, _I32, _I32, _I32, _I32, _P, _I64, _P], ctypes.c_int),
     "jf_cond_gf_chain_split3_f32": ([_I32, _I32, ctypes.POINTER(jf_cond_segment), _I32, _P, _I64, _P, _P, _I32, _I32, _P, _I64, _P, _I64, _I32, _I32,
-                                     ctypes.POINTER(jf_gf_layer), _P, _I64, _P, _P, _P, _P, _P, _P], ctypes.c_int),
+                                     ctypes.POINTER(jf_gf_layer), _P, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _P], ctypes.c_int),
     "jf_linear_wgrad_split_splits": ([_I64, _I32], ctypes.c_int64),
     "jf_linear_wgrad_split_f32": ([_P, _I64, _P, _I64, _I64, _I32, _I32, _P, _P, _P], ctypes.c_int),
     "jf_linear_split_pack_f32": ([_P, _I64, _I64, _I32, _I32, _P, _P], ctypes.c_int),
@@ -884,12 +884,22 @@ def cond_gf_pack(w2, b2, layer_array, n_layers, D, kind="split"):
     return packed
 
 
+COND_GF_MAX_PRE = 4                  # entries of pre_ld / pre_blp (csrc/cond_split_kernels.hip: CS_MAX_PRE)
+
+
 def cond_gf_chain_inv_split(inp, w1, b1, packed, x, log_det, layer_array, n_layers, D, x_out=None, base_logp_in=None, want_base_logp=False,
-                            status=None, kind="split", aux=None):
+                            status=None, kind="split", aux=None, pre_ld=None, pre_blp=None):
     """as cond_gf_chain_inv with the second product on split-bf16 MFMA and the parameter block in registers (float32, default layer options);
     `kind` selects the kernel the packed image was built for.  aux (cond_gf_aux, "split" only): the launch also leaves what
-    cond_gf_chain_inv_split_bwd starts from."""
+    cond_gf_chain_inv_split_bwd starts from.
+    pre_ld / pre_blp (lists of (B,) tensors, with want_base_logp): this block is the last of its pdf -- the launch also adds the earlier blocks'
+    log-dets / base log-probs in front of its own (list order) and returns (x_out, log_det total, base_logp total, total log-prob): the sums of
+    combine_rows without its launch.  Returns None when the segment-input kernel that does this is not the one in use."""
     seg = None
+    if pre_ld is not None or pre_blp is not None:
+        if not (want_base_logp and kind == "split16" and aux is None and isinstance(inp, SegInput) and inp.in_place_ok and inp.dtype == torch.float32
+                and len(pre_ld or []) <= COND_GF_MAX_PRE and len(pre_blp or []) <= COND_GF_MAX_PRE):
+            return None
     if isinstance(inp, SegInput):
         if kind == "split16" and inp.in_place_ok and inp.dtype == torch.float32:
             seg = inp                                      # read in place by jf_cond_gf_chain_split3_f32
@@ -915,10 +925,26 @@ def cond_gf_chain_inv_split(inp, w1, b1, packed, x, log_det, layer_array, n_laye
             raise ValueError("cond_gf_chain_inv_split: aux = cond_gf_aux(B, n_layers)")
         if seg is not None:
             arr = seg.c_array()
+            lists, total = (None, None), None
+            if pre_ld is not None or pre_blp is not None:
+                def lst(items):
+                    r = jf_row_list()
+                    r.n = len(items)
+                    for i, t in enumerate(items):
+                        if t.dtype != torch.float32 or t.shape != (B,) or not t.is_contiguous():
+                            raise ValueError("cond_gf_chain_inv_split: pre_ld / pre_blp entries are contiguous float32 (B,) tensors")
+                        r.p[i] = _ptr(t)
+                    return r
+                require_device(x, *(list(pre_ld or []) + list(pre_blp or [])))
+                lists = (lst(list(pre_ld or [])), lst(list(pre_blp or [])))
+                total = torch.empty((B,), dtype=x.dtype, device=x.device)
             _launch("jf_cond_gf_chain_split3_f32", "K%d_H%d_L%d_D%d" % (K1, H, n_layers, D),
                     (DIR_INV, SPLIT_F16X2, arr, len(seg.segments), _ptr(w1), w1.stride(0), _ptr(b1.contiguous()), _ptr(packed), K1, H, _ptr(x), x.stride(0),
                      _ptr(log_det), B, D, n_layers, layer_array, _ptr(x_out), x_out.stride(0), _ptr(ld_out), _ptr(base_logp_in), _ptr(blp_out), _ptr(aux),
+                     None if lists[0] is None else ctypes.byref(lists[0]), None if lists[1] is None else ctypes.byref(lists[1]), _ptr(total),
                      _ptr(status)), dev)
+            if total is not None:
+                return x_out, ld_out, blp_out, total
             return (x_out, ld_out, blp_out) if want_base_logp else (x_out, ld_out)
         _launch("jf_cond_gf_chain_split2_f32", "K%d_H%d_L%d_D%d" % (K1, H, n_layers, D),
                 (DIR_INV, SPLIT_F16X2, _ptr(inp), inp.stride(0), _ptr(w1), w1.stride(0), _ptr(b1.contiguous()), _ptr(packed), K1, H, _ptr(x), x.stride(0),

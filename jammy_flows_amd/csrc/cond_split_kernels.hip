@@ -84,6 +84,7 @@ template <int NP> __global__ void __launch_bounds__(256) cs_pack_kernel(const Cs
 }
 
 // ---------------------------------------------------------------------------------------------------------- the fused kernel
+constexpr int CS_MAX_PRE = 4;
 struct CsArgs {
     const float* in; int64_t in_stride;
     const float* W1; int64_t w1s; const float* b1;
@@ -100,6 +101,12 @@ struct CsArgs {
     int32_t* status;
     float* aux;                                // SAVE: what the adjoint launch starts from (see cond_bwd_kernels.hip), else unused
     CondIn cin;                                // n > 0: the MLP's input rows are these segments of the targets / conditional input (jf_cond_in.h)
+    // log-prob direction, the LAST block of a pdf: the log-dets / base log-probs of the blocks before it (each block evaluated on its own),
+    // added in list order in front of this block's -- ld_out / blp_out then hold the pdf's totals and total = blp_out + ld_out: the sums
+    // jf_combine_rows would make in a launch of its own (main/default.py:1110-1117)
+    const float* ld_pre[CS_MAX_PRE]; const float* blp_pre[CS_MAX_PRE];
+    int n_ld_pre, n_blp_pre;
+    float* total;
 };
 
 // RG = row groups (16 rows each) per wave.  With RG = 2 every A fragment read from LDS feeds two MFMAs (half the ds_read_b128 per row,
@@ -288,8 +295,20 @@ __global__ void __launch_bounds__(256, (NP == 2 && !FWD) ? 3 : 2) cond_gf_split_
             float sb = 0.f;
             if (a.blp_out) sb = cs_rsum(live ? -0.5f * x[g] * x[g] - M<float>::HALF_LN_2PI : 0.f);
             if (row_valid[g] && leader) {
-                a.ld_out[row[g]] = ld[g];
-                if (a.blp_out) a.blp_out[row[g]] = sb + (a.blp_in ? a.blp_in[row[g]] : 0.f);
+                float ldv = ld[g], bv = sb + (a.blp_in ? a.blp_in[row[g]] : 0.f);
+                if (a.n_ld_pre > 0) {                               // uniform: list order, this block last (bit for bit jf_combine_rows)
+                    float t = a.ld_pre[0][row[g]];
+                    for (int i = 1; i < a.n_ld_pre; ++i) t += a.ld_pre[i][row[g]];
+                    ldv = t + ldv;
+                }
+                if (a.n_blp_pre > 0) {
+                    float t = a.blp_pre[0][row[g]];
+                    for (int i = 1; i < a.n_blp_pre; ++i) t += a.blp_pre[i][row[g]];
+                    bv = t + bv;
+                }
+                a.ld_out[row[g]] = ldv;
+                if (a.blp_out) a.blp_out[row[g]] = bv;
+                if (a.total) a.total[row[g]] = bv + ldv;
             }
             const float bad = cs_rmax((live && !M<float>::finite(x[g])) ? 1.f : 0.f);
             status_add(a.status, JF_STATUS_NONFINITE, row_valid[g] && leader && (bad > 0.f || !M<float>::finite(ld[g])));
@@ -365,7 +384,10 @@ template <bool FWD>
 static int cs_chain(const float* in, int64_t in_stride, const float* W1, int64_t w1s, const float* b1, const void* packed, int32_t K1, int32_t H,
                     const float* x, int64_t xs, const float* ld_in, int64_t B, int32_t D, int32_t n_layers, const jf_gf_layer* layers, float* x_out,
                     int64_t xos, float* ld_out, const float* blp_in, float* blp_out, int32_t* status, void* stream, float* aux = nullptr,
-                    int arithmetic = JF_SPLIT_BF16X3, const jf_cond_segment* segs = nullptr, int32_t n_segs = 0) {
+                    int arithmetic = JF_SPLIT_BF16X3, const jf_cond_segment* segs = nullptr, int32_t n_segs = 0, const jf_row_list* ld_pre = nullptr,
+                    const jf_row_list* blp_pre = nullptr, float* total = nullptr) {
+    if ((ld_pre || blp_pre || total) && (FWD || !blp_out)) return JF_ERR_BADARG;
+    if ((ld_pre && (ld_pre->n < 0 || ld_pre->n > CS_MAX_PRE)) || (blp_pre && (blp_pre->n < 0 || blp_pre->n > CS_MAX_PRE))) return JF_ERR_UNSUPPORTED;
     CondIn cin{};
     if (segs || n_segs) {                                          // segmented input: `in` is not used
         const int rc = cond_in_make(segs, n_segs, K1, cin);
@@ -388,6 +410,15 @@ static int cs_chain(const float* in, int64_t in_stride, const float* W1, int64_t
     a.in = in; a.in_stride = in_stride; a.W1 = W1; a.w1s = w1s; a.b1 = b1; a.packed = static_cast<const unsigned char*>(packed); a.K1 = K1; a.H = H;
     a.x = x; a.xs = xs; a.ld_in = ld_in; a.B = B; a.D = D; a.n_layers = n_layers;
     a.x_out = x_out; a.xos = xos; a.ld_out = ld_out; a.blp_in = blp_in; a.blp_out = blp_out; a.status = status; a.aux = aux; a.cin = cin;
+    if (ld_pre) {
+        for (int i = 0; i < ld_pre->n; ++i) { if (!ld_pre->p[i]) return JF_ERR_BADARG; a.ld_pre[i] = static_cast<const float*>(ld_pre->p[i]); }
+        a.n_ld_pre = ld_pre->n;
+    }
+    if (blp_pre) {
+        for (int i = 0; i < blp_pre->n; ++i) { if (!blp_pre->p[i]) return JF_ERR_BADARG; a.blp_pre[i] = static_cast<const float*>(blp_pre->p[i]); }
+        a.n_blp_pre = blp_pre->n;
+    }
+    a.total = total;
     hipStream_t st = (hipStream_t)stream;
     if constexpr (!FWD) {
         if (aux) return arithmetic == JF_SPLIT_F16X2 ? cs_launch<false, true, 2>(a, B, st) : cs_launch<false, true, 3>(a, B, st);
@@ -441,11 +472,12 @@ int jf_cond_gf_chain_split2_f32(int32_t direction, int32_t arithmetic, const flo
 int jf_cond_gf_chain_split3_f32(int32_t direction, int32_t arithmetic, const jf_cond_segment* segs, int32_t n_segs, const float* W1, int64_t w1s,
                                 const float* b1, const void* packed, int32_t K1, int32_t H, const float* x, int64_t xs, const float* ld_in, int64_t B,
                                 int32_t D, int32_t n, const jf_gf_layer* L, float* xo, int64_t xos, float* ldo, const float* bi, float* bo, float* aux,
-                                int32_t* st, void* s) {
+                                const jf_row_list* ld_pre, const jf_row_list* blp_pre, float* total, int32_t* st, void* s) {
     if (!segs || n_segs < 1) return JF_ERR_BADARG;
     if (direction == JF_DIR_INV)
-        return jf::cs_chain<false>(nullptr, 0, W1, w1s, b1, packed, K1, H, x, xs, ld_in, B, D, n, L, xo, xos, ldo, bi, bo, st, s, aux, arithmetic, segs, n_segs);
-    if (direction == JF_DIR_FWD && !bi && !bo && !aux)
+        return jf::cs_chain<false>(nullptr, 0, W1, w1s, b1, packed, K1, H, x, xs, ld_in, B, D, n, L, xo, xos, ldo, bi, bo, st, s, aux, arithmetic, segs, n_segs,
+                                   ld_pre, blp_pre, total);
+    if (direction == JF_DIR_FWD && !bi && !bo && !aux && !ld_pre && !blp_pre && !total)
         return jf::cs_chain<true>(nullptr, 0, W1, w1s, b1, packed, K1, H, x, xs, ld_in, B, D, n, L, xo, xos, ldo, nullptr, nullptr, st, s, nullptr, arithmetic,
                                   segs, n_segs);
     return JF_ERR_BADARG;

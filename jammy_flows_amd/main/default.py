@@ -209,6 +209,7 @@ class pdf(nn.Module):
         # such as bench.py opt into it and flush inside their timed region).  False: never.
         self.check_status = True
         self._capture_status = None
+        self.fold_combine = os.environ.get("JF_FOLD_COMBINE", "1") != "0"    # the last fused block adds the per-block sums itself (no jf_combine_rows launch)
         self.force_fused_manifold_blocks = False     # tests: run jf_cond_<fam>_chain_inv also where the two-launch path is the faster default
         # conditional e-blocks (Linear-tanh-Linear MLP + g layers, D in {3,4}, float32) as ONE launch with the parameter block kept on chip
         # (jf_cond_gf_chain_inv): +9 % on the C3 step against jf_mlp2 + jf_gf_chain_inv.  False selects the two-launch path.
@@ -870,6 +871,7 @@ class pdf(nn.Module):
         if lanes:
             rec.fork()
         n_blocks = len(self.layer_list)
+        folded_total = None
         for si, block in enumerate(self.layer_list):
             if independent:
                 if si > 0:
@@ -895,9 +897,20 @@ class pdf(nn.Module):
                 if self.fused_matrix_arithmetic != "f32" and fused[0].shape[0] <= 128:
                     packed = self._packed_w2(si, fused[2], fused[3], larr, len(layers), layers[0].dimension, x.shape[0])
                 if packed is not None:
-                    res = _hip.cond_gf_chain_inv_split(self._mlp_input(si, data_summary, embeds), fused[0], fused[1], packed[1], tgt, log_det, larr,
-                                                       len(layers), layers[0].dimension, x_out=out_view, base_logp_in=base_logp,
-                                                       want_base_logp=want_base_logp, status=status, kind=packed[0])
+                    mlp_in = self._mlp_input(si, data_summary, embeds)
+                    res = None
+                    if independent and want_base_logp and si == n_blocks - 1 and not lanes and not overlap and self.fold_combine:
+                        # the last block adds the earlier blocks' sums in its epilogue (list order, itself last: the bits of combine_rows) and
+                        # writes log_prob = log_prob_base + log_det itself (:1110-1117): one launch fewer per step
+                        res = _hip.cond_gf_chain_inv_split(mlp_in, fused[0], fused[1], packed[1], tgt, None, larr, len(layers), layers[0].dimension,
+                                                           x_out=out_view, want_base_logp=True, status=status, kind=packed[0],
+                                                           pre_ld=[t for t in ld_parts if t is not None], pre_blp=[t for t in blp_parts if t is not None])
+                        if res is not None:
+                            folded_total = res[3]
+                    if res is None:
+                        res = _hip.cond_gf_chain_inv_split(mlp_in, fused[0], fused[1], packed[1], tgt, log_det, larr,
+                                                           len(layers), layers[0].dimension, x_out=out_view, base_logp_in=base_logp,
+                                                           want_base_logp=want_base_logp, status=status, kind=packed[0])
                 else:
                     res = _hip.cond_gf_chain_inv(_hip.as_matrix(self._mlp_input(si, data_summary, embeds)), *fused, tgt, log_det, larr, len(layers),
                                                  layers[0].dimension, x_out=out_view, base_logp_in=base_logp, want_base_logp=want_base_logp,
@@ -997,7 +1010,9 @@ class pdf(nn.Module):
             if per_block is not None:
                 per_block.append(log_det)
         total = None
-        if independent:
+        if folded_total is not None:
+            total = folded_total                          # log_det / base_logp are the totals already
+        elif independent:
             ld_parts.append(log_det)
             if want_base_logp:
                 blp_parts.append(base_logp)
@@ -1066,7 +1081,7 @@ class pdf(nn.Module):
                bool(force_embedding_coordinates), bool(force_intrinsic_coordinates),
                # the switches that choose kernels: a plan replays the choice made when it was recorded
                self.fuse_conditional_blocks, self.fused_matrix_arithmetic, self.fused_block_kernel, self.force_fused_manifold_blocks,
-               self.plan_lanes, self.plan_overlap_blocks)
+               self.plan_lanes, self.plan_overlap_blocks, self.fold_combine)
         plan = self._step_plans.get(key)
         if plan is None:
             if len(self._step_plans) >= 8:               # a few signatures per pdf (each plan keeps its intermediate buffers)

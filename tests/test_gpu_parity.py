@@ -1287,3 +1287,35 @@ def test_broadcast_logprob_underflowed_rows_depend_on_their_own_target_only(frac
         centre = torch.randn((64 * idx.numel(), 4), dtype=torch.float32, device="cuda", generator=g)
         centre[::64] = x.float()[idx]
         assert torch.equal(pdf32(centre)[0][::64], lp32[idx])
+
+
+@pytest.mark.parametrize("rows", [192, 5000, 1 << 17])
+def test_last_block_folds_the_combine_launch(rows):
+    """The last fused block of a pdf adds the earlier blocks' log-dets / base log-probs in its epilogue and writes log_prob itself
+    (jf_cond_gf_chain_split3_f32: ld_pre / blp_pre / total): the three outputs of pdf.forward are the bits the separate jf_combine_rows launch
+    gives (pdf.fold_combine = False), eager and through a recorded step plan, and the launch is gone."""
+    from jammy_flows_amd import _hip
+    fx = [f for f in ALL_FIXTURES if f.name == "c3_e4s2e4"][0]
+    reps = rows // fx["x"].shape[0] + 1
+    x = to_dev(np.tile(fx["x"], (reps, 1))[:rows], torch.float32)
+    out = {}
+    for fold in (False, True):
+        pdf = build_product(fx, torch.float32)
+        pdf.fold_combine = fold
+        timer = _hip.KernelTimer()
+        with timer:
+            lp, lpb, base = pdf(x)
+        names = {k[0] for k in timer.summary()}
+        assert ("jf_combine_rows_f32" in names) == (not fold), names
+        assert len(names - {"jf_cond_gf_pack2_f32"}) == (3 if fold else 4), sorted(names)       # (the first call also packs W2)
+        pdf.use_step_plans = True
+        lp2, lpb2, base2 = pdf(x)
+        lp2, lpb2, base2 = pdf(x)                          # (the second call replays the recorded plan)
+        assert torch.equal(lp, lp2) and torch.equal(lpb, lpb2) and torch.equal(base, base2)
+        out[fold] = (lp, lpb, base)
+    for a, b in zip(out[False], out[True]):
+        assert torch.equal(a, b)
+    gold = torch.from_numpy(fx["logp"]).cuda()
+    n = min(rows, gold.shape[0])
+    fin = torch.isfinite(gold[:n])
+    assert float(((out[True][0][:n].double() - gold[:n]).abs() / (1.0 + gold[:n].abs()))[fin].max()) < 1e-3
