@@ -188,7 +188,8 @@ _SIGNATURES_SINGLE = {
     "jf_mlp2_i8_f64": ([_P, _I64, _P, _I64, _P, _P, _I64, _I32, _I32, _I32, _I32, _P, _I64, _P], ctypes.c_int),
     "jf_mlp2_i8_seg_f64": ([ctypes.POINTER(jf_cond_segment), _I32, _P, _I64, _P, _P, _I64, _I32, _I32, _I32, _I32, _P, _I64, _P], ctypes.c_int),
     "jf_cond_gf_chain_split3_f32": ([_I32, _I32, ctypes.POINTER(jf_cond_segment), _I32, _P, _I64, _P, _P, _I32, _I32, _P, _I64, _P, _I64, _I32, _I32,
-                                     ctypes.POINTER(jf_gf_layer), _P, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _P], ctypes.c_int),
+                                     ctypes.POINTER(jf_gf_layer), _P, _I64, _P, _P, _P, _P, ctypes.POINTER(jf_row_list), ctypes.POINTER(jf_row_list), _P,
+                                     _P, _P], ctypes.c_int),
     "jf_linear_wgrad_split_splits": ([_I64, _I32], ctypes.c_int64),
     "jf_linear_wgrad_split_f32": ([_P, _I64, _P, _I64, _I64, _I32, _I32, _P, _P, _P], ctypes.c_int),
     "jf_linear_split_pack_f32": ([_P, _I64, _I64, _I32, _I32, _P, _P], ctypes.c_int),
@@ -1050,9 +1051,16 @@ def linear_wgrad_split16(g, inp, g_absmax, in_exp=14, want_bias=True):
 def cond_gf_chain_fwd_split(inp, w1, b1, packed, z, log_det, layer_array, n_layers, D, x_out=None, status=None, kind="split"):
     """sampling direction of a conditional e-block in one launch (amortisation MLP + bisection / Newton solves on register-resident
     parameters); `packed`: the "split" / "split16" image of cond_gf_pack (`kind` names which)."""
-    dev = require_device(inp, w1, b1, packed, z, log_det, x_out, status)
+    seg = None
+    if isinstance(inp, SegInput):
+        if kind == "split16" and inp.in_place_ok and inp.dtype == torch.float32:
+            seg = inp                                      # read in place by jf_cond_gf_chain_split3_f32 (the earlier blocks' samples where they are)
+            inp = seg.segments[0][0]
+        else:
+            inp = inp.materialize()
+    dev = require_device(inp, w1, b1, packed, z, log_det, x_out, status, *(seg.tensors() if seg else []))
     inp, w1, z = _rowmajor(inp), _rowmajor(w1), _rowmajor(z)
-    B, K1 = inp.shape
+    B, K1 = seg.shape if seg else inp.shape
     H = w1.shape[0]
     if z.shape[0] != B or z.shape[1] != D or w1.shape[1] != K1 or b1.shape[0] != H:
         raise ValueError("cond_gf_chain_fwd_split: inconsistent shapes")
@@ -1063,6 +1071,12 @@ def cond_gf_chain_fwd_split(inp, w1, b1, packed, z, log_det, layer_array, n_laye
     if x_out is None:
         x_out = torch.empty((B, D), dtype=z.dtype, device=z.device)
     ld_out = torch.empty((B,), dtype=z.dtype, device=z.device)
+    if seg is not None:
+        _launch("jf_cond_gf_chain_split3_f32", "K%d_H%d_L%d_D%d_fwd" % (K1, H, n_layers, D),
+                (DIR_FWD, SPLIT_F16X2, seg.c_array(), len(seg.segments), _ptr(w1), w1.stride(0), _ptr(b1.contiguous()), _ptr(packed), K1, H, _ptr(z),
+                 z.stride(0), _ptr(log_det), B, D, n_layers, layer_array, _ptr(x_out), x_out.stride(0), _ptr(ld_out), None, None, None, None, None, None,
+                 _ptr(status)), dev)
+        return x_out, ld_out
     if kind == "split16":
         _launch("jf_cond_gf_chain_split2_f32", "K%d_H%d_L%d_D%d_fwd" % (K1, H, n_layers, D),
                 (DIR_FWD, SPLIT_F16X2, _ptr(inp), inp.stride(0), _ptr(w1), w1.stride(0), _ptr(b1.contiguous()), _ptr(packed), K1, H, _ptr(z), z.stride(0),

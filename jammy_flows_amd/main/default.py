@@ -1298,7 +1298,13 @@ class pdf(nn.Module):
             assert not self.amortize_everything
         B = x.shape[0]
         out = torch.empty((B, self.total_target_dim), dtype=x.dtype, device=x.device)
-        embeds = []
+        # the MLP input rows cat[conditional_input, embed(x_0), ...] (:1440-1456) as SEGMENTS of the output buffer, which the blocks fill one
+        # after the other: block si reads the columns of the blocks before it where they are (the consumers of _mlp_input with segment
+        # support), as in the log-prob direction -- no torch.cat, no embedding launch per sphere block
+        embeds = self._conditioning_rows(out, data_summary)
+        lazy = embeds is None
+        if lazy:
+            embeds = []
         counter = 0
         for si, block in enumerate(self.layer_list):
             kind = self.pdf_defs_list[si][0]
@@ -1315,7 +1321,8 @@ class pdf(nn.Module):
                     _, log_det = _hip.cond_gf_chain_fwd_split(self._mlp_input(si, data_summary, embeds), fused[0], fused[1], packed[1], x[:, ba:bb],
                                                               log_det, larr, len(layers), layers[0].dimension, x_out=out[:, a:b], status=status,
                                                               kind=packed[0])
-                    embeds.append(block[-1]._embedding_conditional_return(out[:, a:b]))
+                    if lazy:
+                        embeds.append(block[-1]._embedding_conditional_return(out[:, a:b]))
                     if per_block is not None:
                         per_block.append(log_det)
                     continue
@@ -1324,12 +1331,13 @@ class pdf(nn.Module):
                 # low-rank AmortizableMLP + the g layers' solves in one launch (float64, ranks <= 8): no (B, N) parameter block in HBM
                 ba, bb = self.base_dim_indices[si]
                 a, b = self.target_dim_indices[si]
-                res = _hip.amlp_gf_chain_fwd(self._mlp_input(si, data_summary, embeds), *lowrank, x[:, ba:bb], log_det,
+                res = _hip.amlp_gf_chain_fwd(_hip.as_matrix(self._mlp_input(si, data_summary, embeds)), *lowrank, x[:, ba:bb], log_det,
                                              _hip.gf_layer_array([l.c_struct() for l in layers]), len(layers), layers[0].dimension,
                                              x_out=out[:, a:b], status=status)
                 if res is not None:
                     log_det = res[1]
-                    embeds.append(block[-1]._embedding_conditional_return(out[:, a:b]))
+                    if lazy:
+                        embeds.append(block[-1]._embedding_conditional_return(out[:, a:b]))
                     if per_block is not None:
                         per_block.append(log_det)
                     continue
@@ -1340,11 +1348,13 @@ class pdf(nn.Module):
                 structs = [l.c_struct() if fam == "r" else l.c_struct(1 if l.euclidean_to_sphere_as_first else 0) for l in layers]
                 ba, bb = self.base_dim_indices[si]
                 a, b = self.target_dim_indices[si]
-                res = _hip.cond_mchain_fwd(fam, self._mlp_input(si, data_summary, embeds), *ws, x[:, ba:bb], log_det, structs, layers[0].dimension,
+                res = _hip.cond_mchain_fwd(fam, _hip.as_matrix(self._mlp_input(si, data_summary, embeds)), *ws, x[:, ba:bb], log_det, structs,
+                                           layers[0].dimension,
                                            x_out=out[:, a:b], status=status)
                 if res is not None:
                     log_det = res[1]
-                    embeds.append(block[-1]._embedding_conditional_return(out[:, a:b]))
+                    if lazy:
+                        embeds.append(block[-1]._embedding_conditional_return(out[:, a:b]))
                     if per_block is not None:
                         per_block.append(log_det)
                     continue
@@ -1392,7 +1402,8 @@ class pdf(nn.Module):
                             kw["fix_euclidean_to_sphere_first"] = True
                         cur, log_det = grp[0].flow_mapping([cur, log_det], extra_inputs=this, **kw)[:2]
                 out_view.copy_(cur)
-            embeds.append(block[-1]._embedding_conditional_return(out_view))
+            if lazy:
+                embeds.append(block[-1]._embedding_conditional_return(out_view))
             if per_block is not None:
                 per_block.append(log_det)
         x_new = out
