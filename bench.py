@@ -283,6 +283,7 @@ KERNEL_OF = {"jf_cond_f_chain_inv_f32": "cond_mchain_kernel<float, jf::FFam", "j
              "jf_cond_gf_chain_inv_f32": "cond_gf_chain_kernel<float",
              "jf_cond_gf_chain_inv_f64": "cond_gf_chain_kernel<double", "jf_mlp2_f32": "mlp2_kernel<float", "jf_mlp2_f64": "mlp2_kernel<double",
              "jf_gf_chain_inv_f32": "gf_chain_kernel<float", "jf_gf_chain_inv_f64": "gf_chain_kernel<double",
+             "jf_gf_chain_inv_total_f32": "gf_chain_kernel<float", "jf_gf_chain_inv_total_f64": "gf_chain_kernel<double",
              "jf_amlp_gf_chain_inv_f64": "amlp_gf_mfma_kernel"}
 
 

@@ -119,6 +119,7 @@ _I32 = ctypes.c_int32
 # name -> argtypes (without the _f32/_f64 suffix); every entry point of include/jammy_hip.h
 _SIGNATURES = {
     "jf_gf_chain_inv": [_P, _I64, _P, _P, _I64, _I32, _I64, _I32, _I32, ctypes.POINTER(jf_gf_layer), _P, _I64, _P, _P, _P, _P, _I64, _P, _P],
+    "jf_gf_chain_inv_total": [_P, _I64, _P, _P, _I64, _I32, _I64, _I32, _I32, ctypes.POINTER(jf_gf_layer), _P, _I64, _P, _P, _P, _P, _P, _I64, _P, _P],
     "jf_cond_gf_chain_inv": [_P, _I64, _P, _I64, _P, _P, _I64, _P, _I32, _I32, _P, _I64, _P, _I64, _I32, _I32, ctypes.POINTER(jf_gf_layer), _P, _I64,
                              _P, _P, _P, _P, _P],
     "jf_amlp_gf_chain_inv": [_P, _I64, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P, _I64, _P, _I64, _I32, _I32, ctypes.POINTER(jf_gf_layer), _P,
@@ -557,9 +558,11 @@ BINS_LOG = None
 FWD_TABLE_MIN_ROWS = int(os.environ.get("JF_FWD_TABLE_MIN_ROWS", "8192")) or (1 << 62)
 
 
-def gf_chain(direction, x, log_det, params, layer_array, n_layers, D, x_out=None, base_logp_in=None, want_base_logp=False, status=None):
+def gf_chain(direction, x, log_det, params, layer_array, n_layers, D, x_out=None, base_logp_in=None, want_base_logp=False, status=None,
+             want_total=False):
     """run a chain of g layers.  direction 'inv' (log-prob) or 'fwd' (sampling).
-    x (B, D) view (row stride arbitrary), log_det (B,) or None, params (1|B, P).  Returns (x_out, log_det_out[, base_logp])."""
+    x (B, D) view (row stride arbitrary), log_det (B,) or None, params (1|B, P).  Returns (x_out, log_det_out[, base_logp[, total]]);
+    want_total (with want_base_logp, 'inv'): the launch also writes total = base_logp + log_det (jf_gf_chain_inv_total)."""
     dev = require_device(x, log_det, params, x_out, base_logp_in, status)
     x = _rowmajor(x)
     params = _rowmajor(params)
@@ -588,6 +591,13 @@ def gf_chain(direction, x, log_det, params, layer_array, n_layers, D, x_out=None
             bins = torch.full((B, n_spl * D), -3, dtype=torch.int64, device=x.device)
             BINS_LOG.append(bins)
     bs = bins.stride(0) if bins is not None else 0
+    if direction == "inv" and want_total and want_base_logp:
+        blp_out = torch.empty((B,), dtype=x.dtype, device=x.device)
+        total = torch.empty((B,), dtype=x.dtype, device=x.device)
+        _launch("jf_gf_chain_inv_total" + suf, "bcast" if pb == 1 else "per-sample",
+                (_ptr(x), x.stride(0), _ptr(log_det), _ptr(params), params.stride(0), pb, B, D, n_layers, layer_array, _ptr(x_out),
+                 x_out.stride(0), _ptr(ld_out), _ptr(base_logp_in), _ptr(blp_out), _ptr(total), _ptr(bins), bs, _ptr(status)), dev)
+        return x_out, ld_out, blp_out, total
     if direction == "inv":
         blp_out = torch.empty((B,), dtype=x.dtype, device=x.device) if want_base_logp else None
         _launch("jf_gf_chain_inv" + suf, "bcast" if pb == 1 else "per-sample",

@@ -40,6 +40,8 @@ template <typename T> struct GfChainArgs {
     // then a division by the stage's derivative), i.e. cot_out = J^{-T} cot_in for the chain's Jacobian J = dy/dx (jf_gf_chain_inv_cot)
     const T* cot_in; int64_t cis;
     T* cot_out; int64_t cos;
+    T* total;                // log-prob direction, nullable (needs blp_out): total[b] = blp_out[b] + ld_out[b] -- log_prob = log_prob_base + log_det
+                             // (main/default.py:1110-1117) written by the chain launch itself instead of a launch of its own
     // sampling direction, broadcast parameters only: interpolation table of every (layer, coordinate)'s inverse x(z) (gf_fwd_table_kernel), or null
     T* table;
 };
@@ -257,7 +259,9 @@ __global__ void __launch_bounds__(BCAST ? 256 : 64, sizeof(T) == 8 ? 2 : 4) gf_c
             if (a.blp_out) s = group_sum<T, G>(live ? T(-0.5) * x * x - M<T>::HALF_LN_2PI : T(0));
             if (row_valid && leader) {
                 a.ld_out[row] = ld;
-                if (a.blp_out) a.blp_out[row] = s + (a.blp_in ? a.blp_in[row] : T(0));
+                const T bv = s + (a.blp_in ? a.blp_in[row] : T(0));
+                if (a.blp_out) a.blp_out[row] = bv;
+                if (a.total) a.total[row] = bv + ld;
             }
             const T bad = group_max<T, G>((live && !M<T>::finite(x)) ? T(1) : T(0));
             status_add(a.status, JF_STATUS_NONFINITE, row_valid && leader && (bad > T(0) || !M<T>::finite(ld)));
@@ -426,7 +430,9 @@ template <typename T, int D> __global__ void __launch_bounds__(256) gfb_chain_in
         }
         if (row_valid) {
             a.ld_out[row] = ld;
-            if (a.blp_out) a.blp_out[row] = sb + (a.blp_in ? a.blp_in[row] : T(0));
+            const T bv = sb + (a.blp_in ? a.blp_in[row] : T(0));
+            if (a.blp_out) a.blp_out[row] = bv;
+            if (a.total) a.total[row] = bv + ld;
         }
         status_add(a.status, JF_STATUS_NONFINITE, row_valid && bad);
     }
@@ -493,7 +499,11 @@ template <typename T, bool FWD> __global__ void __launch_bounds__(GX_THREADS) gf
     }
     if (row_valid) {
         a.ld_out[row] = ld;
-        if (!FWD && a.blp_out) a.blp_out[row] = blp + (a.blp_in ? a.blp_in[row] : T(0));
+        if (!FWD && a.blp_out) {
+            const T bv = blp + (a.blp_in ? a.blp_in[row] : T(0));
+            a.blp_out[row] = bv;
+            if (a.total) a.total[row] = bv + ld;
+        }
     }
     if constexpr (!FWD) status_add(a.status, JF_STATUS_NONFINITE, row_valid && bad);
 }
@@ -669,14 +679,14 @@ template <typename T, bool FWD> static int launch(const GfChainArgs<T>& a, int D
 template <typename T>
 static int gf_chain_inv(const T* x, int64_t xs, const T* ld_in, const T* params, int64_t ps, int32_t pb, int64_t B, int32_t D, int32_t n_layers,
                         const jf_gf_layer* layers, T* x_out, int64_t xos, T* ld_out, const T* blp_in, T* blp_out, int64_t* bins, int64_t bins_stride,
-                        int32_t* status, void* stream) {
-    if (!x || !params || !x_out || !ld_out) return JF_ERR_BADARG;
+                        int32_t* status, void* stream, T* total = nullptr) {
+    if (!x || !params || !x_out || !ld_out || (total && !blp_out)) return JF_ERR_BADARG;
     GfChainArgs<T> a{};
     size_t lds = 0; bool bcast = false, ext = false;
     int rc = fill_args<T>(a, params, ps, pb, B, D, n_layers, layers, lds, bcast, ext);
     if (rc != JF_OK) return rc;
     a.x = x; a.xs = xs; a.ld_in = ld_in; a.x_out = x_out; a.xos = xos; a.ld_out = ld_out; a.blp_in = blp_in; a.blp_out = blp_out; a.status = status;
-    a.bins = bins; a.bins_stride = bins_stride;
+    a.bins = bins; a.bins_stride = bins_stride; a.total = total;
     return launch<T, false>(a, D, bcast, ext, lds, (hipStream_t)stream);
 }
 // J^{-T} cot for the Jacobian J = d x_out / d x of the log-prob direction (the chain is evaluated along the way: x_out, ld_out are scratch outputs)
@@ -742,6 +752,18 @@ int jf_gf_chain_inv_f64(const double* x, int64_t xs, const double* ld_in, const 
                         const jf_gf_layer* L, double* xo, int64_t xos, double* ldo, const double* bi, double* bo, int64_t* bins, int64_t bs,
                         int32_t* st, void* s) {
     return jf::gf_chain_inv<double>(x, xs, ld_in, p, ps, pb, B, D, n, L, xo, xos, ldo, bi, bo, bins, bs, st, s);
+}
+int jf_gf_chain_inv_total_f32(const float* x, int64_t xs, const float* ld_in, const float* p, int64_t ps, int32_t pb, int64_t B, int32_t D, int32_t n,
+                              const jf_gf_layer* L, float* xo, int64_t xos, float* ldo, const float* bi, float* bo, float* total, int64_t* bins,
+                              int64_t bs, int32_t* st, void* s) {
+    if (!total) return JF_ERR_BADARG;
+    return jf::gf_chain_inv<float>(x, xs, ld_in, p, ps, pb, B, D, n, L, xo, xos, ldo, bi, bo, bins, bs, st, s, total);
+}
+int jf_gf_chain_inv_total_f64(const double* x, int64_t xs, const double* ld_in, const double* p, int64_t ps, int32_t pb, int64_t B, int32_t D, int32_t n,
+                              const jf_gf_layer* L, double* xo, int64_t xos, double* ldo, const double* bi, double* bo, double* total, int64_t* bins,
+                              int64_t bs, int32_t* st, void* s) {
+    if (!total) return JF_ERR_BADARG;
+    return jf::gf_chain_inv<double>(x, xs, ld_in, p, ps, pb, B, D, n, L, xo, xos, ldo, bi, bo, bins, bs, st, s, total);
 }
 int jf_gf_chain_inv_cot_f32(const float* x, int64_t xs, const float* p, int64_t ps, int32_t pb, int64_t B, int32_t D, int32_t n, const jf_gf_layer* L,
                             const float* ci, int64_t cis, float* co, int64_t cos, float* xo, int64_t xos, float* ldo, void* s) {

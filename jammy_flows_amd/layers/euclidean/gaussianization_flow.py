@@ -333,9 +333,9 @@ def chain_permanent_row(layers, like):
     return hit[1]
 
 
-def run_chain(layers, direction, x, log_det, params, x_out=None, base_logp_in=None, want_base_logp=False, status=None):
+def run_chain(layers, direction, x, log_det, params, x_out=None, base_logp_in=None, want_base_logp=False, status=None, want_total=False):
     """all layers of an e-block in ONE kernel launch.  `params`: (1|B, sum of the layers' total_param_num), layer order 0..n-1
-    (what the amortisation MLP emits, main/default.py:1002-1012 / :1488)."""
+    (what the amortisation MLP emits, main/default.py:1002-1012 / :1488).  want_total: see _hip.gf_chain."""
     arr = _hip.gf_layer_array([l.c_struct() for l in layers])
     return _hip.gf_chain(direction, x, log_det, params, arr, len(layers), layers[0].dimension, x_out=x_out, base_logp_in=base_logp_in,
-                         want_base_logp=want_base_logp, status=status)
+                         want_base_logp=want_base_logp, status=status, want_total=want_total)

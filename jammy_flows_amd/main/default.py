@@ -963,11 +963,16 @@ class pdf(nn.Module):
                     params = extra[:, extra.shape[1] - layers[0].total_param_num:]
                 else:
                     params = extra
+                # a pdf that is (or, threading the sums, ends with) one plain g chain: the chain launch writes log_prob = base + log_det itself
+                tot = (want_base_logp and not independent and si == n_blocks - 1 and per_block is None and self.fold_combine
+                       and not force_embedding_coordinates and not force_intrinsic_coordinates)
                 res = gfl.run_chain(layers, "inv", tgt, log_det, params, x_out=out_view, base_logp_in=base_logp,
-                                    want_base_logp=want_base_logp, status=status)
+                                    want_base_logp=want_base_logp, status=status, want_total=tot)
                 log_det = res[1]
                 if want_base_logp:
                     base_logp = res[2]
+                if tot:
+                    folded_total = res[3]
             elif _manifold_family(layers) is not None:
                 params = extra
                 if extra is not None and only_last:

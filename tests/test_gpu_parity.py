@@ -384,7 +384,8 @@ def test_fused_conditional_block_vs_golden_and_two_launch_path(name):
         with timer:
             out[mode] = pdf(x, conditional_input=cond, force_embedding_coordinates=emb)
         ran = sorted(set(k[0] for k in timer.summary()))
-        assert kernel in ran or kernel.replace("split2", "split3") in ran, (mode, ran)
+        # (split3: segment inputs read in place; _total: a pdf of one plain chain writes log_prob in the chain launch)
+        assert kernel in ran or kernel.replace("split2", "split3") in ran or kernel.replace("_inv_f32", "_inv_total_f32") in ran, (mode, ran)
         if mode != "split_bf16":
             assert "jf_cond_gf_chain_inv_split_f32" not in ran
         assert_float32_parity(out[mode][0].double().cpu().numpy(), fx["logp"], ok, "%s [%s]" % (name, mode))
@@ -1322,3 +1323,28 @@ def test_last_block_folds_the_combine_launch(rows):
     n = min(rows, gold.shape[0])
     fin = torch.isfinite(gold[:n])
     assert float(((out[True][0][:n].double() - gold[:n]).abs() / (1.0 + gold[:n].abs()))[fin].max()) < 1e-3
+
+
+@pytest.mark.parametrize("name,dtype,rows", [("c1_e2_gg", torch.float64, 4096), ("c2_e4_gggg", torch.float32, 70000), ("c2_e4_gggg", torch.float64, 3000),
+                                             ("g_e3_ggg_cond", torch.float64, 2000)])
+def test_single_g_chain_writes_log_prob_itself(name, dtype, rows):
+    """a pdf that is one plain g chain: jf_gf_chain_inv_total writes log_prob = log_prob_base + log_det in the chain launch (broadcast lane = row
+    kernel, lane = (row, coordinate) kernel for per-sample parameters) -- the bits of the separate jf_add_rows launch (pdf.fold_combine = False)"""
+    from jammy_flows_amd import _hip
+    fx = [f for f in ALL_FIXTURES if f.name == name][0]
+    reps = rows // fx["x"].shape[0] + 1
+    x = to_dev(np.tile(fx["x"], (reps, 1))[:rows], dtype)
+    cond = to_dev(None if fx.get("cond") is None else np.tile(fx["cond"], (reps, 1))[:rows], dtype)
+    out = {}
+    for fold in (False, True):
+        pdf = build_product(fx, dtype)
+        pdf.fold_combine = fold
+        pdf.fuse_conditional_blocks = False                 # (the conditional fixture: MLP launch + per-sample chain)
+        timer = _hip.KernelTimer()
+        with timer:
+            out[fold] = pdf(x, conditional_input=cond)
+        names = {k[0] for k in timer.summary()}
+        suf = "_f32" if dtype == torch.float32 else "_f64"
+        assert (("jf_gf_chain_inv_total" + suf) in names) == fold and (("jf_add_rows" + suf) in names) == (not fold), names
+    for a, b in zip(out[False], out[True]):
+        assert torch.equal(a, b)
