@@ -56,13 +56,18 @@ template <typename T> __device__ inline void spline_unpack_wh(const T* __restric
 
 // in place: unnormalised[0..nb) -> cumulative knots[0..nb]   (spline_fns.py:88-98)
 template <typename T> __device__ inline void spline_cum_knots(T* __restrict__ a, int nb, T lo, T hi, T rel_min, bool pin) {
+    // (the three loops are chains of LDS round trips when taken one element at a time: unrolled four-fold, the loads of a group are in flight
+    //  together -- these kernels sit on that latency, not on arithmetic)
     T m = a[0];
+#pragma unroll 4
     for (int j = 1; j < nb; ++j) m = M<T>::max(m, a[j]);
     T s = T(0);
+#pragma unroll 4
     for (int j = 0; j < nb; ++j) { const T e = M<T>::exp(a[j] - m); a[j] = e; s += e; }
     const T scale = T(1) - rel_min * T(nb);
     T cum = T(0);
     T prev = (hi - lo) * T(0) + lo;
+#pragma unroll 4
     for (int j = 0; j < nb; ++j) {
         const T frac = rel_min + scale * (a[j] / s);
         cum += frac;
