@@ -20,6 +20,8 @@ for mode, title in (("train", "Training step (forward + backward + one-launch Ad
                 "ms_per_step %.3f   value %.4g %s   dtype %s" % (d["ms_per_step"], d["value"], d["unit"], d["dtype"])]
         if d.get("optimizer"):
             out.append("optimizer   %s" % d["optimizer"])
+        if d.get("step_issue"):
+            out.append("step issue  %s   (eager: %s)" % (d["step_issue"], json.dumps(d.get("eager"))))
         if d.get("hip_graph_replay"):
             out.append("hip graph replay of the same step: %s" % json.dumps(d["hip_graph_replay"]))
         out.append("parity      %s" % json.dumps(d.get("parity")))
