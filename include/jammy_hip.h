@@ -522,7 +522,15 @@ typedef struct jf_c_layer { int32_t kind, hh_iter, first, reserved; double lo, h
     int jf_##fam##_chain_fwd_##suffix(const T* x, int64_t x_stride, const T* log_det_in, const T* params, int64_t param_stride,        \
                                       int32_t param_batch, int64_t B, int32_t n_layers, const jf_##fam##_layer* layers, T* x_out,      \
                                       int64_t x_out_stride, T* log_det_out, const T* base_logp_in, T* base_logp_out, int64_t* bins,    \
-                                      int64_t bins_stride, int32_t* status, void* stream);
+                                      int64_t bins_stride, int32_t* status, void* stream);                                             \
+    /* _inv as the LAST block of a pdf whose blocks were evaluated independently: ld_pre / blp_pre (<= 4 entries each, nullable) hold the   \
+     * earlier blocks' per-row sums, log_det_out / base_logp_out receive the pdf's totals (list order, this block last) and total_out =    \
+     * base_logp_out + log_det_out -- see jf_cond_gf_chain_split3_f32 / jf_combine_rows */                                                 \
+    int jf_##fam##_chain_inv_sum_##suffix(const T* x, int64_t x_stride, const T* log_det_in, const T* params, int64_t param_stride,    \
+                                          int32_t param_batch, int64_t B, int32_t n_layers, const jf_##fam##_layer* layers, T* x_out,  \
+                                          int64_t x_out_stride, T* log_det_out, const T* base_logp_in, T* base_logp_out,               \
+                                          const jf_row_list* ld_pre, const jf_row_list* blp_pre, T* total_out, int64_t* bins,          \
+                                          int64_t bins_stride, int32_t* status, void* stream);
 JF_DECLARE_MCHAIN(r, float, f32)
 JF_DECLARE_MCHAIN(r, double, f64)
 JF_DECLARE_MCHAIN(o, float, f32)

@@ -233,6 +233,8 @@ for _fam, _cls in MCHAIN_LAYER_TYPES.items():
     for _d in ("inv", "fwd"):
         _SIGNATURES["jf_%s_chain_%s" % (_fam, _d)] = [_P, _I64, _P, _P, _I64, _I32, _I64, _I32, ctypes.POINTER(_cls), _P, _I64, _P, _P, _P, _P,
                                                       _I64, _P, _P]
+    _SIGNATURES["jf_%s_chain_inv_sum" % _fam] = [_P, _I64, _P, _P, _I64, _I32, _I64, _I32, ctypes.POINTER(_cls), _P, _I64, _P, _P, _P,
+                                                 ctypes.POINTER(jf_row_list), ctypes.POINTER(jf_row_list), _P, _P, _I64, _P, _P]
     if _fam in "romf":
         _SIGNATURES["jf_cond_%s_chain_inv" % _fam] = [_P, _I64, _P, _I64, _P, _P, _I64, _P, _I32, _I32, _P, _I64, _P, _I64, _I32, ctypes.POINTER(_cls),
                                                       _P, _I64, _P, _P, _P, _P, _P]
@@ -1399,9 +1401,12 @@ def normal_logp(z, acc=None):
     return out
 
 
-def mchain(fam, direction, x, log_det, params, layer_structs, dim, x_out=None, base_logp_in=None, want_base_logp=False, bins=None, status=None):
+def mchain(fam, direction, x, log_det, params, layer_structs, dim, x_out=None, base_logp_in=None, want_base_logp=False, bins=None, status=None,
+           pre_ld=None, pre_blp=None):
     """run a chain of manifold layers of family `fam` ('r','o','m','f','v','c') on intrinsic coordinates.
-    x (B, dim) view; params (1|B, P) or None when the chain has no parameters.  Returns (x_out, log_det_out[, base_logp])."""
+    x (B, dim) view; params (1|B, P) or None when the chain has no parameters.  Returns (x_out, log_det_out[, base_logp]).
+    pre_ld / pre_blp ('inv' with want_base_logp; lists of (B,) tensors, <= 4 each): the chain is the last block of its pdf and also adds the
+    earlier blocks' sums in front of its own -> (x_out, log_det total, base_logp total, total log-prob) (jf_<fam>_chain_inv_sum)."""
     dev = require_device(x, log_det, params, x_out, base_logp_in, status, bins)
     x = _rowmajor(x)
     B = x.shape[0]
@@ -1437,6 +1442,24 @@ def mchain(fam, direction, x, log_det, params, layer_structs, dim, x_out=None, b
             BINS_LOG.append(bins)
     if bins is not None:
         assert bins.dtype == torch.int64 and bins.dim() == 2 and bins.shape[0] == B and bins.stride(1) == 1
+    if pre_ld is not None or pre_blp is not None:
+        if direction != "inv" or not want_base_logp:
+            raise ValueError("mchain: pre_ld / pre_blp need direction 'inv' and want_base_logp")
+        def lst(items):
+            r = jf_row_list()
+            r.n = len(items)
+            for i, t in enumerate(items):
+                if t.dtype != x.dtype or t.shape != (B,) or not t.is_contiguous():
+                    raise ValueError("mchain: pre_ld / pre_blp entries are contiguous (B,) tensors of the input dtype")
+                r.p[i] = _ptr(t)
+            return r
+        require_device(x, *(list(pre_ld or []) + list(pre_blp or [])))
+        la, lb = lst(list(pre_ld or [])), lst(list(pre_blp or []))
+        total = torch.empty((B,), dtype=x.dtype, device=x.device)
+        _launch("jf_%s_chain_inv_sum%s" % (fam, suf), "bcast" if pb == 1 else "per-sample",
+                (_ptr(x), x.stride(0), _ptr(log_det), pptr, pstride, pb, B, n, arr, _ptr(x_out), x_out.stride(0), _ptr(ld_out), _ptr(base_logp_in),
+                 _ptr(blp_out), ctypes.byref(la), ctypes.byref(lb), _ptr(total), _ptr(bins), bins.stride(0) if bins is not None else 0, _ptr(status)), dev)
+        return x_out, ld_out, blp_out, total
     _launch(name, "bcast" if pb == 1 else "per-sample",
             (_ptr(x), x.stride(0), _ptr(log_det), pptr, pstride, pb, B, n, arr, _ptr(x_out), x_out.stride(0), _ptr(ld_out), _ptr(base_logp_in),
              _ptr(blp_out), _ptr(bins), bins.stride(0) if bins is not None else 0, _ptr(status)), dev)

@@ -11,6 +11,7 @@
 
 namespace jf {
 
+constexpr int MC_MAX_PRE = 4;
 template <typename T, typename CLayer> struct MChainArgs {
     const T* x; int64_t xs;
     const T* ld_in;
@@ -33,6 +34,11 @@ template <typename T, typename CLayer> struct MChainArgs {
     const T* blp_in; T* blp_out;
     int64_t* bins; int64_t bins_stride;
     int32_t* status;
+    // log-prob direction, the LAST block of a pdf (jf_<fam>_chain_inv_sum): the earlier blocks' per-row log-dets / base log-probs, added in list
+    // order in front of this block's; ld_out / blp_out then hold the pdf's totals and total = blp_out + ld_out (what jf_combine_rows returns)
+    const T* ld_pre[MC_MAX_PRE]; const T* blp_pre[MC_MAX_PRE];
+    int n_ld_pre, n_blp_pre;
+    T* total;
 };
 
 template <typename T, class Fam, bool FWD>
@@ -81,12 +87,24 @@ __global__ void __launch_bounds__(64) mchain_kernel(const MChainArgs<T, typename
     if (active) {
 #pragma unroll
         for (int d = 0; d < Fam::DIM; ++d) if (d < a.dim) a.x_out[row * a.xos + d] = x[d];
-        a.ld_out[row] = ld;
+        T ldv = ld;
+        if (a.n_ld_pre > 0) {                              // uniform: list order, this block last (the bits of jf_combine_rows)
+            T t = a.ld_pre[0][row];
+            for (int i = 1; i < a.n_ld_pre; ++i) t += a.ld_pre[i][row];
+            ldv = t + ld;
+        }
+        a.ld_out[row] = ldv;
         if (a.blp_out) {
             T s = a.blp_in ? a.blp_in[row] : T(0);
 #pragma unroll
             for (int d = 0; d < Fam::DIM; ++d) if (d < a.dim) s += T(-0.5) * x[d] * x[d] - M<T>::HALF_LN_2PI;
+            if (a.n_blp_pre > 0) {
+                T t = a.blp_pre[0][row];
+                for (int i = 1; i < a.n_blp_pre; ++i) t += a.blp_pre[i][row];
+                s = t + s;
+            }
             a.blp_out[row] = s;
+            if (a.total) a.total[row] = s + ldv;
         }
     }
     status_add(a.status, JF_STATUS_NONFINITE, active && (bad || ctx.nonfinite));
@@ -97,8 +115,13 @@ __global__ void __launch_bounds__(64) mchain_kernel(const MChainArgs<T, typename
 template <typename T, class Fam, bool FWD>
 static int mchain(const T* x, int64_t xs, const T* ld_in, const T* params, int64_t ps, int32_t pb, int64_t B, int32_t n_layers,
                   const typename Fam::CLayer* layers, T* x_out, int64_t xos, T* ld_out, const T* blp_in, T* blp_out, int64_t* bins,
-                  int64_t bins_stride, int32_t* status, void* stream) {
+                  int64_t bins_stride, int32_t* status, void* stream, const jf_row_list* ld_pre = nullptr, const jf_row_list* blp_pre = nullptr,
+                  T* total = nullptr) {
     if (!x || !x_out || !ld_out || !layers || n_layers < 1 || n_layers > JF_MAX_MCHAIN || B < 0) return JF_ERR_BADARG;
+    if ((ld_pre || blp_pre || total) && (FWD || !blp_out)) return JF_ERR_BADARG;
+    if ((ld_pre && (ld_pre->n < 0 || ld_pre->n > MC_MAX_PRE)) || (blp_pre && (blp_pre->n < 0 || blp_pre->n > MC_MAX_PRE))) return JF_ERR_UNSUPPORTED;
+    if (ld_pre) for (int i = 0; i < ld_pre->n; ++i) if (!ld_pre->p[i]) return JF_ERR_BADARG;
+    if (blp_pre) for (int i = 0; i < blp_pre->n; ++i) if (!blp_pre->p[i]) return JF_ERR_BADARG;
     if (pb != 1 && pb != B) return JF_ERR_BADARG;
     if (B == 0) return JF_OK;
     MChainArgs<T, typename Fam::CLayer> a{};
@@ -118,6 +141,9 @@ static int mchain(const T* x, int64_t xs, const T* ld_in, const T* params, int64
     a.dim = Fam::DIM;
     if constexpr (std::is_same<Fam, CFam>::value) a.dim = layers[0].kind == 2 ? 2 : 1;
     a.x_out = x_out; a.xos = xos; a.ld_out = ld_out; a.blp_in = blp_in; a.blp_out = blp_out; a.bins = bins; a.bins_stride = bins_stride; a.status = status;
+    if (ld_pre) { for (int i = 0; i < ld_pre->n; ++i) a.ld_pre[i] = static_cast<const T*>(ld_pre->p[i]); a.n_ld_pre = ld_pre->n; }
+    if (blp_pre) { for (int i = 0; i < blp_pre->n; ++i) a.blp_pre[i] = static_cast<const T*>(blp_pre->p[i]); a.n_blp_pre = blp_pre->n; }
+    a.total = total;
     a.scratch = 0;
     if constexpr (std::is_same<Fam, FFam>::value) {
         for (int l = 0; l < n_layers; ++l) {
@@ -186,6 +212,13 @@ using namespace jf;
         CHECK                                                                                                                                  \
         return mchain<T, Fam, false>(x, xs, ld_in, p, ps, pb, B, n, L, xo, xos, ldo, bi, bo, bins, bst, st, s);                                \
     }                                                                                                                                          \
+    extern "C" int jf_##fam##_chain_inv_sum_##suffix(const T* x, int64_t xs, const T* ld_in, const T* p, int64_t ps, int32_t pb, int64_t B,     \
+                                                     int32_t n, const jf_##fam##_layer* L, T* xo, int64_t xos, T* ldo, const T* bi, T* bo,      \
+                                                     const jf_row_list* ldp, const jf_row_list* blpp, T* tot, int64_t* bins, int64_t bst,       \
+                                                     int32_t* st, void* s) {                                                                    \
+        CHECK                                                                                                                                  \
+        return mchain<T, Fam, false>(x, xs, ld_in, p, ps, pb, B, n, L, xo, xos, ldo, bi, bo, bins, bst, st, s, ldp, blpp, tot);                \
+    }                                                                                                                                          \
     extern "C" int jf_##fam##_chain_fwd_##suffix(const T* x, int64_t xs, const T* ld_in, const T* p, int64_t ps, int32_t pb, int64_t B, int32_t n, \
                                                  const jf_##fam##_layer* L, T* xo, int64_t xos, T* ldo, const T* bi, T* bo, int64_t* bins,     \
                                                  int64_t bst, int32_t* st, void* s) {                                                          \
@@ -222,6 +255,10 @@ extern "C" int jf_v_chain_inv_f32(const float*, int64_t, const float*, const flo
                                   float*, const float*, float*, int64_t*, int64_t, int32_t*, void*) { return JF_ERR_UNSUPPORTED; }
 extern "C" int jf_v_chain_fwd_f32(const float*, int64_t, const float*, const float*, int64_t, int32_t, int64_t, int32_t, const jf_v_layer*, float*, int64_t,
                                   float*, const float*, float*, int64_t*, int64_t, int32_t*, void*) { return JF_ERR_UNSUPPORTED; }
+extern "C" int jf_v_chain_inv_sum_f32(const float*, int64_t, const float*, const float*, int64_t, int32_t, int64_t, int32_t, const jf_v_layer*, float*, int64_t,
+                                      float*, const float*, float*, const jf_row_list*, const jf_row_list*, float*, int64_t*, int64_t, int32_t*, void*) {
+    return JF_ERR_UNSUPPORTED;
+}
 
 extern "C" {
 int jf_sphere_to_embedding_f32(const float* x, int64_t xs, const float* li, int64_t B, int32_t dim, float* xo, int64_t xos, float* lo, void* s) {

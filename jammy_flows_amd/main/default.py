@@ -147,7 +147,7 @@ def _layer_groups(layers):
     return groups
 
 
-def _manifold_chain(fam, layers, direction, x, log_det, extra, only_last_first, x_out, base_logp_in, want_base_logp, status):
+def _manifold_chain(fam, layers, direction, x, log_det, extra, only_last_first, x_out, base_logp_in, want_base_logp, status, pre_ld=None, pre_blp=None):
     structs = []
     for l in layers:
         if fam == "r":
@@ -160,7 +160,7 @@ def _manifold_chain(fam, layers, direction, x, log_det, extra, only_last_first, 
     else:
         params = extra
     return _hip.mchain(fam, direction, x, log_det, params, structs, layers[0].dimension, x_out=x_out, base_logp_in=base_logp_in,
-                       want_base_logp=want_base_logp, status=status)
+                       want_base_logp=want_base_logp, status=status, pre_ld=pre_ld, pre_blp=pre_blp)
 
 
 class pdf(nn.Module):
@@ -977,11 +977,20 @@ class pdf(nn.Module):
                 params = extra
                 if extra is not None and only_last:
                     params = extra[:, extra.shape[1] - layers[0].total_param_num:]
+                pl = pb_ = None
+                if (independent and want_base_logp and si == n_blocks - 1 and not lanes and not overlap and self.fold_combine
+                        and _hip.BINS_LOG is None):
+                    # the last block adds the earlier blocks' sums itself and writes log_prob (as the fused g block does): no combine launch
+                    pl, pb_ = [t for t in ld_parts if t is not None], [t for t in blp_parts if t is not None]
+                    if len(pl) > _hip.COND_GF_MAX_PRE or len(pb_) > _hip.COND_GF_MAX_PRE:
+                        pl = pb_ = None
                 res = _manifold_chain(_manifold_family(layers), layers, "inv", tgt, log_det, params, only_last and kind == "s", out_view,
-                                      base_logp, want_base_logp, status)
+                                      base_logp, want_base_logp, status, pre_ld=pl, pre_blp=pb_)
                 log_det = res[1]
                 if want_base_logp:
                     base_logp = res[2]
+                if pl is not None:
+                    folded_total = res[3]
             else:
                 if log_det is None:
                     log_det = torch.zeros(B, dtype=x.dtype, device=x.device)

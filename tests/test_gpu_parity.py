@@ -1293,6 +1293,34 @@ def test_broadcast_logprob_underflowed_rows_depend_on_their_own_target_only(frac
         assert torch.equal(pdf32(centre)[0][::64], lp32[idx])
 
 
+@pytest.mark.parametrize("name,dtype,rows", [("c4_i1s1_ro", torch.float32, 3000), ("c4_i1s1_ro", torch.float64, 70000), ("c5_e8s2_ggggv", torch.float64, 5000),
+                                             ("f_s2_cond_ff", torch.float64, 1000)])
+def test_last_manifold_block_folds_the_combine_launch(name, dtype, rows):
+    """a pdf that ends with a manifold chain (C4: 'o', C5: 'v'): jf_<fam>_chain_inv_sum adds the earlier blocks' sums and writes log_prob in the
+    chain launch -- the bits of the separate jf_combine_rows launch (pdf.fold_combine = False); single-block pdfs are untouched"""
+    from jammy_flows_amd import _hip
+    fx = [f for f in ALL_FIXTURES if f.name == name][0]
+    reps = rows // fx["x"].shape[0] + 1
+    x = to_dev(np.tile(fx["x"], (reps, 1))[:rows], dtype)
+    cond = to_dev(None if fx.get("cond") is None else np.tile(fx["cond"], (reps, 1))[:rows], dtype)
+    emb = bool(fx.meta["embedding"])
+    out = {}
+    suf = "_f32" if dtype == torch.float32 else "_f64"
+    for fold in (False, True):
+        pdf = build_product(fx, dtype)
+        pdf.fold_combine = fold
+        pdf.check_status = False
+        timer = _hip.KernelTimer()
+        with timer:
+            out[fold] = pdf(x, conditional_input=cond, force_embedding_coordinates=emb)
+        names = {k[0] for k in timer.summary()}
+        multi = len(pdf.layer_list) > 1
+        assert (("jf_combine_rows" + suf) in names) == (multi and not fold), (fold, names)
+        assert any(k.endswith("_chain_inv_sum" + suf) for k in names) == (multi and fold), (fold, names)
+    for a, b in zip(out[False], out[True]):
+        assert torch.equal(a, b) or (torch.isnan(a) == torch.isnan(b)).all() and torch.equal(torch.nan_to_num(a), torch.nan_to_num(b))
+
+
 @pytest.mark.parametrize("rows", [192, 5000, 1 << 17])
 def test_last_block_folds_the_combine_launch(rows):
     """The last fused block of a pdf adds the earlier blocks' log-dets / base log-probs in its epilogue and writes log_prob itself

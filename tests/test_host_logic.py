@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol():
     header = open(os.path.join(ROOT, "include", "jammy_hip.h")).read()
     declared = set(re.findall(r"\bint(?:64_t|32_t)?\s+(jf_[a-z0-9_]+)\s*\(", header))
     for fam, suffix in re.findall(r"^JF_DECLARE_MCHAIN\((\w+),\s*\w+,\s*(\w+)\)", header, flags=re.M):   # macro-declared chain entry points
-        declared |= {"jf_%s_chain_inv_%s" % (fam, suffix), "jf_%s_chain_fwd_%s" % (fam, suffix)}
+        declared |= {"jf_%s_chain_inv_%s" % (fam, suffix), "jf_%s_chain_fwd_%s" % (fam, suffix), "jf_%s_chain_inv_sum_%s" % (fam, suffix)}
     for suffix in re.findall(r"^JF_DECLARE_T\(\w+,\s*(\w+)\)", header, flags=re.M):
         declared |= {"jf_t_layer_inv_" + suffix, "jf_t_layer_fwd_" + suffix, "jf_t_layer_inv_bwd_" + suffix}
     for suffix in re.findall(r"^JF_DECLARE_AMLP\(\w+,\s*(\w+)\)", header, flags=re.M):
