@@ -298,7 +298,8 @@ template <typename T> __device__ __forceinline__ void gfb_scaled_rows(const GfPa
     unsigned long long mask = __ballot(under);
     const int lane = threadIdx.x & 63, grp = lane >> 4, k = lane & 15;
     const bool comp = k < K;
-    const GfPack<T> e = pd[comp ? k : 0];
+    GfPack<T> e = pd[comp ? k : 0];
+    if constexpr (sizeof(T) == 4) e.iw *= T(-0.6931471805599453);     // the float32 records carry -log2(e) / width (see the pack loop)
     const T pk = comp ? e.pi : T(0);
     while (mask != 0ull) {                                      // wave-uniform
         const int rank = __popcll(mask & ((1ull << lane) - 1ull));     // this lane's row is the rank-th underflowed row still to do
@@ -355,6 +356,9 @@ template <typename T, int D> __global__ void __launch_bounds__(256) gfb_chain_in
             e.iw = row[o.off_lw + k * D + d];
             e.pi = o.fit_norm ? row[o.off_ln + k * D + d] : M<T>::rcp(T(o.K));
             e.piw = e.pi * e.iw;
+            // float32: the record carries -log2(e) / width, so that e^{-|u|} = 2^{|x - mean| iw} is one multiply and v_exp_f32 (the sign of u
+            // is the sign of x - mean): one VALU instruction less per component (14.5 -> 13.5)
+            if constexpr (sizeof(T) == 4) e.iw *= T(-1.4426950408889634);
             pack[l * pstride + j] = e;
         }
     }
@@ -394,8 +398,14 @@ template <typename T, int D> __global__ void __launch_bounds__(256) gfb_chain_in
 #pragma unroll GFB_UNROLL                                    // (float64 at 5: 132 -> 163 VGPRs, 0.57 -> 0.60 ms per 2^20 rows)
                 for (int k = 0; k < o.K; ++k) {
                     const GfPack<T> e = pd[k];
-                    const T u = (x[d] - e.mean) * e.iw;
-                    const T tt = M<T>::exp_fast(-M<T>::abs(u));
+                    T u, tt;
+                    if constexpr (sizeof(T) == 4) {
+                        u = x[d] - e.mean;                 // (only its sign is used below)
+                        tt = __builtin_amdgcn_exp2f(M<T>::abs(u) * e.iw);
+                    } else {
+                        u = (x[d] - e.mean) * e.iw;
+                        tt = M<T>::exp_fast(-M<T>::abs(u));
+                    }
                     const T hi = M<T>::rcp(T(1) + tt);     // sigma(|u|)
                     const T lo = tt * hi;                  // sigma(-|u|)
                     const bool pos = u >= T(0);
