@@ -679,21 +679,25 @@ def dry_run(args, W, rank, world, B, total_rows, lo):
 
 
 # ---------------------------------------------------------------------------------------------- after the timed region: sweeps and the other configurations
-def _time_steps(fn, flush, steps, warm=5):
+def _time_steps(fn, flush, steps, warm=5, repeats=1):
+    """seconds per call of fn (median of `repeats` timed loops of `steps` calls, each ended by flush() + a device synchronisation)"""
     import torch
     for _ in range(warm):
         fn()
     flush()
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        fn()
-    flush()
-    torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / steps
+    out = []
+    for _ in range(repeats):
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        flush()
+        torch.cuda.synchronize()
+        out.append((time.perf_counter() - t0) / steps)
+    return sorted(out)[len(out) // 2]
 
 
-def rows_sweep(pdf, x, c, steps=50):
+def rows_sweep(pdf, x, c, steps=50, depth=1):
     """the step time against the batch size on this one GPU (prefixes of the resident inputs): what strong scaling over G GPUs needs is
     t(B / G) <= t(B) / (G x 0.85), BASELINE.md section 3.  Every size runs through its own recorded step plan, like the timed step."""
     B = x.shape[0]
@@ -703,8 +707,17 @@ def rows_sweep(pdf, x, c, steps=50):
         if n > B:
             continue
         xs, cs = x[:n], (None if c is None else c[:n])
-        dt = _time_steps(lambda: pdf(xs, conditional_input=cs), pdf.flush_status, steps if lg >= 19 else 4 * steps)
-        out.append({"log2_rows": lg, "ms_per_step": 1e3 * dt, "evals_per_s": n / dt})
+        if depth > 1:                                  # as the timed step: consecutive steps on alternating streams
+            pipe = pdf.pipelined_forward(xs, conditional_input=cs, depth=depth)
+            dt = _time_steps(lambda: pipe.submit(xs, cs), pipe.drain, steps if lg >= 19 else 4 * steps, warm=20, repeats=3)
+            del pipe
+        else:
+            dt = _time_steps(lambda: pdf(xs, conditional_input=cs), pdf.flush_status, steps if lg >= 19 else 4 * steps, warm=20, repeats=3)
+        row = {"log2_rows": lg, "ms_per_step": 1e3 * dt, "evals_per_s": n / dt}
+        if depth > 1:
+            row["one_stream_ms_per_step"] = 1e3 * _time_steps(lambda: pdf(xs, conditional_input=cs), pdf.flush_status, steps if lg >= 19 else 4 * steps,
+                                                              warm=20, repeats=3)
+        out.append(row)
     if out:
         top = out[0]
         for r in out:
@@ -803,6 +816,9 @@ def main():
                     help="run the step untimed for this long before the warm-up steps, so that the timed region sees the chip's sustained clocks (0 = off)")
     ap.add_argument("--no-sweep", action="store_true", help="skip the rows sweep and the table of the other BASELINE configurations (measured after the timed region)")
     ap.add_argument("--no-plan", action="store_true", help="eager pdf.forward (one ctypes call per launch) instead of the recorded step plan")
+    ap.add_argument("--pipeline-depth", type=int, default=2,
+                    help="log-prob steps alternate between this many HIP streams, each through its own recorded plan (pdf.pipelined_forward): the batches "
+                         "of consecutive steps are independent, so the tail of one step overlaps the head of the next; 1 = one stream")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--dry-run", action="store_true",
                     help="exercise launch / rendezvous / row sharding / timing loop / all-gather with a stand-in step on the host (no GPU, no kernels): "
@@ -916,13 +932,31 @@ def main():
         gather = parallel.PipelinedGather(B, dtype, dev) if (world > 1 and total_rows % world == 0) else None
         last = {}
 
+        # consecutive steps are independent batches: they alternate between `--pipeline-depth` streams, each through its own recorded plan, so
+        # the idle tail of one step's last round of workgroups is filled by the head of the next step (DESIGN "small shards"); every step's
+        # kernels, status words and (N > 1) all-gather still complete inside the timed region (finish())
+        pipe = None
+        if not args.no_plan and args.pipeline_depth > 1:
+            pipe = pdf.pipelined_forward(x, conditional_input=c, depth=args.pipeline_depth)
+
         def step():
+            if pipe is not None:
+                t = pipe.submit(x, c)
+                if gather is not None:
+                    with torch.cuda.stream(t.stream):     # the collective waits for THIS step's kernels
+                        gather.submit(t.outputs[0])
+                last["pending"] = t
+                return
             logp = pdf(x, conditional_input=c)[0]
             if gather is not None:
                 gather.submit(logp)
             last["logp"] = logp
 
         def finish():
+            if pipe is not None:
+                pipe.drain()                          # the current stream waits for every submitted step; their status words are examined
+                if "pending" in last:
+                    last["logp"] = last["pending"].result()[0]
             pdf.flush_status()                        # deferred kernel status words of the timed steps: raises if any row went wrong
             if gather is not None:
                 gather.wait()                         # every step's gather has landed inside the timed region
@@ -970,7 +1004,7 @@ def main():
         results[dname] = dict(dt=dt, evals_per_s=total_rows * args.steps / dt, ms_per_step=1e3 * dt / args.steps, err=err, identical=identical, repeats=repeats,
                               untiled=untiled)
         if rank == 0 and world == 1 and dname == main_dt and not args.no_sweep:
-            results[dname]["rows_sweep"] = rows_sweep(pdf, x, c)
+            results[dname]["rows_sweep"] = rows_sweep(pdf, x, c, depth=args.pipeline_depth if pipe is not None else 1)
         if timer is not None:
             kernel_table = timer.summary()
             if rank == 0 and world == 1:
@@ -1113,7 +1147,10 @@ def main():
                            "agreement is ~3e-5); `cpu_baseline` is the float64 oracle; the like-for-like float64 rate is under `float64`")
                           if main_dt == "f32" else None,
             "preheat_ms": args.preheat_ms,
-            "step_issue": "recorded step plan: one ctypes call per step (jf_plan_launch)" if not args.no_plan else "eager: one ctypes call per launch",
+            "step_issue": ("recorded step plan: one ctypes call per step (jf_plan_launch)" + (
+                "; consecutive steps alternate between %d streams (pdf.pipelined_forward)" % args.pipeline_depth if args.pipeline_depth > 1 else ""))
+            if not args.no_plan else "eager: one ctypes call per launch",
+            "pipeline_depth": 1 if args.no_plan else args.pipeline_depth,
             "roofline": roofline,
             "cpu_baseline": cpu,
         }
@@ -1152,6 +1189,9 @@ def main():
             top = sw[0]["log2_rows"]
             if top - 3 in by:
                 line["rows_sweep"]["predicted_8gpu_strong_scaling_efficiency"] = by[top]["ms_per_step"] / (8 * by[top - 3]["ms_per_step"])
+                if "one_stream_ms_per_step" in by[top]:
+                    line["rows_sweep"]["predicted_8gpu_strong_scaling_efficiency_one_stream"] = (by[top]["one_stream_ms_per_step"] /
+                                                                                                 (8 * by[top - 3]["one_stream_ms_per_step"]))
                 line["rows_sweep"]["note"] = ("T_1 / (8 T_8) with T_8 = this GPU's time on an eighth of the batch: compute only, the per-step log-prob "
                                               "all-gather (512 KiB per rank) comes on top")
         if rank == 0 and world == 1 and not args.no_sweep:

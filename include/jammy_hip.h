@@ -674,6 +674,22 @@ int jf_device_math_f64(const double* x, int64_t n, int32_t fn, double* out, void
 /* The last operations of pdf.forward / all_layer_inverse (main/default.py:1110-1117): the sub-manifold blocks of the log-prob direction are
  * independent given the targets, so every block returns its OWN log-det and base log-prob (ld_in = blp_in = NULL) and one launch adds them up,
  * in list order: ld_out[b] = sum_i ld.p[i][b], blp_out[b] = sum_i blp.p[i][b], total_out[b] = blp_out[b] + ld_out[b] (each output nullable). */
+/* Broadcast-parameter g chains of 2 .. 4 dimensions, log-prob direction: batches of fewer than `rows` rows run with one lane per (row,
+ * coordinate) instead of one lane per row -- more waves for small batches, bit-identical results (csrc/jf_gfb.h).  Sets the threshold (0: always
+ * one lane per row; negative: back to the default 2^16 / JF_GFB_LANE_ROWS) and returns the previous one. */
+int64_t jf_gf_bcast_lane_rows(int64_t rows);
+/* Two side blocks of a log-prob step in ONE launch (csrc/merged_kernels.hip).  The blocks of the log-prob direction are independent given the
+ * targets (main/default.py:946-962); between jf_merge_begin and jf_merge_end the launches this thread's entry points would issue are captured
+ * instead, and jf_merge_end issues ONE grid that runs the captured blocks side by side (the blocks' own device code: bit-identical per-row
+ * results).  Accepted: exactly one broadcast g chain (jf_gf_chain_inv_f32, param_batch 1, D <= 4, classic layers) and one conditional `f` block
+ * (jf_cond_f_chain_inv_f32, one layer) over the same B rows.  Otherwise the captured launches are issued one by one in their order and
+ * JF_MERGE_DECLINED is returned; the results are in place either way.  Inside a step-plan recording the (merged or replayed) launches go to
+ * the plan.  jf_merge_abort drops the captured launches (error paths); jf_merge_captured = launches captured so far. */
+#define JF_MERGE_DECLINED 1
+int jf_merge_begin(void);
+int jf_merge_abort(void);
+int jf_merge_captured(void);
+int jf_merge_end(void* stream);
 /* (jf_row_list / JF_MAX_ROW_LISTS: defined above, before jf_cond_gf_chain_split3_f32) */
 int jf_combine_rows_f32(const jf_row_list* ld, const jf_row_list* blp, int64_t B, float* ld_out, float* blp_out, float* total_out, void* stream);
 int jf_combine_rows_f64(const jf_row_list* ld, const jf_row_list* blp, int64_t B, double* ld_out, double* blp_out, double* total_out, void* stream);

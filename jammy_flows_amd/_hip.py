@@ -157,6 +157,11 @@ _SIGNATURES = {
 }
 # entry points that exist for one precision only: full symbol name -> (argtypes, restype)
 _SIGNATURES_SINGLE = {
+    "jf_gf_bcast_lane_rows": ([_I64], ctypes.c_int64),
+    "jf_merge_begin": ([], ctypes.c_int),
+    "jf_merge_abort": ([], ctypes.c_int),
+    "jf_merge_captured": ([], ctypes.c_int),
+    "jf_merge_end": ([_P], ctypes.c_int),
     "jf_plan_create": ([], ctypes.c_int64),
     "jf_plan_destroy": ([_I64], ctypes.c_int32),
     "jf_plan_add_slot": ([_I64, _P, _I64], ctypes.c_int32),
@@ -372,7 +377,7 @@ def _launch(name, tag, args, dev, unsupported_ok=False):
             rc = fn(*args)
             if rc == JF_OK:
                 _RECORDING.calls.append((name, tag, n0, _RECORDING.num_ops()))
-        elif _TIMER is None:
+        elif _TIMER is None or _MERGING:              # (a captured launch is issued by merge_end: nothing to time here)
             rc = fn(*args)
         else:
             e0 = torch.cuda.Event(enable_timing=True)
@@ -408,6 +413,26 @@ def _rowmajor(t):
 
 def new_status(device):
     return torch.zeros(JF_STATUS_WORDS, dtype=torch.int32, device=device)
+
+
+class _MappedHolder:
+    def __init__(self, t):
+        self.t = t
+        self.__cuda_array_interface__ = {"shape": tuple(t.shape), "typestr": "<i4", "data": (t.data_ptr(), False), "version": 2}
+
+
+def mapped_status(device):
+    """status words in PINNED HOST memory -> (host tensor, device-side view of the same words).  The kernels raise a status word with one
+    atomic per wave and only when something is wrong (csrc/jf_common.h status_add), so words that live on the host cost a healthy step
+    nothing -- and the host can look at them without a copy-back on the stream (a recorded step spent ~5 us per replay on its 16-byte
+    __amd_rocclr_copyBuffer: 4 % of a 2^17-row step).  Pinned memory is mapped into the device's address space at the same address."""
+    host = torch.zeros(JF_STATUS_WORDS, dtype=torch.int32).pin_memory()
+    with torch.cuda.device(device):
+        view = torch.as_tensor(_MappedHolder(host), device=device)
+    if view.data_ptr() != host.data_ptr():
+        raise RuntimeError("pinned host memory is not mapped at its own address on this platform")
+    view._jf_host = host                      # the view does not own the memory
+    return host, view
 
 
 # --------------------------------------------------------------------------------------------------------------
@@ -532,6 +557,52 @@ def combine_rows(ld_list, blp_list, want_total=True):
         _launch("jf_combine_rows" + _suffix(like), "", (ctypes.byref(a), ctypes.byref(b), B, _ptr(ld_out), _ptr(blp_out), _ptr(total)), dev)
     return (ld_out if ld_out is not None else (ld_list[0] if ld_list else None),
             blp_out if blp_out is not None else (blp_list[0] if blp_list else None), total)
+
+
+# ---- two side blocks of a log-prob step in one launch (csrc/merged_kernels.hip): merge_begin(); <the blocks' entry points>; merge_end(like)
+JF_MERGE_DECLINED = 1
+_MERGING = False
+
+
+def merge_begin():
+    """from here to merge_end() the launches of this thread's entry points are captured by the library instead of issued"""
+    global _MERGING
+    _check(int(lib().jf_merge_begin()), "jf_merge_begin")
+    _MERGING = True
+
+
+def merge_abort():
+    global _MERGING
+    if _MERGING:
+        _MERGING = False
+        lib().jf_merge_abort()
+
+
+def merge_end(like):
+    """issue the captured blocks (a broadcast g chain + an `f` block) as one launch on `like`'s device; a combination the library does not
+    merge has been issued launch by launch instead: either way the results are in place.  -> True when merged"""
+    global _MERGING
+    dev = require_device(like)
+    _MERGING = False
+    fn = lib().jf_merge_end
+    with torch.cuda.device(dev):
+        stream = torch.cuda.current_stream(dev)
+        if _RECORDING is not None:
+            n0 = _RECORDING.num_ops()
+            rc = int(fn(stream.cuda_stream))
+            _RECORDING.calls.append(("jf_merge_end", "", n0, _RECORDING.num_ops()))
+        elif _TIMER is None:
+            rc = int(fn(stream.cuda_stream))
+        else:
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            rc = int(fn(stream.cuda_stream))
+            e1.record(stream)
+            _TIMER.records.append(("jf_merge_end", "", e0, e1))
+    if rc != JF_MERGE_DECLINED:
+        _check(rc, "jf_merge_end")
+    return rc == JF_OK
 
 
 def add_rows(a, b):

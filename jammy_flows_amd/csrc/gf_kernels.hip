@@ -14,37 +14,11 @@
 //       back (stage_rows) into an LDS tile whose row stride is 4*odd dwords, then read by the lanes of each row.  A wave's tile is a few
 //       KB, so 16+ waves per CU are resident and the HBM latency of one wave's slab is covered by the arithmetic of the others.
 //       HBM traffic is the algorithmic minimum (every parameter byte is read exactly once).
-#include "jf_gf.h"
-#include "jf_gf_ext.h"
-#include "jf_cond_regs.h"
+#include "jf_gfb.h"
+#include "jf_merge.h"
 
 namespace jf {
 
-template <typename T> struct GfChainArgs {
-    const T* x; int64_t xs;
-    const T* ld_in;
-    const T* params; int64_t ps;
-    int64_t B;
-    int D;
-    int n_layers;
-    int tiles_per_block;     // broadcast kernels: row tiles walked by one workgroup
-    int tile_stride;         // per-sample: LDS row stride (elements); broadcast: row capacity per layer
-    int tab_offset;          // element offset of the spline knot tables behind the parameter tile
-    GfLayerDev<T> L[JF_MAX_CHAIN];
-    T* x_out; int64_t xos;
-    T* ld_out;
-    const T* blp_in; T* blp_out;
-    int64_t* bins; int64_t bins_stride;
-    int32_t* status;
-    // log-prob direction only: a co-vector carried along with x -- v <- J_l^{-T} v per layer (J_l = diag(dy/dx) Q_l^T: the same reflections as x,
-    // then a division by the stage's derivative), i.e. cot_out = J^{-T} cot_in for the chain's Jacobian J = dy/dx (jf_gf_chain_inv_cot)
-    const T* cot_in; int64_t cis;
-    T* cot_out; int64_t cos;
-    T* total;                // log-prob direction, nullable (needs blp_out): total[b] = blp_out[b] + ld_out[b] -- log_prob = log_prob_base + log_det
-                             // (main/default.py:1110-1117) written by the chain launch itself instead of a launch of its own
-    // sampling direction, broadcast parameters only: interpolation table of every (layer, coordinate)'s inverse x(z) (gf_fwd_table_kernel), or null
-    T* table;
-};
 
 // ---- the start table of the broadcast sampler.  With row-independent parameters the solve of (layer l, coordinate d) inverts ONE fixed monotone
 // function for every row: x_{l,d}(z).  gf_fwd_table_kernel solves it on GT_N + 1 knots of z in [-zmax, zmax] (plus the interval midpoints),
@@ -117,24 +91,6 @@ template <typename T> __global__ void __launch_bounds__(192) gf_fwd_table_kernel
     }
 }
 
-template <int G> struct Log2 { static constexpr int v = (G == 1) ? 0 : (G == 2) ? 1 : (G == 4) ? 2 : (G == 8) ? 3 : (G == 16) ? 4 : 5; };
-
-// broadcast regime: raw rows -> LDS, then wave w derives layers w, w+4, ... (columns on lanes 0..D-1, reflections on lanes 32..)
-template <typename T> __device__ __forceinline__ void derive_broadcast(T* lds, const GfChainArgs<T>& a) {
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    for (int l = 0; l < a.n_layers; ++l) {
-        const GfLayerDev<T> o = a.L[l];
-        for (int j = tid; j < o.n_params; j += blockDim.x) lds[l * a.tile_stride + j] = a.params[o.col0 + j];
-    }
-    __syncthreads();
-    for (int l = wave; l < a.n_layers; l += 4) {
-        const GfLayerDev<T> o = a.L[l];      // wave-uniform index
-        T* row = lds + l * a.tile_stride;
-        if (lane < a.D) { if (o.stretch == JF_GF_STRETCH_CLASSIC) gf_derive_column<T>(row, o, a.D, lane); }
-        else if (lane >= 32 && lane - 32 < o.hh) gf_derive_reflection<T>(row, o, a.D, lane - 32);
-    }
-    __syncthreads();
-}
 
 template <typename T, int G, bool BCAST, bool FWD>
 __global__ void __launch_bounds__(BCAST ? 256 : 64, sizeof(T) == 8 ? 2 : 4) gf_chain_kernel(const GfChainArgs<T> a) {
@@ -271,182 +227,17 @@ __global__ void __launch_bounds__(BCAST ? 256 : 64, sizeof(T) == 8 ? 2 : 4) gf_c
     }
 }
 
-// Broadcast regime, log-prob direction, classic stretch: lane = ROW, the row's D coordinates in registers.  Every parameter is then the same
-// for all 64 lanes of a wave: the derived (mean, 1/width, pi, pi/width) of a component come from ONE uniform 16-byte (float64: 32-byte) LDS
-// read per 64 rows (the lane = (row, coordinate) kernel above spends 3 ds_read_b32 + 3 address adds per component on 16 rows), the
-// Householder dot products and the sum of the log-derivatives are plain register arithmetic (no DPP butterflies), and x is one row-contiguous
-// load per lane.  Same arithmetic per coordinate as gfg_mixture_impl / gfg_mixture_scaled.
-template <typename T> struct __attribute__((aligned(16))) GfPack { T mean, iw, pi, piw; };
-
-// Rows of a wave whose plain sums underflowed (a target tens of widths from every component), lane = row kernel.  On the SURVEY inputs that is
-// 1 % of the (row, coordinate, layer) evaluations but a lane in 22 % of the waves -- 2.5 lanes of 64 on average -- and rounds 1-3 sent the whole
-// wave through gfg_mixture_scaled for them (a second walk over the components with a distance pass in front: +30 % on the kernel).  Here the
-// wave turns ITS LANES to those few rows instead: four rows per pass, one per 16-lane DPP row, lane k of a row takes component k (K <= 16) of
-// the row's target, and the distance minimum and the five scaled sums are row all-reductions by rotation (row_ror 8 / 4 / 2 / 1).  Same
-// arithmetic per component as gfg_mixture_scaled, the sums in tree order: a row's result still depends on nothing but its own target.
-constexpr int DPP_ROW_ROR4 = 0x124, DPP_ROW_ROR2 = 0x122, DPP_ROW_ROR1 = 0x121;
-template <typename T> __device__ __forceinline__ T row16_sum(T v) {
-    v += dpp_swap<DPP_ROW_ROR8>(v); v += dpp_swap<DPP_ROW_ROR4>(v); v += dpp_swap<DPP_ROW_ROR2>(v); v += dpp_swap<DPP_ROW_ROR1>(v);
-    return v;
-}
-template <typename T> __device__ __forceinline__ T row16_min(T v) {
-    v = M<T>::min(v, dpp_swap<DPP_ROW_ROR8>(v)); v = M<T>::min(v, dpp_swap<DPP_ROW_ROR4>(v));
-    v = M<T>::min(v, dpp_swap<DPP_ROW_ROR2>(v)); v = M<T>::min(v, dpp_swap<DPP_ROW_ROR1>(v));
-    return v;
-}
-template <typename T> __device__ __forceinline__ void gfb_scaled_rows(const GfPack<T>* __restrict__ pd, int K, T xd, bool under, MixQ<T>& q) {
-    unsigned long long mask = __ballot(under);
-    const int lane = threadIdx.x & 63, grp = lane >> 4, k = lane & 15;
-    const bool comp = k < K;
-    GfPack<T> e = pd[comp ? k : 0];
-    if constexpr (sizeof(T) == 4) e.iw *= T(-0.6931471805599453);     // the float32 records carry -log2(e) / width (see the pack loop)
-    const T pk = comp ? e.pi : T(0);
-    while (mask != 0ull) {                                      // wave-uniform
-        const int rank = __popcll(mask & ((1ull << lane) - 1ull));     // this lane's row is the rank-th underflowed row still to do
-        unsigned long long mm = mask;
-        int s[4];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) { s[g] = mm != 0ull ? __ffsll((long long)mm) - 1 : 0; mm &= mm - 1ull; }    // (no row left: lane 0's target, result unused)
-        const int src = grp == 0 ? s[0] : grp == 1 ? s[1] : grp == 2 ? s[2] : s[3];
-        const T xs = __shfl(xd, src, 64);
-        const T u = (xs - e.mean) * e.iw;
-        const T au = comp ? M<T>::abs(u) : T(INFINITY);
-        const T m = row16_min<T>(au);
-        const T em = M<T>::exp_fast(-m);                       // may underflow to 0: the unscaled parts then stand alone
-        const T tp = M<T>::exp_fast(m - au);                   // <= 1; 0 for the lanes without a component
-        const T hi = M<T>::rcp(T(1) + tp * em);
-        const T c1 = pk * hi, c2 = c1 * tp;
-        const bool pos = u >= T(0);
-        const T Cu = row16_sum<T>(pos ? c1 : T(0)), Su = row16_sum<T>(pos ? T(0) : c1);
-        const T Ss = row16_sum<T>(pos ? c2 : T(0)), Cs = row16_sum<T>(pos ? T(0) : c2);
-        const T Ps = row16_sum<T>(c2 * hi * e.iw);
-        MixQ<T> r;
-        r.cdf = Cu + em * Cs;
-        r.sf = Su + em * Ss;
-        r.lc = Cu > T(0) ? M<T>::log_fast(r.cdf) : M<T>::log_fast(Cs) - m;
-        r.ls = Su > T(0) ? M<T>::log_fast(r.sf) : M<T>::log_fast(Ss) - m;
-        r.lp = M<T>::log_fast(Ps) - m;
-        // the row groups hand their results to the rows they worked for
-        const int from = 16 * (rank < 4 ? rank : 0);
-        const T lc = __shfl(r.lc, from, 64), ls = __shfl(r.ls, from, 64), lp = __shfl(r.lp, from, 64), cd = __shfl(r.cdf, from, 64), sf = __shfl(r.sf, from, 64);
-        if (under && ((mask >> lane) & 1ull) != 0ull && rank < 4) { q.lc = lc; q.ls = ls; q.lp = lp; q.cdf = cd; q.sf = sf; }
-        mask = mm;                                              // the four lowest rows are done
-    }
-}
-
+// the lane = row broadcast kernel (body: jf_gfb.h)
 template <typename T, int D> __global__ void __launch_bounds__(256) gfb_chain_inv_kernel(const GfChainArgs<T> a) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
-    T* lds = reinterpret_cast<T*>(smem_raw);
-    const int tid = threadIdx.x;
-    derive_broadcast<T>(lds, a);
-    // the layer count as a scalar register: derive_broadcast reads it under divergent control flow, and the value the compiler then reuses
-    // lives in a vector register -- which turned the layer loop, its descriptor loads and the component loop into divergent (exec-masked) code
-    const int n_layers = __builtin_amdgcn_readfirstlane(a.n_layers);
-    int max_k = 1;
-    for (int l = 0; l < n_layers; ++l) max_k = a.L[l].K > max_k ? a.L[l].K : max_k;
-    const int pstride = __builtin_amdgcn_readfirstlane(max_k) * D;
-    GfPack<T>* pack = reinterpret_cast<GfPack<T>*>(lds + a.tab_offset);
-    for (int l = 0; l < n_layers; ++l) {
-        const GfLayerDev<T> o = a.L[l];
-        const T* row = lds + l * a.tile_stride;
-        for (int j = tid; j < o.K * D; j += 256) {
-            const int d = j / o.K, k = j - d * o.K;
-            GfPack<T> e;
-            e.mean = row[o.off_mean + k * D + d];
-            e.iw = row[o.off_lw + k * D + d];
-            e.pi = o.fit_norm ? row[o.off_ln + k * D + d] : M<T>::rcp(T(o.K));
-            e.piw = e.pi * e.iw;
-            // float32: the record carries -log2(e) / width, so that e^{-|u|} = 2^{|x - mean| iw} is one multiply and v_exp_f32 (the sign of u
-            // is the sign of x - mean): one VALU instruction less per component (14.5 -> 13.5)
-            if constexpr (sizeof(T) == 4) e.iw *= T(-1.4426950408889634);
-            pack[l * pstride + j] = e;
-        }
-    }
-    __syncthreads();
-
-    for (int t = 0; t < a.tiles_per_block; ++t) {
-        const int64_t row0 = ((int64_t)blockIdx.x * a.tiles_per_block + t) * 256;
-        if (row0 >= a.B) break;                          // block-uniform
-        const int64_t row = row0 + tid;
-        const bool row_valid = row < a.B;
-        const int64_t rrow = row_valid ? row : a.B - 1;
-        T x[D];
-#pragma unroll
-        for (int d = 0; d < D; ++d) x[d] = a.x[rrow * a.xs + d];
-        T ld = a.ld_in ? a.ld_in[rrow] : T(0);
-        for (int l = n_layers - 1; l >= 0; --l) {
-            const GfLayerDev<T> o = a.L[l];              // uniform index: scalar loads from the kernarg segment
-            const T* prow = lds + l * a.tile_stride;
-            if (o.model_offset) {                        // euclidean_base.py:40-45
-#pragma unroll
-                for (int d = 0; d < D; ++d) x[d] -= prow[d];
-            }
-            for (int i = 0; i < o.hh; ++i) {             // x <- Q^T x (:1038); derived rows hold sqrt(2) v / |v|
-                const T* v = prow + o.off_rot + i * D;
-                T dot = T(0);
-#pragma unroll
-                for (int d = 0; d < D; ++d) dot += v[d] * x[d];
-#pragma unroll
-                for (int d = 0; d < D; ++d) x[d] -= v[d] * dot;
-            }
-            const GfPack<T>* pk = pack + l * pstride;
-#pragma unroll
-            for (int d = 0; d < D; ++d) {
-                const GfPack<T>* pd = pk + d * o.K;
-                T C = T(0), S = T(0), P = T(0);
-                constexpr int GFB_UNROLL = sizeof(T) == 4 ? 5 : 2;
-#pragma unroll GFB_UNROLL                                    // (float64 at 5: 132 -> 163 VGPRs, 0.57 -> 0.60 ms per 2^20 rows)
-                for (int k = 0; k < o.K; ++k) {
-                    const GfPack<T> e = pd[k];
-                    T u, tt;
-                    if constexpr (sizeof(T) == 4) {
-                        u = x[d] - e.mean;                 // (only its sign is used below)
-                        tt = __builtin_amdgcn_exp2f(M<T>::abs(u) * e.iw);
-                    } else {
-                        u = (x[d] - e.mean) * e.iw;
-                        tt = M<T>::exp_fast(-M<T>::abs(u));
-                    }
-                    const T hi = M<T>::rcp(T(1) + tt);     // sigma(|u|)
-                    const T lo = tt * hi;                  // sigma(-|u|)
-                    const bool pos = u >= T(0);
-                    C += e.pi * (pos ? hi : lo);
-                    S += e.pi * (pos ? lo : hi);
-                    P += e.piw * (hi * lo);
-                }
-                MixQ<T> q;
-                q.lc = M<T>::log_fast(C); q.ls = M<T>::log_fast(S); q.lp = M<T>::log_fast(P);
-                q.cdf = C; q.sf = S;
-                const bool under = !(C > M<T>::TINY && S > M<T>::TINY && P > M<T>::TINY);
-                if (__any(under)) {                        // wave-uniform branch
-                    if (o.K <= 16) {
-                        gfb_scaled_rows<T>(pd, o.K, x[d], under, q);
-                    } else {
-                        const MixQ<T> qs = gfg_mixture_scaled<T, false>(prow + d, o, D, x[d], T(0));
-                        if (under) q = qs;
-                    }
-                }
-                const IcdfOut<T> sy = gf_icdf<T>(o.inv_type, q);
-                x[d] = sy.y;
-                ld += sy.logd;
-            }
-        }
-        T sb = T(0);
-        bool bad = !M<T>::finite(ld);
-#pragma unroll
-        for (int d = 0; d < D; ++d) {
-            if (row_valid) a.x_out[row * a.xos + d] = x[d];
-            sb += T(-0.5) * x[d] * x[d] - M<T>::HALF_LN_2PI;
-            bad = bad || !M<T>::finite(x[d]);
-        }
-        if (row_valid) {
-            a.ld_out[row] = ld;
-            const T bv = sb + (a.blp_in ? a.blp_in[row] : T(0));
-            if (a.blp_out) a.blp_out[row] = bv;
-            if (a.total) a.total[row] = bv + ld;
-        }
-        status_add(a.status, JF_STATUS_NONFINITE, row_valid && bad);
-    }
+    gfb_chain_inv_body<T, D>(a, (int)blockIdx.x, smem_raw);
 }
+// the same chain with G lanes per row (small batches; bit-identical results: jf_gfb.h)
+template <typename T, int D, int G> __global__ void __launch_bounds__(256) gfbg_chain_inv_kernel(const GfChainArgs<T> a) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    gfbg_chain_inv_body<T, D, G>(a, (int)blockIdx.x, smem_raw);
+}
+
 
 // General-option chain (jf_gf_ext.h): one lane per row, every option of the layer; launched when a layer of the chain uses a rotation other
 // than Householder reflections, center_mean or add_skewness.  LDS: two coordinate columns per lane (+ the lane's spline knot table).
@@ -627,7 +418,31 @@ template <typename T, int G, bool FWD> static int launch_g(GfChainArgs<T> a, boo
     return check_launch();
 }
 
+// rows below which the broadcast log-prob chain runs with one lane per (row, coordinate) instead of one lane per row (D = 2 .. 4): the two
+// give bit-identical rows (jf_gfb.h), the first has G times the waves and 1 / G of the dependent chain per lane -- C3's block 0 at 2^15 rows
+// 0.029 -> 0.022 ms, at 2^13 0.032 -> 0.023; from 2^16 rows on lane = row wins (its component records are wave-uniform LDS reads, G times
+// fewer of them: 0.030 vs 0.035 ms at 2^17 rows, 0.123 vs 0.146 at 2^20).  JF_GFB_LANE_ROWS overrides (0: always lane = row)
+static int64_t gfbg_forced_rows = -1;                   // jf_gf_bcast_lane_rows()
+static int64_t gfbg_max_rows() {
+    static const int64_t v = getenv("JF_GFB_LANE_ROWS") ? atoll(getenv("JF_GFB_LANE_ROWS")) : ((int64_t)1 << 16);
+    return gfbg_forced_rows >= 0 ? gfbg_forced_rows : v;
+}
+template <typename T, int D, int G> static int launch_rows_g(GfChainArgs<T> a, size_t lds_bytes, hipStream_t st) {
+    auto k = gfbg_chain_inv_kernel<T, D, G>;
+    if (lds_bytes > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    int resident = resident_blocks(k, lds_bytes);
+    if (resident < 1) resident = 1;
+    const int64_t n_tiles = (a.B + 256 / G - 1) / (256 / G);
+    const int64_t tpb = (n_tiles + resident - 1) / resident;
+    a.tiles_per_block = (int)(tpb < 1 ? 1 : tpb);
+    jf::launch(k, dim3((unsigned)((n_tiles + a.tiles_per_block - 1) / a.tiles_per_block)), dim3(256), lds_bytes, st, a);
+    return check_launch();
+}
+
 template <typename T, int D> static int launch_rows(GfChainArgs<T> a, size_t lds_bytes, hipStream_t st) {
+    if constexpr (D >= 2 && D <= 4) {
+        if (a.B < gfbg_max_rows()) return launch_rows_g<T, D, (D == 2 ? 2 : 4)>(a, lds_bytes, st);
+    }
     auto k = gfb_chain_inv_kernel<T, D>;
     if (lds_bytes > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     int resident = resident_blocks(k, lds_bytes);           // one wave of workgroups, as for the lane = (row, coordinate) broadcast kernel
@@ -738,6 +553,28 @@ static int gf_chain_fwd(const T* z, int64_t zs, const T* ld_in, const T* params,
     return launch<T, true>(a, D, bcast, ext, lds, (hipStream_t)stream);
 }
 
+const void* gfbg_inv_kernel_f32(int D) {
+    switch (D) {
+        case 2: return (const void*)gfbg_chain_inv_kernel<float, 2, 2>;
+        case 3: return (const void*)gfbg_chain_inv_kernel<float, 3, 4>;
+        case 4: return (const void*)gfbg_chain_inv_kernel<float, 4, 4>;
+        default: return nullptr;
+    }
+}
+const void* gfb_inv_kernel_f32(int D) {
+    switch (D) {
+        case 1: return (const void*)gfb_chain_inv_kernel<float, 1>;
+        case 2: return (const void*)gfb_chain_inv_kernel<float, 2>;
+        case 3: return (const void*)gfb_chain_inv_kernel<float, 3>;
+        case 4: return (const void*)gfb_chain_inv_kernel<float, 4>;
+        case 5: return (const void*)gfb_chain_inv_kernel<float, 5>;
+        case 6: return (const void*)gfb_chain_inv_kernel<float, 6>;
+        case 7: return (const void*)gfb_chain_inv_kernel<float, 7>;
+        case 8: return (const void*)gfb_chain_inv_kernel<float, 8>;
+        default: return nullptr;
+    }
+}
+
 // LDS bytes a log-prob / sampling launch of this chain needs, or a negative JF_ERR_* (JF_ERR_UNSUPPORTED: more than a CU has -- cut the chain)
 template <typename T> static int64_t gf_lds_query(int32_t D, int32_t n_layers, const jf_gf_layer* layers, int bcast) {
     GfChainArgs<T> a{};
@@ -750,6 +587,11 @@ template <typename T> static int64_t gf_lds_query(int32_t D, int32_t n_layers, c
 
 extern "C" {
 int jf_abi_version(void) { return 6; }
+int64_t jf_gf_bcast_lane_rows(int64_t rows) {
+    const int64_t prev = jf::gfbg_max_rows();
+    jf::gfbg_forced_rows = rows;
+    return prev;
+}
 int64_t jf_gf_chain_lds_bytes_f32(int32_t D, int32_t n, const jf_gf_layer* L, int32_t pb1) { return jf::gf_lds_query<float>(D, n, L, pb1); }
 int64_t jf_gf_chain_lds_bytes_f64(int32_t D, int32_t n, const jf_gf_layer* L, int32_t pb1) { return jf::gf_lds_query<double>(D, n, L, pb1); }
 

@@ -41,6 +41,7 @@ struct LdsAttrOnce {
 // ---------------------------------------------------------------------------------------------
 struct PlanSink {
     virtual void add_launch(const void* fn, dim3 grid, dim3 block, size_t lds, void** args, const size_t* sizes, const size_t* aligns, int n) = 0;
+    virtual void forget(const PlanSink*) {}                        // `dead` is being destroyed: a sink that forwards to it must stop doing so
     virtual ~PlanSink() {}
 };
 PlanSink*& plan_sink();                                            // thread-local (plan.hip); nullptr = launch for real

@@ -205,6 +205,7 @@ int32_t jf_plan_destroy(int64_t h) {
         g_reg.plans[(size_t)(h & 0xffffff)] = nullptr;
     }
     if (jf::plan_sink() == p) jf::plan_sink() = nullptr;
+    else if (jf::plan_sink()) jf::plan_sink()->forget(p);           // (a merge capture begun inside this plan's recording)
     delete p;
     return JF_OK;
 }

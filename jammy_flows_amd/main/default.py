@@ -240,6 +240,11 @@ class pdf(nn.Module):
         # gradient mode, float64: chains on a low-rank last MLP stage never materialise their (B, P) parameter / gradient blocks
         self.lowrank_chain_training = os.environ.get("JF_LOWRANK_CHAIN_TRAINING", "1") != "0"
         self.use_step_plans = os.environ.get("JF_STEP_PLANS", "0") == "1"      # forward() through recorded step plans (planned_forward)
+        # float32 log-prob steps of up to merge_max_rows rows that start with an unconditional broadcast g chain and a one-launch `f` block issue
+        # the two as ONE launch (csrc/merged_kernels.hip: they overlap each other's latency -- 0.055 -> 0.037 ms at 2^17 rows, 0.228 -> 0.210 at
+        # 2^20); 0 = never
+        self.merge_max_rows = int(os.environ.get("JF_MERGE_MAX_ROWS", str(1 << 40)))
+        self._merge_ok = {}
 
         self._read_model_definition(pdf_defs, flow_defs, options_overwrite, conditional_input_dim, amortization_mlp_dims,
                                     amortization_mlp_ranks)
@@ -708,6 +713,36 @@ class pdf(nn.Module):
                 return False
         return True
 
+    def _merge_candidate(self, x, data_summary, only_last, amort):
+        """do the first two blocks of this log-prob step share a launch (csrc/merged_kernels.hip)?  They must be an unconditional broadcast g
+        chain (<= 4 dimensions, classic layers) and a one-launch `f` block, in either order -- a structural property of the pdf and the switches
+        below, decided once per key -- and the batch small enough for the merge to pay."""
+        B = x.shape[0]
+        if (x.dtype != torch.float32 or only_last or amort is not None or _hip.BINS_LOG is not None or type(data_summary) == list or B == 0
+                or B > self.merge_max_rows or len(self.layer_list) < 2):
+            return False
+        key = (self.fuse_conditional_blocks, self.force_fused_manifold_blocks, data_summary is None, self.amortize_everything)
+        hit = self._merge_ok.get(key)
+        if hit is None:
+            kinds = []
+            for si in (0, 1):
+                layers = list(self.layer_list[si])
+                kind = self.pdf_defs_list[si][0]
+                mlp = self.mlp_predictors[si] if len(self.mlp_predictors) > si else None
+                k = None
+                if kind == "e" and mlp is None and not self.amortize_everything:
+                    if (gfl.chain_supported(layers) and layers[0].dimension <= 4
+                            and not any(l.nonlinear_stretch_type != "classic" or l.has_extended_options for l in layers)):
+                        k = 0
+                elif kind != "e" and len(layers) == 1:
+                    mf = self._fusable_manifold_block(si, layers, False, None, x.dtype)
+                    if mf is not None and mf[0] == "f":
+                        k = 1
+                kinds.append(k)
+            hit = sorted(kinds, key=str) == [0, 1]
+            self._merge_ok[key] = hit
+        return hit
+
     def _fused_kernel_kind(self, n_rows):
         """which register-resident fused block kernel: "pp" (persistent ping-pong workgroups, cond_pp_kernels.hip) from
         or "split" (cond_split_kernels.hip, the default "auto" choice at every batch size while the two measure the same);
@@ -868,11 +903,31 @@ class pdf(nn.Module):
         rec = _hip._RECORDING
         lanes = rec is not None and independent and self.plan_lanes > 1 and B <= self.plan_lane_max_rows
         overlap = rec is not None and independent and not lanes and self.plan_overlap_blocks and B <= self.plan_overlap_max_rows
+        # small batches: the launches of the first two blocks are captured by the library and issued as ONE grid (merged_kernels.hip)
+        merge = (independent and not lanes and not overlap and self._merge_candidate(x, data_summary, only_last, amortization_parameters))
         if lanes:
             rec.fork()
         n_blocks = len(self.layer_list)
         folded_total = None
+        if merge:
+            _hip.merge_begin()
+        try:
+            return self._inverse_blocks(x, log_det, data_summary, amortization_parameters, force_embedding_coordinates, force_intrinsic_coordinates,
+                                        only_last, want_base_logp, status, per_block, B, base, base_logp, embeds, lazy, counter, independent,
+                                        ld_parts, blp_parts, rec, lanes, overlap, n_blocks, folded_total, merge)
+        except BaseException:
+            if merge:
+                _hip.merge_abort()
+            raise
+
+    def _inverse_blocks(self, x, log_det, data_summary, amortization_parameters, force_embedding_coordinates, force_intrinsic_coordinates,
+                        only_last, want_base_logp, status, per_block, B, base, base_logp, embeds, lazy, counter, independent, ld_parts, blp_parts,
+                        rec, lanes, overlap, n_blocks, folded_total, merge):
+        """the block loop of _inverse_impl (:998-1031)"""
         for si, block in enumerate(self.layer_list):
+            if merge and si == 2:
+                _hip.merge_end(x)                         # the first two blocks go out as one launch; the rest follows launch by launch
+                merge = False
             if independent:
                 if si > 0:
                     ld_parts.append(log_det)
@@ -1023,6 +1078,8 @@ class pdf(nn.Module):
                 embeds.append(block[-1]._embedding_conditional_return(tgt))
             if per_block is not None:
                 per_block.append(log_det)
+        if merge:
+            _hip.merge_end(x)                             # (a pdf of two blocks: both were captured)
         total = None
         if folded_total is not None:
             total = folded_total                          # log_det / base_logp are the totals already
@@ -1087,6 +1144,12 @@ class pdf(nn.Module):
         images, flattened permanent rows); a call after a parameter update records again by itself (parameter version counters)."""
         return PlannedForward(self, x, conditional_input, kwargs)
 
+    def pipelined_forward(self, x, conditional_input=None, depth=2, **kwargs):
+        """forward() for a stream of independent batches of THIS signature -> PipelinedForward: submit(x, conditional_input) enqueues a step on
+        one of `depth` alternating streams and returns a PendingStep (result() -> (log_prob, log_prob_base, base) once the caller's stream has
+        been made to wait for it); drain() waits for all.  Keep `depth` steps in flight: the tail of one step overlaps the head of the next."""
+        return PipelinedForward(self, x, conditional_input, depth, kwargs)
+
     def _step_plan(self, x, conditional_input, force_embedding_coordinates, force_intrinsic_coordinates):
         if not x.is_cuda or x.dim() != 2:
             return None
@@ -1095,7 +1158,7 @@ class pdf(nn.Module):
                bool(force_embedding_coordinates), bool(force_intrinsic_coordinates),
                # the switches that choose kernels: a plan replays the choice made when it was recorded
                self.fuse_conditional_blocks, self.fused_matrix_arithmetic, self.fused_block_kernel, self.force_fused_manifold_blocks,
-               self.plan_lanes, self.plan_overlap_blocks, self.fold_combine)
+               self.plan_lanes, self.plan_overlap_blocks, self.fold_combine, self.merge_max_rows)
         plan = self._step_plans.get(key)
         if plan is None:
             if len(self._step_plans) >= 8:               # a few signatures per pdf (each plan keeps its intermediate buffers)
@@ -1778,10 +1841,19 @@ class PlannedForward:
         dev = _hip.require_device(x, conditional_input if isinstance(conditional_input, torch.Tensor) else None)
         if x.dim() != 2 or (conditional_input is not None and not isinstance(conditional_input, torch.Tensor)):
             raise PlanNotApplicable("step plans take one (B, D) target tensor and at most one conditional-input tensor")
+        if x.shape[0] == 0:
+            raise PlanNotApplicable("empty batch")
+        if conditional_input is not None:
+            def span(t):
+                return t.data_ptr(), t.data_ptr() + (sum((n - 1) * st for n, st in zip(t.shape, t.stride())) + 1) * t.element_size()
+            (a0, a1), (b0, b1) = span(x), span(conditional_input)
+            if a0 < b1 and b0 < a1:
+                raise PlanNotApplicable("x and conditional_input overlap in memory (column views of one tensor): a plan rebinds them separately")
         self.pdf, self.kwargs, self.dev = pdf, dict(kwargs), dev
         self.sig = self._signature(x, conditional_input)
-        self.status = _hip.new_status(dev)                                     # accumulates over the replays; examined lazily
-        self.host_status = torch.zeros(_hip.JF_STATUS_WORDS, dtype=torch.int32).pin_memory()
+        # the status words of the replays live in pinned host memory (the kernels write them there when they have something to say): they
+        # accumulate over the replays and are examined lazily, without a copy-back on the stream
+        self.host_status, self.status = _hip.mapped_status(dev)
         self.pool = torch.cuda.MemPool()
         self._record(x, conditional_input)
 
@@ -1822,18 +1894,21 @@ class PlannedForward:
                     with torch.cuda.use_mem_pool(self.pool, device=self.dev), _RecordingPass() as rec:
                         plan.begin()
                         try:
+                            # everything between begin() and end() aborts the recording on failure: a plan left recording keeps this
+                            # thread's launches going into it instead of to the GPU
                             out = pdf.forward(x, conditional_input=cond, **self.kwargs)
-                            plan.copy_to_host(self.host_status, self.status)
+                            if rec.foreign:
+                                raise PlanNotApplicable("the step runs torch operations between the library's launches: %s" % sorted(set(rec.foreign)))
+                            try:
+                                self.slot_x = plan.add_slot(x)
+                                self.slot_c = plan.add_slot(cond) if cond is not None else None
+                                self.slot_out = [plan.add_slot(t) for t in out]
+                            except RuntimeError as e:     # overlapping slots (x and cond views of one tensor), empty tensors
+                                raise PlanNotApplicable("the inputs / outputs cannot be declared as plan slots: %s" % e)
+                            plan.end()
                         except BaseException:
                             plan.abort()
                             raise
-                        if rec.foreign:
-                            plan.abort()
-                            raise PlanNotApplicable("the step runs torch operations between the library's launches: %s" % sorted(set(rec.foreign)))
-                        self.slot_x = plan.add_slot(x)
-                        self.slot_c = plan.add_slot(cond) if cond is not None else None
-                        self.slot_out = [plan.add_slot(t) for t in out]
-                        plan.end()
                 finally:
                     pdf._capture_status = None
                     if "gc_was_on" in locals() and gc_was_on:
@@ -1866,7 +1941,7 @@ class PlannedForward:
                 for g, w in zip(got, want):
                     if not bool(((g == w) | (g.isnan() & w.isnan())).all()):
                         raise PlanNotApplicable("replaying the recorded step does not reproduce pdf.forward for this configuration")
-                self.status.zero_()
+                torch.cuda.synchronize(self.dev)
                 self.host_status.zero_()
             finally:
                 pdf.use_step_plans = saved
@@ -1874,6 +1949,7 @@ class PlannedForward:
     def _replay(self, x, cond):
         out = [torch.empty_strided(t.shape, t.stride(), dtype=t.dtype, device=t.device) for t in self.out_like]
         tensors = [x] + ([cond] if self.slot_c is not None else []) + out
+        self._last_stream = torch.cuda.current_stream(self.dev)
         self.plan.launch(tensors, self.dev)
         return tuple(out)
 
@@ -1892,12 +1968,80 @@ class PlannedForward:
 
     def flush(self):
         """wait for the replays so far and raise / warn as the eager path does (the status words accumulate over the replays)"""
-        torch.cuda.current_stream(self.dev).synchronize()
+        (getattr(self, "_last_stream", None) or torch.cuda.current_stream(self.dev)).synchronize()
         if self.host_status.any():
             words = self.host_status.clone()
-            self.status.zero_()
-            self.host_status.zero_()
+            self.host_status.zero_()                    # (the stream is idle: no kernel is adding to the words)
             self.pdf._report_status(words)
+
+
+class PendingStep:
+    """one submitted step of a PipelinedForward: `outputs` = (log_prob, log_prob_base, base), being computed on `stream`; `event` fires when they
+    are complete.  result() makes the CALLER's current stream wait for them (not the host) and returns them."""
+    __slots__ = ("outputs", "event", "stream")
+
+    def __init__(self, outputs, event, stream):
+        self.outputs, self.event, self.stream = outputs, event, stream
+
+    def result(self):
+        cur = torch.cuda.current_stream(self.outputs[0].device)
+        if cur != self.stream:
+            cur.wait_event(self.event)
+            for t in self.outputs:
+                t.record_stream(cur)                    # (allocated in the step's stream pool, used on the caller's stream)
+        return self.outputs
+
+
+class PipelinedForward:
+    """pdf.forward for a stream of INDEPENDENT batches of one input signature (see pdf.pipelined_forward): consecutive steps alternate between
+    `depth` HIP streams, each through its own recorded step plan (own intermediate buffers, own status words).  The last round of workgroups
+    of one step's fused block leaves most of the chip idle (1.33 rounds at 2^17 rows: a third of the step); with the next step already queued
+    on another stream, its first launches fill that tail -- the step plan of 2^17 rows 0.108 -> 0.089 ms, of 2^20 rows 0.70 -> 0.66 ms per
+    step, results bit-identical (scripts/probe/two_stream.py).  The reference evaluates batches one call after the other
+    (main/default.py:1059-1117); nothing couples them."""
+
+    def __init__(self, pdf, x, conditional_input, depth, kwargs):
+        if depth < 1:
+            raise ValueError("depth >= 1")
+        self.dev = _hip.require_device(x, conditional_input if isinstance(conditional_input, torch.Tensor) else None)
+        self.pdf, self.depth, self.i = pdf, depth, 0
+        caller = torch.cuda.current_stream(self.dev)
+        self.streams = [torch.cuda.Stream(device=self.dev) for _ in range(depth)] if depth > 1 else [caller]
+        self.plans = []
+        for s in self.streams:
+            s.wait_stream(caller)
+            with torch.cuda.stream(s):
+                self.plans.append(PlannedForward(pdf, x, conditional_input, kwargs))
+            caller.wait_stream(s)
+
+    def submit(self, x, conditional_input=None):
+        """enqueue one step; returns a PendingStep at once.  The step starts when the work queued so far on the caller's current stream (the
+        producer of x) is done; the caller's stream does NOT wait for the step -- PendingStep.result() / drain() do that."""
+        j = self.i % self.depth
+        self.i += 1
+        s = self.streams[j]
+        cur = torch.cuda.current_stream(self.dev)
+        if s != cur:
+            s.wait_stream(cur)
+        with torch.cuda.stream(s):
+            out = self.plans[j](x, conditional_input)
+            ev = torch.cuda.Event()
+            ev.record(s)
+        if s != cur:
+            x.record_stream(s)
+            if conditional_input is not None:
+                conditional_input.record_stream(s)
+        return PendingStep(out, ev, s)
+
+    def drain(self):
+        """the caller's current stream waits for every submitted step; then the plans' status words are examined (raises / warns as eager)"""
+        cur = torch.cuda.current_stream(self.dev)
+        for s in self.streams:
+            if s != cur:
+                cur.wait_stream(s)
+        for p in self.plans:
+            if self.pdf.check_status:
+                p.flush()
 
 
 class GraphedForward:

@@ -720,7 +720,8 @@ def test_fused_manifold_block_vs_golden(name, dtype):
     with timer:
         logp = pdf(to_dev(fx["x"], dtype), conditional_input=to_dev(fx.get("cond"), dtype), force_embedding_coordinates=bool(fx.meta["embedding"]))[0]
     ran = sorted(set(k[0] for k in timer.summary()))
-    fused = [k for k in ran if k.startswith("jf_cond_") and "gf" not in k]
+    # (a float32 `f` block behind an unconditional g chain leaves in the launch the two share: jf_merge_end, csrc/merged_kernels.hip)
+    fused = [k for k in ran if (k.startswith("jf_cond_") and "gf" not in k) or k == "jf_merge_end"]
     if not fused:           # the only legitimate ways out: a parameter row beyond the kernel's 64 columns, or the C side declining the float64
         wide = max(sum(blk) for blk in fx.meta["layer_param_nums"]) > _hip.COND_MCHAIN_MAX_PARAMS     # LDS budget (JF_ERR_UNSUPPORTED)
         assert (wide or dtype == torch.float64) and any(k.startswith("jf_mlp2") for k in ran), ran
@@ -1339,7 +1340,8 @@ def test_last_block_folds_the_combine_launch(rows):
             lp, lpb, base = pdf(x)
         names = {k[0] for k in timer.summary()}
         assert ("jf_combine_rows_f32" in names) == (not fold), names
-        assert len(names - {"jf_cond_gf_pack2_f32"}) == (3 if fold else 4), sorted(names)       # (the first call also packs W2)
+        # (the first call also packs W2; the broadcast g chain and the `f` block leave as ONE launch, jf_merge_end: csrc/merged_kernels.hip)
+        assert names - {"jf_cond_gf_pack2_f32", "jf_combine_rows_f32"} == {"jf_merge_end", "jf_cond_gf_chain_split3_f32"}, sorted(names)
         pdf.use_step_plans = True
         lp2, lpb2, base2 = pdf(x)
         lp2, lpb2, base2 = pdf(x)                          # (the second call replays the recorded plan)

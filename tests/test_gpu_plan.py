@@ -37,7 +37,7 @@ def test_plan_replay_equals_eager_forward(fx, dtype):
         pf = pdf.planned_forward(x, conditional_input=cond, **kw)
     except PlanNotApplicable as e:
         pytest.skip("not plannable: %s" % e)
-    assert pf.plan.n_ops >= 2
+    assert pf.plan.n_ops >= 1                      # (the status words live in host memory: no copy-back op, a one-block pdf is one launch)
     # other rows than the recorded ones, in other buffers
     perm = torch.randperm(x.shape[0], device=x.device)
     x2 = x[perm].clone()
@@ -116,7 +116,8 @@ def test_kernel_timer_sees_the_kernels_of_a_replayed_plan():
             pf(x)
     table = t.summary()
     names = {k[0] for k in table}
-    assert "jf_cond_gf_chain_split3_f32" in names and "jf_gf_chain_inv_f32" in names, names
+    # (the broadcast g chain and the `f` block leave as one launch: csrc/merged_kernels.hip)
+    assert "jf_cond_gf_chain_split3_f32" in names and "jf_merge_end" in names, names
     assert all(v["launches"] == 5 and v["mean_ms"] > 0 for v in table.values()), table
 
 
