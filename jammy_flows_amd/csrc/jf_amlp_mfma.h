@@ -71,7 +71,7 @@ __device__ __forceinline__ double am_xmax(double v) { return am_xreduce(v, [](do
 
 // the MLP's own weights in fragment order + the rank-r2 vector t2 of the wave's 16 rows -- shared by the block kernel and the MLP-only kernel
 template <typename T> struct AmMlp {
-    T* fV1; T* fU1; T* sb1; T* fV2; T* next;      // next: first free LDS element behind the MLP image
+    T* fV1; T* fU1; T* sb1; T* fV2; T* ttab; T* next;      // ttab: tanh(k / 32) (jf_math.h: tanh_tab); next: first free LDS element behind the MLP image
     int k1s, HT; bool lowrank1;
 };
 
@@ -86,7 +86,9 @@ template <typename Args> __device__ inline AmMlp<double> am_build_mlp(const Args
     const int nU1 = I.lowrank1 ? I.HT * 2 * 64 : 0;
     I.sb1 = I.fU1 + nU1;                                                  // H
     I.fV2 = I.sb1 + H;                                                    // H / 4 fragments
-    I.next = I.fV2 + (H / 4) * 64;
+    I.ttab = I.fV2 + (H / 4) * 64;
+    I.next = I.ttab + JF_TANH_TAB_N;
+    tanh_tab_load(I.ttab, tid, (int)blockDim.x);
     const T* W = I.lowrank1 ? a.V1 : a.U1;
     for (int e = tid; e < nV1; e += (int)blockDim.x) {
         const int f = e >> 6, l = e & 63, m = l & 15, k = 4 * (I.lowrank1 ? f : f % I.k1s) + (l >> 4);
@@ -126,7 +128,7 @@ template <typename Args> __device__ __forceinline__ void am_t2(const Args& a, co
                 p = __builtin_amdgcn_mfma_f64_16x16x4f64(I.fU1[(2 * t) * 64 + lane], t1a, p, 0, 0, 0);
                 p = __builtin_amdgcn_mfma_f64_16x16x4f64(I.fU1[(2 * t + 1) * 64 + lane], t1b, p, 0, 0, 0);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) hh[t][r] = M<T>::tanh_fast(p[r]);
+                for (int r = 0; r < 4; ++r) hh[t][r] = tanh_tab(I.ttab, p[r]);
             }
         }
     } else {
@@ -141,7 +143,7 @@ template <typename Args> __device__ __forceinline__ void am_t2(const Args& a, co
                 for (int s = 0; s < AG_K1MAX / 4; ++s)
                     if (s < I.k1s) p = __builtin_amdgcn_mfma_f64_16x16x4f64(I.fV1[(t * I.k1s + s) * 64 + lane], cin[s], p, 0, 0, 0);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) hh[t][r] = M<T>::tanh_fast(p[r]);
+                for (int r = 0; r < 4; ++r) hh[t][r] = tanh_tab(I.ttab, p[r]);
             }
         }
     }
@@ -357,7 +359,7 @@ __global__ void __launch_bounds__(FWD ? AM_THREADS_FWD : AM_THREADS) amlp_gf_mfm
 // LDS doubles of the fragment image: the MLP's own part + the last stage (block kernel: permuted tiles per layer; MLP only: ceil(N / 16) tiles)
 inline size_t am_lds_mlp(int K1, int H, bool lowrank1) {
     const int k1s = (K1 + 3) / 4, HT = H / 16;
-    return (size_t)(lowrank1 ? k1s : HT * k1s) * 64 + (lowrank1 ? (size_t)HT * 2 * 64 : 0) + H + (size_t)(H / 4) * 64;
+    return (size_t)(lowrank1 ? k1s : HT * k1s) * 64 + (lowrank1 ? (size_t)HT * 2 * 64 : 0) + H + (size_t)(H / 4) * 64 + JF_TANH_TAB_N;
 }
 inline size_t am_lds_doubles(int K1, int H, bool lowrank1, int n_layers) {
     return am_lds_mlp(K1, H, lowrank1) + (size_t)n_layers * AM_TILES * 2 * 64 + (size_t)n_layers * AM_TILES * 16;

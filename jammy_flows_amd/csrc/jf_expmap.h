@@ -58,7 +58,7 @@ template <typename T, typename ROW> __device__ inline void v_component(ROW pp, i
         // the potential's derivative is a monotone rational-quadratic spline [-1, 1] -> [-1, 1] of mu . x (rational_quadratic_spline with
         // rel_min_bin_width = rel_min_bin_height = min_derivative = 1e-3, :354-362); f = spline value, f' = exp(logabsdet)
         constexpr int NB = JF_V_SPLINE_BINS;
-        KnotTab<T> t(tab);
+        KnotTab<T> t(tab, NB);
         for (int j = 0; j < NB; ++j) { t.cw[j] = pp[(4 + j) * nc + k]; t.ch[j] = pp[(4 + NB + j) * nc + k]; }
         for (int j = 0; j <= NB; ++j) t.d[j] = T(1e-3) + softplus<T>(pp[(4 + 2 * NB + j) * nc + k]);
         spline_cum_knots<T>(t.cw, NB, T(-1), T(1), T(1e-3), true);

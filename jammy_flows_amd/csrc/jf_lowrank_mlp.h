@@ -73,7 +73,7 @@ __global__ void __launch_bounds__(AM_THREADS) lrm_head_fwd_kernel(const LrmFwdAr
             p = __builtin_amdgcn_mfma_f64_16x16x4f64(I.fU1[(2 * t + 1) * 64 + lane], t1b, p, 0, 0, 0);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const T hv = M<T>::tanh_fast(p[r]);
+                const T hv = tanh_tab(I.ttab, p[r]);
                 if (row_valid) a.h[row * a.H + 16 * t + 4 * r + q] = hv;
                 t2 = __builtin_amdgcn_mfma_f64_16x16x4f64(I.fV2[(4 * t + r) * 64 + lane], hv, t2, 0, 0, 0);
             }

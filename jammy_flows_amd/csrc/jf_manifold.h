@@ -21,6 +21,7 @@ template <typename T> struct LaneCtx {
     int bin_i;
     bool oob, nonconv, nonfinite;
     bool lane_valid;
+    bool tab_built = false;   // `tab` is the WORKGROUP's table of the current layer, already built (broadcast parameters: Fam::build, manifold_kernels.hip)
     __device__ __forceinline__ void put_bin(int b) {
         if (bins) bins[bin_i] = (int64_t)b;
         ++bin_i;
@@ -49,7 +50,7 @@ template <typename T> __device__ __forceinline__ T r_core(const jf_r_layer& L, c
     x = x > T(1) ? T(1) : (x < T(-1) ? T(-1) : x);                         // rational_quadratic_spline.py:185-186, 295-296
     bool oob;
     const SplineDev<T> o = to_dev<T>(L.sp);
-    const SplineOut<T> r = spline_interval<T>(p, o, c.tab, x, inverse, (T)L.lo, (T)L.hi, oob);
+    const SplineOut<T> r = spline_interval<T>(p, o, c.tab, x, inverse, (T)L.lo, (T)L.hi, oob, c.tab_built);
     c.oob = c.oob || oob;
     c.put_bin(r.bin);
     ld += r.lad;
@@ -58,10 +59,16 @@ template <typename T> __device__ __forceinline__ T r_core(const jf_r_layer& L, c
 struct RFam {
     using CLayer = jf_r_layer;
     static constexpr int DIM = 1;
+    // the layer's knot table does not depend on the row: with broadcast parameters one lane builds it for the workgroup
+    static constexpr bool HAS_BUILD = true;
+    template <typename T> static __device__ __forceinline__ void build(const CLayer& L, const T* __restrict__ p, T* __restrict__ tab) {
+        spline_interval_build<T>(p, to_dev<T>(L.sp), tab, (T)L.lo, (T)L.hi);
+    }
     static __host__ bool sane(const CLayer& L) { return sane_spline(L.sp); }
     static __host__ int row_len(const CLayer& L) { return spline_row_len(L.sp); }
     static __host__ int n_bins(const CLayer&) { return 1; }
-    static __host__ bool needs_tab(const CLayer&) { return true; }       // lane-private knot tables (JF_SPLINE_TAB elements of LDS per lane)
+    static __host__ bool needs_tab(const CLayer&) { return true; }       // lane-private knot tables (tab_words elements of LDS per lane)
+    static __host__ int tab_words(const CLayer& L) { return spline_tab_words(L.sp.num_bins); }
     template <typename T, bool FWD> static __device__ __forceinline__ void apply(const CLayer& L, const T* __restrict__ p, T (&x)[3], T& ld, LaneCtx<T>& c) {
         if constexpr (FWD) {
             if (L.first) x[0] = real_line_to_interval<T>(x[0], (T)L.lo, (T)L.hi, ld);        // interval_base.py:71-79
@@ -109,7 +116,8 @@ struct OFam {
     static __host__ bool sane(const CLayer& L) { return sane_spline(L.sp) && sane_hh(L.hh_iter); }
     static __host__ int row_len(const CLayer& L) { return rot_len(L.hh_iter, 2) + spline_row_len(L.sp); }
     static __host__ int n_bins(const CLayer&) { return 1; }
-    static __host__ bool needs_tab(const CLayer&) { return true; }       // lane-private knot tables (JF_SPLINE_TAB elements of LDS per lane)
+    static __host__ bool needs_tab(const CLayer&) { return true; }       // lane-private knot tables (tab_words elements of LDS per lane)
+    static __host__ int tab_words(const CLayer& L) { return spline_tab_words(L.sp.num_bins); }
     template <typename T, bool FWD> static __device__ __forceinline__ void apply(const CLayer& L, const T* __restrict__ p, T (&x)[3], T& ld, LaneCtx<T>& c) {
         const T* sp = p + rot_len(L.hh_iter, 2);
         if constexpr (FWD) {

@@ -9,6 +9,8 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 
+#include "jf_tanh_table.h"
+
 namespace jf {
 
 template <typename T> struct M;
@@ -120,6 +122,40 @@ template <> struct M<double> {
     static __device__ __forceinline__ double min(double a, double b) { return ::fmin(a, b); }
     static __device__ __forceinline__ bool finite(double x) { return isfinite(x); }
 };
+
+// tanh of a float64 hidden layer from a TABLE in LDS.  M<double>::tanh_fast is an exponential (OCML: ~42 instructions) and a reciprocal: ~55 float64
+// instructions per hidden unit, 128 units per row -- the float64 MLP kernels are bound by exactly this (jf_mlp2_f64 of the 4 -> 128 -> 10 head:
+// 0.37 ms per 2^20 rows for 0.05 ms of matrix arithmetic).  The units of a row are independent, so a table pays here (it lost for the mixture's
+// exponentials, a dependent chain): |x| = a + r with a = k / 32 on a 2^-5 grid (k <= 608: tanh(19) rounds to 1 - 2^-53) and |r| <= 2^-6,
+//   tanh(a + r) = (T_a + p) / (1 + T_a p),  T_a = tanh(a) from the table (609 doubles, 4.9 KB),  p = tanh r = r - r^3/3 + 2 r^5/15 - 17 r^7/315
+// (next term 62 r^9 / 2835 < 1e-18), the quotient by v_rcp_f64 + one Newton step + one residual correction (the denominator lies in [1, 2]).
+// ~23 instructions; absolute error <= 3e-16 and relative error <= 5e-16 against a 40-digit tanh over [-20, 20] and around 0 (numpy emulation
+// of exactly these operations, scripts/probe/tanh_tab_check.py) -- the accuracy of tanh_fast.  tanh(+-inf) = +-1, tanh(nan) = nan.
+__device__ __forceinline__ void tanh_tab_load(double* __restrict__ lds_tab, int tid, int nthreads) {
+    for (int i = tid; i < JF_TANH_TAB_N; i += nthreads) lds_tab[i] = JF_TANH_TAB[i];
+}
+__device__ __forceinline__ double tanh_tab(const double* __restrict__ lds_tab, double x) {
+#ifdef JF_PROBE_NO_TANH_TAB                                              // A/B builds only (scripts/probe/tanh_ab.sh)
+    return M<double>::tanh_fast(x);
+#endif
+    const double ax = ::fmin(::fabs(x), 19.0);
+    const double k = ::rint(ax * 32.0);
+    const double r = ::fma(k, -0.03125, ax);                             // exact
+    const double T = lds_tab[(int)k];
+    const double r2 = r * r;
+    const double p = r * ::fma(r2, ::fma(r2, ::fma(r2, -17.0 / 315.0, 2.0 / 15.0), -1.0 / 3.0), 1.0);
+    const double n = T + p, d = ::fma(T, p, 1.0);
+    const double r0 = __builtin_amdgcn_rcp(d);
+    const double r1 = ::fma(::fma(-d, r0, 1.0), r0, r0);
+    double q = n * r1;
+    q = ::fma(::fma(-d, q, n), r1, q);
+    return x != x ? x : ::copysign(q, x);
+}
+// (float: the hardware exponential is cheaper than any table)
+template <typename T> __device__ __forceinline__ T tanh_hidden(const double* lds_tab, T x) {
+    if constexpr (sizeof(T) == 8) return tanh_tab(lds_tab, x);
+    else return M<T>::tanh_fast(x);
+}
 
 // softplus(x) = log(1 + e^x), overflow-free (torch F.softplus agrees to < 2.1e-9 with its threshold=20 shortcut)
 template <typename T> __device__ __forceinline__ T softplus(T x) {

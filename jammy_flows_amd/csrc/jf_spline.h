@@ -11,6 +11,26 @@
 
 namespace jf {
 
+// Arithmetic of the table build and of the closed-form evaluation.  float64: OCML functions and IEEE divisions in the reference's order of
+// operations -- the searchsorted results are bit-exact against it (tests/test_gpu_parity.py: test_spline_bins_bit_exact_float64).  float32 (bar
+// |dlogp| < 1e-2): the hardware exponential / logarithm / reciprocal and ONE reciprocal of the softmax sum instead of a division per bin -- a
+// table costs ~3 nb transcendentals (softmax of widths and heights, softplus of the derivatives) and with OCML's expf / log1pf and correctly
+// rounded divisions that was ~600 instructions per row; the spline is C1, so a knot that moves by 1e-6 moves neither y nor log|dy/dx| by more.
+template <typename T> struct SM {
+    static __device__ __forceinline__ T exp(T x) { return M<T>::exp(x); }
+    static __device__ __forceinline__ T log(T x) { return M<T>::log(x); }
+    static __device__ __forceinline__ T sqrt(T x) { return M<T>::sqrt(x); }
+    static __device__ __forceinline__ T div(T a, T b) { return a / b; }
+    static __device__ __forceinline__ T softplus(T x) { return jf::softplus<T>(x); }
+};
+template <> struct SM<float> {
+    static __device__ __forceinline__ float exp(float x) { return M<float>::exp_fast(x); }
+    static __device__ __forceinline__ float log(float x) { return M<float>::log_fast(x); }
+    static __device__ __forceinline__ float sqrt(float x) { return M<float>::sqrt_fast(x); }
+    static __device__ __forceinline__ float div(float a, float b) { return a * M<float>::rcp(b); }
+    static __device__ __forceinline__ float softplus(float x) { return fmaxf(x, 0.f) + M<float>::log_fast(1.0f + M<float>::exp_fast(-fabsf(x))); }
+};
+
 constexpr int JF_SPLINE_MAX_BINS = 16;
 constexpr int JF_SPLINE_TAB = 3 * (JF_SPLINE_MAX_BINS + 1) + 2;   // 53 (odd)
 
@@ -23,10 +43,14 @@ template <typename T> struct SplineDev {
 
 template <typename T> struct SplineOut { T y, lad; int bin; };
 
+// the three sections follow each other at the spline's own bin count: a lane's table is 3 (nb + 1) words, not 3 x 17 -- the LDS a lane takes bounds the
+// resident waves of the lane-per-row kernels (spline_tab_words)
 template <typename T> struct KnotTab {
     T* cw; T* ch; T* d;   // nb+1 entries each
-    __device__ __forceinline__ KnotTab(T* base) : cw(base), ch(base + JF_SPLINE_MAX_BINS + 1), d(base + 2 * (JF_SPLINE_MAX_BINS + 1)) {}
+    __device__ __forceinline__ KnotTab(T* base, int nb) : cw(base), ch(base + nb + 1), d(base + 2 * (nb + 1)) {}
 };
+// per-lane table stride (elements) for splines of at most nb bins: odd, so that lane-dependent indices stay conflict-free
+__host__ __device__ inline int spline_tab_words(int nb) { const int w = 3 * (nb + 1); return (w & 1) ? w : w + 1; }
 
 // unnormalised widths / heights of the lane with the option handling of rational_quadratic_spline.py:200-230 / splines_1d.py:136-156
 template <typename T> __device__ inline void spline_unpack_wh(const T* __restrict__ p, const SplineDev<T>& o, KnotTab<T>& t) {
@@ -63,13 +87,14 @@ template <typename T> __device__ inline void spline_cum_knots(T* __restrict__ a,
     for (int j = 1; j < nb; ++j) m = M<T>::max(m, a[j]);
     T s = T(0);
 #pragma unroll 4
-    for (int j = 0; j < nb; ++j) { const T e = M<T>::exp(a[j] - m); a[j] = e; s += e; }
+    for (int j = 0; j < nb; ++j) { const T e = SM<T>::exp(a[j] - m); a[j] = e; s += e; }
     const T scale = T(1) - rel_min * T(nb);
     T cum = T(0);
     T prev = (hi - lo) * T(0) + lo;
+    const T inv_s = sizeof(T) == 4 ? SM<T>::div(T(1), s) : T(1);       // float32: one reciprocal for the whole softmax
 #pragma unroll 4
     for (int j = 0; j < nb; ++j) {
-        const T frac = rel_min + scale * (a[j] / s);
+        const T frac = rel_min + scale * (sizeof(T) == 4 ? a[j] * inv_s : a[j] / s);
         cum += frac;
         const T knot = (hi - lo) * cum + lo;
         a[j] = prev;          // shift: a[j] becomes knot j, carry knot j+1
@@ -90,7 +115,7 @@ template <typename T> __device__ __forceinline__ int spline_search(const T* __re
 template <typename T> __device__ inline SplineOut<T> spline_core(const KnotTab<T>& t, int b, T x, bool inverse) {
     const T in_cw = t.cw[b], in_w = t.cw[b + 1] - t.cw[b];
     const T in_ch = t.ch[b], in_h = t.ch[b + 1] - t.ch[b];
-    const T delta = in_h / in_w;
+    const T delta = SM<T>::div(in_h, in_w);
     const T d0 = t.d[b], d1 = t.d[b + 1];
     const T s = d0 + d1 - T(2) * delta;
     SplineOut<T> r;
@@ -102,19 +127,19 @@ template <typename T> __device__ inline SplineOut<T> spline_core(const KnotTab<T
         const T bq = in_h * d0 - dy * s;
         const T c = -delta * dy;
         const T disc = bq * bq - T(4) * a * c;
-        theta = (T(2) * c) / (-bq - M<T>::sqrt(disc));
+        theta = SM<T>::div(T(2) * c, -bq - SM<T>::sqrt(disc));
         r.y = theta * in_w + in_cw;
     } else {
-        theta = (x - in_cw) / in_w;
+        theta = SM<T>::div(x - in_cw, in_w);
     }
     const T t1mt = theta * (T(1) - theta);
     const T den = delta + s * t1mt;
     const T num = delta * delta * (d1 * theta * theta + T(2) * delta * t1mt + d0 * (T(1) - theta) * (T(1) - theta));
-    const T lad = M<T>::log(num) - T(2) * M<T>::log(den);
+    const T lad = SM<T>::log(num) - T(2) * SM<T>::log(den);
     if (inverse) {
         r.lad = -lad;
     } else {
-        r.y = in_ch + in_h * (delta * theta * theta + d0 * t1mt) / den;
+        r.y = in_ch + SM<T>::div(in_h * (delta * theta * theta + d0 * t1mt), den);
         r.lad = lad;
     }
     return r;
@@ -145,28 +170,33 @@ template <typename T> __device__ inline void spline_smooth_derivs(KnotTab<T>& t,
 // ---------------------------------------------------------------------------------------------------------------
 // interval spline used by 'r' (plain or smooth) on [lo, hi]  (rational_quadratic_spline.py:232-280 -> spline_fns.py:45-186 / 361-558)
 // ---------------------------------------------------------------------------------------------------------------
-template <typename T> __device__ inline SplineOut<T> spline_interval(const T* __restrict__ p, const SplineDev<T>& o, T* __restrict__ tab, T x, bool inverse,
-                                                                    T lo, T hi, bool& out_of_range) {
-    KnotTab<T> t(tab);
+// build: the knot table of one parameter row (independent of x) -- per lane for per-sample parameters, once per workgroup for broadcast ones
+template <typename T> __device__ inline void spline_interval_build(const T* __restrict__ p, const SplineDev<T>& o, T* __restrict__ tab, T lo, T hi) {
     const int nb = o.nb;
-    out_of_range = (x < lo) || (x > hi);
+    KnotTab<T> t(tab, nb);
     spline_unpack_wh<T>(p, o, t);
     spline_cum_knots<T>(t.cw, nb, lo, hi, o.min_w, true);
     spline_cum_knots<T>(t.ch, nb, lo, hi, o.min_h, true);
     const T* pd = p + o.n_w + o.n_h;
     if (o.smooth == 0) {
         if (o.fix_bd) {
-            const T fixed = o.min_d + softplus(o.fix_bd_value);
+            const T fixed = o.min_d + SM<T>::softplus(o.fix_bd_value);
             t.d[0] = fixed; t.d[nb] = fixed;
-            for (int j = 1; j < nb; ++j) t.d[j] = o.min_d + softplus(pd[j - 1]);
+            for (int j = 1; j < nb; ++j) t.d[j] = o.min_d + SM<T>::softplus(pd[j - 1]);
         } else {
-            for (int j = 0; j <= nb; ++j) t.d[j] = o.min_d + softplus(pd[j]);
+            for (int j = 0; j <= nb; ++j) t.d[j] = o.min_d + SM<T>::softplus(pd[j]);
         }
     } else {
-        const T b0 = o.min_d + softplus(o.fix_bd ? o.fix_bd_value : pd[0]);
-        const T b1 = o.min_d + softplus(o.fix_bd ? o.fix_bd_value : pd[1]);
+        const T b0 = o.min_d + SM<T>::softplus(o.fix_bd ? o.fix_bd_value : pd[0]);
+        const T b1 = o.min_d + SM<T>::softplus(o.fix_bd ? o.fix_bd_value : pd[1]);
         spline_smooth_derivs<T>(t, nb, b0, b1);
     }
+}
+template <typename T> __device__ inline SplineOut<T> spline_interval_eval(const SplineDev<T>& o, const T* __restrict__ tab, T x, bool inverse, T lo, T hi,
+                                                                         bool& out_of_range) {
+    const int nb = o.nb;
+    const KnotTab<T> t(const_cast<T*>(tab), nb);
+    out_of_range = (x < lo) || (x > hi);
     const T eps = T(1e-6);
     int b = spline_search<T>(inverse ? t.ch : t.cw, nb, x, eps);
     const int raw = b;
@@ -175,6 +205,11 @@ template <typename T> __device__ inline SplineOut<T> spline_interval(const T* __
     r.bin = raw;
     return r;
 }
+template <typename T> __device__ inline SplineOut<T> spline_interval(const T* __restrict__ p, const SplineDev<T>& o, T* __restrict__ tab, T x, bool inverse,
+                                                                    T lo, T hi, bool& out_of_range, bool built = false) {
+    if (!built) spline_interval_build<T>(p, o, tab, lo, hi);
+    return spline_interval_eval<T>(o, tab, x, inverse, lo, hi, out_of_range);
+}
 
 // ---------------------------------------------------------------------------------------------------------------
 // circular splines used by 'o': plain periodic (derivative at 0 == derivative at 2pi) or the smooth 2-bin variant
@@ -182,8 +217,8 @@ template <typename T> __device__ inline SplineOut<T> spline_interval(const T* __
 // ---------------------------------------------------------------------------------------------------------------
 template <typename T> __device__ inline SplineOut<T> spline_circular(const T* __restrict__ p, const SplineDev<T>& o, T* __restrict__ tab, T x, bool inverse,
                                                                     T scale, bool& out_of_range) {
-    KnotTab<T> t(tab);
     const int nb = o.nb;
+    KnotTab<T> t(tab, nb);
     const T TWO_PI = M<T>::TWO_PI;
     out_of_range = (x < T(0)) || (x > TWO_PI);
     spline_unpack_wh<T>(p, o, t);
@@ -196,11 +231,11 @@ template <typename T> __device__ inline SplineOut<T> spline_circular(const T* __
     if (o.smooth == 0) {
         const T* pd = p + o.n_w + o.n_h;
         if (o.fix_bd) {
-            const T fixed = o.min_d + softplus(o.fix_bd_value);
+            const T fixed = o.min_d + SM<T>::softplus(o.fix_bd_value);
             t.d[0] = fixed; t.d[nb] = fixed;
-            for (int j = 1; j < nb; ++j) t.d[j] = o.min_d + softplus(pd[j - 1] * scale);
+            for (int j = 1; j < nb; ++j) t.d[j] = o.min_d + SM<T>::softplus(pd[j - 1] * scale);
         } else {
-            for (int j = 0; j < nb; ++j) t.d[j] = o.min_d + softplus(pd[j] * scale);
+            for (int j = 0; j < nb; ++j) t.d[j] = o.min_d + SM<T>::softplus(pd[j] * scale);
             t.d[nb] = t.d[0];
         }
         int b = spline_search<T>(inverse ? t.ch : t.cw, nb, x, eps);
@@ -245,13 +280,13 @@ template <typename T> __device__ inline SplineOut<T> spline_circular(const T* __
 // ---------------------------------------------------------------------------------------------------------------
 template <typename T> __device__ inline SplineOut<T> spline_linext(const T* __restrict__ un_w, const T* __restrict__ un_h, const T* __restrict__ un_d,
                                                                   const T* __restrict__ box, int nb, T* __restrict__ tab, T x, bool inverse) {
-    KnotTab<T> t(tab);
+    KnotTab<T> t(tab, nb);
     const T left = box[0], right = left + M<T>::exp(box[1]) + T(0.5);      // gaussianization_flow.py:901-907
     const T bottom = box[2], top = bottom + M<T>::exp(box[3]) + T(0.5);
     for (int j = 0; j < nb; ++j) { t.cw[j] = un_w[j]; t.ch[j] = un_h[j]; }
     spline_cum_knots<T>(t.cw, nb, left, right, T(1e-3), false);
     spline_cum_knots<T>(t.ch, nb, bottom, top, T(1e-3), false);
-    for (int j = 0; j <= nb; ++j) t.d[j] = T(1e-3) + softplus(un_d[j]);
+    for (int j = 0; j <= nb; ++j) t.d[j] = T(1e-3) + SM<T>::softplus(un_d[j]);
     int b = spline_search<T>(inverse ? t.ch : t.cw, nb, x, T(0));
     const int raw = b;
     b = b < 0 ? 0 : (b > nb - 1 ? nb - 1 : b);

@@ -25,6 +25,7 @@ template <typename T, typename CLayer> struct MChainArgs {
     int tab;                 // per-lane elements of the knot tables: JF_SPLINE_TAB, or 0 for chains without a spline (default 'f', 'm', 'v', 'c'):
                              //   53 words of LDS per lane that bound the resident workgroups of these latency-bound kernels
     int rows;                // rows per workgroup (64 unless the parameter tile of 64 rows would not fit in LDS)
+    int shared_tab;          // broadcast parameters + a family whose knot table does not depend on the row: ONE table per workgroup, built by lane 0
     int vec_ok[JF_MAX_MCHAIN];
     int col0[JF_MAX_MCHAIN];
     int ncols[JF_MAX_MCHAIN];
@@ -41,6 +42,12 @@ template <typename T, typename CLayer> struct MChainArgs {
     T* total;
 };
 
+// per-lane knot-table elements a layer needs: the family's own count where it states one (r, o: 3 (bins + 1)), else the 16-bin maximum
+template <class Fam, class = void> struct fam_tab_words { static int of(const typename Fam::CLayer&) { return JF_SPLINE_TAB; } };
+template <class Fam> struct fam_tab_words<Fam, std::void_t<decltype(&Fam::tab_words)>> { static int of(const typename Fam::CLayer& L) { return Fam::tab_words(L); } };
+template <class Fam, class = void> struct fam_has_build : std::false_type {};
+template <class Fam> struct fam_has_build<Fam, std::void_t<decltype(Fam::HAS_BUILD)>> : std::true_type {};
+
 template <typename T, class Fam, bool FWD>
 __global__ void __launch_bounds__(64) mchain_kernel(const MChainArgs<T, typename Fam::CLayer> a) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -50,7 +57,9 @@ __global__ void __launch_bounds__(64) mchain_kernel(const MChainArgs<T, typename
     const int tile_rows = a.bcast ? 1 : rows;
     const bool lane_in = tid < rows;                     // lanes beyond the workgroup's rows idle (they own no scratch)
     const int slot = lane_in ? tid : 0;
-    T* tab = tile + tile_rows * a.tile_stride + slot * a.tab;
+    constexpr bool CAN_SHARE = fam_has_build<Fam>::value;
+    const bool shared = CAN_SHARE && a.shared_tab != 0;  // uniform
+    T* tab = tile + tile_rows * a.tile_stride + (shared ? 0 : slot * a.tab);
     const int64_t row0 = (int64_t)blockIdx.x * rows;
     const int64_t row = row0 + tid;
     const bool active = lane_in && row < a.B;
@@ -63,7 +72,7 @@ __global__ void __launch_bounds__(64) mchain_kernel(const MChainArgs<T, typename
     T ld = a.ld_in ? a.ld_in[rrow] : T(0);
     LaneCtx<T> ctx;
     ctx.tab = tab;
-    ctx.corr = tile + tile_rows * a.tile_stride + rows * a.tab + slot * a.scratch;
+    ctx.corr = tile + tile_rows * a.tile_stride + (shared ? 1 : rows) * a.tab + slot * a.scratch;
     ctx.bins = (a.bins && active) ? a.bins + row * a.bins_stride : nullptr;
     ctx.bin_i = 0;
     ctx.oob = ctx.nonconv = ctx.nonfinite = false;
@@ -79,6 +88,13 @@ __global__ void __launch_bounds__(64) mchain_kernel(const MChainArgs<T, typename
         }
         __syncthreads();
         const T* prow = tile + (a.bcast ? 0 : slot * a.tile_stride);
+        if constexpr (CAN_SHARE) {
+            if (shared) {                                // the layer's table, once (it was 64 identical builds: ~3 nb transcendentals per lane)
+                if (tid == 0) Fam::template build<T>(a.L[l], prow, tab);
+                __syncthreads();
+                ctx.tab_built = true;
+            }
+        }
         if (lane_in) Fam::template apply<T, FWD>(a.L[l], prow, x, ld, ctx);
     }
     bool bad = !M<T>::finite(ld);
@@ -154,11 +170,13 @@ static int mchain(const T* x, int64_t xs, const T* ld_in, const T* params, int64
         }
     }
     a.tab = 0;
-    for (int l = 0; l < n_layers; ++l) if (Fam::needs_tab(layers[l])) a.tab = JF_SPLINE_TAB;
+    for (int l = 0; l < n_layers; ++l)
+        if (Fam::needs_tab(layers[l])) { const int w = fam_tab_words<Fam>::of(layers[l]); a.tab = w > a.tab ? w : a.tab; }
     a.rows = 64;
+    a.shared_tab = (fam_has_build<Fam>::value && a.bcast && a.tab > 0) ? 1 : 0;
     size_t lds = 0;
     for (;;) {
-        lds = ((size_t)(a.bcast ? 1 : a.rows) * a.tile_stride + (size_t)a.rows * (a.tab + a.scratch)) * sizeof(T);
+        lds = ((size_t)(a.bcast ? 1 : a.rows) * a.tile_stride + (size_t)(a.shared_tab ? 1 : a.rows) * a.tab + (size_t)a.rows * a.scratch) * sizeof(T);
         if (lds <= 160 * 1024 || a.rows == 8) break;
         a.rows >>= 1;
     }

@@ -150,6 +150,8 @@ __device__ __forceinline__ unsigned ci_hidden(const CiArgs& a, int64_t row0, int
     const int k1p = (K1 + KS - 1) / KS * KS, ldk = k1p + 1;
     double* W1s = Xs + CI_ROWS * ldk;
     double* b1s = W1s + CI_HMAX * ldk;
+    // (the table form of the hidden layer's tanh, jf_math.h: tanh_tab, LOSES here -- 1.50 -> 1.68 ms per 2^20 rows, scripts/probe/tanh_ab.sh: the
+    //  32 dependent LDS lookups per lane wait behind the fragment traffic of the int8 products; the narrow-output jf_mlp2_f64 gains, 0.30 -> 0.25)
     {
         const int nx = CI_ROWS * k1p, nw = CI_HMAX * k1p;
         if (a.cin.n) {

@@ -12,6 +12,8 @@
 //                  chunks of 32 staged through LDS (rows padded by one element: conflict-free ds_read_b32 fragment reads).
 #include "jf_common.h"
 #include "jf_math.h"
+#include <cstdlib>
+
 #include "jf_mfma.h"
 
 namespace jf {
@@ -181,11 +183,13 @@ __global__ void __launch_bounds__(256, 3) mlp2_kernel(const T* __restrict__ in, 
     T* Xs = Bs + BN2;                                        // [BMR][ldk]   input tile
     T* W1s = Xs + BMR * ldk;                                 // [HP][ldk]    W1   } staged once per workgroup
     T* b1s = W1s + HP * ldk;                                 // [HP]         b1   }
+    const double* ttab = reinterpret_cast<const double*>(b1s + HP);   // float64 with a first layer: tanh(k / 32) (jf_math.h: tanh_tab)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane % MT, lq = lane / MT;
     const int64_t last = B - 1;
     const int n_tiles = (N + BN2 - 1) / BN2;
     const int64_t n_row_tiles = (B + BMR - 1) / BMR;
+    if constexpr (L1 && sizeof(T) == 8) tanh_tab_load(const_cast<double*>(ttab), tid, 256);
 
     // ---- W1, b1: once per workgroup.  Staging in straight-line batches of 4 loads per thread (clamped addresses + selects): issued
     // back to back, one round trip per batch.
@@ -295,7 +299,7 @@ __global__ void __launch_bounds__(256, 3) mlp2_kernel(const T* __restrict__ in, 
 #pragma unroll
             for (int j = 0; j < JH; ++j)
 #pragma unroll
-                for (int r = 0; r < NREG; ++r) hreg[j][r] = M<T>::tanh_fast(acc[j][r] + b1s[j * MT + MF::row_of(r, lane)]);   // padded units: tanh(0) = 0
+                for (int r = 0; r < NREG; ++r) hreg[j][r] = tanh_hidden<T>(ttab, acc[j][r] + b1s[j * MT + MF::row_of(r, lane)]);   // padded units: tanh(0) = 0
         } else {
             // the input itself in the B-operand layout (lane = row, register r of tile j <-> column j*MT + row_of(r, lane)), staged MT columns at a time
 #pragma unroll
@@ -424,7 +428,8 @@ static int mlp2_launch(const T* in, int64_t in_stride, const T* W1, int64_t w1_s
                        int32_t K1, int32_t H, int32_t N, T* out, int64_t out_stride, int act, void* stream) {
     constexpr int MT = Mfma<T>::MT, KS = Mfma<T>::KS, BMR = 4 * MT, HP = JH * MT;
     const int k1p = L1 ? (K1 + KS - 1) / KS * KS : MT, ldk = k1p + 1;
-    const size_t lds = ((size_t)BMR * ldk + (L1 ? (size_t)HP * ldk + HP : 0) + (size_t)(TN * MT) * Mlp2Cfg<T>::LDW + TN * MT) * sizeof(T);
+    const size_t lds = ((size_t)BMR * ldk + (L1 ? (size_t)HP * ldk + HP : 0) + (size_t)(TN * MT) * Mlp2Cfg<T>::LDW + TN * MT) * sizeof(T) +
+                       ((L1 && sizeof(T) == 8) ? (size_t)JF_TANH_TAB_N * sizeof(double) : 0);
     // 16-byte result stores need 16-byte aligned rows
     const bool vecrow = (out_stride % Vec16<T>::N == 0) && ((reinterpret_cast<uintptr_t>(out) & 15u) == 0);
     auto k = vecrow ? mlp2_kernel<T, JH, TN, true, L1> : mlp2_kernel<T, JH, TN, false, L1>;
@@ -459,11 +464,22 @@ static int mlp2_dispatch(const T* in, int64_t in_stride, const T* W1, int64_t w1
 #undef JF_MLP2_GO
 }
 
+// narrow float32 MLPs (<= 4 inputs, <= 16 outputs): mlp_narrow_kernels.hip
+int mlp2_narrow_f32(const float* in, int64_t is, const float* W1, int64_t w1s, const float* b1, const float* W2, int64_t w2s, const float* b2, int64_t B,
+                    int32_t K1, int32_t H, int32_t N, float* out, int64_t os, void* stream);
+
 template <typename T>
 static int mlp2(const T* in, int64_t in_stride, const T* W1, int64_t w1_stride, const T* b1, const T* W2, int64_t w2_stride, const T* b2, int64_t B,
                 int32_t K1, int32_t H, int32_t N, T* out, int64_t out_stride, void* stream) {
     if (!in || !W1 || !b1 || !W2 || !out || !width_ok(K1) || !width_ok(N) || !width_ok(H) || !rows_ok(B)) return JF_ERR_BADARG;
     if (K1 > K1MAX || H > HMAX) return JF_ERR_UNSUPPORTED;
+    if constexpr (sizeof(T) == 4) {
+        static const bool narrow_off = getenv("JF_MLP2_NARROW_OFF") != nullptr;
+        if (!narrow_off) {
+            const int rc = mlp2_narrow_f32(in, in_stride, W1, w1_stride, b1, W2, w2_stride, b2, B, K1, H, N, out, out_stride, stream);
+            if (rc != JF_ERR_UNSUPPORTED) return rc;
+        }
+    }
     if ((H % Vec16<T>::N) || (w2_stride % Vec16<T>::N) || (reinterpret_cast<uintptr_t>(W2) & 15u)) return JF_ERR_UNSUPPORTED;   // 16-byte W2 rows
     if (B == 0) return JF_OK;
     return mlp2_dispatch<T, true>(in, in_stride, W1, w1_stride, b1, W2, w2_stride, b2, B, K1, H, N, out, out_stride, 0, stream);

@@ -26,7 +26,9 @@ from ..layers.euclidean import gaussianization_flow as gfl
 
 # float64 amortisation MLPs with a wide output: "i8x6" / "i8x5" = second product as int8 digit-slice products (operands kept to 2^-41 / 2^-34,
 # csrc/mlp_i8_kernels.hip), "f64" = jf_mlp2_f64 on the float64 matrix cores.  A one-element list so that tests and benchmarks can switch it.
-MLP_MATRIX_ARITHMETIC_F64 = [os.environ.get("JF_MLP_MATRIX_ARITHMETIC_F64", "i8x6")]
+# Default i8x5 since round 5: its parameters agree with the float64 product to 2e-11 relative (log p of C3 to 2e-8 either way, bar 1e-4, the
+# parity tests' 1e-7) and the 128 -> 548 product needs 15 slice-pair passes instead of 21 (-0.2 ms per 2^20 rows).
+MLP_MATRIX_ARITHMETIC_F64 = [os.environ.get("JF_MLP_MATRIX_ARITHMETIC_F64", "i8x5")]
 MLP_I8_MIN_ROWS, MLP_I8_MIN_COLS = [4096], [128]         # below these the exact kernel costs microseconds and the digit image is not worth building
 if MLP_MATRIX_ARITHMETIC_F64[0] not in ("i8x6", "i8x5", "f64"):
     raise ValueError("JF_MLP_MATRIX_ARITHMETIC_F64 must be 'i8x6', 'i8x5' or 'f64', got %r" % MLP_MATRIX_ARITHMETIC_F64[0])

@@ -103,6 +103,8 @@ def _stack(K1, H, N, seed):
 
 
 def test_linear_stack_dispatch_and_image_cache():
+    # error bound of the digit-slice product in use (default i8x5 since round 5: operands kept to 2^-34; i8x6: 2^-41)
+    tol = 1e-11 if jf_default.MLP_MATRIX_ARITHMETIC_F64[0] == "i8x6" else 2e-9
     st = _stack(7, 128, 548, 0)
     x = torch.randn(5000, 7, dtype=torch.float64, device="cuda")
     small = torch.randn(100, 7, dtype=torch.float64, device="cuda")
@@ -116,7 +118,7 @@ def test_linear_stack_dispatch_and_image_cache():
     out, names = ran(x)
     assert "jf_mlp2_i8_f64" in names and "jf_mlp2_i8_pack_f64" in names, names
     ref = torch.tanh(x @ st[0].weight.t() + st[0].bias) @ st[2].weight.t() + st[2].bias
-    assert (out - ref).abs().max().item() < 1e-11
+    assert (out - ref).abs().max().item() < tol
     out2, names = ran(x)
     assert names == {"jf_mlp2_i8_f64"} and torch.equal(out, out2)   # image reused
     _, names = ran(small)
@@ -126,13 +128,13 @@ def test_linear_stack_dispatch_and_image_cache():
     out3, names = ran(x)
     assert "jf_mlp2_i8_pack_f64" in names
     ref = torch.tanh(x @ st[0].weight.t() + st[0].bias) @ st[2].weight.t() + st[2].bias
-    assert (out3 - ref).abs().max().item() < 1e-11
+    assert (out3 - ref).abs().max().item() < tol
     prev = jf_default.MLP_MATRIX_ARITHMETIC_F64[0]
     try:
         jf_default.MLP_MATRIX_ARITHMETIC_F64[0] = "f64"
         out4, names = ran(x)
         assert names == {"jf_mlp2_f64"}
-        assert (out4 - out3).abs().max().item() < 1e-11
+        assert (out4 - out3).abs().max().item() < tol
     finally:
         jf_default.MLP_MATRIX_ARITHMETIC_F64[0] = prev
     with torch.no_grad():
