@@ -64,7 +64,10 @@ __device__ __forceinline__ MixQ<float> cs_mixture(const float (&P)[CS_SLOTS], co
     }
     const float inv = Mf::rcp(Nn);
     MixQ<float> q;
-    if (!__any(live && m > CS_M_SCALED)) {                         // wave-uniform branch
+    {   // plain sums: every lane.  (Until round 5 a wave with ONE far lane sent all its lanes through the scaled sums below, which round
+        // differently: a row's bits depended on the 15 rows it shared a wave with -- 12 % of the rows of the SURVEY inputs differed between a
+        // 2^20-row batch and the same rows evaluated alone, tests/test_gpu_fullsize.py.  The scaled sums are taken per LANE now; 3 % of the
+        // calls see a far lane and pay for both forms.)
         float C = 0.f, S = 0.f, Pd = 0.f;
 #pragma unroll
         for (int k = 0; k < CS_K; ++k) {
@@ -80,8 +83,9 @@ __device__ __forceinline__ MixQ<float> cs_mixture(const float (&P)[CS_SLOTS], co
         q.lc = Mf::log_fast(C); q.ls = Mf::log_fast(S); q.lp = Mf::log_fast(Pd);
         q.cdf = C; q.sf = S;
         if (sums) *sums = CsSums{C, S, Pd, inv};
-        return q;
     }
+    const bool far = m > CS_M_SCALED;                              // this lane's target is far from every component: plain sums underflow
+    if (!__any(live && far)) return q;                             // wave-uniform branch
     const float em = Mf::exp_fast(-m);                             // may underflow to 0: the unscaled parts then stand alone
     float Cu = 0.f, Cs = 0.f, Su = 0.f, Ss = 0.f, Ps = 0.f;
 #pragma unroll
@@ -94,12 +98,14 @@ __device__ __forceinline__ MixQ<float> cs_mixture(const float (&P)[CS_SLOTS], co
         Ps += c2 * hi * iw[k];
     }
     Cu *= inv; Cs *= inv; Su *= inv; Ss *= inv; Ps *= inv;
-    q.cdf = Cu + em * Cs;
-    q.sf = Su + em * Ss;
-    q.lc = Cu > 0.f ? Mf::log_fast(q.cdf) : Mf::log_fast(Cs) - m;
-    q.ls = Su > 0.f ? Mf::log_fast(q.sf) : Mf::log_fast(Ss) - m;
-    q.lp = Mf::log_fast(Ps) - m;
-    if (sums) *sums = CsSums{q.cdf, q.sf, Ps * em, inv};
+    if (far) {
+        q.cdf = Cu + em * Cs;
+        q.sf = Su + em * Ss;
+        q.lc = Cu > 0.f ? Mf::log_fast(q.cdf) : Mf::log_fast(Cs) - m;
+        q.ls = Su > 0.f ? Mf::log_fast(q.sf) : Mf::log_fast(Ss) - m;
+        q.lp = Mf::log_fast(Ps) - m;
+        if (sums) *sums = CsSums{q.cdf, q.sf, Ps * em, inv};
+    }
     return q;
 }
 

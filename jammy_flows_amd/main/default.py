@@ -1200,6 +1200,9 @@ class pdf(nn.Module):
         """the block's permanent parameters side by side in the extra_inputs layout, built with differentiable ops (torch.cat)"""
         parts = []
         for l in layers:
+            if not hasattr(l, "_permanent_tensors"):       # a user-written layer keeps its own nn.Parameters: a placeholder of its width
+                parts.append(torch.zeros(l.get_total_param_num(), dtype=like.dtype, device=like.device))
+                continue
             parts += [t.reshape(-1).to(dtype=like.dtype) for t in l._permanent_tensors()]
         if not parts:
             return torch.zeros((1, 0), dtype=like.dtype, device=like.device)
@@ -1316,7 +1319,17 @@ class pdf(nn.Module):
                         out, log_det, blp = autograd.TLayerInvFn.apply(out, log_det, this if n > 0 else None, blp_in, grp[0].c_struct(),
                                                                        grp[0].dimension, status)
                     else:
-                        raise NotImplementedError("gradients through %s layers are not implemented" % type(grp[0]).__name__)
+                        # a layer the library has no kernel for -- a user's euclidean_base subclass written in torch (layer_base.py:58-70): the
+                        # layer's own operations carry the autograd graph; amortised parameters arrive as its extra_inputs slice
+                        l = grp[-1]
+                        own = None if (mlp is None and not self.amortize_everything) else (this[:, n - l.total_param_num:] if n > 0 else None)
+                        ld_in = log_det if log_det is not None else torch.zeros(B, dtype=x.dtype, device=x.device)
+                        out, log_det = l.inv_flow_mapping([out, ld_in], extra_inputs=own)[:2]
+                        blp = None
+                        if gi == 0:
+                            blp = (-0.5 * out * out - 0.9189385332046727).sum(dim=1)
+                            if blp_in is not None:
+                                blp = blp_in + blp
                     c1 -= n
                 base_logp = blp
             else:

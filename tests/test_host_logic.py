@@ -330,3 +330,19 @@ def test_one_launch_adam_host_side():
     mine.load_state_dict(topt.state_dict())
     st = mine.state[q]
     assert set(st) == {"step", "exp_avg", "exp_avg_sq"} and int(st["step"]) == 1 and mine.param_groups[0]["lr"] == 2e-3
+
+
+def test_kernel_caps_raise_loudly_without_a_gpu():
+    """the caps the reference does not have (flow_options.py:38, spline_fns.py:45-186) are errors at construction / descriptor
+    time, never silent truncation: 't' beyond 32 dimensions, splines beyond 16 bins, more than 4 nested f sub-layers"""
+    import jammy_flows_amd as jf
+    with pytest.raises(NotImplementedError, match="32 dimensions"):
+        jf.pdf("e33", "t")
+    p = jf.pdf("i1", "r", options_overwrite={"r": {"num_basis_functions": 17}})
+    with pytest.raises(NotImplementedError, match="16 bins"):
+        p.layer_list[0][0].c_struct()
+    jf.pdf("i1", "r", options_overwrite={"r": {"num_basis_functions": 16}}).layer_list[0][0].c_struct()
+    with pytest.raises(NotImplementedError, match="nested"):
+        jf.pdf("s2", "f", options_overwrite={"f": {"add_vertical_rq_spline_flow": 1, "vertical_flow_defs": "rrrrr"}})
+    with pytest.raises(NotImplementedError, match="16 bins|at most 16"):
+        jf.pdf("e2", "g", options_overwrite={"g": {"nonlinear_stretch_type": "rq_splines", "num_kde": 17}})
