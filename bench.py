@@ -276,7 +276,7 @@ def committed_traffic():
 KERNEL_OF = {"jf_cond_f_chain_inv_f32": "cond_mchain_kernel<float, jf::FFam", "jf_cond_f_chain_inv_f64": "cond_mchain_kernel<double, jf::FFam",
              "jf_conditioning_rows_f32": "conditioning_kernel<float", "jf_conditioning_rows_f64": "conditioning_kernel<double",
              "jf_v_chain_inv_f64": "mchain_kernel<double, jf::VFam", "jf_amlp2_f64": "amlp2_mfma_kernel",
-             "jf_cond_gf_chain_inv_split_f32": "cond_gf_split_kernel", "jf_cond_gf_chain_inv_pp_f32": "cond_gf_pp_kernel",
+             "jf_cond_gf_chain_inv_split_f32": "cond_gf_split_kernel",
              "jf_cond_gf_chain_split2_f32": "cond_gf_split_kernel", "jf_cond_gf_chain_split3_f32": "cond_gf_split_kernel",
              "jf_mlp2_i8_f64": "mlp2_i8_kernel", "jf_mlp2_i8_seg_f64": "mlp2_i8_kernel",
              "jf_r_chain_inv_f32": "mchain_kernel<float, jf::RFam", "jf_o_chain_inv_f32": "mchain_kernel<float, jf::OFam",
@@ -309,7 +309,7 @@ def traffic_of(traffic, kname, ktag):
 # ---------------------------------------------------------------------------------------------- algorithmic accounting
 def kernel_accounting(kname, ktag, s):
     """(algorithmic HBM bytes per row, MFMA flops per row, fused?) of one timed kernel; s = bytes per scalar."""
-    if (kname.startswith("jf_cond_gf_chain_inv_split") or kname.startswith("jf_cond_gf_chain_inv_pp") or kname.startswith("jf_cond_gf_chain_split2")
+    if (kname.startswith("jf_cond_gf_chain_inv_split") or kname.startswith("jf_cond_gf_chain_split2")
             or kname.startswith("jf_cond_gf_chain_split3")):
         K1, H, L, D = (int(t[1:]) for t in ktag.split("_")[:4])
         N = L * (3 * 10 * D + D * D) + D                 # default g rows: 3 K D + D^2 (+ D offsets on the last layer)
@@ -1088,9 +1088,9 @@ def main():
                            "executed_f16_TFLOPs": executed * B / secs / 1e12,
                            "frac_of_f16_peak": executed * B / secs / 1e12 / MFMA_BF16_PEAK_TFLOPS,
                            "frac_of_f32_mfma_peak_equivalent": tf / MFMA_F32_PEAK_TFLOPS})
-            elif kname.endswith("_split_f32") or kname.endswith("_pp_f32"):
+            elif kname.endswith("_split_f32"):
                 K1, H, L, D = (int(t[1:]) for t in ktag.split("_"))
-                cols = L * 5 * 32 if kname.endswith("_pp_f32") else L * 9 * 16     # padded columns per row: 5 tiles of 32 / 9 tiles of 16 per layer
+                cols = L * 9 * 16                                                   # padded columns per row: 9 tiles of 16 per layer
                 executed = 2 * K1 * 128 + 6 * 2 * 128 * cols               # first layer + six bf16 passes over the padded columns
                 mf.update({"arithmetic": "3-way split bf16, 6 MFMA passes, f32 accumulate", "executed_bf16_TFLOPs": executed * B / secs / 1e12,
                            "frac_of_bf16_peak": executed * B / secs / 1e12 / MFMA_BF16_PEAK_TFLOPS,

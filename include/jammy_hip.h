@@ -267,18 +267,6 @@ int jf_cond_gf_chain_inv_split_bwd_f32(const float* in, int64_t in_stride, const
  * [2^14, 2^15), `in` by 2^in_exp (14 for activations in (-1, 1)); absolute error of an entry <= max(2^-22 |g|, 2^-39 g_absmax). */
 int jf_linear_wgrad_split16_f32(const float* g, int64_t g_stride, const float* in, int64_t in_stride, int64_t B, int32_t K, int32_t N,
                                 const float* g_absmax, int32_t in_exp, float* partial_w, float* partial_b, void* stream);
-/* Third generation of the same block ("ping-pong", cond_pp_kernels.hip): 32x32x16 bf16 tiles (one MFMA per 32 cycles leaves the vector ALU
- * ~20 free issue cycles, a 16x16x32 one ~4), persistent 512-thread workgroups whose two four-wave teams run the same program half a layer
- * apart, so that on every SIMD one wave multiplies while its partner evaluates the flow.  Same arithmetic (3-way split bf16, six products, f32
- * accumulation; the first layer too), same limits except K1 <= 32, its own packed image (5 tiles of 32 columns per layer, two K halves,
- * biases appended).  Meant for batches of >= ~2^16 rows (256 rows per workgroup, one workgroup per CU). */
-int64_t jf_cond_gf_pp_packed_bytes(int32_t D, int32_t n_layers, const jf_gf_layer* layers);
-int jf_cond_gf_pp_pack_f32(const float* W2, int64_t w2_stride, const float* b2, int32_t H, int32_t D, int32_t n_layers, const jf_gf_layer* layers,
-                           void* packed, void* stream);
-int jf_cond_gf_chain_inv_pp_f32(const float* in, int64_t in_stride, const float* W1, int64_t w1_stride, const float* b1, const void* packed,
-                                int32_t K1, int32_t H, const float* x, int64_t x_stride, const float* log_det_in, int64_t B, int32_t D,
-                                int32_t n_layers, const jf_gf_layer* layers, float* x_out, int64_t x_out_stride, float* log_det_out,
-                                const float* base_logp_in, float* base_logp_out, int32_t* status, void* stream);
 /* 16-row groups per wave of the split kernel: 0 = chosen by batch size (default), 1 or 2 force a variant (process-wide; for A/B timing and the
  * determinism stress tests, which must cover both).  Returns the previous setting; other values only query. */
 int jf_cond_gf_split_row_groups(int32_t row_groups);

@@ -204,10 +204,6 @@ _SIGNATURES_SINGLE = {
     "jf_cond_gf_split_row_groups": ([_I32], ctypes.c_int),
     "jf_cond_gf_chain_fwd_split_f32": ([_P, _I64, _P, _I64, _P, _P, _I32, _I32, _P, _I64, _P, _I64, _I32, _I32, ctypes.POINTER(jf_gf_layer), _P, _I64,
                                         _P, _P, _P], ctypes.c_int),
-    "jf_cond_gf_pp_packed_bytes": ([_I32, _I32, ctypes.POINTER(jf_gf_layer)], ctypes.c_int64),
-    "jf_cond_gf_pp_pack_f32": ([_P, _I64, _P, _I32, _I32, _I32, ctypes.POINTER(jf_gf_layer), _P, _P], ctypes.c_int),
-    "jf_cond_gf_chain_inv_pp_f32": ([_P, _I64, _P, _I64, _P, _P, _I32, _I32, _P, _I64, _P, _I64, _I32, _I32, ctypes.POINTER(jf_gf_layer), _P, _I64,
-                                     _P, _P, _P, _P, _P], ctypes.c_int),
     "jf_cond_gf_pack_f32": ([_P, _I64, _P, _I32, _I32, _I32, ctypes.POINTER(jf_gf_layer), _P, _P], ctypes.c_int),
     "jf_amlp_gf_chain_fwd_f64": ([_P, _I64, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P, _I64, _P, _I64, _I32, _I32, ctypes.POINTER(jf_gf_layer),
                                   _P, _I64, _P, _P, _P], ctypes.c_int),
@@ -933,14 +929,11 @@ def amlp2(inp, v1, u1, b1, v2, u2, b2):
     return out
 
 
-# the two register-resident fused block kernels: "split" (cond_split_kernels.hip, 64 / 128 rows per workgroup) and "pp" (cond_pp_kernels.hip,
-# persistent ping-pong workgroups of 256 rows; large batches)
+# the register-resident fused block kernel (cond_split_kernels.hip, 64 / 128 rows per workgroup) in its two matrix arithmetics
 _COND_GF_PACK = {"split": ("jf_cond_gf_packed_bytes", "jf_cond_gf_pack_f32", "jf_cond_gf_chain_inv_split_f32", 28),
-                 "split16": ("jf_cond_gf_packed_bytes2", "jf_cond_gf_pack2_f32", "jf_cond_gf_chain_split2_f32", 28),
-                 "pp": ("jf_cond_gf_pp_packed_bytes", "jf_cond_gf_pp_pack_f32", "jf_cond_gf_chain_inv_pp_f32", 32)}
+                 "split16": ("jf_cond_gf_packed_bytes2", "jf_cond_gf_pack2_f32", "jf_cond_gf_chain_split2_f32", 28)}
 SPLIT_BF16X3, SPLIT_F16X2 = 0, 1     # include/jammy_hip.h: JF_SPLIT_*; kind "split" = bf16 triple, "split16" = f16 pair (same kernels)
 DIR_INV, DIR_FWD = 0, 1
-COND_GF_PP_MIN_ROWS = 1 << 16        # below this the persistent kernel leaves CUs without a row tile
 
 
 def cond_gf_packed_bytes(layer_array, n_layers, D, kind="split"):

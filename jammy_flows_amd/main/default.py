@@ -224,10 +224,11 @@ class pdf(nn.Module):
         # JF_FUSED_MATRIX_ARITHMETIC=f32 in the environment selects the exact-f32 kernel process-wide (an operational fallback while the
         # full-batch hazard of DESIGN.md 3.9 has a remedy but no root cause).
         self.fused_matrix_arithmetic = os.environ.get("JF_FUSED_MATRIX_ARITHMETIC", "split_f16")
-        # which kernel runs the split-bf16 fused block: "auto" (by batch size), "pp" (cond_pp_kernels.hip) or "split" (cond_split_kernels.hip)
+        # which kernel runs the split-bf16 fused block: "auto" = "split" (cond_split_kernels.hip).  (The persistent ping-pong variant of round 3
+        # measured the same and left the product in round 5: scripts/probe/cond_pp/.)
         self.fused_block_kernel = os.environ.get("JF_FUSED_BLOCK_KERNEL", "auto")
-        if self.fused_block_kernel not in ("auto", "pp", "split"):
-            raise ValueError("JF_FUSED_BLOCK_KERNEL must be 'auto', 'pp' or 'split', got %r" % self.fused_block_kernel)
+        if self.fused_block_kernel not in ("auto", "split"):
+            raise ValueError("JF_FUSED_BLOCK_KERNEL must be 'auto' or 'split', got %r" % self.fused_block_kernel)
         if self.fused_matrix_arithmetic not in ("split_f16", "split_bf16", "f32"):
             raise ValueError("JF_FUSED_MATRIX_ARITHMETIC must be 'split_f16', 'split_bf16' or 'f32', got %r" % self.fused_matrix_arithmetic)
         self._packed_cache = {}
@@ -746,14 +747,10 @@ class pdf(nn.Module):
         return hit
 
     def _fused_kernel_kind(self, n_rows):
-        """which register-resident fused block kernel: "pp" (persistent ping-pong workgroups, cond_pp_kernels.hip) from
-        or "split" (cond_split_kernels.hip, the default "auto" choice at every batch size while the two measure the same);
-        pdf.fused_block_kernel = "pp" / "split" (or JF_FUSED_BLOCK_KERNEL) forces one."""
+        """which arithmetic of the register-resident fused block kernel (cond_split_kernels.hip): "split16" (f16 pairs, the default) or
+        "split" (bf16 triples)"""
         if self.fused_matrix_arithmetic == "split_f16":
-            return "split16"                                                  # cond_split_kernels.hip with f16 pairs
-        if self.fused_block_kernel in ("pp", "split"):
-            return self.fused_block_kernel
-        # measured at 2^20 rows (profiles/r03_pp_*.md): pp 0.77 ms, split 0.775 ms -- no gain yet, and pp needs >= 256 row tiles to fill the chip
+            return "split16"
         return "split"
 
     def _packed_w2(self, si, w2, b2, layer_array, n_layers, D, n_rows, kind=None):

@@ -376,10 +376,9 @@ def test_fused_conditional_block_vs_golden_and_two_launch_path(name):
     pdf.check_status = bool(ok.all())
     out = {}
     for mode, kernel in (("two", "jf_gf_chain_inv_f32"), ("f32", "jf_cond_gf_chain_inv_f32"), ("split_bf16", "jf_cond_gf_chain_inv_split_f32"),
-                         ("split_f16", "jf_cond_gf_chain_split2_f32"), ("pp", "jf_cond_gf_chain_inv_pp_f32")):
+                         ("split_f16", "jf_cond_gf_chain_split2_f32")):
         pdf.fuse_conditional_blocks = mode != "two"
-        pdf.fused_matrix_arithmetic = "split_bf16" if mode == "pp" else mode
-        pdf.fused_block_kernel = "pp" if mode == "pp" else "auto"          # auto: the split kernel at a fixture's batch size
+        pdf.fused_matrix_arithmetic = mode
         timer = _hip.KernelTimer()
         with timer:
             out[mode] = pdf(x, conditional_input=cond, force_embedding_coordinates=emb)
@@ -390,7 +389,7 @@ def test_fused_conditional_block_vs_golden_and_two_launch_path(name):
             assert "jf_cond_gf_chain_inv_split_f32" not in ran
         assert_float32_parity(out[mode][0].double().cpu().numpy(), fx["logp"], ok, "%s [%s]" % (name, mode))
     sel = torch.from_numpy(ok).cuda()
-    for mode in ("f32", "split_bf16", "split_f16", "pp"):
+    for mode in ("f32", "split_bf16", "split_f16"):
         # per row the same flow arithmetic; the parameters differ by the summation order / the 3 * 2^-24 (bf16 triples) or 3 * 2^-22 (f16 pairs)
         # split residue of the 128-term products
         scale = 1.0 + out["two"][0][sel].abs()
@@ -613,7 +612,7 @@ def test_fused_block_two_row_groups_per_wave(name):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("rg", [1, 2, "pp", "bf16_1", "bf16_2"])
+@pytest.mark.parametrize("rg", [1, 2, "bf16_1", "bf16_2"])
 def test_fused_block_stress_20_launches_at_full_size(rg):
     """DESIGN.md 3.9 (not root-caused; remedy = no packed f32): the runtime guard.  20 launches of the C3 step at 2^20 rows for EACH row-group
     variant of the split-bf16 block kernel must be bit-identical over all rows (compared on the device), and every replica of the tiled
@@ -625,12 +624,11 @@ def test_fused_block_stress_20_launches_at_full_size(rg):
     n = fx["x"].shape[0]
     reps = (1 << 20) // n + 1
     x = to_dev(np.tile(fx["x"], (reps, 1)), torch.float32)
-    pdf.fused_block_kernel = "pp" if rg == "pp" else "split"           # "pp": the persistent ping-pong kernel (cond_pp_kernels.hip)
-    # 1 / 2: the default f16-pair arithmetic with one / two row groups per wave; "bf16_*": the bf16-triple arithmetic; "pp" multiplies bf16 triples
+    # 1 / 2: the default f16-pair arithmetic with one / two row groups per wave; "bf16_*": the bf16-triple arithmetic
     pdf.fused_matrix_arithmetic = "split_f16" if rg in (1, 2) else "split_bf16"
-    expect = {"pp": "jf_cond_gf_chain_inv_pp_f32", 1: "jf_cond_gf_chain_split2_f32", 2: "jf_cond_gf_chain_split2_f32"}.get(rg, "jf_cond_gf_chain_inv_split_f32")
+    expect = {1: "jf_cond_gf_chain_split2_f32", 2: "jf_cond_gf_chain_split2_f32"}.get(rg, "jf_cond_gf_chain_inv_split_f32")
     rg = int(rg[-1]) if isinstance(rg, str) and rg.startswith("bf16") else rg
-    prev = _hip.lib().jf_cond_gf_split_row_groups(0 if rg == "pp" else rg)
+    prev = _hip.lib().jf_cond_gf_split_row_groups(rg)
     try:
         timer = _hip.KernelTimer()
         with torch.no_grad():
@@ -750,7 +748,7 @@ def test_packed_image_follows_the_weights():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kernel", ["split16", "split", "pp"])
+@pytest.mark.parametrize("kernel", ["split16", "split"])
 def test_packed_image_follows_the_weights_when_the_module_dtype_differs(kernel):
     """float64 module, float32 inputs: the fused block then works on per-call float32 CASTS of the weights -- fresh temporaries whose own
     in-place version is always 0 and whose addresses the caching allocator reuses.  The packed image must still follow the module's
