@@ -209,7 +209,7 @@ def oracle_rows(workload, x, c, workers, chunk=4096):
 
 
 # ---------------------------------------------------------------------------------------------- HBM traffic (rocprofv3 PMC)
-PROFILE_TRAFFIC = os.path.join(ROOT, "profiles", "r04_traffic.json")
+PROFILE_TRAFFIC = os.path.join(ROOT, "profiles", "r05_traffic.json")
 WRITE_CAL = 0.965     # WRITE_SIZE calibration on scripts/probe/wstore (16-byte lane-per-row tile stores); FETCH_SIZE x 2 on gfx950 (guide)
 
 
@@ -261,14 +261,53 @@ def measure_traffic(workload, rows, fuse):
             "kernels": out}
 
 
+PROFILE_F64_ISSUE = os.path.join(ROOT, "profiles", "r05_f64_issue.json")
+F64_LANES_PER_CLK = 16 * 1024            # float64 vector lanes per clock of the chip: 16 per SIMD x 4 SIMDs x 256 CUs (78.6 TFLOP/s = 2 x this x 2.4 GHz)
+
+
+def float64_issue_roofline(workload, rows, side_table):
+    """the float64 step against the bound the counters show: vector issue of float64 instructions (DESIGN "float64").  The committed profile holds,
+    per kernel of the step, the float64 vector instructions per launch by class (rocprofv3 --pmc SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64, per row:
+    a property of the code) and the chip's clock during the kernel (GRBM_GUI_ACTIVE / duration); with THIS run's kernel times:
+    achieved = float64 lane-operations per second (transcendental-class instructions weighted 4: quarter rate), peak = 16 384 lanes x sustained clock."""
+    try:
+        prof = json.load(open(PROFILE_F64_ISSUE))
+    except (OSError, ValueError):
+        return None
+    if prof.get("workload") != workload:
+        return None
+    out = {"bound": "f64 vector issue", "unit": "T float64 lane-op/s", "source": "profiles/r05_f64_issue.json (rocprofv3 --pmc, per-row instruction counts) x this run's kernel times",
+           "kernel_source_hash_match": prof.get("kernel_source_hash") == kernel_source_hash(), "kernels": {}}
+    total_ops, total_s, peak_w = 0.0, 0.0, 0.0
+    for (name, tag), v in side_table.items():
+        k = prof["kernels"].get("%s[%s]" % (name, tag)) or prof["kernels"].get(name)
+        if not k:
+            continue
+        ops = k["f64_issue_slots_per_row"] * rows * 64          # wave instructions x 64 lanes
+        sec = v["mean_ms"] * 1e-3
+        peak = F64_LANES_PER_CLK * k["clock_ghz"] * 1e9
+        out["kernels"]["%s[%s]" % (name, tag)] = {"ms": round(v["mean_ms"], 4), "achieved": ops / sec / 1e12, "peak_at_measured_clock": peak / 1e12,
+                                                 "frac": ops / sec / peak, "clock_ghz": k["clock_ghz"], "valu_busy_frac": k.get("valu_busy_frac")}
+        total_ops += ops
+        total_s += sec
+        peak_w += peak * sec
+    if total_s <= 0:
+        return None
+    out.update({"achieved": total_ops / total_s / 1e12, "peak": peak_w / total_s / 1e12, "frac": total_ops / (peak_w),
+                "peak_at_2.4GHz": F64_LANES_PER_CLK * 2.4e9 / 1e12,
+                "note": "issue slots of float64 vector instructions (add / mul / fma x 1, transcendental class x 4) over the kernels of the float64 step; "
+                        "the step's remaining cycles are float32 / integer address and select instructions, LDS waits and HBM (the 4.6 GB block)"})
+    return out
+
+
 def committed_traffic():
     try:
         t = json.load(open(PROFILE_TRAFFIC))
     except (OSError, ValueError):
         return None
     if t.get("kernel_source_hash") != kernel_source_hash():
-        return {"stale": True, "source": "profiles/r04_traffic.json (taken at kernel sources %s, now %s)" % (t.get("kernel_source_hash"), kernel_source_hash())}
-    t["source"] = "profiles/r04_traffic.json (committed rocprofv3 --pmc passes of this command; kernel sources unchanged since)"
+        return {"stale": True, "source": "profiles/r05_traffic.json (taken at kernel sources %s, now %s)" % (t.get("kernel_source_hash"), kernel_source_hash())}
+    t["source"] = "profiles/r05_traffic.json (committed rocprofv3 --pmc passes of this command; kernel sources unchanged since)"
     return t
 
 
@@ -284,7 +323,7 @@ KERNEL_OF = {"jf_cond_f_chain_inv_f32": "cond_mchain_kernel<float, jf::FFam", "j
              "jf_cond_gf_chain_inv_f64": "cond_gf_chain_kernel<double", "jf_mlp2_f32": "mlp2_kernel<float", "jf_mlp2_f64": "mlp2_kernel<double",
              "jf_gf_chain_inv_f32": "gf_chain_kernel<float", "jf_gf_chain_inv_f64": "gf_chain_kernel<double",
              "jf_gf_chain_inv_total_f32": "gf_chain_kernel<float", "jf_gf_chain_inv_total_f64": "gf_chain_kernel<double",
-             "jf_amlp_gf_chain_inv_f64": "amlp_gf_mfma_kernel"}
+             "jf_amlp_gf_chain_inv_f64": "amlp_gf_mfma_kernel", "jf_merge_end": "merged_side_kernel"}
 
 
 def traffic_of(traffic, kname, ktag):
@@ -820,6 +859,7 @@ def main():
                     help="log-prob steps alternate between this many HIP streams, each through its own recorded plan (pdf.pipelined_forward): the batches "
                          "of consecutive steps are independent, so the tail of one step overlaps the head of the next; 1 = one stream")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--pmc-dtype", choices=("f32", "f64"), default=None, help=argparse.SUPPRESS)    # precision of the --pmc-child steps (default: the workload's)
     ap.add_argument("--dry-run", action="store_true",
                     help="exercise launch / rendezvous / row sharding / timing loop / all-gather with a stand-in step on the host (no GPU, no kernels): "
                          "the line carries \"dry_run\": true and no throughput claim.  For the CPU tests (JF_BENCH_BACKEND=gloo)")
@@ -904,6 +944,8 @@ def main():
     order = [main_dt] + (["f64"] if (main_dt == "f32" and not args.pmc_child) else [])
 
     if args.pmc_child:                                   # a few untimed steps for the PMC passes
+        if args.pmc_dtype:
+            main_dt = args.pmc_dtype
         pdf = helpers.build_product(fx, dtypes[main_dt], dev)
         pdf.check_status = "deferred"
         pdf.fuse_conditional_blocks = not args.no_fuse
@@ -1180,6 +1222,10 @@ def main():
                                                  "arithmetic": "%d int8 digit slices per operand, %d slice-pair products, exact int32 accumulation" % (slices, pairs),
                                                  "float64_equivalent_TFLOPs": 2.0 * B * 128 * n_out / sec / 1e12,
                                                  "f64_mfma_peak_TFLOPs": 78.6}
+        if "float64" in line and side_table:
+            f64_issue = float64_issue_roofline(args.workload, B, side_table)
+            if f64_issue:
+                line["float64"]["roofline_f64_issue"] = f64_issue
         if rm.get("rows_sweep"):
             sw = rm["rows_sweep"]
             line["rows_sweep"] = {"what": "step time of this workload against the batch size on this ONE GPU (prefixes of the resident inputs, each size "

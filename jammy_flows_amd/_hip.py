@@ -5,6 +5,7 @@ HIP kernels raises (missing library, CPU tensors, unsupported option) -- silentl
 void every parity claim made for the kernels.
 """
 import ctypes
+import threading
 import os
 
 import torch
@@ -90,6 +91,9 @@ class jf_c_layer(ctypes.Structure):
 class jf_t_layer(ctypes.Structure):
     _fields_ = [("cov_type", ctypes.c_int32), ("model_offset", ctypes.c_int32), ("width_mode", ctypes.c_int32), ("clamp_widths", ctypes.c_int32),
                 ("width_min", ctypes.c_double), ("width_max", ctypes.c_double)]
+
+
+JF_MAX_ROW_LISTS = 16
 
 
 class jf_row_list(ctypes.Structure):
@@ -355,7 +359,20 @@ class KernelTimer:
 
 
 _TIMER = None
-_RECORDING = None          # the StepPlan being recorded on this thread (entry points then append to it instead of launching)
+# the StepPlan being recorded on THIS thread (entry points then append to it instead of launching).  Per thread, like the C side's launch sink
+# (csrc/plan.hip: thread_local): another thread's pdf.forward during a recording launches for real and appends nothing.
+# `_hip._RECORDING` (read) resolves through the module __getattr__ below.
+_TLS = threading.local()
+
+
+def _recording():
+    return getattr(_TLS, "plan", None)
+
+
+def __getattr__(name):
+    if name == "_RECORDING":
+        return _recording()
+    raise AttributeError("module %r has no attribute %r" % (__name__, name))
 
 
 def _launch(name, tag, args, dev, unsupported_ok=False):
@@ -368,11 +385,12 @@ def _launch(name, tag, args, dev, unsupported_ok=False):
     with torch.cuda.device(dev):
         stream = torch.cuda.current_stream(dev)
         args = tuple(args) + (stream.cuda_stream,)
-        if _RECORDING is not None:
-            n0 = _RECORDING.num_ops()
+        rec = _recording()
+        if rec is not None:
+            n0 = rec.num_ops()
             rc = fn(*args)
             if rc == JF_OK:
-                _RECORDING.calls.append((name, tag, n0, _RECORDING.num_ops()))
+                rec.calls.append((name, tag, n0, rec.num_ops()))
         elif _TIMER is None or _MERGING:              # (a captured launch is issued by merge_end: nothing to time here)
             rc = fn(*args)
         else:
@@ -462,21 +480,18 @@ class StepPlan:
         return rc
 
     def begin(self):
-        global _RECORDING
-        if _RECORDING is not None:
+        if _recording() is not None:
             raise RuntimeError("a step plan is already being recorded on this thread")
         _check(int(lib().jf_plan_record_begin(self.handle)), "jf_plan_record_begin")
-        _RECORDING = self
+        _TLS.plan = self
 
     def abort(self):
-        global _RECORDING
-        if _RECORDING is self:
-            _RECORDING = None
+        if _recording() is self:
+            _TLS.plan = None
             lib().jf_plan_record_end(self.handle)
 
     def end(self):
-        global _RECORDING
-        _RECORDING = None
+        _TLS.plan = None
         rc = int(lib().jf_plan_record_end(self.handle))
         _check(min(rc, 0), "jf_plan_record_end")
         self._bases = (ctypes.c_void_p * max(1, self.n_slots))()
@@ -532,19 +547,34 @@ class StepPlan:
 
 
 def combine_rows(ld_list, blp_list, want_total=True):
-    """sums of the per-block log-dets and base log-probs in list order (one launch) -> (log_det, base_logp, total); a single entry is returned
-    as it is, an empty list gives None"""
+    """sums of the per-block log-dets and base log-probs in list order (one launch per JF_MAX_ROW_LISTS entries) -> (log_det, base_logp, total); a
+    single entry is returned as it is, an empty list gives None"""
     ts = [t for t in list(ld_list) + list(blp_list)]
     dev = require_device(*ts)
     like = ts[0]
     B = like.shape[0]
+    keep = []                                          # contiguous copies stay alive until their launch is issued (ADVICE r04)
 
     def lst(items):
         r = jf_row_list()
         r.n = len(items)
         for i, t in enumerate(items):
-            r.p[i] = _ptr(t.contiguous())
+            c = t.contiguous()
+            keep.append(c)
+            r.p[i] = _ptr(c)
         return r
+
+    def fold(items):
+        """more than JF_MAX_ROW_LISTS entries: partial sums in list order, each fed back as entry 0 of the next launch (same summation order)"""
+        items = list(items)
+        while len(items) > JF_MAX_ROW_LISTS:
+            head, items = items[:JF_MAX_ROW_LISTS], items[JF_MAX_ROW_LISTS:]
+            part = torch.empty_like(like)
+            a, b = lst(head), lst([])
+            _launch("jf_combine_rows" + _suffix(like), "", (ctypes.byref(a), ctypes.byref(b), B, _ptr(part), None, None), dev)
+            items = [part] + items
+        return items
+    ld_list, blp_list = fold(ld_list), fold(blp_list)
     ld_out = torch.empty_like(like) if len(ld_list) > 1 else None
     blp_out = torch.empty_like(like) if len(blp_list) > 1 else None
     total = torch.empty_like(like) if (want_total and ld_list and blp_list) else None
@@ -583,10 +613,11 @@ def merge_end(like):
     fn = lib().jf_merge_end
     with torch.cuda.device(dev):
         stream = torch.cuda.current_stream(dev)
-        if _RECORDING is not None:
-            n0 = _RECORDING.num_ops()
+        rec = _recording()
+        if rec is not None:
+            n0 = rec.num_ops()
             rc = int(fn(stream.cuda_stream))
-            _RECORDING.calls.append(("jf_merge_end", "", n0, _RECORDING.num_ops()))
+            rec.calls.append(("jf_merge_end", "", n0, rec.num_ops()))
         elif _TIMER is None:
             rc = int(fn(stream.cuda_stream))
         else:

@@ -468,6 +468,19 @@ template <typename F, typename EVAL> __device__ __forceinline__ F gf_approach(EV
             }
         }
     }
+    // safety net: a lane still active after 40 evaluations (one bracket end never left +-1e5: the `slow` rule was off, e.g. narrow
+    // components far apart with |z| near 8) finishes with the reference's plain bisection of what it has -- at most 25 halvings, the guarantee
+    // of bisection_n_newton.py:11-60 -- so the Newton stage never starts from an arbitrary point.  Wave-uniform: skipped when no lane needs it.
+    for (int it = 0; it < 25 && __any(act); ++it) {
+        const F mid = F(0.5) * (blo + bhi);
+        const MixQ<F> q = eval(mid);
+        const F g = proxy ? (neg ? q.lc - tz : tz - q.ls) : q.lc - q.ls - z;
+        if (act) {
+            if (g < F(0)) blo = mid; else bhi = mid;
+            xf = F(0.5) * (blo + bhi);
+            if (bhi - blo <= F(6e-3)) act = false;
+        }
+    }
     return xf;
 }
 

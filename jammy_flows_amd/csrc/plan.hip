@@ -198,11 +198,16 @@ int64_t jf_plan_create(void) {
 }
 
 int32_t jf_plan_destroy(int64_t h) {
-    jf_plan* p = lookup(h);
-    if (!p) return JF_ERR_BADARG;
+    // lookup and removal under ONE lock: of two threads destroying the same handle exactly one finds it.  A plan is replayed by one
+    // host thread at a time (see the top of this file); destroying it while another thread is inside jf_plan_launch is the caller's race.
+    jf_plan* p = nullptr;
     {
+        if ((h & ~(int64_t)0xffffffffffff) != PLAN_TAG) return JF_ERR_BADARG;
+        const uint32_t idx = (uint32_t)(h & 0xffffff), gen = (uint32_t)((h >> 24) & 0xffffff);
         std::lock_guard<std::mutex> lock(g_reg.mu);
-        g_reg.plans[(size_t)(h & 0xffffff)] = nullptr;
+        if (idx >= g_reg.plans.size() || g_reg.gen[idx] != gen || !g_reg.plans[idx]) return JF_ERR_BADARG;
+        p = g_reg.plans[idx];
+        g_reg.plans[idx] = nullptr;
     }
     if (jf::plan_sink() == p) jf::plan_sink() = nullptr;
     else if (jf::plan_sink()) jf::plan_sink()->forget(p);           // (a merge capture begun inside this plan's recording)

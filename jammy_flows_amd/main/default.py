@@ -1152,8 +1152,9 @@ class pdf(nn.Module):
     def _step_plan(self, x, conditional_input, force_embedding_coordinates, force_intrinsic_coordinates):
         if not x.is_cuda or x.dim() != 2:
             return None
-        key = (tuple(x.shape), x.stride(), x.dtype, x.device,
-               None if conditional_input is None else (tuple(conditional_input.shape), conditional_input.stride(), conditional_input.dtype),
+        key = (tuple(x.shape), x.stride(), x.dtype, x.device, x.data_ptr() % 16,
+               None if conditional_input is None else (tuple(conditional_input.shape), conditional_input.stride(), conditional_input.dtype,
+                                                       conditional_input.data_ptr() % 16),
                bool(force_embedding_coordinates), bool(force_intrinsic_coordinates),
                # the switches that choose kernels: a plan replays the choice made when it was recorded
                self.fuse_conditional_blocks, self.fused_matrix_arithmetic, self.fused_block_kernel, self.force_fused_manifold_blocks,
@@ -1871,7 +1872,9 @@ class PlannedForward:
 
     @staticmethod
     def _signature(x, c):
-        return (tuple(x.shape), x.stride(), x.dtype, x.device, None if c is None else (tuple(c.shape), c.stride(), c.dtype, c.device))
+        # (+ the 16-byte alignment of the buffers: the entry points choose vector-load kernel variants by it at record time)
+        return (tuple(x.shape), x.stride(), x.dtype, x.device, x.data_ptr() % 16,
+                None if c is None else (tuple(c.shape), c.stride(), c.dtype, c.device, c.data_ptr() % 16))
 
     def _param_key(self):
         return tuple(p._version for p in self.pdf.parameters())

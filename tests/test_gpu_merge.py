@@ -185,3 +185,67 @@ def test_pipelined_forward_equals_eager_forward(depth):
     t = pipe.submit(batches[2][0], batches[2][1])
     pipe.drain()
     assert same(t.result()[0], want[2][0])
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32], ids=["f64", "f32"])
+def test_sampler_on_far_apart_narrow_components(dtype):
+    """the approach phase of the samplers (csrc/jf_gf.h: gf_approach) replaces the reference's 25 bisections
+    (layers/bisection_n_newton.py:11-60); where its Newton / midpoint rules have not closed the bracket after 40 evaluations it now finishes
+    with plain bisection.  Stress: ten narrow components (widths ~0.01) spread over +-60, base points out to |z| = 8 -- flat stretches of the
+    cdf between the components.  Every finite row must round-trip: encode(decode(z)) = z, and no row may be left non-finite."""
+    import jammy_flows_amd
+    from jammy_flows_amd import _hip
+    torch.manual_seed(11)
+    B, D = 20000, 2
+    pdf = jammy_flows_amd.pdf("e%d" % D, "g", options_overwrite={"g": {"inverse_function_type": "isigmoid", "replace_first_sigmoid_with_icdf": 0,
+                                                                       "skip_model_offset": 1}}).to(dtype).cuda()
+    layer = pdf.layer_list[0][0]
+    c = layer.c_struct()
+    assert not c.model_offset
+    larr = _hip.gf_layer_array([c])
+    kd, r0 = c.num_kde * D, c.hh_iter * D
+    params = torch.zeros((1, layer.total_param_num), dtype=torch.float64, device="cuda")
+    params[0, :r0] = torch.randn(r0, device="cuda")                                                        # Householder vectors
+    params[0, r0:r0 + kd] = torch.linspace(-60.0, 60.0, kd, device="cuda")[torch.randperm(kd, device="cuda")]      # means
+    params[0, r0 + kd:r0 + 2 * kd] = -12.0                                                                 # log-widths far below zero: the lower bound rules
+    params[0, r0 + 2 * kd:r0 + 3 * kd] = torch.randn(kd, device="cuda")                                    # weights
+    params = params.to(dtype)
+    z = torch.empty((B, D), dtype=torch.float64, device="cuda").uniform_(-8.0, 8.0)
+    z[::7] = z[::7].sign() * torch.empty((z[::7].shape[0], D), dtype=torch.float64, device="cuda").uniform_(7.0, 8.0)
+    z = z.to(dtype)
+    prev = _hip.FWD_TABLE_MIN_ROWS
+    _hip.FWD_TABLE_MIN_ROWS = 1 << 62                            # the plain solves: approach phase + Newton stage on every lane
+    try:
+        status = _hip.new_status(z.device)
+        x, ld = _hip.gf_chain("fwd", z, None, params, larr, 1, D, status=status)
+    finally:
+        _hip.FWD_TABLE_MIN_ROWS = prev
+    words = status.cpu().tolist()
+    assert torch.isfinite(x).all() and torch.isfinite(ld).all() and words[1] == 0, words
+    zb, _ = _hip.gf_chain("inv", x, None, params, larr, 1, D)
+    rt = ((zb - z).abs() / (1.0 + z.abs())).max(dim=1).values.sort().values
+    # (rows the Newton stage flags as non-converged are exempt, as in the reference: their count is reported.  float64: it must stay small;
+    #  float32 cannot meet the reference's 1e-7-class stopping rule on cdf slopes of ~100 per unit -- half the rows of this stress are flagged)
+    if dtype == torch.float64:
+        assert words[0] <= B // 200, words
+    assert rt[B - 1 - words[0]].item() < (1e-6 if dtype == torch.float64 else 5e-3), rt[-5:]
+
+
+def test_combine_rows_with_more_lists_than_one_launch_takes():
+    """a pdf of more than 16 blocks has more per-block sums than one jf_combine_rows launch carries; the sums are then folded
+    launch by launch in list order (same summation order), and non-contiguous inputs stay alive until their launch"""
+    from jammy_flows_amd import _hip
+    torch.manual_seed(1)
+    B, n = 3000, 37
+    wide = torch.randn(B, 2 * n, device="cuda")
+    lds = [wide[:, 2 * i] for i in range(n)]                      # strided views: contiguous copies are made (and kept) by combine_rows
+    blps = [torch.randn(B, device="cuda") for _ in range(19)]
+    ld, blp, total = _hip.combine_rows(lds, blps)
+    torch.cuda.synchronize()
+    want_ld = lds[0].clone()
+    for t in lds[1:]:
+        want_ld = want_ld + t
+    want_blp = blps[0].clone()
+    for t in blps[1:]:
+        want_blp = want_blp + t
+    assert torch.equal(ld, want_ld) and torch.equal(blp, want_blp) and torch.equal(total, want_blp + want_ld)
