@@ -262,41 +262,45 @@ def measure_traffic(workload, rows, fuse):
 
 
 PROFILE_F64_ISSUE = os.path.join(ROOT, "profiles", "r05_f64_issue.json")
-F64_LANES_PER_CLK = 16 * 1024            # float64 vector lanes per clock of the chip: 16 per SIMD x 4 SIMDs x 256 CUs (78.6 TFLOP/s = 2 x this x 2.4 GHz)
+N_SIMDS = 1024                           # 4 per CU x 256 CUs
 
 
 def float64_issue_roofline(workload, rows, side_table):
-    """the float64 step against the bound the counters show: vector issue of float64 instructions (DESIGN "float64").  The committed profile holds,
-    per kernel of the step, the float64 vector instructions per launch by class (rocprofv3 --pmc SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64, per row:
-    a property of the code) and the chip's clock during the kernel (GRBM_GUI_ACTIVE / duration); with THIS run's kernel times:
-    achieved = float64 lane-operations per second (transcendental-class instructions weighted 4: quarter rate), peak = 16 384 lanes x sustained clock."""
+    """the float64 step against the bound its counters show: VECTOR ISSUE (DESIGN "float64").  The committed profile holds, per kernel of the step,
+    the vector instructions per row by class (rocprofv3 --pmc SQ_INSTS_VALU*: a property of the code), their issue cycles (4 per wave64
+    instruction, float64 add / mul / fma included; 16 for the transcendental class) and the chip's clock during the kernel (GRBM_GUI_ACTIVE / 8 /
+    duration: ~1.6 GHz under float64 load, not the 2.4 GHz of the headline peaks).  With THIS run's kernel times: achieved = vector issue cycles
+    per second, peak = 1024 SIMDs x the measured clock."""
     try:
         prof = json.load(open(PROFILE_F64_ISSUE))
     except (OSError, ValueError):
         return None
     if prof.get("workload") != workload:
         return None
-    out = {"bound": "f64 vector issue", "unit": "T float64 lane-op/s", "source": "profiles/r05_f64_issue.json (rocprofv3 --pmc, per-row instruction counts) x this run's kernel times",
+    out = {"bound": "vector issue (float64 arithmetic: %s of the instructions)", "unit": "T issue cycles/s",
+           "source": "profiles/r05_f64_issue.json (rocprofv3 --pmc, per-row instruction counts and clocks) x this run's kernel times",
            "kernel_source_hash_match": prof.get("kernel_source_hash") == kernel_source_hash(), "kernels": {}}
-    total_ops, total_s, peak_w = 0.0, 0.0, 0.0
+    tot_c, tot_s, peak_w, f64w = 0.0, 0.0, 0.0, 0.0
     for (name, tag), v in side_table.items():
         k = prof["kernels"].get("%s[%s]" % (name, tag)) or prof["kernels"].get(name)
         if not k:
             continue
-        ops = k["f64_issue_slots_per_row"] * rows * 64          # wave instructions x 64 lanes
+        cyc = k["valu_issue_cycles_per_row"] * rows
         sec = v["mean_ms"] * 1e-3
-        peak = F64_LANES_PER_CLK * k["clock_ghz"] * 1e9
-        out["kernels"]["%s[%s]" % (name, tag)] = {"ms": round(v["mean_ms"], 4), "achieved": ops / sec / 1e12, "peak_at_measured_clock": peak / 1e12,
-                                                 "frac": ops / sec / peak, "clock_ghz": k["clock_ghz"], "valu_busy_frac": k.get("valu_busy_frac")}
-        total_ops += ops
-        total_s += sec
+        peak = N_SIMDS * k["clock_ghz"] * 1e9
+        out["kernels"]["%s[%s]" % (name, tag)] = {"ms": round(v["mean_ms"], 4), "frac": cyc / sec / peak, "clock_ghz": k["clock_ghz"],
+                                                 "valu_busy_frac_in_profile": k.get("valu_busy_frac"), "f64_share_of_valu_insts": k.get("f64_share_of_valu_insts"),
+                                                 "valu_insts_per_row": k["wave_insts_per_row"].get("SQ_INSTS_VALU")}
+        tot_c += cyc
+        tot_s += sec
         peak_w += peak * sec
-    if total_s <= 0:
+        f64w += (k.get("f64_share_of_valu_insts") or 0.0) * cyc
+    if tot_s <= 0:
         return None
-    out.update({"achieved": total_ops / total_s / 1e12, "peak": peak_w / total_s / 1e12, "frac": total_ops / (peak_w),
-                "peak_at_2.4GHz": F64_LANES_PER_CLK * 2.4e9 / 1e12,
-                "note": "issue slots of float64 vector instructions (add / mul / fma x 1, transcendental class x 4) over the kernels of the float64 step; "
-                        "the step's remaining cycles are float32 / integer address and select instructions, LDS waits and HBM (the 4.6 GB block)"})
+    out["bound"] = out["bound"] % ("%.0f %%" % (100.0 * f64w / tot_c))
+    out.update({"achieved": tot_c / tot_s / 1e12, "peak": peak_w / tot_s / 1e12, "frac": tot_c / peak_w, "peak_at_2.4GHz": N_SIMDS * 2.4e9 / 1e12,
+                "note": "vector-issue cycles of the float64 step's kernels over (1024 SIMDs x the clock measured during each kernel).  The flow kernels sit "
+                        "at ~0.8 of this roof; the 40 % HBM bar on SURVEY 8d bytes would need the step in 3.0 ms, i.e. fewer instructions, not more bandwidth"})
     return out
 
 
@@ -1095,7 +1099,12 @@ def main():
         # (MLP reads its inputs and writes the block, the flow reads the block); a fused kernel moves almost none of it and may exceed 100 %.
         dom = max(kernel_table.items(), key=lambda kv: kv[1]["total_ms"])
         (kname, ktag), kstat = dom
-        secs = kstat["mean_ms"] * 1e-3
+        # With --pipeline-depth > 1 the kernels of consecutive steps run SIDE BY SIDE on the chip: a launch's HIP-event / rocprofv3 duration then
+        # covers a time in which it held only part of the chip (the durations of a step add up to `concurrency` x the step time).  The roofline
+        # prices a launch at its share of the chip's time: duration / concurrency -- for one stream that is the duration itself.
+        sum_ms = sum(v["total_ms"] for v in kernel_table.values()) / args.steps
+        concurrency = max(1.0, sum_ms / rm["ms_per_step"])
+        secs = kstat["mean_ms"] * 1e-3 / concurrency
         bytes_per_row, flops_per_row, fused = kernel_accounting(kname, ktag, s)
         if bytes_per_row is None:                        # per-sample g-chain: the block's row (C3 block 2: 548 floats, C5 block 0: 1224 doubles)
             P = {"c3": 548, "c5": 1224}[args.workload]
@@ -1106,7 +1115,11 @@ def main():
         roofline = {"bound": "hbm", "kernel": "%s[%s]" % (kname, ktag), "achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": hbm_gbs / HBM_PEAK_GBS, "traffic": tr["hbm_bytes_per_launch"] if tr else None,
                     "traffic_detail": tr, "traffic_source": (traffic or {}).get("source"), "traffic_stale": bool((traffic or {}).get("stale")),
-                    "mean_launch_ms": kstat["mean_ms"], "algorithmic_bytes_per_launch": bytes_per_row * B}
+                    "mean_launch_ms": kstat["mean_ms"], "concurrency": concurrency, "effective_launch_ms": kstat["mean_ms"] / concurrency,
+                    "concurrency_note": ("HIP-event duration of a launch (what rocprofv3 --kernel-trace reports too) / the number of kernels that ran side "
+                                         "by side on average = (sum of the step's launch durations) / (step time): consecutive steps alternate between "
+                                         "%d streams" % args.pipeline_depth) if concurrency > 1.0 else None,
+                    "algorithmic_bytes_per_launch": bytes_per_row * B}
         if fused:
             roofline["fused"] = True
             roofline["note"] = ("amortisation MLP + its g layers in one launch: the per-sample parameter block never leaves the chip, so the SURVEY 8d "

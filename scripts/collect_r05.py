@@ -45,21 +45,28 @@ if os.path.exists(os.path.join(src, "a.db")):
     B = 1 << 20
     out = {"workload": "c3", "rows": B, "kernel_source_hash": bench.kernel_source_hash(), "kernels": {},
            "how": "rocprofv3 --pmc (two passes) + --kernel-trace of `python3 bench.py --pmc-child --pmc-dtype f64` (scripts/profile_r05.sh); counts are wave "
-                  "instructions per launch summed over the chip, divided by the rows; f64_issue_slots = ADD + MUL + FMA + 4 x TRANS (quarter rate); "
-                  "clock = GRBM_GUI_ACTIVE / kernel duration"}
+                  "instructions per launch summed over the chip, divided by the rows; valu_issue_cycles = 4 x (SQ_INSTS_VALU - TRANS_F64) + 16 x TRANS_F64; "
+                  "clock = GRBM_GUI_ACTIVE / 8 XCDs / kernel duration; valu_busy = SQ_ACTIVE_INST_VALU x 4 / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8)"}
     for kname, c in cnt.items():
         key = next((e for pat, e in ENTRY if pat in kname), None)
         if key is None or "SQ_INSTS_VALU_FMA_F64" not in c:
             continue
         d_us = next((v for k, v in dur.items() if kname[:60] in k or k[:60] in kname), None)
-        slots = c["SQ_INSTS_VALU_ADD_F64"] + c["SQ_INSTS_VALU_MUL_F64"] + c["SQ_INSTS_VALU_FMA_F64"] + 4 * c["SQ_INSTS_VALU_TRANS_F64"]
-        clock = (c.get("GRBM_GUI_ACTIVE", 0.0) / (d_us * 1e3)) if d_us else None          # cycles / ns = GHz
+        f64 = c["SQ_INSTS_VALU_ADD_F64"] + c["SQ_INSTS_VALU_MUL_F64"] + c["SQ_INSTS_VALU_FMA_F64"]
+        # issue cycles of a wave64 vector instruction on a 16-lane SIMD: 4, transcendental class (v_rcp_f64, v_rsq_f64, ...) 16 -- float64 add / mul /
+        # fma included (78.6 TFLOP/s of float64 vector = 16 lanes x 2 flop x 4 SIMDs x 256 CUs x 2.4 GHz); counters are summed over the chip
+        cycles = 4 * (c["SQ_INSTS_VALU"] - c["SQ_INSTS_VALU_TRANS_F64"]) + 16 * c["SQ_INSTS_VALU_TRANS_F64"]
+        gui = c.get("GRBM_GUI_ACTIVE", 0.0) / 8.0                                          # GRBM_GUI_ACTIVE is summed over the 8 XCDs
+        clock = (gui / (d_us * 1e3)) if d_us else None                                     # cycles / ns = GHz
         out["kernels"][key] = {"device_kernel": kname[:100], "avg_us_in_profile": d_us,
                                "wave_insts_per_row": {k: c[k] / B for k in sorted(c) if k.startswith("SQ_INSTS")},
-                               "f64_issue_slots_per_row": slots / B, "clock_ghz": round(clock, 3) if clock else 2.0,
-                               "valu_busy_frac": (c["SQ_ACTIVE_INST_VALU"] * 4 / 1024 / c["GRBM_GUI_ACTIVE"]) if c.get("GRBM_GUI_ACTIVE") else None}
+                               "valu_issue_cycles_per_row": cycles / B, "f64_share_of_valu_insts": (f64 + c["SQ_INSTS_VALU_TRANS_F64"]) / c["SQ_INSTS_VALU"],
+                               "clock_ghz": round(clock, 3) if clock else 1.6,
+                               "valu_busy_frac": (c["SQ_ACTIVE_INST_VALU"] * 4 / 1024 / gui) if gui else None}
+    if "jf_mlp2_i8_seg_f64" in out["kernels"]:
+        out["kernels"]["jf_mlp2_i8_f64"] = out["kernels"]["jf_mlp2_i8_seg_f64"]        # (the same device kernel behind both entry points)
     json.dump(out, open(os.path.join(P, "r05_f64_issue.json"), "w"), indent=1, sort_keys=True)
     shutil.copy(os.path.join(src, "pmc.txt"), os.path.join(P, "r05_c3_f64_pmc.txt"))
     shutil.copy(os.path.join(src, "kernel_stats.md"), os.path.join(P, "r05_c3_f64_kernel_stats.md"))
-    print("float64 issue profile:", {k: round(v["f64_issue_slots_per_row"], 1) for k, v in out["kernels"].items()})
+    print("float64 issue profile:", {k: (round(v["valu_issue_cycles_per_row"], 1), v["clock_ghz"], round(v["valu_busy_frac"] or 0, 2)) for k, v in out["kernels"].items()})
 print(sorted(f for f in os.listdir(P) if f.startswith("r05")))
