@@ -464,14 +464,9 @@ template <typename T, bool FWD> static int launch(const GfChainArgs<T>& a, int D
             pack_elems = a.L[l].K > pack_elems ? a.L[l].K : pack_elems;
         }
         const size_t lds_rows = ((size_t)a.tab_offset + (size_t)a.n_layers * pack_elems * D * 4) * sizeof(T);
-        // lane = row needs B / 64 waves to fill the chip: below ~2^17 rows (8 waves per CU) every lane walks its D coordinates x K components x
-        // layers alone on its SIMD and the kernel sits on that latency (0.035 ms for e4 / gggg however few the rows).  The lane = (row,
-        // coordinate) kernel below brings group_width(D) times the waves but has a floor of its own (0.028 ms: the layers are a dependent
-        // chain), so the switch buys 8 us below 2^16 rows -- and costs the property that a row's result does not depend on the batch it sits
-        // in (the two kernels round differently; tests/test_gpu_parity.py::test_full_size_batch_properties).  Off by default;
-        // JF_GFB_MIN_ROWS=n uses the lane = row kernel from n rows on (measurements: DESIGN.md 3.13).
-        static const int64_t gfb_min_rows = getenv("JF_GFB_MIN_ROWS") ? atoll(getenv("JF_GFB_MIN_ROWS")) : 0;
-        if (classic && D <= 8 && lds_rows <= (size_t)LDS_LIMIT && (a.B >= gfb_min_rows || group_width(D) == 1)) {
+        // lane = row (gfb_chain_inv_kernel) or, for small batches of 2 .. 4 dimensions, one lane per (row, coordinate) with bit-identical rows
+        // (gfbg_chain_inv_kernel: launch_rows picks, jf_gfb.h explains)
+        if (classic && D <= 8 && lds_rows <= (size_t)LDS_LIMIT) {
             switch (D) {
                 case 1: return launch_rows<T, 1>(a, lds_rows, st);
                 case 2: return launch_rows<T, 2>(a, lds_rows, st);
