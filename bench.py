@@ -981,6 +981,7 @@ def main():
         return
 
     results = {}
+    pipeline_error = None
     kernel_table = None
     two_launch = None
     graph_replay = None
@@ -1002,7 +1003,11 @@ def main():
         # kernels, status words and (N > 1) all-gather still complete inside the timed region (finish())
         pipe = None
         if not args.no_plan and args.pipeline_depth > 1:
-            pipe = pdf.pipelined_forward(x, conditional_input=c, depth=args.pipeline_depth)
+            try:
+                pipe = pdf.pipelined_forward(x, conditional_input=c, depth=args.pipeline_depth)
+            except Exception as e:                    # noqa: BLE001 -- reported in the line; the run continues on one stream
+                pipeline_error = "%s: %s" % (type(e).__name__, str(e)[:200])
+                print("bench: pipelined_forward failed (%s); continuing on one stream" % pipeline_error, file=sys.stderr)
 
         def step():
             if pipe is not None:
@@ -1228,7 +1233,7 @@ def main():
             "step_issue": ("recorded step plan: one ctypes call per step (jf_plan_launch)" + (
                 "; consecutive steps alternate between %d streams (pdf.pipelined_forward)" % args.pipeline_depth if args.pipeline_depth > 1 else ""))
             if not args.no_plan else "eager: one ctypes call per launch",
-            "pipeline_depth": 1 if args.no_plan else args.pipeline_depth,
+            "pipeline_depth": 1 if (args.no_plan or pipeline_error) else args.pipeline_depth, "pipeline_error": pipeline_error,
             "roofline": roofline,
             "cpu_baseline": cpu,
         }

@@ -71,13 +71,14 @@ __device__ __forceinline__ MixQ<float> cs_mixture(const float (&P)[CS_SLOTS], co
         float C = 0.f, S = 0.f, Pd = 0.f;
 #pragma unroll
         for (int k = 0; k < CS_K; ++k) {
-            const float t = Mf::exp_fast(-fabsf(u[k]));
-            const float hi = Mf::rcp(1.0f + t);
-            const float lo = t * hi;
-            const bool pos = u[k] >= 0.f;
-            C += wk[k] * (pos ? hi : lo);
-            S += wk[k] * (pos ? lo : hi);
-            Pd += wk[k] * hi * lo * iw[k];
+            // s = sigma(u) = 1 / (1 + e^{-u}), sigma(-u) = e^{-u} s: no |u|, no compare, no selects (jf_gfb.h: gfb_mix_sums).  The exponent is
+            // capped so that e^{-u} stays finite (87 < ln FLT_MAX): such a lane is `far` (m > CS_M_SCALED) and takes the scaled sums below
+            const float t = Mf::exp_fast(fminf(-u[k], 87.0f));
+            const float s = Mf::rcp(1.0f + t);
+            const float ts = t * s;
+            C += wk[k] * s;
+            S += wk[k] * ts;
+            Pd += wk[k] * s * ts * iw[k];
         }
         C *= inv; S *= inv; Pd *= inv;
         q.lc = Mf::log_fast(C); q.ls = Mf::log_fast(S); q.lp = Mf::log_fast(Pd);
@@ -137,13 +138,22 @@ template <typename T> __device__ __forceinline__ MixQ<T> cs_mixture_derived(cons
     for (int k = 0; k < CS_K; ++k) {
         const T iw = P[CS_SLOT_LW + k], wk = P[CS_SLOT_LN + k];
         const T u = (x - P[CS_SLOT_MEAN + k]) * iw;
-        const T t = Mf::exp_fast(-Mf::abs(u));
-        const T hi = Mf::rcp(T(1) + t);
-        const T lo = t * hi;
-        const bool pos = u >= T(0);
-        C += wk * (pos ? hi : lo);
-        S += wk * (pos ? lo : hi);
-        Pd += wk * hi * lo * iw;
+        if constexpr (sizeof(T) == 4) {                            // select-free form (cs_mixture above): sigma(u) = 1 / (1 + e^{-u}), sigma(-u) = e^{-u} sigma(u)
+            const T t = Mf::exp_fast(Mf::min(-u, T(87)));
+            const T s = Mf::rcp(T(1) + t);
+            const T ts = t * s;
+            C += wk * s;
+            S += wk * ts;
+            Pd += wk * s * ts * iw;
+        } else {
+            const T t = Mf::exp_fast(-Mf::abs(u));
+            const T hi = Mf::rcp(T(1) + t);
+            const T lo = t * hi;
+            const bool pos = u >= T(0);
+            C += wk * (pos ? hi : lo);
+            S += wk * (pos ? lo : hi);
+            Pd += wk * hi * lo * iw;
+        }
     }
     MixQ<T> q;
     q.lc = Mf::log_fast(C); q.ls = Mf::log_fast(S); q.lp = Mf::log_fast(Pd);
