@@ -20,7 +20,7 @@
         out[blockIdx.x * 256 + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;              \
         if (threadIdx.x == 0) clk[blockIdx.x] = t1 - t0;                                          \
     }
-#define F3 float f0 = (float)seed; float f1 = 1.0001f; float f2 = 0.5f
+#define F3 float f0 = (float)seed; float f1 = 1.0001f; float f2 = 0.5f; float g0 = f0, g1 = f0 + 1, g2 = f0 + 2, g3 = f0 + 3, g4 = f0 + 4, g5 = f0 + 5, g6 = f0 + 6, g7 = f0 + 7
 #define D8 double a0 = seed; double a1 = seed + 1; double a2 = seed + 2; double a3 = seed + 3; double a4 = seed + 4; double a5 = seed + 5; double a6 = seed + 6; double a7 = seed + 7; const double b = seed * 0.5; const double c = seed * 0.25
 #define EACH(OP) OP(a0) OP(a1) OP(a2) OP(a3) OP(a4) OP(a5) OP(a6) OP(a7)
 
@@ -35,6 +35,12 @@
 #define OP_CNDMASK(x) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(f0) : "v"(f1));
 #define OP_FMA32(x) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(f0) : "v"(f1), "v"(f2));
 #define OP_EXP32(x) asm volatile("v_exp_f32 %0, %0" : "+v"(f0));
+#define OP_FMA32I(x) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(g##x) : "v"(f1), "v"(f2));
+#define OP_EXP32I(x) asm volatile("v_exp_f32 %0, %0" : "+v"(g##x));
+#define OP_RCP32I(x) asm volatile("v_rcp_f32 %0, %0" : "+v"(g##x));
+#define OP_CND32I(x) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(g##x) : "v"(f1));
+#define OP_PKFMA(x) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(x) : "v"(b), "v"(c));
+#define EACHI(OP) OP(0) OP(1) OP(2) OP(3) OP(4) OP(5) OP(6) OP(7)
 #define OP_CMP64(x) asm volatile("v_cmp_gt_f64 vcc, %0, %1" : : "v"(x), "v"(b) : "vcc");
 #define OP_MAX64(x) asm volatile("v_max_f64 %0, %0, %1" : "+v"(x) : "v"(b));
 
@@ -49,6 +55,11 @@ KERNEL(k_cvt_i32_f64_pair, D8; int ti = 0, EACH(OP_CVTI))
 KERNEL(k_cndmask, D8; F3, EACH(OP_CNDMASK))
 KERNEL(k_fma32, D8; F3, EACH(OP_FMA32))
 KERNEL(k_exp32, D8; F3, EACH(OP_EXP32))
+KERNEL(k_fma32_indep, D8; F3, EACHI(OP_FMA32I); a0 += g0 + g1 + g2 + g3 + g4 + g5 + g6 + g7)
+KERNEL(k_exp32_indep, D8; F3, EACHI(OP_EXP32I); a0 += g0 + g1 + g2 + g3 + g4 + g5 + g6 + g7)
+KERNEL(k_rcp32_indep, D8; F3, EACHI(OP_RCP32I); a0 += g0 + g1 + g2 + g3 + g4 + g5 + g6 + g7)
+KERNEL(k_cnd32_indep, D8; F3, EACHI(OP_CND32I); a0 += g0 + g1 + g2 + g3 + g4 + g5 + g6 + g7)
+KERNEL(k_pkfma32, D8, EACH(OP_PKFMA))
 KERNEL(k_cmp64, D8, EACH(OP_CMP64))
 KERNEL(k_max64, D8, EACH(OP_MAX64))
 
@@ -90,6 +101,11 @@ int main() {
         run("v_cndmask_b32", k_cndmask, 1, w);
         run("v_fma_f32", k_fma32, 1, w);
         run("v_exp_f32", k_exp32, 1, w);
+        run("v_fma_f32 indep", k_fma32_indep, 1, w);
+        run("v_exp_f32 indep", k_exp32_indep, 1, w);
+        run("v_rcp_f32 indep", k_rcp32_indep, 1, w);
+        run("v_cndmask_b32 indep", k_cnd32_indep, 1, w);
+        run("v_pk_fma_f32 (2 lanes)", k_pkfma32, 1, w);
     }
     return 0;
 }
