@@ -248,6 +248,11 @@ class pdf(nn.Module):
         # 2^20); 0 = never
         self.merge_max_rows = int(os.environ.get("JF_MERGE_MAX_ROWS", str(1 << 40)))
         self._merge_ok = {}
+        # gradient mode: the blocks of a training step are independent given the targets too.  With train_streams > 1 every block's forward is
+        # issued on one of that many streams (torch.autograd runs a node's backward on the stream of its forward), so the latency-bound kernels
+        # of one block's adjoint overlap the other blocks'; the per-block log-dets / base log-probs are added at the end instead of threaded
+        self.train_streams = int(os.environ.get("JF_TRAIN_STREAMS", "1"))
+        self._train_stream_objs = {}
 
         self._read_model_definition(pdf_defs, flow_defs, options_overwrite, conditional_input_dim, amortization_mlp_dims,
                                     amortization_mlp_ranks)
@@ -1258,6 +1263,15 @@ class pdf(nn.Module):
         base_logp = None
         bases = []
         embeds = []
+        # independent blocks on side streams (self.train_streams): each block starts from zero sums, the sums are added after the loop
+        n_blocks = len(self.layer_list)
+        side = None
+        if self.train_streams > 1 and n_blocks > 1 and collect is None and log_det0 is None:
+            side = self._train_stream_objs.get(x.device)
+            if side is None or len(side) != self.train_streams - 1:
+                side = self._train_stream_objs[x.device] = [torch.cuda.Stream(device=x.device) for _ in range(self.train_streams - 1)]
+        main_stream = torch.cuda.current_stream(x.device)
+        ld_parts, blp_parts = [], []
         for si, block in enumerate(self.layer_list):
             a, b = self.target_dim_indices[si]
             tgt = x[:, a:b]
@@ -1273,84 +1287,99 @@ class pdf(nn.Module):
                 if not pieces:
                     raise Exception("extra conditional input is empty but required for encoding!")
                 inp = torch.cat(pieces, dim=1) if len(pieces) > 1 else pieces[0]
-            if kind == "e" and gfl.chain_supported(layers):
-                D = layers[0].dimension
-                fused = self._fusable_block(si, layers, only_last, amort, x.dtype) if mlp is not None else None
-                if fused is not None:
-                    larr = _hip.gf_layer_array([l.c_struct() for l in layers])
-                    w1, b1, w2, b2 = mlp[0].weight, mlp[0].bias, mlp[2].weight, mlp[2].bias
-                    packed = None
-                    if self.fused_matrix_arithmetic != "f32" and w1.shape[0] <= 128:
-                        packed = self._packed_w2(si, w2.detach(), b2.detach(), larr, len(layers), D, x.shape[0])
-                    out, log_det, base_logp = autograd.CondBlockFn.apply(inp, w1, b1, w2, b2, tgt, log_det, base_logp, packed, larr, len(layers), D,
-                                                                         status)
-                elif self._lowrank_chain_ok(si, layers, only_last, amort, x, mlp):
-                    # low-rank last stage (float64): the chain regenerates its parameters from the rank-space vector, forward and backward
-                    t2, u2, b2 = mlp.forward_to_last_rank(inp)
-                    larr = _hip.gf_layer_array([l.c_struct() for l in layers])
-                    out, log_det, base_logp = autograd.LowRankGfChainFn.apply(t2, u2, b2, tgt, log_det, base_logp, larr, len(layers), D, status)
+            stream_ctx = None
+            if side is not None:
+                log_det, base_logp = None, None
+                if si < n_blocks - 1:                     # the last (usually largest) block stays on the caller's stream
+                    st = side[si % len(side)]
+                    st.wait_stream(main_stream)           # inputs (targets, embeddings, the cat above) were produced on the caller's stream
+                    stream_ctx = torch.cuda.stream(st)
+                    stream_ctx.__enter__()
+            try:
+                if kind == "e" and gfl.chain_supported(layers):
+                    D = layers[0].dimension
+                    fused = self._fusable_block(si, layers, only_last, amort, x.dtype) if mlp is not None else None
+                    if fused is not None:
+                        larr = _hip.gf_layer_array([l.c_struct() for l in layers])
+                        w1, b1, w2, b2 = mlp[0].weight, mlp[0].bias, mlp[2].weight, mlp[2].bias
+                        packed = None
+                        if self.fused_matrix_arithmetic != "f32" and w1.shape[0] <= 128:
+                            packed = self._packed_w2(si, w2.detach(), b2.detach(), larr, len(layers), D, x.shape[0])
+                        out, log_det, base_logp = autograd.CondBlockFn.apply(inp, w1, b1, w2, b2, tgt, log_det, base_logp, packed, larr, len(layers), D,
+                                                                             status)
+                    elif self._lowrank_chain_ok(si, layers, only_last, amort, x, mlp):
+                        # low-rank last stage (float64): the chain regenerates its parameters from the rank-space vector, forward and backward
+                        t2, u2, b2 = mlp.forward_to_last_rank(inp)
+                        larr = _hip.gf_layer_array([l.c_struct() for l in layers])
+                        out, log_det, base_logp = autograd.LowRankGfChainFn.apply(t2, u2, b2, tgt, log_det, base_logp, larr, len(layers), D, status)
+                    else:
+                        params = block_params(si, layers, inp, mlp)
+                        used = layers
+                        if only_last:
+                            used, params = last_only(layers, params, kind)
+                        larr = _hip.gf_layer_array([l.c_struct() for l in used])
+                        out, log_det, base_logp = autograd.GfChainInvFn.apply(tgt, log_det, params, base_logp, larr, len(used), D, status)
+                elif kind == "e":
+                    # Euclidean block mixing 'g' runs with other layers ('t'): one launch per group, last group first (:1002-1012)
+                    from ..layers.euclidean.multivariate_normal import mvn_block
+                    params = block_params(si, layers, inp, mlp)
+                    used = layers
+                    if only_last:
+                        used, params = last_only(layers, params, kind)
+                    groups = _layer_groups(used)
+                    out, c1 = tgt, params.shape[1]
+                    for gi in range(len(groups) - 1, -1, -1):
+                        grp = groups[gi]
+                        n = sum(l.total_param_num for l in grp)
+                        this = params[:, c1 - n:c1]
+                        blp_in = base_logp if gi == 0 else None
+                        if type(grp[0]) is gfl.gf_block:
+                            larr = _hip.gf_layer_array([l.c_struct() for l in grp])
+                            out, log_det, blp = autograd.GfChainInvFn.apply(out, log_det, this, blp_in, larr, len(grp), grp[0].dimension, status)
+                        elif type(grp[0]) is mvn_block:
+                            out, log_det, blp = autograd.TLayerInvFn.apply(out, log_det, this if n > 0 else None, blp_in, grp[0].c_struct(),
+                                                                           grp[0].dimension, status)
+                        else:
+                            # a layer the library has no kernel for -- a user's euclidean_base subclass written in torch (layer_base.py:58-70): the
+                            # layer's own operations carry the autograd graph; amortised parameters arrive as its extra_inputs slice
+                            l = grp[-1]
+                            own = None if (mlp is None and not self.amortize_everything) else (this[:, n - l.total_param_num:] if n > 0 else None)
+                            ld_in = log_det if log_det is not None else torch.zeros(B, dtype=x.dtype, device=x.device)
+                            out, log_det = l.inv_flow_mapping([out, ld_in], extra_inputs=own)[:2]
+                            blp = None
+                            if gi == 0:
+                                blp = (-0.5 * out * out - 0.9189385332046727).sum(dim=1)
+                                if blp_in is not None:
+                                    blp = blp_in + blp
+                        c1 -= n
+                    base_logp = blp
                 else:
                     params = block_params(si, layers, inp, mlp)
                     used = layers
                     if only_last:
                         used, params = last_only(layers, params, kind)
-                    larr = _hip.gf_layer_array([l.c_struct() for l in used])
-                    out, log_det, base_logp = autograd.GfChainInvFn.apply(tgt, log_det, params, base_logp, larr, len(used), D, status)
-            elif kind == "e":
-                # Euclidean block mixing 'g' runs with other layers ('t'): one launch per group, last group first (:1002-1012)
-                from ..layers.euclidean.multivariate_normal import mvn_block
-                params = block_params(si, layers, inp, mlp)
-                used = layers
-                if only_last:
-                    used, params = last_only(layers, params, kind)
-                groups = _layer_groups(used)
-                out, c1 = tgt, params.shape[1]
-                for gi in range(len(groups) - 1, -1, -1):
-                    grp = groups[gi]
-                    n = sum(l.total_param_num for l in grp)
-                    this = params[:, c1 - n:c1]
-                    blp_in = base_logp if gi == 0 else None
-                    if type(grp[0]) is gfl.gf_block:
-                        larr = _hip.gf_layer_array([l.c_struct() for l in grp])
-                        out, log_det, blp = autograd.GfChainInvFn.apply(out, log_det, this, blp_in, larr, len(grp), grp[0].dimension, status)
-                    elif type(grp[0]) is mvn_block:
-                        out, log_det, blp = autograd.TLayerInvFn.apply(out, log_det, this if n > 0 else None, blp_in, grp[0].c_struct(),
+                    fam = _manifold_family(used)
+                    groups = [used] if fam is not None else [[l] for l in used]          # mixed families (e.g. "mo"): one launch per layer
+                    out, c1 = tgt, params.shape[1]
+                    for gi in range(len(groups) - 1, -1, -1):                            # last layer first, parameters sliced tail-first (:1002-1012)
+                        grp = groups[gi]
+                        f = _manifold_family(grp)
+                        if f is None:
+                            raise NotImplementedError("gradients through %s layers are not implemented" % type(grp[0]).__name__)
+                        n = sum(l.total_param_num for l in grp)
+                        # (only_last on a sphere: the last layer also takes the sphere -> plane chart, fix_euclidean_to_sphere_first, :1018-1031)
+                        structs = [l.c_struct() if f == "r" else l.c_struct(1 if (l.euclidean_to_sphere_as_first or (only_last and kind == "s")) else 0)
+                                   for l in grp]
+                        out, log_det, blp = autograd.MChainInvFn.apply(out, log_det, params[:, c1 - n:c1], base_logp if gi == 0 else None, f, structs,
                                                                        grp[0].dimension, status)
-                    else:
-                        # a layer the library has no kernel for -- a user's euclidean_base subclass written in torch (layer_base.py:58-70): the
-                        # layer's own operations carry the autograd graph; amortised parameters arrive as its extra_inputs slice
-                        l = grp[-1]
-                        own = None if (mlp is None and not self.amortize_everything) else (this[:, n - l.total_param_num:] if n > 0 else None)
-                        ld_in = log_det if log_det is not None else torch.zeros(B, dtype=x.dtype, device=x.device)
-                        out, log_det = l.inv_flow_mapping([out, ld_in], extra_inputs=own)[:2]
-                        blp = None
-                        if gi == 0:
-                            blp = (-0.5 * out * out - 0.9189385332046727).sum(dim=1)
-                            if blp_in is not None:
-                                blp = blp_in + blp
-                    c1 -= n
-                base_logp = blp
-            else:
-                params = block_params(si, layers, inp, mlp)
-                used = layers
-                if only_last:
-                    used, params = last_only(layers, params, kind)
-                fam = _manifold_family(used)
-                groups = [used] if fam is not None else [[l] for l in used]          # mixed families (e.g. "mo"): one launch per layer
-                out, c1 = tgt, params.shape[1]
-                for gi in range(len(groups) - 1, -1, -1):                            # last layer first, parameters sliced tail-first (:1002-1012)
-                    grp = groups[gi]
-                    f = _manifold_family(grp)
-                    if f is None:
-                        raise NotImplementedError("gradients through %s layers are not implemented" % type(grp[0]).__name__)
-                    n = sum(l.total_param_num for l in grp)
-                    # (only_last on a sphere: the last layer also takes the sphere -> plane chart, fix_euclidean_to_sphere_first, :1018-1031)
-                    structs = [l.c_struct() if f == "r" else l.c_struct(1 if (l.euclidean_to_sphere_as_first or (only_last and kind == "s")) else 0)
-                               for l in grp]
-                    out, log_det, blp = autograd.MChainInvFn.apply(out, log_det, params[:, c1 - n:c1], base_logp if gi == 0 else None, f, structs,
-                                                                   grp[0].dimension, status)
-                    c1 -= n
-                base_logp = blp
+                        c1 -= n
+                    base_logp = blp
+            finally:
+                if stream_ctx is not None:
+                    stream_ctx.__exit__(None, None, None)
+            if side is not None:
+                ld_parts.append(log_det)
+                blp_parts.append(base_logp)
             bases.append(out)
             if collect is not None:
                 cot = None
@@ -1367,6 +1396,15 @@ class pdf(nn.Module):
                 collect.append({"a": a, "b": b, "y": out, "cot": cot, "coupled": mlp is not None and len(embeds) > 0})
             emb = block[-1]._embedding_conditional_return(tgt.detach()) if not tgt.requires_grad else autograd.embed(tgt, kind, layers[-1])
             embeds.append(emb)
+        if side is not None:
+            for st in side:
+                main_stream.wait_stream(st)               # every block's outputs are complete before the caller's stream adds them up
+            log_det = ld_parts[0]
+            for t in ld_parts[1:]:
+                log_det = log_det + t
+            base_logp = blp_parts[0]
+            for t in blp_parts[1:]:
+                base_logp = base_logp + t
         base = torch.cat(bases, dim=1) if len(bases) > 1 else bases[0]
         total = base_logp + log_det
         self._defer_status(status)
