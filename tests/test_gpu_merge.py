@@ -249,3 +249,25 @@ def test_combine_rows_with_more_lists_than_one_launch_takes():
     for t in blps[1:]:
         want_blp = want_blp + t
     assert torch.equal(ld, want_ld) and torch.equal(blp, want_blp) and torch.equal(total, want_blp + want_ld)
+
+
+def test_pipelined_forward_follows_parameter_updates():
+    """an in-place parameter update (an optimiser step) between two submits: each stream's plan records again by itself"""
+    fx = BY_NAME["c3_e4s2e4"]
+    pdf = build_product(fx, torch.float32)
+    pdf.check_status = "deferred"
+    x, c = rows(fx, 2000, torch.float32, seed=4)
+    pipe = pdf.pipelined_forward(x, conditional_input=c, depth=2)
+    for t in [pipe.submit(x, c) for _ in range(3)]:
+        t.result()
+    pipe.drain()
+    with torch.no_grad():
+        for p in pdf.parameters():
+            p.mul_(1.01)
+    want = pdf(x, conditional_input=c)
+    pdf.flush_status()
+    got = [pipe.submit(x, c) for _ in range(4)]
+    pipe.drain()
+    for t in got:
+        for g, w in zip(t.result(), want):
+            assert same(g, w)
