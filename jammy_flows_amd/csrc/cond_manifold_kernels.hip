@@ -18,6 +18,7 @@ namespace jf {
 
 // (CmArgs and the kernel body: jf_cond_mchain.h)
 // NT threads per workgroup (256 in float32; 128 in float64, whose lane-private knot tables are twice as large)
+// (four workgroups per CU instead of three, round 5: 104 VGPRs allow it, the `f` block measures 0.107 instead of 0.105 ms -- not taken)
 // (float32: a register budget for three waves per SIMD -- 140 + 32 AGPRs -> 112 VGPRs, the `f` block of C3 0.109 -> 0.105 ms per 2^20 rows)
 template <typename T, class Fam, int NT, bool FWD = false>
 __global__ void __launch_bounds__(NT, NT == 256 ? 3 : 1) cond_mchain_kernel(const CmArgs<T, typename Fam::CLayer> a) {
@@ -52,8 +53,14 @@ static int cond_mchain(const T* in, int64_t in_stride, const T* W1, int64_t w1s,
     a.scratch = 0;
     int n_spl = 0;
     for (int l = 0; l < n_layers; ++l) n_spl += Fam::n_bins(layers[l]);
-    a.tab = n_spl > 0 ? JF_SPLINE_TAB : 0;             // 54 KB of LDS per 256 lanes that a spline-free chain (default 'f', 'm') does not need:
-                                                       // without it four workgroups fit a CU instead of one
+    a.tab = 0;                                         // lane-private knot tables: none for a spline-free chain (default 'f', 'm'), else 3 (bins + 1)
+    if (n_spl > 0) {                                   // words where the family states its bin count (r, o), the 16-bin maximum otherwise
+        a.tab = JF_SPLINE_TAB;
+        if constexpr (std::is_same<Fam, RFam>::value || std::is_same<Fam, OFam>::value) {
+            a.tab = 1;
+            for (int l = 0; l < n_layers; ++l) { const int w = Fam::tab_words(layers[l]); a.tab = w > a.tab ? w : a.tab; }
+        }
+    }
     const int k1p = (K1 + 3) / 4 * 4, ldk = k1p + 1;
     constexpr int NT = sizeof(T) == 4 ? 256 : 128;
     // (float32: the W2 region holds np / 16 x 4 k-steps x 2 pieces x 1 KiB of f16 fragments = np x 128 floats, less than the np x 129 reserved;
