@@ -79,6 +79,65 @@ template <typename T, typename ROW> __device__ inline void v_component(ROW pp, i
     }
 }
 
+// Reverse mode of v_component for the closed-form potentials (exponential / linear / quadratic): given the upstream gradients of the summed
+// outputs, Gg = dS / d g (3) and Gj = dS / d gj (3 x 3), this component's share of dS / d x is ADDED to gx and the gradients of its own
+// parameters are returned -- gm: the three rows of its direction, glw: its log-weight with the normaliser lse HELD FIXED (the caller adds the
+// softmax coupling, - softmax_k * sum_m glw_m), glb: its log-beta (exponential potential only, else 0).  Written out by hand from the
+// expressions of v_component above; the dual-number replay of the same function (manifold_bwd_kernels.hip, spline potentials) is its check.
+template <typename T> __device__ inline void v_component_adjoint(const T* __restrict__ pp, int nc, int k, int kind, T lse, const T (&x)[3],
+                                                                 const T (&Gg)[3], const T (&Gj)[3][3], T (&gx)[3], T (&gm)[3], T& glw, T& glb) {
+    const int w_row = 3, b_row = 4;
+    const T m[3] = {pp[k], pp[nc + k], pp[2 * nc + k]};
+    const T nrm = M<T>::sqrt(m[0] * m[0] + m[1] * m[1] + m[2] * m[2]);
+    const T inv_nrm = T(1) / nrm;
+    const T mu[3] = {m[0] * inv_nrm, m[1] * inv_nrm, m[2] * inv_nrm};
+    // v_mu_norm and its derivative: vn = 1 - log(1 + c E), E = exp(-n / 10)  ->  vn' = (c E / 10) / (1 + c E)
+    const T cE = T(1.718281828459045) * M<T>::exp(-nrm / T(10));
+    const T vn = T(1) - M<T>::log(T(1) + cE);
+    const T dvn = (cE / T(10)) / (T(1) + cE);
+    const T w = M<T>::exp(pp[w_row * nc + k] - lse) * vn;
+    const T xmu = x[0] * mu[0] + x[1] * mu[1] + x[2] * mu[2];
+    T f, fp, beta = T(0);
+    if (kind == JF_V_EXPONENTIAL) {
+        beta = M<T>::exp(pp[b_row * nc + k]);
+        f = M<T>::exp(beta * (xmu - T(1)));
+        fp = beta * f;
+    } else if (kind == JF_V_LINEAR) {
+        f = T(1); fp = T(0);
+    } else {
+        f = xmu; fp = T(1);
+    }
+    // S_k = w (f A + fp Q),  A = Gg . mu,  Q = mu^T Gj mu;  h = (Gj + Gj^T) mu = dQ / d mu
+    T h[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) h[i] = (Gj[i][0] + Gj[0][i]) * mu[0] + (Gj[i][1] + Gj[1][i]) * mu[1] + (Gj[i][2] + Gj[2][i]) * mu[2];
+    const T A = Gg[0] * mu[0] + Gg[1] * mu[1] + Gg[2] * mu[2];
+    const T Q = T(0.5) * (h[0] * mu[0] + h[1] * mu[1] + h[2] * mu[2]);
+    const T dS_dw = f * A + fp * Q;
+    T dS_dxmu, dS_dbeta = T(0);
+    if (kind == JF_V_EXPONENTIAL) {
+        dS_dxmu = w * fp * (A + beta * Q);                                    // df / dxmu = fp, dfp / dxmu = beta fp
+        dS_dbeta = w * f * ((xmu - T(1)) * A + (T(1) + beta * (xmu - T(1))) * Q);
+    } else if (kind == JF_V_LINEAR) {
+        dS_dxmu = T(0);
+    } else {
+        dS_dxmu = w * A;
+    }
+    T dmu[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        dmu[i] = w * (f * Gg[i] + fp * h[i]) + dS_dxmu * x[i];
+        gx[i] += dS_dxmu * mu[i];
+    }
+    // mu = m / |m|: d mu_i / d m_j = (delta_ij - mu_i mu_j) / |m|;  w depends on |m| through vn
+    const T radial = dmu[0] * mu[0] + dmu[1] * mu[1] + dmu[2] * mu[2];
+    const T dS_dnrm = dS_dw * (w / vn) * dvn;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) gm[i] = (dmu[i] - mu[i] * radial) * inv_nrm + dS_dnrm * mu[i];
+    glw = dS_dw * w;
+    glb = dS_dbeta * beta;
+}
+
 template <typename T, typename ROW> __device__ inline void v_potential(ROW pp, int nc, int kind, const T (&x)[3], VPotential<T>& P, T* __restrict__ tab,
                                                                       bool& oob) {
     const T lse = v_lse<T>(pp, nc);
@@ -161,6 +220,246 @@ template <typename T> __device__ inline void v_exp_geometry(int kind, const T (&
     const T a22 = c2[0] * c2[0] + c2[1] * c2[1] + c2[2] * c2[2];
     const T a12 = c1[0] * c2[0] + c1[1] * c2[1] + c1[2] * c2[2];
     o.logdet_half = T(0.5) * M<T>::log(M<T>::abs(a11 * a22 - a12 * a12));
+}
+
+// ---- v_exp_geometry in REVERSE mode (the backward kernel, manifold_bwd_kernels.hip).  v_geo_forward evaluates the same expressions as
+// v_exp_geometry above and keeps the intermediates a reverse sweep needs; v_geo_reverse takes the upstream gradients of its two outputs
+// (yb = dS / d y, lb = dS / d logdet_half) back to the three inputs: xb = dS / d x, gb = dS / d g, gjb = dS / d gj (zero for the linear
+// potential, whose geometry does not read gj).  Written out by hand, statement by statement in reverse order of the forward function (the
+// step labels are the forward statements); the dual-number replay of v_exp_geometry (JF_V_BWD_DUAL) is its check.
+template <typename T> struct VGeoTape {
+    T tn, nt[3], ca, sa, tv[3], proj, inv_sq, dth[3];
+    T jt0[3][3];          // d tangent / d base before the terms through gj
+    T jt[3][3], jp[3];    // ... with them
+    T dn[3][3], A[3][3], s[3];
+    T cp, sp, J[3][3], t2[3], c1[3], c2[3], a11, a22, a12, det;
+};
+
+template <typename T> __device__ inline void v_geo_forward(int kind, const T (&x)[3], const VPotential<T>& P, VGeoTape<T>& t, T (&y)[3], T& logdet_half) {
+    const T (&g)[3] = P.g;
+    const T (&gj)[3][3] = P.gj;
+    t.tn = M<T>::sqrt(g[0] * g[0] + g[1] * g[1] + g[2] * g[2]);                                  // F1
+#pragma unroll
+    for (int i = 0; i < 3; ++i) t.nt[i] = g[i] / t.tn;                                           // F2
+    t.ca = t.nt[0] * x[0] + t.nt[1] * x[1] + t.nt[2] * x[2];                                     // F3
+    t.sa = M<T>::sin(M<T>::acos(t.ca));                                                          // F4
+#pragma unroll
+    for (int i = 0; i < 3; ++i) t.tv[i] = (t.nt[i] - x[i] * t.ca) / t.sa;                        // F5
+    t.proj = g[0] * t.tv[0] + g[1] * t.tv[1] + g[2] * t.tv[2];                                   // F6
+    t.inv_sq = T(-1) / M<T>::sqrt(T(1) - t.ca * t.ca);                                           // F7
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        t.dth[i] = (x[i] - t.nt[i] * t.ca) / (t.sa * t.sa);                                      // F8
+#pragma unroll
+        for (int j = 0; j < 3; ++j) t.jt0[i][j] = (i == j ? -t.ca / t.sa : T(0)) + t.dth[i] * (t.inv_sq * t.nt[j]);      // F9
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) t.jp[j] = t.jt0[0][j] * g[0] + t.jt0[1][j] * g[1] + t.jt0[2][j] * g[2];                   // F10
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) t.jt[i][j] = t.jt0[i][j];
+    if (kind != JF_V_LINEAR) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) t.dn[i][j] = (-g[i] / (t.tn * t.tn)) * t.nt[j] + (i == j ? T(1) / t.tn : T(0));  // F11
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) t.A[i][j] = t.dn[i][0] * gj[0][j] + t.dn[i][1] * gj[1][j] + t.dn[i][2] * gj[2][j];  // F12
+#pragma unroll
+        for (int j = 0; j < 3; ++j) t.s[j] = x[0] * t.A[0][j] + x[1] * t.A[1][j] + x[2] * t.A[2][j];                       // F13 (rr = inv_sq s)
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) t.jt[i][j] += t.dth[i] * (t.inv_sq * t.s[j]) + t.A[i][j] / t.sa;                   // F14
+#pragma unroll
+        for (int j = 0; j < 3; ++j) t.jp[j] += t.tv[0] * gj[0][j] + t.tv[1] * gj[1][j] + t.tv[2] * gj[2][j];               // F15
+    }
+    t.cp = M<T>::cos(t.proj); t.sp = M<T>::sin(t.proj);                                          // F16
+#pragma unroll
+    for (int i = 0; i < 3; ++i) y[i] = x[i] * t.cp + t.tv[i] * t.sp;                             // F17
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) t.J[i][j] = (i == j ? t.cp : T(0)) + (t.tv[i] * t.cp - x[i] * t.sp) * t.jp[j] + t.jt[i][j] * t.sp;   // F18
+    t.t2[0] = x[1] * t.tv[2] - x[2] * t.tv[1]; t.t2[1] = x[2] * t.tv[0] - x[0] * t.tv[2]; t.t2[2] = x[0] * t.tv[1] - x[1] * t.tv[0];    // F19
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {                                                                // F20
+        t.c1[i] = t.J[i][0] * t.tv[0] + t.J[i][1] * t.tv[1] + t.J[i][2] * t.tv[2];
+        t.c2[i] = t.J[i][0] * t.t2[0] + t.J[i][1] * t.t2[1] + t.J[i][2] * t.t2[2];
+    }
+    t.a11 = t.c1[0] * t.c1[0] + t.c1[1] * t.c1[1] + t.c1[2] * t.c1[2];                           // F21
+    t.a22 = t.c2[0] * t.c2[0] + t.c2[1] * t.c2[1] + t.c2[2] * t.c2[2];
+    t.a12 = t.c1[0] * t.c2[0] + t.c1[1] * t.c2[1] + t.c1[2] * t.c2[2];
+    t.det = t.a11 * t.a22 - t.a12 * t.a12;
+    logdet_half = T(0.5) * M<T>::log(M<T>::abs(t.det));
+}
+
+template <typename T> __device__ inline void v_geo_reverse(int kind, const T (&x)[3], const VPotential<T>& P, const VGeoTape<T>& t, const T (&yb)[3], T lb,
+                                                          T (&xb)[3], T (&gb)[3], T (&gjb)[3][3]) {
+    const T (&g)[3] = P.g;
+    const T (&gj)[3][3] = P.gj;
+    const bool nl = kind != JF_V_LINEAR;
+    T tvb[3] = {T(0), T(0), T(0)}, ntb[3] = {T(0), T(0), T(0)}, dthb[3] = {T(0), T(0), T(0)};
+    T cab = T(0), sab = T(0), isb = T(0), tnb = T(0), cpb = T(0), spb = T(0);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        xb[i] = T(0); gb[i] = T(0);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) gjb[i][j] = T(0);
+    }
+    // R21: logdet_half = 1/2 log |det|, det = a11 a22 - a12^2
+    const T detb = T(0.5) * lb / t.det;
+    const T a11b = detb * t.a22, a22b = detb * t.a11, a12b = T(-2) * detb * t.a12;
+    // R20: c1 = J tv, c2 = J t2
+    T c1b[3], c2b[3], Jb[3][3], t2b[3] = {T(0), T(0), T(0)};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { c1b[i] = T(2) * a11b * t.c1[i] + a12b * t.c2[i]; c2b[i] = T(2) * a22b * t.c2[i] + a12b * t.c1[i]; }
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            Jb[i][j] = c1b[i] * t.tv[j] + c2b[i] * t.t2[j];
+            tvb[j] += c1b[i] * t.J[i][j];
+            t2b[j] += c2b[i] * t.J[i][j];
+        }
+    // R19: t2 = x cross tv   (c = a x b: ab = b x cb, bb = cb x a)
+    xb[0] += t.tv[1] * t2b[2] - t.tv[2] * t2b[1]; xb[1] += t.tv[2] * t2b[0] - t.tv[0] * t2b[2]; xb[2] += t.tv[0] * t2b[1] - t.tv[1] * t2b[0];
+    tvb[0] += t2b[1] * x[2] - t2b[2] * x[1]; tvb[1] += t2b[2] * x[0] - t2b[0] * x[2]; tvb[2] += t2b[0] * x[1] - t2b[1] * x[0];
+    // R18: J_ij = delta_ij cp + (tv_i cp - x_i sp) jp_j + jt_ij sp
+    T jpb[3] = {T(0), T(0), T(0)}, jtb[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const T q = Jb[i][0] * t.jp[0] + Jb[i][1] * t.jp[1] + Jb[i][2] * t.jp[2];
+        cpb += Jb[i][i] + t.tv[i] * q;
+        spb += -x[i] * q;
+        tvb[i] += t.cp * q;
+        xb[i] += -t.sp * q;
+        const T u = t.tv[i] * t.cp - x[i] * t.sp;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            jpb[j] += Jb[i][j] * u;
+            jtb[i][j] = Jb[i][j] * t.sp;
+            spb += Jb[i][j] * t.jt[i][j];
+        }
+    }
+    // R17: y = x cp + tv sp
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        xb[i] += yb[i] * t.cp; tvb[i] += yb[i] * t.sp;
+        cpb += yb[i] * x[i]; spb += yb[i] * t.tv[i];
+    }
+    // R16: cp = cos(proj), sp = sin(proj)
+    const T projb = -t.sp * cpb + t.cp * spb;
+    T jt0b[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) jt0b[i][j] = jtb[i][j];
+    if (nl) {
+        // R15: jp_j += sum_i tv_i gj_ij
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) { tvb[i] += jpb[j] * gj[i][j]; gjb[i][j] += t.tv[i] * jpb[j]; }
+        // R14: jt_ij += dth_i rr_j + A_ij / sa,  rr = inv_sq s
+        T rrb[3] = {T(0), T(0), T(0)}, Ab[3][3];
+        const T inv_sa = T(1) / t.sa;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                dthb[i] += jtb[i][j] * (t.inv_sq * t.s[j]);
+                rrb[j] += jtb[i][j] * t.dth[i];
+                Ab[i][j] = jtb[i][j] * inv_sa;
+                sab += -jtb[i][j] * t.A[i][j] * inv_sa * inv_sa;
+            }
+        // R13: rr_j = inv_sq sum_i x_i A_ij
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            isb += rrb[j] * t.s[j];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { xb[i] += t.inv_sq * rrb[j] * t.A[i][j]; Ab[i][j] += t.inv_sq * x[i] * rrb[j]; }
+        }
+        // R12: A = dn gj
+        T dnb[3][3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                dnb[i][k] = Ab[i][0] * gj[k][0] + Ab[i][1] * gj[k][1] + Ab[i][2] * gj[k][2];
+#pragma unroll
+                for (int j = 0; j < 3; ++j) gjb[k][j] += t.dn[i][k] * Ab[i][j];
+            }
+        // R11: dn_ij = -g_i nt_j / tn^2 + delta_ij / tn
+        const T itn = T(1) / t.tn, itn2 = itn * itn;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                gb[i] += -dnb[i][j] * t.nt[j] * itn2;
+                ntb[j] += -dnb[i][j] * g[i] * itn2;
+                tnb += T(2) * dnb[i][j] * g[i] * t.nt[j] * itn2 * itn;
+            }
+            tnb += -dnb[i][i] * itn2;
+        }
+    }
+    // R10: jp_j (first part) = sum_i jt0_ij g_i
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { jt0b[i][j] += jpb[j] * g[i]; gb[i] += t.jt0[i][j] * jpb[j]; }
+    // R9: jt0_ij = delta_ij (-ca / sa) + dth_i inv_sq nt_j
+    {
+        const T D = jt0b[0][0] + jt0b[1][1] + jt0b[2][2];
+        cab += -D / t.sa;
+        sab += D * t.ca / (t.sa * t.sa);
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                dthb[i] += jt0b[i][j] * t.inv_sq * t.nt[j];
+                isb += jt0b[i][j] * t.dth[i] * t.nt[j];
+                ntb[j] += jt0b[i][j] * t.dth[i] * t.inv_sq;
+            }
+    }
+    // R8: dth_i = (x_i - nt_i ca) / sa^2
+    {
+        const T is2 = T(1) / (t.sa * t.sa);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            xb[i] += dthb[i] * is2;
+            ntb[i] += -dthb[i] * t.ca * is2;
+            cab += -dthb[i] * t.nt[i] * is2;
+            sab += T(-2) * dthb[i] * t.dth[i] / t.sa;
+        }
+    }
+    // R7: inv_sq = -(1 - ca^2)^(-1/2):  d inv_sq / d ca = ca inv_sq^3
+    cab += isb * t.ca * t.inv_sq * t.inv_sq * t.inv_sq;
+    // R6: proj = g . tv
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { gb[i] += projb * t.tv[i]; tvb[i] += projb * g[i]; }
+    // R5: tv_i = (nt_i - x_i ca) / sa
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        ntb[i] += tvb[i] / t.sa;
+        xb[i] += -tvb[i] * t.ca / t.sa;
+        cab += -tvb[i] * x[i] / t.sa;
+        sab += -tvb[i] * t.tv[i] / t.sa;
+    }
+    // R4: sa = sin(acos(ca)):  d acos = inv_sq, d sin = cos(acos(ca)) = ca
+    cab += sab * t.ca * t.inv_sq;
+    // R3: ca = nt . x
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { ntb[i] += cab * x[i]; xb[i] += cab * t.nt[i]; }
+    // R2: nt = g / tn
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { gb[i] += ntb[i] / t.tn; tnb += -ntb[i] * t.nt[i] / t.tn; }
+    // R1: tn = |g|
+#pragma unroll
+    for (int i = 0; i < 3; ++i) gb[i] += tnb * t.nt[i];
 }
 
 template <typename T> __device__ inline void v_exp_map(const T* __restrict__ pp, int nc, int kind, const T (&x)[3], ExpMapOut<T>& o, T* __restrict__ tab,

@@ -11,6 +11,7 @@
 // One wave per workgroup, one sample per lane, parameters of ALL layers of the chain staged once as dual rows in LDS.
 // Per-sample parameters: g_params (B, P).  Broadcast parameters: the row sums are accumulated into g_params (1, P) with one atomic add per
 // workgroup and parameter (the caller zero-initialises it).
+#include <cstdlib>
 #include <type_traits>
 
 #include "jf_dual.h"
@@ -26,6 +27,7 @@ template <typename T, typename CLayer> struct MBwdArgs {
     int64_t B;
     int n_layers, dim, P, tile_stride, scratch, rows, tab;       // tab: JF_SPLINE_TAB or 0 (no spline in the chain), as in manifold_kernels.hip
     int rot_max;                                                 // staged 'v' kernel: longest rotation row of the chain (lane-private dual copy)
+    int v_dual;                                                  // staged 'v' kernel: dual-number replay for EVERY potential (JF_V_BWD_DUAL: the check of the closed form)
     int col0[JF_MAX_MCHAIN];
     CLayer L[JF_MAX_MCHAIN];
     const T* g_xout; int64_t gxos;
@@ -149,206 +151,323 @@ __global__ void __launch_bounds__(64) mchain_bwd_kernel(const MBwdArgs<T, typena
 // ---------------------------------------------------------------------------------------------------------- 'v' chains, staged
 // The exponential-map layer (natural_direction 0, the default: log-prob direction = one direct evaluation) factors into
 //     pre  : (x, rotation parameters) -> e in R^3                       (rotation, angles -> embedding; cheap)
-//     pot  : (e, potential parameters) -> u = (grad phi (3), its Jacobian (3 x 3))          (a sum over the components; cheap)
+//     pot  : (e, potential parameters) -> u = (grad phi (3), its Jacobian (3 x 3))          (a sum over the components)
 //     geo  : (e, u) -> exp_e(grad phi), 1/2 log det of the projected Jacobian               (no parameters; the expensive part)
 //     post : embedding -> angles (+ chart of the first layer)                               (cheap)
-// The generic kernel above replays ALL of it once per input direction: 2 + 50 passes for the default layer.  Here the expensive stages are
-// replayed only for the 15 directions of (e, u), which gives G = d S / d (e, u) for the upstream-contracted objective S; the parameters and
-// the layer's input then need only pre + pot on dual numbers, contracted with G (chain rule through the 15 intermediates).  Layers of a
-// chain are walked in reverse with the (2 + 1)-component upstream gradient, after one forward sweep that records every layer's input.
+// The generic kernel above replays ALL of it once per input direction: 2 + 50 passes for the default layer.  Here (round 5) the two expensive
+// stages are taken in REVERSE mode, written out by hand (jf_expmap.h):
+//   (1) geo: v_geo_forward keeps the intermediates, v_geo_reverse takes (d S / d y, d S / d logdet) back to G = d S / d (e, u); `post` gives
+//       d S / d y from three dual-number directions;
+//   (2) pot: v_component_adjoint, one evaluation per component -> its five parameters and the potential's share of d S / d e.  Spline
+//       potentials (31 parameters per component behind a bin search) replay the component on dual numbers instead, one parameter at a time,
+//       contracted with G;
+//   (3) pre on dual numbers for the layer's input and its rotation parameters, contracted with d S / d e.
+// Layers of a chain are walked in reverse with the (2 + 1)-component upstream gradient, after a forward sweep that records every layer's
+// input (the last layer applied is evaluated by its own backward step only).  C5's block, 2^17 rows: 0.495 ms (round 4: 15 geometry
+// directions in five 3-tangent passes + one dual replay of a component per parameter) -> 0.348 (2) -> 0.195 ms (1).
+// JF_V_BWD_DUAL=1 selects the dual-number replay of BOTH stages through v_exp_geometry / v_component themselves: the check of the hand-written
+// adjoints (scripts/probe/v_adjoint_check.py, tests/test_gpu_grad.py), not a product path.
+//
+// LV lanes per row: the components of (2), the directions of (3) -- and, in the check build, the 15 geometry directions -- are independent, so
+// LV lanes of a row can take them side by side (k = lane, lane + LV, ...) and exchange sums by lane shuffles: LV times the waves for a kernel
+// whose 2^17 rows are two waves per SIMD at one wave's worth of registers each (vector unit 38 % busy).  Measured with LV = 4 / 8 and the
+// register caps that let the extra waves be resident (256 / 168 / 128 registers): dual-number geometry 0.53 / 0.9 / 1.1 ms against 0.35 for
+// one lane per row, reverse-mode geometry 1.07 (LV 4, 256 registers) against 0.195 -- the geometry's intermediates (~100 doubles) spill to
+// scratch under every cap.  One lane per row is what is instantiated; the code is kept LV-generic (checked at 4 and 8).
 // Parameter rows are kept as PLAIN values in LDS; the potential's functions read them through SeededVals (value + a unit tangent at one index),
-// the <= 12 rotation parameters of the layer at hand are copied into a lane-private dual row.  A dual row for all parameters (round 2's first
-// version) was half of the kernel's LDS, and LDS bounds its resident waves: 1040 -> 616 bytes per lane (C5) = four workgroups per CU instead of two.
+// the <= 12 rotation parameters of the layer at hand are copied into a lane-private dual row.
 template <typename T> struct SeededVals {
     const T* p; int seed;
     __device__ __forceinline__ Dual<T> operator[](int i) const { return Dual<T>(p[i], i == seed ? T(1) : T(0)); }
 };
 constexpr int JF_V_ROT_MAX = 12;
+constexpr int JF_V_G = 16;                                           // G's slot per row (15 used)
 
-template <typename T>
-__global__ void __launch_bounds__(64) vchain_bwd_kernel(const MBwdArgs<T, jf_v_layer> a) {
+template <typename T, int LV> __device__ __forceinline__ T group_sum(T v) {         // over the LV lanes of a row
+#pragma unroll
+    for (int m = 1; m < LV; m <<= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+template <typename T, int LV> __device__ __forceinline__ T group_max(T v) {
+#pragma unroll
+    for (int m = 1; m < LV; m <<= 1) v = M<T>::max(v, __shfl_xor(v, m, 64));
+    return v;
+}
+template <typename T, int LV> __device__ __forceinline__ T rows_sum(T v) {          // over the rows of the wave, for each lane-of-row
+#pragma unroll
+    for (int m = LV; m < 64; m <<= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+
+// v_potential with the components dealt to the LV lanes of the row (g: this lane's index in its row); every lane returns the full sums
+template <typename T, int LV> __device__ inline void v_potential_lanes(const T* __restrict__ pp, int nc, int kind, const T (&x)[3], VPotential<T>& P, T& lse,
+                                                                       T* __restrict__ tab, bool& oob, int g) {
+    T lmax = T(-INFINITY);
+    for (int k = g; k < nc; k += LV) lmax = M<T>::max(lmax, pp[3 * nc + k]);
+    lmax = group_max<T, LV>(lmax);
+    T se = T(0);
+    for (int k = g; k < nc; k += LV) se += M<T>::exp(pp[3 * nc + k] - lmax);
+    lse = lmax + M<T>::log(group_sum<T, LV>(se));
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        P.g[i] = T(0);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) P.gj[i][j] = T(0);
+    }
+    for (int k = g; k < nc; k += LV) v_component<T>(pp, nc, k, kind, lse, x, P, tab, oob);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        P.g[i] = group_sum<T, LV>(P.g[i]);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) P.gj[i][j] = group_sum<T, LV>(P.gj[i][j]);
+    }
+}
+
+template <typename T, int LV, int WPE, bool DUALGEO>
+__global__ void __launch_bounds__(64, WPE) vchain_bwd_kernel(const MBwdArgs<T, jf_v_layer> a) {
     using Du = Dual<T>;
+    constexpr int NG = (15 + LV - 1) / LV;                         // geometry directions per lane
+    using DG = DualN<T, NG>;
     extern __shared__ __align__(16) unsigned char smem_raw[];
     T* tile = reinterpret_cast<T*>(smem_raw);                      // [tile_rows][tile_stride] plain parameter values
-    const int tid = threadIdx.x;
-    const int rows = a.rows;
+    const int tid = threadIdx.x, r = tid / LV, g = tid % LV;
+    const int rows = a.rows;                                       // rows of this workgroup (<= 64 / LV)
     const int tile_rows = a.bcast ? 1 : rows;
-    const bool lane_in = tid < rows;
-    const int slot = lane_in ? tid : 0;
+    const bool lane_in = r < rows;
     const int tile_elems = (tile_rows * a.tile_stride + 1) & ~1;   // the dual regions stay 16-byte aligned
     Du* dual0 = reinterpret_cast<Du*>(tile + tile_elems);
-    Du* tab = dual0 + slot * (a.tab + a.rot_max);                 // lane-private: knot table (spline potentials only), then the rotation row
+    Du* tab = dual0 + tid * (a.tab + a.rot_max);                   // lane-private: knot table (spline potentials only), then the rotation row
     Du* rot = tab + a.tab;
-    // lane-private scratch in LDS (dynamic indexing without scratch memory): every layer's input (2 per layer) and G (15)
-    T* lane_mem = reinterpret_cast<T*>(dual0 + rows * (a.tab + a.rot_max)) + slot * a.scratch;
-    T* xin = lane_mem;                                             // [layer][2]
-    T* G = lane_mem + 2 * a.n_layers;                              // [15]
+    // the row's scratch in LDS: every layer's input (2 per layer) and G (15)
+    T* row_mem = reinterpret_cast<T*>(dual0 + 64 * (a.tab + a.rot_max)) + (lane_in ? r : 0) * a.scratch;
+    T* xin = row_mem;                                              // [layer][2]
+    T* Gm = row_mem + 2 * a.n_layers;                              // [JF_V_G]
     const int64_t row0 = (int64_t)blockIdx.x * rows;
-    const int64_t row = row0 + tid;
+    const int64_t row = row0 + r;
     const bool active = lane_in && row < a.B;
     const int64_t rrow = active ? row : a.B - 1;
     if (a.bcast) {
         for (int j = tid; j < a.P; j += 64) tile[j] = a.params[j];
     } else {
-        for (int r = 0; r < rows; ++r) {
-            const int64_t gr = (row0 + r) < a.B ? (row0 + r) : a.B - 1;
-            for (int j = tid; j < a.P; j += 64) tile[r * a.tile_stride + j] = a.params[gr * a.ps + j];
+        for (int rr = 0; rr < rows; ++rr) {
+            const int64_t gr = (row0 + rr) < a.B ? (row0 + rr) : a.B - 1;
+            for (int j = tid; j < a.P; j += 64) tile[rr * a.tile_stride + j] = a.params[gr * a.ps + j];
         }
     }
     __syncthreads();
-    const T* prow = tile + (a.bcast ? 0 : slot * a.tile_stride);
+    const T* prow = tile + (a.bcast ? 0 : (lane_in ? r : 0) * a.tile_stride);
     const T gld = (a.g_ld && active) ? a.g_ld[rrow] : T(0);
     const T gblp = (a.g_blp && active) ? a.g_blp[rrow] : T(0);
+    const T gxo[2] = {(a.g_xout && active) ? a.g_xout[rrow * a.gxos + 0] : T(0), (a.g_xout && active) ? a.g_xout[rrow * a.gxos + 1] : T(0)};
     bool oob = false;
 
-    // ---- forward sweep (plain values): the input of every layer, the chain's output
-    T up[2];                                                       // d S / d (x after the layer being differentiated)
+    // ---- forward sweep (plain values): the input of every layer (the last one applied, layer 0, is evaluated by its own backward step)
     {
         T x[3] = {a.x[rrow * a.xs + 0], a.x[rrow * a.xs + 1], T(0)};
         T ld = T(0);
-        LaneCtx<T> ctx;
-        ctx.tab = reinterpret_cast<T*>(tab); ctx.corr = nullptr; ctx.bins = nullptr; ctx.bin_i = 0;
-        ctx.oob = ctx.nonconv = ctx.nonfinite = false;
-        ctx.lane_valid = active;
 #pragma unroll 1
         for (int l = a.n_layers - 1; l >= 0; --l) {
-            if (lane_in) { xin[2 * l] = x[0]; xin[2 * l + 1] = x[1]; }          // (lanes beyond `rows` share slot 0: they must not write)
-            if (lane_in) VFam::template apply<T, false>(a.L[l], prow + a.col0[l], x, ld, ctx);
+            if (lane_in && g == 0) { xin[2 * l] = x[0]; xin[2 * l + 1] = x[1]; }
+            if (l == 0) break;
+            const jf_v_layer L = a.L[l];
+            const T* pv = prow + a.col0[l];
+            T e[3];
+            VPotential<T> P;
+            ExpMapOut<T> o;
+            T lse;
+            VFam::template inv_pre<T>(L, pv, x, ld, e);
+            v_potential_lanes<T, LV>(pv + rot_len(L.hh_iter, 3), L.num_components, L.exp_map_type, e, P, lse, reinterpret_cast<T*>(tab), oob, g);
+            v_exp_geometry<T>(L.exp_map_type, e, P, o);
+            VFam::template inv_post<T>(L, o.y, x, ld);
         }
-        up[0] = ((a.g_xout && active) ? a.g_xout[rrow * a.gxos + 0] : T(0)) - x[0] * gblp;
-        up[1] = ((a.g_xout && active) ? a.g_xout[rrow * a.gxos + 1] : T(0)) - x[1] * gblp;
     }
+    __syncthreads();
 
+    T up[2] = {T(0), T(0)};                                        // d S / d (x after the layer being differentiated)
     bool bad = false;
 #pragma unroll 1
     for (int l = 0; l < a.n_layers; ++l) {                        // reverse of the order of application (layer n-1 is applied first)
+        const jf_v_layer L = a.L[l];
+        const T* pv = prow + a.col0[l];                            // this layer's plain row: rotation parameters, then the potential's
+        const int n_rot = rot_len(L.hh_iter, 3);
+        const T* ppv = pv + n_rot;
+        const int nc = L.num_components, kind = L.exp_map_type;
+        if (lane_in) for (int i = 0; i < n_rot; ++i) rot[i] = Du(pv[i]);
+        const Du* p = rot;
+        const T xl[2] = {xin[2 * l], xin[2 * l + 1]};
+        // values of the intermediates at this layer's input
+        T e0[3] = {T(0), T(0), T(0)};
+        VPotential<T> P0;
+        T lse0;
         {
-            const jf_v_layer L = a.L[l];
-            const T* pv = prow + a.col0[l];                        // this layer's plain row: rotation parameters, then the potential's
-            const int n_rot = rot_len(L.hh_iter, 3);
-            const T* ppv = pv + n_rot;
-            const int nc = L.num_components, kind = L.exp_map_type;
-            if (lane_in) for (int i = 0; i < n_rot; ++i) rot[i] = Du(pv[i]);
-            const Du* p = rot;
-            // values of the intermediates at this layer's input
-            T e0[3] = {T(0), T(0), T(0)};
-            VPotential<T> P0;
+            T x[3] = {xl[0], xl[1], T(0)};
+            T ld = T(0);
+            VFam::template inv_pre<T>(L, pv, x, ld, e0);
+            v_potential_lanes<T, LV>(ppv, nc, kind, e0, P0, lse0, reinterpret_cast<T*>(tab), oob, g);
+        }
+        // (1) d S / d (e, g, gj) through geo + post
+        T Gg[3], Gj[3][3], Ge0[3];
+        if constexpr (!DUALGEO) {
+            // reverse mode (v_geo_forward / v_geo_reverse, jf_expmap.h); the three directions of `post` on dual numbers.  Every lane of the row
+            // evaluates it (nothing to deal out)
+            VGeoTape<T> tape;
+            T y[3], ldh;
+            v_geo_forward<T>(kind, e0, P0, tape, y, ldh);
+            using D3 = DualN<T, 3>;
+            D3 yd[3] = {D3(y[0]), D3(y[1]), D3(y[2])}, xd[3], ldd(T(0));
+            yd[0].d[0] = T(1); yd[1].d[1] = T(1); yd[2].d[2] = T(1);
+            VFam::template inv_post<D3>(L, yd, xd, ldd);
+            if (l == 0) { up[0] = gxo[0] - xd[0].v * gblp; up[1] = gxo[1] - xd[1].v * gblp; }    // the chain's output: base log-prob term
+            T yb[3];
 #pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                P0.g[i] = T(0);
-#pragma unroll
-                for (int j = 0; j < 3; ++j) P0.gj[i][j] = T(0);
-            }
-            if (lane_in) {
-                T x[3] = {xin[2 * l], xin[2 * l + 1], T(0)};
-                T ld = T(0);
-                VFam::template inv_pre<T>(L, pv, x, ld, e0);
-                v_potential<T>(ppv, nc, kind, e0, P0, reinterpret_cast<T*>(tab), oob);
-            }
-            // (1) the expensive stages on the 15 directions of (e, g, gj):  G[i] = d S / d u_i, NG directions per pass (DualN: the geometry's
-            //     value part -- square roots, trigonometric functions, the 3 x 3 determinant -- once per pass)
-            constexpr int NG = 3;
-            using DG = DualN<T, NG>;
-#pragma unroll 1
-            for (int i0 = 0; i0 < 15; i0 += NG) {
-                DG e[3];
-                VPotential<DG> P;
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    e[c] = DG(e0[c]);
-                    P.g[c] = DG(P0.g[c]);
-#pragma unroll
-                    for (int d = 0; d < 3; ++d) P.gj[c][d] = DG(P0.gj[c][d]);
-                }
-#pragma unroll
-                for (int t = 0; t < NG; ++t) {
-                    const int i = i0 + t;
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        if (i == c) e[c].d[t] = T(1);
-                        if (i == 3 + c) P.g[c].d[t] = T(1);
-#pragma unroll
-                        for (int d = 0; d < 3; ++d) if (i == 6 + 3 * c + d) P.gj[c][d].d[t] = T(1);
-                    }
-                }
-                ExpMapOut<DG> o;
-                DG x[3], ld(T(0));
-                if (lane_in) {
-                    v_exp_geometry<DG>(kind, e, P, o);
-                    ld = ld + o.logdet_half;
-                    VFam::template inv_post<DG>(L, o.y, x, ld);
-                }
-#pragma unroll
-                for (int t = 0; t < NG; ++t)
-                    if (lane_in) G[i0 + t] = up[0] * x[0].d[t] + up[1] * x[1].d[t] + gld * ld.d[t];
-            }
-            // (2) the cheap stages, contracted with G.  Directions that move e (the layer's input, the rotation parameters) need the whole
-            //     potential on dual numbers; a potential parameter belongs to ONE component, whose term alone carries a tangent -- except the
-            //     log-weights, whose softmax normaliser couples all components: d w_m / d lw_k = w_m (delta_mk - s_k), i.e. the single-component
-            //     tangent (normaliser held fixed) minus s_k times the totals.
-            const int n_row = VFam_row_len_dev(L);
-            const T lse0 = lane_in ? v_lse<T>(ppv, nc) : T(0);
-            T GP0 = T(0);
+            for (int c = 0; c < 3; ++c) yb[c] = up[0] * xd[0].d[c] + up[1] * xd[1].d[c] + gld * ldd.d[c];
+            v_geo_reverse<T>(kind, e0, P0, tape, yb, gld, Ge0, Gg, Gj);
+        } else {
+            // the check of the above (JF_V_BWD_DUAL): this lane's NG of the 15 directions of (e, g, gj) on dual numbers through v_exp_geometry
+            // itself, exchanged through the row's slot in LDS
+            DG e[3];
+            VPotential<DG> P;
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                GP0 += G[3 + c] * P0.g[c];
+                e[c] = DG(e0[c]);
+                P.g[c] = DG(P0.g[c]);
 #pragma unroll
-                for (int d = 0; d < 3; ++d) GP0 += G[6 + 3 * c + d] * P0.gj[c][d];
+                for (int d = 0; d < 3; ++d) P.gj[c][d] = DG(P0.gj[c][d]);
             }
-            T nup[2] = {T(0), T(0)};
-            for (int j = 0; j < 2 + n_row; ++j) {
-                T gj_ = T(0);
-                if (j < 2 + n_rot) {
-                    if (j >= 2 && lane_in) rot[j - 2].d = T(1);    // lane-private row: no barrier
-                    Du x[3] = {Du(xin[2 * l], j == 0 ? T(1) : T(0)), Du(xin[2 * l + 1], j == 1 ? T(1) : T(0)), Du(T(0))};
-                    Du ld(T(0)), e[3];
-                    VPotential<Du> P;
-                    if (lane_in) {
-                        VFam::template inv_pre<Du>(L, p, x, ld, e);
-                        v_potential<Du>(SeededVals<T>{ppv, -1}, nc, kind, e, P, tab, oob);
-                    }
-                    gj_ = gld * ld.d;
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        gj_ += G[c] * e[c].d + G[3 + c] * P.g[c].d;
+            for (int t = 0; t < NG; ++t) {
+                const int i = g * NG + t;
 #pragma unroll
-                        for (int d = 0; d < 3; ++d) gj_ += G[6 + 3 * c + d] * P.gj[c][d].d;
-                    }
-                    if (j >= 2 && lane_in) rot[j - 2].d = T(0);
-                } else {
-                    const int jp = j - 2 - n_rot, k = jp % nc, prow_i = jp / nc;
-                    const Du e[3] = {Du(e0[0]), Du(e0[1]), Du(e0[2])};
-                    VPotential<Du> P;
+                for (int c = 0; c < 3; ++c) {
+                    if (i == c) e[c].d[t] = T(1);
+                    if (i == 3 + c) P.g[c].d[t] = T(1);
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        P.g[c] = Du(T(0));
-#pragma unroll
-                        for (int d = 0; d < 3; ++d) P.gj[c][d] = Du(T(0));
-                    }
-                    if (lane_in) v_component<Du>(SeededVals<T>{ppv, jp}, nc, k, kind, Du(lse0), e, P, tab, oob);
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        gj_ += G[3 + c] * P.g[c].d;
-#pragma unroll
-                        for (int d = 0; d < 3; ++d) gj_ += G[6 + 3 * c + d] * P.gj[c][d].d;
-                    }
-                    if (prow_i == 3 && lane_in) gj_ -= M<T>::exp(ppv[3 * nc + k] - lse0) * GP0;        // softmax coupling of the log-weights
-                }
-                if (!active) gj_ = T(0);
-                bad = bad || !M<T>::finite(gj_);
-                if (j < 2) {
-                    nup[j] = gj_;
-                } else if (a.bcast) {
-                    const T s = wave_sum<T>(gj_);
-                    if (tid == 0) atomicAdd(a.g_params + a.col0[l] + (j - 2), s);
-                } else if (active) {
-                    a.g_params[row * a.gps + a.col0[l] + (j - 2)] = gj_;
+                    for (int d = 0; d < 3; ++d) if (i == 6 + 3 * c + d) P.gj[c][d].d[t] = T(1);
                 }
             }
-            up[0] = nup[0]; up[1] = nup[1];
+            ExpMapOut<DG> o;
+            DG x[3], ld(T(0));
+            v_exp_geometry<DG>(kind, e, P, o);
+            ld = ld + o.logdet_half;
+            VFam::template inv_post<DG>(L, o.y, x, ld);
+            if (l == 0) { up[0] = gxo[0] - x[0].v * gblp; up[1] = gxo[1] - x[1].v * gblp; }
+#pragma unroll
+            for (int t = 0; t < NG; ++t)
+                if (lane_in && g * NG + t < 15) Gm[g * NG + t] = up[0] * x[0].d[t] + up[1] * x[1].d[t] + gld * ld.d[t];
+            __syncthreads();
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                Ge0[c] = Gm[c];
+                Gg[c] = Gm[3 + c];
+#pragma unroll
+                for (int d = 0; d < 3; ++d) Gj[c][d] = Gm[6 + 3 * c + d];
+            }
+            __syncthreads();                                       // (Gm is rewritten by the next layer)
         }
+        T Ge[3] = {T(0), T(0), T(0)};
+        T GP0 = T(0);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            GP0 += Gg[c] * P0.g[c];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) GP0 += Gj[c][d] * P0.gj[c][d];
+        }
+        const int n_row = VFam_row_len_dev(L);
+        const bool closed = kind != JF_V_SPLINES && !a.v_dual;
+        // (2) the potential's parameters
+        if (closed) {
+            const int n_prow = kind == JF_V_EXPONENTIAL ? 5 : 4;
+#pragma unroll 1
+            for (int k0 = 0; k0 < nc; k0 += LV) {
+                const int k = k0 + g;
+                T gp[5] = {T(0), T(0), T(0), T(0), T(0)};
+                if (k < nc) {
+                    T gm[3];
+                    v_component_adjoint<T>(ppv, nc, k, kind, lse0, e0, Gg, Gj, Ge, gm, gp[3], gp[4]);
+                    gp[0] = gm[0]; gp[1] = gm[1]; gp[2] = gm[2];
+                    gp[3] -= M<T>::exp(ppv[3 * nc + k] - lse0) * GP0;                           // softmax coupling of the log-weights
+                }
+#pragma unroll
+                for (int q = 0; q < 5; ++q) {
+                    if (q >= n_prow) break;
+                    const T v = (active && k < nc) ? gp[q] : T(0);
+                    bad = bad || !M<T>::finite(v);
+                    const int col = a.col0[l] + n_rot + q * nc + k;
+                    if (a.bcast) {
+                        const T s = rows_sum<T, LV>(v);
+                        if (tid < LV && k < nc) atomicAdd(a.g_params + col, s);
+                    } else if (active && k < nc) {
+                        a.g_params[row * a.gps + col] = v;
+                    }
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) Ge[c] = Ge0[c] + group_sum<T, LV>(Ge[c]);
+        }
+        // (3) the layer's input and rotation parameters (closed-form potentials); every direction on dual numbers through pre + pot otherwise.
+        //     A potential parameter belongs to ONE component, whose term alone carries a tangent -- except the log-weights, whose softmax
+        //     normaliser couples all components: d w_m / d lw_k = w_m (delta_mk - s_k), i.e. the single-component tangent (normaliser held
+        //     fixed) minus s_k times the totals.
+        T nup[2] = {T(0), T(0)};
+        const int n_dir = closed ? 2 + n_rot : 2 + n_row;
+#pragma unroll 1
+        for (int j0 = 0; j0 < n_dir; j0 += LV) {
+            const int j = j0 + g;
+            const bool jin = j < n_dir;
+            T gj_ = T(0);
+            if (jin && j < 2 + n_rot) {
+                if (j >= 2 && lane_in) rot[j - 2].d = T(1);        // lane-private row: no barrier
+                Du x[3] = {Du(xl[0], j == 0 ? T(1) : T(0)), Du(xl[1], j == 1 ? T(1) : T(0)), Du(T(0))};
+                Du ld(T(0)), e[3];
+                VFam::template inv_pre<Du>(L, p, x, ld, e);
+                gj_ = gld * ld.d;
+                if (closed) {
+                    gj_ += Ge[0] * e[0].d + Ge[1] * e[1].d + Ge[2] * e[2].d;
+                } else {
+                    VPotential<Du> P;
+                    v_potential<Du>(SeededVals<T>{ppv, -1}, nc, kind, e, P, tab, oob);
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        gj_ += Ge0[c] * e[c].d + Gg[c] * P.g[c].d;
+#pragma unroll
+                        for (int d = 0; d < 3; ++d) gj_ += Gj[c][d] * P.gj[c][d].d;
+                    }
+                }
+                if (j >= 2 && lane_in) rot[j - 2].d = T(0);
+            } else if (jin) {
+                const int jp = j - 2 - n_rot, k = jp % nc, prow_i = jp / nc;
+                const Du e[3] = {Du(e0[0]), Du(e0[1]), Du(e0[2])};
+                VPotential<Du> P;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    P.g[c] = Du(T(0));
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) P.gj[c][d] = Du(T(0));
+                }
+                v_component<Du>(SeededVals<T>{ppv, jp}, nc, k, kind, Du(lse0), e, P, tab, oob);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    gj_ += Gg[c] * P.g[c].d;
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) gj_ += Gj[c][d] * P.gj[c][d].d;
+                }
+                if (prow_i == 3) gj_ -= M<T>::exp(ppv[3 * nc + k] - lse0) * GP0;                 // softmax coupling of the log-weights
+            }
+            if (!active || !jin) gj_ = T(0);
+            bad = bad || !M<T>::finite(gj_);
+#pragma unroll
+            for (int t = 0; t < 2; ++t)                            // the layer's input: to every lane of the row
+                if (j0 <= t && t < j0 + LV) nup[t] = __shfl(gj_, (tid & ~(LV - 1)) + (t - j0), 64);
+            if (a.bcast) {
+                const T s = rows_sum<T, LV>(gj_);
+                if (tid < LV && jin && j >= 2) atomicAdd(a.g_params + a.col0[l] + (j - 2), s);
+            } else if (active && jin && j >= 2) {
+                a.g_params[row * a.gps + a.col0[l] + (j - 2)] = gj_;
+            }
+        }
+        up[0] = nup[0]; up[1] = nup[1];
     }
-    if (active) { a.g_x[row * a.gxs + 0] = up[0]; a.g_x[row * a.gxs + 1] = up[1]; }
+    if (active && g == 0) { a.g_x[row * a.gxs + 0] = up[0]; a.g_x[row * a.gxs + 1] = up[1]; }
     status_add(a.status, JF_STATUS_NONFINITE, active && bad);
 }
 
@@ -383,18 +502,21 @@ static int mchain_bwd(const T* x, int64_t xs, const T* params, int64_t ps, int32
         }
     }
     bool staged = false;
-    if constexpr (std::is_same<Fam, VFam>::value) {               // all layers in the default direction: the staged kernel (15 + cheap passes)
+    constexpr int lv = 1;                                          // staged 'v' kernel: lanes per row (the kernel is written for 1, 4, 8; see its header)
+    if constexpr (std::is_same<Fam, VFam>::value) {               // all layers in the default direction: the staged kernel
         staged = true;
         for (int l = 0; l < n_layers; ++l) staged = staged && layers[l].natural_direction == 0 && rot_len(layers[l].hh_iter, 3) <= JF_V_ROT_MAX;
         if (staged) {
-            a.scratch = (2 * n_layers + 15 + 1) & ~1;              // lane-private values (T units in the staged kernel): layer inputs, G
+            static const int v_dual = getenv("JF_V_BWD_DUAL") ? atoi(getenv("JF_V_BWD_DUAL")) : 0;
+            a.v_dual = v_dual;
+            a.scratch = (2 * n_layers + JF_V_G + 1) & ~1;          // per ROW (T units): layer inputs, G
             a.rot_max = 0;
             for (int l = 0; l < n_layers; ++l) a.rot_max = rot_len(layers[l].hh_iter, 3) > a.rot_max ? rot_len(layers[l].hh_iter, 3) : a.rot_max;
         }
     }
     a.tab = 0;
     for (int l = 0; l < n_layers; ++l) if (Fam::needs_tab(layers[l])) a.tab = JF_SPLINE_TAB;
-    a.rows = 64;
+    a.rows = 64 / lv;
     size_t lds = 0;
     // generic kernel: four directions per pass when a full wave of rows still fits the LDS with the wider dual rows, else one
     constexpr int NW = std::is_same<Fam, FFam>::value && sizeof(T) == 4 ? 6 : 4;    // 'f' float32 (2 + 10 directions by default): two passes
@@ -405,9 +527,9 @@ static int mchain_bwd(const T* x, int64_t xs, const T* params, int64_t ps, int32
     }
     for (;;) {
         if (wide) { lds = ((size_t)(a.bcast ? 1 : a.rows) * a.tile_stride + (size_t)a.rows * (a.tab + a.scratch)) * sizeof(DualN<T, NW>); break; }
-        if (staged) {                                              // plain-value parameter tile + per lane: knot table, rotation row (duals), scratch (values)
+        if (staged) {                                              // plain-value parameter tile + per lane: knot table, rotation row (duals) + per row: scratch (values)
             const size_t tile_elems = (((size_t)(a.bcast ? 1 : a.rows) * a.tile_stride) + 1) & ~(size_t)1;
-            lds = tile_elems * sizeof(T) + (size_t)a.rows * ((size_t)(a.tab + a.rot_max) * sizeof(Dual<T>) + (size_t)a.scratch * sizeof(T));
+            lds = tile_elems * sizeof(T) + (size_t)64 * (size_t)(a.tab + a.rot_max) * sizeof(Dual<T>) + (size_t)a.rows * (size_t)a.scratch * sizeof(T);
         } else
         lds = ((size_t)(a.bcast ? 1 : a.rows) * a.tile_stride + (size_t)a.rows * (a.tab + a.scratch)) * sizeof(DualN<T, 1>);
         if (lds <= 160 * 1024 || a.rows == 4) break;
@@ -416,7 +538,7 @@ static int mchain_bwd(const T* x, int64_t xs, const T* params, int64_t ps, int32
     if (lds > 160 * 1024) return JF_ERR_UNSUPPORTED;
     if constexpr (std::is_same<Fam, VFam>::value) {
         if (staged) {
-            auto kv = vchain_bwd_kernel<T>;
+            auto kv = a.v_dual ? vchain_bwd_kernel<T, 1, 1, true> : vchain_bwd_kernel<T, 1, 1, false>;
             if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)kv, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             jf::launch(kv, dim3((unsigned)((B + a.rows - 1) / a.rows)), dim3(64), lds, (hipStream_t)stream, a);
             return check_launch();
