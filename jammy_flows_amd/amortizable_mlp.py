@@ -105,6 +105,7 @@ class AmortizableMLP(nn.Module):
         self.num_amortization_params = sum(n for _, n, _ in self.sub_mlps) + (self.linear[1] if self.linear is not None else 0)
         self.stages = self.sub_mlps[0][0] if (highway_mode == 0) else None        # plain-MLP view used by the fused low-rank block
         self._cast_cache = None
+        self._cut_points = None
         if use_permanent_parameters:
             self.u_v_b_pars = nn.Parameter(torch.randn(self.num_amortization_params).type(torch.double).unsqueeze(0))
             self.initialize_uvbs()
@@ -157,6 +158,7 @@ class AmortizableMLP(nn.Module):
         self.num_amortization_params = sum(n for _, n, _ in self.sub_mlps) + (self.linear[1] if self.linear is not None else 0)
         self.stages = self.sub_mlps[0][0] if (self.highway_mode == 0 and self.sub_mlps) else None
         self._cast_cache = None
+        self._cut_points = None
         if self.use_permanent_parameters:
             self.u_v_b_pars = nn.Parameter(torch.randn(self.num_amortization_params).type(torch.double).unsqueeze(0))
             self.initialize_uvbs()
@@ -200,6 +202,31 @@ class AmortizableMLP(nn.Module):
             with torch.no_grad():
                 self._cast_cache = (key, p.detach().to(device=like.device, dtype=like.dtype).reshape(-1).contiguous())
         return self._cast_cache[1]
+
+    def _cuts(self):
+        """boundaries of every u / v / b block of the parameter vector (the slices the stages take), sorted"""
+        if self._cut_points is None:
+            cuts = {0, self.num_amortization_params}
+
+            def add(stages, o):
+                for st in stages:
+                    cuts.update((o, o + st["num_u"], o + st["num_u"] + st["num_v"], o + st["num_u"] + st["num_v"] + st["num_b"]))
+                    o += st["num_u"] + st["num_v"] + st["num_b"]
+            if self.linear is not None:
+                add(self.linear[0], self.num_amortization_params - self.linear[1])
+            o = 0
+            for stages, n, kind in self.sub_mlps:
+                add(stages, o)
+                o += n
+            self._cut_points = sorted(c for c in cuts if 0 <= c <= self.num_amortization_params)
+        return self._cut_points
+
+    def _grad_flat(self, like):
+        """the permanent parameter vector inside the autograd graph, pre-cut at every block boundary (autograd.FlatPieces)"""
+        flat = self.u_v_b_pars.to(dtype=like.dtype).reshape(-1)
+        if flat.requires_grad and torch.is_grad_enabled():
+            return autograd.FlatPieces(flat, self._cuts())
+        return flat
 
     def lowrank_views(self, flat):
         """(v1, u1, b1, v2, u2, b2) views into the flat vector when this is a plain two-stage MLP whose last stage is low-rank and whose sizes
@@ -265,7 +292,7 @@ class AmortizableMLP(nn.Module):
         if last["full"] or last["num_b"] == 0 or last["act"]:
             return None
         _hip.require_device(i)
-        flat = self.u_v_b_pars.to(dtype=i.dtype).reshape(-1)
+        flat = self._grad_flat(i)
         views = self.lowrank_views(flat) if self.head_one_launch else None
         if views is not None and _hip.lowrank_head_ok(i, *views[:4]):          # the whole head in one launch (csrc/jf_lowrank_mlp.h)
             v1, u1, b1, v2, u2, b2 = views
@@ -289,7 +316,7 @@ class AmortizableMLP(nn.Module):
         else:
             assert self.use_permanent_parameters
             grad = autograd._needs_grad(i, self.u_v_b_pars)
-            flat = self.u_v_b_pars.to(dtype=i.dtype).reshape(-1) if grad else self._flat(i)
+            flat = self._grad_flat(i) if grad else self._flat(i)
             views = self.lowrank_views(flat) if (not grad or self.head_one_launch) else None
             if views is not None and not grad:             # hidden-128 / rank-r MLP of the reference's custom mode: ONE launch (jf_amlp2)
                 return _hip.amlp2(i, *views)

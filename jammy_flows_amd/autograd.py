@@ -167,6 +167,48 @@ class InverseJacobianFn(torch.autograd.Function):
         return lam, None, None
 
 
+class _SplitFlatFn(torch.autograd.Function):
+    """a flat parameter vector cut into consecutive pieces in ONE graph node.  Slicing the vector piece by piece (`flat[a:b]` per weight
+    matrix, as the AmortizableMLP stages do) costs the backward pass a zero-filled copy of the whole vector per piece plus the additions
+    that accumulate them: 30 launches of ~5 us per C5 training step for the two low-rank MLPs (rocprofv3, round 5).  Here the backward is one
+    concatenation."""
+
+    @staticmethod
+    def forward(ctx, flat, sizes):
+        ctx.sizes = sizes
+        ctx.set_materialize_grads(False)
+        return tuple(flat.detach().split(sizes))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        like = next((g for g in gs if g is not None), None)
+        if like is None:
+            return None, None
+        return torch.cat([g.reshape(-1) if g is not None else like.new_zeros(n) for g, n in zip(gs, ctx.sizes)]), None
+
+
+class FlatPieces:
+    """`flat[a:b]` for the (a, b) of a fixed list of cut points, served from one _SplitFlatFn node; any other slice falls back to slicing the
+    vector itself (correct, just the slow pattern above)."""
+
+    def __init__(self, flat, cuts):
+        self.flat = flat
+        sizes = [b - a for a, b in zip(cuts[:-1], cuts[1:])]
+        self._pieces = _SplitFlatFn.apply(flat, sizes)
+        self._index = {(a, b): k for k, (a, b) in enumerate(zip(cuts[:-1], cuts[1:]))}
+        self.dtype, self.device = flat.dtype, flat.device
+
+    def element_size(self):
+        return self.flat.element_size()
+
+    def __getitem__(self, sl):
+        if isinstance(sl, slice) and sl.step is None:
+            k = self._index.get((sl.start or 0, sl.stop))
+            if k is not None:
+                return self._pieces[k]
+        return self.flat[sl]
+
+
 class LowRankHeadFn(torch.autograd.Function):
     """t2 = V2 tanh(U1 (V1 c) + b1): the two-stage low-rank AmortizableMLP up to the input of its last U product (float64), forward and backward
     one launch each (csrc/jf_lowrank_mlp.h) instead of three dense launches forward and eight dense / elementwise launches backward."""

@@ -346,3 +346,24 @@ def test_kernel_caps_raise_loudly_without_a_gpu():
         jf.pdf("s2", "f", options_overwrite={"f": {"add_vertical_rq_spline_flow": 1, "vertical_flow_defs": "rrrrr"}})
     with pytest.raises(NotImplementedError, match="16 bins|at most 16"):
         jf.pdf("e2", "g", options_overwrite={"g": {"nonlinear_stretch_type": "rq_splines", "num_kde": 17}})
+
+
+def test_flat_pieces_gradient_equals_slicing():
+    """autograd.FlatPieces (one graph node for all u / v / b blocks of an AmortizableMLP's parameter vector) gives the gradient of plain
+    slicing, including pieces nobody used and a slice off the cut points"""
+    from jammy_flows_amd import autograd as jfa
+    torch.manual_seed(0)
+    cuts = [0, 6, 6 + 8, 17, 30]
+    w = [torch.randn(b - a, dtype=torch.float64) for a, b in zip(cuts[:-1], cuts[1:])]
+
+    def loss(get):
+        return (get(0, 6).view(2, 3) * w[0].view(2, 3)).sum() + (get(6, 14) ** 2 * w[1]).sum() + (get(17, 30) * w[3]).sum() + 3.0 * get(2, 9).sum()
+
+    with torch.enable_grad():
+        p1 = torch.randn(30, dtype=torch.float64, requires_grad=True)
+        p2 = p1.detach().clone().requires_grad_(True)
+        fp = jfa.FlatPieces(p1, cuts)
+        loss(lambda a, b: fp[a:b]).backward()
+        loss(lambda a, b: p2[a:b]).backward()
+    assert torch.equal(p1.grad, p2.grad)
+    assert float(p1.grad[14:17].abs().max()) == 0.0
