@@ -79,34 +79,60 @@ template <typename T, typename ROW> __device__ inline void v_component(ROW pp, i
     }
 }
 
-// Reverse mode of v_component for the closed-form potentials (exponential / linear / quadratic): given the upstream gradients of the summed
-// outputs, Gg = dS / d g (3) and Gj = dS / d gj (3 x 3), this component's share of dS / d x is ADDED to gx and the gradients of its own
-// parameters are returned -- gm: the three rows of its direction, glw: its log-weight with the normaliser lse HELD FIXED (the caller adds the
-// softmax coupling, - softmax_k * sum_m glw_m), glb: its log-beta (exponential potential only, else 0).  Written out by hand from the
-// expressions of v_component above; the dual-number replay of the same function (manifold_bwd_kernels.hip, spline potentials) is its check.
-template <typename T> __device__ inline void v_component_adjoint(const T* __restrict__ pp, int nc, int k, int kind, T lse, const T (&x)[3],
-                                                                 const T (&Gg)[3], const T (&Gj)[3][3], T (&gx)[3], T (&gm)[3], T& glw, T& glb) {
+// ---- closed-form potentials (exponential / linear / quadratic) for the backward kernel (manifold_bwd_kernels.hip): component k in two halves.
+// v_component_vals: everything of the component that costs a transcendental function or a division -- its weight w (and d w / d |m|), its
+// inverse norm, beta = exp(log beta), f -- five numbers (the potential's kind is a template parameter: the kernel evaluates two components side by side, and a branch inside would split the block the scheduler interleaves them in);
+// v_component_add: the component's term of (grad phi, its Jacobian) from them, as v_component computes it (w = exp(lw - lse) v_mu_norm(|m|)
+// without the round trip through log: gradients only, last-bit differences from the log-prob kernels are immaterial);
+// v_component_adjoint: reverse mode of that term, written out by hand -- given Gg = dS / d g (3) and Gj = dS / d gj (3 x 3), this component's
+// share of dS / d x is ADDED to gx and the gradients of its own parameters are returned -- gm: the three rows of its direction, glw: its
+// log-weight with the normaliser lse HELD FIXED (the caller adds the softmax coupling, - softmax_k * sum_m glw_m), glb: its log-beta
+// (exponential potential only, else 0).  The dual-number replay of v_component (JF_V_BWD_DUAL, spline potentials) is the check.
+template <typename T> struct VCompVals { T w, dwdn, f, beta, inv_nrm; };
+
+template <typename T, int kind> __device__ __forceinline__ VCompVals<T> v_component_vals(const T* __restrict__ pp, int nc, int k, T lse, const T (&x)[3]) {
     const int w_row = 3, b_row = 4;
+    VCompVals<T> v;
     const T m[3] = {pp[k], pp[nc + k], pp[2 * nc + k]};
     const T nrm = M<T>::sqrt(m[0] * m[0] + m[1] * m[1] + m[2] * m[2]);
-    const T inv_nrm = T(1) / nrm;
-    const T mu[3] = {m[0] * inv_nrm, m[1] * inv_nrm, m[2] * inv_nrm};
+    v.inv_nrm = T(1) / nrm;
     // v_mu_norm and its derivative: vn = 1 - log(1 + c E), E = exp(-n / 10)  ->  vn' = (c E / 10) / (1 + c E)
-    const T cE = T(1.718281828459045) * M<T>::exp(-nrm / T(10));
+    const T cE = T(1.718281828459045) * M<T>::exp(nrm * T(-0.1));
     const T vn = T(1) - M<T>::log(T(1) + cE);
-    const T dvn = (cE / T(10)) / (T(1) + cE);
-    const T w = M<T>::exp(pp[w_row * nc + k] - lse) * vn;
-    const T xmu = x[0] * mu[0] + x[1] * mu[1] + x[2] * mu[2];
-    T f, fp, beta = T(0);
+    const T ew = M<T>::exp(pp[w_row * nc + k] - lse);
+    v.w = ew * vn;
+    v.dwdn = ew * (cE * T(0.1)) / (T(1) + cE);
+    const T xmu = (x[0] * m[0] + x[1] * m[1] + x[2] * m[2]) * v.inv_nrm;
     if (kind == JF_V_EXPONENTIAL) {
-        beta = M<T>::exp(pp[b_row * nc + k]);
-        f = M<T>::exp(beta * (xmu - T(1)));
-        fp = beta * f;
-    } else if (kind == JF_V_LINEAR) {
-        f = T(1); fp = T(0);
+        v.beta = M<T>::exp(pp[b_row * nc + k]);
+        v.f = M<T>::exp(v.beta * (xmu - T(1)));
     } else {
-        f = xmu; fp = T(1);
+        v.beta = T(0);
+        v.f = kind == JF_V_LINEAR ? T(1) : xmu;
     }
+    return v;
+}
+
+template <typename T, int kind> __device__ __forceinline__ T v_component_fp(const VCompVals<T>& v) {
+    return kind == JF_V_EXPONENTIAL ? v.beta * v.f : (kind == JF_V_LINEAR ? T(0) : T(1));
+}
+
+template <typename T, int kind> __device__ __forceinline__ void v_component_add(const T* __restrict__ pp, int nc, int k, const VCompVals<T>& v, VPotential<T>& P) {
+    const T mu[3] = {pp[k] * v.inv_nrm, pp[nc + k] * v.inv_nrm, pp[2 * nc + k] * v.inv_nrm};
+    const T wf = v.w * v.f, wfp = v.w * v_component_fp<T, kind>(v);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        P.g[i] += wf * mu[i];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) P.gj[i][j] += wfp * mu[i] * mu[j];
+    }
+}
+
+template <typename T, int kind> __device__ __forceinline__ void v_component_adjoint(const T* __restrict__ pp, int nc, int k, const VCompVals<T>& v, const T (&x)[3],
+                                                                 const T (&Gg)[3], const T (&Gj)[3][3], T (&gx)[3], T (&gm)[3], T& glw, T& glb) {
+    const T mu[3] = {pp[k] * v.inv_nrm, pp[nc + k] * v.inv_nrm, pp[2 * nc + k] * v.inv_nrm};
+    const T xmu = x[0] * mu[0] + x[1] * mu[1] + x[2] * mu[2];
+    const T w = v.w, f = v.f, beta = v.beta, fp = v_component_fp<T, kind>(v);
     // S_k = w (f A + fp Q),  A = Gg . mu,  Q = mu^T Gj mu;  h = (Gj + Gj^T) mu = dQ / d mu
     T h[3];
 #pragma unroll
@@ -129,11 +155,11 @@ template <typename T> __device__ inline void v_component_adjoint(const T* __rest
         dmu[i] = w * (f * Gg[i] + fp * h[i]) + dS_dxmu * x[i];
         gx[i] += dS_dxmu * mu[i];
     }
-    // mu = m / |m|: d mu_i / d m_j = (delta_ij - mu_i mu_j) / |m|;  w depends on |m| through vn
+    // mu = m / |m|: d mu_i / d m_j = (delta_ij - mu_i mu_j) / |m|;  w depends on |m| through v_mu_norm
     const T radial = dmu[0] * mu[0] + dmu[1] * mu[1] + dmu[2] * mu[2];
-    const T dS_dnrm = dS_dw * (w / vn) * dvn;
+    const T dS_dnrm = dS_dw * v.dwdn;
 #pragma unroll
-    for (int i = 0; i < 3; ++i) gm[i] = (dmu[i] - mu[i] * radial) * inv_nrm + dS_dnrm * mu[i];
+    for (int i = 0; i < 3; ++i) gm[i] = (dmu[i] - mu[i] * radial) * v.inv_nrm + dS_dnrm * mu[i];
     glw = dS_dw * w;
     glb = dS_dbeta * beta;
 }

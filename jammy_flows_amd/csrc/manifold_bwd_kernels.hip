@@ -70,9 +70,23 @@ __global__ void __launch_bounds__(64) mchain_bwd_kernel(const MBwdArgs<T, typena
     if (a.bcast) {
         for (int j = tid; j < a.P; j += 64) tile[j] = Du(a.params[j]);
     } else {
-        for (int r = 0; r < rows; ++r) {
-            const int64_t gr = (row0 + r) < a.B ? (row0 + r) : a.B - 1;
-            for (int j = tid; j < a.P; j += 64) tile[r * a.tile_stride + j] = Du(a.params[gr * a.ps + j]);
+        // eight loads in flight per lane (a row at a time is one dependent load after the other: 64 x ~1 us)
+        const int total = rows * a.P;
+        for (int i0 = 0; i0 < total; i0 += 64 * 8) {
+            T v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + u * 64 + tid;
+                const int rr = i / a.P, j = i - rr * a.P;
+                const int64_t gr = (row0 + rr) < a.B ? (row0 + rr) : a.B - 1;
+                v[u] = i < total ? a.params[gr * a.ps + j] : T(0);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + u * 64 + tid;
+                const int rr = i / a.P, j = i - rr * a.P;
+                if (i < total) tile[rr * a.tile_stride + j] = Du(v[u]);
+            }
         }
     }
     __syncthreads();
@@ -199,15 +213,20 @@ template <typename T, int LV> __device__ __forceinline__ T rows_sum(T v) {      
     return v;
 }
 
-// v_potential with the components dealt to the LV lanes of the row (g: this lane's index in its row); every lane returns the full sums
-template <typename T, int LV> __device__ inline void v_potential_lanes(const T* __restrict__ pp, int nc, int kind, const T (&x)[3], VPotential<T>& P, T& lse,
-                                                                       T* __restrict__ tab, bool& oob, int g) {
+// log-sum-exp of the components' log-weights, the components dealt to the LV lanes of the row
+template <typename T, int LV> __device__ inline T v_lse_lanes(const T* __restrict__ pp, int nc, int g) {
     T lmax = T(-INFINITY);
     for (int k = g; k < nc; k += LV) lmax = M<T>::max(lmax, pp[3 * nc + k]);
     lmax = group_max<T, LV>(lmax);
     T se = T(0);
     for (int k = g; k < nc; k += LV) se += M<T>::exp(pp[3 * nc + k] - lmax);
-    lse = lmax + M<T>::log(group_sum<T, LV>(se));
+    return lmax + M<T>::log(group_sum<T, LV>(se));
+}
+
+// v_potential with the components dealt to the LV lanes of the row (g: this lane's index in its row); every lane returns the full sums
+template <typename T, int LV> __device__ inline void v_potential_lanes(const T* __restrict__ pp, int nc, int kind, const T (&x)[3], VPotential<T>& P, T& lse,
+                                                                       T* __restrict__ tab, bool& oob, int g) {
+    lse = v_lse_lanes<T, LV>(pp, nc, g);
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         P.g[i] = T(0);
@@ -220,6 +239,73 @@ template <typename T, int LV> __device__ inline void v_potential_lanes(const T* 
         P.g[i] = group_sum<T, LV>(P.g[i]);
 #pragma unroll
         for (int j = 0; j < 3; ++j) P.gj[i][j] = group_sum<T, LV>(P.gj[i][j]);
+    }
+}
+
+// closed-form potentials: the sums over this lane's components, TWO components per trip -- their chains of transcendental functions are
+// independent, and a kernel that runs one wave per SIMD has nothing else to cover their latency with (KIND as a template parameter keeps the
+// pair in one basic block for the scheduler)
+template <typename T, int LV, int KIND>
+__device__ inline void v_closed_potential(const T* __restrict__ ppv, int nc, T lse, const T (&e)[3], VPotential<T>& P, int g) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        P.g[i] = T(0);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) P.gj[i][j] = T(0);
+    }
+    int k = g;
+#pragma unroll 1
+    for (; k + LV < nc; k += 2 * LV) {
+        const VCompVals<T> v0 = v_component_vals<T, KIND>(ppv, nc, k, lse, e), v1 = v_component_vals<T, KIND>(ppv, nc, k + LV, lse, e);
+        v_component_add<T, KIND>(ppv, nc, k, v0, P);
+        v_component_add<T, KIND>(ppv, nc, k + LV, v1, P);
+    }
+    if (k < nc) v_component_add<T, KIND>(ppv, nc, k, v_component_vals<T, KIND>(ppv, nc, k, lse, e), P);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        P.g[i] = group_sum<T, LV>(P.g[i]);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) P.gj[i][j] = group_sum<T, LV>(P.gj[i][j]);
+    }
+}
+
+// ... and their reverse pass: the gradients of every component's parameters go to g_params (per-sample rows: stored; permanent parameters:
+// summed over the wave's rows, one atomic add per parameter), the potential's share of d S / d e is added to Ge (this lane's components only)
+template <typename T, int LV, int KIND>
+__device__ inline void v_closed_adjoint(const MBwdArgs<T, jf_v_layer>& a, const T* __restrict__ ppv, int nc, T lse, const T (&e)[3], const T (&Gg)[3],
+                                        const T (&Gj)[3][3], T GP0, T (&Ge)[3], int g, int tid, bool active, int64_t row, int col0, bool& bad) {
+    constexpr int n_prow = KIND == JF_V_EXPONENTIAL ? 5 : 4;
+#pragma unroll 1
+    for (int k0 = 0; k0 < nc; k0 += 2 * LV) {
+        const int kk[2] = {k0 + g, k0 + LV + g};
+        T gp[2][5];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int k = kk[u] < nc ? kk[u] : nc - 1;           // (a lane without a component in this trip repeats the last one; its results are dropped)
+            const VCompVals<T> v = v_component_vals<T, KIND>(ppv, nc, k, lse, e);
+            T gm[3], gx[3] = {T(0), T(0), T(0)};
+            v_component_adjoint<T, KIND>(ppv, nc, k, v, e, Gg, Gj, gx, gm, gp[u][3], gp[u][4]);
+            gp[u][0] = gm[0]; gp[u][1] = gm[1]; gp[u][2] = gm[2];
+            gp[u][3] -= M<T>::exp(ppv[3 * nc + k] - lse) * GP0;                                 // softmax coupling of the log-weights
+            if (kk[u] < nc) { Ge[0] += gx[0]; Ge[1] += gx[1]; Ge[2] += gx[2]; }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int k = kk[u];
+            if (k0 + u * LV >= nc) break;                          // (uniform)
+#pragma unroll
+            for (int q = 0; q < n_prow; ++q) {
+                const T v = (active && k < nc) ? gp[u][q] : T(0);
+                bad = bad || !M<T>::finite(v);
+                const int col = col0 + q * nc + k;
+                if (a.bcast) {
+                    const T s = rows_sum<T, LV>(v);
+                    if (tid < LV && k < nc) atomicAdd(a.g_params + col, s);
+                } else if (active && k < nc) {
+                    a.g_params[row * a.gps + col] = v;
+                }
+            }
+        }
     }
 }
 
@@ -249,9 +335,23 @@ __global__ void __launch_bounds__(64, WPE) vchain_bwd_kernel(const MBwdArgs<T, j
     if (a.bcast) {
         for (int j = tid; j < a.P; j += 64) tile[j] = a.params[j];
     } else {
-        for (int rr = 0; rr < rows; ++rr) {
-            const int64_t gr = (row0 + rr) < a.B ? (row0 + rr) : a.B - 1;
-            for (int j = tid; j < a.P; j += 64) tile[rr * a.tile_stride + j] = a.params[gr * a.ps + j];
+        // the rows' parameters, eight loads in flight per lane (a row at a time is one dependent load after the other: 64 x ~1 us)
+        const int total = rows * a.P;
+        for (int i0 = 0; i0 < total; i0 += 64 * 8) {
+            T v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + u * 64 + tid;
+                const int rr = i / a.P, j = i - rr * a.P;
+                const int64_t gr = (row0 + rr) < a.B ? (row0 + rr) : a.B - 1;
+                v[u] = i < total ? a.params[gr * a.ps + j] : T(0);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + u * 64 + tid;
+                const int rr = i / a.P, j = i - rr * a.P;
+                if (i < total) tile[rr * a.tile_stride + j] = v[u];
+            }
         }
     }
     __syncthreads();
@@ -303,6 +403,14 @@ __global__ void __launch_bounds__(64, WPE) vchain_bwd_kernel(const MBwdArgs<T, j
             T x[3] = {xl[0], xl[1], T(0)};
             T ld = T(0);
             VFam::template inv_pre<T>(L, pv, x, ld, e0);
+        }
+        const bool closed = kind != JF_V_SPLINES && !a.v_dual;
+        if (closed) {
+            lse0 = v_lse_lanes<T, LV>(ppv, nc, g);
+            if (kind == JF_V_EXPONENTIAL) v_closed_potential<T, LV, JF_V_EXPONENTIAL>(ppv, nc, lse0, e0, P0, g);
+            else if (kind == JF_V_LINEAR) v_closed_potential<T, LV, JF_V_LINEAR>(ppv, nc, lse0, e0, P0, g);
+            else v_closed_potential<T, LV, JF_V_QUADRATIC>(ppv, nc, lse0, e0, P0, g);
+        } else {
             v_potential_lanes<T, LV>(ppv, nc, kind, e0, P0, lse0, reinterpret_cast<T*>(tab), oob, g);
         }
         // (1) d S / d (e, g, gj) through geo + post
@@ -373,34 +481,12 @@ __global__ void __launch_bounds__(64, WPE) vchain_bwd_kernel(const MBwdArgs<T, j
             for (int d = 0; d < 3; ++d) GP0 += Gj[c][d] * P0.gj[c][d];
         }
         const int n_row = VFam_row_len_dev(L);
-        const bool closed = kind != JF_V_SPLINES && !a.v_dual;
         // (2) the potential's parameters
         if (closed) {
-            const int n_prow = kind == JF_V_EXPONENTIAL ? 5 : 4;
-#pragma unroll 1
-            for (int k0 = 0; k0 < nc; k0 += LV) {
-                const int k = k0 + g;
-                T gp[5] = {T(0), T(0), T(0), T(0), T(0)};
-                if (k < nc) {
-                    T gm[3];
-                    v_component_adjoint<T>(ppv, nc, k, kind, lse0, e0, Gg, Gj, Ge, gm, gp[3], gp[4]);
-                    gp[0] = gm[0]; gp[1] = gm[1]; gp[2] = gm[2];
-                    gp[3] -= M<T>::exp(ppv[3 * nc + k] - lse0) * GP0;                           // softmax coupling of the log-weights
-                }
-#pragma unroll
-                for (int q = 0; q < 5; ++q) {
-                    if (q >= n_prow) break;
-                    const T v = (active && k < nc) ? gp[q] : T(0);
-                    bad = bad || !M<T>::finite(v);
-                    const int col = a.col0[l] + n_rot + q * nc + k;
-                    if (a.bcast) {
-                        const T s = rows_sum<T, LV>(v);
-                        if (tid < LV && k < nc) atomicAdd(a.g_params + col, s);
-                    } else if (active && k < nc) {
-                        a.g_params[row * a.gps + col] = v;
-                    }
-                }
-            }
+            const int col = a.col0[l] + n_rot;
+            if (kind == JF_V_EXPONENTIAL) v_closed_adjoint<T, LV, JF_V_EXPONENTIAL>(a, ppv, nc, lse0, e0, Gg, Gj, GP0, Ge, g, tid, active, row, col, bad);
+            else if (kind == JF_V_LINEAR) v_closed_adjoint<T, LV, JF_V_LINEAR>(a, ppv, nc, lse0, e0, Gg, Gj, GP0, Ge, g, tid, active, row, col, bad);
+            else v_closed_adjoint<T, LV, JF_V_QUADRATIC>(a, ppv, nc, lse0, e0, Gg, Gj, GP0, Ge, g, tid, active, row, col, bad);
 #pragma unroll
             for (int c = 0; c < 3; ++c) Ge[c] = Ge0[c] + group_sum<T, LV>(Ge[c]);
         }
