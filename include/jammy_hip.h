@@ -639,6 +639,12 @@ int jf_tanh_bwd_f64(const double* g, const double* y, int64_t n, double* out, vo
  * bit-identical from run to run (what torch.sum(0) on the slabs did in five launches per training step). */
 int jf_slab_sum_f32(const float* a, int64_t na, float* out_a, const float* b, int64_t nb, float* out_b, int32_t S, int32_t chunk, void* stream);
 int jf_slab_sum_f64(const double* a, int64_t na, double* out_a, const double* b, int64_t nb, double* out_b, int32_t S, int32_t chunk, void* stream);
+/* The totals of ALL S slabs, laid out for their consumer (ABI v7): out[map[i]] = sum_s a[s * na + i] for i < na, out[map[na + i]] = sum_s
+ * b[s * nb + i]; map: na + nb device int32 entries, negative = dropped (padding rows of a packed gradient).  One launch where the plain sum was
+ * followed by copy / gather launches (a transposed weight gradient, bias columns split off a slab, packed parameter rows back in natural
+ * order: main/default.py's torch.autograd does the same with views + .contiguous()).  Same fixed summation order as jf_slab_sum. */
+int jf_slab_sum_map_f32(const float* a, int64_t na, const float* b, int64_t nb, const int32_t* map, float* out, int32_t S, void* stream);
+int jf_slab_sum_map_f64(const double* a, int64_t na, const double* b, int64_t nb, const int32_t* map, double* out, int32_t S, void* stream);
 /* AmortizableMLP nonlinearities other than tanh (extra_functions.py:81-89; tanh is fused into the dense kernels): out = act(z) on the layer's
  * pre-activation, and the backward out = g * act'(z).  n elements, contiguous. */
 #define JF_ACT_RELU 2

@@ -8,6 +8,7 @@ import ctypes
 import threading
 import os
 
+import numpy as np
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -135,6 +136,7 @@ _SIGNATURES = {
     "jf_linear": [_P, _I64, _P, _I64, _P, _I64, _I32, _I32, _I32, _P, _I64, _P],
     "jf_normal_logp": [_P, _I64, _I64, _I32, _P, _P, _P],
     "jf_slab_sum": [_P, _I64, _P, _P, _I64, _P, _I32, _I32, _P],
+    "jf_slab_sum_map": [_P, _I64, _P, _I64, _P, _P, _I32, _P],
     "jf_tanh_bwd": [_P, _P, _I64, _P, _P],
     "jf_mlp_hidden_bwd": [_P, _I64, _P, _I64, _P, _P, _I64, _I64, _I32, _I32, _P, _P],
     "jf_mlp2_small_bwd": [_P, _I64, _P, _I64, _P, _P, _I64, _P, _I64, _I64, _I32, _I32, _I32, _P, _P, _P],
@@ -1140,9 +1142,11 @@ def cond_gf_chain_inv_split_bwd(inp, w1, b1, packed, packed_t, z, aux, layer_arr
     return (g_x, g_pp, h, g_h, absmax) if want_absmax else (g_x, g_pp, h, g_h)
 
 
-def linear_wgrad_split16(g, inp, g_absmax, in_exp=14, want_bias=True):
+def linear_wgrad_split16(g, inp, g_absmax, in_exp=14, want_bias=True, rows=None):
     """linear_wgrad's split path on f16 pairs (jf_linear_wgrad_split16_f32): g scaled by the power of two that brings g_absmax (a device
-    scalar >= max |g|) into [2^14, 2^15), inp by 2^in_exp; for the packed gradient rows and tanh activations of the fused block's adjoint"""
+    scalar >= max |g|) into [2^14, 2^15), inp by 2^in_exp; for the packed gradient rows and tanh activations of the fused block's adjoint.
+    rows (tuple of ints): the result's row i is row rows[i] of the product (packed parameter columns back in natural order, padding
+    dropped) -- laid out by the slab sum itself"""
     dev = require_device(g, inp, g_absmax)
     g, inp = _rowmajor(g), _rowmajor(inp)
     B, N = g.shape
@@ -1152,7 +1156,19 @@ def linear_wgrad_split16(g, inp, g_absmax, in_exp=14, want_bias=True):
     pb = torch.empty((S, N), dtype=g.dtype, device=g.device) if want_bias else None
     _launch("jf_linear_wgrad_split16_f32", "K%d_N%d" % (K, N), (_ptr(g), g.stride(0), _ptr(inp), inp.stride(0), B, K, N, _ptr(g_absmax), in_exp,
                                                              _ptr(pw), _ptr(pb)), dev)
-    return slab_sum(pw, pb)
+    if rows is None:
+        return slab_sum(pw, pb)
+    n = len(rows)
+
+    def build():
+        inv = np.full(N, -1, dtype=np.int64)
+        inv[np.asarray(rows, dtype=np.int64)] = np.arange(n)
+        mw = np.where(inv[:, None] >= 0, inv[:, None] * K + np.arange(K)[None, :], -1).reshape(-1)
+        if not want_bias:
+            return mw
+        return np.concatenate([mw, np.where(inv >= 0, n * K + inv, -1)])
+    out = slab_sum(pw, pb, out_map=slab_map(("wgrad_rows", N, K, bool(want_bias), tuple(rows)), g.device, build), out_size=n * K + (n if want_bias else 0))
+    return out[:n * K].view(n, K), (out[n * K:] if want_bias else None)
 
 
 def cond_gf_chain_fwd_split(inp, w1, b1, packed, z, log_det, layer_array, n_layers, D, x_out=None, status=None, kind="split"):
@@ -1216,13 +1232,28 @@ def linear(inp, weight, bias=None, act=0, out=None):
     return out
 
 
-def slab_sum(a, b=None):
+_SLAB_MAPS = {}
+
+
+def slab_map(key, device, build):
+    """device int32 map of a slab layout -> its consumer's layout (jf_slab_sum_map), built once per (key, device) by `build()` -> 1-d integer
+    array-like with one destination index per slab element (a's, then b's; negative = dropped)"""
+    k = (key, str(device))
+    m = _SLAB_MAPS.get(k)
+    if m is None:
+        m = _SLAB_MAPS[k] = torch.as_tensor(build(), dtype=torch.int32).contiguous().to(device)
+    return m
+
+
+def slab_sum(a, b=None, out_map=None, out_size=None):
     """(a.sum(0), b.sum(0) or None) of the partial slabs a (S, ...) / b (S, ...) of one backward launch with a fixed summation order
-    (jf_slab_sum: one launch for both arrays; two for hundreds of slabs -- chunks of 32 first); S == 1: views, no launch"""
+    (jf_slab_sum: one launch for both arrays; two for hundreds of slabs -- chunks of 32 first); S == 1: views, no launch.
+    out_map (slab_map) + out_size: ONE flat tensor of out_size elements instead, element i of a / na + i of b summed into position out_map[i]
+    (jf_slab_sum_map) -- the caller cuts contiguous views out of it, no copy / gather launch afterwards"""
     S = a.shape[0]
-    if S == 1:
+    if S == 1 and out_map is None:
         return a[0], (None if b is None else b[0])
-    dev = require_device(a, b)
+    dev = require_device(a, b, out_map)
     a = a.contiguous()
     b = None if b is None else b.contiguous()
     na, nb = a[0].numel(), 0 if b is None else b[0].numel()
@@ -1235,6 +1266,12 @@ def slab_sum(a, b=None):
         mid_b = torch.empty((n_chunks, nb), dtype=a.dtype, device=a.device) if b is not None else None
         _launch(fn, "chunks", (_ptr(a), na, _ptr(mid_a), _ptr(b), nb, _ptr(mid_b), S, chunk), dev)
         a, b, S = mid_a, mid_b, n_chunks
+    if out_map is not None:
+        if out_map.numel() != na + nb or out_map.dtype != torch.int32:
+            raise ValueError("slab_sum: out_map must hold one int32 entry per slab element")
+        out = torch.empty((out_size,), dtype=a.dtype, device=a.device)
+        _launch("jf_slab_sum_map" + _suffix(a), "total", (_ptr(a), na, _ptr(b), nb, _ptr(out_map), _ptr(out), S), dev)
+        return out
     out_a = torch.empty(shape_a, dtype=a.dtype, device=a.device)
     out_b = torch.empty(shape_b, dtype=a.dtype, device=a.device) if b is not None else None
     _launch(fn, "total", (_ptr(a), na, _ptr(out_a), _ptr(b), nb, _ptr(out_b), S, S), dev)
@@ -1310,8 +1347,14 @@ def mlp2_small_bwd(x, w1, b1, w2, g):
     _launch("jf_mlp2_small_bwd" + _suffix(x), "K%d_H%d_N%d" % (K1, H, N),
             (_ptr(x), x.stride(0), _ptr(w1), w1.stride(0), _ptr(b1.contiguous()), _ptr(w2), w2.stride(0), _ptr(g), g.stride(0), B, K1, H, N, _ptr(slab),
              _ptr(slab_b2)), dev)
-    tot, tot_b2 = slab_sum(slab, slab_b2)
-    return tot[:, :K1], tot[:, K1], tot[:, K1 + 1:].t(), tot_b2
+    # the slab's (H, K1 | 1 | N) columns and the b2 slab -> [g_w1 (H, K1) | g_b1 (H) | g_w2 (N, H) | g_b2 (N)], every piece contiguous
+    def build():
+        h, c = np.meshgrid(np.arange(H), np.arange(K1 + 1 + N), indexing="ij")
+        m = np.where(c < K1, h * K1 + c, np.where(c == K1, H * K1 + h, H * K1 + H + (c - K1 - 1) * H + h)).reshape(-1)
+        return np.concatenate([m, H * K1 + H + N * H + np.arange(N)])
+    out = slab_sum(slab, slab_b2, out_map=slab_map(("mlp2_small", H, K1, N), x.device, build), out_size=H * K1 + H + N * H + N)
+    o1, o2, o3 = H * K1, H * K1 + H, H * K1 + H + N * H
+    return out[:o1].view(H, K1), out[o1:o2], out[o2:o3].view(N, H), out[o3:]
 
 
 def mlp_hidden_bwd(x, w1, b1, g_hidden):
@@ -1328,8 +1371,11 @@ def mlp_hidden_bwd(x, w1, b1, g_hidden):
     slab = torch.empty((S, H, K1 + 1), dtype=x.dtype, device=x.device)
     _launch("jf_mlp_hidden_bwd" + _suffix(x), "K%d_H%d" % (K1, H),
             (_ptr(x), x.stride(0), _ptr(w1), w1.stride(0), _ptr(b1.contiguous()), _ptr(g_hidden), g_hidden.stride(0), B, K1, H, _ptr(slab)), dev)
-    tot = slab_sum(slab)[0]
-    return tot[:, :K1], tot[:, K1]
+    def build():
+        h, c = np.meshgrid(np.arange(H), np.arange(K1 + 1), indexing="ij")
+        return np.where(c < K1, h * K1 + c, H * K1 + h).reshape(-1)
+    out = slab_sum(slab, out_map=slab_map(("mlp_hidden", H, K1), x.device, build), out_size=H * K1 + H)
+    return out[:H * K1].view(H, K1), out[H * K1:]
 
 
 def tanh_bwd(g, y, inplace=False):

@@ -317,13 +317,15 @@ class CondBlockFn(torch.autograd.Function):
             del aux
             g_w2 = g_b2 = None
             if need[3] or need[4]:
-                rows = _packed_rows(layer_array, n_layers, D, g_p.device)
-                if f16_wgrad:                          # the packed rows' largest entry comes with them: weight gradient on f16 pairs
-                    g_w2, g_b2 = _hip.linear_wgrad_split16(g_p, h, res[4], 14, want_bias=need[4])
+                if f16_wgrad:                          # the packed rows' largest entry comes with them: weight gradient on f16 pairs; its slab
+                    # sum puts the packed rows back in natural order (no gather launches)
+                    g_w2, g_b2 = _hip.linear_wgrad_split16(g_p, h, res[4], 14, want_bias=need[4],
+                                                           rows=tuple(_hip.cond_gf_packed_rows(layer_array, n_layers, D)))
                 else:
+                    rows = _packed_rows(layer_array, n_layers, D, g_p.device)
                     g_w2, g_b2 = _hip.linear_wgrad(g_p, h, want_bias=need[4])
-                g_w2 = g_w2.index_select(0, rows)
-                g_b2 = None if g_b2 is None else g_b2.index_select(0, rows)
+                    g_w2 = g_w2.index_select(0, rows)
+                    g_b2 = None if g_b2 is None else g_b2.index_select(0, rows)
         else:
             # the parameter block is not kept by the forward launch: two dense launches bring it back (the large one on split-bf16 MFMA, float32:
             # the arithmetic of the fused forward block)

@@ -153,9 +153,12 @@ __global__ void __launch_bounds__(256) tanh_bwd_kernel(const T* __restrict__ g, 
 // split (up to 4096); a workgroup owns 32 consecutive elements x one chunk, its 8 slab lanes walk the chunk 8 slabs apart and meet in LDS in a
 // FIXED order, so the result does not depend on scheduling (unlike atomics).  Two launches (chunked, then chunk = all) reduce thousands of slabs
 // with every CU busy; few slabs take one.
+// map (the launch that produces the totals only: one chunk): element i of a / element na + i of b goes to out_a[map[...]] (negative: dropped)
+// -- the totals land in the layout their consumer wants (a weight gradient transposed, bias columns split off a slab, packed parameter rows
+// back in natural order) instead of being re-laid by copy / gather launches of ~5 us each afterwards.
 template <typename T>
 __global__ void __launch_bounds__(256) slab_sum_kernel(const T* __restrict__ a, int64_t na, T* __restrict__ out_a, const T* __restrict__ b, int64_t nb,
-                                                       T* __restrict__ out_b, int S, int chunk) {
+                                                       T* __restrict__ out_b, int S, int chunk, const int32_t* __restrict__ map) {
     __shared__ T part[8][33];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const int64_t i = (int64_t)blockIdx.x * 32 + tx;
@@ -179,15 +182,22 @@ __global__ void __launch_bounds__(256) slab_sum_kernel(const T* __restrict__ a, 
         T t = part[0][tx];
 #pragma unroll
         for (int u = 1; u < 8; ++u) t += part[u][tx];
-        dst[(int64_t)c * n + j] = t;
+        if (map) {
+            const int32_t m = map[i];
+            if (m >= 0) out_a[m] = t;
+        } else {
+            dst[(int64_t)c * n + j] = t;
+        }
     }
 }
-template <typename T> static int slab_sum(const T* a, int64_t na, T* out_a, const T* b, int64_t nb, T* out_b, int32_t S, int32_t chunk, void* stream) {
-    if (!a || !out_a || na < 1 || nb < 0 || (nb > 0 && (!b || !out_b)) || S < 1 || chunk < 1 || na > JF_MAX_ROWS || nb > JF_MAX_ROWS) return JF_ERR_BADARG;
+template <typename T> static int slab_sum(const T* a, int64_t na, T* out_a, const T* b, int64_t nb, T* out_b, int32_t S, int32_t chunk, void* stream,
+                                          const int32_t* map = nullptr) {
+    if (!a || !out_a || na < 1 || nb < 0 || (nb > 0 && (!b || (!out_b && !map))) || S < 1 || chunk < 1 || na > JF_MAX_ROWS || nb > JF_MAX_ROWS) return JF_ERR_BADARG;
     const int64_t chunks = ((int64_t)S + chunk - 1) / chunk;
     if (chunks > 65535) return JF_ERR_UNSUPPORTED;
+    if (map && chunks != 1) return JF_ERR_BADARG;
     jf::launch(slab_sum_kernel<T>, dim3((unsigned)((na + nb + 31) / 32), (unsigned)chunks), dim3(256), 0, (hipStream_t)stream, a, na, out_a, b, nb,
-                       out_b, (int)S, (int)chunk);
+                       out_b, (int)S, (int)chunk, map);
     return hipPeekAtLastError() == hipSuccess ? JF_OK : JF_ERR_LAUNCH;
 }
 
@@ -407,6 +417,12 @@ int jf_slab_sum_f32(const float* a, int64_t na, float* out_a, const float* b, in
 }
 int jf_slab_sum_f64(const double* a, int64_t na, double* out_a, const double* b, int64_t nb, double* out_b, int32_t S, int32_t chunk, void* s) {
     return jf::slab_sum<double>(a, na, out_a, b, nb, out_b, S, chunk, s);
+}
+int jf_slab_sum_map_f32(const float* a, int64_t na, const float* b, int64_t nb, const int32_t* map, float* out, int32_t S, void* s) {
+    return map ? jf::slab_sum<float>(a, na, out, b, nb, nullptr, S, S, s, map) : JF_ERR_BADARG;
+}
+int jf_slab_sum_map_f64(const double* a, int64_t na, const double* b, int64_t nb, const int32_t* map, double* out, int32_t S, void* s) {
+    return map ? jf::slab_sum<double>(a, na, out, b, nb, nullptr, S, S, s, map) : JF_ERR_BADARG;
 }
 int jf_tanh_bwd_f32(const float* g, const float* y, int64_t n, float* out, void* s) { return jf::tanh_bwd<float>(g, y, n, out, s); }
 int jf_tanh_bwd_f64(const double* g, const double* y, int64_t n, double* out, void* s) { return jf::tanh_bwd<double>(g, y, n, out, s); }

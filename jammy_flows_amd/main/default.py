@@ -250,8 +250,10 @@ class pdf(nn.Module):
         self._merge_ok = {}
         # gradient mode: the blocks of a training step are independent given the targets too.  With train_streams > 1 every block's forward is
         # issued on one of that many streams (torch.autograd runs a node's backward on the stream of its forward), so the latency-bound kernels
-        # of one block's adjoint overlap the other blocks'; the per-block log-dets / base log-probs are added at the end instead of threaded
-        self.train_streams = int(os.environ.get("JF_TRAIN_STREAMS", "1"))
+        # of one block's adjoint overlap the other blocks'; the per-block log-dets / base log-probs are added at the end instead of threaded.
+        # Two streams by default (round 5, after the adjoint kernels of the side blocks got shorter): C3 training 1.360 -> 1.303 ms per step,
+        # C5 1.665 -> 1.655; three streams give nothing more (1.367 / 1.650).  1 = everything on the caller's stream.
+        self.train_streams = int(os.environ.get("JF_TRAIN_STREAMS", "2"))
         self._train_stream_objs = {}
 
         self._read_model_definition(pdf_defs, flow_defs, options_overwrite, conditional_input_dim, amortization_mlp_dims,
