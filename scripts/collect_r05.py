@@ -17,6 +17,10 @@ P = os.path.join(ROOT, "profiles")
 subprocess.check_call([sys.executable, os.path.join(ROOT, "scripts", "collect_profiles.py"), "r05", "c3", "c5"])
 for wl in ("c2", "c4"):
     shutil.copy(os.path.join(G, "prof_r05_%s" % wl, "kernel_stats.md"), os.path.join(P, "r05_%s_kernel_stats.md" % wl))
+for wl in ("c3", "c5"):
+    f = os.path.join(G, "prof_r05_%s_train" % wl, "kernel_stats.md")
+    if os.path.exists(f):
+        shutil.copy(f, os.path.join(P, "r05_%s_train_kernel_stats.md" % wl))
 for src, dst in (("bench_r05_default.json", "r05_bench_c3.json"), ("bench_r05_one_stream.json", "r05_bench_c3_one_stream.json"),
                  ("bench_r05_c5.json", "r05_bench_c5.json"), ("bench_r05_c2.json", "r05_bench_c2.json"), ("bench_r05_c4.json", "r05_bench_c4.json"),
                  ("bench_r05_c3_train.json", "r05_bench_c3_train.json"), ("bench_r05_c5_train.json", "r05_bench_c5_train.json"),

@@ -21,6 +21,12 @@ python3 bench.py --pipeline-depth 1 --no-cpu-baseline --no-pmc > gpurun_out/benc
 python3 bench.py --workload c5 --scaling weak > gpurun_out/bench_r05_c5.json 2> gpurun_out/bench_r05_c5.err
 python3 bench.py --workload c2 --no-sweep > gpurun_out/bench_r05_c2.json 2> gpurun_out/bench_r05_c2.err
 python3 bench.py --workload c4 --no-sweep > gpurun_out/bench_r05_c4.json 2> gpurun_out/bench_r05_c4.err
+# the training steps' kernel tables (per-kernel durations of the same command the bench lines below time)
+for wl in c3 c5; do
+  out=gpurun_out/prof_r05_${wl}_train; rm -rf $out; mkdir -p $out
+  rocprofv3 --kernel-trace --stats -d $out/stats -- python3 bench.py --no-pmc --no-sweep --no-cpu-baseline --workload $wl --scaling weak --train > $out/stats.log 2>&1
+  f=$(find $out/stats -name "*.db" | head -1); [ -n "$f" ] && python3 scripts/rocprof_summary.py $f > $out/kernel_stats.md 2>&1; rm -rf $out/stats
+done
 for wl in c3 c5; do
   python3 bench.py --no-pmc --workload $wl --scaling weak --train > gpurun_out/bench_r05_${wl}_train.json 2> gpurun_out/bench_r05_${wl}_train.err
   python3 bench.py --no-pmc --workload $wl --scaling weak --direction sample > gpurun_out/bench_r05_${wl}_sample.json 2> gpurun_out/bench_r05_${wl}_sample.err
