@@ -180,7 +180,7 @@ template <typename T> static bool wgrad_skinny(const T* g, int64_t gs, const T* 
 // A workgroup walks its row range and writes one partial slab [H][K1 + 1 + N] (+ [N] for g_b2), summed by the caller.  No gradient with respect
 // to the input rows (they are data; the caller takes the layer-by-layer path when they require grad).
 constexpr int MS_K1MAX = 32, MS_NMAX = 16;
-// KB / NB: compile-time bounds of the input / output loops (the sizes rounded up to 4, 8, 16, 32 / 4, 8, 16).  Slots beyond the real sizes carry
+// KB / NB: compile-time bounds of the input / output loops (the sizes rounded up to 4, 8, 16, 32 / 4, 8, 12, 16).  Slots beyond the real sizes carry
 // zero weights and read a clamped (duplicate) element, so the row loop has no size-dependent branch and its scalar loads batch up.
 template <typename T, int KB, int NB>
 __global__ void __launch_bounds__(128) mlp2_small_bwd_kernel(const T* __restrict__ x, int64_t xs, const T* __restrict__ W1, int64_t w1s, const T* __restrict__ b1,
@@ -189,14 +189,18 @@ __global__ void __launch_bounds__(128) mlp2_small_bwd_kernel(const T* __restrict
     const int j = threadIdx.x;
     const bool live = j < H;
     const int jj = live ? j : H - 1;
-    T w1[KB], w2[NB], a1[KB], a2[NB], gsum[NB];
+    T w1[KB], w2[NB], a1[KB], a2[NB];
     int kx[KB], nx[NB];
 #pragma unroll
     for (int k = 0; k < KB; ++k) { w1[k] = k < K1 ? W1[(int64_t)jj * w1s + k] : T(0); a1[k] = T(0); kx[k] = k < K1 ? k : K1 - 1; }
 #pragma unroll
-    for (int n = 0; n < NB; ++n) { w2[n] = n < N ? W2[(int64_t)n * w2s + jj] : T(0); a2[n] = T(0); gsum[n] = T(0); nx[n] = n < N ? n : N - 1; }
+    for (int n = 0; n < NB; ++n) { w2[n] = n < N ? W2[(int64_t)n * w2s + jj] : T(0); a2[n] = T(0); nx[n] = n < N ? n : N - 1; }
     const T bj = b1[jj];
     T ab1 = T(0);
+    // g_b2 = the column sums of g: thread j keeps column j % N, read with a vector load of its own (the upstream row sits in scalar registers
+    // for the products below; summing all NB columns there in every thread was a quarter of the loop's vector instructions)
+    const int nj = j % N;
+    T gown = T(0);
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
     const int64_t r1 = r0 + rows_per_block < B ? r0 + rows_per_block : B;
     // rows whose KB / NB-element reads stay inside the arrays are read CONTIGUOUSLY (one or two wide scalar loads per row; the slots beyond K1 / N
@@ -206,14 +210,15 @@ __global__ void __launch_bounds__(128) mlp2_small_bwd_kernel(const T* __restrict
     // and every row takes the clamped reads.  (Selecting zero per padded slot in this loop cost 40 % of the kernel: 0.088 -> 0.125 ms.)
     const int64_t safe = B - 1 - ((KB - K1 + xs - 1) / xs > (NB - N + gs - 1) / gs ? (KB - K1 + xs - 1) / xs : (NB - N + gs - 1) / gs);
     const int64_t rm = !dense ? r0 : (r1 < safe ? r1 : (safe > r0 ? safe : r0));
-    auto one_row = [&](const T (&xv)[KB], const T (&gv)[NB]) {
+    auto one_row = [&](const T (&xv)[KB], const T (&gv)[NB], T gcol) {
+        gown += gcol;
         T pre = bj;
 #pragma unroll
         for (int k = 0; k < KB; ++k) pre += w1[k] * xv[k];
         const T h = M<T>::tanh_fast(pre);                          // the forward kernels' tanh (jf_mlp2 / jf_linear)
         T gh = T(0);
 #pragma unroll
-        for (int n = 0; n < NB; ++n) { gh += gv[n] * w2[n]; a2[n] += gv[n] * h; gsum[n] += gv[n]; }
+        for (int n = 0; n < NB; ++n) { gh += gv[n] * w2[n]; a2[n] += gv[n] * h; }
         gh *= T(1) - h * h;
         ab1 += gh;
 #pragma unroll
@@ -228,7 +233,7 @@ __global__ void __launch_bounds__(128) mlp2_small_bwd_kernel(const T* __restrict
         for (int k = 0; k < KB; ++k) xv[k] = xr[k];
 #pragma unroll
         for (int n = 0; n < NB; ++n) gv[n] = gr[n];
-        one_row(xv, gv);
+        one_row(xv, gv, gr[nj]);
     }
     for (int64_t r = rm; r < r1; ++r) {
         const T* xr = x + r * xs;
@@ -238,7 +243,7 @@ __global__ void __launch_bounds__(128) mlp2_small_bwd_kernel(const T* __restrict
         for (int k = 0; k < KB; ++k) xv[k] = xr[kx[k]];
 #pragma unroll
         for (int n = 0; n < NB; ++n) gv[n] = gr[nx[n]];
-        one_row(xv, gv);
+        one_row(xv, gv, gr[nj]);
     }
     if (live) {
         T* row = slab + ((int64_t)blockIdx.x * H + j) * (K1 + 1 + N);
@@ -248,10 +253,7 @@ __global__ void __launch_bounds__(128) mlp2_small_bwd_kernel(const T* __restrict
 #pragma unroll
         for (int n = 0; n < NB; ++n) if (n < N) row[K1 + 1 + n] = a2[n];
     }
-    if (j == 0) {
-#pragma unroll
-        for (int n = 0; n < NB; ++n) if (n < N) slab_b2[(int64_t)blockIdx.x * N + n] = gsum[n];
-    }
+    if (j < N) slab_b2[(int64_t)blockIdx.x * N + j] = gown;
 }
 
 // the first layer alone: the gradient with respect to the hidden activations (B, H) is given (the second layer's input-gradient product), the
@@ -322,10 +324,10 @@ static int mlp2_small_bwd(const T* x, int64_t xs, const T* W1, int64_t w1s, cons
     const int64_t rpb = (B + S - 1) / S;
     const dim3 grid((unsigned)S), block(128);
     hipStream_t st = (hipStream_t)stream;
-    const int kb = K1 <= 4 ? 4 : K1 <= 8 ? 8 : K1 <= 16 ? 16 : 32, nb = N <= 4 ? 4 : N <= 8 ? 8 : 16;
+    const int kb = K1 <= 4 ? 4 : K1 <= 8 ? 8 : K1 <= 16 ? 16 : 32, nb = N <= 4 ? 4 : N <= 8 ? 8 : N <= 12 ? 12 : 16;
     const int dense = (kb == K1 || xs == K1) && (nb == N || gs == N);           // padded slots read rows of the same array, never a gap
 #define JF_MS(KB_, NB_) jf::launch((mlp2_small_bwd_kernel<T, KB_, NB_>), grid, block, 0, st, x, xs, W1, w1s, b1, W2, w2s, g, gs, B, (int)K1, (int)H, (int)N, rpb, slab, slab_b2, dense)
-#define JF_MS_N(KB_) { if (N <= 4) JF_MS(KB_, 4); else if (N <= 8) JF_MS(KB_, 8); else JF_MS(KB_, 16); }
+#define JF_MS_N(KB_) { if (N <= 4) JF_MS(KB_, 4); else if (N <= 8) JF_MS(KB_, 8); else if (N <= 12) JF_MS(KB_, 12); else JF_MS(KB_, 16); }
     if (K1 <= 4) JF_MS_N(4) else if (K1 <= 8) JF_MS_N(8) else if (K1 <= 16) JF_MS_N(16) else JF_MS_N(32)
 #undef JF_MS_N
 #undef JF_MS
