@@ -8,7 +8,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path[:0] = [ROOT]
 
 CASES = [("s2", "v", k, rot, cond, nc) for k in ("exponential", "linear", "quadratic") for rot in (0, 1) for cond in (0, 2) for nc in (1, 10)]
-CASES += [("s2", "vv", "exponential", 1, 2, 4), ("e2+s2", "gg+v", "quadratic", 0, 3, 10)]
+CASES += [("s2", "vv", "exponential", 1, 2, 4), ("e2+s2", "gg+v", "quadratic", 0, 3, 10),
+          ("s2", "v", "exponential", 1, 2, 70)]          # 362 parameters per row: the kernel takes 32 rows per wave (LDS), half its lanes idle
 
 
 def grads(out):
