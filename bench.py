@@ -725,6 +725,7 @@ def dry_run(args, W, rank, world, B, total_rows, lo):
         full = gather.wait()
         ref = torch.arange(0, total_rows, dtype=torch.float64)
         ok = bool(torch.equal(full, -0.5 * ref * ref))
+    exchange = parallel.gather_report(B, torch.float64, torch.device("cpu")) if world > 1 else None
     if world > 1:
         dist.barrier()
     if rank == 0:
@@ -734,7 +735,7 @@ def dry_run(args, W, rank, world, B, total_rows, lo):
                           "dry_run": True, "config": {"workload": "dry run of %s" % args.workload, "batch_per_gpu": B, "total_rows": total_rows,
                                                       "parallelism": "rows sharded over %d rank(s)" % world},
                           "n_ranks_seen": n_ranks_seen, "collective_backend": dist.get_backend() if world > 1 else None,
-                          "gathered_rows_correct": ok}))
+                          "exchange": exchange, "gathered_rows_correct": ok}))
     if world > 1:
         dist.destroy_process_group()
     return 0 if ok else 1
@@ -1114,6 +1115,8 @@ def main():
                 pdf.fuse_conditional_blocks = True
         del pdf, x, c
 
+    # N > 1: who held how many rows, and what one stand-alone all-gather of the log-probs costs (outside the timed region; every rank)
+    exchange = parallel.gather_report(B, dtypes[main_dt], dev) if world > 1 else None
     if world > 1:
         dist.barrier()
     if rank == 0:
@@ -1221,7 +1224,7 @@ def main():
                                                                                   B if args.scaling == "weak" else total_rows,
                                                                                   "per GPU" if args.scaling == "weak" else "in total, row-sharded"),
                        "batch_per_gpu": B, "total_rows": total_rows, "parallelism": "rows sharded over %d GPU(s)" % world},
-            "n_ranks_seen": n_ranks_seen, "collective_backend": backend_name,
+            "n_ranks_seen": n_ranks_seen, "collective_backend": backend_name, "exchange": exchange,
             "parity": {"max_abs_dlogp_vs_f64_oracle": rm["err"], "bar": 1e-2 if main_dt == "f32" else 1e-4, "rows_checked": min(4096, B),
                        "repeat_launches_bit_identical": rm["identical"], "repeat_launches": rm["repeats"], "repeat_rows_compared": B,
                        "untiled_full_size": rm["untiled"]},

@@ -97,6 +97,45 @@ class PipelinedGather:
         return self.out[(self.i - 1) % len(self.out)] if self.i else None
 
 
+def gather_report(n_rows_local, dtype, device, reps=10, group=None):
+    """what the N > 1 bench line says about its only exchange (collective: every rank calls it, outside the timed region): the rows every rank
+    holds (all_gather_object), and the duration of ONE stand-alone all_gather_into_tensor of the per-row log-probs -- mean of `reps`, HIP events
+    on a GPU, host clock otherwise, MAX over ranks.  In the timed steps the same collective runs asynchronously behind the next step's kernels
+    (PipelinedGather); this is its exposed cost if nothing hid it."""
+    import time
+    world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+    if world == 1:
+        return {"rows_per_rank": [int(n_rows_local)], "gather_us": 0.0, "gather_bytes_per_rank": 0}
+    rows = [None] * world
+    dist.all_gather_object(rows, int(n_rows_local), group=group)
+    on_gpu = torch.device(device).type == "cuda"
+    out = {"rows_per_rank": [int(r) for r in rows], "gather_us": None, "gather_bytes_per_rank": int(n_rows_local) * torch.empty((), dtype=dtype).element_size()}
+    if len(set(rows)) != 1:
+        return out                                     # unequal shards: the bench does not gather (all_gather_into_tensor wants equal blocks)
+    local = torch.zeros((n_rows_local,), dtype=dtype, device=device)
+    full = torch.empty((world * n_rows_local,), dtype=dtype, device=device)
+    for _ in range(2):
+        dist.all_gather_into_tensor(full, local, group=group)
+    if on_gpu:
+        torch.cuda.synchronize(device)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            dist.all_gather_into_tensor(full, local, group=group)
+        e1.record()
+        torch.cuda.synchronize(device)
+        us = e0.elapsed_time(e1) * 1e3 / reps
+    else:
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            dist.all_gather_into_tensor(full, local, group=group)
+        us = (time.perf_counter() - t0) * 1e6 / reps
+    t = torch.tensor([us], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    out["gather_us"] = float(t.item())
+    return out
+
+
 def timed_steps(step, steps, warmup, finish=None, device=None, timer=None):
     """the benchmark contract's timing loop: `warmup` untimed calls of step(), then EXACTLY `steps` calls bracketed by a barrier + device
     synchronisation on both sides; returns the wall time in seconds, MAX over ranks.  `finish()` (optional) runs inside the timed region after

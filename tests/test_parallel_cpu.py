@@ -232,6 +232,8 @@ def test_bench_launches_its_own_ranks_dry_run():
     assert line["n_gpus"] == 2 and line["n_ranks_seen"] == 2 and line["collective_backend"] == "gloo"
     assert line["dry_run"] is True and line["gathered_rows_correct"] is True
     assert line["config"]["total_rows"] == 2000 and line["steps"] == 3 and line["warmup"] == 1 and line["scaling"] == "weak"
+    # the line says who held how many rows and what one stand-alone all-gather of the log-probs takes
+    assert line["exchange"]["rows_per_rank"] == [1000, 1000] and line["exchange"]["gather_us"] > 0 and line["exchange"]["gather_bytes_per_rank"] == 8000
     # the default is STRONG scaling (efficiency at fixed total batch): --batch is then the total, split over the ranks
     r = _run_bench(["--gpus", "2", "--steps", "1", "--warmup", "0", "--dry-run", "--batch", "1000"], {"JF_BENCH_BACKEND": "gloo"},
                    drop=("WORLD_SIZE", "RANK", "LOCAL_RANK"))
@@ -248,6 +250,7 @@ def test_bench_c5_strong_scaling_row_split_dry_run():
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
     assert line["config"]["total_rows"] == 4097 and line["config"]["batch_per_gpu"] == 2049 and line["scaling"] == "strong"
+    assert line["exchange"]["rows_per_rank"] == [2049, 2048] and line["exchange"]["gather_us"] is None      # unequal shards: nothing is gathered
 
 
 def test_bench_refuses_a_rank_count_mismatch():
