@@ -73,7 +73,7 @@ __device__ __forceinline__ void cond_gf_split_body(const CsArgs& a, const int bl
     cs_hidden<RG, false, NP>(a.in, a.in_stride, a.W1, a.w1s, a.b1, a.K1, a.H, row0, last, Xs, hB, nullptr, 0, a.cin.n ? &a.cin : nullptr);
     // ---- flow state: lane = (row li of the row group's 16, coordinate lq)
     const bool live = lq < D, leader = lq == 0;
-    const int d = live ? lq : D - 1;
+    int d = live ? lq : D - 1;
     int64_t row[RG]; bool row_valid[RG];
     float x[RG], ld[RG];
 #pragma unroll
@@ -178,6 +178,12 @@ __device__ __forceinline__ void cond_gf_split_body(const CsArgs& a, const int bl
                 CsSums sums;
                 const MixQ<float> q = cs_mixture(P[g], o, xg, live, SAVE ? &sums : nullptr);
                 if constexpr (SAVE) {
+                    {   // (row number re-derived from the lane index: see the epilogue)
+                        int t2 = tid;
+                        asm volatile("" : "+v"(t2));
+                        row[g] = row0 + ((t2 >> 6) * RG + g) * MT + (t2 & 15);
+                        row_valid[g] = row[g] <= last;
+                    }
                     if (row_valid[g]) {
                         const int64_t slot = ((int64_t)l * a.B + row[g]) * 4 + lq;
                         reinterpret_cast<f32x4*>(a.aux)[slot] = f32x4{sums.C, sums.S, sums.P, sums.invN};
@@ -209,6 +215,21 @@ __device__ __forceinline__ void cond_gf_split_body(const CsArgs& a, const int bl
         landed();
     }
 
+    // The epilogue's row numbers are derived AGAIN from the lane index, behind an empty asm the compiler cannot see through: the copies made
+    // before phase 1 (two 64-bit row numbers, the coordinate index) otherwise stay in registers through every layer, and at this kernel's 168
+    // registers (three workgroups per CU) they were what spilled to scratch (8 registers: 36 B per lane written and read back, 75 MB per
+    // 2^20-row launch on the write counters).
+    if constexpr (!FWD) {                                          // (the sampling variants gain registers from it: 141 -> 153; they have none to spare either)
+        int t2 = tid;
+        asm volatile("" : "+v"(t2));
+        const int lane2 = t2 & 63, wave2 = t2 >> 6, li2 = lane2 & 15, lq2 = lane2 >> 4;
+        d = lq2 < D ? lq2 : D - 1;
+#pragma unroll
+        for (int g = 0; g < RG; ++g) {
+            row[g] = row0 + (wave2 * RG + g) * MT + li2;
+            row_valid[g] = row[g] <= last;
+        }
+    }
 #pragma unroll
     for (int g = 0; g < RG; ++g) {
         if (row_valid[g] && live) a.x_out[row[g] * a.xos + d] = x[g];
