@@ -207,17 +207,31 @@ __device__ __forceinline__ T cs_solve(const T (&P)[CS_SLOTS], int inv_type, bool
         for (int k = 0; k < CS_SLOTS; ++k) PF[k] = k < 3 * CS_K ? (F)P[k] : F(0);
         // start: the mixture's mean moved by z mean-widths -- exact for one component of an isigmoid stage (x = mu + w z), and for a normal-type
         // stage with the classic logistic / normal match x = mu + 1.702 w z
-        F xf = F(0), wbar = F(0);
+        // ... widened by the spread of the component means (round 5): the single logistic / normal with the mixture's mean whose scale is the
+        // within-component scale and the between-component standard deviation added in quadrature -- sqrt(wbar^2 + 3 var_b / pi^2) for the
+        // logistic, sqrt((1.702 wbar)^2 + var_b) for the normal.  With var_b = 0 this is the start above; for components that lie apart
+        // (what a trained or a scaled-up random amortisation MLP emits) the within-width alone put the start several widths short of the root.
+        F xf = F(0), wbar = F(0), m2 = F(0);
 #pragma unroll
         for (int k = 0; k < CS_K; ++k) {
-            xf += PF[CS_SLOT_LN + k] * PF[CS_SLOT_MEAN + k];
+            const F pm = PF[CS_SLOT_LN + k] * PF[CS_SLOT_MEAN + k];
+            xf += pm;
+            m2 += pm * PF[CS_SLOT_MEAN + k];
             wbar += PF[CS_SLOT_LN + k] * M<F>::rcp(PF[CS_SLOT_LW + k]);
         }
         {
             const F zc = M<F>::min(M<F>::max((F)z, F(-8)), F(8));
-            xf += wbar * zc * (inv_type != JF_GF_ISIGMOID ? F(1.702) : F(1));
+            const F var_b = M<F>::max(m2 - xf * xf, F(0));
+            const F sc = inv_type != JF_GF_ISIGMOID ? M<F>::sqrt(F(2.896804) * wbar * wbar + var_b) : M<F>::sqrt(wbar * wbar + F(0.30396355) * var_b);
+            xf += sc * zc;
         }
+#ifdef JF_PROBE_COUNT_APPROACH
+        int n_ev = 0;
+        xf = gf_approach<F>([&](F xx) { return cs_mixture_derived<F>(PF, xx); }, inv_type != JF_GF_ISIGMOID, (F)z, xf, live && !have_start, &n_ev);
+        if (info == nullptr) { for (int i = 0; i < n_ev; ++i) status_add(status, JF_STATUS_NEWTON_STEPS, row_valid && leader); }
+#else
         xf = gf_approach<F>([&](F xx) { return cs_mixture_derived<F>(PF, xx); }, inv_type != JF_GF_ISIGMOID, (F)z, xf, live && !have_start);
+#endif
         if (!have_start) x = (T)xf;
     }
     bool active = row_valid;

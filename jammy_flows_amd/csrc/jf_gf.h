@@ -432,12 +432,13 @@ __device__ __forceinline__ float gf_log_ndtr_neg(float a) {
 // one before it); any other short step says "the root is here" only if g is as linear as its tangent, so the iterate steps 4e-3 PAST the
 // proposal and the next evaluation either closes the bracket around the root or shows that it lies further on.  Typically 4-6 evaluations.
 // eval(x) -> MixQ<F> (log cdf, log sf, log pdf); x0: the mixture's mean.  The Newton stage after it is the reference's, unchanged.
-template <typename F, typename EVAL> __device__ __forceinline__ F gf_approach(EVAL eval, bool proxy, F z, F x0, bool live) {
+template <typename F, typename EVAL> __device__ __forceinline__ F gf_approach(EVAL eval, bool proxy, F z, F x0, bool live, int* n_evals = nullptr) {
     const bool neg = z <= F(0);
     const F tz = proxy ? (F)gf_log_ndtr_neg((float)M<F>::abs(z)) : F(0);
     F xf = x0, blo = F(-1e5), bhi = F(1e5), dxold = F(2e5);
     bool act = live;
     for (int it = 0; it < 40 && __any(act); ++it) {
+        if (n_evals != nullptr) *n_evals += 1;                     // (probe builds: evaluations the WAVE makes, JF_PROBE_COUNT_APPROACH)
         const MixQ<F> q = eval(xf);
         F g, sl;
         if (proxy) {
