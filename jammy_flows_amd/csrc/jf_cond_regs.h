@@ -110,70 +110,6 @@ __device__ __forceinline__ MixQ<float> cs_mixture(const float (&P)[CS_SLOTS], co
     return q;
 }
 
-// The same mixture in log2 units (round 5), for the f16-pair kernels of the log-prob direction.  The raw log-width and log-weight slots arrive
-// PRE-SCALED by -log2(e) -- the multiplication that undoes the f16 scales of the matrix product carries that factor for those slots (it is a
-// compile-time slot index there) -- so both regulators are a bare v_exp_f32; the inverse width is kept times log2(e), which makes
-// u' = (x - mu) iw' the exponent of the component's own v_exp_f32, and the pdf sum (linear in iw') is corrected by ln 2 once per row.
-// Three multiplications less per component than cs_mixture (26 -> 23 vector instructions); same sums up to the rounding of those products.
-__device__ __forceinline__ MixQ<float> cs_mixture_log2(const float (&P)[CS_SLOTS], const CsLayer& o, float x, bool live, CsSums* sums = nullptr) {
-    using Mf = M<float>;
-    constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
-    const float c1 = o.inv_wmax * LOG2E, wminp = o.wmin * LN2;     // ae' = ae log2(e);  wmin ae + 1 = (wmin ln 2) ae' + 1
-    float iw[CS_K], wk[CS_K], u[CS_K];                             // iw, u in log2 units
-    float m = INFINITY, Nn = 0.f;
-#pragma unroll
-    for (int k = 0; k < CS_K; ++k) {
-        const float ae = fmaf(__builtin_amdgcn_exp2f(P[CS_SLOT_LW + k]), LOG2E, c1);
-        iw[k] = ae * Mf::rcp(fmaf(wminp, ae, 1.0f));
-        wk[k] = fmaf(o.nmax, Mf::rcp(1.0f + __builtin_amdgcn_exp2f(P[CS_SLOT_LN + k])), o.nmin);
-        u[k] = (x - P[CS_SLOT_MEAN + k]) * iw[k];
-        m = fminf(m, fabsf(u[k]));
-        Nn += wk[k];
-    }
-    const float inv = Mf::rcp(Nn);
-    MixQ<float> q;
-    {
-        float C = 0.f, S = 0.f, Pd = 0.f;
-#pragma unroll
-        for (int k = 0; k < CS_K; ++k) {
-            const float t = __builtin_amdgcn_exp2f(fminf(-u[k], 126.0f));       // e^{-u}, finite (such a lane is `far`)
-            const float s = Mf::rcp(1.0f + t);
-            const float ts = t * s;
-            C += wk[k] * s;
-            S += wk[k] * ts;
-            Pd += wk[k] * s * ts * iw[k];
-        }
-        C *= inv; S *= inv; Pd *= inv * LN2;
-        q.lc = Mf::log_fast(C); q.ls = Mf::log_fast(S); q.lp = Mf::log_fast(Pd);
-        q.cdf = C; q.sf = S;
-        if (sums) *sums = CsSums{C, S, Pd, inv};
-    }
-    const bool far = m > CS_M_SCALED * LOG2E;
-    if (!__any(live && far)) return q;                             // wave-uniform branch
-    const float em = __builtin_amdgcn_exp2f(-m);                  // may underflow to 0: the unscaled parts then stand alone
-    float Cu = 0.f, Cs = 0.f, Su = 0.f, Ss = 0.f, Ps = 0.f;
-#pragma unroll
-    for (int k = 0; k < CS_K; ++k) {
-        const float t = __builtin_amdgcn_exp2f(m - fabsf(u[k]));
-        const float hi = Mf::rcp(1.0f + t * em);
-        const float c1k = wk[k] * hi, c2 = c1k * t;
-        if (u[k] >= 0.f) { Cu += c1k; Ss += c2; }
-        else { Su += c1k; Cs += c2; }
-        Ps += c2 * hi * iw[k];
-    }
-    Cu *= inv; Cs *= inv; Su *= inv; Ss *= inv; Ps *= inv * LN2;
-    if (far) {
-        const float mn = m * LN2;                                  // the distance in natural units
-        q.cdf = Cu + em * Cs;
-        q.sf = Su + em * Ss;
-        q.lc = Cu > 0.f ? Mf::log_fast(q.cdf) : Mf::log_fast(Cs) - mn;
-        q.ls = Su > 0.f ? Mf::log_fast(q.sf) : Mf::log_fast(Ss) - mn;
-        q.lp = Mf::log_fast(Ps) - mn;
-        if (sums) *sums = CsSums{q.cdf, q.sf, Ps * em, inv};
-    }
-    return q;
-}
-
 // ---------------------------------------------------------------------------------------------------------- sampling direction on register rows
 // gf_derive_column / gfg_mixture_impl<float, false, true> / gfg_mixture_scaled<float, false> / gfg_solve (jf_gf.h) with the lane's parameters in
 // registers: the raw row P is regulated ONCE in place (log-width slots -> 1 / width, log-weight slots -> normalised weight), then the 25

@@ -152,19 +152,12 @@ __device__ __forceinline__ void cond_gf_split_body(const CsArgs& a, const int bl
                         for (int r = 0; r < 4; ++r) P[g][4 * (c * CS_CT + t) + r] = acc[g][t][r];
             } else {
                 const float inv = Bs[CS_B_BYTES / 4];                // 2^-(e + 14): the scales of W2 and h undone (exact)
-                // log-prob direction: the log-width / log-weight slots leave times -log2(e) (cs_mixture_log2: their regulators are exp2 of them)
-                const float inv_l2 = inv * -1.4426950408889634f;
 #pragma unroll
                 for (int g = 0; g < RG; ++g)
 #pragma unroll
                     for (int t = 0; t < CS_CT; ++t)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            constexpr bool PRE = !FWD;
-                            const int slot = 4 * (c * CS_CT + t) + r;
-                            const bool reg = PRE && slot >= CS_SLOT_LW && slot < CS_SLOT_LN + CS_K;      // (compile-time after unrolling)
-                            P[g][slot] = acc[g][t][r] * (reg ? inv_l2 : inv);
-                        }
+                        for (int r = 0; r < 4; ++r) P[g][4 * (c * CS_CT + t) + r] = acc[g][t][r] * inv;
             }
             if (c + 1 < CS_CPL) landed();                          // next chunk in place, every wave has read this one
         }
@@ -183,8 +176,7 @@ __device__ __forceinline__ void cond_gf_split_body(const CsArgs& a, const int bl
                     }
                 }
                 CsSums sums;
-                const MixQ<float> q = NP == 2 ? cs_mixture_log2(P[g], o, xg, live, SAVE ? &sums : nullptr)
-                                              : cs_mixture(P[g], o, xg, live, SAVE ? &sums : nullptr);
+                const MixQ<float> q = cs_mixture(P[g], o, xg, live, SAVE ? &sums : nullptr);
                 if constexpr (SAVE) {
                     {   // (row number re-derived from the lane index: see the epilogue)
                         int t2 = tid;
