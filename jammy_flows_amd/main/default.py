@@ -247,6 +247,7 @@ class pdf(nn.Module):
         # the two as ONE launch (csrc/merged_kernels.hip: they overlap each other's latency -- 0.055 -> 0.037 ms at 2^17 rows, 0.228 -> 0.210 at
         # 2^20); 0 = never
         self.merge_max_rows = int(os.environ.get("JF_MERGE_MAX_ROWS", str(1 << 40)))
+        self.merge_max_rows_pipelined = int(os.environ.get("JF_MERGE_MAX_ROWS_PIPELINED", str(1 << 19)))     # (see PipelinedForward)
         self._merge_ok = {}
         # gradient mode: the blocks of a training step are independent given the targets too.  With train_streams > 1 every block's forward is
         # issued on one of that many streams (torch.autograd runs a node's backward on the stream of its forward), so the latency-bound kernels
@@ -2063,11 +2064,20 @@ class PipelinedForward:
         caller = torch.cuda.current_stream(self.dev)
         self.streams = [torch.cuda.Stream(device=self.dev) for _ in range(depth)] if depth > 1 else [caller]
         self.plans = []
-        for s in self.streams:
-            s.wait_stream(caller)
-            with torch.cuda.stream(s):
-                self.plans.append(PlannedForward(pdf, x, conditional_input, kwargs))
-            caller.wait_stream(s)
+        # the two side blocks in ONE launch (merge_max_rows) pay on one stream at every size (2^20 rows: 0.714 vs 0.730 ms) and, with steps on
+        # alternating streams, up to 2^19 rows (2^17: 0.106 vs 0.115); at 2^20 rows two separate launches interleave better with the neighbour
+        # step's fused block (0.662 vs 0.667-0.69 ms, same-box A/B): recorded accordingly
+        keep = pdf.merge_max_rows
+        if depth > 1:
+            pdf.merge_max_rows = min(keep, pdf.merge_max_rows_pipelined)
+        try:
+            for s in self.streams:
+                s.wait_stream(caller)
+                with torch.cuda.stream(s):
+                    self.plans.append(PlannedForward(pdf, x, conditional_input, kwargs))
+                caller.wait_stream(s)
+        finally:
+            pdf.merge_max_rows = keep
 
     def submit(self, x, conditional_input=None):
         """enqueue one step; returns a PendingStep at once.  The step starts when the work queued so far on the caller's current stream (the
