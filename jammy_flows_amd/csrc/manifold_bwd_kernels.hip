@@ -61,15 +61,17 @@ __global__ void __launch_bounds__(64) mchain_bwd_kernel(const MBwdArgs<T, typena
     const int slot = lane_in ? tid : 0;
     Du* tab = tile + tile_rows * a.tile_stride + slot * a.tab;
     Du* corr = tile + tile_rows * a.tile_stride + rows * a.tab + slot * a.scratch;
-    const int64_t row0 = (int64_t)blockIdx.x * rows;
-    const int64_t row = row0 + tid;
-    const bool active = lane_in && row < a.B;
-    const int64_t rrow = active ? row : a.B - 1;
+    // broadcast parameters: the workgroup's sums of the parameter gradients over ALL its row tiles, added to g_params once at the end.  (Until
+    // round 5 every 64-row workgroup added its sums straight to g_params: 4096 workgroups x 33 atomics on the same 33 words at 2^18 rows of
+    // C4's `r` layer -- 0.86 ms, of which the chain replays are ~0.1.)  A resident set of workgroups walks the tiles instead.
+    T* accp = reinterpret_cast<T*>(tile + tile_rows * a.tile_stride + rows * (a.tab + a.scratch));
+    const int64_t row0_first = (int64_t)blockIdx.x * rows;
 
     // parameters of all layers -> dual rows (tangents 0)
     if (a.bcast) {
-        for (int j = tid; j < a.P; j += 64) tile[j] = Du(a.params[j]);
+        for (int j = tid; j < a.P; j += 64) { tile[j] = Du(a.params[j]); accp[j] = T(0); }
     } else {
+        const int64_t row0 = row0_first;
         // eight loads in flight per lane (a row at a time is one dependent load after the other: 64 x ~1 us)
         const int total = rows * a.P;
         for (int i0 = 0; i0 < total; i0 += 64 * 8) {
@@ -91,6 +93,14 @@ __global__ void __launch_bounds__(64) mchain_bwd_kernel(const MBwdArgs<T, typena
     }
     __syncthreads();
     Du* prow = tile + (a.bcast ? 0 : slot * a.tile_stride);
+    bool bad_any = false;
+    const int64_t n_tiles = (a.B + rows - 1) / rows;
+    const int64_t t_end = a.bcast ? n_tiles : (int64_t)blockIdx.x + 1;      // per-sample parameters: the tile whose rows were staged above
+    for (int64_t tile_i = blockIdx.x; tile_i < t_end; tile_i += gridDim.x) {
+    const int64_t row0 = tile_i * rows;
+    const int64_t row = row0 + tid;
+    const bool active = lane_in && row < a.B;
+    const int64_t rrow = active ? row : a.B - 1;
 
     T x0[3] = {T(0), T(0), T(0)};
 #pragma unroll
@@ -143,7 +153,7 @@ __global__ void __launch_bounds__(64) mchain_bwd_kernel(const MBwdArgs<T, typena
                 if (active) a.g_x[row * a.gxs + j] = gj;
             } else if (a.bcast) {
                 const T s = wave_sum<T>(gj);
-                if (tid == 0) atomicAdd(a.g_params + (j - a.dim), s);
+                if (tid == 0) accp[j - a.dim] += s;
             } else if (active) {
                 a.g_params[row * a.gps + (j - a.dim)] = gj;
             }
@@ -159,7 +169,13 @@ __global__ void __launch_bounds__(64) mchain_bwd_kernel(const MBwdArgs<T, typena
             }
         }
     }
-    status_add(a.status, JF_STATUS_NONFINITE, active && bad);
+    bad_any = bad_any || (active && bad);
+    }
+    if (a.bcast) {
+        __syncthreads();
+        for (int j = tid; j < a.P; j += 64) atomicAdd(a.g_params + j, accp[j]);
+    }
+    status_add(a.status, JF_STATUS_NONFINITE, bad_any);
 }
 
 // ---------------------------------------------------------------------------------------------------------- 'v' chains, staged
@@ -601,23 +617,29 @@ static int mchain_bwd(const T* x, int64_t xs, const T* params, int64_t ps, int32
         }
     }
     a.tab = 0;
-    for (int l = 0; l < n_layers; ++l) if (Fam::needs_tab(layers[l])) a.tab = JF_SPLINE_TAB;
+    for (int l = 0; l < n_layers; ++l) {
+        if (!Fam::needs_tab(layers[l])) continue;
+        int w = JF_SPLINE_TAB;                                     // families that state their bin count ('r', 'o'): 3 (bins + 1) words per lane, as in the
+        if constexpr (std::is_same<Fam, RFam>::value || std::is_same<Fam, OFam>::value) w = Fam::tab_words(layers[l]);   // forward kernels (35 for 10 bins, not 53)
+        a.tab = w > a.tab ? w : a.tab;
+    }
     a.rows = 64 / lv;
     size_t lds = 0;
     // generic kernel: four directions per pass when a full wave of rows still fits the LDS with the wider dual rows, else one
     constexpr int NW = std::is_same<Fam, FFam>::value && sizeof(T) == 4 ? 6 : 4;    // 'f' float32 (2 + 10 directions by default): two passes
     bool wide = false;
     if (!staged) {
-        const size_t lds4 = ((size_t)(a.bcast ? 1 : 64) * a.tile_stride + (size_t)64 * (a.tab + a.scratch)) * sizeof(DualN<T, NW>);
+        const size_t lds4 = ((size_t)(a.bcast ? 1 : 64) * a.tile_stride + (size_t)64 * (a.tab + a.scratch)) * sizeof(DualN<T, NW>) + (a.bcast ? (size_t)a.P * sizeof(T) : 0);
         wide = lds4 <= 64 * 1024;                                  // (also leaves room for two workgroups per CU)
     }
     for (;;) {
-        if (wide) { lds = ((size_t)(a.bcast ? 1 : a.rows) * a.tile_stride + (size_t)a.rows * (a.tab + a.scratch)) * sizeof(DualN<T, NW>); break; }
+        const size_t accp = a.bcast ? (size_t)a.P * sizeof(T) : 0;            // generic kernel, broadcast parameters: the workgroup's gradient sums
+        if (wide) { lds = ((size_t)(a.bcast ? 1 : a.rows) * a.tile_stride + (size_t)a.rows * (a.tab + a.scratch)) * sizeof(DualN<T, NW>) + accp; break; }
         if (staged) {                                              // plain-value parameter tile + per lane: knot table, rotation row (duals) + per row: scratch (values)
             const size_t tile_elems = (((size_t)(a.bcast ? 1 : a.rows) * a.tile_stride) + 1) & ~(size_t)1;
             lds = tile_elems * sizeof(T) + (size_t)64 * (size_t)(a.tab + a.rot_max) * sizeof(Dual<T>) + (size_t)a.rows * (size_t)a.scratch * sizeof(T);
         } else
-        lds = ((size_t)(a.bcast ? 1 : a.rows) * a.tile_stride + (size_t)a.rows * (a.tab + a.scratch)) * sizeof(DualN<T, 1>);
+        lds = ((size_t)(a.bcast ? 1 : a.rows) * a.tile_stride + (size_t)a.rows * (a.tab + a.scratch)) * sizeof(DualN<T, 1>) + accp;
         if (lds <= 160 * 1024 || a.rows == 4) break;
         a.rows >>= 1;
     }
@@ -630,15 +652,25 @@ static int mchain_bwd(const T* x, int64_t xs, const T* params, int64_t ps, int32
             return check_launch();
         }
     }
+    // generic kernel: one workgroup per 64-row tile; broadcast parameters: a resident set of workgroups walks the tiles (four per CU)
+    auto generic_grid = [&]() -> int64_t {
+        const int64_t tiles = (B + a.rows - 1) / a.rows;
+        if (!a.bcast) return tiles;
+        int dev = 0, cus = 256;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        const int64_t resident = (int64_t)cus * 4;
+        return tiles < resident ? tiles : resident;
+    };
     if (wide) {
         auto k4 = mchain_bwd_kernel<T, Fam, NW>;
         if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k4, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        jf::launch(k4, dim3((unsigned)((B + a.rows - 1) / a.rows)), dim3(64), lds, (hipStream_t)stream, a);
+        jf::launch(k4, dim3((unsigned)generic_grid()), dim3(64), lds, (hipStream_t)stream, a);
         return check_launch();
     }
     auto k = mchain_bwd_kernel<T, Fam, 1>;
     if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    jf::launch(k, dim3((unsigned)((B + a.rows - 1) / a.rows)), dim3(64), lds, (hipStream_t)stream, a);
+    jf::launch(k, dim3((unsigned)generic_grid()), dim3(64), lds, (hipStream_t)stream, a);
     return check_launch();
 }
 
