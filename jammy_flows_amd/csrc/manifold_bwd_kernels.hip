@@ -289,7 +289,8 @@ __device__ inline void v_closed_potential(const T* __restrict__ ppv, int nc, T l
 // summed over the wave's rows, one atomic add per parameter), the potential's share of d S / d e is added to Ge (this lane's components only)
 template <typename T, int LV, int KIND>
 __device__ inline void v_closed_adjoint(const MBwdArgs<T, jf_v_layer>& a, const T* __restrict__ ppv, int nc, T lse, const T (&e)[3], const T (&Gg)[3],
-                                        const T (&Gj)[3][3], T GP0, T (&Ge)[3], int g, int tid, bool active, int64_t row, int col0, bool& bad) {
+                                        const T (&Gj)[3][3], T GP0, T (&Ge)[3], int g, int tid, bool active, int64_t row, int col0, bool& bad,
+                                        T* __restrict__ accp) {
     constexpr int n_prow = KIND == JF_V_EXPONENTIAL ? 5 : 4;
 #pragma unroll 1
     for (int k0 = 0; k0 < nc; k0 += 2 * LV) {
@@ -316,7 +317,7 @@ __device__ inline void v_closed_adjoint(const MBwdArgs<T, jf_v_layer>& a, const 
                 const int col = col0 + q * nc + k;
                 if (a.bcast) {
                     const T s = rows_sum<T, LV>(v);
-                    if (tid < LV && k < nc) atomicAdd(a.g_params + col, s);
+                    if (tid < LV && k < nc) accp[col] += s;          // the workgroup's sums (one wave: no atomic), added to g_params at the end
                 } else if (active && k < nc) {
                     a.g_params[row * a.gps + col] = v;
                 }
@@ -344,13 +345,13 @@ __global__ void __launch_bounds__(64, WPE) vchain_bwd_kernel(const MBwdArgs<T, j
     T* row_mem = reinterpret_cast<T*>(dual0 + 64 * (a.tab + a.rot_max)) + (lane_in ? r : 0) * a.scratch;
     T* xin = row_mem;                                              // [layer][2]
     T* Gm = row_mem + 2 * a.n_layers;                              // [JF_V_G]
-    const int64_t row0 = (int64_t)blockIdx.x * rows;
-    const int64_t row = row0 + r;
-    const bool active = lane_in && row < a.B;
-    const int64_t rrow = active ? row : a.B - 1;
+    // broadcast parameters: a resident set of workgroups walks the row tiles and adds its gradient sums to g_params once (mchain_bwd_kernel above)
+    T* accp = row_mem - (lane_in ? r : 0) * a.scratch + (size_t)rows * a.scratch;      // behind the rows' scratch
+    const int64_t row0_first = (int64_t)blockIdx.x * rows;
     if (a.bcast) {
-        for (int j = tid; j < a.P; j += 64) tile[j] = a.params[j];
+        for (int j = tid; j < a.P; j += 64) { tile[j] = a.params[j]; accp[j] = T(0); }
     } else {
+        const int64_t row0 = row0_first;
         // the rows' parameters, eight loads in flight per lane (a row at a time is one dependent load after the other: 64 x ~1 us)
         const int total = rows * a.P;
         for (int i0 = 0; i0 < total; i0 += 64 * 8) {
@@ -372,6 +373,14 @@ __global__ void __launch_bounds__(64, WPE) vchain_bwd_kernel(const MBwdArgs<T, j
     }
     __syncthreads();
     const T* prow = tile + (a.bcast ? 0 : (lane_in ? r : 0) * a.tile_stride);
+    bool bad_any = false;
+    const int64_t n_tiles = (a.B + rows - 1) / rows;
+    const int64_t t_end = a.bcast ? n_tiles : (int64_t)blockIdx.x + 1;
+    for (int64_t tile_i = blockIdx.x; tile_i < t_end; tile_i += gridDim.x) {
+    const int64_t row0 = tile_i * rows;
+    const int64_t row = row0 + r;
+    const bool active = lane_in && row < a.B;
+    const int64_t rrow = active ? row : a.B - 1;
     const T gld = (a.g_ld && active) ? a.g_ld[rrow] : T(0);
     const T gblp = (a.g_blp && active) ? a.g_blp[rrow] : T(0);
     const T gxo[2] = {(a.g_xout && active) ? a.g_xout[rrow * a.gxos + 0] : T(0), (a.g_xout && active) ? a.g_xout[rrow * a.gxos + 1] : T(0)};
@@ -500,9 +509,9 @@ __global__ void __launch_bounds__(64, WPE) vchain_bwd_kernel(const MBwdArgs<T, j
         // (2) the potential's parameters
         if (closed) {
             const int col = a.col0[l] + n_rot;
-            if (kind == JF_V_EXPONENTIAL) v_closed_adjoint<T, LV, JF_V_EXPONENTIAL>(a, ppv, nc, lse0, e0, Gg, Gj, GP0, Ge, g, tid, active, row, col, bad);
-            else if (kind == JF_V_LINEAR) v_closed_adjoint<T, LV, JF_V_LINEAR>(a, ppv, nc, lse0, e0, Gg, Gj, GP0, Ge, g, tid, active, row, col, bad);
-            else v_closed_adjoint<T, LV, JF_V_QUADRATIC>(a, ppv, nc, lse0, e0, Gg, Gj, GP0, Ge, g, tid, active, row, col, bad);
+            if (kind == JF_V_EXPONENTIAL) v_closed_adjoint<T, LV, JF_V_EXPONENTIAL>(a, ppv, nc, lse0, e0, Gg, Gj, GP0, Ge, g, tid, active, row, col, bad, accp);
+            else if (kind == JF_V_LINEAR) v_closed_adjoint<T, LV, JF_V_LINEAR>(a, ppv, nc, lse0, e0, Gg, Gj, GP0, Ge, g, tid, active, row, col, bad, accp);
+            else v_closed_adjoint<T, LV, JF_V_QUADRATIC>(a, ppv, nc, lse0, e0, Gg, Gj, GP0, Ge, g, tid, active, row, col, bad, accp);
 #pragma unroll
             for (int c = 0; c < 3; ++c) Ge[c] = Ge0[c] + group_sum<T, LV>(Ge[c]);
         }
@@ -562,7 +571,7 @@ __global__ void __launch_bounds__(64, WPE) vchain_bwd_kernel(const MBwdArgs<T, j
                 if (j0 <= t && t < j0 + LV) nup[t] = __shfl(gj_, (tid & ~(LV - 1)) + (t - j0), 64);
             if (a.bcast) {
                 const T s = rows_sum<T, LV>(gj_);
-                if (tid < LV && jin && j >= 2) atomicAdd(a.g_params + a.col0[l] + (j - 2), s);
+                if (tid < LV && jin && j >= 2) accp[a.col0[l] + (j - 2)] += s;
             } else if (active && jin && j >= 2) {
                 a.g_params[row * a.gps + a.col0[l] + (j - 2)] = gj_;
             }
@@ -570,7 +579,14 @@ __global__ void __launch_bounds__(64, WPE) vchain_bwd_kernel(const MBwdArgs<T, j
         up[0] = nup[0]; up[1] = nup[1];
     }
     if (active && g == 0) { a.g_x[row * a.gxs + 0] = up[0]; a.g_x[row * a.gxs + 1] = up[1]; }
-    status_add(a.status, JF_STATUS_NONFINITE, active && bad);
+    bad_any = bad_any || (active && bad);
+    __syncthreads();                                               // (the rows' scratch is rewritten by the next tile)
+    }
+    if (a.bcast) {
+        __syncthreads();
+        for (int j = tid; j < a.P; j += 64) atomicAdd(a.g_params + j, accp[j]);
+    }
+    status_add(a.status, JF_STATUS_NONFINITE, bad_any);
 }
 
 template <typename T, class Fam>
@@ -637,7 +653,7 @@ static int mchain_bwd(const T* x, int64_t xs, const T* params, int64_t ps, int32
         if (wide) { lds = ((size_t)(a.bcast ? 1 : a.rows) * a.tile_stride + (size_t)a.rows * (a.tab + a.scratch)) * sizeof(DualN<T, NW>) + accp; break; }
         if (staged) {                                              // plain-value parameter tile + per lane: knot table, rotation row (duals) + per row: scratch (values)
             const size_t tile_elems = (((size_t)(a.bcast ? 1 : a.rows) * a.tile_stride) + 1) & ~(size_t)1;
-            lds = tile_elems * sizeof(T) + (size_t)64 * (size_t)(a.tab + a.rot_max) * sizeof(Dual<T>) + (size_t)a.rows * (size_t)a.scratch * sizeof(T);
+            lds = tile_elems * sizeof(T) + (size_t)64 * (size_t)(a.tab + a.rot_max) * sizeof(Dual<T>) + (size_t)a.rows * (size_t)a.scratch * sizeof(T) + accp;
         } else
         lds = ((size_t)(a.bcast ? 1 : a.rows) * a.tile_stride + (size_t)a.rows * (a.tab + a.scratch)) * sizeof(DualN<T, 1>) + accp;
         if (lds <= 160 * 1024 || a.rows == 4) break;
@@ -648,7 +664,14 @@ static int mchain_bwd(const T* x, int64_t xs, const T* params, int64_t ps, int32
         if (staged) {
             auto kv = a.v_dual ? vchain_bwd_kernel<T, 1, 1, true> : vchain_bwd_kernel<T, 1, 1, false>;
             if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)kv, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            jf::launch(kv, dim3((unsigned)((B + a.rows - 1) / a.rows)), dim3(64), lds, (hipStream_t)stream, a);
+            int64_t grid = (B + a.rows - 1) / a.rows;
+            if (a.bcast) {                                         // a resident set of workgroups walks the tiles (four per CU)
+                int dev = 0, cus = 256;
+                (void)hipGetDevice(&dev);
+                (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+                if (grid > (int64_t)cus * 4) grid = (int64_t)cus * 4;
+            }
+            jf::launch(kv, dim3((unsigned)grid), dim3(64), lds, (hipStream_t)stream, a);
             return check_launch();
         }
     }
