@@ -192,4 +192,29 @@ template <typename T, int N> struct M<DualN<T, N>> {
     static __device__ __forceinline__ bool finite(D x) { return B::finite(x.v); }
 };
 
+// ---- values of a dual row / the implicit-function tangent (DualTraits, jf_math.h)
+template <typename T> struct DualTraits<Dual<T>> {
+    static constexpr bool is_dual = true;
+    using value_type = T;
+    static __host__ __device__ __forceinline__ T value(const Dual<T>& a) { return a.v; }
+    // x = xv with the tangent that solves f(x, p) = z:  dx = (dz - df|_{x fixed}) / f'(x)
+    static __host__ __device__ __forceinline__ Dual<T> implicit(T xv, const Dual<T>& z, const Dual<T>& f, T fprime) { return Dual<T>(xv, (z.d - f.d) / fprime); }
+};
+template <typename T, int N> struct DualTraits<DualN<T, N>> {
+    static constexpr bool is_dual = true;
+    using value_type = T;
+    static __host__ __device__ __forceinline__ T value(const DualN<T, N>& a) { return a.v; }
+    static __host__ __device__ __forceinline__ DualN<T, N> implicit(T xv, const DualN<T, N>& z, const DualN<T, N>& f, T fprime) {
+        DualN<T, N> r(xv);
+        const T inv = T(1) / fprime;
+        JF_DN_LOOP r.d[c] = (z.d[c] - f.d[c]) * inv;
+        return r;
+    }
+};
+// a row of duals read as its values
+template <typename D> struct DualValues {
+    const D* p;
+    __host__ __device__ __forceinline__ typename DualTraits<D>::value_type operator[](int i) const { return p[i].v; }
+};
+
 }  // namespace jf

@@ -135,22 +135,25 @@ struct OFam {
 // =================================================================================================  'm'
 // moebius_1d.py:140-259.  x in [-pi, pi].  value: sum_k pi_k * arg(Moebius_k(e^{ix})) normalised so that -pi -> -pi; deriv: sum_k pi_k (1-|w|^2)/|e^{ix}-w|^2
 // np: parameters per component, 4 = (omega_x, omega_y, logit length, log weight), 3 = (omega angle, logit length, log weight) (:175-178)
-template <typename T> __device__ inline void moebius_eval(const T* __restrict__ p, int nc, int np, T x, T& val, T& deriv) {
+// (ROW: anything indexable that yields T -- a plain pointer, or the values of a dual row, DualValues)
+template <typename T, typename ROW> __device__ inline void moebius_eval(ROW p, int nc, int np, T x, T& val, T& deriv) {
     const T cx = M<T>::cos(x), sx = M<T>::sin(x);
     const T cmp = T(-1), smp = (T)(-1.2246467991473532e-16);          // numpy.cos(-pi), numpy.sin(-pi)
     T lmax = p[np - 1];
     for (int k = 1; k < nc; ++k) lmax = M<T>::max(lmax, p[np * k + np - 1]);
     T wsum = T(0), vsum = T(0), dsum = T(0);
     for (int k = 0; k < nc; ++k) {
-        const T* q = p + np * k;
-        const T denom = logaddexp<T>(T(0), -q[np - 2]);
+        const int q = np * k;
+        const T denom = logaddexp<T>(T(0), -p[q + np - 2]);
         const T len = T(0.001) + M<T>::exp(T(-0.0020020026706730793) - denom);      // ln(0.999 - 0.001)
         T ox, oy;
         if (np == 4) {
-            const T nrm = len / M<T>::sqrt(q[0] * q[0] + q[1] * q[1]);
-            ox = q[0] * nrm; oy = q[1] * nrm;
+            const T q0 = p[q], q1 = p[q + 1];
+            const T nrm = len / M<T>::sqrt(q0 * q0 + q1 * q1);
+            ox = q0 * nrm; oy = q1 * nrm;
         } else {
-            ox = M<T>::cos(q[0]) * len; oy = M<T>::sin(q[0]) * len;
+            const T q0 = p[q];
+            ox = M<T>::cos(q0) * len; oy = M<T>::sin(q0) * len;
         }
         const T omo = T(1) - len * len;
         const T opo = T(1) + len * len - T(2) * (cx * ox + sx * oy);
@@ -162,7 +165,7 @@ template <typename T> __device__ inline void moebius_eval(const T* __restrict__ 
         const T xv = omo * (cx - ox) - ox * opo;
         const T cr = M<T>::cos(rot), sr = M<T>::sin(rot);
         const T arc = M<T>::atan2(sr * xv + cr * yv, cr * xv - sr * yv) + M<T>::PI;
-        const T w = M<T>::exp(q[np - 1] - lmax);
+        const T w = M<T>::exp(p[q + np - 1] - lmax);
         wsum += w;
         vsum += w * arc;
         dsum += w * (omo / opo);
@@ -170,7 +173,8 @@ template <typename T> __device__ inline void moebius_eval(const T* __restrict__ 
     val = vsum / wsum - M<T>::PI;
     deriv = dsum / wsum;
 }
-template <typename T> __device__ inline T moebius_solve(const T* __restrict__ p, int nc, int np, T z, LaneCtx<T>& c) {
+// the iteration of bisection_n_newton.py:171-238 on plain values
+template <typename T, typename ROW> __device__ inline T moebius_solve_values(ROW p, int nc, int np, T z, bool lane_valid, bool& nonconv, bool& nonfinite) {
     T lo = -M<T>::PI, hi = M<T>::PI, x = T(0), f, d;
     for (int it = 0; it < 20; ++it) {                                     // bisection_n_newton.py:171-182
         x = (hi + lo) * T(0.5);
@@ -179,7 +183,7 @@ template <typename T> __device__ inline T moebius_solve(const T* __restrict__ p,
         else if (f < z) lo = x;
         else hi = x;
     }
-    bool active = c.lane_valid;
+    bool active = lane_valid;
     T ferr = T(0);
     for (int it = 0; it < 20 && __any(active); ++it) {                    // :192-238
         moebius_eval<T>(p, nc, np, x, f, d);
@@ -190,9 +194,23 @@ template <typename T> __device__ inline T moebius_solve(const T* __restrict__ p,
             active = M<T>::abs(upd) >= T(1e-14);
         }
     }
-    c.nonconv = c.nonconv || (ferr > (sizeof(T) == 8 ? T(1e-7) : T(1e-4)));
-    c.nonfinite = c.nonfinite || !M<T>::finite(x);
+    nonconv = nonconv || (ferr > (sizeof(T) == 8 ? T(1e-7) : T(1e-4)));
+    nonfinite = nonfinite || !M<T>::finite(x);
     return x;
+}
+// Scalar types with tangents (the backward kernels' dual numbers): the iteration runs on the VALUES, and the solution's tangents follow from
+// ONE evaluation on dual numbers at the solution -- f(x, p) = z  =>  dx = (dz - df|_x) / f'(x) -- instead of 40 evaluations that drag the
+// tangents through every bisection and Newton step (round 5: the per-sample `m` adjoint took 34 x its forward).
+template <typename T> __device__ inline T moebius_solve(const T* __restrict__ p, int nc, int np, T z, LaneCtx<T>& c) {
+    if constexpr (DualTraits<T>::is_dual) {
+        using V = typename DualTraits<T>::value_type;
+        const V xv = moebius_solve_values<V>(DualValues<T>{p}, nc, np, DualTraits<T>::value(z), c.lane_valid, c.nonconv, c.nonfinite);
+        T f, d;
+        moebius_eval<T>(p, nc, np, T(xv), f, d);
+        return DualTraits<T>::implicit(xv, z, f, DualTraits<T>::value(d));
+    } else {
+        return moebius_solve_values<T>(p, nc, np, z, c.lane_valid, c.nonconv, c.nonfinite);
+    }
 }
 struct MFam {
     using CLayer = jf_m_layer;

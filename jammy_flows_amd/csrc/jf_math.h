@@ -15,6 +15,11 @@ namespace jf {
 
 template <typename T> struct M;
 
+// scalar types that carry tangents (jf_dual.h specialises this): the iterative solvers of the layer code run on the VALUES and give the
+// solution's tangents by the implicit-function theorem instead of dragging tangents through every iteration
+template <typename T> struct DualTraits { static constexpr bool is_dual = false; using value_type = T; };
+template <typename D> struct DualValues;           // a row of dual numbers read as its values (jf_dual.h)
+
 
 
 template <> struct M<float> {
