@@ -6,7 +6,7 @@
 // clamps), strictly-lower entries stored sub-diagonal by sub-diagonal starting from the bottom-left corner (matrix_fns.py:36-50).
 // The reference multiplies by an explicit inverse built from sub-determinants (matrix_fns.py:88-141); here the triangular system is solved by
 // forward substitution in registers (same result; D <= 32, kernels instantiated for 8 / 16 / 32 coordinates).  One sample per lane; row: [offset D if model_offset][log-diagonal 1 | D][lower D(D-1)/2].
-//   jf_t_layer_inv_* / jf_t_layer_fwd_* / jf_t_layer_inv_bwd_* (backward in forward mode on dual numbers, like the manifold chains)
+//   jf_t_layer_inv_* / jf_t_layer_fwd_* / jf_t_layer_inv_bwd_* (backward: one forward + one backward substitution, see t_bwd_kernel)
 #include "jf_dual.h"
 #include "jf_gf.h"
 
@@ -111,56 +111,107 @@ template <typename T, bool FWD, int MD> __global__ void __launch_bounds__(256) t
     status_add(a.status, JF_STATUS_NONFINITE, bad);
 }
 
-// backward of the log-prob direction, forward mode: one pass per input direction (D coordinates + P parameters) on dual numbers
+// backward of the log-prob direction in REVERSE mode (round 5; until then one dual-number pass per input direction: 75 passes for a full
+// 10 x 10 covariance, 50 x the forward).  z = L^-1 (x - offset) by forward substitution, then one backward substitution with the upstream
+// gradients zb_d = g_x_out[d] - z_d g_base_logp and g_log_det:
+//     z_i = acc_i e^{-s_i},  acc_i = x_i - off_i - sum_{j<i} L_ij z_j,  log_det -= s_i      (s_i = log of the regulated diagonal)
+//     acc_b_i = zb_i e^{-s_i};   s_b_i = -zb_i z_i - g_log_det;   x_b_i = acc_b_i;   off_b_i = -acc_b_i;   L_b_ij = -acc_b_i z_j;   zb_j -= acc_b_i L_ij
+// walked from the last row up; d s_i / d raw_i comes from one single-tangent evaluation of the width regulator per diagonal entry.
+// Per-sample parameters: g_params (B, P) rows.  Broadcast parameters: the workgroup's sums over ALL its row tiles in LDS, added to g_params
+// once at the end -- a resident set of workgroups walks the tiles (manifold_bwd_kernels.hip: one atomic per 64-row tile and parameter was
+// most of such a kernel's time).
 template <typename T, int MD> __global__ void __launch_bounds__(64) t_bwd_kernel(const TArgs<T> a) {
     using Du = Dual<T>;
     extern __shared__ __align__(16) unsigned char smem_raw[];
-    Du* tile = reinterpret_cast<Du*>(smem_raw);                       // [P][64] (per-sample) or [P] (broadcast): lane-contiguous columns
+    T* tile = reinterpret_cast<T*>(smem_raw);                         // [P][64] (per-sample) or [P] (broadcast): lane-contiguous columns
+    T* accp = tile + (a.P > 0 ? a.P : 1) * (a.bcast ? 1 : 64);         // broadcast: [P] gradient sums
     const int tid = threadIdx.x;
-    const int64_t row = (int64_t)blockIdx.x * 64 + tid;
-    const bool active = row < a.B;
-    const int64_t rrow = active ? row : a.B - 1;
-    const int D = a.o.D;
-    for (int j = 0; j < a.P; ++j) {
-        if (a.bcast) { if (tid == 0) tile[j] = Du(a.params[j]); }
-        else tile[j * 64 + tid] = Du(a.params[rrow * a.ps + j]);
+    const int D = a.o.D, cov = a.o.cov;
+    if (a.bcast) {
+        for (int j = tid; j < a.P; j += 64) { tile[j] = a.params[j]; accp[j] = T(0); }
+    } else {
+        const int64_t row = (int64_t)blockIdx.x * 64 + tid;
+        const int64_t rrow = row < a.B ? row : a.B - 1;
+        for (int j = 0; j < a.P; ++j) tile[j * 64 + tid] = a.params[rrow * a.ps + j];
     }
     __syncthreads();
-    TDev<Du> o;
-    o.cov = a.o.cov; o.model_offset = a.o.model_offset; o.D = D;
-    o.w.width_mode = a.o.w.width_mode; o.w.clamp_widths = a.o.w.clamp_widths;
-    o.w.wmin = Du(a.o.w.wmin); o.w.inv_wmax = Du(a.o.w.inv_wmax); o.w.lw_lo = Du(a.o.w.lw_lo); o.w.lw_hi = Du(a.o.w.lw_hi);
-    T x0[MD], gxo[MD];
-#pragma unroll
-    for (int d = 0; d < MD; ++d) {
-        x0[d] = d < D ? a.x[rrow * a.xs + d] : T(0);
-        gxo[d] = (d < D && a.g_xout && active) ? a.g_xout[rrow * a.gxos + d] : T(0);
-    }
-    const T gld = (a.g_ld && active) ? a.g_ld[rrow] : T(0);
-    const T gblp = (a.g_blp && active) ? a.g_blp[rrow] : T(0);
-    const Du* p = a.bcast ? tile : tile + tid;
+    TDev<Du> od;                                                      // the width regulator on single duals: d log(diagonal) / d raw
+    od.cov = cov; od.model_offset = a.o.model_offset; od.D = D;
+    od.w.width_mode = a.o.w.width_mode; od.w.clamp_widths = a.o.w.clamp_widths;
+    od.w.wmin = Du(a.o.w.wmin); od.w.inv_wmax = Du(a.o.w.inv_wmax); od.w.lw_lo = Du(a.o.w.lw_lo); od.w.lw_hi = Du(a.o.w.lw_hi);
+    const T* p = a.bcast ? tile : tile + tid;
     const int64_t pstep = a.bcast ? 1 : 64;
-    for (int j = 0; j < D + a.P; ++j) {
-        if (j >= D) { if (a.bcast) { if (tid == 0) tile[j - D].d = T(1); } else tile[(j - D) * 64 + tid].d = T(1); }
+    auto P = [&](int i) -> T { return p[i * pstep]; };
+    const int c0 = a.o.model_offset ? D : 0;                          // first diagonal parameter
+    const int n_diag = cov == JF_T_IDENTITY ? 0 : cov == JF_T_DIAGONAL_SYMMETRIC ? 1 : D;
+    const int lo = c0 + D;                                            // first strictly-lower entry (full covariance)
+    const int64_t n_tiles = (a.B + 63) / 64;
+    const int64_t t_end = a.bcast ? n_tiles : (int64_t)blockIdx.x + 1;    // per-sample parameters: the tile staged above
+    for (int64_t tile_i = blockIdx.x; tile_i < t_end; tile_i += gridDim.x) {
+        const int64_t row = tile_i * 64 + tid;
+        const bool active = row < a.B;
+        const int64_t rrow = active ? row : a.B - 1;
+        // a parameter's gradient of this row: stored (per-sample) or summed over the wave into the workgroup's accumulators (broadcast)
+        auto emit = [&](int j, T v) {
+            if (!active) v = T(0);
+            if (a.bcast) {
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+                if (tid == 0) accp[j] += v;
+            } else if (active) {
+                a.g_params[row * a.gps + j] = v;
+            }
+        };
+        T z[MD], zb[MD];
+#pragma unroll
+        for (int d = 0; d < MD; ++d) z[d] = d < D ? a.x[rrow * a.xs + d] : T(0);
+        T ld = T(0);
+        if (cov != JF_T_IDENTITY || a.o.model_offset) t_apply<T, false, MD>(a.o, p, pstep, z, ld);
+        const T gld = (a.g_ld && active) ? a.g_ld[rrow] : T(0);
+        const T gblp = (a.g_blp && active) ? a.g_blp[rrow] : T(0);
+#pragma unroll
+        for (int d = 0; d < MD; ++d) zb[d] = d < D ? ((a.g_xout && active) ? a.g_xout[rrow * a.gxos + d] : T(0)) - z[d] * gblp : T(0);
+        // d log(diagonal_i) / d raw_i and e^{-s_i}
+        T sb_sym = T(0);
+        if (cov == JF_T_FULL) {
+#pragma unroll
+            for (int i = MD - 1; i >= 0; --i) if (i < D) {
+                const Du s = t_log_diag<Du>(od, Du(P(c0 + i), T(1)));
+                const T ab = zb[i] * M<T>::exp(-s.v);              // acc_b_i = x_b_i
+                emit(c0 + i, (-zb[i] * z[i] - gld) * s.d);
+#pragma unroll
+                for (int j = 0; j < MD; ++j) if (j < i) {
+                    const int li = lo + t_lower_index(D, i, j);
+                    emit(li, -ab * z[j]);
+                    zb[j] -= ab * P(li);
+                }
+                zb[i] = ab;
+            }
+        } else if (cov == JF_T_DIAGONAL) {
+#pragma unroll
+            for (int i = 0; i < MD; ++i) if (i < D) {
+                const Du s = t_log_diag<Du>(od, Du(P(c0 + i), T(1)));
+                emit(c0 + i, (-zb[i] * z[i] - gld) * s.d);
+                zb[i] *= M<T>::exp(-s.v);
+            }
+        } else if (cov == JF_T_DIAGONAL_SYMMETRIC) {
+            const Du s = t_log_diag<Du>(od, Du(P(c0), T(1)));
+            const T f = M<T>::exp(-s.v);
+#pragma unroll
+            for (int i = 0; i < MD; ++i) if (i < D) { sb_sym -= zb[i] * z[i]; zb[i] *= f; }
+            emit(c0, (sb_sym - gld * T(D)) * s.d);
+        }
+        (void)n_diag;
+        // zb is now d S / d (x - offset)
+#pragma unroll
+        for (int d = 0; d < MD; ++d) if (d < D) {
+            if (active) a.g_x[row * a.gxs + d] = zb[d];
+            if (a.o.model_offset) emit(d, -zb[d]);
+        }
+    }
+    if (a.bcast) {
         __syncthreads();
-        Du x[MD];
-#pragma unroll
-        for (int d = 0; d < MD; ++d) x[d] = Du(x0[d], d == j ? T(1) : T(0));
-        Du ld(T(0));
-        if (a.o.cov != JF_T_IDENTITY || a.o.model_offset) t_apply<Du, false, MD>(o, p, pstep, x, ld);
-        T gj = gld * ld.d;
-#pragma unroll
-        for (int d = 0; d < MD; ++d) if (d < D) gj += (gxo[d] - x[d].v * gblp) * x[d].d;
-        if (!active) gj = T(0);
-        if (j < D) { if (active) a.g_x[row * a.gxs + j] = gj; }
-        else if (a.bcast) {
-            T s = gj;
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-            if (tid == 0) atomicAdd(a.g_params + (j - D), s);
-        } else if (active) a.g_params[row * a.gps + (j - D)] = gj;
-        __syncthreads();
-        if (j >= D) { if (a.bcast) { if (tid == 0) tile[j - D].d = T(0); } else tile[(j - D) * 64 + tid].d = T(0); }
+        for (int j = tid; j < a.P; j += 64) atomicAdd(a.g_params + j, accp[j]);
     }
 }
 
@@ -208,11 +259,18 @@ static int t_layer_bwd(const T* x, int64_t xs, const T* params, int64_t ps, int3
     if (B == 0) return JF_OK;
     a.x = x; a.xs = xs; a.params = params; a.ps = ps; a.bcast = pb == 1; a.B = B;
     a.g_xout = g_xout; a.gxos = gxos; a.g_ld = g_ld; a.g_blp = g_blp; a.g_x = g_x; a.gxs = gxs; a.g_params = g_params; a.gps = gps; a.status = status;
-    const size_t lds = (size_t)(a.P > 0 ? a.P : 1) * (a.bcast ? 1 : 64) * sizeof(Dual<T>);
+    const size_t lds = ((size_t)(a.P > 0 ? a.P : 1) * (a.bcast ? 1 : 64) + (a.bcast ? (size_t)a.P : 0)) * sizeof(T);
     if (lds > 160 * 1024) return JF_ERR_UNSUPPORTED;
     auto k = D <= 8 ? t_bwd_kernel<T, 8> : D <= 16 ? t_bwd_kernel<T, 16> : t_bwd_kernel<T, 32>;
     if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    jf::launch(k, dim3((unsigned)((B + 63) / 64)), dim3(64), lds, (hipStream_t)stream, a);
+    int64_t grid = (B + 63) / 64;
+    if (a.bcast) {                                                 // a resident set of workgroups walks the tiles (eight per CU: the kernel is light)
+        int dev = 0, cus = 256;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        if (grid > (int64_t)cus * 8) grid = (int64_t)cus * 8;
+    }
+    jf::launch(k, dim3((unsigned)grid), dim3(64), lds, (hipStream_t)stream, a);
     return check_launch();
 }
 
