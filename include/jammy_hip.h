@@ -425,7 +425,8 @@ int jf_mlp2_i8_seg_f64(const jf_cond_segment* segments, int32_t n_segments, cons
  * Row: [offset D if model_offset][raw log-diagonal: 1 (diagonal_symmetric) | D (diagonal, full)][strictly-lower entries D(D-1)/2 (full),
  * sub-diagonal by sub-diagonal from the bottom-left corner, matrix_fns.py:36-50].  log L_ii = the same width regulators as 'g'.  D <= 8.
  * base_logp_out (nullable) as for jf_gf_chain_inv.  jf_t_layer_inv_bwd: backward of the log-prob direction (same conventions as
- * jf_<fam>_chain_inv_bwd below: per-sample g_params (B, P), broadcast row sums ADDED into (1, P)).
+ * jf_<fam>_chain_inv_bwd below: per-sample g_params (B, P), broadcast row sums ADDED into (1, P)); reverse mode in closed form: one forward
+ * and one backward substitution per row.
  * ------------------------------------------------------------------------------------------------------------ */
 enum { JF_T_IDENTITY = 0, JF_T_DIAGONAL_SYMMETRIC = 1, JF_T_DIAGONAL = 2, JF_T_FULL = 3 };
 typedef struct jf_t_layer { int32_t cov_type, model_offset, width_mode, clamp_widths; double width_min, width_max; } jf_t_layer;
@@ -556,8 +557,9 @@ JF_DECLARE_COND_MCHAIN(f, float, f32)
 JF_DECLARE_COND_MCHAIN(f, double, f64)
 
 /* Backward of jf_<fam>_chain_inv_*: vector-Jacobian product for upstream gradients of (x_out, log_det_out, base_logp_out) (each nullable = 0),
- * i.e. torch.autograd over the layer loop of all_layer_inverse (main/default.py:998-1031) for a manifold block.  Evaluated in forward mode:
- * one pass of the chain per input direction on dual numbers through the same device code as the forward kernels.  g_x (B, dim);
+ * i.e. torch.autograd over the layer loop of all_layer_inverse (main/default.py:998-1031) for a manifold block.  Evaluated in forward mode
+ * (one pass of the chain per group of input directions on dual numbers through the same device code as the forward kernels) except for
+ * 'v', whose exponential map and closed-form potentials have hand-written reverse-mode adjoints.  g_x (B, dim);
  * g_params: (B, P) for per-sample parameters; for param_batch == 1 the row sums are ADDED into g_params (1, P) (zero it first).
  * g_log_det_in = g_log_det, g_base_logp_in = g_base_logp (pass through). */
 #define JF_DECLARE_MCHAIN_BWD(fam, T, suffix)                                                                                          \
