@@ -644,8 +644,9 @@ def other_direction(args, W, rank, local_rank, world):
         secs = kstat["mean_ms"] * 1e-3
         bytes_per_row, flops_per_row, fused = kernel_accounting(kname.replace("_fwd", "_inv"), ktag, s)
         if bytes_per_row is None or bytes_per_row == 0:
-            P = {"c3": 548, "c5": 1224}[args.workload]
-            D = {"c3": 4, "c5": 8}[args.workload]
+            # per-row parameters / coordinates of the dominant block (0 parameters: permanent ones, shared by every row)
+            P = {"c1": 0, "c2": 0, "c3": 548, "c4": 8, "c5": 1224}[args.workload]
+            D = {"c1": 2, "c2": 4, "c3": 4, "c4": 1, "c5": 8}[args.workload]
             mult = 3 if kname.endswith("_bwd" + ("_f32" if s == 4 else "_f64")) else 1      # adjoint: parameters read twice, their gradient written
             bytes_per_row = s * (mult * P + (2 + mult) * (D + 1))
         gbs = bytes_per_row * B / secs / 1e9
@@ -1134,8 +1135,9 @@ def main():
         secs = kstat["mean_ms"] * 1e-3 / concurrency
         bytes_per_row, flops_per_row, fused = kernel_accounting(kname, ktag, s)
         if bytes_per_row is None:                        # per-sample g-chain: the block's row (C3 block 2: 548 floats, C5 block 0: 1224 doubles)
-            P = {"c3": 548, "c5": 1224}[args.workload]
-            D = {"c3": 4, "c5": 8}[args.workload]
+            # per-row parameters / coordinates of the dominant block (0 parameters: permanent ones, shared by every row)
+            P = {"c1": 0, "c2": 0, "c3": 548, "c4": 8, "c5": 1224}[args.workload]
+            D = {"c1": 2, "c2": 4, "c3": 4, "c4": 1, "c5": 8}[args.workload]
             bytes_per_row = s * (D + 1 + P + D + 1)
         hbm_gbs = bytes_per_row * B / secs / 1e9
         tr = traffic_of(traffic, kname, ktag)

@@ -24,7 +24,9 @@ for wl in ("c3", "c5"):
 for src, dst in (("bench_r05_default.json", "r05_bench_c3.json"), ("bench_r05_one_stream.json", "r05_bench_c3_one_stream.json"),
                  ("bench_r05_c5.json", "r05_bench_c5.json"), ("bench_r05_c2.json", "r05_bench_c2.json"), ("bench_r05_c4.json", "r05_bench_c4.json"),
                  ("bench_r05_c3_train.json", "r05_bench_c3_train.json"), ("bench_r05_c5_train.json", "r05_bench_c5_train.json"),
-                 ("bench_r05_c3_sample.json", "r05_bench_c3_sample.json"), ("bench_r05_c5_sample.json", "r05_bench_c5_sample.json")):
+                 ("bench_r05_c3_sample.json", "r05_bench_c3_sample.json"), ("bench_r05_c5_sample.json", "r05_bench_c5_sample.json"),
+                 ("bench_r05_c2_train.json", "r05_bench_c2_train.json"), ("bench_r05_c4_train.json", "r05_bench_c4_train.json"),
+                 ("bench_r05_c2_sample.json", "r05_bench_c2_sample.json"), ("bench_r05_c4_sample.json", "r05_bench_c4_sample.json")):
     if os.path.exists(os.path.join(G, src)):
         shutil.copy(os.path.join(G, src), os.path.join(P, dst))
 

@@ -27,6 +27,10 @@ for wl in c3 c5; do
   rocprofv3 --kernel-trace --stats -d $out/stats -- python3 bench.py --no-pmc --no-sweep --no-cpu-baseline --workload $wl --scaling weak --train > $out/stats.log 2>&1
   f=$(find $out/stats -name "*.db" | head -1); [ -n "$f" ] && python3 scripts/rocprof_summary.py $f > $out/kernel_stats.md 2>&1; rm -rf $out/stats
 done
+for wl in c2 c4; do
+  python3 bench.py --no-pmc --no-cpu-baseline --no-sweep --workload $wl --train > gpurun_out/bench_r05_${wl}_train.json 2> gpurun_out/bench_r05_${wl}_train.err
+  python3 bench.py --no-pmc --no-cpu-baseline --no-sweep --workload $wl --direction sample > gpurun_out/bench_r05_${wl}_sample.json 2> gpurun_out/bench_r05_${wl}_sample.err
+done
 for wl in c3 c5; do
   python3 bench.py --no-pmc --workload $wl --scaling weak --train > gpurun_out/bench_r05_${wl}_train.json 2> gpurun_out/bench_r05_${wl}_train.err
   python3 bench.py --no-pmc --workload $wl --scaling weak --direction sample > gpurun_out/bench_r05_${wl}_sample.json 2> gpurun_out/bench_r05_${wl}_sample.err
