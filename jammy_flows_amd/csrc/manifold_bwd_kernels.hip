@@ -28,6 +28,7 @@ template <typename T, typename CLayer> struct MBwdArgs {
     int n_layers, dim, P, tile_stride, scratch, rows, tab;       // tab: JF_SPLINE_TAB or 0 (no spline in the chain), as in manifold_kernels.hip
     int rot_max;                                                 // staged 'v' kernel: longest rotation row of the chain (lane-private dual copy)
     int v_dual;                                                  // staged 'v' kernel: dual-number replay for EVERY potential (JF_V_BWD_DUAL: the check of the closed form)
+    int shared_tab;                                              // generic kernel, broadcast parameters, families with a build(): the layers' knot tables once per workgroup and pass
     int col0[JF_MAX_MCHAIN];
     CLayer L[JF_MAX_MCHAIN];
     const T* g_xout; int64_t gxos;
@@ -48,11 +49,102 @@ template <typename T> __device__ __forceinline__ T wave_sum(T v) {
     return v;
 }
 
+template <class Fam, class = void> struct bwd_has_build : std::false_type {};
+template <class Fam> struct bwd_has_build<Fam, std::void_t<decltype(Fam::HAS_BUILD)>> : std::true_type {};
+
+// Broadcast parameters of a family whose knot table does not depend on the row ('r'): a pass's dual tables are the same for EVERY row, and
+// building them (softmax + cumulative sums + softplus on N-tangent duals: ~3 bins transcendentals per layer) is most of a pass.  The resident
+// workgroup therefore takes the directions OUTSIDE its row tiles: seed, build each layer's table once (lane l builds layer l), then walk the
+// tiles with the closed-form bin evaluation only.  (Per lane the saving is the build of every tile but the first; with four tiles per
+// workgroup at 2^18 rows: C4's `r` adjoint 0.246 -> see DESIGN 3.9.)
+template <typename T, class Fam, int N>
+__device__ __forceinline__ void mchain_bwd_shared_tab(const MBwdArgs<T, typename Fam::CLayer>& a, unsigned char* smem_raw) {
+    using Du = DualN<T, N>;
+    Du* tile = reinterpret_cast<Du*>(smem_raw);                      // [tile_stride] dual parameter row (all layers)
+    Du* stab = tile + a.tile_stride;                                 // [n_layers][a.tab] the pass's knot tables
+    const int tid = threadIdx.x;
+    const int rows = a.rows;
+    const bool lane_in = tid < rows;
+    const int slot = lane_in ? tid : 0;
+    Du* corr = stab + a.n_layers * a.tab + slot * a.scratch;
+    T* accp = reinterpret_cast<T*>(stab + a.n_layers * a.tab + rows * a.scratch);
+    for (int j = tid; j < a.P; j += 64) { tile[j] = Du(a.params[j]); accp[j] = T(0); }
+    __syncthreads();
+    bool bad_any = false;
+    const int64_t n_tiles = (a.B + rows - 1) / rows;
+    const int n_dir = a.dim + a.P;
+    for (int j0 = 0; j0 < n_dir; j0 += N) {
+        if (tid == 0) {
+#pragma unroll
+            for (int c = 0; c < N; ++c) if (j0 + c >= a.dim && j0 + c < n_dir) tile[j0 + c - a.dim].d[c] = T(1);
+        }
+        __syncthreads();
+        if (tid < a.n_layers) Fam::template build<Du>(a.L[tid], tile + a.col0[tid], stab + tid * a.tab);
+        __syncthreads();
+        for (int64_t tile_i = blockIdx.x; tile_i < n_tiles; tile_i += gridDim.x) {
+            const int64_t row = tile_i * rows + tid;
+            const bool active = lane_in && row < a.B;
+            const int64_t rrow = active ? row : a.B - 1;
+            T gxo[3] = {T(0), T(0), T(0)};
+            Du x[3];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                x[d] = Du((d < Fam::DIM && d < a.dim) ? a.x[rrow * a.xs + d] : T(0));
+                if (d < Fam::DIM && d < a.dim && a.g_xout && active) gxo[d] = a.g_xout[rrow * a.gxos + d];
+#pragma unroll
+                for (int c = 0; c < N; ++c) if (d == j0 + c) x[d].d[c] = T(1);
+            }
+            const T gld = (a.g_ld && active) ? a.g_ld[rrow] : T(0);
+            const T gblp = (a.g_blp && active) ? a.g_blp[rrow] : T(0);
+            Du ld(T(0));
+            LaneCtx<Du> ctx;
+            ctx.corr = corr; ctx.bins = nullptr; ctx.bin_i = 0;
+            ctx.oob = ctx.nonconv = ctx.nonfinite = false;
+            ctx.lane_valid = active;
+            ctx.tab_built = true;
+            for (int i = 0; i < a.n_layers; ++i) {
+                const int l = a.n_layers - 1 - i;
+                ctx.tab = stab + l * a.tab;
+                if (lane_in) Fam::template apply<Du, false>(a.L[l], tile + a.col0[l], x, ld, ctx);
+            }
+            bool bad = false;
+#pragma unroll
+            for (int c = 0; c < N; ++c) {
+                const int j = j0 + c;
+                if (j >= n_dir) break;
+                T gj = gld * ld.d[c];
+#pragma unroll
+                for (int d = 0; d < Fam::DIM; ++d) if (d < a.dim) gj += (gxo[d] - x[d].v * gblp) * x[d].d[c];
+                if (!active) gj = T(0);
+                bad = bad || !M<T>::finite(gj);
+                if (j < a.dim) {
+                    if (active) a.g_x[row * a.gxs + j] = gj;
+                } else {
+                    const T s = wave_sum<T>(gj);
+                    if (tid == 0) accp[j - a.dim] += s;
+                }
+            }
+            bad_any = bad_any || (active && bad);
+        }
+        __syncthreads();
+        if (tid == 0) {
+#pragma unroll
+            for (int c = 0; c < N; ++c) if (j0 + c >= a.dim && j0 + c < n_dir) tile[j0 + c - a.dim].d[c] = T(0);
+        }
+    }
+    __syncthreads();
+    for (int j = tid; j < a.P; j += 64) atomicAdd(a.g_params + j, accp[j]);
+    status_add(a.status, JF_STATUS_NONFINITE, bad_any);
+}
+
 // N: input directions per pass (DualN<T, N>, jf_dual.h): the value part of the chain is evaluated once per pass
 template <typename T, class Fam, int N>
 __global__ void __launch_bounds__(64) mchain_bwd_kernel(const MBwdArgs<T, typename Fam::CLayer> a) {
     using Du = DualN<T, N>;
     extern __shared__ __align__(16) unsigned char smem_raw[];
+    if constexpr (bwd_has_build<Fam>::value) {
+        if (a.shared_tab) { mchain_bwd_shared_tab<T, Fam, N>(a, smem_raw); return; }      // (uniform)
+    }
     Du* tile = reinterpret_cast<Du*>(smem_raw);
     const int tid = threadIdx.x;
     const int rows = a.rows;
@@ -645,17 +737,20 @@ static int mchain_bwd(const T* x, int64_t xs, const T* params, int64_t ps, int32
     constexpr int NW = std::is_same<Fam, FFam>::value && sizeof(T) == 4 ? 6 : 4;    // 'f' float32 (2 + 10 directions by default): two passes
     bool wide = false;
     if (!staged) {
-        const size_t lds4 = ((size_t)(a.bcast ? 1 : 64) * a.tile_stride + (size_t)64 * (a.tab + a.scratch)) * sizeof(DualN<T, NW>) + (a.bcast ? (size_t)a.P * sizeof(T) : 0);
+        a.shared_tab = (bwd_has_build<Fam>::value && a.bcast && a.tab > 0) ? 1 : 0;      // ('r' with permanent parameters: mchain_bwd_shared_tab)
+        const size_t lds4 = ((size_t)(a.bcast ? 1 : 64) * a.tile_stride + (size_t)(a.shared_tab ? n_layers : 64) * a.tab + (size_t)64 * a.scratch) * sizeof(DualN<T, NW>) +
+                            (a.bcast ? (size_t)a.P * sizeof(T) : 0);
         wide = lds4 <= 64 * 1024;                                  // (also leaves room for two workgroups per CU)
     }
     for (;;) {
         const size_t accp = a.bcast ? (size_t)a.P * sizeof(T) : 0;            // generic kernel, broadcast parameters: the workgroup's gradient sums
-        if (wide) { lds = ((size_t)(a.bcast ? 1 : a.rows) * a.tile_stride + (size_t)a.rows * (a.tab + a.scratch)) * sizeof(DualN<T, NW>) + accp; break; }
+        const size_t tabs = (size_t)(a.shared_tab ? n_layers : a.rows) * a.tab;
+        if (wide) { lds = ((size_t)(a.bcast ? 1 : a.rows) * a.tile_stride + tabs + (size_t)a.rows * a.scratch) * sizeof(DualN<T, NW>) + accp; break; }
         if (staged) {                                              // plain-value parameter tile + per lane: knot table, rotation row (duals) + per row: scratch (values)
             const size_t tile_elems = (((size_t)(a.bcast ? 1 : a.rows) * a.tile_stride) + 1) & ~(size_t)1;
             lds = tile_elems * sizeof(T) + (size_t)64 * (size_t)(a.tab + a.rot_max) * sizeof(Dual<T>) + (size_t)a.rows * (size_t)a.scratch * sizeof(T) + accp;
         } else
-        lds = ((size_t)(a.bcast ? 1 : a.rows) * a.tile_stride + (size_t)a.rows * (a.tab + a.scratch)) * sizeof(DualN<T, 1>) + accp;
+        lds = ((size_t)(a.bcast ? 1 : a.rows) * a.tile_stride + tabs + (size_t)a.rows * a.scratch) * sizeof(DualN<T, 1>) + accp;
         if (lds <= 160 * 1024 || a.rows == 4) break;
         a.rows >>= 1;
     }
