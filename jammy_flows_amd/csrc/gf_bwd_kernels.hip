@@ -48,6 +48,7 @@ template <typename T> struct GfBwdArgs {
     int active_blocks;                        // broadcast regime: workgroups that take tiles (one resident round); the others write a zero row
     int pk0[JF_MAX_CHAIN];                    // broadcast regime: first packed component record of every layer (gf_chain_bwd_kernel)
     int slsh;                                 // broadcast regime: log2 of the accumulator slots per parameter (see gf_chain_bwd_kernel)
+    int spline_tab;                           // general-option kernel: words of a lane's knot table (0: no spline stretch in the chain)
 };
 
 // d log(1/w) / d(raw log-width) and 1/w for one component (gaussianization_flow.py:269-317)
@@ -682,6 +683,7 @@ __global__ void __launch_bounds__(GX_THREADS) gfx_chain_bwd_kernel(const GfBwdAr
     Du* lds = reinterpret_cast<Du*>(smem_raw);
     T* red = reinterpret_cast<T*>(lds + JF_MAX_D_GF * GX_THREADS);       // one partial per wave (broadcast regime)
     const int tid = threadIdx.x, D = a.D;
+    Du* tab = reinterpret_cast<Du*>(red + 16) + tid * a.spline_tab;      // lane-private knot table (chains with a spline stretch)
     const XCol<Du> x{lds + tid};
     const bool bcast = pstep == 0;
     const int n_dir = D + a.n_params_total;
@@ -702,6 +704,15 @@ __global__ void __launch_bounds__(GX_THREADS) gfx_chain_bwd_kernel(const GfBwdAr
                 const SeededRow<T> p{prow + o.col0, j - D - o.col0};
                 if (o.model_offset) for (int d = 0; d < D; ++d) x[d] = x[d] - p[d];
                 gx_rotate<Du, SeededRow<T>>(o, p, x, D, true);
+                if (o.stretch == JF_GF_STRETCH_RQ_SPLINES) {       // gaussianization_flow.py:863-909 (the log-prob direction evaluates the spline itself)
+                    for (int d = 0; d < D; ++d) {
+                        const SplineOut<Du> r = spline_linext<Du, SeededRow<T>>(p + (o.off_mean + d * o.K), p + (o.off_lw + d * o.K), p + (o.off_ln + d * (o.K + 1)),
+                                                                                p + (o.off_box + d * 4), o.K, tab, x[d], false);
+                        x[d] = r.y;
+                        ld = ld + r.lad;
+                    }
+                    continue;
+                }
                 for (int d = 0; d < D; ++d) {
                     const GxCoord<Du> c = gx_prepare<Du, SeededRow<T>>(o, p, D, d);
                     const IcdfOut<Du> s = gf_icdf<Du>(o.inv_type, gx_mixture<Du, SeededRow<T>>(o, p, D, d, c, x[d]));
@@ -758,12 +769,16 @@ template <typename T> static int gb_fill(GfBwdArgs<T>& a, const T* params, int64
         if (ext_layer) ext = true;
         if (ext_layer && D > JF_MAX_D_GF) return JF_ERR_UNSUPPORTED;
         if (h.width_mode == JF_GF_WIDTH_SMOOTH_SATURATION && h.width_max <= 0) return JF_ERR_BADARG;
-        if (h.nonlinear_stretch_type != JF_GF_STRETCH_CLASSIC) return JF_ERR_UNSUPPORTED;
+        if (h.nonlinear_stretch_type != JF_GF_STRETCH_CLASSIC && h.nonlinear_stretch_type != JF_GF_STRETCH_RQ_SPLINES) return JF_ERR_BADARG;
+        const bool rq = h.nonlinear_stretch_type == JF_GF_STRETCH_RQ_SPLINES;      // spline stretch: the general-option kernel (one lane per row, lane-private knot table)
+        if (rq && (h.center_mean || h.add_skewness)) return JF_ERR_BADARG;
+        if (rq && (h.num_kde > JF_SPLINE_MAX_BINS || D > JF_MAX_D_GF)) return JF_ERR_UNSUPPORTED;
+        if (rq) { ext = true; if (spline_tab_words(h.num_kde) > a.spline_tab) a.spline_tab = spline_tab_words(h.num_kde); }
         o.K = h.num_kde; o.hh = h.hh_iter; o.model_offset = h.model_offset; o.fit_norm = h.fit_normalization;
         o.reg_norm = h.regulate_normalization; o.inv_type = h.inverse_function_type; o.width_mode = h.width_mode;
         o.clamp_widths = h.clamp_widths;
         o.fast = (h.width_mode == JF_GF_WIDTH_SMOOTH_SATURATION && !h.clamp_widths && h.fit_normalization && h.regulate_normalization) ? 1 : 0;
-        o.stretch = JF_GF_STRETCH_CLASSIC; o.off_box = 0;
+        o.stretch = h.nonlinear_stretch_type; o.off_box = 0;
         const int kd = h.num_kde * D;
         o.rot_mode = h.rotation_mode; o.center_mean = h.center_mean ? 1 : 0; o.skew = h.add_skewness ? 1 : 0;
         if (o.rot_mode != JF_GF_ROT_HOUSEHOLDER) o.hh = 0;
@@ -773,6 +788,11 @@ template <typename T> static int gb_fill(GfBwdArgs<T>& a, const T* params, int64
         o.off_ln = o.off_lw + kd;
         o.off_skew = o.off_ln + (h.fit_normalization ? kd : 0);
         o.n_params = o.off_skew + (o.skew ? kd : 0);
+        if (rq) {                                                  // row layout of a spline layer as in gf_kernels.hip: widths, heights (K D each), derivatives ((K + 1) D), box (4 D)
+            o.off_skew = 0;
+            o.off_box = o.off_ln + (h.num_kde + 1) * D;
+            o.n_params = o.off_box + 4 * D;
+        }
         o.col0 = col;
         o.vec_ok = (!bcast && aligned16<T>(params, ps, col) && (o.n_params % Vec16<T>::N == 0)) ? 1 : 0;
         o.wmin = (T)h.width_min; o.wmax = (T)h.width_max; o.inv_wmax = h.width_max > 0 ? (T)(1.0 / h.width_max) : T(0);
@@ -853,7 +873,8 @@ static int gf_chain_inv_bwd(const T* x, int64_t xs, const T* params, int64_t ps,
     if (ext) {                                                     // forward-mode kernel; broadcast: one partial row per workgroup, as the adjoint kernel
         const int64_t tiles = (B + GX_THREADS - 1) / GX_THREADS;
         const int64_t blocks = bcast ? gb_partials(B, D) : tiles;
-        const size_t lds = (size_t)JF_MAX_D_GF * GX_THREADS * sizeof(Dual<T>) + 16 * sizeof(T);
+        const size_t lds = (size_t)JF_MAX_D_GF * GX_THREADS * sizeof(Dual<T>) + 16 * sizeof(T) + (size_t)GX_THREADS * a.spline_tab * sizeof(Dual<T>);
+        if (lds > 160 * 1024) return JF_ERR_UNSUPPORTED;
         auto k = gfx_chain_bwd_kernel<T>;
         if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         jf::launch(k, dim3((unsigned)blocks), dim3(GX_THREADS), lds, (hipStream_t)stream, a, bcast ? (int64_t)0 : ps, tiles);
@@ -879,7 +900,7 @@ template <typename T> static int64_t gb_lds_query(int32_t D, int32_t n_layers, c
     bool ext = false;
     const int rc = gb_fill<T>(a, nullptr, 0, bcast != 0, D, n_layers, layers, ext);
     if (rc != JF_OK) return rc;
-    if (ext) return (int64_t)((size_t)JF_MAX_D_GF * GX_THREADS * sizeof(Dual<T>) + 16 * sizeof(T));
+    if (ext) return (int64_t)((size_t)JF_MAX_D_GF * GX_THREADS * sizeof(Dual<T>) + 16 * sizeof(T) + (size_t)GX_THREADS * a.spline_tab * sizeof(Dual<T>));
     const int G = gb_group_width(D);
     for (int l = 0; l < n_layers; ++l) if (layers[l].hh_iter > (G > GB_MAX_HH ? G : GB_MAX_HH)) return JF_ERR_UNSUPPORTED;
     if (!bcast) return (int64_t)((size_t)(((size_t)D * sizeof(T) >= 32) ? 1 : 2) * (64 / G) * a.tile_stride * sizeof(T));

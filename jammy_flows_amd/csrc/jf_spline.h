@@ -278,8 +278,9 @@ template <typename T> __device__ inline SplineOut<T> spline_circular(const T* __
 // spline_fns.py:188-358): eps = 0 search, clamped index, linear extension outside the box.
 // un_w / un_h / un_d point at this dimension's K / K / K+1 raw values; box = (left, ln(width-0.5), bottom, ln(height-0.5)).
 // ---------------------------------------------------------------------------------------------------------------
-template <typename T> __device__ inline SplineOut<T> spline_linext(const T* __restrict__ un_w, const T* __restrict__ un_h, const T* __restrict__ un_d,
-                                                                  const T* __restrict__ box, int nb, T* __restrict__ tab, T x, bool inverse) {
+// (ROW: anything indexable that yields T -- plain pointers, or the backward kernel's seeded view of a row of plain values)
+template <typename T, typename ROW = const T*> __device__ inline SplineOut<T> spline_linext(ROW un_w, ROW un_h, ROW un_d, ROW box, int nb, T* __restrict__ tab,
+                                                                                        T x, bool inverse) {
     KnotTab<T> t(tab, nb);
     const T left = box[0], right = left + M<T>::exp(box[1]) + T(0.5);      // gaussianization_flow.py:901-907
     const T bottom = box[2], top = bottom + M<T>::exp(box[3]) + T(0.5);
