@@ -1,5 +1,5 @@
 """forward / sampling / training step times of every golden fixture's pdf at one batch size (float64, fixture rows tiled): a scan for paths that are
-out of proportion (e.g. an adjoint at 30 x its forward).  python3 scripts/probe/scan_fixtures.py [rows] [name-substring]"""
+out of proportion (e.g. an adjoint at 30 x its forward).  python3 scripts/probe/scan_fixtures.py [rows] [name-substring] [f32|f64]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden")]
@@ -9,6 +9,7 @@ import fixture_io, helpers
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 16
 sub = sys.argv[2] if len(sys.argv) > 2 else ""
+DT = torch.float32 if (len(sys.argv) > 3 and sys.argv[3] == "f32") else torch.float64
 names = sorted(f[:-4] for f in os.listdir(fixture_io.GOLDEN_DIR) if f.endswith(".npz") and sub in f)
 
 
@@ -26,11 +27,11 @@ def timed(fn, n=8):
 for name in names:
     try:
         fx = fixture_io.load(name)
-        pdf = helpers.build_product(fx, torch.float64, torch.device("cuda"))
+        pdf = helpers.build_product(fx, DT, torch.device("cuda"))
         pdf.check_status = "deferred"
         reps = (B + fx["x"].shape[0] - 1) // fx["x"].shape[0]
-        x = torch.from_numpy(np.tile(fx["x"], (reps, 1))[:B]).cuda()
-        c = None if fx.get("cond") is None else torch.from_numpy(np.tile(fx["cond"], (reps, 1))[:B]).cuda()
+        x = torch.from_numpy(np.tile(fx["x"][:-8], (reps + 1, 1))[:B]).to(device="cuda", dtype=DT)       # (without the 8 adversarial tail rows)
+        c = None if fx.get("cond") is None else torch.from_numpy(np.tile(fx["cond"][:-8], (reps + 1, 1))[:B]).to(device="cuda", dtype=DT)
         emb = bool(fx.meta.get("embedding"))
         with torch.no_grad():
             t_f = timed(lambda: pdf(x, conditional_input=c, force_embedding_coordinates=emb))
@@ -38,6 +39,7 @@ for name in names:
                 t_s = timed(lambda: pdf.sample(conditional_input=c, samplesize=B if c is None else 1))
             except Exception as e:
                 t_s = float("nan")
+                print("   sample: %s" % repr(e)[:160], flush=True)
 
         def step():
             for p in pdf.parameters():
@@ -48,6 +50,7 @@ for name in names:
             t_t = timed(step, 5)
         except Exception as e:
             t_t = float("nan")
+            print("   train: %s" % repr(e)[:160], flush=True)
         print("%-32s fwd %8.3f  sample %8.3f (x%5.1f)  train %8.3f (x%5.1f)" % (name, t_f, t_s, t_s / t_f, t_t, t_t / t_f), flush=True)
     except Exception as e:
         print("%-32s ERROR %s" % (name, repr(e)[:120]), flush=True)
