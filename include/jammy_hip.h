@@ -423,7 +423,7 @@ int jf_mlp2_i8_seg_f64(const jf_cond_segment* segments, int32_t n_segments, cons
  * 't' affine flow / multivariate normal (replaces mvn_block._inv_flow_mapping / _flow_mapping + the euclidean_base offset:
  * jammy_flows/layers/euclidean/multivariate_normal.py:226-263, layers/matrix_fns.py:4-146, euclidean_base.py:34-76).
  * Row: [offset D if model_offset][raw log-diagonal: 1 (diagonal_symmetric) | D (diagonal, full)][strictly-lower entries D(D-1)/2 (full),
- * sub-diagonal by sub-diagonal from the bottom-left corner, matrix_fns.py:36-50].  log L_ii = the same width regulators as 'g'.  D <= 8.
+ * sub-diagonal by sub-diagonal from the bottom-left corner, matrix_fns.py:36-50].  log L_ii = the same width regulators as 'g'.  D <= 32.
  * base_logp_out (nullable) as for jf_gf_chain_inv.  jf_t_layer_inv_bwd: backward of the log-prob direction (same conventions as
  * jf_<fam>_chain_inv_bwd below: per-sample g_params (B, P), broadcast row sums ADDED into (1, P)); reverse mode in closed form: one forward
  * and one backward substitution per row.
