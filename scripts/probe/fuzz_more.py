@@ -1,0 +1,43 @@
+"""tests/test_gpu_fuzz.py's random pdf structures / options against the oracle for seeds beyond the 40 the suite runs, plus a gradient check of
+the same pdf against central finite differences in x:  python3 scripts/probe/fuzz_more.py [first] [last]"""
+import os, sys, traceback
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden")]
+import numpy as np
+import torch
+import test_gpu_fuzz as F
+
+first = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+last = int(sys.argv[2]) if len(sys.argv) > 2 else 160
+bad = 0
+for seed in range(first, last):
+    try:
+        F.test_random_pdf_structures_and_options_vs_oracle(seed)
+        # gradients in x of the same pdf: backward launches vs central differences of the forward launches
+        rng, pdf_defs, flow_defs, kwargs, pdf = F.build_fuzz_pdf(seed)
+        if "rq_splines" in str(kwargs):
+            pass
+        pdf = pdf.cuda()
+        B = 48
+        x = torch.from_numpy(F.domain_rows(pdf_defs, B, rng)).cuda().requires_grad_(True)
+        c = torch.from_numpy(rng.normal(size=(B, 2))).cuda() if "conditional_input_dim" in kwargs else None
+        with torch.enable_grad():
+            pdf(x, conditional_input=c)[0].sum().backward()
+        eps = 1e-6
+        worst = 0.0
+        with torch.no_grad():
+            for j in range(x.shape[1]):
+                tp, tm = x.detach().clone(), x.detach().clone()
+                tp[:, j] += eps; tm[:, j] -= eps
+                fd = (pdf(tp, conditional_input=c)[0] - pdf(tm, conditional_input=c)[0]) / (2 * eps)
+                ok = torch.isfinite(fd) & torch.isfinite(x.grad[:, j])
+                if ok.any():
+                    worst = max(worst, float(((x.grad[:, j] - fd).abs() / (1.0 + fd.abs()))[ok].max()))
+        status = "ok" if worst < 1e-4 else "GRAD MISMATCH %.2e" % worst
+        if worst >= 1e-4:
+            bad += 1
+        print("seed %d %s / %s: %s" % (seed, pdf_defs, flow_defs, status), flush=True)
+    except Exception as e:
+        bad += 1
+        print("seed %d FAILED: %s" % (seed, repr(e)[:300]), flush=True)
+print("failures:", bad)
