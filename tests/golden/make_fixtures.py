@@ -176,6 +176,9 @@ CASES = [
     # (no_bins: the potential's spline searches once per component and Newton iteration -- an internal of the exponential map, not a layer output)
     dict(name="v_s2_splines_cond", pdf="s2", flow="v", mlp_scale=100.0, B=96, no_bins=True,
          kwargs=dict(conditional_input_dim=2, options_overwrite={"v": {"exp_map_type": "splines"}})),
+    # spline potentials with the log-prob in the SOLVING direction (natural_direction = 1: sphere Newton on a C1 potential), 10 components
+    dict(name="v_s2_splines_nat1", pdf="s2", flow="v", mlp_scale=100.0, B=96, no_bins=True,
+         kwargs=dict(conditional_input_dim=2, options_overwrite={"v": {"exp_map_type": "splines", "natural_direction": 1, "num_components": 10}})),
     # mixed extra
     dict(name="mix_e2s1i1", pdf="e2+s1+i1_-2.0_3.0", flow="gg+m+rr", mlp_scale=1000.0, kwargs=dict(conditional_input_dim=3)),
     dict(name="mix_s2e2_emb", pdf="s2+e2", flow="f+gg", mlp_scale=1000.0, embedding=True),

@@ -44,7 +44,13 @@ CASES = ["c1_e2_gg", "c2_e4_gggg", "c3_e4s2e4", "g_e1_g", "g_e3_ggg_cond", "g_e2
          # 'g' with nonlinear_stretch_type = "rq_splines" (gaussianization_flow.py:863-909)
          "g_e3_rqs", "g_e3_rqs_cond",
          # only_last=True (main/default.py:1018, 1490: only the last layer of every sub-pdf is applied), with gradients
-         "c3_e4s2e4@only_last", "g_e3_ggg_cond@only_last", "c4_i1s1_ro@only_last"]
+         "c3_e4s2e4@only_last", "g_e3_ggg_cond@only_last", "c4_i1s1_ro@only_last",
+         # every remaining forward fixture (all but mix_e2s1i1, see tests/test_gpu_grad.py): option products of 'f', 'v' in both directions and with
+         # spline potentials, 'm' / 'o' / 'r' variants with permanent parameters, the remaining 't' covariance types, 20 dimensions
+         "c3b_e4s2e4_fsplines", "f_s2_correlated", "f_s2_extra_rot", "f_s2_identity_region", "f_s2_kappa_logb_clamp", "f_s2_rot_angles",
+         "f_s2_rot_quat_sq", "f_s2_rot_xyz_mu", "f_s2_splines", "f_s2_splines_cond", "g_e20_g", "m_s1", "m_s1_nat1_rot", "o_s1", "o_s1_nat0_norot",
+         "o_s1_nosmooth", "r_i1", "r_i1_fixopts", "r_i1_smooth2", "r_i1_smooth3", "t_e10_diagonal_symmetric", "t_e10_identity", "v_s2",
+         "v_s2_nat1_rot", "v_s2_splines_cond", "v_s2_splines_nat1"]
 N_ADV = 8
 ADAM_STEPS = 10
 
