@@ -482,13 +482,17 @@ def other_direction(args, W, rank, local_rank, world):
     dev_index = local_rank if backend == "nccl" else local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    if world > 1:
+    # JF_FORCE_COLLECTIVES=1 with --gpus 1: a process group of ONE rank, so that the N > 1 code path (RCCL set-up, the all-gather on the step's
+    # stream, gradient all-reduce, barriers, the exchange report) runs on a single-GPU box; the line then says "forced_collectives": true
+    multi = world > 1 or os.environ.get("JF_FORCE_COLLECTIVES") == "1"
+    if multi:
+        os.environ.setdefault("MASTER_PORT", "29577")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
-    n_ranks_seen = dist.get_world_size() if world > 1 else 1
+    n_ranks_seen = dist.get_world_size() if multi else 1
     fx = fixture_io.load(W["fixture"])
     dtype = torch.float32 if W["dtype"] == "f32" else torch.float64
     s = 4 if W["dtype"] == "f32" else 8
@@ -501,7 +505,7 @@ def other_direction(args, W, rank, local_rank, world):
         pdf.check_status = False
         g = torch.Generator(device=dev).manual_seed(17 + rank)
         z = torch.randn((B, pdf.total_base_dim), dtype=dtype, device=dev, generator=g)       # base points resident in HBM
-        gather = parallel.PipelinedGather(B, dtype, dev, tail_shape=(pdf.total_target_dim,)) if (world > 1 and total_rows % world == 0) else None
+        gather = parallel.PipelinedGather(B, dtype, dev, tail_shape=(pdf.total_target_dim,)) if (multi and total_rows % world == 0) else None
         last = {}
 
         # consecutive sampling steps draw independent batches: like the log-prob steps they alternate between --pipeline-depth streams, so the
@@ -547,7 +551,7 @@ def other_direction(args, W, rank, local_rank, world):
             with torch.enable_grad():
                 loss = -pdf(x, conditional_input=c)[0].mean()
             loss.backward()
-            if world > 1:
+            if multi:
                 parallel.allreduce_gradients(pdf.parameters(), average=True)
             opt.step()
             last["loss"] = loss
@@ -636,7 +640,7 @@ def other_direction(args, W, rank, local_rank, world):
                     extra["step_issue"] = "HIP graph replay of the captured step (forward + backward + Adam with the step count on the device)"
                 else:
                     extra["step_issue"] = "eager (one ctypes call per launch, torch autograd)"
-    if world > 1:
+    if multi:
         dist.barrier()
     if rank == 0:
         dom = max(table.items(), key=lambda kv: kv[1]["total_ms"])
@@ -662,13 +666,14 @@ def other_direction(args, W, rank, local_rank, world):
                                                                             B if args.scaling == "weak" else total_rows,
                                                                             "per GPU" if args.scaling == "weak" else "in total, row-sharded"),
                            "direction": direction, "batch_per_gpu": B, "total_rows": total_rows, "parallelism": "rows sharded over %d GPU(s)" % world},
-                "n_ranks_seen": n_ranks_seen, "collective_backend": dist.get_backend() if world > 1 else None, "parity": parity,
+                "n_ranks_seen": n_ranks_seen, "collective_backend": dist.get_backend() if multi else None, "parity": parity,
+                "forced_collectives": bool(multi and world == 1),
                 "roofline": roofline, "cpu_baseline": cpu}
         if direction == "train":
             line["cpu_baseline_note"] = "the oracle restates the forward arithmetic only: no CPU training baseline travels to the GPU box"
         line.update(extra)
-        print(json.dumps(line))
-    if world > 1:
+        emit_line(line)
+    if multi:
         dist.destroy_process_group()
     return 0
 
@@ -681,6 +686,29 @@ def free_port():
     p = s.getsockname()[1]
     s.close()
     return p
+
+
+_LINE_FD = None
+
+
+def isolate_stdout():
+    """keep this process's stdout for the contract's ONE JSON line: RCCL prints a five-line version banner on the C-level stdout when a process
+    group comes up (seen on the GPU box with a one-rank group: "RCCL version : 2.26.6 ...", after the JSON line in the file), and anything a
+    library prints there would sit next to the line the driver parses.  File descriptor 1 is pointed at stderr for the rest of the run (Python's
+    sys.stdout and every C library follow it); emit_line() writes the line to the saved descriptor."""
+    global _LINE_FD
+    if _LINE_FD is None:
+        sys.stdout.flush()
+        _LINE_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit_line(line):
+    data = (json.dumps(line) + "\n").encode()
+    sys.stdout.flush()
+    fd = 1 if _LINE_FD is None else _LINE_FD
+    while data:
+        data = data[os.write(fd, data):]
 
 
 def launch_ranks(n, argv):
@@ -730,13 +758,13 @@ def dry_run(args, W, rank, world, B, total_rows, lo):
     if world > 1:
         dist.barrier()
     if rank == 0:
-        print(json.dumps({"metric": W["metric"], "value": None, "unit": "log-prob evals/s", "n_gpus": world, "steps": args.steps,
+        emit_line({"metric": W["metric"], "value": None, "unit": "log-prob evals/s", "n_gpus": world, "steps": args.steps,
                           "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": args.scaling,
                           "vs_baseline": None, "dtype": W["dtype"], "data": "none (dry run: stand-in row function on the host, no kernels)",
                           "dry_run": True, "config": {"workload": "dry run of %s" % args.workload, "batch_per_gpu": B, "total_rows": total_rows,
                                                       "parallelism": "rows sharded over %d rank(s)" % world},
                           "n_ranks_seen": n_ranks_seen, "collective_backend": dist.get_backend() if world > 1 else None,
-                          "exchange": exchange, "gathered_rows_correct": ok}))
+                          "exchange": exchange, "gathered_rows_correct": ok})
     if world > 1:
         dist.destroy_process_group()
     return 0 if ok else 1
@@ -896,6 +924,8 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.pmc_child:
         sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
 
+    if not args.pmc_child:
+        isolate_stdout()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -952,14 +982,18 @@ def main():
     dev_index = local_rank if backend == "nccl" else local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    if world > 1:
+    # JF_FORCE_COLLECTIVES=1 with --gpus 1: a process group of ONE rank, so that the N > 1 code path (RCCL set-up, the all-gather on the step's
+    # stream, gradient all-reduce, barriers, the exchange report) runs on a single-GPU box; the line then says "forced_collectives": true
+    multi = world > 1 or os.environ.get("JF_FORCE_COLLECTIVES") == "1"
+    if multi:
+        os.environ.setdefault("MASTER_PORT", "29577")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
-    n_ranks_seen = dist.get_world_size() if world > 1 else 1
-    backend_name = dist.get_backend() if world > 1 else None
+    n_ranks_seen = dist.get_world_size() if multi else 1
+    backend_name = dist.get_backend() if multi else None
 
     fx = fixture_io.load(W["fixture"])
     # every rank generates the rows it owns from its own seed (no scatter)
@@ -997,7 +1031,7 @@ def main():
         x = torch.from_numpy(x64).to(device=dev, dtype=dtype)
         c = None if c64 is None else torch.from_numpy(c64).to(device=dev, dtype=dtype)
         # N > 1: the per-row log-probs of every step are all-gathered (RCCL), asynchronously, while the next step computes
-        gather = parallel.PipelinedGather(B, dtype, dev) if (world > 1 and total_rows % world == 0) else None
+        gather = parallel.PipelinedGather(B, dtype, dev) if (multi and total_rows % world == 0) else None
         last = {}
 
         # consecutive steps are independent batches: they alternate between `--pipeline-depth` streams, each through its own recorded plan, so
@@ -1117,8 +1151,8 @@ def main():
         del pdf, x, c
 
     # N > 1: who held how many rows, and what one stand-alone all-gather of the log-probs costs (outside the timed region; every rank)
-    exchange = parallel.gather_report(B, dtypes[main_dt], dev) if world > 1 else None
-    if world > 1:
+    exchange = parallel.gather_report(B, dtypes[main_dt], dev) if multi else None
+    if multi:
         dist.barrier()
     if rank == 0:
         rm = results[main_dt]
@@ -1227,6 +1261,7 @@ def main():
                                                                                   "per GPU" if args.scaling == "weak" else "in total, row-sharded"),
                        "batch_per_gpu": B, "total_rows": total_rows, "parallelism": "rows sharded over %d GPU(s)" % world},
             "n_ranks_seen": n_ranks_seen, "collective_backend": backend_name, "exchange": exchange,
+            "forced_collectives": bool(multi and world == 1),
             "parity": {"max_abs_dlogp_vs_f64_oracle": rm["err"], "bar": 1e-2 if main_dt == "f32" else 1e-4, "rows_checked": min(4096, B),
                        "repeat_launches_bit_identical": rm["identical"], "repeat_launches": rm["repeats"], "repeat_rows_compared": B,
                        "untiled_full_size": rm["untiled"]},
@@ -1327,8 +1362,8 @@ def main():
                 blk["gf_chain_per_sample"] = {"bound": "hbm", "achieved": gb, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gb / HBM_PEAK_GBS,
                                               "mean_launch_ms": gf["mean_ms"], "algorithmic_bytes_per_launch": 4 * 558 * B}
             line["two_launch_path"] = blk
-        print(json.dumps(line))
-    if world > 1:
+        emit_line(line)
+    if multi:
         dist.destroy_process_group()
 
 

@@ -4,8 +4,19 @@ The hot path is embarrassingly parallel over rows: every 
 replicated weights (< 1 MB); no data-path collective is needed.  The only exchange is the optional all-gather of the per-row
 log-probabilities (4 MiB per rank at 2^20 float32 rows) -- one all_gather_into_tensor, never an all-reduce.
 """
+import os
+
 import torch
 import torch.distributed as dist
+
+
+def collectives_active(group=None):
+    """True when the exchanges below really call the backend: an initialised process group of more than one rank -- or of ONE rank with
+    JF_FORCE_COLLECTIVES=1, which is how the RCCL calls (group set-up on the device, all_gather_into_tensor on a step's own stream, the flat
+    gradient all-reduce, the barrier of the timing loop) are exercised on a box that has a single GPU (tests/test_gpu_rccl.py)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size(group) > 1 or os.environ.get("JF_FORCE_COLLECTIVES") == "1"
 
 
 def shard_bounds(n_rows, rank, world_size):
@@ -26,7 +37,7 @@ def shard_rows(t, rank=None, world_size=None):
 
 def all_gather_rows(local, n_rows_total=None, group=None):
     """gather the per-rank row blocks (possibly of different length) into the full tensor, on every rank."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not collectives_active(group):
         return local
     world = dist.get_world_size(group)
     if n_rows_total is None:
@@ -71,6 +82,7 @@ class PipelinedGather:
     def __init__(self, n_rows_local, dtype, device, tail_shape=(), depth=2, group=None):
         self.group = group
         self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+        self.collective = collectives_active(group)
         self.out = [torch.empty((self.world * n_rows_local,) + tuple(tail_shape), dtype=dtype, device=device) for _ in range(depth)]
         self.work = [None] * depth
         self.keep = [None] * depth          # the submitted tensors must outlive their collectives
@@ -81,7 +93,7 @@ class PipelinedGather:
         self.i += 1
         if self.work[j] is not None:
             self.work[j].wait()
-        if self.world == 1:
+        if not self.collective:
             self.out[j].copy_(local)
             return self.out[j]
         self.keep[j] = local.contiguous()
@@ -104,7 +116,7 @@ def gather_report(n_rows_local, dtype, device, reps=10, group=None):
     (PipelinedGather); this is its exposed cost if nothing hid it."""
     import time
     world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
-    if world == 1:
+    if not collectives_active(group):
         return {"rows_per_rank": [int(n_rows_local)], "gather_us": 0.0, "gather_bytes_per_rank": 0}
     rows = [None] * world
     dist.all_gather_object(rows, int(n_rows_local), group=group)
@@ -144,7 +156,7 @@ def timed_steps(step, steps, warmup, finish=None, device=None, timer=None):
     (per-kernel HIP events)."""
     import contextlib
     import time
-    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    multi = collectives_active()
     on_gpu = device is not None and torch.device(device).type == "cuda"
 
     def fence():
@@ -180,7 +192,7 @@ def allreduce_gradients(parameters, average=True, group=None):
     mean over the GLOBAL batch when every shard has the same number of rows).  Parameters without a gradient on this rank contribute zeros
     (they keep grad None only if no rank produced one).  Returns the number of scalars reduced."""
     params = [p for p in parameters if p.requires_grad]
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not collectives_active(group):
         return sum(p.grad.numel() for p in params if p.grad is not None)
     world = dist.get_world_size(group)
     total = 0

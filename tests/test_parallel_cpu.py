@@ -228,6 +228,7 @@ def test_bench_launches_its_own_ranks_dry_run():
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
+    assert [l for l in r.stdout.splitlines() if l.strip()] == lines, "stdout carries the JSON line and nothing else (bench.isolate_stdout)"
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["n_ranks_seen"] == 2 and line["collective_backend"] == "gloo"
     assert line["dry_run"] is True and line["gathered_rows_correct"] is True
