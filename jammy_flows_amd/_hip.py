@@ -25,7 +25,8 @@ GF_INV_TYPES = {"isigmoid": 0, "inormal_partly_precise": 1, "inormal_partly_crud
 GF_WIDTH_SMOOTH, GF_WIDTH_EXP, GF_WIDTH_SOFTPLUS = 0, 1, 2
 GF_STRETCH_CLASSIC, GF_STRETCH_RQ_SPLINES = 0, 1
 GF_ROT_MODES = {"householder": 0, "angles": 1, "cayley": 2, "triangular_combination": 3}
-JF_SPLINE_MAX_BINS = 16
+JF_SPLINE_MAX_BINS = 16          # 'g' with the rq_splines stretch (fixed table stride, csrc/jf_spline.h)
+JF_SPLINE_CAP = 64               # 'r', 'o', splines nested in 'f' (tables at the chain's own bin count; the launch sizes its row tile to the LDS)
 JF_CORR_SCRATCH = 81
 
 

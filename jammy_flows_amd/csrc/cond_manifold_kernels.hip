@@ -55,11 +55,8 @@ static int cond_mchain(const T* in, int64_t in_stride, const T* W1, int64_t w1s,
     for (int l = 0; l < n_layers; ++l) n_spl += Fam::n_bins(layers[l]);
     a.tab = 0;                                         // lane-private knot tables: none for a spline-free chain (default 'f', 'm'), else 3 (bins + 1)
     if (n_spl > 0) {                                   // words where the family states its bin count (r, o), the 16-bin maximum otherwise
-        a.tab = JF_SPLINE_TAB;
-        if constexpr (std::is_same<Fam, RFam>::value || std::is_same<Fam, OFam>::value) {
-            a.tab = 1;
-            for (int l = 0; l < n_layers; ++l) { const int w = Fam::tab_words(layers[l]); a.tab = w > a.tab ? w : a.tab; }
-        }
+        a.tab = 1;
+        for (int l = 0; l < n_layers; ++l) { const int w = fam_tab_words<Fam>::of(layers[l]); a.tab = w > a.tab ? w : a.tab; }
     }
     const int k1p = (K1 + 3) / 4 * 4, ldk = k1p + 1;
     constexpr int NT = sizeof(T) == 4 ? 256 : 128;

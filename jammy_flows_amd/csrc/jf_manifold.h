@@ -41,9 +41,13 @@ __host__ __device__ inline int spline_row_len(const jf_spline_opts& s) { return 
 // end in JF_ERR_BADARG instead of integer overflow or an out-of-bounds index into the nested layer arrays (tests/test_abi_asan.py)
 __host__ inline bool sane_hh(int hh) { return hh >= JF_ROT_QUATERNION && hh <= 64; }
 __host__ inline bool sane_spline(const jf_spline_opts& s) {
-    return s.num_bins >= 1 && s.num_bins <= JF_SPLINE_MAX_BINS && s.n_w >= 0 && s.n_w <= 4 * JF_SPLINE_MAX_BINS && s.n_h >= 0 &&
-           s.n_h <= 4 * JF_SPLINE_MAX_BINS && s.n_d >= 0 && s.n_d <= 4 * JF_SPLINE_MAX_BINS;
+    return s.num_bins >= 1 && s.num_bins <= JF_SPLINE_CAP && s.n_w >= 0 && s.n_w <= 4 * JF_SPLINE_CAP && s.n_h >= 0 &&
+           s.n_h <= 4 * JF_SPLINE_CAP && s.n_d >= 0 && s.n_d <= 4 * JF_SPLINE_CAP;
 }
+
+// per-lane knot-table elements a layer needs: the family's own count where it states one ('r', 'o', 'f': 3 (bins + 1)), else the fixed stride
+template <class Fam, class = void> struct fam_tab_words { static int of(const typename Fam::CLayer&) { return JF_SPLINE_TAB; } };
+template <class Fam> struct fam_tab_words<Fam, std::void_t<decltype(&Fam::tab_words)>> { static int of(const typename Fam::CLayer& L) { return Fam::tab_words(L); } };
 
 // =================================================================================================  'r'
 template <typename T> __device__ __forceinline__ T r_core(const jf_r_layer& L, const T* __restrict__ p, T x, T& ld, LaneCtx<T>& c, bool inverse) {
@@ -349,6 +353,12 @@ struct FFam {
     }
     static __host__ int n_bins(const CLayer& L) { return L.n_vertical + L.n_circular; }
     static __host__ bool needs_tab(const CLayer& L) { return L.n_vertical + L.n_circular > 0; }
+    static __host__ int tab_words(const CLayer& L) {                    // the nested splines are evaluated one after the other on the lane's one table
+        int w = 1;
+        for (int i = 0; i < L.n_vertical && i < JF_MAX_NESTED; ++i) { const int t = spline_tab_words(L.vertical[i].sp.num_bins); w = t > w ? t : w; }
+        for (int i = 0; i < L.n_circular && i < JF_MAX_NESTED; ++i) { const int t = spline_tab_words(L.circular[i].sp.num_bins); w = t > w ? t : w; }
+        return w;
+    }
     static __host__ int scratch(const CLayer& L) { return L.correlated ? JF_CORR_SCRATCH : 0; }
 
     // the per-sample MLP of the correlated variant: out[0..n_out) = W2 tanh(W1 z + b1) + b2 with this row's own weights

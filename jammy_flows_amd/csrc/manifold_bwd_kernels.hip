@@ -727,8 +727,8 @@ static int mchain_bwd(const T* x, int64_t xs, const T* params, int64_t ps, int32
     a.tab = 0;
     for (int l = 0; l < n_layers; ++l) {
         if (!Fam::needs_tab(layers[l])) continue;
-        int w = JF_SPLINE_TAB;                                     // families that state their bin count ('r', 'o'): 3 (bins + 1) words per lane, as in the
-        if constexpr (std::is_same<Fam, RFam>::value || std::is_same<Fam, OFam>::value) w = Fam::tab_words(layers[l]);   // forward kernels (35 for 10 bins, not 53)
+        const int w = fam_tab_words<Fam>::of(layers[l]);           // families that state their bin count ('r', 'o', 'f'): 3 (bins + 1) words per lane, as in
+                                                                   // the forward kernels (35 for 10 bins, not 53)
         a.tab = w > a.tab ? w : a.tab;
     }
     a.rows = 64 / lv;

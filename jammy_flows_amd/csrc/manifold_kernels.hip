@@ -42,9 +42,7 @@ template <typename T, typename CLayer> struct MChainArgs {
     T* total;
 };
 
-// per-lane knot-table elements a layer needs: the family's own count where it states one (r, o: 3 (bins + 1)), else the 16-bin maximum
-template <class Fam, class = void> struct fam_tab_words { static int of(const typename Fam::CLayer&) { return JF_SPLINE_TAB; } };
-template <class Fam> struct fam_tab_words<Fam, std::void_t<decltype(&Fam::tab_words)>> { static int of(const typename Fam::CLayer& L) { return Fam::tab_words(L); } };
+// (fam_tab_words: jf_manifold.h)
 template <class Fam, class = void> struct fam_has_build : std::false_type {};
 template <class Fam> struct fam_has_build<Fam, std::void_t<decltype(Fam::HAS_BUILD)>> : std::true_type {};
 
@@ -188,7 +186,7 @@ static int mchain(const T* x, int64_t xs, const T* ld_in, const T* params, int64
 }
 
 static bool spline_ok(const jf_spline_opts& s) {
-    return s.num_bins >= 1 && s.num_bins <= JF_SPLINE_MAX_BINS && s.n_w >= 0 && s.n_h >= 0 && s.n_d >= 0 && (s.smooth == 0 || s.num_bins <= 3);
+    return s.num_bins >= 1 && s.num_bins <= JF_SPLINE_CAP && s.n_w >= 0 && s.n_h >= 0 && s.n_d >= 0 && (s.smooth == 0 || s.num_bins <= 3);
 }
 
 // ---- sphere <-> embedding

@@ -73,6 +73,6 @@ def spline_struct(layer, ratio=-1.0):
     s.fix_bd_value = layer._fix_bd_value
     s.min_w, s.min_h, s.min_d = float(layer.min_width), float(layer.min_height), float(layer.min_derivative)
     s.ratio = float(ratio)
-    if s.num_bins > 16:
-        raise NotImplementedError("splines with more than 16 bins have no HIP kernel")
+    if s.num_bins > _hip.JF_SPLINE_CAP:
+        raise NotImplementedError("splines with more than %d bins have no HIP kernel" % _hip.JF_SPLINE_CAP)
     return s

@@ -176,6 +176,14 @@ CASES = [
     # (no_bins: the potential's spline searches once per component and Newton iteration -- an internal of the exponential map, not a layer output)
     dict(name="v_s2_splines_cond", pdf="s2", flow="v", mlp_scale=100.0, B=96, no_bins=True,
          kwargs=dict(conditional_input_dim=2, options_overwrite={"v": {"exp_map_type": "splines"}})),
+    # more than 16 bins (round 5: the 'r' / 'o' / nested-'f' kernels size a lane's knot table by the chain's own bin count, up to 64)
+    dict(name="r_i1_bins24_cond", pdf="i1_-1.0_1.0", flow="rr", mlp_scale=1000.0,
+         kwargs=dict(conditional_input_dim=2, options_overwrite={"r": {"num_basis_functions": 24}})),
+    dict(name="r_i1_bins40", pdf="i1", flow="r", perturb=0.7, kwargs=dict(options_overwrite={"r": {"num_basis_functions": 40}})),
+    dict(name="o_s1_bins20_cond", pdf="s1", flow="oo", mlp_scale=1000.0,
+         kwargs=dict(conditional_input_dim=2, options_overwrite={"o": {"smooth_second_derivative": 0, "num_basis_functions": 20}})),
+    dict(name="f_s2_splines_bins24", pdf="s2", flow="f", mlp_scale=300.0,
+         kwargs=dict(conditional_input_dim=2, options_overwrite={"f": dict(_f_splines()["f"], spline_num_basis_functions=24)})),
     # spline potentials with the log-prob in the SOLVING direction (natural_direction = 1: sphere Newton on a C1 potential), 10 components
     dict(name="v_s2_splines_nat1", pdf="s2", flow="v", mlp_scale=100.0, B=96, no_bins=True,
          kwargs=dict(conditional_input_dim=2, options_overwrite={"v": {"exp_map_type": "splines", "natural_direction": 1, "num_components": 10}})),

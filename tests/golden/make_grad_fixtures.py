@@ -50,7 +50,9 @@ CASES = ["c1_e2_gg", "c2_e4_gggg", "c3_e4s2e4", "g_e1_g", "g_e3_ggg_cond", "g_e2
          "c3b_e4s2e4_fsplines", "f_s2_correlated", "f_s2_extra_rot", "f_s2_identity_region", "f_s2_kappa_logb_clamp", "f_s2_rot_angles",
          "f_s2_rot_quat_sq", "f_s2_rot_xyz_mu", "f_s2_splines", "f_s2_splines_cond", "g_e20_g", "m_s1", "m_s1_nat1_rot", "o_s1", "o_s1_nat0_norot",
          "o_s1_nosmooth", "r_i1", "r_i1_fixopts", "r_i1_smooth2", "r_i1_smooth3", "t_e10_diagonal_symmetric", "t_e10_identity", "v_s2",
-         "v_s2_nat1_rot", "v_s2_splines_cond", "v_s2_splines_nat1"]
+         "v_s2_nat1_rot", "v_s2_splines_cond", "v_s2_splines_nat1",
+         # more than 16 bins
+         "r_i1_bins24_cond", "r_i1_bins40", "o_s1_bins20_cond", "f_s2_splines_bins24"]
 N_ADV = 8
 ADAM_STEPS = 10
 

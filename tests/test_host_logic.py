@@ -334,14 +334,15 @@ def test_one_launch_adam_host_side():
 
 def test_kernel_caps_raise_loudly_without_a_gpu():
     """the caps the reference does not have (flow_options.py:38, spline_fns.py:45-186) are errors at construction / descriptor
-    time, never silent truncation: 't' beyond 32 dimensions, splines beyond 16 bins, more than 4 nested f sub-layers"""
+    time, never silent truncation: 't' beyond 32 dimensions, 'r' / 'o' / nested splines beyond 64 bins ('g' with rq_splines: 16), more than 4 nested
+    f sub-layers"""
     import jammy_flows_amd as jf
     with pytest.raises(NotImplementedError, match="32 dimensions"):
         jf.pdf("e33", "t")
-    p = jf.pdf("i1", "r", options_overwrite={"r": {"num_basis_functions": 17}})
-    with pytest.raises(NotImplementedError, match="16 bins"):
+    p = jf.pdf("i1", "r", options_overwrite={"r": {"num_basis_functions": 65}})
+    with pytest.raises(NotImplementedError, match="64 bins"):
         p.layer_list[0][0].c_struct()
-    jf.pdf("i1", "r", options_overwrite={"r": {"num_basis_functions": 16}}).layer_list[0][0].c_struct()
+    jf.pdf("i1", "r", options_overwrite={"r": {"num_basis_functions": 64}}).layer_list[0][0].c_struct()
     with pytest.raises(NotImplementedError, match="nested"):
         jf.pdf("s2", "f", options_overwrite={"f": {"add_vertical_rq_spline_flow": 1, "vertical_flow_defs": "rrrrr"}})
     with pytest.raises(NotImplementedError, match="16 bins|at most 16"):
