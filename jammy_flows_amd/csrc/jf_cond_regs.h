@@ -254,7 +254,7 @@ __device__ __forceinline__ T cs_solve(const T (&P)[CS_SLOTS], int inv_type, bool
             if (Mf::finite(nx)) x = nx; else nonfinite = nonfinite || live;
             ferr = Mf::abs(f);
             last_logd = s.logd;
-            active = usum >= T(1e-14);
+            active = usum >= T(NewtonTol<T>::value);
         }
         if constexpr (sizeof(T) == 4) {
             // float32 floor of the update (see gfg_solve): the reference's float32 runs spend their last ~16 Newton steps on rounding noise
@@ -265,7 +265,7 @@ __device__ __forceinline__ T cs_solve(const T (&P)[CS_SLOTS], int inv_type, bool
         }
     }
     if (logd_out != nullptr) {
-        // the stage's log-derivative at the solution (the caller's log-det term).  A converged row's last update was below 1e-14 (float32: below
+        // the stage's log-derivative at the solution (the caller's log-det term).  A converged row's last update was below 1e-9 (NewtonTol; float32: below
         // 2.5e-7 of the coordinate -- its rounding), so the value of its last evaluation IS the value at the returned point to rounding: one
         // evaluation (mixture + inverse CDF; a fifth of a float64 solve) saved.  A wave with a row that ran out of iterations, or -- float32 --
         // stopped on the stagnation rule (updates up to 1e-4 of the coordinate), evaluates at the returned point as the reference does

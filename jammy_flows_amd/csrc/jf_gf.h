@@ -508,7 +508,7 @@ template <typename T, int G> __device__ __forceinline__ T gfg_solve(const T* __r
             const T nx = x - upd;
             if (M<T>::finite(nx)) x = nx; else nonfinite = nonfinite || live;     // keep the previous iterate (:84-91)
             ferr = M<T>::abs(f);
-            active = usum >= T(1e-14);
+            active = usum >= T(NewtonTol<T>::value);
         }
         if constexpr (sizeof(T) == 4) {
             // float32: the reference's absolute 1e-14 fires only on an exactly zero update, i.e. its float32 runs do all 20 steps and the last

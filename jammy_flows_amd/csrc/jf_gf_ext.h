@@ -245,7 +245,7 @@ template <typename T, typename PA> __device__ inline void gx_solve(const GfLayer
             ferr = M<T>::max(ferr, M<T>::abs(f));
             xs += M<T>::max(M<T>::abs(x[d]), T(1));
         }
-        active = usum >= T(1e-14);
+        active = usum >= T(NewtonTol<T>::value);
         if constexpr (sizeof(T) == 4) {          // float32 rounding floor, as in gfg_solve (jf_gf.h)
             if (usum < T(2.5e-7) * xs || (usum >= T(0.5) * prev && usum < T(1e-4) * xs)) active = false;
             prev = usum;

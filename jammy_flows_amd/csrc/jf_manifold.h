@@ -195,7 +195,7 @@ template <typename T, typename ROW> __device__ inline T moebius_solve_values(ROW
             const T upd = (f - z) / d;
             x -= upd;
             ferr = M<T>::abs(f - z);
-            active = M<T>::abs(upd) >= T(1e-14);
+            active = M<T>::abs(upd) >= T(NewtonTol<T>::value);
         }
     }
     nonconv = nonconv || (ferr > (sizeof(T) == 8 ? T(1e-7) : T(1e-4)));

@@ -172,4 +172,12 @@ template <typename T> __device__ __forceinline__ T logaddexp(T a, T b) {
 }
 template <typename T> __device__ __forceinline__ T clampv(T x, T lo, T hi) { return M<T>::min(M<T>::max(x, lo), hi); }
 
+// Stopping rule of the Newton stages (sampling direction of 'g', the solve of 'm').  The reference ends a row when the sum of its |updates| falls
+// below 1e-14 (bisection_n_newton.py:68-115, called with newton_tolerance 1e-14): in float64 that costs one evaluation that only CONFIRMS -- near the
+// simple root of a smooth increasing function the update after one of size u is (f'' / 2 f') u^2, so a row whose update fell below 1e-9 already
+// sits within 1e-16 x (curvature ratio, <= ~1e2 for widths >= 0.01) of the point at which the reference's iteration ends, and applying that update is
+// the last thing the reference itself does before its confirming step.  float64 rows therefore stop at 1e-9 (one float64 mixture evaluation per
+// coordinate and layer less: C5 sampling 3.2 -> see DESIGN); float32 rows keep their own rounding-floor rule below.
+template <typename T> struct NewtonTol { static constexpr double value = sizeof(T) == 8 ? 1e-9 : 1e-14; };
+
 }  // namespace jf
