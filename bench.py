@@ -640,6 +640,9 @@ def other_direction(args, W, rank, local_rank, world):
                     extra["step_issue"] = "HIP graph replay of the captured step (forward + backward + Adam with the step count on the device)"
                 else:
                     extra["step_issue"] = "eager (one ctypes call per launch, torch autograd)"
+    if direction == "sample" and gather is not None:
+        extra["exchange_path"] = gather.path
+        gather.close()
     if multi:
         dist.barrier()
     if rank == 0:
@@ -911,6 +914,9 @@ def main():
     ap.add_argument("--pipeline-depth", type=int, default=2,
                     help="log-prob steps alternate between this many HIP streams, each through its own recorded plan (pdf.pipelined_forward): the batches "
                          "of consecutive steps are independent, so the tail of one step overlaps the head of the next; 1 = one stream")
+    ap.add_argument("--gather-steps", type=int, default=4,
+                    help="N > 1: the log-probs of this many consecutive steps travel in ONE all-gather (parallel.PipelinedGather(group_steps=k): fewer, larger "
+                         "collectives -- an RCCL enqueue costs ~50 us of host time whatever its size); every step's rows are exchanged inside the timed region")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--pmc-dtype", choices=("f32", "f64"), default=None, help=argparse.SUPPRESS)    # precision of the --pmc-child steps (default: the workload's)
     ap.add_argument("--dry-run", action="store_true",
@@ -1031,7 +1037,7 @@ def main():
         x = torch.from_numpy(x64).to(device=dev, dtype=dtype)
         c = None if c64 is None else torch.from_numpy(c64).to(device=dev, dtype=dtype)
         # N > 1: the per-row log-probs of every step are all-gathered (RCCL), asynchronously, while the next step computes
-        gather = parallel.PipelinedGather(B, dtype, dev) if (multi and total_rows % world == 0) else None
+        gather = parallel.PipelinedGather(B, dtype, dev, group_steps=args.gather_steps) if (multi and total_rows % world == 0) else None
         last = {}
 
         # consecutive steps are independent batches: they alternate between `--pipeline-depth` streams, each through its own recorded plan, so
@@ -1047,10 +1053,13 @@ def main():
 
         def step():
             if pipe is not None:
-                t = pipe.submit(x, c)
                 if gather is not None:
-                    with torch.cuda.stream(t.stream):     # the collective waits for THIS step's kernels
-                        gather.submit(t.outputs[0])
+                    # the step writes its log-probs straight into the stage of the next exchange; every --gather-steps-th step the exchange is
+                    # issued from a side stream that waits for the staged steps' completion events (parallel.PipelinedGather.next_slot / staged)
+                    t = pipe.submit(x, c, logp_out=gather.next_slot())
+                    gather.staged(t)
+                else:
+                    t = pipe.submit(x, c)
                 last["pending"] = t
                 return
             logp = pdf(x, conditional_input=c)[0]
@@ -1078,7 +1087,8 @@ def main():
                     step()
                 torch.cuda.synchronize(dev)
             finish()
-        dt = parallel.timed_steps(step, args.steps, args.warmup, finish=finish, device=dev, timer=timer)
+        tinfo = {}
+        dt = parallel.timed_steps(step, args.steps, args.warmup, finish=finish, device=dev, timer=timer, info=tinfo)
         if timer is None and rank == 0:
             # the secondary (float64) leg: per-kernel HIP-event times of two more steps, outside its timed region
             t64 = _hip.KernelTimer()
@@ -1087,6 +1097,15 @@ def main():
                     pdf(x, conditional_input=c)
             side_table = t64.summary()
         logp = last["logp"]
+        # N > 1: this rank's block of the last gathered buffer is what the last step computed; which path carried it (parallel.PipelinedGather)
+        gather_info = None
+        if gather is not None:
+            full = gather.wait()
+            torch.cuda.synchronize(dev)
+            mine = gather.last_block(rank)
+            gather_info = {"path": gather.path, "direct_error": gather.direct_error, "steps_per_collective": gather.k,
+                           "own_block_correct": bool(((mine == logp) | (mine.isnan() & logp.isnan())).all())}
+            gather.close()
         # parity of what was just timed, against the float64 oracle (rank 0, 4096 rows)
         err = None
         if rank == 0:
@@ -1108,7 +1127,7 @@ def main():
             identical = identical and bool(((again == logp) | (again.isnan() & logp.isnan())).all())
         pdf.flush_status()
         results[dname] = dict(dt=dt, evals_per_s=total_rows * args.steps / dt, ms_per_step=1e3 * dt / args.steps, err=err, identical=identical, repeats=repeats,
-                              untiled=untiled)
+                              untiled=untiled, gather=gather_info, host_issue_ms=1e3 * tinfo.get("host_issue_s", 0.0) / args.steps)
         if rank == 0 and world == 1 and dname == main_dt and not args.no_sweep:
             results[dname]["rows_sweep"] = rows_sweep(pdf, x, c, depth=args.pipeline_depth if pipe is not None else 1)
         if timer is not None:
@@ -1152,6 +1171,8 @@ def main():
 
     # N > 1: who held how many rows, and what one stand-alone all-gather of the log-probs costs (outside the timed region; every rank)
     exchange = parallel.gather_report(B, dtypes[main_dt], dev) if multi else None
+    if exchange is not None and results[main_dt].get("gather"):
+        exchange.update(results[main_dt]["gather"])
     if multi:
         dist.barrier()
     if rank == 0:
@@ -1262,6 +1283,7 @@ def main():
                        "batch_per_gpu": B, "total_rows": total_rows, "parallelism": "rows sharded over %d GPU(s)" % world},
             "n_ranks_seen": n_ranks_seen, "collective_backend": backend_name, "exchange": exchange,
             "forced_collectives": bool(multi and world == 1),
+            "host_issue_ms_per_step": rm["host_issue_ms"],
             "parity": {"max_abs_dlogp_vs_f64_oracle": rm["err"], "bar": 1e-2 if main_dt == "f32" else 1e-4, "rows_checked": min(4096, B),
                        "repeat_launches_bit_identical": rm["identical"], "repeat_launches": rm["repeats"], "repeat_rows_compared": B,
                        "untiled_full_size": rm["untiled"]},

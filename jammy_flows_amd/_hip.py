@@ -523,8 +523,9 @@ class StepPlan:
     def copy_to_host(self, host_t, dev_t):
         _check(int(lib().jf_plan_add_copy_to_host(self.handle, host_t.data_ptr(), _ptr(dev_t), dev_t.numel() * dev_t.element_size())), "jf_plan_add_copy_to_host")
 
-    def launch(self, tensors, dev):
-        """re-issue the step; tensors[i] takes the place of slot i (same shape / strides as the tensor the slot was declared with)"""
+    def launch(self, tensors, dev, stream=None):
+        """re-issue the step; tensors[i] takes the place of slot i (same shape / strides as the tensor the slot was declared with); stream: the
+        current stream of `dev` when the caller already holds it"""
         b = self._bases
         for i, t in enumerate(tensors):
             b[i] = t.data_ptr()
@@ -534,8 +535,11 @@ class StepPlan:
             self._timing = timed
         if timed and self not in _TIMER.plans:
             _TIMER.plans.append(self)
-        with torch.cuda.device(dev):
-            rc = lib().jf_plan_launch(self.handle, b, self.n_slots, torch.cuda.current_stream(dev).cuda_stream)
+        if torch.cuda.current_device() == dev.index:
+            rc = lib().jf_plan_launch(self.handle, b, self.n_slots, (stream if stream is not None else torch.cuda.current_stream(dev)).cuda_stream)
+        else:
+            with torch.cuda.device(dev):
+                rc = lib().jf_plan_launch(self.handle, b, self.n_slots, (stream if stream is not None else torch.cuda.current_stream(dev)).cuda_stream)
         _check(rc, "jf_plan_launch")
 
     def read_timing(self):

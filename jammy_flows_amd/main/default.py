@@ -1918,7 +1918,18 @@ class PlannedForward:
                 None if c is None else (tuple(c.shape), c.stride(), c.dtype, c.device, c.data_ptr() % 16))
 
     def _param_key(self):
-        return tuple(p._version for p in self.pdf.parameters())
+        # the in-place version counters of the pdf's parameters.  Walking nn.Module.parameters() costs ~25 us per call for the 26 tensors of C3 (half
+        # of a shard step's host time, scripts/probe/gather_cost.py): the tensor list is kept and walked again every 256th call -- a parameter
+        # OBJECT that was replaced (not written in place) bumps the generation and the plan is recorded again within 256 steps;
+        # pdf.invalidate_packed_caches() is the immediate way
+        n = self._key_calls = getattr(self, "_key_calls", 0) + 1
+        ps = getattr(self, "_key_params", None)
+        if ps is None or (n & 255) == 0:
+            fresh = list(self.pdf.parameters())
+            if ps is None or len(fresh) != len(ps) or any(a is not b for a, b in zip(fresh, ps)):
+                self._key_gen = getattr(self, "_key_gen", 0) + 1
+                self._key_params = ps = fresh
+        return (self._key_gen,) + tuple([p._version for p in ps])
 
     def _record(self, x, cond):
         pdf = self.pdf
@@ -2002,14 +2013,21 @@ class PlannedForward:
             finally:
                 pdf.use_step_plans = saved
 
-    def _replay(self, x, cond):
+    def _replay(self, x, cond, stream=None, logp_out=None):
         out = [torch.empty_strided(t.shape, t.stride(), dtype=t.dtype, device=t.device) for t in self.out_like]
+        if logp_out is not None:                        # the caller's buffer takes the place of the log-prob output (e.g. a slot of an exchange stage)
+            t = self.out_like[0]
+            if (tuple(logp_out.shape), logp_out.stride(), logp_out.dtype, logp_out.device) != (tuple(t.shape), t.stride(), t.dtype, t.device):
+                raise ValueError("logp_out must be a %s tensor of shape %s, strides %s on %s" % (t.dtype, tuple(t.shape), t.stride(), t.device))
+            out[0] = logp_out
         tensors = [x] + ([cond] if self.slot_c is not None else []) + out
-        self._last_stream = torch.cuda.current_stream(self.dev)
-        self.plan.launch(tensors, self.dev)
+        self._last_stream = stream if stream is not None else torch.cuda.current_stream(self.dev)
+        self.plan.launch(tensors, self.dev, self._last_stream)
         return tuple(out)
 
-    def __call__(self, x, conditional_input=None):
+    def __call__(self, x, conditional_input=None, stream=None, logp_out=None):
+        """stream (optional): the CURRENT stream, when the caller already holds it (PipelinedForward: saves the look-ups); logp_out (optional): the
+        tensor the step writes its log-probs into instead of a fresh one"""
         if self._signature(x, conditional_input) != self.sig:
             raise ValueError("this plan was recorded for inputs %s, got %s" % (self.sig, self._signature(x, conditional_input)))
         pdf = self.pdf
@@ -2017,7 +2035,7 @@ class PlannedForward:
             self.flush()
         if self._param_key() != self.key:                               # parameters updated in place since the recording: the caches moved
             self._record(x, conditional_input)
-        out = self._replay(x, conditional_input)
+        out = self._replay(x, conditional_input, stream, logp_out)
         if pdf.check_status and pdf.check_status != "deferred":
             self.flush()
         return out
@@ -2079,19 +2097,24 @@ class PipelinedForward:
         finally:
             pdf.merge_max_rows = keep
 
-    def submit(self, x, conditional_input=None):
+    def submit(self, x, conditional_input=None, logp_out=None):
         """enqueue one step; returns a PendingStep at once.  The step starts when the work queued so far on the caller's current stream (the
-        producer of x) is done; the caller's stream does NOT wait for the step -- PendingStep.result() / drain() do that."""
+        producer of x) is done; the caller's stream does NOT wait for the step -- PendingStep.result() / drain() do that.  logp_out: a buffer
+        for the step's log-probs (parallel.PipelinedGather.next_slot(): the step writes straight into the stage of the next exchange)."""
         j = self.i % self.depth
         self.i += 1
         s = self.streams[j]
         cur = torch.cuda.current_stream(self.dev)
         if s != cur:
             s.wait_stream(cur)
-        with torch.cuda.stream(s):
-            out = self.plans[j](x, conditional_input)
+        # (torch.cuda.set_stream there and back: the `with torch.cuda.stream(s)` context costs ~10 us of a shard step's ~55 us of host time)
+        torch.cuda.set_stream(s)
+        try:
+            out = self.plans[j](x, conditional_input, stream=s, logp_out=logp_out)
             ev = torch.cuda.Event()
             ev.record(s)
+        finally:
+            torch.cuda.set_stream(cur)
         if s != cur:
             x.record_stream(s)
             if conditional_input is not None:

@@ -75,38 +75,187 @@ def sharded_log_prob(pdf, x, conditional_input=None, gather=True, evaluate=None,
 
 class PipelinedGather:
     """all-gather of equal-sized per-rank row blocks that overlaps with the NEXT step's kernels: submit() enqueues the collective
-    asynchronously (RCCL runs it on its own stream once the producer kernels of `local` are done) into one of `depth` rotating output
-    buffers and returns immediately; the buffer of a submission is complete after the next submit() into the same slot or after wait().
-    A step of the row-sharded hot path therefore never stalls on the 4 MiB log-prob exchange."""
+    asynchronously (on a communication stream, once the producer kernels of `local` on the CURRENT stream are done) into one of `depth` rotating
+    output buffers and returns immediately; the buffer of a submission is complete after the next submit() into the same slot or after wait().
+    A step of the row-sharded hot path therefore never stalls on the 4 MiB log-prob exchange.
 
-    def __init__(self, n_rows_local, dtype, device, tail_shape=(), depth=2, group=None):
+    group_steps = k > 1: FEWER, LARGER collectives -- k consecutive submissions are staged (one device copy each, on the submitting stream) and
+    exchanged in ONE all-gather of (k, rows) per rank; the output buffer is then (world, k, rows, ...) and a step's rows arrive up to k - 1
+    submissions later (flush() / wait() exchange a partly filled stage).  An enqueue of RCCL costs ~50 us of host time and a few us of the device
+    whatever its size (scripts/probe/gather_cost.py: a 2^17-row shard step 0.103 -> 0.110 ms with one gather per step, 0.103 with one per four).
+
+    `self.path` says what carries the exchange: "torch.distributed" (default), "rccl-direct" (JF_RCCL_DIRECT=1: ncclAllGather through ctypes,
+    jammy_flows_amd/rccl.py; every rank falls back to torch unless the direct communicator came up on ALL of them) or "copy" (one rank)."""
+
+    def __init__(self, n_rows_local, dtype, device, tail_shape=(), depth=2, group=None, group_steps=1):
         self.group = group
+        self.k = max(1, int(group_steps))
+        self.n_rows_local = int(n_rows_local)
+        self.device = torch.device(device)
         self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
         self.collective = collectives_active(group)
-        self.out = [torch.empty((self.world * n_rows_local,) + tuple(tail_shape), dtype=dtype, device=device) for _ in range(depth)]
+        if self.k == 1:
+            self.out = [torch.empty((self.world * n_rows_local,) + tuple(tail_shape), dtype=dtype, device=device) for _ in range(depth)]
+            self.stage = None
+        else:
+            self.out = [torch.empty((self.world, self.k, n_rows_local) + tuple(tail_shape), dtype=dtype, device=device) for _ in range(depth)]
+            self.stage = [torch.zeros((self.k, n_rows_local) + tuple(tail_shape), dtype=dtype, device=device) for _ in range(depth)]
+        self.n_staged = 0
+        self.n_submitted = 0
+        self.staged_ev = []
+        self._zero_copy = False
+        self.side_stream = None
         self.work = [None] * depth
         self.keep = [None] * depth          # the submitted tensors must outlive their collectives
         self.i = 0
+        self.comm, self.comm_stream, self.direct_error = None, None, None
+        self.path = "torch.distributed" if self.collective else "copy"
+        if self.collective and self.device.type == "cuda":
+            from . import rccl
+            if rccl.available():
+                ok = 1
+                try:
+                    self.comm = rccl.Communicator(self.device, group)
+                except Exception as e:           # noqa: BLE001 -- reported (direct_error); the torch path takes over on every rank
+                    ok, self.direct_error = 0, "%s: %s" % (type(e).__name__, e)
+                flag = torch.tensor([ok], dtype=torch.int32, device=self.device)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+                if int(flag.item()) == 0 and self.comm is not None:
+                    self.comm.destroy()
+                    self.comm = None
+                if self.comm is not None:
+                    self.comm_stream = torch.cuda.Stream(device=self.device)
+                    self.path = "rccl-direct"
 
     def submit(self, local):
+        self.n_submitted += 1
+        if self.k > 1:
+            # consecutive submissions may come from DIFFERENT streams (pipelined steps): every copy into the stage first waits, on its own stream,
+            # for the exchange that last read this stage buffer, and leaves an event the exchange of the full stage waits for
+            j = self.i % len(self.out)
+            self._wait_on_current(self.work[j])
+            self.stage[j][self.n_staged].copy_(local)
+            if self.device.type == "cuda":
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(self.device))
+                self.staged_ev.append(ev)
+            self.n_staged += 1
+            if self.n_staged < self.k:
+                return self.out[j]
+            return self._exchange_stage(j)
+        return self._exchange(local)           # (submit() copies, next_slot() / staged() do not: one gather object uses one of the two)
+
+    # ---- zero-copy staging for pipelined steps: the step writes its rows straight into the stage of the next exchange
+    def next_slot(self):
+        """the (rows, ...) tensor the NEXT step should write its per-row result into -- pass it as `logp_out` to PipelinedForward.submit(), then
+        hand the PendingStep to staged().  No copy, no per-step event: the steps' own completion events order the exchange behind them, and the
+        caller's current stream (which every pipelined step waits for) is made to wait ONCE per stage for the exchange that last read it."""
+        j = self.i % len(self.out)
+        self._zero_copy = True
+        if self.stage is None:                              # group_steps = 1: one send buffer per slot
+            self.stage = [torch.zeros((1, self.n_rows_local) + tuple(self.out[0].shape[1:]), dtype=self.out[0].dtype, device=self.device)
+                          for _ in range(len(self.out))]
+        if self.n_staged == 0:
+            self._wait_on_current(self.work[j])
+        return self.stage[j][self.n_staged]
+
+    def staged(self, pending):
+        """the step submitted with next_slot() as its output (a PendingStep: .event fires when its rows are in the slot).  Every k-th call issues
+        the exchange, from a side stream that waits for the k steps."""
+        self.n_submitted += 1
+        self.staged_ev.append(pending.event)
+        self.n_staged += 1
+        if self.n_staged >= self.k:
+            self._exchange_stage(self.i % len(self.out), side=True)
+        return self.out[self.i % len(self.out)]
+
+    def _exchange_stage(self, j, side=False):
+        """exchange stage j behind the events of the submissions that filled it; side: from the side stream (zero-copy staging: the caller's
+        stream, which every pipelined step waits for, must not wait for the steps), else from the current stream"""
+        self.n_staged = 0
+        evs, self.staged_ev = self.staged_ev, []
+        stage = self.stage[j] if self.k > 1 else self.stage[j][0]
+        if self.device.type != "cuda":
+            return self._exchange(stage)
+        cur = torch.cuda.current_stream(self.device)
+        if not side:
+            for ev in evs:
+                cur.wait_event(ev)
+            return self._exchange(stage)
+        if self.side_stream is None:
+            self.side_stream = torch.cuda.Stream(device=self.device)
+        torch.cuda.set_stream(self.side_stream)
+        try:
+            for ev in evs:
+                self.side_stream.wait_event(ev)
+            return self._exchange(stage)
+        finally:
+            torch.cuda.set_stream(cur)
+
+    def flush(self):
+        """exchange a partly filled stage now (the rows of the missing steps keep what the stage held before)"""
+        if self.n_staged > 0 and self.stage is not None:
+            self._exchange_stage(self.i % len(self.out), side=self._zero_copy)
+
+    def _wait_on_current(self, w):
+        if w is None:
+            return
+        if self.comm is not None:
+            torch.cuda.current_stream(self.device).wait_event(w)
+        else:
+            w.wait()
+
+    def _wait_one(self, j):
+        w, self.work[j] = self.work[j], None
+        self._wait_on_current(w)
+
+    def _exchange(self, local):
         j = self.i % len(self.out)
         self.i += 1
+        if self.comm is not None:
+            cur = torch.cuda.current_stream(self.device)
+            send = local if local.is_contiguous() else local.contiguous()
+            ready = torch.cuda.Event()
+            ready.record(cur)
+            self.comm_stream.wait_event(ready)                 # the collective waits for the producer of `local`, nobody waits for the collective
+            self.comm.all_gather(self.out[j], send, self.comm_stream)     # (one stream for all gathers: a slot's reuse is ordered behind its last use)
+            done = torch.cuda.Event()
+            done.record(self.comm_stream)
+            send.record_stream(self.comm_stream)
+            self.keep[j], self.work[j] = send, done
+            return self.out[j]
         if self.work[j] is not None:
             self.work[j].wait()
         if not self.collective:
             self.out[j].copy_(local)
             return self.out[j]
         self.keep[j] = local.contiguous()
-        self.work[j] = dist.all_gather_into_tensor(self.out[j], self.keep[j], group=self.group, async_op=True)
+        recv = self.out[j] if self.k == 1 else self.out[j].view((self.world * self.k,) + tuple(self.out[j].shape[2:]))   # (gloo wants the dim-0 concatenation)
+        self.work[j] = dist.all_gather_into_tensor(recv, self.keep[j], group=self.group, async_op=True)
         return self.out[j]
 
     def wait(self):
-        """block the current stream (not the host) until every outstanding gather has landed; returns the most recent buffer."""
-        for j, w in enumerate(self.work):
-            if w is not None:
-                w.wait()
-                self.work[j] = None
+        """block the current stream (not the host) until every outstanding gather has landed (a partly filled stage is exchanged first);
+        returns the most recent buffer."""
+        self.flush()
+        for j in range(len(self.work)):
+            self._wait_one(j)
         return self.out[(self.i - 1) % len(self.out)] if self.i else None
+
+    def last_block(self, rank):
+        """after wait(): the rows rank `rank` handed to the most recent submit()"""
+        full = self.out[(self.i - 1) % len(self.out)]
+        if self.k > 1:
+            return full[rank, (self.n_submitted - 1) % self.k]
+        return full[rank * self.n_rows_local:(rank + 1) * self.n_rows_local]
+
+    def close(self):
+        """wait for the outstanding gathers on the host and give the direct communicator back (collective; before destroy_process_group)"""
+        self.wait()
+        if self.comm is not None:
+            self.comm_stream.synchronize()
+            self.comm.destroy()
+            self.comm = None
 
 
 def gather_report(n_rows_local, dtype, device, reps=10, group=None):
@@ -148,7 +297,7 @@ def gather_report(n_rows_local, dtype, device, reps=10, group=None):
     return out
 
 
-def timed_steps(step, steps, warmup, finish=None, device=None, timer=None):
+def timed_steps(step, steps, warmup, finish=None, device=None, timer=None, info=None):
     """the benchmark contract's timing loop: `warmup` untimed calls of step(), then EXACTLY `steps` calls bracketed by a barrier + device
     synchronisation on both sides; returns the wall time in seconds, MAX over ranks.  `finish()` (optional) runs inside the timed region after
     the last step (flush deferred status words, wait for outstanding gathers).  `device`: the rank's torch device (None / cpu: no device sync,
@@ -174,6 +323,8 @@ def timed_steps(step, steps, warmup, finish=None, device=None, timer=None):
     with (timer if timer is not None else contextlib.nullcontext()):
         for _ in range(steps):
             step()
+    if info is not None:
+        info["host_issue_s"] = time.perf_counter() - t0         # the host's share: when it has issued the last step (the device may still be busy)
     if finish is not None:
         finish()
     fence()

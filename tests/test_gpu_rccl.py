@@ -33,8 +33,12 @@ def one_rank_rccl(monkeypatch):
         dist.destroy_process_group()
 
 
-def test_pipelined_steps_with_gather_on_the_step_stream(one_rank_rccl):
+@pytest.mark.parametrize("direct", ["1", "0"], ids=["rccl-direct", "torch.distributed"])
+def test_pipelined_steps_with_gather_on_the_step_stream(one_rank_rccl, monkeypatch, direct):
+    """both carriers of the exchange: ncclAllGather through ctypes on a communication stream (jammy_flows_amd/rccl.py, the default) and
+    torch.distributed.all_gather_into_tensor (JF_RCCL_DIRECT=0, also the fallback)"""
     from jammy_flows_amd import parallel
+    monkeypatch.setenv("JF_RCCL_DIRECT", direct)
     dev = one_rank_rccl
     assert dist.get_backend() == "nccl" and parallel.collectives_active()
     fx = fixture_io.load("c3_e4s2e4")
@@ -46,7 +50,7 @@ def test_pipelined_steps_with_gather_on_the_step_stream(one_rank_rccl):
         want = pdf(x)[0].clone()
         pipe = pdf.pipelined_forward(x, depth=2)
         gather = parallel.PipelinedGather(B, torch.float32, dev)
-        assert gather.collective
+        assert gather.collective and gather.path == ("rccl-direct" if direct == "1" else "torch.distributed"), (gather.path, gather.direct_error)
         outs = []
         for _ in range(6):
             t = pipe.submit(x)
@@ -57,6 +61,40 @@ def test_pipelined_steps_with_gather_on_the_step_stream(one_rank_rccl):
         torch.cuda.synchronize()
     assert torch.equal(full, want)
     assert all(torch.equal(o, want) for o in outs[-2:])
+    gather.close()
+    # fewer, larger collectives: three pipelined steps (two streams) per all-gather, seven steps = two exchanges + a partly filled stage
+    with torch.no_grad():
+        gk = parallel.PipelinedGather(B, torch.float32, dev, group_steps=3)
+        xs = [x, torch.flip(x, dims=(0,)).contiguous()]
+        wants = [want, pdf(xs[1])[0].clone()]
+        for i in range(7):
+            t = pipe.submit(xs[i % 2])
+            with torch.cuda.stream(t.stream):
+                gk.submit(t.outputs[0])
+        pipe.drain()
+        full = gk.wait()
+        torch.cuda.synchronize()
+    assert tuple(full.shape) == (1, 3, B) and torch.equal(gk.last_block(0), wants[6 % 2]) and torch.equal(full[0, 0], wants[6 % 2])
+    other = gk.out[gk.i % 2]
+    assert all(torch.equal(other[0, t], wants[(3 + t) % 2]) for t in range(3))
+    gk.close()
+    # zero-copy staging (what bench.py does for N > 1): the step writes its log-probs into the stage slot, the exchange waits for the steps' events
+    for k in (1, 3):
+        with torch.no_grad():
+            gz = parallel.PipelinedGather(B, torch.float32, dev, group_steps=k)
+            for i in range(7):
+                t = pipe.submit(xs[i % 2], logp_out=gz.next_slot())
+                gz.staged(t)
+            pipe.drain()
+            full = gz.wait()
+            torch.cuda.synchronize()
+        assert torch.equal(gz.last_block(0), wants[6 % 2]), k
+        prev = gz.out[gz.i % 2]
+        if k == 3:
+            assert all(torch.equal(prev[0, t], wants[(3 + t) % 2]) for t in range(3))
+        else:
+            assert torch.equal(prev, wants[5 % 2])
+        gz.close()
     rep = parallel.gather_report(B, torch.float32, dev)
     assert rep["rows_per_rank"] == [B] and rep["gather_us"] is not None and rep["gather_us"] > 0.0
 

@@ -87,6 +87,18 @@ def _pipe_worker(rank, world, port, q):
         # slot of step 3 (the other buffer) holds step 3's gather
         expect3 = torch.cat([torch.full((n,), float(10 * 3 + r), dtype=torch.float64) for r in range(world)])
         ok = ok and bool(torch.equal(bufs[3][1], expect3))
+        # fewer, larger collectives: three steps per all-gather, 11 steps = three full exchanges + a partly filled stage that wait() exchanges
+        pk = parallel.PipelinedGather(n, torch.float64, torch.device("cpu"), depth=2, group_steps=3)
+        for step in range(11):
+            pk.submit(torch.full((n,), float(100 * step + rank), dtype=torch.float64))
+        full = pk.wait()
+        ok = ok and tuple(full.shape) == (world, 3, n)
+        for r in range(world):                               # the last exchange holds steps 9, 10 (and, in its third slot, step 5 of the stage's previous use)
+            ok = ok and bool((full[r, 0] == 100 * 9 + r).all()) and bool((full[r, 1] == 100 * 10 + r).all()) and bool((full[r, 2] == 100 * 5 + r).all())
+            ok = ok and bool(torch.equal(pk.last_block(r), torch.full((n,), float(100 * 10 + r), dtype=torch.float64)))
+        prev = pk.out[pk.i % 2]                              # the other output buffer: steps 6, 7, 8
+        for r in range(world):
+            ok = ok and all(bool((prev[r, t] == 100 * (6 + t) + r).all()) for t in range(3))
         q.put((rank, ok))
     finally:
         dist.destroy_process_group()
