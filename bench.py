@@ -1093,7 +1093,9 @@ def main():
             if gather is not None:
                 gather.wait()                         # every step's gather has landed inside the timed region
 
-        timer = _hip.KernelTimer() if dname == main_dt else None
+        # HIP events around the kernels of every 4th replay of a plan (the instrumentation costs ~2 % of a 2^20-row step and ~7 % of a 2^17-row
+        # shard step when every replay carries it; 20 steps still give 5 timed replays per kernel; totals are scaled to all replays)
+        timer = _hip.KernelTimer(plan_every=4) if dname == main_dt else None
         # bring the chip to its sustained clocks first: a 20-step region of 0.8 ms steps starts ~20 ms after the GPU sat idle (inputs were being
         # generated on the host), inside the power-management ramp -- the same plan measured 0.86 ms per step there and 0.78 ms once it had run for
         # 50 ms.  Untimed, before the contract's own W warm-up steps; reported in the line (`preheat_ms`).

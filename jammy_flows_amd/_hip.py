@@ -355,9 +355,11 @@ class KernelTimer:
             d[1] += e0.elapsed_time(e1)
         for plan in self.plans:                     # steps replayed from a plan while this timer was active (events recorded by jf_plan_launch)
             for (name, tag), (n, ms) in plan.read_timing().items():
+                # plan_every > 1: only every n-th replay carried events; launches / total_ms are scaled to ALL replays (mean_ms is the measured mean)
+                scale = (plan.replays_since_read / n) if (n > 0 and plan.replays_since_read > n) else 1.0
                 d = out.setdefault((name, tag), [0, 0.0])
-                d[0] += n
-                d[1] += ms
+                d[0] += n * scale
+                d[1] += ms * scale
         return {k: {"launches": v[0], "mean_ms": v[1] / v[0], "total_ms": v[1]} for k, v in out.items() if v[0]}
 
 
@@ -533,8 +535,10 @@ class StepPlan:
         if timed != self._timing:
             lib().jf_plan_set_timing(self.handle, timed)
             self._timing = timed
-        if timed and self not in _TIMER.plans:
-            _TIMER.plans.append(self)
+        if timed:
+            self._replays_under_timer = getattr(self, "_replays_under_timer", 0) + 1
+            if self not in _TIMER.plans:
+                _TIMER.plans.append(self)
         if torch.cuda.current_device() == dev.index:
             rc = lib().jf_plan_launch(self.handle, b, self.n_slots, (stream if stream is not None else torch.cuda.current_stream(dev)).cuda_stream)
         else:
@@ -550,6 +554,8 @@ class StepPlan:
         for name, tag, a, b in self.calls:
             if b > a:
                 out[(name, tag)] = (int(n.value), sum(self._ms[i] for i in range(a, b)))
+        # replays issued while a timer was active since the last read (every n-th of them carried events: KernelTimer.plan_every)
+        self.replays_since_read, self._replays_under_timer = getattr(self, "_replays_under_timer", 0), 0
         return out
 
 
