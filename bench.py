@@ -825,8 +825,14 @@ def shard_with_exchange(workload, rows, gather_steps, full_ms):
     region) runs `bench.py --batch rows` with a process group of ONE rank (JF_FORCE_COLLECTIVES=1), so every step hands its log-probs to RCCL"""
     cmd = [sys.executable, os.path.abspath(__file__), "--workload", workload, "--batch", str(rows), "--gather-steps", str(gather_steps), "--no-cpu-baseline",
            "--no-pmc", "--no-sweep", "--steps", "400", "--warmup", "20"]
-    env = dict(os.environ, JF_FORCE_COLLECTIVES="1")
+    env = dict(os.environ, JF_FORCE_COLLECTIVES="1", MASTER_ADDR="127.0.0.1")
     try:
+        import socket
+        with socket.socket() as sk:                             # a free rendezvous port for the child's one-rank group
+            sk.bind(("127.0.0.1", 0))
+            env["MASTER_PORT"] = str(sk.getsockname()[1])
+        for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+            env.pop(k, None)
         r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
         d = json.loads([l for l in r.stdout.decode().splitlines() if l.startswith("{")][-1])
         return {"rows": rows, "ms_per_step": round(d["ms_per_step"], 5), "host_issue_ms_per_step": round(d.get("host_issue_ms_per_step") or 0.0, 5),
