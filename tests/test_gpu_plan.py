@@ -121,6 +121,49 @@ def test_kernel_timer_sees_the_kernels_of_a_replayed_plan():
     assert all(v["launches"] == 5 and v["mean_ms"] > 0 for v in table.values()), table
 
 
+def test_kernel_timer_sampling_scales_to_all_replays():
+    """KernelTimer(plan_every=4) (bench.py): events on every 4th replay only; launches / total_ms are scaled to all replays, mean_ms is measured"""
+    from jammy_flows_amd import _hip
+    fx = [f for f in SUPPORTED if f.name == "c3_e4s2e4"][0]
+    pdf = build_product(fx, torch.float32)
+    pdf.check_status = False
+    x = to_dev(np.tile(fx["x"], (400, 1)), torch.float32)
+    pf = pdf.planned_forward(x)
+    t = _hip.KernelTimer(plan_every=4)
+    with t:
+        for _ in range(12):
+            pf(x)
+    table = t.summary()
+    assert table and all(abs(v["launches"] - 12) < 1e-9 and v["mean_ms"] > 0 and abs(v["total_ms"] - 12 * v["mean_ms"]) < 1e-9 for v in table.values()), table
+
+
+def test_plan_sees_a_replaced_parameter_object():
+    """the plan's parameter key walks a kept tensor list (the nn.Module walk was half of a shard step's host time) and looks at the module again
+    every 256th call: a Parameter OBJECT that was replaced is seen within that many steps; invalidate_packed_caches() is immediate"""
+    fx = [f for f in SUPPORTED if f.name == "c2_e4_gggg"][0]
+    pdf = build_product(fx, torch.float64)
+    x = to_dev(fx["x"], torch.float64)
+    pdf.use_step_plans = True
+    a = pdf(x)[0].clone()
+    name, old_p = next(iter(pdf.named_parameters()))
+    owner = pdf
+    for part in name.split(".")[:-1]:
+        owner = getattr(owner, part)
+    setattr(owner, name.split(".")[-1], torch.nn.Parameter(old_p.detach() * 1.02))
+    for _ in range(260):
+        b = pdf(x)[0]
+    pdf.use_step_plans = False
+    want = pdf(x)[0]
+    assert same(b, want) and not same(b, a)
+    # ... and at once after invalidate_packed_caches()
+    pdf.use_step_plans = True
+    setattr(owner, name.split(".")[-1], torch.nn.Parameter(old_p.detach() * 0.97))
+    pdf.invalidate_packed_caches()
+    c = pdf(x)[0]
+    pdf.use_step_plans = False
+    assert same(c, pdf(x)[0]) and not same(c, b)
+
+
 def test_mlp_inputs_read_in_place_equal_the_materialised_rows():
     """_hip.SegInput: cat[conditional_input, embed(x_0), ...] (main/default.py:946-962) read by the consumer kernel from the segments themselves
     (csrc/jf_cond_in.h).  float32: angles embedded with the hardware sine / cosine -> within 1e-4 of the materialised path on log p (bar 1e-2);
