@@ -32,6 +32,11 @@ import os
 for _v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS", "NUMEXPR_NUM_THREADS"):
     os.environ.setdefault(_v, "1")
 
+# hardware queues of the HIP runtime (read when it initialises; default 4): an N > 1 step keeps six streams busy -- the caller's, the pipelined
+# steps', the exchange's side stream and RCCL's own -- and streams that share a queue serialise: the 2^17-row shard step with its exchange takes
+# 0.118 ms on 4 queues and 0.094-0.097 on 8 (same-box A/B, one-rank RCCL group); without an exchange 4 or 8 queues time the same
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import argparse  # noqa: E402
 import glob  # noqa: E402
 import hashlib  # noqa: E402
@@ -820,12 +825,16 @@ def rows_sweep(pdf, x, c, steps=50, depth=1):
     return out
 
 
-def shard_with_exchange(workload, rows, gather_steps, full_ms):
-    """the step of an 8-GPU shard through this script's N > 1 path, measured on this one GPU: a child process (fresh GPU context, after the timed
-    region) runs `bench.py --batch rows` with a process group of ONE rank (JF_FORCE_COLLECTIVES=1), so every step hands its log-probs to RCCL"""
+def shard_with_exchange(workload, rows, gather_steps, full_ms, exchange=True):
+    """the step of an 8-GPU shard as a rank of that run would execute it, measured on this one GPU: a child process (fresh GPU context, after the
+    timed region) runs `bench.py --batch rows`; exchange: through the N > 1 path, with a process group of ONE rank (JF_FORCE_COLLECTIVES=1), so
+    every step hands its log-probs to RCCL"""
     cmd = [sys.executable, os.path.abspath(__file__), "--workload", workload, "--batch", str(rows), "--gather-steps", str(gather_steps), "--no-cpu-baseline",
            "--no-pmc", "--no-sweep", "--steps", "400", "--warmup", "20"]
-    env = dict(os.environ, JF_FORCE_COLLECTIVES="1", MASTER_ADDR="127.0.0.1")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.pop("JF_FORCE_COLLECTIVES", None)
+    if exchange:
+        env["JF_FORCE_COLLECTIVES"] = "1"
     try:
         import socket
         with socket.socket() as sk:                             # a free rendezvous port for the child's one-rank group
@@ -836,9 +845,9 @@ def shard_with_exchange(workload, rows, gather_steps, full_ms):
         r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
         d = json.loads([l for l in r.stdout.decode().splitlines() if l.startswith("{")][-1])
         return {"rows": rows, "ms_per_step": round(d["ms_per_step"], 5), "host_issue_ms_per_step": round(d.get("host_issue_ms_per_step") or 0.0, 5),
-                "exchange": d.get("exchange"), "collective_backend": d.get("collective_backend"),
+                "exchange": d.get("exchange"), "collective_backend": d.get("collective_backend"), "pipeline_depth": d.get("pipeline_depth"),
                 "predicted_8gpu_strong_scaling_efficiency": full_ms / (8 * d["ms_per_step"]),
-                "command": "JF_FORCE_COLLECTIVES=1 python bench.py --batch %d --gather-steps %d" % (rows, gather_steps)}
+                "command": "%spython bench.py --batch %d --gather-steps %d" % ("JF_FORCE_COLLECTIVES=1 " if exchange else "", rows, gather_steps)}
     except Exception as e:                                     # noqa: BLE001 -- reported, never hidden
         return {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
 
@@ -934,9 +943,13 @@ def main():
                     help="run the step untimed for this long before the warm-up steps, so that the timed region sees the chip's sustained clocks (0 = off)")
     ap.add_argument("--no-sweep", action="store_true", help="skip the rows sweep and the table of the other BASELINE configurations (measured after the timed region)")
     ap.add_argument("--no-plan", action="store_true", help="eager pdf.forward (one ctypes call per launch) instead of the recorded step plan")
-    ap.add_argument("--pipeline-depth", type=int, default=2,
+    ap.add_argument("--pipeline-depth", type=int, default=None,
                     help="log-prob steps alternate between this many HIP streams, each through its own recorded plan (pdf.pipelined_forward): the batches "
-                         "of consecutive steps are independent, so the tail of one step overlaps the head of the next; 1 = one stream")
+                         "of consecutive steps are independent, so the tail of one step overlaps the head of the next; 1 = one stream.  Three streams: same-box "
+                         "A/B against two -- 2^20 rows 0.663 / 0.663 ms, 2^19 0.335 / 0.338, 2^18 0.172 / 0.175, 2^17 0.0889 / 0.0920, 2^16 0.053 / 0.061; four "
+                         "are slower at every size.  Default: 3, and 2 when the steps also feed the exchange of an N > 1 run (with the side stream and "
+                         "RCCL's own stream that is one stream fewer on the hardware queues: 2^17 rows 0.0935 against 0.0965 ms, both with "
+                         "GPU_MAX_HW_QUEUES=8, which this script sets -- on the runtime's default of 4 queues three streams + exchange take 0.118 ms)")
     ap.add_argument("--gather-steps", type=int, default=4,
                     help="N > 1: the log-probs of this many consecutive steps travel in ONE all-gather (parallel.PipelinedGather(group_steps=k): fewer, larger "
                          "collectives -- an RCCL enqueue costs ~50 us of host time whatever its size); every step's rows are exchanged inside the timed region")
@@ -946,6 +959,9 @@ def main():
                     help="exercise launch / rendezvous / row sharding / timing loop / all-gather with a stand-in step on the host (no GPU, no kernels): "
                          "the line carries \"dry_run\": true and no throughput claim.  For the CPU tests (JF_BENCH_BACKEND=gloo)")
     args = ap.parse_args()
+    if args.pipeline_depth is None:
+        n_ranks = int(os.environ.get("WORLD_SIZE", "1")) if "WORLD_SIZE" in os.environ else args.gpus
+        args.pipeline_depth = 2 if (n_ranks > 1 or os.environ.get("JF_FORCE_COLLECTIVES") == "1") else 3
     if args.train:
         args.direction = "train"
     W = WORKLOADS[args.workload]
@@ -1375,7 +1391,15 @@ def main():
                                               "of this script (a one-rank RCCL process group in a child process, JF_FORCE_COLLECTIVES=1: the exchange's "
                                               "host and device cost without the cross-GPU wait)")
                 if world == 1 and not multi:
-                    line["rows_sweep"]["with_exchange"] = shard_with_exchange(args.workload, (1 << top) // 8, args.gather_steps, t1)
+                    # the shard step as a rank of the 8-GPU run executes it -- a fresh process that runs nothing else (the in-process sweep above
+                    # reads ~10 % more at 2^17 rows: it follows every other size's plans and streams in this process) --, with and without the exchange
+                    rs = line["rows_sweep"]
+                    rs["in_process_sweep_predicted_8gpu_strong_scaling_efficiency"] = rs["predicted_8gpu_strong_scaling_efficiency"]
+                    rs["with_exchange"] = shard_with_exchange(args.workload, (1 << top) // 8, args.gather_steps, t1)
+                    rs["compute_only_fresh_process"] = shard_with_exchange(args.workload, (1 << top) // 8, args.gather_steps, t1, exchange=False)
+                    if "predicted_8gpu_strong_scaling_efficiency" in rs["with_exchange"]:
+                        rs["predicted_8gpu_strong_scaling_efficiency"] = rs["with_exchange"]["predicted_8gpu_strong_scaling_efficiency"]
+                        rs["predicted_8gpu_strong_scaling_efficiency_source"] = "with_exchange (T_1 / 8 T(2^17 rows through the N > 1 path))"
         if rank == 0 and world == 1 and not args.no_sweep:
             # the other BASELINE configurations, after the timed region (C3 float64 is the `float64` object above)
             table = {}

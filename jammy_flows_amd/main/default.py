@@ -1151,7 +1151,7 @@ class pdf(nn.Module):
         images, flattened permanent rows); a call after a parameter update records again by itself (parameter version counters)."""
         return PlannedForward(self, x, conditional_input, kwargs)
 
-    def pipelined_forward(self, x, conditional_input=None, depth=2, **kwargs):
+    def pipelined_forward(self, x, conditional_input=None, depth=3, **kwargs):
         """forward() for a stream of independent batches of THIS signature -> PipelinedForward: submit(x, conditional_input) enqueues a step on
         one of `depth` alternating streams and returns a PendingStep (result() -> (log_prob, log_prob_base, base) once the caller's stream has
         been made to wait for it); drain() waits for all.  Keep `depth` steps in flight: the tail of one step overlaps the head of the next."""
