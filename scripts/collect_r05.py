@@ -17,6 +17,8 @@ P = os.path.join(ROOT, "profiles")
 subprocess.check_call([sys.executable, os.path.join(ROOT, "scripts", "collect_profiles.py"), "r05", "c3", "c5"])
 for wl in ("c2", "c4"):
     shutil.copy(os.path.join(G, "prof_r05_%s" % wl, "kernel_stats.md"), os.path.join(P, "r05_%s_kernel_stats.md" % wl))
+if os.path.exists(os.path.join(G, "prof_r05_c3_one_stream", "kernel_stats.md")):
+    shutil.copy(os.path.join(G, "prof_r05_c3_one_stream", "kernel_stats.md"), os.path.join(P, "r05_c3_one_stream_kernel_stats.md"))
 for wl in ("c3", "c5"):
     f = os.path.join(G, "prof_r05_%s_train" % wl, "kernel_stats.md")
     if os.path.exists(f):

@@ -3,6 +3,11 @@
 export TMPDIR=/tmp
 bash scripts/profile_step.sh r05_c3 > gpurun_out/prof_r05_c3.log 2>&1
 bash scripts/profile_step.sh r05_c5 --workload c5 --scaling weak > gpurun_out/prof_r05_c5.log 2>&1
+# the same step on ONE stream: kernels do not overlap, so rocprofv3's average and the line's mean_launch_ms are the same quantity (with three streams
+# a launch's duration is stretched by its neighbours, and differently under the profiler)
+out=gpurun_out/prof_r05_c3_one_stream; rm -rf $out; mkdir -p $out
+rocprofv3 --kernel-trace --stats -d $out/stats -- python3 bench.py --no-pmc --no-sweep --no-cpu-baseline --pipeline-depth 1 > $out/stats.log 2>&1
+f=$(find $out/stats -name "*.db" | head -1); [ -n "$f" ] && python3 scripts/rocprof_summary.py $f > $out/kernel_stats.md 2>&1; rm -rf $out/stats
 for wl in c2 c4; do
   out=gpurun_out/prof_r05_$wl; rm -rf $out; mkdir -p $out
   rocprofv3 --kernel-trace --stats -d $out/stats -- python3 bench.py --no-pmc --no-sweep --no-cpu-baseline --workload $wl > $out/stats.log 2>&1
