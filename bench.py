@@ -923,8 +923,8 @@ def side_config(key, dev, steps=20):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c3")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="strong",
                     help="strong (default, BASELINE.md section 3: efficiency = T_1 / (G T_G) at FIXED TOTAL batch): the configuration's batch is row-sharded "
@@ -1099,6 +1099,9 @@ def main():
                     gather.staged(t)
                 else:
                     t = pipe.submit(x, c)
+                # (the log-probs are what the step is for: the other two outputs -- 44 MB at 2^20 rows -- go back to the allocator at once, as
+                #  they do for a caller that does not hold on to them; holding three steps' worth of them alive rotates the writes over ~190 MB)
+                t.outputs = t.outputs[:1]
                 last["pending"] = t
                 return
             logp = pdf(x, conditional_input=c)[0]
@@ -1116,8 +1119,8 @@ def main():
                 gather.wait()                         # every step's gather has landed inside the timed region
 
         # HIP events around the kernels of every 4th replay of a plan (the instrumentation costs ~2 % of a 2^20-row step and ~7 % of a 2^17-row
-        # shard step when every replay carries it; 20 steps still give 5 timed replays per kernel; totals are scaled to all replays)
-        timer = _hip.KernelTimer(plan_every=4) if dname == main_dt else None
+        # shard step when every replay carries it; the default 50 steps give a dozen timed replays per kernel; totals are scaled to all replays)
+        timer = _hip.KernelTimer(plan_every=int(os.environ.get("JF_BENCH_TIMER_EVERY", "4"))) if dname == main_dt else None
         # bring the chip to its sustained clocks first: a 20-step region of 0.8 ms steps starts ~20 ms after the GPU sat idle (inputs were being
         # generated on the host), inside the power-management ramp -- the same plan measured 0.86 ms per step there and 0.78 ms once it had run for
         # 50 ms.  Untimed, before the contract's own W warm-up steps; reported in the line (`preheat_ms`).

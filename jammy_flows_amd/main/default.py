@@ -2049,6 +2049,16 @@ class PlannedForward:
             self.pdf._report_status(words)
 
 
+_PIPELINE_STREAMS = {}
+
+
+def _pipeline_streams(dev, depth):
+    pool = _PIPELINE_STREAMS.setdefault((dev.type, dev.index), [])
+    while len(pool) < depth:
+        pool.append(torch.cuda.Stream(device=dev))
+    return pool[:depth]
+
+
 class PendingStep:
     """one submitted step of a PipelinedForward: `outputs` = (log_prob, log_prob_base, base), being computed on `stream`; `event` fires when they
     are complete.  result() makes the CALLER's current stream wait for them (not the host) and returns them."""
@@ -2080,7 +2090,10 @@ class PipelinedForward:
         self.dev = _hip.require_device(x, conditional_input if isinstance(conditional_input, torch.Tensor) else None)
         self.pdf, self.depth, self.i = pdf, depth, 0
         caller = torch.cuda.current_stream(self.dev)
-        self.streams = [torch.cuda.Stream(device=self.dev) for _ in range(depth)] if depth > 1 else [caller]
+        # the step streams are shared by every PipelinedForward of the process (per device): the HIP runtime maps streams onto a few hardware
+        # queues (4 by default, GPU_MAX_HW_QUEUES), and streams that share a queue serialise -- a process that made a fresh set of streams for every
+        # pipeline (bench.py's rows sweep: one per batch size) measured 0.099 ms for the 2^17-row step that takes 0.089 in a fresh process
+        self.streams = _pipeline_streams(self.dev, depth) if depth > 1 else [caller]
         self.plans = []
         # the two side blocks in ONE launch (merge_max_rows) pay on one stream at every size (2^20 rows: 0.714 vs 0.730 ms) and, with steps on
         # alternating streams, up to 2^19 rows (2^17: 0.106 vs 0.115); at 2^20 rows two separate launches interleave better with the neighbour

@@ -5,7 +5,7 @@ tag=$1; shift
 out=gpurun_out/prof_$tag
 mkdir -p $out
 export TMPDIR=/tmp
-# the stats pass runs the DEFAULT bench command (20 timed steps, clocks ramped) so that its per-kernel averages are the ones the bench line reports
+# the stats pass runs the DEFAULT bench command (the default number of timed steps, clocks ramped) so that its per-kernel averages are the ones the bench line reports
 rocprofv3 --kernel-trace --stats -d $out/stats -- python3 bench.py --no-pmc --no-sweep "$@" > $out/stats.log 2>&1     # (--no-sweep: only full-size launches, so the averages are the timed step's)
 rocprofv3 --pmc FETCH_SIZE -d $out/fetch -- python3 bench.py --pmc-child "$@" > $out/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE -d $out/write -- python3 bench.py --pmc-child "$@" > $out/write.log 2>&1
