@@ -73,6 +73,9 @@ def sharded_log_prob(pdf, x, conditional_input=None, gather=True, evaluate=None,
     return all_gather_rows(local, x.shape[0]) if gather else local
 
 
+_SIDE_STREAMS = {}
+
+
 class PipelinedGather:
     """all-gather of equal-sized per-rank row blocks that overlaps with the NEXT step's kernels: submit() enqueues the collective
     asynchronously (on a communication stream, once the producer kernels of `local` on the CURRENT stream are done) into one of `depth` rotating
@@ -182,8 +185,11 @@ class PipelinedGather:
             for ev in evs:
                 cur.wait_event(ev)
             return self._exchange(stage)
-        if self.side_stream is None:
-            self.side_stream = torch.cuda.Stream(device=self.device)
+        if self.side_stream is None:                       # one exchange stream per device for the whole process (streams are mapped onto a few
+            key = (self.device.type, self.device.index)    # hardware queues: every extra one can land on a step stream's queue and serialise with it)
+            if key not in _SIDE_STREAMS:
+                _SIDE_STREAMS[key] = torch.cuda.Stream(device=self.device)
+            self.side_stream = _SIDE_STREAMS[key]
         torch.cuda.set_stream(self.side_stream)
         try:
             for ev in evs:
