@@ -947,9 +947,8 @@ def main():
                     help="log-prob steps alternate between this many HIP streams, each through its own recorded plan (pdf.pipelined_forward): the batches "
                          "of consecutive steps are independent, so the tail of one step overlaps the head of the next; 1 = one stream.  Three streams: same-box "
                          "A/B against two -- 2^20 rows 0.663 / 0.663 ms, 2^19 0.335 / 0.338, 2^18 0.172 / 0.175, 2^17 0.0889 / 0.0920, 2^16 0.053 / 0.061; four "
-                         "are slower at every size.  Default: 3, and 2 when the steps also feed the exchange of an N > 1 run (with the side stream and "
-                         "RCCL's own stream that is one stream fewer on the hardware queues: 2^17 rows 0.0935 against 0.0965 ms, both with "
-                         "GPU_MAX_HW_QUEUES=8, which this script sets -- on the runtime's default of 4 queues three streams + exchange take 0.118 ms)")
+                         "are slower at every size.  With the exchange of an N > 1 run (GPU_MAX_HW_QUEUES=8, which this script sets: on the runtime's default "
+                         "of 4 queues three streams + exchange take 0.118 ms): 2^17 rows 0.0916 on three streams, 0.0946 on two")
     ap.add_argument("--gather-steps", type=int, default=4,
                     help="N > 1: the log-probs of this many consecutive steps travel in ONE all-gather (parallel.PipelinedGather(group_steps=k): fewer, larger "
                          "collectives -- an RCCL enqueue costs ~50 us of host time whatever its size); every step's rows are exchanged inside the timed region")
@@ -960,8 +959,7 @@ def main():
                          "the line carries \"dry_run\": true and no throughput claim.  For the CPU tests (JF_BENCH_BACKEND=gloo)")
     args = ap.parse_args()
     if args.pipeline_depth is None:
-        n_ranks = int(os.environ.get("WORLD_SIZE", "1")) if "WORLD_SIZE" in os.environ else args.gpus
-        args.pipeline_depth = 2 if (n_ranks > 1 or os.environ.get("JF_FORCE_COLLECTIVES") == "1") else 3
+        args.pipeline_depth = 3
     if args.train:
         args.direction = "train"
     W = WORKLOADS[args.workload]
@@ -1095,7 +1093,7 @@ def main():
                 if gather is not None:
                     # the step writes its log-probs straight into the stage of the next exchange; every --gather-steps-th step the exchange is
                     # issued from a side stream that waits for the staged steps' completion events (parallel.PipelinedGather.next_slot / staged)
-                    t = pipe.submit(x, c, logp_out=gather.next_slot())
+                    t = pipe.submit(x, c, logp_out=gather.next_slot(pipe.peek_stream()))
                     gather.staged(t)
                 else:
                     t = pipe.submit(x, c)

@@ -2110,6 +2110,10 @@ class PipelinedForward:
         finally:
             pdf.merge_max_rows = keep
 
+    def peek_stream(self):
+        """the stream the NEXT submit() will run on"""
+        return self.streams[self.i % self.depth]
+
     def submit(self, x, conditional_input=None, logp_out=None):
         """enqueue one step; returns a PendingStep at once.  The step starts when the work queued so far on the caller's current stream (the
         producer of x) is done; the caller's stream does NOT wait for the step -- PendingStep.result() / drain() do that.  logp_out: a buffer

@@ -106,6 +106,7 @@ class PipelinedGather:
         self.n_staged = 0
         self.n_submitted = 0
         self.staged_ev = []
+        self._guarded = set()
         self._zero_copy = False
         self.side_stream = None
         self.work = [None] * depth
@@ -149,17 +150,33 @@ class PipelinedGather:
         return self._exchange(local)           # (submit() copies, next_slot() / staged() do not: one gather object uses one of the two)
 
     # ---- zero-copy staging for pipelined steps: the step writes its rows straight into the stage of the next exchange
-    def next_slot(self):
+    def next_slot(self, stream=None):
         """the (rows, ...) tensor the NEXT step should write its per-row result into -- pass it as `logp_out` to PipelinedForward.submit(), then
-        hand the PendingStep to staged().  No copy, no per-step event: the steps' own completion events order the exchange behind them, and the
-        caller's current stream (which every pipelined step waits for) is made to wait ONCE per stage for the exchange that last read it."""
+        hand the PendingStep to staged().  No copy, no per-step event: the steps' own completion events order the exchange behind them.  The
+        exchange that last read this stage must be over before it is written again: `stream` (the stream the step will run on,
+        PipelinedForward.peek_stream()) waits for it, once per stage and stream; without it the caller's current stream (which every pipelined
+        step waits for) does, once per stage."""
         j = self.i % len(self.out)
         self._zero_copy = True
         if self.stage is None:                              # group_steps = 1: one send buffer per slot
             self.stage = [torch.zeros((1, self.n_rows_local) + tuple(self.out[0].shape[1:]), dtype=self.out[0].dtype, device=self.device)
                           for _ in range(len(self.out))]
-        if self.n_staged == 0:
-            self._wait_on_current(self.work[j])
+        w = self.work[j]
+        if w is not None:
+            if stream is None:
+                if self.n_staged == 0:
+                    self._wait_on_current(w)
+            elif stream.cuda_stream not in self._guarded:
+                self._guarded.add(stream.cuda_stream)
+                if self.comm is not None:
+                    stream.wait_event(w)
+                else:
+                    cur = torch.cuda.current_stream(self.device)
+                    torch.cuda.set_stream(stream)
+                    try:
+                        w.wait()
+                    finally:
+                        torch.cuda.set_stream(cur)
         return self.stage[j][self.n_staged]
 
     def staged(self, pending):
@@ -176,6 +193,7 @@ class PipelinedGather:
         """exchange stage j behind the events of the submissions that filled it; side: from the side stream (zero-copy staging: the caller's
         stream, which every pipelined step waits for, must not wait for the steps), else from the current stream"""
         self.n_staged = 0
+        self._guarded = set()
         evs, self.staged_ev = self.staged_ev, []
         stage = self.stage[j] if self.k > 1 else self.stage[j][0]
         if self.device.type != "cuda":

@@ -82,16 +82,17 @@ def test_pipelined_steps_with_gather_on_the_step_stream(one_rank_rccl, monkeypat
     for k in (1, 3):
         with torch.no_grad():
             gz = parallel.PipelinedGather(B, torch.float32, dev, group_steps=k)
-            for i in range(7):
-                t = pipe.submit(xs[i % 2], logp_out=gz.next_slot())
+            for i in range(16 if k == 3 else 7):            # (k = 3: more than two stage cycles, so that the re-use guard on the step streams runs)
+                t = pipe.submit(xs[i % 2], logp_out=gz.next_slot(pipe.peek_stream() if k == 3 else None))
                 gz.staged(t)
             pipe.drain()
             full = gz.wait()
             torch.cuda.synchronize()
-        assert torch.equal(gz.last_block(0), wants[6 % 2]), k
+        n = 16 if k == 3 else 7
+        assert torch.equal(gz.last_block(0), wants[(n - 1) % 2]), k
         prev = gz.out[gz.i % 2]
-        if k == 3:
-            assert all(torch.equal(prev[0, t], wants[(3 + t) % 2]) for t in range(3))
+        if k == 3:                                           # 16 steps = 5 full exchanges + one step: the previous buffer holds steps 12, 13, 14
+            assert all(torch.equal(prev[0, t], wants[(12 + t) % 2]) for t in range(3))
         else:
             assert torch.equal(prev, wants[5 % 2])
         gz.close()
