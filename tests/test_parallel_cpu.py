@@ -99,6 +99,22 @@ def _pipe_worker(rank, world, port, q):
         prev = pk.out[pk.i % 2]                              # the other output buffer: steps 6, 7, 8
         for r in range(world):
             ok = ok and all(bool((prev[r, t] == 100 * (6 + t) + r).all()) for t in range(3))
+        # zero-copy staging (what bench.py's N > 1 steps do): the producer writes into next_slot(), staged() counts it; same layout across ranks
+
+        class _Step:
+            event = None
+        for k in (1, 4):
+            pz = parallel.PipelinedGather(n, torch.float64, torch.device("cpu"), depth=2, group_steps=k)
+            for step in range(9):
+                pz.next_slot().fill_(float(1000 * step + rank))
+                pz.staged(_Step())
+            full = pz.wait()
+            for r in range(world):
+                ok = ok and bool((pz.last_block(r) == 1000 * 8 + r).all())
+            if k == 4:                                        # 9 steps = two full exchanges + step 8 alone in the third (slots 1..3: steps 1..3 of the stage's first use)
+                ok = ok and tuple(full.shape) == (world, 4, n)
+                ok = ok and all(bool((full[r, 0] == 8000 + r).all()) and bool((full[r, 1] == 1000 + r).all()) for r in range(world))
+                ok = ok and all(bool((pz.out[pz.i % 2][r, t] == 1000 * (4 + t) + r).all()) for r in range(world) for t in range(4))
         q.put((rank, ok))
     finally:
         dist.destroy_process_group()
