@@ -259,14 +259,17 @@ __device__ __forceinline__ T cs_solve(const T (&P)[CS_SLOTS], int inv_type, bool
         if constexpr (sizeof(T) == 4) {
             // float32 floor of the update (see gfg_solve): the reference's float32 runs spend their last ~16 Newton steps on rounding noise
             const T xs = rsum(live ? Mf::max(Mf::abs(x), T(1)) : T(0));
-            if (active && usum >= T(0.5) * prev && usum < T(1e-4) * xs && !(usum < T(2.5e-7) * xs)) coarse_end = true;   // stopped on stagnation
-            if (usum < T(2.5e-7) * xs || (usum >= T(0.5) * prev && usum < T(1e-4) * xs)) active = false;
+            // at the coordinates' resolution, or (jf_math.h) below JF_F32_NEWTON_FLOOR of them with the residual of the evaluation just made
+            // already inside the reference's own convergence threshold (1e-4 in float32: what its report looks at, bisection_n_newton.py:118-131)
+            const bool done = usum < T(2.5e-7) * xs || (usum < T(JF_F32_NEWTON_FLOOR) * xs && rmax(live ? Mf::abs(f) : T(0)) <= T(1e-4));
+            if (active && usum >= T(0.5) * prev && usum < T(1e-4) * xs && !done) coarse_end = true;   // stopped on stagnation
+            if (done || (usum >= T(0.5) * prev && usum < T(1e-4) * xs)) active = false;
             prev = usum;
         }
     }
     if (logd_out != nullptr) {
         // the stage's log-derivative at the solution (the caller's log-det term).  A converged row's last update was below 1e-9 (NewtonTol; float32: below
-        // 2.5e-7 of the coordinate -- its rounding), so the value of its last evaluation IS the value at the returned point to rounding: one
+        // JF_F32_NEWTON_FLOOR = 1e-5 of the coordinate, jf_math.h), so the value of its last evaluation IS the value at the returned point to rounding: one
         // evaluation (mixture + inverse CDF; a fifth of a float64 solve) saved.  A wave with a row that ran out of iterations, or -- float32 --
         // stopped on the stagnation rule (updates up to 1e-4 of the coordinate), evaluates at the returned point as the reference does
         // (gaussianization_flow.py:922-924)

@@ -515,7 +515,8 @@ template <typename T, int G> __device__ __forceinline__ T gfg_solve(const T* __r
             // ~16 of them move the iterate by rounding noise.  A row is at that floor when its update has reached the resolution of its
             // coordinates, or has stopped shrinking while already below 1e-4 of them; further steps cannot improve it.
             const T xs = group_sum<T, G>(live ? M<T>::max(M<T>::abs(x), T(1)) : T(0));
-            if (usum < T(2.5e-7) * xs || (usum >= T(0.5) * prev && usum < T(1e-4) * xs)) active = false;
+            const bool done = usum < T(2.5e-7) * xs || (usum < T(JF_F32_NEWTON_FLOOR) * xs && group_max<T, G>(live ? M<T>::abs(f) : T(0)) <= T(1e-4));   // (jf_math.h)
+            if (done || (usum >= T(0.5) * prev && usum < T(1e-4) * xs)) active = false;
             prev = usum;
         }
     }
