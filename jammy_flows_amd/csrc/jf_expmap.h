@@ -587,7 +587,9 @@ template <typename T> __device__ inline void v_newton(const T* __restrict__ pp, 
                     // a Gauss-Newton step below the reference's own 1e-12 threshold ends the row: at the root fn = 1 - y.t is rounding noise
                     // (+-1 ulp), and fn / |grad| -- the reference's criterion, which its slow approach reaches with fn rounding to exactly 0
                     // -- no longer measures the distance
-                    if (len < T(1e-12)) gn_done = true;
+                    // (round 5: 1e-7, not 1e-12 -- Gauss-Newton steps shrink quadratically, 1e-2, 1e-4, 1e-8, and the evaluation that would
+                    //  follow a step below 1e-7 only confirms with one of ~1e-14 x curvature: NewtonTol, jf_math.h)
+                    if (len < T(1e-7)) gn_done = true;
                 } else if (len == T(0)) {
                     gn_done = true;
                 }
