@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("JF_LIB_PATH") or os.path.join(_HERE, "libjammy_hip.so")
 
 JF_OK, JF_ERR_BADARG, JF_ERR_UNSUPPORTED, JF_ERR_LAUNCH = 0, -1, -2, -3
-JF_ERRORS = {-1: "bad argument", -2: "unsupported configuration (dimension > 8, chain too long, LDS budget ...)", -3: "kernel launch failed"}
+JF_ERRORS = {-1: "bad argument", -2: "unsupported configuration (a kernel cap: g / t beyond their dimension cap, spline bins, chain too long, LDS budget ...)", -3: "kernel launch failed"}
 JF_STATUS_WORDS = 4
 JF_STATUS_NONCONVERGED, JF_STATUS_NONFINITE, JF_STATUS_OUT_OF_RANGE, JF_STATUS_NEWTON_STEPS = 0, 1, 2, 3
 JF_MAX_CHAIN = 8

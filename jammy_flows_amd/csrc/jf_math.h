@@ -73,7 +73,10 @@ template <> struct M<double> {
     static __device__ __forceinline__ double exp_fast(double x) { return ::exp(x); }
     // Natural logarithm for the mixture sums (three per coordinate and layer; OCML's log is 98 VALU instructions, this one ~40): the classic
     // reduction x = 2^e m, m in [sqrt(1/2), sqrt(2)), f = m - 1, s = f / (2 + f), log m = f - f^2/2 + s (f^2/2 + R(s^2)) with the degree-7 even
-    // minimax polynomial R of FreeBSD msun's e_log.c (public domain constants Lg1..Lg7), < 1 ulp.  The division is rcp() above.
+    // minimax polynomial R of FreeBSD msun's e_log.c (coefficients Lg1..Lg7), < 1 ulp.  The division is rcp() above.
+    // The coefficients come from e_log.c, which carries this notice (kept here as it asks):
+    //   Copyright (C) 1993 by Sun Microsystems, Inc. All rights reserved.  Developed at SunPro, a Sun Microsystems, Inc. business.
+    //   Permission to use, copy, modify, and distribute this software is freely granted, provided that this notice is preserved.
     // Exact special values: log(0) = -inf, log(inf) = inf, log(x < 0) = log(nan) = nan; denormals go through v_frexp like everything else.
     static __device__ __forceinline__ double log_fast(double x) {
         int e = __builtin_amdgcn_frexp_exp(x);                         // x = m 2^e, m in [1/2, 1)
