@@ -327,6 +327,33 @@ def _stream(dev=None):
     return torch.cuda.current_stream(dev).cuda_stream
 
 
+# Side streams the library itself issues work on (the training streams of default.pdf).  The caching allocator hands a freed block back to the
+# pool of the stream it was ALLOCATED on: a tensor allocated on the caller's stream that a side-stream kernel still reads (or the reverse) must
+# be announced with record_stream, or its block can be handed out again while that kernel runs.
+SIDE_STREAMS = {}                 # cuda_stream handle -> torch.cuda.Stream
+
+
+def register_side_stream(st):
+    SIDE_STREAMS[st.cuda_stream] = st
+
+
+def record_on(stream, *tensors):
+    """announce that `stream` uses these tensors (None entries / CPU tensors are skipped)"""
+    for t in tensors:
+        if isinstance(t, torch.Tensor) and t.is_cuda and t.numel():
+            t.record_stream(stream)
+
+
+def record_if_side_stream(*tensors):
+    """inside a custom backward: when the node runs on one of the library's side streams (autograd runs a node on its forward's stream),
+    announce the tensors it reads there -- saved tensors are released on the host right after the node, while its kernel may still run"""
+    if not SIDE_STREAMS:
+        return
+    cs = torch.cuda.current_stream()
+    if cs.cuda_stream in SIDE_STREAMS:
+        record_on(cs, *tensors)
+
+
 class KernelTimer:
     """records a pair of HIP events (on torch's current stream = the stream the kernels are launched on) around every kernel launch
     made through this module while active; `summary()` (after a synchronize) gives per-kernel launch counts and mean durations."""

@@ -22,6 +22,18 @@ import torch
 from . import _hip
 
 
+def _side_stream_safe(backward):
+    """backward of a node that may run on one of the pdf's training side streams (default.pdf.train_streams): its saved tensors and incoming
+    gradients were (possibly) allocated on the caller's stream and are released on the host as soon as the node returns -- announce them to the
+    allocator first (_hip.record_if_side_stream; a no-op on the caller's stream)."""
+    def wrapped(ctx, *grads):
+        if _hip.SIDE_STREAMS:
+            _hip.record_if_side_stream(*ctx.saved_tensors, *grads)
+        return backward(ctx, *grads)
+    wrapped.__doc__ = backward.__doc__
+    return wrapped
+
+
 def _needs_grad(*ts):
     return torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad for t in ts)
 
@@ -50,6 +62,7 @@ class LinearFn(torch.autograd.Function):
         return out
 
     @staticmethod
+    @_side_stream_safe
     def backward(ctx, g):
         inp, weight, out = ctx.saved_tensors
         g = _hip.tanh_bwd(g, out) if ctx.act else g.contiguous()
@@ -76,6 +89,7 @@ class ActivationFn(torch.autograd.Function):
         return _hip.activation(z.detach(), code)
 
     @staticmethod
+    @_side_stream_safe
     def backward(ctx, g):
         (z,) = ctx.saved_tensors
         return _hip.activation_bwd(g, z, ctx.code), None
@@ -97,6 +111,7 @@ class Mlp2SmallFn(torch.autograd.Function):
         return _hip.mlp2(x.detach(), w1.detach(), b1.detach(), w2.detach(), b2.detach())
 
     @staticmethod
+    @_side_stream_safe
     def backward(ctx, g):
         x, w1, b1, w2 = ctx.saved_tensors
         g_w1, g_b1, g_w2, g_b2 = _hip.mlp2_small_bwd(x, w1, b1, w2, g)
@@ -122,6 +137,7 @@ class GfChainInvFn(torch.autograd.Function):
         return res
 
     @staticmethod
+    @_side_stream_safe
     def backward(ctx, g_xout, g_ld, g_blp):
         x, params = ctx.saved_tensors
         layer_array, n_layers, D, status = ctx.meta
@@ -147,6 +163,7 @@ class InverseJacobianFn(torch.autograd.Function):
         return torch.zeros_like(r)
 
     @staticmethod
+    @_side_stream_safe
     def backward(ctx, g):
         x0, blocks = ctx.x0, ctx.blocks
         rhs = g.clone()
@@ -180,6 +197,7 @@ class _SplitFlatFn(torch.autograd.Function):
         return tuple(flat.detach().split(sizes))
 
     @staticmethod
+    @_side_stream_safe
     def backward(ctx, *gs):
         like = next((g for g in gs if g is not None), None)
         if like is None:
@@ -220,6 +238,7 @@ class LowRankHeadFn(torch.autograd.Function):
         return t2
 
     @staticmethod
+    @_side_stream_safe
     def backward(ctx, g_t2):
         inp, v1, u1, v2, t1, h = ctx.saved_tensors
         g_inp, g_v1, g_u1, g_b1, g_v2 = _hip.lowrank_head_bwd(inp, v1, u1, v2, t1, h, g_t2, ctx.needs_input_grad[0])
@@ -250,6 +269,7 @@ class LowRankGfChainFn(torch.autograd.Function):
         return res[:3]
 
     @staticmethod
+    @_side_stream_safe
     def backward(ctx, g_xout, g_ld, g_blp):
         t2, u2, b2, z = ctx.saved_tensors
         layer_array, n_layers, D = ctx.meta
@@ -298,6 +318,7 @@ class CondBlockFn(torch.autograd.Function):
         return res
 
     @staticmethod
+    @_side_stream_safe
     def backward(ctx, g_xout, g_ld, g_blp):
         inp, w1, b1, w2, b2, x, z = ctx.saved_tensors
         layer_array, n_layers, D = ctx.meta
@@ -377,6 +398,7 @@ class SphereEmbeddingFn(torch.autograd.Function):
         return out, ld
 
     @staticmethod
+    @_side_stream_safe
     def backward(ctx, g_out, g_ld):
         dim, to_embedding, has_ld = ctx.meta
         x, out = ctx.saved_tensors
@@ -442,6 +464,7 @@ class MChainInvFn(torch.autograd.Function):
         return res
 
     @staticmethod
+    @_side_stream_safe
     def backward(ctx, g_xout, g_ld, g_blp):
         x, params = ctx.saved_tensors
         fam, structs, dim = ctx.meta
@@ -463,6 +486,7 @@ class TLayerInvFn(torch.autograd.Function):
         return res
 
     @staticmethod
+    @_side_stream_safe
     def backward(ctx, g_xout, g_ld, g_blp):
         x, params = ctx.saved_tensors
         struct, D = ctx.meta
@@ -481,6 +505,7 @@ class AmlpStageFn(torch.autograd.Function):
         return y if residual is None else y + residual
 
     @staticmethod
+    @_side_stream_safe
     def backward(ctx, g):
         x, seg, y = ctx.saved_tensors
         n_in, n_out, rank, has_bias, act = ctx.meta

@@ -1273,6 +1273,8 @@ class pdf(nn.Module):
             side = self._train_stream_objs.get(x.device)
             if side is None or len(side) != self.train_streams - 1:
                 side = self._train_stream_objs[x.device] = [torch.cuda.Stream(device=x.device) for _ in range(self.train_streams - 1)]
+                for st in side:
+                    _hip.register_side_stream(st)          # (the backward nodes of these blocks announce their saved tensors, autograd._side_stream_safe)
         main_stream = torch.cuda.current_stream(x.device)
         ld_parts, blp_parts = [], []
         for si, block in enumerate(self.layer_list):
@@ -1296,6 +1298,11 @@ class pdf(nn.Module):
                 if si < n_blocks - 1:                     # the last (usually largest) block stays on the caller's stream
                     st = side[si % len(side)]
                     st.wait_stream(main_stream)           # inputs (targets, embeddings, the cat above) were produced on the caller's stream
+                    # ... and were allocated there: announce their use on the side stream (the allocator would otherwise hand a block freed on
+                    # the host to the caller's stream again while this block's kernels still read it)
+                    _hip.record_on(st, x, inp, amort, *embeds)
+                    if conditional_input is not None:
+                        _hip.record_on(st, *(conditional_input if type(conditional_input) == list else [conditional_input]))
                     stream_ctx = torch.cuda.stream(st)
                     stream_ctx.__enter__()
             try:
@@ -1380,6 +1387,8 @@ class pdf(nn.Module):
             finally:
                 if stream_ctx is not None:
                     stream_ctx.__exit__(None, None, None)
+            if stream_ctx is not None:
+                _hip.record_on(main_stream, out, log_det, base_logp)      # side-stream allocations, summed / concatenated on the caller's stream
             if side is not None:
                 ld_parts.append(log_det)
                 blp_parts.append(base_logp)
@@ -1882,6 +1891,18 @@ def release_plan_memory():
         _RETIRED_POOLS.pop()
 
 
+# every nn.Module.register_parameter call of the process (a replaced Parameter object anywhere): PlannedForward._param_key walks its pdf's
+# parameters again when this moved
+_PARAM_REGISTRATIONS = [0]
+
+
+def _count_parameter_registration(module, name, param):
+    _PARAM_REGISTRATIONS[0] += 1
+
+
+torch.nn.modules.module.register_module_parameter_registration_hook(_count_parameter_registration)
+
+
 class PlannedForward:
     """pdf.forward recorded as a step plan for one input signature (see pdf.planned_forward)."""
 
@@ -1919,12 +1940,16 @@ class PlannedForward:
 
     def _param_key(self):
         # the in-place version counters of the pdf's parameters.  Walking nn.Module.parameters() costs ~25 us per call for the 26 tensors of C3 (half
-        # of a shard step's host time, scripts/probe/gather_cost.py): the tensor list is kept and walked again every 256th call -- a parameter
-        # OBJECT that was replaced (not written in place) bumps the generation and the plan is recorded again within 256 steps;
-        # pdf.invalidate_packed_caches() is the immediate way
+        # of a shard step's host time, scripts/probe/gather_cost.py): the tensor list is kept.  A parameter OBJECT that is replaced (module.weight =
+        # nn.Parameter(...), load_state_dict(assign=True), parametrisation swaps) goes through nn.Module.register_parameter, whose global hook bumps
+        # _PARAM_REGISTRATIONS: the list is walked again on the next call (it used to be noticed only every 256th call).  The periodic
+        # walk stays as a back-stop for edits that bypass register_parameter (module._parameters[...] = ...); pdf.invalidate_packed_caches() is the
+        # explicit way.
         n = self._key_calls = getattr(self, "_key_calls", 0) + 1
         ps = getattr(self, "_key_params", None)
-        if ps is None or (n & 255) == 0:
+        reg = _PARAM_REGISTRATIONS[0]
+        if ps is None or reg != getattr(self, "_key_reg", -1) or (n & 255) == 0:
+            self._key_reg = reg
             fresh = list(self.pdf.parameters())
             if ps is None or len(fresh) != len(ps) or any(a is not b for a, b in zip(fresh, ps)):
                 self._key_gen = getattr(self, "_key_gen", 0) + 1

@@ -5,9 +5,35 @@ replicated weights (< 1 MB); no data-path collective is needed.  The only exchan
 log-probabilities (4 MiB per rank at 2^20 float32 rows) -- one all_gather_into_tensor, never an all-reduce.
 """
 import os
+import warnings
 
 import torch
 import torch.distributed as dist
+
+# An N > 1 step keeps six streams busy (the caller's, up to three step streams, the exchange's side stream, RCCL's own) and the HIP runtime maps
+# streams onto GPU_MAX_HW_QUEUES hardware queues -- 4 by default; streams that share a queue serialise (a 2^17-row shard step 0.118 instead of
+# 0.091 ms, DESIGN section 6).  The variable is read when the runtime initialises, so it is set HERE, at import, while that has not happened yet;
+# later it can only be reported.
+HW_QUEUES_WANTED = 8
+
+
+def ensure_hw_queues(n=HW_QUEUES_WANTED):
+    """set GPU_MAX_HW_QUEUES >= n for this process if the HIP runtime has not started; returns what is in force ("set", "kept", or "late": the
+    runtime was already initialised with fewer -- a warning says so once)"""
+    cur = os.environ.get("GPU_MAX_HW_QUEUES")
+    if cur is not None and cur.isdigit() and int(cur) >= n:
+        return "kept"
+    started = torch.cuda.is_initialized() if hasattr(torch.cuda, "is_initialized") else False
+    if not started:
+        os.environ["GPU_MAX_HW_QUEUES"] = str(n)
+        return "set"
+    warnings.warn("jammy_flows_amd.parallel: the HIP runtime was initialised before this import with GPU_MAX_HW_QUEUES=%s (< %d): pipelined steps and "
+                  "their exchange will share hardware queues and serialise.  Import jammy_flows_amd.parallel (or export GPU_MAX_HW_QUEUES=%d) before "
+                  "the first GPU call." % (cur or "4 (runtime default)", n, n), RuntimeWarning, stacklevel=2)
+    return "late"
+
+
+HW_QUEUES_STATE = ensure_hw_queues()
 
 
 def collectives_active(group=None):
@@ -84,7 +110,9 @@ class PipelinedGather:
 
     group_steps = k > 1: FEWER, LARGER collectives -- k consecutive submissions are staged (one device copy each, on the submitting stream) and
     exchanged in ONE all-gather of (k, rows) per rank; the output buffer is then (world, k, rows, ...) and a step's rows arrive up to k - 1
-    submissions later (flush() / wait() exchange a partly filled stage).  An enqueue of RCCL costs ~50 us of host time and a few us of the device
+    submissions later (flush() / wait() exchange a partly filled stage).  NOTE: with k > 1 the buffer submit() / staged() return is the one the
+    stage WILL be exchanged into -- its exchange has not been issued until the k-th submission (or flush() / wait()); read rows through
+    wait() + last_block().  An enqueue of RCCL costs ~50 us of host time and a few us of the device
     whatever its size (scripts/probe/gather_cost.py: a 2^17-row shard step 0.103 -> 0.110 ms with one gather per step, 0.103 with one per four).
 
     `self.path` says what carries the exchange: "torch.distributed" (default), "rccl-direct" (JF_RCCL_DIRECT=1: ncclAllGather through ctypes,
@@ -105,6 +133,8 @@ class PipelinedGather:
             self.stage = [torch.zeros((self.k, n_rows_local) + tuple(tail_shape), dtype=dtype, device=device) for _ in range(depth)]
         self.n_staged = 0
         self.n_submitted = 0
+        self._last_row = 0                  # stage row of the most recent submission (n_staged restarts after flush() / wait(), n_submitted does not)
+        self._last_out = None               # ... and the buffer its exchange lands in
         self.staged_ev = []
         self._guarded = set()
         self._zero_copy = False
@@ -116,7 +146,12 @@ class PipelinedGather:
         self.path = "torch.distributed" if self.collective else "copy"
         if self.collective and self.device.type == "cuda":
             from . import rccl
-            if rccl.available():
+            # whether the direct path is tried at all is decided by ALL ranks (a rank without librccl.so or without JF_RCCL_DIRECT must not skip
+            # collectives the others enter): MIN of the local availability first, then -- on every rank of a group that tries -- the communicator
+            # (whose set-up always takes part in its broadcast, rccl.Communicator) and the MIN of the outcome
+            want = torch.tensor([1 if rccl.available() else 0], dtype=torch.int32, device=self.device)
+            dist.all_reduce(want, op=dist.ReduceOp.MIN, group=group)
+            if int(want.item()) == 1:
                 ok = 1
                 try:
                     self.comm = rccl.Communicator(self.device, group)
@@ -139,6 +174,7 @@ class PipelinedGather:
             j = self.i % len(self.out)
             self._wait_on_current(self.work[j])
             self.stage[j][self.n_staged].copy_(local)
+            self._last_row, self._last_out = self.n_staged, j
             if self.device.type == "cuda":
                 ev = torch.cuda.Event()
                 ev.record(torch.cuda.current_stream(self.device))
@@ -184,6 +220,7 @@ class PipelinedGather:
         the exchange, from a side stream that waits for the k steps."""
         self.n_submitted += 1
         self.staged_ev.append(pending.event)
+        self._last_row, self._last_out = self.n_staged, self.i % len(self.out)
         self.n_staged += 1
         if self.n_staged >= self.k:
             self._exchange_stage(self.i % len(self.out), side=True)
@@ -267,10 +304,10 @@ class PipelinedGather:
         return self.out[(self.i - 1) % len(self.out)] if self.i else None
 
     def last_block(self, rank):
-        """after wait(): the rows rank `rank` handed to the most recent submit()"""
-        full = self.out[(self.i - 1) % len(self.out)]
+        """after wait(): the rows rank `rank` handed to the most recent submit() / staged()"""
         if self.k > 1:
-            return full[rank, (self.n_submitted - 1) % self.k]
+            return self.out[self._last_out][rank, self._last_row]
+        full = self.out[(self.i - 1) % len(self.out)]
         return full[rank * self.n_rows_local:(rank + 1) * self.n_rows_local]
 
     def close(self):
@@ -353,11 +390,31 @@ def timed_steps(step, steps, warmup, finish=None, device=None, timer=None, info=
         finish()
     fence()
     dt = time.perf_counter() - t0
+    t_own = dt
+    if info is not None:
+        info["rank_s"] = [t_own]
+        info["n_ranks_seen"] = 1
     if multi:
-        t = torch.tensor([dt], dtype=torch.float64, device=device if on_gpu else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        # every rank's own wall time (its clock between the two fences), so that a straggler shows in the line: min / max / mean / slowest rank
+        world = dist.get_world_size()
+        mine = torch.zeros(world, dtype=torch.float64, device=device if on_gpu else "cpu")
+        mine[dist.get_rank()] = t_own
+        dist.all_reduce(mine, op=dist.ReduceOp.SUM)
+        per_rank = [float(v) for v in mine.tolist()]
+        dt = max(per_rank)
+        if info is not None:
+            info["rank_s"] = per_rank
+            info["n_ranks_seen"] = world
     return dt
+
+
+def rank_time_stats(info, steps):
+    """per-rank ms_per_step statistics of a timed_steps(..., info=info) run for the N > 1 line"""
+    ts = [t / max(1, steps) * 1e3 for t in info.get("rank_s", [])]
+    if not ts:
+        return None
+    slow = max(range(len(ts)), key=lambda r: ts[r])
+    return {"min": min(ts), "max": max(ts), "mean": sum(ts) / len(ts), "slowest_rank": slow, "per_rank": ts}
 
 
 def allreduce_gradients(parameters, average=True, group=None):

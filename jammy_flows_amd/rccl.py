@@ -83,14 +83,27 @@ class Communicator:
         self.device = torch.device(device)
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
         self.comm = ctypes.c_void_p()
-        lib = _lib()
         uid = _UniqueId()
-        if self.rank == 0:
-            _check(lib.ncclGetUniqueId(ctypes.byref(uid)), "ncclGetUniqueId")
-        box = [ctypes.string_at(ctypes.byref(uid), NCCL_UNIQUE_ID_BYTES) if self.rank == 0 else None]     # (all 128 bytes: `.internal` stops at a NUL)
+        # rank 0 ALWAYS takes part in the broadcast: a failure before it (library missing, ncclGetUniqueId) travels as an error marker and is
+        # raised on every rank after it -- the others would otherwise wait in the broadcast forever
+        box = [None]
+        lib, early = None, None
+        try:
+            lib = _lib()
+            if self.rank == 0:
+                _check(lib.ncclGetUniqueId(ctypes.byref(uid)), "ncclGetUniqueId")
+                box = [ctypes.string_at(ctypes.byref(uid), NCCL_UNIQUE_ID_BYTES)]     # (all 128 bytes: `.internal` stops at a NUL)
+        except (RcclError, OSError, AttributeError) as e:
+            early = e
+            if self.rank == 0:
+                box = [("error", "%s: %s" % (type(e).__name__, e))]
         if self.world > 1:
             dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
         raw = box[0]
+        if early is not None:
+            raise RcclError("rank %d: %s" % (self.rank, early))
+        if isinstance(raw, tuple) and raw and raw[0] == "error":
+            raise RcclError("rank 0 could not create the unique id: %s" % raw[1])
         if not isinstance(raw, (bytes, bytearray)) or len(raw) != NCCL_UNIQUE_ID_BYTES:
             raise RcclError("unique id did not arrive")
         ctypes.memmove(ctypes.byref(uid), bytes(raw), NCCL_UNIQUE_ID_BYTES)

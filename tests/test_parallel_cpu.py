@@ -115,6 +115,29 @@ def _pipe_worker(rank, world, port, q):
                 ok = ok and tuple(full.shape) == (world, 4, n)
                 ok = ok and all(bool((full[r, 0] == 8000 + r).all()) and bool((full[r, 1] == 1000 + r).all()) for r in range(world))
                 ok = ok and all(bool((pz.out[pz.i % 2][r, t] == 1000 * (4 + t) + r).all()) for r in range(world) for t in range(4))
+        # wait() in the middle of a stage, then more submissions (last_block indexed the stage with n_submitted % k, which is wrong
+        # once a partly filled stage has been flushed): k = 4, 2 submits, wait(), 4 more -> the last rows sit in stage row 3
+        pw = parallel.PipelinedGather(n, torch.float64, torch.device("cpu"), depth=2, group_steps=4)
+        for step in range(2):
+            pw.submit(torch.full((n,), float(7000 + 10 * step + rank), dtype=torch.float64))
+        pw.wait()
+        for r in range(world):
+            ok = ok and bool((pw.last_block(r) == 7000 + 10 * 1 + r).all())
+        for step in range(2, 6):
+            pw.submit(torch.full((n,), float(7000 + 10 * step + rank), dtype=torch.float64))
+        pw.wait()
+        for r in range(world):
+            ok = ok and bool((pw.last_block(r) == 7000 + 10 * 5 + r).all())
+        # ... and the same through the zero-copy staging calls, with a partly filled stage flushed at the end
+        pw = parallel.PipelinedGather(n, torch.float64, torch.device("cpu"), depth=2, group_steps=4)
+        for step in range(7):
+            pw.next_slot().fill_(float(9000 + 10 * step + rank))
+            pw.staged(_Step())
+            if step == 1:
+                pw.wait()
+        pw.wait()
+        for r in range(world):
+            ok = ok and bool((pw.last_block(r) == 9000 + 10 * 6 + r).all())
         q.put((rank, ok))
     finally:
         dist.destroy_process_group()
@@ -138,6 +161,26 @@ def test_pipelined_gather_single_process():
     pg = parallel.PipelinedGather(4, torch.float32, torch.device("cpu"))
     a = pg.submit(torch.arange(4, dtype=torch.float32))
     assert torch.equal(pg.wait(), torch.arange(4, dtype=torch.float32)) and a.shape[0] == 4
+
+
+def test_hw_queue_setting_is_made_by_the_library(monkeypatch):
+    """parallel sets GPU_MAX_HW_QUEUES while the runtime has not started (here: never, no GPU); an explicit larger value is kept"""
+    assert parallel.HW_QUEUES_STATE in ("set", "kept") and int(os.environ["GPU_MAX_HW_QUEUES"]) >= parallel.HW_QUEUES_WANTED
+    monkeypatch.setenv("GPU_MAX_HW_QUEUES", "16")
+    assert parallel.ensure_hw_queues() == "kept" and os.environ["GPU_MAX_HW_QUEUES"] == "16"
+    monkeypatch.setenv("GPU_MAX_HW_QUEUES", "2")
+    assert parallel.ensure_hw_queues() == "set" and os.environ["GPU_MAX_HW_QUEUES"] == str(parallel.HW_QUEUES_WANTED)
+    monkeypatch.setattr(torch.cuda, "is_initialized", lambda: True)
+    monkeypatch.setenv("GPU_MAX_HW_QUEUES", "2")
+    with pytest.warns(RuntimeWarning, match="GPU_MAX_HW_QUEUES"):
+        assert parallel.ensure_hw_queues() == "late"
+
+
+def test_rank_time_stats_single_process():
+    info = {}
+    parallel.timed_steps(lambda: None, steps=3, warmup=1, info=info)
+    st = parallel.rank_time_stats(info, 3)
+    assert info["n_ranks_seen"] == 1 and st["slowest_rank"] == 0 and st["min"] == st["max"] == st["mean"]
 
 
 def _loop_worker(rank, world, port, q):
@@ -169,8 +212,13 @@ def _loop_worker(rank, world, port, q):
                 calls["finish"] += 1
                 gather.wait()
 
-            dt = parallel.timed_steps(step, steps=5, warmup=2, finish=finish, device=None)
+            info = {}
+            dt = parallel.timed_steps(step, steps=5, warmup=2, finish=finish, device=None, info=info)
             ok = ok and calls["step"] == 7 and calls["finish"] == 2 and dt >= 0.05
+            # the per-rank clocks of the N > 1 line: both ranks seen, the job's time is the slowest rank's, the same numbers on every rank
+            st = parallel.rank_time_stats(info, 5)
+            ok = ok and info["n_ranks_seen"] == world and len(st["per_rank"]) == world and abs(st["max"] * 5e-3 - dt) < 1e-12
+            ok = ok and st["min"] <= st["mean"] <= st["max"] and st["per_rank"][st["slowest_rank"]] == st["max"] and st["max"] >= 10.0
             full = gather.wait()
             expect = torch.cat([(torch.arange(n, dtype=torch.float64) + 1000 * r) * 2.0 for r in range(world)])
             ok = ok and bool(torch.equal(full, expect))
