@@ -140,39 +140,44 @@ struct OFam {
 // moebius_1d.py:140-259.  x in [-pi, pi].  value: sum_k pi_k * arg(Moebius_k(e^{ix})) normalised so that -pi -> -pi; deriv: sum_k pi_k (1-|w|^2)/|e^{ix}-w|^2
 // np: parameters per component, 4 = (omega_x, omega_y, logit length, log weight), 3 = (omega angle, logit length, log weight) (:175-178)
 // (ROW: anything indexable that yields T -- a plain pointer, or the values of a dual row, DualValues)
+// one component at e^{ix} = (cx, sx) given its (np - 1) shape parameters: the normalised arc and the derivative's ratio (1 - |w|^2) / |e^{ix} - w|^2
+// (T may carry tangents: the adjoint evaluates a component on DualN<T, 4> -- x and its three parameters, jf_manifold_adj.h)
+template <typename T> __device__ __forceinline__ void moebius_component(int np, T q0, T q1, T logit_len, T cx, T sx, T& arc, T& ratio) {
+    const T cmp = T(-1), smp = (T)(-1.2246467991473532e-16);          // numpy.cos(-pi), numpy.sin(-pi)
+    const T denom = logaddexp<T>(T(0), -logit_len);
+    const T len = T(0.001) + M<T>::exp(T(-0.0020020026706730793) - denom);      // ln(0.999 - 0.001)
+    T ox, oy;
+    if (np == 4) {
+        const T nrm = len / M<T>::sqrt(q0 * q0 + q1 * q1);
+        ox = q0 * nrm; oy = q1 * nrm;
+    } else {
+        ox = M<T>::cos(q0) * len; oy = M<T>::sin(q0) * len;
+    }
+    const T omo = T(1) - len * len;
+    const T opo = T(1) + len * len - T(2) * (cx * ox + sx * oy);
+    const T opo_mp = T(1) + len * len - T(2) * (cmp * ox + smp * oy);
+    const T y_mp = omo * (smp - oy) - oy * opo_mp;
+    const T x_mp = omo * (cmp - ox) - ox * opo_mp;
+    const T rot = -M<T>::PI - M<T>::atan2(y_mp, x_mp);
+    const T yv = omo * (sx - oy) - oy * opo;
+    const T xv = omo * (cx - ox) - ox * opo;
+    const T cr = M<T>::cos(rot), sr = M<T>::sin(rot);
+    arc = M<T>::atan2(sr * xv + cr * yv, cr * xv - sr * yv) + M<T>::PI;
+    ratio = omo / opo;
+}
 template <typename T, typename ROW> __device__ inline void moebius_eval(ROW p, int nc, int np, T x, T& val, T& deriv) {
     const T cx = M<T>::cos(x), sx = M<T>::sin(x);
-    const T cmp = T(-1), smp = (T)(-1.2246467991473532e-16);          // numpy.cos(-pi), numpy.sin(-pi)
     T lmax = p[np - 1];
     for (int k = 1; k < nc; ++k) lmax = M<T>::max(lmax, p[np * k + np - 1]);
     T wsum = T(0), vsum = T(0), dsum = T(0);
     for (int k = 0; k < nc; ++k) {
         const int q = np * k;
-        const T denom = logaddexp<T>(T(0), -p[q + np - 2]);
-        const T len = T(0.001) + M<T>::exp(T(-0.0020020026706730793) - denom);      // ln(0.999 - 0.001)
-        T ox, oy;
-        if (np == 4) {
-            const T q0 = p[q], q1 = p[q + 1];
-            const T nrm = len / M<T>::sqrt(q0 * q0 + q1 * q1);
-            ox = q0 * nrm; oy = q1 * nrm;
-        } else {
-            const T q0 = p[q];
-            ox = M<T>::cos(q0) * len; oy = M<T>::sin(q0) * len;
-        }
-        const T omo = T(1) - len * len;
-        const T opo = T(1) + len * len - T(2) * (cx * ox + sx * oy);
-        const T opo_mp = T(1) + len * len - T(2) * (cmp * ox + smp * oy);
-        const T y_mp = omo * (smp - oy) - oy * opo_mp;
-        const T x_mp = omo * (cmp - ox) - ox * opo_mp;
-        const T rot = -M<T>::PI - M<T>::atan2(y_mp, x_mp);
-        const T yv = omo * (sx - oy) - oy * opo;
-        const T xv = omo * (cx - ox) - ox * opo;
-        const T cr = M<T>::cos(rot), sr = M<T>::sin(rot);
-        const T arc = M<T>::atan2(sr * xv + cr * yv, cr * xv - sr * yv) + M<T>::PI;
+        T arc, ratio;
+        moebius_component<T>(np, p[q], np == 4 ? T(p[q + 1]) : T(0), p[q + np - 2], cx, sx, arc, ratio);
         const T w = M<T>::exp(p[q + np - 1] - lmax);
         wsum += w;
         vsum += w * arc;
-        dsum += w * (omo / opo);
+        dsum += w * ratio;
     }
     val = vsum / wsum - M<T>::PI;
     deriv = dsum / wsum;
@@ -398,6 +403,38 @@ struct FFam {
         }
     }
 
+    // log-prob direction, head: rotation, the von-Mises-Fisher z step and the optional quarter turn -> (cos theta, azimuth) that the nested spline
+    // flows act on (fvm_2d.py:336-402); tail: back to angles and, for the first layer of its block, the plane chart (:434-470).  Separate
+    // functions because the adjoint (jf_manifold_adj.h) differentiates them stage by stage.
+    template <typename T> static __device__ __forceinline__ void inv_head(const CLayer& L, const T* __restrict__ p, T (&x)[3], T& ld, T& ret_out, T& angle_out) {
+        const T* fp = p + rot_len(L.hh_iter, 3);
+        const T zs = (T)L.z_sign;
+        const T kappa = kappa_of<T>(L, p, fp);                                               // fvm_2d.py:105-139, 289-330
+        if (L.hh_iter != 0) s2_rotate<T>(p, L.hh_iter, x, ld, true);
+        const T prev = M<T>::cos(x[0]);
+        ld += M<T>::log(M<T>::sin(safe_angle_pi<T>(x[0])));
+        const T e2k = M<T>::exp(T(-2) * kappa);
+        const T safe = kappa < T(100) ? M<T>::log(M<T>::expm1(T(2) * kappa)) : T(2) * kappa;          // :352-357 (expm1: a kappa of 1e-10
+                                                                                                              // -- log_bounded with the default min_kappa -- survives float32)
+        ld += M<T>::log(T(2) * kappa) + kappa * (zs * prev + T(1)) - safe;
+        T ret = zs * ((T(1) + e2k - T(2) * M<T>::exp(kappa * (zs * prev - T(1)))) / (T(-1) + e2k));       // :361
+        if (kappa < M<T>::KAPPA_ID) ret = prev;
+        ret = safe_cos<T>(ret, M<T>::EPS_COS);
+        T angle = x[1];
+        if (L.extra_rotation) inbetween<T>(ret, angle, ld, true);
+        ret_out = ret; angle_out = angle;
+    }
+    template <typename T> static __device__ __forceinline__ void inv_tail(const CLayer& L, T ret, T angle, T (&x)[3], T& ld) {
+        ret = safe_cos<T>(ret, M<T>::EPS_COS);
+        const T th = M<T>::acos(ret);
+        ld -= M<T>::log(M<T>::sin(safe_angle_pi<T>(th)));
+        if (L.first) {
+            T pl[3];
+            s2_to_plane<T>(th, angle, pl, ld);
+            x[0] = pl[0]; x[1] = pl[1];
+        } else { x[0] = th; x[1] = angle; }
+    }
+
     template <typename T, bool FWD> static __device__ __forceinline__ void apply(const CLayer& L, const T* __restrict__ p, T (&x)[3], T& ld, LaneCtx<T>& c) {
         const T* fp = p + rot_len(L.hh_iter, 3);
         const T zs = (T)L.z_sign, region = (T)L.identity_region;
@@ -407,18 +444,8 @@ struct FFam {
         const T* vert = fp + n_kappa(L);
         const T* circ = vert + nv;
         if constexpr (!FWD) {
-            if (L.hh_iter != 0) s2_rotate<T>(p, L.hh_iter, x, ld, true);
-            const T prev = M<T>::cos(x[0]);
-            ld += M<T>::log(M<T>::sin(safe_angle_pi<T>(x[0])));
-            const T e2k = M<T>::exp(T(-2) * kappa);
-            const T safe = kappa < T(100) ? M<T>::log(M<T>::expm1(T(2) * kappa)) : T(2) * kappa;          // :352-357 (expm1: a kappa of 1e-10
-                                                                                                                  // -- log_bounded with the default min_kappa -- survives float32)
-            ld += M<T>::log(T(2) * kappa) + kappa * (zs * prev + T(1)) - safe;
-            T ret = zs * ((T(1) + e2k - T(2) * M<T>::exp(kappa * (zs * prev - T(1)))) / (T(-1) + e2k));       // :361
-            if (kappa < M<T>::KAPPA_ID) ret = prev;
-            ret = safe_cos<T>(ret, M<T>::EPS_COS);
-            T angle = x[1];
-            if (L.extra_rotation) inbetween<T>(ret, angle, ld, true);
+            T ret, angle;
+            inv_head<T>(L, p, x, ld, ret, angle);
             const bool inside = (region == T(0)) || ((ret > T(-1) + region) && (ret < T(1) - region));
             if (L.correlated) {                                                             // :406-409: nested i1+s1 passthrough pdf, inverse direction
                 if (inside) {
@@ -459,14 +486,7 @@ struct FFam {
                 }
             }
             }
-            ret = safe_cos<T>(ret, M<T>::EPS_COS);
-            const T th = M<T>::acos(ret);
-            ld -= M<T>::log(M<T>::sin(safe_angle_pi<T>(th)));
-            if (L.first) {
-                T pl[3];
-                s2_to_plane<T>(th, angle, pl, ld);
-                x[0] = pl[0]; x[1] = pl[1];
-            } else { x[0] = th; x[1] = angle; }
+            inv_tail<T>(L, ret, angle, x, ld);
         } else {
             if (L.first) {
                 T pl[3] = {x[0], x[1], T(0)};

@@ -113,12 +113,12 @@ template <typename T> __device__ __forceinline__ int spline_search(const T* __re
     return c - 1;
 }
 
-// closed-form evaluation in bin `b` (spline_fns.py:127-186)
-template <typename T> __device__ inline SplineOut<T> spline_core(const KnotTab<T>& t, int b, T x, bool inverse) {
-    const T in_cw = t.cw[b], in_w = t.cw[b + 1] - t.cw[b];
-    const T in_ch = t.ch[b], in_h = t.ch[b + 1] - t.ch[b];
+// closed-form evaluation in a bin given its six knot values (spline_fns.py:127-186); T may carry tangents (the adjoint of the spline layers
+// evaluates this on DualN<T, 7>: the input and the six knot values, jf_spline_adj.h)
+template <typename T> __device__ inline SplineOut<T> spline_core_vals(T in_cw, T cw1, T in_ch, T ch1, T d0, T d1, int b, T x, bool inverse) {
+    const T in_w = cw1 - in_cw;
+    const T in_h = ch1 - in_ch;
     const T delta = SM<T>::div(in_h, in_w);
-    const T d0 = t.d[b], d1 = t.d[b + 1];
     const T s = d0 + d1 - T(2) * delta;
     SplineOut<T> r;
     r.bin = b;
@@ -145,6 +145,10 @@ template <typename T> __device__ inline SplineOut<T> spline_core(const KnotTab<T
         r.lad = lad;
     }
     return r;
+}
+// closed-form evaluation in bin `b` of a knot table
+template <typename T> __device__ inline SplineOut<T> spline_core(const KnotTab<T>& t, int b, T x, bool inverse) {
+    return spline_core_vals<T>(t.cw[b], t.cw[b + 1], t.ch[b], t.ch[b + 1], t.d[b], t.d[b + 1], b, x, inverse);
 }
 
 // interior derivatives of the C2-smooth variants in closed form (spline_fns.py:431-484), boundary ones given

@@ -17,6 +17,7 @@
 #include "jf_dual.h"
 #include "jf_expmap.h"
 #include "jf_manifold.h"
+#include "jf_manifold_rev.h"
 
 namespace jf {
 
@@ -802,14 +803,21 @@ using namespace jf;
                                                      int64_t gxs, T* gp, int64_t gps, int32_t* st, void* s) {                                   \
         return mchain_bwd<T, Fam>(x, xs, p, ps, pb, B, n, L, gxo, gxos, gld, gblp, gx, gxs, gp, gps, st, s);                                     \
     }
-JF_DEFINE_MCHAIN_BWD(r, RFam, float, f32)
-JF_DEFINE_MCHAIN_BWD(r, RFam, double, f64)
-JF_DEFINE_MCHAIN_BWD(o, OFam, float, f32)
-JF_DEFINE_MCHAIN_BWD(o, OFam, double, f64)
-JF_DEFINE_MCHAIN_BWD(m, MFam, float, f32)
-JF_DEFINE_MCHAIN_BWD(m, MFam, double, f64)
-JF_DEFINE_MCHAIN_BWD(f, FFam, float, f32)
-JF_DEFINE_MCHAIN_BWD(f, FFam, double, f64)
+// 'r' / 'o' / 'm' / 'f': the C entry points are the reverse-mode kernels (manifold_rev_kernels.hip); this replay is their check (JF_M_BWD_DUAL=1)
+#define JF_DEFINE_MCHAIN_BWD_DUAL(fam, Fam, T, suffix)                                                                                         \
+    int jf::dual_##fam##_chain_inv_bwd_##suffix(const T* x, int64_t xs, const T* p, int64_t ps, int32_t pb, int64_t B, int32_t n,                  \
+                                                const jf_##fam##_layer* L, const T* gxo, int64_t gxos, const T* gld, const T* gblp, T* gx,        \
+                                                int64_t gxs, T* gp, int64_t gps, int32_t* st, void* s) {                                        \
+        return mchain_bwd<T, Fam>(x, xs, p, ps, pb, B, n, L, gxo, gxos, gld, gblp, gx, gxs, gp, gps, st, s);                                     \
+    }
+JF_DEFINE_MCHAIN_BWD_DUAL(r, RFam, float, f32)
+JF_DEFINE_MCHAIN_BWD_DUAL(r, RFam, double, f64)
+JF_DEFINE_MCHAIN_BWD_DUAL(o, OFam, float, f32)
+JF_DEFINE_MCHAIN_BWD_DUAL(o, OFam, double, f64)
+JF_DEFINE_MCHAIN_BWD_DUAL(m, MFam, float, f32)
+JF_DEFINE_MCHAIN_BWD_DUAL(m, MFam, double, f64)
+JF_DEFINE_MCHAIN_BWD_DUAL(f, FFam, float, f32)
+JF_DEFINE_MCHAIN_BWD_DUAL(f, FFam, double, f64)
 JF_DEFINE_MCHAIN_BWD(v, VFam, double, f64)
 JF_DEFINE_MCHAIN_BWD(c, CFam, float, f32)
 JF_DEFINE_MCHAIN_BWD(c, CFam, double, f64)

@@ -1,0 +1,107 @@
+"""Reverse-mode adjoints of the 'r' / 'o' / 'm' / 'f' chains (csrc/manifold_rev_kernels.hip, jf_manifold_adj.h, jf_spline_adj.h) against the
+dual-number replay of the same chains (JF_M_BWD_DUAL=1, csrc/manifold_bwd_kernels.hip): every golden fixture whose pdf holds such a layer,
+float64 and float32, weighted loss over the fixture rows (without the adversarial tail), gradients of x, the conditional input and every parameter.
+Usage: python scripts/probe/m_adjoint_check.py            (runs itself twice as child processes -- the switch is read once -- and compares)"""
+import os, subprocess, sys, tempfile
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden")]
+
+
+def fixture_names():
+    import fixture_io
+    names = []
+    for f in sorted(os.listdir(fixture_io.GOLDEN_DIR)):
+        if not f.endswith(".npz"):
+            continue
+        fx = fixture_io.load(f[:-4])
+        letters = set("".join(fx.meta["flow_defs"].split("+")))
+        if letters & set("romfn"):
+            names.append(f[:-4])
+    return names
+
+
+def grads(out, names):
+    import torch
+    import fixture_io, helpers
+    res = {}
+    for name in names:
+        print("BEGIN", name, flush=True)
+        fx = fixture_io.load(name)
+        for dt, tag in ((torch.float64, "f64"), (torch.float32, "f32")):
+            if not helpers.product_supports(fx):
+                continue
+            if dt == torch.float32 and "v" in fx.meta["flow_defs"]:
+                continue
+            pdf = helpers.build_product(fx, dt, "cuda:0")
+            pdf.check_status = False
+            x = helpers.to_dev(fx["x"][:-8], dt, "cuda:0").requires_grad_(True)             # (without the 8 adversarial tail rows)
+            c = helpers.to_dev(None if fx.get("cond") is None else fx["cond"][:-8], dt, "cuda:0")
+            if c is not None:
+                c.requires_grad_(True)
+            with torch.enable_grad():
+                lp = pdf(x, conditional_input=c, force_embedding_coordinates=bool(fx.meta["embedding"]))[0]
+                w = torch.linspace(0.5, 1.5, lp.shape[0], dtype=dt, device="cuda")
+                keep = torch.isfinite(lp)
+                (torch.where(keep, lp, torch.zeros_like(lp)) * w).sum().backward()
+            try:
+                pdf.flush_status()
+            except Exception:
+                pass
+            res["%s/%s/x" % (name, tag)] = x.grad.double().cpu().numpy()
+            if c is not None and c.grad is not None:
+                res["%s/%s/c" % (name, tag)] = c.grad.double().cpu().numpy()
+            for n, p in pdf.named_parameters():
+                if p.grad is not None:
+                    res["%s/%s/%s" % (name, tag, n)] = p.grad.double().cpu().numpy()
+        torch.cuda.synchronize()
+        np.savez(out + "." + name + ".npz", **{k: v for k, v in res.items() if k.startswith(name + "/")})
+        print("DONE", name, flush=True)
+
+
+if __name__ == "__main__":
+    if len(sys.argv) > 1:
+        grads(sys.argv[1], sys.argv[2:])
+        sys.exit(0)
+    d = tempfile.mkdtemp()
+    outs = []
+    crashed = []
+    for dual in ("0", "1"):
+        o = os.path.join(d, "g%s" % dual)
+        todo = fixture_names()
+        while todo:                                     # a child that dies (a faulting kernel) is resumed behind the fixture it died in
+            r = subprocess.run([sys.executable, __file__, o] + todo, env=dict(os.environ, JF_M_BWD_DUAL=dual), capture_output=True, text=True)
+            done = [l.split()[1] for l in r.stdout.splitlines() if l.startswith("DONE")]
+            if r.returncode == 0:
+                break
+            began = [l.split()[1] for l in r.stdout.splitlines() if l.startswith("BEGIN")]
+            bad = began[-1] if began else todo[0]
+            crashed.append((dual, bad, r.stderr.strip().splitlines()[-1][:200] if r.stderr.strip() else ""))
+            print("CRASH dual=%s fixture=%s: %s" % crashed[-1], flush=True)
+            todo = todo[todo.index(bad) + 1:]
+        res = {}
+        for f in sorted(os.listdir(d)):
+            if f.startswith("g%s." % dual):
+                with np.load(os.path.join(d, f)) as z:
+                    res.update({k: z[k] for k in z.files})
+        outs.append(res)
+    worst = {"f64": 0.0, "f32": 0.0}
+    nfix = set()
+    for k in sorted(outs[0]):
+        if k not in outs[1]:
+            continue
+        a, b = outs[0][k], outs[1][k]
+        tag = k.split("/")[1]
+        nfix.add(k.split("/")[0])
+        fin = np.isfinite(b)
+        if not np.array_equal(np.isfinite(a), fin):
+            print("MISMATCH (non-finite pattern)", k)
+            worst[tag] = float("inf")
+            continue
+        e = float(np.abs(a[fin] - b[fin]).max() / max(np.abs(b[fin]).max(), 1e-9)) if fin.any() else 0.0
+        worst[tag] = max(worst[tag], e)
+        if e > (1e-9 if tag == "f64" else 2e-3):
+            print("MISMATCH", k, "%.3e" % e)
+    print("fixtures %d, tensors %d, crashed %d, worst relative difference reverse mode vs dual replay: float64 %.3e float32 %.3e"
+          % (len(nfix), len(outs[0]), len(crashed), worst["f64"], worst["f32"]))
