@@ -78,24 +78,44 @@ __device__ inline void stage_dual_adjoint(F&& f, const T* __restrict__ p, int n,
 // splines) can be differentiated in between: *_fwd builds the table in A.scr and evaluates the bin on seven tangents, *_bwd contracts and
 // reverses the table.  Nothing else may use A.scr between the two.
 template <typename T> struct SplineTape {
-    SplineOut<DualN<T, 7>> r;
+    T dy[7], dl[7];                // d (y, lad) / d (x, cw_b, cw_{b+1}, ch_b, ch_{b+1}, d_b, d_{b+1})
     int b;
     bool cl_in, cl_out;
     T y;                           // the core's (clamped) output
 };
 
-template <typename T> __device__ inline SplineOut<DualN<T, 7>> spline_adj_core7(const T* cw, const T* ch, const T* d, int b, T x, bool inverse) {
+template <typename T> __device__ inline T spline_adj_core7(const T* cw, const T* ch, const T* d, int b, T x, bool inverse, SplineTape<T>& tp) {
     using D7 = DualN<T, 7>;
     D7 in[7] = {D7(x), D7(cw[b]), D7(cw[b + 1]), D7(ch[b]), D7(ch[b + 1]), D7(d[b]), D7(d[b + 1])};
 #pragma unroll
     for (int c = 0; c < 7; ++c) in[c].d[c] = T(1);
-    return spline_core_vals<D7>(in[1], in[2], in[3], in[4], in[5], in[6], b, in[0], inverse);
+    const SplineOut<D7> r = spline_core_vals<D7>(in[1], in[2], in[3], in[4], in[5], in[6], b, in[0], inverse);
+#pragma unroll
+    for (int c = 0; c < 7; ++c) { tp.dy[c] = r.y.d[c]; tp.dl[c] = r.lad.d[c]; }
+    tp.b = b;
+    return r.y.v;
+}
+// the C2-smooth circular spline (two bins): everything behind the knot table is a function of (x, cw_1, ch_1) -- three tangents through
+// spline_circular_smooth_vals (jf_spline.h); in the tape's layout cw_1 / ch_1 are the upper knots of bin 0
+template <typename T> __device__ inline T spline_adj_smooth_circular3(T cw1, T ch1, T x, bool inverse, SplineTape<T>& tp) {
+    using D3 = DualN<T, 3>;
+    D3 xd(x), cwd(cw1), chd(ch1);
+    xd.d[0] = T(1); cwd.d[1] = T(1); chd.d[2] = T(1);
+    int raw;
+    const SplineOut<D3> r = spline_circular_smooth_vals<D3>(cwd, chd, xd, inverse, raw);
+#pragma unroll
+    for (int c = 0; c < 7; ++c) { tp.dy[c] = T(0); tp.dl[c] = T(0); }
+    tp.dy[0] = r.y.d[0]; tp.dl[0] = r.lad.d[0];
+    tp.dy[2] = r.y.d[1]; tp.dl[2] = r.lad.d[1];
+    tp.dy[4] = r.y.d[2]; tp.dl[4] = r.lad.d[2];
+    tp.b = 0;
+    return r.y.v;
 }
 // the six knot adjoints of the bin from the tape and the upstream gradients of (y, lad); returns d S / d x of the spline
 template <typename T> __device__ __forceinline__ T spline_tape_contract(const SplineTape<T>& tp, T gy, T glad, T (&gk)[6]) {
 #pragma unroll
-    for (int c = 0; c < 6; ++c) gk[c] = gy * tp.r.y.d[c + 1] + glad * tp.r.lad.d[c + 1];
-    return gy * tp.r.y.d[0] + glad * tp.r.lad.d[0];
+    for (int c = 0; c < 6; ++c) gk[c] = gy * tp.dy[c + 1] + glad * tp.dl[c + 1];
+    return gy * tp.dy[0] + glad * tp.dl[0];
 }
 // contraction + table reverse; returns d S / d x of the spline, g_scale receives d S / d scale (circular)
 template <typename T> __device__ inline T spline_tape_reverse(const T* __restrict__ p, T* __restrict__ gp, const SplineDev<T>& o, const T* __restrict__ tab, const SplineTape<T>& tp,
@@ -116,9 +136,7 @@ template <typename T> __device__ inline void r_core_adj_fwd(const jf_r_layer& L,
     if (!built) spline_adj_build<T>(p, o, tab, (T)L.lo, (T)L.hi, false, T(1));
     const KnotTab<T> t(tab, o.nb);
     A.oob = A.oob || (x < (T)L.lo) || (x > (T)L.hi);
-    tp.b = spline_adj_bin<T>(t.cw, t.ch, o.nb, x, true);
-    tp.r = spline_adj_core7<T>(t.cw, t.ch, t.d, tp.b, x, true);
-    const T y = tp.r.y.v;
+    const T y = spline_adj_core7<T>(t.cw, t.ch, t.d, spline_adj_bin<T>(t.cw, t.ch, o.nb, x, true), x, true, tp);
     tp.cl_out = y > T(1) || y < T(-1);
     tp.y = y > T(1) ? T(1) : (y < T(-1) ? T(-1) : y);
 }
@@ -140,6 +158,7 @@ template <typename T> __device__ inline void r_core_adj_dual(const jf_r_layer& L
     g = gx[0];
 }
 __host__ __device__ inline bool spline_hand_adjoint(const jf_spline_opts& s) { return s.smooth == 0; }
+__host__ __device__ inline bool circ_hand_adjoint(const jf_spline_opts& s) { return s.smooth == 0 || s.num_bins == 2; }      // (the C2-smooth circular spline has two bins)
 
 // ---- 'o' core (splines_1d.py:111-194 -> spline_fns.py:45-186), log-prob direction; scale: fvm_2d's azimuthal scaling (1 for a layer of its own)
 template <typename T> __device__ inline void o_core_adj_fwd(const jf_o_layer& L, const T* __restrict__ p, T xin, T scale, AdjLane<T>& A, SplineTape<T>& tp) {
@@ -151,9 +170,8 @@ template <typename T> __device__ inline void o_core_adj_fwd(const jf_o_layer& L,
     spline_adj_build<T>(p, o, A.scr, T(0), M<T>::TWO_PI, true, scale);
     const KnotTab<T> t(A.scr, o.nb);
     A.oob = A.oob || (x < T(0)) || (x > M<T>::TWO_PI);
-    tp.b = spline_adj_bin<T>(t.cw, t.ch, o.nb, x, use_inverse);
-    tp.r = spline_adj_core7<T>(t.cw, t.ch, t.d, tp.b, x, use_inverse);
-    const T y = tp.r.y.v;
+    const T y = o.smooth ? spline_adj_smooth_circular3<T>(t.cw[1], t.ch[1], x, use_inverse, tp)
+                         : spline_adj_core7<T>(t.cw, t.ch, t.d, spline_adj_bin<T>(t.cw, t.ch, o.nb, x, use_inverse), x, use_inverse, tp);
     tp.cl_out = y > hi || y < lo;
     tp.y = safe_angle_2pi<T>(y);
 }
@@ -243,10 +261,10 @@ struct RAdj {
 
 struct OAdj {
     static __host__ int dual_row(const jf_o_layer& L) {
-        const int r = rot_len(L.hh_iter, 2), s = spline_hand_adjoint(L.sp) ? 0 : spline_row_len(L.sp);
+        const int r = rot_len(L.hh_iter, 2), s = circ_hand_adjoint(L.sp) ? 0 : spline_row_len(L.sp);
         return r > s ? r : s;
     }
-    static __host__ int dual_tab(const jf_o_layer& L) { return spline_hand_adjoint(L.sp) ? 0 : spline_tab_words(L.sp.num_bins); }
+    static __host__ int dual_tab(const jf_o_layer& L) { return circ_hand_adjoint(L.sp) ? 0 : spline_tab_words(L.sp.num_bins); }
     static __host__ int scr_words(const jf_o_layer& L) { return spline_tab_words(L.sp.num_bins); }
     static __host__ int corr_words(const jf_o_layer&) { return 0; }
     template <typename T> static __device__ inline void adjoint(const jf_o_layer& L, const T* __restrict__ p, T* __restrict__ gp, const T (&xin)[3], T (&g)[3], T gld, T gblp,
@@ -256,7 +274,7 @@ struct OAdj {
         T* gsp = gp + n_rot;
         const T x1 = L.hh_iter != 0 ? s1_rotate<T>(p, L.hh_iter, xin[0], true) : xin[0];
         T gc = g[0], gs = T(0);
-        if (spline_hand_adjoint(L.sp)) {
+        if (circ_hand_adjoint(L.sp)) {
             SplineTape<T> tp;
             o_core_adj_fwd<T>(L, sp, x1, T(1), A, tp);
             if (L.first) {                                                // sphere_base.py:460-480 behind the core
@@ -571,7 +589,7 @@ struct FAdj {
                     int coff = 0;
                     for (int i = 0; i < L.n_circular; ++i) {
                         const jf_o_layer& Lc = L.circular[i];
-                        if (spline_hand_adjoint(Lc.sp)) {
+                        if (circ_hand_adjoint(Lc.sp)) {
                             SplineTape<T> tp;
                             o_core_adj_fwd<T>(Lc, circ + coff, ang_in[i], sc, A, tp);
                             o_core_adj_bwd<T>(Lc, circ + coff, gcirc + coff, sc, A, tp, g_ang, gld, g_sc);

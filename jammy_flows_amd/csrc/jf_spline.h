@@ -217,6 +217,39 @@ template <typename T> __device__ inline SplineOut<T> spline_interval(const T* __
     return spline_interval_eval<T>(o, tab, x, inverse, lo, hi, out_of_range);
 }
 
+// The C2-smooth circular spline behind its knot table: two bins on [0, 2 pi] whose only free knot values are cw1 and ch1 (spline_fns.py:628-668).
+// T may carry tangents (the adjoint evaluates this on DualN<T, 3>: x, cw1, ch1 -- jf_manifold_adj.h); the bin search looks at values only.
+template <typename T> __device__ inline SplineOut<T> spline_circular_smooth_vals(T cw1, T ch1, T x, bool inverse, int& raw_bin) {
+    const T TWO_PI = M<T>::TWO_PI;
+    const T cw0 = T(0), cw2 = TWO_PI, ch0 = T(0), ch2 = TWO_PI;
+    const T w1 = cw1 - cw0, w2 = cw2 - cw1;
+    const T h1 = ch1 - ch0, h2 = ch2 - ch1;
+    const T hp = h1 * h2, wp = w1 * w2;
+    const T sq = M<T>::sqrt(hp * (T(8) * ((h2 * w1) * (h2 * w1) + (h1 * w2) * (h1 * w2)) + (T(9) * (w1 + w2) * (w1 + w2) - T(16) * wp) * hp));
+    const T res = (hp * (w1 + w2) + sq) / (T(4) * (h1 + h2) * wp);
+    const T w1mx = -M<T>::PI + w1 * T(0.5);
+    const T w1mx_p_w2 = w1mx + w2;
+    const T nom = h2 * w1mx * (w1mx * h1 - res * w1 * w1mx_p_w2);
+    const T den = h1 * w2 * w2 + T(2) * (h1 - res * w1) * w1mx * w1mx_p_w2;
+    const T corr = TWO_PI - (h1 + nom / den);
+    const T mid = M<T>::PI - w1 * T(0.5);
+    T used = inverse ? x - corr : x - mid;
+    if (used < T(0)) used += TWO_PI;
+    const T eps = T(1e-6);
+    // the counting rule of spline_search on the three knots of the searched axis
+    const T k1 = inverse ? ch1 : cw1;
+    int b = ((used >= T(0)) ? 1 : 0) + ((used >= k1) ? 1 : 0) + ((used >= TWO_PI + eps) ? 1 : 0) - 1;
+    raw_bin = b;
+    b = b < 0 ? 0 : (b > 1 ? 1 : b);
+    SplineOut<T> r = b == 0 ? spline_core_vals<T>(cw0, cw1, ch0, ch1, res, res, 0, used, inverse) : spline_core_vals<T>(cw1, cw2, ch1, ch2, res, res, 1, used, inverse);
+    T y = r.y + (inverse ? mid : corr);
+    if (y > TWO_PI) y -= TWO_PI;
+    if (x == T(0)) y = T(0);
+    if (x == TWO_PI) y = TWO_PI;
+    r.y = y;
+    return r;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // circular splines used by 'o': plain periodic (derivative at 0 == derivative at 2pi) or the smooth 2-bin variant
 // (splines_1d.py:162-194 -> spline_fns.py:45-186 / 561-760)
@@ -252,30 +285,9 @@ template <typename T> __device__ inline SplineOut<T> spline_circular(const T* __
         return r;
     }
     // smooth circular: two bins, one shared derivative, seam shifted to mid-bin (spline_fns.py:628-668)
-    const T w1 = t.cw[1] - t.cw[0], w2 = t.cw[2] - t.cw[1];
-    const T h1 = t.ch[1] - t.ch[0], h2 = t.ch[2] - t.ch[1];
-    const T hp = h1 * h2, wp = w1 * w2;
-    const T sq = M<T>::sqrt(hp * (T(8) * ((h2 * w1) * (h2 * w1) + (h1 * w2) * (h1 * w2)) + (T(9) * (w1 + w2) * (w1 + w2) - T(16) * wp) * hp));
-    const T res = (hp * (w1 + w2) + sq) / (T(4) * (h1 + h2) * wp);
-    t.d[0] = res; t.d[1] = res; t.d[2] = res;
-    const T w1mx = -M<T>::PI + w1 * T(0.5);
-    const T w1mx_p_w2 = w1mx + w2;
-    const T nom = h2 * w1mx * (w1mx * h1 - res * w1 * w1mx_p_w2);
-    const T den = h1 * w2 * w2 + T(2) * (h1 - res * w1) * w1mx * w1mx_p_w2;
-    const T corr = TWO_PI - (h1 + nom / den);
-    const T mid = M<T>::PI - w1 * T(0.5);
-    T used = inverse ? x - corr : x - mid;
-    if (used < T(0)) used += TWO_PI;
-    int b = spline_search<T>(inverse ? t.ch : t.cw, nb, used, eps);
-    const int raw = b;
-    b = b < 0 ? 0 : (b > nb - 1 ? nb - 1 : b);
-    SplineOut<T> r = spline_core<T>(t, b, used, inverse);
+    int raw;
+    SplineOut<T> r = spline_circular_smooth_vals<T>(t.cw[1], t.ch[1], x, inverse, raw);
     r.bin = raw;
-    T y = r.y + (inverse ? mid : corr);
-    if (y > TWO_PI) y -= TWO_PI;
-    if (x == T(0)) y = T(0);
-    if (x == TWO_PI) y = TWO_PI;
-    r.y = y;
     return r;
 }
 

@@ -14,8 +14,10 @@
 // Step (2) is linear in the knot adjoints: chains with permanent (broadcast) parameters whose tables do not depend on the row ('r') add the
 // rows' knot adjoints up per workgroup (LDS atomics on 3 (nb + 1) accumulators) and reverse the table ONCE (spline_adj_table_reverse_dense;
 // mchain_rev_kernel, manifold_rev_kernels.hip).
-// The C2-smooth variants (<= 3 bins, <= 8 parameters; derivatives that are closed-form functions of ALL knots) keep a dual-number pass over
-// the layer's own parameters (stage_dual_adjoint, jf_manifold_adj.h).
+// The C2-smooth circular spline (two bins: everything behind its table is a function of x and the two free knot values) takes step (1) on
+// three tangents through spline_circular_smooth_vals and the same step (2); the C2-smooth interval variants (<= 3 bins, <= 8 parameters;
+// derivatives that are closed-form functions of all knots) keep a dual-number pass over the layer's own parameters (stage_dual_adjoint,
+// jf_manifold_adj.h).
 // Checked against the reference's autograd (tests/golden/grads/) and against the dual-number replay (JF_M_BWD_DUAL=1, scripts/probe/m_adjoint_check.py).
 #pragma once
 #include "jf_dual.h"
@@ -35,6 +37,7 @@ template <typename T> __device__ inline void spline_adj_build(const T* __restric
     }
     spline_cum_knots<T>(t.cw, nb, lo, hi, o.min_w, true);
     spline_cum_knots<T>(t.ch, nb, lo, hi, o.min_h, true);
+    if (o.smooth) return;                                         // (the C2-smooth two-bin variant: its one derivative follows from the knots)
     const T* pd = p + o.n_w + o.n_h;
     if (o.fix_bd) {
         const T fixed = o.min_d + SM<T>::softplus(o.fix_bd_value);
@@ -104,6 +107,7 @@ template <typename T> __device__ inline T spline_adj_table_reverse(const T* __re
         if (j >= un.k) gp[o.n_w + j - un.k] += gh;
         if (j >= un.w_start) gp[j - un.w_start] += gw;
     }
+    if (o.smooth) return g_scale;                                 // (no derivative parameters)
     // derivatives: d_j = min_d + softplus(raw * scale)
     T* gpd = gp + o.n_w + o.n_h;
     const T* pd = p + o.n_w + o.n_h;
