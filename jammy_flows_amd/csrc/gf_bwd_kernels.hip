@@ -23,6 +23,7 @@
 #include "jf_gf.h"
 #include "jf_dual.h"
 #include "jf_gf_ext.h"
+#include <cstdlib>
 #include "jf_gf_bwd.h"
 
 namespace jf {
@@ -31,25 +32,6 @@ constexpr int GB_MAX_HH = 8;                // reflections kept in registers for
 template <int G> constexpr int gb_max_hh() { return G > GB_MAX_HH ? G : GB_MAX_HH; }
 constexpr int GB_NT = 512;                  // threads of a broadcast-regime workgroup: the derived rows / accumulators / records in LDS (~40 KB) are
                                             //   per workgroup, so wider workgroups mean more resident waves per CU (256: 2 per SIMD, 512: 4)
-
-template <typename T> struct GfBwdArgs {
-    const T* x; int64_t xs;
-    const T* params; int64_t ps;
-    int64_t B;
-    int D, n_layers, tile_stride, tiles_per_block;
-    GfLayerDev<T> L[JF_MAX_CHAIN];
-    int n_params_total;
-    const T* g_xout; int64_t gxos;
-    const T* g_ld;
-    const T* g_blp;
-    T* g_x; int64_t gxs;
-    T* g_params; int64_t gps;
-    int32_t* status;
-    int active_blocks;                        // broadcast regime: workgroups that take tiles (one resident round); the others write a zero row
-    int pk0[JF_MAX_CHAIN];                    // broadcast regime: first packed component record of every layer (gf_chain_bwd_kernel)
-    int slsh;                                 // broadcast regime: log2 of the accumulator slots per parameter (see gf_chain_bwd_kernel)
-    int spline_tab;                           // general-option kernel: words of a lane's knot table (0: no spline stretch in the chain)
-};
 
 // d log(1/w) / d(raw log-width) and 1/w for one component (gaussianization_flow.py:269-317)
 template <typename T> __device__ __forceinline__ void gf_inv_width_grad(const GfLayerDev<T>& o, T rw, T& iw, T& dliw) {
@@ -870,9 +852,12 @@ static int gf_chain_inv_bwd(const T* x, int64_t xs, const T* params, int64_t ps,
     if (B == 0) return JF_OK;
     a.x = x; a.xs = xs; a.params = params; a.ps = ps; a.B = B; a.D = D; a.n_layers = n_layers;
     a.g_xout = g_xout; a.gxos = gxos; a.g_ld = g_ld; a.g_blp = g_blp; a.g_x = g_x; a.gxs = gxs; a.g_params = g_params; a.gps = gps; a.status = status;
-    if (ext) {                                                     // forward-mode kernel; broadcast: one partial row per workgroup, as the adjoint kernel
+    if (ext) {                                                     // general-option chains; broadcast: one partial row per workgroup, as the adjoint kernel
         const int64_t tiles = (B + GX_THREADS - 1) / GX_THREADS;
         const int64_t blocks = bcast ? gb_partials(B, D) : tiles;
+        // reverse sweep (gf_rev_kernels.hip); JF_G_BWD_DUAL=1: the dual-number replay below, its check
+        static const int dual_replay = getenv("JF_G_BWD_DUAL") ? atoi(getenv("JF_G_BWD_DUAL")) : 0;
+        if (!dual_replay) return gfx_chain_rev_launch<T>(a, bcast, ps, blocks, tiles, stream);
         const size_t lds = (size_t)JF_MAX_D_GF * GX_THREADS * sizeof(Dual<T>) + 16 * sizeof(T) + (size_t)GX_THREADS * a.spline_tab * sizeof(Dual<T>);
         if (lds > 160 * 1024) return JF_ERR_UNSUPPORTED;
         auto k = gfx_chain_bwd_kernel<T>;
@@ -900,7 +885,12 @@ template <typename T> static int64_t gb_lds_query(int32_t D, int32_t n_layers, c
     bool ext = false;
     const int rc = gb_fill<T>(a, nullptr, 0, bcast != 0, D, n_layers, layers, ext);
     if (rc != JF_OK) return rc;
-    if (ext) return (int64_t)((size_t)JF_MAX_D_GF * GX_THREADS * sizeof(Dual<T>) + 16 * sizeof(T) + (size_t)GX_THREADS * a.spline_tab * sizeof(Dual<T>));
+    if (ext) {
+        a.D = D; a.n_layers = n_layers;
+        const int64_t dual = (int64_t)((size_t)JF_MAX_D_GF * GX_THREADS * sizeof(Dual<T>) + 16 * sizeof(T) + (size_t)GX_THREADS * a.spline_tab * sizeof(Dual<T>));
+        const int64_t rev = gfx_chain_rev_lds_bytes<T>(a, bcast != 0);
+        return rev > dual ? rev : dual;                            // (either kernel may take the launch: JF_G_BWD_DUAL)
+    }
     const int G = gb_group_width(D);
     for (int l = 0; l < n_layers; ++l) if (layers[l].hh_iter > (G > GB_MAX_HH ? G : GB_MAX_HH)) return JF_ERR_UNSUPPORTED;
     if (!bcast) return (int64_t)((size_t)(((size_t)D * sizeof(T) >= 32) ? 1 : 2) * (64 / G) * a.tile_stride * sizeof(T));

@@ -61,4 +61,28 @@ template <> struct LinRange<double> { static constexpr double lo = 1e-280, hi = 
 
 template <typename T> struct MixSums { T C, S, P, invN; };
 
+// arguments of the backward kernels of a 'g' chain (gf_bwd_kernels.hip; the general-option reverse sweep gf_rev_kernels.hip)
+template <typename T> struct GfBwdArgs {
+    const T* x; int64_t xs;
+    const T* params; int64_t ps;
+    int64_t B;
+    int D, n_layers, tile_stride, tiles_per_block;
+    GfLayerDev<T> L[JF_MAX_CHAIN];
+    int n_params_total;
+    const T* g_xout; int64_t gxos;
+    const T* g_ld;
+    const T* g_blp;
+    T* g_x; int64_t gxs;
+    T* g_params; int64_t gps;
+    int32_t* status;
+    int active_blocks;                        // broadcast regime: workgroups that take tiles (one resident round); the others write a zero row
+    int pk0[JF_MAX_CHAIN];                    // broadcast regime: first packed component record of every layer (gf_chain_bwd_kernel)
+    int slsh;                                 // broadcast regime: log2 of the accumulator slots per parameter (see gf_chain_bwd_kernel)
+    int spline_tab;                           // general-option kernel: words of a lane's knot table (0: no spline stretch in the chain)
+};
+
+// general-option chains (jf_gf_ext.h), reverse mode (gf_rev_kernels.hip): launch and the LDS bytes it takes
+template <typename T> int gfx_chain_rev_launch(GfBwdArgs<T> a, bool bcast, int64_t ps, int64_t blocks, int64_t tiles, void* stream);
+template <typename T> int64_t gfx_chain_rev_lds_bytes(const GfBwdArgs<T>& a, bool bcast);
+
 }  // namespace jf

@@ -167,45 +167,58 @@ template <typename T, typename PA> __device__ inline GxCoord<T> gx_prepare(const
     return c;
 }
 
-// logistic_kernel_log_pdf_quantities (:389-454) for one coordinate
-template <typename T, typename PA> __device__ inline MixQ<T> gx_mixture(const GfLayerDev<T>& o, PA p, int D, int d, const GxCoord<T>& c, T x) {
-    Lse<T> lc, ls, lp;
+// one component's terms of the three log-sum-exps (log cdf, log sf, log pdf) of logistic_kernel_log_pdf_quantities (:389-454); T may carry tangents
+// (the reverse sweep evaluates a component on DualN<T, 4>: x and its mean, raw log-width, raw log-exponent -- gf_rev_kernels.hip)
+template <typename T> __device__ __forceinline__ void gx_component(const GfLayerDev<T>& o, T x, T mu, T raw_lw, T raw_skew, bool pos, T ln_pi, T& tc, T& ts, T& tp) {
     const T ln9 = T(2.19722457733621938279), ln01 = T(-2.30258509299404568402);
-    const int n_pos = o.K / 2;                                                   // (:356-359): the first int(K/2) components keep sign +1
-    for (int k = 0; k < o.K; ++k) {
-        const T mu = (o.center_mean && k == o.K - 1) ? c.last_mean : p[o.off_mean + k * D + d];
-        const T w = gf_width<T>(o, p[o.off_lw + k * D + d]);
-        const T logw = M<T>::log(w);
-        const T ln_pi = gx_log_weight<T, PA>(o, p, D, k, d) - c.lse_w;
-        const T u = (x - mu) / w;
-        if (o.skew) {
-            const T log_a = gx_bounded_log<T>(p[o.off_skew + k * D + d], ln01, ln9, true);      // exponent regulator (:367)
-            const T a = M<T>::exp(log_a);
-            const bool pos = k < n_pos;
-            const T su = pos ? u : -u;
-            lp.add(-su - logw + log_a - (a + T(1)) * softplus<T>(-su) + ln_pi);
-            if (pos) {
-                lc.add(-a * softplus<T>(-u) + ln_pi);
-                ls.add(gx_log_one_minus_pow<T>(-u, a) + ln_pi);
-            } else {
-                lc.add(gx_log_one_minus_pow<T>(u, a) + ln_pi);
-                ls.add(-a * softplus<T>(u) + ln_pi);
-            }
+    const T w = gf_width<T>(o, raw_lw);
+    const T logw = M<T>::log(w);
+    const T u = (x - mu) / w;
+    if (o.skew) {
+        const T log_a = gx_bounded_log<T>(raw_skew, ln01, ln9, true);      // exponent regulator (:367)
+        const T a = M<T>::exp(log_a);
+        const T su = pos ? u : -u;
+        tp = -su - logw + log_a - (a + T(1)) * softplus<T>(-su) + ln_pi;
+        if (pos) {
+            tc = -a * softplus<T>(-u) + ln_pi;
+            ts = gx_log_one_minus_pow<T>(-u, a) + ln_pi;
         } else {
-            const T sp = softplus<T>(-u);
-            lp.add(-u - logw - T(2) * sp + ln_pi);
-            lc.add(-sp + ln_pi);
-            ls.add(-u - sp + ln_pi);
+            tc = gx_log_one_minus_pow<T>(u, a) + ln_pi;
+            ts = -a * softplus<T>(u) + ln_pi;
         }
+    } else {
+        const T sp = softplus<T>(-u);
+        tp = -u - logw - T(2) * sp + ln_pi;
+        tc = -sp + ln_pi;
+        ts = -u - sp + ln_pi;
     }
+}
+// the inverse-CDF stage's input from the three log-sum-exps
+template <typename T> __device__ __forceinline__ MixQ<T> gx_mixq(const GfLayerDev<T>& o, T lc, T ls, T lp) {
     MixQ<T> q;
-    q.lc = lc.value(); q.ls = ls.value(); q.lp = lp.value();
+    q.lc = lc; q.ls = ls; q.lp = lp;
     q.cdf = M<T>::exp(q.lc); q.sf = M<T>::exp(q.ls);
     // The skewed components' cdf and sf come from two different closed forms whose shortcuts (extra_functions.py:40-45: the "- 1" is dropped
     // beyond softplus > 20) leave cdf + sf = 1 + O(2e-9).  The reference's central inverse-normal branch reads the cdf only (erfinv(2 cdf - 1),
     // :505-515), this code reads the smaller of the two: hand it the reference's complement so that both see the same number.
     if (o.skew && q.cdf > T(0.5)) q.sf = T(1) - q.cdf;
     return q;
+}
+
+// logistic_kernel_log_pdf_quantities (:389-454) for one coordinate
+template <typename T, typename PA> __device__ inline MixQ<T> gx_mixture(const GfLayerDev<T>& o, PA p, int D, int d, const GxCoord<T>& c, T x) {
+    Lse<T> lc, ls, lp;
+    const int n_pos = o.K / 2;                                                   // (:356-359): the first int(K/2) components keep sign +1
+    for (int k = 0; k < o.K; ++k) {
+        const T mu = (o.center_mean && k == o.K - 1) ? c.last_mean : p[o.off_mean + k * D + d];
+        const T ln_pi = gx_log_weight<T, PA>(o, p, D, k, d) - c.lse_w;
+        T tc, ts, tp;
+        gx_component<T>(o, x, mu, p[o.off_lw + k * D + d], o.skew ? T(p[o.off_skew + k * D + d]) : T(0), k < n_pos, ln_pi, tc, ts, tp);
+        lp.add(tp);
+        lc.add(tc);
+        ls.add(ts);
+    }
+    return gx_mixq<T>(o, lc.value(), ls.value(), lp.value());
 }
 
 // bisection + Newton of the sampling direction (layers/bisection_n_newton.py:11-135; 25 / 20 iterations on [-1e5, 1e5], :921) for one row:

@@ -1,5 +1,6 @@
-"""Reverse-mode adjoints of the 'r' / 'o' / 'm' / 'f' chains (csrc/manifold_rev_kernels.hip, jf_manifold_adj.h, jf_spline_adj.h) against the
-dual-number replay of the same chains (JF_M_BWD_DUAL=1, csrc/manifold_bwd_kernels.hip): every golden fixture whose pdf holds such a layer,
+"""Reverse-mode adjoints of the 'r' / 'o' / 'm' / 'f' chains (csrc/manifold_rev_kernels.hip, jf_manifold_adj.h, jf_spline_adj.h) and of the
+general-option 'g' chains (csrc/gf_rev_kernels.hip) against the dual-number replay of the same chains (JF_M_BWD_DUAL=1 / JF_G_BWD_DUAL=1,
+csrc/manifold_bwd_kernels.hip / gf_bwd_kernels.hip): every golden fixture whose pdf holds such a layer,
 float64 and float32, weighted loss over the fixture rows (without the adversarial tail), gradients of x, the conditional input and every parameter.
 Usage: python scripts/probe/m_adjoint_check.py            (runs itself twice as child processes -- the switch is read once -- and compares)"""
 import os, subprocess, sys, tempfile
@@ -17,7 +18,7 @@ def fixture_names():
             continue
         fx = fixture_io.load(f[:-4])
         letters = set("".join(fx.meta["flow_defs"].split("+")))
-        if letters & set("romfn"):
+        if letters & set("romfng"):
             names.append(f[:-4])
     return names
 
@@ -40,6 +41,14 @@ def grads(out, names):
             c = helpers.to_dev(None if fx.get("cond") is None else fx["cond"][:-8], dt, "cuda:0")
             if c is not None:
                 c.requires_grad_(True)
+            try:
+                with torch.no_grad():
+                    pdf(x, conditional_input=c, force_embedding_coordinates=bool(fx.meta["embedding"]))
+            except RuntimeError as e:                       # an option without a kernel in this precision (add_skewness is float64 only, as in the reference)
+                if "unsupported" in str(e):
+                    print("SKIP", name, tag, flush=True)
+                    continue
+                raise
             with torch.enable_grad():
                 lp = pdf(x, conditional_input=c, force_embedding_coordinates=bool(fx.meta["embedding"]))[0]
                 w = torch.linspace(0.5, 1.5, lp.shape[0], dtype=dt, device="cuda")
@@ -71,7 +80,7 @@ if __name__ == "__main__":
         o = os.path.join(d, "g%s" % dual)
         todo = fixture_names()
         while todo:                                     # a child that dies (a faulting kernel) is resumed behind the fixture it died in
-            r = subprocess.run([sys.executable, __file__, o] + todo, env=dict(os.environ, JF_M_BWD_DUAL=dual), capture_output=True, text=True)
+            r = subprocess.run([sys.executable, __file__, o] + todo, env=dict(os.environ, JF_M_BWD_DUAL=dual, JF_G_BWD_DUAL=dual), capture_output=True, text=True)
             done = [l.split()[1] for l in r.stdout.splitlines() if l.startswith("DONE")]
             if r.returncode == 0:
                 break
@@ -88,6 +97,14 @@ if __name__ == "__main__":
         outs.append(res)
     worst = {"f64": 0.0, "f32": 0.0}
     nfix = set()
+    # known, explained differences (not errors of either path):
+    #  * f_s2_kappa_logb_clamp: kappa ~ 1e-9, d log p / d kappa is what is left of two terms of ~1e9 (tests/test_gpu_grad.py, GRAD_TOL): both paths
+    #    carry that cancellation into the Householder gradient differently (1e-5 relative in float64)
+    #  * mix_e2s1i1 in float32: 47 fixture rows sit ON the [-1, 1] pin of the 'r' layers (tests/test_gpu_grad.py); the reverse path rebuilds its knot
+    #    tables with the forward kernels' float32 hardware exp / log, the dual replay with the accurate functions: last-bit differences of a knot
+    #    put such a row on different sides of the pin (gradient through / no gradient)
+    KNOWN = ("f_s2_kappa_logb_clamp/", "mix_e2s1i1/f32/")
+    unexplained = 0
     for k in sorted(outs[0]):
         if k not in outs[1]:
             continue
@@ -100,8 +117,11 @@ if __name__ == "__main__":
             worst[tag] = float("inf")
             continue
         e = float(np.abs(a[fin] - b[fin]).max() / max(np.abs(b[fin]).max(), 1e-9)) if fin.any() else 0.0
-        worst[tag] = max(worst[tag], e)
+        known = any(k.startswith(p) for p in KNOWN)
+        if not known:
+            worst[tag] = max(worst[tag], e)
         if e > (1e-9 if tag == "f64" else 2e-3):
-            print("MISMATCH", k, "%.3e" % e)
-    print("fixtures %d, tensors %d, crashed %d, worst relative difference reverse mode vs dual replay: float64 %.3e float32 %.3e"
-          % (len(nfix), len(outs[0]), len(crashed), worst["f64"], worst["f32"]))
+            print("MISMATCH%s" % (" (known)" if known else ""), k, "%.3e" % e)
+            unexplained += 0 if known else 1
+    print("fixtures %d, tensors %d, crashed %d, unexplained mismatches %d, worst relative difference reverse mode vs dual replay: float64 %.3e float32 %.3e"
+          % (len(nfix), len(outs[0]), len(crashed), unexplained, worst["f64"], worst["f32"]))
