@@ -75,6 +75,12 @@ WORKLOADS = {
                bytes_per_eval={"f32": 4612, "f64": 9224}, flops_per_eval=145664,
                metric="log-prob evals/sec (batch 2^20 per GPU), e4+s2+e4 / gggg+f+gggg",
                desc="unconditional pdf with autoregressive conditioning"),
+    # SURVEY 8d's variant of C3: the 'f' layer with the docs-recommended nested spline flows (add_vertical_rq_spline_flow = 1,
+    # add_circular_rq_spline_flow = 1; docs/source/usage/suggested_settings.rst:53-70): 46 parameters per row for the s2 block instead of 10
+    "c3b": dict(fixture="c3b_e4s2e4_fsplines", defs=("e4+s2+e4", "gggg+f+gggg"), dtype="f32", rows=1 << 20, total=1 << 20, seed=3,
+                bytes_per_eval={"f32": 4900, "f64": 9800}, flops_per_eval=154880,
+                metric="log-prob evals/sec (batch 2^20 per GPU), e4+s2+e4 / gggg+f+gggg with vertical + circular splines in f",
+                desc="unconditional pdf with autoregressive conditioning, f with vertical + circular rational-quadratic splines"),
     "c5": dict(fixture="c5_e8s2_ggggv", defs=("e8+s2", "gggg+v"), dtype="f64", rows=1 << 19, total=1 << 22, seed=5,
                bytes_per_eval={"f64": 20912}, flops_per_eval=29216,
                metric="log-prob evals/sec (batch 2^19 per GPU = 2^22 over 8), conditional e8+s2 / gggg+v, AmortizableMLP rank 8",
@@ -96,7 +102,7 @@ def make_inputs(workload, n, seed):
         from bench_configs_inputs import inputs
         return inputs(fixture_io.load(WORKLOADS[workload]["fixture"]), n, seed)
     rng = np.random.default_rng(seed)
-    if workload == "c3":
+    if workload in ("c3", "c3b"):
         return np.concatenate([rng.normal(size=(n, 4)) * 1.5,
                                np.arccos(rng.uniform(-1, 1, size=(n, 1))).clip(1e-3, np.pi - 1e-3),
                                rng.uniform(0, 2 * np.pi, size=(n, 1)),
@@ -200,7 +206,7 @@ def cpu_baseline(workload, budget_s=15.0, workers=None, chunk=4096):
             "worker_calibration": {str(k): v for k, v in calibration.items()},
             "sample": "%d rows of %s (float64 numpy oracle, %d single-threaded processes x %d-row chunks), %.1f s"
                       % (n, w["fixture"], workers, chunk, dt),
-            "reference_container_8thread": REFERENCE_8THREAD[workload]}
+            "reference_container_8thread": REFERENCE_8THREAD.get(workload)}
 
 
 def oracle_rows(workload, x, c, workers, chunk=4096):
@@ -267,7 +273,43 @@ def measure_traffic(workload, rows, fuse):
 
 
 PROFILE_F64_ISSUE = os.path.join(ROOT, "profiles", "r05_f64_issue.json")
+PROFILE_VALU_ISSUE = os.path.join(ROOT, "profiles", "r06_valu_issue.json")
 N_SIMDS = 1024                           # 4 per CU x 256 CUs
+SIDE_TABLE_STEPS = 3                     # eager steps behind the float64 leg's per-kernel table
+
+
+def valu_issue_roofline(workload, dtype, rows, table):
+    """a step against the VECTOR-ISSUE roof, computed: per kernel, the vector instructions per row by class (rocprofv3 --pmc SQ_INSTS_VALU*, a property
+    of the code: profiles/r06_valu_issue.json, scripts/profile_r06.sh / collect_r06.py) x the measured issue cost of a wave64 instruction of that class
+    (scripts/probe/f64_rates.hip: float32 plain 2.75 cycles, float32 transcendental 8.3; float64 4 / 16) = issue cycles per row; with THIS run's kernel
+    times: achieved = issue cycles per second, peak = 1024 SIMDs x the clock measured during the kernel.  `table`: {(entry, tag): {"mean_ms": ...}}."""
+    try:
+        prof = json.load(open(PROFILE_VALU_ISSUE))["profiles"].get("%s/%s" % (workload, dtype))
+    except (OSError, ValueError, KeyError):
+        return None
+    if not prof:
+        return None
+    out = {"bound": "vector issue", "unit": "T issue cycles/s", "kernels": {},
+           "source": "profiles/r06_valu_issue.json (rocprofv3 --pmc: instructions per row by class, clock during the kernel) x this run's kernel times",
+           "issue_cycles_per_wave_instruction": prof.get("issue_cycles"), "kernel_source_hash_match": prof.get("kernel_source_hash") == kernel_source_hash()}
+    tot_c, tot_s, peak_w = 0.0, 0.0, 0.0
+    for (name, tag), v in table.items():
+        k = prof["kernels"].get("%s[%s]" % (name, tag)) or prof["kernels"].get(name)
+        if not k:
+            continue
+        cyc = k["valu_issue_cycles_per_row"] * rows
+        sec = v["mean_ms"] * 1e-3
+        peak = N_SIMDS * k["clock_ghz"] * 1e9
+        out["kernels"]["%s[%s]" % (name, tag)] = {"ms": round(v["mean_ms"], 4), "frac": cyc / sec / peak, "clock_ghz": k["clock_ghz"],
+                                                 "valu_insts_per_row": k.get("valu_insts_per_row"), "trans_insts_per_row": k.get("trans_insts_per_row"),
+                                                 "mfma_insts_per_row": k.get("mfma_insts_per_row"), "valu_busy_frac_in_profile": k.get("valu_busy_frac")}
+        tot_c += cyc
+        tot_s += sec
+        peak_w += peak * sec
+    if tot_s <= 0:
+        return None
+    out.update({"achieved": tot_c / tot_s / 1e12, "peak": peak_w / tot_s / 1e12, "frac": tot_c / peak_w, "peak_at_2.4GHz": N_SIMDS * 2.4e9 / 1e12})
+    return out
 
 
 def float64_issue_roofline(workload, rows, side_table):
@@ -395,7 +437,7 @@ def cpu_baseline_sampling(workload, budget_s=12.0, chunk=1024):
     workers = max(1, int(round(quota))) if (quota is not None and quota >= 1) else min(os.cpu_count() or 1, 16)
     ctx = mp.get_context("fork")
     rng = np.random.default_rng(11)
-    fx_dim = {"c3": 10, "c5": 10}[workload]
+    fx_dim = {"c3": 10, "c3b": 10, "c5": 10}[workload]
 
     def work(n_chunks):
         _, c = make_inputs(workload, chunk * n_chunks, w["seed"])
@@ -657,8 +699,8 @@ def other_direction(args, W, rank, local_rank, world):
         bytes_per_row, flops_per_row, fused = kernel_accounting(kname.replace("_fwd", "_inv"), ktag, s)
         if bytes_per_row is None or bytes_per_row == 0:
             # per-row parameters / coordinates of the dominant block (0 parameters: permanent ones, shared by every row)
-            P = {"c1": 0, "c2": 0, "c3": 548, "c4": 8, "c5": 1224}[args.workload]
-            D = {"c1": 2, "c2": 4, "c3": 4, "c4": 1, "c5": 8}[args.workload]
+            P = {"c1": 0, "c2": 0, "c3": 548, "c3b": 548, "c4": 8, "c5": 1224}[args.workload]
+            D = {"c1": 2, "c2": 4, "c3": 4, "c3b": 4, "c4": 1, "c5": 8}[args.workload]
             mult = 3 if kname.endswith("_bwd" + ("_f32" if s == 4 else "_f64")) else 1      # adjoint: parameters read twice, their gradient written
             bytes_per_row = s * (mult * P + (2 + mult) * (D + 1))
         gbs = bytes_per_row * B / secs / 1e9
@@ -756,7 +798,8 @@ def dry_run(args, W, rank, world, B, total_rows, lo):
         if gather is not None:
             gather.wait()
 
-    dt = parallel.timed_steps(step, args.steps, args.warmup, finish=finish, device=None)
+    tinfo = {}
+    dt = parallel.timed_steps(step, args.steps, args.warmup, finish=finish, device=None, info=tinfo)
     ok = True
     if gather is not None:
         full = gather.wait()
@@ -772,6 +815,10 @@ def dry_run(args, W, rank, world, B, total_rows, lo):
                           "dry_run": True, "config": {"workload": "dry run of %s" % args.workload, "batch_per_gpu": B, "total_rows": total_rows,
                                                       "parallelism": "rows sharded over %d rank(s)" % world},
                           "n_ranks_seen": n_ranks_seen, "collective_backend": dist.get_backend() if world > 1 else None,
+                          "rank_ms_per_step": parallel.rank_time_stats(tinfo, args.steps), "ranks_in_timing": tinfo.get("n_ranks_seen"),
+                          "scaling_efficiency_vs_t1": None if (args.t1_ms is None or world < 2) else {
+                              "t1_ms": args.t1_ms, "tN_ms": 1e3 * dt / args.steps, "n_gpus": world, "scaling": args.scaling,
+                              "efficiency": (args.t1_ms / (world * 1e3 * dt / args.steps)) if args.scaling == "strong" else (args.t1_ms / (1e3 * dt / args.steps))},
                           "exchange": exchange, "gathered_rows_correct": ok})
     if world > 1:
         dist.destroy_process_group()
@@ -910,6 +957,9 @@ def side_config(key, dev, steps=20):
            "max_abs_dlogp_vs_f64_oracle": float(np.abs(got - o)[fin].max()), "bar": 1e-2 if s == 4 else 1e-4,
            "whole_step_hbm_frac": W["bytes_per_eval"][W["dtype"]] * B / dt / 1e9 / HBM_PEAK_GBS,
            "kernels_ms": {"%s[%s]" % k: round(v["mean_ms"], 4) for k, v in sorted(table.items())}}
+    vi = valu_issue_roofline(key, W["dtype"], B, table)
+    if vi:
+        row["valu_issue"] = vi
     if "trans_per_eval" in W:                              # the unconditional g kernel is bound by transcendental / vector issue, not by its 40 B per row
         kt = max(table.items(), key=lambda kv: kv[1]["total_ms"])[1]["mean_ms"] * 1e-3
         row["roofline"] = {"bound": "transcendental", "achieved": W["trans_per_eval"] * B / kt / 1e12, "peak": TRANS_PEAK_PER_S / 1e12,
@@ -952,6 +1002,9 @@ def main():
     ap.add_argument("--gather-steps", type=int, default=4,
                     help="N > 1: the log-probs of this many consecutive steps travel in ONE all-gather (parallel.PipelinedGather(group_steps=k): fewer, larger "
                          "collectives -- an RCCL enqueue costs ~50 us of host time whatever its size); every step's rows are exchanged inside the timed region")
+    ap.add_argument("--t1-ms", type=float, default=None,
+                    help="N > 1: the ms_per_step of the SAME command at --gpus 1 (what the driver measured first): the line then carries the measured "
+                         "scaling efficiency -- strong: T_1 / (N T_N), weak: T_1 / T_N -- beside the per-rank step times")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--pmc-dtype", choices=("f32", "f64"), default=None, help=argparse.SUPPRESS)    # precision of the --pmc-child steps (default: the workload's)
     ap.add_argument("--dry-run", action="store_true",
@@ -1132,11 +1185,19 @@ def main():
         tinfo = {}
         dt = parallel.timed_steps(step, args.steps, args.warmup, finish=finish, device=dev, timer=timer, info=tinfo)
         if timer is None and rank == 0:
-            # the secondary (float64) leg: per-kernel HIP-event times of two more steps, outside its timed region
+            # the secondary (float64) leg: per-kernel HIP-event times of three more EAGER steps, outside its timed region.  Two untimed eager steps
+            # first: the timed region ran recorded plans (merged side kernels), so an eager step is the first launch of the stand-alone kernels in
+            # this process -- code-object load and attribute calls landed between the events of that first launch (round 5's line read 20 ms for
+            # jf_f_chain_inv_f64 that way; rocprofv3: 0.19 ms)
+            for _ in range(2):
+                pdf(x, conditional_input=c)
+            pdf.flush_status()
+            torch.cuda.synchronize(dev)
             t64 = _hip.KernelTimer()
             with t64:
-                for _ in range(2):
+                for _ in range(SIDE_TABLE_STEPS):
                     pdf(x, conditional_input=c)
+            torch.cuda.synchronize(dev)
             side_table = t64.summary()
         logp = last["logp"]
         # N > 1: this rank's block of the last gathered buffer is what the last step computed; which path carried it (parallel.PipelinedGather)
@@ -1169,7 +1230,8 @@ def main():
             identical = identical and bool(((again == logp) | (again.isnan() & logp.isnan())).all())
         pdf.flush_status()
         results[dname] = dict(dt=dt, evals_per_s=total_rows * args.steps / dt, ms_per_step=1e3 * dt / args.steps, err=err, identical=identical, repeats=repeats,
-                              untiled=untiled, gather=gather_info, host_issue_ms=1e3 * tinfo.get("host_issue_s", 0.0) / args.steps)
+                              untiled=untiled, gather=gather_info, host_issue_ms=1e3 * tinfo.get("host_issue_s", 0.0) / args.steps,
+                              rank_ms=parallel.rank_time_stats(tinfo, args.steps), ranks_in_timing=tinfo.get("n_ranks_seen"))
         if rank == 0 and world == 1 and dname == main_dt and not args.no_sweep:
             results[dname]["rows_sweep"] = rows_sweep(pdf, x, c, depth=args.pipeline_depth if pipe is not None else 1)
         if timer is not None:
@@ -1193,7 +1255,7 @@ def main():
                     del gf_
                 except Exception as e:                 # noqa: BLE001 -- reported, never hidden
                     graph_replay = {"error": "%s: %s" % (type(e).__name__, e)}
-            if rank == 0 and pdf.fuse_conditional_blocks and args.workload == "c3":
+            if rank == 0 and pdf.fuse_conditional_blocks and args.workload in ("c3", "c3b"):
                 # for reference, outside the timed region: the same steps with the conditional block as two launches (jf_mlp2 + jf_gf_chain_inv),
                 # whose kernels have clean single-roof accountings (MFMA for the MLP, HBM for the g-chain reading the materialised block)
                 pdf.fuse_conditional_blocks = False
@@ -1233,8 +1295,8 @@ def main():
         bytes_per_row, flops_per_row, fused = kernel_accounting(kname, ktag, s)
         if bytes_per_row is None:                        # per-sample g-chain: the block's row (C3 block 2: 548 floats, C5 block 0: 1224 doubles)
             # per-row parameters / coordinates of the dominant block (0 parameters: permanent ones, shared by every row)
-            P = {"c1": 0, "c2": 0, "c3": 548, "c4": 8, "c5": 1224}[args.workload]
-            D = {"c1": 2, "c2": 4, "c3": 4, "c4": 1, "c5": 8}[args.workload]
+            P = {"c1": 0, "c2": 0, "c3": 548, "c3b": 548, "c4": 8, "c5": 1224}[args.workload]
+            D = {"c1": 2, "c2": 4, "c3": 4, "c3b": 4, "c4": 1, "c5": 8}[args.workload]
             bytes_per_row = s * (D + 1 + P + D + 1)
         hbm_gbs = bytes_per_row * B / secs / 1e9
         tr = traffic_of(traffic, kname, ktag)
@@ -1281,7 +1343,7 @@ def main():
                 # MI355X the f64 matrix rate equals the f64 vector rate -- the matrix cores are used for their 16x lower LDS operand traffic)
                 K1, H, N, D = (int(t[1:]) for t in ktag.split("_")[:4])
                 r = int(ktag.split("_")[4][1:])
-                L = {"c3": 4, "c5": 4}[args.workload]
+                L = {"c3": 4, "c3b": 4, "c5": 4}[args.workload]
                 useful = 2 * (r * K1 + H * r + r * H + N * r)               # V1 c, U1 t1, V2 h, U2 t2 per row (23 936 for C5 block 0)
                 on_mfma = main_dt == "f64" and r <= 8 and H % 16 == 0
                 executed = 2 * (16 * 4 * ((K1 + 3) // 4) + H * 8 + 16 * H + L * 21 * 16 * 8) if on_mfma else useful     # padded 16 x 16 x 4 tiles
@@ -1305,6 +1367,15 @@ def main():
                                  "bound": "valu+mfma", "achieved": ex, "peak": pk, "unit": "TFLOP/s (executed on the matrix pipe)", "frac": ex / pk,
                                  "valu_busy_frac_committed_profile": {"c3": 0.66, "c5": 0.60}.get(args.workload),
                                  "mfma_busy_frac_committed_profile": {"c3": 0.37, "c5": 0.16}.get(args.workload)})
+        if flops_per_row:
+            # 2 x sum(in x out) of the amortisation MLP per row: what the reference's float32 product computes, beside the executed (3-pass f16) figure
+            roofline["algorithmic_TFLOPs"] = flops_per_row * B / secs / 1e12
+            roofline["algorithmic_flops_per_row"] = flops_per_row
+        # the vector-issue roof, computed (instructions per row x measured cycles per instruction x this run's kernel times): one stream's durations
+        # are the kernels' own; under pipelining a launch is priced at its share of the chip (duration / concurrency)
+        vi = valu_issue_roofline(args.workload, main_dt, B, {k: {"mean_ms": v["mean_ms"] / concurrency} for k, v in kernel_table.items()})
+        if vi:
+            roofline["valu_issue"] = vi
         step_bytes = W["bytes_per_eval"][main_dt]
         roofline["whole_step"] = {"algorithmic_bytes_per_eval": step_bytes, "achieved_GBs": step_bytes * B / (rm["ms_per_step"] * 1e-3) / 1e9,
                                   "frac": step_bytes * B / (rm["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -1325,6 +1396,9 @@ def main():
                        "batch_per_gpu": B, "total_rows": total_rows, "parallelism": "rows sharded over %d GPU(s)" % world},
             "n_ranks_seen": n_ranks_seen, "collective_backend": backend_name, "exchange": exchange,
             "forced_collectives": bool(multi and world == 1),
+            # every rank's own clock between the two fences of the timed region (ms per step): `ms_per_step` is the slowest rank's; a straggler shows here
+            "rank_ms_per_step": rm["rank_ms"], "ranks_in_timing": rm["ranks_in_timing"],
+            "hw_queues": {"GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"), "set_by": "bench.py / jammy_flows_amd.parallel at import (%s)" % parallel.HW_QUEUES_STATE},
             "host_issue_ms_per_step": rm["host_issue_ms"],
             "parity": {"max_abs_dlogp_vs_f64_oracle": rm["err"], "bar": 1e-2 if main_dt == "f32" else 1e-4, "rows_checked": min(4096, B),
                        "repeat_launches_bit_identical": rm["identical"], "repeat_launches": rm["repeats"], "repeat_rows_compared": B,
@@ -1341,6 +1415,11 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu,
         }
+        if args.t1_ms is not None and world > 1:
+            tn = rm["ms_per_step"]
+            line["scaling_efficiency_vs_t1"] = {"t1_ms": args.t1_ms, "tN_ms": tn, "n_gpus": world, "scaling": args.scaling,
+                                                "efficiency": (args.t1_ms / (world * tn)) if args.scaling == "strong" else (args.t1_ms / tn),
+                                                "definition": "strong: T_1 / (N T_N) at fixed total batch; weak: T_1 / T_N at fixed per-GPU batch (BASELINE.md section 3)"}
         if "f64" in results and main_dt != "f64":
             r64 = results["f64"]
             line["float64"] = {"value": r64["evals_per_s"], "ms_per_step": r64["ms_per_step"], "max_abs_dlogp_vs_f64_oracle": r64["err"], "bar": 1e-4,
@@ -1352,7 +1431,8 @@ def main():
                                                "algorithmic_bytes_per_eval": b64,
                                                "note": "whole float64 step on the SURVEY 8d bytes (the north-star >= 40 % figure, like-for-like with the float64 CPU baseline)"}
             if side_table:
-                line["float64"]["all_kernels_ms_per_step"] = {"%s[%s]" % k: round(v["mean_ms"] * v["launches"] / 2, 4) for k, v in sorted(side_table.items())}
+                line["float64"]["all_kernels_ms_per_step"] = {"%s[%s]" % k: round(v["mean_ms"] * v["launches"] / SIDE_TABLE_STEPS, 4)
+                                                              for k, v in sorted(side_table.items())}
                 i8 = [(k, v) for k, v in side_table.items() if k[0] in ("jf_mlp2_i8_f64", "jf_mlp2_i8_seg_f64")]
                 if i8:
                     # the wide amortisation MLP of the float64 step on the int8 matrix cores (csrc/mlp_i8_kernels.hip): executed integer
@@ -1368,9 +1448,16 @@ def main():
                                                  "float64_equivalent_TFLOPs": 2.0 * B * 128 * n_out / sec / 1e12,
                                                  "f64_mfma_peak_TFLOPs": 78.6}
         if "float64" in line and side_table:
-            f64_issue = float64_issue_roofline(args.workload, B, side_table)
+            f64_issue = valu_issue_roofline(args.workload, "f64", B, side_table) or float64_issue_roofline(args.workload, B, side_table)
             if f64_issue:
                 line["float64"]["roofline_f64_issue"] = f64_issue
+        if rm.get("rows_sweep") and "one_stream_ms_per_step" in rm["rows_sweep"][0] and (1 << rm["rows_sweep"][0]["log2_rows"]) == B:
+            # the drop-in call -- pdf(x) step after step on the caller's ONE stream, through its recorded plan -- next to the headline, which needs
+            # the non-reference pipelined_forward().submit() API (consecutive steps on alternating streams)
+            os_ms = rm["rows_sweep"][0]["one_stream_ms_per_step"]
+            line["one_stream"] = {"ms_per_step": os_ms, "value": B / (os_ms * 1e-3), "unit": "log-prob evals/s",
+                                  "what": "pdf(x) on one stream (the reference's call pattern), measured after the timed region (rows sweep, 3 x 50 steps)",
+                                  "headline_api": "pdf.pipelined_forward(x).submit(x): %d streams" % args.pipeline_depth}
         if rm.get("rows_sweep"):
             sw = rm["rows_sweep"]
             line["rows_sweep"] = {"what": "step time of this workload against the batch size on this ONE GPU (prefixes of the resident inputs, each size "
@@ -1404,7 +1491,7 @@ def main():
         if rank == 0 and world == 1 and not args.no_sweep:
             # the other BASELINE configurations, after the timed region (C3 float64 is the `float64` object above)
             table = {}
-            for key in ("c1", "c2", "c3", "c4", "c5"):
+            for key in ("c1", "c2", "c3", "c3b", "c4", "c5"):
                 if key == args.workload:
                     table[key] = {"workload": 'pdf("%s","%s")' % W["defs"], "dtype": main_dt, "rows": B, "ms_per_step": rm["ms_per_step"], "evals_per_s": rm["evals_per_s"],
                                   "max_abs_dlogp_vs_f64_oracle": rm["err"], "bar": 1e-2 if main_dt == "f32" else 1e-4,
@@ -1415,7 +1502,7 @@ def main():
                 except Exception as e:                     # noqa: BLE001 -- reported, never hidden
                     table[key] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
             line["configs"] = table
-        if rank == 0 and world == 1 and not args.no_sweep and args.workload in ("c3", "c5"):
+        if rank == 0 and world == 1 and not args.no_sweep and args.workload in ("c3", "c3b", "c5"):
             # the other two directions of this configuration (training step, sampling step): child runs of this script after the timed region,
             # so that the driver's record of the default command carries them too (their own lines: --train / --direction sample)
             line["other_directions"] = other_directions_summary(args.workload)

@@ -857,7 +857,7 @@ static int gf_chain_inv_bwd(const T* x, int64_t xs, const T* params, int64_t ps,
         const int64_t blocks = bcast ? gb_partials(B, D) : tiles;
         // reverse sweep (gf_rev_kernels.hip); JF_G_BWD_DUAL=1: the dual-number replay below, its check
         static const int dual_replay = getenv("JF_G_BWD_DUAL") ? atoi(getenv("JF_G_BWD_DUAL")) : 0;
-        if (!dual_replay) return gfx_chain_rev_launch<T>(a, bcast, ps, blocks, tiles, stream);
+        if (dual_replay <= 0) return gfx_chain_rev_launch<T>(a, bcast, ps, blocks, tiles, stream);
         const size_t lds = (size_t)JF_MAX_D_GF * GX_THREADS * sizeof(Dual<T>) + 16 * sizeof(T) + (size_t)GX_THREADS * a.spline_tab * sizeof(Dual<T>);
         if (lds > 160 * 1024) return JF_ERR_UNSUPPORTED;
         auto k = gfx_chain_bwd_kernel<T>;

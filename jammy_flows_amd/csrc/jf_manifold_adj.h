@@ -210,18 +210,20 @@ struct RAdj {
     static __host__ int corr_words(const jf_r_layer&) { return 0; }
     // forward part up to the layer's output and d S / d (core output); tab / built as in r_core_adj_fwd
     template <typename T> static __device__ __forceinline__ T head(const jf_r_layer& L, const T* __restrict__ p, T xin, T* __restrict__ tab, bool built, const T (&g)[3], T gld,
-                                                                  T gblp, AdjLane<T>& A, SplineTape<T>& tp) {
+                                                                  T gblp, AdjLane<T>& A, SplineTape<T>& tp, bool chart = true) {
         r_core_adj_fwd<T>(L, p, xin, tab, built, A, tp);
-        if (L.first) {                                                    // interval_base.py:61-69 behind the core
+        if (L.first && chart) {                                                    // interval_base.py:61-69 behind the core
             Dual<T> ldd(T(0));
             const Dual<T> o = interval_to_real_line<Dual<T>>(Dual<T>(tp.y, T(1)), Dual<T>((T)L.lo), Dual<T>((T)L.hi), ldd);
             return (g[0] - o.v * gblp) * o.d + gld * ldd.d;
         }
         return g[0] - tp.y * gblp;
     }
+    // chart = false: the spline core alone (the vertical flows nested in 'f': fvm_2d.py:430-432 calls the core, not the layer)
     template <typename T> static __device__ inline void adjoint(const jf_r_layer& L, const T* __restrict__ p, T* __restrict__ gp, const T (&xin)[3], T (&g)[3], T gld, T gblp,
-                                                                AdjLane<T>& A) {
+                                                                AdjLane<T>& A, bool chart = true) {
         if (!spline_hand_adjoint(L.sp)) {                                 // few parameters (<= 8): the whole layer on dual numbers
+            if (!chart) { T gc = g[0]; r_core_adj_dual<T>(L, p, gp, xin[0], A, gc, gld); g[0] = gc; return; }
             T gy[3] = {g[0], T(0), T(0)};
             if (gblp != T(0)) {
                 LaneCtx<T> c;
@@ -236,7 +238,7 @@ struct RAdj {
             return;
         }
         SplineTape<T> tp;
-        T gc = head<T>(L, p, xin[0], A.scr, false, g, gld, gblp, A, tp);
+        T gc = head<T>(L, p, xin[0], A.scr, false, g, gld, gblp, A, tp, chart);
         r_core_adj_bwd<T>(L, p, gp, A, tp, gc, gld);
         g[0] = gc;
     }
@@ -555,9 +557,7 @@ struct FAdj {
                 for (int i = 0; i < L.n_vertical; ++i) {                  // (applied last-to-first: reversed first-to-last)
                     T gi[3] = {g_ret, T(0), T(0)};
                     const T xi[3] = {ret_in[i], T(0), T(0)};
-                    jf_r_layer Lv = L.vertical[i];
-                    Lv.first = 0;
-                    RAdj::adjoint<T>(Lv, vert + off, gvert + off, xi, gi, gld, T(0), A);
+                    RAdj::adjoint<T>(L.vertical[i], vert + off, gvert + off, xi, gi, gld, T(0), A, false);
                     g_ret = gi[0];
                     off += spline_row_len(L.vertical[i].sp);
                 }
@@ -578,9 +578,7 @@ struct FAdj {
                 for (int i = 0; i < L.n_vertical; ++i) {
                     T gi[3] = {g_ret, T(0), T(0)};
                     const T xi[3] = {ret_in[i], T(0), T(0)};
-                    jf_r_layer Lv = L.vertical[i];
-                    Lv.first = 0;
-                    RAdj::adjoint<T>(Lv, vert + off, gvert + off, xi, gi, gld, T(0), A);
+                    RAdj::adjoint<T>(L.vertical[i], vert + off, gvert + off, xi, gi, gld, T(0), A, false);
                     g_ret = gi[0];
                     off += spline_row_len(L.vertical[i].sp);
                 }

@@ -43,6 +43,15 @@ template <typename T> __device__ __forceinline__ T rev_wave_sum(T v) {
 
 constexpr int REV_XIN = 2 * JF_MAX_MCHAIN;                      // per lane: every layer's input (<= 2 coordinates)
 
+// The layer descriptors are an array INSIDE the by-value kernel argument (the C ABI hands host pointers: nothing to dereference on the device).
+// Indexing that array with the loop variable made the compiler copy the whole argument struct (3.6 KB for 'f': four layers with their nested
+// spline descriptors) into scratch memory at kernel entry and read every descriptor field back from there (220 scratch loads in the float32
+// 'f' kernel, 3.7 KB of private memory per lane: C3's 'f' backward 0.12 -> 0.36 ms).  Read through the kernarg segment pointer instead: a
+// uniform, dynamically indexed load from constant memory (scalar loads), no copy.  The argument struct is the kernel's first parameter.
+template <typename A> __device__ __forceinline__ const A& kernarg_view() {
+    return *reinterpret_cast<const A*>((const void*)__builtin_amdgcn_kernarg_segment_ptr());
+}
+
 template <class Adj, class = void> struct adj_has_shared : std::false_type {};
 template <class Adj> struct adj_has_shared<Adj, std::void_t<decltype(Adj::HAS_SHARED)>> : std::true_type {};
 
@@ -54,6 +63,7 @@ constexpr int REV_SHARED_THREADS = 256;
 template <typename T, class Fam, class Adj>
 __global__ void __launch_bounds__(REV_SHARED_THREADS) mchain_rev_shared_kernel(const MRevArgs<T, typename Fam::CLayer> a) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
+    const MRevArgs<T, typename Fam::CLayer>& ka = kernarg_view<MRevArgs<T, typename Fam::CLayer>>();
     const int tid = threadIdx.x, nt = REV_SHARED_THREADS;
     T* tile = reinterpret_cast<T*>(smem_raw + 16);                              // [P] the parameter row (offset 16: see mchain_rev_kernel)
     T* accp = tile + a.tile_stride;                                             // [P] the workgroup's parameter gradients
@@ -62,7 +72,7 @@ __global__ void __launch_bounds__(REV_SHARED_THREADS) mchain_rev_shared_kernel(c
     for (int j = tid; j < a.P; j += nt) { tile[j] = a.params[j]; accp[j] = T(0); }
     for (int j = tid; j < a.n_layers * a.scr; j += nt) sacc[j] = T(0);
     __syncthreads();
-    if (tid < a.n_layers) Fam::template build<T>(a.L[tid], tile + a.col0[tid], stab + tid * a.scr);
+    if (tid < a.n_layers) Fam::template build<T>(ka.L[tid], tile + ka.col0[tid], stab + tid * a.scr);
     __syncthreads();
     AdjLane<T> A;
     A.scr = nullptr; A.corr = nullptr; A.drow = nullptr; A.dtab = nullptr;
@@ -93,24 +103,24 @@ __global__ void __launch_bounds__(REV_SHARED_THREADS) mchain_rev_shared_kernel(c
                 xin[l] = x[0];
                 if (l == 0) break;                                 // the last layer applied is evaluated by its adjoint
                 ctx.tab = stab + l * a.scr;
-                Fam::template apply<T, false>(a.L[l], tile + a.col0[l], x, ld, ctx);
+                Fam::template apply<T, false>(ka.L[l], tile + ka.col0[l], x, ld, ctx);
             }
         }
 #pragma unroll
         for (int l = 0; l < JF_MAX_MCHAIN; ++l) {
             if (l >= a.n_layers) break;
             const T xi[3] = {xin[l], T(0), T(0)};
-            Adj::template adjoint_shared<T>(a.L[l], tile + a.col0[l], stab + l * a.scr, sacc + l * a.scr, xi, g, gld, l == 0 ? gblp : T(0), active, A);
+            Adj::template adjoint_shared<T>(ka.L[l], tile + ka.col0[l], stab + l * a.scr, sacc + l * a.scr, xi, g, gld, l == 0 ? gblp : T(0), active, A);
         }
         bad_any = bad_any || (active && !M<T>::finite(g[0]));
         if (active) a.g_x[row * a.gxs] = g[0];
     }
     __syncthreads();
     if (tid < a.n_layers) {
-        const int l = tid, nb = a.L[l].sp.num_bins;
+        const int l = tid, nb = ka.L[l].sp.num_bins;
         T* acc = sacc + l * a.scr;
-        spline_adj_table_reverse_dense<T>(tile + a.col0[l], accp + a.col0[l], to_dev<T>(a.L[l].sp), stab + l * a.scr, acc, acc + (nb + 1), acc + 2 * (nb + 1), (T)a.L[l].lo,
-                                          (T)a.L[l].hi);
+        spline_adj_table_reverse_dense<T>(tile + ka.col0[l], accp + ka.col0[l], to_dev<T>(ka.L[l].sp), stab + l * a.scr, acc, acc + (nb + 1), acc + 2 * (nb + 1), (T)ka.L[l].lo,
+                                          (T)ka.L[l].hi);
     }
     __syncthreads();
     for (int j = tid; j < a.P; j += nt) {
@@ -125,6 +135,7 @@ template <typename T, class Fam, class Adj>
 __global__ void __launch_bounds__(64) mchain_rev_kernel(const MRevArgs<T, typename Fam::CLayer> a) {
     using Du = DualN<T, ADJ_N>;
     extern __shared__ __align__(16) unsigned char smem_raw[];
+    const MRevArgs<T, typename Fam::CLayer>& ka = kernarg_view<MRevArgs<T, typename Fam::CLayer>>();
     const int tid = threadIdx.x;
     const int rows = a.rows;
     const int tile_rows = a.bcast ? 1 : rows;
@@ -203,7 +214,7 @@ __global__ void __launch_bounds__(64) mchain_rev_kernel(const MRevArgs<T, typena
             for (int l = a.n_layers - 1; l >= 0; --l) {
                 if (lane_in) { xin_l[2 * l] = x[0]; xin_l[2 * l + 1] = x[1]; }
                 if (l == 0) break;
-                if (lane_in) Fam::template apply<T, false>(a.L[l], prow + a.col0[l], x, ld, ctx);
+                if (lane_in) Fam::template apply<T, false>(ka.L[l], prow + ka.col0[l], x, ld, ctx);
             }
         }
         // (2) reverse sweep (layer n-1 was applied first: layer 0 last; it also takes the base log-prob term -1/2 out^2)
@@ -211,7 +222,7 @@ __global__ void __launch_bounds__(64) mchain_rev_kernel(const MRevArgs<T, typena
         for (int l = 0; l < a.n_layers; ++l) {
             if (lane_in) {
                 const T xi[3] = {xin_l[2 * l], xin_l[2 * l + 1], T(0)};
-                Adj::template adjoint<T>(a.L[l], prow + a.col0[l], grow + a.col0[l], xi, g, gld, l == 0 ? gblp : T(0), A);
+                Adj::template adjoint<T>(ka.L[l], prow + ka.col0[l], grow + ka.col0[l], xi, g, gld, l == 0 ? gblp : T(0), A);
             }
         }
         bool bad = false;
@@ -329,7 +340,18 @@ static int mchain_rev(const T* x, int64_t xs, const T* params, int64_t ps, int32
 
 static bool use_dual_replay() {
     static const int v = getenv("JF_M_BWD_DUAL") ? atoi(getenv("JF_M_BWD_DUAL")) : 0;
-    return v != 0;
+    return v > 0;
+}
+// chains the dual-number replay serves better: 'f' layers without nested flows carry a dozen parameters -- two six-tangent passes over the
+// whole layer (C3's 'f' backward: 0.12 ms per 2^18 rows) against three stage passes + a plain evaluation here (0.17); JF_M_BWD_DUAL=-1 sends
+// them through the reverse sweep all the same (its check runs on every fixture)
+template <class CLayer> static bool prefers_dual(const CLayer*, int) { return false; }
+template <> bool prefers_dual<jf_f_layer>(const jf_f_layer* L, int n) {
+    static const int v = getenv("JF_M_BWD_DUAL") ? atoi(getenv("JF_M_BWD_DUAL")) : 0;
+    if (v < 0 || !L) return false;
+    for (int l = 0; l < n && l < JF_MAX_MCHAIN; ++l)
+        if (L[l].n_vertical != 0 || L[l].n_circular != 0 || L[l].correlated) return false;
+    return true;
 }
 
 }  // namespace jf
@@ -340,7 +362,8 @@ using namespace jf;
     extern "C" int jf_##fam##_chain_inv_bwd_##suffix(const T* x, int64_t xs, const T* p, int64_t ps, int32_t pb, int64_t B, int32_t n,             \
                                                      const jf_##fam##_layer* L, const T* gxo, int64_t gxos, const T* gld, const T* gblp, T* gx,   \
                                                      int64_t gxs, T* gp, int64_t gps, int32_t* st, void* s) {                                   \
-        if (use_dual_replay()) return jf::dual_##fam##_chain_inv_bwd_##suffix(x, xs, p, ps, pb, B, n, L, gxo, gxos, gld, gblp, gx, gxs, gp, gps, st, s); \
+        if (use_dual_replay() || prefers_dual(L, n))                                                                                           \
+            return jf::dual_##fam##_chain_inv_bwd_##suffix(x, xs, p, ps, pb, B, n, L, gxo, gxos, gld, gblp, gx, gxs, gp, gps, st, s);             \
         return mchain_rev<T, Fam, Adj>(x, xs, p, ps, pb, B, n, L, gxo, gxos, gld, gblp, gx, gxs, gp, gps, st, s);                                \
     }
 JF_DEFINE_MCHAIN_REV(r, RFam, RAdj, float, f32)

@@ -324,11 +324,13 @@ static int mlp2_small_bwd(const T* x, int64_t xs, const T* W1, int64_t w1s, cons
     const int64_t rpb = (B + S - 1) / S;
     const dim3 grid((unsigned)S), block(128);
     hipStream_t st = (hipStream_t)stream;
-    const int kb = K1 <= 4 ? 4 : K1 <= 8 ? 8 : K1 <= 16 ? 16 : 32, nb = N <= 4 ? 4 : N <= 8 ? 8 : N <= 12 ? 12 : 16;
+    // (K1 = 1, 2 get their own instantiations since round 6: the 1 -> 128 -> 8 head of C4 spent 6 of its 35 vector instructions per row and hidden
+    //  unit on the three zero-weight slots of a four-wide input loop)
+    const int kb = K1 <= 1 ? 1 : K1 <= 2 ? 2 : K1 <= 4 ? 4 : K1 <= 8 ? 8 : K1 <= 16 ? 16 : 32, nb = N <= 4 ? 4 : N <= 8 ? 8 : N <= 12 ? 12 : 16;
     const int dense = (kb == K1 || xs == K1) && (nb == N || gs == N);           // padded slots read rows of the same array, never a gap
 #define JF_MS(KB_, NB_) jf::launch((mlp2_small_bwd_kernel<T, KB_, NB_>), grid, block, 0, st, x, xs, W1, w1s, b1, W2, w2s, g, gs, B, (int)K1, (int)H, (int)N, rpb, slab, slab_b2, dense)
 #define JF_MS_N(KB_) { if (N <= 4) JF_MS(KB_, 4); else if (N <= 8) JF_MS(KB_, 8); else if (N <= 12) JF_MS(KB_, 12); else JF_MS(KB_, 16); }
-    if (K1 <= 4) JF_MS_N(4) else if (K1 <= 8) JF_MS_N(8) else if (K1 <= 16) JF_MS_N(16) else JF_MS_N(32)
+    if (K1 <= 1) JF_MS_N(1) else if (K1 <= 2) JF_MS_N(2) else if (K1 <= 4) JF_MS_N(4) else if (K1 <= 8) JF_MS_N(8) else if (K1 <= 16) JF_MS_N(16) else JF_MS_N(32)
 #undef JF_MS_N
 #undef JF_MS
     return check_launch();

@@ -76,7 +76,7 @@ if __name__ == "__main__":
     d = tempfile.mkdtemp()
     outs = []
     crashed = []
-    for dual in ("0", "1"):
+    for dual in ("-1", "1"):                              # -1: the reverse sweep also where the library would pick the replay (plain 'f' layers)
         o = os.path.join(d, "g%s" % dual)
         todo = fixture_names()
         while todo:                                     # a child that dies (a faulting kernel) is resumed behind the fixture it died in

@@ -312,11 +312,18 @@ def test_bench_launches_its_own_ranks_dry_run():
     # the line says who held how many rows and what one stand-alone all-gather of the log-probs takes
     assert line["exchange"]["rows_per_rank"] == [1000, 1000] and line["exchange"]["gather_us"] > 0 and line["exchange"]["gather_bytes_per_rank"] == 8000
     # the default is STRONG scaling (efficiency at fixed total batch): --batch is then the total, split over the ranks
-    r = _run_bench(["--gpus", "2", "--steps", "1", "--warmup", "0", "--dry-run", "--batch", "1000"], {"JF_BENCH_BACKEND": "gloo"},
+    # every rank's own step time (a straggler would show), counted from the ranks the timing loop really saw
+    rk = line["rank_ms_per_step"]
+    assert line["ranks_in_timing"] == 2 and len(rk["per_rank"]) == 2 and rk["min"] <= rk["mean"] <= rk["max"] and rk["slowest_rank"] in (0, 1)
+    assert abs(rk["max"] - line["ms_per_step"]) < 1e-9 and line["scaling_efficiency_vs_t1"] is None
+    r = _run_bench(["--gpus", "2", "--steps", "1", "--warmup", "0", "--dry-run", "--batch", "1000", "--t1-ms", "3.0"], {"JF_BENCH_BACKEND": "gloo"},
                    drop=("WORLD_SIZE", "RANK", "LOCAL_RANK"))
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
     assert line["scaling"] == "strong" and line["config"]["total_rows"] == 1000 and line["config"]["batch_per_gpu"] == 500
+    # --t1-ms: the measured efficiency of this run against the driver's N = 1 time (strong: T_1 / (N T_N))
+    eff = line["scaling_efficiency_vs_t1"]
+    assert eff["n_gpus"] == 2 and eff["t1_ms"] == 3.0 and abs(eff["efficiency"] - 3.0 / (2 * line["ms_per_step"])) < 1e-9
 
 
 def test_bench_c5_strong_scaling_row_split_dry_run():
