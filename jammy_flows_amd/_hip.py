@@ -164,6 +164,8 @@ _SIGNATURES = {
 }
 # entry points that exist for one precision only: full symbol name -> (argtypes, restype)
 _SIGNATURES_SINGLE = {
+    "jf_set_newton_rule": ([_I32], ctypes.c_int),
+    "jf_get_newton_rule": ([], ctypes.c_int),
     "jf_gf_bcast_lane_rows": ([_I64], ctypes.c_int64),
     "jf_merge_begin": ([], ctypes.c_int),
     "jf_merge_abort": ([], ctypes.c_int),
@@ -283,7 +285,28 @@ def lib():
         fn.argtypes = argtypes
         fn.restype = restype
     _lib = l
+    rule = os.environ.get("JF_NEWTON_RULE", "")
+    if rule:                                           # JF_NEWTON_RULE=reference: the audit switch from the environment (set_newton_rule below)
+        if rule not in ("reference", "product"):
+            raise ValueError("JF_NEWTON_RULE must be 'reference' or 'product', not %r" % rule)
+        if rule == "reference" and torch.cuda.is_available():
+            _check(int(l.jf_set_newton_rule(1)), "jf_set_newton_rule")
     return _lib
+
+
+def set_newton_rule(rule):
+    """'reference': every iterative solver (sampling direction of 'g', the solves of 'm' / 'v') follows the reference's own iteration -- 25
+    bisections on [-1e5, 1e5], Newton until the row's update sum is below 1e-14 or 20 steps are done, no float32 floor, 'v' until 1e-12
+    (bisection_n_newton.py:11-135, 330-465); 'product' (default): the library's rules (csrc/jf_math.h NewtonTol, jf_gf.h gf_approach).  Process-wide;
+    synchronises the device first.  Also settable as JF_NEWTON_RULE=reference in the environment."""
+    if rule not in ("reference", "product"):
+        raise ValueError("rule must be 'reference' or 'product'")
+    torch.cuda.synchronize()
+    _check(int(lib().jf_set_newton_rule(1 if rule == "reference" else 0)), "jf_set_newton_rule")
+
+
+def get_newton_rule():
+    return "reference" if int(lib().jf_get_newton_rule()) else "product"
 
 
 def _suffix(t):

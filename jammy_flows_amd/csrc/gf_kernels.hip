@@ -581,7 +581,7 @@ template <typename T> static int64_t gf_lds_query(int32_t D, int32_t n_layers, c
 }  // namespace jf
 
 extern "C" {
-int jf_abi_version(void) { return 7; }   // v7 (round 5): jf_merge_*, jf_gf_bcast_lane_rows; the jf_cond_gf_pp_* entry points left (scripts/probe/cond_pp)
+int jf_abi_version(void) { return 8; }   // v8 (round 6): jf_set_newton_rule / jf_get_newton_rule (the solvers' audit switch); v7: jf_merge_*, jf_gf_bcast_lane_rows
 int64_t jf_gf_bcast_lane_rows(int64_t rows) {
     const int64_t prev = jf::gfbg_max_rows();
     jf::gfbg_forced_rows = rows;

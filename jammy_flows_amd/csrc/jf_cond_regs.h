@@ -254,9 +254,9 @@ __device__ __forceinline__ T cs_solve(const T (&P)[CS_SLOTS], int inv_type, bool
             if (Mf::finite(nx)) x = nx; else nonfinite = nonfinite || live;
             ferr = Mf::abs(f);
             last_logd = s.logd;
-            active = usum >= T(NewtonTol<T>::value);
+            active = usum >= newton_tol<T>();
         }
-        if constexpr (sizeof(T) == 4) {
+        if (sizeof(T) == 4 && !newton_reference_rule()) {
             // float32 floor of the update (see gfg_solve): the reference's float32 runs spend their last ~16 Newton steps on rounding noise
             const T xs = rsum(live ? Mf::max(Mf::abs(x), T(1)) : T(0));
             // at the coordinates' resolution, or (jf_math.h) below JF_F32_NEWTON_FLOOR of them with the residual of the evaluation just made

@@ -589,7 +589,7 @@ template <typename T> __device__ inline void v_newton(const T* __restrict__ pp, 
                     // -- no longer measures the distance
                     // (round 5: 1e-7, not 1e-12 -- Gauss-Newton steps shrink quadratically, 1e-2, 1e-4, 1e-8, and the evaluation that would
                     //  follow a step below 1e-7 only confirms with one of ~1e-14 x curvature: NewtonTol, jf_math.h)
-                    if (len < T(1e-7)) gn_done = true;
+                    if (len < (newton_reference_rule() ? T(1e-12) : T(1e-7))) gn_done = true;      // (audit switch: the reference's own threshold)
                 } else if (len == T(0)) {
                     gn_done = true;
                 }

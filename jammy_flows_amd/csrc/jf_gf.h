@@ -437,6 +437,16 @@ template <typename F, typename EVAL> __device__ __forceinline__ F gf_approach(EV
     const F tz = proxy ? (F)gf_log_ndtr_neg((float)M<F>::abs(z)) : F(0);
     F xf = x0, blo = F(-1e5), bhi = F(1e5), dxold = F(2e5);
     bool act = live;
+    if (newton_reference_rule()) {                                 // audit switch (jf_common.h): the reference's 25 bisections on [-1e5, 1e5] (bisection_n_newton.py:11-60)
+        for (int it = 0; it < 25; ++it) {
+            xf = F(0.5) * (blo + bhi);
+            if (n_evals != nullptr) *n_evals += 1;
+            const MixQ<F> q = eval(xf);
+            const F g = proxy ? (neg ? q.lc - tz : tz - q.ls) : q.lc - q.ls - z;
+            if (g < F(0)) blo = xf; else bhi = xf;
+        }
+        return xf;
+    }
     for (int it = 0; it < 40 && __any(act); ++it) {
         if (n_evals != nullptr) *n_evals += 1;                     // (probe builds: evaluations the WAVE makes, JF_PROBE_COUNT_APPROACH)
         const MixQ<F> q = eval(xf);
@@ -508,9 +518,9 @@ template <typename T, int G> __device__ __forceinline__ T gfg_solve(const T* __r
             const T nx = x - upd;
             if (M<T>::finite(nx)) x = nx; else nonfinite = nonfinite || live;     // keep the previous iterate (:84-91)
             ferr = M<T>::abs(f);
-            active = usum >= T(NewtonTol<T>::value);
+            active = usum >= newton_tol<T>();
         }
-        if constexpr (sizeof(T) == 4) {
+        if (sizeof(T) == 4 && !newton_reference_rule()) {
             // float32: the reference's absolute 1e-14 fires only on an exactly zero update, i.e. its float32 runs do all 20 steps and the last
             // ~16 of them move the iterate by rounding noise.  A row is at that floor when its update has reached the resolution of its
             // coordinates, or has stopped shrinking while already below 1e-4 of them; further steps cannot improve it.

@@ -258,8 +258,8 @@ template <typename T, typename PA> __device__ inline void gx_solve(const GfLayer
             ferr = M<T>::max(ferr, M<T>::abs(f));
             xs += M<T>::max(M<T>::abs(x[d]), T(1));
         }
-        active = usum >= T(NewtonTol<T>::value);
-        if constexpr (sizeof(T) == 4) {          // float32 rounding floor, as in gfg_solve (jf_gf.h)
+        active = usum >= newton_tol<T>();
+        if (sizeof(T) == 4 && !newton_reference_rule()) {          // float32 rounding floor, as in gfg_solve (jf_gf.h)
             const bool done = usum < T(2.5e-7) * xs || (usum < T(JF_F32_NEWTON_FLOOR) * xs && ferr <= T(1e-4));                  // (jf_math.h)
             if (done || (usum >= T(0.5) * prev && usum < T(1e-4) * xs)) active = false;
             prev = usum;

@@ -200,10 +200,10 @@ template <typename T, typename ROW> __device__ inline T moebius_solve_values(ROW
             const T upd = (f - z) / d;
             x -= upd;
             ferr = M<T>::abs(f - z);
-            active = M<T>::abs(upd) >= T(NewtonTol<T>::value);
+            active = M<T>::abs(upd) >= newton_tol<T>();
             // float32 (the absolute 1e-14 only fires on an exactly zero update: all 20 steps ran, 19 of them on rounding noise): the floor of
             // the 'g' solvers (jf_math.h) -- at the coordinate's resolution, or below 1e-5 of it with the residual inside the 1e-4 threshold
-            if constexpr (sizeof(T) == 4) {
+            if (sizeof(T) == 4 && !newton_reference_rule()) {
                 const T xs = M<T>::max(M<T>::abs(x), T(1));
                 if (M<T>::abs(upd) < T(2.5e-7) * xs || (M<T>::abs(upd) < T(JF_F32_NEWTON_FLOOR) * xs && ferr <= T(1e-4))) active = false;
             }

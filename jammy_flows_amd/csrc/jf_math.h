@@ -182,6 +182,11 @@ template <typename T> __device__ __forceinline__ T clampv(T x, T lo, T hi) { ret
 // the last thing the reference itself does before its confirming step.  float64 rows therefore stop at 1e-9 (one float64 mixture evaluation per
 // coordinate and layer less: C5 sampling 3.2 -> see DESIGN); float32 rows keep their own rounding-floor rule below.
 template <typename T> struct NewtonTol { static constexpr double value = sizeof(T) == 8 ? 1e-9 : 1e-14; };
+// the audit switch (jf_common.h: one flag per translation unit, set by jf_set_newton_rule)
+static __device__ int g_newton_reference = 0;
+__device__ __forceinline__ bool newton_reference_rule() { return g_newton_reference != 0; }
+// ... unless the audit switch asks for the reference's own rule (jf_common.h: newton_reference_rule)
+template <typename T> __device__ __forceinline__ T newton_tol() { return newton_reference_rule() ? T(1e-14) : T(NewtonTol<T>::value); }
 // ... and the float32 rows' floor (the reference's absolute 1e-14 never fires in float32: its float32 runs do all 20 steps on rounding noise).  A row
 // stops when the sum of its |updates| is below this fraction of the sum of max(|x|, 1) over its coordinates.  Rounds 1-4 used the resolution of the
 // coordinates (2.5e-7), which -- like 1e-14 in float64 -- made most waves spend a second evaluation confirming a first update of 1e-6 .. 1e-5: the

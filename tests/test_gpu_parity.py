@@ -149,6 +149,58 @@ def test_sampling_float64_vs_reference(fx):
         assert NEWTON_BAND[0] * rec["row_steps_total"] <= got <= NEWTON_BAND[1] * rec["row_steps_total"]
 
 
+def test_reference_newton_rule_reproduces_the_reference_iteration():
+    """the audit switch (jf_set_newton_rule / JF_NEWTON_RULE=reference, include/jammy_hip.h): with it the solvers follow the reference's own
+    iteration -- 25 bisections on [-1e5, 1e5], Newton until 1e-14 / 20 steps, 'v' until 1e-12 (bisection_n_newton.py:11-135, 330-465).  On every
+    sampling fixture, float64: (a) the samples of the two rules agree to 1e-10 of their size (1e-12 and better on all but the skewed-logistic
+    fixtures, whose closed forms leave cdf + sf = 1 + O(2e-9), jf_gf_ext.h: printed) and the log-probs to 1e-9 (the log-density's slope
+    reaches 1e5 between narrow components: 1e-15 in x is 1e-10 in log p); 5e-9 where the sphere Newton of 'v' is in the chain (its two end
+    rules both sit below the reference's own 1e-6 agreement) -- i.e. the product rule loses nothing; (b) under the reference
+    rule the kernel's Newton row-steps equal what the reference's masked iteration spent on the same rows (tests/golden/newton_records.json)
+    within 10 % on most fixtures (band 0.75 ... 1.10: see the end of the test)."""
+    from jammy_flows_amd import _hip
+    assert _hip.get_newton_rule() == "product"
+    worst, checked = 0.0, 0
+    ratios, per_fx = {}, {}
+    try:
+        for fx in SUPPORTED:
+            out = {}
+            for rule in ("product", "reference"):
+                _hip.set_newton_rule(rule)
+                pdf = build_product(fx, torch.float64)
+                z = to_dev(fx["z"], torch.float64)
+                cond = to_dev(fx.get("cond"), torch.float64)
+                x, _, logp, _ = pdf._obtain_sample(conditional_input=cond, predefined_target_input=z, force_embedding_coordinates=fx.meta["embedding"])
+                out[rule] = (x.cpu().numpy(), logp.cpu().numpy(), dict(pdf.last_status_words))
+            fin = np.isfinite(out["reference"][1])
+            ex = float((np.abs(out["product"][0] - out["reference"][0]) / (1.0 + np.abs(out["reference"][0])))[fin].max())
+            el = float((np.abs(out["product"][1] - out["reference"][1]) / (1.0 + np.abs(out["reference"][1])))[fin].max())
+            tol = 5e-9 if "v" in fx.flow_defs else 1e-10
+            assert ex < tol and el < max(tol, 1e-9), (fx.name, ex, el)
+            worst = max(worst, ex if "v" not in fx.flow_defs else 0.0)
+            per_fx[fx.name] = ex
+            rec = NEWTON_RECORDS.get(fx.name)
+            if rec is not None:
+                got = out["reference"][2]["newton_row_steps"]
+                ratios[fx.name] = got / rec["row_steps_total"]
+                assert out["product"][2]["newton_row_steps"] < got
+                checked += 1
+    finally:
+        _hip.set_newton_rule("product")
+    print("reference vs product Newton rule: worst |dx| / (1 + |x|) = %.2e over %d fixtures; row-steps / the reference's: %s"
+          % (worst, len(SUPPORTED), " ".join("%s %.3f" % kv for kv in sorted(ratios.items()))))
+    print("fixtures above 1e-12: %s" % {k: "%.1e" % v for k, v in per_fx.items() if v > 1e-12})
+    assert checked >= 10
+    # 24 of 28 fixtures sit within 10 % of the reference's count (0.90 ... 1.00).  The rest of the gap is not the rule but rounding: in the inormal_*
+    # stages a few rows of the reference never see an update below 1e-14 (their updates stall at 1e-15 ... 1e-13: the rounding floor of the
+    # inverse-normal stage) and run all 20 steps -- 5 of 192 rows of a layer are 20 % of that layer's row-steps (newton_records.json "active");
+    # which rows stall depends on the last bits of the evaluation, and the kernel's log-space mixture rounds differently from torch's.
+    # g_e2_fullpade 0.785, t_e3_gt_full_cond 0.869, g_e2_crude / g_e2_precise 0.8996: the band is 0.75 ... 1.10
+    off = {k: v for k, v in ratios.items() if not 0.75 <= v <= 1.1}
+    assert not off, off
+    assert sum(1 for v in ratios.values() if 0.9 <= v <= 1.1) >= 0.8 * len(ratios), ratios
+
+
 @pytest.mark.parametrize("fx", SUPPORTED, ids=IDS)
 def test_sampling_float32_vs_float64_reference(fx):
     """sampling direction in float32 against the float64 reference samples of the same injected base points.  The Newton stage of the g

@@ -260,7 +260,7 @@ def test_shipped_library_has_no_packed_f32_instructions(tmp_path):
         pytest.skip("library or llvm-objdump not available")
     cos = _device_code_objects(lib)
     csrc = os.path.join(ROOT, "jammy_flows_amd", "csrc")
-    n_src = len([f for f in os.listdir(csrc) if f.endswith(".hip") and "__global__" in open(os.path.join(csrc, f)).read()])   # (plan.hip is host code only)
+    n_src = len([f for f in os.listdir(csrc) if f.endswith(".hip")])   # (every unit holds device code: at least the solvers' audit flag, jf_math.h g_newton_reference)
     assert len(cos) == n_src, "expected one gfx950 code object per .hip translation unit (%d), found %d" % (n_src, len(cos))
     pat = re.compile(rb"\bv_pk_(?:fma|mul|add)_f32\b")
     mfma = 0
@@ -268,7 +268,7 @@ def test_shipped_library_has_no_packed_f32_instructions(tmp_path):
         p = tmp_path / ("dev%d.co" % i)
         p.write_bytes(co)
         asm = subprocess.run([objdump, "-d", "--mcpu=gfx950", str(p)], stdout=subprocess.PIPE, check=True).stdout
-        assert len(asm) > 1000
+        assert len(asm) > (1000 if asm.count(b"s_endpgm") > 1 else 50)  # (plan.hip: host code + the audit flag's one-thread setter only)
         hits = pat.findall(asm)
         assert not hits, "code object %d of libjammy_hip.so contains %d packed-f32 instructions" % (i, len(hits))
         mfma += len(re.findall(rb"\bv_mfma_f32_16x16x32_bf16\b", asm))
