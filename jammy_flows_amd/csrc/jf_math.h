@@ -31,10 +31,25 @@ template <> struct M<float> {
     static constexpr float EPS_COS = 1e-7f;     // sphere_base.return_safe_costheta float32 margin
     static constexpr float EPS_S1 = 1e-5f;      // sphere_base.sphere_to_plane float32 clamp
     static constexpr float KAPPA_ID = 1e-4f;    // fvm_2d small-kappa identity switch (float32)
+    // (JF_PROBE_ACCURATE_*: probe builds that put the correctly rounded library function in place of ONE hardware approximation -- the float32 error
+    //  budget of DESIGN section 4, scripts/probe/f32_error_budget.sh; never defined in the shipped library)
+#ifdef JF_PROBE_ACCURATE_EXP
+    static __device__ __forceinline__ float exp_fast(float x) { return expf(x); }
+#else
     static __device__ __forceinline__ float exp_fast(float x) { return __expf(x); }
+#endif
+#ifdef JF_PROBE_ACCURATE_LOG
+    static __device__ __forceinline__ float log_fast(float x) { return logf(x); }
+#else
     static __device__ __forceinline__ float log_fast(float x) { return 0.69314718056f * __builtin_amdgcn_logf(x); }   // v_log_f32 (normal-range inputs only)
+#endif
+#ifdef JF_PROBE_ACCURATE_RCP
+    static __device__ __forceinline__ float sqrt_fast(float x) { return sqrtf(x); }
+    static __device__ __forceinline__ float rcp(float x) { return __fdiv_rn(1.0f, x); }
+#else
     static __device__ __forceinline__ float sqrt_fast(float x) { return __builtin_amdgcn_sqrtf(x); }
     static __device__ __forceinline__ float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+#endif
     static __device__ __forceinline__ float exp(float x) { return expf(x); }
     static __device__ __forceinline__ float log(float x) { return logf(x); }
     static __device__ __forceinline__ float log1p(float x) { return log1pf(x); }
