@@ -28,6 +28,10 @@ Printed JSON line (rank 0): metric/value (whole-job evals/s), ms_per_step, plus
 """
 import os
 
+if os.environ.get("JF_BENCH_HANG_TRACE"):        # debugging aid: the Python stacks of all threads after this many seconds, then exit
+    import faulthandler
+    faulthandler.dump_traceback_later(float(os.environ["JF_BENCH_HANG_TRACE"]), exit=True)
+
 # the CPU baseline forks one single-threaded worker per core: the BLAS / OpenMP pools must be sized BEFORE numpy is imported
 for _v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS", "NUMEXPR_NUM_THREADS"):
     os.environ.setdefault(_v, "1")

@@ -37,13 +37,13 @@ extern "C" {
 
 int jf_abi_version(void);
 
-/* Audit switch of the iterative solvers (sampling direction of 'g', the solves of 'm' and 'v'; ABI 8).  reference = 0 (default): the product's
- * rules -- a safeguarded Newton approach phase, float64 rows stop at an update of 1e-9, float32 rows at their rounding floor, the sphere Newton
- * of 'v' at a Gauss-Newton step of 1e-7.  reference = 1: the reference's own iteration, bisection_n_newton.py:11-135 (25 bisections on
- * [-1e5, 1e5], then Newton until the row's update sum is below 1e-14 or 20 steps are done) and :330-465 ('v': 1e-12).  Process-wide and
- * synchronous (it waits for the device, writes one flag per translation unit with a one-thread launch each, waits again).  Results of the two rules agree to rounding
- * (tests/test_gpu_parity.py::test_reference_newton_rule_*); the switch exists so that an auditor can reproduce the reference's iteration counts. */
-int jf_set_newton_rule(int32_t reference);
+/* Audit build of the iterative solvers (sampling direction of 'g', the solves of 'm' and 'v'; ABI 8).  The product library's rules: a safeguarded
+ * Newton approach phase, float64 rows stop at an update of 1e-9, float32 rows at their rounding floor, the sphere Newton of 'v' at a
+ * Gauss-Newton step of 1e-7.  csrc/Makefile also builds libjammy_hip_audit.so (-DJF_NEWTON_RULE_REFERENCE): the same entry points with the
+ * reference's own iteration, bisection_n_newton.py:11-135 (25 bisections on [-1e5, 1e5], then Newton until the row's update sum is below 1e-14
+ * or 20 steps are done) and :330-465 ('v': 1e-12).  jf_get_newton_rule() returns 1 for that library, 0 for the product library.  The two agree to
+ * rounding (tests/test_gpu_parity.py::test_reference_newton_rule_*); the audit library exists so that the reference's iteration counts can be
+ * reproduced.  The Python package loads it when JF_NEWTON_RULE=reference is set in the environment. */
 int jf_get_newton_rule(void);
 
 /* one column range of an MLP input row cat[conditional_input, embed(x_0), embed(x_1), ...] (main/default.py:946-962): `src` row-major with row

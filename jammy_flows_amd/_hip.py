@@ -13,7 +13,10 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # JF_LIB_PATH: a private build of the same library (instrumented probes, scripts/probe/pp_trace.sh); the product loads the in-tree one
-LIB_PATH = os.environ.get("JF_LIB_PATH") or os.path.join(_HERE, "libjammy_hip.so")
+NEWTON_RULE = os.environ.get("JF_NEWTON_RULE", "product")
+if NEWTON_RULE not in ("product", "reference"):
+    raise ValueError("JF_NEWTON_RULE must be 'reference' or 'product', not %r" % NEWTON_RULE)
+LIB_PATH = os.environ.get("JF_LIB_PATH") or os.path.join(_HERE, "libjammy_hip_audit.so" if NEWTON_RULE == "reference" else "libjammy_hip.so")
 
 JF_OK, JF_ERR_BADARG, JF_ERR_UNSUPPORTED, JF_ERR_LAUNCH = 0, -1, -2, -3
 JF_ERRORS = {-1: "bad argument", -2: "unsupported configuration (a kernel cap: g / t beyond their dimension cap, spline bins, chain too long, LDS budget ...)", -3: "kernel launch failed"}
@@ -25,7 +28,7 @@ GF_INV_TYPES = {"isigmoid": 0, "inormal_partly_precise": 1, "inormal_partly_crud
 GF_WIDTH_SMOOTH, GF_WIDTH_EXP, GF_WIDTH_SOFTPLUS = 0, 1, 2
 GF_STRETCH_CLASSIC, GF_STRETCH_RQ_SPLINES = 0, 1
 GF_ROT_MODES = {"householder": 0, "angles": 1, "cayley": 2, "triangular_combination": 3}
-JF_SPLINE_MAX_BINS = 16          # 'g' with the rq_splines stretch (fixed table stride, csrc/jf_spline.h)
+JF_SPLINE_MAX_BINS = 64          # 'g' with the rq_splines stretch (= JF_SPLINE_CAP since round 6: a lane's knot table follows the chain's own bin count)
 JF_SPLINE_CAP = 64               # 'r', 'o', splines nested in 'f' (tables at the chain's own bin count; the launch sizes its row tile to the LDS)
 JF_CORR_SCRATCH = 81
 
@@ -164,7 +167,6 @@ _SIGNATURES = {
 }
 # entry points that exist for one precision only: full symbol name -> (argtypes, restype)
 _SIGNATURES_SINGLE = {
-    "jf_set_newton_rule": ([_I32], ctypes.c_int),
     "jf_get_newton_rule": ([], ctypes.c_int),
     "jf_gf_bcast_lane_rows": ([_I64], ctypes.c_int64),
     "jf_merge_begin": ([], ctypes.c_int),
@@ -285,27 +287,15 @@ def lib():
         fn.argtypes = argtypes
         fn.restype = restype
     _lib = l
-    rule = os.environ.get("JF_NEWTON_RULE", "")
-    if rule:                                           # JF_NEWTON_RULE=reference: the audit switch from the environment (set_newton_rule below)
-        if rule not in ("reference", "product"):
-            raise ValueError("JF_NEWTON_RULE must be 'reference' or 'product', not %r" % rule)
-        if rule == "reference" and torch.cuda.is_available():
-            _check(int(l.jf_set_newton_rule(1)), "jf_set_newton_rule")
+    if NEWTON_RULE == "reference" and int(l.jf_get_newton_rule()) != 1:
+        raise HipUnavailable("JF_NEWTON_RULE=reference, but %s was not built with the reference's solver rule" % LIB_PATH)
     return _lib
 
 
-def set_newton_rule(rule):
-    """'reference': every iterative solver (sampling direction of 'g', the solves of 'm' / 'v') follows the reference's own iteration -- 25
-    bisections on [-1e5, 1e5], Newton until the row's update sum is below 1e-14 or 20 steps are done, no float32 floor, 'v' until 1e-12
-    (bisection_n_newton.py:11-135, 330-465); 'product' (default): the library's rules (csrc/jf_math.h NewtonTol, jf_gf.h gf_approach).  Process-wide;
-    synchronises the device first.  Also settable as JF_NEWTON_RULE=reference in the environment."""
-    if rule not in ("reference", "product"):
-        raise ValueError("rule must be 'reference' or 'product'")
-    torch.cuda.synchronize()
-    _check(int(lib().jf_set_newton_rule(1 if rule == "reference" else 0)), "jf_set_newton_rule")
-
-
 def get_newton_rule():
+    """'product' (default) or 'reference': which iteration rule the loaded library's solvers follow.  JF_NEWTON_RULE=reference in the environment
+    (read at import) loads libjammy_hip_audit.so -- the same kernels built with the reference's own iteration: 25 bisections on [-1e5, 1e5], Newton
+    until the row's update sum is below 1e-14 or 20 steps are done, no float32 floor, 'v' until 1e-12 (bisection_n_newton.py:11-135, 330-465)."""
     return "reference" if int(lib().jf_get_newton_rule()) else "product"
 
 
@@ -351,30 +341,38 @@ def _stream(dev=None):
 
 
 # Side streams the library itself issues work on (the training streams of default.pdf).  The caching allocator hands a freed block back to the
-# pool of the stream it was ALLOCATED on: a tensor allocated on the caller's stream that a side-stream kernel still reads (or the reverse) must
-# be announced with record_stream, or its block can be handed out again while that kernel runs.
+# pool of the stream it was ALLOCATED on: a tensor allocated on the caller's stream that a side-stream kernel still reads (or the reverse) can be
+# handed out again while that kernel runs, if the host drops its last reference too early -- e.g. a saved tensor, released as soon as
+# its backward node returns while the node's kernel is still in flight on the side stream.  record_stream would announce every such use, at a
+# price: ~2 us per call and, worse, an event per recorded block when it is freed (the eager C3 training step: 1.33 -> 1.66 ms).  Instead the
+# tensors are KEPT ALIVE until the streams have met again: every tensor that crosses between the caller's stream and a side stream is appended to
+# KEEPALIVE, which the next gradient-mode forward call empties -- by then the caller's stream has waited for the side streams (at the end of the
+# forward pass: default.pdf._forward_with_grad; at the end of backward(): the autograd engine synchronises the streams it used with the
+# caller's), so whatever reuses the blocks is ordered behind their last reader.
 SIDE_STREAMS = {}                 # cuda_stream handle -> torch.cuda.Stream
+KEEPALIVE = []
 
 
 def register_side_stream(st):
     SIDE_STREAMS[st.cuda_stream] = st
 
 
-def record_on(stream, *tensors):
-    """announce that `stream` uses these tensors (None entries / CPU tensors are skipped)"""
-    for t in tensors:
-        if isinstance(t, torch.Tensor) and t.is_cuda and t.numel():
-            t.record_stream(stream)
+def keep_alive(*tensors):
+    """hold these tensors (None entries are skipped) until release_keepalive()"""
+    KEEPALIVE.extend(t for t in tensors if isinstance(t, torch.Tensor))
 
 
-def record_if_side_stream(*tensors):
-    """inside a custom backward: when the node runs on one of the library's side streams (autograd runs a node on its forward's stream),
-    announce the tensors it reads there -- saved tensors are released on the host right after the node, while its kernel may still run"""
-    if not SIDE_STREAMS:
-        return
-    cs = torch.cuda.current_stream()
-    if cs.cuda_stream in SIDE_STREAMS:
-        record_on(cs, *tensors)
+def release_keepalive():
+    """the caller's stream and the side streams have met since the kept tensors' last use (see above)"""
+    if KEEPALIVE:
+        KEEPALIVE.clear()
+
+
+def keep_if_side_stream(*tensors):
+    """inside a custom backward: when the node runs on one of the library's side streams (autograd runs a node on its forward's stream), the
+    tensors it reads there must outlive its kernels"""
+    if SIDE_STREAMS and torch.cuda.current_stream().cuda_stream in SIDE_STREAMS:
+        keep_alive(*tensors)
 
 
 class KernelTimer:

@@ -24,12 +24,15 @@ from . import _hip
 
 def _side_stream_safe(backward):
     """backward of a node that may run on one of the pdf's training side streams (default.pdf.train_streams): its saved tensors and incoming
-    gradients were (possibly) allocated on the caller's stream and are released on the host as soon as the node returns -- announce them to the
-    allocator first (_hip.record_if_side_stream; a no-op on the caller's stream)."""
+    gradients were (possibly) allocated on the caller's stream and are released on the host as soon as the node returns, while its kernels may
+    still be reading them -- they are kept alive until the streams have met again (_hip.keep_if_side_stream; a no-op on the caller's stream)."""
     def wrapped(ctx, *grads):
         if _hip.SIDE_STREAMS:
-            _hip.record_if_side_stream(*ctx.saved_tensors, *grads)
-        return backward(ctx, *grads)
+            _hip.keep_if_side_stream(*ctx.saved_tensors, *grads)
+        out = backward(ctx, *grads)
+        if _hip.SIDE_STREAMS:
+            _hip.keep_if_side_stream(*(out if isinstance(out, tuple) else (out,)))     # side-stream allocations read by nodes on the caller's stream
+        return out
     wrapped.__doc__ = backward.__doc__
     return wrapped
 

@@ -754,7 +754,7 @@ template <typename T> static int gb_fill(GfBwdArgs<T>& a, const T* params, int64
         if (h.nonlinear_stretch_type != JF_GF_STRETCH_CLASSIC && h.nonlinear_stretch_type != JF_GF_STRETCH_RQ_SPLINES) return JF_ERR_BADARG;
         const bool rq = h.nonlinear_stretch_type == JF_GF_STRETCH_RQ_SPLINES;      // spline stretch: the general-option kernel (one lane per row, lane-private knot table)
         if (rq && (h.center_mean || h.add_skewness)) return JF_ERR_BADARG;
-        if (rq && (h.num_kde > JF_SPLINE_MAX_BINS || D > JF_MAX_D_GF)) return JF_ERR_UNSUPPORTED;
+        if (rq && (h.num_kde > JF_SPLINE_CAP || D > JF_MAX_D_GF)) return JF_ERR_UNSUPPORTED;
         if (rq) { ext = true; if (spline_tab_words(h.num_kde) > a.spline_tab) a.spline_tab = spline_tab_words(h.num_kde); }
         o.K = h.num_kde; o.hh = h.hh_iter; o.model_offset = h.model_offset; o.fit_norm = h.fit_normalization;
         o.reg_norm = h.regulate_normalization; o.inv_type = h.inverse_function_type; o.width_mode = h.width_mode;

@@ -143,7 +143,7 @@ __global__ void __launch_bounds__(BCAST ? 256 : 64, sizeof(T) == 8 ? 2 : 4) gf_c
             if (o.stretch == JF_GF_STRETCH_RQ_SPLINES) {
                 // per-dimension spline with learnable box and linear tails (gaussianization_flow.py:926-940, 1060-1068); lane-private knot table
                 const T* pr = p - d;                                                         // start of the lane's row
-                T* tab = spl_tab + tid * JF_SPLINE_TAB;
+                T* tab = spl_tab + tid * a.spline_tab;
                 if constexpr (!FWD) {
                     if (o.model_offset) x -= p[0];
                     x = gfg_rotate_inv<T, G, !BCAST>(p, o, D, live, x);
@@ -246,7 +246,7 @@ template <typename T, bool FWD> __global__ void __launch_bounds__(GX_THREADS) gf
     T* lds = reinterpret_cast<T*>(smem_raw);
     const int tid = threadIdx.x, D = a.D;
     const XCol<T> x{lds + tid}, z{lds + JF_MAX_D_GF * GX_THREADS + tid};
-    T* tab = lds + 2 * JF_MAX_D_GF * GX_THREADS + tid * JF_SPLINE_TAB;
+    T* tab = lds + 2 * JF_MAX_D_GF * GX_THREADS + tid * a.spline_tab;
     const int64_t row = (int64_t)blockIdx.x * GX_THREADS + tid;
     const bool row_valid = row < a.B;
     const int64_t rrow = row_valid ? row : a.B - 1;
@@ -351,10 +351,11 @@ template <typename T> static int fill_args(GfChainArgs<T>& a, const T* params, i
         o.off_lw = o.off_mean + kd - (o.center_mean ? D : 0);
         o.off_ln = o.off_lw + kd;
         if (o.stretch == JF_GF_STRETCH_RQ_SPLINES) {
-            if (h.num_kde > JF_SPLINE_MAX_BINS) return JF_ERR_UNSUPPORTED;
+            if (h.num_kde > JF_SPLINE_CAP) return JF_ERR_UNSUPPORTED;           // (round 6: 16 -> 64 bins; a lane's table follows the chain's own bin count)
             o.off_box = o.off_ln + (h.num_kde + 1) * D;
             o.n_params = o.off_box + 4 * D;
             any_spline = true;
+            if (spline_tab_words(h.num_kde) > a.spline_tab) a.spline_tab = spline_tab_words(h.num_kde);
         } else {
             o.off_box = 0;
             o.off_skew = o.off_ln + (h.fit_normalization ? kd : 0);
@@ -379,9 +380,19 @@ template <typename T> static int fill_args(GfChainArgs<T>& a, const T* params, i
     const int G = group_width(D);
     size_t elems = bcast ? (size_t)n_layers * a.tile_stride : (size_t)(64 / G) * a.tile_stride;
     a.tab_offset = (int)elems;
-    if (any_spline) elems += (size_t)(bcast ? 256 : 64) * JF_SPLINE_TAB;
+    if (any_spline) elems += (size_t)(bcast ? 256 : 64) * a.spline_tab;
+    if (bcast && any_spline && !ext && elems * sizeof(T) > (size_t)LDS_LIMIT) {
+        // permanent parameters with many spline bins: the broadcast kernel's 256 lane-private knot tables do not fit a CU (32 bins in float64:
+        // 203 KB).  The per-sample kernel (64 lanes per workgroup) takes the launch with a parameter row stride of 0: every row reads the one row.
+        bcast = false;
+        a.ps = 0;
+        for (int l = 0; l < n_layers; ++l) a.L[l].vec_ok = 0;
+        elems = (size_t)(64 / G) * a.tile_stride;
+        a.tab_offset = (int)elems;
+        elems += (size_t)64 * a.spline_tab;
+    }
     lds_bytes = elems * sizeof(T);
-    if (ext) lds_bytes = ((size_t)2 * JF_MAX_D_GF * GX_THREADS + (any_spline ? (size_t)GX_THREADS * JF_SPLINE_TAB : 0)) * sizeof(T);
+    if (ext) lds_bytes = ((size_t)2 * JF_MAX_D_GF * GX_THREADS + (any_spline ? (size_t)GX_THREADS * a.spline_tab : 0)) * sizeof(T);
     a.tiles_per_block = 1;                               // broadcast: set by launch_g from the kernel's occupancy
     if (lds_bytes > (size_t)LDS_LIMIT) return JF_ERR_UNSUPPORTED;
     return JF_OK;
@@ -581,7 +592,7 @@ template <typename T> static int64_t gf_lds_query(int32_t D, int32_t n_layers, c
 }  // namespace jf
 
 extern "C" {
-int jf_abi_version(void) { return 8; }   // v8 (round 6): jf_set_newton_rule / jf_get_newton_rule (the solvers' audit switch); v7: jf_merge_*, jf_gf_bcast_lane_rows
+int jf_abi_version(void) { return 8; }   // v8 (round 6): jf_get_newton_rule (which solver rule the library was built with: libjammy_hip_audit.so); v7: jf_merge_*, jf_gf_bcast_lane_rows
 int64_t jf_gf_bcast_lane_rows(int64_t rows) {
     const int64_t prev = jf::gfbg_max_rows();
     jf::gfbg_forced_rows = rows;

@@ -8,7 +8,6 @@
 #include <type_traits>
 
 #include "../../include/jammy_hip.h"
-#include "jf_math.h"
 
 #define JF_WAVE 64
 
@@ -60,30 +59,6 @@ inline void launch(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t lds, 
     }
     (void)hipLaunchKernel((const void*)kernel, grid, block, ptrs, lds, st);
 }
-
-// ---------------------------------------------------------------------------------------------
-// Audit switch for the iterative solvers (jf_set_newton_rule, include/jammy_hip.h; JF_NEWTON_RULE=reference in the Python package).  The product
-// rule ends a Newton row earlier than the reference does and approaches the root differently (jf_math.h NewtonTol, jf_gf.h gf_approach,
-// jf_expmap.h); with the switch on, every solver follows the reference's own rule: 25 bisections on [-1e5, 1e5], then Newton until the row's
-// update sum falls below 1e-14 or 20 steps are done (bisection_n_newton.py:11-135), no float32 floor, the sphere Newton of 'v' until 1e-12.
-// The library is built without relocatable device code, so the flag is one __device__ word per translation unit; every unit registers a setter
-// at load time -- a one-thread kernel of its own that writes the unit's word (symbol look-ups by name do not see internal-linkage variables) --
-// and jf_set_newton_rule walks the list and waits for the device (no allocation).
-// ---------------------------------------------------------------------------------------------
-// (the flag itself and newton_reference_rule(): jf_math.h)
-struct NewtonRuleUnit { NewtonRuleUnit* next; int (*set)(int); };
-NewtonRuleUnit*& newton_rule_units();                              // (plan.hip)
-static __global__ void newton_rule_set_kernel(int v) { g_newton_reference = v; }
-static int newton_rule_set_this_unit(int v) {
-    hipLaunchKernelGGL(newton_rule_set_kernel, dim3(1), dim3(1), 0, (hipStream_t)0, v);
-    return hipGetLastError() == hipSuccess ? JF_OK : JF_ERR_LAUNCH;
-}
-static NewtonRuleUnit newton_rule_this_unit{nullptr, &newton_rule_set_this_unit};
-static const bool newton_rule_registered = [] {
-    newton_rule_this_unit.next = newton_rule_units();
-    newton_rule_units() = &newton_rule_this_unit;
-    return true;
-}();
 
 // ---------------------------------------------------------------------------------------------
 // vector types: 16-byte accesses are what both HBM (global_load_dwordx4) and LDS (ds_read_b128) want

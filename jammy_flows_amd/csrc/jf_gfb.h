@@ -18,6 +18,7 @@ template <typename T> struct GfChainArgs {
     int tiles_per_block;     // broadcast kernels: row tiles walked by one workgroup
     int tile_stride;         // per-sample: LDS row stride (elements); broadcast: row capacity per layer
     int tab_offset;          // element offset of the spline knot tables behind the parameter tile
+    int spline_tab;          // words of a lane's knot table: spline_tab_words of the chain's largest rq_splines bin count (0: no spline stretch)
     GfLayerDev<T> L[JF_MAX_CHAIN];
     T* x_out; int64_t xos;
     T* ld_out;

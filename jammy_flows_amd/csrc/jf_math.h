@@ -197,9 +197,17 @@ template <typename T> __device__ __forceinline__ T clampv(T x, T lo, T hi) { ret
 // the last thing the reference itself does before its confirming step.  float64 rows therefore stop at 1e-9 (one float64 mixture evaluation per
 // coordinate and layer less: C5 sampling 3.2 -> see DESIGN); float32 rows keep their own rounding-floor rule below.
 template <typename T> struct NewtonTol { static constexpr double value = sizeof(T) == 8 ? 1e-9 : 1e-14; };
-// the audit switch (jf_common.h: one flag per translation unit, set by jf_set_newton_rule)
-static __device__ int g_newton_reference = 0;
-__device__ __forceinline__ bool newton_reference_rule() { return g_newton_reference != 0; }
+// The audit switch.  -DJF_NEWTON_RULE_REFERENCE builds the library whose solvers follow the reference's own iteration: 25 bisections on
+// [-1e5, 1e5], then Newton until the row's update sum falls below 1e-14 or 20 steps are done (bisection_n_newton.py:11-135), no float32 floor, the
+// sphere Newton of 'v' until 1e-12 (:330-465).  csrc/Makefile builds it as libjammy_hip_audit.so beside the product library; the Python package
+// loads it when JF_NEWTON_RULE=reference is set (jammy_flows_amd/_hip.py), jf_get_newton_rule() says which one is loaded.  A compile-time
+// constant: the product kernels carry no trace of it.  (A run-time flag in a __device__ word per translation unit was built first: kernels of
+// gf_kernels.hip then hung under rocprofv3 --kernel-trace -- never without the profiler; a constant cannot do that.)
+#ifdef JF_NEWTON_RULE_REFERENCE
+__device__ __forceinline__ constexpr bool newton_reference_rule() { return true; }
+#else
+__device__ __forceinline__ constexpr bool newton_reference_rule() { return false; }
+#endif
 // ... unless the audit switch asks for the reference's own rule (jf_common.h: newton_reference_rule)
 template <typename T> __device__ __forceinline__ T newton_tol() { return newton_reference_rule() ? T(1e-14) : T(NewtonTol<T>::value); }
 // ... and the float32 rows' floor (the reference's absolute 1e-14 never fires in float32: its float32 runs do all 20 steps on rounding noise).  A row

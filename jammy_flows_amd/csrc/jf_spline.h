@@ -31,9 +31,9 @@ template <> struct SM<float> {
     static __device__ __forceinline__ float softplus(float x) { return fmaxf(x, 0.f) + M<float>::log_fast(1.0f + M<float>::exp_fast(-fabsf(x))); }
 };
 
-constexpr int JF_SPLINE_MAX_BINS = 16;                            // 'g' with the rq_splines stretch and the potentials of 'v': tables at a fixed stride
+constexpr int JF_SPLINE_MAX_BINS = 16;                            // the potentials of 'v' (10 bins): tables at a fixed stride
 constexpr int JF_SPLINE_TAB = 3 * (JF_SPLINE_MAX_BINS + 1) + 2;   // 53 (odd)
-constexpr int JF_SPLINE_CAP = 64;                                 // 'r', 'o' and the splines nested in 'f': a lane's table has the chain's own bin count
+constexpr int JF_SPLINE_CAP = 64;                                 // 'r', 'o', the splines nested in 'f' and 'g' with the rq_splines stretch: a lane's table has the chain's own bin count
                                                                   // (spline_tab_words) and the launch sizes its row tile to the LDS that takes
 
 // public option block shared by 'r', 'o' and the Euclidean rq_splines stretch (mirrors jf_spline_opts of the C header)

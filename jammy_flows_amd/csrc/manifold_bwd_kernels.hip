@@ -18,6 +18,7 @@
 #include "jf_expmap.h"
 #include "jf_manifold.h"
 #include "jf_manifold_rev.h"
+#include "jf_spline_adj.h"
 
 namespace jf {
 
@@ -419,6 +420,122 @@ __device__ inline void v_closed_adjoint(const MBwdArgs<T, jf_v_layer>& a, const 
     }
 }
 
+// ... and the spline potentials (round 6): the component's f / f' are a monotone rational-quadratic spline of mu . x and its derivative
+// (v_component, jf_expmap.h), so S_k = w (f A + f' Q) reaches the component's 31 spline parameters through the six knot values of one bin:
+// the seven-tangent bin evaluation and the hand-written reverse of the knot table of jf_spline_adj.h (until round 5: one dual-number replay of
+// the component per parameter -- 31 per component, each with its own table build: v_s2_splines_cond 37 ms per 2^16 rows against 0.9 forward).
+// scr: the lane's scratch, >= 33 + 31 + 31 words (knot table, the component's raw spline parameters made contiguous, their gradients)
+template <typename T, int LV>
+__device__ inline void v_spline_adjoint(const MBwdArgs<T, jf_v_layer>& a, const T* __restrict__ ppv, int nc, T lse, const T (&e)[3], const T (&Gg)[3],
+                                        const T (&Gj)[3][3], T GP0, T (&Ge)[3], int g, int tid, bool active, int64_t row, int col0, bool& bad,
+                                        T* __restrict__ accp, T* __restrict__ scr) {
+    constexpr int NB = JF_V_SPLINE_BINS, NSP = 3 * NB + 1, n_prow = 4 + NSP;
+    using D7 = DualN<T, 7>;
+    SplineDev<T> o;
+    o.nb = NB; o.smooth = 0; o.fix_first = 0; o.fix_second = 0; o.independent = 0; o.fix_bd = 0; o.n_w = NB; o.n_h = NB; o.n_d = NB + 1;
+    o.fix_bd_value = T(0); o.min_w = T(1e-3); o.min_h = T(1e-3); o.min_d = T(1e-3); o.ratio = T(-1);
+    T* tab = scr;
+    T* ploc = scr + 3 * (NB + 1);
+    T* gloc = ploc + NSP;
+#pragma unroll 1
+    for (int k0 = 0; k0 < nc; k0 += LV) {
+        const int kk = k0 + g;
+        const int k = kk < nc ? kk : nc - 1;                       // (a lane without a component in this trip repeats the last one; its results are dropped)
+        const VCompVals<T> v = v_component_vals<T, JF_V_LINEAR>(ppv, nc, k, lse, e);      // weight, d w / d |m|, 1 / |m|  (f of the linear kind: unused)
+        const T mu[3] = {ppv[k] * v.inv_nrm, ppv[nc + k] * v.inv_nrm, ppv[2 * nc + k] * v.inv_nrm};
+        const T xmu = e[0] * mu[0] + e[1] * mu[1] + e[2] * mu[2];
+        for (int j = 0; j < NSP; ++j) { ploc[j] = ppv[(4 + j) * nc + k]; gloc[j] = T(0); }
+        spline_interval_build<T>(ploc, o, tab, T(-1), T(1));
+        const KnotTab<T> t(tab, NB);
+        const int b = spline_adj_bin<T>(t.cw, t.ch, NB, xmu, false);
+        D7 in[7] = {D7(xmu), D7(t.cw[b]), D7(t.cw[b + 1]), D7(t.ch[b]), D7(t.ch[b + 1]), D7(t.d[b]), D7(t.d[b + 1])};
+#pragma unroll
+        for (int c = 0; c < 7; ++c) in[c].d[c] = T(1);
+        const SplineOut<D7> r = spline_core_vals<D7>(in[1], in[2], in[3], in[4], in[5], in[6], b, in[0], false);
+        const T f = r.y.v, fp = M<T>::exp(r.lad.v);
+        // S_k = w (f A + fp Q),  A = Gg . mu,  Q = mu^T Gj mu;  h = (Gj + Gj^T) mu = dQ / d mu
+        T h[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) h[i] = (Gj[i][0] + Gj[0][i]) * mu[0] + (Gj[i][1] + Gj[1][i]) * mu[1] + (Gj[i][2] + Gj[2][i]) * mu[2];
+        const T A = Gg[0] * mu[0] + Gg[1] * mu[1] + Gg[2] * mu[2];
+        const T Q = T(0.5) * (h[0] * mu[0] + h[1] * mu[1] + h[2] * mu[2]);
+        const T w = v.w;
+        const T dS_dw = f * A + fp * Q;
+        const T gy = w * A, glad = w * Q * fp;                     // d fp = fp d lad
+        const T gxmu = gy * r.y.d[0] + glad * r.lad.d[0];
+        T gk[6];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) gk[c] = gy * r.y.d[c + 1] + glad * r.lad.d[c + 1];
+        (void)spline_adj_table_reverse<T>(ploc, gloc, o, tab, b, gk, T(-1), T(1), false, T(1));
+        T dmu[3], gm[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) dmu[i] = w * (f * Gg[i] + fp * h[i]) + gxmu * e[i];
+        if (kk < nc) { Ge[0] += gxmu * mu[0]; Ge[1] += gxmu * mu[1]; Ge[2] += gxmu * mu[2]; }
+        const T radial = dmu[0] * mu[0] + dmu[1] * mu[1] + dmu[2] * mu[2];
+        const T dS_dnrm = dS_dw * v.dwdn;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) gm[i] = (dmu[i] - mu[i] * radial) * v.inv_nrm + dS_dnrm * mu[i];
+        const T glw = dS_dw * w - M<T>::exp(ppv[3 * nc + k] - lse) * GP0;      // softmax coupling of the log-weights
+        if (k0 >= nc) break;                                       // (uniform)
+#pragma unroll 1
+        for (int q = 0; q < n_prow; ++q) {
+            T val = q < 3 ? gm[q] : (q == 3 ? glw : gloc[q - 4]);
+            if (!(active && kk < nc)) val = T(0);
+            bad = bad || !M<T>::finite(val);
+            const int col = col0 + q * nc + k;
+            if (a.bcast) {
+                const T sum = rows_sum<T, LV>(val);
+                if (tid < LV && kk < nc) accp[col] += sum;
+            } else if (active && kk < nc) {
+                a.g_params[row * a.gps + col] = val;
+            }
+        }
+    }
+}
+
+// the potential's share of d S / d e for given (Gg, Gj), no parameter gradients: what the implicit-function adjoint of natural_direction = 1
+// (below) applies three times per row before it knows the multiplier of the solve.  Every potential kind; scr as in v_spline_adjoint.
+template <typename T>
+__device__ inline void v_pot_x_adjoint(const T* __restrict__ ppv, int nc, int kind, T lse, const T (&e)[3], const T (&Gg)[3], const T (&Gj)[3][3], T (&Ge)[3],
+                                       T* __restrict__ scr) {
+    for (int k = 0; k < nc; ++k) {
+        T gx[3] = {T(0), T(0), T(0)}, gm[3], glw, glb;
+        if (kind == JF_V_EXPONENTIAL) {
+            v_component_adjoint<T, JF_V_EXPONENTIAL>(ppv, nc, k, v_component_vals<T, JF_V_EXPONENTIAL>(ppv, nc, k, lse, e), e, Gg, Gj, gx, gm, glw, glb);
+        } else if (kind == JF_V_LINEAR) {
+            v_component_adjoint<T, JF_V_LINEAR>(ppv, nc, k, v_component_vals<T, JF_V_LINEAR>(ppv, nc, k, lse, e), e, Gg, Gj, gx, gm, glw, glb);
+        } else if (kind == JF_V_QUADRATIC) {
+            v_component_adjoint<T, JF_V_QUADRATIC>(ppv, nc, k, v_component_vals<T, JF_V_QUADRATIC>(ppv, nc, k, lse, e), e, Gg, Gj, gx, gm, glw, glb);
+        } else {                                                   // splines: S_k = w (f A + f' Q) through the spline's input mu . e only
+            constexpr int NB = JF_V_SPLINE_BINS, NSP = 3 * NB + 1;
+            using D1 = Dual<T>;
+            SplineDev<T> o;
+            o.nb = NB; o.smooth = 0; o.fix_first = 0; o.fix_second = 0; o.independent = 0; o.fix_bd = 0; o.n_w = NB; o.n_h = NB; o.n_d = NB + 1;
+            o.fix_bd_value = T(0); o.min_w = T(1e-3); o.min_h = T(1e-3); o.min_d = T(1e-3); o.ratio = T(-1);
+            T* tab = scr;
+            T* ploc = scr + 3 * (NB + 1);
+            const VCompVals<T> v = v_component_vals<T, JF_V_LINEAR>(ppv, nc, k, lse, e);
+            const T mu[3] = {ppv[k] * v.inv_nrm, ppv[nc + k] * v.inv_nrm, ppv[2 * nc + k] * v.inv_nrm};
+            const T xmu = e[0] * mu[0] + e[1] * mu[1] + e[2] * mu[2];
+            for (int j = 0; j < NSP; ++j) ploc[j] = ppv[(4 + j) * nc + k];
+            spline_interval_build<T>(ploc, o, tab, T(-1), T(1));
+            const KnotTab<T> t(tab, NB);
+            const int b = spline_adj_bin<T>(t.cw, t.ch, NB, xmu, false);
+            const SplineOut<D1> r = spline_core_vals<D1>(D1(t.cw[b]), D1(t.cw[b + 1]), D1(t.ch[b]), D1(t.ch[b + 1]), D1(t.d[b]), D1(t.d[b + 1]), b, D1(xmu, T(1)), false);
+            const T fp = M<T>::exp(r.lad.v);
+            T h[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) h[i] = (Gj[i][0] + Gj[0][i]) * mu[0] + (Gj[i][1] + Gj[1][i]) * mu[1] + (Gj[i][2] + Gj[2][i]) * mu[2];
+            const T A = Gg[0] * mu[0] + Gg[1] * mu[1] + Gg[2] * mu[2];
+            const T Q = T(0.5) * (h[0] * mu[0] + h[1] * mu[1] + h[2] * mu[2]);
+            const T gxmu = v.w * (A * r.y.d + Q * fp * r.lad.d);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) gx[i] = gxmu * mu[i];
+        }
+        Ge[0] += gx[0]; Ge[1] += gx[1]; Ge[2] += gx[2];
+    }
+}
+
 template <typename T, int LV, int WPE, bool DUALGEO>
 __global__ void __launch_bounds__(64, WPE) vchain_bwd_kernel(const MBwdArgs<T, jf_v_layer> a) {
     using Du = Dual<T>;
@@ -494,9 +611,15 @@ __global__ void __launch_bounds__(64, WPE) vchain_bwd_kernel(const MBwdArgs<T, j
             ExpMapOut<T> o;
             T lse;
             VFam::template inv_pre<T>(L, pv, x, ld, e);
-            v_potential_lanes<T, LV>(pv + rot_len(L.hh_iter, 3), L.num_components, L.exp_map_type, e, P, lse, reinterpret_cast<T*>(tab), oob, g);
-            v_exp_geometry<T>(L.exp_map_type, e, P, o);
-            VFam::template inv_post<T>(L, o.y, x, ld);
+            if (L.natural_direction) {                             // the layer is the INVERSE of the exponential map: its output solves exp map(r) = e
+                T rr[3];
+                v_newton<T>(pv + rot_len(L.hh_iter, 3), L.num_components, L.exp_map_type, e, L.max_newton_iter, false, active, rr, reinterpret_cast<T*>(tab), oob);
+                VFam::template inv_post<T>(L, rr, x, ld);
+            } else {
+                v_potential_lanes<T, LV>(pv + rot_len(L.hh_iter, 3), L.num_components, L.exp_map_type, e, P, lse, reinterpret_cast<T*>(tab), oob, g);
+                v_exp_geometry<T>(L.exp_map_type, e, P, o);
+                VFam::template inv_post<T>(L, o.y, x, ld);
+            }
         }
     }
     __syncthreads();
@@ -522,8 +645,117 @@ __global__ void __launch_bounds__(64, WPE) vchain_bwd_kernel(const MBwdArgs<T, j
             T ld = T(0);
             VFam::template inv_pre<T>(L, pv, x, ld, e0);
         }
-        const bool closed = kind != JF_V_SPLINES && !a.v_dual;
-        if (closed) {
+        // natural_direction = 1 (the log-prob direction SOLVES exp map(r; p) = e, exponential_map_s2.py:459-489): the solution's dependence on e and
+        // on the parameters by the implicit-function theorem, from the same hand-written adjoints evaluated AT the solution r.  With
+        // A(yb, gl) = the pull-back of (d S / d y, d S / d logdet_half) through geometry + potential to (r, parameters):
+        //     the layer's output is r and its log-det term is -logdet_half(r, p), so with rb = d S / d r from the steps behind the layer,
+        //     w = rb - gld grad_r logdet_half,   J^T lambda = w  (J = d exp map / d r between the tangent planes at r and at e),
+        //     d S / d e = lambda,   d S / d p = A(-lambda, -gld).p
+        // J^T is assembled from two pull-backs of tangent vectors at e, grad_r logdet_half is a third; a 2 x 2 solve; the fourth pull-back
+        // carries the parameters.  (Until round 6 these chains went to the generic kernel, which replays the Newton iteration on dual numbers
+        // once per direction: v_s2_nat1_rot 11.6 ms per 2^16 rows against 0.17 forward.)
+        if (L.natural_direction) {
+            if constexpr (!DUALGEO) {
+            T* scrT = reinterpret_cast<T*>(tab);
+            T r[3];
+            v_newton<T>(ppv, nc, kind, e0, L.max_newton_iter, false, active, r, scrT, oob);
+            VPotential<T> Pr;
+            T lser;
+            v_potential_lanes<T, LV>(ppv, nc, kind, r, Pr, lser, scrT, oob, g);
+            VGeoTape<T> tape;
+            T y[3], ldh;
+            v_geo_forward<T>(kind, r, Pr, tape, y, ldh);
+            // d S / d r from what follows the layer (post: embedding -> angles, chart)
+            using D3 = DualN<T, 3>;
+            D3 rd[3] = {D3(r[0]), D3(r[1]), D3(r[2])}, xd[3], ldd(T(0));
+            rd[0].d[0] = T(1); rd[1].d[1] = T(1); rd[2].d[2] = T(1);
+            VFam::template inv_post<D3>(L, rd, xd, ldd);
+            if (l == 0) { up[0] = gxo[0] - xd[0].v * gblp; up[1] = gxo[1] - xd[1].v * gblp; }
+            T rb[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) rb[c] = up[0] * xd[0].d[c] + up[1] * xd[1].d[c] + gld * ldd.d[c];
+            auto pull = [&](const T (&yb)[3], T gl, T (&out)[3], T (&Gg)[3], T (&Gj)[3][3]) {       // A(yb, gl).r; (Gg, Gj) for the parameter part
+                T Ge0[3];
+                v_geo_reverse<T>(kind, r, Pr, tape, yb, gl, Ge0, Gg, Gj);
+                out[0] = Ge0[0]; out[1] = Ge0[1]; out[2] = Ge0[2];
+                v_pot_x_adjoint<T>(ppv, nc, kind, lser, r, Gg, Gj, out, scrT);
+            };
+            // orthonormal tangent bases: (s1, s2) at r, (t1, t2) at the image y = e
+            auto basis = [](const T (&n)[3], T (&b1)[3], T (&b2)[3]) {
+                const int m = (M<T>::abs(n[0]) <= M<T>::abs(n[1]) && M<T>::abs(n[0]) <= M<T>::abs(n[2])) ? 0 : (M<T>::abs(n[1]) <= M<T>::abs(n[2]) ? 1 : 2);
+                T a[3] = {T(0), T(0), T(0)};
+                a[m] = T(1);
+                const T dot = n[m];
+                T nn = T(0);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) { b1[i] = a[i] - dot * n[i]; nn += b1[i] * b1[i]; }
+                const T inv = T(1) / M<T>::sqrt(nn);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) b1[i] *= inv;
+                b2[0] = n[1] * b1[2] - n[2] * b1[1]; b2[1] = n[2] * b1[0] - n[0] * b1[2]; b2[2] = n[0] * b1[1] - n[1] * b1[0];
+            };
+            T s1[3], s2[3], t1[3], t2[3];
+            basis(r, s1, s2);
+            basis(y, t1, t2);
+            T Gg[3], Gj[3][3], c1[3], c2[3], a0[3];
+            const T zero3[3] = {T(0), T(0), T(0)};
+            pull(zero3, T(1), a0, Gg, Gj);
+            pull(t1, T(0), c1, Gg, Gj);
+            pull(t2, T(0), c2, Gg, Gj);
+            auto dot3 = [](const T (&u)[3], const T (&v)[3]) { return u[0] * v[0] + u[1] * v[1] + u[2] * v[2]; };
+            T w[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) w[c] = rb[c] - gld * a0[c];
+            const T m11 = dot3(s1, c1), m12 = dot3(s1, c2), m21 = dot3(s2, c1), m22 = dot3(s2, c2);
+            const T w1 = dot3(s1, w), w2 = dot3(s2, w);
+            const T det = m11 * m22 - m12 * m21;
+            const T l1 = (w1 * m22 - m12 * w2) / det, l2 = (m11 * w2 - m21 * w1) / det;
+            T lam[3], mlam[3], dummy[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { lam[c] = l1 * t1[c] + l2 * t2[c]; mlam[c] = -lam[c]; }
+            // the parameters: A(-lambda, -gld)
+            pull(mlam, -gld, dummy, Gg, Gj);
+            T GP0 = T(0);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                GP0 += Gg[c] * Pr.g[c];
+#pragma unroll
+                for (int d = 0; d < 3; ++d) GP0 += Gj[c][d] * Pr.gj[c][d];
+            }
+            T Gex[3] = {T(0), T(0), T(0)};
+            const int colp = a.col0[l] + n_rot;
+            if (kind == JF_V_SPLINES) v_spline_adjoint<T, LV>(a, ppv, nc, lser, r, Gg, Gj, GP0, Gex, g, tid, active, row, colp, bad, accp, scrT);
+            else if (kind == JF_V_EXPONENTIAL) v_closed_adjoint<T, LV, JF_V_EXPONENTIAL>(a, ppv, nc, lser, r, Gg, Gj, GP0, Gex, g, tid, active, row, colp, bad, accp);
+            else if (kind == JF_V_LINEAR) v_closed_adjoint<T, LV, JF_V_LINEAR>(a, ppv, nc, lser, r, Gg, Gj, GP0, Gex, g, tid, active, row, colp, bad, accp);
+            else v_closed_adjoint<T, LV, JF_V_QUADRATIC>(a, ppv, nc, lser, r, Gg, Gj, GP0, Gex, g, tid, active, row, colp, bad, accp);
+            // the layer's input and rotation parameters: pre on dual numbers, contracted with d S / d e = lambda
+            T nup[2] = {T(0), T(0)};
+            const int n_dir = 2 + n_rot;
+#pragma unroll 1
+            for (int j = 0; j < n_dir; ++j) {
+                if (j >= 2 && lane_in) rot[j - 2].d = T(1);
+                Du x[3] = {Du(xl[0], j == 0 ? T(1) : T(0)), Du(xl[1], j == 1 ? T(1) : T(0)), Du(T(0))};
+                Du ld(T(0)), e[3];
+                VFam::template inv_pre<Du>(L, p, x, ld, e);
+                T gj_ = gld * ld.d + lam[0] * e[0].d + lam[1] * e[1].d + lam[2] * e[2].d;
+                if (j >= 2 && lane_in) rot[j - 2].d = T(0);
+                if (!active) gj_ = T(0);
+                bad = bad || !M<T>::finite(gj_);
+                if (j < 2) nup[j] = gj_;
+                else if (a.bcast) {
+                    const T sum = rows_sum<T, LV>(gj_);
+                    if (tid < LV) accp[a.col0[l] + (j - 2)] += sum;
+                } else if (active) {
+                    a.g_params[row * a.gps + a.col0[l] + (j - 2)] = gj_;
+                }
+            }
+            up[0] = nup[0]; up[1] = nup[1];
+            }
+            continue;
+        }
+        const bool spl = kind == JF_V_SPLINES && !a.v_dual;             // spline potentials: v_spline_adjoint (seven-tangent bin evaluation + table reverse)
+        const bool closed = (kind != JF_V_SPLINES && !a.v_dual) || spl;
+        if (closed && !spl) {
             lse0 = v_lse_lanes<T, LV>(ppv, nc, g);
             if (kind == JF_V_EXPONENTIAL) v_closed_potential<T, LV, JF_V_EXPONENTIAL>(ppv, nc, lse0, e0, P0, g);
             else if (kind == JF_V_LINEAR) v_closed_potential<T, LV, JF_V_LINEAR>(ppv, nc, lse0, e0, P0, g);
@@ -600,7 +832,11 @@ __global__ void __launch_bounds__(64, WPE) vchain_bwd_kernel(const MBwdArgs<T, j
         }
         const int n_row = VFam_row_len_dev(L);
         // (2) the potential's parameters
-        if (closed) {
+        if (spl) {
+            v_spline_adjoint<T, LV>(a, ppv, nc, lse0, e0, Gg, Gj, GP0, Ge, g, tid, active, row, a.col0[l] + n_rot, bad, accp, reinterpret_cast<T*>(tab));
+#pragma unroll
+            for (int c = 0; c < 3; ++c) Ge[c] = Ge0[c] + group_sum<T, LV>(Ge[c]);
+        } else if (closed) {
             const int col = a.col0[l] + n_rot;
             if (kind == JF_V_EXPONENTIAL) v_closed_adjoint<T, LV, JF_V_EXPONENTIAL>(a, ppv, nc, lse0, e0, Gg, Gj, GP0, Ge, g, tid, active, row, col, bad, accp);
             else if (kind == JF_V_LINEAR) v_closed_adjoint<T, LV, JF_V_LINEAR>(a, ppv, nc, lse0, e0, Gg, Gj, GP0, Ge, g, tid, active, row, col, bad, accp);
@@ -716,9 +952,12 @@ static int mchain_bwd(const T* x, int64_t xs, const T* params, int64_t ps, int32
     constexpr int lv = 1;                                          // staged 'v' kernel: lanes per row (the kernel is written for 1, 4, 8; see its header)
     if constexpr (std::is_same<Fam, VFam>::value) {               // all layers in the default direction: the staged kernel
         staged = true;
-        for (int l = 0; l < n_layers; ++l) staged = staged && layers[l].natural_direction == 0 && rot_len(layers[l].hh_iter, 3) <= JF_V_ROT_MAX;
+        static const int v_dual = getenv("JF_V_BWD_DUAL") ? atoi(getenv("JF_V_BWD_DUAL")) : 0;
+        // natural_direction = 1: the implicit-function adjoint of the staged kernel; under JF_V_BWD_DUAL (the check) the generic kernel, which
+        // replays the Newton iteration on dual numbers
+        for (int l = 0; l < n_layers; ++l)
+            staged = staged && (layers[l].natural_direction == 0 || !v_dual) && rot_len(layers[l].hh_iter, 3) <= JF_V_ROT_MAX;
         if (staged) {
-            static const int v_dual = getenv("JF_V_BWD_DUAL") ? atoi(getenv("JF_V_BWD_DUAL")) : 0;
             a.v_dual = v_dual;
             a.scratch = (2 * n_layers + JF_V_G + 1) & ~1;          // per ROW (T units): layer inputs, G
             a.rot_max = 0;

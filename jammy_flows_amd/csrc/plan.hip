@@ -34,30 +34,16 @@ thread_local PlanSink* g_sink = nullptr;
 }
 PlanSink*& plan_sink() { return g_sink; }
 
-// the translation units' setters of the solver audit flag (jf_common.h): registered by static initialisers at load time
-NewtonRuleUnit*& newton_rule_units() {
-    static NewtonRuleUnit* head = nullptr;
-    return head;
-}
-namespace {
-int g_newton_rule_host = 0;
-}
-
 }  // namespace jf
 
 extern "C" {
-// 0: the product rules (default); 1: every iterative solver follows the reference's own iteration (25 bisections on [-1e5, 1e5], Newton until
-// 1e-14 / 20 steps, no float32 floor, 'v' until 1e-12: bisection_n_newton.py:11-135, 330-465).  Process-wide, synchronous (it waits for the device before and after).  Returns JF_OK, or JF_ERR_LAUNCH when a unit's flag could not be written (no device).
-int jf_set_newton_rule(int32_t reference) {
-    int rc = JF_OK;
-    if (hipDeviceSynchronize() != hipSuccess) return JF_ERR_LAUNCH;       // (no solver kernel in flight while the flags change)
-    for (jf::NewtonRuleUnit* u = jf::newton_rule_units(); u != nullptr; u = u->next)
-        if (u->set(reference ? 1 : 0) != JF_OK) rc = JF_ERR_LAUNCH;
-    if (hipDeviceSynchronize() != hipSuccess) rc = JF_ERR_LAUNCH;
-    if (rc == JF_OK) jf::g_newton_rule_host = reference ? 1 : 0;
-    return rc;
-}
-int jf_get_newton_rule(void) { return jf::g_newton_rule_host; }
+// which iteration rule the solvers of THIS library were built with: 0 = the product rules, 1 = the reference's own (libjammy_hip_audit.so,
+// -DJF_NEWTON_RULE_REFERENCE: 25 bisections on [-1e5, 1e5], Newton until 1e-14 / 20 steps, no float32 floor, 'v' until 1e-12)
+#ifdef JF_NEWTON_RULE_REFERENCE
+int jf_get_newton_rule(void) { return 1; }
+#else
+int jf_get_newton_rule(void) { return 0; }
+#endif
 }
 
 struct jf_plan : jf::PlanSink {

@@ -1260,6 +1260,7 @@ class pdf(nn.Module):
             return self._permanent_row_with_grad(layers, x)
         _hip.require_device(x)
         self._poll_status()
+        _hip.release_keepalive()                 # (tensors of the previous step that crossed streams: the streams have met since, _hip.KEEPALIVE)
         status = _hip.new_status(x.device) if self.check_status else None
         B = x.shape[0]
         log_det = log_det0
@@ -1298,11 +1299,11 @@ class pdf(nn.Module):
                 if si < n_blocks - 1:                     # the last (usually largest) block stays on the caller's stream
                     st = side[si % len(side)]
                     st.wait_stream(main_stream)           # inputs (targets, embeddings, the cat above) were produced on the caller's stream
-                    # ... and were allocated there: announce their use on the side stream (the allocator would otherwise hand a block freed on
-                    # the host to the caller's stream again while this block's kernels still read it)
-                    _hip.record_on(st, x, inp, amort, *embeds)
+                    # ... and were allocated there: they must outlive this block's kernels (_hip.KEEPALIVE: held until the next gradient-mode
+                    # forward call, by which time the caller's stream has waited for the side streams)
+                    _hip.keep_alive(x, inp, amort, *embeds)
                     if conditional_input is not None:
-                        _hip.record_on(st, *(conditional_input if type(conditional_input) == list else [conditional_input]))
+                        _hip.keep_alive(*(conditional_input if type(conditional_input) == list else [conditional_input]))
                     stream_ctx = torch.cuda.stream(st)
                     stream_ctx.__enter__()
             try:
@@ -1388,7 +1389,7 @@ class pdf(nn.Module):
                 if stream_ctx is not None:
                     stream_ctx.__exit__(None, None, None)
             if stream_ctx is not None:
-                _hip.record_on(main_stream, out, log_det, base_logp)      # side-stream allocations, summed / concatenated on the caller's stream
+                _hip.keep_alive(out, log_det, base_logp)                  # side-stream allocations, summed / concatenated on the caller's stream
             if side is not None:
                 ld_parts.append(log_det)
                 blp_parts.append(base_logp)

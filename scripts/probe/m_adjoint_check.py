@@ -86,8 +86,14 @@ if __name__ == "__main__":
                 break
             began = [l.split()[1] for l in r.stdout.splitlines() if l.startswith("BEGIN")]
             bad = began[-1] if began else todo[0]
-            crashed.append((dual, bad, r.stderr.strip().splitlines()[-1][:200] if r.stderr.strip() else ""))
-            print("CRASH dual=%s fixture=%s: %s" % crashed[-1], flush=True)
+            msg = r.stderr.strip().splitlines()[-1][:200] if r.stderr.strip() else ""
+            if dual == "1" and "unsupported configuration" in msg:
+                # the dual-number replay has caps of its own (a lane's knot table on dual numbers: 'g' with rq_splines beyond 16 bins does not
+                # fit a CU's LDS in float64); those fixtures are checked against the reference's autograd only (tests/test_gpu_grad.py)
+                print("SKIP (the dual replay cannot run it) fixture=%s: %s" % (bad, msg), flush=True)
+            else:
+                crashed.append((dual, bad, msg))
+                print("CRASH dual=%s fixture=%s: %s" % crashed[-1], flush=True)
             todo = todo[todo.index(bad) + 1:]
         res = {}
         for f in sorted(os.listdir(d)):

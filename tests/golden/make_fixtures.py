@@ -85,6 +85,10 @@ CASES = [
     dict(name="g_e3_rqs", pdf="e3", flow="gg", kwargs=dict(options_overwrite={"g": {"nonlinear_stretch_type": "rq_splines"}})),
     dict(name="g_e3_rqs_cond", pdf="e3", flow="gg", mlp_scale=1000.0,
          kwargs=dict(conditional_input_dim=2, options_overwrite={"g": {"nonlinear_stretch_type": "rq_splines"}})),
+    # more than 16 bins per dimension (round 6: the kernels' knot tables follow the chain's own bin count, cap 64)
+    dict(name="g_e3_rqs_bins32", pdf="e3", flow="gg", kwargs=dict(options_overwrite={"g": {"nonlinear_stretch_type": "rq_splines", "num_kde": 32}})),
+    dict(name="g_e2_rqs_bins24_cond", pdf="e2", flow="g", mlp_scale=1000.0,
+         kwargs=dict(conditional_input_dim=2, options_overwrite={"g": {"nonlinear_stretch_type": "rq_splines", "num_kde": 24}})),
     dict(name="g_e1e2e1_cond", pdf="e1+e2+e1", flow="gg+g+ggg", mlp_scale=1000.0,
          kwargs=dict(conditional_input_dim=2, amortization_mlp_dims="64-30")),
     dict(name="g_e1e2e1_cond_lowrank", pdf="e1+e2+e1", flow="gg+g+ggg", mlp_scale=30.0,

@@ -42,7 +42,7 @@ CASES = ["c1_e2_gg", "c2_e4_gggg", "c3_e4s2e4", "g_e1_g", "g_e3_ggg_cond", "g_e2
          # more than 8 Euclidean dimensions
          "g_e10_gg", "g_e10_ggggg", "g_e12_cond", "t_e10_full", "t_e10_diagonal", "t_e12_full_cond",
          # 'g' with nonlinear_stretch_type = "rq_splines" (gaussianization_flow.py:863-909)
-         "g_e3_rqs", "g_e3_rqs_cond",
+         "g_e3_rqs", "g_e3_rqs_cond", "g_e3_rqs_bins32", "g_e2_rqs_bins24_cond",
          # only_last=True (main/default.py:1018, 1490: only the last layer of every sub-pdf is applied), with gradients
          "c3_e4s2e4@only_last", "g_e3_ggg_cond@only_last", "c4_i1s1_ro@only_last",
          # every remaining forward fixture (all but mix_e2s1i1, see tests/test_gpu_grad.py): option products of 'f', 'v' in both directions and with

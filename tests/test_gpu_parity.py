@@ -149,44 +149,49 @@ def test_sampling_float64_vs_reference(fx):
         assert NEWTON_BAND[0] * rec["row_steps_total"] <= got <= NEWTON_BAND[1] * rec["row_steps_total"]
 
 
-def test_reference_newton_rule_reproduces_the_reference_iteration():
-    """the audit switch (jf_set_newton_rule / JF_NEWTON_RULE=reference, include/jammy_hip.h): with it the solvers follow the reference's own
-    iteration -- 25 bisections on [-1e5, 1e5], Newton until 1e-14 / 20 steps, 'v' until 1e-12 (bisection_n_newton.py:11-135, 330-465).  On every
-    sampling fixture, float64: (a) the samples of the two rules agree to 1e-10 of their size (1e-12 and better on all but the skewed-logistic
-    fixtures, whose closed forms leave cdf + sf = 1 + O(2e-9), jf_gf_ext.h: printed) and the log-probs to 1e-9 (the log-density's slope
-    reaches 1e5 between narrow components: 1e-15 in x is 1e-10 in log p); 5e-9 where the sphere Newton of 'v' is in the chain (its two end
-    rules both sit below the reference's own 1e-6 agreement) -- i.e. the product rule loses nothing; (b) under the reference
-    rule the kernel's Newton row-steps equal what the reference's masked iteration spent on the same rows (tests/golden/newton_records.json)
-    within 10 % on most fixtures (band 0.75 ... 1.10: see the end of the test)."""
+def test_reference_newton_rule_reproduces_the_reference_iteration(tmp_path):
+    """the audit library (libjammy_hip_audit.so: csrc built with -DJF_NEWTON_RULE_REFERENCE, loaded when JF_NEWTON_RULE=reference is set;
+    include/jammy_hip.h jf_get_newton_rule): its solvers follow the reference's own iteration -- 25 bisections on [-1e5, 1e5], Newton until 1e-14 /
+    20 steps, 'v' until 1e-12 (bisection_n_newton.py:11-135, 330-465).  On every sampling fixture, float64 (the audit library runs in a child
+    process, scripts/probe/newton_rule_dump.py): (a) the samples of the two rules agree to 1e-10 of their size (1e-12 and better on all but the
+    skewed-logistic fixtures, whose closed forms leave cdf + sf = 1 + O(2e-9), jf_gf_ext.h: printed) and the log-probs to 1e-9 (the
+    log-density's slope reaches 1e5 between narrow components: 1e-15 in x is 1e-10 in log p); 5e-9 where the sphere Newton of 'v' is in the chain
+    (its two end rules both sit below the reference's own 1e-6 agreement) -- i.e. the product rule loses nothing; (b) under the reference rule
+    the kernel's Newton row-steps equal what the reference's masked iteration spent on the same rows (tests/golden/newton_records.json) within
+    10 % on most fixtures (band 0.75 ... 1.10: see the end of the test)."""
+    import subprocess
+    import sys
     from jammy_flows_amd import _hip
     assert _hip.get_newton_rule() == "product"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    dump = str(tmp_path / "audit.npz")
+    env = dict(os.environ, JF_NEWTON_RULE="reference")
+    env.pop("JF_LIB_PATH", None)
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "probe", "newton_rule_dump.py"), dump], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    ref = np.load(dump)
+    assert str(ref["rule"]) == "reference"
     worst, checked = 0.0, 0
     ratios, per_fx = {}, {}
-    try:
-        for fx in SUPPORTED:
-            out = {}
-            for rule in ("product", "reference"):
-                _hip.set_newton_rule(rule)
-                pdf = build_product(fx, torch.float64)
-                z = to_dev(fx["z"], torch.float64)
-                cond = to_dev(fx.get("cond"), torch.float64)
-                x, _, logp, _ = pdf._obtain_sample(conditional_input=cond, predefined_target_input=z, force_embedding_coordinates=fx.meta["embedding"])
-                out[rule] = (x.cpu().numpy(), logp.cpu().numpy(), dict(pdf.last_status_words))
-            fin = np.isfinite(out["reference"][1])
-            ex = float((np.abs(out["product"][0] - out["reference"][0]) / (1.0 + np.abs(out["reference"][0])))[fin].max())
-            el = float((np.abs(out["product"][1] - out["reference"][1]) / (1.0 + np.abs(out["reference"][1])))[fin].max())
-            tol = 5e-9 if "v" in fx.flow_defs else 1e-10
-            assert ex < tol and el < max(tol, 1e-9), (fx.name, ex, el)
-            worst = max(worst, ex if "v" not in fx.flow_defs else 0.0)
-            per_fx[fx.name] = ex
-            rec = NEWTON_RECORDS.get(fx.name)
-            if rec is not None:
-                got = out["reference"][2]["newton_row_steps"]
-                ratios[fx.name] = got / rec["row_steps_total"]
-                assert out["product"][2]["newton_row_steps"] < got
-                checked += 1
-    finally:
-        _hip.set_newton_rule("product")
+    for fx in SUPPORTED:
+        pdf = build_product(fx, torch.float64)
+        z = to_dev(fx["z"], torch.float64)
+        cond = to_dev(fx.get("cond"), torch.float64)
+        x, _, logp, _ = pdf._obtain_sample(conditional_input=cond, predefined_target_input=z, force_embedding_coordinates=fx.meta["embedding"])
+        px, pl, psteps = x.cpu().numpy(), logp.cpu().numpy(), pdf.last_status_words["newton_row_steps"]
+        rx, rl, rsteps = ref[fx.name + "/x"], ref[fx.name + "/logp"], int(ref[fx.name + "/steps"])
+        fin = np.isfinite(rl)
+        ex = float((np.abs(px - rx) / (1.0 + np.abs(rx)))[fin].max())
+        el = float((np.abs(pl - rl) / (1.0 + np.abs(rl)))[fin].max())
+        tol = 5e-9 if "v" in fx.flow_defs else 1e-10
+        assert ex < tol and el < max(tol, 1e-9), (fx.name, ex, el)
+        worst = max(worst, ex if "v" not in fx.flow_defs else 0.0)
+        per_fx[fx.name] = ex
+        rec = NEWTON_RECORDS.get(fx.name)
+        if rec is not None:
+            ratios[fx.name] = rsteps / rec["row_steps_total"]
+            assert psteps < rsteps
+            checked += 1
     print("reference vs product Newton rule: worst |dx| / (1 + |x|) = %.2e over %d fixtures; row-steps / the reference's: %s"
           % (worst, len(SUPPORTED), " ".join("%s %.3f" % kv for kv in sorted(ratios.items()))))
     print("fixtures above 1e-12: %s" % {k: "%.1e" % v for k, v in per_fx.items() if v > 1e-12})
