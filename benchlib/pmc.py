@@ -91,7 +91,8 @@ def valu_issue_roofline(workload, dtype, rows, table):
            "issue_cycles_per_wave_instruction": prof.get("issue_cycles"), "kernel_source_hash_match": prof.get("kernel_source_hash") == kernel_source_hash()}
     tot_c, tot_s, peak_w = 0.0, 0.0, 0.0
     for (name, tag), v in table.items():
-        k = prof["kernels"].get("%s[%s]" % (name, tag)) or prof["kernels"].get(name)
+        base = name.replace("_inv_total_", "_inv_").replace("_inv_sum_", "_inv_")       # the last block's entry points (..._inv_total / _inv_sum): the same device kernels
+        k = prof["kernels"].get("%s[%s]" % (name, tag)) or prof["kernels"].get(name) or prof["kernels"].get("%s[%s]" % (base, tag)) or prof["kernels"].get(base)
         if not k:
             continue
         cyc = k["valu_issue_cycles_per_row"] * rows

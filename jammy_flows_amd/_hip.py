@@ -1388,11 +1388,18 @@ def linear_split(x, weight, bias=None):
 
 
 MLP2_SMALL_MAX_IN, MLP2_SMALL_MAX_OUT = 32, 16
+MLP2_SMALL_WIDE_IN, MLP2_SMALL_WIDE_OUT = 8, {4: 64, 8: 48}           # with <= 8 inputs: <= 64 outputs (float64: 48), csrc/wgrad_kernels.hip
+
+
+def mlp2_small_shape_ok(k1, h, n, itemsize):
+    """the shapes jf_mlp2_small_bwd takes (csrc/wgrad_kernels.hip: MS_K1MAX, MS_NMAX, MS_K1WIDE, MS_NWIDE / MS_NWIDE64)"""
+    n_max = MLP2_SMALL_WIDE_OUT.get(itemsize, MLP2_SMALL_MAX_OUT) if k1 <= MLP2_SMALL_WIDE_IN else MLP2_SMALL_MAX_OUT
+    return 1 <= k1 <= MLP2_SMALL_MAX_IN and 1 <= h <= MLP2_MAX_HIDDEN and 1 <= n <= n_max
 
 
 def mlp2_small_bwd(x, w1, b1, w2, g):
-    """gradients (g_w1, g_b1, g_w2, g_b2) of out = tanh(x w1^T + b1) w2^T + b2 for upstream g (B, N), narrow heads only (K1 <= 32, N <= 16,
-    H <= 128): one launch that recomputes the hidden activations (jf_mlp2_small_bwd); no input gradient."""
+    """gradients (g_w1, g_b1, g_w2, g_b2) of out = tanh(x w1^T + b1) w2^T + b2 for upstream g (B, N), narrow heads only (K1 <= 32, N <= 16 --
+    or K1 <= 8, N <= 64 (float64: 48) -- H <= 128): one launch that recomputes the hidden activations (jf_mlp2_small_bwd); no input gradient."""
     dev = require_device(x, w1, b1, w2, g)
     x, w1, w2, g = _rowmajor(x), _rowmajor(w1), _rowmajor(w2), _rowmajor(g)
     B, K1 = x.shape

@@ -105,7 +105,7 @@ def activation(z, code):
 
 
 class Mlp2SmallFn(torch.autograd.Function):
-    """narrow Linear - tanh - Linear head (<= 32 inputs, <= 16 outputs) whose input rows need no gradient: forward = the fused jf_mlp2 launch,
+    """narrow Linear - tanh - Linear head (<= 32 inputs, <= 16 outputs; <= 8 inputs, <= 64 outputs) whose input rows need no gradient: forward = the fused jf_mlp2 launch,
     backward = ONE launch (jf_mlp2_small_bwd) instead of tanh', two weight gradients, two bias sums and g W2 of the per-layer path."""
 
     @staticmethod
@@ -122,8 +122,8 @@ class Mlp2SmallFn(torch.autograd.Function):
 
 
 def mlp2_small_ok(x, lin1, lin2):
-    return (not x.requires_grad and lin1.in_features <= _hip.MLP2_SMALL_MAX_IN and lin1.out_features <= _hip.MLP2_MAX_HIDDEN
-            and lin1.out_features % 4 == 0 and lin2.out_features <= _hip.MLP2_SMALL_MAX_OUT and lin1.bias is not None and lin2.bias is not None)
+    return (not x.requires_grad and _hip.mlp2_small_shape_ok(lin1.in_features, lin1.out_features, lin2.out_features, x.element_size())
+            and lin1.out_features % 4 == 0 and lin1.bias is not None and lin2.bias is not None)
 
 
 class GfChainInvFn(torch.autograd.Function):

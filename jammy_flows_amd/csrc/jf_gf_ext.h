@@ -221,22 +221,35 @@ template <typename T, typename PA> __device__ inline MixQ<T> gx_mixture(const Gf
     return gx_mixq<T>(o, lc.value(), ls.value(), lp.value());
 }
 
-// bisection + Newton of the sampling direction (layers/bisection_n_newton.py:11-135; 25 / 20 iterations on [-1e5, 1e5], :921) for one row:
-// z holds the targets, x receives the solution; the Newton stopping rule sums |update| over the row's coordinates
+// approach + Newton of the sampling direction (layers/bisection_n_newton.py:11-135; 25 / 20 iterations on [-1e5, 1e5], :921) for one row:
+// z holds the targets, x receives the solution; the Newton stopping rule sums |update| over the row's coordinates.  The approach phase is
+// gf_approach (jf_gf.h) on this mixture's log cdf / log sf / log pdf from the mixture's mean -- 4-6 evaluations where the reference's 25
+// bisections (restated here through round 5, and still what the audit library runs) made 25: the general-option fixtures sampled at 15-22 x
+// their forward pass (profiles/r06_scan_fixtures.md), this phase being 25 of ~31 evaluations.
 template <typename T, typename PA> __device__ inline void gx_solve(const GfLayerDev<T>& o, PA p, int D, XCol<T> z, XCol<T> x, bool row_valid,
                                                                    int32_t* status) {
     for (int d = 0; d < D; ++d) {
         const GxCoord<T> c = gx_prepare<T, PA>(o, p, D, d);
         const T zd = z[d];
-        T lo = T(-1e5), hi = T(1e5), xm = T(0);
-        for (int it = 0; it < 25; ++it) {
-            xm = (hi + lo) * T(0.5);
-            const T y = gf_icdf<T>(o.inv_type, gx_mixture<T, PA>(o, p, D, d, c, xm)).y;
-            if (M<T>::abs(y - zd) <= T(1e-6) * M<T>::abs(zd)) { lo = xm; hi = xm; }
-            else if (y < zd) lo = xm;
-            else hi = xm;
+        if (newton_reference_rule()) {
+            T lo = T(-1e5), hi = T(1e5), xm = T(0);
+            for (int it = 0; it < 25; ++it) {
+                xm = (hi + lo) * T(0.5);
+                const T y = gf_icdf<T>(o.inv_type, gx_mixture<T, PA>(o, p, D, d, c, xm)).y;
+                if (M<T>::abs(y - zd) <= T(1e-6) * M<T>::abs(zd)) { lo = xm; hi = xm; }
+                else if (y < zd) lo = xm;
+                else hi = xm;
+            }
+            x[d] = xm;
+        } else {
+            T x0 = T(0);
+            for (int k = 0; k < o.K; ++k) {
+                const T mu = (o.center_mean && k == o.K - 1) ? c.last_mean : T(p[o.off_mean + k * D + d]);
+                x0 += M<T>::exp(gx_log_weight<T, PA>(o, p, D, k, d) - c.lse_w) * mu;
+            }
+            if (!M<T>::finite(x0)) x0 = T(0);
+            x[d] = gf_approach<T>([&](T xx) { return gx_mixture<T, PA>(o, p, D, d, c, xx); }, o.inv_type != JF_GF_ISIGMOID, zd, x0, row_valid);
         }
-        x[d] = xm;
     }
     T ferr = T(0);
     bool nonfinite = false;

@@ -172,15 +172,15 @@ template <typename T> static bool wgrad_skinny(const T* g, int64_t gs, const T* 
 }
 
 // ---------------------------------------------------------------------------------------------------------- narrow heads, whole backward
-// Backward of a Linear - tanh - Linear head with few inputs and few outputs (K1 <= 32, N <= 16, H hidden units: the 4 -> 128 -> 10 MLP that
-// parametrises an 'f' layer) in ONE launch: what autograd runs as tanh', two weight gradients, two bias sums and grad_output @ W2.
+// Backward of a Linear - tanh - Linear head with few inputs and few outputs (K1 <= 32, N <= 16, or K1 <= 8, N <= 64; H hidden units: the
+// 4 -> 128 -> 10 MLP that parametrises an 'f' layer, 4 -> 128 -> 46 with the spline options of c3b) in ONE launch: what autograd runs as tanh', two weight gradients, two bias sums and grad_output @ W2.
 // thread = hidden unit j.  Everything a hidden unit needs is its own: W1[j][:], W2[:][j] in registers; the input row and the upstream row are
 // wave-uniform (scalar loads).  Per row: h_j = tanh(W1[j] . x + b1[j]) recomputed (the forward kept nothing), g_j = (g_out . W2[:, j])(1 - h_j^2),
 // and the accumulators  g_W1[j][k] += g_j x[k],  g_b1[j] += g_j,  g_W2[n][j] += g_out[n] h_j  -- no communication between threads at all.
 // A workgroup walks its row range and writes one partial slab [H][K1 + 1 + N] (+ [N] for g_b2), summed by the caller.  No gradient with respect
 // to the input rows (they are data; the caller takes the layer-by-layer path when they require grad).
-constexpr int MS_K1MAX = 32, MS_NMAX = 16;
-// KB / NB: compile-time bounds of the input / output loops (the sizes rounded up to 4, 8, 16, 32 / 4, 8, 12, 16).  Slots beyond the real sizes carry
+constexpr int MS_K1MAX = 32, MS_NMAX = 16, MS_NWIDE = 64, MS_NWIDE64 = 48, MS_K1WIDE = 8;      // N <= 16, or N <= 64 (float64: 48, the register file) with K1 <= 8
+// KB / NB: compile-time bounds of the input / output loops (the sizes rounded up to 1, 2, 4, 8, 16, 32 / 4, 8, 12, 16, 32, 48, 64).  Slots beyond the real sizes carry
 // zero weights and read a clamped (duplicate) element, so the row loop has no size-dependent branch and its scalar loads batch up.
 template <typename T, int KB, int NB>
 __global__ void __launch_bounds__(128) mlp2_small_bwd_kernel(const T* __restrict__ x, int64_t xs, const T* __restrict__ W1, int64_t w1s, const T* __restrict__ b1,
@@ -224,7 +224,8 @@ __global__ void __launch_bounds__(128) mlp2_small_bwd_kernel(const T* __restrict
 #pragma unroll
         for (int k = 0; k < KB; ++k) a1[k] += gh * xv[k];
     };
-#pragma unroll 4
+    constexpr int RU = NB > 16 ? 1 : 4;                            // rows in flight: their NB upstream values sit in scalar registers (~100)
+#pragma unroll RU
     for (int64_t r = r0; r < rm; ++r) {
         const T* xr = x + r * xs;                                 // uniform addresses: scalar loads
         const T* gr = g + r * gs;
@@ -318,7 +319,7 @@ template <typename T>
 static int mlp2_small_bwd(const T* x, int64_t xs, const T* W1, int64_t w1s, const T* b1, const T* W2, int64_t w2s, const T* g, int64_t gs, int64_t B, int32_t K1,
                           int32_t H, int32_t N, T* slab, T* slab_b2, void* stream) {
     if (!x || !W1 || !b1 || !W2 || !g || !slab || !slab_b2 || B < 0) return JF_ERR_BADARG;
-    if (K1 < 1 || K1 > MS_K1MAX || N < 1 || N > MS_NMAX || H < 1 || H > 128) return JF_ERR_UNSUPPORTED;
+    if (K1 < 1 || K1 > MS_K1MAX || N < 1 || N > (K1 <= MS_K1WIDE ? (sizeof(T) == 8 ? MS_NWIDE64 : MS_NWIDE) : MS_NMAX) || H < 1 || H > 128) return JF_ERR_UNSUPPORTED;
     if (B == 0) return JF_OK;
     const int64_t S = mlp2_small_slabs(B);
     const int64_t rpb = (B + S - 1) / S;
@@ -326,11 +327,15 @@ static int mlp2_small_bwd(const T* x, int64_t xs, const T* W1, int64_t w1s, cons
     hipStream_t st = (hipStream_t)stream;
     // (K1 = 1, 2 get their own instantiations since round 6: the 1 -> 128 -> 8 head of C4 spent 6 of its 35 vector instructions per row and hidden
     //  unit on the three zero-weight slots of a four-wide input loop)
-    const int kb = K1 <= 1 ? 1 : K1 <= 2 ? 2 : K1 <= 4 ? 4 : K1 <= 8 ? 8 : K1 <= 16 ? 16 : 32, nb = N <= 4 ? 4 : N <= 8 ? 8 : N <= 12 ? 12 : 16;
+    const int kb = K1 <= 1 ? 1 : K1 <= 2 ? 2 : K1 <= 4 ? 4 : K1 <= 8 ? 8 : K1 <= 16 ? 16 : 32, nb = N <= 4 ? 4 : N <= 8 ? 8 : N <= 12 ? 12 : N <= 16 ? 16 : N <= 32 ? 32 : N <= 48 ? 48 : 64;
     const int dense = (kb == K1 || xs == K1) && (nb == N || gs == N);           // padded slots read rows of the same array, never a gap
 #define JF_MS(KB_, NB_) jf::launch((mlp2_small_bwd_kernel<T, KB_, NB_>), grid, block, 0, st, x, xs, W1, w1s, b1, W2, w2s, g, gs, B, (int)K1, (int)H, (int)N, rpb, slab, slab_b2, dense)
 #define JF_MS_N(KB_) { if (N <= 4) JF_MS(KB_, 4); else if (N <= 8) JF_MS(KB_, 8); else if (N <= 12) JF_MS(KB_, 12); else JF_MS(KB_, 16); }
-    if (K1 <= 1) JF_MS_N(1) else if (K1 <= 2) JF_MS_N(2) else if (K1 <= 4) JF_MS_N(4) else if (K1 <= 8) JF_MS_N(8) else if (K1 <= 16) JF_MS_N(16) else JF_MS_N(32)
+    // (17 .. 64 outputs, round 6: the 4 -> 128 -> 46 head of c3b went through the per-layer path -- a library GEMM, tanh', two weight-gradient
+    //  launches: 0.45 ms per 2^18 rows)
+#define JF_MS_W(KB_) { if (N <= 16) JF_MS_N(KB_) else if (N <= 32) JF_MS(KB_, 32); else if (N <= 48) JF_MS(KB_, 48); else JF_MS(KB_, 64); }
+    if (K1 <= 1) JF_MS_W(1) else if (K1 <= 2) JF_MS_W(2) else if (K1 <= 4) JF_MS_W(4) else if (K1 <= 8) JF_MS_W(8) else if (K1 <= 16) JF_MS_N(16) else JF_MS_N(32)
+#undef JF_MS_W
 #undef JF_MS_N
 #undef JF_MS
     return check_launch();

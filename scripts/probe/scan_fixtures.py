@@ -1,6 +1,6 @@
 """forward / sampling / training step times of every golden fixture's pdf at one batch size (float64, fixture rows tiled): a scan for paths that are
 out of proportion (e.g. an adjoint at 30 x its forward).  python3 scripts/probe/scan_fixtures.py [rows] [name-substring] [f32|f64]"""
-import os, sys, time
+import gc, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden")]
 import numpy as np
@@ -13,19 +13,36 @@ DT = torch.float32 if (len(sys.argv) > 3 and sys.argv[3] == "f32") else torch.fl
 names = sorted(f[:-4] for f in os.listdir(fixture_io.GOLDEN_DIR) if f.endswith(".npz") and sub in f)
 
 
+SPIKES = []
+
+
 def timed(fn, n=8):
+    """best of three timed groups of n calls (a group that ran into a one-off stall of the box -- seen: ~65 ms, about one group in twenty, in
+    any of the three columns -- is recorded in SPIKES and printed at the end, not averaged into the table)"""
     for _ in range(3):
         fn()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(n):
-        fn()
-    torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / n * 1e3
+    groups = []
+    for _ in range(3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        groups.append((time.perf_counter() - t0) / n * 1e3)
+    if max(groups) > 3.0 * min(groups):
+        SPIKES.append(["%.3f" % g for g in groups])
+    return min(groups)
 
 
+pdf = None
 for name in names:
     try:
+        # the previous fixture's pdf goes NOW (its plans, packed images and streams are released by the collector; left to chance that happens
+        # inside a later fixture's timed group: the one-off stalls of the first float32 scan -- scripts/probe/stall_probe.py finds none in 11 000
+        # steady calls of one pdf)
+        pdf = None
+        gc.collect()
+        torch.cuda.synchronize()
         fx = fixture_io.load(name)
         pdf = helpers.build_product(fx, DT, torch.device("cuda"))
         pdf.check_status = "deferred"
@@ -54,3 +71,6 @@ for name in names:
         print("%-32s fwd %8.3f  sample %8.3f (x%5.1f)  train %8.3f (x%5.1f)" % (name, t_f, t_s, t_s / t_f, t_t, t_t / t_f), flush=True)
     except Exception as e:
         print("%-32s ERROR %s" % (name, repr(e)[:120]), flush=True)
+
+if SPIKES:
+    print("timed groups more than 3 x their best sibling (not in the table): %d of %d fixtures x 3 columns: %s" % (len(SPIKES), len(names), SPIKES[:12]))

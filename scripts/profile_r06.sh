@@ -21,6 +21,8 @@ issue() {   # $1 = out dir, $2 = f32|f64, rest = --pmc-child arguments: vector i
   python3 scripts/pmc_dump.py $out/a.db $out/b.db > $out/pmc.txt 2>&1
   python3 scripts/rocprof_summary.py $out/t.db > $out/kernel_stats.md 2>&1; rm -f $out/t.db
 }
+PART=${1:-all}      # 1: kernel stats + traffic, 2: vector-issue profiles, 3: the log-prob bench lines, 4: training / sampling / the fixture scan
+if [ $PART = all ] || [ $PART = 1 ]; then
 # ---- per-kernel durations of the default command (three streams), the same step on one stream, the other configurations
 stats $G/prof_r06_c3
 stats $G/prof_r06_c3_one_stream --pipeline-depth 1
@@ -31,17 +33,23 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c -d $out/p -- python3 bench.py --pmc-child > $out/p.log 2>&1
   f=$(find $out/p -name "*.db" | head -1); [ -n "$f" ] && cp $f $out/p.db; rm -rf $out/p
 done
+fi
+if [ $PART = all ] || [ $PART = 2 ]; then
 # ---- the vector-issue profiles (instructions per row by class, clock): float32 of C3 / C2 / C4 / C3b, float64 of C3
 issue $G/prof_r06_issue_c3_f32 f32
 issue $G/prof_r06_issue_c2_f32 f32 --workload c2
 issue $G/prof_r06_issue_c4_f32 f32 --workload c4
 issue $G/prof_r06_issue_c3b_f32 f32 --workload c3b
 issue $G/prof_r06_issue_c3_f64 f64
+fi
+if [ $PART = all ] || [ $PART = 3 ]; then
 # ---- the bench lines
 python3 bench.py > $G/bench_r06_default.json 2> $G/bench_r06_default.err
 python3 bench.py --pipeline-depth 1 --no-cpu-baseline --no-pmc > $G/bench_r06_one_stream.json 2> $G/bench_r06_one_stream.err
 python3 bench.py --workload c5 --scaling weak > $G/bench_r06_c5.json 2> $G/bench_r06_c5.err
 for wl in c2 c4 c3b; do python3 bench.py --workload $wl --no-sweep > $G/bench_r06_$wl.json 2> $G/bench_r06_$wl.err; done
+fi
+if [ $PART = all ] || [ $PART = 4 ]; then
 # ---- the training steps' kernel tables and lines, sampling lines
 for wl in c3 c3b c5; do stats $G/prof_r06_${wl}_train --workload $wl --scaling weak --train; done
 stats $G/prof_r06_c4_train --workload c4 --train
@@ -56,4 +64,5 @@ done
 # ---- every golden fixture's forward / sampling / training step (the table DESIGN section 8 quotes)
 python3 scripts/probe/scan_fixtures.py 65536 "" f64 > $G/scan_r06_f64.txt 2>&1
 python3 scripts/probe/scan_fixtures.py 65536 "" f32 > $G/scan_r06_f32.txt 2>&1
+fi
 ls -la $G | tail -40

@@ -58,9 +58,16 @@ def test_linear_skinny_shapes(dtype, B, K, N, act):
 
 
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
-@pytest.mark.parametrize("B,K1,H,N", [(1000, 4, 128, 10), (4099, 7, 64, 3), (300, 32, 128, 16), (1, 1, 4, 1), (70001, 4, 128, 10)])
+@pytest.mark.parametrize("B,K1,H,N", [(1000, 4, 128, 10), (4099, 7, 64, 3), (300, 32, 128, 16), (1, 1, 4, 1), (70001, 4, 128, 10),
+                                      (70001, 4, 128, 46), (999, 8, 64, 64), (513, 2, 128, 33), (200, 1, 100, 17), (3000, 4, 128, 48)])
 def test_mlp2_small_backward_vs_autograd(dtype, B, K1, H, N):
-    """jf_mlp2_small_bwd (whole backward of a narrow Linear-tanh-Linear head in one launch) against torch autograd in float64"""
+    """jf_mlp2_small_bwd (whole backward of a narrow Linear-tanh-Linear head in one launch) against torch autograd in float64; the wide
+    variants (17 .. 64 outputs behind <= 8 inputs: the 4 -> 128 -> 46 head of an 'f' layer with spline flows) included"""
+    if not _hip.mlp2_small_shape_ok(K1, H, N, 8 if dtype == torch.float64 else 4):
+        assert dtype == torch.float64 and N > 48
+        with pytest.raises(RuntimeError, match="unsupported"):
+            _hip.mlp2_small_bwd(*(torch.zeros(s, device="cuda", dtype=dtype) for s in ((B, K1), (H, K1), (H,), (N, H), (B, N))))
+        return
     rng = np.random.default_rng(B + K1 + N)
     mk = lambda *s: torch.from_numpy(rng.normal(size=s)).to(device="cuda", dtype=torch.float64)
     x, w1, b1, w2, b2, g = mk(B, K1), mk(H, K1) / np.sqrt(K1), mk(H), mk(N, H) / np.sqrt(H), mk(N), mk(B, N)
@@ -107,3 +114,28 @@ def test_split_kernels_repeat_bit_identically_at_full_size():
         for a, c in zip(first, again):
             assert torch.equal(a, c)
     assert all(torch.isfinite(t).all() for t in first)
+
+
+@pytest.mark.parametrize("B,K1,H,N", [(70001, 4, 128, 46), (1000, 1, 128, 8), (333, 4, 128, 10), (4099, 3, 100, 17), (1, 2, 128, 32), (5000, 4, 128, 64),
+                                      (777, 4, 64, 47), (129, 1, 8, 1), (2048, 4, 128, 16), (2048, 4, 128, 68), (900, 7, 128, 46)])
+def test_mlp2_float32_vs_float64_product(B, K1, H, N):
+    """jf_mlp2_f32 against a float64 evaluation: the narrow kernel (<= 4 inputs, <= 64 outputs in one .. four column tiles of 16,
+    mlp_narrow_kernels.hip: vector-unit first layer, split-f16 second layer), and the exact-float32 MFMA kernel for the shapes beyond it.
+    Strided output rows (the wrapper pads rows to 128-byte lines), rows not a multiple of 16, widths that are not multiples of 4 / 2."""
+    rng = np.random.default_rng(B + 7 * K1 + H + 13 * N)
+    dev = lambda a: torch.from_numpy(a).to(device="cuda", dtype=torch.float32)
+    x = dev(rng.normal(size=(B, K1)) * 1.5)
+    w1, b1 = dev(rng.normal(size=(H, K1)) / np.sqrt(K1)), dev(rng.normal(size=(H,)) * 0.3)
+    w2, b2 = dev(rng.normal(size=(N, H)) / np.sqrt(H)), dev(rng.normal(size=(N,)))
+    out = _hip.mlp2(x, w1, b1, w2, b2)
+    assert out.shape == (B, N) and torch.isfinite(out).all()
+    ref = torch.tanh(x.double() @ w1.double().t() + b1.double()) @ w2.double().t() + b2.double()
+    bound = w2.double().abs().sum(dim=1) + b2.double().abs()           # |h| <= 1: the scale of the rounding of the H-term product
+    err = ((out.double() - ref).abs() / bound).max().item()
+    print("B %d K1 %d H %d N %d: max error / (sum|w2| + |b2|) %.2e" % (B, K1, H, N, err))
+    assert err < 2e-6, err
+    # an odd output width into an unpadded buffer (scalar stores), and a caller's buffer whose neighbours must stay untouched
+    if N <= 64:
+        buf = torch.full((B, N + 3), 7.0, dtype=torch.float32, device="cuda")
+        _hip.mlp2(x, w1, b1, w2, b2, out=buf[:, 1:N + 1])
+        assert torch.equal(buf[:, 1:N + 1], out) and (buf[:, 0] == 7.0).all() and (buf[:, N + 1:] == 7.0).all()
