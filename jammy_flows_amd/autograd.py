@@ -126,6 +126,28 @@ def mlp2_small_ok(x, lin1, lin2):
             and lin1.out_features % 4 == 0 and lin1.bias is not None and lin2.bias is not None)
 
 
+class CombineRowsFn(torch.autograd.Function):
+    """(total, base_logp) = (sum of the blocks' log-dets + sum of their base log-probs, the latter) of a gradient-mode forward whose blocks ran on
+    side streams (main/default.py: _forward_with_grad): ONE launch (jf_combine_rows) where torch ran one add per pair and one for the total --
+    five launches of ~5 us each on the step's longest chain for three blocks; the backward hands the incoming gradients through (no launch
+    unless both outputs carry one)."""
+
+    @staticmethod
+    def forward(ctx, n_ld, *parts):
+        ld, blp = parts[:n_ld], parts[n_ld:]
+        ctx.n = (n_ld, len(blp))
+        ctx.set_materialize_grads(False)
+        _, blp_sum, total = _hip.combine_rows([t.detach() for t in ld], [t.detach() for t in blp], want_total=True)
+        return total, blp_sum
+
+    @staticmethod
+    @_side_stream_safe
+    def backward(ctx, g_total, g_blp):
+        n_ld, n_blp = ctx.n
+        g_b = g_total if g_blp is None else (g_blp if g_total is None else g_total + g_blp)
+        return (None,) + (g_total,) * n_ld + (g_b,) * n_blp
+
+
 class GfChainInvFn(torch.autograd.Function):
     """log-prob direction of a chain of g layers (jf_gf_chain_inv) -> (x_out, log_det_out, base_logp_out)."""
 
@@ -286,6 +308,8 @@ class LowRankGfChainFn(torch.autograd.Function):
 FUSED_BLOCK_BACKWARD = os.environ.get("JF_FUSED_BLOCK_BACKWARD", "1") != "0"
 # its weight-gradient product on f16 pairs (three MFMA passes) instead of bf16 triples (six): JF_WGRAD_F16_PAIRS=0 selects the triples
 WGRAD_F16_PAIRS = os.environ.get("JF_WGRAD_F16_PAIRS", "1") != "0"
+# the blocks' log-det / base log-prob sums and the total of a gradient-mode forward in one launch (CombineRowsFn): JF_COMBINE_ROWS_FN=0 -> torch adds
+COMBINE_ROWS_FN = os.environ.get("JF_COMBINE_ROWS_FN", "1") != "0"
 _packed_row_index = {}
 
 
@@ -340,6 +364,9 @@ class CondBlockFn(torch.autograd.Function):
             ctx.fused = None
             del aux
             g_w2 = g_b2 = None
+            # (round 6: the hidden layer's adjoint forked onto a second stream beside the weight-gradient product -- independent launches,
+            #  0.04 ms off this node's chain on paper -- made the graph-replayed C3 training step 0.10 ms SLOWER, 1.282 -> 1.385 ms: a third stream in
+            #  the captured step costs more than the overlap returns; profiles/r06_experiments.md)
             if need[3] or need[4]:
                 if f16_wgrad:                          # the packed rows' largest entry comes with them: weight gradient on f16 pairs; its slab
                     # sum puts the packed rows back in natural order (no gather launches)

@@ -1412,6 +1412,12 @@ class pdf(nn.Module):
         if side is not None:
             for st in side:
                 main_stream.wait_stream(st)               # every block's outputs are complete before the caller's stream adds them up
+            if autograd.COMBINE_ROWS_FN and all(t is not None and t.dim() == 1 for t in ld_parts + blp_parts):
+                # the blocks' sums and the total in one launch (autograd.CombineRowsFn)
+                total, base_logp = autograd.CombineRowsFn.apply(len(ld_parts), *ld_parts, *blp_parts)
+                base = torch.cat(bases, dim=1) if len(bases) > 1 else bases[0]
+                self._defer_status(status)
+                return total, base_logp, base
             log_det = ld_parts[0]
             for t in ld_parts[1:]:
                 log_det = log_det + t
