@@ -828,7 +828,8 @@ def gf_chain_inv_bwd(x, params, layer_array, n_layers, D, g_xout, g_ld, g_blp, s
 
 
 COND_GF_MAX_IN, COND_GF_MAX_HIDDEN = 28, 128
-GF_MAX_DIM = 32              # 'g' / 't' layers: coordinates per row (groups of up to 32 lanes; fused blocks: 8)
+GF_MAX_DIM = 64              # 'g' layers: coordinates per row (groups of up to 64 lanes = a whole wave per row; fused blocks: 8)
+T_MAX_DIM = 32               # 't' layers: the triangular factor of a row in registers
 LDS_BYTES_PER_CU = 160 * 1024
 
 

@@ -439,7 +439,7 @@ __global__ void __launch_bounds__(BCAST ? GB_NT : 64) gf_chain_bwd_kernel(const 
     constexpr int NT = BCAST ? GB_NT : 64;
     constexpr int R = NT / G;
     const int tid = threadIdx.x;
-    constexpr int LG = G == 1 ? 0 : G == 2 ? 1 : G == 4 ? 2 : G == 8 ? 3 : G == 16 ? 4 : 5;
+    constexpr int LG = G == 1 ? 0 : G == 2 ? 1 : G == 4 ? 2 : G == 8 ? 3 : G == 16 ? 4 : G == 32 ? 5 : 6;
     constexpr int DM = G > 8 ? G : 8, LDM = G > 8 ? LG : 3;      // coordinate slots per layer of the normaliser table (aux)
     const int g = tid & (G - 1), r = tid >> LG;
     const int D = a.D;
@@ -735,7 +735,7 @@ __global__ void __launch_bounds__(GX_THREADS) gfx_chain_bwd_kernel(const GfBwdAr
 }
 
 // ---------------------------------------------------------------------------------------------------------- host side
-static inline int gb_group_width(int D) { return D <= 1 ? 1 : D <= 2 ? 2 : D <= 4 ? 4 : D <= 8 ? 8 : D <= 16 ? 16 : 32; }
+static inline int gb_group_width(int D) { return D <= 1 ? 1 : D <= 2 ? 2 : D <= 4 ? 4 : D <= 8 ? 8 : D <= 16 ? 16 : D <= 32 ? 32 : 64; }
 
 template <typename T> static int gb_fill(GfBwdArgs<T>& a, const T* params, int64_t ps, bool bcast, int32_t D, int32_t n_layers, const jf_gf_layer* layers,
                                          bool& ext) {
@@ -804,7 +804,7 @@ static int gb_launch(GfBwdArgs<T> a, bool bcast, hipStream_t st) {
         const int64_t n_tiles = (a.B + GB_NT / G - 1) / (GB_NT / G);
         const int64_t blocks = gb_partials(a.B, a.D);
         a.tiles_per_block = (int)((n_tiles + blocks - 1) / blocks);
-        int slsh = G == 1 ? 6 : G == 2 ? 5 : G == 4 ? 4 : G == 8 ? 3 : G == 16 ? 2 : 1;       // one slot per row of a wave, fewer when the accumulators would not fit
+        int slsh = G == 1 ? 6 : G == 2 ? 5 : G == 4 ? 4 : G == 8 ? 3 : G == 16 ? 2 : G == 32 ? 1 : 0;       // one slot per row of a wave, fewer when the accumulators would not fit
         const size_t cell = (size_t)a.n_layers * a.tile_stride * sizeof(T), acell = (size_t)a.n_layers * a.tile_stride * sizeof(double);
         while (slsh > 0 && 3 * cell + (acell << slsh) > 28 * 1024) --slsh;   // measured flat between 2 and 8 slots (conflicting ds_add_f64 are cheap); occupancy matters more
         a.slsh = slsh;
@@ -872,7 +872,8 @@ static int gf_chain_inv_bwd(const T* x, int64_t xs, const T* params, int64_t ps,
         case 4: return gb_launch<T, 4>(a, bcast, (hipStream_t)stream);
         case 8: return gb_launch<T, 8>(a, bcast, (hipStream_t)stream);
         case 16: return gb_launch<T, 16>(a, bcast, (hipStream_t)stream);
-        default: return gb_launch<T, 32>(a, bcast, (hipStream_t)stream);
+        case 32: return gb_launch<T, 32>(a, bcast, (hipStream_t)stream);
+        default: return gb_launch<T, 64>(a, bcast, (hipStream_t)stream);
     }
 }
 

@@ -314,7 +314,7 @@ template <typename T, bool FWD> __global__ void __launch_bounds__(GX_THREADS) gf
 // ----------------------------------------------------------------------------------------------------------
 constexpr int LDS_LIMIT = 160 * 1024;
 
-static inline int group_width(int D) { return D <= 1 ? 1 : D <= 2 ? 2 : D <= 4 ? 4 : D <= 8 ? 8 : D <= 16 ? 16 : 32; }
+static inline int group_width(int D) { return D <= 1 ? 1 : D <= 2 ? 2 : D <= 4 ? 4 : D <= 8 ? 8 : D <= 16 ? 16 : D <= 32 ? 32 : 64; }
 
 template <typename T> static int fill_args(GfChainArgs<T>& a, const T* params, int64_t ps, int32_t pb, int64_t B, int32_t D, int32_t n_layers,
                                            const jf_gf_layer* layers, size_t& lds_bytes, bool& bcast, bool& ext) {
@@ -503,7 +503,8 @@ template <typename T, bool FWD> static int launch(const GfChainArgs<T>& a, int D
         case 4: return launch_g<T, 4, FWD>(a, bcast, lds_bytes, st);
         case 8: return launch_g<T, 8, FWD>(a, bcast, lds_bytes, st);
         case 16: return launch_g<T, 16, FWD>(a, bcast, lds_bytes, st);
-        default: return launch_g<T, 32, FWD>(a, bcast, lds_bytes, st);
+        case 32: return launch_g<T, 32, FWD>(a, bcast, lds_bytes, st);
+        default: return launch_g<T, 64, FWD>(a, bcast, lds_bytes, st);
     }
 }
 

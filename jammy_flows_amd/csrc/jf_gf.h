@@ -253,6 +253,8 @@ constexpr int DPP_ROW_ROR8 = 0x128;     // row_ror:8: lane i <-> i ^ 8 inside ea
 
 // lanes 16 apart (G = 32: coordinates 16..31 of a row): no DPP form crosses the 16-lane rows; ds_bpermute does
 template <typename T> __device__ __forceinline__ T xor16(T v) { return __shfl_xor(v, 16, 64); }
+// ... and the two halves of the wave (G = 64: a whole wave per row, 33 .. 64 coordinates, round 6)
+template <typename T> __device__ __forceinline__ T xor32(T v) { return __shfl_xor(v, 32, 64); }
 
 template <typename T, int G> __device__ __forceinline__ T group_sum(T v) {
     if constexpr (G >= 2) v += dpp_swap<DPP_XOR1>(v);
@@ -260,6 +262,7 @@ template <typename T, int G> __device__ __forceinline__ T group_sum(T v) {
     if constexpr (G >= 8) v += dpp_swap<DPP_HALF_MIRROR>(v);
     if constexpr (G >= 16) v += dpp_swap<DPP_ROW_ROR8>(v);
     if constexpr (G >= 32) v += xor16(v);
+    if constexpr (G >= 64) v += xor32(v);
     return v;
 }
 template <typename T, int G> __device__ __forceinline__ T group_max(T v) {
@@ -268,6 +271,7 @@ template <typename T, int G> __device__ __forceinline__ T group_max(T v) {
     if constexpr (G >= 8) v = M<T>::max(v, dpp_swap<DPP_HALF_MIRROR>(v));
     if constexpr (G >= 16) v = M<T>::max(v, dpp_swap<DPP_ROW_ROR8>(v));
     if constexpr (G >= 32) v = M<T>::max(v, xor16(v));
+    if constexpr (G >= 64) v = M<T>::max(v, xor32(v));
     return v;
 }
 

@@ -13,7 +13,7 @@ namespace jf {
 
 constexpr int GX_THREADS = 128;
 constexpr int JF_MAX_D_GF = 8;           // the general-option kernel (this file) takes D <= 8
-constexpr int JF_MAX_D_G = 32;           // the lane = (row, coordinate) kernels: groups of up to 32 lanes per row
+constexpr int JF_MAX_D_G = 64;           // the lane = (row, coordinate) kernels: groups of up to 64 lanes (a whole wave) per row
 
 template <typename T> struct XCol {           // the lane's coordinate vector: element d at b[d * GX_THREADS]
     T* b;

@@ -35,7 +35,7 @@ template <typename T> struct GfChainArgs {
     T* table;
 };
 
-template <int G> struct Log2 { static constexpr int v = (G == 1) ? 0 : (G == 2) ? 1 : (G == 4) ? 2 : (G == 8) ? 3 : (G == 16) ? 4 : 5; };
+template <int G> struct Log2 { static constexpr int v = (G == 1) ? 0 : (G == 2) ? 1 : (G == 4) ? 2 : (G == 8) ? 3 : (G == 16) ? 4 : (G == 32) ? 5 : 6; };
 
 // broadcast regime: raw rows -> LDS, then wave w derives layers w, w+4, ... (columns on lanes 0..D-1, reflections on lanes 32..)
 template <typename T> __device__ __forceinline__ void derive_broadcast(T* lds, const GfChainArgs<T>& a) {
@@ -48,8 +48,13 @@ template <typename T> __device__ __forceinline__ void derive_broadcast(T* lds, c
     for (int l = wave; l < a.n_layers; l += 4) {
         const GfLayerDev<T> o = a.L[l];      // wave-uniform index
         T* row = lds + l * a.tile_stride;
-        if (lane < a.D) { if (o.stretch == JF_GF_STRETCH_CLASSIC) gf_derive_column<T>(row, o, a.D, lane); }
-        else if (lane >= 32 && lane - 32 < o.hh) gf_derive_reflection<T>(row, o, a.D, lane - 32);
+        if (a.D <= 32) {
+            if (lane < a.D) { if (o.stretch == JF_GF_STRETCH_CLASSIC) gf_derive_column<T>(row, o, a.D, lane); }
+            else if (lane >= 32 && lane - 32 < o.hh) gf_derive_reflection<T>(row, o, a.D, lane - 32);
+        } else {                                         // 33 .. 64 coordinates: columns, then reflections (different words of the row), on all lanes
+            if (lane < a.D && o.stretch == JF_GF_STRETCH_CLASSIC) gf_derive_column<T>(row, o, a.D, lane);
+            for (int i = lane; i < o.hh; i += 64) gf_derive_reflection<T>(row, o, a.D, i);
+        }
     }
     __syncthreads();
 }

@@ -19,8 +19,8 @@ class mvn_block(euclidean_base.euclidean_base):
         super().__init__(dimension=dimension, use_permanent_parameters=use_permanent_parameters, model_offset=model_offset)
         assert cov_type in COV_TYPES, cov_type
         assert lower_bound_for_widths > 0.0
-        if dimension > _hip.GF_MAX_DIM:
-            raise NotImplementedError("the 't' kernel handles up to %d dimensions" % _hip.GF_MAX_DIM)
+        if dimension > _hip.T_MAX_DIM:
+            raise NotImplementedError("the 't' kernel handles up to %d dimensions" % _hip.T_MAX_DIM)
         self.cov_type = cov_type
         self.width_min = lower_bound_for_widths
         self.width_max = upper_bound_for_widths if upper_bound_for_widths > 0 else None

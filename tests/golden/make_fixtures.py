@@ -119,6 +119,9 @@ CASES = [
     dict(name="g_e10_ggggg", pdf="e10", flow="ggggg", perturb=0.2),
     dict(name="g_e12_cond", pdf="e12", flow="gg", mlp_scale=300.0, kwargs=dict(conditional_input_dim=3)),
     dict(name="g_e20_g", pdf="e20", flow="g", perturb=0.3),
+    # more than 32 Euclidean dimensions: a whole wave per row in the 'g' kernels (round 6)
+    dict(name="g_e40_gg", pdf="e40", flow="gg", perturb=0.2),
+    dict(name="g_e64_g_cond", pdf="e64", flow="g", mlp_scale=100.0, kwargs=dict(conditional_input_dim=2, amortization_mlp_dims="16")),
     dict(name="t_e10_full", pdf="e10", flow="t", perturb=0.4, kwargs=dict(options_overwrite={"t": {"cov_type": "full"}})),
     dict(name="t_e10_diagonal", pdf="e10", flow="gt", perturb=0.4, kwargs=dict(options_overwrite={"t": {"cov_type": "diagonal"}})),
     dict(name="t_e10_diagonal_symmetric", pdf="e10", flow="t", perturb=0.4, kwargs=dict(options_overwrite={"t": {"cov_type": "diagonal_symmetric"}})),

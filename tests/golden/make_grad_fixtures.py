@@ -52,7 +52,9 @@ CASES = ["c1_e2_gg", "c2_e4_gggg", "c3_e4s2e4", "g_e1_g", "g_e3_ggg_cond", "g_e2
          "o_s1_nosmooth", "r_i1", "r_i1_fixopts", "r_i1_smooth2", "r_i1_smooth3", "t_e10_diagonal_symmetric", "t_e10_identity", "v_s2",
          "v_s2_nat1_rot", "v_s2_splines_cond", "v_s2_splines_nat1",
          # more than 16 bins
-         "r_i1_bins24_cond", "r_i1_bins40", "o_s1_bins20_cond", "f_s2_splines_bins24"]
+         "r_i1_bins24_cond", "r_i1_bins40", "o_s1_bins20_cond", "f_s2_splines_bins24",
+         # more than 32 Euclidean dimensions
+         "g_e40_gg", "g_e64_g_cond"]
 N_ADV = 8
 ADAM_STEPS = 10
 

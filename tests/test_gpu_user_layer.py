@@ -153,7 +153,10 @@ def test_user_layer_next_to_kernel_layers_conditional_and_amortised():
 
 
 def test_kernel_caps_raise_loudly_on_the_device():
-    """a g layer of 33 dimensions constructs (the reference has no cap, flow_options.py:38) but has no kernel: the forward call says so"""
+    """a g layer of 65 dimensions constructs (the reference has no cap, flow_options.py:38) but has no kernel (a wave = 64 lanes per row since
+    round 6, 32 before): the forward call says so; 33 dimensions run"""
+    pdf = jf.pdf("e65", "g").cuda()
+    with pytest.raises((NotImplementedError, RuntimeError), match="65|dimension|unsupported|not supported"):
+        pdf(torch.randn(10, 65, device="cuda"))
     pdf = jf.pdf("e33", "g").cuda()
-    with pytest.raises((NotImplementedError, RuntimeError), match="33|dimension|unsupported|not supported"):
-        pdf(torch.randn(10, 33, device="cuda"))
+    assert torch.isfinite(pdf(torch.randn(10, 33, device="cuda"))[0]).all()
