@@ -87,8 +87,8 @@ typedef struct jf_gf_layer {
     double norm_min, norm_max;
 } jf_gf_layer;
 /* Layers with rotation_mode != HOUSEHOLDER, center_mean or add_skewness run in the general-option kernel of jf_gf_chain_inv / _fwd
- * (one lane per row, D <= 8); the fused block entry points and jf_gf_chain_inv_bwd return JF_ERR_UNSUPPORTED for them.  D <= 32 for layers at the
- * other options (groups of up to 32 lanes per row). */
+ * (one lane per row, D <= 8); the fused block entry points and jf_gf_chain_inv_bwd return JF_ERR_UNSUPPORTED for them.  D <= 64 for layers at the
+ * other options (groups of up to 64 lanes -- a whole wave -- per row; 32 until ABI 8's second build). */
 
 /* log-prob direction of a chain of `n_layers` g layers applied in REVERSE order (layer n-1 first), all in one launch.
  * params row = the layers' rows concatenated in layer order 0..n-1.  log_det_in / base_logp_in may be NULL (= 0);

@@ -912,7 +912,7 @@ def test_c_abi_error_codes():
     assert call(n_layers=_hip.JF_MAX_CHAIN + 1) == _hip.JF_ERR_BADARG
     assert call(xptr=None) == _hip.JF_ERR_BADARG
     assert call(pb=3) == _hip.JF_ERR_BADARG                      # param_batch must be 1 or B
-    assert call(D=33) == _hip.JF_ERR_UNSUPPORTED           # groups of up to 32 lanes per row
+    assert call(D=65) == _hip.JF_ERR_UNSUPPORTED           # groups of up to 64 lanes (a wave) per row
     assert call(B=0) == _hip.JF_OK                                # empty batch: nothing launched
     L.width_min = 0.0
     assert call(layers=(_hip.jf_gf_layer * 1)(L)) == _hip.JF_ERR_BADARG
