@@ -944,6 +944,11 @@ RANDOM_CONFIGS = [
     ("e3+e4", "gg+gg", {"amortization_mlp_dims": "30"}),                       # hidden width not a multiple of 4: per-layer dense kernels
     ("e2+e4", "g+gg", {"amortization_mlp_dims": "64-32"}),                     # two hidden layers
     ("e4+e4", "gg+gg", {"conditional_input_dim": 40, "amortization_mlp_dims": "160"}),   # wider than the fused kernel's limits
+    # 33 .. 64 dimensions (round 6): a whole wave per row, idle lanes beyond the dimension, fewer reflections than dimensions, conditional rows
+    ("e33", "gg", {}),
+    ("e50", "g", {"options_overwrite": {"g": {"num_householder_iter": 5, "num_kde": 4}}}),
+    ("e64", "gg", {"options_overwrite": {"g": {"num_householder_iter": 3, "inverse_function_type": "isigmoid"}}}),
+    ("e2+e40", "g+g", {"amortization_mlp_dims": "16", "options_overwrite": {"g": {"num_householder_iter": 2, "num_kde": 5}}}),
 ]
 
 
