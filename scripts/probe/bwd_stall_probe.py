@@ -36,7 +36,7 @@ torch.cuda.synchronize()
 tab = {"%%s[%%s]" %% k: round(v["mean_ms"], 4) for k, v in timer.summary().items()}
 print(json.dumps({"step_ms": round(dt, 4), "kernels": tab}))
 ''' % ROOT
-libs = [("product", None)] + [(v, os.path.join(ROOT, "jammy_flows_amd", "_probe", "libjammy_hip_%s.so" % v)) for v in ("nodma", "nobarrier", "both")]
+libs = [("product", None)] + [(v, os.path.join(ROOT, "jammy_flows_amd", "_probe", "libjammy_hip_%s.so" % v)) for v in ("nodma", "nobarrier", "both", "occ3")]
 for rnd in range(2):
     for name, path in libs:
         env = dict(os.environ, JF_TRAIN_STREAMS="1")
