@@ -19,21 +19,21 @@ WORKLOADS = {
     "c1": dict(fixture="c1_e2_gg", defs=("e2", "gg"), dtype="f64", rows=4096, total=4096, seed=1, bytes_per_eval={"f64": 48, "f32": 24}, flops_per_eval=0,
                metric="log-prob evals/sec (batch 4096), e2 / gg", desc="unconditional, the reference's CPU-runnable plumbing case"),
     "c2": dict(fixture="c2_e4_gggg", defs=("e4", "gggg"), dtype="f32", rows=1 << 20, total=1 << 20, seed=2, bytes_per_eval={"f32": 40, "f64": 80},
-               flops_per_eval=0, metric="log-prob evals/sec (batch 2^20 per GPU), e4 / gggg", desc="Gaussianization flow only, unconditional",
+               flops_per_eval=0, metric="log-prob evals/sec (batch 2^20), e4 / gggg", desc="Gaussianization flow only, unconditional",
                # transcendental instructions per evaluation of the broadcast g kernel at these options (csrc/gf_kernels.hip gfb_chain_inv_kernel):
                # exp + rcp per (component, coordinate, layer), three logs per (coordinate, layer), ~6 in the inverse-normal stage of layer 0
                trans_per_eval=2 * 10 * 4 * 4 + 3 * 4 * 4 + 6 * 4),
     "c4": dict(fixture="c4_i1s1_ro", defs=("i1+s1", "r+o"), dtype="f32", rows=1 << 20, total=1 << 20, seed=4, bytes_per_eval={"f32": 100, "f64": 200},
-               flops_per_eval=2304, metric="log-prob evals/sec (batch 2^20 per GPU), i1+s1 / r+o", desc="RQ spline on the interval + circular spline on S1"),
+               flops_per_eval=2304, metric="log-prob evals/sec (batch 2^20), i1+s1 / r+o", desc="RQ spline on the interval + circular spline on S1"),
     "c3": dict(fixture="c3_e4s2e4", defs=("e4+s2+e4", "gggg+f+gggg"), dtype="f32", rows=1 << 20, total=1 << 20, seed=3,
                bytes_per_eval={"f32": 4612, "f64": 9224}, flops_per_eval=145664,
-               metric="log-prob evals/sec (batch 2^20 per GPU), e4+s2+e4 / gggg+f+gggg",
+               metric="log-prob evals/sec (batch 2^20), e4+s2+e4 / gggg+f+gggg",
                desc="unconditional pdf with autoregressive conditioning"),
     # SURVEY 8d's variant of C3: the 'f' layer with the docs-recommended nested spline flows (add_vertical_rq_spline_flow = 1,
     # add_circular_rq_spline_flow = 1; docs/source/usage/suggested_settings.rst:53-70): 46 parameters per row for the s2 block instead of 10
     "c3b": dict(fixture="c3b_e4s2e4_fsplines", defs=("e4+s2+e4", "gggg+f+gggg"), dtype="f32", rows=1 << 20, total=1 << 20, seed=3,
                 bytes_per_eval={"f32": 4900, "f64": 9800}, flops_per_eval=154880,
-                metric="log-prob evals/sec (batch 2^20 per GPU), e4+s2+e4 / gggg+f+gggg with vertical + circular splines in f",
+                metric="log-prob evals/sec (batch 2^20), e4+s2+e4 / gggg+f+gggg with vertical + circular splines in f",
                 desc="unconditional pdf with autoregressive conditioning, f with vertical + circular rational-quadratic splines"),
     "c5": dict(fixture="c5_e8s2_ggggv", defs=("e8+s2", "gggg+v"), dtype="f64", rows=1 << 19, total=1 << 22, seed=5,
                bytes_per_eval={"f64": 20912}, flops_per_eval=29216,
